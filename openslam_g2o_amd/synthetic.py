@@ -1,0 +1,183 @@
+"""Deterministic synthetic bundle-adjustment generator + host-side input producers.
+
+The scene is the deterministic-window variant of g2o's `ba_demo`
+(g2o/examples/ba/ba_demo.cpp:151-256) defined in SURVEY.md section 8d: focal length 1000,
+principal point (320,240), information I_2; pose k sits at (k*s, 0, 0) with identity
+rotation; landmark j is centred at pose c_j = floor(j*P/L), drawn uniformly in the box
+x in t_c +- 1.5, y in +-0.5, z in [3,4] and observed by the 5 poses c_j-2..c_j+2 (window
+shifted at the ends); pixel noise N(0,1); initial point perturbation N(0,0.05^2), pose
+perturbation N(0,0.01^2) translation / N(0,0.005^2) rotation; poses 0 and 1 fixed
+(ba_demo.cpp:182-184).  Randomness is a counter-based splitmix64 stream (seed 42) so the
+same numbers come out of any vectorised or scalar implementation.
+
+The error / Jacobian / oplus formulas are the host-side restatement of
+EdgeProjectXYZ2UV (g2o/types/sba/types_six_dof_expmap.cpp:288-326, .h:139-147),
+VertexSE3Expmap::oplusImpl (.h:101-104, SE3Quat::exp g2o/types/slam3d/se3quat.h:223-257)
+and VertexSBAPointXYZ::oplusImpl (g2o/types/sba/types_sba.h:151-155): they are *input
+producers* for the solver, not part of the accelerated path.
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+class CounterRng:
+    """u(stream, i): uniform in [0,1) from splitmix64(seed, stream, i)."""
+
+    def __init__(self, seed=42):
+        self.seed = np.uint64(seed)
+
+    def uniform(self, stream, n):
+        with np.errstate(over="ignore"):
+            idx = np.arange(n, dtype=np.uint64)
+            key = _splitmix64(self.seed * np.uint64(0x100000001B3) + np.uint64(stream))
+            z = _splitmix64(key ^ (idx * np.uint64(0xD6E8FEB86659FD93) & _M64))
+        return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def normal(self, stream, n):
+        u1 = self.uniform(2 * stream, n)
+        u2 = self.uniform(2 * stream + 1, n)
+        return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def _exp_so3(w):
+    """Rodrigues as in SE3Quat::exp; w: [n,3] -> R [n,3,3], V [n,3,3]."""
+    n = len(w)
+    theta = np.linalg.norm(w, axis=1)
+    Om = np.zeros((n, 3, 3))
+    Om[:, 0, 1], Om[:, 0, 2] = -w[:, 2], w[:, 1]
+    Om[:, 1, 0], Om[:, 1, 2] = w[:, 2], -w[:, 0]
+    Om[:, 2, 0], Om[:, 2, 1] = -w[:, 1], w[:, 0]
+    Om2 = Om @ Om
+    I = np.eye(3)[None]
+    small = theta < 0.00001
+    th = np.where(small, 1.0, theta)
+    a = (np.sin(th) / th)[:, None, None]
+    b = ((1 - np.cos(th)) / (th * th))[:, None, None]
+    c = ((th - np.sin(th)) / (th ** 3))[:, None, None]
+    R = I + a * Om + b * Om2
+    V = I + b * Om + c * Om2
+    Rs = I + Om + Om2
+    R = np.where(small[:, None, None], Rs, R)
+    V = np.where(small[:, None, None], Rs, V)
+    return R, V
+
+
+def make_ba_problem(P, L, seed=42, spacing=0.5, obs_per_landmark=5, outlier_frac=0.0,
+                    f=1000.0, cx=320.0, cy=240.0):
+    rng = CounterRng(seed)
+    K = obs_per_landmark
+    assert P >= K
+    j = np.arange(L, dtype=np.int64)
+    c = (j * P) // L
+    lo = np.clip(c - K // 2, 0, P - K)
+    cam_idx = (lo[:, None] + np.arange(K)[None, :]).reshape(-1).astype(np.int32)       # landmark-major edges
+    pt_idx = np.repeat(np.arange(L, dtype=np.int32), K)
+    E = L * K
+    true_pts = np.stack([c * spacing + (rng.uniform(1, L) * 3.0 - 1.5),
+                         rng.uniform(2, L) - 0.5,
+                         3.0 + rng.uniform(3, L)], axis=1)
+    # true cameras: world->camera, R = I, t = -position
+    cams_true = np.zeros((P, 12))
+    cams_true[:, 0] = cams_true[:, 4] = cams_true[:, 8] = 1.0
+    cams_true[:, 9] = -np.arange(P) * spacing
+    # observations
+    Xc = true_pts[pt_idx] + cams_true[cam_idx, 9:12]
+    meas = np.stack([Xc[:, 0] / Xc[:, 2] * f + cx, Xc[:, 1] / Xc[:, 2] * f + cy], axis=1)
+    meas[:, 0] += rng.normal(4, E)
+    meas[:, 1] += rng.normal(5, E)
+    if outlier_frac > 0:                      # ba_demo.cpp:222-227: uniform in the image
+        is_out = rng.uniform(20, E) < outlier_frac
+        meas[is_out, 0] = rng.uniform(21, E)[is_out] * 640.0
+        meas[is_out, 1] = rng.uniform(22, E)[is_out] * 480.0
+    # initial estimates
+    pts = true_pts + 0.05 * np.stack([rng.normal(6, L), rng.normal(7, L), rng.normal(8, L)], axis=1)
+    upd = np.zeros((P, 6))
+    upd[:, 0:3] = 0.005 * np.stack([rng.normal(9, P), rng.normal(10, P), rng.normal(11, P)], axis=1)
+    upd[:, 3:6] = 0.01 * np.stack([rng.normal(12, P), rng.normal(13, P), rng.normal(14, P)], axis=1)
+    upd[:2] = 0.0                             # fixed poses keep the true value
+    cams = _apply_cam_update(cams_true, upd)
+    cam_hidx = np.arange(P, dtype=np.int32) - 2
+    cam_hidx[:2] = -1
+    nP = P - 2
+    return dict(P=P, L=L, E=E, nP=nP, nL=L, f=f, cx=cx, cy=cy, cams=cams, pts=pts, meas=meas,
+                cam_idx=cam_idx, pt_idx=pt_idx, cam_hidx=cam_hidx,
+                v0=(nP + pt_idx).astype(np.int32),        # EdgeProjectXYZ2UV: vertex 0 = point
+                v1=cam_hidx[cam_idx].astype(np.int32))    # vertex 1 = pose (types_six_dof_expmap.h:133)
+
+
+def _apply_cam_update(cams, upd):
+    """estimate <- exp(update) * estimate, update = (omega, upsilon)."""
+    R, V = _exp_so3(upd[:, 0:3])
+    Rold = cams[:, 0:9].reshape(-1, 3, 3).transpose(0, 2, 1)       # stored column-major
+    told = cams[:, 9:12]
+    Rn = R @ Rold
+    tn = (R @ told[:, :, None])[:, :, 0] + (V @ upd[:, 3:6, None])[:, :, 0]
+    out = np.empty_like(cams)
+    out[:, 0:9] = Rn.transpose(0, 2, 1).reshape(-1, 9)
+    out[:, 9:12] = tn
+    return out
+
+
+def ba_linearize(prob, jac=True):
+    """Returns (Jpt [E,6] 2x3 col-major, Jcam [E,12] 2x6 col-major, err [E,2]) or err only."""
+    cams, pts = prob["cams"], prob["pts"]
+    f, cx, cy = prob["f"], prob["cx"], prob["cy"]
+    T = cams[prob["cam_idx"]]
+    X = pts[prob["pt_idx"]]
+    R = T[:, 0:9].reshape(-1, 3, 3).transpose(0, 2, 1)
+    Xc = (R @ X[:, :, None])[:, :, 0] + T[:, 9:12]
+    x, y, z = Xc[:, 0], Xc[:, 1], Xc[:, 2]
+    err = np.stack([prob["meas"][:, 0] - (x / z * f + cx), prob["meas"][:, 1] - (y / z * f + cy)], axis=1)
+    if not jac:
+        return err
+    E = len(x)
+    z2 = z * z
+    tmp = np.zeros((E, 2, 3))
+    tmp[:, 0, 0] = f
+    tmp[:, 0, 2] = -x / z * f
+    tmp[:, 1, 1] = f
+    tmp[:, 1, 2] = -y / z * f
+    A = (-1.0 / z)[:, None, None] * (tmp @ R)
+    Jpt = np.ascontiguousarray(A.transpose(0, 2, 1).reshape(E, 6))          # column-major 2x3
+    B = np.zeros((E, 2, 6))
+    B[:, 0, 0] = x * y / z2 * f
+    B[:, 0, 1] = -(1 + (x * x / z2)) * f
+    B[:, 0, 2] = y / z * f
+    B[:, 0, 3] = -1.0 / z * f
+    B[:, 0, 5] = x / z2 * f
+    B[:, 1, 0] = (1 + y * y / z2) * f
+    B[:, 1, 1] = -x * y / z2 * f
+    B[:, 1, 2] = -x / z * f
+    B[:, 1, 4] = -1.0 / z * f
+    B[:, 1, 5] = y / z2 * f
+    Jcam = np.ascontiguousarray(B.transpose(0, 2, 1).reshape(E, 12))
+    return Jpt, Jcam, err
+
+
+def ba_omega(prob):
+    om = np.zeros((prob["E"], 4))
+    om[:, 0] = om[:, 3] = 1.0
+    return om
+
+
+def ba_oplus(prob, x):
+    """Apply a solver update (poses then landmarks) and return a new problem dict."""
+    nP = prob["nP"]
+    xp = x[:6 * nP].reshape(nP, 6)
+    xl = x[6 * nP:].reshape(prob["nL"], 3)
+    upd = np.zeros((prob["P"], 6))
+    free = prob["cam_hidx"] >= 0
+    upd[free] = xp[prob["cam_hidx"][free]]
+    new = dict(prob)
+    new["cams"] = _apply_cam_update(prob["cams"], upd)
+    new["pts"] = prob["pts"] + xl
+    return new
