@@ -1,0 +1,184 @@
+/* g2ohip.h -- C ABI of the MI355X-native sparse block solver for g2o's GN/LM inner loop.
+ *
+ * Drop-in boundary for g2o's BlockSolver<p,l> path.  Two seams:
+ *
+ *   wide seam   g2o::Solver            /root/reference/g2o/core/solver.h:44-149
+ *               g2o::BlockSolver<T>    /root/reference/g2o/core/block_solver.h:98-178
+ *   narrow seam g2o::LinearSolver<M>   /root/reference/g2o/core/linear_solver.h:40-81
+ *
+ * Every entry point below names the reference member it replaces.  Plain C, plain
+ * pointers and sizes, no C++/Eigen/torch types.  All matrices are fp64, all indices int32
+ * (the reference's hessianIndex / csi=int, EXTERNAL/csparse/cs.h:26).  Dense blocks are
+ * column-major like Eigen's default (config.h.in:16-20).
+ *
+ * Threading: a handle is not thread-safe; all calls for one handle must come from one
+ * thread (the thread that calls SparseOptimizer::optimize()).  Errors are
+ * reported by return code (the reference path uses no exceptions); g2ohip_last_error()
+ * gives the text.  The library never falls back to a CPU path: without a usable HIP
+ * device every compute call returns G2OHIP_ERR_HIP.
+ */
+#ifndef G2OHIP_H
+#define G2OHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G2OHIP_OK 0
+#define G2OHIP_NOT_PD 1            /* Cholesky hit a pivot <= 0: solve() == false (csparse_helper.cpp:136) */
+#define G2OHIP_ERR_ARG (-1)
+#define G2OHIP_ERR_HIP (-2)
+#define G2OHIP_ERR_STATE (-3)
+#define G2OHIP_ERR_UNSUPPORTED (-4)
+
+#define G2OHIP_KERNEL_NONE 0
+#define G2OHIP_KERNEL_HUBER 1      /* RobustKernelHuber, g2o/core/robust_kernel_impl.cpp:65-78 */
+
+/* which-matrix selectors for the inspection calls */
+#define G2OHIP_HPP 0
+#define G2OHIP_HPL 1
+#define G2OHIP_HLL 2
+#define G2OHIP_HSCHUR 3
+#define G2OHIP_DINV 4
+
+typedef struct g2ohip_solver g2ohip_solver;
+typedef struct g2ohip_linear_solver g2ohip_linear_solver;
+
+/* Per-call timing/size record; same fields as G2OBatchStatistics (g2o/core/batch_stats.h:40-77)
+ * so `g2o -stats` columns line up.  Times in seconds, measured with HIP events on the
+ * solver's stream (only filled while profiling is enabled, see g2ohip_set_profiling). */
+typedef struct g2ohip_stats {
+  double timeQuadraticForm;          /* buildSystem                          */
+  double timeSchurComplement;        /* K5-K8                                */
+  double timeSymbolicDecomposition;  /* host ordering + symbolic, last build */
+  double timeNumericDecomposition;   /* multifrontal factorisation           */
+  double timeLinearSolution;         /* triangular solves                    */
+  double timeLinearSolver;           /* numeric + solves                     */
+  double timeBackSubstitution;       /* landmark back-substitution           */
+  size_t hessianDimension, hessianPoseDimension, hessianLandmarkDimension;
+  size_t choleskyNNZ;                /* scalar nnz(L)                        */
+  size_t numFronts, numLevels, maxFrontDim;
+} g2ohip_stats;
+
+const char* g2ohip_last_error(void);
+int g2ohip_device_count(void);
+
+/* ---- wide seam: g2o::BlockSolver<BlockSolverTraits<pose_dim, landmark_dim>> ------------- */
+
+/* BlockSolver(LinearSolverType*) ctor, block_solver.h:116-120.  device = HIP ordinal. */
+int g2ohip_create(g2ohip_solver** out, int pose_dim, int landmark_dim, int device);
+/* ~BlockSolver, block_solver.hpp:135-140 */
+void g2ohip_destroy(g2ohip_solver* s);
+/* Optional: run on a caller-owned hipStream_t (e.g. torch's current stream).  NULL = own stream. */
+int g2ohip_set_stream(g2ohip_solver* s, void* hip_stream);
+
+/* Solver::init(optimizer, online), block_solver.hpp:606-620: forget numeric + symbolic state. */
+int g2ohip_init(g2ohip_solver* s);
+
+/* Graph topology, replacing the walk over activeEdges() in buildStructure
+ * (block_solver.hpp:206-254).  One call per homogeneous edge type ("edge set"): all edges
+ * of a set share error_dim and the vertex classes of their two sides.
+ *   v0, v1: hessianIndex of vertex 0 / vertex 1 in indexMapping order
+ *           (sparse_optimizer.cpp:166-190): poses are [0, num_poses), landmarks
+ *           [num_poses, num_poses+num_landmarks), -1 = fixed vertex.
+ *   v1 == NULL: unary edges (BaseUnaryEdge, base_unary_edge.hpp:42-72).
+ * Returns the set id (>= 0) or an error code (< 0).  Must precede g2ohip_build_structure. */
+int g2ohip_add_edge_set(g2ohip_solver* s, int error_dim, int n_edges, const int32_t* v0, const int32_t* v1);
+
+/* Solver::buildStructure(), block_solver.hpp:142-295.  do_schur mirrors setSchur()
+ * (OptimizationAlgorithmWithHessian::init, optimization_algorithm_with_hessian.cpp:55-69). */
+int g2ohip_build_structure(g2ohip_solver* s, int num_poses, int num_landmarks, int do_schur);
+
+/* Per-iteration edge data = what linearizeOplus()/computeError() leave in each edge
+ * (jacobianOplusXi/Xj, information, error; base_binary_edge.hpp:54-63), flat in edge order:
+ *   J0 [n][error_dim x dim(v0)] column-major, J1 likewise (NULL for unary sets),
+ *   omega [n][error_dim x error_dim], err [n][error_dim].
+ * on_device != 0: the pointers are device pointers that stay valid until the next
+ * g2ohip_build_system returns (zero-copy); otherwise host arrays, copied to the device. */
+int g2ohip_set_edge_data(g2ohip_solver* s, int set, const double* J0, const double* J1, const double* omega,
+                         const double* err, int on_device);
+/* OptimizableGraph::Edge::setRobustKernel (g2o.cpp:322-336); delta as RobustKernel::setDelta. */
+int g2ohip_set_robust_kernel(g2ohip_solver* s, int set, int kind, double delta);
+
+/* Solver::buildSystem(), block_solver.hpp:501-560 (clear + per-edge constructQuadraticForm +
+ * gather b).  Returns G2OHIP_OK on success (the reference returns 0 and nobody checks). */
+int g2ohip_build_system(g2ohip_solver* s);
+/* SparseOptimizer::activeRobustChi2(), sparse_optimizer.cpp:100-114, from the current edge data. */
+int g2ohip_chi2(g2ohip_solver* s, double* chi2);
+
+/* Solver::setLambda(lambda, backup) / restoreDiagonal(), block_solver.hpp:563-604 */
+int g2ohip_set_lambda(g2ohip_solver* s, double lambda, int backup);
+int g2ohip_restore_diagonal(g2ohip_solver* s);
+/* max_j |H_jj| over all free vertices: the quantity computeLambdaInit reads through
+ * v->hessian(j,j) (optimization_algorithm_levenberg.cpp:149-163). */
+int g2ohip_max_diagonal(g2ohip_solver* s, double* out);
+/* sum_j x_j (lambda x_j + b_j): OptimizationAlgorithmLevenberg::computeScale (:165-172). */
+int g2ohip_compute_scale(g2ohip_solver* s, double lambda, double* out);
+
+/* Solver::solve(), block_solver.hpp:353-486: Schur complement, sparse block Cholesky of the
+ * reduced pose system, landmark back-substitution.  G2OHIP_OK | G2OHIP_NOT_PD | error.
+ * b is left untouched (block_solver.hpp:435-436). */
+int g2ohip_solve(g2ohip_solver* s);
+
+/* Solver::vectorSize(), x(), b() (solver.h:80-86).  x/b layout: poses then landmarks
+ * (block_solver.hpp:551-557).  copy_* synchronise and copy to host; *_device return the
+ * resident vectors (valid until destroy / build_structure). */
+size_t g2ohip_vector_size(g2ohip_solver* s);
+int g2ohip_copy_x(g2ohip_solver* s, double* x_host);
+int g2ohip_copy_b(g2ohip_solver* s, double* b_host);
+const double* g2ohip_x_device(g2ohip_solver* s);
+const double* g2ohip_b_device(g2ohip_solver* s);
+
+/* dest += H * src over the full [Hpp Hpl; Hpl' Hll] system (host vectors of vectorSize()).
+ * Superset of BlockSolverBase::multiplyHessian (block_solver.h:83-91,142), used by Dogleg and
+ * by residual checks. */
+int g2ohip_multiply_hessian(g2ohip_solver* s, double* dest_host, const double* src_host);
+
+int g2ohip_sync(g2ohip_solver* s);
+int g2ohip_set_profiling(g2ohip_solver* s, int enabled);
+int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out);
+/* Per-kernel HIP-event timing on the solver's stream (while profiling is enabled): slot in
+ * [0, g2ohip_kernel_slots()), accumulated seconds and launch count since the last reset. */
+int g2ohip_kernel_slots(void);
+const char* g2ohip_kernel_name(int slot);
+int g2ohip_kernel_time(g2ohip_solver* s, int slot, double* total_seconds, long* launches, int reset);
+/* Ordering / symbolic tuning knob: nested-dissection leaf size in blocks (default 32). */
+int g2ohip_set_option(g2ohip_solver* s, const char* name, double value);
+
+/* Inspection for parity tests (saveHessian-like, block_solver.hpp:628-632): block patterns
+ * (column pointers + row block indices, ascending rows per column) and raw block values. */
+int g2ohip_get_nnzb(g2ohip_solver* s, int which, int* nnzb);
+int g2ohip_get_pattern(g2ohip_solver* s, int which, int32_t* colptr, int32_t* rowidx);
+int g2ohip_copy_values(g2ohip_solver* s, int which, double* values_host);
+/* Device pointers + element counts of resident arrays (for multi-GPU exchange through RCCL):
+ * which = G2OHIP_HSCHUR (values), or 100 = bschur. */
+int g2ohip_device_array(g2ohip_solver* s, int which, double** ptr, size_t* count);
+
+/* Split solve for the multi-GPU path: g2ohip_solve == schur + reduced + back_substitute. */
+int g2ohip_solve_schur(g2ohip_solver* s);            /* K5-K8: Hschur, bschur, Dinv          */
+int g2ohip_solve_reduced(g2ohip_solver* s);          /* K9-K12: x_p = Hschur \ bschur        */
+int g2ohip_solve_back_substitute(g2ohip_solver* s);  /* K13: x_l = Dinv (b_l - Hpl' x_p)     */
+
+/* ---- narrow seam: g2o::LinearSolver<MatrixType> ------------------------------------------- */
+
+/* LinearSolver ctor for MatrixType = block_dim x block_dim. */
+int g2ohip_ls_create(g2ohip_linear_solver** out, int block_dim, int device);
+void g2ohip_ls_destroy(g2ohip_linear_solver* ls);
+/* LinearSolver::init(), linear_solver_csparse.h:97-104: drop the symbolic factorisation. */
+int g2ohip_ls_init(g2ohip_linear_solver* ls);
+/* LinearSolver::solve(A, x, b), linear_solver_csparse.h:106-142.  A: symmetric, upper blocks
+ * only (rowidx[q] <= column), ascending rows per column, values [nnzb][bd x bd] column-major,
+ * diagonal blocks fully stored.  Same pattern between init() calls (linear_solver.h:86-105).
+ * x, b: host vectors of n_blocks*block_dim.  G2OHIP_OK | G2OHIP_NOT_PD | error. */
+int g2ohip_ls_solve(g2ohip_linear_solver* ls, int n_blocks, const int32_t* colptr, const int32_t* rowidx,
+                    const double* values, double* x, const double* b);
+int g2ohip_ls_get_stats(g2ohip_linear_solver* ls, g2ohip_stats* out);
+int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G2OHIP_H */

@@ -1,0 +1,367 @@
+"""ctypes binding of include/g2ohip.h and the host-side mirror of g2o's Solver interface.
+
+`HipBlockSolver` keeps the method names, argument meaning and error behaviour of
+g2o::Solver / g2o::BlockSolver<Traits> (/root/reference/g2o/core/solver.h:44-149,
+block_solver.h:98-178): init, buildStructure, buildSystem, solve (-> bool), setLambda,
+restoreDiagonal, x, b, vectorSize ...  `HipLinearSolver` mirrors g2o::LinearSolver<M>
+(/root/reference/g2o/core/linear_solver.h:40-81).
+
+The HIP library is the only compute path: if libg2ohip.so is missing or no GPU is visible
+the calls raise -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libg2ohip.so")
+
+c_int_p = C.POINTER(C.c_int32)
+c_dbl_p = C.POINTER(C.c_double)
+
+OK, NOT_PD = 0, 1
+HPP, HPL, HLL, HSCHUR, DINV = 0, 1, 2, 3, 4
+ARR_BSCHUR, ARR_X, ARR_B = 100, 101, 102
+KERNEL_NONE, KERNEL_HUBER = 0, 1
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "timeQuadraticForm", "timeSchurComplement", "timeSymbolicDecomposition", "timeNumericDecomposition",
+        "timeLinearSolution", "timeLinearSolver", "timeBackSubstitution")] + [(n, C.c_size_t) for n in (
+            "hessianDimension", "hessianPoseDimension", "hessianLandmarkDimension", "choleskyNNZ", "numFronts",
+            "numLevels", "maxFrontDim")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = [
+    "g2ohip_last_error", "g2ohip_device_count", "g2ohip_create", "g2ohip_destroy", "g2ohip_set_stream", "g2ohip_init",
+    "g2ohip_add_edge_set", "g2ohip_build_structure", "g2ohip_set_edge_data", "g2ohip_set_robust_kernel",
+    "g2ohip_build_system", "g2ohip_chi2", "g2ohip_set_lambda", "g2ohip_restore_diagonal", "g2ohip_max_diagonal",
+    "g2ohip_compute_scale", "g2ohip_solve", "g2ohip_vector_size", "g2ohip_copy_x", "g2ohip_copy_b", "g2ohip_x_device",
+    "g2ohip_b_device", "g2ohip_multiply_hessian", "g2ohip_sync", "g2ohip_set_profiling", "g2ohip_get_stats",
+    "g2ohip_set_option", "g2ohip_get_nnzb", "g2ohip_get_pattern", "g2ohip_copy_values", "g2ohip_device_array",
+    "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute", "g2ohip_ls_create",
+    "g2ohip_ls_destroy", "g2ohip_ls_init", "g2ohip_ls_solve", "g2ohip_ls_get_stats", "g2ohip_ls_set_option",
+    "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time",
+]
+
+_lib = None
+
+
+class G2oHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libg2ohip.so (raises if it was not built: build with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise G2oHipError("libg2ohip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                          % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.g2ohip_last_error.restype = C.c_char_p
+    L.g2ohip_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
+    L.g2ohip_destroy.argtypes = [vp]
+    L.g2ohip_destroy.restype = None
+    L.g2ohip_set_stream.argtypes = [vp, vp]
+    L.g2ohip_init.argtypes = [vp]
+    L.g2ohip_add_edge_set.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_int_p]
+    L.g2ohip_build_structure.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.g2ohip_set_edge_data.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int]
+    L.g2ohip_set_robust_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_double]
+    L.g2ohip_build_system.argtypes = [vp]
+    L.g2ohip_chi2.argtypes = [vp, c_dbl_p]
+    L.g2ohip_set_lambda.argtypes = [vp, C.c_double, C.c_int]
+    L.g2ohip_restore_diagonal.argtypes = [vp]
+    L.g2ohip_max_diagonal.argtypes = [vp, c_dbl_p]
+    L.g2ohip_compute_scale.argtypes = [vp, C.c_double, c_dbl_p]
+    for n in ("g2ohip_solve", "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute",
+              "g2ohip_sync"):
+        getattr(L, n).argtypes = [vp]
+    L.g2ohip_vector_size.argtypes = [vp]
+    L.g2ohip_vector_size.restype = C.c_size_t
+    L.g2ohip_copy_x.argtypes = [vp, c_dbl_p]
+    L.g2ohip_copy_b.argtypes = [vp, c_dbl_p]
+    L.g2ohip_x_device.argtypes = [vp]
+    L.g2ohip_x_device.restype = vp
+    L.g2ohip_b_device.argtypes = [vp]
+    L.g2ohip_b_device.restype = vp
+    L.g2ohip_multiply_hessian.argtypes = [vp, c_dbl_p, c_dbl_p]
+    L.g2ohip_set_profiling.argtypes = [vp, C.c_int]
+    L.g2ohip_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.g2ohip_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    L.g2ohip_get_nnzb.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.g2ohip_get_pattern.argtypes = [vp, C.c_int, c_int_p, c_int_p]
+    L.g2ohip_copy_values.argtypes = [vp, C.c_int, c_dbl_p]
+    L.g2ohip_device_array.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.g2ohip_kernel_name.argtypes = [C.c_int]
+    L.g2ohip_kernel_name.restype = C.c_char_p
+    L.g2ohip_kernel_time.argtypes = [vp, C.c_int, c_dbl_p, C.POINTER(C.c_long), C.c_int]
+    L.g2ohip_ls_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    L.g2ohip_ls_destroy.argtypes = [vp]
+    L.g2ohip_ls_destroy.restype = None
+    L.g2ohip_ls_init.argtypes = [vp]
+    L.g2ohip_ls_solve.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p]
+    L.g2ohip_ls_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.g2ohip_ls_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise G2oHipError("%s failed (%d): %s" % (what, rc, load().g2ohip_last_error().decode()))
+    return rc
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_int_p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dbl_p)
+
+
+def _ptr(a):
+    """Host numpy array, torch CUDA tensor or raw int -> (void*, on_device)."""
+    if a is None:
+        return None, None
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data), False
+    if isinstance(a, int):
+        return C.c_void_p(a), True
+    if hasattr(a, "data_ptr"):  # torch tensor
+        return C.c_void_p(a.data_ptr()), bool(a.is_cuda)
+    raise TypeError(type(a))
+
+
+class HipBlockSolver:
+    """g2o::BlockSolver<BlockSolverTraits<p,l>> on one MI355X (block_solver.h:98-178)."""
+
+    def __init__(self, pose_dim, landmark_dim, device=0):
+        self.L = load()
+        self.p, self.l = pose_dim, landmark_dim
+        self.h = C.c_void_p()
+        _check(self.L.g2ohip_create(C.byref(self.h), pose_dim, landmark_dim, device), "g2ohip_create")
+        self._keep = {}
+        self.nP = self.nL = 0
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.g2ohip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- Solver interface ------------------------------------------------------------
+    def init(self):
+        _check(self.L.g2ohip_init(self.h), "init")
+        return True
+
+    def addEdgeSet(self, error_dim, v0, v1=None):
+        v0 = _i32(v0)
+        v1 = None if v1 is None else _i32(v1)
+        return _check(self.L.g2ohip_add_edge_set(self.h, error_dim, len(v0), _ip(v0), _ip(v1)), "add_edge_set")
+
+    def buildStructure(self, num_poses, num_landmarks=0, schur=None):
+        if schur is None:
+            schur = num_landmarks > 0
+        _check(self.L.g2ohip_build_structure(self.h, num_poses, num_landmarks, int(bool(schur))), "buildStructure")
+        self.nP, self.nL = num_poses, num_landmarks
+        return True
+
+    def setEdgeData(self, set_id, J0, J1, omega, err):
+        """Host numpy arrays (copied) or torch CUDA tensors (zero-copy, must outlive buildSystem)."""
+        arrs = []
+        dev = None
+        for a in (J0, J1, omega, err):
+            if isinstance(a, (list, tuple)):
+                a = np.asarray(a)
+            if isinstance(a, np.ndarray):
+                a = _f64(a)
+            arrs.append(a)
+        ptrs = []
+        for a in arrs:
+            p, d = _ptr(a)
+            ptrs.append(p)
+            if d is not None:
+                assert dev is None or dev == d, "mixing host and device arrays"
+                dev = d
+        self._keep[set_id] = arrs
+        _check(self.L.g2ohip_set_edge_data(self.h, set_id, ptrs[0], ptrs[1], ptrs[2], ptrs[3], int(bool(dev))),
+               "setEdgeData")
+
+    def setRobustKernel(self, set_id, kind, delta=1.0):
+        _check(self.L.g2ohip_set_robust_kernel(self.h, set_id, kind, delta), "setRobustKernel")
+
+    def buildSystem(self):
+        _check(self.L.g2ohip_build_system(self.h), "buildSystem")
+        return True
+
+    def chi2(self):
+        v = C.c_double()
+        _check(self.L.g2ohip_chi2(self.h, C.byref(v)), "chi2")
+        return v.value
+
+    def setLambda(self, lam, backup=False):
+        _check(self.L.g2ohip_set_lambda(self.h, lam, int(backup)), "setLambda")
+        return True
+
+    def restoreDiagonal(self):
+        _check(self.L.g2ohip_restore_diagonal(self.h), "restoreDiagonal")
+
+    def maxDiagonal(self):
+        v = C.c_double()
+        _check(self.L.g2ohip_max_diagonal(self.h, C.byref(v)), "maxDiagonal")
+        return v.value
+
+    def computeScale(self, lam):
+        v = C.c_double()
+        _check(self.L.g2ohip_compute_scale(self.h, lam, C.byref(v)), "computeScale")
+        return v.value
+
+    def solve(self):
+        """True on success, False when the system is not positive definite (like the reference)."""
+        return _check(self.L.g2ohip_solve(self.h), "solve") == OK
+
+    def solveSchur(self):
+        _check(self.L.g2ohip_solve_schur(self.h), "solveSchur")
+
+    def solveReduced(self):
+        return _check(self.L.g2ohip_solve_reduced(self.h), "solveReduced") == OK
+
+    def solveBackSubstitute(self):
+        _check(self.L.g2ohip_solve_back_substitute(self.h), "solveBackSubstitute")
+
+    def vectorSize(self):
+        return self.L.g2ohip_vector_size(self.h)
+
+    def x(self):
+        out = np.empty(self.vectorSize())
+        _check(self.L.g2ohip_copy_x(self.h, _dp(out)), "x")
+        return out
+
+    def b(self):
+        out = np.empty(self.vectorSize())
+        _check(self.L.g2ohip_copy_b(self.h, _dp(out)), "b")
+        return out
+
+    def multiplyHessian(self, src):
+        src = _f64(src)
+        dst = np.zeros_like(src)
+        _check(self.L.g2ohip_multiply_hessian(self.h, _dp(dst), _dp(src)), "multiplyHessian")
+        return dst
+
+    def sync(self):
+        _check(self.L.g2ohip_sync(self.h), "sync")
+
+    def setStream(self, raw_stream):
+        _check(self.L.g2ohip_set_stream(self.h, C.c_void_p(raw_stream)), "setStream")
+
+    def setProfiling(self, on):
+        self.L.g2ohip_set_profiling(self.h, int(on))
+
+    def setOption(self, name, value):
+        _check(self.L.g2ohip_set_option(self.h, name.encode(), float(value)), "setOption")
+
+    def stats(self):
+        s = Stats()
+        _check(self.L.g2ohip_get_stats(self.h, C.byref(s)), "stats")
+        return s.as_dict()
+
+    def kernelTimes(self, reset=True):
+        """{kernel name: (total seconds, launches)} from HIP events on the solver stream."""
+        out = {}
+        for k in range(self.L.g2ohip_kernel_slots()):
+            t = C.c_double()
+            n = C.c_long()
+            _check(self.L.g2ohip_kernel_time(self.h, k, C.byref(t), C.byref(n), int(reset)), "kernelTimes")
+            if n.value:
+                out[self.L.g2ohip_kernel_name(k).decode()] = (t.value, n.value)
+        return out
+
+    # ---- inspection --------------------------------------------------------------------
+    def nnzb(self, which):
+        v = C.c_int()
+        _check(self.L.g2ohip_get_nnzb(self.h, which, C.byref(v)), "nnzb")
+        return v.value
+
+    def pattern(self, which):
+        ncols = self.nL if which == HPL else self.nP
+        cp = np.zeros(ncols + 1, np.int32)
+        ri = np.zeros(max(self.nnzb(which), 1), np.int32)
+        _check(self.L.g2ohip_get_pattern(self.h, which, _ip(cp), _ip(ri)), "pattern")
+        return cp, ri[:self.nnzb(which)]
+
+    def values(self, which):
+        p, l = self.p, self.l
+        per = {HPP: p * p, HPL: p * l, HLL: l * l, HSCHUR: p * p, DINV: l * l}[which]
+        out = np.empty(max(self.nnzb(which) * per, 1))
+        _check(self.L.g2ohip_copy_values(self.h, which, _dp(out)), "values")
+        return out[:self.nnzb(which) * per]
+
+    def deviceArray(self, which):
+        ptr = C.c_void_p()
+        n = C.c_size_t()
+        _check(self.L.g2ohip_device_array(self.h, which, C.byref(ptr), C.byref(n)), "deviceArray")
+        return ptr.value, n.value
+
+
+class HipLinearSolver:
+    """g2o::LinearSolver<MatrixType> (linear_solver.h:40-81) over the multifrontal engine."""
+
+    def __init__(self, block_dim, device=0):
+        self.L = load()
+        self.bs = block_dim
+        self.h = C.c_void_p()
+        _check(self.L.g2ohip_ls_create(C.byref(self.h), block_dim, device), "ls_create")
+
+    def init(self):
+        _check(self.L.g2ohip_ls_init(self.h), "ls_init")
+        return True
+
+    def setOption(self, name, value):
+        _check(self.L.g2ohip_ls_set_option(self.h, name.encode(), float(value)), "ls_set_option")
+
+    def solve(self, colptr, rowidx, values, b):
+        """Returns (ok, x).  A = upper block CCS."""
+        colptr, rowidx, values, b = _i32(colptr), _i32(rowidx), _f64(values), _f64(b)
+        nb = len(colptr) - 1
+        x = np.zeros(nb * self.bs)
+        rc = _check(self.L.g2ohip_ls_solve(self.h, nb, _ip(colptr), _ip(rowidx), _dp(values), _dp(x), _dp(b)), "ls_solve")
+        return rc == OK, x
+
+    def stats(self):
+        s = Stats()
+        _check(self.L.g2ohip_ls_get_stats(self.h, C.byref(s)), "ls_stats")
+        return s.as_dict()
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.g2ohip_ls_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

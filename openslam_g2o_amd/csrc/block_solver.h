@@ -1,0 +1,116 @@
+// Device-resident replacement of g2o::BlockSolver<BlockSolverTraits<p,l>>
+//   /root/reference/g2o/core/block_solver.h:98-178, block_solver.hpp (all)
+// over flat index/Jacobian arrays instead of the pointer-chasing SparseBlockMatrix
+// (sparse_block_matrix.h:61-220: vector<map<int,Block*>>, one heap block per tile).
+//
+// Data layout in HBM (all fp64 column-major blocks, int32 indices):
+//   Hpp, Hschur : block-CCS upper triangle, ascending rows per column, values [nnzb][p*p]
+//   Hpl         : block-CCS by landmark column (== _HplCCS, block_solver.h:157), rows = pose
+//                 index ascending, values [nnzb][p*l]
+//   Hll, Dinv   : dense [nL][l*l];  b, x : [nP*p | nL*l]  (block_solver.hpp:551-557)
+// Scatter reductions (many edges -> one vertex block, many landmarks -> one Hschur block)
+// are done destination-major from precomputed contributor lists: deterministic, no fp64
+// atomics, same summation order as the reference's serial loops.
+#pragma once
+#include <memory>
+
+#include "common.h"
+#include "sparse_cholesky.h"
+
+namespace g2ohip {
+
+struct EdgeSet {
+  int d = 0, n = 0, dim0 = 0, dim1 = 0;
+  bool unary = false;
+  std::vector<int> v0, v1;
+  int kernel_kind = 0;
+  double delta = 1.0;
+  // per-iteration data (device); either own buffers or caller-owned device pointers
+  const double *J0 = nullptr, *J1 = nullptr, *omega = nullptr, *err = nullptr;
+  DevBuf<double> own_J0, own_J1, own_omega, own_err;
+  bool has_data = false;
+  // destination-major contributor lists
+  DevBuf<int> vp_ptr, vp_ent, vl_ptr, vl_ent;  // per pose / per landmark: (edge << 1 | side)
+  DevBuf<int> op_dst, op_ptr, op_ent;          // Hpp off-diagonal blocks: dest block id, (edge << 1 | transposed)
+  DevBuf<int> ol_dst, ol_ptr, ol_ent;          // Hpl blocks
+  int n_op = 0, n_ol = 0;
+  long n_vp_ent = 0, n_vl_ent = 0;
+  bool touches_pose = false, touches_lm = false, first_pose = false, first_lm = false, first_op = false, first_ol = false;
+};
+
+struct SolverTimes {
+  double quadratic = 0, schur = 0, numeric = 0, linsolve = 0, backsub = 0;
+};
+
+class BlockSolver {
+ public:
+  BlockSolver(int p, int l, int device);
+  ~BlockSolver();
+
+  void init();
+  int add_edge_set(int d, int n, const int* v0, const int* v1);
+  void build_structure(int nP, int nL, bool do_schur);
+  void set_edge_data(int set, const double* J0, const double* J1, const double* omega, const double* err, bool on_device);
+  void set_robust_kernel(int set, int kind, double delta);
+  void build_system();
+  double chi2();
+  void set_lambda(double lambda, bool backup);
+  void restore_diagonal();
+  double max_diagonal();
+  double compute_scale(double lambda);
+  int solve();                 // 0 ok, 1 not PD
+  void solve_schur();
+  int solve_reduced();
+  void solve_back_substitute();
+  void multiply_hessian(double* dest_host, const double* src_host);
+
+  size_t vector_size() const { return (size_t)nP_ * p_ + (size_t)nL_ * l_; }
+  void copy_x(double* h);
+  void copy_b(double* h);
+  const double* x_device() const { return d_x.p; }
+  const double* b_device() const { return d_b.p; }
+  void sync();
+  void set_stream(hipStream_t st);
+  hipStream_t stream() const { return st_; }
+
+  int nnzb(int which) const;
+  void get_pattern(int which, int* colptr, int* rowidx) const;
+  void copy_values(int which, double* h);
+  void device_array(int which, double** ptr, size_t* count);
+
+  bool profiling = false;
+  KernelProf prof;
+  SolverTimes times;
+  CholOptions chol_opt;
+  const CholStats* chol_stats() const { return chol_ ? &chol_->stats() : nullptr; }
+  int p() const { return p_; }
+  int l() const { return l_; }
+  int nP() const { return nP_; }
+  int nL() const { return nL_; }
+  bool schur() const { return schur_; }
+
+ private:
+  int p_, l_, device_;
+  int nP_ = 0, nL_ = 0;
+  bool schur_ = false, structured_ = false, system_built_ = false;
+  hipStream_t st_ = nullptr;
+  bool own_stream_ = false;
+  std::vector<std::unique_ptr<EdgeSet>> sets_;
+  // host patterns
+  std::vector<int> pp_colptr, pp_row, pp_diag, pl_colptr, pl_row, hs_colptr, hs_row;
+  // device matrices
+  DevBuf<double> d_Hpp, d_Hpl, d_Hll, d_Hschur, d_Dinv, d_db, d_b, d_x, d_bschur, d_bkP, d_bkL, d_red;
+  DevBuf<int> d_pp_diag, d_pl_colptr, d_pl_row, d_pl_lm;
+  DevBuf<int> d_hs_src;                    // Hschur block -> Hpp block id or -1
+  DevBuf<int> d_sc_ptr, d_sc_q1, d_sc_q2;  // Hschur block contributor pairs (Hpl block ids)
+  DevBuf<int> d_plr_ptr, d_plr_blk;        // Hpl blocks by pose row
+  // multiply_hessian pattern
+  DevBuf<int> d_pp_colptr, d_pp_row;
+  long n_sc_ = 0;
+  std::unique_ptr<SparseCholesky> chol_;
+  EventTimer tq_, ts_, tn_, tl_, tb_;
+  void require_structure() const;
+  double reduce_sum_finish(int nblocks);
+};
+
+}  // namespace g2ohip

@@ -1,0 +1,1266 @@
+// BlockSolver on MI355X: structure build (host, once) + the per-iteration kernels
+// K1-K8, K13, K14 of SURVEY.md section 2.3.  See block_solver.h for the layout.
+#include "block_solver.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace g2ohip {
+
+// =====================================================================================
+// Device helpers
+// =====================================================================================
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// rho'(e2) of the robust kernel (Huber: robust_kernel_impl.cpp:65-78); 1 without kernel
+__device__ __forceinline__ double robust_weight(int kind, double delta, double e2) {
+  if (kind == 1) {
+    const double dsqr = delta * delta;
+    return (e2 <= dsqr) ? 1.0 : delta / sqrt(e2);
+  }
+  return 1.0;
+}
+__device__ __forceinline__ double robust_rho(int kind, double delta, double e2) {
+  if (kind == 1) {
+    const double dsqr = delta * delta;
+    return (e2 <= dsqr) ? e2 : 2.0 * sqrt(e2) * delta - dsqr;
+  }
+  return e2;
+}
+
+// ---------------------------------------------------------------------------------
+// K2, vertex part: H_vv (+)= sum_e J' (rho' Omega) J ;  b_v (+)= sum_e J' (-rho' Omega e)
+// base_binary_edge.hpp:54-120 / base_unary_edge.hpp:42-72, destination-major: G lanes share
+// one vertex and walk its contributor list (edge << 1 | side), then a butterfly reduction.
+// ---------------------------------------------------------------------------------
+template <int D, int DV, int G>
+__global__ void __launch_bounds__(kThreads) assemble_vertex_kernel(int nV, const int* __restrict__ vptr, const int* __restrict__ vent,
+                                       const double* __restrict__ J0, const double* __restrict__ J1,
+                                       const double* __restrict__ omega, const double* __restrict__ err, int kind, double delta,
+                                       double* __restrict__ H, const int* __restrict__ diag_blk, double* __restrict__ b,
+                                       int accumulate) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = gt / G, g = gt % G;
+  const bool active = v < nV;
+  double Hacc[DV * DV];
+  double bacc[DV];
+#pragma unroll
+  for (int i = 0; i < DV * DV; ++i) Hacc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < DV; ++i) bacc[i] = 0.0;
+  const int k0 = active ? vptr[v] : 0, k1 = active ? vptr[v + 1] : 0;
+  for (int k = k0 + g; k < k1; k += G) {
+    const int ent = vent[k];
+    const size_t e = (size_t)(ent >> 1);
+    const double* Jp = ((ent & 1) ? J1 : J0) + e * (D * DV);
+    const double* Op = omega + e * (D * D);
+    const double* rp = err + e * D;
+    double J[D * DV], O[D * D], r[D], Or[D];
+#pragma unroll
+    for (int i = 0; i < D * DV; ++i) J[i] = Jp[i];
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) O[i] = Op[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) r[i] = rp[i];
+    double e2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) t += O[i + D * j] * r[j];
+      Or[i] = t;
+      e2 += r[i] * t;
+    }
+    const double w = robust_weight(kind, delta, e2);
+    // b += J' (-w O r)
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) t += J[i + D * c] * Or[i];
+      bacc[c] -= w * t;
+    }
+    // H += J' (w O) J, column by column
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+      double OJ[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) t += O[i + D * j] * J[j + D * c];
+        OJ[i] = w * t;
+      }
+#pragma unroll
+      for (int a = 0; a < DV; ++a) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) t += J[i + D * a] * OJ[i];
+        Hacc[a + DV * c] += t;
+      }
+    }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int i = 0; i < DV * DV; ++i) Hacc[i] = group_sum<G>(Hacc[i]);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) bacc[i] = group_sum<G>(bacc[i]);
+  }
+  if (!active) return;
+  const size_t blk = diag_blk ? (size_t)diag_blk[v] : (size_t)v;
+  double* Hd = H + blk * (DV * DV);
+  double* bd = b + (size_t)v * DV;
+#pragma unroll
+  for (int i = 0; i < DV * DV; ++i)
+    if (G == 1 || (i % G) == g) Hd[i] = accumulate ? Hd[i] + Hacc[i] : Hacc[i];
+#pragma unroll
+  for (int i = 0; i < DV; ++i)
+    if (G == 1 || (i % G) == g) bd[i] = accumulate ? bd[i] + bacc[i] : bacc[i];
+}
+
+// ---------------------------------------------------------------------------------
+// K2, off-diagonal part: H_ij (+)= A' (rho' Omega) B, or B' (rho' Omega) A when the block is
+// stored transposed (block_solver.hpp:221-250).  One thread per destination block.
+// ---------------------------------------------------------------------------------
+template <int D, int DR, int DC>
+__global__ void __launch_bounds__(kThreads) assemble_offdiag_kernel(int nDst, const int* __restrict__ dst, const int* __restrict__ ptr,
+                                        const int* __restrict__ ent, const double* __restrict__ J0, const double* __restrict__ J1,
+                                        const double* __restrict__ omega, const double* __restrict__ err, int kind, double delta,
+                                        double* __restrict__ H, int accumulate) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nDst) return;
+  double acc[DR * DC];
+#pragma unroll
+  for (int i = 0; i < DR * DC; ++i) acc[i] = 0.0;
+  for (int k = ptr[t]; k < ptr[t + 1]; ++k) {
+    const int en = ent[k];
+    const size_t e = (size_t)(en >> 1);
+    const bool tr = en & 1;
+    const double* Lp = tr ? (J1 + e * (D * DR)) : (J0 + e * (D * DR));
+    const double* Rp = tr ? (J0 + e * (D * DC)) : (J1 + e * (D * DC));
+    const double* Op = omega + e * (D * D);
+    double O[D * D], Lm[D * DR];
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) O[i] = Op[i];
+#pragma unroll
+    for (int i = 0; i < D * DR; ++i) Lm[i] = Lp[i];
+    double w = 1.0;
+    if (kind != 0) {
+      const double* rp = err + e * D;
+      double e2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) s += O[i + D * j] * rp[j];
+        e2 += rp[i] * s;
+      }
+      w = robust_weight(kind, delta, e2);
+    }
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+      double OR[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) s += O[i + D * j] * Rp[j + D * c];
+        OR[i] = w * s;
+      }
+#pragma unroll
+      for (int a = 0; a < DR; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) s += Lm[i + D * a] * OR[i];
+        acc[a + DR * c] += s;
+      }
+    }
+  }
+  double* Hd = H + (size_t)dst[t] * (DR * DC);
+#pragma unroll
+  for (int i = 0; i < DR * DC; ++i) Hd[i] = accumulate ? Hd[i] + acc[i] : acc[i];
+}
+
+// chi2 partial sums: sum_e rho(e' Omega e)  (sparse_optimizer.cpp:100-114)
+template <int D>
+__global__ void __launch_bounds__(kThreads) chi2_kernel(int n, const double* __restrict__ omega, const double* __restrict__ err, int kind, double delta,
+                            double* __restrict__ partial) {
+  __shared__ double sh[kThreads];
+  double s = 0.0;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)n; e += (size_t)gridDim.x * blockDim.x) {
+    const double* O = omega + e * (D * D);
+    const double* r = err + e * D;
+    double e2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) t += O[i + D * j] * r[j];
+      e2 += r[i] * t;
+    }
+    s += robust_rho(kind, delta, e2);
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ void __launch_bounds__(kThreads) scale_partial_kernel(size_t n, const double* __restrict__ x, const double* __restrict__ b, double lambda,
+                                     double* __restrict__ partial) {
+  __shared__ double sh[kThreads];
+  double s = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s += x[i] * (lambda * x[i] + b[i]);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// max |diag| partials over nV blocks of dimension DV
+__global__ void __launch_bounds__(kThreads) maxdiag_partial_kernel(int nV, int dv, const double* __restrict__ H, const int* __restrict__ diag_blk,
+                                       double* __restrict__ partial) {
+  __shared__ double sh[kThreads];
+  double s = 0.0;
+  const size_t total = (size_t)nV * dv;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t v = i / dv, j = i % dv;
+    const size_t blk = diag_blk ? (size_t)diag_blk[v] : v;
+    s = fmax(s, fabs(H[blk * dv * dv + j + dv * j]));
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// K4: setLambda / restoreDiagonal (block_solver.hpp:563-604)
+__global__ void __launch_bounds__(kThreads) lambda_kernel(int nV, int dv, double* __restrict__ H, const int* __restrict__ diag_blk, double* __restrict__ backup,
+                              double lambda, int do_backup, int restore) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)nV * dv) return;
+  const size_t v = i / dv, j = i % dv;
+  const size_t blk = diag_blk ? (size_t)diag_blk[v] : v;
+  double* d = H + blk * dv * dv + j + dv * j;
+  if (restore) {
+    *d = backup[i];
+    return;
+  }
+  if (do_backup) backup[i] = *d;
+  *d += lambda;
+}
+
+// K6: Dinv = D^-1 (closed cofactor form like Eigen's fixed-size inverse, block_solver.hpp:389),
+// db = Dinv * b_l (:391-395)
+template <int LD>
+__device__ __forceinline__ void small_inverse(const double* D, double* R) {
+  if (LD == 1) {
+    R[0] = 1.0 / D[0];
+  } else if (LD == 2) {
+    const double det = D[0] * D[3] - D[2] * D[1];
+    const double id = 1.0 / det;
+    R[0] = D[3] * id;
+    R[1] = -D[1] * id;
+    R[2] = -D[2] * id;
+    R[3] = D[0] * id;
+  } else if (LD == 3) {
+#define M_(i, j) D[(i) + 3 * (j)]
+    const double c00 = M_(1, 1) * M_(2, 2) - M_(1, 2) * M_(2, 1);
+    const double c10 = M_(1, 2) * M_(2, 0) - M_(1, 0) * M_(2, 2);
+    const double c20 = M_(1, 0) * M_(2, 1) - M_(1, 1) * M_(2, 0);
+    const double det = M_(0, 0) * c00 + M_(0, 1) * c10 + M_(0, 2) * c20;
+    const double id = 1.0 / det;
+    R[0] = c00 * id;
+    R[1] = c10 * id;
+    R[2] = c20 * id;
+    R[3] = (M_(0, 2) * M_(2, 1) - M_(0, 1) * M_(2, 2)) * id;
+    R[4] = (M_(0, 0) * M_(2, 2) - M_(0, 2) * M_(2, 0)) * id;
+    R[5] = (M_(0, 1) * M_(2, 0) - M_(0, 0) * M_(2, 1)) * id;
+    R[6] = (M_(0, 1) * M_(1, 2) - M_(0, 2) * M_(1, 1)) * id;
+    R[7] = (M_(0, 2) * M_(1, 0) - M_(0, 0) * M_(1, 2)) * id;
+    R[8] = (M_(0, 0) * M_(1, 1) - M_(0, 1) * M_(1, 0)) * id;
+#undef M_
+  }
+}
+template <int LD>
+__global__ void __launch_bounds__(kThreads) landmark_inverse_kernel(int nL, const double* __restrict__ Hll, const double* __restrict__ bl,
+                                        double* __restrict__ Dinv, double* __restrict__ db) {
+  const int lm = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lm >= nL) return;
+  double D[LD * LD], R[LD * LD];
+#pragma unroll
+  for (int i = 0; i < LD * LD; ++i) D[i] = Hll[(size_t)lm * LD * LD + i];
+  small_inverse<LD>(D, R);
+#pragma unroll
+  for (int i = 0; i < LD * LD; ++i) Dinv[(size_t)lm * LD * LD + i] = R[i];
+#pragma unroll
+  for (int i = 0; i < LD; ++i) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < LD; ++j) t += R[i + LD * j] * bl[(size_t)lm * LD + j];
+    db[(size_t)lm * LD + i] = t;
+  }
+}
+
+// K5+K7: Hschur(i1,i2) = Hpp(i1,i2) - sum_lm (B_i1 Dinv) B_i2'   (block_solver.hpp:373-431),
+// destination-major over the contributor pairs of each Hschur block, G lanes per block.
+template <int PD, int LD, int G>
+__global__ void __launch_bounds__(kThreads) schur_blocks_kernel(int nDst, const int* __restrict__ sc_ptr, const int* __restrict__ sc_q1,
+                                    const int* __restrict__ sc_q2, const int* __restrict__ pl_lm, const double* __restrict__ Hpl,
+                                    const double* __restrict__ Dinv, const int* __restrict__ hs_src, const double* __restrict__ Hpp,
+                                    double* __restrict__ Hs) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int d = gt / G, g = gt % G;
+  const bool active = d < nDst;
+  double acc[PD * PD];
+  const int src = active ? hs_src[d] : -1;
+#pragma unroll
+  for (int i = 0; i < PD * PD; ++i) acc[i] = (g == 0 && src >= 0) ? Hpp[(size_t)src * PD * PD + i] : 0.0;
+  const int k0 = active ? sc_ptr[d] : 0, k1 = active ? sc_ptr[d + 1] : 0;
+  for (int k = k0 + g; k < k1; k += G) {
+    const int q1 = sc_q1[k], q2 = sc_q2[k];
+    const int lm = pl_lm[q1];
+    const double* B1 = Hpl + (size_t)q1 * PD * LD;
+    const double* B2 = Hpl + (size_t)q2 * PD * LD;
+    const double* Dv = Dinv + (size_t)lm * LD * LD;
+    double W[PD * LD], Bj[PD * LD], Di[LD * LD];
+#pragma unroll
+    for (int i = 0; i < LD * LD; ++i) Di[i] = Dv[i];
+#pragma unroll
+    for (int i = 0; i < PD * LD; ++i) Bj[i] = B1[i];
+#pragma unroll
+    for (int c = 0; c < LD; ++c)
+#pragma unroll
+      for (int r = 0; r < PD; ++r) {
+        double t = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < LD; ++kk) t += Bj[r + PD * kk] * Di[kk + LD * c];
+        W[r + PD * c] = t;
+      }
+#pragma unroll
+    for (int i = 0; i < PD * LD; ++i) Bj[i] = B2[i];
+#pragma unroll
+    for (int c = 0; c < PD; ++c)
+#pragma unroll
+      for (int r = 0; r < PD; ++r) {
+        double t = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < LD; ++kk) t += W[r + PD * kk] * Bj[c + PD * kk];
+        acc[r + PD * c] -= t;
+      }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int i = 0; i < PD * PD; ++i) acc[i] = group_sum<G>(acc[i]);
+  }
+  if (!active) return;
+  double* out = Hs + (size_t)d * PD * PD;
+  if (G == 1) {
+#pragma unroll
+    for (int i = 0; i < PD * PD; ++i) out[i] = acc[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < PD * PD; ++i)
+      if (i % G == g) out[i] = acc[i];
+  }
+}
+
+// K8: bschur_i = b_i - sum_{blocks in pose row i} B * (Dinv b_l)   (block_solver.hpp:412,435-439)
+template <int PD, int LD, int G>
+__global__ void __launch_bounds__(kThreads) schur_rhs_kernel(int nP, const int* __restrict__ plr_ptr, const int* __restrict__ plr_blk,
+                                 const int* __restrict__ pl_lm, const double* __restrict__ Hpl, const double* __restrict__ db,
+                                 const double* __restrict__ b, double* __restrict__ bschur) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gt / G, g = gt % G;
+  const bool active = i < nP;
+  double acc[PD];
+#pragma unroll
+  for (int r = 0; r < PD; ++r) acc[r] = 0.0;
+  const int k0 = active ? plr_ptr[i] : 0, k1 = active ? plr_ptr[i + 1] : 0;
+  for (int k = k0 + g; k < k1; k += G) {
+    const int q = plr_blk[k];
+    const int lm = pl_lm[q];
+    const double* B = Hpl + (size_t)q * PD * LD;
+#pragma unroll
+    for (int c = 0; c < LD; ++c) {
+      const double dv = db[(size_t)lm * LD + c];
+#pragma unroll
+      for (int r = 0; r < PD; ++r) acc[r] += B[r + PD * c] * dv;
+    }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int r = 0; r < PD; ++r) acc[r] = group_sum<G>(acc[r]);
+  }
+  if (!active) return;
+#pragma unroll
+  for (int r = 0; r < PD; ++r)
+    if (G == 1 || (r % G) == g) bschur[(size_t)i * PD + r] = b[(size_t)i * PD + r] - acc[r];
+}
+
+// K13: x_l = Dinv (b_l - Hpl' x_p)   (block_solver.hpp:459-483)
+template <int PD, int LD>
+__global__ void __launch_bounds__(kThreads) back_substitute_kernel(int nL, const int* __restrict__ pl_colptr, const int* __restrict__ pl_row,
+                                       const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+                                       const double* __restrict__ bl, const double* __restrict__ xp, double* __restrict__ xl) {
+  const int lm = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lm >= nL) return;
+  double c[LD];
+#pragma unroll
+  for (int j = 0; j < LD; ++j) c[j] = bl[(size_t)lm * LD + j];
+  for (int q = pl_colptr[lm]; q < pl_colptr[lm + 1]; ++q) {
+    const double* B = Hpl + (size_t)q * PD * LD;
+    const double* xs = xp + (size_t)pl_row[q] * PD;
+    double xv[PD];
+#pragma unroll
+    for (int r = 0; r < PD; ++r) xv[r] = xs[r];
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < PD; ++r) t += B[r + PD * j] * xv[r];
+      c[j] -= t;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LD; ++i) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < LD; ++j) t += Dinv[(size_t)lm * LD * LD + i + LD * j] * c[j];
+    xl[(size_t)lm * LD + i] = t;
+  }
+}
+
+// K14: dest += H src over the full system (one thread per stored block, fp64 atomics; not on the
+// per-iteration path of GN/LM -- used by Dogleg and residual checks)
+__global__ void __launch_bounds__(kThreads) spmv_sym_blocks_kernel(int ncols, int bs, const int* __restrict__ colptr, const int* __restrict__ row,
+                                       const double* __restrict__ val, const double* __restrict__ src, double* __restrict__ dst) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  for (int q = colptr[c]; q < colptr[c + 1]; ++q) {
+    const int r = row[q];
+    const double* B = val + (size_t)q * bs * bs;
+    for (int i = 0; i < bs; ++i) {
+      double t = 0.0;
+      for (int j = 0; j < bs; ++j) t += B[i + bs * j] * src[(size_t)c * bs + j];
+      atomicAdd(&dst[(size_t)r * bs + i], t);
+    }
+    if (r != c)
+      for (int j = 0; j < bs; ++j) {
+        double t = 0.0;
+        for (int i = 0; i < bs; ++i) t += B[i + bs * j] * src[(size_t)r * bs + i];
+        atomicAdd(&dst[(size_t)c * bs + j], t);
+      }
+  }
+}
+__global__ void __launch_bounds__(kThreads) spmv_pl_kernel(int nL, int p, int l, size_t sizeP, const int* __restrict__ colptr, const int* __restrict__ row,
+                               const double* __restrict__ Hpl, const double* __restrict__ Hll, const double* __restrict__ src,
+                               double* __restrict__ dst) {
+  const int lm = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lm >= nL) return;
+  for (int q = colptr[lm]; q < colptr[lm + 1]; ++q) {
+    const int r = row[q];
+    const double* B = Hpl + (size_t)q * p * l;
+    for (int i = 0; i < p; ++i) {
+      double t = 0.0;
+      for (int j = 0; j < l; ++j) t += B[i + p * j] * src[sizeP + (size_t)lm * l + j];
+      atomicAdd(&dst[(size_t)r * p + i], t);
+    }
+    for (int j = 0; j < l; ++j) {
+      double t = 0.0;
+      for (int i = 0; i < p; ++i) t += B[i + p * j] * src[(size_t)r * p + i];
+      atomicAdd(&dst[sizeP + (size_t)lm * l + j], t);
+    }
+  }
+  const double* D = Hll + (size_t)lm * l * l;
+  for (int i = 0; i < l; ++i) {
+    double t = 0.0;
+    for (int j = 0; j < l; ++j) t += D[i + l * j] * src[sizeP + (size_t)lm * l + j];
+    atomicAdd(&dst[sizeP + (size_t)lm * l + i], t);
+  }
+}
+
+inline int grid_for(size_t n, int threads = kThreads) { return (int)((n + threads - 1) / threads); }
+
+// ---- dispatch tables ----------------------------------------------------------------
+template <int D, int DV>
+void launch_vertex(int G, int nV, const int* vptr, const int* vent, const EdgeSet& es, double* H, const int* diag_blk, double* b,
+                   int accumulate, hipStream_t st) {
+  if (nV == 0) return;
+#define G2OHIP_LV(GG)                                                                                                    \
+  hipLaunchKernelGGL((assemble_vertex_kernel<D, DV, GG>), dim3(grid_for((size_t)nV * GG)), dim3(kThreads), 0, st, nV, vptr, \
+                     vent, es.J0, es.J1, es.omega, es.err, es.kernel_kind, es.delta, H, diag_blk, b, accumulate)
+  if (G <= 1)
+    G2OHIP_LV(1);
+  else if (G <= 4)
+    G2OHIP_LV(4);
+  else
+    G2OHIP_LV(8);
+#undef G2OHIP_LV
+}
+
+void dispatch_vertex(int D, int DV, int G, int nV, const int* vptr, const int* vent, const EdgeSet& es, double* H,
+                     const int* diag_blk, double* b, int accumulate, hipStream_t st) {
+#define G2OHIP_CASE(d_, v_) \
+  if (D == d_ && DV == v_) return launch_vertex<d_, v_>(G, nV, vptr, vent, es, H, diag_blk, b, accumulate, st)
+  G2OHIP_CASE(2, 2);
+  G2OHIP_CASE(2, 3);
+  G2OHIP_CASE(2, 6);
+  G2OHIP_CASE(3, 2);
+  G2OHIP_CASE(3, 3);
+  G2OHIP_CASE(3, 6);
+  G2OHIP_CASE(6, 6);
+  G2OHIP_CASE(7, 7);
+  G2OHIP_CASE(1, 3);
+  G2OHIP_CASE(1, 6);
+#undef G2OHIP_CASE
+  throw ArgFailure("unsupported (error_dim, vertex_dim) = (" + std::to_string(D) + "," + std::to_string(DV) + ")");
+}
+
+void dispatch_offdiag(int D, int DR, int DC, int nDst, const int* dst, const int* ptr, const int* ent, const EdgeSet& es, double* H,
+                      int accumulate, hipStream_t st) {
+  if (nDst == 0) return;
+#define G2OHIP_CASE(d_, r_, c_)                                                                                         \
+  if (D == d_ && DR == r_ && DC == c_) {                                                                                \
+    hipLaunchKernelGGL((assemble_offdiag_kernel<d_, r_, c_>), dim3(grid_for(nDst)), dim3(kThreads), 0, st, nDst, dst, ptr, \
+                       ent, es.J0, es.J1, es.omega, es.err, es.kernel_kind, es.delta, H, accumulate);                    \
+    return;                                                                                                             \
+  }
+  G2OHIP_CASE(2, 3, 2);
+  G2OHIP_CASE(2, 6, 3);
+  G2OHIP_CASE(3, 3, 3);
+  G2OHIP_CASE(3, 6, 3);
+  G2OHIP_CASE(6, 6, 6);
+  G2OHIP_CASE(7, 7, 7);
+  G2OHIP_CASE(2, 3, 3);
+  G2OHIP_CASE(2, 6, 6);
+  G2OHIP_CASE(3, 6, 6);
+#undef G2OHIP_CASE
+  throw ArgFailure("unsupported off-diagonal block shape (d,rows,cols) = (" + std::to_string(D) + "," + std::to_string(DR) + "," +
+                   std::to_string(DC) + ")");
+}
+
+int pick_group(double avg) { return avg <= 2.0 ? 1 : (avg <= 16.0 ? 4 : 8); }
+
+// find row r in column c of a sorted block-CCS pattern
+inline int find_block(const std::vector<int>& colptr, const std::vector<int>& row, int c, int r) {
+  auto b = row.begin() + colptr[c], e = row.begin() + colptr[c + 1];
+  auto it = std::lower_bound(b, e, r);
+  if (it == e || *it != r) return -1;
+  return (int)(it - row.begin());
+}
+
+void keys_to_ccs(std::vector<long long>& keys, long long N, int ncols, std::vector<int>& colptr, std::vector<int>& row) {
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  colptr.assign(ncols + 1, 0);
+  row.resize(keys.size());
+  for (size_t i = 0; i < keys.size(); ++i) {
+    colptr[(int)(keys[i] / N) + 1]++;
+    row[i] = (int)(keys[i] % N);
+  }
+  for (int c = 0; c < ncols; ++c) colptr[c + 1] += colptr[c];
+}
+
+// group (dest, payload) pairs by dest into CSR over [0, ndst)
+void group_by(int ndst, const std::vector<int>& dest, const std::vector<int>& payload, std::vector<int>& ptr, std::vector<int>& ent) {
+  ptr.assign(ndst + 1, 0);
+  for (int d : dest) ptr[d + 1]++;
+  for (int k = 0; k < ndst; ++k) ptr[k + 1] += ptr[k];
+  ent.resize(dest.size());
+  std::vector<int> w(ptr.begin(), ptr.end() - 1);
+  for (size_t k = 0; k < dest.size(); ++k) ent[w[dest[k]]++] = payload[k];  // stable: edge order kept per destination
+}
+
+}  // namespace
+
+// =====================================================================================
+// BlockSolver
+// =====================================================================================
+BlockSolver::BlockSolver(int p, int l, int device) : p_(p), l_(l), device_(device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    throw HipFailure("no HIP device available: libg2ohip has no CPU fallback");
+  if (device < 0 || device >= count) throw ArgFailure("bad device ordinal");
+  G2OHIP_HIP_CHECK(hipSetDevice(device));
+  G2OHIP_HIP_CHECK(hipStreamCreate(&st_));
+  own_stream_ = true;
+  if (!(p == 3 || p == 6 || p == 7)) throw ArgFailure("pose_dim must be 3, 6 or 7");
+  if (!(l == 2 || l == 3 || l == 0)) throw ArgFailure("landmark_dim must be 2 or 3");
+}
+
+BlockSolver::~BlockSolver() {
+  if (own_stream_ && st_) (void)hipStreamDestroy(st_);
+}
+
+void BlockSolver::set_stream(hipStream_t st) {
+  if (own_stream_ && st_) (void)hipStreamDestroy(st_);
+  own_stream_ = false;
+  st_ = st;
+}
+
+void BlockSolver::init() {
+  // block_solver.hpp:606-620: numeric + symbolic state is rebuilt on the next buildStructure/solve
+  if (chol_) chol_->reset();
+  system_built_ = false;
+}
+
+int BlockSolver::add_edge_set(int d, int n, const int* v0, const int* v1) {
+  if (d <= 0 || d > 7 || n < 0 || !v0) throw ArgFailure("add_edge_set: bad arguments");
+  auto es = std::make_unique<EdgeSet>();
+  es->d = d;
+  es->n = n;
+  es->unary = (v1 == nullptr);
+  es->v0.assign(v0, v0 + n);
+  if (v1) es->v1.assign(v1, v1 + n);
+  else es->v1.assign(n, -1);
+  sets_.push_back(std::move(es));
+  structured_ = false;
+  return (int)sets_.size() - 1;
+}
+
+void BlockSolver::require_structure() const {
+  if (!structured_) throw StateFailure("call g2ohip_build_structure first");
+}
+
+void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  nP_ = nP;
+  nL_ = nL;
+  schur_ = do_schur && nL > 0;
+  if (nP <= 0) throw ArgFailure("build_structure: need at least one free pose");
+  if (nL > 0 && l_ == 0) throw ArgFailure("landmarks present but landmark_dim == 0");
+  const int p = p_, l = l_;
+  auto is_lm = [&](int v) { return v >= nP; };
+  // ---- validate sets, vertex classes
+  for (auto& esp : sets_) {
+    EdgeSet& es = *esp;
+    int c0 = -1, c1 = -1;
+    for (int k = 0; k < es.n; ++k) {
+      int a = es.v0[k], b = es.v1[k];
+      if (a >= nP + nL || b >= nP + nL || a < -1 || b < -1) throw ArgFailure("edge index out of range");
+      if (a >= 0) {
+        int c = is_lm(a);
+        if (c0 >= 0 && c0 != c) throw ArgFailure("edge set mixes vertex classes on side 0");
+        c0 = c;
+      }
+      if (b >= 0) {
+        int c = is_lm(b);
+        if (c1 >= 0 && c1 != c) throw ArgFailure("edge set mixes vertex classes on side 1");
+        c1 = c;
+      }
+      if (a >= 0 && b >= 0 && is_lm(a) && is_lm(b)) throw ArgFailure("landmark-landmark edges are not supported (block_solver.hpp:383)");
+    }
+    es.dim0 = (c0 == 1) ? l : p;
+    es.dim1 = es.unary ? 0 : ((c1 == 1) ? l : p);
+  }
+  // ---- Hpp / Hpl patterns (block_solver.hpp:178-254)
+  std::vector<long long> kpp, kpl;
+  kpp.reserve(nP);
+  for (int i = 0; i < nP; ++i) kpp.push_back((long long)i * nP + i);
+  for (auto& esp : sets_) {
+    EdgeSet& es = *esp;
+    for (int k = 0; k < es.n; ++k) {
+      int a = es.v0[k], b = es.v1[k];
+      if (a < 0 || b < 0) continue;
+      if (!is_lm(a) && !is_lm(b)) {
+        int r = std::min(a, b), c = std::max(a, b);
+        kpp.push_back((long long)c * nP + r);
+      } else {
+        int pose = is_lm(a) ? b : a, lm = (is_lm(a) ? a : b) - nP;
+        kpl.push_back((long long)lm * nP + pose);
+      }
+    }
+  }
+  keys_to_ccs(kpp, nP, nP, pp_colptr, pp_row);
+  if (nL > 0) keys_to_ccs(kpl, nP, nL, pl_colptr, pl_row);
+  else {
+    pl_colptr.assign(1, 0);
+    pl_row.clear();
+  }
+  kpp.clear();
+  kpp.shrink_to_fit();
+  kpl.clear();
+  kpl.shrink_to_fit();
+  const int pp_nnzb = (int)pp_row.size(), pl_nnzb = (int)pl_row.size();
+  pp_diag.resize(nP);
+  for (int c = 0; c < nP; ++c) pp_diag[c] = find_block(pp_colptr, pp_row, c, c);
+  // ---- contributor lists per set
+  bool seen_pose = false, seen_lm = false, seen_op = false, seen_ol = false;
+  std::vector<int> offdiag_blocks;
+  offdiag_blocks.reserve(pp_nnzb - nP);
+  for (int c = 0; c < nP; ++c)
+    for (int q = pp_colptr[c]; q < pp_colptr[c + 1]; ++q)
+      if (pp_row[q] != c) offdiag_blocks.push_back(q);
+  for (auto& esp : sets_) {
+    EdgeSet& es = *esp;
+    std::vector<int> dp, pp_, dl, pl_, dop, pop, dol, pol;
+    for (int k = 0; k < es.n; ++k) {
+      int a = es.v0[k], b = es.v1[k];
+      if (a >= 0) {
+        if (is_lm(a)) { dl.push_back(a - nP); pl_.push_back(k << 1); }
+        else { dp.push_back(a); pp_.push_back(k << 1); }
+      }
+      if (b >= 0) {
+        if (is_lm(b)) { dl.push_back(b - nP); pl_.push_back((k << 1) | 1); }
+        else { dp.push_back(b); pp_.push_back((k << 1) | 1); }
+      }
+      if (a >= 0 && b >= 0) {
+        if (!is_lm(a) && !is_lm(b)) {
+          int tr = a > b;
+          int q = find_block(pp_colptr, pp_row, std::max(a, b), std::min(a, b));
+          dop.push_back(q);
+          pop.push_back((k << 1) | tr);
+        } else {
+          int pose = is_lm(a) ? b : a, lm = (is_lm(a) ? a : b) - nP;
+          int tr = is_lm(a) ? 1 : 0;  // vertex 0 marginalized -> write transposed (block_solver.hpp:240-244)
+          dol.push_back(find_block(pl_colptr, pl_row, lm, pose));
+          pol.push_back((k << 1) | tr);
+        }
+      }
+    }
+    es.touches_pose = !dp.empty();
+    es.touches_lm = !dl.empty();
+    std::vector<int> ptr, ent;
+    if (es.touches_pose) {
+      group_by(nP, dp, pp_, ptr, ent);
+      es.vp_ptr.upload(ptr, st_);
+      es.vp_ent.upload(ent, st_);
+      es.n_vp_ent = (long)ent.size();
+      es.first_pose = !seen_pose;
+      seen_pose = true;
+    }
+    if (es.touches_lm) {
+      group_by(nL, dl, pl_, ptr, ent);
+      es.vl_ptr.upload(ptr, st_);
+      es.vl_ent.upload(ent, st_);
+      es.n_vl_ent = (long)ent.size();
+      es.first_lm = !seen_lm;
+      seen_lm = true;
+    }
+    if (!dop.empty()) {
+      es.first_op = !seen_op;
+      seen_op = true;
+      // destination list: all off-diagonal blocks for the first pose-pose set (so every block is written),
+      // only the touched ones afterwards
+      std::vector<int> dst_list;
+      if (es.first_op) dst_list = offdiag_blocks;
+      else {
+        dst_list = dop;
+        std::sort(dst_list.begin(), dst_list.end());
+        dst_list.erase(std::unique(dst_list.begin(), dst_list.end()), dst_list.end());
+      }
+      std::vector<int> local(dop.size());
+      for (size_t k = 0; k < dop.size(); ++k)
+        local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dop[k]) - dst_list.begin());
+      group_by((int)dst_list.size(), local, pop, ptr, ent);
+      es.n_op = (int)dst_list.size();
+      es.op_dst.upload(dst_list, st_);
+      es.op_ptr.upload(ptr, st_);
+      es.op_ent.upload(ent, st_);
+    }
+    if (!dol.empty()) {
+      es.first_ol = !seen_ol;
+      seen_ol = true;
+      std::vector<int> dst_list;
+      if (es.first_ol) {
+        dst_list.resize(pl_nnzb);
+        std::iota(dst_list.begin(), dst_list.end(), 0);
+      } else {
+        dst_list = dol;
+        std::sort(dst_list.begin(), dst_list.end());
+        dst_list.erase(std::unique(dst_list.begin(), dst_list.end()), dst_list.end());
+      }
+      std::vector<int> local(dol.size());
+      for (size_t k = 0; k < dol.size(); ++k)
+        local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dol[k]) - dst_list.begin());
+      group_by((int)dst_list.size(), local, pol, ptr, ent);
+      es.n_ol = (int)dst_list.size();
+      es.ol_dst.upload(dst_list, st_);
+      es.ol_ptr.upload(ptr, st_);
+      es.ol_ent.upload(ent, st_);
+    }
+    es.has_data = false;
+  }
+  // ---- Schur structure (block_solver.hpp:256-292)
+  n_sc_ = 0;
+  if (schur_) {
+    std::vector<long long> ks;
+    size_t cnt = pp_nnzb;
+    for (int c = 0; c < nL; ++c) {
+      size_t k = pl_colptr[c + 1] - pl_colptr[c];
+      cnt += k * (k + 1) / 2;
+    }
+    ks.reserve(cnt);
+    for (int c = 0; c < nP; ++c)
+      for (int q = pp_colptr[c]; q < pp_colptr[c + 1]; ++q) ks.push_back((long long)c * nP + pp_row[q]);
+    for (int c = 0; c < nL; ++c)
+      for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
+        for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) ks.push_back((long long)pl_row[q2] * nP + pl_row[q1]);
+    keys_to_ccs(ks, nP, nP, hs_colptr, hs_row);
+    ks.clear();
+    ks.shrink_to_fit();
+    const int hs_nnzb = (int)hs_row.size();
+    std::vector<int> hs_src(hs_nnzb, -1);
+    for (int c = 0; c < nP; ++c)
+      for (int q = pp_colptr[c]; q < pp_colptr[c + 1]; ++q) hs_src[find_block(hs_colptr, hs_row, c, pp_row[q])] = q;
+    // contributor pairs per Hschur block, in landmark order (== the reference's summation order)
+    std::vector<int> sc_ptr(hs_nnzb + 1, 0);
+    std::vector<int> pair_dst;
+    pair_dst.reserve(cnt - pp_nnzb);
+    for (int c = 0; c < nL; ++c)
+      for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
+        for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) {
+          int d = find_block(hs_colptr, hs_row, pl_row[q2], pl_row[q1]);
+          pair_dst.push_back(d);
+          sc_ptr[d + 1]++;
+        }
+    for (int d = 0; d < hs_nnzb; ++d) sc_ptr[d + 1] += sc_ptr[d];
+    std::vector<int> q1v(pair_dst.size()), q2v(pair_dst.size());
+    {
+      std::vector<int> w(sc_ptr.begin(), sc_ptr.end() - 1);
+      size_t k = 0;
+      for (int c = 0; c < nL; ++c)
+        for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
+          for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) {
+            int pos = w[pair_dst[k++]]++;
+            q1v[pos] = q1;
+            q2v[pos] = q2;
+          }
+    }
+    n_sc_ = (long)pair_dst.size();
+    d_hs_src.upload(hs_src, st_);
+    d_sc_ptr.upload(sc_ptr, st_);
+    d_sc_q1.upload(q1v, st_);
+    d_sc_q2.upload(q2v, st_);
+    // Hpl blocks by pose row, landmark order
+    std::vector<int> plr_ptr(nP + 1, 0), plr_blk(pl_nnzb);
+    for (int q = 0; q < pl_nnzb; ++q) plr_ptr[pl_row[q] + 1]++;
+    for (int i = 0; i < nP; ++i) plr_ptr[i + 1] += plr_ptr[i];
+    {
+      std::vector<int> w(plr_ptr.begin(), plr_ptr.end() - 1);
+      for (int q = 0; q < pl_nnzb; ++q) plr_blk[w[pl_row[q]]++] = q;
+    }
+    d_plr_ptr.upload(plr_ptr, st_);
+    d_plr_blk.upload(plr_blk, st_);
+    d_Hschur.alloc((size_t)hs_nnzb * p * p);
+    d_Dinv.alloc((size_t)nL * l * l);
+    d_db.alloc((size_t)nL * l);
+    d_bschur.alloc((size_t)nP * p);
+  } else {
+    hs_colptr.clear();
+    hs_row.clear();
+  }
+  // landmark id per Hpl block
+  if (nL > 0) {
+    std::vector<int> pl_lm(pl_nnzb);
+    for (int c = 0; c < nL; ++c)
+      for (int q = pl_colptr[c]; q < pl_colptr[c + 1]; ++q) pl_lm[q] = c;
+    d_pl_lm.upload(pl_lm, st_);
+    d_pl_colptr.upload(pl_colptr, st_);
+    d_pl_row.upload(pl_row, st_);
+    d_Hpl.alloc((size_t)pl_nnzb * p * l);
+    d_Hll.alloc((size_t)nL * l * l);
+    d_bkL.alloc((size_t)nL * l);
+  }
+  d_pp_diag.upload(pp_diag, st_);
+  d_pp_colptr.upload(pp_colptr, st_);
+  d_pp_row.upload(pp_row, st_);
+  d_Hpp.alloc((size_t)pp_nnzb * p * p);
+  d_bkP.alloc((size_t)nP * p);
+  d_b.alloc(vector_size());
+  d_x.alloc(vector_size());
+  d_red.alloc(4096);
+  G2OHIP_HIP_CHECK(hipMemsetAsync(d_Hpp.p, 0, (size_t)pp_nnzb * p * p * sizeof(double), st_));
+  if (nL > 0) {
+    G2OHIP_HIP_CHECK(hipMemsetAsync(d_Hpl.p, 0, (size_t)pl_nnzb * p * l * sizeof(double), st_));
+    G2OHIP_HIP_CHECK(hipMemsetAsync(d_Hll.p, 0, (size_t)nL * l * l * sizeof(double), st_));
+  }
+  G2OHIP_HIP_CHECK(hipMemsetAsync(d_b.p, 0, vector_size() * sizeof(double), st_));
+  G2OHIP_HIP_CHECK(hipMemsetAsync(d_x.p, 0, vector_size() * sizeof(double), st_));
+  // ---- symbolic factorisation of the system the linear solver will see
+  chol_ = std::make_unique<SparseCholesky>(p);
+  chol_->opt = chol_opt;
+  if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
+  else chol_->analyze(nP, pp_colptr.data(), pp_row.data(), st_);
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+  structured_ = true;
+  system_built_ = false;
+}
+
+void BlockSolver::set_edge_data(int set, const double* J0, const double* J1, const double* omega, const double* err, bool on_device) {
+  require_structure();
+  if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
+  EdgeSet& es = *sets_[set];
+  if (!J0 || !omega || !err || (!es.unary && !J1)) throw ArgFailure("set_edge_data: null array");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (on_device) {
+    es.J0 = J0;
+    es.J1 = J1;
+    es.omega = omega;
+    es.err = err;
+  } else {
+    const size_t n = (size_t)es.n;
+    es.own_J0.upload(J0, n * es.d * es.dim0, st_);
+    if (!es.unary) es.own_J1.upload(J1, n * es.d * es.dim1, st_);
+    es.own_omega.upload(omega, n * es.d * es.d, st_);
+    es.own_err.upload(err, n * es.d, st_);
+    es.J0 = es.own_J0.p;
+    es.J1 = es.unary ? nullptr : es.own_J1.p;
+    es.omega = es.own_omega.p;
+    es.err = es.own_err.p;
+  }
+  es.has_data = true;
+}
+
+void BlockSolver::set_robust_kernel(int set, int kind, double delta) {
+  if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
+  if (kind != 0 && kind != 1) throw ArgFailure("unsupported robust kernel");
+  sets_[set]->kernel_kind = kind;
+  sets_[set]->delta = delta;
+}
+
+void BlockSolver::build_system() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  for (auto& esp : sets_)
+    if (esp->n > 0 && !esp->has_data) throw StateFailure("build_system: edge data missing for a set");
+  if (profiling) tq_.start(st_);
+  const size_t sizeP = (size_t)nP_ * p_;
+  bool any_pose = false, any_lm = false;
+  for (auto& esp : sets_) {
+    EdgeSet& es = *esp;
+    if (es.n == 0) continue;
+    if (es.touches_pose) {
+      int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
+      prof.begin(KernelProf::kAsmPose, st_);
+      dispatch_vertex(es.d, p_, G, nP_, es.vp_ptr.p, es.vp_ent.p, es, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, st_);
+      prof.end(KernelProf::kAsmPose, st_);
+      any_pose = true;
+    }
+    if (es.touches_lm) {
+      int G = pick_group((double)es.n_vl_ent / std::max(1, nL_));
+      prof.begin(KernelProf::kAsmLandmark, st_);
+      dispatch_vertex(es.d, l_, G, nL_, es.vl_ptr.p, es.vl_ent.p, es, d_Hll.p, nullptr, d_b.p + sizeP, es.first_lm ? 0 : 1, st_);
+      prof.end(KernelProf::kAsmLandmark, st_);
+      any_lm = true;
+    }
+    if (es.n_op > 0) {
+      prof.begin(KernelProf::kAsmOffPP, st_);
+      dispatch_offdiag(es.d, p_, p_, es.n_op, es.op_dst.p, es.op_ptr.p, es.op_ent.p, es, d_Hpp.p, es.first_op ? 0 : 1, st_);
+      prof.end(KernelProf::kAsmOffPP, st_);
+    }
+    if (es.n_ol > 0) {
+      prof.begin(KernelProf::kAsmOffPL, st_);
+      dispatch_offdiag(es.d, p_, l_, es.n_ol, es.ol_dst.p, es.ol_ptr.p, es.ol_ent.p, es, d_Hpl.p, es.first_ol ? 0 : 1, st_);
+      prof.end(KernelProf::kAsmOffPL, st_);
+    }
+  }
+  // classes nobody touches stay zero (cleared once in build_structure)
+  (void)any_pose;
+  (void)any_lm;
+  G2OHIP_HIP_CHECK(hipGetLastError());
+  if (profiling) {
+    tq_.stop(st_);
+    times.quadratic = tq_.seconds();
+  }
+  system_built_ = true;
+}
+
+double BlockSolver::reduce_sum_finish(int nblocks) {
+  std::vector<double> h(nblocks);
+  d_red.download(h.data(), nblocks, st_);
+  double s = 0.0;
+  for (double v : h) s += v;  // fixed order: deterministic
+  return s;
+}
+
+double BlockSolver::chi2() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  double total = 0.0;
+  for (auto& esp : sets_) {
+    EdgeSet& es = *esp;
+    if (es.n == 0) continue;
+    if (!es.has_data) throw StateFailure("chi2: edge data missing");
+    int nblocks = std::min(1024, grid_for(es.n));
+#define G2OHIP_CHI(d_)                                                                                                      \
+  case d_:                                                                                                                  \
+    hipLaunchKernelGGL((chi2_kernel<d_>), dim3(nblocks), dim3(kThreads), 0, st_, es.n, es.omega, es.err, es.kernel_kind, es.delta, \
+                       d_red.p);                                                                                            \
+    break
+    switch (es.d) {
+      G2OHIP_CHI(1);
+      G2OHIP_CHI(2);
+      G2OHIP_CHI(3);
+      G2OHIP_CHI(6);
+      G2OHIP_CHI(7);
+      default:
+        throw ArgFailure("chi2: unsupported error dimension");
+    }
+#undef G2OHIP_CHI
+    total += reduce_sum_finish(nblocks);
+  }
+  return total;
+}
+
+void BlockSolver::set_lambda(double lambda, bool backup) {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  prof.begin(KernelProf::kLambda, st_);
+  hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nP_ * p_)), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p, d_bkP.p,
+                     lambda, backup ? 1 : 0, 0);
+  if (nL_ > 0)
+    hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nL_ * l_)), dim3(kThreads), 0, st_, nL_, l_, d_Hll.p, (const int*)nullptr,
+                       d_bkL.p, lambda, backup ? 1 : 0, 0);
+  prof.end(KernelProf::kLambda, st_);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+void BlockSolver::restore_diagonal() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nP_ * p_)), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p, d_bkP.p,
+                     0.0, 0, 1);
+  if (nL_ > 0)
+    hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nL_ * l_)), dim3(kThreads), 0, st_, nL_, l_, d_Hll.p, (const int*)nullptr,
+                       d_bkL.p, 0.0, 0, 1);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+double BlockSolver::max_diagonal() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  double m = 0.0;
+  {
+    int nblocks = std::min(1024, grid_for((size_t)nP_ * p_));
+    hipLaunchKernelGGL(maxdiag_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p, d_red.p);
+    std::vector<double> h(nblocks);
+    d_red.download(h.data(), nblocks, st_);
+    for (double v : h) m = std::max(m, v);
+  }
+  if (nL_ > 0) {
+    int nblocks = std::min(1024, grid_for((size_t)nL_ * l_));
+    hipLaunchKernelGGL(maxdiag_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, nL_, l_, d_Hll.p, (const int*)nullptr, d_red.p);
+    std::vector<double> h(nblocks);
+    d_red.download(h.data(), nblocks, st_);
+    for (double v : h) m = std::max(m, v);
+  }
+  return m;
+}
+
+double BlockSolver::compute_scale(double lambda) {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  int nblocks = std::min(1024, grid_for(vector_size()));
+  hipLaunchKernelGGL(scale_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, vector_size(), d_x.p, d_b.p, lambda, d_red.p);
+  return reduce_sum_finish(nblocks);
+}
+
+void BlockSolver::solve_schur() {
+  require_structure();
+  if (!schur_) return;
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (profiling) ts_.start(st_);
+  const size_t sizeP = (size_t)nP_ * p_;
+  const int hs_nnzb = (int)hs_row.size();
+  const int G = pick_group((double)n_sc_ / std::max(1, hs_nnzb));
+  const int Gr = pick_group((double)pl_row.size() / std::max(1, nP_));
+#define G2OHIP_SCHUR(P_, L_)                                                                                                   \
+  if (p_ == P_ && l_ == L_) {                                                                                                  \
+    prof.begin(KernelProf::kLmInverse, st_);                                                                                   \
+    hipLaunchKernelGGL((landmark_inverse_kernel<L_>), dim3(grid_for(nL_)), dim3(kThreads), 0, st_, nL_, d_Hll.p, d_b.p + sizeP, \
+                       d_Dinv.p, d_db.p);                                                                                      \
+    prof.end(KernelProf::kLmInverse, st_);                                                                                     \
+    prof.begin(KernelProf::kSchurBlocks, st_);                                                                                 \
+    if (G == 1)                                                                                                                \
+      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 1>), dim3(grid_for((size_t)hs_nnzb)), dim3(kThreads), 0, st_, hs_nnzb,    \
+                         d_sc_ptr.p, d_sc_q1.p, d_sc_q2.p, d_pl_lm.p, d_Hpl.p, d_Dinv.p, d_hs_src.p, d_Hpp.p, d_Hschur.p);     \
+    else if (G == 4)                                                                                                           \
+      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 4>), dim3(grid_for((size_t)hs_nnzb * 4)), dim3(kThreads), 0, st_, hs_nnzb, \
+                         d_sc_ptr.p, d_sc_q1.p, d_sc_q2.p, d_pl_lm.p, d_Hpl.p, d_Dinv.p, d_hs_src.p, d_Hpp.p, d_Hschur.p);     \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 8>), dim3(grid_for((size_t)hs_nnzb * 8)), dim3(kThreads), 0, st_, hs_nnzb, \
+                         d_sc_ptr.p, d_sc_q1.p, d_sc_q2.p, d_pl_lm.p, d_Hpl.p, d_Dinv.p, d_hs_src.p, d_Hpp.p, d_Hschur.p);     \
+    prof.end(KernelProf::kSchurBlocks, st_);                                                                                   \
+    prof.begin(KernelProf::kSchurRhs, st_);                                                                                    \
+    if (Gr == 1)                                                                                                               \
+      hipLaunchKernelGGL((schur_rhs_kernel<P_, L_, 1>), dim3(grid_for((size_t)nP_)), dim3(kThreads), 0, st_, nP_, d_plr_ptr.p,   \
+                         d_plr_blk.p, d_pl_lm.p, d_Hpl.p, d_db.p, d_b.p, d_bschur.p);                                          \
+    else if (Gr == 4)                                                                                                          \
+      hipLaunchKernelGGL((schur_rhs_kernel<P_, L_, 4>), dim3(grid_for((size_t)nP_ * 4)), dim3(kThreads), 0, st_, nP_, d_plr_ptr.p, \
+                         d_plr_blk.p, d_pl_lm.p, d_Hpl.p, d_db.p, d_b.p, d_bschur.p);                                          \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((schur_rhs_kernel<P_, L_, 8>), dim3(grid_for((size_t)nP_ * 8)), dim3(kThreads), 0, st_, nP_, d_plr_ptr.p, \
+                         d_plr_blk.p, d_pl_lm.p, d_Hpl.p, d_db.p, d_b.p, d_bschur.p);                                          \
+    prof.end(KernelProf::kSchurRhs, st_);                                                                                      \
+  } else
+  G2OHIP_SCHUR(6, 3)
+  G2OHIP_SCHUR(3, 2)
+  G2OHIP_SCHUR(7, 3)
+  G2OHIP_SCHUR(6, 2)
+  G2OHIP_SCHUR(3, 3) { throw ArgFailure("unsupported (pose_dim, landmark_dim) for Schur"); }
+#undef G2OHIP_SCHUR
+  G2OHIP_HIP_CHECK(hipGetLastError());
+  if (profiling) {
+    ts_.stop(st_);
+    times.schur = ts_.seconds();
+  }
+}
+
+int BlockSolver::solve_reduced() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (!chol_->analyzed()) {
+    if (schur_) chol_->analyze(nP_, hs_colptr.data(), hs_row.data(), st_);
+    else chol_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
+  }
+  if (profiling) tn_.start(st_);
+  prof.begin(KernelProf::kCholFactor, st_);
+  chol_->factor(schur_ ? d_Hschur.p : d_Hpp.p, st_);
+  prof.end(KernelProf::kCholFactor, st_);
+  if (profiling) {
+    tn_.stop(st_);
+    tl_.start(st_);
+  }
+  prof.begin(KernelProf::kCholSolve, st_);
+  chol_->solve(schur_ ? d_bschur.p : d_b.p, d_x.p, st_);
+  prof.end(KernelProf::kCholSolve, st_);
+  if (profiling) tl_.stop(st_);
+  bool bad = chol_->failed(st_);   // synchronises
+  if (profiling) {
+    times.numeric = tn_.seconds();
+    times.linsolve = tl_.seconds();
+  }
+  return bad ? 1 : 0;
+}
+
+void BlockSolver::solve_back_substitute() {
+  require_structure();
+  if (!schur_) return;
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (profiling) tb_.start(st_);
+  const size_t sizeP = (size_t)nP_ * p_;
+  prof.begin(KernelProf::kBackSub, st_);
+#define G2OHIP_BACK(P_, L_)                                                                                                    \
+  if (p_ == P_ && l_ == L_)                                                                                                    \
+    hipLaunchKernelGGL((back_substitute_kernel<P_, L_>), dim3(grid_for(nL_)), dim3(kThreads), 0, st_, nL_, d_pl_colptr.p,        \
+                       d_pl_row.p, d_Hpl.p, d_Dinv.p, d_b.p + sizeP, d_x.p, d_x.p + sizeP);                                    \
+  else
+  G2OHIP_BACK(6, 3)
+  G2OHIP_BACK(3, 2)
+  G2OHIP_BACK(7, 3)
+  G2OHIP_BACK(6, 2)
+  G2OHIP_BACK(3, 3) { throw ArgFailure("unsupported (pose_dim, landmark_dim)"); }
+#undef G2OHIP_BACK
+  prof.end(KernelProf::kBackSub, st_);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+  if (profiling) {
+    tb_.stop(st_);
+    times.backsub = tb_.seconds();
+  }
+}
+
+int BlockSolver::solve() {
+  if (!system_built_) throw StateFailure("solve before build_system");
+  solve_schur();
+  int rc = solve_reduced();
+  if (rc != 0) return rc;
+  solve_back_substitute();
+  return 0;
+}
+
+void BlockSolver::multiply_hessian(double* dest_host, const double* src_host) {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  const size_t n = vector_size();
+  DevBuf<double> src, dst;
+  src.upload(src_host, n, st_);
+  dst.upload(dest_host, n, st_);
+  hipLaunchKernelGGL(spmv_sym_blocks_kernel, dim3(grid_for(nP_)), dim3(kThreads), 0, st_, nP_, p_, d_pp_colptr.p, d_pp_row.p, d_Hpp.p,
+                     src.p, dst.p);
+  if (nL_ > 0)
+    hipLaunchKernelGGL(spmv_pl_kernel, dim3(grid_for(nL_)), dim3(kThreads), 0, st_, nL_, p_, l_, (size_t)nP_ * p_, d_pl_colptr.p,
+                       d_pl_row.p, d_Hpl.p, d_Hll.p, src.p, dst.p);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+  dst.download(dest_host, n, st_);
+}
+
+void BlockSolver::copy_x(double* h) {
+  require_structure();
+  d_x.download(h, vector_size(), st_);
+}
+void BlockSolver::copy_b(double* h) {
+  require_structure();
+  d_b.download(h, vector_size(), st_);
+}
+void BlockSolver::sync() { G2OHIP_HIP_CHECK(hipStreamSynchronize(st_)); }
+
+int BlockSolver::nnzb(int which) const {
+  switch (which) {
+    case 0: return (int)pp_row.size();
+    case 1: return (int)pl_row.size();
+    case 2: return nL_;
+    case 3: return (int)hs_row.size();
+    case 4: return nL_;
+    default: throw ArgFailure("bad matrix selector");
+  }
+}
+void BlockSolver::get_pattern(int which, int* colptr, int* rowidx) const {
+  const std::vector<int>*cp, *ri;
+  switch (which) {
+    case 0: cp = &pp_colptr; ri = &pp_row; break;
+    case 1: cp = &pl_colptr; ri = &pl_row; break;
+    case 3: cp = &hs_colptr; ri = &hs_row; break;
+    default: throw ArgFailure("pattern available for HPP, HPL, HSCHUR");
+  }
+  std::copy(cp->begin(), cp->end(), colptr);
+  std::copy(ri->begin(), ri->end(), rowidx);
+}
+void BlockSolver::copy_values(int which, double* h) {
+  require_structure();
+  switch (which) {
+    case 0: d_Hpp.download(h, pp_row.size() * p_ * p_, st_); break;
+    case 1: d_Hpl.download(h, pl_row.size() * p_ * l_, st_); break;
+    case 2: d_Hll.download(h, (size_t)nL_ * l_ * l_, st_); break;
+    case 3: d_Hschur.download(h, hs_row.size() * p_ * p_, st_); break;
+    case 4: d_Dinv.download(h, (size_t)nL_ * l_ * l_, st_); break;
+    default: throw ArgFailure("bad matrix selector");
+  }
+}
+void BlockSolver::device_array(int which, double** ptr, size_t* count) {
+  require_structure();
+  switch (which) {
+    case 0: *ptr = d_Hpp.p; *count = pp_row.size() * p_ * p_; break;
+    case 1: *ptr = d_Hpl.p; *count = pl_row.size() * p_ * l_; break;
+    case 2: *ptr = d_Hll.p; *count = (size_t)nL_ * l_ * l_; break;
+    case 3: *ptr = d_Hschur.p; *count = hs_row.size() * p_ * p_; break;
+    case 100: *ptr = d_bschur.p; *count = (size_t)nP_ * p_; break;
+    case 101: *ptr = d_x.p; *count = vector_size(); break;
+    case 102: *ptr = d_b.p; *count = vector_size(); break;
+    default: throw ArgFailure("bad array selector");
+  }
+}
+
+}  // namespace g2ohip

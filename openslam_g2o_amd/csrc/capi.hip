@@ -1,0 +1,421 @@
+// extern "C" surface of libg2ohip (include/g2ohip.h).  Exceptions never cross the boundary:
+// every entry point maps failures to the reference's convention -- a return code plus text
+// (the reference path itself uses `false` + cerr).
+#include "../../include/g2ohip.h"
+
+#include <cstring>
+
+#include "block_solver.h"
+
+namespace g2ohip {
+std::string& last_error_ref() {
+  static thread_local std::string e;
+  return e;
+}
+}  // namespace g2ohip
+
+using namespace g2ohip;
+
+struct g2ohip_solver {
+  std::unique_ptr<BlockSolver> impl;
+};
+
+// Narrow seam: LinearSolver<MatrixType> over the same multifrontal engine.
+struct g2ohip_linear_solver {
+  int bs = 0, device = 0;
+  hipStream_t st = nullptr;
+  std::unique_ptr<SparseCholesky> chol;
+  CholOptions opt;
+  std::vector<int> colptr, rowidx;  // pattern the symbolic factorisation was built for
+  DevBuf<double> dA, db, dx;
+  EventTimer tn, tl;
+  double t_numeric = 0, t_solve = 0;
+};
+
+namespace {
+template <class F>
+int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const ArgFailure& e) {
+    set_error(e.what());
+    return G2OHIP_ERR_ARG;
+  } catch (const StateFailure& e) {
+    set_error(e.what());
+    return G2OHIP_ERR_STATE;
+  } catch (const HipFailure& e) {
+    set_error(e.what());
+    return G2OHIP_ERR_HIP;
+  } catch (const std::exception& e) {
+    set_error(e.what());
+    return G2OHIP_ERR_HIP;
+  }
+}
+#define REQUIRE_HANDLE(s)                 \
+  if (!(s) || !(s)->impl) {               \
+    set_error("null solver handle");      \
+    return G2OHIP_ERR_ARG;                \
+  }
+}  // namespace
+
+extern "C" {
+
+const char* g2ohip_last_error(void) { return last_error_ref().c_str(); }
+
+int g2ohip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int g2ohip_create(g2ohip_solver** out, int pose_dim, int landmark_dim, int device) {
+  if (!out) return G2OHIP_ERR_ARG;
+  *out = nullptr;
+  return guarded([&] {
+    auto h = std::make_unique<g2ohip_solver>();
+    h->impl = std::make_unique<BlockSolver>(pose_dim, landmark_dim, device);
+    *out = h.release();
+    return G2OHIP_OK;
+  });
+}
+
+void g2ohip_destroy(g2ohip_solver* s) { delete s; }
+
+int g2ohip_set_stream(g2ohip_solver* s, void* hip_stream) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_stream((hipStream_t)hip_stream);
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_init(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->init();
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_add_edge_set(g2ohip_solver* s, int error_dim, int n_edges, const int32_t* v0, const int32_t* v1) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] { return s->impl->add_edge_set(error_dim, n_edges, v0, v1); });
+}
+
+int g2ohip_build_structure(g2ohip_solver* s, int num_poses, int num_landmarks, int do_schur) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->build_structure(num_poses, num_landmarks, do_schur != 0);
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_set_edge_data(g2ohip_solver* s, int set, const double* J0, const double* J1, const double* omega, const double* err,
+                         int on_device) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_edge_data(set, J0, J1, omega, err, on_device != 0);
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_set_robust_kernel(g2ohip_solver* s, int set, int kind, double delta) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_robust_kernel(set, kind, delta);
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_build_system(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->build_system();
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_chi2(g2ohip_solver* s, double* chi2) {
+  REQUIRE_HANDLE(s);
+  if (!chi2) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    *chi2 = s->impl->chi2();
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_set_lambda(g2ohip_solver* s, double lambda, int backup) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_lambda(lambda, backup != 0);
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_restore_diagonal(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->restore_diagonal();
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_max_diagonal(g2ohip_solver* s, double* out) {
+  REQUIRE_HANDLE(s);
+  if (!out) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    *out = s->impl->max_diagonal();
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_compute_scale(g2ohip_solver* s, double lambda, double* out) {
+  REQUIRE_HANDLE(s);
+  if (!out) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    *out = s->impl->compute_scale(lambda);
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_solve(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] { return s->impl->solve() ? G2OHIP_NOT_PD : G2OHIP_OK; });
+}
+int g2ohip_solve_schur(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->solve_schur();
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_solve_reduced(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] { return s->impl->solve_reduced() ? G2OHIP_NOT_PD : G2OHIP_OK; });
+}
+int g2ohip_solve_back_substitute(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->solve_back_substitute();
+    return G2OHIP_OK;
+  });
+}
+
+size_t g2ohip_vector_size(g2ohip_solver* s) { return (s && s->impl) ? s->impl->vector_size() : 0; }
+
+int g2ohip_copy_x(g2ohip_solver* s, double* x_host) {
+  REQUIRE_HANDLE(s);
+  if (!x_host) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    s->impl->copy_x(x_host);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_copy_b(g2ohip_solver* s, double* b_host) {
+  REQUIRE_HANDLE(s);
+  if (!b_host) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    s->impl->copy_b(b_host);
+    return G2OHIP_OK;
+  });
+}
+const double* g2ohip_x_device(g2ohip_solver* s) { return (s && s->impl) ? s->impl->x_device() : nullptr; }
+const double* g2ohip_b_device(g2ohip_solver* s) { return (s && s->impl) ? s->impl->b_device() : nullptr; }
+
+int g2ohip_multiply_hessian(g2ohip_solver* s, double* dest_host, const double* src_host) {
+  REQUIRE_HANDLE(s);
+  if (!dest_host || !src_host) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    s->impl->multiply_hessian(dest_host, src_host);
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_sync(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->sync();
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_set_profiling(g2ohip_solver* s, int enabled) {
+  REQUIRE_HANDLE(s);
+  s->impl->profiling = enabled != 0;
+  s->impl->prof.enabled = enabled != 0;
+  return G2OHIP_OK;
+}
+
+int g2ohip_kernel_time(g2ohip_solver* s, int slot, double* total_seconds, long* launches, int reset) {
+  REQUIRE_HANDLE(s);
+  if (slot < 0 || slot >= KernelProf::kNumSlots || !total_seconds || !launches) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    s->impl->prof.collect();
+    *total_seconds = s->impl->prof.total[slot];
+    *launches = s->impl->prof.launches[slot];
+    if (reset) {
+      s->impl->prof.total[slot] = 0;
+      s->impl->prof.launches[slot] = 0;
+    }
+    return G2OHIP_OK;
+  });
+}
+const char* g2ohip_kernel_name(int slot) { return KernelProf::name(slot); }
+int g2ohip_kernel_slots(void) { return KernelProf::kNumSlots; }
+
+static void fill_chol_stats(const CholStats* cs, g2ohip_stats* out) {
+  if (!cs) return;
+  out->timeSymbolicDecomposition = cs->t_symbolic;
+  out->choleskyNNZ = cs->nnzL;
+  out->numFronts = cs->n_fronts;
+  out->numLevels = cs->n_levels;
+  out->maxFrontDim = cs->max_front_dim;
+}
+
+int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out) {
+  REQUIRE_HANDLE(s);
+  if (!out) return G2OHIP_ERR_ARG;
+  std::memset(out, 0, sizeof(*out));
+  BlockSolver& b = *s->impl;
+  out->timeQuadraticForm = b.times.quadratic;
+  out->timeSchurComplement = b.times.schur;
+  out->timeNumericDecomposition = b.times.numeric;
+  out->timeLinearSolution = b.times.linsolve;
+  out->timeLinearSolver = b.times.numeric + b.times.linsolve;
+  out->timeBackSubstitution = b.times.backsub;
+  out->hessianPoseDimension = (size_t)b.nP() * b.p();
+  out->hessianLandmarkDimension = (size_t)b.nL() * b.l();
+  out->hessianDimension = out->hessianPoseDimension + out->hessianLandmarkDimension;
+  fill_chol_stats(b.chol_stats(), out);
+  return G2OHIP_OK;
+}
+
+int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
+  REQUIRE_HANDLE(s);
+  if (!name) return G2OHIP_ERR_ARG;
+  if (!std::strcmp(name, "nd_leaf")) s->impl->chol_opt.nd_leaf = (int)value;
+  else if (!std::strcmp(name, "max_sn_scalars")) s->impl->chol_opt.max_sn_scalars = (int)value;
+  else if (!std::strcmp(name, "lds_front_bytes")) s->impl->chol_opt.lds_front_bytes = (size_t)value;
+  else {
+    set_error(std::string("unknown option ") + name);
+    return G2OHIP_ERR_ARG;
+  }
+  return G2OHIP_OK;
+}
+
+int g2ohip_get_nnzb(g2ohip_solver* s, int which, int* nnzb) {
+  REQUIRE_HANDLE(s);
+  if (!nnzb) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    *nnzb = s->impl->nnzb(which);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_get_pattern(g2ohip_solver* s, int which, int32_t* colptr, int32_t* rowidx) {
+  REQUIRE_HANDLE(s);
+  if (!colptr || !rowidx) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    s->impl->get_pattern(which, colptr, rowidx);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_copy_values(g2ohip_solver* s, int which, double* values_host) {
+  REQUIRE_HANDLE(s);
+  if (!values_host) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    s->impl->copy_values(which, values_host);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_device_array(g2ohip_solver* s, int which, double** ptr, size_t* count) {
+  REQUIRE_HANDLE(s);
+  if (!ptr || !count) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    s->impl->device_array(which, ptr, count);
+    return G2OHIP_OK;
+  });
+}
+
+// ---- narrow seam ---------------------------------------------------------------------
+int g2ohip_ls_create(g2ohip_linear_solver** out, int block_dim, int device) {
+  if (!out) return G2OHIP_ERR_ARG;
+  *out = nullptr;
+  return guarded([&] {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw HipFailure("no HIP device available: libg2ohip has no CPU fallback");
+    if (device < 0 || device >= count) throw ArgFailure("bad device ordinal");
+    if (!(block_dim == 3 || block_dim == 6 || block_dim == 7)) throw ArgFailure("block_dim must be 3, 6 or 7");
+    auto h = std::make_unique<g2ohip_linear_solver>();
+    h->bs = block_dim;
+    h->device = device;
+    G2OHIP_HIP_CHECK(hipSetDevice(device));
+    G2OHIP_HIP_CHECK(hipStreamCreate(&h->st));
+    *out = h.release();
+    return G2OHIP_OK;
+  });
+}
+void g2ohip_ls_destroy(g2ohip_linear_solver* ls) {
+  if (!ls) return;
+  if (ls->st) (void)hipStreamDestroy(ls->st);
+  delete ls;
+}
+int g2ohip_ls_init(g2ohip_linear_solver* ls) {
+  if (!ls) return G2OHIP_ERR_ARG;
+  ls->chol.reset();
+  ls->colptr.clear();
+  ls->rowidx.clear();
+  return G2OHIP_OK;
+}
+int g2ohip_ls_solve(g2ohip_linear_solver* ls, int n_blocks, const int32_t* colptr, const int32_t* rowidx, const double* values,
+                    double* x, const double* b) {
+  if (!ls || !colptr || !rowidx || !values || !x || !b || n_blocks <= 0) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    G2OHIP_HIP_CHECK(hipSetDevice(ls->device));
+    const int nnzb = colptr[n_blocks];
+    const int bs = ls->bs;
+    if (!ls->chol) {  // first call after init(): symbolic factorisation (linear_solver_csparse.h:110-112)
+      ls->chol = std::make_unique<SparseCholesky>(bs);
+      ls->chol->opt = ls->opt;
+      ls->colptr.assign(colptr, colptr + n_blocks + 1);
+      ls->rowidx.assign(rowidx, rowidx + nnzb);
+      ls->chol->analyze(n_blocks, colptr, rowidx, ls->st);
+    } else if ((int)ls->colptr.size() != n_blocks + 1 || ls->colptr.back() != nnzb) {
+      throw StateFailure("pattern changed without init() (linear_solver.h:86-105)");
+    }
+    const size_t n = (size_t)n_blocks * bs;
+    ls->dA.upload(values, (size_t)nnzb * bs * bs, ls->st);
+    ls->db.upload(b, n, ls->st);
+    ls->dx.alloc(n);
+    ls->tn.start(ls->st);
+    ls->chol->factor(ls->dA.p, ls->st);
+    ls->tn.stop(ls->st);
+    ls->tl.start(ls->st);
+    ls->chol->solve(ls->db.p, ls->dx.p, ls->st);
+    ls->tl.stop(ls->st);
+    bool bad = ls->chol->failed(ls->st);
+    ls->t_numeric = ls->tn.seconds();
+    ls->t_solve = ls->tl.seconds();
+    if (bad) return G2OHIP_NOT_PD;
+    ls->dx.download(x, n, ls->st);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ls_get_stats(g2ohip_linear_solver* ls, g2ohip_stats* out) {
+  if (!ls || !out) return G2OHIP_ERR_ARG;
+  std::memset(out, 0, sizeof(*out));
+  if (ls->chol) fill_chol_stats(&ls->chol->stats(), out);
+  out->timeNumericDecomposition = ls->t_numeric;
+  out->timeLinearSolution = ls->t_solve;
+  out->timeLinearSolver = ls->t_numeric + ls->t_solve;
+  return G2OHIP_OK;
+}
+int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double value) {
+  if (!ls || !name) return G2OHIP_ERR_ARG;
+  if (!std::strcmp(name, "nd_leaf")) ls->opt.nd_leaf = (int)value;
+  else if (!std::strcmp(name, "max_sn_scalars")) ls->opt.max_sn_scalars = (int)value;
+  else if (!std::strcmp(name, "lds_front_bytes")) ls->opt.lds_front_bytes = (size_t)value;
+  else return G2OHIP_ERR_ARG;
+  return G2OHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// Shared helpers for libg2ohip: error plumbing and device buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace g2ohip {
+
+std::string& last_error_ref();
+inline void set_error(const std::string& s) { last_error_ref() = s; }
+
+struct HipFailure : std::runtime_error {
+  explicit HipFailure(const std::string& s) : std::runtime_error(s) {}
+};
+struct ArgFailure : std::runtime_error {
+  explicit ArgFailure(const std::string& s) : std::runtime_error(s) {}
+};
+struct StateFailure : std::runtime_error {
+  explicit StateFailure(const std::string& s) : std::runtime_error(s) {}
+};
+
+#define G2OHIP_HIP_CHECK(expr)                                                                       \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      throw ::g2ohip::HipFailure(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                                 ":" + std::to_string(__LINE__) + ")");                              \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count <= n && p) return;
+    release();
+    if (count == 0) count = 1;
+    G2OHIP_HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+  }
+  void upload(const T* h, size_t count, hipStream_t st) {
+    alloc(count);
+    if (count) G2OHIP_HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st));
+  }
+  void upload(const std::vector<T>& v, hipStream_t st) {
+    upload(v.data(), v.size(), st);
+    // pageable host memory: the copy is staged before return, v may die afterwards
+  }
+  void download(T* h, size_t count, hipStream_t st) const {
+    if (count) G2OHIP_HIP_CHECK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, st));
+    G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  void zero(hipStream_t st) {
+    if (p && n) G2OHIP_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), st));
+  }
+};
+
+struct EventTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool armed = false;
+  void ensure() {
+    if (!a) {
+      G2OHIP_HIP_CHECK(hipEventCreate(&a));
+      G2OHIP_HIP_CHECK(hipEventCreate(&b));
+    }
+  }
+  void start(hipStream_t st) {
+    ensure();
+    G2OHIP_HIP_CHECK(hipEventRecord(a, st));
+  }
+  void stop(hipStream_t st) {
+    G2OHIP_HIP_CHECK(hipEventRecord(b, st));
+    armed = true;
+  }
+  double seconds() {
+    if (!armed) return 0.0;
+    float ms = 0;
+    G2OHIP_HIP_CHECK(hipEventSynchronize(b));
+    G2OHIP_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    return 1e-3 * ms;
+  }
+  ~EventTimer() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
+
+
+// Per-kernel timing with HIP events on the launch stream (enabled by g2ohip_set_profiling).
+struct KernelProf {
+  enum Slot { kAsmPose = 0, kAsmLandmark, kAsmOffPP, kAsmOffPL, kLmInverse, kSchurBlocks, kSchurRhs, kCholFactor, kCholSolve,
+              kBackSub, kLambda, kNumSlots };
+  static const char* name(int s) {
+    static const char* n[] = {"assemble_vertex(pose)", "assemble_vertex(landmark)", "assemble_offdiag(Hpp)", "assemble_offdiag(Hpl)",
+                              "landmark_inverse", "schur_blocks", "schur_rhs", "chol_factor(all levels)", "chol_solve(all levels)",
+                              "back_substitute", "set_lambda/restore"};
+    return (s >= 0 && s < kNumSlots) ? n[s] : "?";
+  }
+  bool enabled = false;
+  struct Pair { hipEvent_t a, b; };
+  std::vector<Pair> pending[kNumSlots];
+  std::vector<hipEvent_t> pool;
+  double total[kNumSlots] = {0};
+  long launches[kNumSlots] = {0};
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; G2OHIP_HIP_CHECK(hipEventCreate(&e)); return e;
+  }
+  void begin(int slot, hipStream_t st) {
+    if (!enabled) return;
+    Pair p{get(), get()};
+    G2OHIP_HIP_CHECK(hipEventRecord(p.a, st));
+    pending[slot].push_back(p);
+  }
+  void end(int slot, hipStream_t st) {
+    if (!enabled) return;
+    G2OHIP_HIP_CHECK(hipEventRecord(pending[slot].back().b, st));
+  }
+  // synchronises the recorded events and folds them into total/launches
+  void collect() {
+    for (int s = 0; s < kNumSlots; ++s) {
+      for (Pair& p : pending[s]) {
+        float ms = 0;
+        G2OHIP_HIP_CHECK(hipEventSynchronize(p.b));
+        G2OHIP_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+        total[s] += 1e-3 * ms;
+        launches[s]++;
+        pool.push_back(p.a);
+        pool.push_back(p.b);
+      }
+      pending[s].clear();
+    }
+  }
+  void reset() {
+    collect();
+    for (int s = 0; s < kNumSlots; ++s) { total[s] = 0; launches[s] = 0; }
+  }
+  ~KernelProf() {
+    for (int s = 0; s < kNumSlots; ++s) for (Pair& p : pending[s]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+  }
+};
+
+}  // namespace g2ohip

@@ -1,0 +1,114 @@
+// Multifrontal sparse *block* Cholesky for symmetric positive definite block matrices with
+// uniform bs x bs blocks (bs = pose dimension), resident on one MI355X.
+//
+// Replaces, for the reduced pose system, the reference's linear solver back end
+//   LinearSolverCSparse::solve / computeSymbolicDecomposition
+//       /root/reference/g2o/solvers/csparse/linear_solver_csparse.h:106-142,246-308
+//   csparse_extension::cs_chol_workspace / cs_cholsolsymb
+//       /root/reference/g2o/solvers/csparse/csparse_helper.cpp:56-143
+// (twin: LinearSolverCholmod, g2o/solvers/cholmod/linear_solver_cholmod.h:79-154).
+//
+// Design (MI355X-first, not a translation of the up-looking CSparse loop, which is strictly
+// sequential over rows):
+//   * ordering on the BLOCK graph, like the reference (linear_solver_csparse.h:252-281), but
+//     nested dissection instead of AMD so that the elimination tree is wide and shallow --
+//     on a GPU tree height is the critical path, fill is secondary;
+//   * block elimination tree -> supernodes -> dense frontal matrices; fronts of one tree
+//     level are independent and are factorised by one kernel launch (one workgroup per
+//     front, the front held in LDS when it fits, in an HBM scratch slab otherwise);
+//   * update (Schur) matrices are passed child -> parent through HBM (extend-add), the L
+//     panels stay resident for the two triangular sweeps;
+//   * "not positive definite" (pivot <= 0, csparse_helper.cpp:136) is a device flag read back
+//     once per solve.
+#pragma once
+#include "common.h"
+
+namespace g2ohip {
+
+struct CholOptions {
+  int nd_leaf = 32;          // nested-dissection leaf size (blocks)
+  int max_sn_scalars = 48;   // supernode (pivot panel) width cap, scalars
+  size_t lds_front_bytes = 64 * 1024;  // fronts up to this size are factorised in LDS
+};
+
+struct CholStats {
+  size_t nnzL = 0;        // scalar nnz(L) incl. diagonal
+  size_t n_fronts = 0, n_levels = 0, max_front_dim = 0;
+  double flops = 0;       // factorisation flops (dense-front count)
+  double t_symbolic = 0;  // seconds, host
+  size_t bytes_L = 0, bytes_U = 0;
+};
+
+// Host-side symbolic result (kept for tests / introspection).
+struct CholSymbolic {
+  int nb = 0, bs = 0;
+  std::vector<int> perm, iperm;            // perm[new] = old block
+  std::vector<int> parent;                 // block etree (permuted indices)
+  std::vector<int> sn_start;               // supernode/front f covers block cols [sn_start[f], sn_start[f+1])
+  std::vector<int> f_ns, f_nb, f_parent, f_level;
+  std::vector<int> rows_off, rows;         // boundary rows (permuted block idx) per front
+  std::vector<int> rel_off, rel;           // per front: local block index of each boundary row in the parent front
+  std::vector<long long> L_off, U_off, w_off;
+  std::vector<int> asm_off;                // per front, into asm_q/asm_pos
+  std::vector<int> asm_q, asm_pos;         // source block id; packed lr | lc<<15 | tr<<30
+  std::vector<int> child_off, children;
+  std::vector<int> level_ptr, level_fronts;  // fronts grouped by level (leaves first)
+  long long L_total = 0, U_total = 0, w_total = 0;
+};
+
+struct CholPlanDev {
+  const int *f_ns, *f_nb, *f_c0, *rows_off, *rows, *rel_off, *rel;
+  const long long *L_off, *U_off, *w_off;
+  const int *asm_off, *asm_q, *asm_pos, *child_off, *children;
+  double *L, *U, *w;
+  int* status;
+};
+
+class SparseCholesky {
+ public:
+  explicit SparseCholesky(int block_size) : bs_(block_size) {}
+  CholOptions opt;
+
+  // Host symbolic analysis of an upper-triangular block-CCS pattern (rows <= col, sorted).
+  void analyze(int nb, const int* colptr, const int* rowidx, hipStream_t st);
+  bool analyzed() const { return analyzed_; }
+  void reset() { analyzed_ = false; }
+
+  // Numeric factorisation from device block values [nnzb][bs*bs] (column-major blocks, same
+  // block order as the analysed pattern).  Asynchronous on st.
+  void factor(const double* dA, hipStream_t st);
+  // x = A \ b with device vectors of nb*bs (original block order).  Asynchronous.
+  void solve(const double* d_b, double* d_x, hipStream_t st);
+  // Synchronises st and returns true when the last factorisation met a pivot <= 0.
+  bool failed(hipStream_t st);
+
+  const CholStats& stats() const { return stats_; }
+  const CholSymbolic& symbolic() const { return sym_; }
+  int block_size() const { return bs_; }
+
+ private:
+  int bs_;
+  bool analyzed_ = false;
+  CholSymbolic sym_;
+  CholStats stats_;
+  // device plan
+  DevBuf<int> d_f_ns, d_f_nb, d_f_c0, d_rows_off, d_rows, d_rel_off, d_rel, d_asm_off, d_asm_q, d_asm_pos,
+      d_child_off, d_children, d_level_fronts, d_perm, d_status;
+  DevBuf<long long> d_L_off, d_U_off, d_w_off, d_scratch_off;
+  DevBuf<double> d_L, d_U, d_w, d_y, d_xp, d_scratch;
+  // per level launch info
+  struct LevelLaunch {
+    int lds_begin = 0, lds_count = 0, lds_max_m = 0;     // index range in d_level_fronts
+    int glb_begin = 0, glb_count = 0, glb_max_m = 0;
+    int max_panel = 0;                                   // max m*npiv (doubles) for solve kernels
+    int max_m = 0;
+  };
+  std::vector<LevelLaunch> launches_;
+  CholPlanDev plan_{};
+};
+
+// Nested-dissection ordering of a symmetric block graph (CSR without self loops).
+void nested_dissection(int n, const std::vector<int>& xadj, const std::vector<int>& adj, int leaf,
+                       std::vector<int>& perm);
+
+}  // namespace g2ohip

@@ -1,0 +1,99 @@
+"""Generates the committed golden fixtures under tests/golden/ (run HERE, where
+/root/reference and oracle/_ref exist):
+
+    python tests/golden/make_golden.py
+
+Fixtures are data only -- parsed graph inputs and expected outputs:
+  * manhattan3500.npz : the parse result of data/2d/manhattan3500/manhattanOlson3500.g2o
+    (vertex estimates, edge endpoints, measurements, information upper triangles) and the
+    reference CSparse path's answers for the first Gauss-Newton linear system
+    (x, lnz, chi2), with and without LM damping, plus a 5-iteration GN chi2 trajectory.
+    The expected x comes from the REFERENCE's own compiled code
+    (cs_amd block ordering + csparse_extension::cs_cholsolsymb, oracle/_ref).
+  * ba_small.npz : expected outputs for the deterministic synthetic 20-pose / 200-point BA
+    problem (inputs are regenerated from the seed): x from the reference CSparse path on
+    the Schur-reduced system and from a dense solve of the full system.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from openslam_g2o_amd import g2o_io, synthetic as S  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def manhattan():
+    g = g2o_io.read_g2o("/root/reference/data/2d/manhattan3500/manhattanOlson3500.g2o")
+    nv = len(g["ids"])
+    h, nP = g2o_io.hessian_index(nv, [0])       # the repo fixes the lowest id
+    om = g["info"].transpose(0, 2, 1).reshape(-1, 9)
+    est = g["estimates"].copy()
+    out = dict(estimates=g["estimates"], vi=g["vi"], vj=g["vj"], meas=g["meas"],
+               info_upper=np.stack([g["info"][:, i, j] for i in range(3) for j in range(i, 3)], axis=1))
+    chi_traj = []
+    for it in range(5):
+        J0, J1, err = O.se2_edges(est, g["vi"], g["vj"], g["meas"])
+        s = O.OracleSolver(3, 2, nP, 0, schur=False)
+        k = s.add_edge_set(3, h[g["vi"]], h[g["vj"]])
+        s.set_dims(k, 3, 3)
+        s.build_structure()
+        s.set_edge_data(k, J0, J1, om, err)
+        s.build_system()
+        chi_traj.append(s.chi2())
+        cp, row = s.pattern("pp")
+        val = s.values("Hpp")
+        ok, x, lnz, P = O.ref_solve_blocks(nP, 3, cp, row, val, s.b())
+        assert ok
+        if it == 0:
+            out.update(x_gn0=x, lnz_block_amd=lnz, block_perm=P, b0=s.b(), nnzb=len(row))
+            lam = 1e-5 * s.max_diagonal()           # computeLambdaInit, tau = 1e-5
+            s.set_lambda(lam, True)
+            ok2, x2, _, _ = O.ref_solve_blocks(nP, 3, cp, row, s.values("Hpp"), s.b())
+            s.restore_diagonal()
+            assert ok2
+            out.update(lambda0=lam, x_lm0=x2)
+        est = O.se2_oplus(est, h, x)
+    out["chi2_gn"] = np.asarray(chi_traj)
+    np.savez_compressed(os.path.join(OUT, "manhattan3500.npz"), **out)
+    print("manhattan: nP", nP, "nnzb", out["nnzb"], "lnz", out["lnz_block_amd"], "chi2", chi_traj)
+
+
+def ba_small():
+    pr = S.make_ba_problem(20, 200)
+    Jp, Jc, e = S.ba_linearize(pr)
+    om = S.ba_omega(pr)
+    lam = 1.0
+    s = O.OracleSolver(6, 3, pr["nP"], pr["nL"], True)
+    k = s.add_edge_set(2, pr["v0"], pr["v1"])
+    s.set_dims(k, 3, 6)
+    s.build_structure()
+    s.set_edge_data(k, Jp, Jc, om, e)
+    s.build_system()
+    chi2 = s.chi2()
+    b = s.b()
+    s.set_lambda(lam, True)
+    assert s.solve()          # fills Hschur / bschur
+    cp, row = s.pattern("hs")
+    ok, xp, lnz, _ = O.ref_solve_blocks(pr["nP"], 6, cp, row, s.values("Hschur"), s.bschur())
+    assert ok
+    H = s.dense_full()
+    x_dense = np.linalg.solve(H, b)
+    x_schur = s.x()
+    assert np.abs(x_schur[:6 * pr["nP"]] - xp).max() < 1e-9 * np.abs(xp).max()
+    assert np.abs(x_schur - x_dense).max() < 1e-9 * np.abs(x_dense).max()
+    np.savez_compressed(os.path.join(OUT, "ba_small.npz"), lam=lam, chi2=chi2, b=b, x_dense=x_dense, xp_ref_csparse=xp,
+                        Hschur=s.values("Hschur"), bschur=s.bschur(), hs_colptr=cp, hs_row=row, lnz=lnz,
+                        meas_checksum=float(np.sum(pr["meas"])), pts_checksum=float(np.sum(pr["pts"])))
+    print("ba_small: chi2", chi2, "lnz", lnz)
+
+
+if __name__ == "__main__":
+    O.build()
+    assert O.ref() is not None, "oracle/_ref missing: run `make -C oracle` where /root/reference exists"
+    manhattan()
+    ba_small()

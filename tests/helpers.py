@@ -1,0 +1,57 @@
+"""Shared builders for the parity tests: the same seeded inputs are fed to the HIP path
+(through the C ABI) and to the CPU oracle."""
+import os
+
+import numpy as np
+
+from openslam_g2o_amd import g2o_io, synthetic as S
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def ba_case(P, L, seed=42, outlier_frac=0.0):
+    pr = S.make_ba_problem(P, L, seed=seed, outlier_frac=outlier_frac)
+    Jp, Jc, err = S.ba_linearize(pr)
+    pr.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(pr))
+    return pr
+
+
+def oracle_ba(pr, huber=0.0, schur=True):
+    o = O.OracleSolver(6, 3, pr["nP"], pr["nL"], schur)
+    k = o.add_edge_set(2, pr["v0"], pr["v1"])
+    o.set_dims(k, 3, 6)
+    o.build_structure()
+    o.set_edge_data(k, pr["Jp"], pr["Jc"], pr["omega"], pr["err"], huber)
+    return o
+
+
+def hip_ba(pr, huber=0.0, schur=True, device=0):
+    from openslam_g2o_amd import capi
+    s = capi.HipBlockSolver(6, 3, device)
+    k = s.addEdgeSet(2, pr["v0"], pr["v1"])
+    s.buildStructure(pr["nP"], pr["nL"], schur)
+    s.setEdgeData(k, pr["Jp"], pr["Jc"], pr["omega"], pr["err"])
+    if huber > 0:
+        s.setRobustKernel(k, capi.KERNEL_HUBER, huber)
+    return s
+
+
+def manhattan_golden():
+    g = dict(np.load(os.path.join(GOLD, "manhattan3500.npz")))
+    nv = len(g["estimates"])
+    h, nP = g2o_io.hessian_index(nv, [0])
+    info = np.zeros((len(g["vi"]), 3, 3))
+    k = 0
+    for i in range(3):
+        for j in range(i, 3):
+            info[:, i, j] = info[:, j, i] = g["info_upper"][:, k]
+            k += 1
+    g["omega"] = info.transpose(0, 2, 1).reshape(-1, 9).copy()
+    g["hidx"] = h
+    g["nP"] = nP
+    return g
+
+
+def relerr(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))

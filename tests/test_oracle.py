@@ -1,0 +1,114 @@
+"""CPU-only: pins the oracle (the CPU restatement of the reference path) against
+ (a) the committed golden vectors produced by the REFERENCE's compiled CSparse path,
+ (b) that reference path itself when oracle/_ref is present (bit-exact under equal ordering),
+ (c) dense numpy solves and the Schur == full-system identity."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import ba_case, manhattan_golden, oracle_ba, relerr, GOLD
+import os
+
+
+def _manhattan_system(g):
+    J0, J1, err = O.se2_edges(g["estimates"], g["vi"], g["vj"], g["meas"])
+    s = O.OracleSolver(3, 2, g["nP"], 0, schur=False)
+    k = s.add_edge_set(3, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+    s.set_dims(k, 3, 3)
+    s.build_structure()
+    s.set_edge_data(k, J0, J1, g["omega"], err)
+    s.build_system()
+    return s
+
+
+def test_manhattan_golden_reference_csparse():
+    g = manhattan_golden()
+    s = _manhattan_system(g)
+    assert s.pattern("pp")[1].size == int(g["nnzb"]) == 8949
+    assert abs(s.chi2() - g["chi2_gn"][0]) <= 1e-12 * g["chi2_gn"][0]
+    np.testing.assert_allclose(s.b(), g["b0"], rtol=0, atol=1e-9 * np.abs(g["b0"]).max())
+    # own ordering: same solution as the reference's to roundoff
+    assert s.solve()
+    assert relerr(s.x(), g["x_gn0"]) < 1e-9
+    # the reference's block AMD ordering: bit-exact (same loop structure as cs_chol_workspace)
+    s.set_ordering(2, g["block_perm"])
+    assert s.solve()
+    assert np.array_equal(s.x(), g["x_gn0"])
+    assert s.lnz() == float(g["lnz_block_amd"])
+    # LM-damped system
+    s.set_lambda(float(g["lambda0"]), True)
+    assert s.solve()
+    assert np.array_equal(s.x(), g["x_lm0"])
+    s.restore_diagonal()
+    assert s.solve()
+    assert np.array_equal(s.x(), g["x_gn0"])                             # restoreDiagonal is exact
+
+
+def test_manhattan_gn_trajectory():
+    g = manhattan_golden()
+    est = g["estimates"].copy()
+    for it in range(5):
+        J0, J1, err = O.se2_edges(est, g["vi"], g["vj"], g["meas"])
+        s = O.OracleSolver(3, 2, g["nP"], 0, schur=False)
+        k = s.add_edge_set(3, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+        s.set_dims(k, 3, 3)
+        s.build_structure()
+        s.set_edge_data(k, J0, J1, g["omega"], err)
+        s.build_system()
+        assert abs(s.chi2() - g["chi2_gn"][it]) <= 1e-7 * g["chi2_gn"][it]
+        assert s.solve()
+        est = O.se2_oplus(est, g["hidx"], s.x())
+    assert abs(g["chi2_gn"][-1] - 146.0766) < 1e-3      # the well-known manhattan3500 optimum
+
+
+@pytest.mark.skipif(O.ref() is None, reason="oracle/_ref (reference CSparse build) not present")
+def test_bitwise_against_reference_build():
+    g = manhattan_golden()
+    s = _manhattan_system(g)
+    cp, row = s.pattern("pp")
+    ok, x, lnz, P = O.ref_solve_blocks(g["nP"], 3, cp, row, s.values("Hpp"), s.b())
+    assert ok and np.array_equal(P, g["block_perm"]) and np.array_equal(x, g["x_gn0"])
+    s.set_ordering(2, P)
+    assert s.solve() and np.array_equal(s.x(), x) and s.lnz() == lnz
+
+
+def test_ba_small_golden_and_schur_identity():
+    gold = dict(np.load(os.path.join(GOLD, "ba_small.npz")))
+    pr = ba_case(20, 200)
+    assert abs(float(np.sum(pr["meas"])) - gold["meas_checksum"]) < 1e-6      # generator determinism
+    o = oracle_ba(pr)
+    o.build_system()
+    assert abs(o.chi2() - gold["chi2"]) <= 1e-12 * gold["chi2"]
+    np.testing.assert_allclose(o.b(), gold["b"], rtol=0, atol=1e-12 * np.abs(gold["b"]).max())
+    o.set_lambda(float(gold["lam"]), True)
+    assert o.solve()
+    x = o.x()
+    assert relerr(x, gold["x_dense"]) < 1e-9                                   # Schur path == dense full solve
+    assert relerr(x[:6 * pr["nP"]], gold["xp_ref_csparse"]) < 1e-9            # == reference CSparse on Hschur
+    assert relerr(o.values("Hschur"), gold["Hschur"]) < 1e-13
+    # Schur path == full-system (no Schur) sparse solve
+    o2 = oracle_ba(pr, schur=False)
+    # without Schur the landmark blocks cannot be expressed in BlockSolver<6,3>'s pose matrix;
+    # use the dense full system instead
+    H = o.dense_full()
+    assert relerr(np.linalg.solve(H, o.b()), x) < 1e-9
+    # residual through multiply_full
+    r = o.multiply_full(x) - o.b()
+    assert np.abs(r).max() <= 1e-10 * np.abs(o.b()).max()
+    del o2
+
+
+def test_huber_weights_and_not_pd():
+    pr = ba_case(12, 80, outlier_frac=0.2)
+    o = oracle_ba(pr, huber=1.0)
+    o.build_system()
+    # robust chi2 <= plain chi2, and equals the closed form
+    e2 = np.sum(pr["err"] ** 2, axis=1)
+    rho = np.where(e2 <= 1.0, e2, 2 * np.sqrt(e2) - 1.0)
+    assert abs(o.chi2() - rho.sum()) <= 1e-12 * rho.sum()
+    o.set_lambda(1.0, True)
+    assert o.solve()
+    o.restore_diagonal()
+    # strongly negative damping makes the system indefinite -> solve() == false (csparse_helper.cpp:136)
+    o.set_lambda(-10.0 * o.max_diagonal(), True)
+    assert not o.solve()
