@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- linear-solve iteration benchmark of the MI355X-native g2o block solver.
+
+One "step" = one pass of the hot path over the synthetic BA graph:
+  buildSystem (K1-K3)  ->  setLambda(backup) (K4)  ->  solve (K5-K13: Schur complement,
+  multifrontal block Cholesky of the reduced pose system, landmark back-substitution)
+  ->  restoreDiagonal
+i.e. the linear algebra of one Levenberg-Marquardt trial
+(/root/reference/g2o/core/optimization_algorithm_levenberg.cpp:95-142), with the per-edge
+Jacobians / information / errors already resident in HBM when the timed region starts.
+
+Workload at every N: BASELINE.json's metric configuration -- 100 000 poses / 1 000 000
+landmarks / 5 000 000 observations (configs[3]; it fits one GPU).  For N > 1 the landmarks
+(and their edges) are sharded across ranks and the Schur contributions are summed with an
+RCCL all-reduce (strong scaling, see openslam_g2o_amd/distributed.py and DESIGN.md).
+
+Prints ONE JSON line on rank 0 (contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
+
+
+def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2):
+    """Compulsory traffic per kernel / stage (8 B per double, 4 B per index), SURVEY.md 8d."""
+    kb = {}
+    kb["assemble_vertex(pose)"] = E * 8 * (d * p + d * d + d) + P * 8 * (p * p + p)
+    kb["assemble_vertex(landmark)"] = E * 8 * (d * l + d * d + d) + L * 8 * (l * l + l)
+    kb["assemble_offdiag(Hpl)"] = E * 8 * (d * p + d * l + d * d) + E * 8 * p * l
+    kb["landmark_inverse"] = L * 8 * (2 * l * l + 2 * l)
+    kb["schur_blocks"] = E * 8 * p * l + L * 8 * l * l + pp_nnzb * 8 * p * p + S * 8 * p * p
+    kb["schur_rhs"] = E * 8 * p * l + L * 8 * l + 2 * P * 8 * p
+    kb["back_substitute"] = E * 8 * p * l + L * 8 * (l * l + 2 * l) + P * 8 * p
+    n = p * P
+    nnz_up = S * p * p  # upper blocks of Hschur (diagonal blocks counted full)
+    kb["chol_factor(all levels)"] = 8 * nnz_up + 8 * nnzL
+    kb["chol_solve(all levels)"] = 16 * nnzL + 24 * n
+    stage = {
+        "B_asm": E * (8 * (d * p + d * l + d * d + d) + 8) + E * 8 * p * l + P * 8 * (p * p + p) + L * 8 * (l * l + l),
+        "B_schur": (E * 8 * p * l + L * 8 * (l * l + l) + P * 8 * (p * p + p)) + (L * 8 * l * l + S * 8 * p * p + P * 8 * p),
+        "B_chol": 8 * nnz_up + 8 * nnzL + 16 * nnzL + 24 * n,
+        "B_back": E * 8 * p * l + L * 8 * (l * l + 2 * l) + P * 8 * p + L * 8 * l,
+    }
+    return kb, stage
+
+
+def cpu_baseline(prob, lam, want_x=True):
+    """The oracle (CPU restatement of the reference path, 1 thread = the reference's default
+    build) timed on this host for ONE full iteration of the same workload."""
+    from oracle import oracle as O
+    from openslam_g2o_amd import synthetic as S
+    o = O.OracleSolver(6, 3, prob["nP"], prob["nL"], True)
+    k = o.add_edge_set(2, prob["v0"], prob["v1"])
+    o.set_dims(k, 3, 6)
+    t0 = time.perf_counter()
+    o.build_structure()
+    t_struct = time.perf_counter() - t0
+    o.set_edge_data(k, prob["Jp"], prob["Jc"], prob["omega"], prob["err"])
+    t0 = time.perf_counter()
+    o.build_system()
+    t_asm = time.perf_counter() - t0
+    o.set_lambda(lam, True)
+    t0 = time.perf_counter()
+    ok = o.solve()                      # includes the one-time ordering + symbolic step
+    t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ok = o.solve() and ok               # steady state: Schur + numeric Cholesky + back-substitution
+    t_solve = time.perf_counter() - t0
+    o.restore_diagonal()
+    tt = o.times()
+    out = dict(ok=bool(ok), t_structure=t_struct, t_assembly=t_asm, t_solve=t_solve, t_solve_first=t_first,
+               t_schur=tt["schur"], t_linear=tt["linear"], t_numeric=tt["numeric"], lnz=o.lnz())
+    x = o.x() if want_x else None
+    return out, x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--poses", type=int, default=100000)
+    ap.add_argument("--landmarks", type=int, default=1000000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nd-leaf", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    from openslam_g2o_amd import capi, synthetic as S
+    from openslam_g2o_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    P, L = args.poses, args.landmarks
+    prob = S.make_ba_problem(P, L)                      # identical on every rank (counter-based RNG)
+    Jp, Jc, err = S.ba_linearize(prob)
+    prob.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(prob))
+    lam = 1e-5 * 1.0e6                                  # tau * max diag(H) order of magnitude; fixed for reproducibility
+
+    solver = D.ShardedBlockSolver(6, 3, rank=rank, world=world, device=local_rank)
+    shard = solver.setup_ba(prob, torch_device=dev, nd_leaf=args.nd_leaf)
+    solver.local.setProfiling(True)
+
+    def step():
+        solver.buildSystem()
+        solver.setLambda(lam, True)
+        ok = solver.solve()
+        solver.restoreDiagonal()
+        return ok
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ok = True
+    for _ in range(args.warmup):
+        ok = step() and ok
+    solver.local.kernelTimes(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ok = step() and ok
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = 1e3 * dt / args.steps
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ktimes = solver.local.kernelTimes(reset=True)
+    st = solver.local.stats()
+    S_blocks = solver.local.nnzb(capi.HSCHUR)
+    pp_nnzb = solver.local.nnzb(capi.HPP)
+    E_loc, L_loc = shard["E_local"], shard["L_local"]
+    kb, stage_b = algorithmic_bytes(E_loc, prob["nP"], L_loc, S_blocks, pp_nnzb, st["choleskyNNZ"])
+    per_kernel = {}
+    for name, (tot, n) in ktimes.items():
+        avg = tot / n
+        per_kernel[name] = dict(avg_ms=1e3 * avg, launches_per_step=n / args.steps,
+                                algorithmic_GB=kb.get(name, 0) / 1e9,
+                                achieved_GBs=(kb.get(name, 0) / 1e9 / avg) if avg > 0 else 0.0)
+    dom = max(per_kernel.items(), key=lambda kv: kv[1]["avg_ms"] * kv[1]["launches_per_step"])
+    dname, dk = dom
+    roofline = dict(kernel=dname, bound="hbm", achieved=dk["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=dk["achieved_GBs"] / HBM_PEAK_GBS, traffic=None,
+                    algorithmic_bytes_per_launch=kb.get(dname, 0), avg_launch_ms=dk["avg_ms"])
+
+    x_gpu = solver.local.x()
+    out = {
+        "metric": "linear-solve ms/iter (buildSystem + setLambda + solve + restoreDiagonal), 100k-pose BA",
+        "value": ms, "unit": "ms/iter", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "iters_per_s": 1e3 / ms, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "synthetic BA (BASELINE.json configs[3]): %d poses / %d landmarks / %d observations, "
+                               "BlockSolver_6_3 semantics, Schur + multifrontal block Cholesky, lambda=%g" % (P, L, prob["E"], lam),
+                   "poses": P, "landmarks": L, "edges": prob["E"], "parallelism": solver.parallelism()},
+        "solve_ok": bool(ok),
+        "roofline": roofline,
+        "kernels": per_kernel,
+        "stage_algorithmic_GB": {k: v / 1e9 for k, v in stage_b.items()},
+        "solver_stats": {k: st[k] for k in ("choleskyNNZ", "numFronts", "numLevels", "maxFrontDim", "timeSymbolicDecomposition")},
+    }
+    # size-independent correctness property at full size: residual of the damped system
+    solver.setLambda(lam, True)
+    if world == 1:
+        r = solver.local.multiplyHessian(x_gpu) - solver.local.b()
+        out["residual_rel"] = float(np.abs(r).max() / np.abs(solver.local.b()).max())
+    solver.restoreDiagonal()
+
+    if world == 1 and not args.no_cpu_baseline:
+        cb, x_cpu = cpu_baseline(prob, lam)
+        cpu_ms = 1e3 * (cb["t_assembly"] + cb["t_solve"])
+        out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms/iter", "cores": 1, "kind": "port",
+                               "sample": "1 full iteration of the same %d-pose workload (assembly %.0f ms + solve %.0f ms; "
+                                         "one-time structure %.1f s and ordering/symbolic excluded)" % (
+                                             P, 1e3 * cb["t_assembly"], 1e3 * cb["t_solve"], cb["t_structure"]),
+                               "breakdown_ms": {"assembly": 1e3 * cb["t_assembly"], "schur": 1e3 * cb["t_schur"],
+                                                "linear_solver": 1e3 * cb["t_linear"], "numeric_cholesky": 1e3 * cb["t_numeric"]},
+                               "choleskyNNZ": cb["lnz"]}
+        out["speedup_vs_cpu"] = cpu_ms / ms
+        nx = np.abs(x_cpu).max()
+        out["dx_rel_err"] = float(np.abs(x_gpu - x_cpu).max() / nx)
+        # chi2 after applying each update (host-side error evaluation of the updated state)
+        e_g = S.ba_linearize(S.ba_oplus(prob, x_gpu), jac=False)
+        e_c = S.ba_linearize(S.ba_oplus(prob, x_cpu), jac=False)
+        chi_g, chi_c = float(np.sum(e_g * e_g)), float(np.sum(e_c * e_c))
+        out["chi2_before"] = float(np.sum(prob["err"] ** 2))
+        out["chi2_after_gpu"], out["chi2_after_cpu"] = chi_g, chi_c
+        out["chi2_rel_err"] = abs(chi_g - chi_c) / chi_c
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

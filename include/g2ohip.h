@@ -157,6 +157,16 @@ int g2ohip_copy_values(g2ohip_solver* s, int which, double* values_host);
  * which = G2OHIP_HSCHUR (values), or 100 = bschur. */
 int g2ohip_device_array(g2ohip_solver* s, int which, double** ptr, size_t* count);
 
+/* Multi-GPU sharding support (openslam_g2o_amd/distributed.py).  Each rank holds a landmark
+ * shard; to give every rank the SAME Hschur block layout (so the partial Schur complements
+ * can be summed element-wise by one RCCL all-reduce) the union pattern is declared up front:
+ * extra structural blocks (row <= col, pose block indices) of the reduced system.  Must
+ * precede g2ohip_build_structure. */
+int g2ohip_add_schur_pattern(g2ohip_solver* s, int n_blocks, const int32_t* rows, const int32_t* cols);
+/* setLambda with separate damping of the pose and landmark diagonals: every rank damps its own
+ * landmarks, only one rank adds lambda to the (summed) pose diagonal. */
+int g2ohip_set_lambda_split(g2ohip_solver* s, double lambda_pose, double lambda_landmark, int backup);
+
 /* Split solve for the multi-GPU path: g2ohip_solve == schur + reduced + back_substitute. */
 int g2ohip_solve_schur(g2ohip_solver* s);            /* K5-K8: Hschur, bschur, Dinv          */
 int g2ohip_solve_reduced(g2ohip_solver* s);          /* K9-K12: x_p = Hschur \ bschur        */

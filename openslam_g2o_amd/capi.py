@@ -46,7 +46,8 @@ EXPORTS = [
     "g2ohip_set_option", "g2ohip_get_nnzb", "g2ohip_get_pattern", "g2ohip_copy_values", "g2ohip_device_array",
     "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute", "g2ohip_ls_create",
     "g2ohip_ls_destroy", "g2ohip_ls_init", "g2ohip_ls_solve", "g2ohip_ls_get_stats", "g2ohip_ls_set_option",
-    "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time",
+    "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time", "g2ohip_add_schur_pattern",
+    "g2ohip_set_lambda_split",
 ]
 
 _lib = None
@@ -101,6 +102,8 @@ def load():
     L.g2ohip_get_pattern.argtypes = [vp, C.c_int, c_int_p, c_int_p]
     L.g2ohip_copy_values.argtypes = [vp, C.c_int, c_dbl_p]
     L.g2ohip_device_array.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.g2ohip_add_schur_pattern.argtypes = [vp, C.c_int, c_int_p, c_int_p]
+    L.g2ohip_set_lambda_split.argtypes = [vp, C.c_double, C.c_double, C.c_int]
     L.g2ohip_kernel_name.argtypes = [C.c_int]
     L.g2ohip_kernel_name.restype = C.c_char_p
     L.g2ohip_kernel_time.argtypes = [vp, C.c_int, c_dbl_p, C.POINTER(C.c_long), C.c_int]
@@ -225,6 +228,14 @@ class HipBlockSolver:
     def setLambda(self, lam, backup=False):
         _check(self.L.g2ohip_set_lambda(self.h, lam, int(backup)), "setLambda")
         return True
+
+    def setLambdaSplit(self, lam_pose, lam_landmark, backup=False):
+        _check(self.L.g2ohip_set_lambda_split(self.h, lam_pose, lam_landmark, int(backup)), "setLambdaSplit")
+        return True
+
+    def addSchurPattern(self, rows, cols):
+        rows, cols = _i32(rows), _i32(cols)
+        _check(self.L.g2ohip_add_schur_pattern(self.h, len(rows), _ip(rows), _ip(cols)), "addSchurPattern")
 
     def restoreDiagonal(self):
         _check(self.L.g2ohip_restore_diagonal(self.h), "restoreDiagonal")

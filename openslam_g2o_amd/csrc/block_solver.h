@@ -49,12 +49,14 @@ class BlockSolver {
 
   void init();
   int add_edge_set(int d, int n, const int* v0, const int* v1);
+  void add_schur_pattern(int n, const int* rows, const int* cols);
   void build_structure(int nP, int nL, bool do_schur);
   void set_edge_data(int set, const double* J0, const double* J1, const double* omega, const double* err, bool on_device);
   void set_robust_kernel(int set, int kind, double delta);
   void build_system();
   double chi2();
   void set_lambda(double lambda, bool backup);
+  void set_lambda_split(double lambda_pose, double lambda_landmark, bool backup);
   void restore_diagonal();
   double max_diagonal();
   double compute_scale(double lambda);
@@ -96,6 +98,7 @@ class BlockSolver {
   hipStream_t st_ = nullptr;
   bool own_stream_ = false;
   std::vector<std::unique_ptr<EdgeSet>> sets_;
+  std::vector<std::pair<int, int>> extra_hs_;  // extra structural blocks (row, col) of the reduced system
   // host patterns
   std::vector<int> pp_colptr, pp_row, pp_diag, pl_colptr, pl_row, hs_colptr, hs_row;
   // device matrices

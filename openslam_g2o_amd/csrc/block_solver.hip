@@ -640,6 +640,15 @@ int BlockSolver::add_edge_set(int d, int n, const int* v0, const int* v1) {
   return (int)sets_.size() - 1;
 }
 
+void BlockSolver::add_schur_pattern(int n, const int* rows, const int* cols) {
+  if (n < 0 || (n > 0 && (!rows || !cols))) throw ArgFailure("add_schur_pattern: bad arguments");
+  for (int k = 0; k < n; ++k) {
+    if (rows[k] < 0 || cols[k] < rows[k]) throw ArgFailure("add_schur_pattern: need 0 <= row <= col");
+    extra_hs_.emplace_back(rows[k], cols[k]);
+  }
+  structured_ = false;
+}
+
 void BlockSolver::require_structure() const {
   if (!structured_) throw StateFailure("call g2ohip_build_structure first");
 }
@@ -818,6 +827,10 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     for (int c = 0; c < nL; ++c)
       for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
         for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) ks.push_back((long long)pl_row[q2] * nP + pl_row[q1]);
+    for (auto& rc : extra_hs_) {
+      if (rc.second >= nP) throw ArgFailure("add_schur_pattern: block index out of range");
+      ks.push_back((long long)rc.second * nP + rc.first);
+    }
     keys_to_ccs(ks, nP, nP, hs_colptr, hs_row);
     ks.clear();
     ks.shrink_to_fit();
@@ -1025,15 +1038,17 @@ double BlockSolver::chi2() {
   return total;
 }
 
-void BlockSolver::set_lambda(double lambda, bool backup) {
+void BlockSolver::set_lambda(double lambda, bool backup) { set_lambda_split(lambda, lambda, backup); }
+
+void BlockSolver::set_lambda_split(double lambda_pose, double lambda_landmark, bool backup) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   prof.begin(KernelProf::kLambda, st_);
   hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nP_ * p_)), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p, d_bkP.p,
-                     lambda, backup ? 1 : 0, 0);
+                     lambda_pose, backup ? 1 : 0, 0);
   if (nL_ > 0)
     hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nL_ * l_)), dim3(kThreads), 0, st_, nL_, l_, d_Hll.p, (const int*)nullptr,
-                       d_bkL.p, lambda, backup ? 1 : 0, 0);
+                       d_bkL.p, lambda_landmark, backup ? 1 : 0, 0);
   prof.end(KernelProf::kLambda, st_);
   G2OHIP_HIP_CHECK(hipGetLastError());
 }

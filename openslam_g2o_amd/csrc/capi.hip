@@ -152,6 +152,22 @@ int g2ohip_set_lambda(g2ohip_solver* s, double lambda, int backup) {
   });
 }
 
+int g2ohip_set_lambda_split(g2ohip_solver* s, double lambda_pose, double lambda_landmark, int backup) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_lambda_split(lambda_pose, lambda_landmark, backup != 0);
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_add_schur_pattern(g2ohip_solver* s, int n_blocks, const int32_t* rows, const int32_t* cols) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->add_schur_pattern(n_blocks, rows, cols);
+    return G2OHIP_OK;
+  });
+}
+
 int g2ohip_restore_diagonal(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

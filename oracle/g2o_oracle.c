@@ -68,6 +68,7 @@ typedef struct {
   double *Dinv, *coeff, *bschur, *x, *b;
   double *bkP, *bkL;
   OrcChol chol;
+  int n_extra; int *extra_r, *extra_c;  /* extra structural Hschur blocks (sharding support, no reference analogue) */
   int ordering;                 /* 0 natural, 1 own block minimum degree, 2 external block perm */
   int *ext_block_perm;
   double t_schur, t_linear, t_numeric;  /* seconds, last solve */
@@ -199,8 +200,10 @@ int orc_build_structure(Orc* s) {
   /* Schur pattern: Hpp pattern U {(i1,i2): i1<=i2 co-observe a landmark}  :262-290 */
   long cnt = s->pp_nnzb;
   for (int c = 0; c < nL; ++c) { long k = s->pl_colptr[c + 1] - s->pl_colptr[c]; cnt += k * (k + 1) / 2; }
+  cnt += s->n_extra;
   long long* ks = (long long*)malloc(sizeof(long long) * (size_t)(cnt + 1));
   long is = 0;
+  for (int k = 0; k < s->n_extra; ++k) ks[is++] = (long long)s->extra_c[k] * nP + s->extra_r[k];
   for (int c = 0; c < nP; ++c) for (int q = s->pp_colptr[c]; q < s->pp_colptr[c + 1]; ++q) ks[is++] = (long long)c * nP + s->pp_row[q];
   for (int c = 0; c < nL; ++c)
     for (int q1 = s->pl_colptr[c]; q1 < s->pl_colptr[c + 1]; ++q1)
@@ -209,6 +212,14 @@ int orc_build_structure(Orc* s) {
   free(ks);
   s->Hschur = (double*)calloc((size_t)s->hs_nnzb * p * p + 1, sizeof(double));
   return 0;
+}
+
+void orc_add_schur_pattern(Orc* s, int n, const int* rows, const int* cols) {
+  s->extra_r = (int*)realloc(s->extra_r, sizeof(int) * (size_t)(s->n_extra + n + 1));
+  s->extra_c = (int*)realloc(s->extra_c, sizeof(int) * (size_t)(s->n_extra + n + 1));
+  memcpy(s->extra_r + s->n_extra, rows, sizeof(int) * (size_t)n);
+  memcpy(s->extra_c + s->n_extra, cols, sizeof(int) * (size_t)n);
+  s->n_extra += n;
 }
 
 void orc_set_edge_data(Orc* s, int set, const double* J0, const double* J1, const double* omega, const double* err, double huber_delta) {
@@ -314,6 +325,13 @@ void orc_set_lambda(Orc* s, double lambda, int backup) {
     for (int j = 0; j < p; ++j) { if (backup) s->bkP[i * p + j] = B[j + p * j]; B[j + p * j] += lambda; } }
   for (int i = 0; i < s->nL; ++i) { double* B = s->Hll + (size_t)i * l * l;
     for (int j = 0; j < l; ++j) { if (backup) s->bkL[i * l + j] = B[j + l * j]; B[j + l * j] += lambda; } }
+}
+void orc_set_lambda_split(Orc* s, double lambda_pose, double lambda_landmark, int backup) {
+  const int p = s->p, l = s->l;
+  for (int i = 0; i < s->nP; ++i) { double* B = s->Hpp + (size_t)s->pp_diag[i] * p * p;
+    for (int j = 0; j < p; ++j) { if (backup) s->bkP[i * p + j] = B[j + p * j]; B[j + p * j] += lambda_pose; } }
+  for (int i = 0; i < s->nL; ++i) { double* B = s->Hll + (size_t)i * l * l;
+    for (int j = 0; j < l; ++j) { if (backup) s->bkL[i * l + j] = B[j + l * j]; B[j + l * j] += lambda_landmark; } }
 }
 void orc_restore_diagonal(Orc* s) {
   const int p = s->p, l = s->l;
@@ -583,15 +601,9 @@ long orc_fill_scalar_ccs(int nb, int bs, const int* colptr, const int* row, cons
 }
 
 /* ----------------------------------------------------------------- solve() */
-/* block_solver.hpp:353-486.  Returns 1 ok, 0 not positive definite. */
-int orc_solve(Orc* s) {
+/* block_solver.hpp:367-444: Schur complement (K5-K8) */
+void orc_solve_schur(Orc* s) {
   const int p = s->p, l = s->l, nP = s->nP, nL = s->nL;
-  if (!s->doSchur) {
-    double t = now_s();
-    int ok = linear_solve(s, nP, p, s->pp_colptr, s->pp_row, s->Hpp, s->x, s->b);
-    s->t_linear = now_s() - t; s->t_schur = 0;
-    return ok;
-  }
   double t = now_s();
   /* _Hschur = _Hpp keeping the pattern of _Hschur  :373-374 */
   memset(s->Hschur, 0, sizeof(double) * (size_t)s->hs_nnzb * p * p);
@@ -625,11 +637,17 @@ int orc_solve(Orc* s) {
   memcpy(s->bschur, s->b, sizeof(double) * (size_t)s->sizeP);       /* :435-439 */
   for (int i = 0; i < s->sizeP; ++i) s->bschur[i] -= s->coeff[i];
   s->t_schur = now_s() - t;
-  t = now_s();
-  int ok = linear_solve(s, nP, p, s->hs_colptr, s->hs_row, s->Hschur, s->x, s->bschur);
+}
+/* :446-457 linear solve of the reduced system */
+int orc_solve_reduced(Orc* s) {
+  double t = now_s();
+  int ok = linear_solve(s, s->nP, s->p, s->hs_colptr, s->hs_row, s->Hschur, s->x, s->bschur);
   s->t_linear = now_s() - t;
-  if (!ok) return 0;
-  /* landmark back-substitution :459-483 */
+  return ok;
+}
+/* landmark back-substitution :459-483 */
+void orc_solve_back_substitute(Orc* s) {
+  const int p = s->p, l = s->l, nL = s->nL;
   double* xp = s->x; double* cp = s->coeff; double* xl = s->x + s->sizeP; double* cl = s->coeff + s->sizeP; const double* bl = s->b + s->sizeP;
   for (int i = 0; i < s->sizeP; ++i) cp[i] = -xp[i];
   memcpy(cl, bl, sizeof(double) * (size_t)s->sizeL);
@@ -643,6 +661,19 @@ int orc_solve(Orc* s) {
     const double* Dinv = s->Dinv + (size_t)lm * l * l;
     for (int i = 0; i < l; ++i) { double tt = 0; for (int j = 0; j < l; ++j) tt += Dinv[i + l * j] * cl[lm * l + j]; xl[lm * l + i] += tt; }
   }
+}
+
+/* block_solver.hpp:353-486.  Returns 1 ok, 0 not positive definite. */
+int orc_solve(Orc* s) {
+  if (!s->doSchur) {
+    double t = now_s();
+    int ok = linear_solve(s, s->nP, s->p, s->pp_colptr, s->pp_row, s->Hpp, s->x, s->b);
+    s->t_linear = now_s() - t; s->t_schur = 0;
+    return ok;
+  }
+  orc_solve_schur(s);
+  if (!orc_solve_reduced(s)) return 0;
+  orc_solve_back_substitute(s);
   return 1;
 }
 
@@ -699,6 +730,6 @@ void orc_destroy(Orc* s) {
   free(s->hs_colptr); free(s->hs_row); free(s->Hschur); free(s->Dinv); free(s->coeff); free(s->bschur); free(s->x); free(s->b); free(s->bkP); free(s->bkL);
   OrcChol* C = &s->chol;
   free(C->Ap); free(C->Ai); free(C->Ax); free(C->perm); free(C->pinv); free(C->Cp); free(C->Ci); free(C->Cx); free(C->Cmap); free(C->parent); free(C->Lp); free(C->Li); free(C->Lx); free(C->iw); free(C->xw);
-  free(s->ext_block_perm);
+  free(s->ext_block_perm); free(s->extra_r); free(s->extra_c);
   free(s);
 }

@@ -53,6 +53,11 @@ def lib():
         L.orc_chi2.argtypes = [C.c_void_p]
         L.orc_set_lambda.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.orc_restore_diagonal.argtypes = [C.c_void_p]
+        L.orc_set_lambda_split.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        L.orc_add_schur_pattern.argtypes = [C.c_void_p, C.c_int, c_int_p, c_int_p]
+        L.orc_solve_schur.argtypes = [C.c_void_p]
+        L.orc_solve_reduced.argtypes = [C.c_void_p]
+        L.orc_solve_back_substitute.argtypes = [C.c_void_p]
         L.orc_max_diagonal.restype = C.c_double
         L.orc_max_diagonal.argtypes = [C.c_void_p]
         L.orc_compute_scale.restype = C.c_double
@@ -167,6 +172,27 @@ class OracleSolver:
 
     def restore_diagonal(self):
         self.L.orc_restore_diagonal(self.h)
+
+    def set_lambda_split(self, lam_pose, lam_landmark, backup=False):
+        self.L.orc_set_lambda_split(self.h, lam_pose, lam_landmark, int(backup))
+
+    def add_schur_pattern(self, rows, cols):
+        rows, cols = _i32(rows), _i32(cols)
+        self.L.orc_add_schur_pattern(self.h, len(rows), _ip(rows), _ip(cols))
+
+    def solve_schur(self):
+        self.L.orc_solve_schur(self.h)
+
+    def solve_reduced(self):
+        return bool(self.L.orc_solve_reduced(self.h))
+
+    def solve_back_substitute(self):
+        self.L.orc_solve_back_substitute(self.h)
+
+    def view(self, name, n):
+        """Zero-copy numpy view of an oracle-owned array (for in-place reductions in tests)."""
+        ptr = getattr(self.L, "orc_" + name)(self.h)
+        return np.ctypeslib.as_array(ptr, shape=(n,))
 
     def max_diagonal(self):
         return self.L.orc_max_diagonal(self.h)
