@@ -28,7 +28,9 @@ namespace g2ohip {
 struct CholOptions {
   int nd_leaf = 32;          // nested-dissection leaf size (blocks)
   int max_sn_scalars = 48;   // supernode (pivot panel) width cap, scalars
+  double relax_zeros = 0.25; // relaxed amalgamation: tolerated share of explicit zero blocks in a panel
   size_t lds_front_bytes = 64 * 1024;  // fronts up to this size are factorised in LDS
+  size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
 };
 
 struct CholStats {
@@ -56,12 +58,37 @@ struct CholSymbolic {
   long long L_total = 0, U_total = 0, w_total = 0;
 };
 
+// One 64-byte record per front: everything the factor kernel needs, fetched with scalar loads.
+// Extend-add descriptor of one child (stored contiguously per parent).
+struct ChildDesc {
+  long long U_off;   // packed lower-triangular block storage of the child's update matrix
+  int nbc;           // boundary blocks of the child
+  int crel_start;    // start of its relative-index list inside the parent's crel segment
+  int cmap_start;    // start of its packed-block -> destination-block map inside the parent's cmap segment
+  int w_off;         // offset (doubles) of the child's update vector in the solve workspace
+};
+// One 128-byte record per front: everything the kernels need, fetched with scalar loads; the first
+// two children are embedded so the common case needs no second dependent load.
+struct FrontRec {
+  int ns, nb, c0, asm_off, asm_cnt, child_off, child_cnt, crel_off, crel_cnt, cmap_off, cmap_cnt, tri_cnt;
+  long long L_off, U_off;
+  ChildDesc ch[2];
+  int pad[4];
+};
+
 struct CholPlanDev {
+  const FrontRec* rec;
+  const ChildDesc* cdesc;
+  const int* crel;
+  const int* cmap;   // per parent: child's packed U block -> (row | col << 16) block of the parent front
+  const int* tri;    // row-major enumeration of a lower triangle: idx -> (i | j << 16)
   const int *f_ns, *f_nb, *f_c0, *rows_off, *rows, *rel_off, *rel;
   const long long *L_off, *U_off, *w_off;
   const int *asm_off, *asm_q, *asm_pos, *child_off, *children;
   double *L, *U, *w;
   int* status;
+  long long* dbg;   // developer timing stamps (G2OHIP_ABLATE & 64)
+  int* dbg_slot;
 };
 
 class SparseCholesky {
@@ -95,6 +122,10 @@ class SparseCholesky {
   DevBuf<int> d_f_ns, d_f_nb, d_f_c0, d_rows_off, d_rows, d_rel_off, d_rel, d_asm_off, d_asm_q, d_asm_pos,
       d_child_off, d_children, d_level_fronts, d_perm, d_status;
   DevBuf<long long> d_L_off, d_U_off, d_w_off, d_scratch_off;
+  DevBuf<FrontRec> d_rec;
+  DevBuf<ChildDesc> d_cdesc;
+  DevBuf<int> d_crel, d_cmap, d_tri, d_dbg_slot;
+  DevBuf<long long> d_dbg;
   DevBuf<double> d_L, d_U, d_w, d_y, d_xp, d_scratch;
   // per level launch info
   struct LevelLaunch {
@@ -102,6 +133,7 @@ class SparseCholesky {
     int glb_begin = 0, glb_count = 0, glb_max_m = 0;
     int max_panel = 0;                                   // max m*npiv (doubles) for solve kernels
     int max_m = 0;
+    int lds_idx_ints = 0, glb_idx_ints = 0;              // staged index lists (ints) per front, max over the launch
   };
   std::vector<LevelLaunch> launches_;
   CholPlanDev plan_{};

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -333,13 +334,28 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   // --- supernodes (maximal chains with nested structure), capped in width
   const int max_sn_blocks = std::max(1, opt.max_sn_scalars / bs);
   S.sn_start.clear();
-  for (int j = 0; j < nb; ++j) {
-    bool merge = false;
-    if (j > 0 && S.parent[j - 1] == j && st_[j - 1].size() == st_[j].size() + 1) {
-      int width = j - S.sn_start.back();
-      if (width < max_sn_blocks) merge = true;
+  {
+    // Exact merges (identical structure) always; relaxed merges along a parent chain while the
+    // explicit zero blocks stay below opt.relax_zeros of the dense panel and the front still fits LDS.
+    long true_blocks = 0;  // structural blocks of the current supernode's columns
+    for (int j = 0; j < nb; ++j) {
+      bool merge = false;
+      if (j > 0 && S.parent[j - 1] == j) {
+        const int c0 = S.sn_start.back();
+        const long w = j - c0 + 1, nbn = (long)st_[j].size();
+        const long total = w * (w + 1) / 2 + w * nbn;
+        const long tb = true_blocks + 1 + nbn;
+        const bool exact = st_[j - 1].size() == st_[j].size() + 1 && total == tb;
+        const size_t m = (size_t)(w + nbn) * bs;
+        const bool fits = m * m * 8 <= std::min(opt.lds_front_bytes, opt.relax_front_bytes);
+        if (w <= max_sn_blocks && (exact || (fits && (double)(total - tb) <= opt.relax_zeros * (double)total))) merge = true;
+      }
+      if (!merge) {
+        S.sn_start.push_back(j);
+        true_blocks = 0;
+      }
+      true_blocks += 1 + (long)st_[j].size();
     }
-    if (!merge) S.sn_start.push_back(j);
   }
   const int nf = (int)S.sn_start.size();
   S.sn_start.push_back(nb);
@@ -436,7 +452,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     S.L_off[f] = S.L_total;
     S.L_total += m * np;
     S.U_off[f] = S.U_total;
-    S.U_total += nbs * nbs;
+    S.U_total += (long long)S.f_nb[f] * (S.f_nb[f] + 1) / 2 * bs * bs;   // lower-triangular blocks, packed by block column
     S.w_off[f] = S.w_total;
     S.w_total += nbs;
     stats_.nnzL += (size_t)(np * m - np * (np - 1) / 2);
@@ -490,9 +506,76 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         int m = (S.f_ns[f] + S.f_nb[f]) * bs;
         LL.max_m = std::max(LL.max_m, m);
         LL.max_panel = std::max(LL.max_panel, m * S.f_ns[f] * bs);
+        int idx = 2 * (S.asm_off[f + 1] - S.asm_off[f]);
+        for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) idx += S.f_nb[S.children[ch]];
+        if (k < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, idx);
+        else LL.glb_idx_ints = std::max(LL.glb_idx_ints, idx);
       }
     }
   }
+  // --- packed per-front records and per-parent extend-add descriptors
+  std::vector<FrontRec> recs(nf);
+  std::vector<ChildDesc> cdesc(S.children.size());
+  std::vector<int> crel, cmap;
+  crel.reserve(S.rel.size());
+  const int T_ = (bs % 3 == 0) ? 3 : bs;
+  int tri_max = 1;
+  for (int f = 0; f < nf; ++f) {
+    FrontRec& R = recs[f];
+    std::memset(&R, 0, sizeof(R));
+    R.ns = S.f_ns[f];
+    R.nb = S.f_nb[f];
+    R.c0 = S.sn_start[f];
+    R.asm_off = S.asm_off[f];
+    R.asm_cnt = S.asm_off[f + 1] - S.asm_off[f];
+    R.child_off = S.child_off[f];
+    R.child_cnt = S.child_off[f + 1] - S.child_off[f];
+    R.crel_off = (int)crel.size();
+    R.cmap_off = (int)cmap.size();
+    R.L_off = S.L_off[f];
+    R.U_off = S.U_off[f];
+    for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) {
+      int c = S.children[ch];
+      cdesc[ch].U_off = S.U_off[c];
+      cdesc[ch].nbc = S.f_nb[c];
+      cdesc[ch].crel_start = (int)crel.size() - R.crel_off;
+      cdesc[ch].cmap_start = (int)cmap.size() - R.cmap_off;
+      cdesc[ch].w_off = (int)S.w_off[c];
+      const int* rl = S.rel.data() + S.rel_off[c];
+      crel.insert(crel.end(), rl, rl + S.f_nb[c]);
+      for (int ib = 0; ib < S.f_nb[c]; ++ib)
+        for (int jb = 0; jb <= ib; ++jb) {
+          if (rl[ib] >= (1 << 16) || rl[jb] >= (1 << 15)) throw StateFailure("symbolic: front too large for the packed child map");
+          cmap.push_back(rl[ib] | (rl[jb] << 16));   // packed block (ib,jb), row-major lower order
+        }
+      if (ch - S.child_off[f] < 2) R.ch[ch - S.child_off[f]] = cdesc[ch];
+    }
+    R.crel_cnt = (int)crel.size() - R.crel_off;
+    R.cmap_cnt = (int)cmap.size() - R.cmap_off;
+    const int nt0 = (R.nb + R.ns - 1) * bs / T_;          // trailing tiles per side after the first pivot block
+    R.tri_cnt = std::max(nt0 * (nt0 + 1) / 2, R.nb * (R.nb + 1) / 2);
+    tri_max = std::max(tri_max, R.tri_cnt);
+  }
+  std::vector<int> tri(tri_max);
+  {
+    int k = 0;
+    for (int i = 0; k < tri_max; ++i)
+      for (int j = 0; j <= i && k < tri_max; ++j) tri[k++] = i | (j << 16);
+  }
+  for (LevelLaunch& LL : launches_) {
+    LL.lds_idx_ints = LL.glb_idx_ints = 0;
+    for (int k = LL.lds_begin; k < LL.glb_begin + LL.glb_count; ++k) {
+      const FrontRec& R = recs[S.level_fronts[k]];
+      int idx = 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt;
+      if (k < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, idx);
+      else LL.glb_idx_ints = std::max(LL.glb_idx_ints, idx);
+    }
+  }
+  d_rec.upload(recs, st);
+  d_cdesc.upload(cdesc, st);
+  d_crel.upload(crel, st);
+  d_cmap.upload(cmap, st);
+  d_tri.upload(tri, st);
   // --- upload
   std::vector<int> c0(S.sn_start.begin(), S.sn_start.end() - 1);
   d_f_ns.upload(S.f_ns, st);
@@ -522,6 +605,17 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_status.alloc(1);
   d_status.zero(st);
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
+  d_dbg.alloc(16 * 64 * 3 + 16);
+  d_dbg.zero(st);
+  d_dbg_slot.alloc(4);
+  d_dbg_slot.zero(st);
+  plan_.dbg = d_dbg.p;
+  plan_.dbg_slot = d_dbg_slot.p;
+  plan_.rec = d_rec.p;
+  plan_.cdesc = d_cdesc.p;
+  plan_.crel = d_crel.p;
+  plan_.cmap = d_cmap.p;
+  plan_.tri = d_tri.p;
   plan_.f_ns = d_f_ns.p;
   plan_.f_nb = d_f_nb.p;
   plan_.f_c0 = d_f_c0.p;
@@ -553,74 +647,174 @@ namespace {
 constexpr int kFactorThreads = 256;
 constexpr int kFactorThreadsGlobal = 512;
 
-// column-major enumeration of the lower-triangular tiles of an nt x nt tile grid
-__device__ __forceinline__ void tri_decode(int idx, int nt, int& ti, int& tj) {
-  // tiles before column j: j*nt - j(j-1)/2
-  float fn = 2.f * nt + 1.f;
-  int j = (int)((fn - sqrtf(fn * fn - 8.f * (float)idx)) * 0.5f);
-  if (j < 0) j = 0;
-  if (j > nt - 1) j = nt - 1;
-  while (j > 0 && j * nt - (j * (j - 1)) / 2 > idx) --j;
-  while ((j + 1) * nt - ((j + 1) * j) / 2 <= idx) ++j;
-  tj = j;
-  ti = j + (idx - (j * nt - (j * (j - 1)) / 2));
+// sqrt(d) and 1/sqrt(d) together: v_rsq_f64 seed + two Goldschmidt steps + one Newton correction
+// (the same recipe LLVM uses for f64 sqrt, without the fdiv a separate rsqrt would need).  ~1-2 ulp.
+__device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& r) {
+  const double y = __builtin_amdgcn_rsq(d);
+  double g = d * y, h = 0.5 * y;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  const double dd = fma(-g, g, d);
+  g = fma(dd, h, g);
+  s = g;
+  r = h + h;
 }
 
 // One workgroup factorises one frontal matrix.
 //   F: m x m column-major (ld = m), lower triangle used.  LDS or an HBM scratch slab.
-// Steps: zero, assemble original blocks, extend-add the children's update matrices,
-// partial Cholesky of the ns pivot block columns (blocked by BS), write L panel and the
-// update matrix U.
+// Steps: stage index tables, zero, assemble original blocks, extend-add the children's update
+// matrices, partial Cholesky of the ns pivot block columns (blocked by BS, look-ahead on the
+// diagonal factor), write the L panel and the update matrix U.
+// Lower-triangular block/tile sets are enumerated ROW-major (idx = i(i+1)/2 + j): the enumeration
+// of an n x n triangle is a prefix of that of any larger one, so one table (P.tri) serves every size.
+// LDS: F | 2 diagonal-factor mailboxes | s_q[na] s_pos[na] s_cmap[cmap_cnt] s_tri[tri_cnt]
 template <int BS, bool USE_LDS>
-__global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGlobal) front_factor_kernel(CholPlanDev P, const int* __restrict__ fronts, const double* __restrict__ A,
-                                    double* __restrict__ scratch, const long long* __restrict__ scratch_off) {
+__global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGlobal) front_factor_kernel(
+    CholPlanDev P, const int* __restrict__ fronts, const double* __restrict__ A, double* __restrict__ scratch,
+    const long long* __restrict__ scratch_off, int idx_off_doubles, int ablate) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int T = (BS % 3 == 0) ? 3 : BS;  // register tile edge of the trailing update
+  constexpr int BB = BS * BS;
+  constexpr int UNR = 6;                     // independent global loads in flight per thread
+  constexpr int LA = BS / T;                 // look-ahead span in tiles
   const int f = fronts[blockIdx.x];
-  const int ns = P.f_ns[f], nbd = P.f_nb[f];
+  const FrontRec rec = P.rec[f];             // wave-uniform: scalar loads
+  const int ns = rec.ns, nbd = rec.nb;
   const int m = (ns + nbd) * BS, npiv = ns * BS, ld = m;
   double* F = USE_LDS ? smem : (scratch + scratch_off[blockIdx.x]);
+  double* sd = smem + idx_off_doubles - 2 * (BB + BS);   // two mailboxes: [L_kk (BB) | 1/diag (BS)]
+  int* s_q = reinterpret_cast<int*>(smem + idx_off_doubles);
+  const int na = rec.asm_cnt;
+  int* s_pos = s_q + na;
+  int* s_cmap = s_pos + na;
+  int* s_tri = s_cmap + rec.cmap_cnt;
   const int tid = threadIdx.x, NT = blockDim.x;
+  long long* dbg = (ablate & 64) && blockIdx.x == 0 && tid == 0 ? P.dbg + 16 * P.dbg_slot[0] : nullptr;
+  int dbg_k = 0;
+#define G2OHIP_STAMP() do { if (dbg) dbg[dbg_k++] = wall_clock64(); } while (0)
+  G2OHIP_STAMP();
 
+  // ---- issue the children's update-matrix loads first (fast path: <= 2 children that fit one round)
+  const int nch = rec.child_cnt;
+  const int nU0 = nch > 0 ? rec.ch[0].nbc * (rec.ch[0].nbc + 1) / 2 * BB : 0;
+  const int nU1 = nch > 1 ? rec.ch[1].nbc * (rec.ch[1].nbc + 1) / 2 * BB : 0;
+  const bool fast_children = nch <= 2 && nU0 <= UNR * NT && nU1 <= UNR * NT && !(ablate & 4);
+  double u0[UNR], u1[UNR];
+  if (fast_children) {
+    const double* U0 = P.U + rec.ch[0].U_off;
+    const double* U1 = P.U + rec.ch[1].U_off;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = tid + u * NT;
+      u0[u] = (t < nU0) ? U0[t] : 0.0;
+      u1[u] = (t < nU1) ? U1[t] : 0.0;
+    }
+  }
+  // ---- stage the index tables in LDS (independent loads), zero the front meanwhile
+  for (int t = tid; t < na; t += NT) {
+    s_q[t] = P.asm_q[rec.asm_off + t];
+    s_pos[t] = P.asm_pos[rec.asm_off + t];
+  }
+  for (int t = tid; t < rec.cmap_cnt; t += NT) s_cmap[t] = P.cmap[rec.cmap_off + t];
+  for (int t = tid; t < rec.tri_cnt; t += NT) s_tri[t] = P.tri[t];
   for (int i = tid; i < m * m; i += NT) F[i] = 0.0;
   __syncthreads();
+  G2OHIP_STAMP();
   // ---- original entries (each block lands on a distinct tile)
-  {
-    const int a0 = P.asm_off[f], na = P.asm_off[f + 1] - a0;
-    for (int t = tid; t < na * BS * BS; t += NT) {
-      const int e = t / (BS * BS), rc = t - e * (BS * BS);
-      const int r = rc % BS, c = rc / BS;
-      const int q = P.asm_q[a0 + e], pos = P.asm_pos[a0 + e];
-      const int lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff, tr = (pos >> 30) & 1;
-      const double v = tr ? A[(size_t)q * BS * BS + c + BS * r] : A[(size_t)q * BS * BS + r + BS * c];
-      F[(lr * BS + r) + (size_t)ld * (lc * BS + c)] = v;
+  if (!(ablate & 2)) {
+    const int nA = na * BB;
+    for (int base = tid; base < nA; base += UNR * NT) {
+      double v[UNR];
+      int dst[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int t = base + u * NT;
+        dst[u] = -1;
+        v[u] = 0.0;
+        if (t < nA) {
+          const int e = t / BB, rc = t - e * BB;
+          const int r = rc % BS, c = rc / BS;
+          const int q = s_q[e], pos = s_pos[e];
+          const int lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff, tr = (pos >> 30) & 1;
+          v[u] = tr ? A[(size_t)q * BB + c + BS * r] : A[(size_t)q * BB + r + BS * c];
+          dst[u] = (lr * BS + r) + ld * (lc * BS + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        if (dst[u] >= 0) F[dst[u]] = v[u];
     }
   }
   __syncthreads();
-  // ---- extend-add of the children (sequential over children: tiles may overlap)
-  for (int ch = P.child_off[f]; ch < P.child_off[f + 1]; ++ch) {
-    const int c = P.children[ch];
-    const int nbc = P.f_nb[c] * BS;
-    const double* Uc = P.U + P.U_off[c];
-    const int* rel = P.rel + P.rel_off[c];
-    for (int t = tid; t < nbc * nbc; t += NT) {
-      const int i = t % nbc, j = t / nbc;
-      if (i < j) continue;
-      const int li = rel[i / BS] * BS + (i % BS), lj = rel[j / BS] * BS + (j % BS);
-      F[li + (size_t)ld * lj] += Uc[t];
+  G2OHIP_STAMP();
+  // ---- extend-add of the children (sequential over children: destinations may overlap).  Update
+  // matrices are packed lower-triangular blocks (row-major block order); cmap gives, per packed
+  // block, the destination block (row | col << 16) in this front.
+  if (fast_children) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = tid + u * NT;
+      if (t < nU0) {
+        const int blk = t / BB, e = t - blk * BB;
+        const int d = s_cmap[rec.ch[0].cmap_start + blk];
+        F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += u0[u];
+      }
+    }
+    if (nch > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int t = tid + u * NT;
+        if (t < nU1) {
+          const int blk = t / BB, e = t - blk * BB;
+          const int d = s_cmap[rec.ch[1].cmap_start + blk];
+          F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += u1[u];
+        }
+      }
     }
     __syncthreads();
+  } else {
+    for (int ch = 0; ch < nch && !(ablate & 4); ++ch) {
+      const ChildDesc cd = P.cdesc[rec.child_off + ch];  // wave-uniform
+      const int* cmap = s_cmap + cd.cmap_start;
+      const double* Uc = P.U + cd.U_off;
+      const int nU = cd.nbc * (cd.nbc + 1) / 2 * BB;
+      for (int base = tid; base < nU; base += UNR * NT) {
+        double v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int t = base + u * NT;
+          v[u] = (t < nU) ? Uc[t] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int t = base + u * NT;
+          if (t < nU) {
+            const int blk = t / BB, e = t - blk * BB;
+            const int d = cmap[blk];
+            F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += v[u];
+          }
+        }
+      }
+      __syncthreads();
+    }
   }
-  // ---- partial Cholesky, one pivot block (BS columns) per step
-  for (int kb = 0; kb < ns; ++kb) {
-    const int k0 = kb * BS;
-    double Lk[BS][BS];
-    double inv[BS];
+  G2OHIP_STAMP();
+  // ---- partial Cholesky, one pivot block (BS columns) per step.
+  // The BS x BS diagonal factor is a long dependent chain (rsqrt, scale, update x BS); it is kept off
+  // the critical path by look-ahead: while waves 1.. apply the trailing update of step kb, wave 0
+  // updates only the NEXT diagonal block and factorises it into a small LDS mailbox (sd).
+  auto diag_factor = [&](int kb_, double* box) {                        // executed by every lane of wave 0
+    const int k0_ = kb_ * BS;
+    double Lk[BS][BS], inv[BS];
 #pragma unroll
     for (int c = 0; c < BS; ++c)
 #pragma unroll
-      for (int r = 0; r < BS; ++r) Lk[r][c] = (r >= c) ? F[(k0 + r) + (size_t)ld * (k0 + c)] : 0.0;
-    __syncthreads();  // everyone holds the diagonal block before thread 0 overwrites it
+      for (int r = 0; r < BS; ++r) Lk[r][c] = (r >= c) ? F[(k0_ + r) + (size_t)ld * (k0_ + c)] : 0.0;
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < BS; ++c) {
@@ -629,9 +823,10 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
         bad = true;
         d = 1.0;
       }
-      const double r = rsqrt(d);
+      double sq, r;
+      sqrt_and_rsqrt(d, sq, r);
       inv[c] = r;
-      Lk[c][c] = d * r;
+      Lk[c][c] = sq;
 #pragma unroll
       for (int i = c + 1; i < BS; ++i) Lk[i][c] *= r;
 #pragma unroll
@@ -642,10 +837,38 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
     if (tid == 0) {
       if (bad) *P.status = 1;
 #pragma unroll
-      for (int c = 0; c < BS; ++c)
+      for (int c = 0; c < BS; ++c) {
 #pragma unroll
-        for (int r = 0; r < BS; ++r) F[(k0 + r) + (size_t)ld * (k0 + c)] = (r >= c) ? Lk[r][c] : 0.0;
+        for (int r = 0; r < BS; ++r) {
+          const double v = (r >= c) ? Lk[r][c] : 0.0;
+          box[r + BS * c] = v;
+          F[(k0_ + r) + (size_t)ld * (k0_ + c)] = v;   // final L_kk for the panel store
+        }
+        box[BB + c] = inv[c];
+      }
     }
+  };
+  if (!(ablate & 8) && ns > 0) {
+    if (tid < 64) diag_factor(0, sd);
+    __syncthreads();
+  }
+  G2OHIP_STAMP();
+  long long* dbgA = (ablate & 64) && blockIdx.x == 0 && tid == 0 ? P.dbg + 16 * 64 + 16 * P.dbg_slot[0] : nullptr;       // wave 0
+  long long* dbgB = (ablate & 64) && blockIdx.x == 0 && tid == 64 ? P.dbg + 2 * 16 * 64 + 16 * P.dbg_slot[0] : nullptr;  // wave 1
+  int ka = 0, kbb = 0;
+  for (int kb = 0; kb < ns && !(ablate & 8); ++kb) {
+    const int k0 = kb * BS;
+    const double* box = sd + (kb & 1) * (BB + BS);
+    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
+    if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
+    double Lk[BS][BS], inv[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      inv[c] = box[BB + c];
+#pragma unroll
+      for (int r = 0; r < BS; ++r) Lk[r][c] = (r > c) ? box[r + BS * c] : 0.0;
+    }
+    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
     // rows below the diagonal block: x * Lkk' = row
     for (int i = k0 + BS + tid; i < m; i += NT) {
       double x[BS];
@@ -661,48 +884,76 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
 #pragma unroll
       for (int c = 0; c < BS; ++c) F[i + (size_t)ld * (k0 + c)] = x[c];
     }
+    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
+    if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
     __syncthreads();
-    // trailing update with T x T register tiles over the lower triangle
+    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
+    if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
+    // trailing update with T x T register tiles over the lower triangle (tile coordinates relative
+    // to the first trailing row; the first LA(LA+1)/2 table entries are the next diagonal block)
     const int r0 = k0 + BS;
     const int nt = (m - r0) / T;
     const int ntiles = nt * (nt + 1) / 2;
-    for (int idx = tid; idx < ntiles; idx += NT) {
-      int ti, tj;
-      tri_decode(idx, nt, ti, tj);
-      const int i0 = r0 + ti * T, j0 = r0 + tj * T;
-      double acc[T][T];
-#pragma unroll
-      for (int a = 0; a < T; ++a)
-#pragma unroll
-        for (int b = 0; b < T; ++b) acc[a][b] = 0.0;
+    const bool lookahead = (kb + 1 < ns) && NT > 64;
+    auto update_tile = [&](int packed) {
+      const int i0 = r0 + (packed & 0xffff) * T, j0 = r0 + (packed >> 16) * T;
+      // all LDS operands first (one latency), then the FMAs, then the stores
+      double av[BS][T], bv[BS][T], cv[T][T];
 #pragma unroll
       for (int q = 0; q < BS; ++q) {
-        double av[T], bv[T];
 #pragma unroll
-        for (int a = 0; a < T; ++a) av[a] = F[(i0 + a) + (size_t)ld * (k0 + q)];
+        for (int a = 0; a < T; ++a) av[q][a] = F[(i0 + a) + (size_t)ld * (k0 + q)];
 #pragma unroll
-        for (int b = 0; b < T; ++b) bv[b] = F[(j0 + b) + (size_t)ld * (k0 + q)];
-#pragma unroll
-        for (int a = 0; a < T; ++a)
-#pragma unroll
-          for (int b = 0; b < T; ++b) acc[a][b] += av[a] * bv[b];
+        for (int b = 0; b < T; ++b) bv[q][b] = F[(j0 + b) + (size_t)ld * (k0 + q)];
       }
 #pragma unroll
       for (int b = 0; b < T; ++b)
 #pragma unroll
-        for (int a = 0; a < T; ++a) F[(i0 + a) + (size_t)ld * (j0 + b)] -= acc[a][b];
+        for (int a = 0; a < T; ++a) cv[a][b] = F[(i0 + a) + (size_t)ld * (j0 + b)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < BS; ++q)
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+          for (int b = 0; b < T; ++b) cv[a][b] -= av[q][a] * bv[q][b];
+#pragma unroll
+      for (int b = 0; b < T; ++b)
+#pragma unroll
+        for (int a = 0; a < T; ++a) F[(i0 + a) + (size_t)ld * (j0 + b)] = cv[a][b];
+    };
+    constexpr int NLA = LA * (LA + 1) / 2;
+    if (lookahead && tid < 64) {
+      if (tid < NLA) update_tile(s_tri[tid]);
+      __threadfence_block();   // the wave's own LDS writes are complete before it re-reads the block
+      if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
+      diag_factor(kb + 1, sd + ((kb + 1) & 1) * (BB + BS));
+      if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
+    } else {
+      const int first = lookahead ? NLA + tid - 64 : tid, stride = lookahead ? NT - 64 : NT;
+      for (int idx = first; idx < ntiles; idx += stride) update_tile(s_tri[idx]);
+      if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
     }
     __syncthreads();
+    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
   }
-  // ---- write L panel (m x npiv) and update matrix (lower part of the trailing block)
-  double* Lg = P.L + P.L_off[f];
-  for (int t = tid; t < m * npiv; t += NT) Lg[t] = F[t];  // ld == m: identical layout
-  const int nbs = nbd * BS;
-  double* Ug = P.U + P.U_off[f];
-  for (int t = tid; t < nbs * nbs; t += NT) {
-    const int i = t % nbs, j = t / nbs;
-    Ug[t] = F[(npiv + i) + (size_t)ld * (npiv + j)];
+  G2OHIP_STAMP();
+  // ---- write L panel (m x npiv) and the update matrix (packed lower-triangular blocks, row-major)
+  double* Lg = P.L + rec.L_off;
+  if (!(ablate & 16))
+    for (int t = tid; t < m * npiv; t += NT) Lg[t] = F[t];  // ld == m: identical layout
+  double* Ug = P.U + rec.U_off;
+  if (!(ablate & 32)) {
+    const int nU = nbd * (nbd + 1) / 2 * BB;
+    for (int t = tid; t < nU; t += NT) {
+      const int blk = t / BB, e = t - blk * BB;
+      const int d = s_tri[blk];
+      Ug[t] = F[(npiv + (d & 0xffff) * BS + e % BS) + ld * (npiv + (d >> 16) * BS + e / BS)];
+    }
   }
+  G2OHIP_STAMP();
+  if (dbg) { dbg[15] = m; P.dbg_slot[0] = (P.dbg_slot[0] + 1) % 64; }
+#undef G2OHIP_STAMP
 }
 
 // b_perm[new*bs + r] = b[old*bs + r]
@@ -720,91 +971,189 @@ __global__ void permute_out_kernel(int nb, int bs, const int* __restrict__ perm,
 }
 
 // Forward sweep for one front: y1 = L11 \ (b1 + children), w = (children on boundary) - L21 y1.
-// LDS: panel (optional) + t[m] + ysol[npiv]
-template <bool PANEL_LDS>
-__global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const int* __restrict__ fronts, int bs, const double* __restrict__ bperm,
-                                     double* __restrict__ y, int panel_cap) {
+// Blocked by BS: every thread redundantly solves the BS x BS triangular diagonal system (broadcast
+// LDS reads), then the rows below are updated in parallel -> one barrier per pivot block.
+// LDS: [panel (optional)] [t: m] [ys: npiv]
+template <int BS, bool PANEL_LDS>
+__global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const int* __restrict__ fronts,
+                                                           const double* __restrict__ bperm, double* __restrict__ y, int panel_cap) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int f = fronts[blockIdx.x];
-  const int ns = P.f_ns[f], nbd = P.f_nb[f];
-  const int m = (ns + nbd) * bs, npiv = ns * bs, c0 = P.f_c0[f];
+  const FrontRec rec = P.rec[f];
+  const int ns = rec.ns, nbd = rec.nb;
+  const int m = (ns + nbd) * BS, npiv = ns * BS, c0 = rec.c0;
   const int tid = threadIdx.x, NT = blockDim.x;
   double* Lp = smem;
   double* t = smem + (PANEL_LDS ? panel_cap : 0);
-  const double* Lg = P.L + P.L_off[f];
+  double* ys = t + m;
+  const double* Lg = P.L + rec.L_off;
   if (PANEL_LDS)
     for (int i = tid; i < m * npiv; i += NT) Lp[i] = Lg[i];
   const double* Lx = PANEL_LDS ? Lp : Lg;
-  for (int i = tid; i < m; i += NT) t[i] = (i < npiv) ? bperm[(size_t)c0 * bs + i] : 0.0;
+  // children's update vectors: issue the loads before the first barrier (fast path: <= 2 children
+  // whose boundary fits one round), apply them one child at a time (rows may coincide)
+  const int nch = rec.child_cnt;
+  const int n0 = nch > 0 ? rec.ch[0].nbc * BS : 0, n1 = nch > 1 ? rec.ch[1].nbc * BS : 0;
+  const bool fast_children = nch <= 2 && n0 <= NT && n1 <= NT;
+  double w0 = 0.0, w1 = 0.0;
+  int d0 = 0, d1 = 0;
+  if (fast_children) {
+    if (tid < n0) {
+      w0 = P.w[rec.ch[0].w_off + tid];
+      d0 = P.crel[rec.crel_off + rec.ch[0].crel_start + tid / BS] * BS + tid % BS;
+    }
+    if (tid < n1) {
+      w1 = P.w[rec.ch[1].w_off + tid];
+      d1 = P.crel[rec.crel_off + rec.ch[1].crel_start + tid / BS] * BS + tid % BS;
+    }
+  }
+  for (int i = tid; i < m; i += NT) t[i] = (i < npiv) ? bperm[(size_t)c0 * BS + i] : 0.0;
   __syncthreads();
-  for (int ch = P.child_off[f]; ch < P.child_off[f + 1]; ++ch) {
-    const int c = P.children[ch];
-    const int nbc = P.f_nb[c] * bs;
-    const double* wc = P.w + P.w_off[c];
-    const int* rel = P.rel + P.rel_off[c];
-    for (int i = tid; i < nbc; i += NT) t[rel[i / bs] * bs + (i % bs)] += wc[i];
+  if (fast_children) {
+    if (tid < n0) t[d0] += w0;
+    if (nch > 1) {
+      __syncthreads();
+      if (tid < n1) t[d1] += w1;
+    }
+    if (nch > 0) __syncthreads();
+  } else {
+    for (int ch = 0; ch < nch; ++ch) {
+      const ChildDesc cd = P.cdesc[rec.child_off + ch];
+      const int nbc = cd.nbc * BS;
+      const double* wc = P.w + cd.w_off;
+      const int* rel = P.crel + rec.crel_off + cd.crel_start;
+      for (int i = tid; i < nbc; i += NT) t[rel[i / BS] * BS + (i % BS)] += wc[i];
+      __syncthreads();
+    }
+  }
+  for (int kb = 0; kb < ns; ++kb) {
+    const int k0 = kb * BS;
+    double yv[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      double v = t[k0 + c];
+#pragma unroll
+      for (int q = 0; q < c; ++q) v -= Lx[(k0 + c) + (size_t)m * (k0 + q)] * yv[q];
+      yv[c] = v / Lx[(k0 + c) + (size_t)m * (k0 + c)];
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int c = 0; c < BS; ++c) ys[k0 + c] = yv[c];
+    }
+    for (int i = k0 + BS + tid; i < m; i += NT) {
+      double v = t[i];
+#pragma unroll
+      for (int q = 0; q < BS; ++q) v -= Lx[i + (size_t)m * (k0 + q)] * yv[q];
+      t[i] = v;
+    }
     __syncthreads();
   }
-  double* ys = t + m;
-  for (int k = 0; k < npiv; ++k) {
-    const double yk = t[k] / Lx[k + (size_t)m * k];   // t[k] is final: only rows > k are touched below
-    if (tid == 0) ys[k] = yk;
-    for (int i = k + 1 + tid; i < m; i += NT) t[i] -= Lx[i + (size_t)m * k] * yk;
-    __syncthreads();
-  }
-  for (int i = tid; i < npiv; i += NT) y[(size_t)c0 * bs + i] = ys[i];
+  for (int i = tid; i < npiv; i += NT) y[(size_t)c0 * BS + i] = ys[i];
   double* wf = P.w + P.w_off[f];
-  for (int i = tid; i < nbd * bs; i += NT) wf[i] = t[npiv + i];
+  for (int i = tid; i < nbd * BS; i += NT) wf[i] = t[npiv + i];
 }
 
-// Backward sweep for one front: x1 = L11' \ (y1 - L21' x_boundary)
-template <bool PANEL_LDS>
-__global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, const int* __restrict__ fronts, int bs, const double* __restrict__ y,
-                                      double* __restrict__ xp, int panel_cap) {
+// Backward sweep for one front: x1 = L11' \ (y1 - L21' x_boundary); same blocking.
+// LDS: [panel (optional)] [t: m] [xs: npiv] [sp: partial sums, NT]
+template <int BS, bool PANEL_LDS>
+__global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, const int* __restrict__ fronts,
+                                                            const double* __restrict__ y, double* __restrict__ xp, int panel_cap) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int f = fronts[blockIdx.x];
-  const int ns = P.f_ns[f], nbd = P.f_nb[f];
-  const int m = (ns + nbd) * bs, npiv = ns * bs, c0 = P.f_c0[f];
+  const FrontRec rec = P.rec[f];
+  const int ns = rec.ns, nbd = rec.nb;
+  const int m = (ns + nbd) * BS, npiv = ns * BS, c0 = rec.c0;
   const int tid = threadIdx.x, NT = blockDim.x;
   double* Lp = smem;
   double* t = smem + (PANEL_LDS ? panel_cap : 0);
-  const double* Lg = P.L + P.L_off[f];
+  double* xs = t + m;
+  double* sp = xs + m;
+  const double* Lg = P.L + rec.L_off;
   if (PANEL_LDS)
     for (int i = tid; i < m * npiv; i += NT) Lp[i] = Lg[i];
   const double* Lx = PANEL_LDS ? Lp : Lg;
   const int* rows = P.rows + P.rows_off[f];
   for (int i = tid; i < m; i += NT)
-    t[i] = (i < npiv) ? y[(size_t)c0 * bs + i] : xp[(size_t)rows[(i - npiv) / bs] * bs + ((i - npiv) % bs)];
+    t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : xp[(size_t)rows[(i - npiv) / BS] * BS + ((i - npiv) % BS)];
   __syncthreads();
-  // boundary contribution: t[k] -= sum_{i>=npiv} L[i,k] t[i]
-  for (int k = tid; k < npiv; k += NT) {
+  // boundary contribution t[k] -= sum_{i>=npiv} L[i,k] t[i]: (k, part) decomposition + LDS reduction
+  {
+    const int parts = NT / npiv > 0 ? NT / npiv : 1;
+    const int k = tid % npiv, part = tid / npiv;
     double s = 0.0;
-    for (int i = npiv; i < m; ++i) s += Lx[i + (size_t)m * k] * t[i];
-    t[k] -= s;
+    if (part < parts)
+      for (int i = npiv + part; i < m; i += parts) s += Lx[i + (size_t)m * k] * t[i];
+    if (parts == 1) {
+      // fewer threads than pivot columns: loop over the remaining columns serially
+      for (int kk = tid; kk < npiv; kk += NT) {
+        double s2 = 0.0;
+        for (int i = npiv; i < m; ++i) s2 += Lx[i + (size_t)m * kk] * t[i];
+        sp[kk] = s2;
+      }
+      __syncthreads();
+      for (int kk = tid; kk < npiv; kk += NT) t[kk] -= sp[kk];
+    } else {
+      sp[tid] = (part < parts) ? s : 0.0;
+      __syncthreads();
+      if (tid < npiv) {
+        double a = 0.0;
+        for (int pp = 0; pp < parts; ++pp) a += sp[pp * npiv + tid];
+        t[tid] -= a;
+      }
+    }
   }
   __syncthreads();
-  double* xs = t + m;
-  for (int k = npiv - 1; k >= 0; --k) {
-    const double xk = t[k] / Lx[k + (size_t)m * k];   // t[k] is final: only entries < k are touched below
-    if (tid == 0) xs[k] = xk;
-    for (int j = tid; j < k; j += NT) t[j] -= Lx[k + (size_t)m * j] * xk;
+  for (int kb = ns - 1; kb >= 0; --kb) {
+    const int k0 = kb * BS;
+    double xv[BS];
+#pragma unroll
+    for (int c = BS - 1; c >= 0; --c) {
+      double v = t[k0 + c];
+#pragma unroll
+      for (int q = c + 1; q < BS; ++q) v -= Lx[(k0 + q) + (size_t)m * (k0 + c)] * xv[q];
+      xv[c] = v / Lx[(k0 + c) + (size_t)m * (k0 + c)];
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int c = 0; c < BS; ++c) xs[k0 + c] = xv[c];
+    }
+    for (int j = tid; j < k0; j += NT) {
+      double v = t[j];
+#pragma unroll
+      for (int q = 0; q < BS; ++q) v -= Lx[(k0 + q) + (size_t)m * j] * xv[q];
+      t[j] = v;
+    }
     __syncthreads();
   }
-  for (int i = tid; i < npiv; i += NT) xp[(size_t)c0 * bs + i] = xs[i];
+  for (int i = tid; i < npiv; i += NT) xp[(size_t)c0 * BS + i] = xs[i];
+}
+
+// developer ablation switch (timing experiments only; results are invalid when non-zero)
+inline int ablate_flags() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("G2OHIP_ABLATE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
 }
 
 template <int BS>
 void launch_factor_level(const CholPlanDev& P, const int* d_fronts, const long long* d_scratch_off, double* d_scratch,
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
-                         hipStream_t st) {
+                         int lds_idx_ints, int glb_idx_ints, hipStream_t st) {
   if (lds_count > 0) {
-    size_t sh = (size_t)lds_max_m * lds_max_m * sizeof(double);
-    hipLaunchKernelGGL((front_factor_kernel<BS, true>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, d_fronts + lds_begin,
-                       dA, d_scratch, d_scratch_off + lds_begin);
+    const int idx_off = lds_max_m * lds_max_m + 2 * (BS * BS + BS);   // F | diagonal-factor mailboxes | index lists
+    size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(lds_idx_ints + 4) * sizeof(int);
+    static int nthr = getenv("G2OHIP_FACTOR_THREADS") ? atoi(getenv("G2OHIP_FACTOR_THREADS")) : kFactorThreads;
+    hipLaunchKernelGGL((front_factor_kernel<BS, true>), dim3(lds_count), dim3(nthr), sh, st, P, d_fronts + lds_begin,
+                       dA, d_scratch, d_scratch_off + lds_begin, idx_off, ablate_flags());
   }
   if (glb_count > 0) {
-    hipLaunchKernelGGL((front_factor_kernel<BS, false>), dim3(glb_count), dim3(kFactorThreadsGlobal), 0, st, P,
-                       d_fronts + glb_begin, dA, d_scratch, d_scratch_off + glb_begin);
+    const int idx_off = 2 * (BS * BS + BS);
+    size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(glb_idx_ints + 4) * sizeof(int);
+    hipLaunchKernelGGL((front_factor_kernel<BS, false>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P,
+                       d_fronts + glb_begin, dA, d_scratch, d_scratch_off + glb_begin, idx_off, ablate_flags());
   }
 }
 
@@ -825,15 +1174,15 @@ void SparseCholesky::factor(const double* dA, hipStream_t st) {
     switch (bs_) {
       case 3:
         launch_factor_level<3>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                               LL.glb_begin, LL.glb_count, st);
+                               LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
         break;
       case 6:
         launch_factor_level<6>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                               LL.glb_begin, LL.glb_count, st);
+                               LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
         break;
       case 7:
         launch_factor_level<7>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                               LL.glb_begin, LL.glb_count, st);
+                               LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
         break;
       default:
         throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
@@ -855,19 +1204,27 @@ void SparseCholesky::solve(const double* d_b, double* d_x, hipStream_t st) {
     const int* fl = d_level_fronts.p + LL.lds_begin;
     bool panel = (size_t)LL.max_panel * 8 <= panel_limit;
     int cap = panel ? LL.max_panel : 0;
-    size_t sh = ((size_t)cap + 2 * (size_t)LL.max_m + 8) * sizeof(double);
     int nthreads = LL.max_m <= 64 ? 64 : (LL.max_m <= 128 ? 128 : 256);
-    if (fwd) {
-      if (panel)
-        hipLaunchKernelGGL((front_forward_kernel<true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, bs_, d_xp.p, d_y.p, cap);
-      else
-        hipLaunchKernelGGL((front_forward_kernel<false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, bs_, d_xp.p, d_y.p, cap);
-    } else {
-      if (panel)
-        hipLaunchKernelGGL((front_backward_kernel<true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, bs_, d_y.p, d_xp.p, cap);
-      else
-        hipLaunchKernelGGL((front_backward_kernel<false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, bs_, d_y.p, d_xp.p, cap);
+    size_t sh = ((size_t)cap + 2 * (size_t)LL.max_m + nthreads + 8) * sizeof(double);
+#define G2OHIP_SOLVE_LAUNCH(BS_)                                                                                              \
+  if (fwd) {                                                                                                                  \
+    if (panel)                                                                                                                \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_xp.p, d_y.p, cap);  \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_xp.p, d_y.p, cap); \
+  } else {                                                                                                                    \
+    if (panel)                                                                                                                \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_y.p, d_xp.p, cap); \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_y.p, d_xp.p, cap); \
+  }
+    switch (bs_) {
+      case 3: G2OHIP_SOLVE_LAUNCH(3) break;
+      case 6: G2OHIP_SOLVE_LAUNCH(6) break;
+      case 7: G2OHIP_SOLVE_LAUNCH(7) break;
+      default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
     }
+#undef G2OHIP_SOLVE_LAUNCH
   };
   // forward: d_xp holds the permuted rhs, y receives the pivot solutions
   for (size_t l = 0; l < launches_.size(); ++l) run(launches_[l], true);
@@ -880,6 +1237,26 @@ void SparseCholesky::solve(const double* d_b, double* d_x, hipStream_t st) {
 bool SparseCholesky::failed(hipStream_t st) {
   int h = 0;
   d_status.download(&h, 1, st);
+  if (ablate_flags() & 64) {
+    static int once = 0;
+    if (once++ == 3) {   // print one steady-state iteration: per-level phase stamps of block 0 (100 MHz ticks -> us)
+      std::vector<long long> d(16 * 64 * 3);
+      d_dbg.download(d.data(), d.size(), st);
+      for (int k = 0; k < 64; ++k) {
+        const long long* r = &d[16 * k];
+        if (!r[0]) continue;
+        fprintf(stderr, "[dbg] slot %2d m=%3lld :", k, r[15]);
+        for (int q = 1; q < 8 && r[q]; ++q) fprintf(stderr, " %.2f", (double)(r[q] - r[q - 1]) * 0.01);
+        fprintf(stderr, "  us | w0:");
+        const long long* a = &d[16 * 64 + 16 * k];
+        for (int q = 1; q < 8 && a[q]; ++q) fprintf(stderr, " %.2f", (double)(a[q] - a[q - 1]) * 0.01);
+        fprintf(stderr, " | w1:");
+        const long long* b = &d[2 * 16 * 64 + 16 * k];
+        for (int q = 1; q < 8 && b[q]; ++q) fprintf(stderr, " %.2f", (double)(b[q] - b[q - 1]) * 0.01);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
   return h != 0;
 }
 
