@@ -105,6 +105,7 @@ class BlockSolver {
   DevBuf<double> d_Hpp, d_Hpl, d_Hll, d_Hschur, d_Dinv, d_db, d_b, d_x, d_bschur, d_bkP, d_bkL, d_red;
   DevBuf<int> d_pp_diag, d_pl_colptr, d_pl_row, d_pl_lm;
   DevBuf<int> d_hs_src;                    // Hschur block -> Hpp block id or -1
+  DevBuf<int> d_hs_diag;                   // Hschur block -> pose index when diagonal, else -1
   DevBuf<int> d_sc_ptr, d_sc_q1, d_sc_q2;  // Hschur block contributor pairs (Hpl block ids)
   DevBuf<int> d_plr_ptr, d_plr_blk;        // Hpl blocks by pose row
   // multiply_hessian pattern

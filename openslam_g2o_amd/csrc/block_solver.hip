@@ -23,6 +23,37 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+// N doubles through 16-byte global loads (addresses are 8-byte aligned at least; gfx950 global loads
+// only need dword alignment)
+typedef double dbl2_u __attribute__((ext_vector_type(2), aligned(8)));
+template <int N>
+__device__ __forceinline__ void load_vec(const double* __restrict__ p, double (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) {
+    const dbl2_u t = *reinterpret_cast<const dbl2_u*>(p + i);
+    v[i] = t.x;
+    v[i + 1] = t.y;
+  }
+  if (N & 1) v[N - 1] = p[N - 1];
+}
+template <int N>
+__device__ __forceinline__ void store_vec(double* __restrict__ p, const double (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) {
+    dbl2_u t;
+    t.x = v[i];
+    t.y = v[i + 1];
+    *reinterpret_cast<dbl2_u*>(p + i) = t;
+  }
+  if (N & 1) p[N - 1] = v[N - 1];
+}
+// blockIdx -> logical block so that consecutive logical blocks share an XCD (and its L2):
+// the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md), speed only.
+__device__ __forceinline__ int xcd_swizzle(int b, int nblocks) {
+  const int per = nblocks >> 3;
+  return (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;
+}
+
 // rho'(e2) of the robust kernel (Huber: robust_kernel_impl.cpp:65-78); 1 without kernel
 __device__ __forceinline__ double robust_weight(int kind, double delta, double e2) {
   if (kind == 1) {
@@ -67,12 +98,9 @@ __global__ void __launch_bounds__(kThreads) assemble_vertex_kernel(int nV, const
     const double* Op = omega + e * (D * D);
     const double* rp = err + e * D;
     double J[D * DV], O[D * D], r[D], Or[D];
-#pragma unroll
-    for (int i = 0; i < D * DV; ++i) J[i] = Jp[i];
-#pragma unroll
-    for (int i = 0; i < D * D; ++i) O[i] = Op[i];
-#pragma unroll
-    for (int i = 0; i < D; ++i) r[i] = rp[i];
+    load_vec<D * DV>(Jp, J);
+    load_vec<D * D>(Op, O);
+    load_vec<D>(rp, r);
     double e2 = 0.0;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -150,11 +178,10 @@ __global__ void __launch_bounds__(kThreads) assemble_offdiag_kernel(int nDst, co
     const double* Lp = tr ? (J1 + e * (D * DR)) : (J0 + e * (D * DR));
     const double* Rp = tr ? (J0 + e * (D * DC)) : (J1 + e * (D * DC));
     const double* Op = omega + e * (D * D);
-    double O[D * D], Lm[D * DR];
-#pragma unroll
-    for (int i = 0; i < D * D; ++i) O[i] = Op[i];
-#pragma unroll
-    for (int i = 0; i < D * DR; ++i) Lm[i] = Lp[i];
+    double O[D * D], Lm[D * DR], Rm[D * DC];
+    load_vec<D * D>(Op, O);
+    load_vec<D * DR>(Lp, Lm);
+    load_vec<D * DC>(Rp, Rm);
     double w = 1.0;
     if (kind != 0) {
       const double* rp = err + e * D;
@@ -175,7 +202,7 @@ __global__ void __launch_bounds__(kThreads) assemble_offdiag_kernel(int nDst, co
       for (int i = 0; i < D; ++i) {
         double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < D; ++j) s += O[i + D * j] * Rp[j + D * c];
+        for (int j = 0; j < D; ++j) s += O[i + D * j] * Rm[j + D * c];
         OR[i] = w * s;
       }
 #pragma unroll
@@ -188,8 +215,13 @@ __global__ void __launch_bounds__(kThreads) assemble_offdiag_kernel(int nDst, co
     }
   }
   double* Hd = H + (size_t)dst[t] * (DR * DC);
+  if (accumulate) {
+    double old[DR * DC];
+    load_vec<DR * DC>(Hd, old);
 #pragma unroll
-  for (int i = 0; i < DR * DC; ++i) Hd[i] = accumulate ? Hd[i] + acc[i] : acc[i];
+    for (int i = 0; i < DR * DC; ++i) acc[i] += old[i];
+  }
+  store_vec<DR * DC>(Hd, acc);
 }
 
 // chi2 partial sums: sum_e rho(e' Omega e)  (sparse_optimizer.cpp:100-114)
@@ -323,32 +355,50 @@ __global__ void __launch_bounds__(kThreads) landmark_inverse_kernel(int nL, cons
   }
 }
 
-// K5+K7: Hschur(i1,i2) = Hpp(i1,i2) - sum_lm (B_i1 Dinv) B_i2'   (block_solver.hpp:373-431),
-// destination-major over the contributor pairs of each Hschur block, G lanes per block.
+// K5+K7+K8: Hschur(i1,i2) = Hpp(i1,i2) - sum_lm (B_i1 Dinv) B_i2'   (block_solver.hpp:373-431),
+// destination-major over the contributor pairs of each Hschur block, G lanes per block.  The
+// contributor list of a DIAGONAL block (i,i) is exactly pose row i of Hpl, so the reduced right-hand
+// side bschur_i = b_i - sum_lm B_i Dinv b_lm (block_solver.hpp:412,435-439) is accumulated in the
+// same sweep (diag_pose[d] = i, or -1 for off-diagonal blocks).
 template <int PD, int LD, int G>
 __global__ void __launch_bounds__(kThreads) schur_blocks_kernel(int nDst, const int* __restrict__ sc_ptr, const int* __restrict__ sc_q1,
                                     const int* __restrict__ sc_q2, const int* __restrict__ pl_lm, const double* __restrict__ Hpl,
                                     const double* __restrict__ Dinv, const int* __restrict__ hs_src, const double* __restrict__ Hpp,
-                                    double* __restrict__ Hs) {
-  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+                                    double* __restrict__ Hs, const int* __restrict__ diag_pose, const double* __restrict__ b,
+                                    const double* __restrict__ bl, double* __restrict__ bschur) {
+  const int gt = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const int d = gt / G, g = gt % G;
   const bool active = d < nDst;
   double acc[PD * PD];
+  double cacc[PD];
   const int src = active ? hs_src[d] : -1;
+  const int dpose = active ? diag_pose[d] : -1;
+  if (g == 0 && src >= 0) load_vec<PD * PD>(Hpp + (size_t)src * PD * PD, acc);
+  else {
 #pragma unroll
-  for (int i = 0; i < PD * PD; ++i) acc[i] = (g == 0 && src >= 0) ? Hpp[(size_t)src * PD * PD + i] : 0.0;
+    for (int i = 0; i < PD * PD; ++i) acc[i] = 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < PD; ++r) cacc[r] = 0.0;
   const int k0 = active ? sc_ptr[d] : 0, k1 = active ? sc_ptr[d + 1] : 0;
+  // software pipeline on the index loads: (q1, q2, lm) of the next contributor are fetched while the
+  // current one is being multiplied, so each iteration pays one dependent memory round trip, not three
+  int nq1 = 0, nq2 = 0, nlm = 0;
+  if (k0 + g < k1) {
+    nq1 = sc_q1[k0 + g];
+    nq2 = sc_q2[k0 + g];
+    nlm = pl_lm[nq1];
+  }
   for (int k = k0 + g; k < k1; k += G) {
-    const int q1 = sc_q1[k], q2 = sc_q2[k];
-    const int lm = pl_lm[q1];
-    const double* B1 = Hpl + (size_t)q1 * PD * LD;
-    const double* B2 = Hpl + (size_t)q2 * PD * LD;
-    const double* Dv = Dinv + (size_t)lm * LD * LD;
+    const int q1 = nq1, q2 = nq2, lm = nlm;
+    if (k + G < k1) {
+      nq1 = sc_q1[k + G];
+      nq2 = sc_q2[k + G];
+      nlm = pl_lm[nq1];
+    }
     double W[PD * LD], Bj[PD * LD], Di[LD * LD];
-#pragma unroll
-    for (int i = 0; i < LD * LD; ++i) Di[i] = Dv[i];
-#pragma unroll
-    for (int i = 0; i < PD * LD; ++i) Bj[i] = B1[i];
+    load_vec<LD * LD>(Dinv + (size_t)lm * LD * LD, Di);
+    load_vec<PD * LD>(Hpl + (size_t)q1 * PD * LD, Bj);
 #pragma unroll
     for (int c = 0; c < LD; ++c)
 #pragma unroll
@@ -358,8 +408,16 @@ __global__ void __launch_bounds__(kThreads) schur_blocks_kernel(int nDst, const 
         for (int kk = 0; kk < LD; ++kk) t += Bj[r + PD * kk] * Di[kk + LD * c];
         W[r + PD * c] = t;
       }
+    if (dpose >= 0) {   // q1 == q2: coeff += B (Dinv b_l) = W b_l
+      double bv[LD];
+      load_vec<LD>(bl + (size_t)lm * LD, bv);
 #pragma unroll
-    for (int i = 0; i < PD * LD; ++i) Bj[i] = B2[i];
+      for (int c = 0; c < LD; ++c)
+#pragma unroll
+        for (int r = 0; r < PD; ++r) cacc[r] += W[r + PD * c] * bv[c];
+    } else {
+      load_vec<PD * LD>(Hpl + (size_t)q2 * PD * LD, Bj);
+    }
 #pragma unroll
     for (int c = 0; c < PD; ++c)
 #pragma unroll
@@ -373,16 +431,22 @@ __global__ void __launch_bounds__(kThreads) schur_blocks_kernel(int nDst, const 
   if (G > 1) {
 #pragma unroll
     for (int i = 0; i < PD * PD; ++i) acc[i] = group_sum<G>(acc[i]);
+#pragma unroll
+    for (int r = 0; r < PD; ++r) cacc[r] = group_sum<G>(cacc[r]);
   }
   if (!active) return;
   double* out = Hs + (size_t)d * PD * PD;
   if (G == 1) {
-#pragma unroll
-    for (int i = 0; i < PD * PD; ++i) out[i] = acc[i];
+    store_vec<PD * PD>(out, acc);
   } else {
 #pragma unroll
     for (int i = 0; i < PD * PD; ++i)
       if (i % G == g) out[i] = acc[i];
+  }
+  if (dpose >= 0) {
+#pragma unroll
+    for (int r = 0; r < PD; ++r)
+      if (G == 1 || (r % G) == g) bschur[(size_t)dpose * PD + r] = b[(size_t)dpose * PD + r] - cacc[r];
   }
 }
 
@@ -432,14 +496,14 @@ __global__ void __launch_bounds__(kThreads) back_substitute_kernel(int nL, const
   for (int q = pl_colptr[lm]; q < pl_colptr[lm + 1]; ++q) {
     const double* B = Hpl + (size_t)q * PD * LD;
     const double* xs = xp + (size_t)pl_row[q] * PD;
-    double xv[PD];
-#pragma unroll
-    for (int r = 0; r < PD; ++r) xv[r] = xs[r];
+    double xv[PD], Bm[PD * LD];
+    load_vec<PD>(xs, xv);
+    load_vec<PD * LD>(B, Bm);
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
       double t = 0.0;
 #pragma unroll
-      for (int r = 0; r < PD; ++r) t += B[r + PD * j] * xv[r];
+      for (int r = 0; r < PD; ++r) t += Bm[r + PD * j] * xv[r];
       c[j] -= t;
     }
   }
@@ -864,6 +928,11 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     }
     n_sc_ = (long)pair_dst.size();
     d_hs_src.upload(hs_src, st_);
+    {
+      std::vector<int> hs_diag(hs_nnzb, -1);
+      for (int c = 0; c < nP; ++c) hs_diag[find_block(hs_colptr, hs_row, c, c)] = c;
+      d_hs_diag.upload(hs_diag, st_);
+    }
     d_sc_ptr.upload(sc_ptr, st_);
     d_sc_q1.upload(q1v, st_);
     d_sc_q2.upload(q2v, st_);
@@ -1101,7 +1170,8 @@ void BlockSolver::solve_schur() {
   const size_t sizeP = (size_t)nP_ * p_;
   const int hs_nnzb = (int)hs_row.size();
   const int G = pick_group((double)n_sc_ / std::max(1, hs_nnzb));
-  const int Gr = pick_group((double)pl_row.size() / std::max(1, nP_));
+#define G2OHIP_SCHUR_ARGS hs_nnzb, d_sc_ptr.p, d_sc_q1.p, d_sc_q2.p, d_pl_lm.p, d_Hpl.p, d_Dinv.p, d_hs_src.p, d_Hpp.p, d_Hschur.p, \
+                          d_hs_diag.p, d_b.p, d_b.p + sizeP, d_bschur.p
 #define G2OHIP_SCHUR(P_, L_)                                                                                                   \
   if (p_ == P_ && l_ == L_) {                                                                                                  \
     prof.begin(KernelProf::kLmInverse, st_);                                                                                   \
@@ -1110,26 +1180,15 @@ void BlockSolver::solve_schur() {
     prof.end(KernelProf::kLmInverse, st_);                                                                                     \
     prof.begin(KernelProf::kSchurBlocks, st_);                                                                                 \
     if (G == 1)                                                                                                                \
-      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 1>), dim3(grid_for((size_t)hs_nnzb)), dim3(kThreads), 0, st_, hs_nnzb,    \
-                         d_sc_ptr.p, d_sc_q1.p, d_sc_q2.p, d_pl_lm.p, d_Hpl.p, d_Dinv.p, d_hs_src.p, d_Hpp.p, d_Hschur.p);     \
+      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 1>), dim3(grid_for((size_t)hs_nnzb)), dim3(kThreads), 0, st_,             \
+                         G2OHIP_SCHUR_ARGS);                                                                                   \
     else if (G == 4)                                                                                                           \
-      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 4>), dim3(grid_for((size_t)hs_nnzb * 4)), dim3(kThreads), 0, st_, hs_nnzb, \
-                         d_sc_ptr.p, d_sc_q1.p, d_sc_q2.p, d_pl_lm.p, d_Hpl.p, d_Dinv.p, d_hs_src.p, d_Hpp.p, d_Hschur.p);     \
+      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 4>), dim3(grid_for((size_t)hs_nnzb * 4)), dim3(kThreads), 0, st_,         \
+                         G2OHIP_SCHUR_ARGS);                                                                                   \
     else                                                                                                                       \
-      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 8>), dim3(grid_for((size_t)hs_nnzb * 8)), dim3(kThreads), 0, st_, hs_nnzb, \
-                         d_sc_ptr.p, d_sc_q1.p, d_sc_q2.p, d_pl_lm.p, d_Hpl.p, d_Dinv.p, d_hs_src.p, d_Hpp.p, d_Hschur.p);     \
+      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 8>), dim3(grid_for((size_t)hs_nnzb * 8)), dim3(kThreads), 0, st_,         \
+                         G2OHIP_SCHUR_ARGS);                                                                                   \
     prof.end(KernelProf::kSchurBlocks, st_);                                                                                   \
-    prof.begin(KernelProf::kSchurRhs, st_);                                                                                    \
-    if (Gr == 1)                                                                                                               \
-      hipLaunchKernelGGL((schur_rhs_kernel<P_, L_, 1>), dim3(grid_for((size_t)nP_)), dim3(kThreads), 0, st_, nP_, d_plr_ptr.p,   \
-                         d_plr_blk.p, d_pl_lm.p, d_Hpl.p, d_db.p, d_b.p, d_bschur.p);                                          \
-    else if (Gr == 4)                                                                                                          \
-      hipLaunchKernelGGL((schur_rhs_kernel<P_, L_, 4>), dim3(grid_for((size_t)nP_ * 4)), dim3(kThreads), 0, st_, nP_, d_plr_ptr.p, \
-                         d_plr_blk.p, d_pl_lm.p, d_Hpl.p, d_db.p, d_b.p, d_bschur.p);                                          \
-    else                                                                                                                       \
-      hipLaunchKernelGGL((schur_rhs_kernel<P_, L_, 8>), dim3(grid_for((size_t)nP_ * 8)), dim3(kThreads), 0, st_, nP_, d_plr_ptr.p, \
-                         d_plr_blk.p, d_pl_lm.p, d_Hpl.p, d_db.p, d_b.p, d_bschur.p);                                          \
-    prof.end(KernelProf::kSchurRhs, st_);                                                                                      \
   } else
   G2OHIP_SCHUR(6, 3)
   G2OHIP_SCHUR(3, 2)

@@ -566,9 +566,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     LL.lds_idx_ints = LL.glb_idx_ints = 0;
     for (int k = LL.lds_begin; k < LL.glb_begin + LL.glb_count; ++k) {
       const FrontRec& R = recs[S.level_fronts[k]];
-      int idx = 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt;
-      if (k < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, idx);
-      else LL.glb_idx_ints = std::max(LL.glb_idx_ints, idx);
+      if (k < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt);
+      else LL.glb_idx_ints = std::max(LL.glb_idx_ints, 2 * R.asm_cnt);
     }
   }
   d_rec.upload(recs, st);
@@ -690,8 +689,12 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
   int* s_q = reinterpret_cast<int*>(smem + idx_off_doubles);
   const int na = rec.asm_cnt;
   int* s_pos = s_q + na;
-  int* s_cmap = s_pos + na;
-  int* s_tri = s_cmap + rec.cmap_cnt;
+  // LDS-resident fronts stage the child maps and the triangle table; scratch-slab (large) fronts
+  // read them from global memory (they can exceed the LDS)
+  int* s_cmap_l = s_pos + na;
+  int* s_tri_l = s_cmap_l + rec.cmap_cnt;
+  const int* s_cmap = USE_LDS ? s_cmap_l : (P.cmap + rec.cmap_off);
+  const int* s_tri = USE_LDS ? s_tri_l : P.tri;
   const int tid = threadIdx.x, NT = blockDim.x;
   long long* dbg = (ablate & 64) && blockIdx.x == 0 && tid == 0 ? P.dbg + 16 * P.dbg_slot[0] : nullptr;
   int dbg_k = 0;
@@ -719,8 +722,10 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
     s_q[t] = P.asm_q[rec.asm_off + t];
     s_pos[t] = P.asm_pos[rec.asm_off + t];
   }
-  for (int t = tid; t < rec.cmap_cnt; t += NT) s_cmap[t] = P.cmap[rec.cmap_off + t];
-  for (int t = tid; t < rec.tri_cnt; t += NT) s_tri[t] = P.tri[t];
+  if (USE_LDS) {
+    for (int t = tid; t < rec.cmap_cnt; t += NT) s_cmap_l[t] = P.cmap[rec.cmap_off + t];
+    for (int t = tid; t < rec.tri_cnt; t += NT) s_tri_l[t] = P.tri[t];
+  }
   for (int i = tid; i < m * m; i += NT) F[i] = 0.0;
   __syncthreads();
   G2OHIP_STAMP();

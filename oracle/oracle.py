@@ -385,3 +385,45 @@ def ba_oplus(cams, pts, cam_hidx, pt_hidx_local, x, sizeP):
     L.orc_ba_oplus_cams(len(cam_hidx), _dp(cams), _ip(cam_hidx), _dp(xp))
     L.orc_ba_oplus_pts(len(pt_hidx_local), _dp(pts), _ip(pt_hidx_local), _dp(xl))
     return cams, pts
+
+
+# ---- 3-D pose graphs (VertexSE3 / EdgeSE3) ------------------------------------------------
+def _se3_sigs():
+    L = lib()
+    if not getattr(L, "_se3_ready", False):
+        L.orc_se3_from_qt.argtypes = [C.c_int, c_dbl_p, C.c_int, c_dbl_p]
+        L.orc_se3_edges.argtypes = [C.c_int, c_dbl_p, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]
+        L.orc_se3_oplus.argtypes = [C.c_int, c_dbl_p, c_int_p, c_dbl_p]
+        L._se3_ready = True
+    return L
+
+
+def se3_from_qt(qt, normalize=False):
+    """[n][7] (x y z qx qy qz qw) -> [n][12] isometries (R column-major | t)."""
+    L = _se3_sigs()
+    qt = _f64(qt)
+    T = np.zeros((len(qt), 12))
+    L.orc_se3_from_qt(len(qt), _dp(qt), int(normalize), _dp(T))
+    return T
+
+
+def se3_edges(poses, vi, vj, meas, jac=True):
+    L = _se3_sigs()
+    poses, vi, vj, meas = _f64(poses), _i32(vi), _i32(vj), _f64(meas)
+    n = len(vi)
+    err = np.zeros((n, 6))
+    if jac:
+        J0 = np.zeros((n, 36))
+        J1 = np.zeros((n, 36))
+        L.orc_se3_edges(n, _dp(poses), _ip(vi), _ip(vj), _dp(meas), _dp(J0), _dp(J1), _dp(err))
+        return J0, J1, err
+    L.orc_se3_edges(n, _dp(poses), _ip(vi), _ip(vj), _dp(meas), None, None, _dp(err))
+    return err
+
+
+def se3_oplus(poses, hidx, x):
+    L = _se3_sigs()
+    poses = _f64(poses).copy()
+    hidx, x = _i32(hidx), _f64(x)
+    L.orc_se3_oplus(len(hidx), _dp(poses), _ip(hidx), _dp(x))
+    return poses

@@ -10,6 +10,9 @@ Fixtures are data only -- parsed graph inputs and expected outputs:
     (x, lnz, chi2), with and without LM damping, plus a 5-iteration GN chi2 trajectory.
     The expected x comes from the REFERENCE's own compiled code
     (cs_amd block ordering + csparse_extension::cs_cholsolsymb, oracle/_ref).
+  * sphere2200.npz : the same for data/3d/sphere/sphere_bignoise_vertex3.g2o (config 2; the
+    bundled file has 2 200 vertices / 8 647 EDGE_SE3:QUAT): first-iteration x (plain and damped)
+    from the reference CSparse path, lnz, and the chi2 of three damped iterations.
   * ba_small.npz : expected outputs for the deterministic synthetic 20-pose / 200-point BA
     problem (inputs are regenerated from the seed): x from the reference CSparse path on
     the Schur-reduced system and from a dense solve of the full system.
@@ -92,8 +95,50 @@ def ba_small():
     print("ba_small: chi2", chi2, "lnz", lnz)
 
 
+def sphere():
+    """Config 2 input: data/3d/sphere/sphere_bignoise_vertex3.g2o (2 200 VERTEX_SE3:QUAT, 8 647
+    EDGE_SE3:QUAT), vertex 0 fixed, BlockSolver_6_3 semantics without Schur."""
+    g = g2o_io.read_g2o("/root/reference/data/3d/sphere/sphere_bignoise_vertex3.g2o")
+    nv = len(g["ids"])
+    h, nP = g2o_io.hessian_index(nv, [0])
+    om = g["info"].transpose(0, 2, 1).reshape(-1, 36)
+    poses = O.se3_from_qt(g["estimates"], normalize=False)          # VertexSE3::read: fromVectorQT
+    Z = O.se3_from_qt(g["meas"], normalize=True)                    # EdgeSE3::read normalises the quaternion
+    out = dict(estimates=g["estimates"], vi=g["vi"], vj=g["vj"], meas=g["meas"],
+               info_upper=np.stack([g["info"][:, i, j] for i in range(6) for j in range(i, 6)], axis=1))
+    chi_traj = []
+    lam = None
+    for it in range(3):
+        J0, J1, err = O.se3_edges(poses, g["vi"], g["vj"], Z)
+        s = O.OracleSolver(6, 3, nP, 0, schur=False)
+        k = s.add_edge_set(6, h[g["vi"]], h[g["vj"]])
+        s.set_dims(k, 6, 6)
+        s.build_structure()
+        s.set_edge_data(k, J0, J1, om, err)
+        s.build_system()
+        chi_traj.append(s.chi2())
+        cp, row = s.pattern("pp")
+        if it == 0:
+            ok, x, lnz, P = O.ref_solve_blocks(nP, 6, cp, row, s.values("Hpp"), s.b())
+            assert ok
+            lam = 1e-5 * s.max_diagonal()
+            out.update(x_gn0=x, lnz_block_amd=lnz, block_perm=P, b0=s.b(), nnzb=len(row), lambda0=lam)
+        # damped steps (plain GN diverges on this very noisy initial guess): x = (H + lam I)^-1 b
+        s.set_lambda(lam, True)
+        ok2, x2, _, _ = O.ref_solve_blocks(nP, 6, cp, row, s.values("Hpp"), s.b())
+        s.restore_diagonal()
+        assert ok2
+        if it == 0:
+            out["x_lm0"] = x2
+        poses = O.se3_oplus(poses, h, x2)
+    out["chi2_lm"] = np.asarray(chi_traj)
+    np.savez_compressed(os.path.join(OUT, "sphere2200.npz"), **out)
+    print("sphere: nP", nP, "nnzb", out["nnzb"], "lnz", out["lnz_block_amd"], "chi2", chi_traj)
+
+
 if __name__ == "__main__":
     O.build()
     assert O.ref() is not None, "oracle/_ref missing: run `make -C oracle` where /root/reference exists"
     manhattan()
     ba_small()
+    sphere()

@@ -55,3 +55,22 @@ def manhattan_golden():
 
 def relerr(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def sphere_golden():
+    """Config 2 fixture (sphere, VertexSE3/EdgeSE3): parse results + reference CSparse answers."""
+    g = dict(np.load(os.path.join(GOLD, "sphere2200.npz")))
+    nv = len(g["estimates"])
+    h, nP = g2o_io.hessian_index(nv, [0])
+    ne = len(g["vi"])
+    info = np.zeros((ne, 6, 6))
+    k = 0
+    for i in range(6):
+        for j in range(i, 6):
+            info[:, i, j] = info[:, j, i] = g["info_upper"][:, k]
+            k += 1
+    g["omega"] = info.transpose(0, 2, 1).reshape(-1, 36).copy()
+    g["hidx"], g["nP"] = h, nP
+    g["poses"] = O.se3_from_qt(g["estimates"], normalize=False)
+    g["Z"] = O.se3_from_qt(g["meas"], normalize=True)
+    return g

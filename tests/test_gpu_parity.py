@@ -265,3 +265,40 @@ def test_large_scale_properties():
     assert relerr(s.x(), 2.0 * x) < 1e-9 and relerr(s.b(), 2.0 * b) < 1e-13
     st = s.stats()
     assert st["hessianPoseDimension"] == 6 * pr["nP"] and st["choleskyNNZ"] > 0
+
+
+def test_sphere_golden_no_schur():
+    """Config 2 input (sphere, 2 200 VertexSE3 / 8 647 EdgeSE3, BlockSolver_6_3 semantics, fp64,
+    1 GPU): first-iteration x against the reference CSparse golden vectors, then three damped
+    iterations reproduce the reference chi2 trajectory.  The nested-dissection fronts of this graph
+    exceed the LDS budget, so the HBM-scratch front path is exercised too."""
+    capi = _capi()
+    from tests.helpers import sphere_golden
+    g = sphere_golden()
+    s = capi.HipBlockSolver(6, 3, 0)
+    k = s.addEdgeSet(6, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+    s.buildStructure(g["nP"], 0, False)
+    assert s.nnzb(capi.HPP) == 10843
+    poses = g["poses"].copy()
+    lam = float(g["lambda0"])
+    for it in range(3):
+        J0, J1, err = O.se3_edges(poses, g["vi"], g["vj"], g["Z"])
+        s.setEdgeData(k, J0, J1, g["omega"], err)
+        s.buildSystem()
+        assert abs(s.chi2() - g["chi2_lm"][it]) <= 1e-6 * g["chi2_lm"][it]
+        if it == 0:
+            assert relerr(s.b(), g["b0"]) < TOL_MAT
+            assert abs(s.maxDiagonal() * 1e-5 - lam) <= 1e-12 * lam
+            assert s.solve()
+            assert relerr(s.x(), g["x_gn0"]) < 1e-7
+        s.setLambda(lam, True)
+        assert s.solve()
+        x = s.x()
+        if it == 0:
+            assert relerr(x, g["x_lm0"]) < 1e-8
+        r = s.multiplyHessian(x) - s.b()
+        assert np.abs(r).max() <= TOL_RES * np.abs(s.b()).max()
+        s.restoreDiagonal()
+        poses = O.se3_oplus(poses, g["hidx"], x)
+    st = s.stats()
+    assert st["maxFrontDim"] > 90          # large separators: scratch-slab fronts were used

@@ -112,3 +112,50 @@ def test_huber_weights_and_not_pd():
     # strongly negative damping makes the system indefinite -> solve() == false (csparse_helper.cpp:136)
     o.set_lambda(-10.0 * o.max_diagonal(), True)
     assert not o.solve()
+
+
+def test_sphere_golden_reference_csparse():
+    """Config 2 (sphere, BlockSolver_6_3 without Schur): oracle == reference CSparse golden vector."""
+    from tests.helpers import sphere_golden
+    g = sphere_golden()
+    J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
+    s = O.OracleSolver(6, 3, g["nP"], 0, schur=False)
+    k = s.add_edge_set(6, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+    s.set_dims(k, 6, 6)
+    s.build_structure()
+    s.set_edge_data(k, J0, J1, g["omega"], err)
+    s.build_system()
+    assert s.pattern("pp")[1].size == int(g["nnzb"]) == 10843          # SURVEY.md section 8 table
+    assert abs(s.chi2() - g["chi2_lm"][0]) <= 1e-12 * g["chi2_lm"][0]
+    s.set_ordering(2, g["block_perm"])
+    assert s.solve()
+    assert np.array_equal(s.x(), g["x_gn0"]) and s.lnz() == float(g["lnz_block_amd"])
+    s.set_lambda(float(g["lambda0"]), True)
+    assert s.solve()
+    assert np.array_equal(s.x(), g["x_lm0"])
+
+
+def test_se3_jacobian_against_central_differences():
+    """The reference's own check (g2o/types/slam3d/test_slam3d_jacobian.cpp:116-148): analytic
+    EdgeSE3 Jacobian vs central differences, tolerance 1e-6."""
+    rng = np.random.default_rng(0)
+    n = 100
+
+    def rand_iso(n):
+        q = rng.normal(size=(n, 4))
+        q /= np.linalg.norm(q, axis=1)[:, None]
+        return O.se3_from_qt(np.hstack([rng.normal(size=(n, 3)), q]))
+    poses = np.vstack([rand_iso(n), rand_iso(n)])
+    Z = rand_iso(n)
+    vi = np.arange(n, dtype=np.int32)
+    vj = vi + n
+    J0, J1, _ = O.se3_edges(poses, vi, vj, Z)
+    hid = np.arange(2 * n, dtype=np.int32)
+    h = 1e-6
+    for side, J in ((0, J0), (1, J1)):
+        for c in range(6):
+            x = np.zeros((2 * n, 6))
+            x[(vi if side == 0 else vj), c] = h
+            ep = O.se3_edges(O.se3_oplus(poses, hid, x.reshape(-1)), vi, vj, Z, jac=False)
+            em = O.se3_edges(O.se3_oplus(poses, hid, -x.reshape(-1)), vi, vj, Z, jac=False)
+            assert np.abs((ep - em) / (2 * h) - J.reshape(n, 6, 6)[:, c, :]).max() < 1e-6
