@@ -169,9 +169,20 @@ def main():
                                 achieved_GBs=(kb.get(name, 0) / 1e9 / avg) if avg > 0 else 0.0)
     dom = max(per_kernel.items(), key=lambda kv: kv[1]["avg_ms"] * kv[1]["launches_per_step"])
     dname, dk = dom
+    # HBM bytes per launch from the PMC counters: collected by a separate rocprofv3 --pmc pass of this
+    # same command (profiles/r1_pmc_traffic.json, recipe in its _note); null when that file is absent
+    # or the workload differs from the profiled one.
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if os.path.exists(pmc_path) and world == 1 and (P, L) == (100000, 1000000):
+        pmc = json.load(open(pmc_path)).get(dname)
+        if pmc:
+            traffic = pmc["hbm_bytes_per_step"]
     roofline = dict(kernel=dname, bound="hbm", achieved=dk["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=dk["achieved_GBs"] / HBM_PEAK_GBS, traffic=None,
-                    algorithmic_bytes_per_launch=kb.get(dname, 0), avg_launch_ms=dk["avg_ms"])
+                    frac=dk["achieved_GBs"] / HBM_PEAK_GBS, traffic=traffic,
+                    algorithmic_bytes_per_launch=kb.get(dname, 0), avg_launch_ms=dk["avg_ms"],
+                    traffic_source="profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, 2x FETCH correction)"
+                    if traffic else None)
 
     x_gpu = solver.local.x()
     out = {

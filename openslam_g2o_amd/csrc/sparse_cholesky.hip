@@ -450,7 +450,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   for (int f = 0; f < nf; ++f) {
     long long m = (long long)(S.f_ns[f] + S.f_nb[f]) * bs, np = (long long)S.f_ns[f] * bs, nbs = (long long)S.f_nb[f] * bs;
     S.L_off[f] = S.L_total;
-    S.L_total += m * np;
+    S.L_total += m * np + np;   // panel + reciprocals of its diagonal (used by the triangular sweeps)
     S.U_off[f] = S.U_total;
     S.U_total += (long long)S.f_nb[f] * (S.f_nb[f] + 1) / 2 * bs * bs;   // lower-triangular blocks, packed by block column
     S.w_off[f] = S.w_total;
@@ -505,7 +505,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         int f = S.level_fronts[k];
         int m = (S.f_ns[f] + S.f_nb[f]) * bs;
         LL.max_m = std::max(LL.max_m, m);
-        LL.max_panel = std::max(LL.max_panel, m * S.f_ns[f] * bs);
+        LL.max_panel = std::max(LL.max_panel, m * S.f_ns[f] * bs + S.f_ns[f] * bs);
         int idx = 2 * (S.asm_off[f + 1] - S.asm_off[f]);
         for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) idx += S.f_nb[S.children[ch]];
         if (k < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, idx);
@@ -864,7 +864,7 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
   for (int kb = 0; kb < ns && !(ablate & 8); ++kb) {
     const int k0 = kb * BS;
     const double* box = sd + (kb & 1) * (BB + BS);
-    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
+    if (dbgA && ka < 14) dbgA[ka++] = wall_clock64();
     if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
     double Lk[BS][BS], inv[BS];
 #pragma unroll
@@ -873,7 +873,6 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
 #pragma unroll
       for (int r = 0; r < BS; ++r) Lk[r][c] = (r > c) ? box[r + BS * c] : 0.0;
     }
-    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
     // rows below the diagonal block: x * Lkk' = row
     for (int i = k0 + BS + tid; i < m; i += NT) {
       double x[BS];
@@ -889,10 +888,9 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
 #pragma unroll
       for (int c = 0; c < BS; ++c) F[i + (size_t)ld * (k0 + c)] = x[c];
     }
-    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
+    if (dbgA && ka < 14) dbgA[ka++] = wall_clock64();
     if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
     __syncthreads();
-    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
     if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
     // trailing update with T x T register tiles over the lower triangle (tile coordinates relative
     // to the first trailing row; the first LA(LA+1)/2 table entries are the next diagonal block)
@@ -931,22 +929,22 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
     if (lookahead && tid < 64) {
       if (tid < NLA) update_tile(s_tri[tid]);
       __threadfence_block();   // the wave's own LDS writes are complete before it re-reads the block
-      if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
       diag_factor(kb + 1, sd + ((kb + 1) & 1) * (BB + BS));
-      if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
     } else {
       const int first = lookahead ? NLA + tid - 64 : tid, stride = lookahead ? NT - 64 : NT;
       for (int idx = first; idx < ntiles; idx += stride) update_tile(s_tri[idx]);
       if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
     }
     __syncthreads();
-    if (kb == 0 && dbgA) dbgA[ka++] = wall_clock64();
   }
   G2OHIP_STAMP();
   // ---- write L panel (m x npiv) and the update matrix (packed lower-triangular blocks, row-major)
   double* Lg = P.L + rec.L_off;
   if (!(ablate & 16))
+  {
     for (int t = tid; t < m * npiv; t += NT) Lg[t] = F[t];  // ld == m: identical layout
+    for (int k = tid; k < npiv; k += NT) Lg[(size_t)m * npiv + k] = 1.0 / F[k + (size_t)ld * k];
+  }
   double* Ug = P.U + rec.U_off;
   if (!(ablate & 32)) {
     const int nU = nbd * (nbd + 1) / 2 * BB;
@@ -993,8 +991,9 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const
   double* ys = t + m;
   const double* Lg = P.L + rec.L_off;
   if (PANEL_LDS)
-    for (int i = tid; i < m * npiv; i += NT) Lp[i] = Lg[i];
+    for (int i = tid; i < m * npiv + npiv; i += NT) Lp[i] = Lg[i];
   const double* Lx = PANEL_LDS ? Lp : Lg;
+  const double* Linv = Lx + (size_t)m * npiv;
   // children's update vectors: issue the loads before the first barrier (fast path: <= 2 children
   // whose boundary fits one round), apply them one child at a time (rows may coincide)
   const int nch = rec.child_cnt;
@@ -1039,7 +1038,7 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const
       double v = t[k0 + c];
 #pragma unroll
       for (int q = 0; q < c; ++q) v -= Lx[(k0 + c) + (size_t)m * (k0 + q)] * yv[q];
-      yv[c] = v / Lx[(k0 + c) + (size_t)m * (k0 + c)];
+      yv[c] = v * Linv[k0 + c];
     }
     if (tid == 0) {
 #pragma unroll
@@ -1075,8 +1074,9 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, cons
   double* sp = xs + m;
   const double* Lg = P.L + rec.L_off;
   if (PANEL_LDS)
-    for (int i = tid; i < m * npiv; i += NT) Lp[i] = Lg[i];
+    for (int i = tid; i < m * npiv + npiv; i += NT) Lp[i] = Lg[i];
   const double* Lx = PANEL_LDS ? Lp : Lg;
+  const double* Linv = Lx + (size_t)m * npiv;
   const int* rows = P.rows + P.rows_off[f];
   for (int i = tid; i < m; i += NT)
     t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : xp[(size_t)rows[(i - npiv) / BS] * BS + ((i - npiv) % BS)];
@@ -1116,7 +1116,7 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, cons
       double v = t[k0 + c];
 #pragma unroll
       for (int q = c + 1; q < BS; ++q) v -= Lx[(k0 + q) + (size_t)m * (k0 + c)] * xv[q];
-      xv[c] = v / Lx[(k0 + c) + (size_t)m * (k0 + c)];
+      xv[c] = v * Linv[k0 + c];
     }
     if (tid == 0) {
 #pragma unroll
@@ -1254,7 +1254,7 @@ bool SparseCholesky::failed(hipStream_t st) {
         for (int q = 1; q < 8 && r[q]; ++q) fprintf(stderr, " %.2f", (double)(r[q] - r[q - 1]) * 0.01);
         fprintf(stderr, "  us | w0:");
         const long long* a = &d[16 * 64 + 16 * k];
-        for (int q = 1; q < 8 && a[q]; ++q) fprintf(stderr, " %.2f", (double)(a[q] - a[q - 1]) * 0.01);
+        for (int q = 1; q < 14 && a[q]; ++q) fprintf(stderr, " %.2f", (double)(a[q] - a[q - 1]) * 0.01);
         fprintf(stderr, " | w1:");
         const long long* b = &d[2 * 16 * 64 + 16 * k];
         for (int q = 1; q < 8 && b[q]; ++q) fprintf(stderr, " %.2f", (double)(b[q] - b[q - 1]) * 0.01);
