@@ -37,8 +37,8 @@ def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2):
     kb["assemble_vertex(landmark)"] = E * 8 * (d * l + d * d + d) + L * 8 * (l * l + l)
     kb["assemble_offdiag(Hpl)"] = E * 8 * (d * p + d * l + d * d) + E * 8 * p * l
     kb["landmark_inverse"] = L * 8 * (2 * l * l + 2 * l)
-    kb["schur_blocks"] = E * 8 * p * l + L * 8 * l * l + pp_nnzb * 8 * p * p + S * 8 * p * p
-    kb["schur_rhs"] = E * 8 * p * l + L * 8 * l + 2 * P * 8 * p
+    kb["schur_tiles"] = E * 8 * p * l + L * 8 * (l * l + l) + S * 8 * p * p          # Hpl, Dinv, b_l in; one Hschur worth out
+    kb["schur_reduce"] = pp_nnzb * 8 * p * p + 2 * S * 8 * p * p + 3 * P * 8 * p      # Hpp + partials in, Hschur + bschur out
     kb["back_substitute"] = E * 8 * p * l + L * 8 * (l * l + 2 * l) + P * 8 * p
     n = p * P
     nnz_up = S * p * p  # upper blocks of Hschur (diagonal blocks counted full)
@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--landmarks", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nd-leaf", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="solver option name=value (tuning experiments)")
     args = ap.parse_args()
 
     import torch
@@ -119,6 +120,9 @@ def main():
     lam = 1e-5 * 1.0e6                                  # tau * max diag(H) order of magnitude; fixed for reproducibility
 
     solver = D.ShardedBlockSolver(6, 3, rank=rank, world=world, device=local_rank)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        solver.local.setOption(k_, float(v_))
     shard = solver.setup_ba(prob, torch_device=dev, nd_leaf=args.nd_leaf)
     solver.local.setProfiling(True)
 

@@ -84,6 +84,8 @@ class BlockSolver {
   KernelProf prof;
   SolverTimes times;
   CholOptions chol_opt;
+  size_t schur_tile_bytes = 48 * 1024;     // LDS budget of one Schur tile
+  int schur_group = 0;                     // lanes per destination in the Schur tile kernel (0 = auto)
   const CholStats* chol_stats() const { return chol_ ? &chol_->stats() : nullptr; }
   int p() const { return p_; }
   int l() const { return l_; }
@@ -106,8 +108,13 @@ class BlockSolver {
   DevBuf<int> d_pp_diag, d_pl_colptr, d_pl_row, d_pl_lm;
   DevBuf<int> d_hs_src;                    // Hschur block -> Hpp block id or -1
   DevBuf<int> d_hs_diag;                   // Hschur block -> pose index when diagonal, else -1
-  DevBuf<int> d_sc_ptr, d_sc_q1, d_sc_q2;  // Hschur block contributor pairs (Hpl block ids)
-  DevBuf<int> d_plr_ptr, d_plr_blk;        // Hpl blocks by pose row
+  // Schur tiles: landmark ranges, their destination blocks and LDS-local contributor entries
+  DevBuf<int> d_tile_lm0, d_tile_td0, d_td_diag, d_td_ptr, d_te_pack, d_rd_ptr, d_rd_slot;
+  DevBuf<unsigned short> d_te_lm;
+  DevBuf<double> d_Pd, d_Pr;               // per (tile, destination) partial blocks / rhs
+  int n_tiles_ = 0;
+  long n_td_ = 0;
+  size_t schur_lds_bytes_ = 0;
   // multiply_hessian pattern
   DevBuf<int> d_pp_colptr, d_pp_row;
   long n_sc_ = 0;

@@ -16,10 +16,21 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// Sum over groups of G consecutive lanes (G = 1, 2, 4, 8, 16) with DPP lane permutations: no LDS
+// round trip (ds_bpermute) per step.  Every lane of the group ends up with the total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_permute(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi2, lo2);
+}
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (G >= 2) v += dpp_permute<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (G >= 4) v += dpp_permute<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (G >= 8) v += dpp_permute<0x141>(v);   // row_half_mirror: lane i <-> 7-i inside each 8-lane half row
+  if (G >= 16) v += dpp_permute<0x140>(v);  // row_mirror: lane i <-> 15-i inside each 16-lane row
   return v;
 }
 
@@ -46,6 +57,22 @@ __device__ __forceinline__ void store_vec(double* __restrict__ p, const double (
     *reinterpret_cast<dbl2_u*>(p + i) = t;
   }
   if (N & 1) p[N - 1] = v[N - 1];
+}
+// N doubles out of LDS with 16-byte reads when the block size keeps every block 16-byte aligned
+typedef double dbl2_a __attribute__((ext_vector_type(2), aligned(16)));
+template <int N>
+__device__ __forceinline__ void lds_block(const double* p, double (&v)[N]) {
+  if (N % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+      const dbl2_a t = *reinterpret_cast<const dbl2_a*>(p + i);
+      v[i] = t.x;
+      v[i + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = p[i];
+  }
 }
 // blockIdx -> logical block so that consecutive logical blocks share an XCD (and its L2):
 // the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md), speed only.
@@ -355,132 +382,190 @@ __global__ void __launch_bounds__(kThreads) landmark_inverse_kernel(int nL, cons
   }
 }
 
-// K5+K7+K8: Hschur(i1,i2) = Hpp(i1,i2) - sum_lm (B_i1 Dinv) B_i2'   (block_solver.hpp:373-431),
-// destination-major over the contributor pairs of each Hschur block, G lanes per block.  The
-// contributor list of a DIAGONAL block (i,i) is exactly pose row i of Hpl, so the reduced right-hand
-// side bschur_i = b_i - sum_lm B_i Dinv b_lm (block_solver.hpp:412,435-439) is accumulated in the
-// same sweep (diag_pose[d] = i, or -1 for off-diagonal blocks).
+// K5+K7+K8, pass 1: Schur outer products over a TILE of consecutive landmarks
+//   partial(i1,i2) = sum_{lm in tile} (B_i1 Dinv) B_i2'     (block_solver.hpp:400-431)
+//   partial_rhs(i) = sum_{lm in tile} B_i Dinv b_lm         (block_solver.hpp:412)
+// A tile's Hpl columns are contiguous in HBM: they are staged ONCE into LDS with coalesced 16-byte
+// loads (Hpl is read once per iteration instead of once per pose pair), together with Dinv, b_l and the
+// tile's contributor entries.  Each destination block touched by the tile is owned by G lanes that walk
+// its entry list out of LDS (no atomics, fixed order) and write one partial block to HBM.
 template <int PD, int LD, int G>
-__global__ void __launch_bounds__(kThreads) schur_blocks_kernel(int nDst, const int* __restrict__ sc_ptr, const int* __restrict__ sc_q1,
-                                    const int* __restrict__ sc_q2, const int* __restrict__ pl_lm, const double* __restrict__ Hpl,
-                                    const double* __restrict__ Dinv, const int* __restrict__ hs_src, const double* __restrict__ Hpp,
-                                    double* __restrict__ Hs, const int* __restrict__ diag_pose, const double* __restrict__ b,
-                                    const double* __restrict__ bl, double* __restrict__ bschur) {
-  const int gt = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  const int d = gt / G, g = gt % G;
-  const bool active = d < nDst;
-  double acc[PD * PD];
-  double cacc[PD];
-  const int src = active ? hs_src[d] : -1;
-  const int dpose = active ? diag_pose[d] : -1;
-  if (g == 0 && src >= 0) load_vec<PD * PD>(Hpp + (size_t)src * PD * PD, acc);
-  else {
+__global__ void __launch_bounds__(kThreads) schur_tile_kernel(const int* __restrict__ tile_lm0, const int* __restrict__ tile_td0,
+                                                            const int* __restrict__ pl_colptr, const double* __restrict__ Hpl,
+                                                            const double* __restrict__ Dinv, const double* __restrict__ bl,
+                                                            const int* __restrict__ td_diag, const int* __restrict__ td_ptr,
+                                                            const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm,
+                                                            double* __restrict__ Pd,
+                                                            double* __restrict__ Pr, long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int PL = PD * LD;
+  long long* dbgp = (dbg && blockIdx.x == 1000 && threadIdx.x == 0) ? dbg : nullptr;
+  if (dbgp) dbgp[0] = wall_clock64();
+  const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int l0 = tile_lm0[t], l1 = tile_lm0[t + 1];
+  const int q0 = pl_colptr[l0], nslots = pl_colptr[l1] - q0, nlm = l1 - l0;
+  const int td0 = tile_td0[t], td1 = tile_td0[t + 1];
+  const int e0 = td_ptr[td0], ne = td_ptr[td1] - e0;
+  double* Bs = smem;
+  double* Ds = Bs + ((nslots * PL + 1) & ~1);
+  double* bsm = Ds + ((nlm * LD * LD + 1) & ~1);
+  int* ep = reinterpret_cast<int*>(bsm + ((nlm * LD + 1) & ~1));
+  int* dptr = ep + ne;                                // td_ptr[td0 .. td1]
+  int* ddiag = dptr + (td1 - td0 + 1);                // destination is a diagonal block?
+  unsigned short* el = reinterpret_cast<unsigned short*>(ddiag + (td1 - td0));
+  const int tid = threadIdx.x, NT = blockDim.x;
+  {
+    // All global loads of the tile are issued before the first LDS store (one HBM round trip in total);
+    // anything beyond the unrolled part (only with an enlarged tile budget) goes through stage_copy.
+    const dbl2_u* srcB = reinterpret_cast<const dbl2_u*>(Hpl + (size_t)q0 * PL);
+    dbl2_u* dstB = reinterpret_cast<dbl2_u*>(Bs);
+    const int n2 = (nslots * PL) >> 1;
+    const double* srcD = Dinv + (size_t)l0 * LD * LD;
+    const double* srcb = bl + (size_t)l0 * LD;
+    const int nD = nlm * LD * LD, nb = nlm * LD, ndp = td1 - td0 + 1;
+    constexpr int UB = 12, UD = 3, UE = 4;
+    dbl2_u vB[UB];
+    double vD[UD], vb;
+    int vE[UE], vP, vG;
+    unsigned short vL[UE];
+    // branch-free loads (indices clamped into range) so that the compiler emits them back to back
+    // without intermediate s_waitcnt; the LDS stores below are predicated instead
+#pragma unroll
+    for (int u = 0; u < UB; ++u) vB[u] = srcB[min(tid + u * NT, n2 - 1)];
+#pragma unroll
+    for (int u = 0; u < UD; ++u) vD[u] = srcD[min(tid + u * NT, nD - 1)];
+    vb = srcb[min(tid, nb - 1)];
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+      const int i = min(tid + u * NT, ne - 1);
+      vE[u] = te_pack[e0 + i];
+      vL[u] = te_lm[e0 + i];
+    }
+    vP = td_ptr[td0 + min(tid, ndp - 1)];
+    vG = td_diag[td0 + min(tid, max(ndp - 2, 0))];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int i = tid + u * NT;
+      if (i < n2) dstB[i] = vB[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      const int i = tid + u * NT;
+      if (i < nD) Ds[i] = vD[u];
+    }
+    if (tid < nb) bsm[tid] = vb;
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+      const int i = tid + u * NT;
+      if (i < ne) {
+        ep[i] = vE[u];
+        el[i] = vL[u];
+      }
+    }
+    if (tid < ndp) dptr[tid] = vP;
+    if (tid < ndp - 1) ddiag[tid] = vG;
+    // remainders
+    if (n2 > UB * NT) stage_copy<4>(dstB + UB * NT, srcB + UB * NT, n2 - UB * NT, tid, NT);
+    if (((nslots * PL) & 1) && tid == 0) Bs[nslots * PL - 1] = Hpl[(size_t)q0 * PL + nslots * PL - 1];
+    if (nD > UD * NT) stage_copy<4>(Ds + UD * NT, srcD + UD * NT, nD - UD * NT, tid, NT);
+    if (nb > NT) stage_copy<2>(bsm + NT, srcb + NT, nb - NT, tid, NT);
+    if (ne > UE * NT) {
+      stage_copy<4>(ep + UE * NT, te_pack + e0 + UE * NT, ne - UE * NT, tid, NT);
+      stage_copy<4>(el + UE * NT, te_lm + e0 + UE * NT, ne - UE * NT, tid, NT);
+    }
+    if (ndp > NT) stage_copy<2>(dptr + NT, td_ptr + td0 + NT, ndp - NT, tid, NT);
+    if (ndp - 1 > NT) stage_copy<2>(ddiag + NT, td_diag + td0 + NT, ndp - 1 - NT, tid, NT);
+  }
+  __syncthreads();
+  if (dbgp) dbgp[1] = wall_clock64();
+  const int grp = tid / G, g = tid % G, ngroups = NT / G;
+  int dk = 2;
+  for (int ld = td0 + grp; ld < td1; ld += ngroups) {
+    double acc[PD * PD], cacc[PD];
 #pragma unroll
     for (int i = 0; i < PD * PD; ++i) acc[i] = 0.0;
-  }
 #pragma unroll
-  for (int r = 0; r < PD; ++r) cacc[r] = 0.0;
-  const int k0 = active ? sc_ptr[d] : 0, k1 = active ? sc_ptr[d + 1] : 0;
-  // software pipeline on the index loads: (q1, q2, lm) of the next contributor are fetched while the
-  // current one is being multiplied, so each iteration pays one dependent memory round trip, not three
-  int nq1 = 0, nq2 = 0, nlm = 0;
-  if (k0 + g < k1) {
-    nq1 = sc_q1[k0 + g];
-    nq2 = sc_q2[k0 + g];
-    nlm = pl_lm[nq1];
-  }
-  for (int k = k0 + g; k < k1; k += G) {
-    const int q1 = nq1, q2 = nq2, lm = nlm;
-    if (k + G < k1) {
-      nq1 = sc_q1[k + G];
-      nq2 = sc_q2[k + G];
-      nlm = pl_lm[nq1];
-    }
-    double W[PD * LD], Bj[PD * LD], Di[LD * LD];
-    load_vec<LD * LD>(Dinv + (size_t)lm * LD * LD, Di);
-    load_vec<PD * LD>(Hpl + (size_t)q1 * PD * LD, Bj);
+    for (int r = 0; r < PD; ++r) cacc[r] = 0.0;
+    const bool diag = ddiag[ld - td0] != 0;
+    const int k0 = dptr[ld - td0] - e0, k1 = dptr[ld - td0 + 1] - e0;
+    for (int k = k0 + g; k < k1; k += G) {
+      const int pk = ep[k], lm = el[k];
+      const int s1 = pk & 0xffff, s2 = (pk >> 16) & 0xffff;
+      double W[PL], Bj[PL], Di[LD * LD];
 #pragma unroll
-    for (int c = 0; c < LD; ++c)
-#pragma unroll
-      for (int r = 0; r < PD; ++r) {
-        double t = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < LD; ++kk) t += Bj[r + PD * kk] * Di[kk + LD * c];
-        W[r + PD * c] = t;
-      }
-    if (dpose >= 0) {   // q1 == q2: coeff += B (Dinv b_l) = W b_l
-      double bv[LD];
-      load_vec<LD>(bl + (size_t)lm * LD, bv);
+      for (int i = 0; i < LD * LD; ++i) Di[i] = Ds[lm * (LD * LD) + i];
+      lds_block<PL>(Bs + s1 * PL, Bj);
 #pragma unroll
       for (int c = 0; c < LD; ++c)
 #pragma unroll
-        for (int r = 0; r < PD; ++r) cacc[r] += W[r + PD * c] * bv[c];
-    } else {
-      load_vec<PD * LD>(Hpl + (size_t)q2 * PD * LD, Bj);
-    }
+        for (int r = 0; r < PD; ++r) {
+          double v = 0.0;
 #pragma unroll
-    for (int c = 0; c < PD; ++c)
+          for (int kk = 0; kk < LD; ++kk) v += Bj[r + PD * kk] * Di[kk + LD * c];
+          W[r + PD * c] = v;
+        }
+      if (diag) {   // s1 == s2: rhs contribution B (Dinv b_l) = W b_l
 #pragma unroll
-      for (int r = 0; r < PD; ++r) {
-        double t = 0.0;
+        for (int c = 0; c < LD; ++c) {
+          const double bv = bsm[lm * LD + c];
 #pragma unroll
-        for (int kk = 0; kk < LD; ++kk) t += W[r + PD * kk] * Bj[c + PD * kk];
-        acc[r + PD * c] -= t;
+          for (int r = 0; r < PD; ++r) cacc[r] += W[r + PD * c] * bv;
+        }
+      } else {
+        lds_block<PL>(Bs + s2 * PL, Bj);
       }
-  }
-  if (G > 1) {
 #pragma unroll
-    for (int i = 0; i < PD * PD; ++i) acc[i] = group_sum<G>(acc[i]);
+      for (int c = 0; c < PD; ++c)
 #pragma unroll
-    for (int r = 0; r < PD; ++r) cacc[r] = group_sum<G>(cacc[r]);
-  }
-  if (!active) return;
-  double* out = Hs + (size_t)d * PD * PD;
-  if (G == 1) {
-    store_vec<PD * PD>(out, acc);
-  } else {
+        for (int r = 0; r < PD; ++r) {
+          double v = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < LD; ++kk) v += W[r + PD * kk] * Bj[c + PD * kk];
+          acc[r + PD * c] += v;
+        }
+    }
+    if (G > 1) {
+#pragma unroll
+      for (int i = 0; i < PD * PD; ++i) acc[i] = group_sum<G>(acc[i]);
+#pragma unroll
+      for (int r = 0; r < PD; ++r) cacc[r] = group_sum<G>(cacc[r]);
+    }
+    double* out = Pd + (size_t)ld * PD * PD;
 #pragma unroll
     for (int i = 0; i < PD * PD; ++i)
-      if (i % G == g) out[i] = acc[i];
-  }
-  if (dpose >= 0) {
+      if (G == 1 || (i % G) == g) out[i] = acc[i];
+    if (diag) {
 #pragma unroll
-    for (int r = 0; r < PD; ++r)
-      if (G == 1 || (r % G) == g) bschur[(size_t)dpose * PD + r] = b[(size_t)dpose * PD + r] - cacc[r];
+      for (int r = 0; r < PD; ++r)
+        if (G == 1 || (r % G) == g) Pr[(size_t)ld * PD + r] = cacc[r];
+    }
+    if (dbgp && dk < 8) dbgp[dk++] = wall_clock64();
   }
+  if (dbgp) { dbgp[9] = nslots; dbgp[10] = nlm; dbgp[11] = td1 - td0; dbgp[12] = ne; }
 }
 
-// K8: bschur_i = b_i - sum_{blocks in pose row i} B * (Dinv b_l)   (block_solver.hpp:412,435-439)
-template <int PD, int LD, int G>
-__global__ void __launch_bounds__(kThreads) schur_rhs_kernel(int nP, const int* __restrict__ plr_ptr, const int* __restrict__ plr_blk,
-                                 const int* __restrict__ pl_lm, const double* __restrict__ Hpl, const double* __restrict__ db,
-                                 const double* __restrict__ b, double* __restrict__ bschur) {
-  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = gt / G, g = gt % G;
-  const bool active = i < nP;
-  double acc[PD];
-#pragma unroll
-  for (int r = 0; r < PD; ++r) acc[r] = 0.0;
-  const int k0 = active ? plr_ptr[i] : 0, k1 = active ? plr_ptr[i + 1] : 0;
-  for (int k = k0 + g; k < k1; k += G) {
-    const int q = plr_blk[k];
-    const int lm = pl_lm[q];
-    const double* B = Hpl + (size_t)q * PD * LD;
-#pragma unroll
-    for (int c = 0; c < LD; ++c) {
-      const double dv = db[(size_t)lm * LD + c];
-#pragma unroll
-      for (int r = 0; r < PD; ++r) acc[r] += B[r + PD * c] * dv;
-    }
+// K5+K7+K8, pass 2: Hschur(d) = Hpp(d) - sum_tiles partial(d) (fixed tile order), bschur = b_p - sum partial_rhs
+template <int PD>
+__global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const int* __restrict__ rd_ptr, const int* __restrict__ rd_slot,
+                                                              const int* __restrict__ hs_src, const double* __restrict__ Hpp,
+                                                              const double* __restrict__ Pd, double* __restrict__ Hs,
+                                                              const int* __restrict__ hs_diag, const double* __restrict__ Pr,
+                                                              const double* __restrict__ b, double* __restrict__ bschur) {
+  constexpr int BB = PD * PD;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= (size_t)nDst * BB) return;
+  const int d = (int)(t / BB), e = (int)(t % BB);
+  const int src = hs_src[d];
+  double v = src >= 0 ? Hpp[(size_t)src * BB + e] : 0.0;
+  const int k0 = rd_ptr[d], k1 = rd_ptr[d + 1];
+  for (int k = k0; k < k1; ++k) v -= Pd[(size_t)rd_slot[k] * BB + e];
+  Hs[t] = v;
+  const int pose = hs_diag[d];
+  if (pose >= 0 && e < PD) {
+    double r = b[(size_t)pose * PD + e];
+    for (int k = k0; k < k1; ++k) r -= Pr[(size_t)rd_slot[k] * PD + e];
+    bschur[(size_t)pose * PD + e] = r;
   }
-  if (G > 1) {
-#pragma unroll
-    for (int r = 0; r < PD; ++r) acc[r] = group_sum<G>(acc[r]);
-  }
-  if (!active) return;
-#pragma unroll
-  for (int r = 0; r < PD; ++r)
-    if (G == 1 || (r % G) == g) bschur[(size_t)i * PD + r] = b[(size_t)i * PD + r] - acc[r];
 }
 
 // K13: x_l = Dinv (b_l - Hpl' x_p)   (block_solver.hpp:459-483)
@@ -902,50 +987,98 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     std::vector<int> hs_src(hs_nnzb, -1);
     for (int c = 0; c < nP; ++c)
       for (int q = pp_colptr[c]; q < pp_colptr[c + 1]; ++q) hs_src[find_block(hs_colptr, hs_row, c, pp_row[q])] = q;
-    // contributor pairs per Hschur block, in landmark order (== the reference's summation order)
-    std::vector<int> sc_ptr(hs_nnzb + 1, 0);
-    std::vector<int> pair_dst;
-    pair_dst.reserve(cnt - pp_nnzb);
-    for (int c = 0; c < nL; ++c)
-      for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
-        for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) {
-          int d = find_block(hs_colptr, hs_row, pl_row[q2], pl_row[q1]);
-          pair_dst.push_back(d);
-          sc_ptr[d + 1]++;
-        }
-    for (int d = 0; d < hs_nnzb; ++d) sc_ptr[d + 1] += sc_ptr[d];
-    std::vector<int> q1v(pair_dst.size()), q2v(pair_dst.size());
-    {
-      std::vector<int> w(sc_ptr.begin(), sc_ptr.end() - 1);
-      size_t k = 0;
-      for (int c = 0; c < nL; ++c)
-        for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
-          for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) {
-            int pos = w[pair_dst[k++]]++;
-            q1v[pos] = q1;
-            q2v[pos] = q2;
-          }
-    }
-    n_sc_ = (long)pair_dst.size();
-    d_hs_src.upload(hs_src, st_);
     {
       std::vector<int> hs_diag(hs_nnzb, -1);
       for (int c = 0; c < nP; ++c) hs_diag[find_block(hs_colptr, hs_row, c, c)] = c;
       d_hs_diag.upload(hs_diag, st_);
     }
-    d_sc_ptr.upload(sc_ptr, st_);
-    d_sc_q1.upload(q1v, st_);
-    d_sc_q2.upload(q2v, st_);
-    // Hpl blocks by pose row, landmark order
-    std::vector<int> plr_ptr(nP + 1, 0), plr_blk(pl_nnzb);
-    for (int q = 0; q < pl_nnzb; ++q) plr_ptr[pl_row[q] + 1]++;
-    for (int i = 0; i < nP; ++i) plr_ptr[i + 1] += plr_ptr[i];
+    d_hs_src.upload(hs_src, st_);
+    // ---- landmark-range tiles for the Schur outer products (schur_tile_kernel)
     {
-      std::vector<int> w(plr_ptr.begin(), plr_ptr.end() - 1);
-      for (int q = 0; q < pl_nnzb; ++q) plr_blk[w[pl_row[q]]++] = q;
+      const size_t PL = (size_t)p * l, DP = ((size_t)l * l + 1) & ~(size_t)1, BP = ((size_t)l + 1) & ~(size_t)1;
+      std::vector<int> tile_lm0, tile_td0, td_dest, td_ptr, te_pack;
+      std::vector<unsigned short> te_lm;
+      std::vector<int> rd_cnt(hs_nnzb, 0);
+      std::vector<int> hs_row_is_diag(hs_nnzb, 0);
+      for (int c = 0; c < nP; ++c) hs_row_is_diag[find_block(hs_colptr, hs_row, c, c)] = 1;
+      tile_lm0.push_back(0);
+      tile_td0.push_back(0);
+      td_ptr.push_back(0);
+      size_t max_lds = 0;
+      int lm = 0;
+      struct Ent { int dest, pack; unsigned short lml; };
+      std::vector<Ent> ents;
+      std::vector<int> order;
+      while (lm < nL) {
+        // greedy tile: as many landmarks as fit the LDS budget (at least one)
+        int l0 = lm;
+        size_t bytes = 0, nent = 0;
+        while (lm < nL) {
+          size_t K = pl_colptr[lm + 1] - pl_colptr[lm];
+          size_t add = K * PL * 8 + DP * 8 + BP * 8 + K * (K + 1) / 2 * (6 + 8);   // blocks, Dinv, b_l, entries (+ per-destination metadata bound)
+          bool ok16 = (size_t)(pl_colptr[lm + 1] - pl_colptr[l0]) < 65536 && (lm + 1 - l0) < 65536;
+          if (lm > l0 && (bytes + add > schur_tile_bytes || !ok16)) break;
+          bytes += add;
+          nent += K * (K + 1) / 2;
+          ++lm;
+        }
+        if ((size_t)(pl_colptr[lm] - pl_colptr[l0]) >= 65536) throw ArgFailure("a landmark is observed by >= 65536 poses: unsupported");
+        max_lds = std::max(max_lds, bytes + 64);
+        ents.clear();
+        ents.reserve(nent);
+        const int q0 = pl_colptr[l0];
+        for (int c = l0; c < lm; ++c)
+          for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
+            for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) {
+              Ent e;
+              e.dest = find_block(hs_colptr, hs_row, pl_row[q2], pl_row[q1]);
+              e.pack = (q1 - q0) | ((q2 - q0) << 16);
+              e.lml = (unsigned short)(c - l0);
+              ents.push_back(e);
+            }
+        order.resize(ents.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ents[a].dest < ents[b].dest; });  // landmark order kept per dest
+        for (size_t k = 0; k < order.size(); ++k) {
+          const Ent& e = ents[order[k]];
+          if (k == 0 || e.dest != ents[order[k - 1]].dest) {
+            if (k > 0) td_ptr.push_back((int)te_pack.size());
+            td_dest.push_back(e.dest);
+            rd_cnt[e.dest]++;
+          }
+          te_pack.push_back(e.pack);
+          te_lm.push_back(e.lml);
+        }
+        if (!order.empty()) td_ptr.push_back((int)te_pack.size());
+        tile_lm0.push_back(lm);
+        tile_td0.push_back((int)td_dest.size());
+      }
+      n_tiles_ = (int)tile_lm0.size() - 1;
+      n_td_ = (long)td_dest.size();
+      n_sc_ = (long)te_pack.size();
+      schur_lds_bytes_ = max_lds;
+      // per destination: its partial slots in tile order
+      std::vector<int> rd_ptr(hs_nnzb + 1, 0), rd_slot(td_dest.size());
+      for (int d = 0; d < hs_nnzb; ++d) rd_ptr[d + 1] = rd_ptr[d] + rd_cnt[d];
+      {
+        std::vector<int> w(rd_ptr.begin(), rd_ptr.end() - 1);
+        for (size_t k = 0; k < td_dest.size(); ++k) rd_slot[w[td_dest[k]]++] = (int)k;
+      }
+      d_tile_lm0.upload(tile_lm0, st_);
+      d_tile_td0.upload(tile_td0, st_);
+      {
+        std::vector<int> td_diag(td_dest.size());
+        for (size_t k = 0; k < td_dest.size(); ++k) td_diag[k] = hs_row_is_diag[td_dest[k]];
+        d_td_diag.upload(td_diag, st_);
+      }
+      d_td_ptr.upload(td_ptr, st_);
+      d_te_pack.upload(te_pack, st_);
+      d_te_lm.upload(te_lm, st_);
+      d_rd_ptr.upload(rd_ptr, st_);
+      d_rd_slot.upload(rd_slot, st_);
+      d_Pd.alloc((size_t)std::max<long>(n_td_, 1) * p * p);
+      d_Pr.alloc((size_t)std::max<long>(n_td_, 1) * p);
     }
-    d_plr_ptr.upload(plr_ptr, st_);
-    d_plr_blk.upload(plr_blk, st_);
     d_Hschur.alloc((size_t)hs_nnzb * p * p);
     d_Dinv.alloc((size_t)nL * l * l);
     d_db.alloc((size_t)nL * l);
@@ -1169,9 +1302,9 @@ void BlockSolver::solve_schur() {
   if (profiling) ts_.start(st_);
   const size_t sizeP = (size_t)nP_ * p_;
   const int hs_nnzb = (int)hs_row.size();
-  const int G = pick_group((double)n_sc_ / std::max(1, hs_nnzb));
-#define G2OHIP_SCHUR_ARGS hs_nnzb, d_sc_ptr.p, d_sc_q1.p, d_sc_q2.p, d_pl_lm.p, d_Hpl.p, d_Dinv.p, d_hs_src.p, d_Hpp.p, d_Hschur.p, \
-                          d_hs_diag.p, d_b.p, d_b.p + sizeP, d_bschur.p
+  const int G = schur_group > 0 ? schur_group : pick_group((double)n_sc_ / std::max<long>(1, n_td_));
+#define G2OHIP_TILE_ARGS d_tile_lm0.p, d_tile_td0.p, d_pl_colptr.p, d_Hpl.p, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p, d_te_pack.p, \
+                         d_te_lm.p, d_Pd.p, d_Pr.p, (long long*)(getenv("G2OHIP_SCHUR_DEBUG") ? d_red.p : nullptr)
 #define G2OHIP_SCHUR(P_, L_)                                                                                                   \
   if (p_ == P_ && l_ == L_) {                                                                                                  \
     prof.begin(KernelProf::kLmInverse, st_);                                                                                   \
@@ -1179,16 +1312,29 @@ void BlockSolver::solve_schur() {
                        d_Dinv.p, d_db.p);                                                                                      \
     prof.end(KernelProf::kLmInverse, st_);                                                                                     \
     prof.begin(KernelProf::kSchurBlocks, st_);                                                                                 \
-    if (G == 1)                                                                                                                \
-      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 1>), dim3(grid_for((size_t)hs_nnzb)), dim3(kThreads), 0, st_,             \
-                         G2OHIP_SCHUR_ARGS);                                                                                   \
-    else if (G == 4)                                                                                                           \
-      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 4>), dim3(grid_for((size_t)hs_nnzb * 4)), dim3(kThreads), 0, st_,         \
-                         G2OHIP_SCHUR_ARGS);                                                                                   \
-    else                                                                                                                       \
-      hipLaunchKernelGGL((schur_blocks_kernel<P_, L_, 8>), dim3(grid_for((size_t)hs_nnzb * 8)), dim3(kThreads), 0, st_,         \
-                         G2OHIP_SCHUR_ARGS);                                                                                   \
+    if (n_tiles_ > 0) {                                                                                                        \
+      static bool attr = false;                                                                                                \
+      if (!attr) {                                                                                                             \
+        (void)hipFuncSetAttribute((const void*)schur_tile_kernel<P_, L_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)schur_tile_kernel<P_, L_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)schur_tile_kernel<P_, L_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)schur_tile_kernel<P_, L_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        attr = true;                                                                                                           \
+      }                                                                                                                        \
+      if (G <= 1)                                                                                                              \
+        hipLaunchKernelGGL((schur_tile_kernel<P_, L_, 1>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, G2OHIP_TILE_ARGS); \
+      else if (G <= 2)                                                                                                         \
+        hipLaunchKernelGGL((schur_tile_kernel<P_, L_, 2>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, G2OHIP_TILE_ARGS); \
+      else if (G <= 4)                                                                                                         \
+        hipLaunchKernelGGL((schur_tile_kernel<P_, L_, 4>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, G2OHIP_TILE_ARGS); \
+      else                                                                                                                     \
+        hipLaunchKernelGGL((schur_tile_kernel<P_, L_, 8>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, G2OHIP_TILE_ARGS); \
+    }                                                                                                                          \
     prof.end(KernelProf::kSchurBlocks, st_);                                                                                   \
+    prof.begin(KernelProf::kSchurRhs, st_);                                                                                    \
+    hipLaunchKernelGGL((schur_reduce_kernel<P_>), dim3(grid_for((size_t)hs_nnzb * P_ * P_)), dim3(kThreads), 0, st_, hs_nnzb,     \
+                       d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p); \
+    prof.end(KernelProf::kSchurRhs, st_);                                                                                      \
   } else
   G2OHIP_SCHUR(6, 3)
   G2OHIP_SCHUR(3, 2)
@@ -1196,6 +1342,19 @@ void BlockSolver::solve_schur() {
   G2OHIP_SCHUR(6, 2)
   G2OHIP_SCHUR(3, 3) { throw ArgFailure("unsupported (pose_dim, landmark_dim) for Schur"); }
 #undef G2OHIP_SCHUR
+#undef G2OHIP_TILE_ARGS
+  if (getenv("G2OHIP_SCHUR_DEBUG")) {
+    static int once = 0;
+    if (once++ == 3) {
+      long long h[16];
+      G2OHIP_HIP_CHECK(hipMemcpyAsync(h, d_red.p, sizeof(h), hipMemcpyDeviceToHost, st_));
+      G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+      fprintf(stderr, "[schur dbg] tile 1000: slots %lld lms %lld dests %lld entries %lld | stage %.2f us, dest rounds:", h[9], h[10], h[11], h[12],
+              (h[1] - h[0]) * 0.01);
+      for (int q = 2; q < 8 && h[q]; ++q) fprintf(stderr, " %.2f", (h[q] - h[q - 1]) * 0.01);
+      fprintf(stderr, " us\n");
+    }
+  }
   G2OHIP_HIP_CHECK(hipGetLastError());
   if (profiling) {
     ts_.stop(st_);

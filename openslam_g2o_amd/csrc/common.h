@@ -99,13 +99,32 @@ struct EventTimer {
 };
 
 
+// global -> LDS copy with U independent loads in flight per thread.  A plain `for (i...) lds[i] = g[i]`
+// loop is compiled as load / wait / store per iteration and pays one full HBM latency per element.
+template <int U, class T>
+__device__ __forceinline__ void stage_copy(T* __restrict__ dst, const T* __restrict__ src, int n, int tid, int nthreads) {
+  for (int base = tid; base < n; base += U * nthreads) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * nthreads;
+      if (i < n) v[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * nthreads;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+
 // Per-kernel timing with HIP events on the launch stream (enabled by g2ohip_set_profiling).
 struct KernelProf {
   enum Slot { kAsmPose = 0, kAsmLandmark, kAsmOffPP, kAsmOffPL, kLmInverse, kSchurBlocks, kSchurRhs, kCholFactor, kCholSolve,
               kBackSub, kLambda, kNumSlots };
   static const char* name(int s) {
     static const char* n[] = {"assemble_vertex(pose)", "assemble_vertex(landmark)", "assemble_offdiag(Hpp)", "assemble_offdiag(Hpl)",
-                              "landmark_inverse", "schur_blocks", "schur_rhs", "chol_factor(all levels)", "chol_solve(all levels)",
+                              "landmark_inverse", "schur_tiles", "schur_reduce", "chol_factor(all levels)", "chol_solve(all levels)",
                               "back_substitute", "set_lambda/restore"};
     return (s >= 0 && s < kNumSlots) ? n[s] : "?";
   }

@@ -718,13 +718,11 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
     }
   }
   // ---- stage the index tables in LDS (independent loads), zero the front meanwhile
-  for (int t = tid; t < na; t += NT) {
-    s_q[t] = P.asm_q[rec.asm_off + t];
-    s_pos[t] = P.asm_pos[rec.asm_off + t];
-  }
+  stage_copy<2>(s_q, P.asm_q + rec.asm_off, na, tid, NT);
+  stage_copy<2>(s_pos, P.asm_pos + rec.asm_off, na, tid, NT);
   if (USE_LDS) {
-    for (int t = tid; t < rec.cmap_cnt; t += NT) s_cmap_l[t] = P.cmap[rec.cmap_off + t];
-    for (int t = tid; t < rec.tri_cnt; t += NT) s_tri_l[t] = P.tri[t];
+    stage_copy<2>(s_cmap_l, P.cmap + rec.cmap_off, rec.cmap_cnt, tid, NT);
+    stage_copy<2>(s_tri_l, P.tri, rec.tri_cnt, tid, NT);
   }
   for (int i = tid; i < m * m; i += NT) F[i] = 0.0;
   __syncthreads();
@@ -990,8 +988,7 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const
   double* t = smem + (PANEL_LDS ? panel_cap : 0);
   double* ys = t + m;
   const double* Lg = P.L + rec.L_off;
-  if (PANEL_LDS)
-    for (int i = tid; i < m * npiv + npiv; i += NT) Lp[i] = Lg[i];
+  if (PANEL_LDS) stage_copy<8>(Lp, Lg, m * npiv + npiv, tid, NT);
   const double* Lx = PANEL_LDS ? Lp : Lg;
   const double* Linv = Lx + (size_t)m * npiv;
   // children's update vectors: issue the loads before the first barrier (fast path: <= 2 children
@@ -1073,8 +1070,7 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, cons
   double* xs = t + m;
   double* sp = xs + m;
   const double* Lg = P.L + rec.L_off;
-  if (PANEL_LDS)
-    for (int i = tid; i < m * npiv + npiv; i += NT) Lp[i] = Lg[i];
+  if (PANEL_LDS) stage_copy<8>(Lp, Lg, m * npiv + npiv, tid, NT);
   const double* Lx = PANEL_LDS ? Lp : Lg;
   const double* Linv = Lx + (size_t)m * npiv;
   const int* rows = P.rows + P.rows_off[f];
