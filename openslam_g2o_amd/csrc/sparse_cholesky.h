@@ -30,12 +30,13 @@ struct CholOptions {
   int max_sn_scalars = 48;   // supernode (pivot panel) width cap, scalars
   double relax_zeros = 0.25; // relaxed amalgamation: tolerated share of explicit zero blocks in a panel
   size_t lds_front_bytes = 64 * 1024;  // fronts up to this size are factorised in LDS
+  bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
 };
 
 struct CholStats {
   size_t nnzL = 0;        // scalar nnz(L) incl. diagonal
-  size_t n_fronts = 0, n_levels = 0, max_front_dim = 0;
+  size_t n_fronts = 0, n_levels = 0, n_tasks = 0, max_front_dim = 0;
   double flops = 0;       // factorisation flops (dense-front count)
   double t_symbolic = 0;  // seconds, host
   size_t bytes_L = 0, bytes_U = 0;
@@ -54,7 +55,8 @@ struct CholSymbolic {
   std::vector<int> asm_off;                // per front, into asm_q/asm_pos
   std::vector<int> asm_q, asm_pos;         // source block id; packed lr | lc<<15 | tr<<30
   std::vector<int> child_off, children;
-  std::vector<int> level_ptr, level_fronts;  // fronts grouped by level (leaves first)
+  std::vector<int> task_ptr, task_fronts;    // tasks (chains of fronts fused into one workgroup)
+  std::vector<int> level_ptr, level_fronts;  // task ids grouped by task level (leaves first)
   long long L_total = 0, U_total = 0, w_total = 0;
 };
 
@@ -77,6 +79,7 @@ struct FrontRec {
 };
 
 struct CholPlanDev {
+  const int *task_ptr, *task_fronts;   // task t = chain of fronts task_fronts[task_ptr[t] .. task_ptr[t+1])
   const FrontRec* rec;
   const ChildDesc* cdesc;
   const int* crel;
@@ -87,8 +90,6 @@ struct CholPlanDev {
   const int *asm_off, *asm_q, *asm_pos, *child_off, *children;
   double *L, *U, *w;
   int* status;
-  long long* dbg;   // developer timing stamps (G2OHIP_ABLATE & 64)
-  int* dbg_slot;
 };
 
 class SparseCholesky {
@@ -124,8 +125,7 @@ class SparseCholesky {
   DevBuf<long long> d_L_off, d_U_off, d_w_off, d_scratch_off;
   DevBuf<FrontRec> d_rec;
   DevBuf<ChildDesc> d_cdesc;
-  DevBuf<int> d_crel, d_cmap, d_tri, d_dbg_slot;
-  DevBuf<long long> d_dbg;
+  DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts;
   DevBuf<double> d_L, d_U, d_w, d_y, d_xp, d_scratch;
   // per level launch info
   struct LevelLaunch {

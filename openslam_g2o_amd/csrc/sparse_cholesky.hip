@@ -11,6 +11,10 @@
 
 namespace g2ohip {
 
+constexpr int kFactorThreads = 256;
+constexpr int kFactorThreadsGlobal = 512;
+constexpr int kChainU = 6;  // doubles per thread that carry an update matrix from one chain front to the next
+
 // =====================================================================================
 // Host: nested dissection on the block graph (George-Liu automatic nested dissection:
 // BFS level structure from a pseudo-peripheral node, separator = the part of the middle
@@ -464,52 +468,80 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   stats_.n_levels = nlev;
   stats_.bytes_L = (size_t)S.L_total * 8;
   stats_.bytes_U = (size_t)S.U_total * 8;
-  // --- level lists: LDS-class fronts first, then global-class
+  // --- tasks: a front whose parent has no other child is fused with it (chain); the workgroup that
+  // factorises the child carries the update matrix to the parent in registers.  Both fronts must be
+  // LDS-resident and the carried matrix must fit kChainU doubles per thread.
+  auto front_dim = [&](int f) { return (size_t)(S.f_ns[f] + S.f_nb[f]) * bs; };
+  auto is_lds = [&](int f) { return front_dim(f) * front_dim(f) * 8 <= opt.lds_front_bytes; };
+  std::vector<int> chain_next(nf, -1), has_prev(nf, 0);
+  if (opt.fuse_chains)
+    for (int f = 0; f < nf; ++f) {
+      const int p = S.f_parent[f];
+      if (p < 0 || S.child_off[p + 1] - S.child_off[p] != 1 || !is_lds(f) || !is_lds(p)) continue;
+      if ((size_t)S.f_nb[f] * (S.f_nb[f] + 1) / 2 * bs * bs > (size_t)kChainU * kFactorThreads) continue;
+      if (S.f_nb[f] * bs > 256) continue;   // solve kernels carry the boundary vector in one round
+      chain_next[f] = p;
+      has_prev[p] = 1;
+    }
+  S.task_ptr.assign(1, 0);
+  S.task_fronts.clear();
+  std::vector<int> task_of(nf, -1), task_level;
+  for (int f = 0; f < nf; ++f) {
+    if (has_prev[f]) continue;
+    const int t = (int)S.task_ptr.size() - 1;
+    int lvl = 0;
+    for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) lvl = std::max(lvl, task_level[task_of[S.children[ch]]] + 1);
+    for (int g = f; g >= 0; g = chain_next[g]) {
+      S.task_fronts.push_back(g);
+      task_of[g] = t;
+    }
+    S.task_ptr.push_back((int)S.task_fronts.size());
+    task_level.push_back(lvl);
+  }
+  const int ntask = (int)task_level.size();
+  nlev = 0;
+  for (int t = 0; t < ntask; ++t) nlev = std::max(nlev, task_level[t] + 1);
+  stats_.n_levels = nlev;
+  stats_.n_tasks = ntask;
+  // --- launch lists (task ids): LDS-class tasks first, then scratch-slab (single large front) tasks
   S.level_ptr.assign(nlev + 1, 0);
-  for (int f = 0; f < nf; ++f) S.level_ptr[S.f_level[f] + 1]++;
+  for (int t = 0; t < ntask; ++t) S.level_ptr[task_level[t] + 1]++;
   for (int l = 0; l < nlev; ++l) S.level_ptr[l + 1] += S.level_ptr[l];
-  S.level_fronts.resize(nf);
+  S.level_fronts.resize(ntask);
   launches_.assign(nlev, LevelLaunch());
-  std::vector<long long> scratch_off(nf, 0);
+  std::vector<long long> scratch_off(ntask, 0);
   long long scratch_max = 0;
   {
     std::vector<std::vector<int>> lds(nlev), glb(nlev);
-    for (int f = 0; f < nf; ++f) {
-      size_t m = (size_t)(S.f_ns[f] + S.f_nb[f]) * bs;
-      if (m * m * 8 <= opt.lds_front_bytes)
-        lds[S.f_level[f]].push_back(f);
-      else
-        glb[S.f_level[f]].push_back(f);
-    }
+    for (int t = 0; t < ntask; ++t) (is_lds(S.task_fronts[S.task_ptr[t]]) ? lds : glb)[task_level[t]].push_back(t);
     for (int l = 0; l < nlev; ++l) {
       LevelLaunch& LL = launches_[l];
       int pos = S.level_ptr[l];
       LL.lds_begin = pos;
       LL.lds_count = (int)lds[l].size();
-      for (int f : lds[l]) {
-        S.level_fronts[pos++] = f;
-        LL.lds_max_m = std::max(LL.lds_max_m, (S.f_ns[f] + S.f_nb[f]) * bs);
+      for (int t : lds[l]) {
+        S.level_fronts[pos++] = t;
+        for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) LL.lds_max_m = std::max(LL.lds_max_m, (int)front_dim(S.task_fronts[k]));
       }
       LL.glb_begin = pos;
       LL.glb_count = (int)glb[l].size();
       long long so = 0;
-      for (int f : glb[l]) {
+      for (int t : glb[l]) {
         scratch_off[pos] = so;
-        long long m = (long long)(S.f_ns[f] + S.f_nb[f]) * bs;
+        const long long m = (long long)front_dim(S.task_fronts[S.task_ptr[t]]);
         so += m * m;
-        S.level_fronts[pos++] = f;
+        S.level_fronts[pos++] = t;
         LL.glb_max_m = std::max(LL.glb_max_m, (int)m);
       }
       scratch_max = std::max(scratch_max, so);
-      for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
-        int f = S.level_fronts[k];
-        int m = (S.f_ns[f] + S.f_nb[f]) * bs;
-        LL.max_m = std::max(LL.max_m, m);
-        LL.max_panel = std::max(LL.max_panel, m * S.f_ns[f] * bs + S.f_ns[f] * bs);
-        int idx = 2 * (S.asm_off[f + 1] - S.asm_off[f]);
-        for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) idx += S.f_nb[S.children[ch]];
-        if (k < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, idx);
-        else LL.glb_idx_ints = std::max(LL.glb_idx_ints, idx);
+      for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
+        const int t = S.level_fronts[q];
+        for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
+          const int f = S.task_fronts[k];
+          const int m = (int)front_dim(f);
+          LL.max_m = std::max(LL.max_m, m);
+          LL.max_panel = std::max(LL.max_panel, m * S.f_ns[f] * bs + S.f_ns[f] * bs);
+        }
       }
     }
   }
@@ -564,12 +596,17 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   }
   for (LevelLaunch& LL : launches_) {
     LL.lds_idx_ints = LL.glb_idx_ints = 0;
-    for (int k = LL.lds_begin; k < LL.glb_begin + LL.glb_count; ++k) {
-      const FrontRec& R = recs[S.level_fronts[k]];
-      if (k < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt);
-      else LL.glb_idx_ints = std::max(LL.glb_idx_ints, 2 * R.asm_cnt);
+    for (int q = LL.lds_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+      const int t = S.level_fronts[q];
+      for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
+        const FrontRec& R = recs[S.task_fronts[k]];
+        if (q < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt);
+        else LL.glb_idx_ints = std::max(LL.glb_idx_ints, 2 * R.asm_cnt);
+      }
     }
   }
+  d_task_ptr.upload(S.task_ptr, st);
+  d_task_fronts.upload(S.task_fronts, st);
   d_rec.upload(recs, st);
   d_cdesc.upload(cdesc, st);
   d_crel.upload(crel, st);
@@ -604,12 +641,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_status.alloc(1);
   d_status.zero(st);
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
-  d_dbg.alloc(16 * 64 * 3 + 16);
-  d_dbg.zero(st);
-  d_dbg_slot.alloc(4);
-  d_dbg_slot.zero(st);
-  plan_.dbg = d_dbg.p;
-  plan_.dbg_slot = d_dbg_slot.p;
+  plan_.task_ptr = d_task_ptr.p;
+  plan_.task_fronts = d_task_fronts.p;
   plan_.rec = d_rec.p;
   plan_.cdesc = d_cdesc.p;
   plan_.crel = d_crel.p;
@@ -643,8 +676,6 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
 // =====================================================================================
 namespace {
 
-constexpr int kFactorThreads = 256;
-constexpr int kFactorThreadsGlobal = 512;
 
 // sqrt(d) and 1/sqrt(d) together: v_rsq_f64 seed + two Goldschmidt steps + one Newton correction
 // (the same recipe LLVM uses for f64 sqrt, without the fdiv a separate rsqrt would need).  ~1-2 ulp.
@@ -663,298 +694,311 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& r) {
   r = h + h;
 }
 
-// One workgroup factorises one frontal matrix.
+// One workgroup factorises one TASK = a chain of frontal matrices f1 -> f2 -> ... in which every
+// front is the only child of the next one; the update matrix travels from front to front in
+// registers, only the last one of the chain is written to HBM.  A single-front task is the plain
+// multifrontal step.
 //   F: m x m column-major (ld = m), lower triangle used.  LDS or an HBM scratch slab.
-// Steps: stage index tables, zero, assemble original blocks, extend-add the children's update
+// Per front: stage index tables, zero, assemble original blocks, extend-add the children's update
 // matrices, partial Cholesky of the ns pivot block columns (blocked by BS, look-ahead on the
-// diagonal factor), write the L panel and the update matrix U.
+// diagonal factor), write the L panel (+ reciprocal diagonal) and hand over / store the update matrix.
 // Lower-triangular block/tile sets are enumerated ROW-major (idx = i(i+1)/2 + j): the enumeration
 // of an n x n triangle is a prefix of that of any larger one, so one table (P.tri) serves every size.
 // LDS: F | 2 diagonal-factor mailboxes | s_q[na] s_pos[na] s_cmap[cmap_cnt] s_tri[tri_cnt]
 template <int BS, bool USE_LDS>
 __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGlobal) front_factor_kernel(
-    CholPlanDev P, const int* __restrict__ fronts, const double* __restrict__ A, double* __restrict__ scratch,
-    const long long* __restrict__ scratch_off, int idx_off_doubles, int ablate) {
+    CholPlanDev P, const int* __restrict__ tasks, const double* __restrict__ A, double* __restrict__ scratch,
+    const long long* __restrict__ scratch_off, int idx_off_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int T = (BS % 3 == 0) ? 3 : BS;  // register tile edge of the trailing update
   constexpr int BB = BS * BS;
   constexpr int UNR = 6;                     // independent global loads in flight per thread
   constexpr int LA = BS / T;                 // look-ahead span in tiles
-  const int f = fronts[blockIdx.x];
-  const FrontRec rec = P.rec[f];             // wave-uniform: scalar loads
-  const int ns = rec.ns, nbd = rec.nb;
-  const int m = (ns + nbd) * BS, npiv = ns * BS, ld = m;
+  constexpr int NLA = LA * (LA + 1) / 2;
+  const int task = tasks[blockIdx.x];
+  const int t0 = P.task_ptr[task], t1 = P.task_ptr[task + 1];
   double* F = USE_LDS ? smem : (scratch + scratch_off[blockIdx.x]);
   double* sd = smem + idx_off_doubles - 2 * (BB + BS);   // two mailboxes: [L_kk (BB) | 1/diag (BS)]
   int* s_q = reinterpret_cast<int*>(smem + idx_off_doubles);
-  const int na = rec.asm_cnt;
-  int* s_pos = s_q + na;
-  // LDS-resident fronts stage the child maps and the triangle table; scratch-slab (large) fronts
-  // read them from global memory (they can exceed the LDS)
-  int* s_cmap_l = s_pos + na;
-  int* s_tri_l = s_cmap_l + rec.cmap_cnt;
-  const int* s_cmap = USE_LDS ? s_cmap_l : (P.cmap + rec.cmap_off);
-  const int* s_tri = USE_LDS ? s_tri_l : P.tri;
   const int tid = threadIdx.x, NT = blockDim.x;
-  long long* dbg = (ablate & 64) && blockIdx.x == 0 && tid == 0 ? P.dbg + 16 * P.dbg_slot[0] : nullptr;
-  int dbg_k = 0;
-#define G2OHIP_STAMP() do { if (dbg) dbg[dbg_k++] = wall_clock64(); } while (0)
-  G2OHIP_STAMP();
+  double ucarry[kChainU];   // update matrix of the previous chain front: packed element tid + u * NT
+  int ncarry = 0;
 
-  // ---- issue the children's update-matrix loads first (fast path: <= 2 children that fit one round)
-  const int nch = rec.child_cnt;
-  const int nU0 = nch > 0 ? rec.ch[0].nbc * (rec.ch[0].nbc + 1) / 2 * BB : 0;
-  const int nU1 = nch > 1 ? rec.ch[1].nbc * (rec.ch[1].nbc + 1) / 2 * BB : 0;
-  const bool fast_children = nch <= 2 && nU0 <= UNR * NT && nU1 <= UNR * NT && !(ablate & 4);
-  double u0[UNR], u1[UNR];
-  if (fast_children) {
-    const double* U0 = P.U + rec.ch[0].U_off;
-    const double* U1 = P.U + rec.ch[1].U_off;
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int t = tid + u * NT;
-      u0[u] = (t < nU0) ? U0[t] : 0.0;
-      u1[u] = (t < nU1) ? U1[t] : 0.0;
-    }
-  }
-  // ---- stage the index tables in LDS (independent loads), zero the front meanwhile
-  stage_copy<2>(s_q, P.asm_q + rec.asm_off, na, tid, NT);
-  stage_copy<2>(s_pos, P.asm_pos + rec.asm_off, na, tid, NT);
-  if (USE_LDS) {
-    stage_copy<2>(s_cmap_l, P.cmap + rec.cmap_off, rec.cmap_cnt, tid, NT);
-    stage_copy<2>(s_tri_l, P.tri, rec.tri_cnt, tid, NT);
-  }
-  for (int i = tid; i < m * m; i += NT) F[i] = 0.0;
-  __syncthreads();
-  G2OHIP_STAMP();
-  // ---- original entries (each block lands on a distinct tile)
-  if (!(ablate & 2)) {
-    const int nA = na * BB;
-    for (int base = tid; base < nA; base += UNR * NT) {
-      double v[UNR];
-      int dst[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int t = base + u * NT;
-        dst[u] = -1;
-        v[u] = 0.0;
-        if (t < nA) {
-          const int e = t / BB, rc = t - e * BB;
-          const int r = rc % BS, c = rc / BS;
-          const int q = s_q[e], pos = s_pos[e];
-          const int lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff, tr = (pos >> 30) & 1;
-          v[u] = tr ? A[(size_t)q * BB + c + BS * r] : A[(size_t)q * BB + r + BS * c];
-          dst[u] = (lr * BS + r) + ld * (lc * BS + c);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u)
-        if (dst[u] >= 0) F[dst[u]] = v[u];
-    }
-  }
-  __syncthreads();
-  G2OHIP_STAMP();
-  // ---- extend-add of the children (sequential over children: destinations may overlap).  Update
-  // matrices are packed lower-triangular blocks (row-major block order); cmap gives, per packed
-  // block, the destination block (row | col << 16) in this front.
-  if (fast_children) {
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int t = tid + u * NT;
-      if (t < nU0) {
-        const int blk = t / BB, e = t - blk * BB;
-        const int d = s_cmap[rec.ch[0].cmap_start + blk];
-        F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += u0[u];
-      }
-    }
-    if (nch > 1) {
-      __syncthreads();
+  for (int ti = t0; ti < t1; ++ti) {
+    const int f = P.task_fronts[ti];
+    const FrontRec rec = P.rec[f];             // wave-uniform: scalar loads
+    const int ns = rec.ns, nbd = rec.nb;
+    const int m = (ns + nbd) * BS, npiv = ns * BS, ld = m;
+    const int na = rec.asm_cnt;
+    int* s_pos = s_q + na;
+    // LDS-resident fronts stage the child maps and the triangle table; scratch-slab (large) fronts
+    // read them from global memory (they can exceed the LDS)
+    int* s_cmap_l = s_pos + na;
+    int* s_tri_l = s_cmap_l + rec.cmap_cnt;
+    const int* s_cmap = USE_LDS ? s_cmap_l : (P.cmap + rec.cmap_off);
+    const int* s_tri = USE_LDS ? s_tri_l : P.tri;
+    const bool carried = ncarry > 0;            // the only child arrived through registers
+
+    // ---- issue the children's update-matrix loads first (fast path: <= 2 children that fit one round)
+    const int nch = rec.child_cnt;
+    const int nU0 = nch > 0 ? rec.ch[0].nbc * (rec.ch[0].nbc + 1) / 2 * BB : 0;
+    const int nU1 = nch > 1 ? rec.ch[1].nbc * (rec.ch[1].nbc + 1) / 2 * BB : 0;
+    const bool fast_children = !carried && nch <= 2 && nU0 <= UNR * NT && nU1 <= UNR * NT;
+    double u0[UNR], u1[UNR];
+    if (fast_children) {
+      const double* U0 = P.U + rec.ch[0].U_off;
+      const double* U1 = P.U + rec.ch[1].U_off;
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int t = tid + u * NT;
-        if (t < nU1) {
-          const int blk = t / BB, e = t - blk * BB;
-          const int d = s_cmap[rec.ch[1].cmap_start + blk];
-          F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += u1[u];
+        u0[u] = (t < nU0) ? U0[t] : 0.0;
+        u1[u] = (t < nU1) ? U1[t] : 0.0;
+      }
+    }
+    // ---- stage the index tables in LDS (independent loads), zero the front meanwhile
+    stage_copy<2>(s_q, P.asm_q + rec.asm_off, na, tid, NT);
+    stage_copy<2>(s_pos, P.asm_pos + rec.asm_off, na, tid, NT);
+    if (USE_LDS) {
+      stage_copy<2>(s_cmap_l, P.cmap + rec.cmap_off, rec.cmap_cnt, tid, NT);
+      stage_copy<2>(s_tri_l, P.tri, rec.tri_cnt, tid, NT);
+    }
+    for (int i = tid; i < m * m; i += NT) F[i] = 0.0;
+    __syncthreads();
+    // ---- original entries (each block lands on a distinct tile)
+    {
+      const int nA = na * BB;
+      for (int base = tid; base < nA; base += UNR * NT) {
+        double v[UNR];
+        int dst[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int t = base + u * NT;
+          dst[u] = -1;
+          v[u] = 0.0;
+          if (t < nA) {
+            const int e = t / BB, rc = t - e * BB;
+            const int r = rc % BS, c = rc / BS;
+            const int q = s_q[e], pos = s_pos[e];
+            const int lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff, tr = (pos >> 30) & 1;
+            v[u] = tr ? A[(size_t)q * BB + c + BS * r] : A[(size_t)q * BB + r + BS * c];
+            dst[u] = (lr * BS + r) + ld * (lc * BS + c);
+          }
         }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          if (dst[u] >= 0) F[dst[u]] = v[u];
       }
     }
     __syncthreads();
-  } else {
-    for (int ch = 0; ch < nch && !(ablate & 4); ++ch) {
-      const ChildDesc cd = P.cdesc[rec.child_off + ch];  // wave-uniform
-      const int* cmap = s_cmap + cd.cmap_start;
-      const double* Uc = P.U + cd.U_off;
-      const int nU = cd.nbc * (cd.nbc + 1) / 2 * BB;
-      for (int base = tid; base < nU; base += UNR * NT) {
-        double v[UNR];
+    // ---- extend-add of the children (sequential over children: destinations may overlap).  Update
+    // matrices are packed lower-triangular blocks (row-major block order); cmap gives, per packed
+    // block, the destination block (row | col << 16) in this front.
+    if (carried) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int t = base + u * NT;
-          v[u] = (t < nU) ? Uc[t] : 0.0;
+      for (int u = 0; u < kChainU; ++u) {
+        const int t = tid + u * NT;
+        if (t < ncarry) {
+          const int blk = t / BB, e = t - blk * BB;
+          const int d = s_cmap[rec.ch[0].cmap_start + blk];
+          F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += ucarry[u];
         }
+      }
+      __syncthreads();
+    } else if (fast_children) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int t = tid + u * NT;
+        if (t < nU0) {
+          const int blk = t / BB, e = t - blk * BB;
+          const int d = s_cmap[rec.ch[0].cmap_start + blk];
+          F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += u0[u];
+        }
+      }
+      if (nch > 1) {
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-          const int t = base + u * NT;
-          if (t < nU) {
+          const int t = tid + u * NT;
+          if (t < nU1) {
             const int blk = t / BB, e = t - blk * BB;
-            const int d = cmap[blk];
-            F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += v[u];
+            const int d = s_cmap[rec.ch[1].cmap_start + blk];
+            F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += u1[u];
           }
         }
       }
       __syncthreads();
-    }
-  }
-  G2OHIP_STAMP();
-  // ---- partial Cholesky, one pivot block (BS columns) per step.
-  // The BS x BS diagonal factor is a long dependent chain (rsqrt, scale, update x BS); it is kept off
-  // the critical path by look-ahead: while waves 1.. apply the trailing update of step kb, wave 0
-  // updates only the NEXT diagonal block and factorises it into a small LDS mailbox (sd).
-  auto diag_factor = [&](int kb_, double* box) {                        // executed by every lane of wave 0
-    const int k0_ = kb_ * BS;
-    double Lk[BS][BS], inv[BS];
-#pragma unroll
-    for (int c = 0; c < BS; ++c)
-#pragma unroll
-      for (int r = 0; r < BS; ++r) Lk[r][c] = (r >= c) ? F[(k0_ + r) + (size_t)ld * (k0_ + c)] : 0.0;
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < BS; ++c) {
-      double d = Lk[c][c];
-      if (!(d > 0.0)) {
-        bad = true;
-        d = 1.0;
-      }
-      double sq, r;
-      sqrt_and_rsqrt(d, sq, r);
-      inv[c] = r;
-      Lk[c][c] = sq;
-#pragma unroll
-      for (int i = c + 1; i < BS; ++i) Lk[i][c] *= r;
-#pragma unroll
-      for (int j = c + 1; j < BS; ++j)
-#pragma unroll
-        for (int i = j; i < BS; ++i) Lk[i][j] -= Lk[i][c] * Lk[j][c];
-    }
-    if (tid == 0) {
-      if (bad) *P.status = 1;
-#pragma unroll
-      for (int c = 0; c < BS; ++c) {
-#pragma unroll
-        for (int r = 0; r < BS; ++r) {
-          const double v = (r >= c) ? Lk[r][c] : 0.0;
-          box[r + BS * c] = v;
-          F[(k0_ + r) + (size_t)ld * (k0_ + c)] = v;   // final L_kk for the panel store
-        }
-        box[BB + c] = inv[c];
-      }
-    }
-  };
-  if (!(ablate & 8) && ns > 0) {
-    if (tid < 64) diag_factor(0, sd);
-    __syncthreads();
-  }
-  G2OHIP_STAMP();
-  long long* dbgA = (ablate & 64) && blockIdx.x == 0 && tid == 0 ? P.dbg + 16 * 64 + 16 * P.dbg_slot[0] : nullptr;       // wave 0
-  long long* dbgB = (ablate & 64) && blockIdx.x == 0 && tid == 64 ? P.dbg + 2 * 16 * 64 + 16 * P.dbg_slot[0] : nullptr;  // wave 1
-  int ka = 0, kbb = 0;
-  for (int kb = 0; kb < ns && !(ablate & 8); ++kb) {
-    const int k0 = kb * BS;
-    const double* box = sd + (kb & 1) * (BB + BS);
-    if (dbgA && ka < 14) dbgA[ka++] = wall_clock64();
-    if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
-    double Lk[BS][BS], inv[BS];
-#pragma unroll
-    for (int c = 0; c < BS; ++c) {
-      inv[c] = box[BB + c];
-#pragma unroll
-      for (int r = 0; r < BS; ++r) Lk[r][c] = (r > c) ? box[r + BS * c] : 0.0;
-    }
-    // rows below the diagonal block: x * Lkk' = row
-    for (int i = k0 + BS + tid; i < m; i += NT) {
-      double x[BS];
-#pragma unroll
-      for (int c = 0; c < BS; ++c) x[c] = F[i + (size_t)ld * (k0 + c)];
-#pragma unroll
-      for (int c = 0; c < BS; ++c) {
-        double v = x[c];
-#pragma unroll
-        for (int q = 0; q < c; ++q) v -= x[q] * Lk[c][q];
-        x[c] = v * inv[c];
-      }
-#pragma unroll
-      for (int c = 0; c < BS; ++c) F[i + (size_t)ld * (k0 + c)] = x[c];
-    }
-    if (dbgA && ka < 14) dbgA[ka++] = wall_clock64();
-    if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
-    __syncthreads();
-    if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
-    // trailing update with T x T register tiles over the lower triangle (tile coordinates relative
-    // to the first trailing row; the first LA(LA+1)/2 table entries are the next diagonal block)
-    const int r0 = k0 + BS;
-    const int nt = (m - r0) / T;
-    const int ntiles = nt * (nt + 1) / 2;
-    const bool lookahead = (kb + 1 < ns) && NT > 64;
-    auto update_tile = [&](int packed) {
-      const int i0 = r0 + (packed & 0xffff) * T, j0 = r0 + (packed >> 16) * T;
-      // all LDS operands first (one latency), then the FMAs, then the stores
-      double av[BS][T], bv[BS][T], cv[T][T];
-#pragma unroll
-      for (int q = 0; q < BS; ++q) {
-#pragma unroll
-        for (int a = 0; a < T; ++a) av[q][a] = F[(i0 + a) + (size_t)ld * (k0 + q)];
-#pragma unroll
-        for (int b = 0; b < T; ++b) bv[q][b] = F[(j0 + b) + (size_t)ld * (k0 + q)];
-      }
-#pragma unroll
-      for (int b = 0; b < T; ++b)
-#pragma unroll
-        for (int a = 0; a < T; ++a) cv[a][b] = F[(i0 + a) + (size_t)ld * (j0 + b)];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < BS; ++q)
-#pragma unroll
-        for (int a = 0; a < T; ++a)
-#pragma unroll
-          for (int b = 0; b < T; ++b) cv[a][b] -= av[q][a] * bv[q][b];
-#pragma unroll
-      for (int b = 0; b < T; ++b)
-#pragma unroll
-        for (int a = 0; a < T; ++a) F[(i0 + a) + (size_t)ld * (j0 + b)] = cv[a][b];
-    };
-    constexpr int NLA = LA * (LA + 1) / 2;
-    if (lookahead && tid < 64) {
-      if (tid < NLA) update_tile(s_tri[tid]);
-      __threadfence_block();   // the wave's own LDS writes are complete before it re-reads the block
-      diag_factor(kb + 1, sd + ((kb + 1) & 1) * (BB + BS));
     } else {
-      const int first = lookahead ? NLA + tid - 64 : tid, stride = lookahead ? NT - 64 : NT;
-      for (int idx = first; idx < ntiles; idx += stride) update_tile(s_tri[idx]);
-      if (kb == 0 && dbgB) dbgB[kbb++] = wall_clock64();
+      for (int ch = 0; ch < nch; ++ch) {
+        const ChildDesc cd = P.cdesc[rec.child_off + ch];  // wave-uniform
+        const int* cmap = s_cmap + cd.cmap_start;
+        const double* Uc = P.U + cd.U_off;
+        const int nU = cd.nbc * (cd.nbc + 1) / 2 * BB;
+        for (int base = tid; base < nU; base += UNR * NT) {
+          double v[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int t = base + u * NT;
+            v[u] = (t < nU) ? Uc[t] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int t = base + u * NT;
+            if (t < nU) {
+              const int blk = t / BB, e = t - blk * BB;
+              const int d = cmap[blk];
+              F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += v[u];
+            }
+          }
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
-  }
-  G2OHIP_STAMP();
-  // ---- write L panel (m x npiv) and the update matrix (packed lower-triangular blocks, row-major)
-  double* Lg = P.L + rec.L_off;
-  if (!(ablate & 16))
-  {
+    // ---- partial Cholesky, one pivot block (BS columns) per step.
+    // The BS x BS diagonal factor is a long dependent chain (rsqrt, scale, update x BS); it is kept off
+    // the critical path by look-ahead: while waves 1.. apply the trailing update of step kb, wave 0
+    // updates only the NEXT diagonal block and factorises it into a small LDS mailbox (sd).
+    auto diag_factor = [&](int kb_, double* box) {                        // executed by every lane of wave 0
+      const int k0_ = kb_ * BS;
+      double Lk[BS][BS], inv[BS];
+#pragma unroll
+      for (int c = 0; c < BS; ++c)
+#pragma unroll
+        for (int r = 0; r < BS; ++r) Lk[r][c] = (r >= c) ? F[(k0_ + r) + (size_t)ld * (k0_ + c)] : 0.0;
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < BS; ++c) {
+        double d = Lk[c][c];
+        if (!(d > 0.0)) {
+          bad = true;
+          d = 1.0;
+        }
+        double sq, r;
+        sqrt_and_rsqrt(d, sq, r);
+        inv[c] = r;
+        Lk[c][c] = sq;
+#pragma unroll
+        for (int i = c + 1; i < BS; ++i) Lk[i][c] *= r;
+#pragma unroll
+        for (int j = c + 1; j < BS; ++j)
+#pragma unroll
+          for (int i = j; i < BS; ++i) Lk[i][j] -= Lk[i][c] * Lk[j][c];
+      }
+      if (tid == 0) {
+        if (bad) *P.status = 1;
+#pragma unroll
+        for (int c = 0; c < BS; ++c) {
+#pragma unroll
+          for (int r = 0; r < BS; ++r) {
+            const double v = (r >= c) ? Lk[r][c] : 0.0;
+            box[r + BS * c] = v;
+            F[(k0_ + r) + (size_t)ld * (k0_ + c)] = v;   // final L_kk for the panel store
+          }
+          box[BB + c] = inv[c];
+        }
+      }
+    };
+    if (ns > 0) {
+      if (tid < 64) diag_factor(0, sd);
+      __syncthreads();
+    }
+    for (int kb = 0; kb < ns; ++kb) {
+      const int k0 = kb * BS;
+      const double* box = sd + (kb & 1) * (BB + BS);
+      double Lk[BS][BS], inv[BS];
+#pragma unroll
+      for (int c = 0; c < BS; ++c) {
+        inv[c] = box[BB + c];
+#pragma unroll
+        for (int r = 0; r < BS; ++r) Lk[r][c] = (r > c) ? box[r + BS * c] : 0.0;
+      }
+      // rows below the diagonal block: x * Lkk' = row
+      for (int i = k0 + BS + tid; i < m; i += NT) {
+        double x[BS];
+#pragma unroll
+        for (int c = 0; c < BS; ++c) x[c] = F[i + (size_t)ld * (k0 + c)];
+#pragma unroll
+        for (int c = 0; c < BS; ++c) {
+          double v = x[c];
+#pragma unroll
+          for (int q = 0; q < c; ++q) v -= x[q] * Lk[c][q];
+          x[c] = v * inv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < BS; ++c) F[i + (size_t)ld * (k0 + c)] = x[c];
+      }
+      __syncthreads();
+      // trailing update with T x T register tiles over the lower triangle (tile coordinates relative
+      // to the first trailing row; the first LA(LA+1)/2 table entries are the next diagonal block)
+      const int r0 = k0 + BS;
+      const int nt = (m - r0) / T;
+      const int ntiles = nt * (nt + 1) / 2;
+      const bool lookahead = (kb + 1 < ns) && NT > 64;
+      auto update_tile = [&](int packed) {
+        const int i0 = r0 + (packed & 0xffff) * T, j0 = r0 + (packed >> 16) * T;
+        // all LDS operands first (one latency), then the FMAs, then the stores
+        double av[BS][T], bv[BS][T], cv[T][T];
+#pragma unroll
+        for (int q = 0; q < BS; ++q) {
+#pragma unroll
+          for (int a = 0; a < T; ++a) av[q][a] = F[(i0 + a) + (size_t)ld * (k0 + q)];
+#pragma unroll
+          for (int b = 0; b < T; ++b) bv[q][b] = F[(j0 + b) + (size_t)ld * (k0 + q)];
+        }
+#pragma unroll
+        for (int b = 0; b < T; ++b)
+#pragma unroll
+          for (int a = 0; a < T; ++a) cv[a][b] = F[(i0 + a) + (size_t)ld * (j0 + b)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < BS; ++q)
+#pragma unroll
+          for (int a = 0; a < T; ++a)
+#pragma unroll
+            for (int b = 0; b < T; ++b) cv[a][b] -= av[q][a] * bv[q][b];
+#pragma unroll
+        for (int b = 0; b < T; ++b)
+#pragma unroll
+          for (int a = 0; a < T; ++a) F[(i0 + a) + (size_t)ld * (j0 + b)] = cv[a][b];
+      };
+      if (lookahead && tid < 64) {
+        if (tid < NLA) update_tile(s_tri[tid]);
+        __threadfence_block();   // the wave's own LDS writes are complete before it re-reads the block
+        diag_factor(kb + 1, sd + ((kb + 1) & 1) * (BB + BS));
+      } else {
+        const int first = lookahead ? NLA + tid - 64 : tid, stride = lookahead ? NT - 64 : NT;
+        for (int idx = first; idx < ntiles; idx += stride) update_tile(s_tri[idx]);
+      }
+      __syncthreads();
+    }
+    // ---- write the L panel (m x npiv) and the reciprocals of its diagonal
+    double* Lg = P.L + rec.L_off;
     for (int t = tid; t < m * npiv; t += NT) Lg[t] = F[t];  // ld == m: identical layout
     for (int k = tid; k < npiv; k += NT) Lg[(size_t)m * npiv + k] = 1.0 / F[k + (size_t)ld * k];
-  }
-  double* Ug = P.U + rec.U_off;
-  if (!(ablate & 32)) {
+    // ---- update matrix (packed lower-triangular blocks, row-major): to the next chain front through
+    // registers, or to HBM for a parent in a later launch
     const int nU = nbd * (nbd + 1) / 2 * BB;
-    for (int t = tid; t < nU; t += NT) {
-      const int blk = t / BB, e = t - blk * BB;
-      const int d = s_tri[blk];
-      Ug[t] = F[(npiv + (d & 0xffff) * BS + e % BS) + ld * (npiv + (d >> 16) * BS + e / BS)];
+    if (ti + 1 < t1) {
+      ncarry = nU;
+#pragma unroll
+      for (int u = 0; u < kChainU; ++u) {
+        const int t = tid + u * NT;
+        if (t < nU) {
+          const int blk = t / BB, e = t - blk * BB;
+          const int d = s_tri[blk];
+          ucarry[u] = F[(npiv + (d & 0xffff) * BS + e % BS) + ld * (npiv + (d >> 16) * BS + e / BS)];
+        }
+      }
+    } else {
+      ncarry = 0;
+      double* Ug = P.U + rec.U_off;
+      for (int t = tid; t < nU; t += NT) {
+        const int blk = t / BB, e = t - blk * BB;
+        const int d = s_tri[blk];
+        Ug[t] = F[(npiv + (d & 0xffff) * BS + e % BS) + ld * (npiv + (d >> 16) * BS + e / BS)];
+      }
     }
+    __syncthreads();   // F and the LDS tables are reused by the next front of the chain
   }
-  G2OHIP_STAMP();
-  if (dbg) { dbg[15] = m; P.dbg_slot[0] = (P.dbg_slot[0] + 1) % 64; }
-#undef G2OHIP_STAMP
 }
 
 // b_perm[new*bs + r] = b[old*bs + r]
@@ -971,190 +1015,215 @@ __global__ void permute_out_kernel(int nb, int bs, const int* __restrict__ perm,
   x[(size_t)perm[k] * bs + r] = xp[t];
 }
 
-// Forward sweep for one front: y1 = L11 \ (b1 + children), w = (children on boundary) - L21 y1.
-// Blocked by BS: every thread redundantly solves the BS x BS triangular diagonal system (broadcast
-// LDS reads), then the rows below are updated in parallel -> one barrier per pivot block.
-// LDS: [panel (optional)] [t: m] [ys: npiv]
+// Forward sweep over one task (chain of fronts, leaves first):
+//   y1 = L11 \ (b1 + children), w = (children on boundary) - L21 y1
+// Blocked by BS: every thread redundantly solves the BS x BS triangular diagonal system (broadcast LDS
+// reads, reciprocal diagonal), then the rows below are updated in parallel -> one barrier per pivot
+// block.  Inside a chain the update vector w stays in LDS.
+// LDS: [panel (optional)] [t: mcap] [ys: mcap] [wprev: mcap]
 template <int BS, bool PANEL_LDS>
-__global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const int* __restrict__ fronts,
-                                                           const double* __restrict__ bperm, double* __restrict__ y, int panel_cap) {
+__global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const int* __restrict__ tasks,
+                                                           const double* __restrict__ bperm, double* __restrict__ y, int panel_cap,
+                                                           int mcap) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int f = fronts[blockIdx.x];
-  const FrontRec rec = P.rec[f];
-  const int ns = rec.ns, nbd = rec.nb;
-  const int m = (ns + nbd) * BS, npiv = ns * BS, c0 = rec.c0;
+  const int task = tasks[blockIdx.x];
+  const int t0 = P.task_ptr[task], t1 = P.task_ptr[task + 1];
   const int tid = threadIdx.x, NT = blockDim.x;
   double* Lp = smem;
   double* t = smem + (PANEL_LDS ? panel_cap : 0);
-  double* ys = t + m;
-  const double* Lg = P.L + rec.L_off;
-  if (PANEL_LDS) stage_copy<8>(Lp, Lg, m * npiv + npiv, tid, NT);
-  const double* Lx = PANEL_LDS ? Lp : Lg;
-  const double* Linv = Lx + (size_t)m * npiv;
-  // children's update vectors: issue the loads before the first barrier (fast path: <= 2 children
-  // whose boundary fits one round), apply them one child at a time (rows may coincide)
-  const int nch = rec.child_cnt;
-  const int n0 = nch > 0 ? rec.ch[0].nbc * BS : 0, n1 = nch > 1 ? rec.ch[1].nbc * BS : 0;
-  const bool fast_children = nch <= 2 && n0 <= NT && n1 <= NT;
-  double w0 = 0.0, w1 = 0.0;
-  int d0 = 0, d1 = 0;
-  if (fast_children) {
-    if (tid < n0) {
-      w0 = P.w[rec.ch[0].w_off + tid];
-      d0 = P.crel[rec.crel_off + rec.ch[0].crel_start + tid / BS] * BS + tid % BS;
-    }
-    if (tid < n1) {
-      w1 = P.w[rec.ch[1].w_off + tid];
-      d1 = P.crel[rec.crel_off + rec.ch[1].crel_start + tid / BS] * BS + tid % BS;
-    }
-  }
-  for (int i = tid; i < m; i += NT) t[i] = (i < npiv) ? bperm[(size_t)c0 * BS + i] : 0.0;
-  __syncthreads();
-  if (fast_children) {
-    if (tid < n0) t[d0] += w0;
-    if (nch > 1) {
-      __syncthreads();
-      if (tid < n1) t[d1] += w1;
-    }
-    if (nch > 0) __syncthreads();
-  } else {
-    for (int ch = 0; ch < nch; ++ch) {
-      const ChildDesc cd = P.cdesc[rec.child_off + ch];
-      const int nbc = cd.nbc * BS;
-      const double* wc = P.w + cd.w_off;
-      const int* rel = P.crel + rec.crel_off + cd.crel_start;
-      for (int i = tid; i < nbc; i += NT) t[rel[i / BS] * BS + (i % BS)] += wc[i];
-      __syncthreads();
-    }
-  }
-  for (int kb = 0; kb < ns; ++kb) {
-    const int k0 = kb * BS;
-    double yv[BS];
-#pragma unroll
-    for (int c = 0; c < BS; ++c) {
-      double v = t[k0 + c];
-#pragma unroll
-      for (int q = 0; q < c; ++q) v -= Lx[(k0 + c) + (size_t)m * (k0 + q)] * yv[q];
-      yv[c] = v * Linv[k0 + c];
-    }
-    if (tid == 0) {
-#pragma unroll
-      for (int c = 0; c < BS; ++c) ys[k0 + c] = yv[c];
-    }
-    for (int i = k0 + BS + tid; i < m; i += NT) {
-      double v = t[i];
-#pragma unroll
-      for (int q = 0; q < BS; ++q) v -= Lx[i + (size_t)m * (k0 + q)] * yv[q];
-      t[i] = v;
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < npiv; i += NT) y[(size_t)c0 * BS + i] = ys[i];
-  double* wf = P.w + P.w_off[f];
-  for (int i = tid; i < nbd * BS; i += NT) wf[i] = t[npiv + i];
-}
-
-// Backward sweep for one front: x1 = L11' \ (y1 - L21' x_boundary); same blocking.
-// LDS: [panel (optional)] [t: m] [xs: npiv] [sp: partial sums, NT]
-template <int BS, bool PANEL_LDS>
-__global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, const int* __restrict__ fronts,
-                                                            const double* __restrict__ y, double* __restrict__ xp, int panel_cap) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int f = fronts[blockIdx.x];
-  const FrontRec rec = P.rec[f];
-  const int ns = rec.ns, nbd = rec.nb;
-  const int m = (ns + nbd) * BS, npiv = ns * BS, c0 = rec.c0;
-  const int tid = threadIdx.x, NT = blockDim.x;
-  double* Lp = smem;
-  double* t = smem + (PANEL_LDS ? panel_cap : 0);
-  double* xs = t + m;
-  double* sp = xs + m;
-  const double* Lg = P.L + rec.L_off;
-  if (PANEL_LDS) stage_copy<8>(Lp, Lg, m * npiv + npiv, tid, NT);
-  const double* Lx = PANEL_LDS ? Lp : Lg;
-  const double* Linv = Lx + (size_t)m * npiv;
-  const int* rows = P.rows + P.rows_off[f];
-  for (int i = tid; i < m; i += NT)
-    t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : xp[(size_t)rows[(i - npiv) / BS] * BS + ((i - npiv) % BS)];
-  __syncthreads();
-  // boundary contribution t[k] -= sum_{i>=npiv} L[i,k] t[i]: (k, part) decomposition + LDS reduction
-  {
-    const int parts = NT / npiv > 0 ? NT / npiv : 1;
-    const int k = tid % npiv, part = tid / npiv;
-    double s = 0.0;
-    if (part < parts)
-      for (int i = npiv + part; i < m; i += parts) s += Lx[i + (size_t)m * k] * t[i];
-    if (parts == 1) {
-      // fewer threads than pivot columns: loop over the remaining columns serially
-      for (int kk = tid; kk < npiv; kk += NT) {
-        double s2 = 0.0;
-        for (int i = npiv; i < m; ++i) s2 += Lx[i + (size_t)m * kk] * t[i];
-        sp[kk] = s2;
+  double* ys = t + mcap;
+  double* wprev = ys + mcap;
+  int nprev = 0;
+  for (int ti = t0; ti < t1; ++ti) {
+    const int f = P.task_fronts[ti];
+    const FrontRec rec = P.rec[f];
+    const int ns = rec.ns, nbd = rec.nb;
+    const int m = (ns + nbd) * BS, npiv = ns * BS, c0 = rec.c0;
+    const double* Lg = P.L + rec.L_off;
+    if (PANEL_LDS) stage_copy<8>(Lp, Lg, m * npiv + npiv, tid, NT);
+    const double* Lx = PANEL_LDS ? Lp : Lg;
+    const double* Linv = Lx + (size_t)m * npiv;
+    // children's update vectors: issue the loads before the first barrier (fast path: <= 2 children
+    // whose boundary fits one round), apply them one child at a time (rows may coincide)
+    const bool carried = nprev > 0;
+    const int nch = rec.child_cnt;
+    const int n0 = nch > 0 ? rec.ch[0].nbc * BS : 0, n1 = nch > 1 ? rec.ch[1].nbc * BS : 0;
+    const bool fast_children = nch <= 2 && n0 <= NT && n1 <= NT;
+    double w0 = 0.0, w1 = 0.0;
+    int d0 = 0, d1 = 0;
+    if (fast_children) {
+      if (tid < n0) {
+        w0 = carried ? 0.0 : P.w[rec.ch[0].w_off + tid];
+        d0 = P.crel[rec.crel_off + rec.ch[0].crel_start + tid / BS] * BS + tid % BS;
       }
-      __syncthreads();
-      for (int kk = tid; kk < npiv; kk += NT) t[kk] -= sp[kk];
+      if (tid < n1) {
+        w1 = P.w[rec.ch[1].w_off + tid];
+        d1 = P.crel[rec.crel_off + rec.ch[1].crel_start + tid / BS] * BS + tid % BS;
+      }
+    }
+    for (int i = tid; i < m; i += NT) t[i] = (i < npiv) ? bperm[(size_t)c0 * BS + i] : 0.0;
+    __syncthreads();
+    if (fast_children) {
+      if (tid < n0) t[d0] += carried ? wprev[tid] : w0;
+      if (nch > 1) {
+        __syncthreads();
+        if (tid < n1) t[d1] += w1;
+      }
+      if (nch > 0) __syncthreads();
     } else {
-      sp[tid] = (part < parts) ? s : 0.0;
-      __syncthreads();
-      if (tid < npiv) {
-        double a = 0.0;
-        for (int pp = 0; pp < parts; ++pp) a += sp[pp * npiv + tid];
-        t[tid] -= a;
+      for (int ch = 0; ch < nch; ++ch) {
+        const ChildDesc cd = P.cdesc[rec.child_off + ch];
+        const int nbc = cd.nbc * BS;
+        const double* wc = P.w + cd.w_off;
+        const int* rel = P.crel + rec.crel_off + cd.crel_start;
+        for (int i = tid; i < nbc; i += NT) t[rel[i / BS] * BS + (i % BS)] += (carried ? wprev[i] : wc[i]);
+        __syncthreads();
       }
     }
-  }
-  __syncthreads();
-  for (int kb = ns - 1; kb >= 0; --kb) {
-    const int k0 = kb * BS;
-    double xv[BS];
+    for (int kb = 0; kb < ns; ++kb) {
+      const int k0 = kb * BS;
+      double yv[BS];
 #pragma unroll
-    for (int c = BS - 1; c >= 0; --c) {
-      double v = t[k0 + c];
+      for (int c = 0; c < BS; ++c) {
+        double v = t[k0 + c];
 #pragma unroll
-      for (int q = c + 1; q < BS; ++q) v -= Lx[(k0 + q) + (size_t)m * (k0 + c)] * xv[q];
-      xv[c] = v * Linv[k0 + c];
+        for (int q = 0; q < c; ++q) v -= Lx[(k0 + c) + (size_t)m * (k0 + q)] * yv[q];
+        yv[c] = v * Linv[k0 + c];
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < BS; ++c) ys[k0 + c] = yv[c];
+      }
+      for (int i = k0 + BS + tid; i < m; i += NT) {
+        double v = t[i];
+#pragma unroll
+        for (int q = 0; q < BS; ++q) v -= Lx[i + (size_t)m * (k0 + q)] * yv[q];
+        t[i] = v;
+      }
+      __syncthreads();
     }
-    if (tid == 0) {
-#pragma unroll
-      for (int c = 0; c < BS; ++c) xs[k0 + c] = xv[c];
-    }
-    for (int j = tid; j < k0; j += NT) {
-      double v = t[j];
-#pragma unroll
-      for (int q = 0; q < BS; ++q) v -= Lx[(k0 + q) + (size_t)m * j] * xv[q];
-      t[j] = v;
+    for (int i = tid; i < npiv; i += NT) y[(size_t)c0 * BS + i] = ys[i];
+    if (ti + 1 < t1) {
+      nprev = nbd * BS;
+      for (int i = tid; i < nprev; i += NT) wprev[i] = t[npiv + i];
+    } else {
+      nprev = 0;
+      double* wf = P.w + P.w_off[f];
+      for (int i = tid; i < nbd * BS; i += NT) wf[i] = t[npiv + i];
     }
     __syncthreads();
   }
-  for (int i = tid; i < npiv; i += NT) xp[(size_t)c0 * BS + i] = xs[i];
 }
 
-// developer ablation switch (timing experiments only; results are invalid when non-zero)
-inline int ablate_flags() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("G2OHIP_ABLATE");
-    v = e ? atoi(e) : 0;
+// Backward sweep over one task (chain top first): x1 = L11' \ (y1 - L21' x_boundary); same blocking.
+// Inside a chain the child's boundary values are taken from the parent's vector kept in LDS.
+// LDS: [panel (optional)] [t: mcap] [xs: mcap] [sp: NT] [fullprev: mcap]
+template <int BS, bool PANEL_LDS>
+__global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, const int* __restrict__ tasks,
+                                                            const double* __restrict__ y, double* __restrict__ xp, int panel_cap,
+                                                            int mcap) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int task = tasks[blockIdx.x];
+  const int t0 = P.task_ptr[task], t1 = P.task_ptr[task + 1];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  double* Lp = smem;
+  double* t = smem + (PANEL_LDS ? panel_cap : 0);
+  double* xs = t + mcap;
+  double* sp = xs + mcap;
+  double* fullprev = sp + NT;
+  const int* prel = nullptr;   // this front's relative indices inside its chain parent
+  for (int ti = t1 - 1; ti >= t0; --ti) {
+    const int f = P.task_fronts[ti];
+    const FrontRec rec = P.rec[f];
+    const int ns = rec.ns, nbd = rec.nb;
+    const int m = (ns + nbd) * BS, npiv = ns * BS, c0 = rec.c0;
+    const double* Lg = P.L + rec.L_off;
+    if (PANEL_LDS) stage_copy<8>(Lp, Lg, m * npiv + npiv, tid, NT);
+    const double* Lx = PANEL_LDS ? Lp : Lg;
+    const double* Linv = Lx + (size_t)m * npiv;
+    if (prel) {
+      for (int i = tid; i < m; i += NT)
+        t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : fullprev[prel[(i - npiv) / BS] * BS + ((i - npiv) % BS)];
+    } else {
+      const int* rows = P.rows + P.rows_off[f];
+      for (int i = tid; i < m; i += NT)
+        t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : xp[(size_t)rows[(i - npiv) / BS] * BS + ((i - npiv) % BS)];
+    }
+    __syncthreads();
+    // boundary contribution t[k] -= sum_{i>=npiv} L[i,k] t[i]: (k, part) decomposition + LDS reduction
+    {
+      const int parts = NT / npiv > 0 ? NT / npiv : 1;
+      const int k = tid % npiv, part = tid / npiv;
+      double s = 0.0;
+      if (part < parts && NT >= npiv)
+        for (int i = npiv + part; i < m; i += parts) s += Lx[i + (size_t)m * k] * t[i];
+      if (NT < npiv) {
+        // fewer threads than pivot columns: loop over the columns serially
+        for (int kk = tid; kk < npiv; kk += NT) {
+          double s2 = 0.0;
+          for (int i = npiv; i < m; ++i) s2 += Lx[i + (size_t)m * kk] * t[i];
+          xs[kk] = s2;
+        }
+        __syncthreads();
+        for (int kk = tid; kk < npiv; kk += NT) t[kk] -= xs[kk];
+      } else {
+        sp[tid] = (part < parts) ? s : 0.0;
+        __syncthreads();
+        if (tid < npiv) {
+          double a = 0.0;
+          for (int pp = 0; pp < parts; ++pp) a += sp[pp * npiv + tid];
+          t[tid] -= a;
+        }
+      }
+    }
+    __syncthreads();
+    for (int kb = ns - 1; kb >= 0; --kb) {
+      const int k0 = kb * BS;
+      double xv[BS];
+#pragma unroll
+      for (int c = BS - 1; c >= 0; --c) {
+        double v = t[k0 + c];
+#pragma unroll
+        for (int q = c + 1; q < BS; ++q) v -= Lx[(k0 + q) + (size_t)m * (k0 + c)] * xv[q];
+        xv[c] = v * Linv[k0 + c];
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < BS; ++c) xs[k0 + c] = xv[c];
+      }
+      for (int j = tid; j < k0; j += NT) {
+        double v = t[j];
+#pragma unroll
+        for (int q = 0; q < BS; ++q) v -= Lx[(k0 + q) + (size_t)m * j] * xv[q];
+        t[j] = v;
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < npiv; i += NT) xp[(size_t)c0 * BS + i] = xs[i];
+    if (ti > t0) {
+      // the next front down the chain is this one's only child: keep the whole local solution for it
+      for (int i = tid; i < m; i += NT) fullprev[i] = (i < npiv) ? xs[i] : t[i];
+      prel = P.crel + rec.crel_off + rec.ch[0].crel_start;
+    }
+    __syncthreads();
   }
-  return v;
 }
 
 template <int BS>
-void launch_factor_level(const CholPlanDev& P, const int* d_fronts, const long long* d_scratch_off, double* d_scratch,
+void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long long* d_scratch_off, double* d_scratch,
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
                          int lds_idx_ints, int glb_idx_ints, hipStream_t st) {
   if (lds_count > 0) {
     const int idx_off = lds_max_m * lds_max_m + 2 * (BS * BS + BS);   // F | diagonal-factor mailboxes | index lists
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(lds_idx_ints + 4) * sizeof(int);
-    static int nthr = getenv("G2OHIP_FACTOR_THREADS") ? atoi(getenv("G2OHIP_FACTOR_THREADS")) : kFactorThreads;
-    hipLaunchKernelGGL((front_factor_kernel<BS, true>), dim3(lds_count), dim3(nthr), sh, st, P, d_fronts + lds_begin,
-                       dA, d_scratch, d_scratch_off + lds_begin, idx_off, ablate_flags());
+    hipLaunchKernelGGL((front_factor_kernel<BS, true>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, d_tasks + lds_begin,
+                       dA, d_scratch, d_scratch_off + lds_begin, idx_off);
   }
   if (glb_count > 0) {
     const int idx_off = 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(glb_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, false>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P,
-                       d_fronts + glb_begin, dA, d_scratch, d_scratch_off + glb_begin, idx_off, ablate_flags());
+                       d_tasks + glb_begin, dA, d_scratch, d_scratch_off + glb_begin, idx_off);
   }
 }
 
@@ -1206,18 +1275,18 @@ void SparseCholesky::solve(const double* d_b, double* d_x, hipStream_t st) {
     bool panel = (size_t)LL.max_panel * 8 <= panel_limit;
     int cap = panel ? LL.max_panel : 0;
     int nthreads = LL.max_m <= 64 ? 64 : (LL.max_m <= 128 ? 128 : 256);
-    size_t sh = ((size_t)cap + 2 * (size_t)LL.max_m + nthreads + 8) * sizeof(double);
+    size_t sh = ((size_t)cap + 3 * (size_t)LL.max_m + nthreads + 8) * sizeof(double);
 #define G2OHIP_SOLVE_LAUNCH(BS_)                                                                                              \
   if (fwd) {                                                                                                                  \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_xp.p, d_y.p, cap);  \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_xp.p, d_y.p, cap, LL.max_m);  \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_xp.p, d_y.p, cap); \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_xp.p, d_y.p, cap, LL.max_m); \
   } else {                                                                                                                    \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_y.p, d_xp.p, cap); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_y.p, d_xp.p, cap, LL.max_m); \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_y.p, d_xp.p, cap); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_y.p, d_xp.p, cap, LL.max_m); \
   }
     switch (bs_) {
       case 3: G2OHIP_SOLVE_LAUNCH(3) break;
@@ -1238,26 +1307,6 @@ void SparseCholesky::solve(const double* d_b, double* d_x, hipStream_t st) {
 bool SparseCholesky::failed(hipStream_t st) {
   int h = 0;
   d_status.download(&h, 1, st);
-  if (ablate_flags() & 64) {
-    static int once = 0;
-    if (once++ == 3) {   // print one steady-state iteration: per-level phase stamps of block 0 (100 MHz ticks -> us)
-      std::vector<long long> d(16 * 64 * 3);
-      d_dbg.download(d.data(), d.size(), st);
-      for (int k = 0; k < 64; ++k) {
-        const long long* r = &d[16 * k];
-        if (!r[0]) continue;
-        fprintf(stderr, "[dbg] slot %2d m=%3lld :", k, r[15]);
-        for (int q = 1; q < 8 && r[q]; ++q) fprintf(stderr, " %.2f", (double)(r[q] - r[q - 1]) * 0.01);
-        fprintf(stderr, "  us | w0:");
-        const long long* a = &d[16 * 64 + 16 * k];
-        for (int q = 1; q < 14 && a[q]; ++q) fprintf(stderr, " %.2f", (double)(a[q] - a[q - 1]) * 0.01);
-        fprintf(stderr, " | w1:");
-        const long long* b = &d[2 * 16 * 64 + 16 * k];
-        for (int q = 1; q < 8 && b[q]; ++q) fprintf(stderr, " %.2f", (double)(b[q] - b[q - 1]) * 0.01);
-        fprintf(stderr, "\n");
-      }
-    }
-  }
   return h != 0;
 }
 
