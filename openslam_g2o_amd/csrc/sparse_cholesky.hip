@@ -706,7 +706,7 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& r) {
 // of an n x n triangle is a prefix of that of any larger one, so one table (P.tri) serves every size.
 // LDS: F | 2 diagonal-factor mailboxes | s_q[na] s_pos[na] s_cmap[cmap_cnt] s_tri[tri_cnt]
 template <int BS, bool USE_LDS>
-__global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGlobal) front_factor_kernel(
+__global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGlobal, USE_LDS ? 3 : 1) front_factor_kernel(
     CholPlanDev P, const int* __restrict__ tasks, const double* __restrict__ A, double* __restrict__ scratch,
     const long long* __restrict__ scratch_off, int idx_off_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -935,26 +935,23 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
       const bool lookahead = (kb + 1 < ns) && NT > 64;
       auto update_tile = [&](int packed) {
         const int i0 = r0 + (packed & 0xffff) * T, j0 = r0 + (packed >> 16) * T;
-        // all LDS operands first (one latency), then the FMAs, then the stores
-        double av[BS][T], bv[BS][T], cv[T][T];
-#pragma unroll
-        for (int q = 0; q < BS; ++q) {
-#pragma unroll
-          for (int a = 0; a < T; ++a) av[q][a] = F[(i0 + a) + (size_t)ld * (k0 + q)];
-#pragma unroll
-          for (int b = 0; b < T; ++b) bv[q][b] = F[(j0 + b) + (size_t)ld * (k0 + q)];
-        }
+        double cv[T][T];
 #pragma unroll
         for (int b = 0; b < T; ++b)
 #pragma unroll
           for (int a = 0; a < T; ++a) cv[a][b] = F[(i0 + a) + (size_t)ld * (j0 + b)];
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < BS; ++q)
+        for (int q = 0; q < BS; ++q) {
+          double av[T], bv[T];
+#pragma unroll
+          for (int a = 0; a < T; ++a) av[a] = F[(i0 + a) + (size_t)ld * (k0 + q)];
+#pragma unroll
+          for (int b = 0; b < T; ++b) bv[b] = F[(j0 + b) + (size_t)ld * (k0 + q)];
 #pragma unroll
           for (int a = 0; a < T; ++a)
 #pragma unroll
-            for (int b = 0; b < T; ++b) cv[a][b] -= av[q][a] * bv[q][b];
+            for (int b = 0; b < T; ++b) cv[a][b] -= av[a] * bv[b];
+        }
 #pragma unroll
         for (int b = 0; b < T; ++b)
 #pragma unroll

@@ -68,11 +68,12 @@ def tensor_from_device_ptr(ptr, n, device):
 class TorchComm:
     """all-reduce(SUM) through torch.distributed (backend nccl == RCCL on ROCm, gloo on CPU)."""
 
-    def __init__(self, world):
+    def __init__(self, world, force=False):
         self.world = world
+        self.force = force    # run the collective even on a 1-rank group (exercises RCCL in single-GPU tests)
 
     def all_reduce_sum(self, tensors):
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return
         import torch.distributed as dist
         for t in tensors:
@@ -80,14 +81,15 @@ class TorchComm:
 
 
 class ShardedBlockSolver:
-    def __init__(self, pose_dim, landmark_dim, rank=0, world=1, device=0, local=None, comm=None):
+    def __init__(self, pose_dim, landmark_dim, rank=0, world=1, device=0, local=None, comm=None, force_exchange=False):
         self.p, self.l = pose_dim, landmark_dim
         self.rank, self.world = rank, world
+        self.exchange = world > 1 or force_exchange   # union Schur pattern + all-reduce step active
         if local is None:
             from . import capi
             local = capi.HipBlockSolver(pose_dim, landmark_dim, device)
         self.local = local
-        self.comm = comm or TorchComm(world)
+        self.comm = comm or TorchComm(world, force=force_exchange)
         self._reduced = None
         self._keep = []
 
@@ -109,7 +111,7 @@ class ShardedBlockSolver:
         if nd_leaf:
             self.local.setOption("nd_leaf", nd_leaf)
         self.set_id = self.local.addEdgeSet(2, v0, v1)
-        if self.world > 1:
+        if self.exchange:
             rows, cols = schur_pattern_pairs(prob["v1"], lm)
             self.local.addSchurPattern(rows, cols)
         self.local.buildStructure(nP, lm1 - lm0, True)
@@ -153,7 +155,7 @@ class ShardedBlockSolver:
 
     def solve(self):
         self.local.solveSchur()
-        if self.world > 1:
+        if self.exchange:
             self.comm.all_reduce_sum(self._reduced_tensors())
         ok = self.local.solveReduced()
         if not ok:

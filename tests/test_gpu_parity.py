@@ -302,3 +302,38 @@ def test_sphere_golden_no_schur():
         poses = O.se3_oplus(poses, g["hidx"], x)
     st = s.stats()
     assert st["maxFrontDim"] > 90          # large separators: scratch-slab fronts were used
+
+
+def test_sharded_path_single_rank_rccl():
+    """The N>1 code path on real hardware with world_size 1: RCCL process group, zero-copy torch views
+    of the resident Hschur / bschur arrays (__cuda_array_interface__), the solver running on torch's
+    stream, all-reduce, split solve -- must reproduce the plain solve."""
+    import torch
+    import torch.distributed as dist
+    from openslam_g2o_amd import distributed as D
+    capi = _capi()
+    pr = ba_case(64, 700)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sh = D.ShardedBlockSolver(6, 3, rank=0, world=1, force_exchange=True)   # union pattern + all-reduce on 1 rank
+        info = sh.setup_ba(pr, torch_device=dev)
+        assert info["L_local"] == pr["nL"]
+        sh.buildSystem()
+        sh.setLambda(25.0, True)
+        ok = sh.solve()                   # all_reduce over a 1-rank group is the identity
+        sh.restoreDiagonal()
+        ts = sh._reduced_tensors()
+        assert ts[0].is_cuda and ts[0].dtype == torch.float64 and ts[0].numel() == sh.local.nnzb(capi.HSCHUR) * 36
+        x = sh.local.x()
+        ref = hip_ba(pr)
+        ref.buildSystem()
+        ref.setLambda(25.0, True)
+        assert ok and ref.solve()
+        assert relerr(x, ref.x()) < 1e-12
+        assert torch.allclose(ts[0].cpu(), torch.from_numpy(ref.values(capi.HSCHUR)), rtol=0, atol=1e-9)
+    finally:
+        dist.destroy_process_group()
