@@ -172,6 +172,32 @@ int g2ohip_solve_schur(g2ohip_solver* s);            /* K5-K8: Hschur, bschur, D
 int g2ohip_solve_reduced(g2ohip_solver* s);          /* K9-K12: x_p = Hschur \ bschur        */
 int g2ohip_solve_back_substitute(g2ohip_solver* s);  /* K13: x_l = Dinv (b_l - Hpl' x_p)     */
 
+/* ---- device-resident bundle-adjustment front end (a "next" row) -----
+ * For graphs of EdgeProjectXYZ2UV (g2o/types/sba/types_six_dof_expmap.h:127-150) the library can
+ * produce errors and Jacobians itself and keep the vertex estimates on the device, so a whole
+ * Levenberg-Marquardt trial loop (optimization_algorithm_levenberg.cpp:57-146) runs without moving
+ * Jacobians or estimates over PCIe.  Estimates: cams [n][12] = R (column-major) | t, world -> camera
+ * (what VertexSE3Expmap holds, types_six_dof_expmap.cpp:88-103); points [n][3]. */
+/* edge set `set` (added with error_dim 2, vertex 0 = point, vertex 1 = pose): per-edge indices into
+ * the estimate arrays (all vertices, fixed ones included), measurements [n][2], information [n][2x2]
+ * (NULL = identity), CameraParameters (focal_length, principle_point). After g2ohip_build_structure. */
+int g2ohip_ba_set_edges(g2ohip_solver* s, int set, const int32_t* cam_vertex, const int32_t* point_vertex, const double* meas,
+                        const double* info, double focal_length, double cx, double cy);
+/* setEstimate for every vertex + the index mapping: cam_hidx[v] = hessianIndex (-1 fixed),
+ * point_hidx[v] = landmark index (0-based, i.e. hessianIndex - num_poses) or -1. */
+int g2ohip_ba_set_estimates(g2ohip_solver* s, int n_cams, const double* cams, const int32_t* cam_hidx, int n_points,
+                            const double* points, const int32_t* point_hidx);
+int g2ohip_ba_get_estimates(g2ohip_solver* s, double* cams, double* points);
+/* computeActiveErrors() (+ linearizeOplus() when jacobians != 0) into the set's edge data
+ * (sparse_optimizer.cpp:61-76, types_six_dof_expmap.cpp:288-326). */
+int g2ohip_ba_linearize(g2ohip_solver* s, int jacobians);
+/* SparseOptimizer::update(x): oplus of every free vertex with the current solution (sparse_optimizer.cpp:421-434). */
+int g2ohip_ba_update(g2ohip_solver* s);
+/* SparseOptimizer::push / pop / discardTop on all vertices (one level, what LM needs; sparse_optimizer.cpp:599-650). */
+int g2ohip_ba_push(g2ohip_solver* s);
+int g2ohip_ba_pop(g2ohip_solver* s);
+int g2ohip_ba_discard_top(g2ohip_solver* s);
+
 /* ---- narrow seam: g2o::LinearSolver<MatrixType> ------------------------------------------- */
 
 /* LinearSolver ctor for MatrixType = block_dim x block_dim. */

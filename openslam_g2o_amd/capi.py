@@ -47,7 +47,8 @@ EXPORTS = [
     "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute", "g2ohip_ls_create",
     "g2ohip_ls_destroy", "g2ohip_ls_init", "g2ohip_ls_solve", "g2ohip_ls_get_stats", "g2ohip_ls_set_option",
     "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time", "g2ohip_add_schur_pattern",
-    "g2ohip_set_lambda_split",
+    "g2ohip_set_lambda_split", "g2ohip_ba_set_edges", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
+    "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
 ]
 
 _lib = None
@@ -104,6 +105,12 @@ def load():
     L.g2ohip_device_array.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.g2ohip_add_schur_pattern.argtypes = [vp, C.c_int, c_int_p, c_int_p]
     L.g2ohip_set_lambda_split.argtypes = [vp, C.c_double, C.c_double, C.c_int]
+    L.g2ohip_ba_set_edges.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, C.c_double, C.c_double, C.c_double]
+    L.g2ohip_ba_set_estimates.argtypes = [vp, C.c_int, c_dbl_p, c_int_p, C.c_int, c_dbl_p, c_int_p]
+    L.g2ohip_ba_get_estimates.argtypes = [vp, c_dbl_p, c_dbl_p]
+    L.g2ohip_ba_linearize.argtypes = [vp, C.c_int]
+    for n in ("g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top"):
+        getattr(L, n).argtypes = [vp]
     L.g2ohip_kernel_name.argtypes = [C.c_int]
     L.g2ohip_kernel_name.restype = C.c_char_p
     L.g2ohip_kernel_time.argtypes = [vp, C.c_int, c_dbl_p, C.POINTER(C.c_long), C.c_int]
@@ -298,6 +305,41 @@ class HipBlockSolver:
         s = Stats()
         _check(self.L.g2ohip_get_stats(self.h, C.byref(s)), "stats")
         return s.as_dict()
+
+    # ---- device-resident bundle-adjustment front end (EdgeProjectXYZ2UV graphs) ----------------
+    def baSetEdges(self, set_id, cam_vertex, point_vertex, meas, info=None, f=1000.0, cx=320.0, cy=240.0):
+        cv, pv, m = _i32(cam_vertex), _i32(point_vertex), _f64(meas)
+        inf = None if info is None else _f64(info)
+        _check(self.L.g2ohip_ba_set_edges(self.h, set_id, _ip(cv), _ip(pv), _dp(m), None if inf is None else _dp(inf),
+                                          f, cx, cy), "baSetEdges")
+
+    def baSetEstimates(self, cams, cam_hidx, points, point_hidx):
+        cams, points = _f64(cams), _f64(points)
+        ch, ph = _i32(cam_hidx), _i32(point_hidx)
+        self._ba_n = (len(ch), len(ph))
+        _check(self.L.g2ohip_ba_set_estimates(self.h, len(ch), _dp(cams), _ip(ch), len(ph), _dp(points), _ip(ph)),
+               "baSetEstimates")
+
+    def baGetEstimates(self):
+        cams = np.empty((self._ba_n[0], 12))
+        pts = np.empty((self._ba_n[1], 3))
+        _check(self.L.g2ohip_ba_get_estimates(self.h, _dp(cams), _dp(pts)), "baGetEstimates")
+        return cams, pts
+
+    def baLinearize(self, jacobians=True):
+        _check(self.L.g2ohip_ba_linearize(self.h, int(jacobians)), "baLinearize")
+
+    def baUpdate(self):
+        _check(self.L.g2ohip_ba_update(self.h), "baUpdate")
+
+    def baPush(self):
+        _check(self.L.g2ohip_ba_push(self.h), "baPush")
+
+    def baPop(self):
+        _check(self.L.g2ohip_ba_pop(self.h), "baPop")
+
+    def baDiscardTop(self):
+        _check(self.L.g2ohip_ba_discard_top(self.h), "baDiscardTop")
 
     def kernelTimes(self, reset=True):
         """{kernel name: (total seconds, launches)} from HIP events on the solver stream."""

@@ -80,6 +80,19 @@ class BlockSolver {
   void copy_values(int which, double* h);
   void device_array(int which, double** ptr, size_t* count);
 
+  // ---- device-resident bundle-adjustment front end: error / Jacobian
+  // producers, oplus and the estimate stack for EdgeProjectXYZ2UV graphs, so that a whole LM trial
+  // loop needs no host round trip of Jacobians or estimates
+  void ba_set_edges(int set, const int* cam_vertex, const int* point_vertex, const double* meas, const double* info, double f,
+                    double cx, double cy);
+  void ba_set_estimates(int n_cams, const double* cams, const int* cam_hidx, int n_points, const double* points, const int* point_hidx);
+  void ba_get_estimates(double* cams, double* points);
+  void ba_linearize(bool jacobians);
+  void ba_update();
+  void ba_push();
+  void ba_pop();
+  void ba_discard_top();
+
   bool profiling = false;
   KernelProf prof;
   SolverTimes times;
@@ -119,6 +132,13 @@ class BlockSolver {
   DevBuf<int> d_pp_colptr, d_pp_row;
   long n_sc_ = 0;
   std::unique_ptr<SparseCholesky> chol_;
+  struct BaFrontEnd {
+    int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
+    double f = 0, cx = 0, cy = 0;
+    DevBuf<int> cam_v, pt_v, cam_hidx, pt_hidx;
+    DevBuf<double> meas, cams, pts, cams_bak, pts_bak;
+    bool has_backup = false;
+  } ba_;
   EventTimer tq_, ts_, tn_, tl_, tb_;
   void require_structure() const;
   double reduce_sum_finish(int nblocks);

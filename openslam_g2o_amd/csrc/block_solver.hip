@@ -650,6 +650,116 @@ __global__ void __launch_bounds__(kThreads) spmv_pl_kernel(int nL, int p, int l,
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Device-side input producers for EdgeProjectXYZ2UV:
+//   computeError      g2o/types/sba/types_six_dof_expmap.h:139-147 (obs - cam_map(T.map(X)))
+//   linearizeOplus    g2o/types/sba/types_six_dof_expmap.cpp:288-326
+// cams: [n][12] = R (column-major) | t, world -> camera.  Jacobians are written in the layout
+// g2ohip_set_edge_data documents (2x3 point block = J0, 2x6 pose block = J1, column-major).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) ba_linearize_kernel(int n, const double* __restrict__ cams, const double* __restrict__ pts,
+                                                              const int* __restrict__ cam_v, const int* __restrict__ pt_v,
+                                                              const double* __restrict__ meas, double f, double cx, double cy,
+                                                              double* __restrict__ Jpt, double* __restrict__ Jcam,
+                                                              double* __restrict__ err, int want_jac) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double T[12], X[3], z2[2];
+  load_vec<12>(cams + (size_t)cam_v[e] * 12, T);
+  const double* Xp = pts + (size_t)pt_v[e] * 3;
+  X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+  load_vec<2>(meas + (size_t)e * 2, z2);
+  const double x = T[0] * X[0] + T[3] * X[1] + T[6] * X[2] + T[9];
+  const double y = T[1] * X[0] + T[4] * X[1] + T[7] * X[2] + T[10];
+  const double z = T[2] * X[0] + T[5] * X[1] + T[8] * X[2] + T[11];
+  double r[2] = {z2[0] - (x / z * f + cx), z2[1] - (y / z * f + cy)};
+  store_vec<2>(err + (size_t)e * 2, r);
+  if (!want_jac) return;
+  const double z_2 = z * z;
+  const double tmp[6] = {f, 0.0, -x / z * f, 0.0, f, -y / z * f};   // row-major 2x3
+  double A[6], B[12];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) t += tmp[rr * 3 + m] * T[m + 3 * c];
+      A[rr + 2 * c] = -1.0 / z * t;
+    }
+  B[0 + 2 * 0] = x * y / z_2 * f;        B[0 + 2 * 1] = -(1.0 + (x * x / z_2)) * f; B[0 + 2 * 2] = y / z * f;
+  B[0 + 2 * 3] = -1.0 / z * f;           B[0 + 2 * 4] = 0.0;                        B[0 + 2 * 5] = x / z_2 * f;
+  B[1 + 2 * 0] = (1.0 + y * y / z_2) * f; B[1 + 2 * 1] = -x * y / z_2 * f;          B[1 + 2 * 2] = -x / z * f;
+  B[1 + 2 * 3] = 0.0;                    B[1 + 2 * 4] = -1.0 / z * f;               B[1 + 2 * 5] = y / z_2 * f;
+  store_vec<6>(Jpt + (size_t)e * 6, A);
+  store_vec<12>(Jcam + (size_t)e * 12, B);
+}
+
+// VertexSE3Expmap::oplusImpl: estimate <- SE3Quat::exp(update) * estimate
+// (g2o/types/sba/types_six_dof_expmap.h:101-104, g2o/types/slam3d/se3quat.h:223-257); update = (omega, upsilon)
+__global__ void __launch_bounds__(kThreads) ba_update_cams_kernel(int nc, double* __restrict__ cams, const int* __restrict__ hidx,
+                                                                const double* __restrict__ xp) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nc) return;
+  const int h = hidx[v];
+  if (h < 0) return;
+  const double* u = xp + (size_t)h * 6;
+  double* T = cams + (size_t)v * 12;
+  const double wx = u[0], wy = u[1], wz = u[2];
+  const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+  const double Om[9] = {0.0, wz, -wy, -wz, 0.0, wx, wy, -wx, 0.0};   // column-major skew(omega)
+  double Om2[9], R[9], V[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) t += Om[r + 3 * m] * Om[m + 3 * c];
+      Om2[r + 3 * c] = t;
+    }
+  double a, b, cc;
+  const bool small = theta < 0.00001;
+  if (!small) {
+    a = sin(theta) / theta;
+    b = (1.0 - cos(theta)) / (theta * theta);
+    cc = (theta - sin(theta)) / (theta * theta * theta);
+  } else {
+    a = 1.0; b = 1.0; cc = 1.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double I = (i % 4 == 0) ? 1.0 : 0.0;
+    R[i] = I + a * Om[i] + b * Om2[i];
+    V[i] = small ? R[i] : I + b * Om[i] + cc * Om2[i];
+  }
+  double Rn[9], tn[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) t += R[r + 3 * m] * T[m + 3 * c];
+      Rn[r + 3 * c] = t;
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    tn[r] = R[r] * T[9] + R[r + 3] * T[10] + R[r + 6] * T[11] + V[r] * u[3] + V[r + 3] * u[4] + V[r + 6] * u[5];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) T[i] = Rn[i];
+  T[9] = tn[0]; T[10] = tn[1]; T[11] = tn[2];
+}
+// VertexSBAPointXYZ::oplusImpl (g2o/types/sba/types_sba.h:151-155)
+__global__ void __launch_bounds__(kThreads) ba_update_pts_kernel(int np, double* __restrict__ pts, const int* __restrict__ hidx,
+                                                               const double* __restrict__ xl) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= np * 3) return;
+  const int v = t / 3, c = t % 3;
+  const int h = hidx[v];
+  if (h >= 0) pts[t] += xl[(size_t)h * 3 + c];
+}
+
 inline int grid_for(size_t n, int threads = kThreads) { return (int)((n + threads - 1) / threads); }
 
 // ---- dispatch tables ----------------------------------------------------------------
@@ -1482,6 +1592,101 @@ void BlockSolver::copy_values(int which, double* h) {
     default: throw ArgFailure("bad matrix selector");
   }
 }
+// ---- bundle-adjustment front end -------------------------------------------------------------
+void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_vertex, const double* meas, const double* info,
+                               double f, double cx, double cy) {
+  require_structure();
+  if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
+  EdgeSet& es = *sets_[set];
+  if (es.d != 2 || es.unary || es.dim0 != 3 || es.dim1 != 6 || p_ != 6 || l_ != 3)
+    throw ArgFailure("ba_set_edges: the set must be EdgeProjectXYZ2UV-shaped (d=2, vertex0 = 3-dof point, vertex1 = 6-dof pose)");
+  if (!cam_vertex || !point_vertex || !meas) throw ArgFailure("ba_set_edges: null array");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  const size_t n = (size_t)es.n;
+  ba_.set = set;
+  ba_.n_edges = es.n;
+  ba_.f = f; ba_.cx = cx; ba_.cy = cy;
+  ba_.cam_v.upload(cam_vertex, n, st_);
+  ba_.pt_v.upload(point_vertex, n, st_);
+  ba_.meas.upload(meas, n * 2, st_);
+  std::vector<double> om;
+  if (!info) {
+    om.assign(n * 4, 0.0);
+    for (size_t k = 0; k < n; ++k) om[4 * k] = om[4 * k + 3] = 1.0;   // information().setIdentity()
+    info = om.data();
+  }
+  es.own_omega.upload(info, n * 4, st_);
+  es.own_J0.alloc(n * 6);
+  es.own_J1.alloc(n * 12);
+  es.own_err.alloc(n * 2);
+  es.J0 = es.own_J0.p; es.J1 = es.own_J1.p; es.omega = es.own_omega.p; es.err = es.own_err.p;
+  es.has_data = false;   // becomes valid with the first ba_linearize
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void BlockSolver::ba_set_estimates(int n_cams, const double* cams, const int* cam_hidx, int n_points, const double* points,
+                                   const int* point_hidx) {
+  if (n_cams <= 0 || n_points <= 0 || !cams || !points || !cam_hidx || !point_hidx) throw ArgFailure("ba_set_estimates: bad arguments");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  ba_.n_cams = n_cams;
+  ba_.n_points = n_points;
+  ba_.cams.upload(cams, (size_t)n_cams * 12, st_);
+  ba_.pts.upload(points, (size_t)n_points * 3, st_);
+  ba_.cam_hidx.upload(cam_hidx, n_cams, st_);
+  ba_.pt_hidx.upload(point_hidx, n_points, st_);
+  ba_.cams_bak.alloc((size_t)n_cams * 12);
+  ba_.pts_bak.alloc((size_t)n_points * 3);
+  ba_.has_backup = false;
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void BlockSolver::ba_get_estimates(double* cams, double* points) {
+  if (ba_.n_cams <= 0) throw StateFailure("ba_get_estimates before ba_set_estimates");
+  if (cams) ba_.cams.download(cams, (size_t)ba_.n_cams * 12, st_);
+  if (points) ba_.pts.download(points, (size_t)ba_.n_points * 3, st_);
+}
+
+void BlockSolver::ba_linearize(bool jacobians) {
+  if (ba_.set < 0 || ba_.n_cams <= 0) throw StateFailure("ba_linearize: call ba_set_edges and ba_set_estimates first");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  EdgeSet& es = *sets_[ba_.set];
+  hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid_for(es.n)), dim3(kThreads), 0, st_, es.n, ba_.cams.p, ba_.pts.p, ba_.cam_v.p,
+                     ba_.pt_v.p, ba_.meas.p, ba_.f, ba_.cx, ba_.cy, es.own_J0.p, es.own_J1.p, es.own_err.p, jacobians ? 1 : 0);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+  if (jacobians) es.has_data = true;
+}
+
+void BlockSolver::ba_update() {
+  require_structure();
+  if (ba_.n_cams <= 0) throw StateFailure("ba_update before ba_set_estimates");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  hipLaunchKernelGGL(ba_update_cams_kernel, dim3(grid_for(ba_.n_cams)), dim3(kThreads), 0, st_, ba_.n_cams, ba_.cams.p, ba_.cam_hidx.p,
+                     d_x.p);
+  hipLaunchKernelGGL(ba_update_pts_kernel, dim3(grid_for((size_t)ba_.n_points * 3)), dim3(kThreads), 0, st_, ba_.n_points, ba_.pts.p,
+                     ba_.pt_hidx.p, d_x.p + (size_t)nP_ * p_);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+// estimate stack of depth one: what the LM trial loop needs (push / pop / discardTop,
+// optimization_algorithm_levenberg.cpp:96,135,139; base_vertex.h:96-99)
+void BlockSolver::ba_push() {
+  if (ba_.n_cams <= 0) throw StateFailure("ba_push before ba_set_estimates");
+  if (ba_.has_backup) throw StateFailure("ba_push: the estimate stack holds one level");
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.cams_bak.p, ba_.cams.p, (size_t)ba_.n_cams * 12 * sizeof(double), hipMemcpyDeviceToDevice, st_));
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.pts_bak.p, ba_.pts.p, (size_t)ba_.n_points * 3 * sizeof(double), hipMemcpyDeviceToDevice, st_));
+  ba_.has_backup = true;
+}
+void BlockSolver::ba_pop() {
+  if (!ba_.has_backup) throw StateFailure("ba_pop without push");
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.cams.p, ba_.cams_bak.p, (size_t)ba_.n_cams * 12 * sizeof(double), hipMemcpyDeviceToDevice, st_));
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.pts.p, ba_.pts_bak.p, (size_t)ba_.n_points * 3 * sizeof(double), hipMemcpyDeviceToDevice, st_));
+  ba_.has_backup = false;
+}
+void BlockSolver::ba_discard_top() {
+  if (!ba_.has_backup) throw StateFailure("ba_discard_top without push");
+  ba_.has_backup = false;
+}
+
 void BlockSolver::device_array(int which, double** ptr, size_t* count) {
   require_structure();
   switch (which) {

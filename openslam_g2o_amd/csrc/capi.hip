@@ -357,6 +357,66 @@ int g2ohip_device_array(g2ohip_solver* s, int which, double** ptr, size_t* count
   });
 }
 
+// ---- device-resident bundle-adjustment front end ---------------------------------------
+int g2ohip_ba_set_edges(g2ohip_solver* s, int set, const int32_t* cam_vertex, const int32_t* point_vertex, const double* meas,
+                        const double* info, double f, double cx, double cy) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_set_edges(set, cam_vertex, point_vertex, meas, info, f, cx, cy);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ba_set_estimates(g2ohip_solver* s, int n_cams, const double* cams, const int32_t* cam_hidx, int n_points,
+                            const double* points, const int32_t* point_hidx) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_set_estimates(n_cams, cams, cam_hidx, n_points, points, point_hidx);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ba_get_estimates(g2ohip_solver* s, double* cams, double* points) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_get_estimates(cams, points);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ba_linearize(g2ohip_solver* s, int jacobians) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_linearize(jacobians != 0);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ba_update(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_update();
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ba_push(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_push();
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ba_pop(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_pop();
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ba_discard_top(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_discard_top();
+    return G2OHIP_OK;
+  });
+}
+
 // ---- narrow seam ---------------------------------------------------------------------
 int g2ohip_ls_create(g2ohip_linear_solver** out, int block_dim, int device) {
   if (!out) return G2OHIP_ERR_ARG;

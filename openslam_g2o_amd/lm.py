@@ -1,0 +1,150 @@
+"""Host-side mirror of g2o's non-linear drivers over the device-resident solver.
+
+`levenberg_solve_iteration` restates OptimizationAlgorithmLevenberg::solve
+(/root/reference/g2o/core/optimization_algorithm_levenberg.cpp:57-146) and
+`gauss_newton_iteration` OptimizationAlgorithmGaussNewton::solve
+(/root/reference/g2o/core/optimization_algorithm_gauss_newton.cpp:50-93), written against a small
+"graph" protocol so the same loop drives the GPU solver (estimates, errors and Jacobians stay in
+HBM) and, in the tests, the CPU oracle:
+
+    graph.compute_active_errors()   SparseOptimizer::computeActiveErrors   sparse_optimizer.cpp:61-76
+    graph.linearize()               errors + Jacobians (what buildSystem's per-edge linearizeOplus needs)
+    graph.chi2()                    activeRobustChi2                        sparse_optimizer.cpp:100-114
+    graph.update()                  update(solver.x())                      sparse_optimizer.cpp:421-434
+    graph.push() / pop() / discard_top()                                    sparse_optimizer.cpp:599-650
+    solver.buildSystem/setLambda/solve/restoreDiagonal/maxDiagonal/computeScale   (Solver interface)
+"""
+import math
+
+OK, TERMINATE, FAIL = 1, 0, -1          # OptimizationAlgorithm::SolverResult (optimization_algorithm.h:49)
+DBL_MAX = 1.7976931348623157e308
+
+
+class LevenbergState:
+    """The members of OptimizationAlgorithmLevenberg (optimization_algorithm_levenberg.h:83-96)."""
+
+    def __init__(self, tau=1e-5, max_trials=10, user_lambda_init=0.0):
+        self.tau = tau
+        self.good_step_upper = 2.0 / 3.0
+        self.good_step_lower = 1.0 / 3.0
+        self.max_trials = max_trials
+        self.user_lambda_init = user_lambda_init
+        self.current_lambda = -1.0
+        self.ni = 2.0
+        self.levenberg_iterations = 0
+
+
+def levenberg_solve_iteration(graph, solver, st, iteration):
+    graph.linearize()                                   # computeActiveErrors + per-edge linearizeOplus
+    current_chi = graph.chi2()
+    temp_chi = current_chi
+    solver.buildSystem()
+    if iteration == 0:                                  # computeLambdaInit :149-163
+        st.current_lambda = st.user_lambda_init if st.user_lambda_init > 0 else st.tau * solver.maxDiagonal()
+        st.ni = 2.0
+    rho = 0.0
+    qmax = 0
+    while True:
+        graph.push()
+        solver.setLambda(st.current_lambda, True)
+        ok2 = solver.solve()
+        graph.update()
+        solver.restoreDiagonal()
+        graph.compute_active_errors()
+        temp_chi = graph.chi2()
+        if not ok2:
+            temp_chi = DBL_MAX
+        rho = current_chi - temp_chi
+        scale = (solver.computeScale(st.current_lambda) if ok2 else 0.0) + 1e-3   # computeScale :165-172
+        rho /= scale
+        if rho > 0 and math.isfinite(temp_chi):         # last step was good
+            alpha = 1.0 - (2.0 * rho - 1.0) ** 3
+            alpha = min(alpha, st.good_step_upper)
+            st.current_lambda *= max(st.good_step_lower, alpha)
+            st.ni = 2.0
+            current_chi = temp_chi
+            graph.discard_top()
+        else:
+            st.current_lambda *= st.ni
+            st.ni *= 2.0
+            graph.pop()
+        qmax += 1
+        if not (rho < 0 and qmax < st.max_trials):
+            break
+    st.levenberg_iterations = qmax
+    result = TERMINATE if (qmax == st.max_trials or rho == 0) else OK
+    return result, current_chi
+
+
+def gauss_newton_iteration(graph, solver):
+    graph.linearize()
+    chi = graph.chi2()
+    solver.buildSystem()
+    if not solver.solve():
+        return FAIL, chi
+    graph.update()
+    return OK, chi
+
+
+def optimize(graph, solver, iterations, algorithm="lm", **lm_args):
+    """SparseOptimizer::optimize (sparse_optimizer.cpp:354-419): returns (#iterations done, chi2 per
+    iteration before its step, lambda per iteration, LM trials per iteration)."""
+    st = LevenbergState(**lm_args)
+    chis, lams, trials = [], [], []
+    done = 0
+    for it in range(iterations):
+        if algorithm == "lm":
+            res, _ = levenberg_solve_iteration(graph, solver, st, it)
+            lams.append(st.current_lambda)
+            trials.append(st.levenberg_iterations)
+        else:
+            res, _ = gauss_newton_iteration(graph, solver)
+        graph.compute_active_errors()
+        chis.append(graph.chi2())
+        done += 1
+        if res != OK:
+            break
+    return done, chis, lams, trials
+
+
+class DeviceBAGraph:
+    """The graph protocol over HipBlockSolver's device-resident BA front end."""
+
+    def __init__(self, solver):
+        self.s = solver
+
+    def linearize(self):
+        self.s.baLinearize(True)
+
+    def compute_active_errors(self):
+        self.s.baLinearize(False)
+
+    def chi2(self):
+        return self.s.chi2()
+
+    def update(self):
+        self.s.baUpdate()
+
+    def push(self):
+        self.s.baPush()
+
+    def pop(self):
+        self.s.baPop()
+
+    def discard_top(self):
+        self.s.baDiscardTop()
+
+
+def setup_device_ba(prob, huber_delta=0.0, device=0):
+    """Build a HipBlockSolver for an openslam_g2o_amd.synthetic BA problem with the estimates, errors
+    and Jacobians produced on the device.  Returns (solver, graph)."""
+    import numpy as np
+    from . import capi
+    s = capi.HipBlockSolver(6, 3, device)
+    k = s.addEdgeSet(2, prob["v0"], prob["v1"])
+    s.buildStructure(prob["nP"], prob["nL"], True)
+    s.baSetEdges(k, prob["cam_idx"], prob["pt_idx"], prob["meas"], None, prob["f"], prob["cx"], prob["cy"])
+    s.baSetEstimates(prob["cams"], prob["cam_hidx"], prob["pts"], np.arange(prob["L"], dtype=np.int32))
+    if huber_delta > 0:
+        s.setRobustKernel(k, capi.KERNEL_HUBER, huber_delta)
+    return s, DeviceBAGraph(s)
