@@ -36,6 +36,9 @@ def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2):
     kb["assemble_vertex(pose)"] = E * 8 * (d * p + d * d + d) + P * 8 * (p * p + p)
     kb["assemble_vertex(landmark)"] = E * 8 * (d * l + d * d + d) + L * 8 * (l * l + l)
     kb["assemble_offdiag(Hpl)"] = E * 8 * (d * p + d * l + d * d) + E * 8 * p * l
+    # fused EdgeProjectXYZ2UV assembly (no Jacobian arrays): measurements + information in, blocks out
+    kb["fused:assemble_vertex(landmark)"] = E * 8 * (d + d * d + p * l + d) + L * 8 * (l + l * l + l) + P * 8 * 12
+    kb["fused:assemble_vertex(pose)"] = E * 8 * (d + d * d + l) + P * 8 * (12 + p * p + p)
     kb["landmark_inverse"] = L * 8 * (2 * l * l + 2 * l)
     kb["schur_tiles"] = E * 8 * p * l + L * 8 * (l * l + l) + S * 8 * p * p          # Hpl, Dinv, b_l in; one Hschur worth out
     kb["schur_reduce"] = pp_nnzb * 8 * p * p + 2 * S * 8 * p * p + 3 * P * 8 * p      # Hpp + partials in, Hschur + bschur out
@@ -53,7 +56,7 @@ def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2):
     return kb, stage
 
 
-def cpu_baseline(prob, lam, want_x=True):
+def cpu_baseline(prob, lam, want_x=True, include_linearize=True):
     """The oracle (CPU restatement of the reference path, 1 thread = the reference's default
     build) timed on this host for ONE full iteration of the same workload."""
     from oracle import oracle as O
@@ -64,10 +67,17 @@ def cpu_baseline(prob, lam, want_x=True):
     t0 = time.perf_counter()
     o.build_structure()
     t_struct = time.perf_counter() - t0
-    o.set_edge_data(k, prob["Jp"], prob["Jc"], prob["omega"], prob["err"])
+    t_lin = 0.0
+    if include_linearize:     # the reference's buildSystem runs linearizeOplus per edge (block_solver.hpp:531)
+        t0 = time.perf_counter()
+        Jp, Jc, err = O.ba_edges(prob["cams"], prob["pts"], prob["cam_idx"], prob["pt_idx"], prob["meas"], prob["f"], prob["cx"], prob["cy"])
+        t_lin = time.perf_counter() - t0
+        o.set_edge_data(k, Jp, Jc, prob["omega"], err)
+    else:
+        o.set_edge_data(k, prob["Jp"], prob["Jc"], prob["omega"], prob["err"])
     t0 = time.perf_counter()
     o.build_system()
-    t_asm = time.perf_counter() - t0
+    t_asm = time.perf_counter() - t0 + t_lin
     o.set_lambda(lam, True)
     t0 = time.perf_counter()
     ok = o.solve()                      # includes the one-time ordering + symbolic step
@@ -93,6 +103,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nd-leaf", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="solver option name=value (tuning experiments)")
+    ap.add_argument("--edge-data", choices=["fused", "arrays"], default="fused",
+                    help="fused: estimates + measurements resident in HBM, errors/Jacobians evaluated inside buildSystem "
+                         "(what the reference's buildSystem does per edge); arrays: precomputed Jacobian arrays resident in HBM")
     args = ap.parse_args()
 
     import torch
@@ -123,7 +136,8 @@ def main():
     for kv in args.opt:
         k_, v_ = kv.split("=")
         solver.local.setOption(k_, float(v_))
-    shard = solver.setup_ba(prob, torch_device=dev, nd_leaf=args.nd_leaf)
+    fused = args.edge_data == "fused"
+    shard = solver.setup_ba(prob, torch_device=dev, nd_leaf=args.nd_leaf, fused=fused)
     solver.local.setProfiling(True)
 
     def step():
@@ -165,6 +179,9 @@ def main():
     pp_nnzb = solver.local.nnzb(capi.HPP)
     E_loc, L_loc = shard["E_local"], shard["L_local"]
     kb, stage_b = algorithmic_bytes(E_loc, prob["nP"], L_loc, S_blocks, pp_nnzb, st["choleskyNNZ"])
+    if fused:
+        kb["assemble_vertex(landmark)"] = kb["fused:assemble_vertex(landmark)"]
+        kb["assemble_vertex(pose)"] = kb["fused:assemble_vertex(pose)"]
     per_kernel = {}
     for name, (tot, n) in ktimes.items():
         avg = tot / n
@@ -196,7 +213,9 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "synthetic BA (BASELINE.json configs[3]): %d poses / %d landmarks / %d observations, "
                                "BlockSolver_6_3 semantics, Schur + multifrontal block Cholesky, lambda=%g" % (P, L, prob["E"], lam),
-                   "poses": P, "landmarks": L, "edges": prob["E"], "parallelism": solver.parallelism()},
+                   "poses": P, "landmarks": L, "edges": prob["E"], "parallelism": solver.parallelism(),
+                   "edge_data": "estimates+measurements in HBM, errors/Jacobians evaluated inside buildSystem" if fused
+                   else "precomputed Jacobian arrays in HBM"},
         "solve_ok": bool(ok),
         "roofline": roofline,
         "kernels": per_kernel,
@@ -211,7 +230,7 @@ def main():
     solver.restoreDiagonal()
 
     if world == 1 and not args.no_cpu_baseline:
-        cb, x_cpu = cpu_baseline(prob, lam)
+        cb, x_cpu = cpu_baseline(prob, lam, include_linearize=fused)
         cpu_ms = 1e3 * (cb["t_assembly"] + cb["t_solve"])
         out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms/iter", "cores": 1, "kind": "port",
                                "sample": "1 full iteration of the same %d-pose workload (assembly %.0f ms + solve %.0f ms; "

@@ -98,6 +98,7 @@ class BlockSolver {
   SolverTimes times;
   CholOptions chol_opt;
   size_t schur_tile_bytes = 48 * 1024;     // LDS budget of one Schur tile
+  bool ba_fused = true;                    // evaluate BA errors/Jacobians inside the assembly kernels (no J arrays)
   int schur_group = 0;                     // lanes per destination in the Schur tile kernel (0 = auto)
   const CholStats* chol_stats() const { return chol_ ? &chol_->stats() : nullptr; }
   int p() const { return p_; }
@@ -135,7 +136,8 @@ class BlockSolver {
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
     double f = 0, cx = 0, cy = 0;
-    DevBuf<int> cam_v, pt_v, cam_hidx, pt_hidx;
+    DevBuf<int> cam_v, pt_v, cam_hidx, pt_hidx, edge_hpl;
+    bool fused_ok = false;   // every Hpl block has exactly one observation: fused on-the-fly assembly allowed
     DevBuf<double> meas, cams, pts, cams_bak, pts_bak;
     bool has_backup = false;
   } ba_;

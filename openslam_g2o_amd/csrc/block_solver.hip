@@ -760,6 +760,172 @@ __global__ void __launch_bounds__(kThreads) ba_update_pts_kernel(int np, double*
   if (h >= 0) pts[t] += xl[(size_t)h * 3 + c];
 }
 
+// Shared by the fused assembly kernels: projection error, Jacobians and robust weight of one edge.
+struct BaEdgeLin {
+  double A[6], B[12], r[2], O[4], w;   // A: 2x3 point block, B: 2x6 pose block (column-major), r: error
+};
+__device__ __forceinline__ void ba_edge_linearize(const double* __restrict__ T, const double* __restrict__ X, const double* __restrict__ z2,
+                                                  const double* __restrict__ Op, double f, double cx, double cy, int kind, double delta,
+                                                  bool want_A, BaEdgeLin& L) {
+  const double x = T[0] * X[0] + T[3] * X[1] + T[6] * X[2] + T[9];
+  const double y = T[1] * X[0] + T[4] * X[1] + T[7] * X[2] + T[10];
+  const double z = T[2] * X[0] + T[5] * X[1] + T[8] * X[2] + T[11];
+  const double iz = 1.0 / z;
+  L.r[0] = z2[0] - (x * iz * f + cx);
+  L.r[1] = z2[1] - (y * iz * f + cy);
+  L.O[0] = Op[0]; L.O[1] = Op[1]; L.O[2] = Op[2]; L.O[3] = Op[3];
+  const double Or0 = L.O[0] * L.r[0] + L.O[2] * L.r[1], Or1 = L.O[1] * L.r[0] + L.O[3] * L.r[1];
+  L.w = robust_weight(kind, delta, L.r[0] * Or0 + L.r[1] * Or1);
+  // one reciprocal instead of a dozen fp64 divisions (each ~30 instructions): x/z -> x*iz etc.
+  const double fz = f * iz, xz = x * iz, yz = y * iz;
+  if (want_A) {
+    const double tmp[6] = {f, 0.0, -xz * f, 0.0, f, -yz * f};
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) t += tmp[rr * 3 + m] * T[m + 3 * c];
+        L.A[rr + 2 * c] = -iz * t;
+      }
+  }
+  L.B[0 + 2 * 0] = xz * yz * f;          L.B[0 + 2 * 1] = -(1.0 + xz * xz) * f; L.B[0 + 2 * 2] = yz * f;
+  L.B[0 + 2 * 3] = -fz;                  L.B[0 + 2 * 4] = 0.0;                  L.B[0 + 2 * 5] = xz * fz;
+  L.B[1 + 2 * 0] = (1.0 + yz * yz) * f;  L.B[1 + 2 * 1] = -xz * yz * f;         L.B[1 + 2 * 2] = -xz * f;
+  L.B[1 + 2 * 3] = 0.0;                  L.B[1 + 2 * 4] = -fz;                  L.B[1 + 2 * 5] = yz * fz;
+}
+
+// Fused buildSystem for EdgeProjectXYZ2UV graphs, landmark side (K1-K2 of SURVEY.md 2.3 with the
+// reference's per-edge linearizeOplus + constructQuadraticForm, block_solver.hpp:529-532): one thread
+// per landmark walks its observations, evaluates error and Jacobians on the fly (no Jacobian arrays in
+// HBM), accumulates Hll / b_l and writes each Hpl block exactly once.
+template <int G>
+__global__ void __launch_bounds__(kThreads) ba_assemble_landmarks_kernel(
+    int nL, const int* __restrict__ vptr, const int* __restrict__ vent, const double* __restrict__ cams, const double* __restrict__ pts,
+    const int* __restrict__ cam_v, const int* __restrict__ pt_v, const double* __restrict__ meas, const double* __restrict__ omega,
+    const int* __restrict__ edge_hpl, double f, double cx, double cy, int kind, double delta, double* __restrict__ Hll,
+    double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ err) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lm = gt / G, g = gt % G;
+  const bool active = lm < nL;
+  double H[9], b[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) H[i] = 0.0;
+  b[0] = b[1] = b[2] = 0.0;
+  const int k0 = active ? vptr[lm] : 0, k1 = active ? vptr[lm + 1] : 0;
+  for (int k = k0 + g; k < k1; k += G) {
+    const int e = vent[k] >> 1;
+    double T[12], X[3], z2[2], Op[4];
+    const double* Xp = pts + (size_t)pt_v[e] * 3;
+    X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+    load_vec<12>(cams + (size_t)cam_v[e] * 12, T);
+    load_vec<2>(meas + (size_t)e * 2, z2);
+    load_vec<4>(omega + (size_t)e * 4, Op);
+    BaEdgeLin L;
+    ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
+    store_vec<2>(err + (size_t)e * 2, L.r);
+    // weighted information
+    const double w = L.w;
+    const double O00 = w * L.O[0], O10 = w * L.O[1], O01 = w * L.O[2], O11 = w * L.O[3];
+    double OA[6];   // (w Omega) A : 2x3
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      OA[0 + 2 * c] = O00 * L.A[0 + 2 * c] + O01 * L.A[1 + 2 * c];
+      OA[1 + 2 * c] = O10 * L.A[0 + 2 * c] + O11 * L.A[1 + 2 * c];
+    }
+    const double Or0 = O00 * L.r[0] + O01 * L.r[1], Or1 = O10 * L.r[0] + O11 * L.r[1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      b[c] -= L.A[0 + 2 * c] * Or0 + L.A[1 + 2 * c] * Or1;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) H[a + 3 * c] += L.A[0 + 2 * a] * OA[0 + 2 * c] + L.A[1 + 2 * a] * OA[1 + 2 * c];
+    }
+    const int q = edge_hpl[e];
+    if (q >= 0) {   // Hpl(pose, lm) = B' (w Omega) A  (written transposed, block_solver.hpp:240-244)
+      double blk[18];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) blk[a + 6 * c] = L.B[0 + 2 * a] * OA[0 + 2 * c] + L.B[1 + 2 * a] * OA[1 + 2 * c];
+      store_vec<18>(Hpl + (size_t)q * 18, blk);
+    }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[i] = group_sum<G>(H[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b[i] = group_sum<G>(b[i]);
+  }
+  if (!active) return;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    if (G == 1 || (i % G) == g) Hll[(size_t)lm * 9 + i] = H[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (G == 1 || (i % G) == g) bl[(size_t)lm * 3 + i] = b[i];
+}
+
+// Pose side: G lanes per free pose walk its observations, re-evaluate the pose Jacobian on the fly
+// and reduce Hpp_ii / b_i with DPP butterflies.
+template <int G>
+__global__ void __launch_bounds__(kThreads) ba_assemble_poses_kernel(
+    int nP, const int* __restrict__ vptr, const int* __restrict__ vent, const double* __restrict__ cams, const double* __restrict__ pts,
+    const int* __restrict__ cam_v, const int* __restrict__ pt_v, const double* __restrict__ meas, const double* __restrict__ omega,
+    double f, double cx, double cy, int kind, double delta, double* __restrict__ Hpp, const int* __restrict__ diag_blk,
+    double* __restrict__ bp, int accumulate) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = gt / G, g = gt % G;
+  const bool active = v < nP;
+  double H[36], b[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) H[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) b[i] = 0.0;
+  const int k0 = active ? vptr[v] : 0, k1 = active ? vptr[v + 1] : 0;
+  double T[12];
+  bool haveT = false;
+  for (int k = k0 + g; k < k1; k += G) {
+    const int e = vent[k] >> 1;
+    if (!haveT) {
+      load_vec<12>(cams + (size_t)cam_v[e] * 12, T);
+      haveT = true;
+    }
+    double X[3], z2[2], Op[4];
+    const double* Xp = pts + (size_t)pt_v[e] * 3;
+    X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+    load_vec<2>(meas + (size_t)e * 2, z2);
+    load_vec<4>(omega + (size_t)e * 4, Op);
+    BaEdgeLin L;
+    ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, false, L);
+    const double w = L.w;
+    const double O00 = w * L.O[0], O10 = w * L.O[1], O01 = w * L.O[2], O11 = w * L.O[3];
+    const double Or0 = O00 * L.r[0] + O01 * L.r[1], Or1 = O10 * L.r[0] + O11 * L.r[1];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double OB0 = O00 * L.B[0 + 2 * c] + O01 * L.B[1 + 2 * c], OB1 = O10 * L.B[0 + 2 * c] + O11 * L.B[1 + 2 * c];
+      b[c] -= L.B[0 + 2 * c] * Or0 + L.B[1 + 2 * c] * Or1;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) H[a + 6 * c] += L.B[0 + 2 * a] * OB0 + L.B[1 + 2 * a] * OB1;
+    }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) H[i] = group_sum<G>(H[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = group_sum<G>(b[i]);
+  }
+  if (!active) return;
+  double* Hd = Hpp + (size_t)diag_blk[v] * 36;
+  double* bd = bp + (size_t)v * 6;
+#pragma unroll
+  for (int i = 0; i < 36; ++i)
+    if (G == 1 || (i % G) == g) Hd[i] = accumulate ? Hd[i] + H[i] : H[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    if (G == 1 || (i % G) == g) bd[i] = accumulate ? bd[i] + b[i] : b[i];
+}
+
 inline int grid_for(size_t n, int threads = kThreads) { return (int)((n + threads - 1) / threads); }
 
 // ---- dispatch tables ----------------------------------------------------------------
@@ -1274,9 +1440,42 @@ void BlockSolver::build_system() {
   if (profiling) tq_.start(st_);
   const size_t sizeP = (size_t)nP_ * p_;
   bool any_pose = false, any_lm = false;
+  int set_index = -1;
   for (auto& esp : sets_) {
     EdgeSet& es = *esp;
+    ++set_index;
     if (es.n == 0) continue;
+    if (set_index == ba_.set && ba_fused && ba_.fused_ok && ba_.n_cams > 0) {
+      // fused EdgeProjectXYZ2UV path: errors + Jacobians evaluated inside the assembly kernels
+      prof.begin(KernelProf::kAsmLandmark, st_);
+      {
+        const double avgK = (double)es.n_vl_ent / std::max(1, nL_);
+        const int GL = avgK <= 1.5 ? 1 : (avgK <= 4.0 ? 4 : 8);   // one observation per lane where possible
+#define G2OHIP_BA_LM(GG)                                                                                                         \
+  hipLaunchKernelGGL((ba_assemble_landmarks_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p, \
+                     es.vl_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_v.p, ba_.pt_v.p, ba_.meas.p, es.omega, ba_.edge_hpl.p, ba_.f,     \
+                     ba_.cx, ba_.cy, es.kernel_kind, es.delta, d_Hll.p, d_b.p + sizeP, d_Hpl.p, es.own_err.p)
+        if (GL == 1) G2OHIP_BA_LM(1);
+        else if (GL == 4) G2OHIP_BA_LM(4);
+        else G2OHIP_BA_LM(8);
+#undef G2OHIP_BA_LM
+      }
+      prof.end(KernelProf::kAsmLandmark, st_);
+      prof.begin(KernelProf::kAsmPose, st_);
+      const int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
+#define G2OHIP_BA_POSE(GG)                                                                                                       \
+  hipLaunchKernelGGL((ba_assemble_poses_kernel<GG>), dim3(grid_for((size_t)nP_ * GG)), dim3(kThreads), 0, st_, nP_, es.vp_ptr.p,  \
+                     es.vp_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_v.p, ba_.pt_v.p, ba_.meas.p, es.omega, ba_.f, ba_.cx, ba_.cy,      \
+                     es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1)
+      if (es.touches_pose) {
+        if (G <= 1) G2OHIP_BA_POSE(1);
+        else if (G <= 4) G2OHIP_BA_POSE(4);
+        else G2OHIP_BA_POSE(8);
+      }
+#undef G2OHIP_BA_POSE
+      prof.end(KernelProf::kAsmPose, st_);
+      continue;
+    }
     if (es.touches_pose) {
       int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
       prof.begin(KernelProf::kAsmPose, st_);
@@ -1616,6 +1815,24 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
     info = om.data();
   }
   es.own_omega.upload(info, n * 4, st_);
+  {
+    // Hpl block written by each edge; the fused assembly requires one observation per (pose, landmark) pair
+    std::vector<int> edge_hpl(n, -1);
+    std::vector<char> seen(pl_row.size(), 0);
+    bool unique = es.first_lm && es.first_ol;
+    for (size_t k = 0; k < n; ++k)
+      if (es.v0[k] < 0) unique = false;   // a fixed landmark: its edges would be skipped by the landmark-major kernel
+    for (size_t k = 0; k < n; ++k) {
+      const int a = es.v0[k], b = es.v1[k];
+      if (a < 0 || b < 0) continue;
+      const int q = find_block(pl_colptr, pl_row, a - nP_, b);
+      edge_hpl[k] = q;
+      if (seen[q]) unique = false;
+      seen[q] = 1;
+    }
+    ba_.fused_ok = unique;
+    ba_.edge_hpl.upload(edge_hpl, st_);
+  }
   es.own_J0.alloc(n * 6);
   es.own_J1.alloc(n * 12);
   es.own_err.alloc(n * 2);
@@ -1650,8 +1867,10 @@ void BlockSolver::ba_linearize(bool jacobians) {
   if (ba_.set < 0 || ba_.n_cams <= 0) throw StateFailure("ba_linearize: call ba_set_edges and ba_set_estimates first");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   EdgeSet& es = *sets_[ba_.set];
+  const bool fused = ba_fused && ba_.fused_ok;
+  // fused mode: build_system re-evaluates the Jacobians itself, only the errors (for chi2) are produced here
   hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid_for(es.n)), dim3(kThreads), 0, st_, es.n, ba_.cams.p, ba_.pts.p, ba_.cam_v.p,
-                     ba_.pt_v.p, ba_.meas.p, ba_.f, ba_.cx, ba_.cy, es.own_J0.p, es.own_J1.p, es.own_err.p, jacobians ? 1 : 0);
+                     ba_.pt_v.p, ba_.meas.p, ba_.f, ba_.cx, ba_.cy, es.own_J0.p, es.own_J1.p, es.own_err.p, (jacobians && !fused) ? 1 : 0);
   G2OHIP_HIP_CHECK(hipGetLastError());
   if (jacobians) es.has_data = true;
 }

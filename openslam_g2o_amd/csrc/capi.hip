@@ -317,6 +317,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "fuse_chains")) s->impl->chol_opt.fuse_chains = value != 0;
   else if (!std::strcmp(name, "schur_tile_bytes")) s->impl->schur_tile_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_group")) s->impl->schur_group = (int)value;
+  else if (!std::strcmp(name, "ba_fused")) s->impl->ba_fused = value != 0;
   else {
     set_error(std::string("unknown option ") + name);
     return G2OHIP_ERR_ARG;

@@ -97,9 +97,12 @@ class ShardedBlockSolver:
         return "1 GPU" if self.world == 1 else "landmark-range shards x%d, all-reduce(Hschur,bschur), replicated Cholesky" % self.world
 
     # ------------------------------------------------------------------------------------
-    def setup_ba(self, prob, torch_device=None, nd_leaf=0):
+    def setup_ba(self, prob, torch_device=None, nd_leaf=0, fused=False):
         """Shard a bundle-adjustment problem dict (openslam_g2o_amd.synthetic layout: landmark
-        index nP + j as vertex 0, pose index as vertex 1) and upload the local edge data."""
+        index nP + j as vertex 0, pose index as vertex 1) and upload the local edge data.
+        fused=True: hand over estimates + measurements instead of Jacobian arrays; errors and Jacobians
+        are evaluated inside the assembly kernels (the reference's buildSystem does the same per edge,
+        block_solver.hpp:529-532)."""
         nP, nL = prob["nP"], prob["nL"]
         lm0, lm1 = landmark_range(nL, self.world, self.rank)
         lm = prob["v0"].astype(np.int64) - nP
@@ -115,6 +118,18 @@ class ShardedBlockSolver:
             rows, cols = schur_pattern_pairs(prob["v1"], lm)
             self.local.addSchurPattern(rows, cols)
         self.local.buildStructure(nP, lm1 - lm0, True)
+        if fused:
+            if torch_device is not None:
+                import torch
+                self.local.setStream(torch.cuda.current_stream().cuda_stream)
+                self._torch_device = torch_device
+            else:
+                self._torch_device = None
+            self.local.baSetEdges(self.set_id, prob["cam_idx"][mine], (prob["pt_idx"][mine] - lm0).astype(np.int32),
+                                  prob["meas"][mine], None, prob["f"], prob["cx"], prob["cy"])
+            self.local.baSetEstimates(prob["cams"], prob["cam_hidx"], prob["pts"][lm0:lm1], np.arange(lm1 - lm0, dtype=np.int32))
+            self.local.baLinearize(True)
+            return dict(E_local=int(mine.sum()), L_local=int(lm1 - lm0), lm0=int(lm0), lm1=int(lm1))
         arrays = [np.ascontiguousarray(prob[k][mine]) for k in ("Jp", "Jc", "omega", "err")]
         if torch_device is not None:
             import torch

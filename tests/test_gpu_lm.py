@@ -79,9 +79,13 @@ class OracleSolverAdapter:
         return self.o.compute_scale(lam)
 
 
-def test_device_producers_match_oracle():
+@pytest.mark.parametrize("fused", [1, 0])
+def test_device_producers_match_oracle(fused):
+    """fused=1: errors/Jacobians evaluated inside the assembly kernels; fused=0: separate linearize
+    kernel filling the Jacobian arrays of the generic edge-data path."""
     pr = ba_case(30, 300)
     s, g = lm.setup_device_ba(pr)
+    s.setOption("ba_fused", fused)
     g.linearize()
     s.buildSystem()
     o = oracle_ba(pr)
