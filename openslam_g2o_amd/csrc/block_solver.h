@@ -28,7 +28,8 @@ struct EdgeSet {
   // per-iteration data (device); either own buffers or caller-owned device pointers
   const double *J0 = nullptr, *J1 = nullptr, *omega = nullptr, *err = nullptr;
   DevBuf<double> own_J0, own_J1, own_omega, own_err;
-  bool has_data = false;
+  bool has_data = false;   // Jacobians + information + errors available for build_system
+  bool has_err = false;    // errors + information available (enough for chi2)
   // destination-major contributor lists
   DevBuf<int> vp_ptr, vp_ent, vl_ptr, vl_ent;  // per pose / per landmark: (edge << 1 | side)
   DevBuf<int> op_dst, op_ptr, op_ent;          // Hpp off-diagonal blocks: dest block id, (edge << 1 | transposed)

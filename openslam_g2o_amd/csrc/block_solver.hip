@@ -1423,6 +1423,7 @@ void BlockSolver::set_edge_data(int set, const double* J0, const double* J1, con
     es.err = es.own_err.p;
   }
   es.has_data = true;
+  es.has_err = true;
 }
 
 void BlockSolver::set_robust_kernel(int set, int kind, double delta) {
@@ -1527,7 +1528,7 @@ double BlockSolver::chi2() {
   for (auto& esp : sets_) {
     EdgeSet& es = *esp;
     if (es.n == 0) continue;
-    if (!es.has_data) throw StateFailure("chi2: edge data missing");
+    if (!es.has_err) throw StateFailure("chi2: edge data missing");
     int nblocks = std::min(1024, grid_for(es.n));
 #define G2OHIP_CHI(d_)                                                                                                      \
   case d_:                                                                                                                  \
@@ -1872,6 +1873,7 @@ void BlockSolver::ba_linearize(bool jacobians) {
   hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid_for(es.n)), dim3(kThreads), 0, st_, es.n, ba_.cams.p, ba_.pts.p, ba_.cam_v.p,
                      ba_.pt_v.p, ba_.meas.p, ba_.f, ba_.cx, ba_.cy, es.own_J0.p, es.own_J1.p, es.own_err.p, (jacobians && !fused) ? 1 : 0);
   G2OHIP_HIP_CHECK(hipGetLastError());
+  es.has_err = true;
   if (jacobians) es.has_data = true;
 }
 
