@@ -167,6 +167,32 @@ int g2ohip_add_schur_pattern(g2ohip_solver* s, int n_blocks, const int32_t* rows
  * landmarks, only one rank adds lambda to the (summed) pose diagonal. */
 int g2ohip_set_lambda_split(g2ohip_solver* s, double lambda_pose, double lambda_landmark, int backup);
 
+/* Subtree-distributed factorisation of the reduced system: the top of the
+ * elimination-task tree is split into >= world subtrees; rank r factorises its own subtrees, every rank
+ * factorises the few shared tasks above them redundantly.  g2ohip_set_partition precedes
+ * g2ohip_build_structure (all ranks must pass the same union Schur pattern and options: the symbolic
+ * analysis is deterministic, so every rank derives the same partition).  Per solve:
+ *   g2ohip_solve_reduced_local   own subtrees: factor + forward sweep, pack the subtree roots' update
+ *                                matrices/vectors into the exchange buffer (g2ohip_device_array 103)
+ *   [caller: all-reduce(SUM) of buffer 103 over the ranks]
+ *   g2ohip_solve_reduced_shared  shared top: factor + forward/backward, backward sweep of the own
+ *                                subtrees, mask x_p entries owned elsewhere (g2ohip_device_array 104)
+ *   [caller: all-reduce(SUM) of buffer 104]
+ *   g2ohip_solve_reduced_finish  un-permute x_p; G2OHIP_NOT_PD if a local pivot was <= 0
+ * g2ohip_get_partition: owner rank (-1 = shared) of every pose block and of every Hschur block (the rank
+ * that consumes its value) -- what the caller needs to exchange only the boundary blocks.
+ * g2ohip_partition_poses: the same partition (block_consumer may be NULL) from a bare block pattern, host only (no device), so
+ * landmarks can be dealt to ranks before build_structure; options_from (may be NULL) supplies the ordering
+ * options (g2ohip_set_option) so that the result matches what that solver will compute.  In partitioned
+ * mode g2ohip_set_lambda[_split] damps a pose block only on the rank that consumes its diagonal block. */
+int g2ohip_set_partition(g2ohip_solver* s, int rank, int world);
+int g2ohip_solve_reduced_local(g2ohip_solver* s);
+int g2ohip_solve_reduced_shared(g2ohip_solver* s);
+int g2ohip_solve_reduced_finish(g2ohip_solver* s);
+int g2ohip_get_partition(g2ohip_solver* s, int32_t* pose_owner, int32_t* block_consumer);
+int g2ohip_partition_poses(const g2ohip_solver* options_from, int block_dim, int n_blocks, const int32_t* colptr,
+                           const int32_t* rowidx, int world, int32_t* pose_owner, int32_t* block_consumer);
+
 /* Split solve for the multi-GPU path: g2ohip_solve == schur + reduced + back_substitute. */
 int g2ohip_solve_schur(g2ohip_solver* s);            /* K5-K8: Hschur, bschur, Dinv          */
 int g2ohip_solve_reduced(g2ohip_solver* s);          /* K9-K12: x_p = Hschur \ bschur        */

@@ -22,7 +22,7 @@ c_dbl_p = C.POINTER(C.c_double)
 
 OK, NOT_PD = 0, 1
 HPP, HPL, HLL, HSCHUR, DINV = 0, 1, 2, 3, 4
-ARR_BSCHUR, ARR_X, ARR_B = 100, 101, 102
+ARR_BSCHUR, ARR_X, ARR_B, ARR_EXCHANGE, ARR_XP = 100, 101, 102, 103, 104
 KERNEL_NONE, KERNEL_HUBER = 0, 1
 
 
@@ -49,6 +49,8 @@ EXPORTS = [
     "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time", "g2ohip_add_schur_pattern",
     "g2ohip_set_lambda_split", "g2ohip_ba_set_edges", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
+    "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
+    "g2ohip_get_partition", "g2ohip_partition_poses",
 ]
 
 _lib = None
@@ -84,8 +86,12 @@ def load():
     L.g2ohip_restore_diagonal.argtypes = [vp]
     L.g2ohip_max_diagonal.argtypes = [vp, c_dbl_p]
     L.g2ohip_compute_scale.argtypes = [vp, C.c_double, c_dbl_p]
+    L.g2ohip_set_partition.argtypes = [vp, C.c_int, C.c_int]
+    L.g2ohip_get_partition.argtypes = [vp, c_int_p, c_int_p]
+    L.g2ohip_partition_poses.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p]
     for n in ("g2ohip_solve", "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute",
-              "g2ohip_sync"):
+              "g2ohip_sync", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared",
+              "g2ohip_solve_reduced_finish"):
         getattr(L, n).argtypes = [vp]
     L.g2ohip_vector_size.argtypes = [vp]
     L.g2ohip_vector_size.restype = C.c_size_t
@@ -197,6 +203,7 @@ class HipBlockSolver:
             schur = num_landmarks > 0
         _check(self.L.g2ohip_build_structure(self.h, num_poses, num_landmarks, int(bool(schur))), "buildStructure")
         self.nP, self.nL = num_poses, num_landmarks
+        self.schur = bool(schur)
         return True
 
     def setEdgeData(self, set_id, J0, J1, omega, err):
@@ -266,6 +273,30 @@ class HipBlockSolver:
 
     def solveReduced(self):
         return _check(self.L.g2ohip_solve_reduced(self.h), "solveReduced") == OK
+
+    # ---- subtree-distributed reduced solve (include/g2ohip.h, "Subtree-distributed factorisation")
+    def setPartition(self, rank, world):
+        _check(self.L.g2ohip_set_partition(self.h, rank, world), "setPartition")
+
+    def getPartition(self):
+        """(pose_owner[nP], block_consumer[nnzb of the reduced system]); -1 = shared by all ranks."""
+        po = np.zeros(self.nP, np.int32)
+        bc = np.zeros(max(self.nnzb(HSCHUR if self.schur else HPP), 1), np.int32)
+        _check(self.L.g2ohip_get_partition(self.h, _ip(po), _ip(bc)), "getPartition")
+        return po, bc[:self.nnzb(HSCHUR if self.schur else HPP)]
+
+    def partitionPoses(self, colptr, rowidx, world):
+        """Host-only pose partition of an upper block-CCS pattern, with this solver's ordering options."""
+        return partition_poses(self.p, colptr, rowidx, world, self.h)
+
+    def solveReducedLocal(self):
+        _check(self.L.g2ohip_solve_reduced_local(self.h), "solveReducedLocal")
+
+    def solveReducedShared(self):
+        _check(self.L.g2ohip_solve_reduced_shared(self.h), "solveReducedShared")
+
+    def solveReducedFinish(self):
+        return _check(self.L.g2ohip_solve_reduced_finish(self.h), "solveReducedFinish") == OK
 
     def solveBackSubstitute(self):
         _check(self.L.g2ohip_solve_back_substitute(self.h), "solveBackSubstitute")
@@ -377,6 +408,19 @@ class HipBlockSolver:
         n = C.c_size_t()
         _check(self.L.g2ohip_device_array(self.h, which, C.byref(ptr), C.byref(n)), "deviceArray")
         return ptr.value, n.value
+
+
+def partition_poses(block_dim, colptr, rowidx, world, options_from=None):
+    """g2ohip_partition_poses: (owner rank of every block column, consumer rank of every block of the
+    pattern); -1 = shared top of the elimination tree.  Host only, no device."""
+    L = load()
+    colptr, rowidx = _i32(colptr), _i32(rowidx)
+    nb = len(colptr) - 1
+    po = np.zeros(nb, np.int32)
+    bc = np.zeros(max(len(rowidx), 1), np.int32)
+    _check(L.g2ohip_partition_poses(options_from, block_dim, nb, _ip(colptr), _ip(rowidx), world, _ip(po), _ip(bc)),
+           "partitionPoses")
+    return po, bc[:len(rowidx)]
 
 
 class HipLinearSolver:

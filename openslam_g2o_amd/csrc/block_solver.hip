@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(kThreads) maxdiag_partial_kernel(int nV, int d
 
 // K4: setLambda / restoreDiagonal (block_solver.hpp:563-604)
 __global__ void __launch_bounds__(kThreads) lambda_kernel(int nV, int dv, double* __restrict__ H, const int* __restrict__ diag_blk, double* __restrict__ backup,
-                              double lambda, int do_backup, int restore) {
+                              double lambda, int do_backup, int restore, const unsigned char* __restrict__ mask = nullptr) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= (size_t)nV * dv) return;
   const size_t v = i / dv, j = i % dv;
@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(kThreads) lambda_kernel(int nV, int dv, double
     return;
   }
   if (do_backup) backup[i] = *d;
+  if (mask && !mask[v]) return;   // multi-GPU: exactly one rank damps each pose block (the sum is formed later)
   *d += lambda;
 }
 
@@ -1395,6 +1396,17 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   chol_->opt = chol_opt;
   if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
   else chol_->analyze(nP, pp_colptr.data(), pp_row.data(), st_);
+  if (chol_opt.world > 1) {
+    // the rank that consumes a pose's diagonal block adds lambda to it (rank 0 for the shared ones)
+    const std::vector<int>& cons = chol_->symbolic().block_consumer;
+    const std::vector<int>& cp = schur_ ? hs_colptr : pp_colptr;
+    std::vector<unsigned char> m(nP);
+    for (int c = 0; c < nP; ++c) {
+      const int o = cons[cp[c + 1] - 1];
+      m[c] = (o == chol_opt.rank) || (o < 0 && chol_opt.rank == 0);
+    }
+    d_lam_mask.upload(m, st_);
+  }
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   structured_ = true;
   system_built_ = false;
@@ -1557,7 +1569,7 @@ void BlockSolver::set_lambda_split(double lambda_pose, double lambda_landmark, b
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   prof.begin(KernelProf::kLambda, st_);
   hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nP_ * p_)), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p, d_bkP.p,
-                     lambda_pose, backup ? 1 : 0, 0);
+                     lambda_pose, backup ? 1 : 0, 0, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr);
   if (nL_ > 0)
     hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nL_ * l_)), dim3(kThreads), 0, st_, nL_, l_, d_Hll.p, (const int*)nullptr,
                        d_bkL.p, lambda_landmark, backup ? 1 : 0, 0);
@@ -1697,6 +1709,57 @@ int BlockSolver::solve_reduced() {
     times.linsolve = tl_.seconds();
   }
   return bad ? 1 : 0;
+}
+
+void BlockSolver::set_partition(int rank, int world) {
+  if (world < 1 || rank < 0 || rank >= world) throw ArgFailure("set_partition: bad rank/world");
+  chol_opt.rank = rank;
+  chol_opt.world = world;
+  structured_ = false;
+}
+
+void BlockSolver::solve_reduced_local() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  prof.begin(KernelProf::kCholFactor, st_);
+  chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 0, st_);
+  prof.end(KernelProf::kCholFactor, st_);
+  prof.begin(KernelProf::kCholSolve, st_);
+  chol_->solve_begin(schur_ ? d_bschur.p : d_b.p, st_);
+  chol_->solve_forward_phase(0, st_);
+  chol_->pack_exchange(st_);
+  prof.end(KernelProf::kCholSolve, st_);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+void BlockSolver::solve_reduced_shared() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  chol_->unpack_exchange(st_);
+  prof.begin(KernelProf::kCholFactor, st_);
+  chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 1, st_);
+  prof.end(KernelProf::kCholFactor, st_);
+  prof.begin(KernelProf::kCholSolve, st_);
+  chol_->solve_forward_phase(1, st_);
+  chol_->solve_backward_phase(1, st_);
+  chol_->solve_backward_phase(0, st_);
+  chol_->mask_solution(st_);
+  prof.end(KernelProf::kCholSolve, st_);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+int BlockSolver::solve_reduced_finish() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  chol_->solve_end(d_x.p, st_);
+  return chol_->failed(st_) ? 1 : 0;
+}
+
+void BlockSolver::partition_info(int* pose_owner, int* block_consumer) {
+  require_structure();
+  const CholSymbolic& S = chol_->symbolic();
+  if (pose_owner) std::copy(S.pose_owner.begin(), S.pose_owner.end(), pose_owner);
+  if (block_consumer) std::copy(S.block_consumer.begin(), S.block_consumer.end(), block_consumer);
 }
 
 void BlockSolver::solve_back_substitute() {
@@ -1918,6 +1981,8 @@ void BlockSolver::device_array(int which, double** ptr, size_t* count) {
     case 100: *ptr = d_bschur.p; *count = (size_t)nP_ * p_; break;
     case 101: *ptr = d_x.p; *count = vector_size(); break;
     case 102: *ptr = d_b.p; *count = vector_size(); break;
+    case 103: *ptr = chol_->exchange_buffer(count); break;      // subtree-root update matrices + vectors
+    case 104: *ptr = chol_->permuted_solution(count); break;   // x_p in elimination order (masked before the all-reduce)
     default: throw ArgFailure("bad array selector");
   }
 }

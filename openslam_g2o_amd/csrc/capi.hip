@@ -209,6 +209,54 @@ int g2ohip_solve_reduced(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] { return s->impl->solve_reduced() ? G2OHIP_NOT_PD : G2OHIP_OK; });
 }
+int g2ohip_set_partition(g2ohip_solver* s, int rank, int world) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_partition(rank, world);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_solve_reduced_local(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->solve_reduced_local();
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_solve_reduced_shared(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->solve_reduced_shared();
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_solve_reduced_finish(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] { return s->impl->solve_reduced_finish() ? G2OHIP_NOT_PD : G2OHIP_OK; });
+}
+int g2ohip_get_partition(g2ohip_solver* s, int32_t* pose_owner, int32_t* block_consumer) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->partition_info(pose_owner, block_consumer);
+    return G2OHIP_OK;
+  });
+}
+// Host-only: partition of the reduced system's block columns over `world` ranks (no device needed).
+int g2ohip_partition_poses(const g2ohip_solver* options_from, int block_dim, int n_blocks, const int32_t* colptr, const int32_t* rowidx,
+                           int world, int32_t* pose_owner, int32_t* block_consumer) {
+  if (!colptr || !rowidx || !pose_owner || n_blocks <= 0 || world < 1) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    SparseCholesky chol(block_dim);
+    if (options_from) chol.opt = options_from->impl->chol_opt;
+    chol.opt.rank = 0;
+    chol.opt.world = world;
+    chol.analyze(n_blocks, colptr, rowidx, nullptr, /*host_only=*/true);
+    const CholSymbolic& S = chol.symbolic();
+    std::copy(S.pose_owner.begin(), S.pose_owner.end(), pose_owner);
+    if (block_consumer) std::copy(S.block_consumer.begin(), S.block_consumer.end(), block_consumer);
+    return G2OHIP_OK;
+  });
+}
 int g2ohip_solve_back_substitute(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

@@ -31,6 +31,13 @@ struct StateFailure : std::runtime_error {
                                  ":" + std::to_string(__LINE__) + ")");                              \
   } while (0)
 
+// When set, DevBuf operations are skipped: lets the host-only symbolic analysis (partition queries, CPU
+// tests) share the code path of the device build without touching HIP.
+inline bool& host_only_flag() {
+  static thread_local bool f = false;
+  return f;
+}
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -45,6 +52,7 @@ struct DevBuf {
     n = 0;
   }
   void alloc(size_t count) {
+    if (host_only_flag()) return;
     if (count <= n && p) return;
     release();
     if (count == 0) count = 1;
@@ -52,6 +60,7 @@ struct DevBuf {
     n = count;
   }
   void upload(const T* h, size_t count, hipStream_t st) {
+    if (host_only_flag()) return;
     alloc(count);
     if (count) G2OHIP_HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st));
   }
@@ -64,6 +73,7 @@ struct DevBuf {
     G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
   }
   void zero(hipStream_t st) {
+    if (host_only_flag()) return;
     if (p && n) G2OHIP_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), st));
   }
 };

@@ -31,6 +31,7 @@ struct CholOptions {
   double relax_zeros = 0.25; // relaxed amalgamation: tolerated share of explicit zero blocks in a panel
   size_t lds_front_bytes = 64 * 1024;  // fronts up to this size are factorised in LDS
   bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task
+  int rank = 0, world = 1;   // multi-GPU: this rank factorises its own subtrees + (redundantly) the shared top of the tree
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
 };
 
@@ -57,6 +58,10 @@ struct CholSymbolic {
   std::vector<int> child_off, children;
   std::vector<int> task_ptr, task_fronts;    // tasks (chains of fronts fused into one workgroup)
   std::vector<int> level_ptr, level_fronts;  // task ids grouped by task level (leaves first)
+  // multi-GPU partition (world > 1): owner rank of every task (-1 = shared top-of-tree task, done by all
+  // ranks), of every block column (original order) and of every block of the analysed pattern
+  std::vector<int> task_owner, pose_owner, block_consumer;
+  std::vector<int> xroots;                   // subtree-root tasks whose update matrix / vector is exchanged
   long long L_total = 0, U_total = 0, w_total = 0;
 };
 
@@ -98,7 +103,8 @@ class SparseCholesky {
   CholOptions opt;
 
   // Host symbolic analysis of an upper-triangular block-CCS pattern (rows <= col, sorted).
-  void analyze(int nb, const int* colptr, const int* rowidx, hipStream_t st);
+  // host_only: no device work at all (partition queries, CPU tests).
+  void analyze(int nb, const int* colptr, const int* rowidx, hipStream_t st, bool host_only = false);
   bool analyzed() const { return analyzed_; }
   void reset() { analyzed_ = false; }
 
@@ -107,6 +113,18 @@ class SparseCholesky {
   void factor(const double* dA, hipStream_t st);
   // x = A \ b with device vectors of nb*bs (original block order).  Asynchronous.
   void solve(const double* d_b, double* d_x, hipStream_t st);
+  // ---- phased interface for the multi-GPU path (phase 0: this rank's subtrees, phase 1: shared top)
+  void factor_phase(const double* dA, int phase, hipStream_t st);
+  void solve_begin(const double* d_b, hipStream_t st);            // permute the right-hand side in
+  void solve_forward_phase(int phase, hipStream_t st);
+  void solve_backward_phase(int phase, hipStream_t st);
+  void solve_end(double* d_x, hipStream_t st);                    // permute the solution out
+  void pack_exchange(hipStream_t st);                             // own subtree roots: U, w -> exchange buffer (others zero)
+  void unpack_exchange(hipStream_t st);                           // foreign subtree roots: exchange buffer -> U, w
+  void mask_solution(hipStream_t st);                             // zero the entries other ranks own (before the x all-reduce)
+  double* exchange_buffer(size_t* count) { *count = xbuf_count_; return d_xbuf.p; }
+  double* permuted_solution(size_t* count) { *count = (size_t)sym_.nb * bs_; return d_xp.p; }
+  int* status_flag() { return d_status.p; }
   // Synchronises st and returns true when the last factorisation met a pivot <= 0.
   bool failed(hipStream_t st);
 
@@ -135,7 +153,14 @@ class SparseCholesky {
     int max_m = 0;
     int lds_idx_ints = 0, glb_idx_ints = 0;              // staged index lists (ints) per front, max over the launch
   };
-  std::vector<LevelLaunch> launches_;
+  std::vector<LevelLaunch> launches_[2];   // [0] own tasks, [1] shared top-of-tree tasks
+  struct SegCopy { long long a, b; int n, flags; };  // exchange segment: a = offset in U (or w: flag 2), b = offset in xbuf; flag 1 = mine
+  DevBuf<SegCopy> d_xseg;
+  DevBuf<double> d_xbuf, d_xmask;
+  int n_xseg_ = 0;
+  size_t xbuf_count_ = 0;
+  void launch_factor(const LevelLaunch& LL, const double* dA, hipStream_t st);
+  void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st);
   CholPlanDev plan_{};
 };
 

@@ -263,7 +263,12 @@ void postorder(int nb, const std::vector<int>& parent, std::vector<int>& post) {
 
 }  // namespace
 
-void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipStream_t st) {
+void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipStream_t st, bool host_only) {
+  struct HostOnlyScope {
+    bool prev;
+    explicit HostOnlyScope(bool on) : prev(host_only_flag()) { host_only_flag() = on; }
+    ~HostOnlyScope() { host_only_flag() = prev; }
+  } host_scope(host_only);
   auto t0 = std::chrono::steady_clock::now();
   const int bs = bs_;
   CholSymbolic& S = sym_;
@@ -503,38 +508,122 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   for (int t = 0; t < ntask; ++t) nlev = std::max(nlev, task_level[t] + 1);
   stats_.n_levels = nlev;
   stats_.n_tasks = ntask;
-  // --- launch lists (task ids): LDS-class tasks first, then scratch-slab (single large front) tasks
-  S.level_ptr.assign(nlev + 1, 0);
-  for (int t = 0; t < ntask; ++t) S.level_ptr[task_level[t] + 1]++;
-  for (int l = 0; l < nlev; ++l) S.level_ptr[l + 1] += S.level_ptr[l];
-  S.level_fronts.resize(ntask);
-  launches_.assign(nlev, LevelLaunch());
-  std::vector<long long> scratch_off(ntask, 0);
+  // --- multi-GPU partition of the task tree: the top of the tree is split until there are >= world
+  // subtrees and the longest-processing-time deal of them to the ranks is balanced within 10%; every task
+  // above them is "shared" and executed redundantly by all ranks
+  S.task_owner.assign(ntask, opt.world > 1 ? -2 : opt.rank);
+  S.xroots.clear();
+  if (opt.world > 1) {
+    std::vector<std::vector<int>> tkids(ntask);
+    std::vector<int> tparent(ntask, -1);
+    for (int t = 0; t < ntask; ++t) {
+      const int last = S.task_fronts[S.task_ptr[t + 1] - 1];
+      const int pf = S.f_parent[last];
+      if (pf >= 0) {
+        tparent[t] = task_of[pf];
+        tkids[task_of[pf]].push_back(t);
+      }
+    }
+    std::vector<double> work(ntask, 0.0);
+    for (int t = 0; t < ntask; ++t) {   // tasks are created in postorder of their head fronts: children first
+      for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
+        const double m = (double)front_dim(S.task_fronts[k]), np = (double)S.f_ns[S.task_fronts[k]] * bs;
+        work[t] += np * m * m;
+      }
+      for (int c : tkids[t]) work[t] += work[c];
+    }
+    std::vector<int> cut;
+    for (int t = 0; t < ntask; ++t)
+      if (tparent[t] < 0) cut.push_back(t);
+    // longest-processing-time deal of the current cut; returns max load / mean load
+    std::vector<int> cut_rank;
+    auto deal = [&]() {
+      std::vector<int> order(cut.size());
+      for (size_t k = 0; k < cut.size(); ++k) order[k] = (int)k;
+      std::sort(order.begin(), order.end(), [&](int x, int y) { return work[cut[x]] != work[cut[y]] ? work[cut[x]] > work[cut[y]] : cut[x] < cut[y]; });
+      std::vector<double> load(opt.world, 0.0);
+      cut_rank.assign(cut.size(), 0);
+      double total = 0.0;
+      for (int k : order) {
+        int r = 0;
+        for (int q = 1; q < opt.world; ++q)
+          if (load[q] < load[r]) r = q;
+        load[r] += work[cut[k]];
+        cut_rank[k] = r;
+        total += work[cut[k]];
+      }
+      return *std::max_element(load.begin(), load.end()) / std::max(total / opt.world, 1e-300);
+    };
+    for (;;) {
+      const bool enough = (int)cut.size() >= opt.world;
+      if (enough && ((int)cut.size() >= 8 * opt.world || deal() <= 1.10)) break;
+      int best = -1;
+      for (size_t k = 0; k < cut.size(); ++k)
+        if (!tkids[cut[k]].empty() && (best < 0 || work[cut[k]] > work[cut[best]])) best = (int)k;
+      if (best < 0) break;
+      const int t = cut[best];
+      S.task_owner[t] = -1;   // shared
+      cut.erase(cut.begin() + best);
+      for (int c : tkids[t]) cut.push_back(c);
+    }
+    deal();
+    for (size_t k = 0; k < cut.size(); ++k) {
+      const int t = cut[k];
+      std::vector<int> stk(1, t);
+      while (!stk.empty()) {
+        int u = stk.back();
+        stk.pop_back();
+        S.task_owner[u] = cut_rank[k];
+        for (int c : tkids[u]) stk.push_back(c);
+      }
+      if (tparent[t] >= 0) S.xroots.push_back(t);   // its update matrix / vector feeds a shared task
+    }
+    std::sort(S.xroots.begin(), S.xroots.end());
+    for (int t = 0; t < ntask; ++t)
+      if (S.task_owner[t] == -2) throw StateFailure("partition: unassigned task");
+  }
+  S.pose_owner.assign(nb, opt.rank);
+  for (int t = 0; t < ntask; ++t)
+    for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
+      const int f = S.task_fronts[k];
+      for (int j = S.sn_start[f]; j < S.sn_start[f + 1]; ++j) S.pose_owner[S.perm[j]] = S.task_owner[t];
+    }
+  S.block_consumer.resize(nnzb);
+  for (int q = 0; q < nnzb; ++q) S.block_consumer[q] = S.task_owner[task_of[ent_front[q]]];
+  // --- launch lists (task ids) per phase: [0] this rank's tasks, [1] shared tasks; inside a level the
+  // LDS-class tasks come first, then the scratch-slab (single large front) tasks
+  S.level_fronts.clear();
+  std::vector<long long> scratch_off;
   long long scratch_max = 0;
-  {
+  for (int ph = 0; ph < 2; ++ph) {
+    launches_[ph].assign(nlev, LevelLaunch());
     std::vector<std::vector<int>> lds(nlev), glb(nlev);
-    for (int t = 0; t < ntask; ++t) (is_lds(S.task_fronts[S.task_ptr[t]]) ? lds : glb)[task_level[t]].push_back(t);
+    for (int t = 0; t < ntask; ++t) {
+      const bool in_phase = ph == 0 ? (S.task_owner[t] == opt.rank) : (S.task_owner[t] == -1);
+      if (!in_phase) continue;
+      (is_lds(S.task_fronts[S.task_ptr[t]]) ? lds : glb)[task_level[t]].push_back(t);
+    }
     for (int l = 0; l < nlev; ++l) {
-      LevelLaunch& LL = launches_[l];
-      int pos = S.level_ptr[l];
-      LL.lds_begin = pos;
+      LevelLaunch& LL = launches_[ph][l];
+      LL.lds_begin = (int)S.level_fronts.size();
       LL.lds_count = (int)lds[l].size();
       for (int t : lds[l]) {
-        S.level_fronts[pos++] = t;
+        S.level_fronts.push_back(t);
+        scratch_off.push_back(0);
         for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) LL.lds_max_m = std::max(LL.lds_max_m, (int)front_dim(S.task_fronts[k]));
       }
-      LL.glb_begin = pos;
+      LL.glb_begin = (int)S.level_fronts.size();
       LL.glb_count = (int)glb[l].size();
       long long so = 0;
       for (int t : glb[l]) {
-        scratch_off[pos] = so;
+        scratch_off.push_back(so);
         const long long m = (long long)front_dim(S.task_fronts[S.task_ptr[t]]);
         so += m * m;
-        S.level_fronts[pos++] = t;
+        S.level_fronts.push_back(t);
         LL.glb_max_m = std::max(LL.glb_max_m, (int)m);
       }
       scratch_max = std::max(scratch_max, so);
-      for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
+      for (int q = LL.lds_begin; q < LL.glb_begin + LL.glb_count; ++q) {
         const int t = S.level_fronts[q];
         for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
           const int f = S.task_fronts[k];
@@ -544,6 +633,10 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         }
       }
     }
+  }
+  if (S.level_fronts.empty()) {
+    S.level_fronts.push_back(0);
+    scratch_off.push_back(0);
   }
   // --- packed per-front records and per-parent extend-add descriptors
   std::vector<FrontRec> recs(nf);
@@ -594,7 +687,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     for (int i = 0; k < tri_max; ++i)
       for (int j = 0; j <= i && k < tri_max; ++j) tri[k++] = i | (j << 16);
   }
-  for (LevelLaunch& LL : launches_) {
+  for (int ph = 0; ph < 2; ++ph)
+  for (LevelLaunch& LL : launches_[ph]) {
     LL.lds_idx_ints = LL.glb_idx_ints = 0;
     for (int q = LL.lds_begin; q < LL.glb_begin + LL.glb_count; ++q) {
       const int t = S.level_fronts[q];
@@ -612,6 +706,36 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_crel.upload(crel, st);
   d_cmap.upload(cmap, st);
   d_tri.upload(tri, st);
+  // --- multi-GPU exchange plan: update matrices / vectors of the subtree roots, solution mask
+  {
+    std::vector<SegCopy> segs;
+    long long xoff = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int t : S.xroots) {
+        const int f = S.task_fronts[S.task_ptr[t + 1] - 1];
+        SegCopy sc;
+        sc.flags = (S.task_owner[t] == opt.rank ? 1 : 0) | (pass ? 2 : 0);
+        sc.a = pass ? S.w_off[f] : S.U_off[f];
+        sc.n = pass ? S.f_nb[f] * bs : S.f_nb[f] * (S.f_nb[f] + 1) / 2 * bs * bs;
+        sc.b = xoff;
+        xoff += sc.n;
+        segs.push_back(sc);
+      }
+    n_xseg_ = (int)segs.size();
+    xbuf_count_ = (size_t)xoff;
+    if (n_xseg_ > 0) {
+      d_xseg.upload(segs, st);
+      d_xbuf.alloc(xbuf_count_);
+    }
+    std::vector<double> mask((size_t)nb * bs, 1.0);
+    if (opt.world > 1)
+      for (int j = 0; j < nb; ++j) {
+        const int o = S.task_owner[task_of[sn_of[j]]];
+        const double v = (o == opt.rank || (o == -1 && opt.rank == 0)) ? 1.0 : 0.0;
+        for (int r = 0; r < bs; ++r) mask[(size_t)j * bs + r] = v;
+      }
+    d_xmask.upload(mask, st);
+  }
   // --- upload
   std::vector<int> c0(S.sn_start.begin(), S.sn_start.end() - 1);
   d_f_ns.upload(S.f_ns, st);
@@ -640,7 +764,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_scratch.alloc((size_t)scratch_max);
   d_status.alloc(1);
   d_status.zero(st);
-  G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
+  if (!host_only) G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
   plan_.task_ptr = d_task_ptr.p;
   plan_.task_fronts = d_task_fronts.p;
   plan_.rec = d_rec.p;
@@ -667,7 +791,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.U = d_U.p;
   plan_.w = d_w.p;
   plan_.status = d_status.p;
-  analyzed_ = true;
+  analyzed_ = !host_only;
   stats_.t_symbolic = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -1206,6 +1330,26 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, cons
   }
 }
 
+// exchange segments: dir 0 = pack (own subtree roots -> buffer), dir 1 = unpack (foreign roots <- buffer)
+struct SegCopyDev { long long a, b; int n, flags; };
+__global__ void seg_copy_kernel(const SegCopyDev* __restrict__ segs, double* __restrict__ U, double* __restrict__ w,
+                                double* __restrict__ buf, int dir) {
+  const SegCopyDev sc = segs[blockIdx.x];
+  const bool mine = sc.flags & 1;
+  double* arr = (sc.flags & 2) ? w : U;
+  if (dir == 0) {
+    if (!mine) return;
+    for (int i = threadIdx.x; i < sc.n; i += blockDim.x) buf[sc.b + i] = arr[sc.a + i];
+  } else {
+    if (mine) return;
+    for (int i = threadIdx.x; i < sc.n; i += blockDim.x) arr[sc.a + i] = buf[sc.b + i];
+  }
+}
+__global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* __restrict__ x) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= mask[i];
+}
+
 template <int BS>
 void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long long* d_scratch_off, double* d_scratch,
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
@@ -1226,9 +1370,27 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
 
 }  // namespace
 
-void SparseCholesky::factor(const double* dA, hipStream_t st) {
+void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, hipStream_t st) {
+  switch (bs_) {
+    case 3:
+      launch_factor_level<3>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
+                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
+      break;
+    case 6:
+      launch_factor_level<6>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
+                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
+      break;
+    case 7:
+      launch_factor_level<7>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
+                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
+      break;
+    default:
+      throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
+  }
+}
+
+void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st) {
   if (!analyzed_) throw StateFailure("SparseCholesky::factor before analyze");
-  G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
   static bool attr_done = false;
   if (!attr_done) {
     // allow > 64 KiB dynamic LDS for the LDS-resident front kernels
@@ -1237,42 +1399,25 @@ void SparseCholesky::factor(const double* dA, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  for (const LevelLaunch& LL : launches_) {
-    switch (bs_) {
-      case 3:
-        launch_factor_level<3>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                               LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
-        break;
-      case 6:
-        launch_factor_level<6>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                               LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
-        break;
-      case 7:
-        launch_factor_level<7>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                               LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
-        break;
-      default:
-        throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
-    }
-  }
+  if (phase == 0) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
+  for (const LevelLaunch& LL : launches_[phase]) launch_factor(LL, dA, st);
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 
-void SparseCholesky::solve(const double* d_b, double* d_x, hipStream_t st) {
-  if (!analyzed_) throw StateFailure("SparseCholesky::solve before analyze");
-  const int n = sym_.nb * bs_;
-  if (n == 0) return;
-  const int thr = 256;
-  hipLaunchKernelGGL(permute_in_kernel, dim3((n + thr - 1) / thr), dim3(thr), 0, st, sym_.nb, bs_, d_perm.p, d_b, d_xp.p);
+void SparseCholesky::factor(const double* dA, hipStream_t st) {
+  factor_phase(dA, 0, st);
+  factor_phase(dA, 1, st);
+}
+
+void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st) {
   const size_t panel_limit = 48 * 1024;  // bytes of L panel staged in LDS
-  auto run = [&](const LevelLaunch& LL, bool fwd) {
-    int count = LL.lds_count + LL.glb_count;
-    if (count == 0) return;
-    const int* fl = d_level_fronts.p + LL.lds_begin;
-    bool panel = (size_t)LL.max_panel * 8 <= panel_limit;
-    int cap = panel ? LL.max_panel : 0;
-    int nthreads = LL.max_m <= 64 ? 64 : (LL.max_m <= 128 ? 128 : 256);
-    size_t sh = ((size_t)cap + 3 * (size_t)LL.max_m + nthreads + 8) * sizeof(double);
+  int count = LL.lds_count + LL.glb_count;
+  if (count == 0) return;
+  const int* fl = d_level_fronts.p + LL.lds_begin;
+  bool panel = (size_t)LL.max_panel * 8 <= panel_limit;
+  int cap = panel ? LL.max_panel : 0;
+  int nthreads = LL.max_m <= 64 ? 64 : (LL.max_m <= 128 ? 128 : 256);
+  size_t sh = ((size_t)cap + 3 * (size_t)LL.max_m + nthreads + 8) * sizeof(double);
 #define G2OHIP_SOLVE_LAUNCH(BS_)                                                                                              \
   if (fwd) {                                                                                                                  \
     if (panel)                                                                                                                \
@@ -1285,20 +1430,58 @@ void SparseCholesky::solve(const double* d_b, double* d_x, hipStream_t st) {
     else                                                                                                                      \
       hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_y.p, d_xp.p, cap, LL.max_m); \
   }
-    switch (bs_) {
-      case 3: G2OHIP_SOLVE_LAUNCH(3) break;
-      case 6: G2OHIP_SOLVE_LAUNCH(6) break;
-      case 7: G2OHIP_SOLVE_LAUNCH(7) break;
-      default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
-    }
+  switch (bs_) {
+    case 3: G2OHIP_SOLVE_LAUNCH(3) break;
+    case 6: G2OHIP_SOLVE_LAUNCH(6) break;
+    case 7: G2OHIP_SOLVE_LAUNCH(7) break;
+    default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
+  }
 #undef G2OHIP_SOLVE_LAUNCH
-  };
-  // forward: d_xp holds the permuted rhs, y receives the pivot solutions
-  for (size_t l = 0; l < launches_.size(); ++l) run(launches_[l], true);
-  // backward: overwrite d_xp with the solution, root level first
-  for (size_t l = launches_.size(); l-- > 0;) run(launches_[l], false);
-  hipLaunchKernelGGL(permute_out_kernel, dim3((n + thr - 1) / thr), dim3(thr), 0, st, sym_.nb, bs_, d_perm.p, d_xp.p, d_x);
+}
+
+void SparseCholesky::solve_begin(const double* d_b, hipStream_t st) {
+  if (!analyzed_) throw StateFailure("SparseCholesky::solve before analyze");
+  const int n = sym_.nb * bs_;
+  if (n == 0) return;
+  hipLaunchKernelGGL(permute_in_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sym_.nb, bs_, d_perm.p, d_b, d_xp.p);
+}
+void SparseCholesky::solve_forward_phase(int phase, hipStream_t st) {
+  // d_xp holds the permuted rhs, y receives the pivot solutions
+  for (size_t l = 0; l < launches_[phase].size(); ++l) launch_solve(launches_[phase][l], true, st);
+}
+void SparseCholesky::solve_backward_phase(int phase, hipStream_t st) {
+  // overwrite d_xp with the solution, highest level first
+  for (size_t l = launches_[phase].size(); l-- > 0;) launch_solve(launches_[phase][l], false, st);
+}
+void SparseCholesky::solve_end(double* d_x, hipStream_t st) {
+  const int n = sym_.nb * bs_;
+  if (n == 0) return;
+  hipLaunchKernelGGL(permute_out_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sym_.nb, bs_, d_perm.p, d_xp.p, d_x);
   G2OHIP_HIP_CHECK(hipGetLastError());
+}
+void SparseCholesky::solve(const double* d_b, double* d_x, hipStream_t st) {
+  solve_begin(d_b, st);
+  solve_forward_phase(0, st);
+  solve_forward_phase(1, st);
+  solve_backward_phase(1, st);
+  solve_backward_phase(0, st);
+  solve_end(d_x, st);
+}
+void SparseCholesky::pack_exchange(hipStream_t st) {
+  if (n_xseg_ == 0) return;
+  G2OHIP_HIP_CHECK(hipMemsetAsync(d_xbuf.p, 0, xbuf_count_ * sizeof(double), st));
+  hipLaunchKernelGGL(seg_copy_kernel, dim3(n_xseg_), dim3(256), 0, st, reinterpret_cast<const SegCopyDev*>(d_xseg.p), d_U.p, d_w.p,
+                     d_xbuf.p, 0);
+}
+void SparseCholesky::unpack_exchange(hipStream_t st) {
+  if (n_xseg_ == 0) return;
+  hipLaunchKernelGGL(seg_copy_kernel, dim3(n_xseg_), dim3(256), 0, st, reinterpret_cast<const SegCopyDev*>(d_xseg.p), d_U.p, d_w.p,
+                     d_xbuf.p, 1);
+}
+void SparseCholesky::mask_solution(hipStream_t st) {
+  const size_t n = (size_t)sym_.nb * bs_;
+  if (opt.world <= 1 || n == 0) return;
+  hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, d_xmask.p, d_xp.p);
 }
 
 bool SparseCholesky::failed(hipStream_t st) {

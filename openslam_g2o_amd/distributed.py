@@ -22,6 +22,18 @@ rank back-substitutes its own landmarks, so x_p is replicated and x_l stays shar
 
 The local solver is injected (HipBlockSolver in production); tests/test_distributed.py
 drives the same code with a CPU stand-in over gloo.
+
+mode "subtree" (default with HipBlockSolver when world > 1) removes both the replicated
+factorisation and the full-size all-reduce.  The elimination-task tree of the reduced system
+(nested dissection, sparse_cholesky.hip) is cut near the root into >= N subtrees, dealt to the
+ranks; the few tasks above the cut are "shared".  Every pose then has an owner rank (or is
+shared), every Hschur block a consumer rank.  Landmarks are dealt to the owner of (the first of)
+their observing poses, so nearly all Schur contributions are produced on the rank that consumes
+them; only "boundary" blocks (a producer differs from the consumer, or the consumer is shared)
+go through a compact gather -> all-reduce -> scatter.  Per solve: boundary blocks + bschur
+all-reduce, own subtrees factor/forward (no communication), all-reduce of the subtree roots'
+update matrices (tiny: separator-sized), shared top factor/solve + own backward sweep,
+all-reduce of the masked x_p, back-substitution of the own landmarks.
 """
 import numpy as np
 
@@ -55,6 +67,64 @@ def schur_pattern_pairs(pose_idx, lm_idx):
     return (keys % nmax).astype(np.int32), (keys // nmax).astype(np.int32)
 
 
+def coobservation_pairs(pose_idx, lm_idx):
+    """All (row <= col) pose-block pairs co-observing a landmark, one entry per (landmark, pair):
+    returns rows, cols, landmark.  Free poses only."""
+    pose_idx = np.asarray(pose_idx, np.int64)
+    lm_idx = np.asarray(lm_idx, np.int64)
+    keep = pose_idx >= 0
+    pose_idx, lm_idx = pose_idx[keep], lm_idx[keep]
+    order = np.lexsort((pose_idx, lm_idx))
+    p, l = pose_idx[order], lm_idx[order]
+    n = len(p)
+    if n == 0:
+        z = np.zeros(0, np.int64)
+        return z, z, z
+    start = np.flatnonzero(np.r_[True, l[1:] != l[:-1]])
+    size = np.diff(np.r_[start, n])
+    gid = np.repeat(np.arange(len(start)), size)
+    cnt = size[gid] - (np.arange(n) - start[gid])
+    a = np.repeat(np.arange(n), cnt)
+    b = a + (np.arange(len(a)) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    return p[a], p[b], l[a]
+
+
+def reduced_pattern(rows, cols, nP):
+    """Upper block-CCS (colptr, rowidx, sorted keys col*nP+row) of the reduced system: the given
+    pairs plus the full diagonal (block_solver.hpp:262-288)."""
+    d = np.arange(nP, dtype=np.int64)
+    keys = np.unique(np.r_[np.asarray(cols, np.int64) * nP + np.asarray(rows, np.int64), d * nP + d])
+    colptr = np.searchsorted(keys // nP, np.arange(nP + 1)).astype(np.int32)
+    return colptr, (keys % nP).astype(np.int32), keys
+
+
+def assign_landmarks(pose_idx, lm_idx, pose_owner, nL, world):
+    """Owner rank of every landmark: the owner of its lowest-numbered observing pose that has one
+    (poses of the shared top of the tree have none); unobserved / all-shared landmarks round-robin."""
+    pose_idx = np.asarray(pose_idx, np.int64)
+    lm_idx = np.asarray(lm_idx, np.int64)
+    own = np.where(pose_idx >= 0, pose_owner[np.maximum(pose_idx, 0)], -1)
+    ok = own >= 0
+    owner = (np.arange(nL) % world).astype(np.int32)
+    if ok.any():
+        order = np.lexsort((pose_idx[ok], lm_idx[ok]))
+        l, o = lm_idx[ok][order], own[ok][order]
+        first = np.r_[True, l[1:] != l[:-1]]
+        owner[l[first]] = o[first]
+    return owner
+
+
+def boundary_blocks(keys, block_consumer, rows, cols, lms, lm_owner, nP):
+    """Indices of the reduced-system blocks whose value must be summed over ranks: a producer (the
+    rank owning a landmark co-observed by the block's two poses) differs from the consumer, or the
+    consumer is shared."""
+    blk = np.searchsorted(keys, cols * nP + rows)
+    bad = lm_owner[lms] != block_consumer[blk]
+    mark = np.zeros(len(keys), bool)
+    mark[blk[bad]] = True
+    return np.flatnonzero(mark)
+
+
 class _DevArray:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f8", data=(int(ptr), False), version=2, strides=None)
@@ -77,14 +147,48 @@ class TorchComm:
             return
         import torch.distributed as dist
         for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if t.numel():
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def all_reduce_scalar(self, v, device="cpu"):
+        if self.world <= 1:
+            return v
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([v], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def all_ok(self, ok, device="cpu"):
+        return self.all_reduce_scalar(0.0 if ok else 1.0, device) == 0.0
+
+
+class HostStagedComm(TorchComm):
+    """Same exchange through host memory (gloo): several ranks sharing one GPU (tests), or a box
+    without RCCL peer access.  Not a performance path."""
+
+    def all_reduce_sum(self, tensors):
+        if self.world <= 1 and not self.force:
+            return
+        import torch.distributed as dist
+        for t in tensors:
+            if t.numel():
+                c = t.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)
+                t.copy_(c)
 
 
 class ShardedBlockSolver:
-    def __init__(self, pose_dim, landmark_dim, rank=0, world=1, device=0, local=None, comm=None, force_exchange=False):
+    def __init__(self, pose_dim, landmark_dim, rank=0, world=1, device=0, local=None, comm=None, force_exchange=False,
+                 mode="auto"):
         self.p, self.l = pose_dim, landmark_dim
         self.rank, self.world = rank, world
         self.exchange = world > 1 or force_exchange   # union Schur pattern + all-reduce step active
+        if mode == "auto":
+            mode = "subtree" if (world > 1 and local is None) else "replicated"
+        if mode not in ("subtree", "replicated"):
+            raise ValueError("mode must be auto, subtree or replicated")
+        self.mode = mode
         if local is None:
             from . import capi
             local = capi.HipBlockSolver(pose_dim, landmark_dim, device)
@@ -94,7 +198,11 @@ class ShardedBlockSolver:
         self._keep = []
 
     def parallelism(self):
-        return "1 GPU" if self.world == 1 else "landmark-range shards x%d, all-reduce(Hschur,bschur), replicated Cholesky" % self.world
+        if self.world == 1:
+            return "1 GPU"
+        if self.mode == "subtree":
+            return "x%d: landmarks by pose owner, boundary-block all-reduce, subtree-distributed Cholesky" % self.world
+        return "landmark-range shards x%d, all-reduce(Hschur,bschur), replicated Cholesky" % self.world
 
     # ------------------------------------------------------------------------------------
     def setup_ba(self, prob, torch_device=None, nd_leaf=0, fused=False):
@@ -104,20 +212,45 @@ class ShardedBlockSolver:
         are evaluated inside the assembly kernels (the reference's buildSystem does the same per edge,
         block_solver.hpp:529-532)."""
         nP, nL = prob["nP"], prob["nL"]
-        lm0, lm1 = landmark_range(nL, self.world, self.rank)
         lm = prob["v0"].astype(np.int64) - nP
-        mine = (lm >= lm0) & (lm < lm1)
-        v0 = (nP + (lm[mine] - lm0)).astype(np.int32)
-        v1 = prob["v1"][mine].astype(np.int32)
-        self.lm0, self.lm1 = lm0, lm1
-        self.edge_mask = mine
         if nd_leaf:
             self.local.setOption("nd_leaf", nd_leaf)
+        if self.mode == "subtree":
+            prow, pcol, plm = coobservation_pairs(prob["v1"], lm)
+            colptr, rowidx, keys = reduced_pattern(prow, pcol, nP)
+            pose_owner, consumer = self.local.partitionPoses(colptr, rowidx, self.world)
+            lm_owner = assign_landmarks(prob["v1"], lm, pose_owner, nL, self.world)
+            my = np.flatnonzero(lm_owner == self.rank)
+            self.boundary = boundary_blocks(keys, consumer, prow, pcol, plm, lm_owner, nP)
+            self.pose_owner, self.nnzb_reduced = pose_owner, len(keys)
+            rows, cols = (keys % nP).astype(np.int32), (keys // nP).astype(np.int32)
+            del prow, pcol, plm
+        else:
+            lm0, lm1 = landmark_range(nL, self.world, self.rank)
+            my = np.arange(lm0, lm1)
+            if self.exchange:
+                rows, cols = schur_pattern_pairs(prob["v1"], lm)
+        loc = np.full(nL, -1, np.int64)
+        loc[my] = np.arange(len(my))
+        mine = loc[lm] >= 0
+        v0 = (nP + loc[lm[mine]]).astype(np.int32)
+        v1 = prob["v1"][mine].astype(np.int32)
+        lm0, lm1 = (int(my[0]), int(my[-1]) + 1) if len(my) else (0, 0)
+        self.lm0, self.lm1 = lm0, lm1          # (contiguous range in replicated mode)
+        self.lm_index = my                      # global landmark id of every local landmark
+        self.edge_mask = mine
         self.set_id = self.local.addEdgeSet(2, v0, v1)
         if self.exchange:
-            rows, cols = schur_pattern_pairs(prob["v1"], lm)
             self.local.addSchurPattern(rows, cols)
-        self.local.buildStructure(nP, lm1 - lm0, True)
+        if self.mode == "subtree":
+            self.local.setPartition(self.rank, self.world)
+        self.local.buildStructure(nP, len(my), True)
+        if self.mode == "subtree":
+            cp2, ri2 = self.local.pattern(3)
+            po2, bc2 = self.local.getPartition()
+            if not (np.array_equal(cp2, colptr) and np.array_equal(ri2, rowidx) and np.array_equal(po2, pose_owner)
+                    and np.array_equal(bc2, consumer)):
+                raise RuntimeError("subtree partition: the solver's reduced pattern/partition differs from the pre-pass")
         if fused:
             if torch_device is not None:
                 import torch
@@ -125,11 +258,11 @@ class ShardedBlockSolver:
                 self._torch_device = torch_device
             else:
                 self._torch_device = None
-            self.local.baSetEdges(self.set_id, prob["cam_idx"][mine], (prob["pt_idx"][mine] - lm0).astype(np.int32),
+            self.local.baSetEdges(self.set_id, prob["cam_idx"][mine], loc[prob["pt_idx"][mine]].astype(np.int32),
                                   prob["meas"][mine], None, prob["f"], prob["cx"], prob["cy"])
-            self.local.baSetEstimates(prob["cams"], prob["cam_hidx"], prob["pts"][lm0:lm1], np.arange(lm1 - lm0, dtype=np.int32))
+            self.local.baSetEstimates(prob["cams"], prob["cam_hidx"], prob["pts"][my], np.arange(len(my), dtype=np.int32))
             self.local.baLinearize(True)
-            return dict(E_local=int(mine.sum()), L_local=int(lm1 - lm0), lm0=int(lm0), lm1=int(lm1))
+            return dict(E_local=int(mine.sum()), L_local=int(len(my)), lm0=int(lm0), lm1=int(lm1))
         arrays = [np.ascontiguousarray(prob[k][mine]) for k in ("Jp", "Jc", "omega", "err")]
         if torch_device is not None:
             import torch
@@ -143,7 +276,31 @@ class ShardedBlockSolver:
             self._keep = arrays
             self.local.setEdgeData(self.set_id, *arrays)
             self._torch_device = None
-        return dict(E_local=int(mine.sum()), L_local=int(lm1 - lm0), lm0=int(lm0), lm1=int(lm1))
+        return dict(E_local=int(mine.sum()), L_local=int(len(my)), lm0=int(lm0), lm1=int(lm1))
+
+    def _device_tensor(self, which):
+        ptr, n = self.local.deviceArray(which)
+        if n == 0:
+            import torch
+            return torch.zeros(0, dtype=torch.float64, device=self._torch_device)
+        return tensor_from_device_ptr(ptr, n, self._torch_device)
+
+    def _subtree_tensors(self):
+        if getattr(self, "_sub", None) is None:
+            import torch
+            from . import capi
+            H = self._device_tensor(capi.HSCHUR).view(self.nnzb_reduced, self.p * self.p)
+            idx = torch.from_numpy(self.boundary).to(H.device)
+            self._sub = dict(H=H, idx=idx, b=self._device_tensor(capi.ARR_BSCHUR),
+                             xbuf=self._device_tensor(capi.ARR_EXCHANGE), xp=self._device_tensor(capi.ARR_XP))
+        return self._sub
+
+    def exchange_volume(self):
+        """Doubles all-reduced per solve (for DESIGN.md / bench config)."""
+        if self.mode != "subtree":
+            return sum(int(t.numel()) for t in self._reduced_tensors()) if self.exchange else 0
+        t = self._subtree_tensors()
+        return int(len(self.boundary) * self.p * self.p + t["b"].numel() + t["xbuf"].numel() + t["xp"].numel())
 
     def _reduced_tensors(self):
         if self._reduced is None:
@@ -163,12 +320,35 @@ class ShardedBlockSolver:
         return self.local.buildSystem()
 
     def setLambda(self, lam, backup=False):
+        if self.mode == "subtree":   # the solver damps a pose block only on the rank that consumes its diagonal
+            return self.local.setLambdaSplit(lam, lam, backup)
         return self.local.setLambdaSplit(lam if self.rank == 0 else 0.0, lam, backup)
 
     def restoreDiagonal(self):
         return self.local.restoreDiagonal()
 
+    def _solve_subtree(self):
+        t = self._subtree_tensors()
+        self.local.solveSchur()
+        if len(self.boundary):
+            buf = t["H"].index_select(0, t["idx"])
+            self.comm.all_reduce_sum([buf])
+            t["H"].index_copy_(0, t["idx"], buf)
+        self.comm.all_reduce_sum([t["b"]])
+        self.local.solveReducedLocal()          # own subtrees: factor + forward sweep, pack the roots
+        self.comm.all_reduce_sum([t["xbuf"]])
+        self.local.solveReducedShared()         # shared top, then back down the own subtrees; x_p masked
+        self.comm.all_reduce_sum([t["xp"]])
+        ok = self.local.solveReducedFinish()
+        ok = self.comm.all_ok(ok, t["b"].device)
+        if not ok:
+            return False
+        self.local.solveBackSubstitute()
+        return True
+
     def solve(self):
+        if self.mode == "subtree":
+            return self._solve_subtree()
         self.local.solveSchur()
         if self.exchange:
             self.comm.all_reduce_sum(self._reduced_tensors())
@@ -179,15 +359,8 @@ class ShardedBlockSolver:
         return True
 
     def chi2(self):
-        c = self.local.chi2()
-        if self.world > 1:
-            import torch
-            import torch.distributed as dist
-            dev = self._torch_device if self._torch_device is not None else "cpu"
-            t = torch.tensor([c], dtype=torch.float64, device=dev)
-            dist.all_reduce(t)
-            c = float(t.item())
-        return c
+        dev = self._torch_device if getattr(self, "_torch_device", None) is not None else "cpu"
+        return self.comm.all_reduce_scalar(self.local.chi2(), dev)
 
     def x_poses(self):
         return self.local.x()[:self.p * self.local.nP]
