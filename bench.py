@@ -106,6 +106,13 @@ def main():
     ap.add_argument("--edge-data", choices=["fused", "arrays"], default="fused",
                     help="fused: estimates + measurements resident in HBM, errors/Jacobians evaluated inside buildSystem "
                          "(what the reference's buildSystem does per edge); arrays: precomputed Jacobian arrays resident in HBM")
+    ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
+                    help="staged: gloo + host staging with every rank on cuda:0 (functional check of the N>1 path on a "
+                         "1-GPU box; its timing is meaningless)")
+    ap.add_argument("--emulate", default="", help="R/W: run rank R of a W-rank job alone with a no-op exchange (results are "
+                    "meaningless, per-rank kernel and wall time without communication are not) -- sizing tool for 1-GPU boxes")
+    ap.add_argument("--mode", choices=["auto", "subtree", "replicated"], default="auto", help="N>1 reduced-solve strategy")
+    ap.add_argument("--dump-xp", default="", help="rank 0 saves the pose increment to this .npy (cross-run comparison)")
     args = ap.parse_args()
 
     import torch
@@ -119,24 +126,46 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    emulate = None
+    if args.emulate:
+        emulate = tuple(int(v) for v in args.emulate.split("/"))
+    if args.comm == "staged":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.comm == "staged":
+            dist.init_process_group("gloo")
+            comm = D.HostStagedComm(world)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     P, L = args.poses, args.landmarks
     prob = S.make_ba_problem(P, L)                      # identical on every rank (counter-based RNG)
-    Jp, Jc, err = S.ba_linearize(prob)
-    prob.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(prob))
+    fused = args.edge_data == "fused"
+    prob["omega"] = S.ba_omega(prob)
+    if not fused:
+        Jp, Jc, err = S.ba_linearize(prob)
+        prob.update(Jp=Jp, Jc=Jc, err=err)
     lam = 1e-5 * 1.0e6                                  # tau * max diag(H) order of magnitude; fixed for reproducibility
 
-    solver = D.ShardedBlockSolver(6, 3, rank=rank, world=world, device=local_rank)
+    if emulate:
+        class NullComm(D.TorchComm):
+            def all_reduce_sum(self, tensors):
+                pass
+
+            def all_reduce_scalar(self, v, device="cpu"):
+                return v
+        solver = D.ShardedBlockSolver(6, 3, rank=emulate[0], world=emulate[1], device=local_rank, comm=NullComm(1),
+                                      mode="subtree" if args.mode == "auto" else args.mode)
+    else:
+        solver = D.ShardedBlockSolver(6, 3, rank=rank, world=world, device=local_rank, comm=comm, mode=args.mode)
     for kv in args.opt:
         k_, v_ = kv.split("=")
         solver.local.setOption(k_, float(v_))
-    fused = args.edge_data == "fused"
     shard = solver.setup_ba(prob, torch_device=dev, nd_leaf=args.nd_leaf, fused=fused)
     solver.local.setProfiling(True)
 
@@ -163,7 +192,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.comm == "rccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
@@ -206,6 +235,9 @@ def main():
                     if traffic else None)
 
     x_gpu = solver.local.x()
+    if args.dump_xp:
+        os.makedirs(os.path.dirname(os.path.abspath(args.dump_xp)), exist_ok=True)
+        np.save(args.dump_xp, x_gpu[:6 * prob["nP"]])
     out = {
         "metric": "linear-solve ms/iter (buildSystem + setLambda + solve + restoreDiagonal), 100k-pose BA",
         "value": ms, "unit": "ms/iter", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -222,14 +254,22 @@ def main():
         "stage_algorithmic_GB": {k: v / 1e9 for k, v in stage_b.items()},
         "solver_stats": {k: st[k] for k in ("choleskyNNZ", "numFronts", "numLevels", "maxFrontDim", "timeSymbolicDecomposition")},
     }
+    if emulate:
+        out["emulate"] = "rank %d of %d alone, exchange skipped: timing only" % emulate
+    if world > 1 or emulate:
+        out["shard"] = dict(rank0_edges=E_loc, rank0_landmarks=L_loc, exchange_doubles_per_solve=solver.exchange_volume(),
+                            comm=args.comm)
+        if solver.mode == "subtree":
+            out["shard"].update(boundary_blocks=int(len(solver.boundary)), reduced_blocks=int(solver.nnzb_reduced),
+                                poses_per_rank=np.bincount(solver.pose_owner + 1).tolist())
     # size-independent correctness property at full size: residual of the damped system
     solver.setLambda(lam, True)
-    if world == 1:
+    if world == 1 and not emulate:
         r = solver.local.multiplyHessian(x_gpu) - solver.local.b()
         out["residual_rel"] = float(np.abs(r).max() / np.abs(solver.local.b()).max())
     solver.restoreDiagonal()
 
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not emulate and not args.no_cpu_baseline:
         cb, x_cpu = cpu_baseline(prob, lam, include_linearize=fused)
         cpu_ms = 1e3 * (cb["t_assembly"] + cb["t_solve"])
         out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms/iter", "cores": 1, "kind": "port",
@@ -246,7 +286,7 @@ def main():
         e_g = S.ba_linearize(S.ba_oplus(prob, x_gpu), jac=False)
         e_c = S.ba_linearize(S.ba_oplus(prob, x_cpu), jac=False)
         chi_g, chi_c = float(np.sum(e_g * e_g)), float(np.sum(e_c * e_c))
-        out["chi2_before"] = float(np.sum(prob["err"] ** 2))
+        out["chi2_before"] = float(np.sum(S.ba_linearize(prob, jac=False) ** 2))
         out["chi2_after_gpu"], out["chi2_after_cpu"] = chi_g, chi_c
         out["chi2_rel_err"] = abs(chi_g - chi_c) / chi_c
     print(json.dumps(out))

@@ -363,6 +363,8 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "relax_zeros")) s->impl->chol_opt.relax_zeros = value;
   else if (!std::strcmp(name, "relax_front_bytes")) s->impl->chol_opt.relax_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "fuse_chains")) s->impl->chol_opt.fuse_chains = value != 0;
+  else if (!std::strcmp(name, "wave_front_tasks")) s->impl->chol_opt.wave_front_tasks = (int)value;
+  else if (!std::strcmp(name, "wave_front_bytes")) s->impl->chol_opt.wave_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_tile_bytes")) s->impl->schur_tile_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_group")) s->impl->schur_group = (int)value;
   else if (!std::strcmp(name, "ba_fused")) s->impl->ba_fused = value != 0;
@@ -547,6 +549,8 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "relax_zeros")) ls->opt.relax_zeros = value;
   else if (!std::strcmp(name, "relax_front_bytes")) ls->opt.relax_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "fuse_chains")) ls->opt.fuse_chains = value != 0;
+  else if (!std::strcmp(name, "wave_front_tasks")) ls->opt.wave_front_tasks = (int)value;
+  else if (!std::strcmp(name, "wave_front_bytes")) ls->opt.wave_front_bytes = (size_t)value;
   else return G2OHIP_ERR_ARG;
   return G2OHIP_OK;
 }

@@ -32,6 +32,8 @@ struct CholOptions {
   size_t lds_front_bytes = 64 * 1024;  // fronts up to this size are factorised in LDS
   bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task
   int rank = 0, world = 1;   // multi-GPU: this rank factorises its own subtrees + (redundantly) the shared top of the tree
+  int wave_front_tasks = 1024;           // launches at least this wide use two waves (128 threads) per front
+  size_t wave_front_bytes = 0;           // (unused)
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
 };
 
@@ -84,6 +86,7 @@ struct FrontRec {
 };
 
 struct CholPlanDev {
+  const int2* slots;                   // launch slot -> (first front id, chain length)
   const int *task_ptr, *task_fronts;   // task t = chain of fronts task_fronts[task_ptr[t] .. task_ptr[t+1])
   const FrontRec* rec;
   const ChildDesc* cdesc;
@@ -95,6 +98,7 @@ struct CholPlanDev {
   const int *asm_off, *asm_q, *asm_pos, *child_off, *children;
   double *L, *U, *w;
   int* status;
+  long long* dbg;   // G2OHIP_CHOL_STAMPS builds only: per-launch wall-clock stamps of workgroup 0
 };
 
 class SparseCholesky {
@@ -152,12 +156,16 @@ class SparseCholesky {
     int max_panel = 0;                                   // max m*npiv (doubles) for solve kernels
     int max_m = 0;
     int lds_idx_ints = 0, glb_idx_ints = 0;              // staged index lists (ints) per front, max over the launch
+    int sm_count = 0, sm_max_m = 0, sm_idx_ints = 0;     // leading part of the lds range: small fronts, one wave each
   };
   std::vector<LevelLaunch> launches_[2];   // [0] own tasks, [1] shared top-of-tree tasks
   struct SegCopy { long long a, b; int n, flags; };  // exchange segment: a = offset in U (or w: flag 2), b = offset in xbuf; flag 1 = mine
   DevBuf<SegCopy> d_xseg;
   DevBuf<double> d_xbuf, d_xmask;
+  DevBuf<long long> d_dbg;
+  DevBuf<int2> d_slots;
   int n_xseg_ = 0;
+  int dbg_launch_ = 0;
   size_t xbuf_count_ = 0;
   void launch_factor(const LevelLaunch& LL, const double* dA, hipStream_t st);
   void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st);

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <type_traits>
 
 namespace g2ohip {
 
@@ -607,10 +608,17 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       LevelLaunch& LL = launches_[ph][l];
       LL.lds_begin = (int)S.level_fronts.size();
       LL.lds_count = (int)lds[l].size();
-      for (int t : lds[l]) {
+      // wide launches run two waves per front (see front_factor_kernel); *_max_m = packed doubles of the largest front
+      if (opt.wave_front_tasks > 0 && LL.lds_count >= opt.wave_front_tasks) LL.sm_count = LL.lds_count;
+      for (int i = 0; i < (int)lds[l].size(); ++i) {
+        const int t = lds[l][i];
         S.level_fronts.push_back(t);
         scratch_off.push_back(0);
-        for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) LL.lds_max_m = std::max(LL.lds_max_m, (int)front_dim(S.task_fronts[k]));
+        int& mx = i < LL.sm_count ? LL.sm_max_m : LL.lds_max_m;
+        for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
+          const int nbt = S.f_ns[S.task_fronts[k]] + S.f_nb[S.task_fronts[k]];
+          mx = std::max(mx, nbt * (nbt + 1) / 2 * bs * bs);
+        }
       }
       LL.glb_begin = (int)S.level_fronts.size();
       LL.glb_count = (int)glb[l].size();
@@ -689,12 +697,13 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   }
   for (int ph = 0; ph < 2; ++ph)
   for (LevelLaunch& LL : launches_[ph]) {
-    LL.lds_idx_ints = LL.glb_idx_ints = 0;
+    LL.lds_idx_ints = LL.glb_idx_ints = LL.sm_idx_ints = 0;
     for (int q = LL.lds_begin; q < LL.glb_begin + LL.glb_count; ++q) {
       const int t = S.level_fronts[q];
       for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
         const FrontRec& R = recs[S.task_fronts[k]];
-        if (q < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt);
+        if (q < LL.lds_begin + LL.sm_count) LL.sm_idx_ints = std::max(LL.sm_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt);
+        else if (q < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt);
         else LL.glb_idx_ints = std::max(LL.glb_idx_ints, 2 * R.asm_cnt);
       }
     }
@@ -751,6 +760,17 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_child_off.upload(S.child_off, st);
   d_children.upload(S.children, st);
   d_level_fronts.upload(S.level_fronts, st);
+  {
+    std::vector<int2> slots(S.level_fronts.size());
+    for (size_t q = 0; q < slots.size(); ++q) {
+      const int t = S.level_fronts[q];
+      const int a = S.task_ptr[t], b = S.task_ptr[t + 1];
+      for (int k = a + 1; k < b; ++k)
+        if (S.task_fronts[k] != S.task_fronts[k - 1] + 1) throw StateFailure("symbolic: chain fronts are not consecutive");
+      slots[q] = make_int2(a < b ? S.task_fronts[a] : 0, b - a);
+    }
+    d_slots.upload(slots, st);
+  }
   d_perm.upload(S.perm, st);
   d_L_off.upload(S.L_off, st);
   d_U_off.upload(S.U_off, st);
@@ -791,6 +811,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.U = d_U.p;
   plan_.w = d_w.p;
   plan_.status = d_status.p;
+  plan_.dbg = nullptr;
+  plan_.slots = d_slots.p;
   analyzed_ = !host_only;
   stats_.t_symbolic = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -822,16 +844,27 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& r) {
 // front is the only child of the next one; the update matrix travels from front to front in
 // registers, only the last one of the chain is written to HBM.  A single-front task is the plain
 // multifrontal step.
-//   F: m x m column-major (ld = m), lower triangle used.  LDS or an HBM scratch slab.
+//   F: LDS-resident fronts are stored as packed lower-triangular BS x BS blocks (block (bi,bj), bi >= bj,
+//   at ((bi(bi+1)/2 + bj) * BS*BS, column-major inside): half the LDS of a dense square, so twice the
+//   fronts per CU.  Large fronts live in an HBM scratch slab as a dense m x m column-major matrix.
 // Per front: stage index tables, zero, assemble original blocks, extend-add the children's update
 // matrices, partial Cholesky of the ns pivot block columns (blocked by BS, look-ahead on the
 // diagonal factor), write the L panel (+ reciprocal diagonal) and hand over / store the update matrix.
 // Lower-triangular block/tile sets are enumerated ROW-major (idx = i(i+1)/2 + j): the enumeration
 // of an n x n triangle is a prefix of that of any larger one, so one table (P.tri) serves every size.
 // LDS: F | 2 diagonal-factor mailboxes | s_q[na] s_pos[na] s_cmap[cmap_cnt] s_tri[tri_cnt]
-template <int BS, bool USE_LDS>
-__global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGlobal, USE_LDS ? 3 : 1) front_factor_kernel(
-    CholPlanDev P, const int* __restrict__ tasks, const double* __restrict__ A, double* __restrict__ scratch,
+// NTC = workgroup size: 256, or 128 for the wide bottom levels (wave 0: look-ahead diagonal factor, wave 1:
+// trailing update -- the factorisation of a small front is a latency chain, so 6 two-wave workgroups per
+// CU beat 3 four-wave ones).
+template <int BS, bool USE_LDS, int NTC = (USE_LDS ? kFactorThreads : kFactorThreadsGlobal)>
+#ifndef G2OHIP_OCC256
+#define G2OHIP_OCC256 2
+#endif
+#ifndef G2OHIP_OCC128
+#define G2OHIP_OCC128 3
+#endif
+__global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G2OHIP_OCC256) : 1) front_factor_kernel(
+    CholPlanDev P, int slot0, const double* __restrict__ A, double* __restrict__ scratch,
     const long long* __restrict__ scratch_off, int idx_off_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int T = (BS % 3 == 0) ? 3 : BS;  // register tile edge of the trailing update
@@ -839,20 +872,43 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
   constexpr int UNR = 6;                     // independent global loads in flight per thread
   constexpr int LA = BS / T;                 // look-ahead span in tiles
   constexpr int NLA = LA * (LA + 1) / 2;
-  const int task = tasks[blockIdx.x];
-  const int t0 = P.task_ptr[task], t1 = P.task_ptr[task + 1];
+  // launch slot -> (first front, chain length): the fronts of a chain have consecutive ids (postorder)
+  const int2 slot = P.slots[slot0 + blockIdx.x];
+  const int f_first = __builtin_amdgcn_readfirstlane(slot.x), t1 = __builtin_amdgcn_readfirstlane(slot.y), t0 = 0;
   double* F = USE_LDS ? smem : (scratch + scratch_off[blockIdx.x]);
   double* sd = smem + idx_off_doubles - 2 * (BB + BS);   // two mailboxes: [L_kk (BB) | 1/diag (BS)]
   int* s_q = reinterpret_cast<int*>(smem + idx_off_doubles);
-  const int tid = threadIdx.x, NT = blockDim.x;
-  double ucarry[kChainU];   // update matrix of the previous chain front: packed element tid + u * NT
+  const int tid = threadIdx.x;
+  constexpr int NT = NTC;
+  constexpr int kCarry = kChainU * kFactorThreads / NTC;   // same carry capacity for every workgroup size
+  double ucarry[kCarry];    // update matrix of the previous chain front: packed element tid + u * NT
   int ncarry = 0;
+#ifdef G2OHIP_CHOL_STAMPS
+  int nstamp = 0;
+#define STAMP() do { if (P.dbg && blockIdx.x == 0 && tid == 0 && nstamp < 60) P.dbg[4 + nstamp++] = wall_clock64(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
 
   for (int ti = t0; ti < t1; ++ti) {
-    const int f = P.task_fronts[ti];
-    const FrontRec rec = P.rec[f];             // wave-uniform: scalar loads
+    const int f = f_first + ti;
+    // wave-uniform and never written by a kernel: constant address space => scalar (SMEM) loads
+    FrontRec rec;
+    {
+      typedef int __attribute__((may_alias)) alias_int;
+      const __attribute__((address_space(4))) int* rp =
+          (const __attribute__((address_space(4))) int*)reinterpret_cast<uintptr_t>(P.rec + f);
+      alias_int* ri = reinterpret_cast<alias_int*>(&rec);
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(FrontRec) / sizeof(int)); ++i) ri[i] = rp[i];
+    }
     const int ns = rec.ns, nbd = rec.nb;
-    const int m = (ns + nbd) * BS, npiv = ns * BS, ld = m;
+    const int nbt = ns + nbd;
+    const int m = nbt * BS, npiv = ns * BS, ld = m;
+    const int cs = USE_LDS ? BS : ld;   // column stride inside a block
+    auto blk_off = [&](int bi, int bj) { return USE_LDS ? (bi * (bi + 1) / 2 + bj) * BB : bi * BS + ld * (bj * BS); };
+    const int nF = USE_LDS ? nbt * (nbt + 1) / 2 * BB : m * m;
     const int na = rec.asm_cnt;
     int* s_pos = s_q + na;
     // LDS-resident fronts stage the child maps and the triangle table; scratch-slab (large) fronts
@@ -862,32 +918,78 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
     const int* s_cmap = USE_LDS ? s_cmap_l : (P.cmap + rec.cmap_off);
     const int* s_tri = USE_LDS ? s_tri_l : P.tri;
     const bool carried = ncarry > 0;            // the only child arrived through registers
+    // extend-add of up to N register-held elements per thread, branch-free: every LDS gather is issued
+    // before the first add (elements past the end go to a sink slot next to the mailboxes)
+    const int sink = idx_off_doubles - 2 * (BB + BS);   // LDS fronts: L part of mailbox 0 is unused
+    auto scatter_add = [&](const double* vals, auto N_, int count, int cmap_start) {
+      constexpr int N = decltype(N_)::value;
+      int dd[N];
+      double cur[N];
+#pragma unroll
+      for (int u = 0; u < N; ++u) {
+        const int t = tid + u * NT;
+        const bool ok = t < count;
+        const int tt = ok ? t : 0;
+        const int blk = tt / BB, e = tt - blk * BB;
+        const int d = s_cmap[cmap_start + blk];
+        dd[u] = ok ? blk_off(d & 0xffff, d >> 16) + e % BS + cs * (e / BS) : sink;
+      }
+#pragma unroll
+      for (int u = 0; u < N; ++u) cur[u] = F[dd[u]];
+#pragma unroll
+      for (int u = 0; u < N; ++u) F[dd[u]] = cur[u] + vals[u];
+    };
 
     // ---- issue the children's update-matrix loads first (fast path: <= 2 children that fit one round)
     const int nch = rec.child_cnt;
     const int nU0 = nch > 0 ? rec.ch[0].nbc * (rec.ch[0].nbc + 1) / 2 * BB : 0;
     const int nU1 = nch > 1 ? rec.ch[1].nbc * (rec.ch[1].nbc + 1) / 2 * BB : 0;
-    const bool fast_children = !carried && nch <= 2 && nU0 <= UNR * NT && nU1 <= UNR * NT;
-    double u0[UNR], u1[UNR];
-    if (fast_children) {
-      const double* U0 = P.U + rec.ch[0].U_off;
-      const double* U1 = P.U + rec.ch[1].U_off;
+#ifndef G2OHIP_UC
+#define G2OHIP_UC 12
+#endif
+    constexpr int UC = USE_LDS ? G2OHIP_UC : UNR;      // child elements in flight per thread and child
+    const bool fast_children = !carried && nch <= 2 && nU0 <= UC * NT && nU1 <= UC * NT;
+#ifdef G2OHIP_CHOL_STAMPS
+    if (P.dbg && blockIdx.x == 0 && tid == 0) { P.dbg[1] = nch; P.dbg[2] = nU0 * 10000LL + nU1; P.dbg[3] = fast_children; }
+#endif
+    // ---- stage the index tables in LDS, zero the front meanwhile.  The four tables are contiguous in LDS
+    // (q | pos | cmap | tri); all their loads are issued before the first wait: one memory round trip.
+    {
+      const int n1 = na, n2 = 2 * na, n3 = USE_LDS ? n2 + rec.cmap_cnt : n2, n4 = USE_LDS ? n3 + rec.tri_cnt : n2;
+      const int* g_q = P.asm_q + rec.asm_off;
+      const int* g_pos = P.asm_pos + rec.asm_off - n1;
+      const int* g_cmap = P.cmap + rec.cmap_off - n2;
+      const int* g_tri = P.tri - n3;
+      constexpr int SU = 4;
+      for (int base = tid; base < n4; base += SU * NT) {
+        int v[SU];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int t = tid + u * NT;
-        u0[u] = (t < nU0) ? U0[t] : 0.0;
-        u1[u] = (t < nU1) ? U1[t] : 0.0;
+        for (int u = 0; u < SU; ++u) {
+          const int i = base + u * NT;
+          const int* src = i < n1 ? g_q : (i < n2 ? g_pos : (i < n3 ? g_cmap : g_tri));
+          v[u] = (i < n4) ? src[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = base + u * NT;
+          if (i < n4) s_q[i] = v[u];
+        }
       }
     }
-    // ---- stage the index tables in LDS (independent loads), zero the front meanwhile
-    stage_copy<2>(s_q, P.asm_q + rec.asm_off, na, tid, NT);
-    stage_copy<2>(s_pos, P.asm_pos + rec.asm_off, na, tid, NT);
-    if (USE_LDS) {
-      stage_copy<2>(s_cmap_l, P.cmap + rec.cmap_off, rec.cmap_cnt, tid, NT);
-      stage_copy<2>(s_tri_l, P.tri, rec.tri_cnt, tid, NT);
-    }
-    for (int i = tid; i < m * m; i += NT) F[i] = 0.0;
+    for (int i = tid; i < nF; i += NT) F[i] = 0.0;
     __syncthreads();
+    STAMP();
+    // the children's update matrices share the memory round trip of the original entries (branch-free
+    // clamped loads so that all of them are in flight together)
+    double u0[UC];
+    if (fast_children) {
+      const double* U0 = P.U + rec.ch[0].U_off;
+#pragma unroll
+      for (int u = 0; u < UC; ++u) {
+        const int t = tid + u * NT;
+        u0[u] = U0[t < nU0 ? t : 0];
+      }
+    }
     // ---- original entries (each block lands on a distinct tile)
     {
       const int nA = na * BB;
@@ -905,7 +1007,7 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
             const int q = s_q[e], pos = s_pos[e];
             const int lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff, tr = (pos >> 30) & 1;
             v[u] = tr ? A[(size_t)q * BB + c + BS * r] : A[(size_t)q * BB + r + BS * c];
-            dst[u] = (lr * BS + r) + ld * (lc * BS + c);
+            dst[u] = blk_off(lr, lc) + r + cs * c;
           }
         }
 #pragma unroll
@@ -914,39 +1016,63 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
       }
     }
     __syncthreads();
+    STAMP();
     // ---- extend-add of the children (sequential over children: destinations may overlap).  Update
     // matrices are packed lower-triangular blocks (row-major block order); cmap gives, per packed
     // block, the destination block (row | col << 16) in this front.
     if (carried) {
+      if (USE_LDS) {
+        scatter_add(ucarry, std::integral_constant<int, kCarry>(), ncarry, rec.ch[0].cmap_start);
+      } else {
 #pragma unroll
-      for (int u = 0; u < kChainU; ++u) {
-        const int t = tid + u * NT;
-        if (t < ncarry) {
-          const int blk = t / BB, e = t - blk * BB;
-          const int d = s_cmap[rec.ch[0].cmap_start + blk];
-          F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += ucarry[u];
+        for (int u = 0; u < kCarry; ++u) {
+          const int t = tid + u * NT;
+          if (t < ncarry) {
+            const int blk = t / BB, e = t - blk * BB;
+            const int d = s_cmap[rec.ch[0].cmap_start + blk];
+            F[blk_off(d & 0xffff, d >> 16) + e % BS + cs * (e / BS)] += ucarry[u];
+          }
         }
       }
       __syncthreads();
     } else if (fast_children) {
+      // the second child's loads are issued before the first child is added (registers: both are live
+      // only here); the two children may hit the same destination blocks, hence the barrier between them
+      double u1[UC];
+      if (nch > 1) {
+        const double* U1 = P.U + rec.ch[1].U_off;
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int t = tid + u * NT;
-        if (t < nU0) {
-          const int blk = t / BB, e = t - blk * BB;
-          const int d = s_cmap[rec.ch[0].cmap_start + blk];
-          F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += u0[u];
+        for (int u = 0; u < UC; ++u) {
+          const int t = tid + u * NT;
+          u1[u] = U1[t < nU1 ? t : 0];
         }
       }
-      if (nch > 1) {
-        __syncthreads();
+      if (USE_LDS) {
+        scatter_add(u0, std::integral_constant<int, UC>(), nU0, rec.ch[0].cmap_start);
+        if (nch > 1) {
+          __syncthreads();
+          scatter_add(u1, std::integral_constant<int, UC>(), nU1, rec.ch[1].cmap_start);
+        }
+      } else {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < UC; ++u) {
           const int t = tid + u * NT;
-          if (t < nU1) {
+          if (t < nU0) {
             const int blk = t / BB, e = t - blk * BB;
-            const int d = s_cmap[rec.ch[1].cmap_start + blk];
-            F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += u1[u];
+            const int d = s_cmap[rec.ch[0].cmap_start + blk];
+            F[blk_off(d & 0xffff, d >> 16) + e % BS + cs * (e / BS)] += u0[u];
+          }
+        }
+        if (nch > 1) {
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < UC; ++u) {
+            const int t = tid + u * NT;
+            if (t < nU1) {
+              const int blk = t / BB, e = t - blk * BB;
+              const int d = s_cmap[rec.ch[1].cmap_start + blk];
+              F[blk_off(d & 0xffff, d >> 16) + e % BS + cs * (e / BS)] += u1[u];
+            }
           }
         }
       }
@@ -970,7 +1096,7 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
             if (t < nU) {
               const int blk = t / BB, e = t - blk * BB;
               const int d = cmap[blk];
-              F[((d & 0xffff) * BS + e % BS) + ld * ((d >> 16) * BS + e / BS)] += v[u];
+              F[blk_off(d & 0xffff, d >> 16) + e % BS + cs * (e / BS)] += v[u];
             }
           }
         }
@@ -981,13 +1107,14 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
     // The BS x BS diagonal factor is a long dependent chain (rsqrt, scale, update x BS); it is kept off
     // the critical path by look-ahead: while waves 1.. apply the trailing update of step kb, wave 0
     // updates only the NEXT diagonal block and factorises it into a small LDS mailbox (sd).
+    STAMP();
     auto diag_factor = [&](int kb_, double* box) {                        // executed by every lane of wave 0
-      const int k0_ = kb_ * BS;
+      double* Fd = F + blk_off(kb_, kb_);
       double Lk[BS][BS], inv[BS];
 #pragma unroll
       for (int c = 0; c < BS; ++c)
 #pragma unroll
-        for (int r = 0; r < BS; ++r) Lk[r][c] = (r >= c) ? F[(k0_ + r) + (size_t)ld * (k0_ + c)] : 0.0;
+        for (int r = 0; r < BS; ++r) Lk[r][c] = (r >= c) ? Fd[r + cs * c] : 0.0;
       bool bad = false;
 #pragma unroll
       for (int c = 0; c < BS; ++c) {
@@ -1007,15 +1134,16 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
 #pragma unroll
           for (int i = j; i < BS; ++i) Lk[i][j] -= Lk[i][c] * Lk[j][c];
       }
+      // publish: the packed LDS layout keeps the diagonal block contiguous, so it is its own mailbox
+      // (only 1/diag goes to the box); the dense HBM layout needs the LDS copy
       if (tid == 0) {
         if (bad) *P.status = 1;
 #pragma unroll
         for (int c = 0; c < BS; ++c) {
 #pragma unroll
-          for (int r = 0; r < BS; ++r) {
-            const double v = (r >= c) ? Lk[r][c] : 0.0;
-            box[r + BS * c] = v;
-            F[(k0_ + r) + (size_t)ld * (k0_ + c)] = v;   // final L_kk for the panel store
+          for (int r = c; r < BS; ++r) {
+            if (!USE_LDS) box[r + BS * c] = Lk[r][c];
+            Fd[r + cs * c] = Lk[r][c];   // final L_kk (the part above the diagonal stays zero)
           }
           box[BB + c] = inv[c];
         }
@@ -1025,21 +1153,24 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
       if (tid < 64) diag_factor(0, sd);
       __syncthreads();
     }
+    STAMP();
     for (int kb = 0; kb < ns; ++kb) {
       const int k0 = kb * BS;
       const double* box = sd + (kb & 1) * (BB + BS);
+      const double* Lb = USE_LDS ? F + blk_off(kb, kb) : box;   // column stride BS either way
       double Lk[BS][BS], inv[BS];
 #pragma unroll
       for (int c = 0; c < BS; ++c) {
         inv[c] = box[BB + c];
 #pragma unroll
-        for (int r = 0; r < BS; ++r) Lk[r][c] = (r > c) ? box[r + BS * c] : 0.0;
+        for (int r = 0; r < BS; ++r) Lk[r][c] = (r > c) ? Lb[r + BS * c] : 0.0;
       }
       // rows below the diagonal block: x * Lkk' = row
       for (int i = k0 + BS + tid; i < m; i += NT) {
         double x[BS];
+        double* Fr = F + blk_off(i / BS, kb) + i % BS;
 #pragma unroll
-        for (int c = 0; c < BS; ++c) x[c] = F[i + (size_t)ld * (k0 + c)];
+        for (int c = 0; c < BS; ++c) x[c] = Fr[cs * c];
 #pragma unroll
         for (int c = 0; c < BS; ++c) {
           double v = x[c];
@@ -1048,9 +1179,11 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
           x[c] = v * inv[c];
         }
 #pragma unroll
-        for (int c = 0; c < BS; ++c) F[i + (size_t)ld * (k0 + c)] = x[c];
+        for (int c = 0; c < BS; ++c) Fr[cs * c] = x[c];
       }
+      if (kb < 2) STAMP();
       __syncthreads();
+      if (kb < 2) STAMP();
       // trailing update with T x T register tiles over the lower triangle (tile coordinates relative
       // to the first trailing row; the first LA(LA+1)/2 table entries are the next diagonal block)
       const int r0 = k0 + BS;
@@ -1058,55 +1191,73 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
       const int ntiles = nt * (nt + 1) / 2;
       const bool lookahead = (kb + 1 < ns) && NT > 64;
       auto update_tile = [&](int packed) {
-        const int i0 = r0 + (packed & 0xffff) * T, j0 = r0 + (packed >> 16) * T;
-        double cv[T][T];
-#pragma unroll
-        for (int b = 0; b < T; ++b)
-#pragma unroll
-          for (int a = 0; a < T; ++a) cv[a][b] = F[(i0 + a) + (size_t)ld * (j0 + b)];
+        const int ti = packed & 0xffff, tj = packed >> 16;   // tile coordinates relative to the first trailing row
+        const int bi = kb + 1 + ti / LA, bj = kb + 1 + tj / LA, ia = (ti % LA) * T, ja = (tj % LA) * T;
+        double* Fc = F + blk_off(bi, bj) + ia + cs * ja;
+        const double* Fa = F + blk_off(bi, kb) + ia;
+        const double* Fb = F + blk_off(bj, kb) + ja;
+        double cv[T][T], av[BS][T], bv[BS][T];   // all operands first: one LDS latency per tile, not one per q
 #pragma unroll
         for (int q = 0; q < BS; ++q) {
-          double av[T], bv[T];
 #pragma unroll
-          for (int a = 0; a < T; ++a) av[a] = F[(i0 + a) + (size_t)ld * (k0 + q)];
+          for (int a = 0; a < T; ++a) av[q][a] = Fa[a + cs * q];
 #pragma unroll
-          for (int b = 0; b < T; ++b) bv[b] = F[(j0 + b) + (size_t)ld * (k0 + q)];
-#pragma unroll
-          for (int a = 0; a < T; ++a)
-#pragma unroll
-            for (int b = 0; b < T; ++b) cv[a][b] -= av[a] * bv[b];
+          for (int b = 0; b < T; ++b) bv[q][b] = Fb[b + cs * q];
         }
 #pragma unroll
         for (int b = 0; b < T; ++b)
 #pragma unroll
-          for (int a = 0; a < T; ++a) F[(i0 + a) + (size_t)ld * (j0 + b)] = cv[a][b];
+          for (int a = 0; a < T; ++a) cv[a][b] = Fc[a + cs * b];
+#pragma unroll
+        for (int q = 0; q < BS; ++q)
+#pragma unroll
+          for (int a = 0; a < T; ++a)
+#pragma unroll
+            for (int b = 0; b < T; ++b) cv[a][b] -= av[q][a] * bv[q][b];
+#pragma unroll
+        for (int b = 0; b < T; ++b)
+#pragma unroll
+          for (int a = 0; a < T; ++a) Fc[a + cs * b] = cv[a][b];
       };
       if (lookahead && tid < 64) {
         if (tid < NLA) update_tile(s_tri[tid]);
         __threadfence_block();   // the wave's own LDS writes are complete before it re-reads the block
+        if (kb < 2) STAMP();
         diag_factor(kb + 1, sd + ((kb + 1) & 1) * (BB + BS));
+        if (kb < 2) STAMP();
       } else {
         const int first = lookahead ? NLA + tid - 64 : tid, stride = lookahead ? NT - 64 : NT;
         for (int idx = first; idx < ntiles; idx += stride) update_tile(s_tri[idx]);
       }
       __syncthreads();
+      STAMP();
     }
     // ---- write the L panel (m x npiv) and the reciprocals of its diagonal
     double* Lg = P.L + rec.L_off;
-    for (int t = tid; t < m * npiv; t += NT) Lg[t] = F[t];  // ld == m: identical layout
-    for (int k = tid; k < npiv; k += NT) Lg[(size_t)m * npiv + k] = 1.0 / F[k + (size_t)ld * k];
+    if (USE_LDS) {   // m x npiv column-major panel out of the packed blocks (blocks above the diagonal are zero)
+      const float invm = 1.0f / (float)m;
+      for (int t = tid; t < m * npiv; t += NT) {
+        const int c = (int)(((float)t + 0.5f) * invm), r = t - c * m;
+        const int bi = r / BS, bj = c / BS;
+        Lg[t] = (bi >= bj) ? F[blk_off(bi, bj) + r % BS + BS * (c % BS)] : 0.0;
+      }
+    } else {
+      for (int t = tid; t < m * npiv; t += NT) Lg[t] = F[t];  // ld == m: identical layout
+    }
+    for (int k = tid; k < npiv; k += NT) Lg[(size_t)m * npiv + k] = 1.0 / F[blk_off(k / BS, k / BS) + (k % BS) * (1 + cs)];
     // ---- update matrix (packed lower-triangular blocks, row-major): to the next chain front through
     // registers, or to HBM for a parent in a later launch
+    STAMP();
     const int nU = nbd * (nbd + 1) / 2 * BB;
     if (ti + 1 < t1) {
       ncarry = nU;
 #pragma unroll
-      for (int u = 0; u < kChainU; ++u) {
+      for (int u = 0; u < kCarry; ++u) {
         const int t = tid + u * NT;
         if (t < nU) {
           const int blk = t / BB, e = t - blk * BB;
           const int d = s_tri[blk];
-          ucarry[u] = F[(npiv + (d & 0xffff) * BS + e % BS) + ld * (npiv + (d >> 16) * BS + e / BS)];
+          ucarry[u] = F[blk_off(ns + (d & 0xffff), ns + (d >> 16)) + e % BS + cs * (e / BS)];
         }
       }
     } else {
@@ -1115,11 +1266,20 @@ __global__ void __launch_bounds__(USE_LDS ? kFactorThreads : kFactorThreadsGloba
       for (int t = tid; t < nU; t += NT) {
         const int blk = t / BB, e = t - blk * BB;
         const int d = s_tri[blk];
-        Ug[t] = F[(npiv + (d & 0xffff) * BS + e % BS) + ld * (npiv + (d >> 16) * BS + e / BS)];
+        Ug[t] = F[blk_off(ns + (d & 0xffff), ns + (d >> 16)) + e % BS + cs * (e / BS)];
       }
     }
     __syncthreads();   // F and the LDS tables are reused by the next front of the chain
+    STAMP();
+#ifdef G2OHIP_CHOL_STAMPS
+    if (P.dbg && blockIdx.x == 0 && tid == 0 && nstamp < 58) {
+      P.dbg[4 + nstamp++] = -(long long)(ns * 1000 + m);   // front marker
+    }
+#endif
   }
+#ifdef G2OHIP_CHOL_STAMPS
+  if (P.dbg && blockIdx.x == 0 && tid == 0) P.dbg[0] = nstamp;
+#endif
 }
 
 // b_perm[new*bs + r] = b[old*bs + r]
@@ -1353,36 +1513,49 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
 template <int BS>
 void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long long* d_scratch_off, double* d_scratch,
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
-                         int lds_idx_ints, int glb_idx_ints, hipStream_t st) {
+                         int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, hipStream_t st) {
+  if (sm_count > 0) {   // wide launch: two waves per front
+    const int idx_off = sm_max_m + 2 * (BS * BS + BS);
+    size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(sm_idx_ints + 4) * sizeof(int);
+    hipLaunchKernelGGL((front_factor_kernel<BS, true, 128>), dim3(sm_count), dim3(128), sh, st, P, lds_begin, dA, d_scratch,
+                       d_scratch_off + lds_begin, idx_off);
+    lds_begin += sm_count;
+    lds_count -= sm_count;
+  }
   if (lds_count > 0) {
-    const int idx_off = lds_max_m * lds_max_m + 2 * (BS * BS + BS);   // F | diagonal-factor mailboxes | index lists
+    const int idx_off = lds_max_m + 2 * (BS * BS + BS);   // F (packed doubles) | diagonal-factor mailboxes | index lists
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(lds_idx_ints + 4) * sizeof(int);
-    hipLaunchKernelGGL((front_factor_kernel<BS, true>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, d_tasks + lds_begin,
-                       dA, d_scratch, d_scratch_off + lds_begin, idx_off);
+    hipLaunchKernelGGL((front_factor_kernel<BS, true>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
+                       d_scratch_off + lds_begin, idx_off);
   }
   if (glb_count > 0) {
     const int idx_off = 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(glb_idx_ints + 4) * sizeof(int);
-    hipLaunchKernelGGL((front_factor_kernel<BS, false>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P,
-                       d_tasks + glb_begin, dA, d_scratch, d_scratch_off + glb_begin, idx_off);
+    hipLaunchKernelGGL((front_factor_kernel<BS, false>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P, glb_begin, dA,
+                       d_scratch, d_scratch_off + glb_begin, idx_off);
   }
 }
 
 }  // namespace
 
 void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, hipStream_t st) {
+#ifdef G2OHIP_CHOL_STAMPS
+  if (d_dbg.p) {
+    plan_.dbg = d_dbg.p + 64 * (dbg_launch_++ % 64);
+  }
+#endif
   switch (bs_) {
     case 3:
       launch_factor_level<3>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
+                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, st);
       break;
     case 6:
       launch_factor_level<6>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
+                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, st);
       break;
     case 7:
       launch_factor_level<7>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, st);
+                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, st);
       break;
     default:
       throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
@@ -1397,9 +1570,19 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (phase == 0) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
+#ifdef G2OHIP_CHOL_STAMPS
+  if (phase == 0) {
+    if (!d_dbg.p) d_dbg.alloc(64 * 64);
+    G2OHIP_HIP_CHECK(hipMemsetAsync(d_dbg.p, 0, 64 * 64 * sizeof(long long), st));
+    dbg_launch_ = 0;
+  }
+#endif
   for (const LevelLaunch& LL : launches_[phase]) launch_factor(LL, dA, st);
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
@@ -1485,6 +1668,23 @@ void SparseCholesky::mask_solution(hipStream_t st) {
 }
 
 bool SparseCholesky::failed(hipStream_t st) {
+#ifdef G2OHIP_CHOL_STAMPS
+  if (d_dbg.p && getenv("G2OHIP_CHOL_STAMPS_PRINT")) {
+    std::vector<long long> h(64 * 64);
+    d_dbg.download(h.data(), h.size(), st);
+    for (int l = 0; l < dbg_launch_ && l < 64; ++l) {
+      const long long* s = h.data() + 64 * l;
+      fprintf(stderr, "launch %2d: (nch %lld nU %lld fast %lld)", l, s[1], s[2], s[3]);
+      long long prev = s[4];
+      for (int k = 1; k < (int)s[0]; ++k) {
+        if (s[4 + k] < 0) { fprintf(stderr, " [ns=%lld m=%lld]", -s[4 + k] / 1000, -s[4 + k] % 1000); continue; }
+        fprintf(stderr, " %.2f", (s[4 + k] - prev) * 0.01);
+        prev = s[4 + k];
+      }
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   int h = 0;
   d_status.download(&h, 1, st);
   return h != 0;
