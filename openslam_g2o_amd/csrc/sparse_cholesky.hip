@@ -923,21 +923,25 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
     const int sink = idx_off_doubles - 2 * (BB + BS);   // LDS fronts: L part of mailbox 0 is unused
     auto scatter_add = [&](const double* vals, auto N_, int count, int cmap_start) {
       constexpr int N = decltype(N_)::value;
-      int dd[N];
-      double cur[N];
+      constexpr int CH = (N % 6 == 0) ? 6 : N;   // chunked: bounds the registers held at once
 #pragma unroll
-      for (int u = 0; u < N; ++u) {
-        const int t = tid + u * NT;
-        const bool ok = t < count;
-        const int tt = ok ? t : 0;
-        const int blk = tt / BB, e = tt - blk * BB;
-        const int d = s_cmap[cmap_start + blk];
-        dd[u] = ok ? blk_off(d & 0xffff, d >> 16) + e % BS + cs * (e / BS) : sink;
+      for (int h = 0; h < N; h += CH) {
+        int dd[CH];
+        double cur[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int t = tid + (h + u) * NT;
+          const bool ok = t < count;
+          const int tt = ok ? t : 0;
+          const int blk = tt / BB, e = tt - blk * BB;
+          const int d = s_cmap[cmap_start + blk];
+          dd[u] = ok ? blk_off(d & 0xffff, d >> 16) + e % BS + cs * (e / BS) : sink;
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) cur[u] = F[dd[u]];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) F[dd[u]] = cur[u] + vals[h + u];
       }
-#pragma unroll
-      for (int u = 0; u < N; ++u) cur[u] = F[dd[u]];
-#pragma unroll
-      for (int u = 0; u < N; ++u) F[dd[u]] = cur[u] + vals[u];
     };
 
     // ---- issue the children's update-matrix loads first (fast path: <= 2 children that fit one round)
@@ -1038,20 +1042,30 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
     } else if (fast_children) {
       // the second child's loads are issued before the first child is added (registers: both are live
       // only here); the two children may hit the same destination blocks, hence the barrier between them
-      double u1[UC];
-      if (nch > 1) {
+      // (two-wave variant: registers are scarce and the launch is wide -- one child at a time, reusing u0)
+      constexpr bool DUAL = NTC != 128;
+      double u1[DUAL ? UC : 1];
+      if (DUAL && nch > 1) {
         const double* U1 = P.U + rec.ch[1].U_off;
 #pragma unroll
         for (int u = 0; u < UC; ++u) {
           const int t = tid + u * NT;
-          u1[u] = U1[t < nU1 ? t : 0];
+          u1[DUAL ? u : 0] = U1[t < nU1 ? t : 0];
         }
       }
       if (USE_LDS) {
         scatter_add(u0, std::integral_constant<int, UC>(), nU0, rec.ch[0].cmap_start);
         if (nch > 1) {
+          if (!DUAL) {
+            const double* U1 = P.U + rec.ch[1].U_off;
+#pragma unroll
+            for (int u = 0; u < UC; ++u) {
+              const int t = tid + u * NT;
+              u0[u] = U1[t < nU1 ? t : 0];
+            }
+          }
           __syncthreads();
-          scatter_add(u1, std::integral_constant<int, UC>(), nU1, rec.ch[1].cmap_start);
+          scatter_add(DUAL ? u1 : u0, std::integral_constant<int, UC>(), nU1, rec.ch[1].cmap_start);
         }
       } else {
 #pragma unroll
@@ -1262,6 +1276,8 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       }
     } else {
       ncarry = 0;
+#pragma unroll
+      for (int u = 0; u < kCarry; ++u) ucarry[u] = 0.0;   // ends the live range: no registers held across the next front
       double* Ug = P.U + rec.U_off;
       for (int t = tid; t < nU; t += NT) {
         const int blk = t / BB, e = t - blk * BB;
