@@ -82,7 +82,7 @@ struct FrontRec {
   int ns, nb, c0, asm_off, asm_cnt, child_off, child_cnt, crel_off, crel_cnt, cmap_off, cmap_cnt, tri_cnt;
   long long L_off, U_off;
   ChildDesc ch[2];
-  int pad[4];
+  int rows_off, w_off, pad[2];   // boundary row list; update vector in the solve workspace
 };
 
 struct CholPlanDev {

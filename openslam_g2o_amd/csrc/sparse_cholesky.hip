@@ -666,6 +666,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     R.crel_off = (int)crel.size();
     R.cmap_off = (int)cmap.size();
     R.L_off = S.L_off[f];
+    R.rows_off = S.rows_off[f];
+    if (S.w_off[f] > 0x7fffffffLL) throw StateFailure("symbolic: solve workspace exceeds 2^31 doubles");
+    R.w_off = (int)S.w_off[f];
     R.U_off = S.U_off[f];
     for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) {
       int c = S.children[ch];
@@ -840,6 +843,18 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& r) {
   r = h + h;
 }
 
+// Front record through the constant address space: wave-uniform and never written by a kernel => scalar
+// (SMEM) loads instead of a vector load per lane.
+__device__ __forceinline__ FrontRec load_front_rec(const FrontRec* p) {
+  FrontRec rec;
+  typedef int __attribute__((may_alias)) alias_int;
+  const __attribute__((address_space(4))) int* rp = (const __attribute__((address_space(4))) int*)reinterpret_cast<uintptr_t>(p);
+  alias_int* ri = reinterpret_cast<alias_int*>(&rec);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(FrontRec) / sizeof(int)); ++i) ri[i] = rp[i];
+  return rec;
+}
+
 // One workgroup factorises one TASK = a chain of frontal matrices f1 -> f2 -> ... in which every
 // front is the only child of the next one; the update matrix travels from front to front in
 // registers, only the last one of the chain is written to HBM.  A single-front task is the plain
@@ -894,15 +909,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
   for (int ti = t0; ti < t1; ++ti) {
     const int f = f_first + ti;
     // wave-uniform and never written by a kernel: constant address space => scalar (SMEM) loads
-    FrontRec rec;
-    {
-      typedef int __attribute__((may_alias)) alias_int;
-      const __attribute__((address_space(4))) int* rp =
-          (const __attribute__((address_space(4))) int*)reinterpret_cast<uintptr_t>(P.rec + f);
-      alias_int* ri = reinterpret_cast<alias_int*>(&rec);
-#pragma unroll
-      for (int i = 0; i < (int)(sizeof(FrontRec) / sizeof(int)); ++i) ri[i] = rp[i];
-    }
+    const FrontRec rec = load_front_rec(P.rec + f);
     const int ns = rec.ns, nbd = rec.nb;
     const int nbt = ns + nbd;
     const int m = nbt * BS, npiv = ns * BS, ld = m;
@@ -1319,12 +1326,12 @@ __global__ void permute_out_kernel(int nb, int bs, const int* __restrict__ perm,
 // block.  Inside a chain the update vector w stays in LDS.
 // LDS: [panel (optional)] [t: mcap] [ys: mcap] [wprev: mcap]
 template <int BS, bool PANEL_LDS>
-__global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const int* __restrict__ tasks,
+__global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, int slot0,
                                                            const double* __restrict__ bperm, double* __restrict__ y, int panel_cap,
                                                            int mcap) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int task = tasks[blockIdx.x];
-  const int t0 = P.task_ptr[task], t1 = P.task_ptr[task + 1];
+  const int2 slot = P.slots[slot0 + blockIdx.x];
+  const int f_first = __builtin_amdgcn_readfirstlane(slot.x), t0 = 0, t1 = __builtin_amdgcn_readfirstlane(slot.y);
   const int tid = threadIdx.x, NT = blockDim.x;
   double* Lp = smem;
   double* t = smem + (PANEL_LDS ? panel_cap : 0);
@@ -1332,16 +1339,17 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const
   double* wprev = ys + mcap;
   int nprev = 0;
   for (int ti = t0; ti < t1; ++ti) {
-    const int f = P.task_fronts[ti];
-    const FrontRec rec = P.rec[f];
+    const int f = f_first + ti;
+    const FrontRec rec = load_front_rec(P.rec + f);
     const int ns = rec.ns, nbd = rec.nb;
     const int m = (ns + nbd) * BS, npiv = ns * BS, c0 = rec.c0;
     const double* Lg = P.L + rec.L_off;
-    if (PANEL_LDS) stage_copy<8>(Lp, Lg, m * npiv + npiv, tid, NT);
     const double* Lx = PANEL_LDS ? Lp : Lg;
     const double* Linv = Lx + (size_t)m * npiv;
-    // children's update vectors: issue the loads before the first barrier (fast path: <= 2 children
-    // whose boundary fits one round), apply them one child at a time (rows may coincide)
+    // Everything this front reads from memory is requested before the first wait (one round trip): the
+    // right-hand side, the children's update vectors (fast path: <= 2 children whose boundary fits one
+    // round; applied one child at a time, rows may coincide) and the L panel.
+    const double bfirst = (tid < npiv) ? bperm[(size_t)c0 * BS + tid] : 0.0;
     const bool carried = nprev > 0;
     const int nch = rec.child_cnt;
     const int n0 = nch > 0 ? rec.ch[0].nbc * BS : 0, n1 = nch > 1 ? rec.ch[1].nbc * BS : 0;
@@ -1358,7 +1366,9 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const
         d1 = P.crel[rec.crel_off + rec.ch[1].crel_start + tid / BS] * BS + tid % BS;
       }
     }
-    for (int i = tid; i < m; i += NT) t[i] = (i < npiv) ? bperm[(size_t)c0 * BS + i] : 0.0;
+    if (PANEL_LDS) stage_copy<16>(Lp, Lg, m * npiv + npiv, tid, NT);
+    if (tid < m) t[tid] = bfirst;
+    for (int i = tid + NT; i < m; i += NT) t[i] = (i < npiv) ? bperm[(size_t)c0 * BS + i] : 0.0;
     __syncthreads();
     if (fast_children) {
       if (tid < n0) t[d0] += carried ? wprev[tid] : w0;
@@ -1405,7 +1415,7 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const
       for (int i = tid; i < nprev; i += NT) wprev[i] = t[npiv + i];
     } else {
       nprev = 0;
-      double* wf = P.w + P.w_off[f];
+      double* wf = P.w + rec.w_off;
       for (int i = tid; i < nbd * BS; i += NT) wf[i] = t[npiv + i];
     }
     __syncthreads();
@@ -1416,12 +1426,12 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, const
 // Inside a chain the child's boundary values are taken from the parent's vector kept in LDS.
 // LDS: [panel (optional)] [t: mcap] [xs: mcap] [sp: NT] [fullprev: mcap]
 template <int BS, bool PANEL_LDS>
-__global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, const int* __restrict__ tasks,
+__global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int slot0,
                                                             const double* __restrict__ y, double* __restrict__ xp, int panel_cap,
                                                             int mcap) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int task = tasks[blockIdx.x];
-  const int t0 = P.task_ptr[task], t1 = P.task_ptr[task + 1];
+  const int2 slot = P.slots[slot0 + blockIdx.x];
+  const int f_first = __builtin_amdgcn_readfirstlane(slot.x), t0 = 0, t1 = __builtin_amdgcn_readfirstlane(slot.y);
   const int tid = threadIdx.x, NT = blockDim.x;
   double* Lp = smem;
   double* t = smem + (PANEL_LDS ? panel_cap : 0);
@@ -1430,21 +1440,28 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, cons
   double* fullprev = sp + NT;
   const int* prel = nullptr;   // this front's relative indices inside its chain parent
   for (int ti = t1 - 1; ti >= t0; --ti) {
-    const int f = P.task_fronts[ti];
-    const FrontRec rec = P.rec[f];
+    const int f = f_first + ti;
+    const FrontRec rec = load_front_rec(P.rec + f);
     const int ns = rec.ns, nbd = rec.nb;
     const int m = (ns + nbd) * BS, npiv = ns * BS, c0 = rec.c0;
     const double* Lg = P.L + rec.L_off;
-    if (PANEL_LDS) stage_copy<8>(Lp, Lg, m * npiv + npiv, tid, NT);
     const double* Lx = PANEL_LDS ? Lp : Lg;
     const double* Linv = Lx + (size_t)m * npiv;
-    if (prel) {
-      for (int i = tid; i < m; i += NT)
-        t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : fullprev[prel[(i - npiv) / BS] * BS + ((i - npiv) % BS)];
-    } else {
-      const int* rows = P.rows + P.rows_off[f];
-      for (int i = tid; i < m; i += NT)
-        t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : xp[(size_t)rows[(i - npiv) / BS] * BS + ((i - npiv) % BS)];
+    // request the pivot part of y and the boundary row indices (then the boundary values, one dependent
+    // round trip) before the panel, so that the panel's round trip covers them
+    {
+      const int* relp = prel ? prel : P.rows + rec.rows_off;
+      const bool bnd = tid >= npiv && tid < m;
+      const double yfirst = (tid < npiv) ? y[(size_t)c0 * BS + tid] : 0.0;
+      const int rfirst = bnd ? relp[(tid - npiv) / BS] * BS + (tid - npiv) % BS : 0;
+      double xfirst = 0.0;
+      if (bnd && !prel) xfirst = xp[rfirst];
+      if (PANEL_LDS) stage_copy<16>(Lp, Lg, m * npiv + npiv, tid, NT);
+      if (tid < m) t[tid] = (tid < npiv) ? yfirst : (prel ? fullprev[rfirst] : xfirst);
+      for (int i = tid + NT; i < m; i += NT) {
+        const int r = relp[(i - npiv) / BS] * BS + (i - npiv) % BS;   // (i >= NT >= npiv here unless npiv > NT)
+        t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : (prel ? fullprev[r] : xp[r]);
+      }
     }
     __syncthreads();
     // boundary contribution t[k] -= sum_{i>=npiv} L[i,k] t[i]: (k, part) decomposition + LDS reduction
@@ -1612,7 +1629,6 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
   const size_t panel_limit = 48 * 1024;  // bytes of L panel staged in LDS
   int count = LL.lds_count + LL.glb_count;
   if (count == 0) return;
-  const int* fl = d_level_fronts.p + LL.lds_begin;
   bool panel = (size_t)LL.max_panel * 8 <= panel_limit;
   int cap = panel ? LL.max_panel : 0;
   int nthreads = LL.max_m <= 64 ? 64 : (LL.max_m <= 128 ? 128 : 256);
@@ -1620,14 +1636,14 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
 #define G2OHIP_SOLVE_LAUNCH(BS_)                                                                                              \
   if (fwd) {                                                                                                                  \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_xp.p, d_y.p, cap, LL.max_m);  \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, LL.lds_begin, d_xp.p, d_y.p, cap, LL.max_m);  \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_xp.p, d_y.p, cap, LL.max_m); \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, LL.lds_begin, d_xp.p, d_y.p, cap, LL.max_m); \
   } else {                                                                                                                    \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_y.p, d_xp.p, cap, LL.max_m); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, LL.lds_begin, d_y.p, d_xp.p, cap, LL.max_m); \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, fl, d_y.p, d_xp.p, cap, LL.max_m); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, LL.lds_begin, d_y.p, d_xp.p, cap, LL.max_m); \
   }
   switch (bs_) {
     case 3: G2OHIP_SOLVE_LAUNCH(3) break;
