@@ -403,10 +403,9 @@ __global__ void __launch_bounds__(kThreads) schur_tile_kernel(const int* __restr
   long long* dbgp = (dbg && blockIdx.x == 1000 && threadIdx.x == 0) ? dbg : nullptr;
   if (dbgp) dbgp[0] = wall_clock64();
   const int t = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int l0 = tile_lm0[t], l1 = tile_lm0[t + 1];
-  const int q0 = pl_colptr[l0], nslots = pl_colptr[l1] - q0, nlm = l1 - l0;
-  const int td0 = tile_td0[t], td1 = tile_td0[t + 1];
-  const int e0 = td_ptr[td0], ne = td_ptr[td1] - e0;
+  const int* tm = tile_lm0 + (size_t)t * 8;   // packed tile record (see build_structure)
+  const int l0 = tm[0], l1 = tm[1], q0 = tm[2], nslots = tm[3], nlm = l1 - l0;
+  const int td0 = tm[4], td1 = tm[5], e0 = tm[6], ne = tm[7];
   double* Bs = smem;
   double* Ds = Bs + ((nslots * PL + 1) & ~1);
   double* bsm = Ds + ((nlm * LD * LD + 1) & ~1);
@@ -479,66 +478,86 @@ __global__ void __launch_bounds__(kThreads) schur_tile_kernel(const int* __restr
   }
   __syncthreads();
   if (dbgp) dbgp[1] = wall_clock64();
+  // G lanes per destination block = GC column parts x GE entry parts: a lane owns PD/GC columns of the
+  // block (PD*PD/GC accumulator registers instead of PD*PD: what keeps 3 workgroups on a CU) and walks
+  // every GE-th entry; the GE partial sums are combined with DPP (fixed order: deterministic).
+  constexpr int GC = (PD % 2 == 0 && G >= 2) ? 2 : 1, GE = G / GC, NC = PD / GC;
+  static_assert(GE == 1 || GE == 2 || GE == 4 || GE == 8 || (GC == 1 && GE == 16), "unsupported lane group");
+  auto ge_sum = [](double v) {   // sum over the GE lanes that share gc
+    if (GC == 1) return group_sum<GE>(v);
+    v += dpp_permute<0x4E>(v);                                       // lane ^ 2
+    if (GE >= 4) v += dpp_permute<0x141>(dpp_permute<0x1B>(v));      // lane ^ 4 = (lane ^ 3) ^ 7
+    if (GE >= 8) v += dpp_permute<0x128>(v);                         // row_ror:8 = lane ^ 8 inside a 16-lane row
+    return v;
+  };
   const int grp = tid / G, g = tid % G, ngroups = NT / G;
+  const int gc = g % GC, ge = g / GC;
   int dk = 2;
   for (int ld = td0 + grp; ld < td1; ld += ngroups) {
-    double acc[PD * PD], cacc[PD];
+    double acc[PD * NC], cacc[PD];
 #pragma unroll
-    for (int i = 0; i < PD * PD; ++i) acc[i] = 0.0;
+    for (int i = 0; i < PD * NC; ++i) acc[i] = 0.0;
 #pragma unroll
     for (int r = 0; r < PD; ++r) cacc[r] = 0.0;
     const bool diag = ddiag[ld - td0] != 0;
     const int k0 = dptr[ld - td0] - e0, k1 = dptr[ld - td0 + 1] - e0;
-    for (int k = k0 + g; k < k1; k += G) {
+    for (int k = k0 + ge; k < k1; k += GE) {
       const int pk = ep[k], lm = el[k];
       const int s1 = pk & 0xffff, s2 = (pk >> 16) & 0xffff;
-      double W[PL], Bj[PL], Di[LD * LD];
+      double W[PL];
+      {
+        double Bj[PL], Di[LD * LD];
 #pragma unroll
-      for (int i = 0; i < LD * LD; ++i) Di[i] = Ds[lm * (LD * LD) + i];
-      lds_block<PL>(Bs + s1 * PL, Bj);
+        for (int i = 0; i < LD * LD; ++i) Di[i] = Ds[lm * (LD * LD) + i];
+        lds_block<PL>(Bs + s1 * PL, Bj);
 #pragma unroll
-      for (int c = 0; c < LD; ++c)
+        for (int c = 0; c < LD; ++c)
 #pragma unroll
-        for (int r = 0; r < PD; ++r) {
-          double v = 0.0;
+          for (int r = 0; r < PD; ++r) {
+            double v = 0.0;
 #pragma unroll
-          for (int kk = 0; kk < LD; ++kk) v += Bj[r + PD * kk] * Di[kk + LD * c];
-          W[r + PD * c] = v;
-        }
-      if (diag) {   // s1 == s2: rhs contribution B (Dinv b_l) = W b_l
+            for (int kk = 0; kk < LD; ++kk) v += Bj[r + PD * kk] * Di[kk + LD * c];
+            W[r + PD * c] = v;
+          }
+      }
+      if (diag && gc == 0) {   // s1 == s2: rhs contribution B (Dinv b_l) = W b_l
 #pragma unroll
         for (int c = 0; c < LD; ++c) {
           const double bv = bsm[lm * LD + c];
 #pragma unroll
           for (int r = 0; r < PD; ++r) cacc[r] += W[r + PD * c] * bv;
         }
-      } else {
-        lds_block<PL>(Bs + s2 * PL, Bj);
       }
+      // this lane's columns of W * B_s2'
+      const double* B2 = Bs + s2 * PL + gc * NC;
 #pragma unroll
-      for (int c = 0; c < PD; ++c)
+      for (int cc = 0; cc < NC; ++cc) {
+        double b2[LD];
+#pragma unroll
+        for (int kk = 0; kk < LD; ++kk) b2[kk] = B2[cc + PD * kk];
 #pragma unroll
         for (int r = 0; r < PD; ++r) {
           double v = 0.0;
 #pragma unroll
-          for (int kk = 0; kk < LD; ++kk) v += W[r + PD * kk] * Bj[c + PD * kk];
-          acc[r + PD * c] += v;
+          for (int kk = 0; kk < LD; ++kk) v += W[r + PD * kk] * b2[kk];
+          acc[r + PD * cc] += v;
         }
+      }
     }
-    if (G > 1) {
+    if (GE > 1) {   // lanes with the same gc are GC apart
 #pragma unroll
-      for (int i = 0; i < PD * PD; ++i) acc[i] = group_sum<G>(acc[i]);
+      for (int i = 0; i < PD * NC; ++i) acc[i] = ge_sum(acc[i]);
 #pragma unroll
-      for (int r = 0; r < PD; ++r) cacc[r] = group_sum<G>(cacc[r]);
+      for (int r = 0; r < PD; ++r) cacc[r] = ge_sum(cacc[r]);
     }
-    double* out = Pd + (size_t)ld * PD * PD;
+    double* out = Pd + (size_t)ld * PD * PD + gc * NC * PD;
 #pragma unroll
-    for (int i = 0; i < PD * PD; ++i)
-      if (G == 1 || (i % G) == g) out[i] = acc[i];
-    if (diag) {
+    for (int i = 0; i < PD * NC; ++i)
+      if (GE == 1 || (i % GE) == ge) out[i] = acc[i];
+    if (diag && gc == 0) {
 #pragma unroll
       for (int r = 0; r < PD; ++r)
-        if (G == 1 || (r % G) == g) Pr[(size_t)ld * PD + r] = cacc[r];
+        if (GE == 1 || (r % GE) == ge) Pr[(size_t)ld * PD + r] = cacc[r];
     }
     if (dbgp && dk < 8) dbgp[dk++] = wall_clock64();
   }
@@ -1341,7 +1360,23 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         std::vector<int> w(rd_ptr.begin(), rd_ptr.end() - 1);
         for (size_t k = 0; k < td_dest.size(); ++k) rd_slot[w[td_dest[k]]++] = (int)k;
       }
-      d_tile_lm0.upload(tile_lm0, st_);
+      {
+        // one 32-byte record per tile (l0, l1, first Hpl slot, slots, td0, td1, first entry, entries): a single
+        // scalar load instead of three dependent ones
+        std::vector<int> meta((size_t)n_tiles_ * 8);
+        for (int t = 0; t < n_tiles_; ++t) {
+          int* m = &meta[(size_t)t * 8];
+          m[0] = tile_lm0[t];
+          m[1] = tile_lm0[t + 1];
+          m[2] = pl_colptr[m[0]];
+          m[3] = pl_colptr[m[1]] - m[2];
+          m[4] = tile_td0[t];
+          m[5] = tile_td0[t + 1];
+          m[6] = td_ptr[m[4]];
+          m[7] = td_ptr[m[5]] - m[6];
+        }
+        d_tile_lm0.upload(meta, st_);
+      }
       d_tile_td0.upload(tile_td0, st_);
       {
         std::vector<int> td_diag(td_dest.size());
@@ -1641,6 +1676,7 @@ void BlockSolver::solve_schur() {
         (void)hipFuncSetAttribute((const void*)schur_tile_kernel<P_, L_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         (void)hipFuncSetAttribute((const void*)schur_tile_kernel<P_, L_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         (void)hipFuncSetAttribute((const void*)schur_tile_kernel<P_, L_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)schur_tile_kernel<P_, L_, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         attr = true;                                                                                                           \
       }                                                                                                                        \
       if (G <= 1)                                                                                                              \
@@ -1649,8 +1685,10 @@ void BlockSolver::solve_schur() {
         hipLaunchKernelGGL((schur_tile_kernel<P_, L_, 2>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, G2OHIP_TILE_ARGS); \
       else if (G <= 4)                                                                                                         \
         hipLaunchKernelGGL((schur_tile_kernel<P_, L_, 4>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, G2OHIP_TILE_ARGS); \
-      else                                                                                                                     \
+      else if (G <= 8)                                                                                                         \
         hipLaunchKernelGGL((schur_tile_kernel<P_, L_, 8>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, G2OHIP_TILE_ARGS); \
+      else                                                                                                                     \
+        hipLaunchKernelGGL((schur_tile_kernel<P_, L_, 16>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, G2OHIP_TILE_ARGS); \
     }                                                                                                                          \
     prof.end(KernelProf::kSchurBlocks, st_);                                                                                   \
     prof.begin(KernelProf::kSchurRhs, st_);                                                                                    \

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""HBM traffic per bench kernel slot from two rocprofv3 PMC passes (rocpd SQLite DBs).
+
+Recipe (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and WRITE_SIZE do not fit one pass; no
+other tracing domains next to --pmc):
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/f -o f -- python bench.py --no-cpu-baseline --steps 2 --warmup 1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/w -o w -- python bench.py --no-cpu-baseline --steps 2 --warmup 1
+  python tools/pmc_traffic.py out/f/f_results.db out/w/w_results.db 2 > profiles/rN_pmc_traffic.json
+Values: KiB per counter summed over the launches of a slot in the LAST bench iteration (identified as
+the last 1/steps_total share of each kernel's dispatches).  On gfx950 FETCH_SIZE tallies 64 B per 128 B
+request for wide streaming reads, so hbm_bytes_per_step = (2*FETCH + WRITE) KiB * 1024; hbm_bytes_raw
+leaves FETCH unscaled (gather-type access is uncalibrated: the truth lies between the two)."""
+import json
+import sqlite3
+import sys
+
+SLOTS = [("assemble_vertex(pose)", ("ba_assemble_poses", "assemble_vertex_kernelILi2ELi6")),
+         ("assemble_vertex(landmark)", ("ba_assemble_landmarks", "assemble_vertex_kernelILi2ELi3")),
+         ("assemble_offdiag(Hpl)", ("assemble_offdiag",)),
+         ("landmark_inverse", ("landmark_inverse",)),
+         ("schur_tiles", ("schur_tile_kernel",)),
+         ("schur_reduce", ("schur_reduce_kernel",)),
+         ("chol_factor(all levels)", ("front_factor_kernel",)),
+         ("chol_solve(all levels)", ("front_forward_kernel", "front_backward_kernel", "permute_in_kernel", "permute_out_kernel")),
+         ("back_substitute", ("back_substitute",)),
+         ("set_lambda/restore", ("lambda_kernel",))]
+
+
+def per_kernel(path, iters):
+    db = sqlite3.connect(path)
+    tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    pe = [t for t in tabs if t.startswith("rocpd_pmc_event")][0]
+    rows = list(db.execute("select s.display_name, d.start, p.value from %s d join %s s on d.kernel_id = s.id "
+                           "join %s p on p.event_id = d.id order by d.start" % (kd, ks, pe)))
+    by = {}
+    for name, start, val in rows:
+        by.setdefault(name, []).append(val)
+    out = {}
+    for name, vals in by.items():
+        n = len(vals) // iters if len(vals) >= iters else len(vals)
+        out[name] = (sum(vals[-n:]), n)
+    return out
+
+
+def main():
+    iters = int(sys.argv[3]) + 1 if len(sys.argv) > 3 else 3     # warmup 1 + steps
+    f, w = per_kernel(sys.argv[1], iters), per_kernel(sys.argv[2], iters)
+    res = {"_note": __doc__.split("Values:")[1].strip().replace("\n", " ")}
+    for slot, keys in SLOTS:
+        fk = sum(v for n, (v, c) in f.items() if any(k in n for k in keys))
+        wk = sum(v for n, (v, c) in w.items() if any(k in n for k in keys))
+        cnt = sum(c for n, (v, c) in f.items() if any(k in n for k in keys))
+        if cnt == 0:
+            continue
+        res[slot] = dict(launches_per_step=cnt, FETCH_SIZE_KiB=fk, WRITE_SIZE_KiB=wk,
+                         hbm_bytes_raw=(fk + wk) * 1024.0, hbm_bytes_per_step=(2 * fk + wk) * 1024.0)
+    json.dump(res, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
