@@ -111,6 +111,9 @@ def main():
                          "1-GPU box; its timing is meaningless)")
     ap.add_argument("--emulate", default="", help="R/W: run rank R of a W-rank job alone with a no-op exchange (results are "
                     "meaningless, per-rank kernel and wall time without communication are not) -- sizing tool for 1-GPU boxes")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="hipGraph replay of the fixed kernel sequences in the timed region (auto: on for N>1, where the "
+                         "per-rank work is launch-bound); per-kernel HIP-event times then come from a second, profiled pass")
     ap.add_argument("--mode", choices=["auto", "subtree", "replicated"], default="auto", help="N>1 reduced-solve strategy")
     ap.add_argument("--dump-xp", default="", help="rank 0 saves the pose increment to this .npy (cross-run comparison)")
     args = ap.parse_args()
@@ -166,8 +169,14 @@ def main():
     for kv in args.opt:
         k_, v_ = kv.split("=")
         solver.local.setOption(k_, float(v_))
+    use_graph = args.graph == "on" or (args.graph == "auto" and (world > 1 or emulate is not None))
+    side = torch.cuda.Stream(device=dev)          # graphs cannot be captured on the default stream
+    torch.cuda.set_stream(side)
     shard = solver.setup_ba(prob, torch_device=dev, nd_leaf=args.nd_leaf, fused=fused)
-    solver.local.setProfiling(True)
+    if use_graph:
+        solver.local.setOption("use_graph", 1)
+    else:
+        solver.local.setProfiling(True)
 
     def step():
         solver.buildSystem()
@@ -196,6 +205,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
+    if use_graph:
+        # per-kernel HIP-event times from a second pass of the same K steps (events cannot be recorded inside a graph)
+        solver.local.setProfiling(True)
+        solver.local.kernelTimes(reset=True)
+        for _ in range(args.steps):
+            ok = step() and ok
+        barrier()
 
     if rank != 0:
         if world > 1:
@@ -249,6 +265,8 @@ def main():
                    "edge_data": "estimates+measurements in HBM, errors/Jacobians evaluated inside buildSystem" if fused
                    else "precomputed Jacobian arrays in HBM"},
         "solve_ok": bool(ok),
+        "launch": "hipGraph replay per segment; per-kernel times from a separate profiled pass" if use_graph
+        else "plain launches, HIP events inside the timed region",
         "roofline": roofline,
         "kernels": per_kernel,
         "stage_algorithmic_GB": {k: v / 1e9 for k, v in stage_b.items()},

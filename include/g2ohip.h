@@ -109,7 +109,13 @@ int g2ohip_build_system(g2ohip_solver* s);
 /* SparseOptimizer::activeRobustChi2(), sparse_optimizer.cpp:100-114, from the current edge data. */
 int g2ohip_chi2(g2ohip_solver* s, double* chi2);
 
-/* Solver::setLambda(lambda, backup) / restoreDiagonal(), block_solver.hpp:563-604 */
+/* Solver::setLambda(lambda, backup) / restoreDiagonal(), block_solver.hpp:563-604.
+ * With the Schur complement enabled the damping is virtual: lambda is held in device scalars and applied where
+ * the diagonal is consumed (Hll + lambda I before the landmark inversion, Hpp + lambda I when Hschur is
+ * formed), so Hpp / Hll in HBM are not modified and restoreDiagonal is exact by construction.  Everything read
+ * through this ABI (g2ohip_copy_values, g2ohip_multiply_hessian, g2ohip_max_diagonal, Hschur, Dinv, x) shows the
+ * damped system exactly as after the reference's setLambda; only raw g2ohip_device_array views of Hpp / Hll are
+ * undamped.  Without Schur the diagonal is modified and restored in place as in the reference. */
 int g2ohip_set_lambda(g2ohip_solver* s, double lambda, int backup);
 int g2ohip_restore_diagonal(g2ohip_solver* s);
 /* max_j |H_jj| over all free vertices: the quantity computeLambdaInit reads through
@@ -179,6 +185,9 @@ int g2ohip_set_lambda_split(g2ohip_solver* s, double lambda_pose, double lambda_
  *                                subtrees, mask x_p entries owned elsewhere (g2ohip_device_array 104)
  *   [caller: all-reduce(SUM) of buffer 104]
  *   g2ohip_solve_reduced_finish  un-permute x_p; G2OHIP_NOT_PD if a local pivot was <= 0
+ * With option "mask_solution" = 0 the masking is skipped: every rank then holds valid x_p for its own and
+ * the shared poses, and the caller exchanges only the few foreign poses its landmarks observe (after
+ * g2ohip_solve_reduced_finish, on g2ohip_device_array 101).
  * g2ohip_get_partition: owner rank (-1 = shared) of every pose block and of every Hschur block (the rank
  * that consumes its value) -- what the caller needs to exchange only the boundary blocks.
  * g2ohip_partition_poses: the same partition (block_consumer may be NULL) from a bare block pattern, host only (no device), so

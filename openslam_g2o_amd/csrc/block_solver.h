@@ -107,6 +107,12 @@ class BlockSolver {
   CholOptions chol_opt;
   size_t schur_tile_bytes = 48 * 1024;     // LDS budget of one Schur tile
   bool ba_fused = true;                    // evaluate BA errors/Jacobians inside the assembly kernels (no J arrays)
+  // hipGraph replay of the fixed kernel sequences (build_system, solve_schur, the reduced solve phases,
+  // back-substitution): the launch-bound tree sweeps cost ~75 launches per iteration, which is what limits
+  // a rank once the per-rank work shrinks (multi-GPU).  Needs a non-default stream; off while profiling.
+  bool use_graph = false;
+  void invalidate_graphs();
+  bool mask_solution = true;               // solve_reduced_shared zeroes the x_p entries other ranks own (all-reduce of x_p)
   int schur_group = 0;                     // lanes per destination in the Schur tile kernel (0 = auto)
   const CholStats* chol_stats() const { return chol_ ? &chol_->stats() : nullptr; }
   int p() const { return p_; }
@@ -126,7 +132,25 @@ class BlockSolver {
   // host patterns
   std::vector<int> pp_colptr, pp_row, pp_diag, pl_colptr, pl_row, hs_colptr, hs_row;
   // device matrices
+  enum Seg { kSegBuild = 0, kSegSchur, kSegReduced, kSegBack, kSegLocal, kSegShared, kNumSeg };
+  struct GraphSeg {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t e = nullptr;
+    int state = 0;   // 0: run plainly once (first-use initialisation), 1: capture, 2: replay
+  };
+  GraphSeg segs_[kNumSeg];
+  template <class F>
+  void run_seg(int id, F&& body);
+  void build_system_impl();
+  void solve_schur_impl();
+  void solve_reduced_device();
+  void solve_back_substitute_impl();
+  void solve_reduced_local_impl();
+  void solve_reduced_shared_impl();
   DevBuf<unsigned char> d_lam_mask;
+  DevBuf<double> d_lam;                    // {lambda_pose, lambda_landmark}: virtual damping (Schur mode)
+  double lam_pose_ = 0.0, lam_lm_ = 0.0;
+  std::vector<unsigned char> lam_mask_h_;
   DevBuf<double> d_Hpp, d_Hpl, d_Hll, d_Hschur, d_Dinv, d_db, d_b, d_x, d_bschur, d_bkP, d_bkL, d_red;
   DevBuf<int> d_pp_diag, d_pl_colptr, d_pl_row, d_pl_lm;
   DevBuf<int> d_hs_src;                    // Hschur block -> Hpp block id or -1

@@ -365,12 +365,15 @@ __device__ __forceinline__ void small_inverse(const double* D, double* R) {
 }
 template <int LD>
 __global__ void __launch_bounds__(kThreads) landmark_inverse_kernel(int nL, const double* __restrict__ Hll, const double* __restrict__ bl,
-                                        double* __restrict__ Dinv, double* __restrict__ db) {
+                                        double* __restrict__ Dinv, double* __restrict__ db, const double* __restrict__ lam) {
   const int lm = blockIdx.x * blockDim.x + threadIdx.x;
   if (lm >= nL) return;
+  const double lambda = lam[1];   // virtual damping of the landmark blocks (set_lambda does not touch Hll)
   double D[LD * LD], R[LD * LD];
 #pragma unroll
   for (int i = 0; i < LD * LD; ++i) D[i] = Hll[(size_t)lm * LD * LD + i];
+#pragma unroll
+  for (int i = 0; i < LD; ++i) D[i * (LD + 1)] += lambda;
   small_inverse<LD>(D, R);
 #pragma unroll
   for (int i = 0; i < LD * LD; ++i) Dinv[(size_t)lm * LD * LD + i] = R[i];
@@ -570,17 +573,20 @@ __global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const 
                                                               const int* __restrict__ hs_src, const double* __restrict__ Hpp,
                                                               const double* __restrict__ Pd, double* __restrict__ Hs,
                                                               const int* __restrict__ hs_diag, const double* __restrict__ Pr,
-                                                              const double* __restrict__ b, double* __restrict__ bschur) {
+                                                              const double* __restrict__ b, double* __restrict__ bschur,
+                                                              const double* __restrict__ lam, const unsigned char* __restrict__ lam_mask) {
   constexpr int BB = PD * PD;
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (t >= (size_t)nDst * BB) return;
   const int d = (int)(t / BB), e = (int)(t % BB);
   const int src = hs_src[d];
+  const int pose = hs_diag[d];
   double v = src >= 0 ? Hpp[(size_t)src * BB + e] : 0.0;
+  // virtual damping of the pose blocks: (Hpp + lambda I) first, like the materialised setLambda did
+  if (pose >= 0 && e % (PD + 1) == 0 && (!lam_mask || lam_mask[pose])) v += lam[0];
   const int k0 = rd_ptr[d], k1 = rd_ptr[d + 1];
   for (int k = k0; k < k1; ++k) v -= Pd[(size_t)rd_slot[k] * BB + e];
   Hs[t] = v;
-  const int pose = hs_diag[d];
   if (pose >= 0 && e < PD) {
     double r = b[(size_t)pose * PD + e];
     for (int k = k0; k < k1; ++k) r -= Pr[(size_t)rd_slot[k] * PD + e];
@@ -1056,16 +1062,19 @@ BlockSolver::BlockSolver(int p, int l, int device) : p_(p), l_(l), device_(devic
 }
 
 BlockSolver::~BlockSolver() {
+  invalidate_graphs();
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
 }
 
 void BlockSolver::set_stream(hipStream_t st) {
+  invalidate_graphs();
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
   own_stream_ = false;
   st_ = st;
 }
 
 void BlockSolver::init() {
+  invalidate_graphs();
   // block_solver.hpp:606-620: numeric + symbolic state is rebuilt on the next buildStructure/solve
   if (chol_) chol_->reset();
   system_built_ = false;
@@ -1099,6 +1108,7 @@ void BlockSolver::require_structure() const {
 }
 
 void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
+  invalidate_graphs();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   nP_ = nP;
   nL_ = nL;
@@ -1431,6 +1441,12 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   chol_->opt = chol_opt;
   if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
   else chol_->analyze(nP, pp_colptr.data(), pp_row.data(), st_);
+  {
+    const double zero2[2] = {0.0, 0.0};
+    d_lam.upload(zero2, 2, st_);
+    lam_pose_ = lam_lm_ = 0.0;
+    lam_mask_h_.clear();
+  }
   if (chol_opt.world > 1) {
     // the rank that consumes a pose's diagonal block adds lambda to it (rank 0 for the shared ones)
     const std::vector<int>& cons = chol_->symbolic().block_consumer;
@@ -1441,6 +1457,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       m[c] = (o == chol_opt.rank) || (o < 0 && chol_opt.rank == 0);
     }
     d_lam_mask.upload(m, st_);
+    lam_mask_h_ = m;
   }
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   structured_ = true;
@@ -1448,6 +1465,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
 }
 
 void BlockSolver::set_edge_data(int set, const double* J0, const double* J1, const double* omega, const double* err, bool on_device) {
+  invalidate_graphs();
   require_structure();
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
   EdgeSet& es = *sets_[set];
@@ -1474,10 +1492,48 @@ void BlockSolver::set_edge_data(int set, const double* J0, const double* J1, con
 }
 
 void BlockSolver::set_robust_kernel(int set, int kind, double delta) {
+  invalidate_graphs();
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
   if (kind != 0 && kind != 1) throw ArgFailure("unsupported robust kernel");
   sets_[set]->kernel_kind = kind;
   sets_[set]->delta = delta;
+}
+
+void BlockSolver::invalidate_graphs() {
+  for (GraphSeg& sg : segs_) {
+    if (sg.e) (void)hipGraphExecDestroy(sg.e);
+    if (sg.g) (void)hipGraphDestroy(sg.g);
+    sg = GraphSeg();
+  }
+}
+
+template <class F>
+void BlockSolver::run_seg(int id, F&& body) {
+  if (!use_graph || profiling || prof.enabled || st_ == nullptr) {
+    body();
+    return;
+  }
+  GraphSeg& sg = segs_[id];
+  if (sg.state == 0) {   // first use: one-time initialisation (function attributes, lazy analysis) runs outside a capture
+    body();
+    sg.state = 1;
+    return;
+  }
+  if (sg.state == 1) {
+    G2OHIP_HIP_CHECK(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+    try {
+      body();
+    } catch (...) {
+      hipGraph_t dead = nullptr;
+      (void)hipStreamEndCapture(st_, &dead);
+      if (dead) (void)hipGraphDestroy(dead);
+      throw;
+    }
+    G2OHIP_HIP_CHECK(hipStreamEndCapture(st_, &sg.g));
+    G2OHIP_HIP_CHECK(hipGraphInstantiate(&sg.e, sg.g, nullptr, nullptr, 0));
+    sg.state = 2;
+  }
+  G2OHIP_HIP_CHECK(hipGraphLaunch(sg.e, st_));
 }
 
 void BlockSolver::build_system() {
@@ -1485,6 +1541,11 @@ void BlockSolver::build_system() {
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   for (auto& esp : sets_)
     if (esp->n > 0 && !esp->has_data) throw StateFailure("build_system: edge data missing for a set");
+  run_seg(kSegBuild, [&] { build_system_impl(); });
+  system_built_ = true;
+}
+
+void BlockSolver::build_system_impl() {
   if (profiling) tq_.start(st_);
   const size_t sizeP = (size_t)nP_ * p_;
   bool any_pose = false, any_lm = false;
@@ -1557,7 +1618,6 @@ void BlockSolver::build_system() {
     tq_.stop(st_);
     times.quadratic = tq_.seconds();
   }
-  system_built_ = true;
 }
 
 double BlockSolver::reduce_sum_finish(int nblocks) {
@@ -1599,9 +1659,27 @@ double BlockSolver::chi2() {
 
 void BlockSolver::set_lambda(double lambda, bool backup) { set_lambda_split(lambda, lambda, backup); }
 
+// With the Schur complement the damping is VIRTUAL: lambda lives in two device scalars that
+// landmark_inverse (Hll + lambda I) and schur_reduce (Hpp + lambda I) read; Hpp / Hll stay untouched, so
+// there is nothing to back up or restore (the reference walks every diagonal block twice per trial,
+// block_solver.hpp:563-604).  Readers of the matrices (copy_values, multiply_hessian, max_diagonal) add it.
+__global__ void set_pair_kernel(double* __restrict__ p, double a, double b) {
+  p[0] = a;
+  p[1] = b;
+}
+
 void BlockSolver::set_lambda_split(double lambda_pose, double lambda_landmark, bool backup) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (schur_) {
+    prof.begin(KernelProf::kLambda, st_);
+    hipLaunchKernelGGL(set_pair_kernel, dim3(1), dim3(1), 0, st_, d_lam.p, lambda_pose, lambda_landmark);
+    prof.end(KernelProf::kLambda, st_);
+    lam_pose_ = lambda_pose;
+    lam_lm_ = lambda_landmark;
+    G2OHIP_HIP_CHECK(hipGetLastError());
+    return;
+  }
   prof.begin(KernelProf::kLambda, st_);
   hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nP_ * p_)), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p, d_bkP.p,
                      lambda_pose, backup ? 1 : 0, 0, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr);
@@ -1615,6 +1693,12 @@ void BlockSolver::set_lambda_split(double lambda_pose, double lambda_landmark, b
 void BlockSolver::restore_diagonal() {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (schur_) {
+    hipLaunchKernelGGL(set_pair_kernel, dim3(1), dim3(1), 0, st_, d_lam.p, 0.0, 0.0);
+    lam_pose_ = lam_lm_ = 0.0;
+    G2OHIP_HIP_CHECK(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(lambda_kernel, dim3(grid_for((size_t)nP_ * p_)), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p, d_bkP.p,
                      0.0, 0, 1);
   if (nL_ > 0)
@@ -1632,14 +1716,14 @@ double BlockSolver::max_diagonal() {
     hipLaunchKernelGGL(maxdiag_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p, d_red.p);
     std::vector<double> h(nblocks);
     d_red.download(h.data(), nblocks, st_);
-    for (double v : h) m = std::max(m, v);
+    for (double v : h) m = std::max(m, v + lam_pose_);
   }
   if (nL_ > 0) {
     int nblocks = std::min(1024, grid_for((size_t)nL_ * l_));
     hipLaunchKernelGGL(maxdiag_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, nL_, l_, d_Hll.p, (const int*)nullptr, d_red.p);
     std::vector<double> h(nblocks);
     d_red.download(h.data(), nblocks, st_);
-    for (double v : h) m = std::max(m, v);
+    for (double v : h) m = std::max(m, v + lam_lm_);
   }
   return m;
 }
@@ -1656,6 +1740,10 @@ void BlockSolver::solve_schur() {
   require_structure();
   if (!schur_) return;
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  run_seg(kSegSchur, [&] { solve_schur_impl(); });
+}
+
+void BlockSolver::solve_schur_impl() {
   if (profiling) ts_.start(st_);
   const size_t sizeP = (size_t)nP_ * p_;
   const int hs_nnzb = (int)hs_row.size();
@@ -1666,7 +1754,7 @@ void BlockSolver::solve_schur() {
   if (p_ == P_ && l_ == L_) {                                                                                                  \
     prof.begin(KernelProf::kLmInverse, st_);                                                                                   \
     hipLaunchKernelGGL((landmark_inverse_kernel<L_>), dim3(grid_for(nL_)), dim3(kThreads), 0, st_, nL_, d_Hll.p, d_b.p + sizeP, \
-                       d_Dinv.p, d_db.p);                                                                                      \
+                       d_Dinv.p, d_db.p, d_lam.p);                                                                             \
     prof.end(KernelProf::kLmInverse, st_);                                                                                     \
     prof.begin(KernelProf::kSchurBlocks, st_);                                                                                 \
     if (n_tiles_ > 0) {                                                                                                        \
@@ -1693,7 +1781,8 @@ void BlockSolver::solve_schur() {
     prof.end(KernelProf::kSchurBlocks, st_);                                                                                   \
     prof.begin(KernelProf::kSchurRhs, st_);                                                                                    \
     hipLaunchKernelGGL((schur_reduce_kernel<P_>), dim3(grid_for((size_t)hs_nnzb * P_ * P_)), dim3(kThreads), 0, st_, hs_nnzb,     \
-                       d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p); \
+                       d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, d_lam.p, \
+                       chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr);                                      \
     prof.end(KernelProf::kSchurRhs, st_);                                                                                      \
   } else
   G2OHIP_SCHUR(6, 3)
@@ -1729,6 +1818,16 @@ int BlockSolver::solve_reduced() {
     if (schur_) chol_->analyze(nP_, hs_colptr.data(), hs_row.data(), st_);
     else chol_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
   }
+  run_seg(kSegReduced, [&] { solve_reduced_device(); });
+  bool bad = chol_->failed(st_);   // synchronises
+  if (profiling) {
+    times.numeric = tn_.seconds();
+    times.linsolve = tl_.seconds();
+  }
+  return bad ? 1 : 0;
+}
+
+void BlockSolver::solve_reduced_device() {
   if (profiling) tn_.start(st_);
   prof.begin(KernelProf::kCholFactor, st_);
   chol_->factor(schur_ ? d_Hschur.p : d_Hpp.p, st_);
@@ -1741,16 +1840,11 @@ int BlockSolver::solve_reduced() {
   chol_->solve(schur_ ? d_bschur.p : d_b.p, d_x.p, st_);
   prof.end(KernelProf::kCholSolve, st_);
   if (profiling) tl_.stop(st_);
-  bool bad = chol_->failed(st_);   // synchronises
-  if (profiling) {
-    times.numeric = tn_.seconds();
-    times.linsolve = tl_.seconds();
-  }
-  return bad ? 1 : 0;
 }
 
 void BlockSolver::set_partition(int rank, int world) {
   if (world < 1 || rank < 0 || rank >= world) throw ArgFailure("set_partition: bad rank/world");
+  invalidate_graphs();
   chol_opt.rank = rank;
   chol_opt.world = world;
   structured_ = false;
@@ -1759,6 +1853,10 @@ void BlockSolver::set_partition(int rank, int world) {
 void BlockSolver::solve_reduced_local() {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  run_seg(kSegLocal, [&] { solve_reduced_local_impl(); });
+}
+
+void BlockSolver::solve_reduced_local_impl() {
   prof.begin(KernelProf::kCholFactor, st_);
   chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 0, st_);
   prof.end(KernelProf::kCholFactor, st_);
@@ -1773,6 +1871,10 @@ void BlockSolver::solve_reduced_local() {
 void BlockSolver::solve_reduced_shared() {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  run_seg(kSegShared, [&] { solve_reduced_shared_impl(); });
+}
+
+void BlockSolver::solve_reduced_shared_impl() {
   chol_->unpack_exchange(st_);
   prof.begin(KernelProf::kCholFactor, st_);
   chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 1, st_);
@@ -1781,7 +1883,7 @@ void BlockSolver::solve_reduced_shared() {
   chol_->solve_forward_phase(1, st_);
   chol_->solve_backward_phase(1, st_);
   chol_->solve_backward_phase(0, st_);
-  chol_->mask_solution(st_);
+  if (mask_solution) chol_->mask_solution(st_);
   prof.end(KernelProf::kCholSolve, st_);
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
@@ -1804,6 +1906,10 @@ void BlockSolver::solve_back_substitute() {
   require_structure();
   if (!schur_) return;
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  run_seg(kSegBack, [&] { solve_back_substitute_impl(); });
+}
+
+void BlockSolver::solve_back_substitute_impl() {
   if (profiling) tb_.start(st_);
   const size_t sizeP = (size_t)nP_ * p_;
   prof.begin(KernelProf::kBackSub, st_);
@@ -1849,6 +1955,13 @@ void BlockSolver::multiply_hessian(double* dest_host, const double* src_host) {
                        d_pl_row.p, d_Hpl.p, d_Hll.p, src.p, dst.p);
   G2OHIP_HIP_CHECK(hipGetLastError());
   dst.download(dest_host, n, st_);
+  if (lam_pose_ != 0.0 || lam_lm_ != 0.0) {   // virtual damping
+    const size_t np = (size_t)nP_ * p_;
+    for (size_t i = 0; i < n; ++i) {
+      if (i < np && !lam_mask_h_.empty() && !lam_mask_h_[i / p_]) continue;
+      dest_host[i] += (i < np ? lam_pose_ : lam_lm_) * src_host[i];
+    }
+  }
 }
 
 void BlockSolver::copy_x(double* h) {
@@ -1885,9 +1998,22 @@ void BlockSolver::get_pattern(int which, int* colptr, int* rowidx) const {
 void BlockSolver::copy_values(int which, double* h) {
   require_structure();
   switch (which) {
-    case 0: d_Hpp.download(h, pp_row.size() * p_ * p_, st_); break;
+    case 0:
+      d_Hpp.download(h, pp_row.size() * p_ * p_, st_);
+      if (lam_pose_ != 0.0)
+        for (int c = 0; c < nP_; ++c) {
+          if (!lam_mask_h_.empty() && !lam_mask_h_[c]) continue;
+          double* blk = h + (size_t)(pp_colptr[c + 1] - 1) * p_ * p_;   // the diagonal block closes its column
+          for (int i = 0; i < p_; ++i) blk[i * (p_ + 1)] += lam_pose_;
+        }
+      break;
     case 1: d_Hpl.download(h, pl_row.size() * p_ * l_, st_); break;
-    case 2: d_Hll.download(h, (size_t)nL_ * l_ * l_, st_); break;
+    case 2:
+      d_Hll.download(h, (size_t)nL_ * l_ * l_, st_);
+      if (lam_lm_ != 0.0)
+        for (size_t j = 0; j < (size_t)nL_; ++j)
+          for (int i = 0; i < l_; ++i) h[j * l_ * l_ + i * (l_ + 1)] += lam_lm_;
+      break;
     case 3: d_Hschur.download(h, hs_row.size() * p_ * p_, st_); break;
     case 4: d_Dinv.download(h, (size_t)nL_ * l_ * l_, st_); break;
     default: throw ArgFailure("bad matrix selector");
@@ -1896,6 +2022,7 @@ void BlockSolver::copy_values(int which, double* h) {
 // ---- bundle-adjustment front end -------------------------------------------------------------
 void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_vertex, const double* meas, const double* info,
                                double f, double cx, double cy) {
+  invalidate_graphs();
   require_structure();
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
   EdgeSet& es = *sets_[set];
@@ -1945,6 +2072,7 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
 
 void BlockSolver::ba_set_estimates(int n_cams, const double* cams, const int* cam_hidx, int n_points, const double* points,
                                    const int* point_hidx) {
+  invalidate_graphs();
   if (n_cams <= 0 || n_points <= 0 || !cams || !points || !cam_hidx || !point_hidx) throw ArgFailure("ba_set_estimates: bad arguments");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ba_.n_cams = n_cams;

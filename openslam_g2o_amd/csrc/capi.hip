@@ -367,11 +367,14 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "wave_front_bytes")) s->impl->chol_opt.wave_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_tile_bytes")) s->impl->schur_tile_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_group")) s->impl->schur_group = (int)value;
+  else if (!std::strcmp(name, "mask_solution")) s->impl->mask_solution = value != 0;
+  else if (!std::strcmp(name, "use_graph")) s->impl->use_graph = value != 0;
   else if (!std::strcmp(name, "ba_fused")) s->impl->ba_fused = value != 0;
   else {
     set_error(std::string("unknown option ") + name);
     return G2OHIP_ERR_ARG;
   }
+  s->impl->invalidate_graphs();   // options change kernel arguments / launch shapes
   return G2OHIP_OK;
 }
 

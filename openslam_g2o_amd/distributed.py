@@ -32,8 +32,12 @@ their observing poses, so nearly all Schur contributions are produced on the ran
 them; only "boundary" blocks (a producer differs from the consumer, or the consumer is shared)
 go through a compact gather -> all-reduce -> scatter.  Per solve: boundary blocks + bschur
 all-reduce, own subtrees factor/forward (no communication), all-reduce of the subtree roots'
-update matrices (tiny: separator-sized), shared top factor/solve + own backward sweep,
-all-reduce of the masked x_p, back-substitution of the own landmarks.
+update matrices (tiny: separator-sized), shared top factor/solve + own backward sweep, exchange
+of x_p, back-substitution of the own landmarks.  With x_exchange="halo" (default) both vector
+exchanges are compact too: b_p only for the poses whose right-hand side has a foreign producer,
+x_p only for the foreign poses a rank's landmarks observe -- three latency-sized collectives per
+solve; x_p then stays distributed like x_l (every rank holds its own, the shared and its halo
+poses; gather_x_poses() assembles the full vector on demand, outside the iteration).
 """
 import numpy as np
 
@@ -114,6 +118,19 @@ def assign_landmarks(pose_idx, lm_idx, pose_owner, nL, world):
     return owner
 
 
+def boundary_poses(pose_idx, lm_idx, pose_owner, lm_owner):
+    """(poses whose b_p is summed over ranks, poses whose x_p another rank needs): an observing
+    landmark lives on a rank other than the pose's owner; shared poses (owner -1) only need b_p."""
+    pose_idx = np.asarray(pose_idx, np.int64)
+    lm_idx = np.asarray(lm_idx, np.int64)
+    keep = pose_idx >= 0
+    p, l = pose_idx[keep], lm_idx[keep]
+    foreign = lm_owner[l] != pose_owner[p]
+    bposes = np.unique(p[foreign])
+    halo = np.unique(p[foreign & (pose_owner[p] >= 0)])
+    return bposes, halo
+
+
 def boundary_blocks(keys, block_consumer, rows, cols, lms, lm_owner, nP):
     """Indices of the reduced-system blocks whose value must be summed over ranks: a producer (the
     rank owning a landmark co-observed by the block's two poses) differs from the consumer, or the
@@ -132,7 +149,10 @@ class _DevArray:
 
 def tensor_from_device_ptr(ptr, n, device):
     import torch
-    return torch.as_tensor(_DevArray(ptr, n), device=device)
+    t = torch.as_tensor(_DevArray(ptr, n), device=device)
+    if t.data_ptr() != int(ptr):   # a silent copy would detach the collective from the solver's memory
+        raise RuntimeError("torch made a copy of a device array (wrong device for this pointer?)")
+    return t
 
 
 class TorchComm:
@@ -180,7 +200,7 @@ class HostStagedComm(TorchComm):
 
 class ShardedBlockSolver:
     def __init__(self, pose_dim, landmark_dim, rank=0, world=1, device=0, local=None, comm=None, force_exchange=False,
-                 mode="auto"):
+                 mode="auto", x_exchange="halo"):
         self.p, self.l = pose_dim, landmark_dim
         self.rank, self.world = rank, world
         self.exchange = world > 1 or force_exchange   # union Schur pattern + all-reduce step active
@@ -189,6 +209,9 @@ class ShardedBlockSolver:
         if mode not in ("subtree", "replicated"):
             raise ValueError("mode must be auto, subtree or replicated")
         self.mode = mode
+        if x_exchange not in ("halo", "full"):
+            raise ValueError("x_exchange must be halo or full")
+        self.x_exchange = x_exchange   # subtree mode: exchange only boundary b_p / halo x_p, or the full vectors
         if local is None:
             from . import capi
             local = capi.HipBlockSolver(pose_dim, landmark_dim, device)
@@ -222,6 +245,7 @@ class ShardedBlockSolver:
             lm_owner = assign_landmarks(prob["v1"], lm, pose_owner, nL, self.world)
             my = np.flatnonzero(lm_owner == self.rank)
             self.boundary = boundary_blocks(keys, consumer, prow, pcol, plm, lm_owner, nP)
+            self.bposes, self.halo = boundary_poses(prob["v1"], lm, pose_owner, lm_owner)
             self.pose_owner, self.nnzb_reduced = pose_owner, len(keys)
             rows, cols = (keys % nP).astype(np.int32), (keys // nP).astype(np.int32)
             del prow, pcol, plm
@@ -244,6 +268,7 @@ class ShardedBlockSolver:
             self.local.addSchurPattern(rows, cols)
         if self.mode == "subtree":
             self.local.setPartition(self.rank, self.world)
+            self.local.setOption("mask_solution", 0 if self.x_exchange == "halo" else 1)
         self.local.buildStructure(nP, len(my), True)
         if self.mode == "subtree":
             cp2, ri2 = self.local.pattern(3)
@@ -290,9 +315,20 @@ class ShardedBlockSolver:
             import torch
             from . import capi
             H = self._device_tensor(capi.HSCHUR).view(self.nnzb_reduced, self.p * self.p)
-            idx = torch.from_numpy(self.boundary).to(H.device)
-            self._sub = dict(H=H, idx=idx, b=self._device_tensor(capi.ARR_BSCHUR),
-                             xbuf=self._device_tensor(capi.ARR_EXCHANGE), xp=self._device_tensor(capi.ARR_XP))
+            dev = H.device
+            idx = torch.from_numpy(self.boundary).to(dev)
+            b = self._device_tensor(capi.ARR_BSCHUR)
+            nP = self.local.nP
+            x = self._device_tensor(capi.ARR_X)
+            sub = dict(H=H, idx=idx, b=b, xbuf=self._device_tensor(capi.ARR_EXCHANGE), xp=self._device_tensor(capi.ARR_XP))
+            if self.x_exchange == "halo":
+                nb, p = len(self.boundary), self.p
+                sub.update(b2=b.view(nP, p), x2=x[:nP * p].view(nP, p),
+                           bidx=torch.from_numpy(self.bposes).to(dev), hidx=torch.from_numpy(self.halo).to(dev),
+                           hmine=torch.from_numpy((self.pose_owner[self.halo] == self.rank).astype(np.float64)).to(dev)[:, None],
+                           buf1=torch.zeros(nb * p * p + len(self.bposes) * p, dtype=torch.float64, device=dev),
+                           buf3=torch.zeros(len(self.halo) * p + 1, dtype=torch.float64, device=dev))
+            self._sub = sub
         return self._sub
 
     def exchange_volume(self):
@@ -300,6 +336,8 @@ class ShardedBlockSolver:
         if self.mode != "subtree":
             return sum(int(t.numel()) for t in self._reduced_tensors()) if self.exchange else 0
         t = self._subtree_tensors()
+        if self.x_exchange == "halo":
+            return int(t["buf1"].numel() + t["xbuf"].numel() + t["buf3"].numel())
         return int(len(self.boundary) * self.p * self.p + t["b"].numel() + t["xbuf"].numel() + t["xp"].numel())
 
     def _reduced_tensors(self):
@@ -327,7 +365,54 @@ class ShardedBlockSolver:
     def restoreDiagonal(self):
         return self.local.restoreDiagonal()
 
+    def _solve_subtree_halo(self):
+        """Three latency-sized collectives: boundary Hschur blocks + boundary b_p | subtree roots | halo x_p + status."""
+        import torch
+        t = self._subtree_tensors()
+        p = self.p
+        nbb = len(self.boundary) * p * p
+        self.local.solveSchur()
+        buf1 = t["buf1"]
+        if buf1.numel():
+            torch.index_select(t["H"], 0, t["idx"], out=buf1[:nbb].view(-1, p * p))
+            torch.index_select(t["b2"], 0, t["bidx"], out=buf1[nbb:].view(-1, p))
+            self.comm.all_reduce_sum([buf1])
+            t["H"].index_copy_(0, t["idx"], buf1[:nbb].view(-1, p * p))
+            t["b2"].index_copy_(0, t["bidx"], buf1[nbb:].view(-1, p))
+        self.local.solveReducedLocal()
+        self.comm.all_reduce_sum([t["xbuf"]])
+        self.local.solveReducedShared()
+        ok = self.local.solveReducedFinish()
+        buf3 = t["buf3"]
+        if len(self.halo):
+            torch.mul(t["x2"].index_select(0, t["hidx"]), t["hmine"], out=buf3[:-1].view(-1, p))
+        buf3[-1] = 0.0 if ok else 1.0
+        self.comm.all_reduce_sum([buf3])
+        if len(self.halo):
+            t["x2"].index_copy_(0, t["hidx"], buf3[:-1].view(-1, p))
+        if self.world > 1 or self.comm.force:
+            ok = float(buf3[-1].item()) == 0.0
+        if not ok:
+            return False
+        self.local.solveBackSubstitute()
+        return True
+
+    def gather_x_poses(self):
+        """Full pose increment on every rank (outside the iteration: one all-reduce of 6 P doubles)."""
+        import torch
+        x = self.x_poses()
+        if self.mode != "subtree" or self.x_exchange != "halo" or self.world == 1:
+            return x
+        own = (self.pose_owner == self.rank) | ((self.pose_owner < 0) & (self.rank == 0))
+        t = torch.from_numpy(np.where(np.repeat(own, self.p), x, 0.0))
+        dev = self._torch_device if getattr(self, "_torch_device", None) is not None else "cpu"
+        t = t.to(dev)
+        self.comm.all_reduce_sum([t])
+        return t.cpu().numpy()
+
     def _solve_subtree(self):
+        if self.x_exchange == "halo":
+            return self._solve_subtree_halo()
         t = self._subtree_tensors()
         self.local.solveSchur()
         if len(self.boundary):

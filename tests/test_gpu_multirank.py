@@ -15,7 +15,7 @@ from tests.helpers import ba_case, oracle_ba
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, P, L, lam, fused, out_dir):
+def _worker(rank, world, port, P, L, lam, fused, x_exchange, out_dir):
     import torch
     import torch.distributed as dist
     from openslam_g2o_amd import distributed as D
@@ -26,7 +26,7 @@ def _worker(rank, world, port, P, L, lam, fused, out_dir):
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
         pr = ba_case(P, L)
-        s = D.ShardedBlockSolver(6, 3, rank=rank, world=world, comm=D.HostStagedComm(world), mode="subtree")
+        s = D.ShardedBlockSolver(6, 3, rank=rank, world=world, comm=D.HostStagedComm(world), mode="subtree", x_exchange=x_exchange)
         info = s.setup_ba(pr, torch_device=dev, fused=fused)
         chis, xs = [], []
         for it in range(2):               # twice: the phased factorisation must be repeatable
@@ -38,7 +38,11 @@ def _worker(rank, world, port, P, L, lam, fused, out_dir):
             xs.append(s.local.x())
         assert np.array_equal(xs[0], xs[1])
         owned = np.bincount(s.pose_owner + 1, minlength=world + 1)
-        np.savez(os.path.join(out_dir, "r%d.npz" % rank), ok=ok, xp=s.x_poses(), xl=s.x_landmarks_local(),
+        xloc = s.x_poses()
+        valid = (s.pose_owner == rank) | (s.pose_owner < 0)
+        valid[s.halo] = True            # own + shared + halo poses are valid without any gather
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), ok=ok, xp=s.gather_x_poses(), xl=s.x_landmarks_local(),
+                 xloc=xloc, valid=valid, halo=len(s.halo), bposes=len(s.bposes),
                  lm_index=s.lm_index, chi2=chis[0], owned=owned, boundary=len(s.boundary), nnzb=s.nnzb_reduced,
                  volume=s.exchange_volume(), E_local=info["E_local"])
     finally:
@@ -51,11 +55,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,fused", [(2, False), (3, True)])
-def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused):
+@pytest.mark.parametrize("world,fused,x_exchange", [(2, False, "full"), (3, True, "halo"), (2, True, "halo")])
+def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused, x_exchange):
     import torch.multiprocessing as mp
     P, L, lam = 700, 6000, 30.0
-    mp.spawn(_worker, args=(world, _free_port(), P, L, lam, fused, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), P, L, lam, fused, x_exchange, str(tmp_path)), nprocs=world, join=True)
     pr = ba_case(P, L)
     o = oracle_ba(pr)
     o.build_system()
@@ -71,7 +75,10 @@ def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused):
         z = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
         assert bool(z["ok"])
         assert abs(float(z["chi2"]) - chi2) <= 1e-9 * chi2
-        assert np.abs(z["xp"] - xp).max() <= 1e-7 * np.abs(xp).max()          # x_p replicated on every rank
+        assert np.abs(z["xp"] - xp).max() <= 1e-7 * np.abs(xp).max()          # gathered x_p
+        v = np.repeat(z["valid"], 6) if x_exchange == "halo" else np.ones(6 * nP, bool)
+        assert np.abs(z["xloc"][v] - xp[v]).max() <= 1e-7 * np.abs(xp).max()  # own + shared + halo poses without the gather
+        assert int(z["halo"]) < 0.1 * nP and int(z["bposes"]) < 0.2 * nP
         idx = z["lm_index"]
         seen[idx] += 1
         assert np.abs(z["xl"].reshape(-1, 3) - xl[idx]).max() <= 1e-7 * np.abs(xl).max()   # x_l sharded by owner
