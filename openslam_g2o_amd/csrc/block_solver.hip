@@ -1828,16 +1828,23 @@ int BlockSolver::solve_reduced() {
 }
 
 void BlockSolver::solve_reduced_device() {
+  // factorisation with the forward sweep fused into it, then the backward sweep
+  const double* Hred = schur_ ? d_Hschur.p : d_Hpp.p;
+  const double* bred = schur_ ? d_bschur.p : d_b.p;
   if (profiling) tn_.start(st_);
+  chol_->solve_begin(bred, st_);
   prof.begin(KernelProf::kCholFactor, st_);
-  chol_->factor(schur_ ? d_Hschur.p : d_Hpp.p, st_);
+  chol_->factor_phase(Hred, 0, st_, true);
+  chol_->factor_phase(Hred, 1, st_, true);
   prof.end(KernelProf::kCholFactor, st_);
   if (profiling) {
     tn_.stop(st_);
     tl_.start(st_);
   }
   prof.begin(KernelProf::kCholSolve, st_);
-  chol_->solve(schur_ ? d_bschur.p : d_b.p, d_x.p, st_);
+  chol_->solve_backward_phase(1, st_);
+  chol_->solve_backward_phase(0, st_);
+  chol_->solve_end(d_x.p, st_);
   prof.end(KernelProf::kCholSolve, st_);
   if (profiling) tl_.stop(st_);
 }
@@ -1857,14 +1864,11 @@ void BlockSolver::solve_reduced_local() {
 }
 
 void BlockSolver::solve_reduced_local_impl() {
-  prof.begin(KernelProf::kCholFactor, st_);
-  chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 0, st_);
-  prof.end(KernelProf::kCholFactor, st_);
-  prof.begin(KernelProf::kCholSolve, st_);
   chol_->solve_begin(schur_ ? d_bschur.p : d_b.p, st_);
-  chol_->solve_forward_phase(0, st_);
+  prof.begin(KernelProf::kCholFactor, st_);
+  chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 0, st_, true);   // forward sweep fused in
+  prof.end(KernelProf::kCholFactor, st_);
   chol_->pack_exchange(st_);
-  prof.end(KernelProf::kCholSolve, st_);
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 
@@ -1877,10 +1881,9 @@ void BlockSolver::solve_reduced_shared() {
 void BlockSolver::solve_reduced_shared_impl() {
   chol_->unpack_exchange(st_);
   prof.begin(KernelProf::kCholFactor, st_);
-  chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 1, st_);
+  chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 1, st_, true);
   prof.end(KernelProf::kCholFactor, st_);
   prof.begin(KernelProf::kCholSolve, st_);
-  chol_->solve_forward_phase(1, st_);
   chol_->solve_backward_phase(1, st_);
   chol_->solve_backward_phase(0, st_);
   if (mask_solution) chol_->mask_solution(st_);

@@ -118,7 +118,8 @@ class SparseCholesky {
   // x = A \ b with device vectors of nb*bs (original block order).  Asynchronous.
   void solve(const double* d_b, double* d_x, hipStream_t st);
   // ---- phased interface for the multi-GPU path (phase 0: this rank's subtrees, phase 1: shared top)
-  void factor_phase(const double* dA, int phase, hipStream_t st);
+  void factor_phase(const double* dA, int phase, hipStream_t st, bool fwd = false);   // fwd: fused forward sweep (after solve_begin)
+  void factor_solve(const double* dA, const double* d_b, double* d_x, hipStream_t st);
   void solve_begin(const double* d_b, hipStream_t st);            // permute the right-hand side in
   void solve_forward_phase(int phase, hipStream_t st);
   void solve_backward_phase(int phase, hipStream_t st);
@@ -156,6 +157,7 @@ class SparseCholesky {
     int max_panel = 0;                                   // max m*npiv (doubles) for solve kernels
     int max_m = 0;
     int lds_idx_ints = 0, glb_idx_ints = 0;              // staged index lists (ints) per front, max over the launch
+    bool fuse_fwd = true;                                // every LDS front of the launch is within the fused forward sweep's limits
     int sm_count = 0, sm_max_m = 0, sm_idx_ints = 0;     // leading part of the lds range: small fronts, one wave each
   };
   std::vector<LevelLaunch> launches_[2];   // [0] own tasks, [1] shared top-of-tree tasks
@@ -167,8 +169,8 @@ class SparseCholesky {
   int n_xseg_ = 0;
   int dbg_launch_ = 0;
   size_t xbuf_count_ = 0;
-  void launch_factor(const LevelLaunch& LL, const double* dA, hipStream_t st);
-  void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st);
+  void launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st);
+  void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false);
   CholPlanDev plan_{};
 };
 

@@ -13,6 +13,7 @@
 namespace g2ohip {
 
 constexpr int kFactorThreads = 256;
+constexpr int kFwdChildren = 4;   // fused forward sweep: children per front handled by the factor kernel
 constexpr int kFactorThreadsGlobal = 512;
 constexpr int kChainU = 6;  // doubles per thread that carry an update matrix from one chain front to the next
 
@@ -705,8 +706,14 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       const int t = S.level_fronts[q];
       for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
         const FrontRec& R = recs[S.task_fronts[k]];
-        if (q < LL.lds_begin + LL.sm_count) LL.sm_idx_ints = std::max(LL.sm_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt);
-        else if (q < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt);
+        if (q < LL.glb_begin) {   // may the factor kernel carry the forward sweep of this launch?
+          const int nthr = LL.sm_count > 0 ? 128 : kFactorThreads;
+          bool ok = R.child_cnt <= kFwdChildren && R.ns * bs <= nthr;
+          for (int c = 0; c < R.child_cnt && ok; ++c) ok = cdesc[R.child_off + c].nbc * bs <= nthr;
+          if (!ok) LL.fuse_fwd = false;
+        }
+        if (q < LL.lds_begin + LL.sm_count) LL.sm_idx_ints = std::max(LL.sm_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt + R.crel_cnt);
+        else if (q < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt + R.crel_cnt);
         else LL.glb_idx_ints = std::max(LL.glb_idx_ints, 2 * R.asm_cnt);
       }
     }
@@ -855,6 +862,16 @@ __device__ __forceinline__ FrontRec load_front_rec(const FrontRec* p) {
   return rec;
 }
 
+__device__ __forceinline__ ChildDesc load_child_desc(const ChildDesc* p) {
+  ChildDesc cd;
+  typedef int __attribute__((may_alias)) alias_int;
+  const __attribute__((address_space(4))) int* rp = (const __attribute__((address_space(4))) int*)reinterpret_cast<uintptr_t>(p);
+  alias_int* ri = reinterpret_cast<alias_int*>(&cd);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(ChildDesc) / sizeof(int)); ++i) ri[i] = rp[i];
+  return cd;
+}
+
 // One workgroup factorises one TASK = a chain of frontal matrices f1 -> f2 -> ... in which every
 // front is the only child of the next one; the update matrix travels from front to front in
 // registers, only the last one of the chain is written to HBM.  A single-front task is the plain
@@ -880,9 +897,17 @@ template <int BS, bool USE_LDS, int NTC = (USE_LDS ? kFactorThreads : kFactorThr
 #endif
 __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G2OHIP_OCC256) : 1) front_factor_kernel(
     CholPlanDev P, int slot0, const double* __restrict__ A, double* __restrict__ scratch,
-    const long long* __restrict__ scratch_off, int idx_off_doubles) {
+    const long long* __restrict__ scratch_off, int idx_off_doubles, int wcap, const double* __restrict__ bperm,
+    double* __restrict__ yout) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int T = (BS % 3 == 0) ? 3 : BS;  // register tile edge of the trailing update
+  // Fused forward sweep (LDS fronts, bperm != nullptr): the right-hand side rides along as ONE EXTRA ROW of the
+  // front, kept in a small LDS vector tv[m].  The panel row solve turns its pivot part into y = L11^-1 b (one
+  // more row for the thread that owns it), one lane per trailing column leaves  w = b2 - L21 y  in its boundary
+  // part -- exactly cs_lsolve restricted to this front -- so the forward sweep costs no launch, no second
+  // read of L and almost no extra work.
+  // LDS: F | tv[wcap] | wprev[wcap] (update vector handed down a chain) | 2 diagonal-factor mailboxes | index tables
+  const bool fwd = USE_LDS && bperm != nullptr;
   constexpr int BB = BS * BS;
   constexpr int UNR = 6;                     // independent global loads in flight per thread
   constexpr int LA = BS / T;                 // look-ahead span in tiles
@@ -892,6 +917,8 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
   const int f_first = __builtin_amdgcn_readfirstlane(slot.x), t1 = __builtin_amdgcn_readfirstlane(slot.y), t0 = 0;
   double* F = USE_LDS ? smem : (scratch + scratch_off[blockIdx.x]);
   double* sd = smem + idx_off_doubles - 2 * (BB + BS);   // two mailboxes: [L_kk (BB) | 1/diag (BS)]
+  double* wprev = sd - wcap;
+  double* tv = wprev - wcap;
   int* s_q = reinterpret_cast<int*>(smem + idx_off_doubles);
   const int tid = threadIdx.x;
   constexpr int NT = NTC;
@@ -916,6 +943,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
     const int cs = USE_LDS ? BS : ld;   // column stride inside a block
     auto blk_off = [&](int bi, int bj) { return USE_LDS ? (bi * (bi + 1) / 2 + bj) * BB : bi * BS + ld * (bj * BS); };
     const int nF = USE_LDS ? nbt * (nbt + 1) / 2 * BB : m * m;
+    const int m_ext = fwd ? m + 1 : m;                  // rows taking part in the row solve (row m = tv)
     const int na = rec.asm_cnt;
     int* s_pos = s_q + na;
     // LDS-resident fronts stage the child maps and the triangle table; scratch-slab (large) fronts
@@ -924,6 +952,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
     int* s_tri_l = s_cmap_l + rec.cmap_cnt;
     const int* s_cmap = USE_LDS ? s_cmap_l : (P.cmap + rec.cmap_off);
     const int* s_tri = USE_LDS ? s_tri_l : P.tri;
+    const int* s_crel = USE_LDS ? s_tri_l + rec.tri_cnt : (P.crel + rec.crel_off);
     const bool carried = ncarry > 0;            // the only child arrived through registers
     // extend-add of up to N register-held elements per thread, branch-free: every LDS gather is issued
     // before the first add (elements past the end go to a sink slot next to the mailboxes)
@@ -966,18 +995,20 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
     // ---- stage the index tables in LDS, zero the front meanwhile.  The four tables are contiguous in LDS
     // (q | pos | cmap | tri); all their loads are issued before the first wait: one memory round trip.
     {
-      const int n1 = na, n2 = 2 * na, n3 = USE_LDS ? n2 + rec.cmap_cnt : n2, n4 = USE_LDS ? n3 + rec.tri_cnt : n2;
+      const int n1 = na, n2 = 2 * na, n3 = USE_LDS ? n2 + rec.cmap_cnt : n2, n5 = USE_LDS ? n3 + rec.tri_cnt : n2;
+      const int n4 = USE_LDS ? n5 + rec.crel_cnt : n2;   // (q | pos | cmap | tri | crel)
       const int* g_q = P.asm_q + rec.asm_off;
       const int* g_pos = P.asm_pos + rec.asm_off - n1;
       const int* g_cmap = P.cmap + rec.cmap_off - n2;
       const int* g_tri = P.tri - n3;
+      const int* g_crel = P.crel + rec.crel_off - n5;
       constexpr int SU = 4;
       for (int base = tid; base < n4; base += SU * NT) {
         int v[SU];
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
           const int i = base + u * NT;
-          const int* src = i < n1 ? g_q : (i < n2 ? g_pos : (i < n3 ? g_cmap : g_tri));
+          const int* src = i < n1 ? g_q : (i < n2 ? g_pos : (i < n3 ? g_cmap : (i < n5 ? g_tri : g_crel)));
           v[u] = (i < n4) ? src[i] : 0;
         }
 #pragma unroll
@@ -999,6 +1030,35 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       for (int u = 0; u < UC; ++u) {
         const int t = tid + u * NT;
         u0[u] = U0[t < nU0 ? t : 0];
+      }
+    }
+    // right-hand side and the children's update vectors (same round trip).  The host only fuses the forward
+    // sweep into launches whose fronts have <= kFwdChildren children with boundaries of <= NT scalars and
+    // <= NT pivot columns, so one value per thread and child suffices.
+    constexpr bool EARLY_W = NTC != 128;   // two-wave variant: registers are scarce, the launch is wide -> load at use
+    double bval = 0.0, wv[kFwdChildren];
+    int wn[kFwdChildren], wcrel[kFwdChildren], woff[kFwdChildren];
+    if (fwd) {
+      if (tid < npiv) bval = bperm[(size_t)rec.c0 * BS + tid];
+#pragma unroll
+      for (int c = 0; c < kFwdChildren; ++c) {
+        wn[c] = 0;
+        wcrel[c] = 0;
+        woff[c] = 0;
+        wv[c] = 0.0;
+        if (c < nch) {
+          int nbc_c, crel_c, woff_c;
+          if (c < 2) {
+            nbc_c = rec.ch[c].nbc; crel_c = rec.ch[c].crel_start; woff_c = rec.ch[c].w_off;
+          } else {
+            const ChildDesc cd = load_child_desc(P.cdesc + rec.child_off + c);
+            nbc_c = cd.nbc; crel_c = cd.crel_start; woff_c = cd.w_off;
+          }
+          wn[c] = nbc_c * BS;
+          wcrel[c] = crel_c;
+          woff[c] = woff_c;
+          if (EARLY_W && tid < wn[c] && !(carried && c == 0)) wv[c] = P.w[woff_c + tid];
+        }
       }
     }
     // ---- original entries (each block lands on a distinct tile)
@@ -1026,12 +1086,25 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
           if (dst[u] >= 0) F[dst[u]] = v[u];
       }
     }
+    if (fwd) {
+      for (int i = tid; i < m; i += NT) tv[i] = (i == tid) ? bval : 0.0;   // (npiv <= NT; bval = 0 beyond the pivot part)
+    }
     __syncthreads();
     STAMP();
+    // the children's update vectors are added in the same phases as their update matrices (one child at a
+    // time: rows may coincide); returns true when the fast path handled them
+    auto add_child_vec = [&](int ch) {
+      if (!fwd) return;
+#pragma unroll
+      for (int c = 0; c < kFwdChildren; ++c)   // (compile-time register index)
+        if (c == ch && tid < wn[c])
+          tv[s_crel[wcrel[c] + tid / BS] * BS + tid % BS] += (carried && c == 0) ? wprev[tid] : (EARLY_W ? wv[c] : P.w[woff[c] + tid]);
+    };
     // ---- extend-add of the children (sequential over children: destinations may overlap).  Update
     // matrices are packed lower-triangular blocks (row-major block order); cmap gives, per packed
     // block, the destination block (row | col << 16) in this front.
     if (carried) {
+      add_child_vec(0);
       if (USE_LDS) {
         scatter_add(ucarry, std::integral_constant<int, kCarry>(), ncarry, rec.ch[0].cmap_start);
       } else {
@@ -1060,6 +1133,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
           u1[DUAL ? u : 0] = U1[t < nU1 ? t : 0];
         }
       }
+      if (nch > 0) add_child_vec(0);
       if (USE_LDS) {
         scatter_add(u0, std::integral_constant<int, UC>(), nU0, rec.ch[0].cmap_start);
         if (nch > 1) {
@@ -1072,6 +1146,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
             }
           }
           __syncthreads();
+          add_child_vec(1);
           scatter_add(DUAL ? u1 : u0, std::integral_constant<int, UC>(), nU1, rec.ch[1].cmap_start);
         }
       } else {
@@ -1101,6 +1176,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
     } else {
       for (int ch = 0; ch < nch; ++ch) {
         const ChildDesc cd = P.cdesc[rec.child_off + ch];  // wave-uniform
+        add_child_vec(ch);
         const int* cmap = s_cmap + cd.cmap_start;
         const double* Uc = P.U + cd.U_off;
         const int nU = cd.nbc * (cd.nbc + 1) / 2 * BB;
@@ -1187,11 +1263,13 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
         for (int r = 0; r < BS; ++r) Lk[r][c] = (r > c) ? Lb[r + BS * c] : 0.0;
       }
       // rows below the diagonal block: x * Lkk' = row
-      for (int i = k0 + BS + tid; i < m; i += NT) {
+      for (int i = k0 + BS + tid; i < m_ext; i += NT) {   // (row m = the right-hand side, kept in tv)
         double x[BS];
-        double* Fr = F + blk_off(i / BS, kb) + i % BS;
+        const bool rhs_row = i == m;
+        double* Fr = rhs_row ? tv + k0 : F + blk_off(i / BS, kb) + i % BS;
+        const int rs = rhs_row ? 1 : cs;
 #pragma unroll
-        for (int c = 0; c < BS; ++c) x[c] = Fr[cs * c];
+        for (int c = 0; c < BS; ++c) x[c] = Fr[rs * c];
 #pragma unroll
         for (int c = 0; c < BS; ++c) {
           double v = x[c];
@@ -1200,7 +1278,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
           x[c] = v * inv[c];
         }
 #pragma unroll
-        for (int c = 0; c < BS; ++c) Fr[cs * c] = x[c];
+        for (int c = 0; c < BS; ++c) Fr[rs * c] = x[c];
       }
       if (kb < 2) STAMP();
       __syncthreads();
@@ -1248,10 +1326,29 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
         if (kb < 2) STAMP();
       } else {
         const int first = lookahead ? NLA + tid - 64 : tid, stride = lookahead ? NT - 64 : NT;
+        if (fwd) {   // right-hand side: tv[j] -= L[j, k0..k0+BS) . y_kb, one lane per trailing column
+          for (int j = r0 + (lookahead ? tid - 64 : tid); j < m; j += stride) {
+            const double* Lj = F + blk_off(j / BS, kb) + j % BS;
+            double v = tv[j];
+#pragma unroll
+            for (int q = 0; q < BS; ++q) v -= Lj[cs * q] * tv[k0 + q];
+            tv[j] = v;
+          }
+        }
         for (int idx = first; idx < ntiles; idx += stride) update_tile(s_tri[idx]);
       }
       __syncthreads();
       STAMP();
+    }
+    // ---- forward-sweep results: y (pivot part) to HBM, w (boundary part) to the next chain front or to HBM
+    if (fwd) {
+      for (int i = tid; i < npiv; i += NT) yout[(size_t)rec.c0 * BS + i] = tv[i];
+      if (ti + 1 < t1) {
+        for (int i = tid; i < nbd * BS; i += NT) wprev[i] = tv[npiv + i];
+      } else {
+        double* wf = P.w + rec.w_off;
+        for (int i = tid; i < nbd * BS; i += NT) wf[i] = tv[npiv + i];
+      }
     }
     // ---- write the L panel (m x npiv) and the reciprocals of its diagonal
     double* Lg = P.L + rec.L_off;
@@ -1546,32 +1643,33 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
 template <int BS>
 void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long long* d_scratch_off, double* d_scratch,
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
-                         int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, hipStream_t st) {
+                         int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, int wcap,
+                         const double* bperm, double* yout, hipStream_t st) {
   if (sm_count > 0) {   // wide launch: two waves per front
-    const int idx_off = sm_max_m + 2 * (BS * BS + BS);
+    const int idx_off = sm_max_m + 2 * wcap + 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(sm_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, true, 128>), dim3(sm_count), dim3(128), sh, st, P, lds_begin, dA, d_scratch,
-                       d_scratch_off + lds_begin, idx_off);
+                       d_scratch_off + lds_begin, idx_off, wcap, bperm, yout);
     lds_begin += sm_count;
     lds_count -= sm_count;
   }
   if (lds_count > 0) {
-    const int idx_off = lds_max_m + 2 * (BS * BS + BS);   // F (packed doubles) | diagonal-factor mailboxes | index lists
+    const int idx_off = lds_max_m + 2 * wcap + 2 * (BS * BS + BS);   // F (packed doubles) | tv | wprev | mailboxes | index lists
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(lds_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, true>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
-                       d_scratch_off + lds_begin, idx_off);
+                       d_scratch_off + lds_begin, idx_off, wcap, bperm, yout);
   }
   if (glb_count > 0) {
     const int idx_off = 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(glb_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, false>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P, glb_begin, dA,
-                       d_scratch, d_scratch_off + glb_begin, idx_off);
+                       d_scratch, d_scratch_off + glb_begin, idx_off, 0, (const double*)nullptr, (double*)nullptr);
   }
 }
 
 }  // namespace
 
-void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, hipStream_t st) {
+void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st) {
 #ifdef G2OHIP_CHOL_STAMPS
   if (d_dbg.p) {
     plan_.dbg = d_dbg.p + 64 * (dbg_launch_++ % 64);
@@ -1580,22 +1678,25 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, hipS
   switch (bs_) {
     case 3:
       launch_factor_level<3>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, st);
+                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, LL.max_m,
+                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, st);
       break;
     case 6:
       launch_factor_level<6>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, st);
+                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, LL.max_m,
+                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, st);
       break;
     case 7:
       launch_factor_level<7>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, st);
+                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, LL.max_m,
+                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, st);
       break;
     default:
       throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
   }
 }
 
-void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st) {
+void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, bool fwd) {
   if (!analyzed_) throw StateFailure("SparseCholesky::factor before analyze");
   static bool attr_done = false;
   if (!attr_done) {
@@ -1616,7 +1717,14 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st) {
     dbg_launch_ = 0;
   }
 #endif
-  for (const LevelLaunch& LL : launches_[phase]) launch_factor(LL, dA, st);
+  for (const LevelLaunch& LL : launches_[phase]) {
+    const bool fused = fwd && LL.fuse_fwd;
+    launch_factor(LL, dA, fused, st);
+    // what the factor kernel did not carry (fronts too large for LDS, launches outside the fused kernel's
+    // limits) gets its forward step inside the same level
+    if (fwd && !fused) launch_solve(LL, true, st);
+    else if (fwd && LL.glb_count > 0) launch_solve(LL, true, st, /*glb_only=*/true);
+  }
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 
@@ -1625,9 +1733,21 @@ void SparseCholesky::factor(const double* dA, hipStream_t st) {
   factor_phase(dA, 1, st);
 }
 
-void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st) {
+// Factorisation with the forward sweep fused in (what every reference solve() call amounts to: it refactorises
+// each time, linear_solver_csparse.h:106-142), then the backward sweep.
+void SparseCholesky::factor_solve(const double* dA, const double* d_b, double* d_x, hipStream_t st) {
+  solve_begin(d_b, st);
+  factor_phase(dA, 0, st, true);
+  factor_phase(dA, 1, st, true);
+  solve_backward_phase(1, st);
+  solve_backward_phase(0, st);
+  solve_end(d_x, st);
+}
+
+void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only) {
   const size_t panel_limit = 48 * 1024;  // bytes of L panel staged in LDS
-  int count = LL.lds_count + LL.glb_count;
+  const int count = glb_only ? LL.glb_count : LL.lds_count + LL.glb_count;
+  const int slot0 = glb_only ? LL.glb_begin : LL.lds_begin;
   if (count == 0) return;
   bool panel = (size_t)LL.max_panel * 8 <= panel_limit;
   int cap = panel ? LL.max_panel : 0;
@@ -1636,14 +1756,14 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
 #define G2OHIP_SOLVE_LAUNCH(BS_)                                                                                              \
   if (fwd) {                                                                                                                  \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, LL.lds_begin, d_xp.p, d_y.p, cap, LL.max_m);  \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m);  \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, LL.lds_begin, d_xp.p, d_y.p, cap, LL.max_m); \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m); \
   } else {                                                                                                                    \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, LL.lds_begin, d_y.p, d_xp.p, cap, LL.max_m); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_y.p, d_xp.p, cap, LL.max_m); \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, LL.lds_begin, d_y.p, d_xp.p, cap, LL.max_m); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_y.p, d_xp.p, cap, LL.max_m); \
   }
   switch (bs_) {
     case 3: G2OHIP_SOLVE_LAUNCH(3) break;
