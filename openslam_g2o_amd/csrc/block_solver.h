@@ -151,6 +151,9 @@ class BlockSolver {
   DevBuf<double> d_lam;                    // {lambda_pose, lambda_landmark}: virtual damping (Schur mode)
   double lam_pose_ = 0.0, lam_lm_ = 0.0;
   std::vector<unsigned char> lam_mask_h_;
+  DevBuf<int> d_active;                    // multi-GPU: reduced-system blocks this rank forms (schur_reduce)
+  int n_active_ = -1;                      // -1: all
+  std::vector<int> rd_cnt_h_;
   DevBuf<double> d_Hpp, d_Hpl, d_Hll, d_Hschur, d_Dinv, d_db, d_b, d_x, d_bschur, d_bkP, d_bkL, d_red;
   DevBuf<int> d_pp_diag, d_pl_colptr, d_pl_row, d_pl_lm;
   DevBuf<int> d_hs_src;                    // Hschur block -> Hpp block id or -1

@@ -574,11 +574,14 @@ __global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const 
                                                               const double* __restrict__ Pd, double* __restrict__ Hs,
                                                               const int* __restrict__ hs_diag, const double* __restrict__ Pr,
                                                               const double* __restrict__ b, double* __restrict__ bschur,
-                                                              const double* __restrict__ lam, const unsigned char* __restrict__ lam_mask) {
+                                                              const double* __restrict__ lam, const unsigned char* __restrict__ lam_mask,
+                                                              const int* __restrict__ active) {
   constexpr int BB = PD * PD;
-  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (t >= (size_t)nDst * BB) return;
-  const int d = (int)(t / BB), e = (int)(t % BB);
+  const size_t ta = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (ta >= (size_t)nDst * BB) return;
+  // multi-GPU: only the blocks this rank produces or consumes (the others stay zero)
+  const int e = (int)(ta % BB), d = active ? active[ta / BB] : (int)(ta / BB);
+  const size_t t = (size_t)d * BB + e;
   const int src = hs_src[d];
   const int pose = hs_diag[d];
   double v = src >= 0 ? Hpp[(size_t)src * BB + e] : 0.0;
@@ -1366,6 +1369,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       // per destination: its partial slots in tile order
       std::vector<int> rd_ptr(hs_nnzb + 1, 0), rd_slot(td_dest.size());
       for (int d = 0; d < hs_nnzb; ++d) rd_ptr[d + 1] = rd_ptr[d] + rd_cnt[d];
+      rd_cnt_h_ = rd_cnt;
       {
         std::vector<int> w(rd_ptr.begin(), rd_ptr.end() - 1);
         for (size_t k = 0; k < td_dest.size(); ++k) rd_slot[w[td_dest[k]]++] = (int)k;
@@ -1441,6 +1445,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   chol_->opt = chol_opt;
   if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
   else chol_->analyze(nP, pp_colptr.data(), pp_row.data(), st_);
+  n_active_ = -1;
   {
     const double zero2[2] = {0.0, 0.0};
     d_lam.upload(zero2, 2, st_);
@@ -1458,6 +1463,18 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     }
     d_lam_mask.upload(m, st_);
     lam_mask_h_ = m;
+    if (schur_) {
+      // reduced-system blocks this rank has to form: the ones it consumes (own or shared fronts) and the ones
+      // it contributes to; everything else stays zero (cleared below once)
+      std::vector<int> act;
+      for (int d = 0; d < (int)cons.size(); ++d)
+        if (cons[d] == chol_opt.rank || cons[d] < 0 || (d < (int)rd_cnt_h_.size() && rd_cnt_h_[d] > 0)) act.push_back(d);
+      n_active_ = (int)act.size();
+      if (act.empty()) act.push_back(0);
+      d_active.upload(act, st_);
+      G2OHIP_HIP_CHECK(hipMemsetAsync(d_Hschur.p, 0, hs_row.size() * (size_t)p * p * sizeof(double), st_));
+      G2OHIP_HIP_CHECK(hipMemsetAsync(d_bschur.p, 0, (size_t)nP * p * sizeof(double), st_));
+    }
   }
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   structured_ = true;
@@ -1780,9 +1797,12 @@ void BlockSolver::solve_schur_impl() {
     }                                                                                                                          \
     prof.end(KernelProf::kSchurBlocks, st_);                                                                                   \
     prof.begin(KernelProf::kSchurRhs, st_);                                                                                    \
-    hipLaunchKernelGGL((schur_reduce_kernel<P_>), dim3(grid_for((size_t)hs_nnzb * P_ * P_)), dim3(kThreads), 0, st_, hs_nnzb,     \
-                       d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, d_lam.p, \
-                       chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr);                                      \
+    const int n_red = n_active_ >= 0 ? n_active_ : hs_nnzb;                                                                    \
+    if (n_red > 0)                                                                                                             \
+      hipLaunchKernelGGL((schur_reduce_kernel<P_>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red,       \
+                         d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, \
+                         d_lam.p, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr,                              \
+                         n_active_ >= 0 ? d_active.p : (const int*)nullptr);                                                     \
     prof.end(KernelProf::kSchurRhs, st_);                                                                                      \
   } else
   G2OHIP_SCHUR(6, 3)

@@ -246,6 +246,7 @@ class ShardedBlockSolver:
             my = np.flatnonzero(lm_owner == self.rank)
             self.boundary = boundary_blocks(keys, consumer, prow, pcol, plm, lm_owner, nP)
             self.bposes, self.halo = boundary_poses(prob["v1"], lm, pose_owner, lm_owner)
+            self.consumer = consumer
             self.pose_owner, self.nnzb_reduced = pose_owner, len(keys)
             rows, cols = (keys % nP).astype(np.int32), (keys // nP).astype(np.int32)
             del prow, pcol, plm
@@ -321,9 +322,14 @@ class ShardedBlockSolver:
             nP = self.local.nP
             x = self._device_tensor(capi.ARR_X)
             sub = dict(H=H, idx=idx, b=b, xbuf=self._device_tensor(capi.ARR_EXCHANGE), xp=self._device_tensor(capi.ARR_XP))
+            # after an all-reduce a rank keeps only what it consumes: a block / pose it neither consumes nor produces
+            # is not re-formed by its schur_reduce, so a stale sum there would be added again next iteration
+            keep = lambda o: torch.from_numpy(((o == self.rank) | (o < 0)).astype(np.float64)).to(dev)[:, None]
+            sub.update(hkeep=keep(self.consumer[self.boundary]), bkeep=keep(self.pose_owner[self.bposes]),
+                       bkeep_all=keep(self.pose_owner), b2=b.view(nP, self.p))
             if self.x_exchange == "halo":
                 nb, p = len(self.boundary), self.p
-                sub.update(b2=b.view(nP, p), x2=x[:nP * p].view(nP, p),
+                sub.update(x2=x[:nP * p].view(nP, p),
                            bidx=torch.from_numpy(self.bposes).to(dev), hidx=torch.from_numpy(self.halo).to(dev),
                            hmine=torch.from_numpy((self.pose_owner[self.halo] == self.rank).astype(np.float64)).to(dev)[:, None],
                            buf1=torch.zeros(nb * p * p + len(self.bposes) * p, dtype=torch.float64, device=dev),
@@ -377,8 +383,8 @@ class ShardedBlockSolver:
             torch.index_select(t["H"], 0, t["idx"], out=buf1[:nbb].view(-1, p * p))
             torch.index_select(t["b2"], 0, t["bidx"], out=buf1[nbb:].view(-1, p))
             self.comm.all_reduce_sum([buf1])
-            t["H"].index_copy_(0, t["idx"], buf1[:nbb].view(-1, p * p))
-            t["b2"].index_copy_(0, t["bidx"], buf1[nbb:].view(-1, p))
+            t["H"].index_copy_(0, t["idx"], buf1[:nbb].view(-1, p * p) * t["hkeep"])
+            t["b2"].index_copy_(0, t["bidx"], buf1[nbb:].view(-1, p) * t["bkeep"])
         self.local.solveReducedLocal()
         self.comm.all_reduce_sum([t["xbuf"]])
         self.local.solveReducedShared()
@@ -418,8 +424,9 @@ class ShardedBlockSolver:
         if len(self.boundary):
             buf = t["H"].index_select(0, t["idx"])
             self.comm.all_reduce_sum([buf])
-            t["H"].index_copy_(0, t["idx"], buf)
+            t["H"].index_copy_(0, t["idx"], buf * t["hkeep"])
         self.comm.all_reduce_sum([t["b"]])
+        t["b2"].mul_(t["bkeep_all"])
         self.local.solveReducedLocal()          # own subtrees: factor + forward sweep, pack the roots
         self.comm.all_reduce_sum([t["xbuf"]])
         self.local.solveReducedShared()         # shared top, then back down the own subtrees; x_p masked
