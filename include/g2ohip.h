@@ -144,6 +144,9 @@ const double* g2ohip_b_device(g2ohip_solver* s);
 int g2ohip_multiply_hessian(g2ohip_solver* s, double* dest_host, const double* src_host);
 
 int g2ohip_sync(g2ohip_solver* s);
+/* HIP-event timing on the solver's stream.  0: off; 1: every kernel slot (g2ohip_kernel_time) and the stage
+ * timers of g2ohip_get_stats; 2 + k: kernel slot k only (two event records per iteration -- the records are
+ * not free next to sub-millisecond iterations). */
 int g2ohip_set_profiling(g2ohip_solver* s, int enabled);
 int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out);
 /* Per-kernel HIP-event timing on the solver's stream (while profiling is enabled): slot in

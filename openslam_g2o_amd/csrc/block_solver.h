@@ -107,9 +107,9 @@ class BlockSolver {
   CholOptions chol_opt;
   size_t schur_tile_bytes = 48 * 1024;     // LDS budget of one Schur tile
   bool ba_fused = true;                    // evaluate BA errors/Jacobians inside the assembly kernels (no J arrays)
-  // hipGraph replay of the fixed kernel sequences (build_system, solve_schur, the reduced solve phases,
-  // back-substitution): the launch-bound tree sweeps cost ~75 launches per iteration, which is what limits
-  // a rank once the per-rank work shrinks (multi-GPU).  Needs a non-default stream; off while profiling.
+  // hipGraph replay of the launch-bound kernel sequences (one launch per tree level: factorisation with the
+  // fused forward sweep, backward sweep): ~30 launches per iteration, which is what limits a rank once the
+  // per-rank work shrinks (multi-GPU).  Needs a non-default stream.  Timing events sit between the graphs.
   bool use_graph = false;
   void invalidate_graphs();
   bool mask_solution = true;               // solve_reduced_shared zeroes the x_p entries other ranks own (all-reduce of x_p)
@@ -132,7 +132,7 @@ class BlockSolver {
   // host patterns
   std::vector<int> pp_colptr, pp_row, pp_diag, pl_colptr, pl_row, hs_colptr, hs_row;
   // device matrices
-  enum Seg { kSegBuild = 0, kSegSchur, kSegReduced, kSegBack, kSegLocal, kSegShared, kNumSeg };
+  enum Seg { kSegFactor = 0, kSegBackward, kSegLocal, kSegShared, kSegSharedBack, kNumSeg };
   struct GraphSeg {
     hipGraph_t g = nullptr;
     hipGraphExec_t e = nullptr;

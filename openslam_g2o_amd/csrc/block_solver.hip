@@ -1526,7 +1526,7 @@ void BlockSolver::invalidate_graphs() {
 
 template <class F>
 void BlockSolver::run_seg(int id, F&& body) {
-  if (!use_graph || profiling || prof.enabled || st_ == nullptr) {
+  if (!use_graph || st_ == nullptr) {
     body();
     return;
   }
@@ -1558,7 +1558,7 @@ void BlockSolver::build_system() {
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   for (auto& esp : sets_)
     if (esp->n > 0 && !esp->has_data) throw StateFailure("build_system: edge data missing for a set");
-  run_seg(kSegBuild, [&] { build_system_impl(); });
+  build_system_impl();   // a handful of kernels: launched plainly
   system_built_ = true;
 }
 
@@ -1757,7 +1757,7 @@ void BlockSolver::solve_schur() {
   require_structure();
   if (!schur_) return;
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  run_seg(kSegSchur, [&] { solve_schur_impl(); });
+  solve_schur_impl();
 }
 
 void BlockSolver::solve_schur_impl() {
@@ -1838,7 +1838,7 @@ int BlockSolver::solve_reduced() {
     if (schur_) chol_->analyze(nP_, hs_colptr.data(), hs_row.data(), st_);
     else chol_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
   }
-  run_seg(kSegReduced, [&] { solve_reduced_device(); });
+  solve_reduced_device();
   bool bad = chol_->failed(st_);   // synchronises
   if (profiling) {
     times.numeric = tn_.seconds();
@@ -1851,20 +1851,26 @@ void BlockSolver::solve_reduced_device() {
   // factorisation with the forward sweep fused into it, then the backward sweep
   const double* Hred = schur_ ? d_Hschur.p : d_Hpp.p;
   const double* bred = schur_ ? d_bschur.p : d_b.p;
+  // The two launch-bound sequences (one launch per tree level) are hipGraph segments; the timing events sit
+  // between the segments, so per-slot times stay available while the graphs replay.
   if (profiling) tn_.start(st_);
-  chol_->solve_begin(bred, st_);
   prof.begin(KernelProf::kCholFactor, st_);
-  chol_->factor_phase(Hred, 0, st_, true);
-  chol_->factor_phase(Hred, 1, st_, true);
+  run_seg(kSegFactor, [&] {
+    chol_->solve_begin(bred, st_);
+    chol_->factor_phase(Hred, 0, st_, true);
+    chol_->factor_phase(Hred, 1, st_, true);
+  });
   prof.end(KernelProf::kCholFactor, st_);
   if (profiling) {
     tn_.stop(st_);
     tl_.start(st_);
   }
   prof.begin(KernelProf::kCholSolve, st_);
-  chol_->solve_backward_phase(1, st_);
-  chol_->solve_backward_phase(0, st_);
-  chol_->solve_end(d_x.p, st_);
+  run_seg(kSegBackward, [&] {
+    chol_->solve_backward_phase(1, st_);
+    chol_->solve_backward_phase(0, st_);
+    chol_->solve_end(d_x.p, st_);
+  });
   prof.end(KernelProf::kCholSolve, st_);
   if (profiling) tl_.stop(st_);
 }
@@ -1880,33 +1886,39 @@ void BlockSolver::set_partition(int rank, int world) {
 void BlockSolver::solve_reduced_local() {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  run_seg(kSegLocal, [&] { solve_reduced_local_impl(); });
+  solve_reduced_local_impl();
 }
 
 void BlockSolver::solve_reduced_local_impl() {
-  chol_->solve_begin(schur_ ? d_bschur.p : d_b.p, st_);
   prof.begin(KernelProf::kCholFactor, st_);
-  chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 0, st_, true);   // forward sweep fused in
+  run_seg(kSegLocal, [&] {
+    chol_->solve_begin(schur_ ? d_bschur.p : d_b.p, st_);
+    chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 0, st_, true);   // forward sweep fused in
+    chol_->pack_exchange(st_);
+  });
   prof.end(KernelProf::kCholFactor, st_);
-  chol_->pack_exchange(st_);
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 
 void BlockSolver::solve_reduced_shared() {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  run_seg(kSegShared, [&] { solve_reduced_shared_impl(); });
+  solve_reduced_shared_impl();
 }
 
 void BlockSolver::solve_reduced_shared_impl() {
-  chol_->unpack_exchange(st_);
   prof.begin(KernelProf::kCholFactor, st_);
-  chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 1, st_, true);
+  run_seg(kSegShared, [&] {
+    chol_->unpack_exchange(st_);
+    chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 1, st_, true);
+  });
   prof.end(KernelProf::kCholFactor, st_);
   prof.begin(KernelProf::kCholSolve, st_);
-  chol_->solve_backward_phase(1, st_);
-  chol_->solve_backward_phase(0, st_);
-  if (mask_solution) chol_->mask_solution(st_);
+  run_seg(kSegSharedBack, [&] {
+    chol_->solve_backward_phase(1, st_);
+    chol_->solve_backward_phase(0, st_);
+    if (mask_solution) chol_->mask_solution(st_);
+  });
   prof.end(KernelProf::kCholSolve, st_);
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
@@ -1929,7 +1941,7 @@ void BlockSolver::solve_back_substitute() {
   require_structure();
   if (!schur_) return;
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  run_seg(kSegBack, [&] { solve_back_substitute_impl(); });
+  solve_back_substitute_impl();
 }
 
 void BlockSolver::solve_back_substitute_impl() {

@@ -305,8 +305,10 @@ int g2ohip_sync(g2ohip_solver* s) {
 
 int g2ohip_set_profiling(g2ohip_solver* s, int enabled) {
   REQUIRE_HANDLE(s);
-  s->impl->profiling = enabled != 0;
+  // 0: off; 1: every kernel slot + the stage timers of g2ohip_get_stats; 2 + k: kernel slot k only
+  s->impl->profiling = enabled == 1;
   s->impl->prof.enabled = enabled != 0;
+  s->impl->prof.only = enabled >= 2 ? enabled - 2 : -1;
   return G2OHIP_OK;
 }
 

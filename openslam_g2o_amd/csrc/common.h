@@ -139,6 +139,7 @@ struct KernelProf {
     return (s >= 0 && s < kNumSlots) ? n[s] : "?";
   }
   bool enabled = false;
+  int only = -1;   // >= 0: time this slot only (two events per iteration instead of ~20: the records are not free)
   struct Pair { hipEvent_t a, b; };
   std::vector<Pair> pending[kNumSlots];
   std::vector<hipEvent_t> pool;
@@ -149,13 +150,13 @@ struct KernelProf {
     hipEvent_t e; G2OHIP_HIP_CHECK(hipEventCreate(&e)); return e;
   }
   void begin(int slot, hipStream_t st) {
-    if (!enabled) return;
+    if (!enabled || (only >= 0 && slot != only)) return;
     Pair p{get(), get()};
     G2OHIP_HIP_CHECK(hipEventRecord(p.a, st));
     pending[slot].push_back(p);
   }
   void end(int slot, hipStream_t st) {
-    if (!enabled) return;
+    if (!enabled || (only >= 0 && slot != only)) return;
     G2OHIP_HIP_CHECK(hipEventRecord(pending[slot].back().b, st));
   }
   // synchronises the recorded events and folds them into total/launches
