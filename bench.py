@@ -45,8 +45,10 @@ def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2):
     kb["back_substitute"] = E * 8 * p * l + L * 8 * (l * l + 2 * l) + P * 8 * p
     n = p * P
     nnz_up = S * p * p  # upper blocks of Hschur (diagonal blocks counted full)
-    kb["chol_factor(all levels)"] = 8 * nnz_up + 8 * nnzL
-    kb["chol_solve(all levels)"] = 16 * nnzL + 24 * n
+    # the forward sweep is fused into the factorisation (it reads b and writes y, L never leaves LDS in between);
+    # the backward sweep reads L once
+    kb["chol_factor(all levels)"] = 8 * nnz_up + 8 * nnzL + 16 * n
+    kb["chol_solve(all levels)"] = 8 * nnzL + 24 * n
     stage = {
         "B_asm": E * (8 * (d * p + d * l + d * d + d) + 8) + E * 8 * p * l + P * 8 * (p * p + p) + L * 8 * (l * l + l),
         "B_schur": (E * 8 * p * l + L * 8 * (l * l + l) + P * 8 * (p * p + p)) + (L * 8 * l * l + S * 8 * p * p + P * 8 * p),

@@ -394,7 +394,10 @@ __global__ void __launch_bounds__(kThreads) landmark_inverse_kernel(int nL, cons
 // tile's contributor entries.  Each destination block touched by the tile is owned by G lanes that walk
 // its entry list out of LDS (no atomics, fixed order) and write one partial block to HBM.
 template <int PD, int LD, int G>
-__global__ void __launch_bounds__(kThreads) schur_tile_kernel(const int* __restrict__ tile_lm0, const int* __restrict__ tile_td0,
+#ifndef G2OHIP_SCHUR_OCC
+#define G2OHIP_SCHUR_OCC 3
+#endif
+__global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(const int* __restrict__ tile_lm0, const int* __restrict__ tile_td0,
                                                             const int* __restrict__ pl_colptr, const double* __restrict__ Hpl,
                                                             const double* __restrict__ Dinv, const double* __restrict__ bl,
                                                             const int* __restrict__ td_diag, const int* __restrict__ td_ptr,

@@ -6,9 +6,9 @@ other tracing domains next to --pmc):
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/f -o f -- python bench.py --no-cpu-baseline --steps 2 --warmup 1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/w -o w -- python bench.py --no-cpu-baseline --steps 2 --warmup 1
-  python tools/pmc_traffic.py out/f/f_results.db out/w/w_results.db 2 > profiles/rN_pmc_traffic.json
+  python tools/pmc_traffic.py out/f/f_results.db out/w/w_results.db > profiles/rN_pmc_traffic.json
 Values: KiB per counter summed over the launches of a slot in the LAST bench iteration (identified as
-the last 1/steps_total share of each kernel's dispatches).  On gfx950 FETCH_SIZE tallies 64 B per 128 B
+the last 1/iterations share of each kernel's dispatches; iterations = dispatches of a once-per-iteration kernel).  On gfx950 FETCH_SIZE tallies 64 B per 128 B
 request for wide streaming reads, so hbm_bytes_per_step = (2*FETCH + WRITE) KiB * 1024; hbm_bytes_raw
 leaves FETCH unscaled (gather-type access is uncalibrated: the truth lies between the two)."""
 import json
@@ -27,7 +27,7 @@ SLOTS = [("assemble_vertex(pose)", ("ba_assemble_poses", "assemble_vertex_kernel
          ("set_lambda/restore", ("lambda_kernel",))]
 
 
-def per_kernel(path, iters):
+def per_kernel(path, iters=None):
     db = sqlite3.connect(path)
     tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
@@ -38,6 +38,9 @@ def per_kernel(path, iters):
     by = {}
     for name, start, val in rows:
         by.setdefault(name, []).append(val)
+    if iters is None:   # bench iterations in the trace = dispatches of a kernel that runs once per iteration
+        once = [len(v) for n, v in by.items() if "back_substitute_kernel" in n or "landmark_inverse_kernel" in n]
+        iters = max(once) if once else 1
     out = {}
     for name, vals in by.items():
         n = len(vals) // iters if len(vals) >= iters else len(vals)
@@ -46,8 +49,7 @@ def per_kernel(path, iters):
 
 
 def main():
-    iters = int(sys.argv[3]) + 1 if len(sys.argv) > 3 else 3     # warmup 1 + steps
-    f, w = per_kernel(sys.argv[1], iters), per_kernel(sys.argv[2], iters)
+    f, w = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
     res = {"_note": __doc__.split("Values:")[1].strip().replace("\n", " ")}
     for slot, keys in SLOTS:
         fk = sum(v for n, (v, c) in f.items() if any(k in n for k in keys))
