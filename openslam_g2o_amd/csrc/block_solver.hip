@@ -403,11 +403,9 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
                                                             const int* __restrict__ td_diag, const int* __restrict__ td_ptr,
                                                             const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm,
                                                             double* __restrict__ Pd,
-                                                            double* __restrict__ Pr, long long* __restrict__ dbg) {
+                                                            double* __restrict__ Pr) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int PL = PD * LD;
-  long long* dbgp = (dbg && blockIdx.x == 1000 && threadIdx.x == 0) ? dbg : nullptr;
-  if (dbgp) dbgp[0] = wall_clock64();
   const int t = xcd_swizzle(blockIdx.x, gridDim.x);
   const int* tm = tile_lm0 + (size_t)t * 8;   // packed tile record (see build_structure)
   const int l0 = tm[0], l1 = tm[1], q0 = tm[2], nslots = tm[3], nlm = l1 - l0;
@@ -483,7 +481,6 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
     if (ndp - 1 > NT) stage_copy<2>(ddiag + NT, td_diag + td0 + NT, ndp - 1 - NT, tid, NT);
   }
   __syncthreads();
-  if (dbgp) dbgp[1] = wall_clock64();
   // G lanes per destination block = GC column parts x GE entry parts: a lane owns PD/GC columns of the
   // block (PD*PD/GC accumulator registers instead of PD*PD: what keeps 3 workgroups on a CU) and walks
   // every GE-th entry; the GE partial sums are combined with DPP (fixed order: deterministic).
@@ -498,7 +495,6 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
   };
   const int grp = tid / G, g = tid % G, ngroups = NT / G;
   const int gc = g % GC, ge = g / GC;
-  int dk = 2;
   for (int ld = td0 + grp; ld < td1; ld += ngroups) {
     double acc[PD * NC], cacc[PD];
 #pragma unroll
@@ -565,9 +561,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
       for (int r = 0; r < PD; ++r)
         if (GE == 1 || (r % GE) == ge) Pr[(size_t)ld * PD + r] = cacc[r];
     }
-    if (dbgp && dk < 8) dbgp[dk++] = wall_clock64();
   }
-  if (dbgp) { dbgp[9] = nslots; dbgp[10] = nlm; dbgp[11] = td1 - td0; dbgp[12] = ne; }
 }
 
 // K5+K7+K8, pass 2: Hschur(d) = Hpp(d) - sum_tiles partial(d) (fixed tile order), bschur = b_p - sum partial_rhs
@@ -1769,7 +1763,7 @@ void BlockSolver::solve_schur_impl() {
   const int hs_nnzb = (int)hs_row.size();
   const int G = schur_group > 0 ? schur_group : pick_group((double)n_sc_ / std::max<long>(1, n_td_));
 #define G2OHIP_TILE_ARGS d_tile_lm0.p, d_tile_td0.p, d_pl_colptr.p, d_Hpl.p, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p, d_te_pack.p, \
-                         d_te_lm.p, d_Pd.p, d_Pr.p, (long long*)(getenv("G2OHIP_SCHUR_DEBUG") ? d_red.p : nullptr)
+                         d_te_lm.p, d_Pd.p, d_Pr.p
 #define G2OHIP_SCHUR(P_, L_)                                                                                                   \
   if (p_ == P_ && l_ == L_) {                                                                                                  \
     prof.begin(KernelProf::kLmInverse, st_);                                                                                   \
@@ -1815,18 +1809,6 @@ void BlockSolver::solve_schur_impl() {
   G2OHIP_SCHUR(3, 3) { throw ArgFailure("unsupported (pose_dim, landmark_dim) for Schur"); }
 #undef G2OHIP_SCHUR
 #undef G2OHIP_TILE_ARGS
-  if (getenv("G2OHIP_SCHUR_DEBUG")) {
-    static int once = 0;
-    if (once++ == 3) {
-      long long h[16];
-      G2OHIP_HIP_CHECK(hipMemcpyAsync(h, d_red.p, sizeof(h), hipMemcpyDeviceToHost, st_));
-      G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
-      fprintf(stderr, "[schur dbg] tile 1000: slots %lld lms %lld dests %lld entries %lld | stage %.2f us, dest rounds:", h[9], h[10], h[11], h[12],
-              (h[1] - h[0]) * 0.01);
-      for (int q = 2; q < 8 && h[q]; ++q) fprintf(stderr, " %.2f", (h[q] - h[q - 1]) * 0.01);
-      fprintf(stderr, " us\n");
-    }
-  }
   G2OHIP_HIP_CHECK(hipGetLastError());
   if (profiling) {
     ts_.stop(st_);
