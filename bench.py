@@ -37,8 +37,9 @@ def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2):
     kb["assemble_vertex(landmark)"] = E * 8 * (d * l + d * d + d) + L * 8 * (l * l + l)
     kb["assemble_offdiag(Hpl)"] = E * 8 * (d * p + d * l + d * d) + E * 8 * p * l
     # fused EdgeProjectXYZ2UV assembly (no Jacobian arrays): measurements + information in, blocks out
-    kb["fused:assemble_vertex(landmark)"] = E * 8 * (d + d * d + p * l + d) + L * 8 * (l + l * l + l) + P * 8 * 12
-    kb["fused:assemble_vertex(pose)"] = E * 8 * (d + d * d + l) + P * 8 * (12 + p * p + p)
+    # (information = identity is declared for the whole set, so it is not read per edge)
+    kb["fused:assemble_vertex(landmark)"] = E * 8 * (d + p * l + d) + L * 8 * (l + l * l + l) + P * 8 * 12
+    kb["fused:assemble_vertex(pose)"] = E * 8 * (d + l) + P * 8 * (12 + p * p + p)
     kb["landmark_inverse"] = L * 8 * (2 * l * l + 2 * l)
     kb["schur_tiles"] = E * 8 * p * l + L * 8 * (l * l + l) + S * 8 * p * p          # Hpl, Dinv, b_l in; one Hschur worth out
     kb["schur_reduce"] = pp_nnzb * 8 * p * p + 2 * S * 8 * p * p + 3 * P * 8 * p      # Hpp + partials in, Hschur + bschur out

@@ -32,6 +32,7 @@ struct EdgeSet {
   bool has_err = false;    // errors + information available (enough for chi2)
   // destination-major contributor lists
   DevBuf<int> vp_ptr, vp_ent, vl_ptr, vl_ent;  // per pose / per landmark: (edge << 1 | side)
+  std::vector<int> h_vp_ent;                   // host copy (pose-major copies of per-edge inputs)
   DevBuf<int> op_dst, op_ptr, op_ent;          // Hpp off-diagonal blocks: dest block id, (edge << 1 | transposed)
   DevBuf<int> ol_dst, ol_ptr, ol_ent;          // Hpl blocks
   int n_op = 0, n_ol = 0;
@@ -173,8 +174,11 @@ class BlockSolver {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
     double f = 0, cx = 0, cy = 0;
     DevBuf<int> cam_v, pt_v, cam_hidx, pt_hidx, edge_hpl;
+    bool omega_identity = false;   // information = identity for the whole set (info == NULL): not read per edge
     bool fused_ok = false;   // every Hpl block has exactly one observation: fused on-the-fly assembly allowed
     DevBuf<double> meas, cams, pts, cams_bak, pts_bak;
+    DevBuf<double> meas_pm, omega_pm;   // pose-major copies (observation-list order of the pose side)
+    DevBuf<int> pt_pm, cam_pm;
     bool has_backup = false;
   } ba_;
   EventTimer tq_, ts_, tn_, tl_, tb_;

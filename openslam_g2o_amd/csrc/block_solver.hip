@@ -831,7 +831,7 @@ __global__ void __launch_bounds__(kThreads) ba_assemble_landmarks_kernel(
     int nL, const int* __restrict__ vptr, const int* __restrict__ vent, const double* __restrict__ cams, const double* __restrict__ pts,
     const int* __restrict__ cam_v, const int* __restrict__ pt_v, const double* __restrict__ meas, const double* __restrict__ omega,
     const int* __restrict__ edge_hpl, double f, double cx, double cy, int kind, double delta, double* __restrict__ Hll,
-    double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ err) {
+    double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ err, int ident) {
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int lm = gt / G, g = gt % G;
   const bool active = lm < nL;
@@ -847,7 +847,12 @@ __global__ void __launch_bounds__(kThreads) ba_assemble_landmarks_kernel(
     X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
     load_vec<12>(cams + (size_t)cam_v[e] * 12, T);
     load_vec<2>(meas + (size_t)e * 2, z2);
-    load_vec<4>(omega + (size_t)e * 4, Op);
+    if (ident) {   // information().setIdentity() declared for the whole set: no per-edge read
+      Op[0] = Op[3] = 1.0;
+      Op[1] = Op[2] = 0.0;
+    } else {
+      load_vec<4>(omega + (size_t)e * 4, Op);
+    }
     BaEdgeLin L;
     ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
     store_vec<2>(err + (size_t)e * 2, L.r);
@@ -896,10 +901,10 @@ __global__ void __launch_bounds__(kThreads) ba_assemble_landmarks_kernel(
 // and reduce Hpp_ii / b_i with DPP butterflies.
 template <int G>
 __global__ void __launch_bounds__(kThreads) ba_assemble_poses_kernel(
-    int nP, const int* __restrict__ vptr, const int* __restrict__ vent, const double* __restrict__ cams, const double* __restrict__ pts,
-    const int* __restrict__ cam_v, const int* __restrict__ pt_v, const double* __restrict__ meas, const double* __restrict__ omega,
+    int nP, const int* __restrict__ vptr, const double* __restrict__ cams, const double* __restrict__ pts,
+    const int* __restrict__ cam_pm, const int* __restrict__ pt_pm, const double* __restrict__ meas_pm, const double* __restrict__ omega_pm,
     double f, double cx, double cy, int kind, double delta, double* __restrict__ Hpp, const int* __restrict__ diag_blk,
-    double* __restrict__ bp, int accumulate) {
+    double* __restrict__ bp, int accumulate, int ident) {
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int v = gt / G, g = gt % G;
   const bool active = v < nP;
@@ -911,17 +916,21 @@ __global__ void __launch_bounds__(kThreads) ba_assemble_poses_kernel(
   const int k0 = active ? vptr[v] : 0, k1 = active ? vptr[v + 1] : 0;
   double T[12];
   bool haveT = false;
-  for (int k = k0 + g; k < k1; k += G) {
-    const int e = vent[k] >> 1;
+  for (int k = k0 + g; k < k1; k += G) {   // (pose-major arrays: streaming reads)
     if (!haveT) {
-      load_vec<12>(cams + (size_t)cam_v[e] * 12, T);
+      load_vec<12>(cams + (size_t)cam_pm[k] * 12, T);
       haveT = true;
     }
     double X[3], z2[2], Op[4];
-    const double* Xp = pts + (size_t)pt_v[e] * 3;
+    const double* Xp = pts + (size_t)pt_pm[k] * 3;
     X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
-    load_vec<2>(meas + (size_t)e * 2, z2);
-    load_vec<4>(omega + (size_t)e * 4, Op);
+    load_vec<2>(meas_pm + (size_t)k * 2, z2);
+    if (ident) {
+      Op[0] = Op[3] = 1.0;
+      Op[1] = Op[2] = 0.0;
+    } else {
+      load_vec<4>(omega_pm + (size_t)k * 4, Op);
+    }
     BaEdgeLin L;
     ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, false, L);
     const double w = L.w;
@@ -1211,6 +1220,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       group_by(nP, dp, pp_, ptr, ent);
       es.vp_ptr.upload(ptr, st_);
       es.vp_ent.upload(ent, st_);
+      es.h_vp_ent = ent;
       es.n_vp_ent = (long)ent.size();
       es.first_pose = !seen_pose;
       seen_pose = true;
@@ -1577,7 +1587,7 @@ void BlockSolver::build_system_impl() {
 #define G2OHIP_BA_LM(GG)                                                                                                         \
   hipLaunchKernelGGL((ba_assemble_landmarks_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p, \
                      es.vl_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_v.p, ba_.pt_v.p, ba_.meas.p, es.omega, ba_.edge_hpl.p, ba_.f,     \
-                     ba_.cx, ba_.cy, es.kernel_kind, es.delta, d_Hll.p, d_b.p + sizeP, d_Hpl.p, es.own_err.p)
+                     ba_.cx, ba_.cy, es.kernel_kind, es.delta, d_Hll.p, d_b.p + sizeP, d_Hpl.p, es.own_err.p, ba_.omega_identity ? 1 : 0)
         if (GL == 1) G2OHIP_BA_LM(1);
         else if (GL == 4) G2OHIP_BA_LM(4);
         else G2OHIP_BA_LM(8);
@@ -1588,8 +1598,8 @@ void BlockSolver::build_system_impl() {
       const int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
 #define G2OHIP_BA_POSE(GG)                                                                                                       \
   hipLaunchKernelGGL((ba_assemble_poses_kernel<GG>), dim3(grid_for((size_t)nP_ * GG)), dim3(kThreads), 0, st_, nP_, es.vp_ptr.p,  \
-                     es.vp_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_v.p, ba_.pt_v.p, ba_.meas.p, es.omega, ba_.f, ba_.cx, ba_.cy,      \
-                     es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1)
+                     ba_.cams.p, ba_.pts.p, ba_.cam_pm.p, ba_.pt_pm.p, ba_.meas_pm.p, ba_.omega_pm.p, ba_.f, ba_.cx, ba_.cy,       \
+                     es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, ba_.omega_identity ? 1 : 0)
       if (es.touches_pose) {
         if (G <= 1) G2OHIP_BA_POSE(1);
         else if (G <= 4) G2OHIP_BA_POSE(4);
@@ -2058,6 +2068,7 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
   ba_.pt_v.upload(point_vertex, n, st_);
   ba_.meas.upload(meas, n * 2, st_);
   std::vector<double> om;
+  ba_.omega_identity = info == nullptr;
   if (!info) {
     om.assign(n * 4, 0.0);
     for (size_t k = 0; k < n; ++k) om[4 * k] = om[4 * k + 3] = 1.0;   // information().setIdentity()
@@ -2081,6 +2092,26 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
     }
     ba_.fused_ok = unique;
     ba_.edge_hpl.upload(edge_hpl, st_);
+  }
+  {
+    // pose-major copies of what the pose-side assembly reads per observation (it walks a pose's observation list:
+    // through the edge id these would be 16-byte gathers at an 80-byte stride)
+    const size_t nk = es.h_vp_ent.size();
+    std::vector<double> mpm(nk * 2), opm(ba_.omega_identity ? 0 : nk * 4);
+    std::vector<int> ppm(nk), cpm(nk);
+    for (size_t k = 0; k < nk; ++k) {
+      const size_t e = (size_t)(es.h_vp_ent[k] >> 1);
+      mpm[2 * k] = meas[2 * e];
+      mpm[2 * k + 1] = meas[2 * e + 1];
+      ppm[k] = point_vertex[e];
+      cpm[k] = cam_vertex[e];
+      if (!ba_.omega_identity)
+        for (int i = 0; i < 4; ++i) opm[4 * k + i] = info[4 * e + i];
+    }
+    ba_.meas_pm.upload(mpm, st_);
+    ba_.pt_pm.upload(ppm, st_);
+    ba_.cam_pm.upload(cpm, st_);
+    if (!ba_.omega_identity) ba_.omega_pm.upload(opm, st_);
   }
   es.own_J0.alloc(n * 6);
   es.own_J1.alloc(n * 12);
