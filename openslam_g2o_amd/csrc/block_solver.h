@@ -32,7 +32,7 @@ struct EdgeSet {
   bool has_err = false;    // errors + information available (enough for chi2)
   // destination-major contributor lists
   DevBuf<int> vp_ptr, vp_ent, vl_ptr, vl_ent;  // per pose / per landmark: (edge << 1 | side)
-  std::vector<int> h_vp_ent;                   // host copy (pose-major copies of per-edge inputs)
+  std::vector<int> h_vp_ent, h_vl_ent;         // host copies (pose- / landmark-major copies of per-edge inputs)
   DevBuf<int> op_dst, op_ptr, op_ent;          // Hpp off-diagonal blocks: dest block id, (edge << 1 | transposed)
   DevBuf<int> ol_dst, ol_ptr, ol_ent;          // Hpl blocks
   int n_op = 0, n_ol = 0;
@@ -179,6 +179,8 @@ class BlockSolver {
     DevBuf<double> meas, cams, pts, cams_bak, pts_bak;
     DevBuf<double> meas_pm, omega_pm;   // pose-major copies (observation-list order of the pose side)
     DevBuf<int> pt_pm, cam_pm;
+    DevBuf<double> meas_lm, omega_lm;   // landmark-major copies
+    DevBuf<int> cam_lm, pt_lm, hpl_lm;
     bool has_backup = false;
   } ba_;
   EventTimer tq_, ts_, tn_, tl_, tb_;

@@ -829,29 +829,37 @@ __device__ __forceinline__ void ba_edge_linearize(const double* __restrict__ T, 
 template <int G>
 __global__ void __launch_bounds__(kThreads) ba_assemble_landmarks_kernel(
     int nL, const int* __restrict__ vptr, const int* __restrict__ vent, const double* __restrict__ cams, const double* __restrict__ pts,
-    const int* __restrict__ cam_v, const int* __restrict__ pt_v, const double* __restrict__ meas, const double* __restrict__ omega,
-    const int* __restrict__ edge_hpl, double f, double cx, double cy, int kind, double delta, double* __restrict__ Hll,
-    double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ err, int ident) {
+    const int* __restrict__ cam_lm, const int* __restrict__ pt_lm, const double* __restrict__ meas_lm, const double* __restrict__ omega_lm,
+    const int* __restrict__ hpl_lm, double f, double cx, double cy, int kind, double delta, double* __restrict__ Hll,
+    double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ err, int ident, const int* __restrict__ pl_colptr) {
+  // The Hpl blocks of a wave's landmarks are contiguous in HBM (block-CCS by landmark column).  Written by
+  // their lanes directly they would be 16-byte pieces at a 144-byte stride (64 memory transactions per
+  // store instruction); instead the wave collects them in LDS and streams them out fully coalesced.
+  __shared__ __attribute__((aligned(16))) double stage[kThreads / 64][64 * 18];
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int lm = gt / G, g = gt % G;
   const bool active = lm < nL;
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const int lm_w0 = min((gt - lane) / G, nL), lm_w1 = min(lm_w0 + 64 / G, nL);   // landmarks of this wave
+  const int q_base = pl_colptr[lm_w0], nslots = pl_colptr[lm_w1] - q_base;          // wave-uniform
+  const bool staged = nslots <= 64;
   double H[9], b[3];
 #pragma unroll
   for (int i = 0; i < 9; ++i) H[i] = 0.0;
   b[0] = b[1] = b[2] = 0.0;
   const int k0 = active ? vptr[lm] : 0, k1 = active ? vptr[lm + 1] : 0;
   for (int k = k0 + g; k < k1; k += G) {
-    const int e = vent[k] >> 1;
+    const int e = vent[k] >> 1;   // (only for the error store; everything read is in observation-list order)
     double T[12], X[3], z2[2], Op[4];
-    const double* Xp = pts + (size_t)pt_v[e] * 3;
+    const double* Xp = pts + (size_t)pt_lm[k] * 3;
     X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
-    load_vec<12>(cams + (size_t)cam_v[e] * 12, T);
-    load_vec<2>(meas + (size_t)e * 2, z2);
+    load_vec<12>(cams + (size_t)cam_lm[k] * 12, T);
+    load_vec<2>(meas_lm + (size_t)k * 2, z2);
     if (ident) {   // information().setIdentity() declared for the whole set: no per-edge read
       Op[0] = Op[3] = 1.0;
       Op[1] = Op[2] = 0.0;
     } else {
-      load_vec<4>(omega + (size_t)e * 4, Op);
+      load_vec<4>(omega_lm + (size_t)k * 4, Op);
     }
     BaEdgeLin L;
     ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
@@ -872,15 +880,22 @@ __global__ void __launch_bounds__(kThreads) ba_assemble_landmarks_kernel(
 #pragma unroll
       for (int a = 0; a < 3; ++a) H[a + 3 * c] += L.A[0 + 2 * a] * OA[0 + 2 * c] + L.A[1 + 2 * a] * OA[1 + 2 * c];
     }
-    const int q = edge_hpl[e];
+    const int q = hpl_lm[k];
     if (q >= 0) {   // Hpl(pose, lm) = B' (w Omega) A  (written transposed, block_solver.hpp:240-244)
       double blk[18];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int a = 0; a < 6; ++a) blk[a + 6 * c] = L.B[0 + 2 * a] * OA[0 + 2 * c] + L.B[1 + 2 * a] * OA[1 + 2 * c];
-      store_vec<18>(Hpl + (size_t)q * 18, blk);
+      if (staged) store_vec<18>(&stage[wave][(q - q_base) * 18], blk);
+      else store_vec<18>(Hpl + (size_t)q * 18, blk);
     }
+  }
+  if (staged) {   // (same wave wrote and reads: LDS operations of a wave complete in order)
+    __builtin_amdgcn_wave_barrier();
+    const dbl2_u* src = reinterpret_cast<const dbl2_u*>(&stage[wave][0]);
+    dbl2_u* dst = reinterpret_cast<dbl2_u*>(Hpl + (size_t)q_base * 18);
+    for (int t = lane; t < nslots * 9; t += 64) dst[t] = src[t];
   }
   if (G > 1) {
 #pragma unroll
@@ -1229,6 +1244,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       group_by(nL, dl, pl_, ptr, ent);
       es.vl_ptr.upload(ptr, st_);
       es.vl_ent.upload(ent, st_);
+      es.h_vl_ent = ent;
       es.n_vl_ent = (long)ent.size();
       es.first_lm = !seen_lm;
       seen_lm = true;
@@ -1586,8 +1602,9 @@ void BlockSolver::build_system_impl() {
         const int GL = avgK <= 1.5 ? 1 : (avgK <= 4.0 ? 4 : 8);   // one observation per lane where possible
 #define G2OHIP_BA_LM(GG)                                                                                                         \
   hipLaunchKernelGGL((ba_assemble_landmarks_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p, \
-                     es.vl_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_v.p, ba_.pt_v.p, ba_.meas.p, es.omega, ba_.edge_hpl.p, ba_.f,     \
-                     ba_.cx, ba_.cy, es.kernel_kind, es.delta, d_Hll.p, d_b.p + sizeP, d_Hpl.p, es.own_err.p, ba_.omega_identity ? 1 : 0)
+                     es.vl_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_lm.p, ba_.pt_lm.p, ba_.meas_lm.p, ba_.omega_lm.p, ba_.hpl_lm.p, ba_.f, \
+                     ba_.cx, ba_.cy, es.kernel_kind, es.delta, d_Hll.p, d_b.p + sizeP, d_Hpl.p, es.own_err.p, ba_.omega_identity ? 1 : 0, \
+                     d_pl_colptr.p)
         if (GL == 1) G2OHIP_BA_LM(1);
         else if (GL == 4) G2OHIP_BA_LM(4);
         else G2OHIP_BA_LM(8);
@@ -2108,6 +2125,26 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
       if (!ba_.omega_identity)
         for (int i = 0; i < 4; ++i) opm[4 * k + i] = info[4 * e + i];
     }
+    // the same for the landmark side (observation-list order of the landmarks)
+    const size_t nl = es.h_vl_ent.size();
+    std::vector<double> mlm(nl * 2), olm(ba_.omega_identity ? 0 : nl * 4);
+    std::vector<int> clm(nl), hlm(nl), plm(nl);
+    for (size_t k = 0; k < nl; ++k) {
+      const size_t e = (size_t)(es.h_vl_ent[k] >> 1);
+      mlm[2 * k] = meas[2 * e];
+      mlm[2 * k + 1] = meas[2 * e + 1];
+      clm[k] = cam_vertex[e];
+      plm[k] = point_vertex[e];
+      const int a = es.v0[e], b = es.v1[e];
+      hlm[k] = (a >= 0 && b >= 0) ? find_block(pl_colptr, pl_row, a - nP_, b) : -1;
+      if (!ba_.omega_identity)
+        for (int i = 0; i < 4; ++i) olm[4 * k + i] = info[4 * e + i];
+    }
+    ba_.meas_lm.upload(mlm, st_);
+    ba_.cam_lm.upload(clm, st_);
+    ba_.pt_lm.upload(plm, st_);
+    ba_.hpl_lm.upload(hlm, st_);
+    if (!ba_.omega_identity) ba_.omega_lm.upload(olm, st_);
     ba_.meas_pm.upload(mpm, st_);
     ba_.pt_pm.upload(ppm, st_);
     ba_.cam_pm.upload(cpm, st_);
