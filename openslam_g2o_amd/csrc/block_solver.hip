@@ -553,9 +553,21 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
       for (int r = 0; r < PD; ++r) cacc[r] = ge_sum(cacc[r]);
     }
     double* out = Pd + (size_t)ld * PD * PD + gc * NC * PD;
+    if constexpr ((PD * NC) % 2 == 0) {   // 16-byte pieces, dealt round-robin to the GE lanes (all hold the sum)
+      dbl2_u* out2 = reinterpret_cast<dbl2_u*>(out);
 #pragma unroll
-    for (int i = 0; i < PD * NC; ++i)
-      if (GE == 1 || (i % GE) == ge) out[i] = acc[i];
+      for (int u = 0; u < PD * NC / 2; ++u)
+        if (GE == 1 || (u % GE) == ge) {
+          dbl2_u v;
+          v.x = acc[2 * u];
+          v.y = acc[2 * u + 1];
+          out2[u] = v;
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PD * NC; ++i)
+        if (GE == 1 || (i % GE) == ge) out[i] = acc[i];
+    }
     if (diag && gc == 0) {
 #pragma unroll
       for (int r = 0; r < PD; ++r)
