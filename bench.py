@@ -41,7 +41,8 @@ def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2):
     kb["fused:assemble_vertex(landmark)"] = E * 8 * (d + p * l + d) + L * 8 * (l + l * l + l) + P * 8 * 12
     kb["fused:assemble_vertex(pose)"] = E * 8 * (d + l) + P * 8 * (12 + p * p + p)
     kb["landmark_inverse"] = L * 8 * (2 * l * l + 2 * l)
-    kb["schur_tiles"] = E * 8 * p * l + L * 8 * (l * l + l) + S * 8 * p * p          # Hpl, Dinv, b_l in; one Hschur worth out
+    # Hpl, Hll, b_l in; Dinv (the landmark inversion is done on the staged tile) and one Hschur worth of partials out
+    kb["schur_tiles"] = E * 8 * p * l + L * 8 * (l * l + l) + L * 8 * l * l + S * 8 * p * p
     kb["schur_reduce"] = pp_nnzb * 8 * p * p + 2 * S * 8 * p * p + 3 * P * 8 * p      # Hpp + partials in, Hschur + bschur out
     kb["back_substitute"] = E * 8 * p * l + L * 8 * (l * l + 2 * l) + P * 8 * p
     n = p * P

@@ -113,6 +113,8 @@ class BlockSolver {
   // per-rank work shrinks (multi-GPU).  Needs a non-default stream.  Timing events sit between the graphs.
   bool use_graph = false;
   void invalidate_graphs();
+  bool fuse_landmark_inverse = true;       // invert the landmark blocks inside the Schur tile kernel
+  bool tiles_cover_all_ = false;
   bool mask_solution = true;               // solve_reduced_shared zeroes the x_p entries other ranks own (all-reduce of x_p)
   int schur_group = 0;                     // lanes per destination in the Schur tile kernel (0 = auto)
   const CholStats* chol_stats() const { return chol_ ? &chol_->stats() : nullptr; }

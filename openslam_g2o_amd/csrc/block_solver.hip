@@ -377,13 +377,8 @@ __global__ void __launch_bounds__(kThreads) landmark_inverse_kernel(int nL, cons
   small_inverse<LD>(D, R);
 #pragma unroll
   for (int i = 0; i < LD * LD; ++i) Dinv[(size_t)lm * LD * LD + i] = R[i];
-#pragma unroll
-  for (int i = 0; i < LD; ++i) {
-    double t = 0.0;
-#pragma unroll
-    for (int j = 0; j < LD; ++j) t += R[i + LD * j] * bl[(size_t)lm * LD + j];
-    db[(size_t)lm * LD + i] = t;
-  }
+  (void)bl;
+  (void)db;
 }
 
 // K5+K7+K8, pass 1: Schur outer products over a TILE of consecutive landmarks
@@ -399,11 +394,14 @@ template <int PD, int LD, int G>
 #endif
 __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(const int* __restrict__ tile_lm0, const int* __restrict__ tile_td0,
                                                             const int* __restrict__ pl_colptr, const double* __restrict__ Hpl,
-                                                            const double* __restrict__ Dinv, const double* __restrict__ bl,
+                                                            double* __restrict__ Dinv, const double* __restrict__ bl,
                                                             const int* __restrict__ td_diag, const int* __restrict__ td_ptr,
                                                             const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm,
                                                             double* __restrict__ Pd,
-                                                            double* __restrict__ Pr) {
+                                                            double* __restrict__ Pr, const double* __restrict__ Hll,
+                                                            const double* __restrict__ lam) {
+  // Hll != nullptr: the landmark inversion (block_solver.hpp:386-389, with the virtual damping) is done here on
+  // the staged blocks -- the tile reads Hll instead of Dinv and writes Dinv (back-substitution needs it) on the way.
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int PL = PD * LD;
   const int t = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -424,7 +422,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
     const dbl2_u* srcB = reinterpret_cast<const dbl2_u*>(Hpl + (size_t)q0 * PL);
     dbl2_u* dstB = reinterpret_cast<dbl2_u*>(Bs);
     const int n2 = (nslots * PL) >> 1;
-    const double* srcD = Dinv + (size_t)l0 * LD * LD;
+    const double* srcD = (Hll ? Hll : Dinv) + (size_t)l0 * LD * LD;
     const double* srcb = bl + (size_t)l0 * LD;
     const int nD = nlm * LD * LD, nb = nlm * LD, ndp = td1 - td0 + 1;
     constexpr int UB = 12, UD = 3, UE = 4;
@@ -481,6 +479,22 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
     if (ndp - 1 > NT) stage_copy<2>(ddiag + NT, td_diag + td0 + NT, ndp - 1 - NT, tid, NT);
   }
   __syncthreads();
+  if (Hll) {
+    const double lambda = lam[1];
+    for (int j = tid; j < nlm; j += NT) {
+      double D[LD * LD], R[LD * LD];
+#pragma unroll
+      for (int i = 0; i < LD * LD; ++i) D[i] = Ds[j * (LD * LD) + i];
+#pragma unroll
+      for (int i = 0; i < LD; ++i) D[i * (LD + 1)] += lambda;
+      small_inverse<LD>(D, R);
+#pragma unroll
+      for (int i = 0; i < LD * LD; ++i) Ds[j * (LD * LD) + i] = R[i];
+    }
+    __syncthreads();
+    double* dstD = Dinv + (size_t)l0 * LD * LD;
+    for (int i = tid; i < nlm * LD * LD; i += NT) dstD[i] = Ds[i];
+  }
   // G lanes per destination block = GC column parts x GE entry parts: a lane owns PD/GC columns of the
   // block (PD*PD/GC accumulator registers instead of PD*PD: what keeps 3 workgroups on a CU) and walks
   // every GE-th entry; the GE partial sums are combined with DPP (fixed order: deterministic).
@@ -1398,6 +1412,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         tile_td0.push_back((int)td_dest.size());
       }
       n_tiles_ = (int)tile_lm0.size() - 1;
+      tiles_cover_all_ = tile_lm0.front() == 0 && tile_lm0.back() == nL;
       n_td_ = (long)td_dest.size();
       n_sc_ = (long)te_pack.size();
       schur_lds_bytes_ = max_lds;
@@ -1801,14 +1816,18 @@ void BlockSolver::solve_schur_impl() {
   const size_t sizeP = (size_t)nP_ * p_;
   const int hs_nnzb = (int)hs_row.size();
   const int G = schur_group > 0 ? schur_group : pick_group((double)n_sc_ / std::max<long>(1, n_td_));
+  // every landmark lies in exactly one tile, so the tiles can invert the landmark blocks themselves
+  const bool fuse_inv = fuse_landmark_inverse && n_tiles_ > 0 && tiles_cover_all_;
 #define G2OHIP_TILE_ARGS d_tile_lm0.p, d_tile_td0.p, d_pl_colptr.p, d_Hpl.p, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p, d_te_pack.p, \
-                         d_te_lm.p, d_Pd.p, d_Pr.p
+                         d_te_lm.p, d_Pd.p, d_Pr.p, fuse_inv ? d_Hll.p : (const double*)nullptr, d_lam.p
 #define G2OHIP_SCHUR(P_, L_)                                                                                                   \
   if (p_ == P_ && l_ == L_) {                                                                                                  \
-    prof.begin(KernelProf::kLmInverse, st_);                                                                                   \
-    hipLaunchKernelGGL((landmark_inverse_kernel<L_>), dim3(grid_for(nL_)), dim3(kThreads), 0, st_, nL_, d_Hll.p, d_b.p + sizeP, \
-                       d_Dinv.p, d_db.p, d_lam.p);                                                                             \
-    prof.end(KernelProf::kLmInverse, st_);                                                                                     \
+    if (!fuse_inv) {                                                                                                           \
+      prof.begin(KernelProf::kLmInverse, st_);                                                                                 \
+      hipLaunchKernelGGL((landmark_inverse_kernel<L_>), dim3(grid_for(nL_)), dim3(kThreads), 0, st_, nL_, d_Hll.p, d_b.p + sizeP, \
+                         d_Dinv.p, d_db.p, d_lam.p);                                                                           \
+      prof.end(KernelProf::kLmInverse, st_);                                                                                   \
+    }                                                                                                                          \
     prof.begin(KernelProf::kSchurBlocks, st_);                                                                                 \
     if (n_tiles_ > 0) {                                                                                                        \
       static bool attr = false;                                                                                                \

@@ -370,6 +370,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "schur_tile_bytes")) s->impl->schur_tile_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_group")) s->impl->schur_group = (int)value;
   else if (!std::strcmp(name, "mask_solution")) s->impl->mask_solution = value != 0;
+  else if (!std::strcmp(name, "fuse_landmark_inverse")) s->impl->fuse_landmark_inverse = value != 0;
   else if (!std::strcmp(name, "use_graph")) s->impl->use_graph = value != 0;
   else if (!std::strcmp(name, "ba_fused")) s->impl->ba_fused = value != 0;
   else {
