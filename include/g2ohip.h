@@ -165,6 +165,9 @@ int g2ohip_copy_values(g2ohip_solver* s, int which, double* values_host);
 /* Device pointers + element counts of resident arrays (for multi-GPU exchange through RCCL):
  * which = G2OHIP_HSCHUR (values), or 100 = bschur. */
 int g2ohip_device_array(g2ohip_solver* s, int which, double** ptr, size_t* count);
+/* The per-edge data the next g2ohip_build_system will consume, copied to the host (inspection / tests of the
+ * device-side producers): J0 [n][d*dim0], J1 [n][d*dim1], err [n][d]; any pointer may be NULL. */
+int g2ohip_copy_edge_data(g2ohip_solver* s, int set, double* J0, double* J1, double* err);
 
 /* Multi-GPU sharding support (openslam_g2o_amd/distributed.py).  Each rank holds a landmark
  * shard; to give every rank the SAME Hschur block layout (so the partial Schur complements
@@ -235,6 +238,25 @@ int g2ohip_ba_update(g2ohip_solver* s);
 int g2ohip_ba_push(g2ohip_solver* s);
 int g2ohip_ba_pop(g2ohip_solver* s);
 int g2ohip_ba_discard_top(g2ohip_solver* s);
+
+/* ---- device-resident pose-graph front end ----------------------------
+ * Error + Jacobian producers and vertex updates for pose graphs, so a Gauss-Newton / LM iteration needs no
+ * host round trip: type 1 = EdgeSE2 / VertexSE2 (g2o/types/slam2d/edge_se2.h:51-57, edge_se2.cpp:76-99,
+ * vertex_se2.h:55-59), estimates and measurements (x, y, theta), information [n][3x3];
+ * type 2 = EdgeSE3 / VertexSE3 (g2o/types/slam3d/edge_se3.cpp:48-75, isometry3d_gradients.h:39-126,
+ * vertex_se3.h:107-116), estimates and measurements as isometries [12] = R (column-major) | t,
+ * information [n][6x6].  Edge set `set` was added with error_dim 3 / 6 and hessian indices of its two
+ * vertices; vi/vj index the estimate array (all vertices, fixed ones included), hidx[v] = hessianIndex or -1.
+ * The calls mirror the g2ohip_ba_* ones (set_edges after g2ohip_build_structure). */
+int g2ohip_pg_set_edges(g2ohip_solver* s, int set, int type, const int32_t* vi, const int32_t* vj, const double* meas,
+                        const double* info);
+int g2ohip_pg_set_estimates(g2ohip_solver* s, int n_vertices, const double* poses, const int32_t* hidx);
+int g2ohip_pg_get_estimates(g2ohip_solver* s, double* poses);
+int g2ohip_pg_linearize(g2ohip_solver* s, int jacobians);
+int g2ohip_pg_update(g2ohip_solver* s);
+int g2ohip_pg_push(g2ohip_solver* s);
+int g2ohip_pg_pop(g2ohip_solver* s);
+int g2ohip_pg_discard_top(g2ohip_solver* s);
 
 /* ---- narrow seam: g2o::LinearSolver<MatrixType> ------------------------------------------- */
 

@@ -51,6 +51,8 @@ EXPORTS = [
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
     "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
     "g2ohip_get_partition", "g2ohip_partition_poses",
+    "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
+    "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
 ]
 
 _lib = None
@@ -115,8 +117,14 @@ def load():
     L.g2ohip_ba_set_estimates.argtypes = [vp, C.c_int, c_dbl_p, c_int_p, C.c_int, c_dbl_p, c_int_p]
     L.g2ohip_ba_get_estimates.argtypes = [vp, c_dbl_p, c_dbl_p]
     L.g2ohip_ba_linearize.argtypes = [vp, C.c_int]
-    for n in ("g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top"):
+    for n in ("g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top", "g2ohip_pg_update", "g2ohip_pg_push",
+              "g2ohip_pg_pop", "g2ohip_pg_discard_top"):
         getattr(L, n).argtypes = [vp]
+    L.g2ohip_pg_set_edges.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p]
+    L.g2ohip_pg_set_estimates.argtypes = [vp, C.c_int, c_dbl_p, c_int_p]
+    L.g2ohip_pg_get_estimates.argtypes = [vp, c_dbl_p]
+    L.g2ohip_pg_linearize.argtypes = [vp, C.c_int]
+    L.g2ohip_copy_edge_data.argtypes = [vp, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]
     L.g2ohip_kernel_name.argtypes = [C.c_int]
     L.g2ohip_kernel_name.restype = C.c_char_p
     L.g2ohip_kernel_time.argtypes = [vp, C.c_int, c_dbl_p, C.POINTER(C.c_long), C.c_int]
@@ -402,6 +410,43 @@ class HipBlockSolver:
         out = np.empty(max(self.nnzb(which) * per, 1))
         _check(self.L.g2ohip_copy_values(self.h, which, _dp(out)), "values")
         return out[:self.nnzb(which) * per]
+
+    def edgeData(self, set_id, n, d, d0, d1):
+        """(J0, J1, err) of a binary edge set (n edges, error dim d, vertex dims d0 / d1) as the next buildSystem reads them."""
+        J0, J1, err = np.empty((n, d * d0)), np.empty((n, d * d1)), np.empty((n, d))
+        _check(self.L.g2ohip_copy_edge_data(self.h, set_id, _dp(J0), _dp(J1), _dp(err)), "edgeData")
+        return J0, J1, err
+
+    # ---- device-resident pose-graph front end (EdgeSE2 = 1, EdgeSE3 = 2) ------------------------------
+    def pgSetEdges(self, set_id, edge_type, vi, vj, meas, info):
+        vi, vj, meas, info = _i32(vi), _i32(vj), _f64(meas), _f64(info)
+        self._pg = (edge_type, 3 if edge_type == 1 else 12)
+        _check(self.L.g2ohip_pg_set_edges(self.h, set_id, edge_type, _ip(vi), _ip(vj), _dp(meas), _dp(info)), "pgSetEdges")
+
+    def pgSetEstimates(self, poses, hidx):
+        poses, hidx = _f64(poses), _i32(hidx)
+        self._pg_nv = len(hidx)
+        _check(self.L.g2ohip_pg_set_estimates(self.h, len(hidx), _dp(poses), _ip(hidx)), "pgSetEstimates")
+
+    def pgGetEstimates(self):
+        out = np.empty((self._pg_nv, self._pg[1]))
+        _check(self.L.g2ohip_pg_get_estimates(self.h, _dp(out)), "pgGetEstimates")
+        return out
+
+    def pgLinearize(self, jacobians=True):
+        _check(self.L.g2ohip_pg_linearize(self.h, int(jacobians)), "pgLinearize")
+
+    def pgUpdate(self):
+        _check(self.L.g2ohip_pg_update(self.h), "pgUpdate")
+
+    def pgPush(self):
+        _check(self.L.g2ohip_pg_push(self.h), "pgPush")
+
+    def pgPop(self):
+        _check(self.L.g2ohip_pg_pop(self.h), "pgPop")
+
+    def pgDiscardTop(self):
+        _check(self.L.g2ohip_pg_discard_top(self.h), "pgDiscardTop")
 
     def deviceArray(self, which):
         ptr = C.c_void_p()

@@ -72,6 +72,15 @@ class BlockSolver {
   void solve_reduced_shared();
   int solve_reduced_finish();
   void partition_info(int* pose_owner, int* block_consumer);
+  void copy_edge_data(int set, double* J0, double* J1, double* err);
+  void pg_set_edges(int set, int type, const int* vi, const int* vj, const double* meas, const double* info);
+  void pg_set_estimates(int nv, const double* poses, const int* hidx);
+  void pg_get_estimates(double* poses);
+  void pg_linearize(bool jacobians);
+  void pg_update();
+  void pg_push();
+  void pg_pop();
+  void pg_discard_top();
   void solve_back_substitute();
   void multiply_hessian(double* dest_host, const double* src_host);
 
@@ -185,6 +194,12 @@ class BlockSolver {
     DevBuf<int> cam_lm, pt_lm, hpl_lm;
     bool has_backup = false;
   } ba_;
+  struct PgFrontEnd {   // pose-graph front end: type 1 = EdgeSE2 (x, y, theta), 2 = EdgeSE3 (isometries T[12])
+    int set = -1, type = 0, nv = 0;
+    DevBuf<int> vi, vj, hidx;
+    DevBuf<double> meas, poses, poses_bak;
+    bool has_backup = false;
+  } pg_;
   EventTimer tq_, ts_, tn_, tl_, tb_;
   void require_structure() const;
   double reduce_sum_finish(int nblocks);

@@ -1002,6 +1002,315 @@ __global__ void __launch_bounds__(kThreads) ba_assemble_poses_kernel(
     if (G == 1 || (i % G) == g) bd[i] = accumulate ? bd[i] + b[i] : b[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Pose-graph front end: EdgeSE2 / EdgeSE3 error + Jacobian producers and the vertex updates on the
+// device, so that a Gauss-Newton / LM iteration of a pose graph needs no host round trip.
+//   EdgeSE2::computeError / linearizeOplus     g2o/types/slam2d/edge_se2.h:51-57, edge_se2.cpp:76-99
+//   VertexSE2::oplusImpl                        g2o/types/slam2d/vertex_se2.h:55-59, se2.h:92-98
+//   EdgeSE3::computeError / linearizeOplus      g2o/types/slam3d/edge_se3.cpp:48-75 (analytic Jacobian of
+//                                               isometry3d_gradients.h:39-126, dq_dR of dquat2mat.cpp)
+//   VertexSE3::oplusImpl                        g2o/types/slam3d/vertex_se3.h:107-116 (fromVectorMQT)
+// SE2 estimates are (x, y, theta); SE3 estimates / measurements are isometries T[12] = R (column-major) | t.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pg_normalize_theta(double theta) {
+  if (theta >= -M_PI && theta < M_PI) return theta;
+  const double multiplier = floor(theta / (2 * M_PI));
+  theta = theta - multiplier * 2 * M_PI;
+  if (theta >= M_PI) theta -= 2 * M_PI;
+  if (theta < -M_PI) theta += 2 * M_PI;
+  return theta;
+}
+__device__ __forceinline__ void pg_se2_inverse(const double* a, double* r) {
+  const double th = pg_normalize_theta(-a[2]), c = cos(th), s = sin(th);
+  r[0] = c * (-a[0]) - s * (-a[1]);
+  r[1] = s * (-a[0]) + c * (-a[1]);
+  r[2] = th;
+}
+__device__ __forceinline__ void pg_se2_mul(const double* a, const double* b, double* r) {
+  const double c = cos(a[2]), s = sin(a[2]);
+  const double x = a[0] + c * b[0] - s * b[1], y = a[1] + s * b[0] + c * b[1];
+  r[0] = x;
+  r[1] = y;
+  r[2] = pg_normalize_theta(a[2] + b[2]);
+}
+__global__ void __launch_bounds__(kThreads) pg_se2_linearize_kernel(int n, const double* __restrict__ poses, const int* __restrict__ vi,
+                                                                  const int* __restrict__ vj, const double* __restrict__ meas,
+                                                                  double* __restrict__ J0, double* __restrict__ J1,
+                                                                  double* __restrict__ err, int jac) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double* xi = poses + 3 * (size_t)vi[k];
+  const double* xj = poses + 3 * (size_t)vj[k];
+  double invm[3], invi[3], t1[3], delta[3];
+  pg_se2_inverse(meas + 3 * (size_t)k, invm);
+  pg_se2_inverse(xi, invi);
+  pg_se2_mul(invi, xj, t1);
+  pg_se2_mul(invm, t1, delta);
+  err[3 * (size_t)k] = delta[0];
+  err[3 * (size_t)k + 1] = delta[1];
+  err[3 * (size_t)k + 2] = delta[2];
+  if (!jac) return;
+  const double thetai = xi[2], dtx = xj[0] - xi[0], dty = xj[1] - xi[1];
+  const double si = sin(thetai), ci = cos(thetai);
+  const double A[9] = {-ci, -si, -si * dtx + ci * dty, si, -ci, -ci * dtx - si * dty, 0, 0, -1};   // row-major
+  const double B[9] = {ci, si, 0, -si, ci, 0, 0, 0, 1};
+  const double cz = cos(invm[2]), sz = sin(invm[2]);
+  const double Z[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+  double* o0 = J0 + 9 * (size_t)k;
+  double* o1 = J1 + 9 * (size_t)k;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double a = 0, b = 0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        a += Z[r * 3 + m] * A[m * 3 + c];
+        b += Z[r * 3 + m] * B[m * 3 + c];
+      }
+      o0[r + 3 * c] = a;
+      o1[r + 3 * c] = b;
+    }
+}
+__global__ void __launch_bounds__(kThreads) pg_se2_update_kernel(int nv, double* __restrict__ poses, const int* __restrict__ hidx,
+                                                               const double* __restrict__ x) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv || hidx[v] < 0) return;
+  const double* u = x + 3 * (size_t)hidx[v];
+  double* p = poses + 3 * (size_t)v;
+  p[0] += u[0];
+  p[1] += u[1];
+  p[2] = pg_normalize_theta(p[2] + u[2]);
+}
+
+#define PG_R(T, a, b) (T)[(a) + 3 * (b)]
+__device__ __forceinline__ void pg_iso_mul(const double* A, const double* B, double* C) {
+  double R[9], t[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double s = 0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) s += PG_R(A, r, m) * PG_R(B, m, c);
+      R[r + 3 * c] = s;
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) t[r] = PG_R(A, r, 0) * B[9] + PG_R(A, r, 1) * B[10] + PG_R(A, r, 2) * B[11] + A[9 + r];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) C[i] = R[i];
+  C[9] = t[0];
+  C[10] = t[1];
+  C[11] = t[2];
+}
+__device__ __forceinline__ void pg_iso_inv(const double* A, double* C) {
+  double R[9], t[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) R[r + 3 * c] = PG_R(A, c, r);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) t[r] = -(R[r] * A[9] + R[r + 3] * A[10] + R[r + 6] * A[11]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) C[i] = R[i];
+  C[9] = t[0];
+  C[10] = t[1];
+  C[11] = t[2];
+}
+// Quaterniond(w,x,y,z).toRotationMatrix() (no normalisation, like Eigen)
+__device__ __forceinline__ void pg_quat_to_R(double w, double x, double y, double z, double* R) {
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  PG_R(R, 0, 0) = 1 - (tyy + tzz); PG_R(R, 0, 1) = txy - twz; PG_R(R, 0, 2) = txz + twy;
+  PG_R(R, 1, 0) = txy + twz; PG_R(R, 1, 1) = 1 - (txx + tzz); PG_R(R, 1, 2) = tyz - twx;
+  PG_R(R, 2, 0) = txz - twy; PG_R(R, 2, 1) = tyz + twx; PG_R(R, 2, 2) = 1 - (txx + tyy);
+}
+// Quaterniond(R) (four cases), normalised, w >= 0 (isometry3d_mappings.cpp:38-44); q = (x, y, z, w)
+__device__ void pg_R_to_quat(const double* R, double* q) {
+  const double tr = PG_R(R, 0, 0) + PG_R(R, 1, 1) + PG_R(R, 2, 2);
+  if (tr > 0) {
+    double t = sqrt(tr + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (PG_R(R, 2, 1) - PG_R(R, 1, 2)) * t;
+    q[1] = (PG_R(R, 0, 2) - PG_R(R, 2, 0)) * t;
+    q[2] = (PG_R(R, 1, 0) - PG_R(R, 0, 1)) * t;
+  } else {
+    int i = 0;
+    if (PG_R(R, 1, 1) > PG_R(R, 0, 0)) i = 1;
+    if (PG_R(R, 2, 2) > PG_R(R, i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = sqrt(PG_R(R, i, i) - PG_R(R, j, j) - PG_R(R, k, k) + 1.0);
+    double qq[4];
+    qq[i] = 0.5 * t;
+    t = 0.5 / t;
+    qq[3] = (PG_R(R, k, j) - PG_R(R, j, k)) * t;
+    qq[j] = (PG_R(R, j, i) + PG_R(R, i, j)) * t;
+    qq[k] = (PG_R(R, k, i) + PG_R(R, i, k)) * t;
+    q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+  }
+  const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] /= nrm;
+  if (q[3] < 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = -q[i];
+  }
+}
+// d(qx,qy,qz)/d vec(R) (3 x 9, vec column-major; D row-major): partials of the case formulas of dquat2mat.cpp:9-43
+__device__ void pg_dq_dR(const double* R, double* D) {
+  for (int i = 0; i < 27; ++i) D[i] = 0;
+#define PG_COL(a, b) ((a) + 3 * (b))
+  const double r00 = PG_R(R, 0, 0), r11 = PG_R(R, 1, 1), r22 = PG_R(R, 2, 2);
+  const double tr = r00 + r11 + r22;
+  double qw;
+  if (tr > 0) {
+    const double w = 0.5 * sqrt(tr + 1.0);
+    qw = w;
+    const double num[3] = {PG_R(R, 2, 1) - PG_R(R, 1, 2), PG_R(R, 0, 2) - PG_R(R, 2, 0), PG_R(R, 1, 0) - PG_R(R, 0, 1)};
+    const int pa[3] = {2, 0, 1}, pb[3] = {1, 2, 0};
+    for (int c = 0; c < 3; ++c) {
+      const double dd = -num[c] / (32.0 * w * w * w);
+      D[c * 9 + PG_COL(0, 0)] = dd;
+      D[c * 9 + PG_COL(1, 1)] = dd;
+      D[c * 9 + PG_COL(2, 2)] = dd;
+      D[c * 9 + PG_COL(pa[c], pb[c])] = 0.25 / w;
+      D[c * 9 + PG_COL(pb[c], pa[c])] = -0.25 / w;
+    }
+  } else {
+    int i = 0;
+    if ((r00 > r11) & (r00 > r22)) i = 0;
+    else if (r11 > r22) i = 1;
+    else i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    const double s = 0.5 * sqrt(1.0 + PG_R(R, i, i) - PG_R(R, j, j) - PG_R(R, k, k));
+    qw = (PG_R(R, k, j) - PG_R(R, j, k)) / (4.0 * s);
+    D[i * 9 + PG_COL(i, i)] = 1.0 / (8.0 * s);
+    D[i * 9 + PG_COL(j, j)] = -1.0 / (8.0 * s);
+    D[i * 9 + PG_COL(k, k)] = -1.0 / (8.0 * s);
+    const int other[2] = {j, k};
+    for (int o = 0; o < 2; ++o) {
+      const int c = other[o];
+      const double num = PG_R(R, c, i) + PG_R(R, i, c);
+      D[c * 9 + PG_COL(c, i)] += 0.25 / s;
+      D[c * 9 + PG_COL(i, c)] += 0.25 / s;
+      const double dd = num / (32.0 * s * s * s);
+      D[c * 9 + PG_COL(i, i)] += -dd;
+      D[c * 9 + PG_COL(j, j)] += dd;
+      D[c * 9 + PG_COL(k, k)] += dd;
+    }
+  }
+  if (qw <= 0)
+    for (int i = 0; i < 27; ++i) D[i] = -D[i];
+#undef PG_COL
+}
+__global__ void __launch_bounds__(kThreads) pg_se3_linearize_kernel(int n, const double* __restrict__ poses, const int* __restrict__ vi,
+                                                                  const int* __restrict__ vj, const double* __restrict__ meas,
+                                                                  double* __restrict__ J0, double* __restrict__ J1,
+                                                                  double* __restrict__ err, int jac) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const double* Xi = poses + 12 * (size_t)vi[e];
+  const double* Xj = poses + 12 * (size_t)vj[e];
+  const double* Z = meas + 12 * (size_t)e;
+  double A[12], Xii[12], B[12], E[12], q[4];
+  pg_iso_inv(Z, A);
+  pg_iso_inv(Xi, Xii);
+  pg_iso_mul(Xii, Xj, B);
+  pg_iso_mul(A, B, E);
+  pg_R_to_quat(E, q);
+  double* r = err + 6 * (size_t)e;
+  r[0] = E[9]; r[1] = E[10]; r[2] = E[11]; r[3] = q[0]; r[4] = q[1]; r[5] = q[2];
+  if (!jac) return;
+  double* Ji = J0 + 36 * (size_t)e;   // column-major 6x6
+  double* Jj = J1 + 36 * (size_t)e;
+  for (int i = 0; i < 36; ++i) Ji[i] = Jj[i] = 0;
+  const double* Ra = A;
+  const double* Rab = E;
+  const double* Rbc = B;
+  const double* tbc = B + 9;
+  for (int c = 0; c < 3; ++c)
+    for (int rr = 0; rr < 3; ++rr) {
+      Ji[rr + 6 * c] = -PG_R(Ra, rr, c);
+      Jj[rr + 6 * c] = PG_R(Rab, rr, c);
+    }
+  {  // dte/dqi = Ra * skewT(tbc) (doubled components); dte/dqj = 0
+    const double x = 2 * tbc[0], y = 2 * tbc[1], z = 2 * tbc[2];
+    double S[9];
+    PG_R(S, 0, 0) = 0; PG_R(S, 0, 1) = -z; PG_R(S, 0, 2) = y;
+    PG_R(S, 1, 0) = z; PG_R(S, 1, 1) = 0; PG_R(S, 1, 2) = -x;
+    PG_R(S, 2, 0) = -y; PG_R(S, 2, 1) = x; PG_R(S, 2, 2) = 0;
+    for (int c = 0; c < 3; ++c)
+      for (int rr = 0; rr < 3; ++rr) {
+        double s = 0;
+        for (int m = 0; m < 3; ++m) s += PG_R(Ra, rr, m) * PG_R(S, m, c);
+        Ji[rr + 6 * (3 + c)] = s;
+      }
+  }
+  double D[27];
+  pg_dq_dR(E, D);
+  {  // dre/dqi
+    const double r11 = 2 * PG_R(Rbc, 0, 0), r12 = 2 * PG_R(Rbc, 0, 1), r13 = 2 * PG_R(Rbc, 0, 2), r21 = 2 * PG_R(Rbc, 1, 0),
+                 r22 = 2 * PG_R(Rbc, 1, 1), r23 = 2 * PG_R(Rbc, 1, 2), r31 = 2 * PG_R(Rbc, 2, 0), r32 = 2 * PG_R(Rbc, 2, 1),
+                 r33 = 2 * PG_R(Rbc, 2, 2);
+    const double S[3][9] = {{0, 0, 0, r31, r32, r33, -r21, -r22, -r23}, {-r31, -r32, -r33, 0, 0, 0, r11, r12, r13},
+                            {r21, r22, r23, -r11, -r12, -r13, 0, 0, 0}};   // row-wise
+    for (int a = 0; a < 3; ++a) {
+      double M[9];
+      for (int c = 0; c < 3; ++c)
+        for (int rr = 0; rr < 3; ++rr) {
+          double s = 0;
+          for (int m = 0; m < 3; ++m) s += PG_R(Ra, rr, m) * S[a][m * 3 + c];
+          M[rr + 3 * c] = s;
+        }
+      for (int rr = 0; rr < 3; ++rr) {
+        double s = 0;
+        for (int m = 0; m < 9; ++m) s += D[rr * 9 + m] * M[m];
+        Ji[(3 + rr) + 6 * (3 + a)] = s;
+      }
+    }
+  }
+  {  // dre/dqj (Rc = I)
+    const double S[3][9] = {{0, 0, 0, 0, 0, -2, 0, 2, 0}, {0, 0, 2, 0, 0, 0, -2, 0, 0}, {0, -2, 0, 2, 0, 0, 0, 0, 0}};
+    for (int a = 0; a < 3; ++a) {
+      double M[9];
+      for (int c = 0; c < 3; ++c)
+        for (int rr = 0; rr < 3; ++rr) {
+          double s = 0;
+          for (int m = 0; m < 3; ++m) s += PG_R(Rab, rr, m) * S[a][m * 3 + c];
+          M[rr + 3 * c] = s;
+        }
+      for (int rr = 0; rr < 3; ++rr) {
+        double s = 0;
+        for (int m = 0; m < 9; ++m) s += D[rr * 9 + m] * M[m];
+        Jj[(3 + rr) + 6 * (3 + a)] = s;
+      }
+    }
+  }
+}
+// estimate <- estimate * fromVectorMQT(update)
+__global__ void __launch_bounds__(kThreads) pg_se3_update_kernel(int nv, double* __restrict__ poses, const int* __restrict__ hidx,
+                                                               const double* __restrict__ x) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv || hidx[v] < 0) return;
+  const double* u = x + 6 * (size_t)hidx[v];
+  double* T = poses + 12 * (size_t)v;
+  double inc[12];
+  const double w = 1 - (u[3] * u[3] + u[4] * u[4] + u[5] * u[5]);
+  if (w < 0) {
+    for (int i = 0; i < 9; ++i) inc[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    pg_quat_to_R(sqrt(w), u[3], u[4], u[5], inc);
+  }
+  inc[9] = u[0]; inc[10] = u[1]; inc[11] = u[2];
+  double Tl[12], out[12];
+  for (int i = 0; i < 12; ++i) Tl[i] = T[i];
+  pg_iso_mul(Tl, inc, out);
+  for (int i = 0; i < 12; ++i) T[i] = out[i];
+}
+#undef PG_R
+
 inline int grid_for(size_t n, int threads = kThreads) { return (int)((n + threads - 1) / threads); }
 
 // ---- dispatch tables ----------------------------------------------------------------
@@ -2254,6 +2563,116 @@ void BlockSolver::ba_pop() {
 void BlockSolver::ba_discard_top() {
   if (!ba_.has_backup) throw StateFailure("ba_discard_top without push");
   ba_.has_backup = false;
+}
+
+
+// ---- pose-graph front end (EdgeSE2 / EdgeSE3) ---------------------------------------------------------
+void BlockSolver::pg_set_edges(int set, int type, const int* vi, const int* vj, const double* meas, const double* info) {
+  invalidate_graphs();
+  require_structure();
+  if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
+  if (type != 1 && type != 2) throw ArgFailure("pg_set_edges: type must be 1 (EdgeSE2) or 2 (EdgeSE3)");
+  EdgeSet& es = *sets_[set];
+  const int d = type == 1 ? 3 : 6;
+  if (es.unary || es.d != d || es.dim0 != d || es.dim1 != d) throw ArgFailure("pg_set_edges: the set must be a binary pose-pose set of matching dimension");
+  if (!vi || !vj || !meas || !info) throw ArgFailure("pg_set_edges: null array");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  const size_t n = (size_t)es.n, ms = type == 1 ? 3 : 12;
+  pg_.set = set;
+  pg_.type = type;
+  pg_.vi.upload(vi, n, st_);
+  pg_.vj.upload(vj, n, st_);
+  pg_.meas.upload(meas, n * ms, st_);
+  es.own_omega.upload(info, n * d * d, st_);
+  es.own_J0.alloc(n * d * d);
+  es.own_J1.alloc(n * d * d);
+  es.own_err.alloc(n * d);
+  es.J0 = es.own_J0.p; es.J1 = es.own_J1.p; es.omega = es.own_omega.p; es.err = es.own_err.p;
+  es.has_data = false;
+  es.has_err = false;
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void BlockSolver::pg_set_estimates(int nv, const double* poses, const int* hidx) {
+  if (pg_.type == 0) throw StateFailure("pg_set_estimates: call pg_set_edges first");
+  if (nv <= 0 || !poses || !hidx) throw ArgFailure("pg_set_estimates: bad arguments");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  const size_t ps = pg_.type == 1 ? 3 : 12;
+  pg_.nv = nv;
+  pg_.poses.upload(poses, (size_t)nv * ps, st_);
+  pg_.hidx.upload(hidx, (size_t)nv, st_);
+  pg_.poses_bak.alloc((size_t)nv * ps);
+  pg_.has_backup = false;
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void BlockSolver::pg_get_estimates(double* poses) {
+  if (pg_.nv <= 0) throw StateFailure("pg_get_estimates before pg_set_estimates");
+  pg_.poses.download(poses, (size_t)pg_.nv * (pg_.type == 1 ? 3 : 12), st_);
+}
+
+void BlockSolver::pg_linearize(bool jacobians) {
+  if (pg_.set < 0 || pg_.nv <= 0) throw StateFailure("pg_linearize: call pg_set_edges and pg_set_estimates first");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  EdgeSet& es = *sets_[pg_.set];
+  if (pg_.type == 1)
+    hipLaunchKernelGGL(pg_se2_linearize_kernel, dim3(grid_for(es.n)), dim3(kThreads), 0, st_, es.n, pg_.poses.p, pg_.vi.p, pg_.vj.p,
+                       pg_.meas.p, es.own_J0.p, es.own_J1.p, es.own_err.p, jacobians ? 1 : 0);
+  else
+    hipLaunchKernelGGL(pg_se3_linearize_kernel, dim3(grid_for(es.n)), dim3(kThreads), 0, st_, es.n, pg_.poses.p, pg_.vi.p, pg_.vj.p,
+                       pg_.meas.p, es.own_J0.p, es.own_J1.p, es.own_err.p, jacobians ? 1 : 0);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+  es.has_err = true;
+  if (jacobians) es.has_data = true;
+}
+
+void BlockSolver::pg_update() {
+  require_structure();
+  if (pg_.nv <= 0) throw StateFailure("pg_update before pg_set_estimates");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (pg_.type == 1)
+    hipLaunchKernelGGL(pg_se2_update_kernel, dim3(grid_for(pg_.nv)), dim3(kThreads), 0, st_, pg_.nv, pg_.poses.p, pg_.hidx.p, d_x.p);
+  else
+    hipLaunchKernelGGL(pg_se3_update_kernel, dim3(grid_for(pg_.nv)), dim3(kThreads), 0, st_, pg_.nv, pg_.poses.p, pg_.hidx.p, d_x.p);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+void BlockSolver::pg_push() {
+  if (pg_.nv <= 0) throw StateFailure("pg_push before pg_set_estimates");
+  if (pg_.has_backup) throw StateFailure("pg_push: the estimate stack holds one level");
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(pg_.poses_bak.p, pg_.poses.p, (size_t)pg_.nv * (pg_.type == 1 ? 3 : 12) * sizeof(double),
+                                  hipMemcpyDeviceToDevice, st_));
+  pg_.has_backup = true;
+}
+void BlockSolver::pg_pop() {
+  if (!pg_.has_backup) throw StateFailure("pg_pop without push");
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(pg_.poses.p, pg_.poses_bak.p, (size_t)pg_.nv * (pg_.type == 1 ? 3 : 12) * sizeof(double),
+                                  hipMemcpyDeviceToDevice, st_));
+  pg_.has_backup = false;
+}
+void BlockSolver::pg_discard_top() {
+  if (!pg_.has_backup) throw StateFailure("pg_discard_top without push");
+  pg_.has_backup = false;
+}
+
+void BlockSolver::copy_edge_data(int set, double* J0, double* J1, double* err) {
+  if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
+  EdgeSet& es = *sets_[set];
+  if (!es.has_err) throw StateFailure("copy_edge_data: the set has no edge data yet");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  const size_t n = (size_t)es.n;
+  auto pull = [&](double* dst, const double* src, size_t cnt) {
+    if (!dst || !src || cnt == 0) return;
+    G2OHIP_HIP_CHECK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyDeviceToHost, st_));
+  };
+  if (es.has_data) {
+    pull(J0, es.J0, n * es.d * es.dim0);
+    if (!es.unary) pull(J1, es.J1, n * es.d * es.dim1);
+  } else if (J0 || J1) {
+    throw StateFailure("copy_edge_data: Jacobians were not produced (fused assembly or error-only linearize)");
+  }
+  pull(err, es.err, n * es.d);
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
 }
 
 void BlockSolver::device_array(int which, double** ptr, size_t* count) {

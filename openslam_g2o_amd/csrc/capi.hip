@@ -474,6 +474,57 @@ int g2ohip_ba_discard_top(g2ohip_solver* s) {
   });
 }
 
+int g2ohip_copy_edge_data(g2ohip_solver* s, int set, double* J0, double* J1, double* err) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->copy_edge_data(set, J0, J1, err);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_pg_set_edges(g2ohip_solver* s, int set, int type, const int32_t* vi, const int32_t* vj, const double* meas,
+                        const double* info) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->pg_set_edges(set, type, vi, vj, meas, info);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_pg_set_estimates(g2ohip_solver* s, int n_vertices, const double* poses, const int32_t* hidx) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->pg_set_estimates(n_vertices, poses, hidx);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_pg_get_estimates(g2ohip_solver* s, double* poses) {
+  REQUIRE_HANDLE(s);
+  if (!poses) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    s->impl->pg_get_estimates(poses);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_pg_linearize(g2ohip_solver* s, int jacobians) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->pg_linearize(jacobians != 0);
+    return G2OHIP_OK;
+  });
+}
+#define G2OHIP_PG_SIMPLE(NAME, METHOD)   \
+  int NAME(g2ohip_solver* s) {           \
+    REQUIRE_HANDLE(s);                   \
+    return guarded([&] {                 \
+      s->impl->METHOD();                 \
+      return G2OHIP_OK;                  \
+    });                                  \
+  }
+G2OHIP_PG_SIMPLE(g2ohip_pg_update, pg_update)
+G2OHIP_PG_SIMPLE(g2ohip_pg_push, pg_push)
+G2OHIP_PG_SIMPLE(g2ohip_pg_pop, pg_pop)
+G2OHIP_PG_SIMPLE(g2ohip_pg_discard_top, pg_discard_top)
+#undef G2OHIP_PG_SIMPLE
+
 // ---- narrow seam ---------------------------------------------------------------------
 int g2ohip_ls_create(g2ohip_linear_solver** out, int block_dim, int device) {
   if (!out) return G2OHIP_ERR_ARG;

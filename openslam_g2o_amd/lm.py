@@ -148,3 +148,48 @@ def setup_device_ba(prob, huber_delta=0.0, device=0):
     if huber_delta > 0:
         s.setRobustKernel(k, capi.KERNEL_HUBER, huber_delta)
     return s, DeviceBAGraph(s)
+
+
+class DevicePoseGraph:
+    """The graph protocol over HipBlockSolver's device-resident pose-graph front end (EdgeSE2 / EdgeSE3)."""
+
+    def __init__(self, solver):
+        self.s = solver
+
+    def linearize(self):
+        self.s.pgLinearize(True)
+
+    def compute_active_errors(self):
+        self.s.pgLinearize(False)
+
+    def chi2(self):
+        return self.s.chi2()
+
+    def update(self):
+        self.s.pgUpdate()
+
+    def push(self):
+        self.s.pgPush()
+
+    def pop(self):
+        self.s.pgPop()
+
+    def discard_top(self):
+        self.s.pgDiscardTop()
+
+
+def setup_device_pose_graph(edge_type, estimates, hidx, num_free, vi, vj, meas, info, landmark_dim=None, device=0):
+    """HipBlockSolver for a pose graph with estimates, errors and Jacobians on the device.
+    edge_type 1: EdgeSE2 (estimates / measurements (x, y, theta), information [n][9]);
+    edge_type 2: EdgeSE3 (isometries [12] = R column-major | t, information [n][36]).
+    hidx[v] = hessian index of vertex v or -1 (fixed); BlockSolver_3_2 / BlockSolver_6_3 semantics, no Schur."""
+    import numpy as np
+    from . import capi
+    d = 3 if edge_type == 1 else 6
+    s = capi.HipBlockSolver(d, landmark_dim or (2 if edge_type == 1 else 3), device)
+    hidx = np.asarray(hidx, np.int32)
+    k = s.addEdgeSet(d, hidx[np.asarray(vi)], hidx[np.asarray(vj)])
+    s.buildStructure(num_free, 0, False)
+    s.pgSetEdges(k, edge_type, vi, vj, meas, info)
+    s.pgSetEstimates(estimates, hidx)
+    return s, DevicePoseGraph(s)
