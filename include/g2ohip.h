@@ -61,6 +61,7 @@ typedef struct g2ohip_stats {
   size_t hessianDimension, hessianPoseDimension, hessianLandmarkDimension;
   size_t choleskyNNZ;                /* scalar nnz(L)                        */
   size_t numFronts, numLevels, maxFrontDim;
+  size_t iterationsLinearSolver;     /* PCG iterations of the last solve (G2OBatchStatistics::iterationsLinearSolver) */
 } g2ohip_stats;
 
 const char* g2ohip_last_error(void);

@@ -31,7 +31,7 @@ class Stats(C.Structure):
         "timeQuadraticForm", "timeSchurComplement", "timeSymbolicDecomposition", "timeNumericDecomposition",
         "timeLinearSolution", "timeLinearSolver", "timeBackSubstitution")] + [(n, C.c_size_t) for n in (
             "hessianDimension", "hessianPoseDimension", "hessianLandmarkDimension", "choleskyNNZ", "numFronts",
-            "numLevels", "maxFrontDim")]
+            "numLevels", "maxFrontDim", "iterationsLinearSolver")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -15,6 +15,7 @@
 #include <memory>
 
 #include "common.h"
+#include "block_pcg.h"
 #include "sparse_cholesky.h"
 
 namespace g2ohip {
@@ -122,6 +123,9 @@ class BlockSolver {
   // per-rank work shrinks (multi-GPU).  Needs a non-default stream.  Timing events sit between the graphs.
   bool use_graph = false;
   void invalidate_graphs();
+  int linear_solver = 0;                   // 0: multifrontal block Cholesky, 1: block-Jacobi PCG (LinearSolverPCG)
+  PcgOptions pcg_opt;
+  int pcg_iterations = 0;
   bool fuse_landmark_inverse = true;       // invert the landmark blocks inside the Schur tile kernel
   bool tiles_cover_all_ = false;
   bool mask_solution = true;               // solve_reduced_shared zeroes the x_p entries other ranks own (all-reduce of x_p)
@@ -181,6 +185,7 @@ class BlockSolver {
   DevBuf<int> d_pp_colptr, d_pp_row;
   long n_sc_ = 0;
   std::unique_ptr<SparseCholesky> chol_;
+  std::unique_ptr<BlockPCG> pcg_;
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
     double f = 0, cx = 0, cy = 0;

@@ -1800,6 +1800,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   G2OHIP_HIP_CHECK(hipMemsetAsync(d_b.p, 0, vector_size() * sizeof(double), st_));
   G2OHIP_HIP_CHECK(hipMemsetAsync(d_x.p, 0, vector_size() * sizeof(double), st_));
   // ---- symbolic factorisation of the system the linear solver will see
+  pcg_.reset();
   chol_ = std::make_unique<SparseCholesky>(p);
   chol_->opt = chol_opt;
   if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
@@ -2189,6 +2190,25 @@ int BlockSolver::solve_reduced() {
   if (!chol_->analyzed()) {
     if (schur_) chol_->analyze(nP_, hs_colptr.data(), hs_row.data(), st_);
     else chol_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
+  }
+  if (linear_solver == 1) {   // LinearSolverPCG on the reduced system
+    if (!pcg_) pcg_ = std::make_unique<BlockPCG>(p_);
+    if (!pcg_->analyzed()) {
+      if (schur_) pcg_->analyze(nP_, hs_colptr.data(), hs_row.data(), st_);
+      else pcg_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
+    }
+    pcg_->opt = pcg_opt;
+    if (profiling) tn_.start(st_);
+    prof.begin(KernelProf::kCholFactor, st_);
+    const bool ok = pcg_->solve(schur_ ? d_Hschur.p : d_Hpp.p, schur_ ? d_bschur.p : d_b.p, d_x.p, st_);
+    prof.end(KernelProf::kCholFactor, st_);
+    if (profiling) {
+      tn_.stop(st_);
+      times.numeric = tn_.seconds();
+      times.linsolve = 0.0;
+    }
+    pcg_iterations = pcg_->last_iterations();
+    return ok ? 0 : 1;
   }
   solve_reduced_device();
   bool bad = chol_->failed(st_);   // synchronises

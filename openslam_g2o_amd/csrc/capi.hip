@@ -353,6 +353,7 @@ int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out) {
   out->hessianLandmarkDimension = (size_t)b.nL() * b.l();
   out->hessianDimension = out->hessianPoseDimension + out->hessianLandmarkDimension;
   fill_chol_stats(b.chol_stats(), out);
+  out->iterationsLinearSolver = (size_t)b.pcg_iterations;
   return G2OHIP_OK;
 }
 
@@ -370,6 +371,11 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "schur_tile_bytes")) s->impl->schur_tile_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_group")) s->impl->schur_group = (int)value;
   else if (!std::strcmp(name, "mask_solution")) s->impl->mask_solution = value != 0;
+  else if (!std::strcmp(name, "linear_solver")) s->impl->linear_solver = (int)value;       // 0 Cholesky, 1 PCG
+  else if (!std::strcmp(name, "pcg_tolerance")) s->impl->pcg_opt.tolerance = value;
+  else if (!std::strcmp(name, "pcg_max_iterations")) s->impl->pcg_opt.max_iter = (int)value;
+  else if (!std::strcmp(name, "pcg_absolute_tolerance")) s->impl->pcg_opt.absolute_tolerance = value != 0;
+  else if (!std::strcmp(name, "pcg_check_every")) s->impl->pcg_opt.check_every = std::max(1, (int)value);
   else if (!std::strcmp(name, "fuse_landmark_inverse")) s->impl->fuse_landmark_inverse = value != 0;
   else if (!std::strcmp(name, "use_graph")) s->impl->use_graph = value != 0;
   else if (!std::strcmp(name, "ba_fused")) s->impl->ba_fused = value != 0;

@@ -733,3 +733,79 @@ void orc_destroy(Orc* s) {
   free(s->ext_block_perm); free(s->extra_r); free(s->extra_c);
   free(s);
 }
+
+/* ========================================================================
+ * LinearSolverPCG<MatrixType>::solve, g2o/solvers/pcg/linear_solver_pcg.hpp:79-196 (+ defaults
+ * linear_solver_pcg.h:53-57): block-Jacobi preconditioned CG on the upper block-CCS matrix.
+ *   J_i = A_ii^-1 (:96, Eigen inverse(); here Gauss-Jordan with partial pivoting),
+ *   x = 0, r = b, d = J r, dn = r'd, d0 = tol*dn (raised to the previous call's residual when absolute, :127-131),
+ *   loop (:135-151): stop when dn <= d0; q = A d (mult :192-213: diagonal blocks, then every upper block and its
+ *   transpose); a = dn/d'q; x += a d; r -= a q; s = J r; ba = r's / dn; d = s + ba d.
+ *   residual_inout: in = _residual of the previous solve (<= 0: none), out = 0.5 * dn (:153).
+ * Test infrastructure only.
+ * ======================================================================== */
+static int small_inverse_gj(int n, const double* A /* col-major */, double* R) {
+  double M[16 * 32];
+  if (n > 16) return 0;
+  for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) { M[r * 2 * n + c] = A[r + n * c]; M[r * 2 * n + n + c] = (r == c); }
+  for (int c = 0; c < n; ++c) {
+    int p = c; double best = fabs(M[c * 2 * n + c]);
+    for (int r = c + 1; r < n; ++r) if (fabs(M[r * 2 * n + c]) > best) { best = fabs(M[r * 2 * n + c]); p = r; }
+    if (best == 0.0) return 0;
+    if (p != c) for (int k = 0; k < 2 * n; ++k) { double t = M[c * 2 * n + k]; M[c * 2 * n + k] = M[p * 2 * n + k]; M[p * 2 * n + k] = t; }
+    double inv = 1.0 / M[c * 2 * n + c];
+    for (int k = 0; k < 2 * n; ++k) M[c * 2 * n + k] *= inv;
+    for (int r = 0; r < n; ++r) if (r != c) { double f = M[r * 2 * n + c]; if (f != 0.0) for (int k = 0; k < 2 * n; ++k) M[r * 2 * n + k] -= f * M[c * 2 * n + k]; }
+  }
+  for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) R[r + n * c] = M[r * 2 * n + n + c];
+  return 1;
+}
+
+int orc_pcg_solve_blocks(int nb, int bs, const int* colptr, const int* row, const double* val, const double* b, double* x,
+                         double tolerance, int absolute, int max_iter, double* residual_inout, int* iterations) {
+  const int n = nb * bs, bb = bs * bs;
+  double* J = (double*)malloc(sizeof(double) * (size_t)nb * bb);
+  int* diag = (int*)malloc(sizeof(int) * (size_t)nb);
+  double* r = (double*)malloc(sizeof(double) * (size_t)n * 4);
+  double *d = r + n, *q = d + n, *s = q + n;
+  int ok = 1;
+  for (int c = 0; c < nb && ok; ++c) {
+    diag[c] = -1;
+    for (int k = colptr[c]; k < colptr[c + 1]; ++k) if (row[k] == c) diag[c] = k;
+    if (diag[c] < 0 || !small_inverse_gj(bs, val + (size_t)diag[c] * bb, J + (size_t)c * bb)) ok = 0;
+  }
+  if (!ok) { free(J); free(diag); free(r); return 0; }
+#define MULT_DIAG(M_, idx_, src_, dst_) \
+  for (int i_ = 0; i_ < nb; ++i_) { const double* B_ = (M_) + (size_t)(idx_) * bb; \
+    for (int rr = 0; rr < bs; ++rr) { double t_ = 0; for (int cc = 0; cc < bs; ++cc) t_ += B_[rr + bs * cc] * (src_)[i_ * bs + cc]; (dst_)[i_ * bs + rr] = t_; } }
+  for (int i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; }
+  MULT_DIAG(J, i_, r, d)
+  double dn = 0; for (int i = 0; i < n; ++i) dn += r[i] * d[i];
+  double d0 = tolerance * dn;
+  if (absolute && residual_inout && *residual_inout > 0.0 && *residual_inout > d0) d0 = *residual_inout;
+  int maxit = max_iter < 0 ? n : max_iter, it;
+  for (it = 0; it < maxit; ++it) {
+    if (dn <= d0) break;
+    MULT_DIAG(val, diag[i_], d, q)
+    for (int c = 0; c < nb; ++c)
+      for (int k = colptr[c]; k < colptr[c + 1]; ++k) {
+        const int rw = row[k]; if (rw == c) continue;
+        const double* B = val + (size_t)k * bb;
+        for (int rr = 0; rr < bs; ++rr) { double t = 0; for (int cc = 0; cc < bs; ++cc) t += B[rr + bs * cc] * d[c * bs + cc]; q[rw * bs + rr] += t; }
+        for (int cc = 0; cc < bs; ++cc) { double t = 0; for (int rr = 0; rr < bs; ++rr) t += B[rr + bs * cc] * d[rw * bs + rr]; q[c * bs + cc] += t; }
+      }
+    double dq = 0; for (int i = 0; i < n; ++i) dq += d[i] * q[i];
+    const double a = dn / dq;
+    for (int i = 0; i < n; ++i) { x[i] += a * d[i]; r[i] -= a * q[i]; }
+    MULT_DIAG(J, i_, r, s)
+    const double dold = dn;
+    dn = 0; for (int i = 0; i < n; ++i) dn += r[i] * s[i];
+    const double ba = dn / dold;
+    for (int i = 0; i < n; ++i) d[i] = s[i] + ba * d[i];
+  }
+#undef MULT_DIAG
+  if (residual_inout) *residual_inout = 0.5 * dn;
+  if (iterations) *iterations = it;
+  free(J); free(diag); free(r);
+  return 1;
+}

@@ -427,3 +427,18 @@ def se3_oplus(poses, hidx, x):
     hidx, x = _i32(hidx), _f64(x)
     L.orc_se3_oplus(len(hidx), _dp(poses), _ip(hidx), _dp(x))
     return poses
+
+
+def pcg_solve_blocks(nb, bs, colptr, row, val, b, tolerance=1e-6, absolute=True, max_iter=-1, residual=-1.0):
+    """LinearSolverPCG::solve restated (oracle/g2o_oracle.c): returns (ok, x, iterations, residual_out)."""
+    L = lib()
+    colptr, row, val, b = _i32(colptr), _i32(row), _f64(val), _f64(b)
+    x = np.zeros(nb * bs)
+    res = C.c_double(residual)
+    it = C.c_int(0)
+    L.orc_pcg_solve_blocks.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int, C.c_int,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    ok = L.orc_pcg_solve_blocks(nb, bs, _ip(colptr), _ip(row), _dp(val), _dp(b), _dp(x), tolerance, int(absolute), max_iter,
+                                C.byref(res), C.byref(it))
+    return bool(ok), x, it.value, res.value
