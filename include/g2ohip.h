@@ -155,7 +155,14 @@ int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out);
 int g2ohip_kernel_slots(void);
 const char* g2ohip_kernel_name(int slot);
 int g2ohip_kernel_time(g2ohip_solver* s, int slot, double* total_seconds, long* launches, int reset);
-/* Ordering / symbolic tuning knob: nested-dissection leaf size in blocks (default 32). */
+/* Options (name, value).  Linear solver of the reduced system: "linear_solver" 0 = multifrontal block Cholesky
+ * (replaces LinearSolverCSparse / LinearSolverCholmod), 1 = block-Jacobi preconditioned CG (replaces
+ * LinearSolverPCG, g2o/solvers/pcg/linear_solver_pcg.hpp:79-196) with "pcg_tolerance" (1e-6),
+ * "pcg_absolute_tolerance" (1), "pcg_max_iterations" (-1 = dimension), like LinearSolverPCG's setters
+ * (linear_solver_pcg.h:74-85); iterations of the last solve in g2ohip_stats.iterationsLinearSolver.
+ * Ordering / symbolic knobs: "nd_leaf" (nested-dissection leaf size in blocks, 32), "max_sn_scalars",
+ * "relax_zeros", "relax_front_bytes", "lds_front_bytes", "fuse_chains", "wave_front_tasks".  Kernel knobs:
+ * "schur_tile_bytes", "schur_group", "fuse_landmark_inverse", "ba_fused", "use_graph", "mask_solution". */
 int g2ohip_set_option(g2ohip_solver* s, const char* name, double value);
 
 /* Inspection for parity tests (saveHessian-like, block_solver.hpp:628-632): block patterns
