@@ -10,8 +10,8 @@ from oracle import oracle as O
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def ba_case(P, L, seed=42, outlier_frac=0.0):
-    pr = S.make_ba_problem(P, L, seed=seed, outlier_frac=outlier_frac)
+def ba_case(P, L, seed=42, outlier_frac=0.0, obs_per_landmark=5):
+    pr = S.make_ba_problem(P, L, seed=seed, outlier_frac=outlier_frac, obs_per_landmark=obs_per_landmark)
     Jp, Jc, err = S.ba_linearize(pr)
     pr.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(pr))
     return pr

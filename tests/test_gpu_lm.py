@@ -107,6 +107,26 @@ def test_device_producers_match_oracle(fused):
     assert np.array_equal(cams2, pr["cams"]) and np.array_equal(pts2, pr["pts"])   # pop restores bit-exactly
 
 
+@pytest.mark.parametrize("K", [2, 11, 23])
+def test_fused_assembly_with_short_and_long_observation_lists(K):
+    """Landmarks with fewer / more observations than the 8 lanes of their group: the looped lanes, the LDS-staged
+    Hpl stream-out (a wave's blocks beyond its 64 slots fall back to direct stores) and the pose-major copies."""
+    pr = ba_case(40, 90, obs_per_landmark=K)
+    s, g = lm.setup_device_ba(pr)
+    g.linearize()
+    s.buildSystem()
+    o = oracle_ba(pr)
+    o.build_system()
+    from openslam_g2o_amd import capi
+    for which, name in ((capi.HPP, "Hpp"), (capi.HPL, "Hpl"), (capi.HLL, "Hll")):
+        assert relerr(s.values(which), o.values(name)) < 1e-12, name
+    assert relerr(s.b(), o.b()) < 1e-12
+    s.setLambda(5.0, True)
+    o.set_lambda(5.0, True)
+    assert s.solve() and o.solve()
+    assert relerr(s.x(), o.x()) < 1e-8
+
+
 @pytest.mark.parametrize("huber,outliers", [(0.0, 0.0), (1.0, 0.05)])
 def test_lm_trajectory_matches_oracle(huber, outliers):
     pr = ba_case(60, 600, outlier_frac=outliers)
