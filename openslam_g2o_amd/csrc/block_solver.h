@@ -126,6 +126,8 @@ class BlockSolver {
   int linear_solver = 0;                   // 0: multifrontal block Cholesky, 1: block-Jacobi PCG (LinearSolverPCG)
   PcgOptions pcg_opt;
   int pcg_iterations = 0;
+  bool schur_sort_dests = true;            // order a tile's destinations by entry count (lockstep lane groups)
+  int num_cus_ = 256;
   bool fuse_landmark_inverse = true;       // invert the landmark blocks inside the Schur tile kernel
   bool tiles_cover_all_ = false;
   bool mask_solution = true;               // solve_reduced_shared zeroes the x_p entries other ranks own (all-reduce of x_p)

@@ -388,97 +388,11 @@ __global__ void __launch_bounds__(kThreads) landmark_inverse_kernel(int nL, cons
 // loads (Hpl is read once per iteration instead of once per pose pair), together with Dinv, b_l and the
 // tile's contributor entries.  Each destination block touched by the tile is owned by G lanes that walk
 // its entry list out of LDS (no atomics, fixed order) and write one partial block to HBM.
-template <int PD, int LD, int G>
-#ifndef G2OHIP_SCHUR_OCC
-#define G2OHIP_SCHUR_OCC 3
-#endif
-__global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(const int* __restrict__ tile_lm0, const int* __restrict__ tile_td0,
-                                                            const int* __restrict__ pl_colptr, const double* __restrict__ Hpl,
-                                                            double* __restrict__ Dinv, const double* __restrict__ bl,
-                                                            const int* __restrict__ td_diag, const int* __restrict__ td_ptr,
-                                                            const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm,
-                                                            double* __restrict__ Pd,
-                                                            double* __restrict__ Pr, const double* __restrict__ Hll,
-                                                            const double* __restrict__ lam) {
-  // Hll != nullptr: the landmark inversion (block_solver.hpp:386-389, with the virtual damping) is done here on
-  // the staged blocks -- the tile reads Hll instead of Dinv and writes Dinv (back-substitution needs it) on the way.
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int PL = PD * LD;
-  const int t = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int* tm = tile_lm0 + (size_t)t * 8;   // packed tile record (see build_structure)
-  const int l0 = tm[0], l1 = tm[1], q0 = tm[2], nslots = tm[3], nlm = l1 - l0;
-  const int td0 = tm[4], td1 = tm[5], e0 = tm[6], ne = tm[7];
-  double* Bs = smem;
-  double* Ds = Bs + ((nslots * PL + 1) & ~1);
-  double* bsm = Ds + ((nlm * LD * LD + 1) & ~1);
-  int* ep = reinterpret_cast<int*>(bsm + ((nlm * LD + 1) & ~1));
-  int* dptr = ep + ne;                                // td_ptr[td0 .. td1]
-  int* ddiag = dptr + (td1 - td0 + 1);                // destination is a diagonal block?
-  unsigned short* el = reinterpret_cast<unsigned short*>(ddiag + (td1 - td0));
-  const int tid = threadIdx.x, NT = blockDim.x;
-  {
-    // All global loads of the tile are issued before the first LDS store (one HBM round trip in total);
-    // anything beyond the unrolled part (only with an enlarged tile budget) goes through stage_copy.
-    const dbl2_u* srcB = reinterpret_cast<const dbl2_u*>(Hpl + (size_t)q0 * PL);
-    dbl2_u* dstB = reinterpret_cast<dbl2_u*>(Bs);
-    const int n2 = (nslots * PL) >> 1;
-    const double* srcD = (Hll ? Hll : Dinv) + (size_t)l0 * LD * LD;
-    const double* srcb = bl + (size_t)l0 * LD;
-    const int nD = nlm * LD * LD, nb = nlm * LD, ndp = td1 - td0 + 1;
-    constexpr int UB = 12, UD = 3, UE = 4;
-    dbl2_u vB[UB];
-    double vD[UD], vb;
-    int vE[UE], vP, vG;
-    unsigned short vL[UE];
-    // branch-free loads (indices clamped into range) so that the compiler emits them back to back
-    // without intermediate s_waitcnt; the LDS stores below are predicated instead
-#pragma unroll
-    for (int u = 0; u < UB; ++u) vB[u] = srcB[min(tid + u * NT, n2 - 1)];
-#pragma unroll
-    for (int u = 0; u < UD; ++u) vD[u] = srcD[min(tid + u * NT, nD - 1)];
-    vb = srcb[min(tid, nb - 1)];
-#pragma unroll
-    for (int u = 0; u < UE; ++u) {
-      const int i = min(tid + u * NT, ne - 1);
-      vE[u] = te_pack[e0 + i];
-      vL[u] = te_lm[e0 + i];
-    }
-    vP = td_ptr[td0 + min(tid, ndp - 1)];
-    vG = td_diag[td0 + min(tid, max(ndp - 2, 0))];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int i = tid + u * NT;
-      if (i < n2) dstB[i] = vB[u];
-    }
-#pragma unroll
-    for (int u = 0; u < UD; ++u) {
-      const int i = tid + u * NT;
-      if (i < nD) Ds[i] = vD[u];
-    }
-    if (tid < nb) bsm[tid] = vb;
-#pragma unroll
-    for (int u = 0; u < UE; ++u) {
-      const int i = tid + u * NT;
-      if (i < ne) {
-        ep[i] = vE[u];
-        el[i] = vL[u];
-      }
-    }
-    if (tid < ndp) dptr[tid] = vP;
-    if (tid < ndp - 1) ddiag[tid] = vG;
-    // remainders
-    if (n2 > UB * NT) stage_copy<4>(dstB + UB * NT, srcB + UB * NT, n2 - UB * NT, tid, NT);
-    if (((nslots * PL) & 1) && tid == 0) Bs[nslots * PL - 1] = Hpl[(size_t)q0 * PL + nslots * PL - 1];
-    if (nD > UD * NT) stage_copy<4>(Ds + UD * NT, srcD + UD * NT, nD - UD * NT, tid, NT);
-    if (nb > NT) stage_copy<2>(bsm + NT, srcb + NT, nb - NT, tid, NT);
-    if (ne > UE * NT) {
-      stage_copy<4>(ep + UE * NT, te_pack + e0 + UE * NT, ne - UE * NT, tid, NT);
-      stage_copy<4>(el + UE * NT, te_lm + e0 + UE * NT, ne - UE * NT, tid, NT);
-    }
-    if (ndp > NT) stage_copy<2>(dptr + NT, td_ptr + td0 + NT, ndp - NT, tid, NT);
-    if (ndp - 1 > NT) stage_copy<2>(ddiag + NT, td_diag + td0 + NT, ndp - 1 - NT, tid, NT);
-  }
-  __syncthreads();
+// Shared by the two tile kernels: (optional) landmark inversion on the staged blocks, then the destination loop.
+// (optional) landmark inversion on the staged blocks; ends with the Dinv write (after a barrier)
+template <int LD>
+__device__ __forceinline__ void schur_tile_invert(double* Ds, int l0, int nlm, double* __restrict__ Dinv, const double* __restrict__ Hll,
+                                                  const double* __restrict__ lam, int tid, int NT) {
   if (Hll) {
     const double lambda = lam[1];
     for (int j = tid; j < nlm; j += NT) {
@@ -495,6 +409,14 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
     double* dstD = Dinv + (size_t)l0 * LD * LD;
     for (int i = tid; i < nlm * LD * LD; i += NT) dstD[i] = Ds[i];
   }
+}
+
+// the destination loop (no barrier inside)
+template <int PD, int LD, int G, class EL>
+__device__ __forceinline__ void schur_tile_dests(const double* Bs, const double* Ds, const double* bsm, const int* ep, const int* dptr,
+                                                 const int* ddiag, const EL* el, int td0, int td1, int e0, double* __restrict__ Pd,
+                                                 double* __restrict__ Pr, int tid, int NT) {
+  constexpr int PL = PD * LD;
   // G lanes per destination block = GC column parts x GE entry parts: a lane owns PD/GC columns of the
   // block (PD*PD/GC accumulator registers instead of PD*PD: what keeps 3 workgroups on a CU) and walks
   // every GE-th entry; the GE partial sums are combined with DPP (fixed order: deterministic).
@@ -588,6 +510,101 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
         if (GE == 1 || (r % GE) == ge) Pr[(size_t)ld * PD + r] = cacc[r];
     }
   }
+}
+
+template <int PD, int LD, int G>
+#ifndef G2OHIP_SCHUR_OCC
+#define G2OHIP_SCHUR_OCC 3
+#endif
+__global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(const int* __restrict__ tile_lm0, const int* __restrict__ tile_td0,
+                                                            const int* __restrict__ pl_colptr, const double* __restrict__ Hpl,
+                                                            double* __restrict__ Dinv, const double* __restrict__ bl,
+                                                            const int* __restrict__ td_diag, const int* __restrict__ td_ptr,
+                                                            const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm,
+                                                            double* __restrict__ Pd,
+                                                            double* __restrict__ Pr, const double* __restrict__ Hll,
+                                                            const double* __restrict__ lam) {
+  // Hll != nullptr: the landmark inversion (block_solver.hpp:386-389, with the virtual damping) is done here on
+  // the staged blocks -- the tile reads Hll instead of Dinv and writes Dinv (back-substitution needs it) on the way.
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int PL = PD * LD;
+  const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int* tm = tile_lm0 + (size_t)t * 8;   // packed tile record (see build_structure)
+  const int l0 = tm[0], l1 = tm[1], q0 = tm[2], nslots = tm[3], nlm = l1 - l0;
+  const int td0 = tm[4], td1 = tm[5], e0 = tm[6], ne = tm[7];
+  double* Bs = smem;
+  double* Ds = Bs + ((nslots * PL + 1) & ~1);
+  double* bsm = Ds + ((nlm * LD * LD + 1) & ~1);
+  int* ep = reinterpret_cast<int*>(bsm + ((nlm * LD + 1) & ~1));
+  int* dptr = ep + ne;                                // td_ptr[td0 .. td1]
+  int* ddiag = dptr + (td1 - td0 + 1);                // destination is a diagonal block?
+  unsigned short* el = reinterpret_cast<unsigned short*>(ddiag + (td1 - td0));
+  const int tid = threadIdx.x, NT = blockDim.x;
+  {
+    // All global loads of the tile are issued before the first LDS store (one HBM round trip in total);
+    // anything beyond the unrolled part (only with an enlarged tile budget) goes through stage_copy.
+    const dbl2_u* srcB = reinterpret_cast<const dbl2_u*>(Hpl + (size_t)q0 * PL);
+    dbl2_u* dstB = reinterpret_cast<dbl2_u*>(Bs);
+    const int n2 = (nslots * PL) >> 1;
+    const double* srcD = (Hll ? Hll : Dinv) + (size_t)l0 * LD * LD;
+    const double* srcb = bl + (size_t)l0 * LD;
+    const int nD = nlm * LD * LD, nb = nlm * LD, ndp = td1 - td0 + 1;
+    constexpr int UB = 12, UD = 3, UE = 4;
+    dbl2_u vB[UB];
+    double vD[UD], vb;
+    int vE[UE], vP, vG;
+    unsigned short vL[UE];
+    // branch-free loads (indices clamped into range) so that the compiler emits them back to back
+    // without intermediate s_waitcnt; the LDS stores below are predicated instead
+#pragma unroll
+    for (int u = 0; u < UB; ++u) vB[u] = srcB[min(tid + u * NT, n2 - 1)];
+#pragma unroll
+    for (int u = 0; u < UD; ++u) vD[u] = srcD[min(tid + u * NT, nD - 1)];
+    vb = srcb[min(tid, nb - 1)];
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+      const int i = min(tid + u * NT, ne - 1);
+      vE[u] = te_pack[e0 + i];
+      vL[u] = te_lm[e0 + i];
+    }
+    vP = td_ptr[td0 + min(tid, ndp - 1)];
+    vG = td_diag[td0 + min(tid, max(ndp - 2, 0))];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int i = tid + u * NT;
+      if (i < n2) dstB[i] = vB[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      const int i = tid + u * NT;
+      if (i < nD) Ds[i] = vD[u];
+    }
+    if (tid < nb) bsm[tid] = vb;
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+      const int i = tid + u * NT;
+      if (i < ne) {
+        ep[i] = vE[u];
+        el[i] = vL[u];
+      }
+    }
+    if (tid < ndp) dptr[tid] = vP;
+    if (tid < ndp - 1) ddiag[tid] = vG;
+    // remainders
+    if (n2 > UB * NT) stage_copy<4>(dstB + UB * NT, srcB + UB * NT, n2 - UB * NT, tid, NT);
+    if (((nslots * PL) & 1) && tid == 0) Bs[nslots * PL - 1] = Hpl[(size_t)q0 * PL + nslots * PL - 1];
+    if (nD > UD * NT) stage_copy<4>(Ds + UD * NT, srcD + UD * NT, nD - UD * NT, tid, NT);
+    if (nb > NT) stage_copy<2>(bsm + NT, srcb + NT, nb - NT, tid, NT);
+    if (ne > UE * NT) {
+      stage_copy<4>(ep + UE * NT, te_pack + e0 + UE * NT, ne - UE * NT, tid, NT);
+      stage_copy<4>(el + UE * NT, te_lm + e0 + UE * NT, ne - UE * NT, tid, NT);
+    }
+    if (ndp > NT) stage_copy<2>(dptr + NT, td_ptr + td0 + NT, ndp - NT, tid, NT);
+    if (ndp - 1 > NT) stage_copy<2>(ddiag + NT, td_diag + td0 + NT, ndp - 1 - NT, tid, NT);
+  }
+  __syncthreads();
+  schur_tile_invert<LD>(Ds, l0, nlm, Dinv, Hll, lam, tid, NT);
+  schur_tile_dests<PD, LD, G>(Bs, Ds, bsm, ep, dptr, ddiag, el, td0, td1, e0, Pd, Pr, tid, NT);
 }
 
 // K5+K7+K8, pass 2: Hschur(d) = Hpp(d) - sum_tiles partial(d) (fixed tile order), bschur = b_p - sum partial_rhs
@@ -1416,6 +1433,10 @@ BlockSolver::BlockSolver(int p, int l, int device) : p_(p), l_(l), device_(devic
   G2OHIP_HIP_CHECK(hipSetDevice(device));
   G2OHIP_HIP_CHECK(hipStreamCreate(&st_));
   own_stream_ = true;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) num_cus_ = prop.multiProcessorCount;
+  }
   if (!(p == 3 || p == 6 || p == 7)) throw ArgFailure("pose_dim must be 3, 6 or 7");
   if (!(l == 2 || l == 3 || l == 0)) throw ArgFailure("landmark_dim must be 2 or 3");
 }
@@ -1706,17 +1727,29 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         order.resize(ents.size());
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ents[a].dest < ents[b].dest; });  // landmark order kept per dest
-        for (size_t k = 0; k < order.size(); ++k) {
-          const Ent& e = ents[order[k]];
-          if (k == 0 || e.dest != ents[order[k - 1]].dest) {
-            if (k > 0) td_ptr.push_back((int)te_pack.size());
-            td_dest.push_back(e.dest);
-            rd_cnt[e.dest]++;
-          }
-          te_pack.push_back(e.pack);
-          te_lm.push_back(e.lml);
+        // runs of equal destination, longest first: the lane groups of one wave run in lockstep, so a wave should
+        // hold destinations with similar entry counts (the order of the partials of a destination over the tiles,
+        // and the entry order inside a destination, are unaffected: results do not change)
+        std::vector<std::pair<int, int>> runs;   // (begin, end) into order
+        for (size_t k = 0; k < order.size();) {
+          size_t k2 = k + 1;
+          while (k2 < order.size() && ents[order[k2]].dest == ents[order[k]].dest) ++k2;
+          runs.emplace_back((int)k, (int)k2);
+          k = k2;
         }
-        if (!order.empty()) td_ptr.push_back((int)te_pack.size());
+        if (schur_sort_dests)
+          std::stable_sort(runs.begin(), runs.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
+            return (x.second - x.first) > (y.second - y.first);
+          });
+        for (const auto& run : runs) {
+          td_dest.push_back(ents[order[run.first]].dest);
+          rd_cnt[ents[order[run.first]].dest]++;
+          for (int k = run.first; k < run.second; ++k) {
+            te_pack.push_back(ents[order[k]].pack);
+            te_lm.push_back(ents[order[k]].lml);
+          }
+          td_ptr.push_back((int)te_pack.size());
+        }
         tile_lm0.push_back(lm);
         tile_td0.push_back((int)td_dest.size());
       }

@@ -371,6 +371,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "schur_tile_bytes")) s->impl->schur_tile_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_group")) s->impl->schur_group = (int)value;
   else if (!std::strcmp(name, "mask_solution")) s->impl->mask_solution = value != 0;
+  else if (!std::strcmp(name, "schur_sort_dests")) s->impl->schur_sort_dests = value != 0;
   else if (!std::strcmp(name, "linear_solver")) s->impl->linear_solver = (int)value;       // 0 Cholesky, 1 PCG
   else if (!std::strcmp(name, "pcg_tolerance")) s->impl->pcg_opt.tolerance = value;
   else if (!std::strcmp(name, "pcg_max_iterations")) s->impl->pcg_opt.max_iter = (int)value;
