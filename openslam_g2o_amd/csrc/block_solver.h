@@ -116,7 +116,7 @@ class BlockSolver {
   KernelProf prof;
   SolverTimes times;
   CholOptions chol_opt;
-  size_t schur_tile_bytes = 48 * 1024;     // LDS budget of one Schur tile
+  size_t schur_tile_bytes = 39 * 1024;     // LDS budget of one Schur tile
   bool ba_fused = true;                    // evaluate BA errors/Jacobians inside the assembly kernels (no J arrays)
   // hipGraph replay of the launch-bound kernel sequences (one launch per tree level: factorisation with the
   // fused forward sweep, backward sweep): ~30 launches per iteration, which is what limits a rank once the

@@ -417,10 +417,12 @@ __device__ __forceinline__ void schur_tile_dests(const double* Bs, const double*
                                                  const int* ddiag, const EL* el, int td0, int td1, int e0, double* __restrict__ Pd,
                                                  double* __restrict__ Pr, int tid, int NT) {
   constexpr int PL = PD * LD;
-  // G lanes per destination block = GC column parts x GE entry parts: a lane owns PD/GC columns of the
-  // block (PD*PD/GC accumulator registers instead of PD*PD: what keeps 3 workgroups on a CU) and walks
-  // every GE-th entry; the GE partial sums are combined with DPP (fixed order: deterministic).
-  constexpr int GC = (PD % 2 == 0 && G >= 2) ? 2 : 1, GE = G / GC, NC = PD / GC;
+  // G lanes per destination block = GC row parts x GE entry parts: a lane owns NR = PD/GC ROWS of the block
+  // (PD*PD/GC accumulator registers: what keeps 3 workgroups on a CU) and walks every GE-th entry.  With the row
+  // split a lane only needs its own rows of W = B_s1 Dinv (NR*LD*LD FMAs instead of PD*LD*LD): the kernel is
+  // bound by VALU issue, and this takes a quarter of its FMAs away.  The GE partial sums are combined with DPP
+  // (fixed order: deterministic).  Partial block layout in Pd: [row part][column][row inside the part].
+  constexpr int GC = (PD % 2 == 0 && G >= 2) ? 2 : 1, GE = G / GC, NR = PD / GC;
   static_assert(GE == 1 || GE == 2 || GE == 4 || GE == 8 || (GC == 1 && GE == 16), "unsupported lane group");
   auto ge_sum = [](double v) {   // sum over the GE lanes that share gc
     if (GC == 1) return group_sum<GE>(v);
@@ -432,67 +434,68 @@ __device__ __forceinline__ void schur_tile_dests(const double* Bs, const double*
   const int grp = tid / G, g = tid % G, ngroups = NT / G;
   const int gc = g % GC, ge = g / GC;
   for (int ld = td0 + grp; ld < td1; ld += ngroups) {
-    double acc[PD * NC], cacc[PD];
+    double acc[NR * PD], cacc[NR];   // acc[rr + NR * c]: row gc*NR + rr, column c
 #pragma unroll
-    for (int i = 0; i < PD * NC; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NR * PD; ++i) acc[i] = 0.0;
 #pragma unroll
-    for (int r = 0; r < PD; ++r) cacc[r] = 0.0;
+    for (int r = 0; r < NR; ++r) cacc[r] = 0.0;
     const bool diag = ddiag[ld - td0] != 0;
     const int k0 = dptr[ld - td0] - e0, k1 = dptr[ld - td0 + 1] - e0;
     for (int k = k0 + ge; k < k1; k += GE) {
       const int pk = ep[k], lm = el[k];
       const int s1 = pk & 0xffff, s2 = (pk >> 16) & 0xffff;
-      double W[PL];
+      double W[NR * LD];   // W[rr + NR * c] = (B_s1 Dinv)(gc*NR + rr, c)
       {
-        double Bj[PL], Di[LD * LD];
+        double B1[NR * LD], Di[LD * LD];
 #pragma unroll
         for (int i = 0; i < LD * LD; ++i) Di[i] = Ds[lm * (LD * LD) + i];
-        lds_block<PL>(Bs + s1 * PL, Bj);
+        const double* B1p = Bs + s1 * PL + gc * NR;
+#pragma unroll
+        for (int kk = 0; kk < LD; ++kk)
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) B1[rr + NR * kk] = B1p[rr + PD * kk];
 #pragma unroll
         for (int c = 0; c < LD; ++c)
 #pragma unroll
-          for (int r = 0; r < PD; ++r) {
+          for (int rr = 0; rr < NR; ++rr) {
             double v = 0.0;
 #pragma unroll
-            for (int kk = 0; kk < LD; ++kk) v += Bj[r + PD * kk] * Di[kk + LD * c];
-            W[r + PD * c] = v;
+            for (int kk = 0; kk < LD; ++kk) v += B1[rr + NR * kk] * Di[kk + LD * c];
+            W[rr + NR * c] = v;
           }
       }
-      if (diag && gc == 0) {   // s1 == s2: rhs contribution B (Dinv b_l) = W b_l
+      if (diag) {   // s1 == s2: rhs contribution B (Dinv b_l) = W b_l, this lane's rows
 #pragma unroll
         for (int c = 0; c < LD; ++c) {
           const double bv = bsm[lm * LD + c];
 #pragma unroll
-          for (int r = 0; r < PD; ++r) cacc[r] += W[r + PD * c] * bv;
+          for (int rr = 0; rr < NR; ++rr) cacc[rr] += W[rr + NR * c] * bv;
         }
       }
-      // this lane's columns of W * B_s2'
-      const double* B2 = Bs + s2 * PL + gc * NC;
+      // this lane's rows of W * B_s2'
+      double B2[PL];
+      lds_block<PL>(Bs + s2 * PL, B2);
 #pragma unroll
-      for (int cc = 0; cc < NC; ++cc) {
-        double b2[LD];
+      for (int c = 0; c < PD; ++c)
 #pragma unroll
-        for (int kk = 0; kk < LD; ++kk) b2[kk] = B2[cc + PD * kk];
-#pragma unroll
-        for (int r = 0; r < PD; ++r) {
+        for (int rr = 0; rr < NR; ++rr) {
           double v = 0.0;
 #pragma unroll
-          for (int kk = 0; kk < LD; ++kk) v += W[r + PD * kk] * b2[kk];
-          acc[r + PD * cc] += v;
+          for (int kk = 0; kk < LD; ++kk) v += W[rr + NR * kk] * B2[c + PD * kk];
+          acc[rr + NR * c] += v;
         }
-      }
     }
     if (GE > 1) {   // lanes with the same gc are GC apart
 #pragma unroll
-      for (int i = 0; i < PD * NC; ++i) acc[i] = ge_sum(acc[i]);
+      for (int i = 0; i < NR * PD; ++i) acc[i] = ge_sum(acc[i]);
 #pragma unroll
-      for (int r = 0; r < PD; ++r) cacc[r] = ge_sum(cacc[r]);
+      for (int r = 0; r < NR; ++r) cacc[r] = ge_sum(cacc[r]);
     }
-    double* out = Pd + (size_t)ld * PD * PD + gc * NC * PD;
-    if constexpr ((PD * NC) % 2 == 0) {   // 16-byte pieces, dealt round-robin to the GE lanes (all hold the sum)
+    double* out = Pd + (size_t)ld * PD * PD + gc * NR * PD;
+    if constexpr ((NR * PD) % 2 == 0) {   // 16-byte pieces, dealt round-robin to the GE lanes (all hold the sum)
       dbl2_u* out2 = reinterpret_cast<dbl2_u*>(out);
 #pragma unroll
-      for (int u = 0; u < PD * NC / 2; ++u)
+      for (int u = 0; u < NR * PD / 2; ++u)
         if (GE == 1 || (u % GE) == ge) {
           dbl2_u v;
           v.x = acc[2 * u];
@@ -501,20 +504,20 @@ __device__ __forceinline__ void schur_tile_dests(const double* Bs, const double*
         }
     } else {
 #pragma unroll
-      for (int i = 0; i < PD * NC; ++i)
+      for (int i = 0; i < NR * PD; ++i)
         if (GE == 1 || (i % GE) == ge) out[i] = acc[i];
     }
-    if (diag && gc == 0) {
+    if (diag) {
 #pragma unroll
-      for (int r = 0; r < PD; ++r)
-        if (GE == 1 || (r % GE) == ge) Pr[(size_t)ld * PD + r] = cacc[r];
+      for (int r = 0; r < NR; ++r)
+        if (GE == 1 || (r % GE) == ge) Pr[(size_t)ld * PD + gc * NR + r] = cacc[r];
     }
   }
 }
 
 template <int PD, int LD, int G>
 #ifndef G2OHIP_SCHUR_OCC
-#define G2OHIP_SCHUR_OCC 3
+#define G2OHIP_SCHUR_OCC 4   // 110 VGPRs after the row split: 4 workgroups of 39 KB tiles per CU
 #endif
 __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(const int* __restrict__ tile_lm0, const int* __restrict__ tile_td0,
                                                             const int* __restrict__ pl_colptr, const double* __restrict__ Hpl,
@@ -608,7 +611,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
 }
 
 // K5+K7+K8, pass 2: Hschur(d) = Hpp(d) - sum_tiles partial(d) (fixed tile order), bschur = b_p - sum partial_rhs
-template <int PD>
+template <int PD, int NRP>
 __global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const int* __restrict__ rd_ptr, const int* __restrict__ rd_slot,
                                                               const int* __restrict__ hs_src, const double* __restrict__ Hpp,
                                                               const double* __restrict__ Pd, double* __restrict__ Hs,
@@ -628,7 +631,9 @@ __global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const 
   // virtual damping of the pose blocks: (Hpp + lambda I) first, like the materialised setLambda did
   if (pose >= 0 && e % (PD + 1) == 0 && (!lam_mask || lam_mask[pose])) v += lam[0];
   const int k0 = rd_ptr[d], k1 = rd_ptr[d + 1];
-  for (int k = k0; k < k1; ++k) v -= Pd[(size_t)rd_slot[k] * BB + e];
+  // partial blocks are stored [row part][column][row inside the part] (see schur_tile_dests)
+  const int pe = (e % PD) / NRP * (NRP * PD) + (e % PD) % NRP + NRP * (e / PD);
+  for (int k = k0; k < k1; ++k) v -= Pd[(size_t)rd_slot[k] * BB + pe];
   Hs[t] = v;
   if (pose >= 0 && e < PD) {
     double r = b[(size_t)pose * PD + e];
@@ -2196,8 +2201,15 @@ void BlockSolver::solve_schur_impl() {
     prof.end(KernelProf::kSchurBlocks, st_);                                                                                   \
     prof.begin(KernelProf::kSchurRhs, st_);                                                                                    \
     const int n_red = n_active_ >= 0 ? n_active_ : hs_nnzb;                                                                    \
-    if (n_red > 0)                                                                                                             \
-      hipLaunchKernelGGL((schur_reduce_kernel<P_>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red,       \
+    constexpr int kHalf = (P_ % 2 == 0) ? P_ / 2 : P_;   /* rows per lane part of the tile kernel (G >= 2, even P) */            \
+    const bool split = (P_ % 2 == 0) && G >= 2;                                                                                \
+    if (n_red > 0 && split)                                                                                                    \
+      hipLaunchKernelGGL((schur_reduce_kernel<P_, kHalf>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red, \
+                         d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, \
+                         d_lam.p, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr,                              \
+                         n_active_ >= 0 ? d_active.p : (const int*)nullptr);                                                     \
+    else if (n_red > 0)                                                                                                        \
+      hipLaunchKernelGGL((schur_reduce_kernel<P_, P_>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red,    \
                          d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, \
                          d_lam.p, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr,                              \
                          n_active_ >= 0 ? d_active.p : (const int*)nullptr);                                                     \
