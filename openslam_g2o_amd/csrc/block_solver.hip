@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const 
                                                               const int* __restrict__ hs_diag, const double* __restrict__ Pr,
                                                               const double* __restrict__ b, double* __restrict__ bschur,
                                                               const double* __restrict__ lam, const unsigned char* __restrict__ lam_mask,
-                                                              const int* __restrict__ active) {
+                                                              const int* __restrict__ active, int n_slots) {
   constexpr int BB = PD * PD;
   const size_t ta = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (ta >= (size_t)nDst * BB) return;
@@ -633,7 +633,15 @@ __global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const 
   const int k0 = rd_ptr[d], k1 = rd_ptr[d + 1];
   // partial blocks are stored [row part][column][row inside the part] (see schur_tile_dests)
   const int pe = (e % PD) / NRP * (NRP * PD) + (e % PD) % NRP + NRP * (e / PD);
-  for (int k = k0; k < k1; ++k) v -= Pd[(size_t)rd_slot[k] * BB + pe];
+  // a block has one to three partials almost always: their slot ids, then their values, are requested together
+  // (two dependent memory round trips instead of one per partial); same subtraction order as the plain loop
+  const int n = k1 - k0, kc = min(k0, n_slots - 1);
+  const int s0 = rd_slot[kc], s1 = rd_slot[min(kc + 1, n_slots - 1)], s2 = rd_slot[min(kc + 2, n_slots - 1)];
+  const double p0 = Pd[(size_t)s0 * BB + pe], p1 = Pd[(size_t)s1 * BB + pe], p2 = Pd[(size_t)s2 * BB + pe];
+  if (n > 0) v -= p0;
+  if (n > 1) v -= p1;
+  if (n > 2) v -= p2;
+  for (int k = k0 + 3; k < k1; ++k) v -= Pd[(size_t)rd_slot[k] * BB + pe];
   Hs[t] = v;
   if (pose >= 0 && e < PD) {
     double r = b[(size_t)pose * PD + e];
@@ -2207,12 +2215,12 @@ void BlockSolver::solve_schur_impl() {
       hipLaunchKernelGGL((schur_reduce_kernel<P_, kHalf>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red, \
                          d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, \
                          d_lam.p, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr,                              \
-                         n_active_ >= 0 ? d_active.p : (const int*)nullptr);                                                     \
+                         n_active_ >= 0 ? d_active.p : (const int*)nullptr, (int)std::max<long>(1, n_td_));                       \
     else if (n_red > 0)                                                                                                        \
       hipLaunchKernelGGL((schur_reduce_kernel<P_, P_>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red,    \
                          d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, \
                          d_lam.p, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr,                              \
-                         n_active_ >= 0 ? d_active.p : (const int*)nullptr);                                                     \
+                         n_active_ >= 0 ? d_active.p : (const int*)nullptr, (int)std::max<long>(1, n_td_));                       \
     prof.end(KernelProf::kSchurRhs, st_);                                                                                      \
   } else
   G2OHIP_SCHUR(6, 3)
