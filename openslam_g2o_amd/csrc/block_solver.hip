@@ -882,8 +882,11 @@ __device__ __forceinline__ void ba_edge_linearize(const double* __restrict__ T, 
 // reference's per-edge linearizeOplus + constructQuadraticForm, block_solver.hpp:529-532): one thread
 // per landmark walks its observations, evaluates error and Jacobians on the fly (no Jacobian arrays in
 // HBM), accumulates Hll / b_l and writes each Hpl block exactly once.
+#ifndef G2OHIP_ASMLM_OCC
+#define G2OHIP_ASMLM_OCC 4   // 126 VGPRs, 36 KB LDS: 4 workgroups per CU
+#endif
 template <int G>
-__global__ void __launch_bounds__(kThreads) ba_assemble_landmarks_kernel(
+__global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landmarks_kernel(
     int nL, const int* __restrict__ vptr, const int* __restrict__ vent, const double* __restrict__ cams, const double* __restrict__ pts,
     const int* __restrict__ cam_lm, const int* __restrict__ pt_lm, const double* __restrict__ meas_lm, const double* __restrict__ omega_lm,
     const int* __restrict__ hpl_lm, double f, double cx, double cy, int kind, double delta, double* __restrict__ Hll,
@@ -970,8 +973,11 @@ __global__ void __launch_bounds__(kThreads) ba_assemble_landmarks_kernel(
 
 // Pose side: G lanes per free pose walk its observations, re-evaluate the pose Jacobian on the fly
 // and reduce Hpp_ii / b_i with DPP butterflies.
+#ifndef G2OHIP_ASMP_OCC
+#define G2OHIP_ASMP_OCC 2
+#endif
 template <int G>
-__global__ void __launch_bounds__(kThreads) ba_assemble_poses_kernel(
+__global__ void __launch_bounds__(kThreads, G2OHIP_ASMP_OCC) ba_assemble_poses_kernel(
     int nP, const int* __restrict__ vptr, const double* __restrict__ cams, const double* __restrict__ pts,
     const int* __restrict__ cam_pm, const int* __restrict__ pt_pm, const double* __restrict__ meas_pm, const double* __restrict__ omega_pm,
     double f, double cx, double cy, int kind, double delta, double* __restrict__ Hpp, const int* __restrict__ diag_blk,
