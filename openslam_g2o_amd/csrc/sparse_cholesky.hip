@@ -667,6 +667,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     R.crel_off = (int)crel.size();
     R.cmap_off = (int)cmap.size();
     R.L_off = S.L_off[f];
+    R.pad[0] = 0;   // (set below once the children are known) third child fits the three-children fast path
     R.rows_off = S.rows_off[f];
     if (S.w_off[f] > 0x7fffffffLL) throw StateFailure("symbolic: solve workspace exceeds 2^31 doubles");
     R.w_off = (int)S.w_off[f];
@@ -686,6 +687,10 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           cmap.push_back(rl[ib] | (rl[jb] << 16));   // packed block (ib,jb), row-major lower order
         }
       if (ch - S.child_off[f] < 2) R.ch[ch - S.child_off[f]] = cdesc[ch];
+    }
+    if (R.child_cnt == 3) {   // third child within the three-children fast path of the factor kernel (8 doubles x 256 threads)?
+      const int nbc2 = cdesc[R.child_off + 2].nbc;
+      R.pad[0] = (nbc2 * (nbc2 + 1) / 2 * bs * bs <= 8 * kFactorThreads) ? 1 : 0;
     }
     R.crel_cnt = (int)crel.size() - R.crel_off;
     R.cmap_cnt = (int)cmap.size() - R.cmap_off;
@@ -989,6 +994,8 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
 #endif
     constexpr int UC = USE_LDS ? G2OHIP_UC : UNR;      // child elements in flight per thread and child
     const bool fast_children = !carried && nch <= 2 && nU0 <= UC * NT && nU1 <= UC * NT;
+    // (third child's size is checked on the host side of this condition: every LDS front has nbc <= 15 blocks)
+    const bool three_fit = nU0 <= 8 * NT && nU1 <= 8 * NT && rec.pad[0] != 0;
 #ifdef G2OHIP_CHOL_STAMPS
     if (P.dbg && blockIdx.x == 0 && tid == 0) { P.dbg[1] = nch; P.dbg[2] = nU0 * 10000LL + nU1; P.dbg[3] = fast_children; }
 #endif
@@ -1172,6 +1179,34 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
           }
         }
       }
+      __syncthreads();
+    } else if (USE_LDS && NTC == 256 && !carried && nch == 3 && three_fit) {
+      // three children (a separator front merged with one of its child separators): all their update matrices are
+      // requested together -- one memory round trip instead of two per child on the generic path below
+      constexpr int U3 = 8;
+      const ChildDesc cd2 = load_child_desc(P.cdesc + rec.child_off + 2);
+      const int nU2 = cd2.nbc * (cd2.nbc + 1) / 2 * BB;
+      double v0[U3], v1[U3], v2[U3];
+      {
+        const double* U0 = P.U + rec.ch[0].U_off;
+        const double* U1 = P.U + rec.ch[1].U_off;
+        const double* U2 = P.U + cd2.U_off;
+#pragma unroll
+        for (int u = 0; u < U3; ++u) {
+          const int t = tid + u * NT;
+          v0[u] = U0[t < nU0 ? t : 0];
+          v1[u] = U1[t < nU1 ? t : 0];
+          v2[u] = U2[t < nU2 ? t : 0];
+        }
+      }
+      add_child_vec(0);
+      scatter_add(v0, std::integral_constant<int, U3>(), nU0, rec.ch[0].cmap_start);
+      __syncthreads();
+      add_child_vec(1);
+      scatter_add(v1, std::integral_constant<int, U3>(), nU1, rec.ch[1].cmap_start);
+      __syncthreads();
+      add_child_vec(2);
+      scatter_add(v2, std::integral_constant<int, U3>(), nU2, cd2.cmap_start);
       __syncthreads();
     } else {
       for (int ch = 0; ch < nch; ++ch) {
