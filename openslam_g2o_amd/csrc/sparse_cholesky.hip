@@ -1240,13 +1240,33 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
     // the critical path by look-ahead: while waves 1.. apply the trailing update of step kb, wave 0
     // updates only the NEXT diagonal block and factorises it into a small LDS mailbox (sd).
     STAMP();
-    auto diag_factor = [&](int kb_, double* box) {                        // executed by every lane of wave 0
+    // upd: the block still lacks the update of pivot step kb_ - 1; it is applied here in registers from the
+    // (already row-solved) block (kb_, kb_ - 1) -- look-ahead without a trip of the diagonal block through LDS
+    auto diag_factor = [&](int kb_, double* box, auto upd_) {             // executed by every lane of wave 0
+      constexpr bool upd = decltype(upd_)::value;
       double* Fd = F + blk_off(kb_, kb_);
       double Lk[BS][BS], inv[BS];
 #pragma unroll
       for (int c = 0; c < BS; ++c)
 #pragma unroll
         for (int r = 0; r < BS; ++r) Lk[r][c] = (r >= c) ? Fd[r + cs * c] : 0.0;
+      if constexpr (upd) {
+        const double* Xp = F + blk_off(kb_, kb_ - 1);
+        double X[BS][BS];
+#pragma unroll
+        for (int q = 0; q < BS; ++q)
+#pragma unroll
+          for (int r = 0; r < BS; ++r) X[r][q] = Xp[r + cs * q];
+#pragma unroll
+        for (int c = 0; c < BS; ++c)
+#pragma unroll
+          for (int r = c; r < BS; ++r) {
+            double v = Lk[r][c];
+#pragma unroll
+            for (int q = 0; q < BS; ++q) v -= X[r][q] * X[c][q];
+            Lk[r][c] = v;
+          }
+      }
       bool bad = false;
 #pragma unroll
       for (int c = 0; c < BS; ++c) {
@@ -1282,7 +1302,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       }
     };
     if (ns > 0) {
-      if (tid < 64) diag_factor(0, sd);
+      if (tid < 64) diag_factor(0, sd, std::false_type());
       __syncthreads();
     }
     STAMP();
@@ -1354,10 +1374,15 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
           for (int a = 0; a < T; ++a) Fc[a + cs * b] = cv[a][b];
       };
       if (lookahead && tid < 64) {
-        if (tid < NLA) update_tile(s_tri[tid]);
-        __threadfence_block();   // the wave's own LDS writes are complete before it re-reads the block
-        if (kb < 2) STAMP();
-        diag_factor(kb + 1, sd + ((kb + 1) & 1) * (BB + BS));
+        if constexpr (NTC == 128) {   // (two-wave variant: no registers to spare for the in-register update)
+          if (tid < NLA) update_tile(s_tri[tid]);
+          __threadfence_block();   // the wave's own LDS writes are complete before it re-reads the block
+          if (kb < 2) STAMP();
+          diag_factor(kb + 1, sd + ((kb + 1) & 1) * (BB + BS), std::false_type());
+        } else {
+          if (kb < 2) STAMP();
+          diag_factor(kb + 1, sd + ((kb + 1) & 1) * (BB + BS), std::true_type());
+        }
         if (kb < 2) STAMP();
       } else {
         const int first = lookahead ? NLA + tid - 64 : tid, stride = lookahead ? NT - 64 : NT;
