@@ -53,6 +53,7 @@ EXPORTS = [
     "g2ohip_get_partition", "g2ohip_partition_poses",
     "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
+    "g2ohip_compute_marginals",
 ]
 
 _lib = None
@@ -125,6 +126,7 @@ def load():
     L.g2ohip_pg_get_estimates.argtypes = [vp, c_dbl_p]
     L.g2ohip_pg_linearize.argtypes = [vp, C.c_int]
     L.g2ohip_copy_edge_data.argtypes = [vp, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]
+    L.g2ohip_compute_marginals.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p]
     L.g2ohip_kernel_name.argtypes = [C.c_int]
     L.g2ohip_kernel_name.restype = C.c_char_p
     L.g2ohip_kernel_time.argtypes = [vp, C.c_int, c_dbl_p, C.POINTER(C.c_long), C.c_int]
@@ -410,6 +412,15 @@ class HipBlockSolver:
         out = np.empty(max(self.nnzb(which) * per, 1))
         _check(self.L.g2ohip_copy_values(self.h, which, _dp(out)), "values")
         return out[:self.nnzb(which) * per]
+
+    def computeMarginals(self, rows, cols):
+        """Blocks (rows[i], cols[i]) of the inverse of the (reduced) pose system: [n][p][p] (row, column) or None if not PD."""
+        rows, cols = _i32(rows), _i32(cols)
+        out = np.empty((len(rows), self.p * self.p))
+        rc = _check(self.L.g2ohip_compute_marginals(self.h, len(rows), _ip(rows), _ip(cols), _dp(out)), "computeMarginals")
+        if rc != OK:
+            return None
+        return out.reshape(len(rows), self.p, self.p).transpose(0, 2, 1).copy()   # column-major blocks -> [row][col]
 
     def edgeData(self, set_id, n, d, d0, d1):
         """(J0, J1, err) of a binary edge set (n edges, error dim d, vertex dims d0 / d1) as the next buildSystem reads them."""

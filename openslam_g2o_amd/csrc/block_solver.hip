@@ -2734,6 +2734,53 @@ void BlockSolver::pg_discard_top() {
   pg_.has_backup = false;
 }
 
+// Blocks (rows[i], cols[i]) of the inverse of the system the linear solver factorises (Hpp without Schur, the reduced
+// pose system with it: the pose marginals with the landmarks integrated out).  One factorisation, then a pair of
+// triangular sweeps per requested scalar column.  Replaces BlockSolver::computeMarginals -> LinearSolver::solvePattern
+// (block_solver.hpp:489-498, linear_solver.h:63-69, marginal_covariance_cholesky.cpp:71-220 computes the same entries
+// by recursion on the factor).
+__global__ void set_unit_kernel(double* __restrict__ v, size_t n, size_t k) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (i == k) ? 1.0 : 0.0;
+}
+int BlockSolver::compute_marginals(int n, const int* rows, const int* cols, double* out) {
+  require_structure();
+  if (!system_built_) throw StateFailure("compute_marginals before build_system");
+  if (n < 0 || (n > 0 && (!rows || !cols || !out))) throw ArgFailure("compute_marginals: bad arguments");
+  for (int i = 0; i < n; ++i)
+    if (rows[i] < 0 || rows[i] >= nP_ || cols[i] < 0 || cols[i] >= nP_) throw ArgFailure("compute_marginals: block index out of range");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (schur_) solve_schur_impl();   // (re)forms the reduced system with the current damping
+  const double* H = schur_ ? d_Hschur.p : d_Hpp.p;
+  chol_->factor(H, st_);
+  if (chol_->failed(st_)) return 1;
+  const size_t np = (size_t)nP_ * p_;
+  DevBuf<double> rhs, sol;
+  rhs.alloc(np);
+  sol.alloc(np);
+  std::vector<double> h(np);
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cols[a] < cols[b]; });
+  for (int i = 0; i < n;) {
+    const int c = cols[order[i]];
+    int i1 = i;
+    while (i1 < n && cols[order[i1]] == c) ++i1;
+    for (int k = 0; k < p_; ++k) {
+      hipLaunchKernelGGL(set_unit_kernel, dim3(grid_for(np)), dim3(kThreads), 0, st_, rhs.p, np, (size_t)c * p_ + k);
+      chol_->solve(rhs.p, sol.p, st_);
+      sol.download(h.data(), np, st_);
+      for (int j = i; j < i1; ++j) {
+        const int r = rows[order[j]];
+        double* blk = out + (size_t)order[j] * p_ * p_;
+        for (int rr = 0; rr < p_; ++rr) blk[rr + p_ * k] = h[(size_t)r * p_ + rr];
+      }
+    }
+    i = i1;
+  }
+  return 0;
+}
+
 void BlockSolver::copy_edge_data(int set, double* J0, double* J1, double* err) {
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
   EdgeSet& es = *sets_[set];
