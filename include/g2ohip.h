@@ -135,6 +135,9 @@ int g2ohip_solve(g2ohip_solver* s);
  * resident vectors (valid until destroy / build_structure). */
 size_t g2ohip_vector_size(g2ohip_solver* s);
 int g2ohip_copy_x(g2ohip_solver* s, double* x_host);
+/* Overwrite the resident increment x (what g2ohip_ba_update / g2ohip_pg_update apply): SparseOptimizer::update
+ * takes an arbitrary vector, e.g. Dogleg's h_dl (optimization_algorithm_dogleg.cpp:179). */
+int g2ohip_set_x(g2ohip_solver* s, const double* x_host);
 int g2ohip_copy_b(g2ohip_solver* s, double* b_host);
 const double* g2ohip_x_device(g2ohip_solver* s);
 const double* g2ohip_b_device(g2ohip_solver* s);

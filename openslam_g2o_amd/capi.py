@@ -53,7 +53,7 @@ EXPORTS = [
     "g2ohip_get_partition", "g2ohip_partition_poses",
     "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
-    "g2ohip_compute_marginals",
+    "g2ohip_compute_marginals", "g2ohip_set_x",
 ]
 
 _lib = None
@@ -100,6 +100,7 @@ def load():
     L.g2ohip_vector_size.restype = C.c_size_t
     L.g2ohip_copy_x.argtypes = [vp, c_dbl_p]
     L.g2ohip_copy_b.argtypes = [vp, c_dbl_p]
+    L.g2ohip_set_x.argtypes = [vp, c_dbl_p]
     L.g2ohip_x_device.argtypes = [vp]
     L.g2ohip_x_device.restype = vp
     L.g2ohip_b_device.argtypes = [vp]
@@ -323,6 +324,12 @@ class HipBlockSolver:
         out = np.empty(self.vectorSize())
         _check(self.L.g2ohip_copy_b(self.h, _dp(out)), "b")
         return out
+
+    def setX(self, x):
+        x = _f64(x)
+        if len(x) != self.vectorSize():
+            raise ValueError("setX: wrong vector length")
+        _check(self.L.g2ohip_set_x(self.h, _dp(x)), "setX")
 
     def multiplyHessian(self, src):
         src = _f64(src)

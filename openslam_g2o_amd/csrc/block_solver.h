@@ -87,6 +87,7 @@ class BlockSolver {
   void multiply_hessian(double* dest_host, const double* src_host);
 
   size_t vector_size() const { return (size_t)nP_ * p_ + (size_t)nL_ * l_; }
+  void set_x(const double* h);
   void copy_x(double* h);
   void copy_b(double* h);
   const double* x_device() const { return d_x.p; }

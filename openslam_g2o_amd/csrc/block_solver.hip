@@ -2430,6 +2430,11 @@ void BlockSolver::multiply_hessian(double* dest_host, const double* src_host) {
   }
 }
 
+void BlockSolver::set_x(const double* h) {
+  require_structure();
+  if (!h) throw ArgFailure("set_x: null vector");
+  d_x.upload(h, vector_size(), st_);
+}
 void BlockSolver::copy_x(double* h) {
   require_structure();
   d_x.download(h, vector_size(), st_);

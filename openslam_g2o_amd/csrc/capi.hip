@@ -485,6 +485,13 @@ int g2ohip_compute_marginals(g2ohip_solver* s, int n_blocks, const int32_t* rows
   REQUIRE_HANDLE(s);
   return guarded([&] { return s->impl->compute_marginals(n_blocks, rows, cols, out) ? G2OHIP_NOT_PD : G2OHIP_OK; });
 }
+int g2ohip_set_x(g2ohip_solver* s, const double* x_host) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_x(x_host);
+    return G2OHIP_OK;
+  });
+}
 int g2ohip_copy_edge_data(g2ohip_solver* s, int set, double* J0, double* J1, double* err) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

@@ -86,14 +86,114 @@ def gauss_newton_iteration(graph, solver):
     return OK, chi
 
 
+class DoglegState:
+    """The members of OptimizationAlgorithmDogleg (optimization_algorithm_dogleg.cpp:40-50, .h:83-100)."""
+
+    def __init__(self, initial_delta=1e4, max_trials_after_failure=100, initial_lambda=1e-7, lambda_factor=10.0):
+        self.delta = initial_delta
+        self.max_trials = max_trials_after_failure
+        self.current_lambda = initial_lambda
+        self.lambda_factor = lambda_factor
+        self.was_pd = True
+        self.last_step = "Undefined"
+        self.last_num_tries = 0
+
+
+def dogleg_solve_iteration(graph, solver, st):
+    """OptimizationAlgorithmDogleg::solve (optimization_algorithm_dogleg.cpp:57-207).  Needs solver.b(), x(), setX(),
+    multiplyHessian(v) (dest += H v from a zero dest, block_solver.h:142) besides the LM protocol."""
+    import numpy as np
+    graph.linearize()                                   # computeActiveErrors + the Jacobians buildSystem needs
+    current_chi = graph.chi2()
+    solver.buildSystem()
+    b = solver.b()
+    aux = solver.multiplyHessian(b)
+    alpha = float(b @ b) / float(aux @ b)
+    hsd = alpha * b
+    hsd_norm = float(np.linalg.norm(hsd))
+    hgn = None
+    hgn_norm = -1.0
+    good = False
+    tries = 0
+    while True:
+        tries += 1
+        if hgn is None:
+            min_lambda, max_lambda = 1e-12, 1e3
+            ok = False
+            while not ok:                               # damp only once the matrix was seen not positive definite
+                if not st.was_pd:
+                    solver.setLambda(st.current_lambda, True)
+                ok = solver.solve()
+                if not st.was_pd:
+                    solver.restoreDiagonal()
+                st.was_pd = st.was_pd and ok
+                if not st.was_pd:
+                    if ok:
+                        st.current_lambda = max(min_lambda, st.current_lambda / (0.5 * st.lambda_factor))
+                    else:
+                        st.current_lambda *= st.lambda_factor
+                        if st.current_lambda > max_lambda:
+                            st.current_lambda = max_lambda
+                            return FAIL, current_chi
+            hgn = solver.x()
+            hgn_norm = float(np.linalg.norm(hgn))
+        if hgn_norm < st.delta:
+            hdl = hgn
+            st.last_step = "GN"
+        elif hsd_norm > st.delta:
+            hdl = st.delta / hsd_norm * hsd
+            st.last_step = "Descent"
+        else:
+            d = hgn - hsd
+            c = float(hsd @ d)
+            bma = float(d @ d)
+            if c <= 0.0:
+                beta = (-c + math.sqrt(c * c + bma * (st.delta * st.delta - float(hsd @ hsd)))) / bma
+            else:
+                hs2 = float(hsd @ hsd)
+                beta = (st.delta * st.delta - hs2) / (c + math.sqrt(c * c + bma * (st.delta * st.delta - hs2)))
+            hdl = hsd + beta * d
+            st.last_step = "Dogleg"
+        aux = solver.multiplyHessian(hdl)
+        linear_gain = -1.0 * float(aux @ hdl) + 2.0 * float(b @ hdl)
+        graph.push()
+        solver.setX(hdl)
+        graph.update()
+        graph.compute_active_errors()
+        new_chi = graph.chi2()
+        nonlinear_gain = current_chi - new_chi
+        if abs(linear_gain) < 1e-12:
+            linear_gain = 1e-12
+        rho = nonlinear_gain / linear_gain
+        if rho > 0:
+            graph.discard_top()
+            good = True
+        else:
+            graph.pop()
+        if rho > 0.75:
+            st.delta = max(st.delta, 3.0 * float(np.linalg.norm(hdl)))
+        elif rho < 0.25:
+            st.delta *= 0.5
+        if good or tries >= st.max_trials:
+            break
+    st.last_num_tries = tries
+    if tries == st.max_trials or not good:
+        return TERMINATE, current_chi
+    return OK, current_chi
+
+
 def optimize(graph, solver, iterations, algorithm="lm", **lm_args):
     """SparseOptimizer::optimize (sparse_optimizer.cpp:354-419): returns (#iterations done, chi2 per
     iteration before its step, lambda per iteration, LM trials per iteration)."""
-    st = LevenbergState(**lm_args)
+    st = DoglegState(**lm_args) if algorithm == "dogleg" else LevenbergState(**lm_args)
     chis, lams, trials = [], [], []
     done = 0
     for it in range(iterations):
-        if algorithm == "lm":
+        if algorithm == "dogleg":
+            res, _ = dogleg_solve_iteration(graph, solver, st)
+            lams.append(st.delta)
+            trials.append(st.last_num_tries)
+        elif algorithm == "lm":
             res, _ = levenberg_solve_iteration(graph, solver, st, it)
             lams.append(st.current_lambda)
             trials.append(st.levenberg_iterations)

@@ -78,6 +78,18 @@ class OracleSolverAdapter:
     def computeScale(self, lam):
         return self.o.compute_scale(lam)
 
+    def b(self):
+        return self.o.b()
+
+    def x(self):
+        return self.o.x()
+
+    def setX(self, v):
+        self.o.view("x", self.o.n)[:] = v
+
+    def multiplyHessian(self, v):
+        return self.o.multiply_full(v)
+
 
 @pytest.mark.parametrize("fused", [1, 0])
 def test_device_producers_match_oracle(fused):
@@ -142,3 +154,23 @@ def test_lm_trajectory_matches_oracle(huber, outliers):
         assert chi_gpu[-1] < 3.0 * pr["E"]                      # converged to the pixel-noise level (sigma = 1)
     cams, pts = s.baGetEstimates()
     assert relerr(cams, og.pr["cams"]) < 1e-6 and relerr(pts, og.pr["pts"]) < 1e-6
+
+
+def test_dogleg_trajectory_matches_oracle():
+    """OptimizationAlgorithmDogleg restated in lm.py (optimization_algorithm_dogleg.cpp:57-207) over the device-resident
+    BA graph against the same driver over the CPU oracle: chi2 trajectory, trust-region radius and step types."""
+    pr = ba_case(40, 400)
+    s, g = lm.setup_device_ba(pr)
+    n_it = 6
+    done, chis, deltas, trials = lm.optimize(g, s, n_it, algorithm="dogleg")
+    og = OracleBAGraph(pr)
+    done_o, chis_o, deltas_o, trials_o = lm.optimize(og, OracleSolverAdapter(og.o), n_it, algorithm="dogleg")
+    assert done == done_o and trials == trials_o
+    assert relerr(chis, chis_o) < 1e-7 and relerr(deltas, deltas_o) < 1e-6
+    assert all(b <= a for a, b in zip(chis, chis[1:])) and chis[-1] < chis[0]
+    # a small trust region forces the steepest-descent and dogleg branches
+    s2, g2 = lm.setup_device_ba(pr)
+    og2 = OracleBAGraph(pr)
+    r1 = lm.optimize(g2, s2, 5, algorithm="dogleg", initial_delta=0.05)
+    r2 = lm.optimize(og2, OracleSolverAdapter(og2.o), 5, algorithm="dogleg", initial_delta=0.05)
+    assert r1[0] == r2[0] and r1[3] == r2[3] and relerr(r1[1], r2[1]) < 1e-7 and relerr(r1[2], r2[2]) < 1e-6
