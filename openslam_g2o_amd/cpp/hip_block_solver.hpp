@@ -74,6 +74,15 @@ class HipBlockSolver {
   }
   // BlockSolverBase::multiplyHessian(dest, src)
   void multiplyHessian(double* dest, const double* src) { (void)ok(g2ohip_multiply_hessian(h_, dest, src), "multiplyHessian"); }
+  // Solver::computeMarginals (block_solver.hpp:489-498): out[i] = column-major PoseDim x PoseDim block (rows[i], cols[i])
+  bool computeMarginals(int n, const int32_t* rows, const int32_t* cols, double* out) {
+    return g2ohip_compute_marginals(h_, n, rows, cols, out) == G2OHIP_OK;
+  }
+  // LinearSolverPCG instead of the direct solver (linear_solver_pcg.h:53-85)
+  bool usePCG(bool on, double tolerance = 1e-6) {
+    return ok(g2ohip_set_option(h_, "linear_solver", on ? 1.0 : 0.0), "set_option") &&
+           ok(g2ohip_set_option(h_, "pcg_tolerance", tolerance), "set_option");
+  }
   double* x() { return x_.data(); }
   const double* b() const { return b_.data(); }
   size_t vectorSize() const { return x_.size(); }

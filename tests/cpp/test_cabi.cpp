@@ -58,6 +58,29 @@ int main() {
   solver.setLambda(-100.0 * solver.maxDiagonal(), true);
   bool bad = solver.solve();
   solver.restoreDiagonal();
-  std::printf("residual %.3e chi2 %.6e notpd_detected %d\n", rmax / bmax, solver.chi2(), bad ? 0 : 1);
-  return (rmax <= 1e-11 * bmax && !bad) ? 0 : 1;
+  // marginals: block (3,3) of the inverse of the (damped: some landmarks here have a single observation) reduced
+  // system is symmetric with a positive diagonal
+  solver.setLambda(lambda, true);
+  const int32_t mr[1] = {3}, mc[1] = {3};
+  double M[36];
+  bool mok = solver.computeMarginals(1, mr, mc, M);
+  for (int i = 0; i < 6 && mok; ++i) {
+    if (!(M[i * 7] > 0)) mok = false;
+    for (int j = 0; j < i; ++j)
+      if (std::fabs(M[i + 6 * j] - M[j + 6 * i]) > 1e-9 * std::fabs(M[i * 7])) mok = false;
+  }
+  // PCG on the same damped system agrees with the direct solve
+  bool pok = solver.solve();
+  std::vector<double> xd(solver.x(), solver.x() + solver.vectorSize());
+  pok = pok && solver.usePCG(true, 1e-24) && solver.solve();
+  double dmax = 0, xmax = 0;
+  for (size_t i = 0; i < xd.size(); ++i) {
+    dmax = std::fmax(dmax, std::fabs(xd[i] - solver.x()[i]));
+    xmax = std::fmax(xmax, std::fabs(xd[i]));
+  }
+  solver.usePCG(false);
+  solver.restoreDiagonal();
+  std::printf("residual %.3e chi2 %.6e notpd_detected %d marginals %d pcg_vs_direct %.2e\n", rmax / bmax, solver.chi2(), bad ? 0 : 1,
+              mok ? 1 : 0, dmax / xmax);
+  return (rmax <= 1e-11 * bmax && !bad && mok && pok && dmax <= 1e-7 * xmax) ? 0 : 1;
 }
