@@ -1380,6 +1380,9 @@ void dispatch_vertex(int D, int DV, int G, int nV, const int* vptr, const int* v
   G2OHIP_CASE(7, 7);
   G2OHIP_CASE(1, 3);
   G2OHIP_CASE(1, 6);
+  G2OHIP_CASE(1, 2);   // bearing-only observations of 2D points (EdgeSE2PointBearing)
+  G2OHIP_CASE(2, 7);   // projections seen from similarity poses (EdgeSim3ProjectXYZ, BlockSolver_7_3)
+  G2OHIP_CASE(3, 7);
 #undef G2OHIP_CASE
   throw ArgFailure("unsupported (error_dim, vertex_dim) = (" + std::to_string(D) + "," + std::to_string(DV) + ")");
 }
@@ -1402,6 +1405,10 @@ void dispatch_offdiag(int D, int DR, int DC, int nDst, const int* dst, const int
   G2OHIP_CASE(2, 3, 3);
   G2OHIP_CASE(2, 6, 6);
   G2OHIP_CASE(3, 6, 6);
+  G2OHIP_CASE(1, 3, 2);
+  G2OHIP_CASE(1, 6, 3);
+  G2OHIP_CASE(2, 7, 3);
+  G2OHIP_CASE(3, 7, 3);
 #undef G2OHIP_CASE
   throw ArgFailure("unsupported off-diagonal block shape (d,rows,cols) = (" + std::to_string(D) + "," + std::to_string(DR) + "," +
                    std::to_string(DC) + ")");

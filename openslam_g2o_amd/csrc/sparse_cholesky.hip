@@ -643,6 +643,29 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       }
     }
   }
+  if (getenv("G2OHIP_PLAN_DUMP")) {   // per level: tasks, fronts per task, histogram of the largest front (blocks) per task
+    for (int l = 0; l < nlev; ++l) {
+      const LevelLaunch& LL = launches_[0][l];
+      std::vector<int> hist(32, 0);
+      long long nfr = 0, npiv = 0, sumtri = 0;
+      for (int q = LL.lds_begin; q < LL.lds_begin + LL.lds_count; ++q) {
+        const int t = S.level_fronts[q];
+        int mx = 0;
+        for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
+          const int f = S.task_fronts[k], nbt = S.f_ns[f] + S.f_nb[f];
+          mx = std::max(mx, nbt);
+          ++nfr;
+          npiv += S.f_ns[f];
+          sumtri += nbt * (nbt + 1) / 2;
+        }
+        ++hist[std::min(mx, 31)];
+      }
+      fprintf(stderr, "level %d: tasks %d fronts %lld pivots %lld blocks %lld | max-front hist:", l, LL.lds_count, nfr, npiv, sumtri);
+      for (int i = 0; i < 32; ++i)
+        if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
+      fprintf(stderr, "\n");
+    }
+  }
   if (S.level_fronts.empty()) {
     S.level_fronts.push_back(0);
     scratch_off.push_back(0);

@@ -337,3 +337,53 @@ def test_sharded_path_single_rank_rccl():
         assert torch.allclose(ts[0].cpu(), torch.from_numpy(ref.values(capi.HSCHUR)), rtol=0, atol=1e-9)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("p,l,d", [(7, 3, 2), (7, 3, 3), (3, 2, 2), (3, 2, 1), (6, 3, 3), (6, 3, 1)])
+def test_block_solver_dimension_families(p, l, d):
+    """The fixed-size solver families of the reference (BlockSolver_7_3 / _3_2 / _6_3, block_solver.h:163-175) with the
+    edge shapes its type libraries produce for them: sim3 projections (d=2/3 on 7-dof poses, types_seven_dof_expmap.h),
+    SE2 landmark observations (d=2) and bearings (d=1, types_slam2d), 3D point observations (d=3) and depth-only (d=1).
+    Random Jacobians / information through the generic edge-data path, Schur on, against the oracle."""
+    capi = _capi()
+    rng = np.random.default_rng(100 * p + 10 * l + d)
+    nP, nL, K = 40, 150, 4 if d > 1 else 6
+    pt = np.repeat(np.arange(nL), K)
+    cam = (rng.integers(0, nP - K, size=nL)[:, None] + np.arange(K)[None, :]).reshape(-1)
+    cam[rng.random(len(cam)) < 0.03] = -1                         # a few observations from fixed poses
+    v0, v1 = (nP + pt).astype(np.int32), cam.astype(np.int32)
+    E = len(v0)
+    J0, J1 = rng.normal(size=(E, d * l)), rng.normal(size=(E, d * p))
+    W = rng.normal(size=(E, d, d))
+    om = (W @ W.transpose(0, 2, 1) + d * np.eye(d)).reshape(E, d * d)
+    err = rng.normal(size=(E, d))
+    # pose-pose edges of full dimension keep the pose system connected (EdgeSim3 / EdgeSE2 / EdgeSE3)
+    a, b = np.arange(0, nP - 1, dtype=np.int32), np.arange(1, nP, dtype=np.int32)
+    JA, JB = rng.normal(size=(nP - 1, p * p)), rng.normal(size=(nP - 1, p * p))
+    W2 = rng.normal(size=(nP - 1, p, p))
+    O2 = (W2 @ W2.transpose(0, 2, 1) + p * np.eye(p)).reshape(nP - 1, p * p)
+    e2 = rng.normal(size=(nP - 1, p))
+    s = capi.HipBlockSolver(p, l, 0)
+    k0, k1 = s.addEdgeSet(d, v0, v1), s.addEdgeSet(p, a, b)
+    s.buildStructure(nP, nL, True)
+    s.setEdgeData(k0, J0, J1, om, err)
+    s.setEdgeData(k1, JA, JB, O2, e2)
+    s.setRobustKernel(k0, capi.KERNEL_HUBER, 1.5)
+    o = O.OracleSolver(p, l, nP, nL, True)
+    q0 = o.add_edge_set(d, v0, v1); o.set_dims(q0, l, p)
+    q1 = o.add_edge_set(p, a, b); o.set_dims(q1, p, p)
+    o.build_structure()
+    o.set_edge_data(q0, J0, J1, om, err, 1.5)
+    o.set_edge_data(q1, JA, JB, O2, e2)
+    s.buildSystem()
+    o.build_system()
+    _cmp_system(s, o, capi)
+    assert abs(s.chi2() - o.chi2()) <= 1e-12 * o.chi2()
+    lam = 1e-3 * o.max_diagonal()
+    s.setLambda(lam, True)
+    o.set_lambda(lam, True)
+    assert s.solve() and o.solve()
+    assert relerr(s.values(capi.HSCHUR), o.values("Hschur")) < TOL_MAT
+    assert relerr(s.x(), o.x()) < 1e-9
+    r = s.multiplyHessian(s.x()) - s.b()
+    assert np.abs(r).max() <= TOL_RES * np.abs(s.b()).max()
