@@ -2278,6 +2278,11 @@ int BlockSolver::solve_reduced() {
   }
   solve_reduced_device();
   bool bad = chol_->failed(st_);   // synchronises
+  if (bad && chol_->dependency_stall()) {   // (safety net of the dependency-driven launches: repeat with one launch per level)
+    invalidate_graphs();
+    solve_reduced_device();
+    bad = chol_->failed(st_);
+  }
   if (profiling) {
     times.numeric = tn_.seconds();
     times.linsolve = tl_.seconds();
@@ -2365,7 +2370,9 @@ int BlockSolver::solve_reduced_finish() {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   chol_->solve_end(d_x.p, st_);
-  return chol_->failed(st_) ? 1 : 0;
+  const bool bad = chol_->failed(st_);
+  if (bad && chol_->dependency_stall()) invalidate_graphs();   // this solve is reported failed; the next one runs level by level
+  return bad ? 1 : 0;
 }
 
 void BlockSolver::partition_info(int* pose_owner, int* block_consumer) {

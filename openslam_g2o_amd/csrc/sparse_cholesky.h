@@ -32,6 +32,11 @@ struct CholOptions {
   size_t lds_front_bytes = 64 * 1024;  // fronts up to this size are factorised in LDS
   bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task
   int rank = 0, world = 1;   // multi-GPU: this rank factorises its own subtrees + (redundantly) the shared top of the tree
+  int dep_levels = 16;                   // > 1: up to this many consecutive task levels share ONE launch; a parent task waits for its
+                                         // children through device-scope counters instead of the launch boundary
+  int dep_spin_limit = 1 << 21;          // polls (~0.2 us each) before a waiting workgroup gives up and flags status 2
+  int dep_backward = 1;                  // the backward sweep uses the same dependency-driven groups (parents first)
+  int dep_delay = 0;                     // launch-order distance between a task and its parent inside a wide dependency-driven launch
   int wave_front_tasks = 1024;           // launches at least this wide use two waves (128 threads) per front
   size_t wave_front_bytes = 0;           // (unused)
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
@@ -82,7 +87,8 @@ struct FrontRec {
   int ns, nb, c0, asm_off, asm_cnt, child_off, child_cnt, crel_off, crel_cnt, cmap_off, cmap_cnt, tri_cnt;
   long long L_off, U_off;
   ChildDesc ch[2];
-  int rows_off, w_off, pad[2];   // boundary row list; update vector in the solve workspace
+  int rows_off, w_off, pad[2];   // boundary row list; update vector in the solve workspace; pad[0]: three-children fast path,
+                                 // pad[1]: parent front (bits 0-23) | children to wait for (24-30) | signal the parent (31)
 };
 
 struct CholPlanDev {
@@ -98,6 +104,8 @@ struct CholPlanDev {
   const int *asm_off, *asm_q, *asm_pos, *child_off, *children;
   double *L, *U, *w;
   int* status;
+  int* ready;        // dependency-driven launches: children finished so far, per front
+  int dep_spin_limit;
   long long* dbg;   // G2OHIP_CHOL_STAMPS builds only: per-launch wall-clock stamps of workgroup 0
 };
 
@@ -132,6 +140,9 @@ class SparseCholesky {
   int* status_flag() { return d_status.p; }
   // Synchronises st and returns true when the last factorisation met a pivot <= 0.
   bool failed(hipStream_t st);
+  // true once after failed() saw a dependency-driven launch give up waiting; those launches are off from then on
+  // (the caller drops its captured graphs and repeats the solve)
+  bool dependency_stall() { const bool v = dep_stalled_; dep_stalled_ = false; return v; }
 
   const CholStats& stats() const { return stats_; }
   const CholSymbolic& symbolic() const { return sym_; }
@@ -161,16 +172,21 @@ class SparseCholesky {
     int sm_count = 0, sm_max_m = 0, sm_idx_ints = 0;     // leading part of the lds range: small fronts, one wave each
   };
   std::vector<LevelLaunch> launches_[2];   // [0] own tasks, [1] shared top-of-tree tasks
+  struct FactorGroup { LevelLaunch LL; int first_level, last_level; bool dep; };
+  std::vector<FactorGroup> groups_[2];     // factorisation launches: runs of levels (dep: one launch, in-kernel dependencies)
+  DevBuf<int> d_ready;
   struct SegCopy { long long a, b; int n, flags; };  // exchange segment: a = offset in U (or w: flag 2), b = offset in xbuf; flag 1 = mine
   DevBuf<SegCopy> d_xseg;
   DevBuf<double> d_xbuf, d_xmask;
   DevBuf<long long> d_dbg;
-  DevBuf<int2> d_slots;
+  DevBuf<int2> d_slots, d_fslots, d_bslots;
+  int n_slots_ = 0;
+  bool dep_off_ = false, dep_stalled_ = false;
   int n_xseg_ = 0;
   int dbg_launch_ = 0;
   size_t xbuf_count_ = 0;
-  void launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st);
-  void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false);
+  void launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep = false);
+  void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false);
   CholPlanDev plan_{};
 };
 

@@ -746,6 +746,108 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       }
     }
   }
+  // --- factorisation launch groups.  Consecutive levels with the same kernel variant (and nothing the fused
+  // kernel cannot carry) may share one launch: workgroups are dispatched in blockIdx order and the slots are in
+  // level order, so every child of a waiting parent is already running or done (no deadlock); the parent
+  // prefetches its tables, then spins on a device-scope counter its children bump after a release fence.
+  for (int f = 0; f < nf; ++f) recs[f].pad[1] = 0x00ffffff;
+  for (int f = 0; f < nf; ++f)
+    for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) recs[S.children[ch]].pad[1] = f & 0x00ffffff;
+  std::vector<int> factor_order(S.level_fronts);   // launch slot -> task for the FACTOR launches (solve sweeps keep level order)
+  for (int ph = 0; ph < 2; ++ph) {
+    groups_[ph].clear();
+    auto in_phase = [&](int t) { return ph == 0 ? (S.task_owner[t] == opt.rank) : (S.task_owner[t] == -1); };
+    for (int l = 0; l < nlev;) {
+      FactorGroup G{launches_[ph][l], l, l, false};
+      int l1 = l + 1;
+      const bool sm = G.LL.sm_count > 0;
+      auto plain = [](const LevelLaunch& X) { return X.glb_count == 0 && X.lds_count > 0 && X.fuse_fwd; };
+      if (opt.dep_levels > 1 && nf < (1 << 24) && plain(G.LL)) {
+        int end = G.LL.lds_begin + G.LL.lds_count;
+        while (l1 < nlev && l1 - l < opt.dep_levels) {
+          const LevelLaunch& N = launches_[ph][l1];
+          if (!plain(N) || (N.sm_count > 0) != sm || N.lds_begin != end) break;
+          end += N.lds_count;
+          ++l1;
+        }
+        // children each task of the levels (l, l1) has to wait for (those inside the group)
+        std::vector<std::pair<int, int>> waits;   // (front, count)
+        std::vector<int> signals;
+        bool ok = l1 - l > 1;
+        for (int lev = l + 1; lev < l1 && ok; ++lev) {
+          const LevelLaunch& N = launches_[ph][lev];
+          for (int q = N.lds_begin; q < N.lds_begin + N.lds_count && ok; ++q) {
+            const int t = S.level_fronts[q], f = S.task_fronts[S.task_ptr[t]];
+            int cnt = 0;
+            for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) {
+              const int c = S.children[ch], ct = task_of[c];
+              if (ct != t && in_phase(ct) && task_level[ct] >= l && task_level[ct] < l1) {
+                ++cnt;
+                signals.push_back(c);
+              }
+            }
+            if (cnt > 127) ok = false;
+            if (cnt > 0) waits.emplace_back(f, cnt);
+          }
+        }
+        if (ok) {
+          for (int lev = l + 1; lev < l1; ++lev) {
+            const LevelLaunch& N = launches_[ph][lev];
+            G.LL.lds_count += N.lds_count;
+            if (sm) {
+              G.LL.sm_count += N.sm_count;
+              G.LL.sm_max_m = std::max(G.LL.sm_max_m, N.sm_max_m);
+              G.LL.sm_idx_ints = std::max(G.LL.sm_idx_ints, N.sm_idx_ints);
+            } else {
+              G.LL.lds_max_m = std::max(G.LL.lds_max_m, N.lds_max_m);
+              G.LL.lds_idx_ints = std::max(G.LL.lds_idx_ints, N.lds_idx_ints);
+            }
+            G.LL.max_m = std::max(G.LL.max_m, N.max_m);
+            G.LL.max_panel = std::max(G.LL.max_panel, N.max_panel);
+          }
+          G.LL.glb_begin = G.LL.lds_begin + G.LL.lds_count;
+          for (auto& w : waits) recs[w.first].pad[1] |= w.second << 24;
+          for (int c : signals) recs[c].pad[1] |= (int)0x80000000u;
+          // the backward sweep runs the same groups top-down: the child task (its top front c) waits for the parent front
+          for (auto& w : waits) recs[w.first].pad[0] |= w.second << 8;
+          for (int c : signals) recs[c].pad[0] |= 2;
+          G.last_level = l1 - 1;
+          G.dep = true;
+          // Launch order inside a wide group: level order would dispatch a parent only after EVERY task of the
+          // level below (the last parents then wait a whole round for their children); a parent is placed
+          // dep_delay slots (about the number of resident workgroups) behind its last child instead -- still
+          // behind all its children, which is what the no-deadlock argument needs.
+          if (sm && opt.dep_delay > 0) {
+            const int b0 = G.LL.lds_begin, cnt = G.LL.lds_count;
+            std::vector<long long> key(cnt);
+            std::vector<int> pos_of_task(ntask, -1);
+            for (int i = 0; i < cnt; ++i) pos_of_task[factor_order[b0 + i]] = i;
+            for (int i = 0; i < cnt; ++i) {   // (level order: children before parents)
+              const int t = factor_order[b0 + i], f = S.task_fronts[S.task_ptr[t]];
+              long long k = -1;
+              for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) {
+                const int ct = task_of[S.children[ch]];
+                if (ct != t && pos_of_task[ct] >= 0) k = std::max(k, key[pos_of_task[ct]]);
+              }
+              key[i] = k < 0 ? (long long)i : k + opt.dep_delay;
+            }
+            std::vector<int> ord(cnt);
+            for (int i = 0; i < cnt; ++i) ord[i] = i;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] < key[b]; });
+            std::vector<int> tmp(cnt);
+            for (int i = 0; i < cnt; ++i) tmp[i] = factor_order[b0 + ord[i]];
+            std::copy(tmp.begin(), tmp.end(), factor_order.begin() + b0);
+          }
+        } else {
+          l1 = l + 1;
+        }
+      }
+      groups_[ph].push_back(G);
+      l = l1;
+    }
+  }
+  d_ready.alloc((size_t)std::max(nf, 1));
+  d_ready.zero(st);
   d_task_ptr.upload(S.task_ptr, st);
   d_task_fronts.upload(S.task_fronts, st);
   d_rec.upload(recs, st);
@@ -808,6 +910,21 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       slots[q] = make_int2(a < b ? S.task_fronts[a] : 0, b - a);
     }
     d_slots.upload(slots, st);
+    for (size_t q = 0; q < slots.size(); ++q) {
+      const int t = factor_order[q];
+      const int a = S.task_ptr[t], b = S.task_ptr[t + 1];
+      slots[q] = make_int2(a < b ? S.task_fronts[a] : 0, b - a);
+    }
+    d_fslots.upload(slots, st);
+    // backward sweep of a dependency-driven group: the same slots in reverse (parents before children)
+    std::vector<int2> rslots(slots.size());
+    for (size_t q = 0; q < slots.size(); ++q) {
+      const int t = S.level_fronts[slots.size() - 1 - q];
+      const int a = S.task_ptr[t], b = S.task_ptr[t + 1];
+      rslots[q] = make_int2(a < b ? S.task_fronts[a] : 0, b - a);
+    }
+    d_bslots.upload(rslots, st);
+    n_slots_ = (int)slots.size();
   }
   d_perm.upload(S.perm, st);
   d_L_off.upload(S.L_off, st);
@@ -849,6 +966,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.U = d_U.p;
   plan_.w = d_w.p;
   plan_.status = d_status.p;
+  plan_.ready = d_ready.p;
+  plan_.dep_spin_limit = opt.dep_spin_limit;
   plan_.dbg = nullptr;
   plan_.slots = d_slots.p;
   analyzed_ = !host_only;
@@ -880,6 +999,12 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& r) {
 
 // Front record through the constant address space: wave-uniform and never written by a kernel => scalar
 // (SMEM) loads instead of a vector load per lane.
+// Update matrices / vectors travel between workgroups that may run on different XCDs INSIDE one launch
+// (dependency-driven launches): they are written and read with agent-scope accesses (sc1: coherent at the
+// device level) instead of write-back/invalidate fences over the whole L2.
+__device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ FrontRec load_front_rec(const FrontRec* p) {
   FrontRec rec;
   typedef int __attribute__((may_alias)) alias_int;
@@ -926,7 +1051,7 @@ template <int BS, bool USE_LDS, int NTC = (USE_LDS ? kFactorThreads : kFactorThr
 __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G2OHIP_OCC256) : 1) front_factor_kernel(
     CholPlanDev P, int slot0, const double* __restrict__ A, double* __restrict__ scratch,
     const long long* __restrict__ scratch_off, int idx_off_doubles, int wcap, const double* __restrict__ bperm,
-    double* __restrict__ yout) {
+    double* __restrict__ yout, int dep) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int T = (BS % 3 == 0) ? 3 : BS;  // register tile edge of the trailing update
   // Fused forward sweep (LDS fronts, bperm != nullptr): the right-hand side rides along as ONE EXTRA ROW of the
@@ -1018,7 +1143,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
     constexpr int UC = USE_LDS ? G2OHIP_UC : UNR;      // child elements in flight per thread and child
     const bool fast_children = !carried && nch <= 2 && nU0 <= UC * NT && nU1 <= UC * NT;
     // (third child's size is checked on the host side of this condition: every LDS front has nbc <= 15 blocks)
-    const bool three_fit = nU0 <= 8 * NT && nU1 <= 8 * NT && rec.pad[0] != 0;
+    const bool three_fit = nU0 <= 8 * NT && nU1 <= 8 * NT && (rec.pad[0] & 1) != 0;
 #ifdef G2OHIP_CHOL_STAMPS
     if (P.dbg && blockIdx.x == 0 && tid == 0) { P.dbg[1] = nch; P.dbg[2] = nU0 * 10000LL + nU1; P.dbg[3] = fast_children; }
 #endif
@@ -1049,6 +1174,20 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       }
     }
     for (int i = tid; i < nF; i += NT) F[i] = 0.0;
+    // dependency-driven launch: the children of this front run in THIS launch.  Everything above did not depend
+    // on them; now one lane waits for their count (bounded: a broken plan flags status 2 instead of hanging).
+    const int dep_wait = dep ? ((rec.pad[1] >> 24) & 0x7f) : 0;
+    if (dep_wait > 0 && tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(P.ready + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < dep_wait) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > P.dep_spin_limit || ((spins & 255) == 0 && __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
+          __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __hip_atomic_store(P.ready + f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next factorisation
+    }
     __syncthreads();
     STAMP();
     // the children's update matrices share the memory round trip of the original entries (branch-free
@@ -1059,7 +1198,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
 #pragma unroll
       for (int u = 0; u < UC; ++u) {
         const int t = tid + u * NT;
-        u0[u] = U0[t < nU0 ? t : 0];
+        u0[u] = ld_coh(U0 + (t < nU0 ? t : 0));
       }
     }
     // right-hand side and the children's update vectors (same round trip).  The host only fuses the forward
@@ -1087,7 +1226,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
           wn[c] = nbc_c * BS;
           wcrel[c] = crel_c;
           woff[c] = woff_c;
-          if (EARLY_W && tid < wn[c] && !(carried && c == 0)) wv[c] = P.w[woff_c + tid];
+          if (EARLY_W && tid < wn[c] && !(carried && c == 0)) wv[c] = ld_coh(P.w + woff_c + tid);
         }
       }
     }
@@ -1128,7 +1267,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
 #pragma unroll
       for (int c = 0; c < kFwdChildren; ++c)   // (compile-time register index)
         if (c == ch && tid < wn[c])
-          tv[s_crel[wcrel[c] + tid / BS] * BS + tid % BS] += (carried && c == 0) ? wprev[tid] : (EARLY_W ? wv[c] : P.w[woff[c] + tid]);
+          tv[s_crel[wcrel[c] + tid / BS] * BS + tid % BS] += (carried && c == 0) ? wprev[tid] : (EARLY_W ? wv[c] : ld_coh(P.w + woff[c] + tid));
     };
     // ---- extend-add of the children (sequential over children: destinations may overlap).  Update
     // matrices are packed lower-triangular blocks (row-major block order); cmap gives, per packed
@@ -1160,7 +1299,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
 #pragma unroll
         for (int u = 0; u < UC; ++u) {
           const int t = tid + u * NT;
-          u1[DUAL ? u : 0] = U1[t < nU1 ? t : 0];
+          u1[DUAL ? u : 0] = ld_coh(U1 + (t < nU1 ? t : 0));
         }
       }
       if (nch > 0) add_child_vec(0);
@@ -1172,7 +1311,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
 #pragma unroll
             for (int u = 0; u < UC; ++u) {
               const int t = tid + u * NT;
-              u0[u] = U1[t < nU1 ? t : 0];
+              u0[u] = ld_coh(U1 + (t < nU1 ? t : 0));
             }
           }
           __syncthreads();
@@ -1217,9 +1356,9 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
 #pragma unroll
         for (int u = 0; u < U3; ++u) {
           const int t = tid + u * NT;
-          v0[u] = U0[t < nU0 ? t : 0];
-          v1[u] = U1[t < nU1 ? t : 0];
-          v2[u] = U2[t < nU2 ? t : 0];
+          v0[u] = ld_coh(U0 + (t < nU0 ? t : 0));
+          v1[u] = ld_coh(U1 + (t < nU1 ? t : 0));
+          v2[u] = ld_coh(U2 + (t < nU2 ? t : 0));
         }
       }
       add_child_vec(0);
@@ -1243,7 +1382,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
             const int t = base + u * NT;
-            v[u] = (t < nU) ? Uc[t] : 0.0;
+            v[u] = (t < nU) ? ld_coh(Uc + t) : 0.0;
           }
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
@@ -1430,7 +1569,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
         for (int i = tid; i < nbd * BS; i += NT) wprev[i] = tv[npiv + i];
       } else {
         double* wf = P.w + rec.w_off;
-        for (int i = tid; i < nbd * BS; i += NT) wf[i] = tv[npiv + i];
+        for (int i = tid; i < nbd * BS; i += NT) st_coh(wf + i, tv[npiv + i]);
       }
     }
     // ---- write the L panel (m x npiv) and the reciprocals of its diagonal
@@ -1469,10 +1608,13 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       for (int t = tid; t < nU; t += NT) {
         const int blk = t / BB, e = t - blk * BB;
         const int d = s_tri[blk];
-        Ug[t] = F[blk_off(ns + (d & 0xffff), ns + (d >> 16)) + e % BS + cs * (e / BS)];
+        st_coh(Ug + t, F[blk_off(ns + (d & 0xffff), ns + (d >> 16)) + e % BS + cs * (e / BS)]);
       }
     }
+    const bool dep_signal = dep && rec.pad[1] < 0;   // (bit 31) the parent front waits in this launch
+    if (dep_signal) __builtin_amdgcn_s_waitcnt(0);   // every wave: its own (coherent) U / w stores have been acknowledged
     __syncthreads();   // F and the LDS tables are reused by the next front of the chain
+    if (dep_signal && tid == 0) __hip_atomic_fetch_add(P.ready + (rec.pad[1] & 0x00ffffff), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP();
 #ifdef G2OHIP_CHOL_STAMPS
     if (P.dbg && blockIdx.x == 0 && tid == 0 && nstamp < 58) {
@@ -1608,7 +1750,9 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, int s
 template <int BS, bool PANEL_LDS>
 __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int slot0,
                                                             const double* __restrict__ y, double* __restrict__ xp, int panel_cap,
-                                                            int mcap) {
+                                                            int mcap, int dep) {
+  // dep != 0: dependency-driven launch over several levels, parents in front of their children; the top front of
+  // a task waits for the parent front's counter, the bottom front releases its children (see the factor kernel).
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int2 slot = P.slots[slot0 + blockIdx.x];
   const int f_first = __builtin_amdgcn_readfirstlane(slot.x), t0 = 0, t1 = __builtin_amdgcn_readfirstlane(slot.y);
@@ -1634,13 +1778,30 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int 
       const bool bnd = tid >= npiv && tid < m;
       const double yfirst = (tid < npiv) ? y[(size_t)c0 * BS + tid] : 0.0;
       const int rfirst = bnd ? relp[(tid - npiv) / BS] * BS + (tid - npiv) % BS : 0;
+      const bool dep_wait = dep && !prel && (rec.pad[0] & 2);
+      if (dep_wait) {   // the panel does not depend on the parent: stage it, then wait for the boundary values
+        if (PANEL_LDS) stage_copy<16>(Lp, Lg, m * npiv + npiv, tid, NT);
+        if (tid == 0) {
+          int* flag = P.ready + (rec.pad[1] & 0x00ffffff);
+          int spins = 0;
+          while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > P.dep_spin_limit || ((spins & 255) == 0 && __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
+              __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+          __hip_atomic_fetch_add(flag, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the last child leaves it at zero
+        }
+        __syncthreads();
+      }
       double xfirst = 0.0;
-      if (bnd && !prel) xfirst = xp[rfirst];
-      if (PANEL_LDS) stage_copy<16>(Lp, Lg, m * npiv + npiv, tid, NT);
+      if (bnd && !prel) xfirst = ld_coh(xp + rfirst);
+      if (PANEL_LDS && !dep_wait) stage_copy<16>(Lp, Lg, m * npiv + npiv, tid, NT);
       if (tid < m) t[tid] = (tid < npiv) ? yfirst : (prel ? fullprev[rfirst] : xfirst);
       for (int i = tid + NT; i < m; i += NT) {
         const int r = relp[(i - npiv) / BS] * BS + (i - npiv) % BS;   // (i >= NT >= npiv here unless npiv > NT)
-        t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : (prel ? fullprev[r] : xp[r]);
+        t[i] = (i < npiv) ? y[(size_t)c0 * BS + i] : (prel ? fullprev[r] : ld_coh(xp + r));
       }
     }
     __syncthreads();
@@ -1693,13 +1854,16 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int 
       }
       __syncthreads();
     }
-    for (int i = tid; i < npiv; i += NT) xp[(size_t)c0 * BS + i] = xs[i];
+    for (int i = tid; i < npiv; i += NT) st_coh(xp + (size_t)c0 * BS + i, xs[i]);
     if (ti > t0) {
       // the next front down the chain is this one's only child: keep the whole local solution for it
       for (int i = tid; i < m; i += NT) fullprev[i] = (i < npiv) ? xs[i] : t[i];
       prel = P.crel + rec.crel_off + rec.ch[0].crel_start;
     }
+    const int dep_release = (dep && ti == t0) ? (rec.pad[0] >> 8) : 0;   // child tasks waiting in this launch
+    if (dep_release > 0) __builtin_amdgcn_s_waitcnt(0);   // every wave: its x stores have been acknowledged
     __syncthreads();
+    if (dep_release > 0 && tid == 0) __hip_atomic_fetch_add(P.ready + f, dep_release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1727,12 +1891,12 @@ template <int BS>
 void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long long* d_scratch_off, double* d_scratch,
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
                          int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, int wcap,
-                         const double* bperm, double* yout, hipStream_t st) {
+                         const double* bperm, double* yout, int dep, hipStream_t st) {
   if (sm_count > 0) {   // wide launch: two waves per front
     const int idx_off = sm_max_m + 2 * wcap + 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(sm_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, true, 128>), dim3(sm_count), dim3(128), sh, st, P, lds_begin, dA, d_scratch,
-                       d_scratch_off + lds_begin, idx_off, wcap, bperm, yout);
+                       d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
     lds_begin += sm_count;
     lds_count -= sm_count;
   }
@@ -1740,39 +1904,41 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     const int idx_off = lds_max_m + 2 * wcap + 2 * (BS * BS + BS);   // F (packed doubles) | tv | wprev | mailboxes | index lists
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(lds_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, true>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
-                       d_scratch_off + lds_begin, idx_off, wcap, bperm, yout);
+                       d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
   }
   if (glb_count > 0) {
     const int idx_off = 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(glb_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, false>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P, glb_begin, dA,
-                       d_scratch, d_scratch_off + glb_begin, idx_off, 0, (const double*)nullptr, (double*)nullptr);
+                       d_scratch, d_scratch_off + glb_begin, idx_off, 0, (const double*)nullptr, (double*)nullptr, 0);
   }
 }
 
 }  // namespace
 
-void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st) {
+void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep) {
 #ifdef G2OHIP_CHOL_STAMPS
   if (d_dbg.p) {
     plan_.dbg = d_dbg.p + 64 * (dbg_launch_++ % 64);
   }
 #endif
+  CholPlanDev fplan = plan_;
+  fplan.slots = d_fslots.p;
   switch (bs_) {
     case 3:
-      launch_factor_level<3>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
+      launch_factor_level<3>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
                              LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, LL.max_m,
-                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, st);
+                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, dep ? 1 : 0, st);
       break;
     case 6:
-      launch_factor_level<6>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
+      launch_factor_level<6>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
                              LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, LL.max_m,
-                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, st);
+                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, dep ? 1 : 0, st);
       break;
     case 7:
-      launch_factor_level<7>(plan_, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
+      launch_factor_level<7>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
                              LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, LL.max_m,
-                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, st);
+                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, dep ? 1 : 0, st);
       break;
     default:
       throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
@@ -1800,9 +1966,14 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     dbg_launch_ = 0;
   }
 #endif
-  for (const LevelLaunch& LL : launches_[phase]) {
+  for (const FactorGroup& G : groups_[phase]) {
+    if (G.dep && dep_off_) {   // (groups only hold levels the fused kernel carries completely)
+      for (int l = G.first_level; l <= G.last_level; ++l) launch_factor(launches_[phase][l], dA, fwd, st, false);
+      continue;
+    }
+    const LevelLaunch& LL = G.LL;
     const bool fused = fwd && LL.fuse_fwd;
-    launch_factor(LL, dA, fused, st);
+    launch_factor(LL, dA, fused, st, G.dep);
     // what the factor kernel did not carry (fronts too large for LDS, launches outside the fused kernel's
     // limits) gets its forward step inside the same level
     if (fwd && !fused) launch_solve(LL, true, st);
@@ -1827,11 +1998,15 @@ void SparseCholesky::factor_solve(const double* dA, const double* d_b, double* d
   solve_end(d_x, st);
 }
 
-void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only) {
+void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only, bool dep) {
   const size_t panel_limit = 48 * 1024;  // bytes of L panel staged in LDS
   const int count = glb_only ? LL.glb_count : LL.lds_count + LL.glb_count;
-  const int slot0 = glb_only ? LL.glb_begin : LL.lds_begin;
+  // dep: backward sweep of a dependency-driven group (no scratch-slab tasks) over the reversed slot list
+  const int slot0 = dep ? n_slots_ - (LL.lds_begin + LL.lds_count) : (glb_only ? LL.glb_begin : LL.lds_begin);
   if (count == 0) return;
+  CholPlanDev bplan = plan_;
+  if (dep) bplan.slots = d_bslots.p;
+  const int depi = dep ? 1 : 0;
   bool panel = (size_t)LL.max_panel * 8 <= panel_limit;
   int cap = panel ? LL.max_panel : 0;
   int nthreads = LL.max_m <= 64 ? 64 : (LL.max_m <= 128 ? 128 : 256);
@@ -1844,9 +2019,9 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
       hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m); \
   } else {                                                                                                                    \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_y.p, d_xp.p, cap, LL.max_m); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, LL.max_m, depi); \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_y.p, d_xp.p, cap, LL.max_m); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, LL.max_m, depi); \
   }
   switch (bs_) {
     case 3: G2OHIP_SOLVE_LAUNCH(3) break;
@@ -1869,7 +2044,14 @@ void SparseCholesky::solve_forward_phase(int phase, hipStream_t st) {
 }
 void SparseCholesky::solve_backward_phase(int phase, hipStream_t st) {
   // overwrite d_xp with the solution, highest level first
-  for (size_t l = launches_[phase].size(); l-- > 0;) launch_solve(launches_[phase][l], false, st);
+  for (size_t g = groups_[phase].size(); g-- > 0;) {
+    const FactorGroup& G = groups_[phase][g];
+    if (G.dep && opt.dep_backward && !dep_off_) {
+      launch_solve(G.LL, false, st, false, true);
+    } else {
+      for (int l = G.last_level; l >= G.first_level; --l) launch_solve(launches_[phase][l], false, st);
+    }
+  }
 }
 void SparseCholesky::solve_end(double* d_x, hipStream_t st) {
   const int n = sym_.nb * bs_;
@@ -1922,6 +2104,12 @@ bool SparseCholesky::failed(hipStream_t st) {
 #endif
   int h = 0;
   d_status.download(&h, 1, st);
+  if (h != 0 && d_ready.p) d_ready.zero(st);   // an aborted dependency-driven launch may leave counters behind
+  if (h == 2) {   // a waiting workgroup gave up (should not happen: see analyze): per-level launches from now on
+    if (!dep_off_) fprintf(stderr, "g2ohip: a dependency-driven launch gave up waiting; using one launch per level from now on\n");
+    dep_off_ = true;
+    dep_stalled_ = true;
+  }
   return h != 0;
 }
 

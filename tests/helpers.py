@@ -26,9 +26,11 @@ def oracle_ba(pr, huber=0.0, schur=True):
     return o
 
 
-def hip_ba(pr, huber=0.0, schur=True, device=0):
+def hip_ba(pr, huber=0.0, schur=True, device=0, options=None):
     from openslam_g2o_amd import capi
     s = capi.HipBlockSolver(6, 3, device)
+    for name, value in (options or {}).items():      # analysis-time knobs go in before buildStructure
+        s.setOption(name, value)
     k = s.addEdgeSet(2, pr["v0"], pr["v1"])
     s.buildStructure(pr["nP"], pr["nL"], schur)
     s.setEdgeData(k, pr["Jp"], pr["Jc"], pr["omega"], pr["err"])

@@ -387,3 +387,27 @@ def test_block_solver_dimension_families(p, l, d):
     assert relerr(s.x(), o.x()) < 1e-9
     r = s.multiplyHessian(s.x()) - s.b()
     assert np.abs(r).max() <= TOL_RES * np.abs(s.b()).max()
+
+
+def test_dependency_driven_launches_and_stall_fallback():
+    """Levels of the elimination tree sharing one launch (parents wait on device-scope counters their children bump)
+    give bit-identical results to one launch per level; a waiting workgroup that gives up (spin limit 0 forces it)
+    flags the factorisation, the solver drops to per-level launches and repeats the solve."""
+    pr = ba_case(600, 6000)
+    xs = []
+    for opts in ({"dep_levels": 0}, {"dep_levels": 16}, {"dep_levels": 16, "dep_backward": 0},
+                 {"dep_levels": 16, "dep_spin_limit": 0}, {"dep_levels": 3, "use_graph": 1}):
+        s = hip_ba(pr, options=opts)
+        assert s.stats()["numLevels"] >= 4
+        for it in range(3):
+            s.buildSystem()
+            s.setLambda(10.0, True)
+            assert s.solve(), opts
+            s.restoreDiagonal()
+            xs.append(s.x())
+    for x in xs[1:]:
+        assert np.array_equal(x, xs[0])
+    o = oracle_ba(pr)
+    o.build_system()
+    o.set_lambda(10.0, True)
+    assert o.solve() and relerr(xs[0], o.x()) < 1e-8
