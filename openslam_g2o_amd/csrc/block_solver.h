@@ -131,6 +131,8 @@ class BlockSolver {
   bool schur_sort_dests = true;            // order a tile's destinations by entry count (lockstep lane groups)
   int num_cus_ = 256;
   bool fuse_landmark_inverse = true;       // invert the landmark blocks inside the Schur tile kernel
+  bool fuse_schur_reduce = true;           // solve(): the factorisation assembles its fronts from Hpp and the tiles' partial
+                                           // blocks directly; Hschur is only written out when somebody asks for it
   bool tiles_cover_all_ = false;
   bool mask_solution = true;               // solve_reduced_shared zeroes the x_p entries other ranks own (all-reduce of x_p)
   int schur_group = 0;                     // lanes per destination in the Schur tile kernel (0 = auto)
@@ -162,8 +164,12 @@ class BlockSolver {
   template <class F>
   void run_seg(int id, F&& body);
   void build_system_impl();
-  void solve_schur_impl();
+  void solve_schur_impl(bool want_matrix = true);
+  void launch_schur_reduce(bool matrix);
+  void ensure_hschur();
+  bool virtual_reduced_ok();
   void solve_reduced_device();
+  int solve_reduced_impl();
   void solve_back_substitute_impl();
   void solve_reduced_local_impl();
   void solve_reduced_shared_impl();
@@ -173,7 +179,9 @@ class BlockSolver {
   std::vector<unsigned char> lam_mask_h_;
   DevBuf<int> d_active;                    // multi-GPU: reduced-system blocks this rank forms (schur_reduce)
   int n_active_ = -1;                      // -1: all
-  std::vector<int> rd_cnt_h_;
+  std::vector<int> rd_cnt_h_, rd_ptr_h_, rd_slot_h_, hs_src_h_, hs_diag_h_;
+  DevBuf<int> d_pose_diag;                 // pose -> its diagonal block of the reduced system
+  bool hschur_valid_ = true, virt_now_ = false;
   DevBuf<double> d_Hpp, d_Hpl, d_Hll, d_Hschur, d_Dinv, d_db, d_b, d_x, d_bschur, d_bkP, d_bkL, d_red;
   DevBuf<int> d_pp_diag, d_pl_colptr, d_pl_row, d_pl_lm;
   DevBuf<int> d_hs_src;                    // Hschur block -> Hpp block id or -1

@@ -650,6 +650,21 @@ __global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const 
   }
 }
 
+// the right-hand side half of the reduction alone (the matrix half is folded into the factorisation's front
+// assembly: SparseCholesky::set_virtual_blocks): bschur = b_p - sum partial_rhs, same order as schur_reduce_kernel
+template <int PD>
+__global__ void __launch_bounds__(kThreads) schur_rhs_kernel(int nP, const int* __restrict__ pose_diag, const int* __restrict__ rd_ptr,
+                                                           const int* __restrict__ rd_slot, const double* __restrict__ Pr,
+                                                           const double* __restrict__ b, double* __restrict__ bschur) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nP * PD) return;
+  const int pose = t / PD, e = t - pose * PD;
+  const int d = pose_diag[pose];
+  double r = b[t];
+  for (int k = rd_ptr[d]; k < rd_ptr[d + 1]; ++k) r -= Pr[(size_t)rd_slot[k] * PD + e];
+  bschur[t] = r;
+}
+
 // K13: x_l = Dinv (b_l - Hpl' x_p)   (block_solver.hpp:459-483)
 template <int PD, int LD>
 __global__ void __launch_bounds__(kThreads) back_substitute_kernel(int nL, const int* __restrict__ pl_colptr, const int* __restrict__ pl_row,
@@ -1698,15 +1713,23 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     ks.clear();
     ks.shrink_to_fit();
     const int hs_nnzb = (int)hs_row.size();
+    rd_ptr_h_.clear();
+    rd_slot_h_.clear();
     std::vector<int> hs_src(hs_nnzb, -1);
     for (int c = 0; c < nP; ++c)
       for (int q = pp_colptr[c]; q < pp_colptr[c + 1]; ++q) hs_src[find_block(hs_colptr, hs_row, c, pp_row[q])] = q;
     {
-      std::vector<int> hs_diag(hs_nnzb, -1);
-      for (int c = 0; c < nP; ++c) hs_diag[find_block(hs_colptr, hs_row, c, c)] = c;
+      std::vector<int> hs_diag(hs_nnzb, -1), pose_diag(std::max(nP, 1), 0);
+      for (int c = 0; c < nP; ++c) {
+        pose_diag[c] = find_block(hs_colptr, hs_row, c, c);
+        hs_diag[pose_diag[c]] = c;
+      }
       d_hs_diag.upload(hs_diag, st_);
+      d_pose_diag.upload(pose_diag, st_);
+      hs_diag_h_ = hs_diag;
     }
     d_hs_src.upload(hs_src, st_);
+    hs_src_h_ = hs_src;
     // ---- landmark-range tiles for the Schur outer products (schur_tile_kernel)
     {
       const size_t PL = (size_t)p * l, DP = ((size_t)l * l + 1) & ~(size_t)1, BP = ((size_t)l + 1) & ~(size_t)1;
@@ -1820,7 +1843,10 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       d_te_lm.upload(te_lm, st_);
       d_rd_ptr.upload(rd_ptr, st_);
       d_rd_slot.upload(rd_slot, st_);
-      d_Pd.alloc((size_t)std::max<long>(n_td_, 1) * p * p);
+      rd_ptr_h_ = rd_ptr;
+      rd_slot_h_ = rd_slot;
+      d_Pd.alloc((size_t)(std::max<long>(n_td_, 1) + 1) * p * p);   // + one all-zero block (slot n_td_): "no partial"
+      d_Pd.zero(st_);
       d_Pr.alloc((size_t)std::max<long>(n_td_, 1) * p);
     }
     d_Hschur.alloc((size_t)hs_nnzb * p * p);
@@ -1865,11 +1891,27 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
   else chol_->analyze(nP, pp_colptr.data(), pp_row.data(), st_);
   n_active_ = -1;
+  hschur_valid_ = true;
   {
     const double zero2[2] = {0.0, 0.0};
     d_lam.upload(zero2, 2, st_);
     lam_pose_ = lam_lm_ = 0.0;
     lam_mask_h_.clear();
+  }
+  if (schur_ && chol_opt.world == 1 && n_tiles_ > 0 && !rd_ptr_h_.empty()) {
+    // lets solve() skip the reduction pass: the fronts are assembled from Hpp and the tiles' partial blocks
+    SparseCholesky::VirtualBlocks vb;
+    vb.base_idx = hs_src_h_.data();
+    vb.is_diag = hs_diag_h_.data();
+    vb.part_ptr = rd_ptr_h_.data();
+    vb.part_slot = rd_slot_h_.data();
+    vb.d_part_slot = d_rd_slot.p;
+    vb.base = d_Hpp.p;
+    vb.parts = d_Pd.p;
+    vb.lam = d_lam.p;
+    vb.zero_slot = (int)std::max<long>(n_td_, 1);
+    vb.split = false;   // (set per solve: launch_schur_reduce)
+    chol_->set_virtual_blocks(vb, st_);
   }
   if (chol_opt.world > 1) {
     // the rank that consumes a pose's diagonal block adds lambda to it (rank 0 for the shared ones)
@@ -2180,7 +2222,7 @@ void BlockSolver::solve_schur() {
   solve_schur_impl();
 }
 
-void BlockSolver::solve_schur_impl() {
+void BlockSolver::solve_schur_impl(bool want_matrix) {
   if (profiling) ts_.start(st_);
   const size_t sizeP = (size_t)nP_ * p_;
   const int hs_nnzb = (int)hs_row.size();
@@ -2220,21 +2262,6 @@ void BlockSolver::solve_schur_impl() {
         hipLaunchKernelGGL((schur_tile_kernel<P_, L_, 16>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, G2OHIP_TILE_ARGS); \
     }                                                                                                                          \
     prof.end(KernelProf::kSchurBlocks, st_);                                                                                   \
-    prof.begin(KernelProf::kSchurRhs, st_);                                                                                    \
-    const int n_red = n_active_ >= 0 ? n_active_ : hs_nnzb;                                                                    \
-    constexpr int kHalf = (P_ % 2 == 0) ? P_ / 2 : P_;   /* rows per lane part of the tile kernel (G >= 2, even P) */            \
-    const bool split = (P_ % 2 == 0) && G >= 2;                                                                                \
-    if (n_red > 0 && split)                                                                                                    \
-      hipLaunchKernelGGL((schur_reduce_kernel<P_, kHalf>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red, \
-                         d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, \
-                         d_lam.p, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr,                              \
-                         n_active_ >= 0 ? d_active.p : (const int*)nullptr, (int)std::max<long>(1, n_td_));                       \
-    else if (n_red > 0)                                                                                                        \
-      hipLaunchKernelGGL((schur_reduce_kernel<P_, P_>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red,    \
-                         d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, \
-                         d_lam.p, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr,                              \
-                         n_active_ >= 0 ? d_active.p : (const int*)nullptr, (int)std::max<long>(1, n_td_));                       \
-    prof.end(KernelProf::kSchurRhs, st_);                                                                                      \
   } else
   G2OHIP_SCHUR(6, 3)
   G2OHIP_SCHUR(3, 2)
@@ -2243,6 +2270,9 @@ void BlockSolver::solve_schur_impl() {
   G2OHIP_SCHUR(3, 3) { throw ArgFailure("unsupported (pose_dim, landmark_dim) for Schur"); }
 #undef G2OHIP_SCHUR
 #undef G2OHIP_TILE_ARGS
+  prof.begin(KernelProf::kSchurRhs, st_);
+  launch_schur_reduce(want_matrix);
+  prof.end(KernelProf::kSchurRhs, st_);
   G2OHIP_HIP_CHECK(hipGetLastError());
   if (profiling) {
     ts_.stop(st_);
@@ -2250,9 +2280,69 @@ void BlockSolver::solve_schur_impl() {
   }
 }
 
+// Pass 2 of the Schur complement.  matrix: Hschur and bschur (schur_reduce_kernel); otherwise only bschur -- the
+// factorisation then reads Hpp and the partial blocks itself (virtual_reduced_ok) and Hschur stays stale until
+// ensure_hschur().
+void BlockSolver::launch_schur_reduce(bool matrix) {
+  const int hs_nnzb = (int)hs_row.size();
+  const int G = schur_group > 0 ? schur_group : pick_group((double)n_sc_ / std::max<long>(1, n_td_));
+  const bool split = (p_ % 2 == 0) && G >= 2;   // rows per lane part of the tile kernel's partial layout
+  chol_->set_virtual_split(split);
+  if (!matrix) {
+    hschur_valid_ = false;
+#define G2OHIP_RHS(P_)                                                                                                        \
+  case P_:                                                                                                                    \
+    hipLaunchKernelGGL((schur_rhs_kernel<P_>), dim3(grid_for((size_t)nP_ * P_)), dim3(kThreads), 0, st_, nP_, d_pose_diag.p, d_rd_ptr.p, \
+                       d_rd_slot.p, d_Pr.p, d_b.p, d_bschur.p);                                                                \
+    break
+    switch (p_) {
+      G2OHIP_RHS(3);
+      G2OHIP_RHS(6);
+      G2OHIP_RHS(7);
+      default: throw ArgFailure("unsupported pose dimension for Schur");
+    }
+#undef G2OHIP_RHS
+    return;
+  }
+  hschur_valid_ = true;
+  const int n_red = n_active_ >= 0 ? n_active_ : hs_nnzb;
+  if (n_red <= 0) return;
+#define G2OHIP_RED(P_, NRP_)                                                                                                  \
+  hipLaunchKernelGGL((schur_reduce_kernel<P_, NRP_>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red,     \
+                     d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, d_Hschur.p, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, \
+                     d_lam.p, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr,                              \
+                     n_active_ >= 0 ? d_active.p : (const int*)nullptr, (int)std::max<long>(1, n_td_))
+  switch (p_) {
+    case 3: G2OHIP_RED(3, 3); break;
+    case 6: if (split) G2OHIP_RED(6, 3); else G2OHIP_RED(6, 6); break;
+    case 7: G2OHIP_RED(7, 7); break;
+    default: throw ArgFailure("unsupported pose dimension for Schur");
+  }
+#undef G2OHIP_RED
+}
+
+// somebody reads Hschur (copy_values, PCG, marginals, multi-GPU exchange) after a solve() that skipped it
+void BlockSolver::ensure_hschur() {
+  if (!schur_ || hschur_valid_) return;
+  launch_schur_reduce(true);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+// may solve() leave the reduction to the factorisation?  (one GPU, direct solver, tiled Schur pass)
+bool BlockSolver::virtual_reduced_ok() {
+  return schur_ && fuse_schur_reduce && chol_opt.world == 1 && linear_solver == 0 && n_tiles_ > 0 && n_active_ < 0 && !rd_ptr_h_.empty();
+}
+
 int BlockSolver::solve_reduced() {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  ensure_hschur();
+  if (virt_now_) invalidate_graphs();
+  virt_now_ = false;
+  return solve_reduced_impl();
+}
+
+int BlockSolver::solve_reduced_impl() {
   if (!chol_->analyzed()) {
     if (schur_) chol_->analyze(nP_, hs_colptr.data(), hs_row.data(), st_);
     else chol_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
@@ -2292,7 +2382,7 @@ int BlockSolver::solve_reduced() {
 
 void BlockSolver::solve_reduced_device() {
   // factorisation with the forward sweep fused into it, then the backward sweep
-  const double* Hred = schur_ ? d_Hschur.p : d_Hpp.p;
+  const double* Hred = schur_ ? (virt_now_ ? (const double*)nullptr : d_Hschur.p) : d_Hpp.p;   // nullptr: virtual source
   const double* bred = schur_ ? d_bschur.p : d_b.p;
   // The two launch-bound sequences (one launch per tree level) are hipGraph segments; the timing events sit
   // between the segments, so per-slot times stay available while the graphs replay.
@@ -2414,8 +2504,13 @@ void BlockSolver::solve_back_substitute_impl() {
 
 int BlockSolver::solve() {
   if (!system_built_) throw StateFailure("solve before build_system");
-  solve_schur();
-  int rc = solve_reduced();
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  const bool virt = virtual_reduced_ok();
+  if (virt != virt_now_) invalidate_graphs();   // the captured factor segment is specific to the source of the matrix
+  virt_now_ = virt;
+  if (schur_) solve_schur_impl(!virt);
+  int rc = solve_reduced_impl();
   if (rc != 0) return rc;
   solve_back_substitute();
   return 0;
@@ -2499,7 +2594,7 @@ void BlockSolver::copy_values(int which, double* h) {
         for (size_t j = 0; j < (size_t)nL_; ++j)
           for (int i = 0; i < l_; ++i) h[j * l_ * l_ + i * (l_ + 1)] += lam_lm_;
       break;
-    case 3: d_Hschur.download(h, hs_row.size() * p_ * p_, st_); break;
+    case 3: ensure_hschur(); d_Hschur.download(h, hs_row.size() * p_ * p_, st_); break;
     case 4: d_Dinv.download(h, (size_t)nL_ * l_ * l_, st_); break;
     default: throw ArgFailure("bad matrix selector");
   }
@@ -2769,7 +2864,7 @@ int BlockSolver::compute_marginals(int n, const int* rows, const int* cols, doub
   for (int i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= nP_ || cols[i] < 0 || cols[i] >= nP_) throw ArgFailure("compute_marginals: block index out of range");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  if (schur_) solve_schur_impl();   // (re)forms the reduced system with the current damping
+  if (schur_) solve_schur_impl(true);   // (re)forms the reduced system with the current damping
   const double* H = schur_ ? d_Hschur.p : d_Hpp.p;
   chol_->factor(H, st_);
   if (chol_->failed(st_)) return 1;
@@ -2826,7 +2921,7 @@ void BlockSolver::device_array(int which, double** ptr, size_t* count) {
     case 0: *ptr = d_Hpp.p; *count = pp_row.size() * p_ * p_; break;
     case 1: *ptr = d_Hpl.p; *count = pl_row.size() * p_ * l_; break;
     case 2: *ptr = d_Hll.p; *count = (size_t)nL_ * l_ * l_; break;
-    case 3: *ptr = d_Hschur.p; *count = hs_row.size() * p_ * p_; break;
+    case 3: ensure_hschur(); *ptr = d_Hschur.p; *count = hs_row.size() * p_ * p_; break;
     case 100: *ptr = d_bschur.p; *count = (size_t)nP_ * p_; break;
     case 101: *ptr = d_x.p; *count = vector_size(); break;
     case 102: *ptr = d_b.p; *count = vector_size(); break;

@@ -83,6 +83,8 @@ struct ChildDesc {
 };
 // One 128-byte record per front: everything the kernels need, fetched with scalar loads; the first
 // two children are embedded so the common case needs no second dependent load.
+constexpr int kVirtInts = 5;
+
 struct FrontRec {
   int ns, nb, c0, asm_off, asm_cnt, child_off, child_cnt, crel_off, crel_cnt, cmap_off, cmap_cnt, tri_cnt;
   long long L_off, U_off;
@@ -103,6 +105,11 @@ struct CholPlanDev {
   const long long *L_off, *U_off, *w_off;
   const int *asm_off, *asm_q, *asm_pos, *child_off, *children;
   double *L, *U, *w;
+  // virtual source (set_virtual_blocks): per assembly entry the base block (-1: none), pos with bit 31 = diagonal
+  // block, and kVirtInts ints (count, three partial slots, first index into vslots)
+  const int *asm_vq, *asm_vpos, *asm_v, *vslots;
+  const double *vbase, *vparts, *vlam;
+  int vsplit;
   int* status;
   int* ready;        // dependency-driven launches: children finished so far, per front
   int dep_spin_limit;
@@ -139,6 +146,21 @@ class SparseCholesky {
   double* permuted_solution(size_t* count) { *count = (size_t)sym_.nb * bs_; return d_xp.p; }
   int* status_flag() { return d_status.p; }
   // Synchronises st and returns true when the last factorisation met a pivot <= 0.
+  // The matrix to factorise given as  A[q] = base[base_idx[q]] (+ lam[0] on the diagonal of diagonal blocks)
+  //                                          - sum_k parts[part_slot[k]],  k in [part_ptr[q], part_ptr[q+1])
+  // (q = block in pattern order; partial blocks stored [row part][column][row inside the part] with BS/2 rows per
+  // part when `split`, else plain column-major; block `zero_slot` of parts is all zeros).  factor_phase(nullptr,..)
+  // then assembles the fronts straight from it: the Schur complement is never written out.
+  struct VirtualBlocks {
+    const int *base_idx, *is_diag, *part_ptr, *part_slot;   // host
+    const int* d_part_slot;                                 // device copy of part_slot
+    const double *base, *parts, *lam;                       // device
+    int zero_slot;
+    bool split;
+  };
+  void set_virtual_blocks(const VirtualBlocks& vb, hipStream_t st);
+  bool has_virtual_blocks() const { return d_asm_v.p != nullptr; }
+  void set_virtual_split(bool split) { plan_.vsplit = split ? 1 : 0; }
   bool failed(hipStream_t st);
   // true once after failed() saw a dependency-driven launch give up waiting; those launches are off from then on
   // (the caller drops its captured graphs and repeats the solve)
@@ -180,6 +202,7 @@ class SparseCholesky {
   DevBuf<double> d_xbuf, d_xmask;
   DevBuf<long long> d_dbg;
   DevBuf<int2> d_slots, d_fslots, d_bslots;
+  DevBuf<int> d_asm_vq, d_asm_vpos, d_asm_v;
   int n_slots_ = 0;
   bool dep_off_ = false, dep_stalled_ = false;
   int n_xseg_ = 0;

@@ -740,9 +740,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           for (int c = 0; c < R.child_cnt && ok; ++c) ok = cdesc[R.child_off + c].nbc * bs <= nthr;
           if (!ok) LL.fuse_fwd = false;
         }
-        if (q < LL.lds_begin + LL.sm_count) LL.sm_idx_ints = std::max(LL.sm_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt + R.crel_cnt);
-        else if (q < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, 2 * R.asm_cnt + R.cmap_cnt + R.tri_cnt + R.crel_cnt);
-        else LL.glb_idx_ints = std::max(LL.glb_idx_ints, 2 * R.asm_cnt);
+        if (q < LL.lds_begin + LL.sm_count) LL.sm_idx_ints = std::max(LL.sm_idx_ints, (2 + kVirtInts) * R.asm_cnt + R.cmap_cnt + R.tri_cnt + R.crel_cnt);
+        else if (q < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, (2 + kVirtInts) * R.asm_cnt + R.cmap_cnt + R.tri_cnt + R.crel_cnt);
+        else LL.glb_idx_ints = std::max(LL.glb_idx_ints, (2 + kVirtInts) * R.asm_cnt);
       }
     }
   }
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ ChildDesc load_child_desc(const ChildDesc* p) {
 // NTC = workgroup size: 256, or 128 for the wide bottom levels (wave 0: look-ahead diagonal factor, wave 1:
 // trailing update -- the factorisation of a small front is a latency chain, so 6 two-wave workgroups per
 // CU beat 3 four-wave ones).
-template <int BS, bool USE_LDS, int NTC = (USE_LDS ? kFactorThreads : kFactorThreadsGlobal)>
+template <int BS, bool USE_LDS, int NTC = (USE_LDS ? kFactorThreads : kFactorThreadsGlobal), bool VIRT = false>
 #ifndef G2OHIP_OCC256
 #define G2OHIP_OCC256 2
 #endif
@@ -1151,25 +1151,27 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
     // (q | pos | cmap | tri); all their loads are issued before the first wait: one memory round trip.
     {
       const int n1 = na, n2 = 2 * na, n3 = USE_LDS ? n2 + rec.cmap_cnt : n2, n5 = USE_LDS ? n3 + rec.tri_cnt : n2;
-      const int n4 = USE_LDS ? n5 + rec.crel_cnt : n2;   // (q | pos | cmap | tri | crel)
-      const int* g_q = P.asm_q + rec.asm_off;
-      const int* g_pos = P.asm_pos + rec.asm_off - n1;
+      const int n4 = USE_LDS ? n5 + rec.crel_cnt : n2;   // (q | pos | cmap | tri | crel | v)
+      const int n6 = VIRT ? n4 + kVirtInts * na : n4;    // virtual source: (count, 3 partial slots, first list index) per entry
+      const int* g_q = (VIRT ? P.asm_vq : P.asm_q) + rec.asm_off;
+      const int* g_pos = (VIRT ? P.asm_vpos : P.asm_pos) + rec.asm_off - n1;
       const int* g_cmap = P.cmap + rec.cmap_off - n2;
       const int* g_tri = P.tri - n3;
       const int* g_crel = P.crel + rec.crel_off - n5;
+      const int* g_v = P.asm_v + (size_t)kVirtInts * rec.asm_off - n4;
       constexpr int SU = 4;
-      for (int base = tid; base < n4; base += SU * NT) {
+      for (int base = tid; base < n6; base += SU * NT) {
         int v[SU];
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
           const int i = base + u * NT;
-          const int* src = i < n1 ? g_q : (i < n2 ? g_pos : (i < n3 ? g_cmap : (i < n5 ? g_tri : g_crel)));
-          v[u] = (i < n4) ? src[i] : 0;
+          const int* src = i < n1 ? g_q : (i < n2 ? g_pos : (i < n3 ? g_cmap : (i < n5 ? g_tri : (i < n4 ? g_crel : g_v))));
+          v[u] = (i < n6) ? src[i] : 0;
         }
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
           const int i = base + u * NT;
-          if (i < n4) s_q[i] = v[u];
+          if (i < n6) s_q[i] = v[u];
         }
       }
     }
@@ -1231,28 +1233,83 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       }
     }
     // ---- original entries (each block lands on a distinct tile)
-    {
+    if constexpr (VIRT) {
+      // The matrix is not materialised: block q = base[q] (+ lambda on the diagonal of diagonal blocks) minus its
+      // partial blocks, subtracted in list order -- the Schur complement's reduction pass folded into this load
+      // (same operations in the same order as the stand-alone reduction: identical bits).
       const int nA = na * BB;
-      for (int base = tid; base < nA; base += UNR * NT) {
-        double v[UNR];
-        int dst[UNR];
+      const int* s_v = s_q + (USE_LDS ? 2 * na + rec.cmap_cnt + rec.tri_cnt + rec.crel_cnt : 2 * na);
+      const double lam0 = P.vlam[0];
+      constexpr int UA = 3, HB = BS / 2;
+      const bool vsplit = P.vsplit != 0;
+      for (int base = tid; base < nA; base += UA * NT) {
+        double a[UA], p0[UA], p1[UA], p2[UA];
+        int dst[UA], nn[UA], k0[UA], pe[UA];
+        bool dl[UA];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < UA; ++u) {
           const int t = base + u * NT;
           dst[u] = -1;
-          v[u] = 0.0;
+          a[u] = p0[u] = p1[u] = p2[u] = 0.0;
+          nn[u] = 0;
+          k0[u] = 0;
+          pe[u] = 0;
+          dl[u] = false;
           if (t < nA) {
             const int e = t / BB, rc = t - e * BB;
             const int r = rc % BS, c = rc / BS;
             const int q = s_q[e], pos = s_pos[e];
             const int lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff, tr = (pos >> 30) & 1;
-            v[u] = tr ? A[(size_t)q * BB + c + BS * r] : A[(size_t)q * BB + r + BS * c];
+            const int rr = tr ? c : r, cc = tr ? r : c;               // element of the stored (upper) block
+            const int rp = (vsplit && rr >= HB) ? 1 : 0, nrp = vsplit ? HB : BS;
+            pe[u] = rp * (nrp * BS) + (rr - rp * nrp) + nrp * cc;     // partial layout [row part][column][row in part]
+            const int* sv = s_v + kVirtInts * e;
+            nn[u] = sv[0];
+            k0[u] = sv[4];
+            if (q >= 0) a[u] = P.vbase[(size_t)q * BB + rr + BS * cc];
+            p0[u] = P.vparts[(size_t)sv[1] * BB + pe[u]];
+            p1[u] = P.vparts[(size_t)sv[2] * BB + pe[u]];
+            p2[u] = P.vparts[(size_t)sv[3] * BB + pe[u]];
+            dl[u] = (pos < 0) && rr == cc;                            // (bit 31: diagonal block)
             dst[u] = blk_off(lr, lc) + r + cs * c;
           }
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
-          if (dst[u] >= 0) F[dst[u]] = v[u];
+        for (int u = 0; u < UA; ++u)
+          if (dst[u] >= 0) {
+            double v = a[u];
+            if (dl[u]) v += lam0;
+            if (nn[u] > 0) v -= p0[u];
+            if (nn[u] > 1) v -= p1[u];
+            if (nn[u] > 2) v -= p2[u];
+            for (int k = k0[u] + 3; k < k0[u] + nn[u]; ++k) v -= P.vparts[(size_t)P.vslots[k] * BB + pe[u]];
+            F[dst[u]] = v;
+          }
+      }
+    } else {
+      {
+        const int nA = na * BB;
+        for (int base = tid; base < nA; base += UNR * NT) {
+          double v[UNR];
+          int dst[UNR];
+  #pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int t = base + u * NT;
+            dst[u] = -1;
+            v[u] = 0.0;
+            if (t < nA) {
+              const int e = t / BB, rc = t - e * BB;
+              const int r = rc % BS, c = rc / BS;
+              const int q = s_q[e], pos = s_pos[e];
+              const int lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff, tr = (pos >> 30) & 1;
+              v[u] = tr ? A[(size_t)q * BB + c + BS * r] : A[(size_t)q * BB + r + BS * c];
+              dst[u] = blk_off(lr, lc) + r + cs * c;
+            }
+          }
+  #pragma unroll
+          for (int u = 0; u < UNR; ++u)
+            if (dst[u] >= 0) F[dst[u]] = v[u];
+        }
       }
     }
     if (fwd) {
@@ -1451,7 +1508,7 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       // publish: the packed LDS layout keeps the diagonal block contiguous, so it is its own mailbox
       // (only 1/diag goes to the box); the dense HBM layout needs the LDS copy
       if (tid == 0) {
-        if (bad) *P.status = 1;
+        if (bad) atomicMax(P.status, 1);   // (2 = a dependency wait gave up: must survive)
 #pragma unroll
         for (int c = 0; c < BS; ++c) {
 #pragma unroll
@@ -1572,19 +1629,24 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
         for (int i = tid; i < nbd * BS; i += NT) st_coh(wf + i, tv[npiv + i]);
       }
     }
-    // ---- write the L panel (m x npiv) and the reciprocals of its diagonal
+    // ---- write the L panel (m x npiv) and the reciprocals of its diagonal.  A task whose parent waits in this
+    // launch hands over its update matrix FIRST and writes the panel afterwards (the parent does not read L).
     double* Lg = P.L + rec.L_off;
-    if (USE_LDS) {   // m x npiv column-major panel out of the packed blocks (blocks above the diagonal are zero)
-      const float invm = 1.0f / (float)m;
-      for (int t = tid; t < m * npiv; t += NT) {
-        const int c = (int)(((float)t + 0.5f) * invm), r = t - c * m;
-        const int bi = r / BS, bj = c / BS;
-        Lg[t] = (bi >= bj) ? F[blk_off(bi, bj) + r % BS + BS * (c % BS)] : 0.0;
+    auto write_panel = [&]() {
+      if (USE_LDS) {   // m x npiv column-major panel out of the packed blocks (blocks above the diagonal are zero)
+        const float invm = 1.0f / (float)m;
+        for (int t = tid; t < m * npiv; t += NT) {
+          const int c = (int)(((float)t + 0.5f) * invm), r = t - c * m;
+          const int bi = r / BS, bj = c / BS;
+          Lg[t] = (bi >= bj) ? F[blk_off(bi, bj) + r % BS + BS * (c % BS)] : 0.0;
+        }
+      } else {
+        for (int t = tid; t < m * npiv; t += NT) Lg[t] = F[t];  // ld == m: identical layout
       }
-    } else {
-      for (int t = tid; t < m * npiv; t += NT) Lg[t] = F[t];  // ld == m: identical layout
-    }
-    for (int k = tid; k < npiv; k += NT) Lg[(size_t)m * npiv + k] = 1.0 / F[blk_off(k / BS, k / BS) + (k % BS) * (1 + cs)];
+      for (int k = tid; k < npiv; k += NT) Lg[(size_t)m * npiv + k] = 1.0 / F[blk_off(k / BS, k / BS) + (k % BS) * (1 + cs)];
+    };
+    const bool dep_signal = dep && rec.pad[1] < 0;   // (bit 31) the parent front waits in this launch
+    if (!dep_signal) write_panel();
     // ---- update matrix (packed lower-triangular blocks, row-major): to the next chain front through
     // registers, or to HBM for a parent in a later launch
     STAMP();
@@ -1611,10 +1673,13 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
         st_coh(Ug + t, F[blk_off(ns + (d & 0xffff), ns + (d >> 16)) + e % BS + cs * (e / BS)]);
       }
     }
-    const bool dep_signal = dep && rec.pad[1] < 0;   // (bit 31) the parent front waits in this launch
-    if (dep_signal) __builtin_amdgcn_s_waitcnt(0);   // every wave: its own (coherent) U / w stores have been acknowledged
+    if (dep_signal) {
+      __builtin_amdgcn_s_waitcnt(0);   // every wave: its own (coherent) U / w stores have been acknowledged
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(P.ready + (rec.pad[1] & 0x00ffffff), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      write_panel();
+    }
     __syncthreads();   // F and the LDS tables are reused by the next front of the chain
-    if (dep_signal && tid == 0) __hip_atomic_fetch_add(P.ready + (rec.pad[1] & 0x00ffffff), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP();
 #ifdef G2OHIP_CHOL_STAMPS
     if (P.dbg && blockIdx.x == 0 && tid == 0 && nstamp < 58) {
@@ -1887,7 +1952,7 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
   if (i < n) x[i] *= mask[i];
 }
 
-template <int BS>
+template <int BS, bool VIRT>
 void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long long* d_scratch_off, double* d_scratch,
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
                          int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, int wcap,
@@ -1895,7 +1960,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
   if (sm_count > 0) {   // wide launch: two waves per front
     const int idx_off = sm_max_m + 2 * wcap + 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(sm_idx_ints + 4) * sizeof(int);
-    hipLaunchKernelGGL((front_factor_kernel<BS, true, 128>), dim3(sm_count), dim3(128), sh, st, P, lds_begin, dA, d_scratch,
+    hipLaunchKernelGGL((front_factor_kernel<BS, true, 128, VIRT>), dim3(sm_count), dim3(128), sh, st, P, lds_begin, dA, d_scratch,
                        d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
     lds_begin += sm_count;
     lds_count -= sm_count;
@@ -1903,18 +1968,50 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
   if (lds_count > 0) {
     const int idx_off = lds_max_m + 2 * wcap + 2 * (BS * BS + BS);   // F (packed doubles) | tv | wprev | mailboxes | index lists
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(lds_idx_ints + 4) * sizeof(int);
-    hipLaunchKernelGGL((front_factor_kernel<BS, true>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
+    hipLaunchKernelGGL((front_factor_kernel<BS, true, kFactorThreads, VIRT>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
                        d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
   }
   if (glb_count > 0) {
     const int idx_off = 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(glb_idx_ints + 4) * sizeof(int);
-    hipLaunchKernelGGL((front_factor_kernel<BS, false>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P, glb_begin, dA,
+    hipLaunchKernelGGL((front_factor_kernel<BS, false, kFactorThreadsGlobal, VIRT>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P, glb_begin, dA,
                        d_scratch, d_scratch_off + glb_begin, idx_off, 0, (const double*)nullptr, (double*)nullptr, 0);
   }
 }
 
 }  // namespace
+
+void SparseCholesky::set_virtual_blocks(const VirtualBlocks& vb, hipStream_t st) {
+  if (!analyzed_) throw StateFailure("SparseCholesky::set_virtual_blocks before analyze");
+  const size_t n = sym_.asm_q.size();
+  std::vector<int> vq(n), vpos(n), v(n * kVirtInts);
+  for (size_t e = 0; e < n; ++e) {
+    const int q = sym_.asm_q[e];
+    vq[e] = vb.base_idx[q];
+    vpos[e] = sym_.asm_pos[e] | (vb.is_diag[q] >= 0 ? (int)0x80000000u : 0);
+    const int k0 = vb.part_ptr[q], cnt = vb.part_ptr[q + 1] - k0;
+    int* r = &v[e * kVirtInts];
+    r[0] = cnt;
+    for (int j = 0; j < 3; ++j) r[1 + j] = j < cnt ? vb.part_slot[k0 + j] : vb.zero_slot;
+    r[4] = k0;
+  }
+  if (n == 0) {
+    vq.push_back(-1);
+    vpos.push_back(0);
+    v.resize(kVirtInts, 0);
+  }
+  d_asm_vq.upload(vq, st);
+  d_asm_vpos.upload(vpos, st);
+  d_asm_v.upload(v, st);
+  plan_.asm_vq = d_asm_vq.p;
+  plan_.asm_vpos = d_asm_vpos.p;
+  plan_.asm_v = d_asm_v.p;
+  plan_.vslots = vb.d_part_slot;
+  plan_.vbase = vb.base;
+  plan_.vparts = vb.parts;
+  plan_.vlam = vb.lam;
+  plan_.vsplit = vb.split ? 1 : 0;
+}
 
 void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep) {
 #ifdef G2OHIP_CHOL_STAMPS
@@ -1924,25 +2021,27 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
 #endif
   CholPlanDev fplan = plan_;
   fplan.slots = d_fslots.p;
+  const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
+  if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
+#define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
+  launch_factor_level<BS_, V_>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m, \
+                               LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m,            \
+                               LL.sm_idx_ints, LL.max_m, fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr,   \
+                               dep ? 1 : 0, st)
   switch (bs_) {
     case 3:
-      launch_factor_level<3>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, LL.max_m,
-                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, dep ? 1 : 0, st);
+      if (virt) G2OHIP_FACTOR_LEVEL(3, true); else G2OHIP_FACTOR_LEVEL(3, false);
       break;
     case 6:
-      launch_factor_level<6>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, LL.max_m,
-                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, dep ? 1 : 0, st);
+      if (virt) G2OHIP_FACTOR_LEVEL(6, true); else G2OHIP_FACTOR_LEVEL(6, false);
       break;
     case 7:
-      launch_factor_level<7>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m,
-                             LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m, LL.sm_idx_ints, LL.max_m,
-                             fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr, dep ? 1 : 0, st);
+      if (virt) G2OHIP_FACTOR_LEVEL(7, true); else G2OHIP_FACTOR_LEVEL(7, false);
       break;
     default:
       throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
   }
+#undef G2OHIP_FACTOR_LEVEL
 }
 
 void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, bool fwd) {
@@ -1956,6 +2055,12 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true, kFactorThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, kFactorThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, kFactorThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (phase == 0) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));

@@ -441,9 +441,10 @@ class ShardedBlockSolver:
     def solve(self):
         if self.mode == "subtree":
             return self._solve_subtree()
+        if not self.exchange:
+            return self.local.solve()     # one rank: the solver may fold the Schur reduction into the factorisation
         self.local.solveSchur()
-        if self.exchange:
-            self.comm.all_reduce_sum(self._reduced_tensors())
+        self.comm.all_reduce_sum(self._reduced_tensors())
         ok = self.local.solveReduced()
         if not ok:
             return False

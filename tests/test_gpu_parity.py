@@ -411,3 +411,29 @@ def test_dependency_driven_launches_and_stall_fallback():
     o.build_system()
     o.set_lambda(10.0, True)
     assert o.solve() and relerr(xs[0], o.x()) < 1e-8
+
+
+def test_schur_reduction_folded_into_factorisation():
+    """solve() on one GPU skips the reduction pass of the Schur complement: the factorisation assembles its fronts
+    from Hpp and the tiles' partial blocks (same operations, same order).  Bit-identical to the materialised path;
+    Hschur is written on demand; the split API (solveSchur / solveReduced) keeps materialising."""
+    capi = _capi()
+    pr = ba_case(300, 3000)
+    a, b = hip_ba(pr, options={"fuse_schur_reduce": 1}), hip_ba(pr, options={"fuse_schur_reduce": 0})
+    for s in (a, b):
+        s.buildSystem()
+        s.setLambda(7.0, True)
+        assert s.solve()
+    assert np.array_equal(a.x(), b.x())
+    assert np.array_equal(a.values(capi.HSCHUR), b.values(capi.HSCHUR))
+    xa = a.x()
+    a.solveSchur()
+    assert a.solveReduced()
+    a.solveBackSubstitute()
+    assert np.array_equal(a.x(), xa)
+    assert a.solve() and np.array_equal(a.x(), xa)          # and back to the folded path
+    o = oracle_ba(pr)
+    o.build_system()
+    o.set_lambda(7.0, True)
+    assert o.solve() and relerr(xa, o.x()) < 1e-8
+    assert relerr(a.values(capi.HSCHUR), o.values("Hschur")) < TOL_MAT
