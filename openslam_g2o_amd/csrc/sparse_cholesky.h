@@ -35,6 +35,8 @@ struct CholOptions {
   int dep_levels = 16;                   // > 1: up to this many consecutive task levels share ONE launch; a parent task waits for its
                                          // children through device-scope counters instead of the launch boundary
   int dep_spin_limit = 1 << 21;          // polls (~0.2 us each) before a waiting workgroup gives up and flags status 2
+  int big_front_min_dim = 240;           // ... for the launches whose largest front has at least this many rows
+  int big_front_passes = 1;              // scratch-slab (large) fronts: whole-GPU passes instead of one workgroup per front
   int dep_backward = 1;                  // the backward sweep uses the same dependency-driven groups (parents first)
   int dep_delay = 0;                     // launch-order distance between a task and its parent inside a wide dependency-driven launch
   int wave_front_tasks = 1024;           // launches at least this wide use two waves (128 threads) per front
@@ -192,6 +194,13 @@ class SparseCholesky {
     int lds_idx_ints = 0, glb_idx_ints = 0;              // staged index lists (ints) per front, max over the launch
     bool fuse_fwd = true;                                // every LDS front of the launch is within the fused forward sweep's limits
     int sm_count = 0, sm_max_m = 0, sm_idx_ints = 0;     // leading part of the lds range: small fronts, one wave each
+    int bt_begin = 0, bt_count = 0;                      // 64 x 64 trailing-update tiles of the scratch-slab fronts (d_big_tiles)
+    // scratch-slab fronts as whole-GPU passes (all ranges index d_big_tiles): assembly chunks, one extend-add pass
+    // per child ordinal, row chunks of the panel solve; big_ok: every such front has at most 64 pivot columns
+    int ba_begin = 0, ba_count = 0, tr_begin = 0, tr_count = 0;
+    std::vector<std::pair<int, int>> be_pass;
+    long long glb_scratch = 0;                           // doubles of the scratch slab this launch uses
+    bool big_ok = false;
   };
   std::vector<LevelLaunch> launches_[2];   // [0] own tasks, [1] shared top-of-tree tasks
   struct FactorGroup { LevelLaunch LL; int first_level, last_level; bool dep; };
@@ -203,6 +212,7 @@ class SparseCholesky {
   DevBuf<long long> d_dbg;
   DevBuf<int2> d_slots, d_fslots, d_bslots;
   DevBuf<int> d_asm_vq, d_asm_vpos, d_asm_v;
+  DevBuf<int4> d_big_tiles;
   int n_slots_ = 0;
   bool dep_off_ = false, dep_stalled_ = false;
   int n_xseg_ = 0;

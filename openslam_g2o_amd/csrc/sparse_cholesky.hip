@@ -632,6 +632,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         LL.glb_max_m = std::max(LL.glb_max_m, (int)m);
       }
       scratch_max = std::max(scratch_max, so);
+      LL.glb_scratch = so;
       for (int q = LL.lds_begin; q < LL.glb_begin + LL.glb_count; ++q) {
         const int t = S.level_fronts[q];
         for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
@@ -745,6 +746,57 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         else LL.glb_idx_ints = std::max(LL.glb_idx_ints, (2 + kVirtInts) * R.asm_cnt);
       }
     }
+  }
+  // --- trailing-update tiles of the scratch-slab fronts (big_front_update_kernel), per level launch
+  {
+    std::vector<int4> bt;
+    for (int ph = 0; ph < 2; ++ph)
+      for (LevelLaunch& LL : launches_[ph]) {
+        LL.bt_begin = (int)bt.size();
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          const int nt64 = (S.f_nb[f] * bs + 63) / 64;
+          for (int ti = 0; ti < nt64; ++ti)
+            for (int tj = 0; tj <= ti; ++tj) bt.push_back(make_int4(q, ti, tj, 0));
+        }
+        LL.bt_count = (int)bt.size() - LL.bt_begin;
+        // assembly chunks (32 original blocks each)
+        LL.ba_begin = (int)bt.size();
+        LL.big_ok = LL.glb_count > 0;
+        int max_children = 0;
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          if (S.f_ns[f] * bs > 64) LL.big_ok = false;
+          const int na = S.asm_off[f + 1] - S.asm_off[f];
+          for (int e = 0; e < na; e += 32) bt.push_back(make_int4(q, e, std::min(32, na - e), 0));
+          max_children = std::max(max_children, S.child_off[f + 1] - S.child_off[f]);
+        }
+        LL.ba_count = (int)bt.size() - LL.ba_begin;
+        if (max_children > 16) LL.big_ok = false;   // (one launch per child ordinal)
+        // extend-add passes: pass c handles child c of every front (the children of one front may hit the same blocks)
+        LL.be_pass.clear();
+        for (int c = 0; c < max_children && LL.big_ok; ++c) {
+          const int b0 = (int)bt.size();
+          for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+            const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+            if (S.child_off[f] + c >= S.child_off[f + 1]) continue;
+            const int nbc = S.f_nb[S.children[S.child_off[f] + c]];
+            const int nblk = nbc * (nbc + 1) / 2;
+            for (int b = 0; b < nblk; b += 64) bt.push_back(make_int4(q, c, b, std::min(64, nblk - b)));
+          }
+          LL.be_pass.emplace_back(b0, (int)bt.size() - b0);
+        }
+        // panel row chunks (256 rows below the pivot block each)
+        LL.tr_begin = (int)bt.size();
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          const int rows = S.f_nb[f] * bs;
+          for (int r = 0; r < rows; r += 256) bt.push_back(make_int4(q, r, 0, 0));
+        }
+        LL.tr_count = (int)bt.size() - LL.tr_begin;
+      }
+    if (bt.empty()) bt.push_back(make_int4(0, 0, 0, 0));
+    d_big_tiles.upload(bt, st);
   }
   // --- factorisation launch groups.  Consecutive levels with the same kernel variant (and nothing the fused
   // kernel cannot carry) may share one launch: workgroups are dispatched in blockIdx order and the slots are in
@@ -1240,19 +1292,21 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       const int nA = na * BB;
       const int* s_v = s_q + (USE_LDS ? 2 * na + rec.cmap_cnt + rec.tri_cnt + rec.crel_cnt : 2 * na);
       const double lam0 = P.vlam[0];
-      constexpr int UA = 3, HB = BS / 2;
+      constexpr int UA = 4, HB = BS / 2;
       const bool vsplit = P.vsplit != 0;
       for (int base = tid; base < nA; base += UA * NT) {
-        double a[UA], p0[UA], p1[UA], p2[UA];
-        int dst[UA], nn[UA], k0[UA], pe[UA];
+        // a block has one or two partials almost always: the base block and two partials per element are requested
+        // together (one round trip for UA elements); the rare third and later ones follow
+        double a[UA], p0[UA], p1[UA];
+        int dst[UA], nn[UA], sv3[UA], pe[UA];
         bool dl[UA];
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
           const int t = base + u * NT;
           dst[u] = -1;
-          a[u] = p0[u] = p1[u] = p2[u] = 0.0;
+          a[u] = p0[u] = p1[u] = 0.0;
           nn[u] = 0;
-          k0[u] = 0;
+          sv3[u] = 0;
           pe[u] = 0;
           dl[u] = false;
           if (t < nA) {
@@ -1265,11 +1319,10 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
             pe[u] = rp * (nrp * BS) + (rr - rp * nrp) + nrp * cc;     // partial layout [row part][column][row in part]
             const int* sv = s_v + kVirtInts * e;
             nn[u] = sv[0];
-            k0[u] = sv[4];
+            sv3[u] = kVirtInts * e;
             if (q >= 0) a[u] = P.vbase[(size_t)q * BB + rr + BS * cc];
             p0[u] = P.vparts[(size_t)sv[1] * BB + pe[u]];
             p1[u] = P.vparts[(size_t)sv[2] * BB + pe[u]];
-            p2[u] = P.vparts[(size_t)sv[3] * BB + pe[u]];
             dl[u] = (pos < 0) && rr == cc;                            // (bit 31: diagonal block)
             dst[u] = blk_off(lr, lc) + r + cs * c;
           }
@@ -1281,8 +1334,11 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
             if (dl[u]) v += lam0;
             if (nn[u] > 0) v -= p0[u];
             if (nn[u] > 1) v -= p1[u];
-            if (nn[u] > 2) v -= p2[u];
-            for (int k = k0[u] + 3; k < k0[u] + nn[u]; ++k) v -= P.vparts[(size_t)P.vslots[k] * BB + pe[u]];
+            if (nn[u] > 2) {
+              const int* sv = s_v + sv3[u];
+              v -= P.vparts[(size_t)sv[3] * BB + pe[u]];
+              for (int k = sv[4] + 3; k < sv[4] + nn[u]; ++k) v -= P.vparts[(size_t)P.vslots[k] * BB + pe[u]];
+            }
             F[dst[u]] = v;
           }
       }
@@ -1614,7 +1670,20 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
             tv[j] = v;
           }
         }
-        for (int idx = first; idx < ntiles; idx += stride) update_tile(s_tri[idx]);
+        if constexpr (USE_LDS) {
+          for (int idx = first; idx < ntiles; idx += stride) update_tile(s_tri[idx]);
+        } else {
+          // scratch-slab (large) fronts: only the remaining PANEL columns are updated here; the rank-npiv update
+          // of the trailing matrix is one pass of big_front_update_kernel over the whole GPU afterwards
+          const int ntc = (npiv - r0) / T;
+          const int total = nt * ntc;
+          (void)ntiles;
+          for (int idx = lookahead ? tid - 64 : tid; idx < total; idx += stride) {
+            const int ti_ = idx / ntc, tj_ = idx - ti_ * ntc;
+            if (tj_ > ti_ || (lookahead && ti_ < LA)) continue;   // (upper triangle; the next diagonal block: wave 0)
+            update_tile(ti_ | (tj_ << 16));
+          }
+        }
       }
       __syncthreads();
       STAMP();
@@ -1666,11 +1735,13 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       ncarry = 0;
 #pragma unroll
       for (int u = 0; u < kCarry; ++u) ucarry[u] = 0.0;   // ends the live range: no registers held across the next front
-      double* Ug = P.U + rec.U_off;
-      for (int t = tid; t < nU; t += NT) {
-        const int blk = t / BB, e = t - blk * BB;
-        const int d = s_tri[blk];
-        st_coh(Ug + t, F[blk_off(ns + (d & 0xffff), ns + (d >> 16)) + e % BS + cs * (e / BS)]);
+      if constexpr (USE_LDS) {   // (scratch-slab fronts: big_front_update_kernel writes the update matrix)
+        double* Ug = P.U + rec.U_off;
+        for (int t = tid; t < nU; t += NT) {
+          const int blk = t / BB, e = t - blk * BB;
+          const int d = s_tri[blk];
+          st_coh(Ug + t, F[blk_off(ns + (d & 0xffff), ns + (d >> 16)) + e % BS + cs * (e / BS)]);
+        }
       }
     }
     if (dep_signal) {
@@ -1690,6 +1761,219 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
 #ifdef G2OHIP_CHOL_STAMPS
   if (P.dbg && blockIdx.x == 0 && tid == 0) P.dbg[0] = nstamp;
 #endif
+}
+
+// ---- Scratch-slab (large) fronts as whole-GPU passes.  One workgroup per front cannot feed a front of several
+// hundred rows (zeroing, extend-add and the trailing update are megabytes each); per level the work is cut into
+//   memset -> big_assemble (original entries) -> big_extend_add (one pass per child ordinal) -> big_diag (the
+//   npiv x npiv pivot block, one wave per front) -> big_trsm (panel rows, one thread per row) -> big_front_update
+// (MFMA rank-npiv update straight into the packed update matrix).  The dense front F (m x m, column-major, lower
+// triangle) lives in the level's scratch slab.
+template <int BS, bool VIRT>
+__global__ void __launch_bounds__(256) big_assemble_kernel(CholPlanDev P, const int4* __restrict__ chunks, const double* __restrict__ A,
+                                                          double* __restrict__ scratch, const long long* __restrict__ scratch_off) {
+  constexpr int BB = BS * BS, HB = BS / 2;
+  const int4 ck = chunks[blockIdx.x];   // x: launch slot, y: first original block of the chunk, z: blocks
+  const int f = P.slots[ck.x].x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int m = (rec.ns + rec.nb) * BS;
+  double* F = scratch + scratch_off[ck.x];
+  const double lam0 = VIRT ? P.vlam[0] : 0.0;
+  const bool vsplit = VIRT && P.vsplit != 0;
+  for (int t = threadIdx.x; t < ck.z * BB; t += 256) {
+    const int e = rec.asm_off + ck.y + t / BB, rc = t % BB;
+    const int r = rc % BS, c = rc / BS;
+    const int q = (VIRT ? P.asm_vq : P.asm_q)[e], pos = (VIRT ? P.asm_vpos : P.asm_pos)[e];
+    const int lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff, tr = (pos >> 30) & 1;
+    const int rr = tr ? c : r, cc = tr ? r : c;   // element of the stored (upper) block
+    double v;
+    if constexpr (VIRT) {   // base (+ lambda) - partial blocks in list order (see front_factor_kernel)
+      const int rp = (vsplit && rr >= HB) ? 1 : 0, nrp = vsplit ? HB : BS;
+      const int pe = rp * (nrp * BS) + (rr - rp * nrp) + nrp * cc;
+      const int* sv = P.asm_v + (size_t)kVirtInts * e;
+      const int n = sv[0];
+      v = q >= 0 ? P.vbase[(size_t)q * BB + rr + BS * cc] : 0.0;
+      if (pos < 0 && rr == cc) v += lam0;
+      for (int k = 0; k < n && k < 3; ++k) v -= P.vparts[(size_t)sv[1 + k] * BB + pe];
+      for (int k = sv[4] + 3; k < sv[4] + n; ++k) v -= P.vparts[(size_t)P.vslots[k] * BB + pe];
+    } else {
+      v = A[(size_t)q * BB + rr + BS * cc];
+    }
+    F[(size_t)(lr * BS + r) + (size_t)m * (lc * BS + c)] = v;
+  }
+}
+
+template <int BS>
+__global__ void __launch_bounds__(256) big_extend_add_kernel(CholPlanDev P, const int4* __restrict__ chunks, double* __restrict__ scratch,
+                                                            const long long* __restrict__ scratch_off) {
+  constexpr int BB = BS * BS;
+  const int4 ck = chunks[blockIdx.x];   // x: launch slot, y: child ordinal, z: first packed block, w: blocks
+  const int f = P.slots[ck.x].x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int m = (rec.ns + rec.nb) * BS;
+  double* F = scratch + scratch_off[ck.x];
+  const ChildDesc cd = P.cdesc[rec.child_off + ck.y];
+  const double* Uc = P.U + cd.U_off;
+  const int* cmap = P.cmap + rec.cmap_off + cd.cmap_start;
+  for (int t = threadIdx.x; t < ck.w * BB; t += 256) {
+    const int blk = ck.z + t / BB, e = t % BB;
+    const int d = cmap[blk];
+    F[(size_t)((d & 0xffff) * BS + e % BS) + (size_t)m * ((d >> 16) * BS + e / BS)] += Uc[(size_t)blk * BB + e];
+  }
+}
+
+// pivot block (npiv <= 64): left-looking Cholesky, lane i owns row i, one wave per front, everything in LDS
+template <int BS>
+__global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, double* __restrict__ scratch,
+                                                     const long long* __restrict__ scratch_off) {
+  __shared__ double S[64 * 65];
+  const int slot = slot0 + blockIdx.x, lane = threadIdx.x;
+  const int f = P.slots[slot].x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int m = (rec.ns + rec.nb) * BS, n = rec.ns * BS;
+  double* F = scratch + scratch_off[slot];
+  for (int idx = lane; idx < n * n; idx += 64) {
+    const int i = idx % n, j = idx / n;
+    S[i + 65 * j] = (i >= j) ? F[(size_t)i + (size_t)m * j] : 0.0;
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int j = 0; j < n; ++j) {
+    double v = (lane >= j && lane < n) ? S[lane + 65 * j] : 0.0;
+    const int li = lane < n ? lane : 0;
+    for (int k = 0; k < j; ++k) v -= S[li + 65 * k] * S[j + 65 * k];
+    double d = __shfl(v, j);
+    if (!(d > 0.0)) {
+      bad = true;
+      d = 1.0;
+    }
+    const double s = sqrt(d);
+    if (lane > j && lane < n) S[lane + 65 * j] = v / s;
+    if (lane == j) S[j + 65 * j] = s;
+    __syncthreads();
+  }
+  if (bad && lane == 0) atomicMax(P.status, 1);
+  double* Lg = P.L + rec.L_off;
+  for (int idx = lane; idx < n * n; idx += 64) {
+    const int i = idx % n, j = idx / n;
+    const double v = S[i + 65 * j];   // (zero above the diagonal)
+    F[(size_t)i + (size_t)m * j] = v;
+    Lg[(size_t)i + (size_t)m * j] = v;
+  }
+  if (lane < n) Lg[(size_t)m * n + lane] = 1.0 / S[lane + 65 * lane];
+}
+
+// panel rows below the pivot block: x L11' = row, one thread per row, the row in registers
+template <int BS>
+__global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4* __restrict__ chunks, double* __restrict__ scratch,
+                                                      const long long* __restrict__ scratch_off) {
+  __shared__ double S[64 * 65];
+  __shared__ double inv[64];
+  constexpr int MAXB = 64 / BS;
+  const int4 ck = chunks[blockIdx.x];   // x: launch slot, y: first row (relative to the pivot block's end)
+  const int f = P.slots[ck.x].x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int ns = rec.ns, m = (rec.ns + rec.nb) * BS, n = ns * BS;
+  double* F = scratch + scratch_off[ck.x];
+  for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+    const int i = idx % n, j = idx / n;
+    S[i + 65 * j] = F[(size_t)i + (size_t)m * j];
+  }
+  __syncthreads();
+  if (threadIdx.x < n) inv[threadIdx.x] = 1.0 / S[threadIdx.x * 66];
+  __syncthreads();
+  const int i = n + ck.y + threadIdx.x;
+  if (i >= m) return;
+  double* Lg = P.L + rec.L_off;
+  double x[MAXB * BS];
+#pragma unroll
+  for (int cb = 0; cb < MAXB; ++cb) {
+    if (cb < ns) {
+#pragma unroll
+      for (int c = 0; c < BS; ++c) x[cb * BS + c] = F[(size_t)i + (size_t)m * (cb * BS + c)];
+#pragma unroll
+      for (int qb = 0; qb < cb; ++qb)
+#pragma unroll
+        for (int c = 0; c < BS; ++c)
+#pragma unroll
+          for (int q = 0; q < BS; ++q) x[cb * BS + c] -= x[qb * BS + q] * S[(cb * BS + c) + 65 * (qb * BS + q)];
+#pragma unroll
+      for (int c = 0; c < BS; ++c) {
+        double v = x[cb * BS + c];
+#pragma unroll
+        for (int q = 0; q < c; ++q) v -= x[cb * BS + q] * S[(cb * BS + c) + 65 * (cb * BS + q)];
+        v *= inv[cb * BS + c];
+        x[cb * BS + c] = v;
+        F[(size_t)i + (size_t)m * (cb * BS + c)] = v;
+        Lg[(size_t)i + (size_t)m * (cb * BS + c)] = v;
+      }
+    }
+  }
+}
+
+// Rank-npiv update of the trailing part of the scratch-slab (large) fronts of one level, over the whole GPU:
+//   U(ib, jb) = F(ns+ib, ns+jb) - L(ns+ib, 0..npiv) L(ns+jb, 0..npiv)'        (packed lower blocks of P.U)
+// one workgroup per 64 x 64 tile of the trailing matrix, one 32 x 32 quadrant per wave as 2 x 2 MFMA tiles
+// (v_mfma_f64_16x16x4_f64: a true GEMM contraction, K = npiv).  Operands straight from the panel in the slab
+// (L2-resident, 128-byte coalesced: 16 consecutive rows per k).  Layout of the instruction (probed on gfx950,
+// tools/probe/mfma_f64_layout.hip): A[i][k] from lane i + 16k, B[j][k] from lane j + 16k, D[lane/16 + 4v][lane%16]
+// in register v.  The ROW of the trailing matrix rides on j (lanes 0..15: consecutive addresses), the column on i.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+template <int BS>
+__global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, const int4* __restrict__ tiles,
+                                                              const double* __restrict__ scratch,
+                                                              const long long* __restrict__ scratch_off) {
+  constexpr int BB = BS * BS;
+  const int4 td = tiles[blockIdx.x];   // x: launch slot of the front, y / z: tile row / column
+  const int f = P.slots[td.x].x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int ns = rec.ns, nbd = rec.nb;
+  const int m = (ns + nbd) * BS, npiv = ns * BS, mt = nbd * BS;
+  const double* F = scratch + scratch_off[td.x];
+  double* U = P.U + rec.U_off;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+  const int r0 = td.y * 64 + (wave & 1) * 32, c0 = td.z * 64 + (wave >> 1) * 32;
+  if (r0 >= mt || c0 >= mt || c0 > r0 + 31) return;   // outside, or entirely above the diagonal
+  mfma_d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  const double* Lr[2];
+  const double* Lc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    Lr[q] = F + npiv + min(r0 + 16 * q + lr, mt - 1);
+    Lc[q] = F + npiv + min(c0 + 16 * q + lr, mt - 1);
+  }
+  for (int k0 = 0; k0 < npiv; k0 += 4) {
+    const int k = min(k0 + lk, npiv - 1);
+    const double keep = (k0 + lk < npiv) ? 1.0 : 0.0;
+    double rv[2], cv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      rv[q] = Lr[q][(size_t)m * k] * keep;
+      cv[q] = Lc[q][(size_t)m * k];
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[b], rv[a], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = r0 + 16 * a + lr, c = c0 + 16 * b + lk + 4 * v;
+        if (r < mt && c < mt) {
+          const int ib = r / BS, jb = c / BS;
+          if (ib >= jb)
+            U[(size_t)(ib * (ib + 1) / 2 + jb) * BB + (r - ib * BS) + BS * (c - jb * BS)] =
+                F[(size_t)(npiv + r) + (size_t)m * (npiv + c)] - acc[a][b][v];
+        }
+      }
 }
 
 // b_perm[new*bs + r] = b[old*bs + r]
@@ -1952,11 +2236,20 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
   if (i < n) x[i] *= mask[i];
 }
 
+struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one level (LevelLaunch::ba_* / be_pass / tr_*)
+  bool ok;
+  const int4* chunks;
+  int ba_begin, ba_count, tr_begin, tr_count;
+  const std::vector<std::pair<int, int>>* be_pass;
+  long long scratch;
+};
+
 template <int BS, bool VIRT>
 void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long long* d_scratch_off, double* d_scratch,
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
                          int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, int wcap,
-                         const double* bperm, double* yout, int dep, hipStream_t st) {
+                         const double* bperm, double* yout, int dep, const int4* big_tiles, int bt_count, const BigLaunch& big,
+                         hipStream_t st) {
   if (sm_count > 0) {   // wide launch: two waves per front
     const int idx_off = sm_max_m + 2 * wcap + 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(sm_idx_ints + 4) * sizeof(int);
@@ -1971,11 +2264,28 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     hipLaunchKernelGGL((front_factor_kernel<BS, true, kFactorThreads, VIRT>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
                        d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
   }
-  if (glb_count > 0) {
+  if (glb_count > 0 && big.ok) {   // large fronts as whole-GPU passes
+    G2OHIP_HIP_CHECK(hipMemsetAsync(d_scratch, 0, (size_t)big.scratch * sizeof(double), st));
+    if (big.ba_count > 0)
+      hipLaunchKernelGGL((big_assemble_kernel<BS, VIRT>), dim3(big.ba_count), dim3(256), 0, st, P, big.chunks + big.ba_begin, dA, d_scratch,
+                         d_scratch_off);
+    for (const auto& pass : *big.be_pass)
+      if (pass.second > 0)
+        hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
+                           d_scratch_off);
+    hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off);
+    if (big.tr_count > 0)
+      hipLaunchKernelGGL((big_trsm_kernel<BS>), dim3(big.tr_count), dim3(256), 0, st, P, big.chunks + big.tr_begin, d_scratch,
+                         d_scratch_off);
+    if (bt_count > 0)
+      hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off);
+  } else if (glb_count > 0) {
     const int idx_off = 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(glb_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, false, kFactorThreadsGlobal, VIRT>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P, glb_begin, dA,
                        d_scratch, d_scratch_off + glb_begin, idx_off, 0, (const double*)nullptr, (double*)nullptr, 0);
+    if (bt_count > 0)   // their trailing matrices: one MFMA pass over all of them
+      hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off);
   }
 }
 
@@ -2021,13 +2331,15 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
 #endif
   CholPlanDev fplan = plan_;
   fplan.slots = d_fslots.p;
+  const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
+                      LL.glb_scratch};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
   launch_factor_level<BS_, V_>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m, \
                                LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m,            \
                                LL.sm_idx_ints, LL.max_m, fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr,   \
-                               dep ? 1 : 0, st)
+                               dep ? 1 : 0, d_big_tiles.p + LL.bt_begin, LL.bt_count, big, st)
   switch (bs_) {
     case 3:
       if (virt) G2OHIP_FACTOR_LEVEL(3, true); else G2OHIP_FACTOR_LEVEL(3, false);
