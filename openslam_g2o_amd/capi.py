@@ -11,6 +11,7 @@ the calls raise -- there is no CPU fallback.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -71,6 +72,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise G2oHipError("libg2ohip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
                           % LIB_PATH)
+    # One HIP/HSA runtime per process: PyTorch ships its own libamdhip64 / libhsa-runtime64 (same SONAMEs as
+    # /opt/rocm's).  If this library pulled in the system copies first, a later `import torch` would bring up a
+    # second HSA runtime that finds no GPU; importing torch first makes its copies the ones both sides use.
+    # (Plain C/C++ consumers of the ABI link the system runtime and are not affected.)
+    if "torch" not in sys.modules and os.environ.get("G2OHIP_NO_TORCH_PRELOAD") is None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.g2ohip_last_error.restype = C.c_char_p

@@ -1841,7 +1841,20 @@ __global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, 
   for (int j = 0; j < n; ++j) {
     double v = (lane >= j && lane < n) ? S[lane + 65 * j] : 0.0;
     const int li = lane < n ? lane : 0;
-    for (int k = 0; k < j; ++k) v -= S[li + 65 * k] * S[j + 65 * k];
+    {   // four independent partial sums, eight LDS reads in flight (a plain loop is one LDS latency per term)
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int k = 0;
+      for (; k + 4 <= j; k += 4) {
+        const double x0 = S[li + 65 * k], x1 = S[li + 65 * (k + 1)], x2 = S[li + 65 * (k + 2)], x3 = S[li + 65 * (k + 3)];
+        const double y0 = S[j + 65 * k], y1 = S[j + 65 * (k + 1)], y2 = S[j + 65 * (k + 2)], y3 = S[j + 65 * (k + 3)];
+        a0 += x0 * y0;
+        a1 += x1 * y1;
+        a2 += x2 * y2;
+        a3 += x3 * y3;
+      }
+      for (; k < j; ++k) a0 += S[li + 65 * k] * S[j + 65 * k];
+      v -= (a0 + a1) + (a2 + a3);
+    }
     double d = __shfl(v, j);
     if (!(d > 0.0)) {
       bad = true;
