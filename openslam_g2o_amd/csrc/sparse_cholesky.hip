@@ -1822,58 +1822,64 @@ __global__ void __launch_bounds__(256) big_extend_add_kernel(CholPlanDev P, cons
   }
 }
 
-// pivot block (npiv <= 64): left-looking Cholesky, lane i owns row i, one wave per front, everything in LDS
+// pivot block (npiv <= 64): right-looking Cholesky, one wave per front, lane i owns row i IN REGISTERS; column j of L
+// reaches the other lanes through v_readlane (the loops are fully unrolled: lane and register indices are
+// compile-time constants) -- no LDS, no barriers, ~n^2/2 FMAs with scalar operands
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
 template <int BS>
 __global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, double* __restrict__ scratch,
                                                      const long long* __restrict__ scratch_off) {
-  __shared__ double S[64 * 65];
+  constexpr int MAXB = 64 / BS, N = MAXB * BS;
   const int slot = slot0 + blockIdx.x, lane = threadIdx.x;
   const int f = P.slots[slot].x;
   const FrontRec rec = load_front_rec(P.rec + f);
-  const int m = (rec.ns + rec.nb) * BS, n = rec.ns * BS;
+  const int ns = rec.ns, m = (rec.ns + rec.nb) * BS, n = ns * BS;
   double* F = scratch + scratch_off[slot];
-  for (int idx = lane; idx < n * n; idx += 64) {
-    const int i = idx % n, j = idx / n;
-    S[i + 65 * j] = (i >= j) ? F[(size_t)i + (size_t)m * j] : 0.0;
-  }
-  __syncthreads();
+  double* Lg = P.L + rec.L_off;
+  double r[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) r[c] = (c < n && lane < n && lane >= c) ? F[(size_t)lane + (size_t)m * c] : 0.0;
   bool bad = false;
-  for (int j = 0; j < n; ++j) {
-    double v = (lane >= j && lane < n) ? S[lane + 65 * j] : 0.0;
-    const int li = lane < n ? lane : 0;
-    {   // four independent partial sums, eight LDS reads in flight (a plain loop is one LDS latency per term)
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int k = 0;
-      for (; k + 4 <= j; k += 4) {
-        const double x0 = S[li + 65 * k], x1 = S[li + 65 * (k + 1)], x2 = S[li + 65 * (k + 2)], x3 = S[li + 65 * (k + 3)];
-        const double y0 = S[j + 65 * k], y1 = S[j + 65 * (k + 1)], y2 = S[j + 65 * (k + 2)], y3 = S[j + 65 * (k + 3)];
-        a0 += x0 * y0;
-        a1 += x1 * y1;
-        a2 += x2 * y2;
-        a3 += x3 * y3;
+#pragma unroll
+  for (int jb = 0; jb < MAXB; ++jb) {
+    if (jb < ns) {   // (wave-uniform)
+#pragma unroll
+      for (int jj = 0; jj < BS; ++jj) {
+        const int j = jb * BS + jj;
+        double d = readlane_f64(r[j], j);
+        if (!(d > 0.0)) {
+          bad = true;
+          d = 1.0;
+        }
+        double sq, rs;
+        sqrt_and_rsqrt(d, sq, rs);
+        const double l = lane > j ? r[j] * rs : (lane == j ? sq : 0.0);   // column j of L (zero above the diagonal)
+        r[j] = l;
+        if (lane == j) Lg[(size_t)m * n + j] = rs;
+#pragma unroll
+        for (int c = j + 1; c < (jb + 1) * BS; ++c) r[c] -= l * readlane_f64(l, c);
+#pragma unroll
+        for (int cb = jb + 1; cb < MAXB; ++cb)
+          if (cb < ns) {
+#pragma unroll
+            for (int cc = 0; cc < BS; ++cc) r[cb * BS + cc] -= l * readlane_f64(l, cb * BS + cc);
+          }
       }
-      for (; k < j; ++k) a0 += S[li + 65 * k] * S[j + 65 * k];
-      v -= (a0 + a1) + (a2 + a3);
     }
-    double d = __shfl(v, j);
-    if (!(d > 0.0)) {
-      bad = true;
-      d = 1.0;
-    }
-    const double s = sqrt(d);
-    if (lane > j && lane < n) S[lane + 65 * j] = v / s;
-    if (lane == j) S[j + 65 * j] = s;
-    __syncthreads();
   }
   if (bad && lane == 0) atomicMax(P.status, 1);
-  double* Lg = P.L + rec.L_off;
-  for (int idx = lane; idx < n * n; idx += 64) {
-    const int i = idx % n, j = idx / n;
-    const double v = S[i + 65 * j];   // (zero above the diagonal)
-    F[(size_t)i + (size_t)m * j] = v;
-    Lg[(size_t)i + (size_t)m * j] = v;
+  if (lane < n) {
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+      if (c < n) {
+        F[(size_t)lane + (size_t)m * c] = r[c];
+        Lg[(size_t)lane + (size_t)m * c] = r[c];
+      }
   }
-  if (lane < n) Lg[(size_t)m * n + lane] = 1.0 / S[lane + 65 * lane];
 }
 
 // panel rows below the pivot block: x L11' = row, one thread per row, the row in registers
@@ -1888,9 +1894,17 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4
   const FrontRec rec = load_front_rec(P.rec + f);
   const int ns = rec.ns, m = (rec.ns + rec.nb) * BS, n = ns * BS;
   double* F = scratch + scratch_off[ck.x];
-  for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-    const int i = idx % n, j = idx / n;
-    S[i + 65 * j] = F[(size_t)i + (size_t)m * j];
+  {   // thread = (row, column group of 4): all 16 columns of a thread in one round trip
+    const int si = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    double t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = sg + 4 * u;
+      t[u] = (si < n && j < n) ? F[(size_t)si + (size_t)m * j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (sg + 4 * u < n) S[si + 65 * (sg + 4 * u)] = t[u];
   }
   __syncthreads();
   if (threadIdx.x < n) inv[threadIdx.x] = 1.0 / S[threadIdx.x * 66];
@@ -1900,10 +1914,12 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4
   double* Lg = P.L + rec.L_off;
   double x[MAXB * BS];
 #pragma unroll
+  for (int cb = 0; cb < MAXB; ++cb)   // the whole row first: one round trip
+#pragma unroll
+    for (int c = 0; c < BS; ++c) x[cb * BS + c] = (cb < ns) ? F[(size_t)i + (size_t)m * (cb * BS + c)] : 0.0;
+#pragma unroll
   for (int cb = 0; cb < MAXB; ++cb) {
     if (cb < ns) {
-#pragma unroll
-      for (int c = 0; c < BS; ++c) x[cb * BS + c] = F[(size_t)i + (size_t)m * (cb * BS + c)];
 #pragma unroll
       for (int qb = 0; qb < cb; ++qb)
 #pragma unroll
