@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
 
 
-def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2):
+def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2, folded=False):
     """Compulsory traffic per kernel / stage (8 B per double, 4 B per index), SURVEY.md 8d."""
     kb = {}
     kb["assemble_vertex(pose)"] = E * 8 * (d * p + d * d + d) + P * 8 * (p * p + p)
@@ -51,12 +51,21 @@ def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2):
     # the backward sweep reads L once
     kb["chol_factor(all levels)"] = 8 * nnz_up + 8 * nnzL + 16 * n
     kb["chol_solve(all levels)"] = 8 * nnzL + 24 * n
+    if folded:
+        # one GPU: the reduction pass of the Schur complement is folded into the factorisation's front assembly --
+        # the factor kernel reads Hpp and (at least one Hschur worth of) partial blocks, Hschur is never written;
+        # the "schur_reduce" slot only forms bschur
+        kb["schur_reduce"] = 3 * P * 8 * p
+        kb["chol_factor(all levels)"] += pp_nnzb * 8 * p * p
     stage = {
         "B_asm": E * (8 * (d * p + d * l + d * d + d) + 8) + E * 8 * p * l + P * 8 * (p * p + p) + L * 8 * (l * l + l),
         "B_schur": (E * 8 * p * l + L * 8 * (l * l + l) + P * 8 * (p * p + p)) + (L * 8 * l * l + S * 8 * p * p + P * 8 * p),
         "B_chol": 8 * nnz_up + 8 * nnzL + 16 * nnzL + 24 * n,
         "B_back": E * 8 * p * l + L * 8 * (l * l + 2 * l) + P * 8 * p + L * 8 * l,
     }
+    if folded:
+        stage["B_schur"] = E * 8 * p * l + L * 8 * (l * l + l) + L * 8 * l * l + S * 8 * p * p + 3 * P * 8 * p
+        stage["B_chol"] += pp_nnzb * 8 * p * p
     return kb, stage
 
 
@@ -230,7 +239,8 @@ def main():
     S_blocks = solver.local.nnzb(capi.HSCHUR)
     pp_nnzb = solver.local.nnzb(capi.HPP)
     E_loc, L_loc = shard["E_local"], shard["L_local"]
-    kb, stage_b = algorithmic_bytes(E_loc, prob["nP"], L_loc, S_blocks, pp_nnzb, st["choleskyNNZ"])
+    folded = world == 1 and not emulate and not any(kv.replace(" ", "") in ("fuse_schur_reduce=0", "linear_solver=1") for kv in args.opt)
+    kb, stage_b = algorithmic_bytes(E_loc, prob["nP"], L_loc, S_blocks, pp_nnzb, st["choleskyNNZ"], folded=folded)
     if fused:
         kb["assemble_vertex(landmark)"] = kb["fused:assemble_vertex(landmark)"]
         kb["assemble_vertex(pose)"] = kb["fused:assemble_vertex(pose)"]
@@ -272,7 +282,7 @@ def main():
                    "edge_data": "estimates+measurements in HBM, errors/Jacobians evaluated inside buildSystem" if fused
                    else "precomputed Jacobian arrays in HBM"},
         "solve_ok": bool(ok),
-        "launch": ("hipGraph replay of the per-level launch sequences" if use_graph else "plain launches") +
+        "launch": ("hipGraph replay of the launch sequences (elimination-tree levels grouped into dependency-driven launches)" if use_graph else "plain launches") +
                   "; timed region: HIP events around the dominant kernel slot only (roofline); the other per-kernel times come "
                   "from a second pass of the same steps with every slot timed",
         "roofline": roofline,

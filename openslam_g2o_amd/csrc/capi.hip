@@ -362,6 +362,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   if (!name) return G2OHIP_ERR_ARG;
   if (!std::strcmp(name, "nd_leaf")) s->impl->chol_opt.nd_leaf = (int)value;
   else if (!std::strcmp(name, "max_sn_scalars")) s->impl->chol_opt.max_sn_scalars = (int)value;
+  else if (!std::strcmp(name, "max_sn_scalars_lds")) s->impl->chol_opt.max_sn_scalars_lds = (int)value;
   else if (!std::strcmp(name, "lds_front_bytes")) s->impl->chol_opt.lds_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "relax_zeros")) s->impl->chol_opt.relax_zeros = value;
   else if (!std::strcmp(name, "relax_front_bytes")) s->impl->chol_opt.relax_front_bytes = (size_t)value;
@@ -627,6 +628,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   if (!ls || !name) return G2OHIP_ERR_ARG;
   if (!std::strcmp(name, "nd_leaf")) ls->opt.nd_leaf = (int)value;
   else if (!std::strcmp(name, "max_sn_scalars")) ls->opt.max_sn_scalars = (int)value;
+  else if (!std::strcmp(name, "max_sn_scalars_lds")) ls->opt.max_sn_scalars_lds = (int)value;
   else if (!std::strcmp(name, "lds_front_bytes")) ls->opt.lds_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "relax_zeros")) ls->opt.relax_zeros = value;
   else if (!std::strcmp(name, "relax_front_bytes")) ls->opt.relax_front_bytes = (size_t)value;

@@ -28,6 +28,7 @@ namespace g2ohip {
 struct CholOptions {
   int nd_leaf = 32;          // nested-dissection leaf size (blocks)
   int max_sn_scalars = 48;   // supernode (pivot panel) width cap, scalars
+  int max_sn_scalars_lds = 24;  // ... for the fronts small enough for LDS
   double relax_zeros = 0.25; // relaxed amalgamation: tolerated share of explicit zero blocks in a panel
   size_t lds_front_bytes = 64 * 1024;  // fronts up to this size are factorised in LDS
   bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task

@@ -359,7 +359,11 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         const bool exact = st_[j - 1].size() == st_[j].size() + 1 && total == tb;
         const size_t m = (size_t)(w + nbn) * bs;
         const bool fits = m * m * 8 <= std::min(opt.lds_front_bytes, opt.relax_front_bytes);
-        if (w <= max_sn_blocks && (exact || (fits && (double)(total - tb) <= opt.relax_zeros * (double)total))) merge = true;
+        // narrower panels for the fronts that live in LDS (shorter pivot loops per front, smaller solve panels), wide
+        // ones for the scratch-slab fronts (each panel is a whole-GPU pass there)
+        const bool lds_class = m * m * 8 <= opt.lds_front_bytes;
+        const long cap = lds_class ? std::max(1, std::min(opt.max_sn_scalars, opt.max_sn_scalars_lds) / bs) : max_sn_blocks;
+        if (w <= cap && (exact || (fits && (double)(total - tb) <= opt.relax_zeros * (double)total))) merge = true;
       }
       if (!merge) {
         S.sn_start.push_back(j);

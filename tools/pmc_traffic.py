@@ -4,8 +4,8 @@
 Recipe (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and WRITE_SIZE do not fit one pass; no
 other tracing domains next to --pmc):
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/f -o f -- python bench.py --no-cpu-baseline --steps 2 --warmup 1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/w -o w -- python bench.py --no-cpu-baseline --steps 2 --warmup 1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/f -o f -- python bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/w -o w -- python bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1
   python tools/pmc_traffic.py out/f/f_results.db out/w/w_results.db > profiles/rN_pmc_traffic.json
 Values: KiB per counter summed over the launches of a slot in the LAST bench iteration (identified as
 the last 1/iterations share of each kernel's dispatches; iterations = dispatches of a once-per-iteration kernel).  On gfx950 FETCH_SIZE tallies 64 B per 128 B
@@ -20,7 +20,7 @@ SLOTS = [("assemble_vertex(pose)", ("ba_assemble_poses", "assemble_vertex_kernel
          ("assemble_offdiag(Hpl)", ("assemble_offdiag",)),
          ("landmark_inverse", ("landmark_inverse",)),
          ("schur_tiles", ("schur_tile_kernel",)),
-         ("schur_reduce", ("schur_reduce_kernel",)),
+         ("schur_reduce", ("schur_reduce_kernel", "schur_rhs_kernel")),
          ("chol_factor(all levels)", ("front_factor_kernel",)),
          ("chol_solve(all levels)", ("front_forward_kernel", "front_backward_kernel", "permute_in_kernel", "permute_out_kernel")),
          ("back_substitute", ("back_substitute",)),
