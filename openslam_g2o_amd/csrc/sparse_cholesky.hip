@@ -1585,7 +1585,11 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       __syncthreads();
     }
     STAMP();
+#if defined(G2OHIP_ABL) && G2OHIP_ABL == 2
+    for (int kb = 0; kb < 0; ++kb) {
+#else
     for (int kb = 0; kb < ns; ++kb) {
+#endif
       const int k0 = kb * BS;
       const double* box = sd + (kb & 1) * (BB + BS);
       const double* Lb = USE_LDS ? F + blk_off(kb, kb) : box;   // column stride BS either way
@@ -1719,7 +1723,9 @@ __global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G
       for (int k = tid; k < npiv; k += NT) Lg[(size_t)m * npiv + k] = 1.0 / F[blk_off(k / BS, k / BS) + (k % BS) * (1 + cs)];
     };
     const bool dep_signal = dep && rec.pad[1] < 0;   // (bit 31) the parent front waits in this launch
+#if !defined(G2OHIP_ABL) || G2OHIP_ABL != 1   // (ablation builds, make EXTRA=-DG2OHIP_ABL=n: 1 = no L panel, 2 = no pivot loop)
     if (!dep_signal) write_panel();
+#endif
     // ---- update matrix (packed lower-triangular blocks, row-major): to the next chain front through
     // registers, or to HBM for a parent in a later launch
     STAMP();
