@@ -163,9 +163,14 @@ int g2ohip_kernel_time(g2ohip_solver* s, int slot, double* total_seconds, long* 
  * LinearSolverPCG, g2o/solvers/pcg/linear_solver_pcg.hpp:79-196) with "pcg_tolerance" (1e-6),
  * "pcg_absolute_tolerance" (1), "pcg_max_iterations" (-1 = dimension), like LinearSolverPCG's setters
  * (linear_solver_pcg.h:74-85); iterations of the last solve in g2ohip_stats.iterationsLinearSolver.
- * Ordering / symbolic knobs: "nd_leaf" (nested-dissection leaf size in blocks, 32), "max_sn_scalars",
- * "relax_zeros", "relax_front_bytes", "lds_front_bytes", "fuse_chains", "wave_front_tasks".  Kernel knobs:
- * "schur_tile_bytes", "schur_group", "fuse_landmark_inverse", "ba_fused", "use_graph", "mask_solution". */
+ * Ordering / symbolic knobs (before g2ohip_build_structure): "nd_leaf" (nested-dissection leaf size in blocks, 32),
+ * "max_sn_scalars" (48) / "max_sn_scalars_lds" (24: fronts that fit LDS), "relax_zeros", "relax_front_bytes",
+ * "lds_front_bytes", "fuse_chains", "wave_front_tasks", "dep_levels" (16: task levels that may share one
+ * dependency-driven launch, 0/1 = one launch per level), "dep_backward" (1), "dep_delay", "dep_spin_limit",
+ * "big_front_passes" (1: large fronts as whole-GPU passes with an MFMA update) / "big_front_min_dim" (240).
+ * Kernel knobs: "schur_tile_bytes", "schur_group", "fuse_landmark_inverse", "fuse_schur_reduce" (1: g2ohip_solve on
+ * one GPU folds the Schur reduction into the factorisation; Hschur is then written only when it is asked for),
+ * "ba_fused", "use_graph", "mask_solution". */
 int g2ohip_set_option(g2ohip_solver* s, const char* name, double value);
 
 /* Inspection for parity tests (saveHessian-like, block_solver.hpp:628-632): block patterns
