@@ -38,6 +38,24 @@ def run(name, opts):
         s.setLambda(lam, True); s.solve(); s.restoreDiagonal()
     dt = (time.perf_counter() - t0) / n
     st = s.stats()
+    if os.environ.get("POSEGRAPH_CPU"):   # the CPU oracle (single thread) on the same system, for profiles/r1_posegraph.json
+        import json
+        o = O.OracleSolver(p, l, g["nP"], 0, schur=False)
+        ko = o.add_edge_set(d, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+        o.set_dims(ko, p, p)
+        o.build_structure()
+        o.set_edge_data(ko, J0, J1, g["omega"], err)
+        o.build_system()
+        o.set_lambda(lam, True)
+        assert o.solve()                  # (ordering + symbolic factorisation happen once, like the reference: not timed)
+        t0 = time.perf_counter()
+        assert o.solve()
+        cpu = time.perf_counter() - t0
+        xg = s.x(); xo = o.x()
+        print(json.dumps({"graph": name, "poses": int(g["nP"]), "edges": int(len(g["vi"])), "gpu_ms_per_solve": 1e3 * dt,
+                          "cpu_oracle_ms_per_solve": 1e3 * cpu, "dx_rel_err": float(np.abs(xg - xo).max() / np.abs(xo).max()),
+                          "fronts": st["numFronts"], "levels": st["numLevels"], "maxFrontDim": st["maxFrontDim"],
+                          "choleskyNNZ": st["choleskyNNZ"]}))
     print("%-10s %-28s %.3f ms/solve  fronts %d levels %d maxdim %d nnz %d" % (name, " ".join(opts), 1e3 * dt, st["numFronts"], st["numLevels"], st["maxFrontDim"], st["choleskyNNZ"]))
 
 for name in ("manhattan", "sphere"):
