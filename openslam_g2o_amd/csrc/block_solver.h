@@ -30,6 +30,7 @@ struct EdgeSet {
   const double *J0 = nullptr, *J1 = nullptr, *omega = nullptr, *err = nullptr;
   DevBuf<double> own_J0, own_J1, own_omega, own_err;
   bool has_data = false;   // Jacobians + information + errors available for build_system
+  bool external = false;   // the arrays belong to the caller (set_edge_data on_device): they may change behind the solver's back
   bool has_err = false;    // errors + information available (enough for chi2)
   // destination-major contributor lists
   DevBuf<int> vp_ptr, vp_ent, vl_ptr, vl_ent;  // per pose / per landmark: (edge << 1 | side)
@@ -182,6 +183,8 @@ class BlockSolver {
   std::vector<int> rd_cnt_h_, rd_ptr_h_, rd_slot_h_, hs_src_h_, hs_diag_h_;
   DevBuf<int> d_pose_diag;                 // pose -> its diagonal block of the reduced system
   bool hschur_valid_ = true, virt_now_ = false;
+  bool chi2_valid_ = false;                // chi2_value_ matches the errors / kernels of every edge set
+  double chi2_value_ = 0.0;
   DevBuf<double> d_Hpp, d_Hpl, d_Hll, d_Hschur, d_Dinv, d_db, d_b, d_x, d_bschur, d_bkP, d_bkL, d_red;
   DevBuf<int> d_pp_diag, d_pl_colptr, d_pl_row, d_pl_lm;
   DevBuf<int> d_hs_src;                    // Hschur block -> Hpp block id or -1
@@ -203,6 +206,7 @@ class BlockSolver {
     double f = 0, cx = 0, cy = 0;
     DevBuf<int> cam_v, pt_v, cam_hidx, pt_hidx, edge_hpl;
     bool omega_identity = false;   // information = identity for the whole set (info == NULL): not read per edge
+    bool err_valid = false, jac_valid = false;   // errors / Jacobians of the set match the current estimates
     bool fused_ok = false;   // every Hpl block has exactly one observation: fused on-the-fly assembly allowed
     DevBuf<double> meas, cams, pts, cams_bak, pts_bak;
     DevBuf<double> meas_pm, omega_pm;   // pose-major copies (observation-list order of the pose side)
@@ -216,6 +220,7 @@ class BlockSolver {
     DevBuf<int> vi, vj, hidx;
     DevBuf<double> meas, poses, poses_bak;
     bool has_backup = false;
+    bool err_valid = false, jac_valid = false;
   } pg_;
   EventTimer tq_, ts_, tn_, tl_, tb_;
   void require_structure() const;

@@ -1949,6 +1949,7 @@ void BlockSolver::set_edge_data(int set, const double* J0, const double* J1, con
   EdgeSet& es = *sets_[set];
   if (!J0 || !omega || !err || (!es.unary && !J1)) throw ArgFailure("set_edge_data: null array");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  es.external = on_device;
   if (on_device) {
     es.J0 = J0;
     es.J1 = J1;
@@ -1978,6 +1979,10 @@ void BlockSolver::set_robust_kernel(int set, int kind, double delta) {
 }
 
 void BlockSolver::invalidate_graphs() {
+  // (called by every setter that changes what the kernels read: also drops the cached evaluations)
+  chi2_valid_ = false;
+  ba_.err_valid = ba_.jac_valid = false;
+  pg_.err_valid = pg_.jac_valid = false;
   for (GraphSeg& sg : segs_) {
     if (sg.e) (void)hipGraphExecDestroy(sg.e);
     if (sg.g) (void)hipGraphDestroy(sg.g);
@@ -2109,6 +2114,7 @@ double BlockSolver::reduce_sum_finish(int nblocks) {
 
 double BlockSolver::chi2() {
   require_structure();
+  if (chi2_valid_) return chi2_value_;   // same errors, same kernels as the last evaluation (LM asks twice per accepted step)
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   double total = 0.0;
   for (auto& esp : sets_) {
@@ -2133,6 +2139,10 @@ double BlockSolver::chi2() {
 #undef G2OHIP_CHI
     total += reduce_sum_finish(nblocks);
   }
+  chi2_value_ = total;
+  chi2_valid_ = true;
+  for (auto& esp : sets_)
+    if (esp->external) chi2_valid_ = false;   // caller-owned arrays: nothing tells the solver when they change
   return total;
 }
 
@@ -2720,6 +2730,14 @@ void BlockSolver::ba_linearize(bool jacobians) {
   EdgeSet& es = *sets_[ba_.set];
   const bool fused = ba_fused && ba_.fused_ok;
   // fused mode: build_system re-evaluates the Jacobians itself, only the errors (for chi2) are produced here
+  const bool need_jac = jacobians && !fused;
+  if (ba_.err_valid && (!need_jac || ba_.jac_valid)) {   // the estimates have not moved since the last evaluation
+    if (jacobians) es.has_data = true;
+    return;
+  }
+  ba_.err_valid = true;
+  if (need_jac) ba_.jac_valid = true;
+  chi2_valid_ = false;
   hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid_for(es.n)), dim3(kThreads), 0, st_, es.n, ba_.cams.p, ba_.pts.p, ba_.cam_v.p,
                      ba_.pt_v.p, ba_.meas.p, ba_.f, ba_.cx, ba_.cy, es.own_J0.p, es.own_J1.p, es.own_err.p, (jacobians && !fused) ? 1 : 0);
   G2OHIP_HIP_CHECK(hipGetLastError());
@@ -2731,6 +2749,7 @@ void BlockSolver::ba_update() {
   require_structure();
   if (ba_.n_cams <= 0) throw StateFailure("ba_update before ba_set_estimates");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  ba_.err_valid = ba_.jac_valid = false;
   hipLaunchKernelGGL(ba_update_cams_kernel, dim3(grid_for(ba_.n_cams)), dim3(kThreads), 0, st_, ba_.n_cams, ba_.cams.p, ba_.cam_hidx.p,
                      d_x.p);
   hipLaunchKernelGGL(ba_update_pts_kernel, dim3(grid_for((size_t)ba_.n_points * 3)), dim3(kThreads), 0, st_, ba_.n_points, ba_.pts.p,
@@ -2749,6 +2768,7 @@ void BlockSolver::ba_push() {
 }
 void BlockSolver::ba_pop() {
   if (!ba_.has_backup) throw StateFailure("ba_pop without push");
+  ba_.err_valid = ba_.jac_valid = false;
   G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.cams.p, ba_.cams_bak.p, (size_t)ba_.n_cams * 12 * sizeof(double), hipMemcpyDeviceToDevice, st_));
   G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.pts.p, ba_.pts_bak.p, (size_t)ba_.n_points * 3 * sizeof(double), hipMemcpyDeviceToDevice, st_));
   ba_.has_backup = false;
@@ -2789,6 +2809,7 @@ void BlockSolver::pg_set_edges(int set, int type, const int* vi, const int* vj, 
 void BlockSolver::pg_set_estimates(int nv, const double* poses, const int* hidx) {
   if (pg_.type == 0) throw StateFailure("pg_set_estimates: call pg_set_edges first");
   if (nv <= 0 || !poses || !hidx) throw ArgFailure("pg_set_estimates: bad arguments");
+  pg_.err_valid = pg_.jac_valid = false;
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t ps = pg_.type == 1 ? 3 : 12;
   pg_.nv = nv;
@@ -2808,6 +2829,13 @@ void BlockSolver::pg_linearize(bool jacobians) {
   if (pg_.set < 0 || pg_.nv <= 0) throw StateFailure("pg_linearize: call pg_set_edges and pg_set_estimates first");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   EdgeSet& es = *sets_[pg_.set];
+  if (pg_.err_valid && (!jacobians || pg_.jac_valid)) {   // the estimates have not moved since the last evaluation
+    if (jacobians) es.has_data = true;
+    return;
+  }
+  pg_.err_valid = true;
+  if (jacobians) pg_.jac_valid = true;
+  chi2_valid_ = false;
   if (pg_.type == 1)
     hipLaunchKernelGGL(pg_se2_linearize_kernel, dim3(grid_for(es.n)), dim3(kThreads), 0, st_, es.n, pg_.poses.p, pg_.vi.p, pg_.vj.p,
                        pg_.meas.p, es.own_J0.p, es.own_J1.p, es.own_err.p, jacobians ? 1 : 0);
@@ -2823,6 +2851,7 @@ void BlockSolver::pg_update() {
   require_structure();
   if (pg_.nv <= 0) throw StateFailure("pg_update before pg_set_estimates");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  pg_.err_valid = pg_.jac_valid = false;
   if (pg_.type == 1)
     hipLaunchKernelGGL(pg_se2_update_kernel, dim3(grid_for(pg_.nv)), dim3(kThreads), 0, st_, pg_.nv, pg_.poses.p, pg_.hidx.p, d_x.p);
   else
@@ -2839,6 +2868,7 @@ void BlockSolver::pg_push() {
 }
 void BlockSolver::pg_pop() {
   if (!pg_.has_backup) throw StateFailure("pg_pop without push");
+  pg_.err_valid = pg_.jac_valid = false;
   G2OHIP_HIP_CHECK(hipMemcpyAsync(pg_.poses.p, pg_.poses_bak.p, (size_t)pg_.nv * (pg_.type == 1 ? 3 : 12) * sizeof(double),
                                   hipMemcpyDeviceToDevice, st_));
   pg_.has_backup = false;
