@@ -2003,18 +2003,37 @@ void BlockSolver::run_seg(int id, F&& body) {
     return;
   }
   if (sg.state == 1) {
-    G2OHIP_HIP_CHECK(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
-    try {
-      body();
-    } catch (...) {
-      hipGraph_t dead = nullptr;
-      (void)hipStreamEndCapture(st_, &dead);
-      if (dead) (void)hipGraphDestroy(dead);
-      throw;
+    // A capture that the runtime refuses (another library touching the stream, an unsupported node) is not an
+    // error of the solve: the segment then runs as plain launches, for good.
+    bool ok = hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      try {
+        body();
+      } catch (...) {
+        hipGraph_t dead = nullptr;
+        (void)hipStreamEndCapture(st_, &dead);
+        if (dead) (void)hipGraphDestroy(dead);
+        throw;
+      }
+      hipGraph_t g = nullptr;
+      hipGraphExec_t e = nullptr;
+      ok = hipStreamEndCapture(st_, &g) == hipSuccess && g != nullptr;
+      if (ok) ok = hipGraphInstantiate(&e, g, nullptr, nullptr, 0) == hipSuccess;
+      if (ok) {
+        sg.g = g;
+        sg.e = e;
+        sg.state = 2;
+      } else if (g) {
+        (void)hipGraphDestroy(g);
+      }
     }
-    G2OHIP_HIP_CHECK(hipStreamEndCapture(st_, &sg.g));
-    G2OHIP_HIP_CHECK(hipGraphInstantiate(&sg.e, sg.g, nullptr, nullptr, 0));
-    sg.state = 2;
+    if (!ok) {
+      (void)hipGetLastError();
+      fprintf(stderr, "g2ohip: hipGraph capture of a launch sequence failed; continuing with plain launches\n");
+      use_graph = false;
+      body();
+      return;
+    }
   }
   G2OHIP_HIP_CHECK(hipGraphLaunch(sg.e, st_));
 }
