@@ -132,6 +132,7 @@ class BlockSolver {
   bool schur_sort_dests = true;            // order a tile's destinations by entry count (lockstep lane groups)
   int num_cus_ = 256;
   bool fuse_landmark_inverse = true;       // invert the landmark blocks inside the Schur tile kernel
+  bool overlap_assembly = false;           // fused BA assembly: pose-side kernel on a side stream next to the landmark-side one (measured: 0.2 ms SLOWER per iteration, kept as a switch)
   bool fuse_schur_reduce = true;           // solve(): the factorisation assembles its fronts from Hpp and the tiles' partial
                                            // blocks directly; Hschur is only written out when somebody asks for it
   bool tiles_cover_all_ = false;
@@ -183,6 +184,8 @@ class BlockSolver {
   std::vector<int> rd_cnt_h_, rd_ptr_h_, rd_slot_h_, hs_src_h_, hs_diag_h_;
   DevBuf<int> d_pose_diag;                 // pose -> its diagonal block of the reduced system
   bool hschur_valid_ = true, virt_now_ = false;
+  hipStream_t side_ = nullptr;
+  hipEvent_t side_fork_ = nullptr, side_join_ = nullptr;
   bool chi2_valid_ = false;                // chi2_value_ matches the errors / kernels of every edge set
   double chi2_value_ = 0.0;
   DevBuf<double> d_Hpp, d_Hpl, d_Hll, d_Hschur, d_Dinv, d_db, d_b, d_x, d_bschur, d_bkP, d_bkL, d_red;

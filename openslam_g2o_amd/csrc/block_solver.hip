@@ -1484,6 +1484,9 @@ BlockSolver::BlockSolver(int p, int l, int device) : p_(p), l_(l), device_(devic
 
 BlockSolver::~BlockSolver() {
   invalidate_graphs();
+  if (side_) (void)hipStreamDestroy(side_);
+  if (side_fork_) (void)hipEventDestroy(side_fork_);
+  if (side_join_) (void)hipEventDestroy(side_join_);
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
 }
 
@@ -2058,6 +2061,18 @@ void BlockSolver::build_system_impl() {
     if (es.n == 0) continue;
     if (set_index == ba_.set && ba_fused && ba_.fused_ok && ba_.n_cams > 0) {
       // fused EdgeProjectXYZ2UV path: errors + Jacobians evaluated inside the assembly kernels
+      // The two sides write disjoint arrays (Hll / b_l / Hpl and Hpp / b_p): the pose side runs on a side stream
+      // next to the landmark side unless one of them is being timed on its own.
+      const bool overlap = overlap_assembly && es.touches_pose && !prof.timing(KernelProf::kAsmLandmark) && !prof.timing(KernelProf::kAsmPose);
+      if (overlap) {
+        if (!side_) {
+          G2OHIP_HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+          G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&side_fork_, hipEventDisableTiming));
+          G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&side_join_, hipEventDisableTiming));
+        }
+        G2OHIP_HIP_CHECK(hipEventRecord(side_fork_, st_));             // fork before either kernel is queued
+        G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_, side_fork_, 0));
+      }
       prof.begin(KernelProf::kAsmLandmark, st_);
       {
         const double avgK = (double)es.n_vl_ent / std::max(1, nL_);
@@ -2075,8 +2090,9 @@ void BlockSolver::build_system_impl() {
       prof.end(KernelProf::kAsmLandmark, st_);
       prof.begin(KernelProf::kAsmPose, st_);
       const int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
+      hipStream_t sp = overlap ? side_ : st_;   // stream of the pose kernel
 #define G2OHIP_BA_POSE(GG)                                                                                                       \
-  hipLaunchKernelGGL((ba_assemble_poses_kernel<GG>), dim3(grid_for((size_t)nP_ * GG)), dim3(kThreads), 0, st_, nP_, es.vp_ptr.p,  \
+  hipLaunchKernelGGL((ba_assemble_poses_kernel<GG>), dim3(grid_for((size_t)nP_ * GG)), dim3(kThreads), 0, sp, nP_, es.vp_ptr.p,  \
                      ba_.cams.p, ba_.pts.p, ba_.cam_pm.p, ba_.pt_pm.p, ba_.meas_pm.p, ba_.omega_pm.p, ba_.f, ba_.cx, ba_.cy,       \
                      es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, ba_.omega_identity ? 1 : 0)
       if (es.touches_pose) {
@@ -2085,6 +2101,10 @@ void BlockSolver::build_system_impl() {
         else G2OHIP_BA_POSE(8);
       }
 #undef G2OHIP_BA_POSE
+      if (overlap) {
+        G2OHIP_HIP_CHECK(hipEventRecord(side_join_, side_));
+        G2OHIP_HIP_CHECK(hipStreamWaitEvent(st_, side_join_, 0));
+      }
       prof.end(KernelProf::kAsmPose, st_);
       continue;
     }

@@ -149,6 +149,7 @@ struct KernelProf {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e; G2OHIP_HIP_CHECK(hipEventCreate(&e)); return e;
   }
+  bool timing(int slot) const { return enabled && (only < 0 || slot == only); }
   void begin(int slot, hipStream_t st) {
     if (!enabled || (only >= 0 && slot != only)) return;
     Pair p{get(), get()};
