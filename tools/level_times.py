@@ -10,4 +10,4 @@ nlev = int(sys.argv[2])
 for key in ("front_factor", "front_forward", "front_backward"):
     sel = [r for r in rows if key in r[0]][-nlev:]
     print(key, "total %.0f us" % (sum(r[2] - r[1] for r in sel) / 1e3))
-    print("   grid:ldsKB:us ", " ".join("%d:%d:%.0f" % (r[3] // r[4], r[5] // 1024, (r[2] - r[1]) / 1e3) for r in sel))
+    print("   grid:ldsB:us ", " ".join("%d:%d:%.0f" % (r[3] // r[4], r[5], (r[2] - r[1]) / 1e3) for r in sel))
