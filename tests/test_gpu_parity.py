@@ -443,3 +443,25 @@ def test_schur_reduction_folded_into_factorisation():
     o.set_lambda(7.0, True)
     assert o.solve() and relerr(xa, o.x()) < 1e-8
     assert relerr(a.values(capi.HSCHUR), o.values("Hschur")) < TOL_MAT
+
+
+@pytest.mark.parametrize("fold", [1, 0])
+def test_ba_with_large_fronts(fold):
+    """BA whose reduced system is nearly dense (every landmark seen by 60 of 100 cameras): the fronts exceed the
+    LDS budget, so the scratch-slab path (whole-GPU passes, MFMA trailing update) runs on a Schur complement --
+    with the reduction folded into the large fronts' assembly (fold=1) and from a materialised Hschur (fold=0)."""
+    capi = _capi()
+    pr = ba_case(100, 240, obs_per_landmark=60)
+    s = hip_ba(pr, options={"fuse_schur_reduce": fold})
+    assert s.stats()["maxFrontDim"] >= 240
+    o = oracle_ba(pr)
+    s.buildSystem()
+    o.build_system()
+    lam = 1e-4 * o.max_diagonal()
+    s.setLambda(lam, True)
+    o.set_lambda(lam, True)
+    assert s.solve() and o.solve()
+    assert relerr(s.values(capi.HSCHUR), o.values("Hschur")) < TOL_MAT
+    assert relerr(s.x(), o.x()) < 1e-7
+    r = s.multiplyHessian(s.x()) - s.b()
+    assert np.abs(r).max() <= 1e-9 * np.abs(s.b()).max()
