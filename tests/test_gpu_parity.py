@@ -465,3 +465,42 @@ def test_ba_with_large_fronts(fold):
     assert relerr(s.x(), o.x()) < 1e-7
     r = s.multiplyHessian(s.x()) - s.b()
     assert np.abs(r).max() <= 1e-9 * np.abs(s.b()).max()
+
+
+@pytest.mark.parametrize("bs", [3, 6, 7])
+@pytest.mark.parametrize("passes", [1, 0])
+def test_linear_solver_large_fronts_all_block_sizes(bs, passes):
+    """LinearSolver seam on random block-sparse SPD systems dense enough for fronts of several hundred rows: the
+    scratch-slab path for every block size (whole-GPU passes with the MFMA update, and one workgroup per front),
+    against a dense LAPACK solve."""
+    capi = _capi()
+    rng = np.random.default_rng(50 + bs)
+    nb = 160 if bs > 3 else 260
+    dens = 0.18
+    mask = np.triu(rng.random((nb, nb)) < dens, 1)
+    mask |= np.eye(nb, k=1, dtype=bool)                      # connected
+    n = nb * bs
+    A = np.zeros((n, n))
+    for j in range(nb):
+        for i in np.nonzero(mask[:, j])[0]:
+            A[i * bs:(i + 1) * bs, j * bs:(j + 1) * bs] = rng.normal(size=(bs, bs))
+    A = A + A.T
+    A += np.eye(n) * (np.abs(A).sum(axis=1).max() + 1.0)     # strictly diagonally dominant: SPD
+    cp, row, vals = [0], [], []
+    for j in range(nb):
+        for i in range(j + 1):
+            if i == j or mask[i, j]:
+                row.append(i)
+                vals.append(A[i * bs:(i + 1) * bs, j * bs:(j + 1) * bs].T.reshape(-1))   # column-major block
+        cp.append(len(row))
+    cp, row, vals = np.array(cp, np.int32), np.array(row, np.int32), np.array(vals)
+    b = rng.normal(size=n)
+    ls = capi.HipLinearSolver(bs, 0)
+    ls.setOption("big_front_passes", passes)
+    ok, x = ls.solve(cp, row, vals, b)
+    assert ok
+    assert ls.stats()["maxFrontDim"] >= 240
+    xr = np.linalg.solve(A, b)
+    assert relerr(x, xr) < 1e-10
+    ok, _ = ls.solve(cp, row, -vals, b)
+    assert not ok
