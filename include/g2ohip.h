@@ -226,6 +226,20 @@ int g2ohip_set_partition(g2ohip_solver* s, int rank, int world);
 int g2ohip_solve_reduced_local(g2ohip_solver* s);
 int g2ohip_solve_reduced_shared(g2ohip_solver* s);
 int g2ohip_solve_reduced_finish(g2ohip_solver* s);
+/* The same exchange without host round trips (what openslam_g2o_amd/distributed.py does per solve): the caller
+ * registers once the reduced-system blocks / poses on partition boundaries (with 0/1 keep flags: a rank keeps the
+ * summed value only of what it consumes) and the foreign "halo" poses its landmarks observe (flag 1 where this rank
+ * owns the value); then per solve
+ *   g2ohip_solve_schur, g2ohip_exchange_pack(1), [all-reduce g2ohip_device_array 105], g2ohip_exchange_unpack(1),
+ *   g2ohip_solve_reduced_local, [all-reduce 103], g2ohip_solve_reduced_shared, g2ohip_solve_reduced_finish_async,
+ *   g2ohip_exchange_pack(3), [all-reduce 106: halo x_p + failure flags], g2ohip_exchange_unpack(3),
+ *   g2ohip_solve_back_substitute, g2ohip_exchange_status  (the only synchronisation; G2OHIP_NOT_PD if any rank failed). */
+int g2ohip_exchange_setup(g2ohip_solver* s, int n_blocks, const int32_t* block_idx, const double* block_keep, int n_poses,
+                          const int32_t* pose_idx, const double* pose_keep, int n_halo, const int32_t* halo_idx, const double* halo_mine);
+int g2ohip_exchange_pack(g2ohip_solver* s, int which);
+int g2ohip_exchange_unpack(g2ohip_solver* s, int which);
+int g2ohip_exchange_status(g2ohip_solver* s);
+int g2ohip_solve_reduced_finish_async(g2ohip_solver* s);
 int g2ohip_get_partition(g2ohip_solver* s, int32_t* pose_owner, int32_t* block_consumer);
 int g2ohip_partition_poses(const g2ohip_solver* options_from, int block_dim, int n_blocks, const int32_t* colptr,
                            const int32_t* rowidx, int world, int32_t* pose_owner, int32_t* block_consumer);

@@ -23,7 +23,7 @@ c_dbl_p = C.POINTER(C.c_double)
 
 OK, NOT_PD = 0, 1
 HPP, HPL, HLL, HSCHUR, DINV = 0, 1, 2, 3, 4
-ARR_BSCHUR, ARR_X, ARR_B, ARR_EXCHANGE, ARR_XP = 100, 101, 102, 103, 104
+ARR_BSCHUR, ARR_X, ARR_B, ARR_EXCHANGE, ARR_XP, ARR_XBOUNDARY, ARR_XHALO = 100, 101, 102, 103, 104, 105, 106
 KERNEL_NONE, KERNEL_HUBER = 0, 1
 
 
@@ -51,6 +51,7 @@ EXPORTS = [
     "g2ohip_set_lambda_split", "g2ohip_ba_set_edges", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
     "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
+    "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
     "g2ohip_get_partition", "g2ohip_partition_poses",
     "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
@@ -104,8 +105,11 @@ def load():
     L.g2ohip_partition_poses.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p]
     for n in ("g2ohip_solve", "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute",
               "g2ohip_sync", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared",
-              "g2ohip_solve_reduced_finish"):
+              "g2ohip_solve_reduced_finish", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_status"):
         getattr(L, n).argtypes = [vp]
+    L.g2ohip_exchange_setup.argtypes = [vp, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_dbl_p]
+    L.g2ohip_exchange_pack.argtypes = [vp, C.c_int]
+    L.g2ohip_exchange_unpack.argtypes = [vp, C.c_int]
     L.g2ohip_vector_size.argtypes = [vp]
     L.g2ohip_vector_size.restype = C.c_size_t
     L.g2ohip_copy_x.argtypes = [vp, c_dbl_p]
@@ -318,6 +322,24 @@ class HipBlockSolver:
 
     def solveReducedFinish(self):
         return _check(self.L.g2ohip_solve_reduced_finish(self.h), "solveReducedFinish") == OK
+
+    def solveReducedFinishAsync(self):
+        _check(self.L.g2ohip_solve_reduced_finish_async(self.h), "solveReducedFinishAsync")
+
+    def exchangeSetup(self, block_idx, block_keep, pose_idx, pose_keep, halo_idx, halo_mine):
+        bi, pi, hi = _i32(block_idx), _i32(pose_idx), _i32(halo_idx)
+        bk, pk, hm = _f64(block_keep), _f64(pose_keep), _f64(halo_mine)
+        _check(self.L.g2ohip_exchange_setup(self.h, len(bi), _ip(bi), _dp(bk), len(pi), _ip(pi), _dp(pk), len(hi), _ip(hi), _dp(hm)),
+               "exchangeSetup")
+
+    def exchangePack(self, which):
+        _check(self.L.g2ohip_exchange_pack(self.h, which), "exchangePack")
+
+    def exchangeUnpack(self, which):
+        _check(self.L.g2ohip_exchange_unpack(self.h, which), "exchangeUnpack")
+
+    def exchangeStatus(self):
+        return _check(self.L.g2ohip_exchange_status(self.h), "exchangeStatus") == OK
 
     def solveBackSubstitute(self):
         _check(self.L.g2ohip_solve_back_substitute(self.h), "solveBackSubstitute")

@@ -2514,6 +2514,120 @@ int BlockSolver::solve_reduced_finish() {
   return bad ? 1 : 0;
 }
 
+// ---- halo exchange helpers (see block_solver.h) ------------------------------------------------------
+__global__ void exchange_boundary_kernel(int nbb, int nbp, int pp, int p, const int* __restrict__ bblock, const int* __restrict__ bpose,
+                                         const double* __restrict__ hkeep, const double* __restrict__ bkeep, double* __restrict__ Hs,
+                                         double* __restrict__ bs, double* __restrict__ buf, int unpack) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n1 = nbb * pp;
+  if (t >= n1 + nbp * p) return;
+  double* target;
+  double keep;
+  if (t < n1) {
+    target = Hs + (size_t)bblock[t / pp] * pp + t % pp;
+    keep = hkeep[t / pp];
+  } else {
+    const int u = t - n1;
+    target = bs + (size_t)bpose[u / p] * p + u % p;
+    keep = bkeep[u / p];
+  }
+  if (unpack) *target = buf[t] * keep;   // a rank keeps only what it consumes (a stale sum would be added again)
+  else buf[t] = *target;
+}
+__global__ void exchange_halo_kernel(int nh, int p, const int* __restrict__ halo, const double* __restrict__ hmine, double* __restrict__ x,
+                                     double* __restrict__ buf, const int* __restrict__ status, int unpack) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > nh * p) return;
+  if (t == nh * p) {
+    if (!unpack) buf[t] = (*status != 0) ? 1.0 : 0.0;
+    return;
+  }
+  double* target = x + (size_t)halo[t / p] * p + t % p;
+  if (unpack) *target = buf[t];
+  else buf[t] = *target * hmine[t / p];
+}
+
+void BlockSolver::exchange_setup(int nbb, const int* bblock, const double* hkeep, int nbp, const int* bpose, const double* bkeep, int nh,
+                                 const int* halo, const double* hmine) {
+  require_structure();
+  if (nbb < 0 || nbp < 0 || nh < 0) throw ArgFailure("exchange_setup: negative count");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  ex_.nbb = nbb;
+  ex_.nbp = nbp;
+  ex_.nh = nh;
+  auto up_i = [&](DevBuf<int>& d, const int* h, int n) {
+    std::vector<int> v(h, h + n);
+    if (v.empty()) v.push_back(0);
+    d.upload(v, st_);
+  };
+  auto up_d = [&](DevBuf<double>& d, const double* h, int n) {
+    std::vector<double> v(h, h + n);
+    if (v.empty()) v.push_back(0.0);
+    d.upload(v, st_);
+  };
+  up_i(ex_.bblock, bblock, nbb);
+  up_i(ex_.bpose, bpose, nbp);
+  up_i(ex_.halo, halo, nh);
+  up_d(ex_.hkeep, hkeep, nbb);
+  up_d(ex_.bkeep, bkeep, nbp);
+  up_d(ex_.hmine, hmine, nh);
+  ex_.buf1.alloc((size_t)std::max(1, nbb * p_ * p_ + nbp * p_));
+  ex_.buf1.zero(st_);
+  ex_.buf3.alloc((size_t)nh * p_ + 1);
+  ex_.buf3.zero(st_);
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void BlockSolver::exchange_pack(int which) {
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (which == 1) {
+    const int n = ex_.nbb * p_ * p_ + ex_.nbp * p_;
+    if (n > 0)
+      hipLaunchKernelGGL(exchange_boundary_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st_, ex_.nbb, ex_.nbp, p_ * p_, p_, ex_.bblock.p,
+                         ex_.bpose.p, ex_.hkeep.p, ex_.bkeep.p, d_Hschur.p, d_bschur.p, ex_.buf1.p, 0);
+  } else if (which == 3) {
+    hipLaunchKernelGGL(exchange_halo_kernel, dim3(grid_for(ex_.nh * p_ + 1)), dim3(kThreads), 0, st_, ex_.nh, p_, ex_.halo.p, ex_.hmine.p,
+                       d_x.p, ex_.buf3.p, chol_->status_device(), 0);
+  } else {
+    throw ArgFailure("exchange_pack: which must be 1 or 3");
+  }
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+void BlockSolver::exchange_unpack(int which) {
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (which == 1) {
+    const int n = ex_.nbb * p_ * p_ + ex_.nbp * p_;
+    if (n > 0)
+      hipLaunchKernelGGL(exchange_boundary_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st_, ex_.nbb, ex_.nbp, p_ * p_, p_, ex_.bblock.p,
+                         ex_.bpose.p, ex_.hkeep.p, ex_.bkeep.p, d_Hschur.p, d_bschur.p, ex_.buf1.p, 1);
+  } else if (which == 3) {
+    hipLaunchKernelGGL(exchange_halo_kernel, dim3(grid_for(ex_.nh * p_ + 1)), dim3(kThreads), 0, st_, ex_.nh, p_, ex_.halo.p, ex_.hmine.p,
+                       d_x.p, ex_.buf3.p, chol_->status_device(), 1);
+  } else {
+    throw ArgFailure("exchange_unpack: which must be 1 or 3");
+  }
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+void BlockSolver::solve_reduced_finish_async() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  chol_->solve_end(d_x.p, st_);
+}
+
+int BlockSolver::exchange_status() {
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  double flag = 0.0;
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(&flag, ex_.buf3.p + (size_t)ex_.nh * p_, sizeof(double), hipMemcpyDeviceToHost, st_));
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+  if (flag != 0.0) {   // some rank failed; the local cleanup (dependency counters, stall fallback) runs where it applies
+    if (chol_->failed(st_) && chol_->dependency_stall()) invalidate_graphs();
+    return 1;
+  }
+  return 0;
+}
+
 void BlockSolver::partition_info(int* pose_owner, int* block_consumer) {
   require_structure();
   const CholSymbolic& S = chol_->symbolic();
@@ -2996,6 +3110,8 @@ void BlockSolver::device_array(int which, double** ptr, size_t* count) {
     case 102: *ptr = d_b.p; *count = vector_size(); break;
     case 103: *ptr = chol_->exchange_buffer(count); break;      // subtree-root update matrices + vectors
     case 104: *ptr = chol_->permuted_solution(count); break;   // x_p in elimination order (masked before the all-reduce)
+    case 105: *ptr = ex_.buf1.p; *count = (size_t)std::max(1, ex_.nbb * p_ * p_ + ex_.nbp * p_); break;   // exchange_setup buffers
+    case 106: *ptr = ex_.buf3.p; *count = (size_t)ex_.nh * p_ + 1; break;
     default: throw ArgFailure("bad array selector");
   }
 }

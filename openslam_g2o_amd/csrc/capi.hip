@@ -234,6 +234,42 @@ int g2ohip_solve_reduced_finish(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] { return s->impl->solve_reduced_finish() ? G2OHIP_NOT_PD : G2OHIP_OK; });
 }
+int g2ohip_solve_reduced_finish_async(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->solve_reduced_finish_async();
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_exchange_setup(g2ohip_solver* s, int n_blocks, const int32_t* block_idx, const double* block_keep, int n_poses,
+                          const int32_t* pose_idx, const double* pose_keep, int n_halo, const int32_t* halo_idx, const double* halo_mine) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    if ((n_blocks > 0 && (!block_idx || !block_keep)) || (n_poses > 0 && (!pose_idx || !pose_keep)) ||
+        (n_halo > 0 && (!halo_idx || !halo_mine)))
+      throw g2ohip::ArgFailure("g2ohip_exchange_setup: null array");
+    s->impl->exchange_setup(n_blocks, block_idx, block_keep, n_poses, pose_idx, pose_keep, n_halo, halo_idx, halo_mine);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_exchange_pack(g2ohip_solver* s, int which) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->exchange_pack(which);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_exchange_unpack(g2ohip_solver* s, int which) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->exchange_unpack(which);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_exchange_status(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] { return s->impl->exchange_status() ? G2OHIP_NOT_PD : G2OHIP_OK; });
+}
 int g2ohip_get_partition(g2ohip_solver* s, int32_t* pose_owner, int32_t* block_consumer) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

@@ -164,6 +164,7 @@ class SparseCholesky {
   void set_virtual_blocks(const VirtualBlocks& vb, hipStream_t st);
   bool has_virtual_blocks() const { return d_asm_v.p != nullptr; }
   void set_virtual_split(bool split) { plan_.vsplit = split ? 1 : 0; }
+  const int* status_device() const { return d_status.p; }   // 0 ok, 1 non-positive pivot, 2 dependency wait gave up
   bool failed(hipStream_t st);
   // true once after failed() saw a dependency-driven launch give up waiting; those launches are off from then on
   // (the caller drops its captured graphs and repeats the solve)

@@ -371,8 +371,41 @@ class ShardedBlockSolver:
     def restoreDiagonal(self):
         return self.local.restoreDiagonal()
 
+    def _native_exchange(self):
+        """Pack / unpack kernels and device-side status inside libg2ohip (g2ohip_exchange_*): no torch ops and a single
+        synchronisation per solve.  Falls back to the torch formulation for stand-in locals (CPU tests)."""
+        if getattr(self, "_native", None) is None:
+            self._native = False
+            if hasattr(self.local, "exchangeSetup") and self.x_exchange == "halo":
+                from . import capi
+                keep = lambda o: ((o == self.rank) | (o < 0)).astype(np.float64)
+                self.local.exchangeSetup(self.boundary, keep(self.consumer[self.boundary]), self.bposes,
+                                         keep(self.pose_owner[self.bposes]), self.halo,
+                                         (self.pose_owner[self.halo] == self.rank).astype(np.float64))
+                self._nbuf1 = self._device_tensor(capi.ARR_XBOUNDARY)
+                self._nbuf3 = self._device_tensor(capi.ARR_XHALO)
+                self._nxbuf = self._device_tensor(capi.ARR_EXCHANGE)
+                self._native = True
+        return self._native
+
     def _solve_subtree_halo(self):
         """Three latency-sized collectives: boundary Hschur blocks + boundary b_p | subtree roots | halo x_p + status."""
+        if self._native_exchange():
+            L = self.local
+            L.solveSchur()
+            if len(self.boundary) or len(self.bposes):
+                L.exchangePack(1)
+                self.comm.all_reduce_sum([self._nbuf1])
+                L.exchangeUnpack(1)
+            L.solveReducedLocal()
+            self.comm.all_reduce_sum([self._nxbuf])
+            L.solveReducedShared()
+            L.solveReducedFinishAsync()
+            L.exchangePack(3)
+            self.comm.all_reduce_sum([self._nbuf3])
+            L.exchangeUnpack(3)
+            L.solveBackSubstitute()           # (harmless after a failed factorisation: the caller discards x)
+            return L.exchangeStatus()
         import torch
         t = self._subtree_tensors()
         p = self.p
