@@ -158,6 +158,13 @@ int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out);
 int g2ohip_kernel_slots(void);
 const char* g2ohip_kernel_name(int slot);
 int g2ohip_kernel_time(g2ohip_solver* s, int slot, double* total_seconds, long* launches, int reset);
+/* One Levenberg-Marquardt trial with a single host synchronisation (optimization_algorithm_levenberg.cpp:96-128 asks for
+ * the solve status, the new chi2 and computeScale one after the other): g2ohip_solve_async queues g2ohip_solve and
+ * leaves its status on the device; after the caller has updated the estimates and re-evaluated the errors,
+ * g2ohip_trial_stats returns that status (solve_ok 1/0), activeRobustChi2 and computeScale(lambda) = x'(lambda x + b)
+ * together.  Without a pending g2ohip_solve_async it just evaluates the two sums. */
+int g2ohip_solve_async(g2ohip_solver* s);
+int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* chi2, double* scale);
 /* Options (name, value).  Linear solver of the reduced system: "linear_solver" 0 = multifrontal block Cholesky
  * (replaces LinearSolverCSparse / LinearSolverCholmod), 1 = block-Jacobi preconditioned CG (replaces
  * LinearSolverPCG, g2o/solvers/pcg/linear_solver_pcg.hpp:79-196) with "pcg_tolerance" (1e-6),

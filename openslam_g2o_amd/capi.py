@@ -51,7 +51,7 @@ EXPORTS = [
     "g2ohip_set_lambda_split", "g2ohip_ba_set_edges", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
     "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
-    "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
+    "g2ohip_solve_async", "g2ohip_trial_stats", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
     "g2ohip_get_partition", "g2ohip_partition_poses",
     "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
@@ -105,9 +105,10 @@ def load():
     L.g2ohip_partition_poses.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p]
     for n in ("g2ohip_solve", "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute",
               "g2ohip_sync", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared",
-              "g2ohip_solve_reduced_finish", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_status"):
+              "g2ohip_solve_reduced_finish", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_status", "g2ohip_solve_async"):
         getattr(L, n).argtypes = [vp]
     L.g2ohip_exchange_setup.argtypes = [vp, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_dbl_p]
+    L.g2ohip_trial_stats.argtypes = [vp, C.c_double, c_int_p, c_dbl_p, c_dbl_p]
     L.g2ohip_exchange_pack.argtypes = [vp, C.c_int]
     L.g2ohip_exchange_unpack.argtypes = [vp, C.c_int]
     L.g2ohip_vector_size.argtypes = [vp]
@@ -322,6 +323,15 @@ class HipBlockSolver:
 
     def solveReducedFinish(self):
         return _check(self.L.g2ohip_solve_reduced_finish(self.h), "solveReducedFinish") == OK
+
+    def solveAsync(self):
+        _check(self.L.g2ohip_solve_async(self.h), "solveAsync")
+
+    def trialStats(self, lam):
+        """(solve status of a pending solveAsync, chi2, computeScale(lam)) behind one synchronisation."""
+        ok, chi, sc = C.c_int(1), C.c_double(0.0), C.c_double(0.0)
+        _check(self.L.g2ohip_trial_stats(self.h, float(lam), C.byref(ok), C.byref(chi), C.byref(sc)), "trialStats")
+        return bool(ok.value), chi.value, sc.value
 
     def solveReducedFinishAsync(self):
         _check(self.L.g2ohip_solve_reduced_finish_async(self.h), "solveReducedFinishAsync")

@@ -175,6 +175,11 @@ class BlockSolver {
  public:
   // Multi-GPU halo exchange without host round trips (openslam_g2o_amd/distributed.py): index lists and keep-masks
   // live on the device, pack / unpack are single kernels, the status travels inside the last buffer.
+  // LM trial without intermediate host round trips: solve_async() queues the whole solve and leaves the status on the
+  // device; trial_stats() (after the caller's update / error evaluation) returns that status together with chi2 and
+  // computeScale(lambda) = x'(lambda x + b) behind ONE synchronisation
+  void solve_async();
+  void trial_stats(double lambda, int* ok, double* chi2, double* scale);
   void exchange_setup(int nbb, const int* bblock, const double* hkeep, int nbp, const int* bpose, const double* bkeep, int nh,
                       const int* halo, const double* hmine);
   void exchange_pack(int which);     // 1: boundary Hschur blocks + boundary bschur -> buffer 105; 3: halo x (masked) + status -> 106
@@ -201,6 +206,9 @@ class BlockSolver {
   bool hschur_valid_ = true, virt_now_ = false;
   hipStream_t side_ = nullptr;
   hipEvent_t side_fork_ = nullptr, side_join_ = nullptr;
+  DevBuf<double> d_red_multi;              // trial_stats: partial sums of every reduction of the call
+  int sync_status_ = -1;                   // status of a solve_async() that had to run synchronously (-1: none)
+  bool deferred_status_ = false;           // a solve_async() whose status has not been read yet
   bool chi2_valid_ = false;                // chi2_value_ matches the errors / kernels of every edge set
   double chi2_value_ = 0.0;
   DevBuf<double> d_Hpp, d_Hpl, d_Hll, d_Hschur, d_Dinv, d_db, d_b, d_x, d_bschur, d_bkP, d_bkL, d_red;

@@ -2679,6 +2679,89 @@ int BlockSolver::solve() {
   return 0;
 }
 
+void BlockSolver::solve_async() {
+  if (!system_built_) throw StateFailure("solve before build_system");
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (linear_solver != 0) {   // (the iterative solver synchronises anyway: keep its status for trial_stats)
+    sync_status_ = solve();
+    return;
+  }
+  const bool virt = virtual_reduced_ok();
+  if (virt != virt_now_) invalidate_graphs();
+  virt_now_ = virt;
+  if (schur_) solve_schur_impl(!virt);
+  solve_reduced_device();
+  if (schur_) solve_back_substitute_impl();
+  deferred_status_ = true;
+}
+
+void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* scale_out) {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  constexpr int kMaxBlocks = 1024;
+  const size_t nsets = sets_.size();
+  if (d_red_multi.n < (nsets + 1) * kMaxBlocks) d_red_multi.alloc((nsets + 1) * kMaxBlocks);
+  std::vector<int> nblk(nsets + 1, 0);
+  // slot 0: computeScale (optimization_algorithm_levenberg.cpp:165-172)
+  nblk[0] = std::min(kMaxBlocks, grid_for(vector_size()));
+  hipLaunchKernelGGL(scale_partial_kernel, dim3(nblk[0]), dim3(kThreads), 0, st_, vector_size(), d_x.p, d_b.p, lambda, d_red_multi.p);
+  // slots 1..: chi2 of every edge set (same kernels as chi2())
+  const bool need_chi = !chi2_valid_;
+  for (size_t k = 0; k < nsets && need_chi; ++k) {
+    EdgeSet& es = *sets_[k];
+    if (es.n == 0) continue;
+    if (!es.has_err) throw StateFailure("trial_stats: edge data missing");
+    nblk[k + 1] = std::min(kMaxBlocks, grid_for(es.n));
+    double* red = d_red_multi.p + (k + 1) * kMaxBlocks;
+#define G2OHIP_CHI(d_)                                                                                                      \
+  case d_:                                                                                                                  \
+    hipLaunchKernelGGL((chi2_kernel<d_>), dim3(nblk[k + 1]), dim3(kThreads), 0, st_, es.n, es.omega, es.err, es.kernel_kind, es.delta, red); \
+    break
+    switch (es.d) {
+      G2OHIP_CHI(1);
+      G2OHIP_CHI(2);
+      G2OHIP_CHI(3);
+      G2OHIP_CHI(6);
+      G2OHIP_CHI(7);
+      default:
+        throw ArgFailure("chi2: unsupported error dimension");
+    }
+#undef G2OHIP_CHI
+  }
+  G2OHIP_HIP_CHECK(hipGetLastError());
+  std::vector<double> h((nsets + 1) * kMaxBlocks);
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(h.data(), d_red_multi.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+  bool bad = false;
+  if (sync_status_ >= 0) {
+    bad = sync_status_ != 0;
+    sync_status_ = -1;
+    G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+  } else if (deferred_status_) {
+    bad = chol_->failed(st_);   // synchronises (covers the copy above: same stream)
+    deferred_status_ = false;
+    if (bad && chol_->dependency_stall()) invalidate_graphs();   // reported failed; the next solve runs level by level
+  } else {
+    G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+  }
+  auto sum = [&](size_t slot) {
+    double s = 0.0;
+    for (int i = 0; i < nblk[slot]; ++i) s += h[slot * kMaxBlocks + i];   // fixed order: deterministic
+    return s;
+  };
+  *scale_out = sum(0);
+  if (need_chi) {
+    double total = 0.0;
+    for (size_t k = 0; k < nsets; ++k) total += sum(k + 1);
+    chi2_value_ = total;
+    chi2_valid_ = true;
+    for (auto& esp : sets_)
+      if (esp->external) chi2_valid_ = false;
+  }
+  *chi2_out = chi2_value_;
+  *ok = bad ? 0 : 1;
+}
+
 void BlockSolver::multiply_hessian(double* dest_host, const double* src_host) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));

@@ -234,6 +234,21 @@ int g2ohip_solve_reduced_finish(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] { return s->impl->solve_reduced_finish() ? G2OHIP_NOT_PD : G2OHIP_OK; });
 }
+int g2ohip_solve_async(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->solve_async();
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* chi2, double* scale) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    if (!solve_ok || !chi2 || !scale) throw g2ohip::ArgFailure("g2ohip_trial_stats: null output");
+    s->impl->trial_stats(lambda, solve_ok, chi2, scale);
+    return G2OHIP_OK;
+  });
+}
 int g2ohip_solve_reduced_finish_async(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

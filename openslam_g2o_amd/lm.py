@@ -44,18 +44,29 @@ def levenberg_solve_iteration(graph, solver, st, iteration):
         st.ni = 2.0
     rho = 0.0
     qmax = 0
+    # device-resident graph + HIP solver: the trial's three host round trips (solve status, chi2, computeScale) collapse
+    # into one (g2ohip_solve_async / g2ohip_trial_stats); same values, same decisions
+    fused = getattr(graph, "device_resident", False) and hasattr(solver, "solveAsync") and hasattr(solver, "trialStats")
     while True:
         graph.push()
         solver.setLambda(st.current_lambda, True)
-        ok2 = solver.solve()
-        graph.update()
-        solver.restoreDiagonal()
-        graph.compute_active_errors()
-        temp_chi = graph.chi2()
+        if fused:
+            solver.solveAsync()
+            graph.update()
+            solver.restoreDiagonal()
+            graph.compute_active_errors()
+            ok2, temp_chi, sc = solver.trialStats(st.current_lambda)
+        else:
+            ok2 = solver.solve()
+            graph.update()
+            solver.restoreDiagonal()
+            graph.compute_active_errors()
+            temp_chi = graph.chi2()
+            sc = solver.computeScale(st.current_lambda) if ok2 else 0.0
         if not ok2:
             temp_chi = DBL_MAX
         rho = current_chi - temp_chi
-        scale = (solver.computeScale(st.current_lambda) if ok2 else 0.0) + 1e-3   # computeScale :165-172
+        scale = (sc if ok2 else 0.0) + 1e-3             # computeScale :165-172
         rho /= scale
         if rho > 0 and math.isfinite(temp_chi):         # last step was good
             alpha = 1.0 - (2.0 * rho - 1.0) ** 3
@@ -210,6 +221,8 @@ def optimize(graph, solver, iterations, algorithm="lm", **lm_args):
 class DeviceBAGraph:
     """The graph protocol over HipBlockSolver's device-resident BA front end."""
 
+    device_resident = True
+
     def __init__(self, solver):
         self.s = solver
 
@@ -252,6 +265,8 @@ def setup_device_ba(prob, huber_delta=0.0, device=0):
 
 class DevicePoseGraph:
     """The graph protocol over HipBlockSolver's device-resident pose-graph front end (EdgeSE2 / EdgeSE3)."""
+
+    device_resident = True
 
     def __init__(self, solver):
         self.s = solver
