@@ -415,6 +415,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "max_sn_scalars")) s->impl->chol_opt.max_sn_scalars = (int)value;
   else if (!std::strcmp(name, "max_sn_scalars_lds")) s->impl->chol_opt.max_sn_scalars_lds = (int)value;
   else if (!std::strcmp(name, "lds_front_bytes")) s->impl->chol_opt.lds_front_bytes = (size_t)value;
+  else if (!std::strcmp(name, "lds_budget_bytes")) s->impl->chol_opt.lds_budget_bytes = (size_t)value;
   else if (!std::strcmp(name, "relax_zeros")) s->impl->chol_opt.relax_zeros = value;
   else if (!std::strcmp(name, "relax_front_bytes")) s->impl->chol_opt.relax_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "fuse_chains")) s->impl->chol_opt.fuse_chains = value != 0;
@@ -682,6 +683,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "max_sn_scalars")) ls->opt.max_sn_scalars = (int)value;
   else if (!std::strcmp(name, "max_sn_scalars_lds")) ls->opt.max_sn_scalars_lds = (int)value;
   else if (!std::strcmp(name, "lds_front_bytes")) ls->opt.lds_front_bytes = (size_t)value;
+  else if (!std::strcmp(name, "lds_budget_bytes")) ls->opt.lds_budget_bytes = (size_t)value;
   else if (!std::strcmp(name, "relax_zeros")) ls->opt.relax_zeros = value;
   else if (!std::strcmp(name, "relax_front_bytes")) ls->opt.relax_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "fuse_chains")) ls->opt.fuse_chains = value != 0;

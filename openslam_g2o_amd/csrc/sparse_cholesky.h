@@ -30,7 +30,8 @@ struct CholOptions {
   int max_sn_scalars = 48;   // supernode (pivot panel) width cap, scalars
   int max_sn_scalars_lds = 24;  // ... for the fronts small enough for LDS
   double relax_zeros = 0.25; // relaxed amalgamation: tolerated share of explicit zero blocks in a panel
-  size_t lds_front_bytes = 64 * 1024;  // fronts up to this size are factorised in LDS
+  size_t lds_front_bytes = 256 * 1024;  // fronts up to this DENSE size (m*m*8) are candidates for LDS (stored packed: half) ...
+  size_t lds_budget_bytes = 150 * 1024; // ... if blocks + vectors + index tables fit this per-workgroup LDS budget
   bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task
   int rank = 0, world = 1;   // multi-GPU: this rank factorises its own subtrees + (redundantly) the shared top of the tree
   int dep_levels = 16;                   // > 1: up to this many consecutive task levels share ONE launch; a parent task waits for its

@@ -483,7 +483,22 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   // factorises the child carries the update matrix to the parent in registers.  Both fronts must be
   // LDS-resident and the carried matrix must fit kChainU doubles per thread.
   auto front_dim = [&](int f) { return (size_t)(S.f_ns[f] + S.f_nb[f]) * bs; };
-  auto is_lds = [&](int f) { return front_dim(f) * front_dim(f) * 8 <= opt.lds_front_bytes; };
+  // LDS-resident iff the dense size is within the class limit AND everything the factor kernel keeps in LDS for this
+  // front (packed blocks, rhs vectors, mailboxes, index tables) fits the per-workgroup budget
+  auto lds_need = [&](int f) {
+    const long long nbt = S.f_ns[f] + S.f_nb[f], mm = nbt * bs;
+    const long long T_ = (bs % 3 == 0) ? 3 : bs;
+    const long long nt0 = (nbt - 1) * bs / T_;
+    long long ints = (2 + kVirtInts) * (long long)(S.asm_off[f + 1] - S.asm_off[f]) + std::max(nt0 * (nt0 + 1) / 2, (long long)S.f_nb[f] * (S.f_nb[f] + 1) / 2) + 4;
+    for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) {
+      const long long nbc = S.f_nb[S.children[ch]];
+      ints += nbc * (nbc + 1) / 2 + nbc;
+    }
+    return 8 * (nbt * (nbt + 1) / 2 * bs * bs + 2 * mm + 2 * (bs * bs + bs)) + 4 * ints;
+  };
+  auto is_lds = [&](int f) {
+    return front_dim(f) * front_dim(f) * 8 <= opt.lds_front_bytes && lds_need(f) <= (long long)opt.lds_budget_bytes;
+  };
   std::vector<int> chain_next(nf, -1), has_prev(nf, 0);
   if (opt.fuse_chains)
     for (int f = 0; f < nf; ++f) {
