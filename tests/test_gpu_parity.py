@@ -504,3 +504,14 @@ def test_linear_solver_large_fronts_all_block_sizes(bs, passes):
     assert relerr(x, xr) < 1e-10
     ok, _ = ls.solve(cp, row, -vals, b)
     assert not ok
+
+
+def test_dependency_driven_launches_soak():
+    """Random problem sizes / leaf sizes through the dependency-driven launches (tools/probe/soak_dep.py, short form):
+    bit-identical factorisation against one launch per level, repeatable across solves."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probe", "soak_dep.py")
+    out = subprocess.run([sys.executable, tool, "3", "24"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "problems 24 bad 0" in out.stdout, out.stdout[-2000:]
