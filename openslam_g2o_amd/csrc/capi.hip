@@ -424,6 +424,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "dep_delay")) s->impl->chol_opt.dep_delay = (int)value;
   else if (!std::strcmp(name, "dep_backward")) s->impl->chol_opt.dep_backward = (int)value;
   else if (!std::strcmp(name, "big_front_passes")) s->impl->chol_opt.big_front_passes = (int)value;
+  else if (!std::strcmp(name, "wide_front_doubles")) s->impl->chol_opt.wide_front_doubles = (int)value;
   else if (!std::strcmp(name, "big_front_min_dim")) s->impl->chol_opt.big_front_min_dim = (int)value;
   else if (!std::strcmp(name, "dep_spin_limit")) s->impl->chol_opt.dep_spin_limit = (int)value;
   else if (!std::strcmp(name, "wave_front_bytes")) s->impl->chol_opt.wave_front_bytes = (size_t)value;
@@ -692,6 +693,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "dep_delay")) ls->opt.dep_delay = (int)value;
   else if (!std::strcmp(name, "dep_backward")) ls->opt.dep_backward = (int)value;
   else if (!std::strcmp(name, "big_front_passes")) ls->opt.big_front_passes = (int)value;
+  else if (!std::strcmp(name, "wide_front_doubles")) ls->opt.wide_front_doubles = (int)value;
   else if (!std::strcmp(name, "big_front_min_dim")) ls->opt.big_front_min_dim = (int)value;
   else if (!std::strcmp(name, "dep_spin_limit")) ls->opt.dep_spin_limit = (int)value;
   else if (!std::strcmp(name, "wave_front_bytes")) ls->opt.wave_front_bytes = (size_t)value;

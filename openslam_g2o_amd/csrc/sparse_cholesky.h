@@ -38,6 +38,7 @@ struct CholOptions {
                                          // children through device-scope counters instead of the launch boundary
   int dep_spin_limit = 1 << 21;          // polls (~0.2 us each) before a waiting workgroup gives up and flags status 2
   int big_front_min_dim = 180;           // ... for the launches whose largest front has at least this many rows
+  int wide_front_doubles = 5000;         // launches whose largest LDS front has this many packed doubles (100 rows) use 512 threads per front
   int big_front_passes = 1;              // scratch-slab (large) fronts: whole-GPU passes instead of one workgroup per front
   int dep_backward = 1;                  // the backward sweep uses the same dependency-driven groups (parents first)
   int dep_delay = 0;                     // launch-order distance between a task and its parent inside a wide dependency-driven launch

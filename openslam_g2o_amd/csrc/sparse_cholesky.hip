@@ -1119,7 +1119,7 @@ template <int BS, bool USE_LDS, int NTC = (USE_LDS ? kFactorThreads : kFactorThr
 #ifndef G2OHIP_OCC128
 #define G2OHIP_OCC128 3
 #endif
-__global__ void __launch_bounds__(NTC, USE_LDS ? (NTC == 128 ? G2OHIP_OCC128 : G2OHIP_OCC256) : 1) front_factor_kernel(
+__global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G2OHIP_OCC128 : G2OHIP_OCC256) : 1) front_factor_kernel(
     CholPlanDev P, int slot0, const double* __restrict__ A, double* __restrict__ scratch,
     const long long* __restrict__ scratch_off, int idx_off_doubles, int wcap, const double* __restrict__ bperm,
     double* __restrict__ yout, int dep) {
@@ -2303,7 +2303,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
                          int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, int wcap,
                          const double* bperm, double* yout, int dep, const int4* big_tiles, int bt_count, const BigLaunch& big,
-                         hipStream_t st) {
+                         int wide_doubles, hipStream_t st) {
   if (sm_count > 0) {   // wide launch: two waves per front
     const int idx_off = sm_max_m + 2 * wcap + 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(sm_idx_ints + 4) * sizeof(int);
@@ -2315,8 +2315,13 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
   if (lds_count > 0) {
     const int idx_off = lds_max_m + 2 * wcap + 2 * (BS * BS + BS);   // F (packed doubles) | tv | wprev | mailboxes | index lists
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(lds_idx_ints + 4) * sizeof(int);
-    hipLaunchKernelGGL((front_factor_kernel<BS, true, kFactorThreads, VIRT>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
-                       d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
+    // fronts of a hundred rows and more (pose graphs; they keep a CU to themselves anyway): eight waves per front
+    if (lds_max_m >= wide_doubles)
+      hipLaunchKernelGGL((front_factor_kernel<BS, true, 512, VIRT>), dim3(lds_count), dim3(512), sh, st, P, lds_begin, dA, d_scratch,
+                         d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
+    else
+      hipLaunchKernelGGL((front_factor_kernel<BS, true, kFactorThreads, VIRT>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
+                         d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
   }
   if (glb_count > 0 && big.ok) {   // large fronts as whole-GPU passes
     G2OHIP_HIP_CHECK(hipMemsetAsync(d_scratch, 0, (size_t)big.scratch * sizeof(double), st));
@@ -2393,7 +2398,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   launch_factor_level<BS_, V_>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m, \
                                LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m,            \
                                LL.sm_idx_ints, LL.max_m, fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr,   \
-                               dep ? 1 : 0, d_big_tiles.p + LL.bt_begin, LL.bt_count, big, st)
+                               dep ? 1 : 0, d_big_tiles.p + LL.bt_begin, LL.bt_count, big, opt.wide_front_doubles, st)
   switch (bs_) {
     case 3:
       if (virt) G2OHIP_FACTOR_LEVEL(3, true); else G2OHIP_FACTOR_LEVEL(3, false);
@@ -2421,6 +2426,12 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true, kFactorThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, kFactorThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
