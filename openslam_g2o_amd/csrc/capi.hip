@@ -419,6 +419,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "relax_zeros")) s->impl->chol_opt.relax_zeros = value;
   else if (!std::strcmp(name, "relax_front_bytes")) s->impl->chol_opt.relax_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "fuse_chains")) s->impl->chol_opt.fuse_chains = value != 0;
+  else if (!std::strcmp(name, "max_chain_fronts")) s->impl->chol_opt.max_chain_fronts = (int)value;
   else if (!std::strcmp(name, "wave_front_tasks")) s->impl->chol_opt.wave_front_tasks = (int)value;
   else if (!std::strcmp(name, "dep_levels")) s->impl->chol_opt.dep_levels = (int)value;
   else if (!std::strcmp(name, "dep_delay")) s->impl->chol_opt.dep_delay = (int)value;
@@ -688,6 +689,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "relax_zeros")) ls->opt.relax_zeros = value;
   else if (!std::strcmp(name, "relax_front_bytes")) ls->opt.relax_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "fuse_chains")) ls->opt.fuse_chains = value != 0;
+  else if (!std::strcmp(name, "max_chain_fronts")) ls->opt.max_chain_fronts = (int)value;
   else if (!std::strcmp(name, "wave_front_tasks")) ls->opt.wave_front_tasks = (int)value;
   else if (!std::strcmp(name, "dep_levels")) ls->opt.dep_levels = (int)value;
   else if (!std::strcmp(name, "dep_delay")) ls->opt.dep_delay = (int)value;

@@ -33,6 +33,7 @@ struct CholOptions {
   size_t lds_front_bytes = 256 * 1024;  // fronts up to this DENSE size (m*m*8) are candidates for LDS (stored packed: half) ...
   size_t lds_budget_bytes = 150 * 1024; // ... if blocks + vectors + index tables fit this per-workgroup LDS budget
   bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task
+  int max_chain_fronts = 0;  // > 0: chains longer than this are cut into equal segments
   int rank = 0, world = 1;   // multi-GPU: this rank factorises its own subtrees + (redundantly) the shared top of the tree
   int dep_levels = 16;                   // > 1: up to this many consecutive task levels share ONE launch; a parent task waits for its
                                          // children through device-scope counters instead of the launch boundary

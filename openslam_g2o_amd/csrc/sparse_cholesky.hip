@@ -509,6 +509,27 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       chain_next[f] = p;
       has_prev[p] = 1;
     }
+  if (opt.max_chain_fronts > 0) {
+    // Long chains are cut into segments of about equal length (a finer work granularity than whole leaf subtrees for
+    // the dependency-driven launch; the update matrix then crosses the cut through HBM instead of registers).
+    for (int f = 0; f < nf; ++f) {
+      if (has_prev[f] || chain_next[f] < 0) continue;   // chain heads only
+      int len = 0;
+      for (int g = f; g >= 0; g = chain_next[g]) ++len;
+      const int nseg = (len + opt.max_chain_fronts - 1) / opt.max_chain_fronts;
+      if (nseg <= 1) continue;
+      const int seg = (len + nseg - 1) / nseg;
+      int k = 0;
+      for (int g = f; g >= 0;) {
+        const int nx = chain_next[g];
+        if (++k % seg == 0 && nx >= 0) {
+          chain_next[g] = -1;
+          has_prev[nx] = 0;
+        }
+        g = nx;
+      }
+    }
+  }
   S.task_ptr.assign(1, 0);
   S.task_fronts.clear();
   std::vector<int> task_of(nf, -1), task_level;
