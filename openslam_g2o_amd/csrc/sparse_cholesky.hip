@@ -1861,10 +1861,23 @@ __global__ void __launch_bounds__(256) big_extend_add_kernel(CholPlanDev P, cons
   const ChildDesc cd = P.cdesc[rec.child_off + ck.y];
   const double* Uc = P.U + cd.U_off;
   const int* cmap = P.cmap + rec.cmap_off + cd.cmap_start;
-  for (int t = threadIdx.x; t < ck.w * BB; t += 256) {
-    const int blk = ck.z + t / BB, e = t % BB;
-    const int d = cmap[blk];
-    F[(size_t)((d & 0xffff) * BS + e % BS) + (size_t)m * ((d >> 16) * BS + e / BS)] += Uc[(size_t)blk * BB + e];
+  const int n = ck.w * BB;
+  for (int base = threadIdx.x; base < n; base += 3 * 256) {   // three elements per thread in flight
+    double v[3], cur[3];
+    size_t dst[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int t = min(base + u * 256, n - 1);
+      const int blk = ck.z + t / BB, e = t % BB;
+      const int d = cmap[blk];
+      dst[u] = (size_t)((d & 0xffff) * BS + e % BS) + (size_t)m * ((d >> 16) * BS + e / BS);
+      v[u] = Uc[(size_t)blk * BB + e];
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) cur[u] = F[dst[u]];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (base + u * 256 < n) F[dst[u]] = cur[u] + v[u];
   }
 }
 
@@ -2235,7 +2248,26 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int 
       const int k = tid % npiv, part = tid / npiv;
       double s = 0.0;
       if (part < parts && NT >= npiv)
-        for (int i = npiv + part; i < m; i += parts) s += Lx[i + (size_t)m * k] * t[i];
+      {
+        if (PANEL_LDS) {
+          for (int i = npiv + part; i < m; i += parts) s += Lx[i + (size_t)m * k] * t[i];
+        } else {
+          // panel in HBM (large fronts): eight loads in flight per thread instead of one latency per term
+          const double* Lk = Lx + (size_t)m * k;
+          double s0 = 0.0, s1 = 0.0;
+          for (int i0 = npiv + part; i0 < m; i0 += 8 * parts) {
+            double lv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lv[u] = Lk[min(i0 + u * parts, m - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+              s0 += lv[u] * (i0 + u * parts < m ? t[i0 + u * parts] : 0.0);
+              s1 += lv[u + 1] * (i0 + (u + 1) * parts < m ? t[i0 + (u + 1) * parts] : 0.0);
+            }
+          }
+          s = s0 + s1;
+        }
+      }
       if (NT < npiv) {
         // fewer threads than pivot columns: loop over the columns serially
         for (int kk = tid; kk < npiv; kk += NT) {
