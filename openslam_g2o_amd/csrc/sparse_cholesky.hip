@@ -2034,19 +2034,27 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
     Lr[q] = F + npiv + min(r0 + 16 * q + lr, mt - 1);
     Lc[q] = F + npiv + min(c0 + 16 * q + lr, mt - 1);
   }
-  for (int k0 = 0; k0 < npiv; k0 += 4) {
-    const int k = min(k0 + lk, npiv - 1);
-    const double keep = (k0 + lk < npiv) ? 1.0 : 0.0;
-    double rv[2], cv[2];
+  // KS k-steps of operands are requested together (a step per round trip would make the kernel a chain of L2 latencies)
+  constexpr int KS = 6;
+  for (int k00 = 0; k00 < npiv; k00 += 4 * KS) {
+    double rv[KS][2], cv[KS][2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      rv[q] = Lr[q][(size_t)m * k] * keep;
-      cv[q] = Lc[q][(size_t)m * k];
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const int k0 = k00 + 4 * s_;
+      const int k = min(k0 + lk, npiv - 1);
+      const double keep = (k0 + lk < npiv) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        rv[s_][q] = Lr[q][(size_t)m * k] * keep;
+        cv[s_][q] = Lc[q][(size_t)m * k];
+      }
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int s_ = 0; s_ < KS; ++s_)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[b], rv[a], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[s_][b], rv[s_][a], acc[a][b], 0, 0, 0);
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
