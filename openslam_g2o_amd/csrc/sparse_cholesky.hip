@@ -1826,26 +1826,42 @@ __global__ void __launch_bounds__(256) big_assemble_kernel(CholPlanDev P, const 
   double* F = scratch + scratch_off[ck.x];
   const double lam0 = VIRT ? P.vlam[0] : 0.0;
   const bool vsplit = VIRT && P.vsplit != 0;
-  for (int t = threadIdx.x; t < ck.z * BB; t += 256) {
-    const int e = rec.asm_off + ck.y + t / BB, rc = t % BB;
-    const int r = rc % BS, c = rc / BS;
-    const int q = (VIRT ? P.asm_vq : P.asm_q)[e], pos = (VIRT ? P.asm_vpos : P.asm_pos)[e];
-    const int lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff, tr = (pos >> 30) & 1;
-    const int rr = tr ? c : r, cc = tr ? r : c;   // element of the stored (upper) block
-    double v;
-    if constexpr (VIRT) {   // base (+ lambda) - partial blocks in list order (see front_factor_kernel)
-      const int rp = (vsplit && rr >= HB) ? 1 : 0, nrp = vsplit ? HB : BS;
-      const int pe = rp * (nrp * BS) + (rr - rp * nrp) + nrp * cc;
-      const int* sv = P.asm_v + (size_t)kVirtInts * e;
-      const int n = sv[0];
-      v = q >= 0 ? P.vbase[(size_t)q * BB + rr + BS * cc] : 0.0;
-      if (pos < 0 && rr == cc) v += lam0;
-      for (int k = 0; k < n && k < 3; ++k) v -= P.vparts[(size_t)sv[1 + k] * BB + pe];
-      for (int k = sv[4] + 3; k < sv[4] + n; ++k) v -= P.vparts[(size_t)P.vslots[k] * BB + pe];
-    } else {
-      v = A[(size_t)q * BB + rr + BS * cc];
+  const int nel = ck.z * BB;
+  for (int base = threadIdx.x; base < nel; base += 4 * 256) {   // four elements per thread: index loads, then value loads, together
+    int q[4], pos[4], ee[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = min(base + u * 256, nel - 1);
+      ee[u] = rec.asm_off + ck.y + t / BB;
+      q[u] = (VIRT ? P.asm_vq : P.asm_q)[ee[u]];
+      pos[u] = (VIRT ? P.asm_vpos : P.asm_pos)[ee[u]];
     }
-    F[(size_t)(lr * BS + r) + (size_t)m * (lc * BS + c)] = v;
+    double v[4];
+    size_t dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = min(base + u * 256, nel - 1);
+      const int rc = t % BB, r = rc % BS, c = rc / BS;
+      const int lr = pos[u] & 0x7fff, lc = (pos[u] >> 15) & 0x7fff, tr = (pos[u] >> 30) & 1;
+      const int rr = tr ? c : r, cc = tr ? r : c;   // element of the stored (upper) block
+      if constexpr (VIRT) {   // base (+ lambda) - partial blocks in list order (see front_factor_kernel)
+        const int rp = (vsplit && rr >= HB) ? 1 : 0, nrp = vsplit ? HB : BS;
+        const int pe = rp * (nrp * BS) + (rr - rp * nrp) + nrp * cc;
+        const int* sv = P.asm_v + (size_t)kVirtInts * ee[u];
+        const int n = sv[0];
+        double x = q[u] >= 0 ? P.vbase[(size_t)q[u] * BB + rr + BS * cc] : 0.0;
+        if (pos[u] < 0 && rr == cc) x += lam0;
+        for (int k = 0; k < n && k < 3; ++k) x -= P.vparts[(size_t)sv[1 + k] * BB + pe];
+        for (int k = sv[4] + 3; k < sv[4] + n; ++k) x -= P.vparts[(size_t)P.vslots[k] * BB + pe];
+        v[u] = x;
+      } else {
+        v[u] = A[(size_t)q[u] * BB + rr + BS * cc];
+      }
+      dst[u] = (size_t)(lr * BS + r) + (size_t)m * (lc * BS + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (base + u * 256 < nel) F[dst[u]] = v[u];
   }
 }
 
