@@ -2173,6 +2173,18 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, int s
     for (int kb = 0; kb < ns; ++kb) {
       const int k0 = kb * BS;
       double yv[BS];
+      // panel in HBM (large fronts): the L values of this thread's first rows do not depend on y -- they are requested
+      // together with the diagonal block (one round trip per pivot block instead of two)
+      constexpr int RU = 4;
+      double lv[RU][BS];
+      if (!PANEL_LDS) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const int i = min(k0 + BS + tid + u * NT, m - 1);
+#pragma unroll
+          for (int q = 0; q < BS; ++q) lv[u][q] = Lx[i + (size_t)m * (k0 + q)];
+        }
+      }
 #pragma unroll
       for (int c = 0; c < BS; ++c) {
         double v = t[k0 + c];
@@ -2184,7 +2196,19 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, int s
 #pragma unroll
         for (int c = 0; c < BS; ++c) ys[k0 + c] = yv[c];
       }
-      for (int i = k0 + BS + tid; i < m; i += NT) {
+      if (!PANEL_LDS) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const int i = k0 + BS + tid + u * NT;
+          if (i < m) {
+            double v = t[i];
+#pragma unroll
+            for (int q = 0; q < BS; ++q) v -= lv[u][q] * yv[q];
+            t[i] = v;
+          }
+        }
+      }
+      for (int i = k0 + BS + tid + (PANEL_LDS ? 0 : RU * NT); i < m; i += NT) {
         double v = t[i];
 #pragma unroll
         for (int q = 0; q < BS; ++q) v -= Lx[i + (size_t)m * (k0 + q)] * yv[q];
