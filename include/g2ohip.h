@@ -36,6 +36,10 @@ extern "C" {
 
 #define G2OHIP_KERNEL_NONE 0
 #define G2OHIP_KERNEL_HUBER 1      /* RobustKernelHuber, g2o/core/robust_kernel_impl.cpp:65-78 */
+#define G2OHIP_KERNEL_PSEUDOHUBER 2 /* RobustKernelPseudoHuber :80-89 */
+#define G2OHIP_KERNEL_CAUCHY 3     /* RobustKernelCauchy :91-99 */
+#define G2OHIP_KERNEL_SATURATED 4  /* RobustKernelSaturated :101-113 */
+#define G2OHIP_KERNEL_DCS 5        /* RobustKernelDCS :116-126 (delta = phi) */
 
 /* which-matrix selectors for the inspection calls */
 #define G2OHIP_HPP 0

@@ -24,7 +24,7 @@ c_dbl_p = C.POINTER(C.c_double)
 OK, NOT_PD = 0, 1
 HPP, HPL, HLL, HSCHUR, DINV = 0, 1, 2, 3, 4
 ARR_BSCHUR, ARR_X, ARR_B, ARR_EXCHANGE, ARR_XP, ARR_XBOUNDARY, ARR_XHALO = 100, 101, 102, 103, 104, 105, 106
-KERNEL_NONE, KERNEL_HUBER = 0, 1
+KERNEL_NONE, KERNEL_HUBER, KERNEL_PSEUDOHUBER, KERNEL_CAUCHY, KERNEL_SATURATED, KERNEL_DCS = 0, 1, 2, 3, 4, 5
 
 
 class Stats(C.Structure):

@@ -48,6 +48,8 @@ class HipBlockSolver {
     return ok(g2ohip_set_edge_data(h_, set, J0, J1, omega, err, onDevice ? 1 : 0), "setEdgeData");
   }
   bool setRobustKernelHuber(int set, double delta) { return ok(g2ohip_set_robust_kernel(h_, set, G2OHIP_KERNEL_HUBER, delta), "setRobustKernel"); }
+  // any kernel of robust_kernel_impl.cpp: G2OHIP_KERNEL_{HUBER, PSEUDOHUBER, CAUCHY, SATURATED, DCS}
+  bool setRobustKernel(int set, int kind, double delta) { return ok(g2ohip_set_robust_kernel(h_, set, kind, delta), "setRobustKernel"); }
   // Solver::buildSystem(): afterwards b() holds -J' Omega e (block_solver.hpp:551-557)
   bool buildSystem() {
     if (!ok(g2ohip_build_system(h_), "buildSystem")) return false;

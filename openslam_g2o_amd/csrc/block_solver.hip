@@ -81,20 +81,38 @@ __device__ __forceinline__ int xcd_swizzle(int b, int nblocks) {
   return (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;
 }
 
-// rho'(e2) of the robust kernel (Huber: robust_kernel_impl.cpp:65-78); 1 without kernel
+// rho'(e2) and rho(e2) of the robust kernels of g2o/core/robust_kernel_impl.cpp (the weight base_binary_edge.hpp:92-112
+// puts on the information matrix, and the value activeRobustChi2 sums): 1 Huber (:65-78), 2 PseudoHuber (:80-89),
+// 3 Cauchy (:91-99), 4 Saturated (:101-113), 5 DCS (:116-126, delta is phi); 0 = none
 __device__ __forceinline__ double robust_weight(int kind, double delta, double e2) {
-  if (kind == 1) {
-    const double dsqr = delta * delta;
-    return (e2 <= dsqr) ? 1.0 : delta / sqrt(e2);
+  const double dsqr = delta * delta;
+  switch (kind) {
+    case 1: return (e2 <= dsqr) ? 1.0 : delta / sqrt(e2);
+    case 2: return 1.0 / sqrt(e2 / dsqr + 1.0);
+    case 3: return 1.0 / (e2 / dsqr + 1.0);
+    case 4: return (e2 <= dsqr) ? 1.0 : 0.0;
+    case 5: {
+      double sc = (2.0 * delta) / (delta + e2);
+      if (sc >= 1.0) sc = 1.0;
+      return sc * sc;
+    }
+    default: return 1.0;
   }
-  return 1.0;
 }
 __device__ __forceinline__ double robust_rho(int kind, double delta, double e2) {
-  if (kind == 1) {
-    const double dsqr = delta * delta;
-    return (e2 <= dsqr) ? e2 : 2.0 * sqrt(e2) * delta - dsqr;
+  const double dsqr = delta * delta;
+  switch (kind) {
+    case 1: return (e2 <= dsqr) ? e2 : 2.0 * sqrt(e2) * delta - dsqr;
+    case 2: return 2.0 * dsqr * (sqrt(e2 / dsqr + 1.0) - 1.0);
+    case 3: return dsqr * log(e2 / dsqr + 1.0);
+    case 4: return (e2 <= dsqr) ? e2 : dsqr;
+    case 5: {
+      double sc = (2.0 * delta) / (delta + e2);
+      if (sc >= 1.0) sc = 1.0;
+      return sc * e2 * sc;
+    }
+    default: return e2;
   }
-  return e2;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1976,7 +1994,8 @@ void BlockSolver::set_edge_data(int set, const double* J0, const double* J1, con
 void BlockSolver::set_robust_kernel(int set, int kind, double delta) {
   invalidate_graphs();
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
-  if (kind != 0 && kind != 1) throw ArgFailure("unsupported robust kernel");
+  if (kind < 0 || kind > 5) throw ArgFailure("unsupported robust kernel");
+  if (kind != 0 && !(delta > 0.0)) throw ArgFailure("robust kernel: delta must be positive");
   sets_[set]->kernel_kind = kind;
   sets_[set]->delta = delta;
 }

@@ -40,6 +40,7 @@ typedef struct {
   int *v0, *v1;                 /* hessian indices, -1 == fixed (or absent for unary) */
   const double *J0, *J1, *omega, *err;
   double huber_delta;           /* <= 0: no robust kernel */
+  int kernel_kind;              /* which robust kernel huber_delta parametrises (0/1: Huber; orc_set_robust_kernel) */
   long *o00, *o11, *o01;        /* offsets (in doubles) of the mapped blocks, -1 == none */
   char *k00, *k11, *k01;        /* 0 none, 1 Hpp, 2 Hll, 3 Hpl */
   char *tr01;                   /* edge writes the off-diagonal block transposed */
@@ -227,15 +228,36 @@ void orc_set_edge_data(Orc* s, int set, const double* J0, const double* J1, cons
   e->J0 = J0; e->J1 = J1; e->omega = omega; e->err = err; e->huber_delta = huber_delta;
 }
 
+static void robustify(int kind, double delta, double e, double* rho);
+/* rho(e), rho'(e), rho''(e) of kernel `kind` (tests: consistency of the three, known values) */
+void orc_robustify(int kind, double delta, double e, double* rho) { robustify(kind, delta, e, rho); }
+/* other kernels than Huber for the set (the delta stays the one given to orc_set_edge_data) */
+void orc_set_robust_kernel(Orc* s, int set, int kind) { s->sets[set].kernel_kind = kind; }
+
 static double* blkptr(Orc* s, char kind, long off) {
   switch (kind) { case 1: return s->Hpp + off; case 2: return s->Hll + off; case 3: return s->Hpl + off; default: return NULL; }
 }
 
-/* Huber: robust_kernel_impl.cpp:65-78.  rho[0..2] */
-static void huber(double delta, double e, double* rho) {
-  double dsqr = delta * delta;
-  if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
-  else { double sqrte = sqrt(e); rho[0] = 2 * sqrte * delta - dsqr; rho[1] = delta / sqrte; rho[2] = -0.5 * rho[1] / e; }
+/* The robust kernels of robust_kernel_impl.cpp, rho[0..2] = rho(e), rho'(e), rho''(e):
+ * kind 1 Huber :65-78, 2 PseudoHuber :80-89, 3 Cauchy :91-99, 4 Saturated :101-113, 5 DCS :116-126 (delta = phi) */
+static void robustify(int kind, double delta, double e, double* rho) {
+  double dsqr = delta * delta, dsqrReci = 1. / dsqr;
+  switch (kind) {
+    case 1:
+      if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
+      else { double sqrte = sqrt(e); rho[0] = 2 * sqrte * delta - dsqr; rho[1] = delta / sqrte; rho[2] = -0.5 * rho[1] / e; }
+      break;
+    case 2: { double aux1 = dsqrReci * e + 1.0, aux2 = sqrt(aux1);
+      rho[0] = 2 * dsqr * (aux2 - 1); rho[1] = 1. / aux2; rho[2] = -0.5 * dsqrReci * rho[1] / aux1; } break;
+    case 3: { double aux = dsqrReci * e + 1.0;
+      rho[0] = dsqr * log(aux); rho[1] = 1. / aux; rho[2] = -dsqrReci * rho[1] * rho[1]; } break;
+    case 4:
+      if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; } else { rho[0] = dsqr; rho[1] = 0.; rho[2] = 0.; }
+      break;
+    case 5: { double scale = (2.0 * delta) / (delta + e); if (scale >= 1.0) scale = 1.0;
+      rho[0] = scale * e * scale; rho[1] = scale * scale; rho[2] = 0; } break;
+    default: rho[0] = e; rho[1] = 1.; rho[2] = 0.;
+  }
 }
 static double edge_chi2(const OrcSet* e, int k) {   /* base_edge.h:58-61: e' Omega e */
   const int d = e->d; const double* O = e->omega + (size_t)k * d * d; const double* r = e->err + (size_t)k * d;
@@ -280,7 +302,7 @@ int orc_build_system(Orc* s) {
       for (int i = 0; i < d; ++i) { double t = 0; for (int j = 0; j < d; ++j) t += O[i + d * j] * r[j]; omega_r[i] = -t; }
       const double* Ouse = O;
       if (e->huber_delta > 0) {              /* robust branch, base_binary_edge.hpp:92-112 */
-        double rho[3]; huber(e->huber_delta, edge_chi2(e, k), rho);
+        double rho[3]; robustify(e->kernel_kind > 0 ? e->kernel_kind : 1, e->huber_delta, edge_chi2(e, k), rho);
         for (int i = 0; i < d; ++i) omega_r[i] *= rho[1];
         for (int i = 0; i < d * d; ++i) Ow[i] = rho[1] * O[i];           /* base_edge.h:96-102 */
         Ouse = Ow;
@@ -311,7 +333,7 @@ double orc_chi2(Orc* s) {
     OrcSet* e = &s->sets[si];
     for (int k = 0; k < e->n; ++k) {
       double c = edge_chi2(e, k);
-      if (e->huber_delta > 0) { double rho[3]; huber(e->huber_delta, c, rho); c = rho[0]; }
+      if (e->huber_delta > 0) { double rho[3]; robustify(e->kernel_kind > 0 ? e->kernel_kind : 1, e->huber_delta, c, rho); c = rho[0]; }
       chi += c;
     }
   }

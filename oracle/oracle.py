@@ -51,6 +51,8 @@ def lib():
         L.orc_build_system.argtypes = [C.c_void_p]
         L.orc_chi2.restype = C.c_double
         L.orc_chi2.argtypes = [C.c_void_p]
+        L.orc_set_robust_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_robustify.argtypes = [C.c_int, C.c_double, C.c_double, c_dbl_p]
         L.orc_set_lambda.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.orc_restore_diagonal.argtypes = [C.c_void_p]
         L.orc_set_lambda_split.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
@@ -160,6 +162,10 @@ class OracleSolver:
         J1 = None if J1 is None else _f64(J1)
         self._keep = [k for k in self._keep if k[0] != s] + [(s, J0, J1, omega, err)]
         self.L.orc_set_edge_data(self.h, s, _dp(J0), _dp(J1), _dp(omega), _dp(err), float(huber_delta))
+
+    def set_robust_kernel(self, s, kind):
+        """1 Huber (default), 2 PseudoHuber, 3 Cauchy, 4 Saturated, 5 DCS; delta = the huber_delta of set_edge_data."""
+        self.L.orc_set_robust_kernel(self.h, s, int(kind))
 
     def build_system(self):
         self.L.orc_build_system(self.h)
@@ -442,3 +448,11 @@ def pcg_solve_blocks(nb, bs, colptr, row, val, b, tolerance=1e-6, absolute=True,
     ok = L.orc_pcg_solve_blocks(nb, bs, _ip(colptr), _ip(row), _dp(val), _dp(b), _dp(x), tolerance, int(absolute), max_iter,
                                 C.byref(res), C.byref(it))
     return bool(ok), x, it.value, res.value
+
+
+def robustify(kind, delta, e):
+    """(rho, rho', rho'') of the reference's robust kernel `kind` at squared error e (robust_kernel_impl.cpp)."""
+    L = lib()
+    out = np.zeros(3)
+    L.orc_robustify(int(kind), float(delta), float(e), out.ctypes.data_as(c_dbl_p))
+    return out

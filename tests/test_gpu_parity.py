@@ -515,3 +515,33 @@ def test_dependency_driven_launches_soak():
     out = subprocess.run([sys.executable, tool, "3", "24"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "problems 24 bad 0" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("kind", [2, 3, 4, 5])
+def test_robust_kernels_other_than_huber(kind):
+    """PseudoHuber, Cauchy, Saturated and DCS (robust_kernel_impl.cpp:80-126) through assembly, chi2 and a damped solve,
+    generic edge-data path and fused BA path, against the oracle."""
+    capi = _capi()
+    pr = ba_case(40, 400, outlier_frac=0.1)
+    delta = 1.2
+    o = oracle_ba(pr, huber=delta)
+    o.set_robust_kernel(0, kind)
+    o.build_system()
+    s = hip_ba(pr)
+    s.setRobustKernel(0, kind, delta)
+    s.buildSystem()
+    _cmp_system(s, o, capi)
+    assert abs(s.chi2() - o.chi2()) <= 1e-12 * o.chi2()
+    lam = 1e-3 * o.max_diagonal()
+    s.setLambda(lam, True)
+    o.set_lambda(lam, True)
+    assert s.solve() and o.solve()
+    assert relerr(s.x(), o.x()) < 1e-8
+    from openslam_g2o_amd import lm
+    sf, g = lm.setup_device_ba(pr)
+    sf.setRobustKernel(0, kind, delta)
+    g.linearize()
+    sf.buildSystem()
+    assert relerr(sf.b(), o.b()) < 1e-11 and abs(sf.chi2() - o.chi2()) <= 1e-11 * o.chi2()
+    with pytest.raises(Exception):
+        s.setRobustKernel(0, 9, 1.0)

@@ -159,3 +159,29 @@ def test_se3_jacobian_against_central_differences():
             ep = O.se3_edges(O.se3_oplus(poses, hid, x.reshape(-1)), vi, vj, Z, jac=False)
             em = O.se3_edges(O.se3_oplus(poses, hid, -x.reshape(-1)), vi, vj, Z, jac=False)
             assert np.abs((ep - em) / (2 * h) - J.reshape(n, 6, 6)[:, c, :]).max() < 1e-6
+
+
+def test_robust_kernels_known_values_and_consistency():
+    """The five robust kernels of the reference (robust_kernel_impl.cpp:65-126) in the oracle: closed-form values at
+    hand-computed points, rho' = d rho / de and rho'' = d rho' / de by central differences, no-op below the threshold."""
+    import math
+    d = 1.5
+    # Huber: inlier identity, outlier 2 d sqrt(e) - d^2
+    assert np.allclose(O.robustify(1, d, 1.0), [1.0, 1.0, 0.0])
+    assert np.allclose(O.robustify(1, d, 9.0), [2 * 3 * d - d * d, d / 3.0, -0.5 * (d / 3.0) / 9.0])
+    # PseudoHuber / Cauchy at e = 3 d^2: aux = 4
+    e = 3 * d * d
+    assert np.allclose(O.robustify(2, d, e), [2 * d * d * (2 - 1), 0.5, -0.5 / (d * d) * 0.5 / 4])
+    assert np.allclose(O.robustify(3, d, e), [d * d * math.log(4.0), 0.25, -(1 / (d * d)) * 0.0625])
+    # Saturated: clamps at d^2
+    assert np.allclose(O.robustify(4, d, 1.0), [1.0, 1.0, 0.0]) and np.allclose(O.robustify(4, d, 10.0), [d * d, 0.0, 0.0])
+    # DCS (delta = phi): scale = 2 phi / (phi + e), capped at 1
+    assert np.allclose(O.robustify(5, d, 1.0), [1.0, 1.0, 0.0])
+    sc = 2 * d / (d + 6.0)
+    assert np.allclose(O.robustify(5, d, 6.0), [sc * sc * 6.0, sc * sc, 0.0])
+    for kind in (1, 2, 3):
+        for e in (0.3, 4.0, 50.0):
+            h = 1e-6 * max(1.0, e)
+            r, rp, rm = O.robustify(kind, d, e), O.robustify(kind, d, e + h), O.robustify(kind, d, e - h)
+            assert abs((rp[0] - rm[0]) / (2 * h) - r[1]) < 1e-6
+            assert abs((rp[1] - rm[1]) / (2 * h) - r[2]) < 1e-6
