@@ -2293,7 +2293,6 @@ void BlockSolver::solve_schur() {
 void BlockSolver::solve_schur_impl(bool want_matrix) {
   if (profiling) ts_.start(st_);
   const size_t sizeP = (size_t)nP_ * p_;
-  const int hs_nnzb = (int)hs_row.size();
   const int G = schur_group > 0 ? schur_group : pick_group((double)n_sc_ / std::max<long>(1, n_td_));
   // every landmark lies in exactly one tile, so the tiles can invert the landmark blocks themselves
   const bool fuse_inv = fuse_landmark_inverse && n_tiles_ > 0 && tiles_cover_all_;

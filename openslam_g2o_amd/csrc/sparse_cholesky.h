@@ -221,7 +221,7 @@ class SparseCholesky {
   int n_slots_ = 0;
   bool dep_off_ = false, dep_stalled_ = false;
   int n_xseg_ = 0;
-  int dbg_launch_ = 0;
+  [[maybe_unused]] int dbg_launch_ = 0;   // (G2OHIP_CHOL_STAMPS builds)
   size_t xbuf_count_ = 0;
   void launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep = false);
   void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false);
