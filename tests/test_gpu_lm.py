@@ -174,3 +174,34 @@ def test_dogleg_trajectory_matches_oracle():
     r1 = lm.optimize(g2, s2, 5, algorithm="dogleg", initial_delta=0.05)
     r2 = lm.optimize(og2, OracleSolverAdapter(og2.o), 5, algorithm="dogleg", initial_delta=0.05)
     assert r1[0] == r2[0] and r1[3] == r2[3] and relerr(r1[1], r2[1]) < 1e-7 and relerr(r1[2], r2[2]) < 1e-6
+
+
+def test_trial_stats_matches_the_three_separate_calls():
+    """g2ohip_solve_async + g2ohip_trial_stats (one synchronisation per LM trial) against solve / chi2 / computeScale, and
+    the failure flag of an indefinite system arriving through the deferred status."""
+    pr = ba_case(50, 500)
+    a, ga = lm.setup_device_ba(pr)
+    b, gb = lm.setup_device_ba(pr)
+    for s, g in ((a, ga), (b, gb)):
+        g.linearize()
+        s.buildSystem()
+        s.setLambda(3.0, True)
+    assert a.solve()
+    ga.update(); a.restoreDiagonal(); ga.compute_active_errors()
+    chi, sc = a.chi2(), a.computeScale(3.0)
+    b.solveAsync()
+    gb.update(); b.restoreDiagonal(); gb.compute_active_errors()
+    ok, chi_b, sc_b = b.trialStats(3.0)
+    assert ok and chi_b == chi and sc_b == sc
+    assert np.array_equal(a.x(), b.x())
+    # without a pending solve the call only evaluates the sums (chi2 comes out of the cache)
+    ok, chi_c, sc_c = b.trialStats(3.0)
+    assert ok and chi_c == chi and sc_c == sc
+    b.buildSystem()
+    b.setLambda(-1e3 * b.maxDiagonal(), True)
+    b.solveAsync()
+    ok, _, _ = b.trialStats(1.0)
+    assert not ok
+    b.restoreDiagonal()
+    b.setLambda(3.0, True)
+    assert b.solve()

@@ -55,7 +55,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,fused,x_exchange", [(2, False, "full"), (3, True, "halo"), (2, True, "halo")])
+@pytest.mark.parametrize("world,fused,x_exchange", [(2, False, "full"), (3, True, "halo"), (2, True, "halo"), (4, True, "halo")])
 def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused, x_exchange):
     import torch.multiprocessing as mp
     P, L, lam = 700, 6000, 30.0
