@@ -171,7 +171,9 @@ int g2ohip_solve_async(g2ohip_solver* s);
 int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* chi2, double* scale);
 /* Options (name, value).  Linear solver of the reduced system: "linear_solver" 0 = multifrontal block Cholesky
  * (replaces LinearSolverCSparse / LinearSolverCholmod), 1 = block-Jacobi preconditioned CG (replaces
- * LinearSolverPCG, g2o/solvers/pcg/linear_solver_pcg.hpp:79-196) with "pcg_tolerance" (1e-6),
+ * LinearSolverPCG, g2o/solvers/pcg/linear_solver_pcg.hpp:79-196; 2 = the same iteration matrix-free: with the Schur
+ * complement on, Hschur is never formed -- Hschur v = Hpp v + lambda v - Hpl Dinv Hpl' v, exact block-Jacobi preconditioner)
+ * with "pcg_tolerance" (1e-6),
  * "pcg_absolute_tolerance" (1), "pcg_max_iterations" (-1 = dimension), like LinearSolverPCG's setters
  * (linear_solver_pcg.h:74-85); iterations of the last solve in g2ohip_stats.iterationsLinearSolver.
  * Ordering / symbolic knobs (before g2ohip_build_structure): "nd_leaf" (nested-dissection leaf size in blocks, 32),

@@ -11,6 +11,8 @@
 // reference's serial loop order is replaced by a fixed gather order, results are deterministic); dot products
 // are two-stage reductions with a fixed partition.
 #pragma once
+#include <functional>
+
 #include "common.h"
 
 namespace g2ohip {
@@ -32,6 +34,14 @@ class BlockPCG {
   // x = A \ b; A values [nnzb][bs*bs] column-major blocks in pattern order; device pointers.  Returns false when a
   // diagonal block is singular / the iteration broke down (NaN).  Synchronises st.
   bool solve(const double* dA, const double* d_b, double* d_x, hipStream_t st);
+  // The same iteration with the matrix given as an operator (matrix-free Schur complement: linear_solver_pcg.hpp:79-196 only
+  // ever needs A*d and the diagonal blocks): diag_blocks [nb][bs*bs] column-major (block i = A_ii), apply(d_in, d_out)
+  // queues d_out = A d_in on st.  analyze_operator(nb) instead of analyze().
+  void analyze_operator(int nb, hipStream_t st);
+  bool solve_operator(const double* d_diag_blocks, const std::function<void(const double*, double*)>& apply, const double* d_b,
+                      double* d_x, hipStream_t st);
+  // d_out = A d_in with the analysed pattern (deterministic gather form of the symmetric product)
+  void multiply(const double* dA, const double* d_in, double* d_out, hipStream_t st);
   int last_iterations() const { return iters_; }
   double residual() const { return residual_; }   // 0.5 * r'Jr of the last solve
   void reset_residual() { residual_ = -1.0; }
@@ -41,6 +51,7 @@ class BlockPCG {
   double residual_ = -1.0;
   DevBuf<int> d_diag, d_ent_ptr, d_ent;   // per block row: diagonal block id; entries (block id << 1 | transposed, other block row)
   DevBuf<int> d_ent_other;
+  DevBuf<double> d_zero_scal;   // multiply(): an all-zero scalar block (the product kernel checks its "done" flag)
   DevBuf<double> d_J, d_r, d_d, d_q, d_s, d_part, d_scal;
   int n_part_ = 0;
 };

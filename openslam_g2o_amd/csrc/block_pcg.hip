@@ -295,6 +295,105 @@ void BlockPCG::analyze(int nb, const int* colptr, const int* rowidx, hipStream_t
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
 }
 
+// partial sums of d'q per block of kT block rows (what pcg_spmv_kernel leaves in `part`)
+template <int BS>
+__global__ void __launch_bounds__(kT) pcg_dot_kernel(int nb, const double* __restrict__ d, const double* __restrict__ q,
+                                                    double* __restrict__ part, const double* __restrict__ scal) {
+  __shared__ double sh[kT];
+  if (scal[S_DONE] != 0.0) return;
+  const int i = blockIdx.x * kT + threadIdx.x;
+  double dot = 0.0;
+  if (i < nb) {
+#pragma unroll
+    for (int k = 0; k < BS; ++k) dot += d[(size_t)i * BS + k] * q[(size_t)i * BS + k];
+  }
+  const double s = block_sum(dot, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+void BlockPCG::analyze_operator(int nb, hipStream_t st) {
+  if (bs_ != 3 && bs_ != 6 && bs_ != 7) throw ArgFailure("BlockPCG: unsupported block size (3, 6, 7)");
+  nb_ = nb;
+  std::vector<int> diag(std::max(nb, 1));
+  for (int i = 0; i < nb; ++i) diag[i] = i;   // diagonal block i of the array handed to solve_operator
+  d_diag.upload(diag, st);
+  const size_t n = (size_t)nb * bs_;
+  d_J.alloc((size_t)nb * bs_ * bs_);
+  d_r.alloc(n);
+  d_d.alloc(n);
+  d_q.alloc(n);
+  d_s.alloc(n);
+  n_part_ = (nb + kT - 1) / kT;
+  d_part.alloc(n_part_);
+  d_scal.alloc(S_COUNT);
+  residual_ = -1.0;
+}
+
+void BlockPCG::multiply(const double* dA, const double* d_in, double* d_out, hipStream_t st) {
+  if (nb_ <= 0 || !d_ent_ptr.p) throw StateFailure("BlockPCG::multiply before analyze");
+  if (!d_zero_scal.p) {
+    d_zero_scal.alloc(S_COUNT);
+    d_zero_scal.zero(st);
+  }
+  switch (bs_) {
+#define G2OHIP_MUL(BS_)                                                                                                          \
+  case BS_:                                                                                                                      \
+    hipLaunchKernelGGL((pcg_spmv_kernel<BS_>), dim3(n_part_), dim3(kT), 0, st, nb_, dA, d_diag.p, d_ent_ptr.p, d_ent.p, d_ent_other.p, \
+                       d_in, d_out, d_part.p, d_zero_scal.p);                                                                    \
+    break
+    G2OHIP_MUL(3);
+    G2OHIP_MUL(6);
+    G2OHIP_MUL(7);
+#undef G2OHIP_MUL
+    default: throw ArgFailure("BlockPCG: unsupported block size (3, 6, 7)");
+  }
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+bool BlockPCG::solve_operator(const double* d_diag_blocks, const std::function<void(const double*, double*)>& apply,
+                              const double* d_b, double* d_x, hipStream_t st) {
+  if (nb_ <= 0) throw StateFailure("BlockPCG::solve_operator before analyze_operator");
+  const int nb = nb_, grid = n_part_;
+  const size_t n = (size_t)nb * bs_;
+  const int max_iter = opt.max_iter < 0 ? (int)n : opt.max_iter;
+  G2OHIP_HIP_CHECK(hipMemsetAsync(d_scal.p, 0, S_COUNT * sizeof(double), st));
+#define G2OHIP_PCGOP(BS_)                                                                                                        \
+  {                                                                                                                              \
+    hipLaunchKernelGGL((pcg_init_kernel<BS_>), dim3(grid), dim3(kT), 0, st, nb, d_diag_blocks, d_diag.p, d_b, d_J.p, d_r.p, d_d.p, \
+                       d_x, d_part.p, d_scal.p);                                                                                 \
+    hipLaunchKernelGGL(pcg_reduce_kernel, dim3(1), dim3(kT), 0, st, grid, d_part.p, d_scal.p, 0, opt.tolerance,                   \
+                       opt.absolute_tolerance ? 1 : 0, residual_, max_iter);                                                     \
+    double h[S_COUNT] = {0};                                                                                                     \
+    int launched = 0;                                                                                                            \
+    for (;;) {                                                                                                                   \
+      const int chunk = std::max(1, std::min(opt.check_every, max_iter - launched));                                             \
+      for (int k = 0; k < chunk; ++k) {                                                                                          \
+        apply(d_d.p, d_q.p);                                                                                                     \
+        hipLaunchKernelGGL((pcg_dot_kernel<BS_>), dim3(grid), dim3(kT), 0, st, nb, d_d.p, d_q.p, d_part.p, d_scal.p);             \
+        hipLaunchKernelGGL(pcg_reduce_kernel, dim3(1), dim3(kT), 0, st, grid, d_part.p, d_scal.p, 1, 0.0, 0, 0.0, max_iter);     \
+        hipLaunchKernelGGL((pcg_update_kernel<BS_>), dim3(grid), dim3(kT), 0, st, nb, d_J.p, d_x, d_r.p, d_d.p, d_q.p, d_s.p,      \
+                           d_part.p, d_scal.p);                                                                                  \
+        hipLaunchKernelGGL(pcg_reduce_kernel, dim3(1), dim3(kT), 0, st, grid, d_part.p, d_scal.p, 2, 0.0, 0, 0.0, max_iter);     \
+        hipLaunchKernelGGL(pcg_direction_kernel, dim3((unsigned)((n + kT - 1) / kT)), dim3(kT), 0, st, n, d_s.p, d_d.p, d_scal.p); \
+      }                                                                                                                          \
+      launched += chunk;                                                                                                         \
+      G2OHIP_HIP_CHECK(hipGetLastError());                                                                                       \
+      d_scal.download(h, S_COUNT, st);                                                                                           \
+      if (h[S_DONE] != 0.0 || launched >= max_iter) break;                                                                       \
+    }                                                                                                                            \
+    iters_ = (int)h[S_ITERS];                                                                                                    \
+    residual_ = 0.5 * h[S_DN];                                                                                                   \
+    return h[S_BAD] == 0.0;                                                                                                      \
+  }
+  switch (bs_) {
+    case 3: G2OHIP_PCGOP(3)
+    case 6: G2OHIP_PCGOP(6)
+    case 7: G2OHIP_PCGOP(7)
+    default: throw ArgFailure("BlockPCG: unsupported block size (3, 6, 7)");
+  }
+#undef G2OHIP_PCGOP
+}
+
 bool BlockPCG::solve(const double* dA, const double* d_b, double* d_x, hipStream_t st) {
   if (nb_ <= 0) throw StateFailure("BlockPCG::solve before analyze");
   const int nb = nb_, grid = n_part_;

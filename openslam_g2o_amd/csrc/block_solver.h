@@ -126,7 +126,8 @@ class BlockSolver {
   // per-rank work shrinks (multi-GPU).  Needs a non-default stream.  Timing events sit between the graphs.
   bool use_graph = false;
   void invalidate_graphs();
-  int linear_solver = 0;                   // 0: multifrontal block Cholesky, 1: block-Jacobi PCG (LinearSolverPCG)
+  int linear_solver = 0;                   // 0: multifrontal block Cholesky, 1: block-Jacobi PCG (LinearSolverPCG) on Hschur,
+                                           // 2: the same PCG matrix-free (Schur complement never formed; Schur mode only)
   PcgOptions pcg_opt;
   int pcg_iterations = 0;
   bool schur_sort_dests = true;            // order a tile's destinations by entry count (lockstep lane groups)
@@ -227,6 +228,12 @@ class BlockSolver {
   long n_sc_ = 0;
   std::unique_ptr<SparseCholesky> chol_;
   std::unique_ptr<BlockPCG> pcg_;
+  // linear_solver 2: PCG on the reduced system WITHOUT forming it (Hschur v = Hpp v + lambda v - Hpl Dinv Hpl' v)
+  std::unique_ptr<BlockPCG> pcg_mf_, pcg_hpp_;
+  DevBuf<int> d_pm_ptr, d_pm_q, d_pm_lm;     // pose-major lists of the Hpl blocks (block id, landmark)
+  DevBuf<double> d_mf_l, d_mf_diag, d_mf_zero;
+  bool mf_ready_ = false;
+  int solve_matrix_free();
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
     double f = 0, cx = 0, cy = 0;

@@ -1907,6 +1907,9 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   G2OHIP_HIP_CHECK(hipMemsetAsync(d_x.p, 0, vector_size() * sizeof(double), st_));
   // ---- symbolic factorisation of the system the linear solver will see
   pcg_.reset();
+  pcg_mf_.reset();
+  pcg_hpp_.reset();
+  mf_ready_ = false;
   chol_ = std::make_unique<SparseCholesky>(p);
   chol_->opt = chol_opt;
   if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
@@ -2683,10 +2686,132 @@ void BlockSolver::solve_back_substitute_impl() {
   }
 }
 
+// ---- matrix-free PCG on the reduced system (linear_solver 2) -------------------------------------------
+// out_i = init_i (+ lam d_i) + sign * sum_{blocks q of pose i} Hpl_q t[lm(q)]      (thread = scalar row of a pose)
+template <int PD, int LD>
+__global__ void __launch_bounds__(kThreads) mf_pose_kernel(int nP, const int* __restrict__ pm_ptr, const int* __restrict__ pm_q,
+                                                         const int* __restrict__ pm_lm, const double* __restrict__ Hpl,
+                                                         const double* __restrict__ tl, const double* init,
+                                                         const double* __restrict__ dvec, const double* __restrict__ lam, double sign,
+                                                         double* out) {   // (init may be out)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nP * PD) return;
+  const int i = t / PD, r = t - i * PD;
+  double acc = 0.0;
+  for (int k = pm_ptr[i]; k < pm_ptr[i + 1]; ++k) {
+    const double* B = Hpl + (size_t)pm_q[k] * PD * LD + r;
+    const double* tv = tl + (size_t)pm_lm[k] * LD;
+#pragma unroll
+    for (int c = 0; c < LD; ++c) acc += B[PD * c] * tv[c];
+  }
+  double v = init[t];
+  if (dvec) v += lam[0] * dvec[t];
+  out[t] = v + sign * acc;
+}
+// diagonal blocks of the reduced system: Hpp_ii + lam I - sum_q B_q Dinv B_q'   (thread = element of a block)
+template <int PD, int LD>
+__global__ void __launch_bounds__(kThreads) mf_diag_kernel(int nP, const int* __restrict__ pm_ptr, const int* __restrict__ pm_q,
+                                                         const int* __restrict__ pm_lm, const double* __restrict__ Hpl,
+                                                         const double* __restrict__ Dinv, const double* __restrict__ Hpp,
+                                                         const int* __restrict__ pp_diag, const double* __restrict__ lam,
+                                                         double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nP * PD * PD) return;
+  const int i = t / (PD * PD), e = t - i * PD * PD, r = e % PD, c = e / PD;
+  double acc = 0.0;
+  for (int k = pm_ptr[i]; k < pm_ptr[i + 1]; ++k) {
+    const double* B = Hpl + (size_t)pm_q[k] * PD * LD;
+    const double* D = Dinv + (size_t)pm_lm[k] * LD * LD;
+#pragma unroll
+    for (int b = 0; b < LD; ++b) {
+      double w = 0.0;
+#pragma unroll
+      for (int a = 0; a < LD; ++a) w += B[r + PD * a] * D[a + LD * b];
+      acc += w * B[c + PD * b];
+    }
+  }
+  out[t] = Hpp[(size_t)pp_diag[i] * PD * PD + e] + (r == c ? lam[0] : 0.0) - acc;
+}
+
+int BlockSolver::solve_matrix_free() {
+  if (!schur_) throw StateFailure("linear_solver 2 needs the Schur complement mode");
+  if (chol_opt.world > 1) throw StateFailure("linear_solver 2: one GPU only");
+  const size_t sizeP = (size_t)nP_ * p_;
+  if (!mf_ready_) {   // pose-major view of the Hpl pattern (stored landmark-major)
+    mf_ready_ = true;
+    std::vector<int> ptr(nP_ + 1, 0), qq(pl_row.size()), lm(pl_row.size());
+    for (int r : pl_row) ptr[r + 1]++;
+    for (int i = 0; i < nP_; ++i) ptr[i + 1] += ptr[i];
+    std::vector<int> w(ptr.begin(), ptr.end() - 1);
+    for (int l = 0; l < nL_; ++l)
+      for (int q = pl_colptr[l]; q < pl_colptr[l + 1]; ++q) {
+        const int k = w[pl_row[q]]++;
+        qq[k] = q;
+        lm[k] = l;
+      }
+    if (qq.empty()) { qq.push_back(0); lm.push_back(0); }
+    d_pm_ptr.upload(ptr, st_);
+    d_pm_q.upload(qq, st_);
+    d_pm_lm.upload(lm, st_);
+    d_mf_l.alloc((size_t)std::max(nL_, 1) * l_);
+    d_mf_diag.alloc(sizeP * p_);
+    d_mf_zero.alloc(std::max(sizeP, (size_t)nL_ * l_) + 1);
+    d_mf_zero.zero(st_);
+    pcg_mf_ = std::make_unique<BlockPCG>(p_);
+    pcg_mf_->analyze_operator(nP_, st_);
+    pcg_hpp_ = std::make_unique<BlockPCG>(p_);
+    pcg_hpp_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
+  }
+  pcg_mf_->opt = pcg_opt;
+  if (profiling) tn_.start(st_);
+  prof.begin(KernelProf::kCholFactor, st_);
+  bool ok = false;
+#define G2OHIP_MF(P_, L_)                                                                                                        \
+  if (p_ == P_ && l_ == L_) {                                                                                                    \
+    const int gl = grid_for(nL_), gp = grid_for(sizeP), gd = grid_for(sizeP * P_);                                               \
+    hipLaunchKernelGGL((landmark_inverse_kernel<L_>), dim3(gl), dim3(kThreads), 0, st_, nL_, d_Hll.p, d_b.p + sizeP, d_Dinv.p,     \
+                       d_db.p, d_lam.p);                                                                                         \
+    /* bschur = b_p - Hpl (Dinv b_l) */                                                                                          \
+    hipLaunchKernelGGL((back_substitute_kernel<P_, L_>), dim3(gl), dim3(kThreads), 0, st_, nL_, d_pl_colptr.p, d_pl_row.p, d_Hpl.p, \
+                       d_Dinv.p, d_b.p + sizeP, d_mf_zero.p, d_mf_l.p);                                                          \
+    hipLaunchKernelGGL((mf_pose_kernel<P_, L_>), dim3(gp), dim3(kThreads), 0, st_, nP_, d_pm_ptr.p, d_pm_q.p, d_pm_lm.p, d_Hpl.p,   \
+                       d_mf_l.p, d_b.p, (const double*)nullptr, d_lam.p, -1.0, d_bschur.p);                                       \
+    hipLaunchKernelGGL((mf_diag_kernel<P_, L_>), dim3(gd), dim3(kThreads), 0, st_, nP_, d_pm_ptr.p, d_pm_q.p, d_pm_lm.p, d_Hpl.p,   \
+                       d_Dinv.p, d_Hpp.p, d_pp_diag.p, d_lam.p, d_mf_diag.p);                                                    \
+    auto apply = [&](const double* din, double* dout) {                                                                          \
+      pcg_hpp_->multiply(d_Hpp.p, din, dout, st_);                                                                               \
+      hipLaunchKernelGGL((back_substitute_kernel<P_, L_>), dim3(gl), dim3(kThreads), 0, st_, nL_, d_pl_colptr.p, d_pl_row.p,       \
+                         d_Hpl.p, d_Dinv.p, d_mf_zero.p, din, d_mf_l.p);   /* -Dinv Hpl' d */                                     \
+      hipLaunchKernelGGL((mf_pose_kernel<P_, L_>), dim3(gp), dim3(kThreads), 0, st_, nP_, d_pm_ptr.p, d_pm_q.p, d_pm_lm.p, d_Hpl.p, \
+                         d_mf_l.p, dout, din, d_lam.p, 1.0, dout);                                                               \
+    };                                                                                                                           \
+    ok = pcg_mf_->solve_operator(d_mf_diag.p, apply, d_bschur.p, d_x.p, st_);                                                    \
+  } else
+  G2OHIP_MF(6, 3)
+  G2OHIP_MF(3, 2)
+  G2OHIP_MF(7, 3) { throw ArgFailure("unsupported (pose_dim, landmark_dim) for the matrix-free solver"); }
+#undef G2OHIP_MF
+  prof.end(KernelProf::kCholFactor, st_);
+  if (profiling) {
+    tn_.stop(st_);
+    times.numeric = tn_.seconds();
+    times.linsolve = 0.0;
+  }
+  hschur_valid_ = false;
+  pcg_iterations = pcg_mf_->last_iterations();
+  return ok ? 0 : 1;
+}
+
 int BlockSolver::solve() {
   if (!system_built_) throw StateFailure("solve before build_system");
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (linear_solver == 2) {   // matrix-free PCG: neither the Schur tiles nor the reduction run
+    const int rc = solve_matrix_free();
+    if (rc != 0) return rc;
+    solve_back_substitute();
+    return 0;
+  }
   const bool virt = virtual_reduced_ok();
   if (virt != virt_now_) invalidate_graphs();   // the captured factor segment is specific to the source of the matrix
   virt_now_ = virt;

@@ -98,3 +98,26 @@ def test_device_pcg_on_the_schur_complement():
     # a non positive definite diagonal block is reported like a failed factorisation
     s.setLambda(-1e12, True)
     assert not s.solve()
+
+
+@pytest.mark.gpu
+def test_matrix_free_pcg_on_the_reduced_system():
+    """linear_solver 2: LinearSolverPCG's iteration (linear_solver_pcg.hpp:79-196) on the Schur complement WITHOUT forming it
+    (Hschur v = Hpp v + lambda v - Hpl Dinv Hpl' v, exact block-Jacobi preconditioner): same solution as the direct solver
+    and as the PCG on the explicit Hschur, same iteration count as the latter."""
+    from openslam_g2o_amd import capi
+    from tests.helpers import ba_case, hip_ba, relerr
+    pr = ba_case(120, 1500)
+    xs, iters = {}, {}
+    for ls in (0, 1, 2):
+        s = hip_ba(pr, options={"linear_solver": ls, "pcg_tolerance": 1e-20, "pcg_absolute_tolerance": 0, "pcg_max_iterations": 6000})
+        s.buildSystem()
+        s.setLambda(5.0, True)
+        assert s.solve()
+        xs[ls] = s.x()
+        iters[ls] = s.stats()["iterationsLinearSolver"]
+        r = s.multiplyHessian(xs[ls]) - s.b()
+        assert np.abs(r).max() <= 1e-7 * np.abs(s.b()).max()
+        assert s.solve() and relerr(s.x(), xs[ls]) < 1e-6          # repeatable
+    assert relerr(xs[1], xs[0]) < 1e-6 and relerr(xs[2], xs[0]) < 1e-6
+    assert iters[2] > 0 and abs(iters[2] - iters[1]) <= max(5, iters[1] // 20)   # same iteration up to rounding
