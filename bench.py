@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--graph", choices=["on", "off"], default="on",
                     help="hipGraph replay of the two launch-bound kernel sequences (factorisation + fused forward sweep, "
                          "backward sweep: one launch per tree level); the HIP timing events sit between the graphs")
-    ap.add_argument("--mode", choices=["auto", "subtree", "replicated"], default="auto", help="N>1 reduced-solve strategy")
+    ap.add_argument("--mode", choices=["auto", "subtree", "replicated", "pcg"], default="auto", help="N>1 reduced-solve strategy")
     ap.add_argument("--dump-xp", default="", help="rank 0 saves the pose increment to this .npy (cross-run comparison)")
     args = ap.parse_args()
 

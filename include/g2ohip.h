@@ -167,6 +167,13 @@ int g2ohip_kernel_time(g2ohip_solver* s, int slot, double* total_seconds, long* 
  * leaves its status on the device; after the caller has updated the estimates and re-evaluated the errors,
  * g2ohip_trial_stats returns that status (solve_ok 1/0), activeRobustChi2 and computeScale(lambda) = x'(lambda x + b)
  * together.  Without a pending g2ohip_solve_async it just evaluates the two sums. */
+/* The reduced (Schur) system as an operator, never formed (what "linear_solver" 2 iterates on; callers that run their own
+ * Krylov loop, e.g. sharded over GPUs with one all-reduce of the product per iteration, use these directly):
+ * prepare: Dinv = (Hll + lambda_l I)^-1, bschur = b_p - Hpl Dinv b_l (g2ohip_device_array 100) and the diagonal blocks
+ * Hpp_ii + lambda_p I - sum B Dinv B' (g2ohip_device_array 107, [nP][p*p]); apply: out = (Hpp + lambda_p I - Hpl Dinv Hpl') in
+ * on device vectors of nP*p doubles.  With landmarks sharded over ranks both are this rank's summands. */
+int g2ohip_schur_operator_prepare(g2ohip_solver* s);
+int g2ohip_schur_operator_apply(g2ohip_solver* s, const double* in_device, double* out_device);
 int g2ohip_solve_async(g2ohip_solver* s);
 int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* chi2, double* scale);
 /* Options (name, value).  Linear solver of the reduced system: "linear_solver" 0 = multifrontal block Cholesky

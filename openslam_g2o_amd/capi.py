@@ -23,7 +23,7 @@ c_dbl_p = C.POINTER(C.c_double)
 
 OK, NOT_PD = 0, 1
 HPP, HPL, HLL, HSCHUR, DINV = 0, 1, 2, 3, 4
-ARR_BSCHUR, ARR_X, ARR_B, ARR_EXCHANGE, ARR_XP, ARR_XBOUNDARY, ARR_XHALO = 100, 101, 102, 103, 104, 105, 106
+ARR_BSCHUR, ARR_X, ARR_B, ARR_EXCHANGE, ARR_XP, ARR_XBOUNDARY, ARR_XHALO, ARR_SCHUR_DIAG = 100, 101, 102, 103, 104, 105, 106, 107
 KERNEL_NONE, KERNEL_HUBER, KERNEL_PSEUDOHUBER, KERNEL_CAUCHY, KERNEL_SATURATED, KERNEL_DCS = 0, 1, 2, 3, 4, 5
 
 
@@ -51,7 +51,7 @@ EXPORTS = [
     "g2ohip_set_lambda_split", "g2ohip_ba_set_edges", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
     "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
-    "g2ohip_solve_async", "g2ohip_trial_stats", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
+    "g2ohip_schur_operator_prepare", "g2ohip_schur_operator_apply", "g2ohip_solve_async", "g2ohip_trial_stats", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
     "g2ohip_get_partition", "g2ohip_partition_poses",
     "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
@@ -109,6 +109,8 @@ def load():
         getattr(L, n).argtypes = [vp]
     L.g2ohip_exchange_setup.argtypes = [vp, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_dbl_p]
     L.g2ohip_trial_stats.argtypes = [vp, C.c_double, c_int_p, c_dbl_p, c_dbl_p]
+    L.g2ohip_schur_operator_prepare.argtypes = [vp]
+    L.g2ohip_schur_operator_apply.argtypes = [vp, C.c_void_p, C.c_void_p]
     L.g2ohip_exchange_pack.argtypes = [vp, C.c_int]
     L.g2ohip_exchange_unpack.argtypes = [vp, C.c_int]
     L.g2ohip_vector_size.argtypes = [vp]
@@ -323,6 +325,13 @@ class HipBlockSolver:
 
     def solveReducedFinish(self):
         return _check(self.L.g2ohip_solve_reduced_finish(self.h), "solveReducedFinish") == OK
+
+    def schurOperatorPrepare(self):
+        _check(self.L.g2ohip_schur_operator_prepare(self.h), "schurOperatorPrepare")
+
+    def schurOperatorApply(self, in_ptr, out_ptr):
+        """out = (Hpp + lambda I - Hpl Dinv Hpl') in on raw device pointers (nP * p doubles each)."""
+        _check(self.L.g2ohip_schur_operator_apply(self.h, C.c_void_p(int(in_ptr)), C.c_void_p(int(out_ptr))), "schurOperatorApply")
 
     def solveAsync(self):
         _check(self.L.g2ohip_solve_async(self.h), "solveAsync")

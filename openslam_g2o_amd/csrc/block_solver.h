@@ -179,6 +179,9 @@ class BlockSolver {
   // LM trial without intermediate host round trips: solve_async() queues the whole solve and leaves the status on the
   // device; trial_stats() (after the caller's update / error evaluation) returns that status together with chi2 and
   // computeScale(lambda) = x'(lambda x + b) behind ONE synchronisation
+  // the reduced system as an operator (matrix-free PCG, here and sharded in distributed.py)
+  void schur_operator_prepare();
+  void schur_operator_apply(const double* din, double* dout);
   void solve_async();
   void trial_stats(double lambda, int* ok, double* chi2, double* scale);
   void exchange_setup(int nbb, const int* bblock, const double* hkeep, int nbp, const int* bpose, const double* bkeep, int nh,
@@ -234,6 +237,7 @@ class BlockSolver {
   DevBuf<double> d_mf_l, d_mf_diag, d_mf_zero;
   bool mf_ready_ = false;
   int solve_matrix_free();
+  void mf_prepare_lists();
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
     double f = 0, cx = 0, cy = 0;

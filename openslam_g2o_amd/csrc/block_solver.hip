@@ -2733,71 +2733,98 @@ __global__ void __launch_bounds__(kThreads) mf_diag_kernel(int nP, const int* __
   out[t] = Hpp[(size_t)pp_diag[i] * PD * PD + e] + (r == c ? lam[0] : 0.0) - acc;
 }
 
-int BlockSolver::solve_matrix_free() {
-  if (!schur_) throw StateFailure("linear_solver 2 needs the Schur complement mode");
-  if (chol_opt.world > 1) throw StateFailure("linear_solver 2: one GPU only");
+void BlockSolver::mf_prepare_lists() {
+  if (!schur_) throw StateFailure("the matrix-free reduced operator needs the Schur complement mode");
+  if (mf_ready_) return;
+  mf_ready_ = true;
   const size_t sizeP = (size_t)nP_ * p_;
-  if (!mf_ready_) {   // pose-major view of the Hpl pattern (stored landmark-major)
-    mf_ready_ = true;
-    std::vector<int> ptr(nP_ + 1, 0), qq(pl_row.size()), lm(pl_row.size());
-    for (int r : pl_row) ptr[r + 1]++;
-    for (int i = 0; i < nP_; ++i) ptr[i + 1] += ptr[i];
-    std::vector<int> w(ptr.begin(), ptr.end() - 1);
-    for (int l = 0; l < nL_; ++l)
-      for (int q = pl_colptr[l]; q < pl_colptr[l + 1]; ++q) {
-        const int k = w[pl_row[q]]++;
-        qq[k] = q;
-        lm[k] = l;
-      }
-    if (qq.empty()) { qq.push_back(0); lm.push_back(0); }
-    d_pm_ptr.upload(ptr, st_);
-    d_pm_q.upload(qq, st_);
-    d_pm_lm.upload(lm, st_);
-    d_mf_l.alloc((size_t)std::max(nL_, 1) * l_);
-    d_mf_diag.alloc(sizeP * p_);
-    d_mf_zero.alloc(std::max(sizeP, (size_t)nL_ * l_) + 1);
-    d_mf_zero.zero(st_);
+  // pose-major view of the Hpl pattern (stored landmark-major)
+  std::vector<int> ptr(nP_ + 1, 0), qq(pl_row.size()), lm(pl_row.size());
+  for (int r : pl_row) ptr[r + 1]++;
+  for (int i = 0; i < nP_; ++i) ptr[i + 1] += ptr[i];
+  std::vector<int> w(ptr.begin(), ptr.end() - 1);
+  for (int l = 0; l < nL_; ++l)
+    for (int q = pl_colptr[l]; q < pl_colptr[l + 1]; ++q) {
+      const int k = w[pl_row[q]]++;
+      qq[k] = q;
+      lm[k] = l;
+    }
+  if (qq.empty()) { qq.push_back(0); lm.push_back(0); }
+  d_pm_ptr.upload(ptr, st_);
+  d_pm_q.upload(qq, st_);
+  d_pm_lm.upload(lm, st_);
+  d_mf_l.alloc((size_t)std::max(nL_, 1) * l_);
+  d_mf_diag.alloc(std::max(sizeP * p_, (size_t)1));
+  d_mf_zero.alloc(std::max(sizeP, (size_t)nL_ * l_) + 1);
+  d_mf_zero.zero(st_);
+  pcg_hpp_ = std::make_unique<BlockPCG>(p_);
+  pcg_hpp_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
+}
+
+#define G2OHIP_MF_DISPATCH(BODY)                                                                              \
+  if (p_ == 6 && l_ == 3) { constexpr int P_ = 6, L_ = 3; BODY }                                              \
+  else if (p_ == 3 && l_ == 2) { constexpr int P_ = 3, L_ = 2; BODY }                                         \
+  else if (p_ == 7 && l_ == 3) { constexpr int P_ = 7, L_ = 3; BODY }                                         \
+  else throw ArgFailure("unsupported (pose_dim, landmark_dim) for the matrix-free reduced operator");
+
+// Dinv = (Hll + lam_l I)^-1, bschur = b_p - Hpl Dinv b_l, diagonal blocks of the reduced system (device array 107)
+void BlockSolver::schur_operator_prepare() {
+  require_structure();
+  if (!system_built_) throw StateFailure("schur_operator_prepare before build_system");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  mf_prepare_lists();
+  const size_t sizeP = (size_t)nP_ * p_;
+  const int gl = grid_for(nL_), gp = grid_for(sizeP);
+  G2OHIP_MF_DISPATCH(
+    const int gd = grid_for(sizeP * P_);
+    hipLaunchKernelGGL((landmark_inverse_kernel<L_>), dim3(gl), dim3(kThreads), 0, st_, nL_, d_Hll.p, d_b.p + sizeP, d_Dinv.p, d_db.p,
+                       d_lam.p);
+    hipLaunchKernelGGL((back_substitute_kernel<P_, L_>), dim3(gl), dim3(kThreads), 0, st_, nL_, d_pl_colptr.p, d_pl_row.p, d_Hpl.p,
+                       d_Dinv.p, d_b.p + sizeP, d_mf_zero.p, d_mf_l.p);   // Dinv b_l
+    hipLaunchKernelGGL((mf_pose_kernel<P_, L_>), dim3(gp), dim3(kThreads), 0, st_, nP_, d_pm_ptr.p, d_pm_q.p, d_pm_lm.p, d_Hpl.p,
+                       d_mf_l.p, d_b.p, (const double*)nullptr, d_lam.p, -1.0, d_bschur.p);
+    hipLaunchKernelGGL((mf_diag_kernel<P_, L_>), dim3(gd), dim3(kThreads), 0, st_, nP_, d_pm_ptr.p, d_pm_q.p, d_pm_lm.p, d_Hpl.p,
+                       d_Dinv.p, d_Hpp.p, d_pp_diag.p, d_lam.p, d_mf_diag.p);
+  )
+  hschur_valid_ = false;
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+// dout = (Hpp + lam_p I - Hpl Dinv Hpl') din on device vectors of nP * p doubles (after schur_operator_prepare)
+void BlockSolver::schur_operator_apply(const double* din, double* dout) {
+  if (!mf_ready_) throw StateFailure("schur_operator_apply before schur_operator_prepare");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  const size_t sizeP = (size_t)nP_ * p_;
+  const int gl = grid_for(nL_), gp = grid_for(sizeP);
+  pcg_hpp_->multiply(d_Hpp.p, din, dout, st_);
+  G2OHIP_MF_DISPATCH(
+    hipLaunchKernelGGL((back_substitute_kernel<P_, L_>), dim3(gl), dim3(kThreads), 0, st_, nL_, d_pl_colptr.p, d_pl_row.p, d_Hpl.p,
+                       d_Dinv.p, d_mf_zero.p, din, d_mf_l.p);   // -Dinv Hpl' d
+    hipLaunchKernelGGL((mf_pose_kernel<P_, L_>), dim3(gp), dim3(kThreads), 0, st_, nP_, d_pm_ptr.p, d_pm_q.p, d_pm_lm.p, d_Hpl.p,
+                       d_mf_l.p, dout, din, d_lam.p, 1.0, dout);
+  )
+}
+#undef G2OHIP_MF_DISPATCH
+
+int BlockSolver::solve_matrix_free() {
+  if (chol_opt.world > 1) throw StateFailure("linear_solver 2 inside the library: one GPU (the sharded form lives in distributed.py)");
+  mf_prepare_lists();
+  if (!pcg_mf_) {
     pcg_mf_ = std::make_unique<BlockPCG>(p_);
     pcg_mf_->analyze_operator(nP_, st_);
-    pcg_hpp_ = std::make_unique<BlockPCG>(p_);
-    pcg_hpp_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
   }
   pcg_mf_->opt = pcg_opt;
   if (profiling) tn_.start(st_);
   prof.begin(KernelProf::kCholFactor, st_);
-  bool ok = false;
-#define G2OHIP_MF(P_, L_)                                                                                                        \
-  if (p_ == P_ && l_ == L_) {                                                                                                    \
-    const int gl = grid_for(nL_), gp = grid_for(sizeP), gd = grid_for(sizeP * P_);                                               \
-    hipLaunchKernelGGL((landmark_inverse_kernel<L_>), dim3(gl), dim3(kThreads), 0, st_, nL_, d_Hll.p, d_b.p + sizeP, d_Dinv.p,     \
-                       d_db.p, d_lam.p);                                                                                         \
-    /* bschur = b_p - Hpl (Dinv b_l) */                                                                                          \
-    hipLaunchKernelGGL((back_substitute_kernel<P_, L_>), dim3(gl), dim3(kThreads), 0, st_, nL_, d_pl_colptr.p, d_pl_row.p, d_Hpl.p, \
-                       d_Dinv.p, d_b.p + sizeP, d_mf_zero.p, d_mf_l.p);                                                          \
-    hipLaunchKernelGGL((mf_pose_kernel<P_, L_>), dim3(gp), dim3(kThreads), 0, st_, nP_, d_pm_ptr.p, d_pm_q.p, d_pm_lm.p, d_Hpl.p,   \
-                       d_mf_l.p, d_b.p, (const double*)nullptr, d_lam.p, -1.0, d_bschur.p);                                       \
-    hipLaunchKernelGGL((mf_diag_kernel<P_, L_>), dim3(gd), dim3(kThreads), 0, st_, nP_, d_pm_ptr.p, d_pm_q.p, d_pm_lm.p, d_Hpl.p,   \
-                       d_Dinv.p, d_Hpp.p, d_pp_diag.p, d_lam.p, d_mf_diag.p);                                                    \
-    auto apply = [&](const double* din, double* dout) {                                                                          \
-      pcg_hpp_->multiply(d_Hpp.p, din, dout, st_);                                                                               \
-      hipLaunchKernelGGL((back_substitute_kernel<P_, L_>), dim3(gl), dim3(kThreads), 0, st_, nL_, d_pl_colptr.p, d_pl_row.p,       \
-                         d_Hpl.p, d_Dinv.p, d_mf_zero.p, din, d_mf_l.p);   /* -Dinv Hpl' d */                                     \
-      hipLaunchKernelGGL((mf_pose_kernel<P_, L_>), dim3(gp), dim3(kThreads), 0, st_, nP_, d_pm_ptr.p, d_pm_q.p, d_pm_lm.p, d_Hpl.p, \
-                         d_mf_l.p, dout, din, d_lam.p, 1.0, dout);                                                               \
-    };                                                                                                                           \
-    ok = pcg_mf_->solve_operator(d_mf_diag.p, apply, d_bschur.p, d_x.p, st_);                                                    \
-  } else
-  G2OHIP_MF(6, 3)
-  G2OHIP_MF(3, 2)
-  G2OHIP_MF(7, 3) { throw ArgFailure("unsupported (pose_dim, landmark_dim) for the matrix-free solver"); }
-#undef G2OHIP_MF
+  schur_operator_prepare();
+  auto apply = [&](const double* din, double* dout) { schur_operator_apply(din, dout); };
+  const bool ok = pcg_mf_->solve_operator(d_mf_diag.p, apply, d_bschur.p, d_x.p, st_);
   prof.end(KernelProf::kCholFactor, st_);
   if (profiling) {
     tn_.stop(st_);
     times.numeric = tn_.seconds();
     times.linsolve = 0.0;
   }
-  hschur_valid_ = false;
   pcg_iterations = pcg_mf_->last_iterations();
   return ok ? 0 : 1;
 }
@@ -3338,6 +3365,7 @@ void BlockSolver::device_array(int which, double** ptr, size_t* count) {
     case 104: *ptr = chol_->permuted_solution(count); break;   // x_p in elimination order (masked before the all-reduce)
     case 105: *ptr = ex_.buf1.p; *count = (size_t)std::max(1, ex_.nbb * p_ * p_ + ex_.nbp * p_); break;   // exchange_setup buffers
     case 106: *ptr = ex_.buf3.p; *count = (size_t)ex_.nh * p_ + 1; break;
+    case 107: *ptr = d_mf_diag.p; *count = mf_ready_ ? (size_t)nP_ * p_ * p_ : 0; break;   // schur_operator_prepare: diagonal blocks
     default: throw ArgFailure("bad array selector");
   }
 }

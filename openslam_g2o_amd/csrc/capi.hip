@@ -234,6 +234,21 @@ int g2ohip_solve_reduced_finish(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] { return s->impl->solve_reduced_finish() ? G2OHIP_NOT_PD : G2OHIP_OK; });
 }
+int g2ohip_schur_operator_prepare(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->schur_operator_prepare();
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_schur_operator_apply(g2ohip_solver* s, const double* in_device, double* out_device) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    if (!in_device || !out_device) throw g2ohip::ArgFailure("g2ohip_schur_operator_apply: null vector");
+    s->impl->schur_operator_apply(in_device, out_device);
+    return G2OHIP_OK;
+  });
+}
 int g2ohip_solve_async(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

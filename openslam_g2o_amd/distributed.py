@@ -206,8 +206,9 @@ class ShardedBlockSolver:
         self.exchange = world > 1 or force_exchange   # union Schur pattern + all-reduce step active
         if mode == "auto":
             mode = "subtree" if (world > 1 and local is None) else "replicated"
-        if mode not in ("subtree", "replicated"):
-            raise ValueError("mode must be auto, subtree or replicated")
+        if mode not in ("subtree", "replicated", "pcg"):
+            raise ValueError("mode must be auto, subtree, replicated or pcg")
+        self.pcg_tolerance, self.pcg_max_iterations, self.pcg_check_every, self.pcg_iterations = 1e-6, -1, 8, 0
         self.mode = mode
         if x_exchange not in ("halo", "full"):
             raise ValueError("x_exchange must be halo or full")
@@ -225,6 +226,8 @@ class ShardedBlockSolver:
             return "1 GPU"
         if self.mode == "subtree":
             return "x%d: landmarks by pose owner, boundary-block all-reduce, subtree-distributed Cholesky" % self.world
+        if self.mode == "pcg":
+            return "landmark-range shards x%d, matrix-free PCG, all-reduce(Hschur*d) per iteration" % self.world
         return "landmark-range shards x%d, all-reduce(Hschur,bschur), replicated Cholesky" % self.world
 
     # ------------------------------------------------------------------------------------
@@ -253,7 +256,7 @@ class ShardedBlockSolver:
         else:
             lm0, lm1 = landmark_range(nL, self.world, self.rank)
             my = np.arange(lm0, lm1)
-            if self.exchange:
+            if self.exchange and self.mode != "pcg":
                 rows, cols = schur_pattern_pairs(prob["v1"], lm)
         loc = np.full(nL, -1, np.int64)
         loc[my] = np.arange(len(my))
@@ -265,7 +268,7 @@ class ShardedBlockSolver:
         self.lm_index = my                      # global landmark id of every local landmark
         self.edge_mask = mine
         self.set_id = self.local.addEdgeSet(2, v0, v1)
-        if self.exchange:
+        if self.exchange and self.mode != "pcg":   # (the matrix-free mode never forms Hschur: no union pattern needed)
             self.local.addSchurPattern(rows, cols)
         if self.mode == "subtree":
             self.local.setPartition(self.rank, self.world)
@@ -471,7 +474,56 @@ class ShardedBlockSolver:
         self.local.solveBackSubstitute()
         return True
 
+    def _solve_pcg(self):
+        """LinearSolverPCG's iteration (linear_solver_pcg.hpp:79-196, block-Jacobi, relative tolerance) on the reduced system
+        with landmarks sharded over the ranks and Hschur never formed: every rank applies ITS summand
+        (Hpp_r + lambda_r I - Hpl_r Dinv_r Hpl_r') d (g2ohip_schur_operator_apply), one all-reduce per iteration makes it the
+        full product; bschur and the preconditioner blocks are summed once per solve.  Vectors are torch tensors on the
+        solver's stream; the scalars stay on the device, the host looks at the residual every pcg_check_every iterations."""
+        import torch
+        from . import capi
+        L, p, nP = self.local, self.p, self.local.nP
+        L.schurOperatorPrepare()
+        b = self._device_tensor(capi.ARR_BSCHUR)
+        D = self._device_tensor(capi.ARR_SCHUR_DIAG)
+        self.comm.all_reduce_sum([b, D])
+        J = torch.linalg.inv(D.view(nP, p, p).transpose(1, 2)).contiguous()      # (blocks are stored column-major)
+        x = self._device_tensor(capi.ARR_X)[:nP * p]
+        x.zero_()
+        r = b.clone()
+        d = torch.bmm(J, r.view(nP, p, 1)).view(-1)
+        q = torch.empty_like(d)
+        dn = torch.dot(r, d)
+        d0 = float(self.pcg_tolerance * dn.item())
+        max_iter = self.pcg_max_iterations if self.pcg_max_iterations > 0 else nP * p
+        it, ok = 0, True
+        while it < max_iter:
+            L.schurOperatorApply(d.data_ptr(), q.data_ptr())
+            self.comm.all_reduce_sum([q])
+            alpha = dn / torch.dot(d, q)
+            x.add_(alpha * d)
+            r.sub_(alpha * q)
+            s = torch.bmm(J, r.view(nP, p, 1)).view(-1)
+            dold = dn
+            dn = torch.dot(r, s)
+            d = s + (dn / dold) * d
+            it += 1
+            if it % self.pcg_check_every == 0 or it == max_iter:
+                v = float(dn.item())
+                if not np.isfinite(v):
+                    ok = False
+                    break
+                if v <= d0:
+                    break
+        self.pcg_iterations = it
+        if not ok:
+            return False
+        L.solveBackSubstitute()
+        return True
+
     def solve(self):
+        if self.mode == "pcg":
+            return self._solve_pcg()
         if self.mode == "subtree":
             return self._solve_subtree()
         if not self.exchange:

@@ -87,3 +87,54 @@ def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused, x_exch
         assert int(z["boundary"]) < 0.25 * int(z["nnzb"])                     # most Schur blocks never leave their rank
         edges += int(z["E_local"])
     assert (seen == 1).all() and edges == pr["E"]
+
+
+def _pcg_worker(rank, world, port, P, L, lam, out_dir):
+    import torch
+    import torch.distributed as dist
+    from openslam_g2o_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        pr = ba_case(P, L)
+        s = D.ShardedBlockSolver(6, 3, rank=rank, world=world, comm=D.HostStagedComm(world), mode="pcg")
+        s.pcg_tolerance, s.pcg_max_iterations = 1e-20, 8000
+        s.setup_ba(pr, torch_device=dev, fused=True)
+        s.buildSystem()
+        chi = s.chi2()
+        s.setLambda(lam, True)
+        ok = s.solve()
+        s.restoreDiagonal()
+        np.savez(os.path.join(out_dir, "p%d.npz" % rank), ok=ok, xp=s.x_poses(), xl=s.x_landmarks_local(), lm_index=s.lm_index,
+                 chi2=chi, iters=s.pcg_iterations)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_matrix_free_pcg_matches_oracle(tmp_path, world):
+    """mode "pcg": landmarks sharded by range, the reduced system never formed, every rank applies its summand of
+    Hschur*d and one all-reduce per iteration completes it (exchange staged through gloo: the ranks share one GPU)."""
+    import torch.multiprocessing as mp
+    P, L, lam = 150, 1800, 20.0
+    mp.spawn(_pcg_worker, args=(world, _free_port(), P, L, lam, str(tmp_path)), nprocs=world, join=True)
+    pr = ba_case(P, L)
+    o = oracle_ba(pr)
+    o.build_system()
+    chi2 = o.chi2()
+    o.set_lambda(lam, True)
+    assert o.solve()
+    x = o.x()
+    nP = pr["nP"]
+    xp, xl = x[:6 * nP], x[6 * nP:].reshape(-1, 3)
+    its = []
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "p%d.npz" % r))
+        assert bool(z["ok"]) and abs(float(z["chi2"]) - chi2) <= 1e-9 * chi2
+        assert np.abs(z["xp"] - xp).max() <= 1e-6 * np.abs(xp).max()             # x_p replicated
+        assert np.abs(z["xl"].reshape(-1, 3) - xl[z["lm_index"]]).max() <= 1e-6 * np.abs(xl).max()
+        its.append(int(z["iters"]))
+    assert len(set(its)) == 1 and its[0] > 0                                      # every rank took the same decisions
