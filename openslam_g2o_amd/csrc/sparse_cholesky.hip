@@ -16,6 +16,11 @@ constexpr int kFactorThreads = 256;
 constexpr int kFwdChildren = 4;   // fused forward sweep: children per front handled by the factor kernel
 constexpr int kFactorThreadsGlobal = 512;
 constexpr int kChainU = 6;  // doubles per thread that carry an update matrix from one chain front to the next
+// register-resident wave kernel (wave_front.inc): limits of a front
+constexpr int kWvNPV = 24;             // pivot columns (scalars)
+constexpr int kWvNTL = 3;              // 16-row tiles of boundary rows (48 rows)
+constexpr int kWvKS = kWvNPV / 4;      // MFMA k-steps
+constexpr int kWvTiles = kWvNTL * (kWvNTL + 1) / 2;
 
 // =====================================================================================
 // Host: nested dissection on the block graph (George-Liu automatic nested dissection:
@@ -649,8 +654,21 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       LevelLaunch& LL = launches_[ph][l];
       LL.lds_begin = (int)S.level_fronts.size();
       LL.lds_count = (int)lds[l].size();
+      // levels whose fronts all fit the register-resident wave kernel (wave_front.inc): <= kWvNPV pivot columns,
+      // <= 16 kWvNTL boundary rows, <= kFwdChildren children
+      LL.wv = opt.wave_kernel != 0 && glb[l].empty() && !lds[l].empty();
+      for (int t : lds[l]) {
+        if (!LL.wv) break;
+        for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1] && LL.wv; ++k) {
+          const int f = S.task_fronts[k];
+          const int npv = S.f_ns[f] * bs, nbr = S.f_nb[f] * bs;
+          if (npv > kWvNPV || nbr > 16 * kWvNTL || S.child_off[f + 1] - S.child_off[f] > kFwdChildren) LL.wv = false;
+          LL.wv_pn = std::max(LL.wv_pn, (npv + nbr) * npv);
+        }
+      }
+      LL.wv_pn = std::max(LL.wv_pn, kWvNTL * kWvKS * 64);
       // wide launches run two waves per front (see front_factor_kernel); *_max_m = packed doubles of the largest front
-      if (opt.wave_front_tasks > 0 && LL.lds_count >= opt.wave_front_tasks) LL.sm_count = LL.lds_count;
+      if (!LL.wv && opt.wave_front_tasks > 0 && LL.lds_count >= opt.wave_front_tasks) LL.sm_count = LL.lds_count;
       for (int i = 0; i < (int)lds[l].size(); ++i) {
         const int t = lds[l][i];
         S.level_fronts.push_back(t);
@@ -781,6 +799,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           for (int c = 0; c < R.child_cnt && ok; ++c) ok = cdesc[R.child_off + c].nbc * bs <= nthr;
           if (!ok) LL.fuse_fwd = false;
         }
+        if (q < LL.glb_begin) LL.wv_idx_ints = std::max(LL.wv_idx_ints, (2 + kVirtInts) * R.asm_cnt + R.cmap_cnt + R.crel_cnt);
         if (q < LL.lds_begin + LL.sm_count) LL.sm_idx_ints = std::max(LL.sm_idx_ints, (2 + kVirtInts) * R.asm_cnt + R.cmap_cnt + R.tri_cnt + R.crel_cnt);
         else if (q < LL.glb_begin) LL.lds_idx_ints = std::max(LL.lds_idx_ints, (2 + kVirtInts) * R.asm_cnt + R.cmap_cnt + R.tri_cnt + R.crel_cnt);
         else LL.glb_idx_ints = std::max(LL.glb_idx_ints, (2 + kVirtInts) * R.asm_cnt);
@@ -852,13 +871,13 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     for (int l = 0; l < nlev;) {
       FactorGroup G{launches_[ph][l], l, l, false};
       int l1 = l + 1;
-      const bool sm = G.LL.sm_count > 0;
+      const bool sm = G.LL.sm_count > 0, wv = G.LL.wv;
       auto plain = [](const LevelLaunch& X) { return X.glb_count == 0 && X.lds_count > 0 && X.fuse_fwd; };
       if (opt.dep_levels > 1 && nf < (1 << 24) && plain(G.LL)) {
         int end = G.LL.lds_begin + G.LL.lds_count;
         while (l1 < nlev && l1 - l < opt.dep_levels) {
           const LevelLaunch& N = launches_[ph][l1];
-          if (!plain(N) || (N.sm_count > 0) != sm || N.lds_begin != end) break;
+          if (!plain(N) || (N.sm_count > 0) != sm || N.wv != wv || N.lds_begin != end) break;
           end += N.lds_count;
           ++l1;
         }
@@ -896,6 +915,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
             }
             G.LL.max_m = std::max(G.LL.max_m, N.max_m);
             G.LL.max_panel = std::max(G.LL.max_panel, N.max_panel);
+            G.LL.wv_pn = std::max(G.LL.wv_pn, N.wv_pn);
+            G.LL.wv_idx_ints = std::max(G.LL.wv_idx_ints, N.wv_idx_ints);
           }
           G.LL.glb_begin = G.LL.lds_begin + G.LL.lds_count;
           for (auto& w : waits) recs[w.first].pad[1] |= w.second << 24;
@@ -2391,6 +2412,8 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
   if (i < n) x[i] *= mask[i];
 }
 
+#include "wave_front.inc"
+
 struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one level (LevelLaunch::ba_* / be_pass / tr_*)
   bool ok;
   const int4* chunks;
@@ -2404,7 +2427,12 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
                          int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, int wcap,
                          const double* bperm, double* yout, int dep, const int4* big_tiles, int bt_count, const BigLaunch& big,
-                         int wide_doubles, hipStream_t st) {
+                         int wide_doubles, bool wv, int wv_pn, int wv_idx_ints, hipStream_t st) {
+  if (wv) {   // every front of the launch fits the register-resident wave kernel: one wavefront per task
+    const size_t sh = ((size_t)wv_pn + kWvTiles * 256 + 2 * (size_t)wcap) * sizeof(double) + (size_t)(wv_idx_ints + 4) * sizeof(int);
+    hipLaunchKernelGGL((wave_front_kernel<BS, VIRT>), dim3(lds_count), dim3(64), sh, st, P, lds_begin, dA, bperm, yout, dep, wv_pn, wcap);
+    return;
+  }
   if (sm_count > 0) {   // wide launch: two waves per front
     const int idx_off = sm_max_m + 2 * wcap + 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(sm_idx_ints + 4) * sizeof(int);
@@ -2499,7 +2527,8 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   launch_factor_level<BS_, V_>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m, \
                                LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m,            \
                                LL.sm_idx_ints, LL.max_m, fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr,   \
-                               dep ? 1 : 0, d_big_tiles.p + LL.bt_begin, LL.bt_count, big, opt.wide_front_doubles, st)
+                               dep ? 1 : 0, d_big_tiles.p + LL.bt_begin, LL.bt_count, big, opt.wide_front_doubles, LL.wv, LL.wv_pn,   \
+                               LL.wv_idx_ints, st)
   switch (bs_) {
     case 3:
       if (virt) G2OHIP_FACTOR_LEVEL(3, true); else G2OHIP_FACTOR_LEVEL(3, false);
