@@ -16,7 +16,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libg2ohip.so")
+# G2OHIP_LIB: an instrumented build of the same sources (make VARIANT=...), for the profiling tools only
+LIB_PATH = os.environ.get("G2OHIP_LIB") or os.path.join(_HERE, "lib", "libg2ohip.so")
 
 c_int_p = C.POINTER(C.c_int32)
 c_dbl_p = C.POINTER(C.c_double)

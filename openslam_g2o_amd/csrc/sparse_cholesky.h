@@ -115,12 +115,14 @@ struct CholPlanDev {
   // virtual source (set_virtual_blocks): per assembly entry the base block (-1: none), pos with bit 31 = diagonal
   // block, and kVirtInts ints (count, three partial slots, first index into vslots)
   const int *asm_vq, *asm_vpos, *asm_v, *vslots;
+  const int* asm_r8;   // the same per assembly entry as ONE 32-byte record (base, pos, count, three partial slots, first list index, 0): wave kernel, scalar loads
   const double *vbase, *vparts, *vlam;
   int vsplit;
   int* status;
   int* ready;        // dependency-driven launches: children finished so far, per front
   int dep_spin_limit;
   long long* dbg;   // G2OHIP_CHOL_STAMPS builds only: per-launch wall-clock stamps of workgroup 0
+  long long* tl;    // ... and (start, end) wall-clock of every workgroup of the wave-kernel launch
 };
 
 class SparseCholesky {
@@ -219,7 +221,7 @@ class SparseCholesky {
   DevBuf<double> d_xbuf, d_xmask;
   DevBuf<long long> d_dbg;
   DevBuf<int2> d_slots, d_fslots, d_bslots;
-  DevBuf<int> d_asm_vq, d_asm_vpos, d_asm_v;
+  DevBuf<int> d_asm_vq, d_asm_vpos, d_asm_v, d_asm_r8;
   DevBuf<int4> d_big_tiles;
   int n_slots_ = 0;
   bool dep_off_ = false, dep_stalled_ = false;

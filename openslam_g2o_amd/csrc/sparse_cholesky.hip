@@ -19,8 +19,8 @@ constexpr int kChainU = 6;  // doubles per thread that carry an update matrix fr
 // register-resident wave kernel (wave_front.inc): limits of a front
 constexpr int kWvNPV = 24;             // pivot columns (scalars)
 constexpr int kWvNTL = 3;              // 16-row tiles of boundary rows (48 rows)
-constexpr int kWvKS = kWvNPV / 4;      // MFMA k-steps
-constexpr int kWvTiles = kWvNTL * (kWvNTL + 1) / 2;
+constexpr int kWvT = (kWvNPV + 16 * kWvNTL + 1 + 15) / 16;   // 16 x 16 tiles per side of the front incl. the right-hand side row
+constexpr int kWvTiles = kWvT * (kWvT + 1) / 2;
 
 // =====================================================================================
 // Host: nested dissection on the block graph (George-Liu automatic nested dissection:
@@ -663,10 +663,13 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           const int f = S.task_fronts[k];
           const int npv = S.f_ns[f] * bs, nbr = S.f_nb[f] * bs;
           if (npv > kWvNPV || nbr > 16 * kWvNTL || S.child_off[f + 1] - S.child_off[f] > kFwdChildren) LL.wv = false;
-          LL.wv_pn = std::max(LL.wv_pn, (npv + nbr) * npv);
+          if (S.asm_off[f + 1] - S.asm_off[f] > 64) LL.wv = false;   // (one table entry per lane)
+          for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) {
+            const int nbc = S.f_nb[S.children[ch]];
+            if (nbc * (nbc + 1) / 2 > 64) LL.wv = false;
+          }
         }
       }
-      LL.wv_pn = std::max(LL.wv_pn, kWvNTL * kWvKS * 64);
       // wide launches run two waves per front (see front_factor_kernel); *_max_m = packed doubles of the largest front
       if (!LL.wv && opt.wave_front_tasks > 0 && LL.lds_count >= opt.wave_front_tasks) LL.sm_count = LL.lds_count;
       for (int i = 0; i < (int)lds[l].size(); ++i) {
@@ -955,6 +958,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           l1 = l + 1;
         }
       }
+      if (getenv("G2OHIP_PLAN_DUMP"))
+        fprintf(stderr, "phase %d group: levels %d..%d tasks %d dep %d sm %d wv %d (pn %d idx %d)\n", ph, G.first_level, G.last_level, G.LL.lds_count + G.LL.glb_count,
+                (int)G.dep, G.LL.sm_count, (int)G.LL.wv, G.LL.wv_pn, G.LL.wv_idx_ints);
       groups_[ph].push_back(G);
       l = l1;
     }
@@ -1082,6 +1088,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.ready = d_ready.p;
   plan_.dep_spin_limit = opt.dep_spin_limit;
   plan_.dbg = nullptr;
+  plan_.tl = nullptr;
   plan_.slots = d_slots.p;
   analyzed_ = !host_only;
   stats_.t_symbolic = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -2429,8 +2436,8 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
                          const double* bperm, double* yout, int dep, const int4* big_tiles, int bt_count, const BigLaunch& big,
                          int wide_doubles, bool wv, int wv_pn, int wv_idx_ints, hipStream_t st) {
   if (wv) {   // every front of the launch fits the register-resident wave kernel: one wavefront per task
-    const size_t sh = ((size_t)wv_pn + kWvTiles * 256 + 2 * (size_t)wcap) * sizeof(double) + (size_t)(wv_idx_ints + 4) * sizeof(int);
-    hipLaunchKernelGGL((wave_front_kernel<BS, VIRT>), dim3(lds_count), dim3(64), sh, st, P, lds_begin, dA, bperm, yout, dep, wv_pn, wcap);
+    const size_t sh = ((size_t)kWvTiles * 256 + 64 + 2 * kWvT * 64 + 64) * sizeof(double) + (size_t)(2 * 16 * kWvT + 64) * sizeof(int);
+    hipLaunchKernelGGL((wave_front_kernel<BS, VIRT>), dim3(lds_count), dim3(64 * kWvWaves), sh, st, P, lds_begin, dA, bperm, yout, dep);
     return;
   }
   if (sm_count > 0) {   // wide launch: two waves per front
@@ -2497,6 +2504,17 @@ void SparseCholesky::set_virtual_blocks(const VirtualBlocks& vb, hipStream_t st)
     vq.push_back(-1);
     vpos.push_back(0);
     v.resize(kVirtInts, 0);
+  }
+  {
+    std::vector<int> r8(vq.size() * 8, 0);
+    for (size_t e = 0; e < vq.size(); ++e) {
+      int* r = &r8[e * 8];
+      r[0] = vq[e];
+      r[1] = vpos[e];
+      for (int j = 0; j < kVirtInts; ++j) r[2 + j] = v[e * kVirtInts + j];
+    }
+    d_asm_r8.upload(r8, st);
+    plan_.asm_r8 = d_asm_r8.p;
   }
   d_asm_vq.upload(vq, st);
   d_asm_vpos.upload(vpos, st);
@@ -2573,8 +2591,9 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
   if (phase == 0) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
 #ifdef G2OHIP_CHOL_STAMPS
   if (phase == 0) {
-    if (!d_dbg.p) d_dbg.alloc(64 * 64);
+    if (!d_dbg.p) d_dbg.alloc(64 * 64 + 2 * (size_t)n_slots_ + 2);
     G2OHIP_HIP_CHECK(hipMemsetAsync(d_dbg.p, 0, 64 * 64 * sizeof(long long), st));
+    plan_.tl = d_dbg.p + 64 * 64;
     dbg_launch_ = 0;
   }
 #endif
@@ -2698,6 +2717,14 @@ void SparseCholesky::mask_solution(hipStream_t st) {
 
 bool SparseCholesky::failed(hipStream_t st) {
 #ifdef G2OHIP_CHOL_STAMPS
+  if (d_dbg.p && getenv("G2OHIP_CHOL_TIMELINE")) {   // (start, end) of every workgroup of the last wave-kernel launch, 10 ns ticks
+    std::vector<long long> h(64 * 64 + 2 * (size_t)n_slots_);
+    d_dbg.download(h.data(), h.size(), st);
+    if (FILE* fp = fopen(getenv("G2OHIP_CHOL_TIMELINE"), "w")) {
+      for (int q = 0; q < n_slots_; ++q) fprintf(fp, "%d %lld %lld\n", q, h[64 * 64 + 2 * q], h[64 * 64 + 2 * q + 1]);
+      fclose(fp);
+    }
+  }
   if (d_dbg.p && getenv("G2OHIP_CHOL_STAMPS_PRINT")) {
     std::vector<long long> h(64 * 64);
     d_dbg.download(h.data(), h.size(), st);
