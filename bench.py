@@ -69,41 +69,61 @@ def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2, folded=False):
     return kb, stage
 
 
-def cpu_baseline(prob, lam, want_x=True, include_linearize=True):
-    """The oracle (CPU restatement of the reference path, 1 thread = the reference's default
-    build) timed on this host for ONE full iteration of the same workload."""
+def cpu_baseline(prob, lam, want_x=True, include_linearize=True, omp=False, reps=3):
+    """The oracle (CPU restatement of the reference path) timed on this host for `reps` full iterations of the
+    same workload; medians per stage.  omp=False: one thread = the reference's default build (G2O_USE_OPENMP OFF,
+    CMakeLists.txt:137); omp=True: the reference's optional OpenMP regions (buildSystem over edges,
+    block_solver.hpp:527; Schur complement over landmarks, :379) on every host core -- the sparse Cholesky stays
+    serial there too (CSparse)."""
     from oracle import oracle as O
-    from openslam_g2o_amd import synthetic as S
-    o = O.OracleSolver(6, 3, prob["nP"], prob["nL"], True)
+    o = O.OracleSolver(6, 3, prob["nP"], prob["nL"], True, omp=omp)
     k = o.add_edge_set(2, prob["v0"], prob["v1"])
     o.set_dims(k, 3, 6)
     t0 = time.perf_counter()
     o.build_structure()
     t_struct = time.perf_counter() - t0
-    t_lin = 0.0
-    if include_linearize:     # the reference's buildSystem runs linearizeOplus per edge (block_solver.hpp:531)
+    t_asm, t_solve, t_schur, t_lin, t_num = [], [], [], [], []
+    ok = True
+    for rep in range(reps + 1):            # rep 0 carries the one-time ordering + symbolic step: not counted
+        tl = 0.0
+        if include_linearize:              # the reference's buildSystem runs linearizeOplus per edge (block_solver.hpp:531)
+            t0 = time.perf_counter()
+            Jp, Jc, err = O.ba_edges(prob["cams"], prob["pts"], prob["cam_idx"], prob["pt_idx"], prob["meas"], prob["f"],
+                                     prob["cx"], prob["cy"], omp=omp)
+            tl = time.perf_counter() - t0
+            o.set_edge_data(k, Jp, Jc, prob["omega"], err)
+        elif rep == 0:
+            o.set_edge_data(k, prob["Jp"], prob["Jc"], prob["omega"], prob["err"])
         t0 = time.perf_counter()
-        Jp, Jc, err = O.ba_edges(prob["cams"], prob["pts"], prob["cam_idx"], prob["pt_idx"], prob["meas"], prob["f"], prob["cx"], prob["cy"])
-        t_lin = time.perf_counter() - t0
-        o.set_edge_data(k, Jp, Jc, prob["omega"], err)
-    else:
-        o.set_edge_data(k, prob["Jp"], prob["Jc"], prob["omega"], prob["err"])
-    t0 = time.perf_counter()
-    o.build_system()
-    t_asm = time.perf_counter() - t0 + t_lin
+        o.build_system()
+        ta = time.perf_counter() - t0 + tl
+        o.set_lambda(lam, True)
+        t0 = time.perf_counter()
+        ok = o.solve() and ok              # Schur + numeric Cholesky + back-substitution
+        ts = time.perf_counter() - t0
+        o.restore_diagonal()
+        if rep > 0:
+            tt = o.times()
+            t_asm.append(ta); t_solve.append(ts); t_schur.append(tt["schur"]); t_lin.append(tt["linear"]); t_num.append(tt["numeric"])
+    med = lambda v: float(np.median(v))
+    out = dict(ok=bool(ok), t_structure=t_struct, t_assembly=med(t_asm), t_solve=med(t_solve), t_schur=med(t_schur),
+               t_linear=med(t_lin), t_numeric=med(t_num), lnz=o.lnz(), reps=reps, threads=o.L.orc_num_threads(),
+               spread=float((max(a + b for a, b in zip(t_asm, t_solve)) - min(a + b for a, b in zip(t_asm, t_solve))) /
+                            np.median([a + b for a, b in zip(t_asm, t_solve)])))
     o.set_lambda(lam, True)
-    t0 = time.perf_counter()
-    ok = o.solve()                      # includes the one-time ordering + symbolic step
-    t_first = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ok = o.solve() and ok               # steady state: Schur + numeric Cholesky + back-substitution
-    t_solve = time.perf_counter() - t0
-    o.restore_diagonal()
-    tt = o.times()
-    out = dict(ok=bool(ok), t_structure=t_struct, t_assembly=t_asm, t_solve=t_solve, t_solve_first=t_first,
-               t_schur=tt["schur"], t_linear=tt["linear"], t_numeric=tt["numeric"], lnz=o.lnz())
     x = o.x() if want_x else None
+    o.restore_diagonal()
     return out, x
+
+
+def host_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -308,13 +328,22 @@ def main():
     if world == 1 and not emulate and not args.no_cpu_baseline:
         cb, x_cpu = cpu_baseline(prob, lam, include_linearize=fused)
         cpu_ms = 1e3 * (cb["t_assembly"] + cb["t_solve"])
+        cbo, _ = cpu_baseline(prob, lam, want_x=False, include_linearize=fused, omp=True)
+        omp_ms = 1e3 * (cbo["t_assembly"] + cbo["t_solve"])
         out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms/iter", "cores": 1, "kind": "port",
-                               "sample": "1 full iteration of the same %d-pose workload (assembly %.0f ms + solve %.0f ms; "
-                                         "one-time structure %.1f s and ordering/symbolic excluded)" % (
-                                             P, 1e3 * cb["t_assembly"], 1e3 * cb["t_solve"], cb["t_structure"]),
+                               "sample": "median of %d full iterations of the same %d-pose workload, one thread = the reference's "
+                                         "default build (assembly %.0f ms + solve %.0f ms, spread %.1f %%; one-time structure %.1f s "
+                                         "and ordering/symbolic excluded)" % (
+                                             cb["reps"], P, 1e3 * cb["t_assembly"], 1e3 * cb["t_solve"], 100 * cb["spread"], cb["t_structure"]),
                                "breakdown_ms": {"assembly": 1e3 * cb["t_assembly"], "schur": 1e3 * cb["t_schur"],
                                                 "linear_solver": 1e3 * cb["t_linear"], "numeric_cholesky": 1e3 * cb["t_numeric"]},
-                               "choleskyNNZ": cb["lnz"]}
+                               "choleskyNNZ": cb["lnz"], "host": host_model(), "host_cores": os.cpu_count(),
+                               "best_cpu": {"value": omp_ms, "unit": "ms/iter", "cores": cbo["threads"], "kind": "port",
+                                            "sample": "median of %d iterations with the reference's optional OpenMP regions on "
+                                                      "(buildSystem over edges, Schur complement over landmarks; the sparse Cholesky "
+                                                      "is serial in the reference too)" % cbo["reps"],
+                                            "breakdown_ms": {"assembly": 1e3 * cbo["t_assembly"], "schur": 1e3 * cbo["t_schur"],
+                                                             "linear_solver": 1e3 * cbo["t_linear"]}}}
         out["speedup_vs_cpu"] = cpu_ms / ms
         nx = np.abs(x_cpu).max()
         out["dx_rel_err"] = float(np.abs(x_gpu - x_cpu).max() / nx)

@@ -202,10 +202,11 @@ int g2ohip_copy_values(g2ohip_solver* s, int which, double* values_host);
  * which = G2OHIP_HSCHUR (values), or 100 = bschur. */
 int g2ohip_device_array(g2ohip_solver* s, int which, double** ptr, size_t* count);
 /* BlockSolver::computeMarginals / LinearSolver::solvePattern (block_solver.hpp:489-498, linear_solver.h:63-69,
- * marginal_covariance_cholesky.cpp:71-220): blocks (rows[i], cols[i]) (pose block indices) of the inverse of the
- * system the linear solver factorises -- Hpp without Schur, the reduced pose system with it (pose marginals with the
- * landmarks integrated out) -- with the current damping.  out [n][p*p], column-major blocks.  After
- * g2ohip_build_system.  G2OHIP_OK | G2OHIP_NOT_PD. */
+ * marginal_covariance_cholesky.cpp:71-220): blocks (rows[i], cols[i]) (pose block indices) of the inverse of Hpp
+ * with the current damping -- what the reference hands to solvePattern (`*_Hpp`, block_solver.hpp:492), also when
+ * the Schur complement is on.  Option "marginals_reduced" = 1 (g2ohip_set_option) inverts the reduced pose system
+ * instead: the pose marginals with the landmarks integrated out (a deviation from the reference, off by default).
+ * out [n][p*p], column-major blocks.  After g2ohip_build_system.  G2OHIP_OK | G2OHIP_NOT_PD. */
 int g2ohip_compute_marginals(g2ohip_solver* s, int n_blocks, const int32_t* rows, const int32_t* cols, double* out);
 /* The per-edge data the next g2ohip_build_system will consume, copied to the host (inspection / tests of the
  * device-side producers): J0 [n][d*dim0], J1 [n][d*dim1], err [n][d]; any pointer may be NULL. */

@@ -208,6 +208,9 @@ class BlockSolver {
   std::vector<int> rd_cnt_h_, rd_ptr_h_, rd_slot_h_, hs_src_h_, hs_diag_h_;
   DevBuf<int> d_pose_diag;                 // pose -> its diagonal block of the reduced system
   bool hschur_valid_ = true, virt_now_ = false;
+ public:
+  bool marginals_reduced = false;   // compute_marginals: invert the reduced pose system instead of Hpp alone (the reference inverts Hpp)
+ private:
   hipStream_t side_ = nullptr;
   hipEvent_t side_fork_ = nullptr, side_join_ = nullptr;
   DevBuf<double> d_red_multi;              // trial_stats: partial sums of every reduction of the call

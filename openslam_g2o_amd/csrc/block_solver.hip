@@ -3293,6 +3293,19 @@ __global__ void set_unit_kernel(double* __restrict__ v, size_t n, size_t k) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < n) v[i] = (i == k) ? 1.0 : 0.0;
 }
+// Hpp (+ lambda on the diagonal of the diagonal blocks) laid out on the pattern of Hschur, which the factorisation was
+// analysed for (a superset of Hpp's pattern): the matrix BlockSolver::computeMarginals hands to solvePattern
+__global__ void hpp_on_schur_pattern_kernel(size_t n, int bb, int pd, const int* __restrict__ hs_src, const int* __restrict__ hs_diag,
+                                            const double* __restrict__ Hpp, const double* __restrict__ lam, double* __restrict__ Hs) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int d = (int)(t / bb), e = (int)(t % bb);
+  const int src = hs_src[d];
+  double v = src >= 0 ? Hpp[(size_t)src * bb + e] : 0.0;
+  if (hs_diag[d] >= 0 && e % (pd + 1) == 0) v += lam[0];
+  Hs[t] = v;
+}
+
 int BlockSolver::compute_marginals(int n, const int* rows, const int* cols, double* out) {
   require_structure();
   if (!system_built_) throw StateFailure("compute_marginals before build_system");
@@ -3300,7 +3313,17 @@ int BlockSolver::compute_marginals(int n, const int* rows, const int* cols, doub
   for (int i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= nP_ || cols[i] < 0 || cols[i] >= nP_) throw ArgFailure("compute_marginals: block index out of range");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  if (schur_) solve_schur_impl(true);   // (re)forms the reduced system with the current damping
+  // Reference behaviour (block_solver.hpp:489-493): solvePattern(spinv, blockIndices, *_Hpp) -- the inverse of Hpp
+  // ALONE, also when the Schur complement is on.  Option "marginals_reduced" = 1 inverts the reduced pose system
+  // instead (the pose marginals with the landmarks integrated out).
+  if (schur_ && marginals_reduced) {
+    solve_schur_impl(true);   // (re)forms the reduced system with the current damping
+  } else if (schur_) {
+    const size_t ne = hs_row.size() * (size_t)p_ * p_;
+    hipLaunchKernelGGL(hpp_on_schur_pattern_kernel, dim3(grid_for(ne)), dim3(kThreads), 0, st_, ne, p_ * p_, p_, d_hs_src.p,
+                       d_hs_diag.p, d_Hpp.p, d_lam.p, d_Hschur.p);
+    hschur_valid_ = false;    // d_Hschur no longer holds the reduced system
+  }
   const double* H = schur_ ? d_Hschur.p : d_Hpp.p;
   chol_->factor(H, st_);
   if (chol_->failed(st_)) return 1;

@@ -75,6 +75,27 @@ typedef struct {
   double t_schur, t_linear, t_numeric;  /* seconds, last solve */
 } Orc;
 
+/* OpenMP build (libg2o_oracle_omp.so, -fopenmp): the reference's optional G2O_OPENMP regions -- buildSystem parallel over
+ * edges with a lock per vertex (block_solver.hpp:527, base_binary_edge.hpp:69-72,114-117), the Schur complement parallel
+ * over landmarks with a lock per pose row (block_solver.hpp:378-380,411-413).  The default build has no threads
+ * (the reference's default: G2O_USE_OPENMP OFF, CMakeLists.txt:137). */
+#ifdef _OPENMP
+#include <omp.h>
+static omp_lock_t* g_locks = NULL;
+static long g_nlocks = 0;
+static void ensure_locks(long n) {
+  if (n <= g_nlocks) return;
+  g_locks = (omp_lock_t*)realloc(g_locks, sizeof(omp_lock_t) * (size_t)n);
+  for (long i = g_nlocks; i < n; ++i) omp_init_lock(&g_locks[i]);
+  g_nlocks = n;
+}
+int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { omp_set_num_threads(n); }
+#else
+int orc_num_threads(void) { return 1; }
+void orc_set_num_threads(int n) { (void)n; }
+#endif
+
 static double now_s(void) {
   struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
@@ -290,10 +311,21 @@ int orc_build_system(Orc* s) {
   for (int si = 0; si < s->nsets; ++si) {
     OrcSet* e = &s->sets[si];
     const int d = e->d, d0 = e->dim0, d1 = e->dim1;
+#ifdef _OPENMP
+    ensure_locks((long)s->nP + s->nL);
+#pragma omp parallel for default(shared) if (e->n > 100)
+#endif
     for (int k = 0; k < e->n; ++k) {
       const int a = e->v0[k], bidx = e->v1[k];
       const int fromNotFixed = a >= 0, toNotFixed = (!e->unary) && bidx >= 0;
       if (!fromNotFixed && !toNotFixed) continue;
+#ifdef _OPENMP
+      /* from->lockQuadraticForm(); to->lockQuadraticForm();  (ascending order here: the reference locks in edge order) */
+      { const int l0 = fromNotFixed ? a : -1, l1 = toNotFixed ? bidx : -1;
+        const int lo = (l0 >= 0 && (l1 < 0 || l0 < l1)) ? l0 : l1, hi = (lo == l0) ? l1 : l0;
+        if (lo >= 0) omp_set_lock(&g_locks[lo]);
+        if (hi >= 0 && hi != lo) omp_set_lock(&g_locks[hi]); }
+#endif
       const double* A = e->J0 + (size_t)k * d * d0;
       const double* B = e->unary ? NULL : e->J1 + (size_t)k * d * d1;
       const double* O = e->omega + (size_t)k * d * d;
@@ -321,6 +353,10 @@ int orc_build_system(Orc* s) {
         atx(B, d, d1, omega_r, bv);
         atob(B, d1, Ouse, B, d1, d, blkptr(s, e->k11[k], e->o11[k]));
       }
+#ifdef _OPENMP
+      if (toNotFixed) omp_unset_lock(&g_locks[bidx]);
+      if (fromNotFixed && !(toNotFixed && a == bidx)) omp_unset_lock(&g_locks[a]);
+#endif
     }
   }
   return 0;
@@ -451,7 +487,8 @@ static hent heap_pop(hent* H, int* n) {
   for (;;) { int l = 2 * i + 1, r = l + 1, m = i;
     if (l < *n && (H[l].deg < H[m].deg || (H[l].deg == H[m].deg && H[l].v < H[m].v))) m = l;
     if (r < *n && (H[r].deg < H[m].deg || (H[r].deg == H[m].deg && H[r].v < H[m].v))) m = r;
-    if (m == i) break; hent t = H[m]; H[m] = H[i]; H[i] = t; i = m; }
+    if (m == i) break;
+    hent t = H[m]; H[m] = H[i]; H[i] = t; i = m; }
   return top;
 }
 static int cmp_int(const void* a, const void* b) { return (*(const int*)a > *(const int*)b) - (*(const int*)a < *(const int*)b); }
@@ -635,6 +672,10 @@ void orc_solve_schur(Orc* s) {
     for (int i = 0; i < p * p; ++i) dst[i] += src[i];
   }
   memset(s->coeff, 0, sizeof(double) * (size_t)s->sizeP);
+#ifdef _OPENMP
+  ensure_locks((long)s->nP + s->nL);
+#pragma omp parallel for default(shared) schedule(dynamic, 10)
+#endif
   for (int lm = 0; lm < nL; ++lm) {
     const double* D = s->Hll + (size_t)lm * l * l;
     double* Dinv = s->Dinv + (size_t)lm * l * l;
@@ -647,6 +688,9 @@ void orc_solve_schur(Orc* s) {
       const double* Bi = s->Hpl + (size_t)q1 * p * l;
       double BDinv[8 * 8];
       for (int r = 0; r < p; ++r) for (int cc = 0; cc < l; ++cc) { double tt = 0; for (int k = 0; k < l; ++k) tt += Bi[r + p * k] * Dinv[k + l * cc]; BDinv[r + p * cc] = tt; }
+#ifdef _OPENMP
+      omp_set_lock(&g_locks[i1]);                                   /* ScopedOpenMPMutex mutexLock(&_coefficientsMutex[i1]) :411 */
+#endif
       for (int r = 0; r < p; ++r) { double tt = 0; for (int k = 0; k < l; ++k) tt += Bi[r + p * k] * db[k]; s->coeff[i1 * p + r] += tt; }   /* :412 */
       for (int q2 = q1; q2 < s->pl_colptr[lm + 1]; ++q2) {          /* lower_bound start at i2 >= i1, :418-419 */
         const int i2 = s->pl_row[q2];
@@ -654,6 +698,9 @@ void orc_solve_schur(Orc* s) {
         double* H = s->Hschur + (size_t)find_row(s->hs_colptr, s->hs_row, i2, i1) * p * p;
         for (int r = 0; r < p; ++r) for (int cc = 0; cc < p; ++cc) { double tt = 0; for (int k = 0; k < l; ++k) tt += BDinv[r + p * k] * Bj[cc + p * k]; H[r + p * cc] -= tt; }  /* :430 */
       }
+#ifdef _OPENMP
+      omp_unset_lock(&g_locks[i1]);                                 /* (scope of the mutex: the body of the outer loop) */
+#endif
     }
   }
   memcpy(s->bschur, s->b, sizeof(double) * (size_t)s->sizeP);       /* :435-439 */

@@ -85,6 +85,9 @@ void orc_se2_oplus(int nv, double* poses, const int* hidx, const double* x) {
 void orc_ba_edges(int n, const double* cams, const double* pts, const int* cam_idx, const int* pt_idx,
                   const double* meas, double f, double cx, double cy,
                   double* Jpt /* [n][2x3] */, double* Jcam /* [n][2x6] */, double* err /* [n][2] */) {
+#ifdef _OPENMP   /* the reference linearises inside its parallel loop over the edges, block_solver.hpp:527-531 */
+#pragma omp parallel for default(shared) if (n > 100)
+#endif
   for (int k = 0; k < n; ++k) {
     const double* T = cams + 12 * (size_t)cam_idx[k]; const double* X = pts + 3 * (size_t)pt_idx[k];
     double x = T[0] * X[0] + T[3] * X[1] + T[6] * X[2] + T[9];

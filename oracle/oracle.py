@@ -37,11 +37,29 @@ def build(force=False):
         subprocess.check_call(["make", "-C", HERE, "-s", "ref"])
 
 
-def lib():
-    global _LIB
+_LIB_OMP = None
+
+
+def lib(omp=False):
+    """The oracle library; omp=True: the build with the reference's optional OpenMP regions enabled
+    (libg2o_oracle_omp.so, "best CPU" timing only -- its summation order depends on the thread schedule)."""
+    global _LIB, _LIB_OMP
+    if omp:
+        if _LIB_OMP is None:
+            so = os.path.join(HERE, "libg2o_oracle_omp.so")
+            src = [os.path.join(HERE, f) for f in ("g2o_oracle.c", "g2o_oracle_types.c")]
+            if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in src):
+                subprocess.check_call(["make", "-C", HERE, "-s", so])
+            _LIB_OMP = _proto(C.CDLL(so))
+        return _LIB_OMP
     if _LIB is None:
         build()
-        L = C.CDLL(os.path.join(HERE, "libg2o_oracle.so"))
+        _LIB = _proto(C.CDLL(os.path.join(HERE, "libg2o_oracle.so")))
+    return _LIB
+
+
+def _proto(L):
+    if True:   # (prototypes)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int] * 5
         L.orc_add_edge_set.argtypes = [C.c_void_p, C.c_int, C.c_int, c_int_p, c_int_p]
@@ -92,8 +110,9 @@ def lib():
                                    C.c_double, c_dbl_p, c_dbl_p, c_dbl_p]
         L.orc_ba_oplus_cams.argtypes = [C.c_int, c_dbl_p, c_int_p, c_dbl_p]
         L.orc_ba_oplus_pts.argtypes = [C.c_int, c_dbl_p, c_int_p, c_dbl_p]
-        _LIB = L
-    return _LIB
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+    return L
 
 
 def ref():
@@ -127,8 +146,8 @@ def _f64(a):
 class OracleSolver:
     """Mirror of g2o::BlockSolver<p,l> (g2o/core/block_solver.h:98-178) over flat arrays."""
 
-    def __init__(self, p, l, nP, nL, schur=True):
-        self.L = lib()
+    def __init__(self, p, l, nP, nL, schur=True, omp=False):
+        self.L = lib(omp)
         self.p, self.l, self.nP, self.nL = p, l, nP, nL
         self.h = C.c_void_p(self.L.orc_create(p, l, nP, nL, int(schur)))
         self.schur = bool(schur) and nL > 0
@@ -368,8 +387,8 @@ def se2_oplus(poses, hidx, x):
     return poses
 
 
-def ba_edges(cams, pts, cam_idx, pt_idx, meas, f, cx, cy, jac=True):
-    L = lib()
+def ba_edges(cams, pts, cam_idx, pt_idx, meas, f, cx, cy, jac=True, omp=False):
+    L = lib(omp)
     cams, pts, cam_idx, pt_idx, meas = _f64(cams), _f64(pts), _i32(cam_idx), _i32(pt_idx), _f64(meas)
     n = len(cam_idx)
     err = np.zeros((n, 2))

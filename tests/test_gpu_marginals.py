@@ -45,9 +45,35 @@ def test_pose_graph_marginals_match_oracle_solves():
     assert np.all(np.linalg.eigvalsh(0.5 * (M[0] + M[0].T)) > 0)         # a covariance block
 
 
+def test_ba_marginals_default_is_the_inverse_of_hpp_like_the_reference():
+    """BlockSolver::computeMarginals hands *_Hpp to solvePattern also under Schur (block_solver.hpp:489-493): the
+    default result is the inverse of Hpp alone (dense numpy inverse of the oracle's Hpp)."""
+    pr = ba_case(10, 40)
+    s = hip_ba(pr)
+    s.buildSystem()
+    o = oracle_ba(pr)
+    o.build_system()
+    nP = pr["nP"]
+    Hpp = o.dense_full()[:6 * nP, :6 * nP]
+    Hinv = np.linalg.inv(Hpp)
+    rows = np.array([0, 2, 7, 3], np.int32)
+    cols = np.array([0, 5, 7, 1], np.int32)
+    M = s.computeMarginals(rows, cols)
+    for i in range(len(rows)):
+        ref = Hinv[6 * rows[i]:6 * rows[i] + 6, 6 * cols[i]:6 * cols[i] + 6]
+        assert np.abs(M[i] - ref).max() <= 1e-9 * np.abs(Hinv).max()
+    s.setLambda(1.0, True)      # the reduced system is formed again by the next solve
+    assert s.solve()
+    xo = None
+    o.set_lambda(1.0, True)
+    assert o.solve()
+    assert relerr(s.x(), o.x()) < 1e-7
+
+
 def test_ba_pose_marginals_are_the_pose_block_of_the_full_inverse():
     pr = ba_case(10, 40)
     s = hip_ba(pr)
+    s.setOption("marginals_reduced", 1)
     s.buildSystem()
     o = oracle_ba(pr)
     o.build_system()
