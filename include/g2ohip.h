@@ -128,6 +128,10 @@ int g2ohip_restore_diagonal(g2ohip_solver* s);
 int g2ohip_max_diagonal(g2ohip_solver* s, double* out);
 /* sum_j x_j (lambda x_j + b_j): OptimizationAlgorithmLevenberg::computeScale (:165-172). */
 int g2ohip_compute_scale(g2ohip_solver* s, double lambda, double* out);
+/* The scalar diagonal of H (poses then landmarks, hessian-index order; vector_size() doubles) with the current damping:
+ * what OptimizationAlgorithmLevenberg::computeLambdaInit reads through v->hessian(j, j) in the vertices' mapped memory
+ * (optimization_algorithm_levenberg.cpp:149-163, base_vertex.h:62-110) -- the g2o adapter mirrors it on the host. */
+int g2ohip_copy_diagonal(g2ohip_solver* s, double* diag_host);
 
 /* Solver::solve(), block_solver.hpp:353-486: Schur complement, sparse block Cholesky of the
  * reduced pose system, landmark back-substitution.  G2OHIP_OK | G2OHIP_NOT_PD | error.

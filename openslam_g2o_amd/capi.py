@@ -56,7 +56,7 @@ EXPORTS = [
     "g2ohip_get_partition", "g2ohip_partition_poses",
     "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
-    "g2ohip_compute_marginals", "g2ohip_set_x",
+    "g2ohip_compute_marginals", "g2ohip_set_x", "g2ohip_copy_diagonal",
 ]
 
 _lib = None
@@ -146,6 +146,7 @@ def load():
     L.g2ohip_pg_linearize.argtypes = [vp, C.c_int]
     L.g2ohip_copy_edge_data.argtypes = [vp, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]
     L.g2ohip_compute_marginals.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p]
+    L.g2ohip_copy_diagonal.argtypes = [vp, c_dbl_p]
     L.g2ohip_kernel_name.argtypes = [C.c_int]
     L.g2ohip_kernel_name.restype = C.c_char_p
     L.g2ohip_kernel_time.argtypes = [vp, C.c_int, c_dbl_p, C.POINTER(C.c_long), C.c_int]
@@ -480,6 +481,12 @@ class HipBlockSolver:
         if rc != OK:
             return None
         return out.reshape(len(rows), self.p, self.p).transpose(0, 2, 1).copy()   # column-major blocks -> [row][col]
+
+    def diagonal(self):
+        """Scalar diagonal of H with the current damping (poses then landmarks): g2ohip_copy_diagonal."""
+        out = np.empty(self.vectorSize())
+        _check(self.L.g2ohip_copy_diagonal(self.h, _dp(out)), "diagonal")
+        return out
 
     def edgeData(self, set_id, n, d, d0, d1):
         """(J0, J1, err) of a binary edge set (n edges, error dim d, vertex dims d0 / d1) as the next buildSystem reads them."""

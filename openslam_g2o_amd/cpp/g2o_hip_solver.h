@@ -1,0 +1,356 @@
+// g2o adapter over the C ABI of libg2ohip (include/g2ohip.h): what a g2o maintainer adds to the g2o tree
+// (e.g. as g2o/solvers/hip/block_solver_hip.h) to run SparseOptimizer::optimize() on an MI355X.
+//
+//   BlockSolverHip<p, l>        wide seam: replaces g2o::BlockSolver<BlockSolverTraits<p, l>> behind g2o::Solver
+//                               (/root/reference/g2o/core/solver.h:44-149, block_solver.h:83-178)
+//   LinearSolverHip<MatrixType> narrow seam: replaces LinearSolverCSparse / LinearSolverCholmod behind
+//                               g2o::LinearSolver<MatrixType> (/root/reference/g2o/core/linear_solver.h:40-81)
+//
+// Everything here is C++ ABI of the consumer's g2o build (vtables, Eigen types), so it is compiled against the
+// consumer's g2o + Eigen; this repository syntax-checks it against tests/cpp/g2o_decl (declarations of the g2o
+// members it touches, tests/test_adapter_syntax.py).  Registration as a plugin: solver_hip.cpp.
+#ifndef G2O_HIP_SOLVER_H
+#define G2O_HIP_SOLVER_H
+
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <string>
+#include <typeinfo>
+#include <utility>
+#include <vector>
+
+#include "g2o/core/batch_stats.h"
+#include "g2o/core/block_solver.h"
+#include "g2o/core/jacobian_workspace.h"
+#include "g2o/core/linear_solver.h"
+#include "g2o/core/robust_kernel_impl.h"
+#include "g2o/core/sparse_optimizer.h"
+#include "g2o/stuff/timeutil.h"
+#include "g2ohip.h"
+
+namespace g2o {
+
+// ---------------------------------------------------------------------------------------------------------
+// Wide seam.  The edges keep producing errors and Jacobians on the CPU (computeError / linearizeOplus of the
+// consumer's edge types); assembly, damping, Schur complement, factorisation and back-substitution run on the
+// device.  Edges are grouped into homogeneous SETS (error dimension, vertex dimensions, unary / binary, robust
+// kernel): one g2ohip edge set per group, flat arrays in the group's edge order.
+// ---------------------------------------------------------------------------------------------------------
+template <int p, int l>
+class BlockSolverHip : public BlockSolverBase {
+ public:
+  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0) {
+    if (g2ohip_create(&_h, p, l, device) != G2OHIP_OK) {
+      std::cerr << "BlockSolverHip: " << g2ohip_last_error() << std::endl;   // (no exceptions on this path)
+      _h = 0;
+    }
+  }
+  virtual ~BlockSolverHip() { if (_h) g2ohip_destroy(_h); }
+
+  // block_solver.hpp:606-620: store the optimizer, drop numeric / symbolic state
+  virtual bool init(SparseOptimizer* optimizer, bool online = false) {
+    (void)online;
+    _optimizer = optimizer;
+    _groups.clear();
+    return _h && g2ohip_init(_h) == G2OHIP_OK;
+  }
+
+  // block_solver.hpp:142-295: index arrays from indexMapping() / activeEdges(); called at iteration 0 only
+  // (optimization_algorithm_levenberg.cpp:62-68), so the edge sets are registered exactly once per init()
+  virtual bool buildStructure(bool zeroBlocks = false) {
+    (void)zeroBlocks;
+    if (!_h || !_optimizer) return false;
+    if (g2ohip_init(_h) != G2OHIP_OK) return fail("init");
+    _groups.clear();
+    // poses first, then marginalized vertices, each in index order (sparse_optimizer.cpp:174-187)
+    _nP = _nL = 0;
+    size_t diagDoubles = 0;
+    for (size_t i = 0; i < _optimizer->indexMapping().size(); ++i) {
+      OptimizableGraph::Vertex* v = _optimizer->indexMapping()[i];
+      const bool lm = v->marginalized();
+      if (v->dimension() != (lm ? l : p)) {
+        std::cerr << "BlockSolverHip: vertex dimension " << v->dimension() << " does not fit <" << p << "," << l << ">" << std::endl;
+        return false;
+      }
+      (lm ? _nL : _nP)++;
+      diagDoubles += (size_t)v->dimension() * v->dimension();
+    }
+    // host mirror of the diagonal blocks: OptimizationAlgorithmLevenberg::computeLambdaInit reads v->hessian(j, j)
+    // through the vertices' mapped memory (optimization_algorithm_levenberg.cpp:149-163, base_vertex.h:62-110)
+    _diagMirror.assign(diagDoubles, 0.0);
+    {
+      size_t off = 0;
+      int col = 0;
+      for (size_t i = 0; i < _optimizer->indexMapping().size(); ++i) {
+        OptimizableGraph::Vertex* v = _optimizer->indexMapping()[i];
+        v->setColInHessian(col);                       // block_solver.hpp:170,177
+        v->mapHessianMemory(&_diagMirror[off]);
+        col += v->dimension();
+        off += (size_t)v->dimension() * v->dimension();
+      }
+    }
+    // group the active edges
+    std::map<GroupKey, size_t> index;
+    for (size_t k = 0; k < _optimizer->activeEdges().size(); ++k) {
+      OptimizableGraph::Edge* e = _optimizer->activeEdges()[k];
+      const size_t nv = e->vertices().size();
+      if (nv < 1 || nv > 2) {
+        std::cerr << "BlockSolverHip: edges with " << nv << " vertices are not supported (BaseMultiEdge)" << std::endl;
+        return false;
+      }
+      OptimizableGraph::Vertex* v0 = static_cast<OptimizableGraph::Vertex*>(e->vertex(0));
+      OptimizableGraph::Vertex* v1 = nv == 2 ? static_cast<OptimizableGraph::Vertex*>(e->vertex(1)) : 0;
+      GroupKey key;
+      key.d = e->dimension();
+      key.dim0 = v0->dimension();
+      key.dim1 = v1 ? v1->dimension() : 0;
+      kernelOf(e->robustKernel(), key.kernel, key.delta);
+      if (key.kernel < 0) {
+        std::cerr << "BlockSolverHip: robust kernel " << typeid(*e->robustKernel()).name() << " has no device counterpart" << std::endl;
+        return false;
+      }
+      typename std::map<GroupKey, size_t>::iterator it = index.find(key);
+      if (it == index.end()) {
+        it = index.insert(std::make_pair(key, _groups.size())).first;
+        _groups.push_back(Group());
+        _groups.back().key = key;
+      }
+      Group& g = _groups[it->second];
+      g.edges.push_back(e);
+      g.v0.push_back(v0->hessianIndex());              // -1 when fixed (optimizable_graph.h:299)
+      if (v1) g.v1.push_back(v1->hessianIndex());
+    }
+    for (size_t gi = 0; gi < _groups.size(); ++gi) {
+      Group& g = _groups[gi];
+      const int n = (int)g.edges.size();
+      g.set = g2ohip_add_edge_set(_h, g.key.d, n, g.v0.data(), g.key.dim1 ? g.v1.data() : 0);
+      if (g.set < 0) return fail("add_edge_set");
+      if (g.key.kernel > 0 && g2ohip_set_robust_kernel(_h, g.set, g.key.kernel, g.key.delta) != G2OHIP_OK) return fail("set_robust_kernel");
+      g.J0.assign((size_t)n * g.key.d * g.key.dim0, 0.0);
+      g.J1.assign((size_t)n * g.key.d * g.key.dim1, 0.0);
+      g.Om.assign((size_t)n * g.key.d * g.key.d, 0.0);
+      g.err.assign((size_t)n * g.key.d, 0.0);
+    }
+    if (g2ohip_build_structure(_h, _nP, _nL, _doSchur ? 1 : 0) != G2OHIP_OK) return fail("build_structure");
+    resizeVector(g2ohip_vector_size(_h));              // Solver::_x, _b (solver.cpp:46-70)
+    _diag.assign(g2ohip_vector_size(_h), 0.0);
+    return true;
+  }
+
+  // online growth: the reference aborts for Schur too (block_solver.hpp:313-316)
+  virtual bool updateStructure(const std::vector<HyperGraph::Vertex*>& vset, const HyperGraph::EdgeSet& edges) {
+    (void)vset;
+    (void)edges;
+    return false;
+  }
+
+  // block_solver.hpp:501-560.  After it returns b() holds -J' Omega e (poses then landmarks) and H is assembled on
+  // the device.  The reference returns 0 and nobody checks (optimization_algorithm_levenberg.cpp:81).
+  virtual bool buildSystem() {
+    if (!_h) return false;
+    JacobianWorkspace& ws = _optimizer->jacobianWorkspace();
+    for (size_t gi = 0; gi < _groups.size(); ++gi) {
+      Group& g = _groups[gi];
+      const int d = g.key.d, d0 = g.key.dim0, d1 = g.key.dim1;
+      for (size_t k = 0; k < g.edges.size(); ++k) {
+        OptimizableGraph::Edge* e = g.edges[k];
+        e->linearizeOplus(ws);                         // block_solver.hpp:531 (the error is current: computeActiveErrors)
+        // Jacobians sit column-major (d x dim) in the workspace (base_binary_edge.h: Map onto workspaceForVertex(i));
+        // a fixed vertex has no Jacobian and is never read on the device (index -1)
+        if (g.v0[k] >= 0) std::memcpy(&g.J0[k * d * d0], ws.workspaceForVertex(0), sizeof(double) * d * d0);
+        if (d1 && g.v1[k] >= 0) std::memcpy(&g.J1[k * d * d1], ws.workspaceForVertex(1), sizeof(double) * d * d1);
+        std::memcpy(&g.Om[k * d * d], e->informationData(), sizeof(double) * d * d);
+        std::memcpy(&g.err[k * d], e->errorData(), sizeof(double) * d);
+      }
+      if (g2ohip_set_edge_data(_h, g.set, g.J0.data(), d1 ? g.J1.data() : 0, g.Om.data(), g.err.data(), /*on_device*/ 0) != G2OHIP_OK)
+        return fail("set_edge_data");
+    }
+    if (g2ohip_build_system(_h) != G2OHIP_OK) return fail("build_system");
+    if (g2ohip_copy_b(_h, _b) != G2OHIP_OK) return fail("copy_b");          // LM reads b() (levenberg.cpp:169)
+    refreshDiagonalMirror();
+    return true;
+  }
+
+  // block_solver.hpp:353-486: x() <- solution of (H (+ lambda I)) x = b, full length; b() untouched; false iff not
+  // positive definite
+  virtual bool solve() {
+    if (!_h) return false;
+    const double t = get_monotonic_time();
+    const int rc = g2ohip_solve(_h);
+    if (rc != G2OHIP_OK) {
+      if (rc != G2OHIP_NOT_PD) fail("solve");
+      return false;
+    }
+    if (g2ohip_copy_x(_h, _x) != G2OHIP_OK) return fail("copy_x");
+    G2OBatchStatistics* gs = G2OBatchStatistics::globalStats();
+    if (gs) {                                          // batch_stats.h:40-77
+      g2ohip_stats st;
+      if (g2ohip_get_stats(_h, &st) == G2OHIP_OK) {
+        gs->timeSchurComplement = st.timeSchurComplement;
+        gs->timeSymbolicDecomposition = st.timeSymbolicDecomposition;
+        gs->timeNumericDecomposition = st.timeNumericDecomposition;
+        gs->timeLinearSolver = st.timeLinearSolver;
+        gs->choleskyNNZ = st.choleskyNNZ;
+        gs->hessianPoseDimension = st.hessianPoseDimension;
+        gs->hessianLandmarkDimension = st.hessianLandmarkDimension;
+        gs->hessianDimension = st.hessianPoseDimension + st.hessianLandmarkDimension;
+      }
+      (void)t;   // timeLinearSolution is accumulated by the algorithm around solve() (levenberg.cpp:105)
+    }
+    return true;
+  }
+
+  // block_solver.hpp:563-604: lambda on every scalar diagonal entry of Hpp and Hll; exact restore
+  virtual bool setLambda(double lambda, bool backup = false) { return _h && g2ohip_set_lambda(_h, lambda, backup ? 1 : 0) == G2OHIP_OK; }
+  virtual void restoreDiagonal() { if (_h) g2ohip_restore_diagonal(_h); }
+
+  // block_solver.hpp:489-498: blocks of the inverse of Hpp
+  virtual bool computeMarginals(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices) {
+    if (!_h) return false;
+    const double t = get_monotonic_time();
+    std::vector<int32_t> r(blockIndices.size()), c(blockIndices.size());
+    for (size_t i = 0; i < blockIndices.size(); ++i) {
+      r[i] = blockIndices[i].first;
+      c[i] = blockIndices[i].second;
+    }
+    std::vector<double> out(blockIndices.size() * p * p);
+    if (g2ohip_compute_marginals(_h, (int)blockIndices.size(), r.data(), c.data(), out.data()) != G2OHIP_OK) return false;
+    for (size_t i = 0; i < blockIndices.size(); ++i) {
+      MatrixXd* blk = spinv.block(r[i], c[i], true);   // allocated p x p, column-major like `out`
+      std::memcpy(blk->data(), &out[i * p * p], sizeof(double) * p * p);
+    }
+    G2OBatchStatistics* gs = G2OBatchStatistics::globalStats();
+    if (gs) gs->timeMarginals = get_monotonic_time() - t;
+    return true;
+  }
+
+  virtual bool supportsSchur() { return true; }
+  virtual bool schur() { return _doSchur; }
+  virtual void setSchur(bool s) { _doSchur = s; }
+  virtual void setWriteDebug(bool b) { _writeDebug = b; }
+  virtual bool writeDebug() const { return _writeDebug; }
+  virtual bool saveHessian(const std::string& fileName) const { (void)fileName; return false; }
+  // BlockSolverBase (block_solver.h:83-91), used by OptimizationAlgorithmDogleg: dest = H * src
+  virtual void multiplyHessian(double* dest, const double* src) const { if (_h) g2ohip_multiply_hessian(_h, dest, src); }
+
+  g2ohip_solver* handle() const { return _h; }
+
+ private:
+  struct GroupKey {
+    int d, dim0, dim1, kernel;
+    double delta;
+    bool operator<(const GroupKey& o) const {
+      if (d != o.d) return d < o.d;
+      if (dim0 != o.dim0) return dim0 < o.dim0;
+      if (dim1 != o.dim1) return dim1 < o.dim1;
+      if (kernel != o.kernel) return kernel < o.kernel;
+      return delta < o.delta;
+    }
+  };
+  struct Group {
+    GroupKey key;
+    int set;
+    std::vector<OptimizableGraph::Edge*> edges;
+    std::vector<int32_t> v0, v1;
+    std::vector<double> J0, J1, Om, err;
+    Group() : set(-1) {}
+  };
+
+  // robust kernel -> the kind numbers of g2ohip_set_robust_kernel (robust_kernel_impl.h:77-140); 0: none, -1: unknown
+  static void kernelOf(const RobustKernel* k, int& kind, double& delta) {
+    kind = 0;
+    delta = 0.0;
+    if (!k) return;
+    delta = k->delta();
+    if (dynamic_cast<const RobustKernelHuber*>(k)) kind = 1;
+    else if (dynamic_cast<const RobustKernelPseudoHuber*>(k)) kind = 2;
+    else if (dynamic_cast<const RobustKernelCauchy*>(k)) kind = 3;
+    else if (dynamic_cast<const RobustKernelSaturated*>(k)) kind = 4;
+    else if (dynamic_cast<const RobustKernelDCS*>(k)) kind = 5;
+    else kind = -1;
+  }
+
+  void refreshDiagonalMirror() {
+    if (g2ohip_copy_diagonal(_h, _diag.data()) != G2OHIP_OK) return;
+    size_t off = 0, s = 0;
+    for (size_t i = 0; i < _optimizer->indexMapping().size(); ++i) {
+      const int dim = _optimizer->indexMapping()[i]->dimension();
+      for (int j = 0; j < dim; ++j) _diagMirror[off + (size_t)j * (dim + 1)] = _diag[s + j];
+      off += (size_t)dim * dim;
+      s += dim;
+    }
+  }
+
+  bool fail(const char* what) const {
+    std::cerr << "BlockSolverHip::" << what << ": " << g2ohip_last_error() << std::endl;
+    return false;
+  }
+
+  g2ohip_solver* _h;
+  bool _doSchur, _writeDebug;
+  int _nP, _nL;
+  std::vector<Group> _groups;
+  std::vector<double> _diagMirror, _diag;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Narrow seam: g2o's own CPU assembly and Schur complement stay, only the sparse Cholesky solve moves to the device
+// (LinearSolverCSparse::solve, solvers/csparse/linear_solver_csparse.h:106-142).
+// ---------------------------------------------------------------------------------------------------------
+template <typename MatrixType>
+class LinearSolverHip : public LinearSolver<MatrixType> {
+ public:
+  explicit LinearSolverHip(int blockDim = MatrixType::RowsAtCompileTime, int device = 0) : _ls(0) {
+    if (g2ohip_ls_create(&_ls, blockDim, device) != G2OHIP_OK) {
+      std::cerr << "LinearSolverHip: " << g2ohip_last_error() << std::endl;
+      _ls = 0;
+    }
+  }
+  virtual ~LinearSolverHip() { if (_ls) g2ohip_ls_destroy(_ls); }
+
+  // drop the symbolic factorisation: the pattern may change until the next init() (linear_solver.h:50)
+  virtual bool init() { return _ls && g2ohip_ls_init(_ls) == G2OHIP_OK; }
+
+  // A symmetric, upper blocks only; x, b caller-allocated of length A.rows(); false iff not positive definite
+  virtual bool solve(const SparseBlockMatrix<MatrixType>& A, double* x, double* b) {
+    if (!_ls) return false;
+    const int nb = (int)A.blockCols().size();
+    _colptr.assign(1, 0);
+    _rowidx.clear();
+    _values.clear();
+    for (int c = 0; c < nb; ++c) {
+      const typename SparseBlockMatrix<MatrixType>::IntBlockMap& column = A.blockCols()[c];
+      for (typename SparseBlockMatrix<MatrixType>::IntBlockMap::const_iterator it = column.begin(); it != column.end(); ++it) {
+        if (it->first > c) break;                      // upper triangle, ascending rows (std::map)
+        const MatrixType* blk = it->second;
+        _rowidx.push_back(it->first);
+        _values.insert(_values.end(), blk->data(), blk->data() + blk->rows() * blk->cols());   // column-major (Eigen default)
+      }
+      _colptr.push_back((int32_t)_rowidx.size());
+    }
+    const double t = get_monotonic_time();
+    const int rc = g2ohip_ls_solve(_ls, nb, _colptr.data(), _rowidx.data(), _values.data(), x, b);
+    G2OBatchStatistics* gs = G2OBatchStatistics::globalStats();
+    if (gs) {
+      g2ohip_stats st;
+      if (g2ohip_ls_get_stats(_ls, &st) == G2OHIP_OK) {
+        gs->timeSymbolicDecomposition = st.timeSymbolicDecomposition;
+        gs->choleskyNNZ = st.choleskyNNZ;
+      }
+      gs->timeNumericDecomposition = get_monotonic_time() - t;
+    }
+    if (rc != G2OHIP_OK && rc != G2OHIP_NOT_PD) std::cerr << "LinearSolverHip::solve: " << g2ohip_last_error() << std::endl;
+    return rc == G2OHIP_OK;
+  }
+
+ private:
+  g2ohip_linear_solver* _ls;
+  std::vector<int32_t> _colptr, _rowidx;
+  std::vector<double> _values;
+};
+
+}  // namespace g2o
+
+#endif

@@ -75,6 +75,7 @@ class BlockSolver {
   int solve_reduced_finish();
   void partition_info(int* pose_owner, int* block_consumer);
   int compute_marginals(int n, const int* rows, const int* cols, double* out);
+  void copy_diagonal(double* host);
   void copy_edge_data(int set, double* J0, double* J1, double* err);
   void pg_set_edges(int set, int type, const int* vi, const int* vj, const double* meas, const double* info);
   void pg_set_estimates(int nv, const double* poses, const int* hidx);

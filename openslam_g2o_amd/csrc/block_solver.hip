@@ -2278,6 +2278,32 @@ double BlockSolver::max_diagonal() {
   return m;
 }
 
+// scalar diagonal of H, poses then landmarks, in hessian-index order (what OptimizationAlgorithmLevenberg::computeLambdaInit
+// reads through v->hessian(j, j), optimization_algorithm_levenberg.cpp:149-163); includes the current damping
+__global__ void gather_diag_kernel(int nv, int dim, const double* __restrict__ H, const int* __restrict__ diag_block, double add,
+                                   double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nv * dim) return;
+  const int v = t / dim, j = t - v * dim;
+  const size_t blk = diag_block ? (size_t)diag_block[v] : (size_t)v;
+  out[t] = H[blk * dim * dim + (size_t)j * (dim + 1)] + add;
+}
+
+void BlockSolver::copy_diagonal(double* host) {
+  require_structure();
+  if (!host) throw ArgFailure("copy_diagonal: null pointer");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  const size_t n = vector_size();
+  DevBuf<double> tmp;
+  tmp.alloc(n);
+  hipLaunchKernelGGL(gather_diag_kernel, dim3(grid_for((size_t)nP_ * p_)), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p,
+                     schur_ ? lam_pose_ : 0.0, tmp.p);
+  if (nL_ > 0)
+    hipLaunchKernelGGL(gather_diag_kernel, dim3(grid_for((size_t)nL_ * l_)), dim3(kThreads), 0, st_, nL_, l_, d_Hll.p, (const int*)nullptr,
+                       schur_ ? lam_lm_ : 0.0, tmp.p + (size_t)nP_ * p_);
+  tmp.download(host, n, st_);
+}
+
 double BlockSolver::compute_scale(double lambda) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));

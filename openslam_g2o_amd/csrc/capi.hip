@@ -561,6 +561,10 @@ int g2ohip_ba_discard_top(g2ohip_solver* s) {
   });
 }
 
+int g2ohip_copy_diagonal(g2ohip_solver* s, double* diag_host) {
+  if (!s) return G2OHIP_ERR_ARG;
+  return guarded([&] { s->impl->copy_diagonal(diag_host); return G2OHIP_OK; });
+}
 int g2ohip_compute_marginals(g2ohip_solver* s, int n_blocks, const int32_t* rows, const int32_t* cols, double* out) {
   REQUIRE_HANDLE(s);
   return guarded([&] { return s->impl->compute_marginals(n_blocks, rows, cols, out) ? G2OHIP_NOT_PD : G2OHIP_OK; });
