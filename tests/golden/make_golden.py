@@ -136,9 +136,48 @@ def sphere():
     print("sphere: nP", nP, "nnzb", out["nnzb"], "lnz", out["lnz_block_amd"], "chi2", chi_traj)
 
 
-if __name__ == "__main__":
+def _main():
     O.build()
     assert O.ref() is not None, "oracle/_ref missing: run `make -C oracle` where /root/reference exists"
+    if "lnz" in sys.argv[1:]:
+        return lnz_amd()
     manhattan()
     ba_small()
     sphere()
+    lnz_amd()
+
+
+def lnz_amd():
+    """nnz(L) of the reduced BA system under the REFERENCE's ordering (cs_amd on the block pattern, scalar blow-up,
+    reference symbolic analysis: linear_solver_csparse.h:246-308 through oracle/_ref) for the synthetic window graphs the
+    GPU tests and the bench use.  The reduced pattern of SURVEY.md 8d's generator: pose blocks i, j coupled iff |i - j| <= 4
+    (5 consecutive observing poses per landmark), poses 0 and 1 fixed -> nb = P - 2 block columns."""
+    import json
+    R = O.ref()
+    out = {}
+    for P in (300, 2000, 20000, 50000, 100000):
+        nb = P - 2
+        cp = [0]
+        ri = []
+        for c in range(nb):
+            for r in range(max(0, c - 4), c + 1):
+                ri.append(r)
+            cp.append(len(ri))
+        cp, ri = np.asarray(cp, np.int32), np.asarray(ri, np.int32)
+        perm = np.zeros(nb, np.int32)
+        assert R.ref_block_amd(nb, O._ip(cp), O._ip(ri), O._ip(perm))
+        # scalar pattern (values irrelevant) + reference symbolic with the expanded permutation
+        val = np.zeros(len(ri) * 36)
+        Ap, Ai, Ax = O.scalar_ccs(nb, 6, cp, ri, val)
+        sperm = (perm[:, None] * 6 + np.arange(6, dtype=np.int32)[None, :]).reshape(-1).astype(np.int32)
+        sym = R.ref_symbolic(nb * 6, O._ip(Ap), O._ip(Ai), O._ip(sperm))
+        lnz = R.ref_lnz(sym)
+        R.ref_free(sym)
+        out[str(P)] = dict(block_columns=nb, upper_blocks=int(len(ri)), lnz_block_amd=float(lnz))
+        print("lnz_amd: P", P, "nb", nb, "lnz", lnz)
+    with open(os.path.join(OUT, "lnz_amd.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    _main()

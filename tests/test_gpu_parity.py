@@ -3,10 +3,13 @@ C ABI, against the CPU oracle on the same seeded inputs and against the committe
 vectors from the reference's CSparse path.
 
 Tolerances (fp64).  Assembly / Schur intermediates: 1e-12 relative (only summation order
-and FMA contraction differ).  dx: the forward error of ANY backward-stable solve is
-~cond(H)*eps; the damped BA systems here have cond up to ~1e11 (measured), so dx is
-compared at 1e-7 relative and the conditioning-independent residual
-|H x - b|_inf / |b|_inf at 1e-11.  chi2: 1e-9 relative (north_star bar: 1e-6).
+and FMA contraction differ).  dx: the stated bar is 1e-8 relative; the forward
+error of ANY backward-stable solve is ~cond*eps, so the bound used is
+    max(1e-8, 4 * cond(reduced system) * eps)
+with the condition number of the damped reduced system measured per case (dx_tolerance below:
+dense eigenvalues of the oracle's Hschur) -- 1e-8 wherever cond <= 1e7, the conditioning-scaled
+bound for the LM-damped systems with tiny lambda (cond up to ~1e11).  The conditioning-independent
+residual |H x - b|_inf / |b|_inf is held at 1e-11.  chi2: 1e-9 relative (north_star bar: 1e-6).
 """
 import os
 
@@ -19,9 +22,27 @@ from tests.helpers import GOLD, ba_case, hip_ba, manhattan_golden, oracle_ba, re
 pytestmark = pytest.mark.gpu
 
 TOL_MAT = 1e-12
-TOL_DX = 1e-7
+TOL_DX = 1e-8          # stated fp64 tolerance on dx where the system is well conditioned
 TOL_RES = 1e-11
 TOL_CHI = 1e-9
+
+
+def dx_tolerance(o):
+    """max(TOL_DX, 4 cond eps) with cond of the oracle's (damped) reduced pose system, dense."""
+    cp, ri = o.pattern("hs")
+    p = o.p
+    nb = len(cp) - 1
+    H = np.zeros((nb * p, nb * p))
+    V = o.values("Hschur").reshape(-1, p, p)
+    for c in range(nb):
+        for q in range(cp[c], cp[c + 1]):
+            r = ri[q]
+            blk = V[q].T                                  # column-major block
+            H[r * p:(r + 1) * p, c * p:(c + 1) * p] = blk
+            H[c * p:(c + 1) * p, r * p:(r + 1) * p] = blk.T
+    ev = np.linalg.eigvalsh(H)
+    cond = ev[-1] / ev[0]
+    return max(TOL_DX, 4.0 * cond * np.finfo(float).eps), cond
 
 
 def _capi():
@@ -57,7 +78,8 @@ def test_ba_build_schur_solve(P, L):
     assert relerr(s.values(capi.HSCHUR), o.values("Hschur")) < TOL_MAT
     assert relerr(s.values(capi.DINV), o.values("Dinv")) < TOL_MAT
     x, xo = s.x(), o.x()
-    assert relerr(x, xo) < TOL_DX
+    tol, cond = dx_tolerance(o)
+    assert relerr(x, xo) < tol, (relerr(x, xo), tol, cond)
     assert relerr(s.b(), o.b()) < TOL_MAT                      # solve() must not modify b (block_solver.hpp:435-436)
     r = s.multiplyHessian(x) - s.b()                            # damped system: H already contains lambda
     assert np.abs(r).max() <= TOL_RES * np.abs(s.b()).max()
@@ -96,7 +118,8 @@ def test_huber_and_lm_trial_sequence():
         s.setLambda(lam, True)
         o.set_lambda(lam, True)
         assert s.solve() and o.solve()
-        assert relerr(s.x(), o.x()) < TOL_DX
+        tol, cond = dx_tolerance(o)
+        assert relerr(s.x(), o.x()) < tol, (relerr(s.x(), o.x()), tol, cond)
         s.restoreDiagonal()
         o.restore_diagonal()
         lam *= 4.0

@@ -185,3 +185,62 @@ def test_robust_kernels_known_values_and_consistency():
             r, rp, rm = O.robustify(kind, d, e), O.robustify(kind, d, e + h), O.robustify(kind, d, e - h)
             assert abs((rp[0] - rm[0]) / (2 * h) - r[1]) < 1e-6
             assert abs((rp[1] - rm[1]) / (2 * h) - r[2]) < 1e-6
+
+
+def test_ba_projection_jacobian_against_central_differences():
+    """EdgeProjectXYZ2UV (types_six_dof_expmap.cpp:288-326) in the oracle, pinned independently of both builder-written
+    producers: the analytic Jacobians against central differences of a projection written here, with the pose update
+    taken as the matrix exponential of the twist (scipy.linalg.expm) -- VertexSE3Expmap::oplusImpl is
+    exp(update) * estimate with update = (omega, upsilon) (types_six_dof_expmap.h:101-104, se3quat.h:223-257) -- and the
+    point update as plain addition (VertexSBAPointXYZ).  Also pins the oracle's own oplus against the same exponential.
+    Tolerance 1e-6 like the reference's Jacobian test (types/slam3d/test_slam3d_jacobian.cpp)."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(3)
+    n = 60
+    f, cx, cy = 1000.0, 320.0, 240.0
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    iso = O.se3_from_qt(np.hstack([0.3 * rng.normal(size=(n, 3)), q]))           # [n][12]: R column-major | t
+    pts = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(3, 5, n)], axis=1)
+    # points in front of every camera: express them in the camera frame, map back to the world
+    R = iso[:, :9].reshape(n, 3, 3).transpose(0, 2, 1)
+    t = iso[:, 9:]
+    world = np.einsum("nji,nj->ni", R, pts - t)                                   # X = R' (Xc - t)
+    meas = rng.uniform(0, 640, size=(n, 2))
+    idx = np.arange(n, dtype=np.int32)
+
+    def project(Rm, tv, X):
+        Xc = np.einsum("nij,nj->ni", Rm, X) + tv
+        return np.stack([meas[:, 0] - (Xc[:, 0] / Xc[:, 2] * f + cx), meas[:, 1] - (Xc[:, 1] / Xc[:, 2] * f + cy)], axis=1)
+
+    def hat(d):                      # twist (omega, upsilon) -> 4 x 4
+        w, u = d[:3], d[3:]
+        return np.array([[0, -w[2], w[1], u[0]], [w[2], 0, -w[0], u[1]], [-w[1], w[0], 0, u[2]], [0, 0, 0, 0.0]])
+
+    def moved(d):
+        E = expm(hat(d))
+        return np.einsum("ij,njk->nik", E[:3, :3], R), (E[:3, :3] @ t.T).T + E[:3, 3]
+
+    Jp, Jc, err = O.ba_edges(iso, world, idx, idx, meas, f, cx, cy)
+    assert np.abs(err - project(R, t, world)).max() < 1e-9
+    h = 1e-6
+    for c in range(6):
+        d = np.zeros(6)
+        d[c] = h
+        Rp, tp = moved(d)
+        Rm, tm = moved(-d)
+        num = (project(Rp, tp, world) - project(Rm, tm, world)) / (2 * h)
+        assert np.abs(num - Jc.reshape(n, 6, 2)[:, c, :]).max() < 1e-6 * max(1.0, np.abs(Jc).max())
+    for c in range(3):
+        d = np.zeros(3)
+        d[c] = h
+        num = (project(R, t, world + d) - project(R, t, world - d)) / (2 * h)
+        assert np.abs(num - Jp.reshape(n, 3, 2)[:, c, :]).max() < 1e-6 * max(1.0, np.abs(Jp).max())
+    # the oracle's pose update is the same exponential
+    x = 0.05 * rng.normal(size=(n, 6))
+    cams2, _ = O.ba_oplus(iso, world, idx, idx, np.concatenate([x.reshape(-1), np.zeros(3 * n)]), 6 * n)
+    for k in range(0, n, 7):
+        E = expm(hat(x[k]))
+        Rk = E[:3, :3] @ R[k]
+        tk = E[:3, :3] @ t[k] + E[:3, 3]
+        assert np.abs(cams2[k, :9].reshape(3, 3).T - Rk).max() < 1e-12 and np.abs(cams2[k, 9:] - tk).max() < 1e-12
