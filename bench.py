@@ -209,6 +209,26 @@ def main():
     if use_graph:
         solver.local.setOption("use_graph", 1)
     solver.local.setProfiling(True)
+    # N > 1: the collectives run INSIDE libg2ohip (ncclCommInitRank / ncclAllReduce bound there; g2ohip_solve_sharded);
+    # falls back to the torch.distributed formulation of the same exchange if the library communicator cannot be
+    # brought up (the reason goes to stderr and into the JSON line)
+    lib_comm = "n/a"
+    if (world > 1 or emulate) and solver.mode == "subtree" and not emulate:
+        try:
+            lib_comm = "rccl" if args.comm == "rccl" else "host"
+            if not solver.attach_library_comm(lib_comm):
+                lib_comm = "torch (library communicator not applicable)"
+            else:
+                # self-check: an all-reduce of ones must give the world size on every rank
+                one = torch.ones(8, dtype=torch.float64, device=dev)
+                solver.local.commAllReduce(one.data_ptr(), 8, 0)
+                torch.cuda.synchronize()
+                if not bool((one == float(world)).all().item()):
+                    raise RuntimeError("library all-reduce self-check failed: %r" % one.tolist())
+        except Exception as e:      # noqa: BLE001
+            sys.stderr.write("bench: library communicator unavailable (%s); using torch.distributed\n" % e)
+            solver._lib_comm = None
+            lib_comm = "torch (fallback: %s)" % type(e).__name__
 
     def step():
         solver.buildSystem()
@@ -313,6 +333,7 @@ def main():
     if emulate:
         out["emulate"] = "rank %d of %d alone, exchange skipped: timing only" % emulate
     if world > 1 or emulate:
+        out["collectives"] = lib_comm
         out["shard"] = dict(rank0_edges=E_loc, rank0_landmarks=L_loc, exchange_doubles_per_solve=solver.exchange_volume(),
                             comm=args.comm)
         if solver.mode == "subtree":

@@ -266,6 +266,34 @@ int g2ohip_exchange_unpack(g2ohip_solver* s, int which);
 int g2ohip_exchange_status(g2ohip_solver* s);
 int g2ohip_solve_reduced_finish_async(g2ohip_solver* s);
 int g2ohip_get_partition(g2ohip_solver* s, int32_t* pose_owner, int32_t* block_consumer);
+
+/* ---- collectives inside the library: the N > 1 path for C / C++ consumers -------------------------------------------
+ * One process per GPU; every rank creates its solver, registers ITS shard of the edges, calls g2ohip_set_partition +
+ * g2ohip_build_structure + g2ohip_exchange_setup (the index lists come from g2ohip_partition_poses, see
+ * openslam_g2o_amd/distributed.py for the host-side recipe) and attaches a communicator:
+ *   RCCL over xGMI: rank 0 calls g2ohip_comm_unique_id, hands the 128 bytes to the other ranks by any means (MPI, a file,
+ *   a socket), every rank calls g2ohip_comm_init_rccl -- ncclCommInitRank; librccl is bound at run time, libg2ohip.so
+ *   itself has no link dependency on it;
+ *   host callback: g2ohip_comm_init_host with an in-place all-reduce over host memory (op 0 = sum, 1 = max; MPI_Allreduce
+ *   fits directly): device buffers are staged through pinned memory.  For ranks sharing one GPU (tests) and boxes
+ *   without peer access; not a performance path.
+ * g2ohip_solve_sharded then runs the whole linear solve (BlockSolver::solve, block_solver.hpp:353-486, on the sharded
+ * system): local Schur pass | all-reduce of the boundary blocks of the reduced system and boundary b_p | own subtrees of
+ * the elimination tree | all-reduce of the subtree roots' update matrices | shared top + backward sweep | all-reduce of
+ * the halo x_p and the failure flags | back-substitution of the own landmarks.  G2OHIP_OK | G2OHIP_NOT_PD (on every rank
+ * alike).  x_p is valid for own, shared and halo poses, x_l for the own landmarks.
+ * The *_sharded scalars are the Levenberg-Marquardt quantities over all ranks (activeRobustChi2, computeLambdaInit's
+ * maximum, computeScale: optimization_algorithm_levenberg.cpp:149-172). */
+typedef int (*g2ohip_host_allreduce_fn)(void* ctx, double* host_buffer, size_t count, int op);
+int g2ohip_comm_unique_id(char* id128);
+int g2ohip_comm_init_rccl(g2ohip_solver* s, int rank, int world, const char* id128);
+int g2ohip_comm_init_host(g2ohip_solver* s, int rank, int world, g2ohip_host_allreduce_fn fn, void* ctx);
+int g2ohip_comm_destroy(g2ohip_solver* s);
+int g2ohip_comm_all_reduce(g2ohip_solver* s, double* device_buffer, size_t count, int op);   /* in place, on the solver's stream */
+int g2ohip_solve_sharded(g2ohip_solver* s);
+int g2ohip_chi2_sharded(g2ohip_solver* s, double* chi2);
+int g2ohip_max_diagonal_sharded(g2ohip_solver* s, double* out);
+int g2ohip_compute_scale_sharded(g2ohip_solver* s, double lambda, double* out);
 int g2ohip_partition_poses(const g2ohip_solver* options_from, int block_dim, int n_blocks, const int32_t* colptr,
                            const int32_t* rowidx, int world, int32_t* pose_owner, int32_t* block_consumer);
 

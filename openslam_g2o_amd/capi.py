@@ -57,7 +57,11 @@ EXPORTS = [
     "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
     "g2ohip_compute_marginals", "g2ohip_set_x", "g2ohip_copy_diagonal",
+    "g2ohip_comm_unique_id", "g2ohip_comm_init_rccl", "g2ohip_comm_init_host", "g2ohip_comm_destroy", "g2ohip_comm_all_reduce",
+    "g2ohip_solve_sharded", "g2ohip_chi2_sharded", "g2ohip_max_diagonal_sharded", "g2ohip_compute_scale_sharded",
 ]
+
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_int)
 
 _lib = None
 
@@ -147,6 +151,15 @@ def load():
     L.g2ohip_copy_edge_data.argtypes = [vp, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]
     L.g2ohip_compute_marginals.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p]
     L.g2ohip_copy_diagonal.argtypes = [vp, c_dbl_p]
+    L.g2ohip_comm_unique_id.argtypes = [C.c_char_p]
+    L.g2ohip_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.g2ohip_comm_init_host.argtypes = [vp, C.c_int, C.c_int, HOST_ALLREDUCE_FN, vp]
+    L.g2ohip_comm_destroy.argtypes = [vp]
+    L.g2ohip_comm_all_reduce.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.g2ohip_solve_sharded.argtypes = [vp]
+    L.g2ohip_chi2_sharded.argtypes = [vp, c_dbl_p]
+    L.g2ohip_max_diagonal_sharded.argtypes = [vp, c_dbl_p]
+    L.g2ohip_compute_scale_sharded.argtypes = [vp, C.c_double, c_dbl_p]
     L.g2ohip_kernel_name.argtypes = [C.c_int]
     L.g2ohip_kernel_name.restype = C.c_char_p
     L.g2ohip_kernel_time.argtypes = [vp, C.c_int, c_dbl_p, C.POINTER(C.c_long), C.c_int]
@@ -364,6 +377,55 @@ class HipBlockSolver:
 
     def solveBackSubstitute(self):
         _check(self.L.g2ohip_solve_back_substitute(self.h), "solveBackSubstitute")
+
+    # ---- collectives inside the library (g2ohip_comm_*) ----
+    @staticmethod
+    def commUniqueId():
+        """128 opaque bytes (ncclGetUniqueId); rank 0 creates them, every rank passes them to commInitRccl."""
+        buf = C.create_string_buffer(128)
+        _check(load().g2ohip_comm_unique_id(buf), "commUniqueId")
+        return buf.raw
+
+    def commInitRccl(self, rank, world, unique_id):
+        _check(self.L.g2ohip_comm_init_rccl(self.h, rank, world, C.create_string_buffer(bytes(unique_id), 128)), "commInitRccl")
+
+    def commInitHost(self, rank, world, fn):
+        """fn(numpy view of the host buffer, op) reduces IN PLACE over the ranks (op 0 = sum, 1 = max)."""
+        def tramp(ctx, ptr, n, op):
+            try:
+                fn(np.ctypeslib.as_array(ptr, shape=(n,)), op)
+                return 0
+            except Exception:      # noqa: BLE001 -- a Python exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_comm_cb = HOST_ALLREDUCE_FN(tramp)      # keep the trampoline alive as long as the handle
+        _check(self.L.g2ohip_comm_init_host(self.h, rank, world, self._host_comm_cb, None), "commInitHost")
+
+    def commDestroy(self):
+        _check(self.L.g2ohip_comm_destroy(self.h), "commDestroy")
+
+    def commAllReduce(self, device_ptr, count, op=0):
+        _check(self.L.g2ohip_comm_all_reduce(self.h, C.c_void_p(int(device_ptr)), int(count), int(op)), "commAllReduce")
+
+    def solveSharded(self):
+        """The whole sharded linear solve with the collectives inside the library; False = not positive definite."""
+        return _check(self.L.g2ohip_solve_sharded(self.h), "solveSharded") == OK
+
+    def chi2Sharded(self):
+        v = C.c_double()
+        _check(self.L.g2ohip_chi2_sharded(self.h, C.byref(v)), "chi2Sharded")
+        return v.value
+
+    def maxDiagonalSharded(self):
+        v = C.c_double()
+        _check(self.L.g2ohip_max_diagonal_sharded(self.h, C.byref(v)), "maxDiagonalSharded")
+        return v.value
+
+    def computeScaleSharded(self, lam):
+        v = C.c_double()
+        _check(self.L.g2ohip_compute_scale_sharded(self.h, lam, C.byref(v)), "computeScaleSharded")
+        return v.value
 
     def vectorSize(self):
         return self.L.g2ohip_vector_size(self.h)

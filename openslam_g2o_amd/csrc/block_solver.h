@@ -15,6 +15,7 @@
 #include <memory>
 
 #include "common.h"
+#include "comm.h"
 #include "block_pcg.h"
 #include "sparse_cholesky.h"
 
@@ -191,6 +192,14 @@ class BlockSolver {
   void exchange_unpack(int which);   // 1: buffer 105 (x keep) -> Hschur / bschur; 3: buffer 106 -> x
   void solve_reduced_finish_async(); // un-permute x_p, no status read
   int exchange_status();             // after exchange_unpack(3): 0 ok, 1 some rank's factorisation failed (synchronises)
+  // Collectives inside the library (comm.h): the whole sharded solve and the LM scalars without a Python / torch layer.
+  Comm comm;
+  void comm_init_rccl(int rank, int world, const char* id128);
+  void comm_all_reduce(double* dev, size_t n, int op);
+  int solve_sharded();                       // Schur pass, three all-reduces, subtree-distributed factorisation, back-substitution
+  double chi2_sharded();                     // activeRobustChi2 over all ranks
+  double max_diagonal_sharded();             // computeLambdaInit's maximum over the SUMMED pose diagonal and all landmarks
+  double compute_scale_sharded(double lambda);
  private:
   struct Exchange {
     int nbb = 0, nbp = 0, nh = 0;

@@ -2675,6 +2675,131 @@ int BlockSolver::exchange_status() {
   return 0;
 }
 
+// ---- sharded solve / LM scalars with the collectives inside the library ------------------------------------------
+// x'(lambda x + b) of this rank: b_p holds this rank's contributions only (they sum to b_p over the ranks), x_p is valid
+// for the poses this rank's landmarks observe (own, shared, halo) -- exactly where its b_p can be non-zero; lambda x^2
+// is counted once per pose, by the rank that damps it (mask), and for every local landmark.
+__global__ void __launch_bounds__(kThreads) scale_sharded_partial_kernel(size_t nPose, size_t n, const double* __restrict__ x,
+                                                                         const double* __restrict__ b, double lambda, int pd,
+                                                                         const unsigned char* __restrict__ mask,
+                                                                         double* __restrict__ partial) {
+  __shared__ double sh[kThreads];
+  double s = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double bi = b[i];
+    if (i < nPose) {
+      const double xi = (bi != 0.0 || (mask && mask[i / pd])) ? x[i] : 0.0;   // (entries of foreign poses are never read)
+      s += xi * bi;
+      if (!mask || mask[i / pd]) s += lambda * xi * xi;
+    } else {
+      s += x[i] * (lambda * x[i] + bi);
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(kThreads) max_partial_kernel(size_t n, const double* __restrict__ v, double* __restrict__ partial) {
+  __shared__ double sh[kThreads];
+  double s = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s = fmax(s, fabs(v[i]));
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+void BlockSolver::comm_init_rccl(int rank, int world, const char* id128) {
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));   // the communicator binds to the current device
+  comm.init_rccl(rank, world, id128);
+}
+void BlockSolver::comm_all_reduce(double* dev, size_t n, int op) {
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  comm.all_reduce(dev, n, op, st_);
+}
+
+int BlockSolver::solve_sharded() {
+  require_structure();
+  if (!schur_) throw StateFailure("solve_sharded: the sharded path needs the Schur complement");
+  if (comm.kind() == Comm::kNone && chol_opt.world > 1) throw StateFailure("solve_sharded: no communicator (g2ohip_comm_init_*)");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  // (1) local Schur pass; boundary blocks of the reduced system + boundary right-hand sides summed over the ranks
+  solve_schur();
+  if (ex_.nbb > 0 || ex_.nbp > 0) {
+    exchange_pack(1);
+    comm.all_reduce(ex_.buf1.p, (size_t)ex_.nbb * p_ * p_ + (size_t)ex_.nbp * p_, 0, st_);
+    exchange_unpack(1);
+  }
+  // (2) own subtrees: factor + forward sweep; update matrices / vectors of the subtree roots summed (separator-sized)
+  solve_reduced_local();
+  {
+    size_t n = 0;
+    double* xb = chol_->exchange_buffer(&n);
+    comm.all_reduce(xb, n, 0, st_);
+  }
+  // (3) shared top of the tree (redundant), backward sweep down the own subtrees; halo x_p + failure flags summed
+  solve_reduced_shared();
+  solve_reduced_finish_async();
+  exchange_pack(3);
+  comm.all_reduce(ex_.buf3.p, (size_t)ex_.nh * p_ + 1, 0, st_);
+  exchange_unpack(3);
+  solve_back_substitute();           // (harmless after a failed factorisation: the caller discards x)
+  return exchange_status();
+}
+
+double BlockSolver::chi2_sharded() {
+  double v = chi2();
+  comm.all_reduce_host(&v, 1, 0, st_);
+  return v;
+}
+
+double BlockSolver::compute_scale_sharded(double lambda) {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  const int nblocks = std::min(1024, grid_for(vector_size()));
+  hipLaunchKernelGGL(scale_sharded_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, (size_t)nP_ * p_, vector_size(), d_x.p, d_b.p,
+                     lambda, p_, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr, d_red.p);
+  double v = reduce_sum_finish(nblocks);
+  comm.all_reduce_host(&v, 1, 0, st_);
+  return v;
+}
+
+double BlockSolver::max_diagonal_sharded() {
+  require_structure();
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  // pose diagonal: every rank holds its own contributions -> sum over the ranks first, then the maximum
+  const size_t np = (size_t)nP_ * p_;
+  DevBuf<double> diag;
+  diag.alloc(np);
+  hipLaunchKernelGGL(gather_diag_kernel, dim3(grid_for(np)), dim3(kThreads), 0, st_, nP_, p_, d_Hpp.p, d_pp_diag.p, 0.0, diag.p);
+  comm.all_reduce(diag.p, np, 0, st_);
+  double m = 0.0;
+  {
+    const int nblocks = std::min(1024, grid_for(np));
+    hipLaunchKernelGGL(max_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, np, diag.p, d_red.p);
+    std::vector<double> h(nblocks);
+    d_red.download(h.data(), nblocks, st_);
+    for (double v : h) m = std::max(m, v + lam_pose_);
+  }
+  double ml = 0.0;
+  if (nL_ > 0) {
+    const int nblocks = std::min(1024, grid_for((size_t)nL_ * l_));
+    hipLaunchKernelGGL(maxdiag_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, nL_, l_, d_Hll.p, (const int*)nullptr, d_red.p);
+    std::vector<double> h(nblocks);
+    d_red.download(h.data(), nblocks, st_);
+    for (double v : h) ml = std::max(ml, v + lam_lm_);
+  }
+  comm.all_reduce_host(&ml, 1, 1, st_);
+  return std::max(m, ml);
+}
+
 void BlockSolver::partition_info(int* pose_owner, int* block_consumer) {
   require_structure();
   const CholSymbolic& S = chol_->symbolic();

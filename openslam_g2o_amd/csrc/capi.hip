@@ -561,6 +561,42 @@ int g2ohip_ba_discard_top(g2ohip_solver* s) {
   });
 }
 
+int g2ohip_comm_unique_id(char* id128) {
+  if (!id128) return G2OHIP_ERR_ARG;
+  return guarded([&] { Comm::unique_id(id128); return G2OHIP_OK; });
+}
+int g2ohip_comm_init_rccl(g2ohip_solver* s, int rank, int world, const char* id128) {
+  if (!s || !id128 || world < 1 || rank < 0 || rank >= world) return G2OHIP_ERR_ARG;
+  return guarded([&] { s->impl->comm_init_rccl(rank, world, id128); return G2OHIP_OK; });
+}
+int g2ohip_comm_init_host(g2ohip_solver* s, int rank, int world, g2ohip_host_allreduce_fn fn, void* ctx) {
+  if (!s || !fn || world < 1 || rank < 0 || rank >= world) return G2OHIP_ERR_ARG;
+  return guarded([&] { s->impl->comm.init_host(rank, world, fn, ctx); return G2OHIP_OK; });
+}
+int g2ohip_comm_destroy(g2ohip_solver* s) {
+  if (!s) return G2OHIP_ERR_ARG;
+  return guarded([&] { s->impl->comm.destroy(); return G2OHIP_OK; });
+}
+int g2ohip_comm_all_reduce(g2ohip_solver* s, double* device_buffer, size_t count, int op) {
+  if (!s || (count && !device_buffer)) return G2OHIP_ERR_ARG;
+  return guarded([&] { s->impl->comm_all_reduce(device_buffer, count, op); return G2OHIP_OK; });
+}
+int g2ohip_solve_sharded(g2ohip_solver* s) {
+  if (!s) return G2OHIP_ERR_ARG;
+  return guarded([&] { return s->impl->solve_sharded() ? G2OHIP_NOT_PD : G2OHIP_OK; });
+}
+int g2ohip_chi2_sharded(g2ohip_solver* s, double* chi2) {
+  if (!s || !chi2) return G2OHIP_ERR_ARG;
+  return guarded([&] { *chi2 = s->impl->chi2_sharded(); return G2OHIP_OK; });
+}
+int g2ohip_max_diagonal_sharded(g2ohip_solver* s, double* out) {
+  if (!s || !out) return G2OHIP_ERR_ARG;
+  return guarded([&] { *out = s->impl->max_diagonal_sharded(); return G2OHIP_OK; });
+}
+int g2ohip_compute_scale_sharded(g2ohip_solver* s, double lambda, double* out) {
+  if (!s || !out) return G2OHIP_ERR_ARG;
+  return guarded([&] { *out = s->impl->compute_scale_sharded(lambda); return G2OHIP_OK; });
+}
 int g2ohip_copy_diagonal(g2ohip_solver* s, double* diag_host) {
   if (!s) return G2OHIP_ERR_ARG;
   return guarded([&] { s->impl->copy_diagonal(diag_host); return G2OHIP_OK; });

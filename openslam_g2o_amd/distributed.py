@@ -521,9 +521,63 @@ class ShardedBlockSolver:
         L.solveBackSubstitute()
         return True
 
+    # ---- collectives inside libg2ohip (g2ohip_comm_*, g2ohip_solve_sharded): no torch op in the iteration ----------
+    def attach_library_comm(self, kind="auto"):
+        """Give the local solver its own communicator and let the library run the whole sharded solve and the LM scalars.
+        kind "rccl": ncclCommInitRank inside the library (the unique id travels through torch.distributed once);
+        "host": an all-reduce over host memory through torch.distributed (gloo) -- ranks sharing one GPU, tests;
+        "auto": rccl when the process group's backend is nccl, host otherwise.  Returns True when attached."""
+        if self.mode != "subtree" or self.x_exchange != "halo" or not hasattr(self.local, "solveSharded"):
+            return False
+        if not self._native_exchange():
+            return False
+        import torch
+        import torch.distributed as dist
+        have_pg = dist.is_available() and dist.is_initialized()
+        if kind == "auto":
+            kind = "rccl" if (have_pg and dist.get_backend() == "nccl") or (self.world == 1 and not have_pg) else "host"
+        if kind == "rccl":
+            if self.world > 1:
+                idt = torch.zeros(128, dtype=torch.uint8, device=self._torch_device)
+                if self.rank == 0:
+                    idt = torch.frombuffer(bytearray(self.local.commUniqueId()), dtype=torch.uint8).to(self._torch_device)
+                dist.broadcast(idt, src=0)
+                uid = bytes(idt.cpu().numpy().tobytes())
+            else:
+                uid = self.local.commUniqueId()
+            self.local.commInitRccl(self.rank, self.world, uid)
+        else:
+            def host_all_reduce(buf, op):
+                if self.world <= 1:
+                    return
+                t = torch.from_numpy(buf)          # shares the pinned staging memory: reduced in place
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+            self.local.commInitHost(self.rank, self.world, host_all_reduce)
+        self._lib_comm = kind
+        return True
+
+    def setRobustKernel(self, kind, delta):
+        return self.local.setRobustKernel(self.set_id, kind, delta)
+
+    def maxDiagonal(self):
+        if getattr(self, "_lib_comm", None):
+            return self.local.maxDiagonalSharded()
+        if self.world <= 1:
+            return self.local.maxDiagonal()
+        raise RuntimeError("maxDiagonal over several ranks needs attach_library_comm()")
+
+    def computeScale(self, lam):
+        if getattr(self, "_lib_comm", None):
+            return self.local.computeScaleSharded(lam)
+        if self.world <= 1:
+            return self.local.computeScale(lam)
+        raise RuntimeError("computeScale over several ranks needs attach_library_comm()")
+
     def solve(self):
         if self.mode == "pcg":
             return self._solve_pcg()
+        if self.mode == "subtree" and getattr(self, "_lib_comm", None):
+            return self.local.solveSharded()
         if self.mode == "subtree":
             return self._solve_subtree()
         if not self.exchange:
@@ -537,6 +591,8 @@ class ShardedBlockSolver:
         return True
 
     def chi2(self):
+        if getattr(self, "_lib_comm", None):
+            return self.local.chi2Sharded()
         dev = self._torch_device if getattr(self, "_torch_device", None) is not None else "cpu"
         return self.comm.all_reduce_scalar(self.local.chi2(), dev)
 
@@ -545,3 +601,36 @@ class ShardedBlockSolver:
 
     def x_landmarks_local(self):
         return self.local.x()[self.p * self.local.nP:]
+
+
+class ShardedBAGraph:
+    """lm.py's graph protocol over a ShardedBlockSolver whose shard was set up with fused=True: every rank linearises,
+    updates and stacks ITS edges / landmarks and its copy of the cameras (x_p is valid for the cameras its landmarks
+    observe: own, shared, halo); chi2 is the sum over the ranks (sparse_optimizer.cpp:100-114)."""
+
+    device_resident = False     # (the fused solve_async / trial_stats pair is a single-GPU shortcut)
+
+    def __init__(self, solver):
+        self.s = solver
+
+    def linearize(self):
+        self.s.local.baLinearize(True)
+
+    def compute_active_errors(self):
+        self.s.local.baLinearize(False)
+
+    def chi2(self):
+        return self.s.chi2()
+
+    def update(self):
+        self.s.local.baUpdate()
+
+    def push(self):
+        self.s.local.baPush()
+
+    def pop(self):
+        self.s.local.baPop()
+
+    def discard_top(self):
+        self.s.local.baDiscardTop()
+

@@ -10,7 +10,7 @@ import socket
 import numpy as np
 import pytest
 
-from tests.helpers import ba_case, oracle_ba
+from tests.helpers import ba_case, oracle_ba, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -138,3 +138,90 @@ def test_sharded_matrix_free_pcg_matches_oracle(tmp_path, world):
         assert np.abs(z["xl"].reshape(-1, 3) - xl[z["lm_index"]]).max() <= 1e-6 * np.abs(xl).max()
         its.append(int(z["iters"]))
     assert len(set(its)) == 1 and its[0] > 0                                      # every rank took the same decisions
+
+
+def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir):
+    import torch
+    import torch.distributed as dist
+    from openslam_g2o_amd import capi, distributed as D, lm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        pr = ba_case(P, L, outlier_frac=outliers)
+        s = D.ShardedBlockSolver(6, 3, rank=rank, world=world, comm=D.HostStagedComm(world), mode="subtree")
+        s.setup_ba(pr, torch_device=dev, fused=True)
+        assert s.attach_library_comm("host")      # collectives inside libg2ohip (host callback: the ranks share one GPU)
+        if huber > 0:
+            s.setRobustKernel(capi.KERNEL_HUBER, huber)
+        g = D.ShardedBAGraph(s)
+        done, chis, lams, trials = lm.optimize(g, s, n_it, "lm")
+        cams, pts = s.local.baGetEstimates()
+        np.savez(os.path.join(out_dir, "lm%d.npz" % rank), done=done, chis=chis, lams=lams, trials=trials, cams=cams, pts=pts,
+                 lm_index=s.lm_index, pose_owner=s.pose_owner, halo=s.halo)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_lm_with_huber_matches_single_rank_and_oracle(tmp_path, world):
+    """BASELINE.json config 5 in its stated form at test size: Huber (delta 1, 5 % outliers) Levenberg-Marquardt with
+    per-iteration lambda damping on N ranks -- sharded buildSystem / Schur / subtree-distributed Cholesky with the collectives
+    inside the library (g2ohip_solve_sharded, *_sharded scalars), device-resident update / push / pop per shard.  The lambda
+    sequence, the trials per iteration and chi2 must equal the single-rank run and the oracle-driven loop
+    (optimization_algorithm_levenberg.cpp:57-172, base_binary_edge.hpp:92-112)."""
+    import torch.multiprocessing as mp
+    from openslam_g2o_amd import lm
+    from tests.test_gpu_lm import OracleBAGraph, OracleSolverAdapter
+    P, L, huber, outliers, n_it = 400, 3600, 1.0, 0.05, 6
+    mp.spawn(_lm_worker, args=(world, _free_port(), P, L, huber, outliers, n_it, str(tmp_path)), nprocs=world, join=True)
+    pr = ba_case(P, L, outlier_frac=outliers)
+    s1, g1 = lm.setup_device_ba(pr, huber_delta=huber)
+    done1, chis1, lams1, trials1 = lm.optimize(g1, s1, n_it, "lm")
+    og = OracleBAGraph(pr, huber)
+    done_o, chis_o, lams_o, trials_o = lm.optimize(og, OracleSolverAdapter(og.o), n_it, "lm")
+    assert done1 == done_o and trials1 == trials_o and np.allclose(chis1, chis_o, rtol=1e-6, atol=0)
+    cams1, pts1 = s1.baGetEstimates()
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "lm%d.npz" % r))
+        assert int(z["done"]) == done1 and list(z["trials"]) == trials1       # same accept / reject decisions on every rank
+        assert np.allclose(z["chis"], chis1, rtol=1e-6, atol=0) and np.allclose(z["chis"], chis_o, rtol=1e-6, atol=0)
+        assert np.allclose(z["lams"], lams1, rtol=1e-6, atol=0)
+        # estimates: the landmarks a rank owns, the cameras it owns / shares / needs (halo)
+        assert relerr(z["pts"], pts1[z["lm_index"]]) < 1e-6
+        valid = (z["pose_owner"] == r) | (z["pose_owner"] < 0)
+        valid[z["halo"]] = True
+        free = pr["cam_hidx"] >= 0
+        cam_ok = np.ones(len(pr["cam_hidx"]), bool)
+        cam_ok[free] = valid[pr["cam_hidx"][free]]
+        assert relerr(z["cams"][cam_ok], cams1[cam_ok]) < 1e-6
+    assert chis1[-1] < chis1[0]
+
+
+def test_library_comm_over_rccl_single_rank():
+    """g2ohip_comm_init_rccl / ncclAllReduce inside the library on the one GPU a test box has (world 1): the sharded solve
+    through RCCL equals the plain solve."""
+    import torch
+    from openslam_g2o_amd import distributed as D
+    pr = ba_case(300, 3000)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    s = D.ShardedBlockSolver(6, 3, rank=0, world=1, mode="subtree", force_exchange=True)
+    s.setup_ba(pr, torch_device=dev, fused=True)
+    assert s.attach_library_comm("rccl")
+    s.buildSystem()
+    chi = s.chi2()
+    md = s.maxDiagonal()
+    s.setLambda(7.0, True)
+    assert s.solve()
+    sc = s.computeScale(7.0)
+    s.restoreDiagonal()
+    x = s.local.x()
+    o = oracle_ba(pr)
+    o.build_system()
+    assert abs(chi - o.chi2()) <= 1e-9 * chi and abs(md - o.max_diagonal()) <= 1e-12 * md
+    o.set_lambda(7.0, True)
+    assert o.solve()
+    assert relerr(x, o.x()) < 1e-7 and abs(sc - o.compute_scale(7.0)) <= 1e-6 * abs(sc)
