@@ -66,7 +66,13 @@ typedef struct g2ohip_stats {
   size_t choleskyNNZ;                /* scalar nnz(L)                        */
   size_t numFronts, numLevels, maxFrontDim;
   size_t iterationsLinearSolver;     /* PCG iterations of the last solve (G2OBatchStatistics::iterationsLinearSolver) */
+  double timeResiduals;              /* device front end: last error-only evaluation (computeActiveErrors)   */
+  double timeLinearize;              /* device front end: last error + Jacobian evaluation                   */
+  double timeUpdate;                 /* device front end: last oplus over all vertices (SparseOptimizer::update) */
+  size_t dependencyFallbacks;        /* dependency-driven launches that gave up waiting and were repeated level by level (0 expected) */
 } g2ohip_stats;
+/* (G2OBatchStatistics::timeIteration / levenbergIterations / chi2 belong to the caller's optimisation loop:
+ *  openslam_g2o_amd/lm.py fills them and prints the `g2o -stats` line, batch_stats.cpp:49-82.) */
 
 const char* g2ohip_last_error(void);
 int g2ohip_device_count(void);

@@ -44,7 +44,7 @@ struct EdgeSet {
 };
 
 struct SolverTimes {
-  double quadratic = 0, schur = 0, numeric = 0, linsolve = 0, backsub = 0;
+  double quadratic = 0, schur = 0, numeric = 0, linsolve = 0, backsub = 0, residuals = 0, linearize = 0, update = 0;
 };
 
 class BlockSolver {
@@ -219,6 +219,7 @@ class BlockSolver {
   DevBuf<int> d_pose_diag;                 // pose -> its diagonal block of the reduced system
   bool hschur_valid_ = true, virt_now_ = false;
  public:
+  size_t dependency_fallbacks = 0;   // dependency-driven launches that gave up and were repeated level by level
   bool marginals_reduced = false;   // compute_marginals: invert the reduced pose system instead of Hpp alone (the reference inverts Hpp)
  private:
   hipStream_t side_ = nullptr;
@@ -247,6 +248,8 @@ class BlockSolver {
   // linear_solver 2: PCG on the reduced system WITHOUT forming it (Hschur v = Hpp v + lambda v - Hpl Dinv Hpl' v)
   std::unique_ptr<BlockPCG> pcg_mf_, pcg_hpp_;
   DevBuf<int> d_pm_ptr, d_pm_q, d_pm_lm;     // pose-major lists of the Hpl blocks (block id, landmark)
+  DevBuf<int> d_mh_ptr, d_mh_q, d_mh_lm;     // ... the same for multiply_hessian (any mode)
+  std::unique_ptr<BlockPCG> mh_hpp_;         // gather-form symmetric product with Hpp (multiply_hessian)
   DevBuf<double> d_mf_l, d_mf_diag, d_mf_zero;
   bool mf_ready_ = false;
   int solve_matrix_free();
@@ -272,7 +275,7 @@ class BlockSolver {
     bool has_backup = false;
     bool err_valid = false, jac_valid = false;
   } pg_;
-  EventTimer tq_, ts_, tn_, tl_, tb_;
+  EventTimer tq_, ts_, tn_, tl_, tb_, tfe_;
   void require_structure() const;
   double reduce_sum_finish(int nblocks);
 };

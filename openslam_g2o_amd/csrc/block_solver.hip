@@ -716,53 +716,44 @@ __global__ void __launch_bounds__(kThreads) back_substitute_kernel(int nL, const
   }
 }
 
-// K14: dest += H src over the full system (one thread per stored block, fp64 atomics; not on the
-// per-iteration path of GN/LM -- used by Dogleg and residual checks)
-__global__ void __launch_bounds__(kThreads) spmv_sym_blocks_kernel(int ncols, int bs, const int* __restrict__ colptr, const int* __restrict__ row,
-                                       const double* __restrict__ val, const double* __restrict__ src, double* __restrict__ dst) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
-  for (int q = colptr[c]; q < colptr[c + 1]; ++q) {
-    const int r = row[q];
-    const double* B = val + (size_t)q * bs * bs;
-    for (int i = 0; i < bs; ++i) {
-      double t = 0.0;
-      for (int j = 0; j < bs; ++j) t += B[i + bs * j] * src[(size_t)c * bs + j];
-      atomicAdd(&dst[(size_t)r * bs + i], t);
-    }
-    if (r != c)
-      for (int j = 0; j < bs; ++j) {
-        double t = 0.0;
-        for (int i = 0; i < bs; ++i) t += B[i + bs * j] * src[(size_t)r * bs + i];
-        atomicAdd(&dst[(size_t)c * bs + j], t);
-      }
-  }
+// K14: dest += H src over the full system, destination-major like the assembly (no atomics: the result does not depend on
+// the launch's timing; Dogleg and the residual checks read it).  Hpp part: BlockPCG's gather-form symmetric product;
+// Hpl part: thread = scalar row of a pose over the pose-major list of its Hpl blocks / thread = landmark.
+__global__ void __launch_bounds__(kThreads) add_vec_kernel(size_t n, const double* __restrict__ a, double* __restrict__ y) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a[i];
 }
-__global__ void __launch_bounds__(kThreads) spmv_pl_kernel(int nL, int p, int l, size_t sizeP, const int* __restrict__ colptr, const int* __restrict__ row,
-                               const double* __restrict__ Hpl, const double* __restrict__ Hll, const double* __restrict__ src,
-                               double* __restrict__ dst) {
-  const int lm = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lm >= nL) return;
+__global__ void __launch_bounds__(kThreads) spmv_pl_pose_kernel(int nP, int p, int l, size_t sizeP, const int* __restrict__ pm_ptr,
+                                                              const int* __restrict__ pm_q, const int* __restrict__ pm_lm,
+                                                              const double* __restrict__ Hpl, const double* __restrict__ src,
+                                                              double* __restrict__ dst) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= (size_t)nP * p) return;
+  const int i = (int)(t / p), r = (int)(t - (size_t)i * p);
+  double acc = 0.0;
+  for (int k = pm_ptr[i]; k < pm_ptr[i + 1]; ++k) {   // ascending landmark order: fixed
+    const double* B = Hpl + (size_t)pm_q[k] * p * l + r;
+    const double* sv = src + sizeP + (size_t)pm_lm[k] * l;
+    for (int c = 0; c < l; ++c) acc += B[(size_t)p * c] * sv[c];
+  }
+  dst[t] += acc;
+}
+__global__ void __launch_bounds__(kThreads) spmv_pl_landmark_kernel(int nL, int p, int l, size_t sizeP, const int* __restrict__ colptr,
+                                                                  const int* __restrict__ row, const double* __restrict__ Hpl,
+                                                                  const double* __restrict__ Hll, const double* __restrict__ src,
+                                                                  double* __restrict__ dst) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= (size_t)nL * l) return;
+  const int lm = (int)(t / l), j = (int)(t - (size_t)lm * l);
+  double acc = 0.0;
   for (int q = colptr[lm]; q < colptr[lm + 1]; ++q) {
-    const int r = row[q];
-    const double* B = Hpl + (size_t)q * p * l;
-    for (int i = 0; i < p; ++i) {
-      double t = 0.0;
-      for (int j = 0; j < l; ++j) t += B[i + p * j] * src[sizeP + (size_t)lm * l + j];
-      atomicAdd(&dst[(size_t)r * p + i], t);
-    }
-    for (int j = 0; j < l; ++j) {
-      double t = 0.0;
-      for (int i = 0; i < p; ++i) t += B[i + p * j] * src[(size_t)r * p + i];
-      atomicAdd(&dst[sizeP + (size_t)lm * l + j], t);
-    }
+    const double* B = Hpl + (size_t)q * p * l + (size_t)p * j;
+    const double* sv = src + (size_t)row[q] * p;
+    for (int i = 0; i < p; ++i) acc += B[i] * sv[i];
   }
   const double* D = Hll + (size_t)lm * l * l;
-  for (int i = 0; i < l; ++i) {
-    double t = 0.0;
-    for (int j = 0; j < l; ++j) t += D[i + l * j] * src[sizeP + (size_t)lm * l + j];
-    atomicAdd(&dst[sizeP + (size_t)lm * l + i], t);
-  }
+  for (int c = 0; c < l; ++c) acc += D[j + l * c] * src[sizeP + (size_t)lm * l + c];
+  dst[sizeP + t] += acc;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1909,6 +1900,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   pcg_.reset();
   pcg_mf_.reset();
   pcg_hpp_.reset();
+  mh_hpp_.reset();
   mf_ready_ = false;
   chol_ = std::make_unique<SparseCholesky>(p);
   chol_->opt = chol_opt;
@@ -2464,7 +2456,7 @@ int BlockSolver::solve_reduced_impl() {
   }
   solve_reduced_device();
   bool bad = chol_->failed(st_);   // synchronises
-  if (bad && chol_->dependency_stall()) {   // (safety net of the dependency-driven launches: repeat with one launch per level)
+  if (bad && chol_->dependency_stall() && ++dependency_fallbacks) {   // (safety net of the dependency-driven launches: repeat with one launch per level)
     invalidate_graphs();
     solve_reduced_device();
     bad = chol_->failed(st_);
@@ -2557,7 +2549,7 @@ int BlockSolver::solve_reduced_finish() {
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   chol_->solve_end(d_x.p, st_);
   const bool bad = chol_->failed(st_);
-  if (bad && chol_->dependency_stall()) invalidate_graphs();   // this solve is reported failed; the next one runs level by level
+  if (bad && chol_->dependency_stall() && ++dependency_fallbacks) invalidate_graphs();   // this solve is reported failed; the next one runs level by level
   return bad ? 1 : 0;
 }
 
@@ -2669,7 +2661,7 @@ int BlockSolver::exchange_status() {
   G2OHIP_HIP_CHECK(hipMemcpyAsync(&flag, ex_.buf3.p + (size_t)ex_.nh * p_, sizeof(double), hipMemcpyDeviceToHost, st_));
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   if (flag != 0.0) {   // some rank failed; the local cleanup (dependency counters, stall fallback) runs where it applies
-    if (chol_->failed(st_) && chol_->dependency_stall()) invalidate_graphs();
+    if (chol_->failed(st_) && chol_->dependency_stall() && ++dependency_fallbacks) invalidate_graphs();
     return 1;
   }
   return 0;
@@ -3061,7 +3053,7 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
   } else if (deferred_status_) {
     bad = chol_->failed(st_);   // synchronises (covers the copy above: same stream)
     deferred_status_ = false;
-    if (bad && chol_->dependency_stall()) invalidate_graphs();   // reported failed; the next solve runs level by level
+    if (bad && chol_->dependency_stall() && ++dependency_fallbacks) invalidate_graphs();   // reported failed; the next solve runs level by level
   } else {
     G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   }
@@ -3087,14 +3079,42 @@ void BlockSolver::multiply_hessian(double* dest_host, const double* src_host) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t n = vector_size();
-  DevBuf<double> src, dst;
+  DevBuf<double> src, dst, tmp;
   src.upload(src_host, n, st_);
   dst.upload(dest_host, n, st_);
-  hipLaunchKernelGGL(spmv_sym_blocks_kernel, dim3(grid_for(nP_)), dim3(kThreads), 0, st_, nP_, p_, d_pp_colptr.p, d_pp_row.p, d_Hpp.p,
-                     src.p, dst.p);
-  if (nL_ > 0)
-    hipLaunchKernelGGL(spmv_pl_kernel, dim3(grid_for(nL_)), dim3(kThreads), 0, st_, nL_, p_, l_, (size_t)nP_ * p_, d_pl_colptr.p,
-                       d_pl_row.p, d_Hpl.p, d_Hll.p, src.p, dst.p);
+  const size_t sizeP = (size_t)nP_ * p_;
+  if (!mh_hpp_) {   // gather-form lists, once per structure
+    mh_hpp_ = std::make_unique<BlockPCG>(p_);
+    mh_hpp_->analyze(nP_, pp_colptr.data(), pp_row.data(), st_);
+    if (nL_ > 0) {
+      std::vector<int> ptr(nP_ + 1, 0), qq(pl_row.size()), lm(pl_row.size());
+      for (int r : pl_row) ptr[r + 1]++;
+      for (int i = 0; i < nP_; ++i) ptr[i + 1] += ptr[i];
+      std::vector<int> w(ptr.begin(), ptr.end() - 1);
+      for (int l = 0; l < nL_; ++l)
+        for (int q = pl_colptr[l]; q < pl_colptr[l + 1]; ++q) {
+          const int k = w[pl_row[q]]++;
+          qq[k] = q;
+          lm[k] = l;
+        }
+      if (qq.empty()) { qq.push_back(0); lm.push_back(0); }
+      d_mh_ptr.upload(ptr, st_);
+      d_mh_q.upload(qq, st_);
+      d_mh_lm.upload(lm, st_);
+    }
+  }
+  if (sizeP > 0) {
+    tmp.alloc(sizeP);
+    mh_hpp_->multiply(d_Hpp.p, src.p, tmp.p, st_);
+    hipLaunchKernelGGL(add_vec_kernel, dim3(grid_for(sizeP)), dim3(kThreads), 0, st_, sizeP, tmp.p, dst.p);
+  }
+  if (nL_ > 0) {
+    if (sizeP > 0)
+      hipLaunchKernelGGL(spmv_pl_pose_kernel, dim3(grid_for(sizeP)), dim3(kThreads), 0, st_, nP_, p_, l_, sizeP, d_mh_ptr.p, d_mh_q.p,
+                         d_mh_lm.p, d_Hpl.p, src.p, dst.p);
+    hipLaunchKernelGGL(spmv_pl_landmark_kernel, dim3(grid_for((size_t)nL_ * l_)), dim3(kThreads), 0, st_, nL_, p_, l_, sizeP,
+                       d_pl_colptr.p, d_pl_row.p, d_Hpl.p, d_Hll.p, src.p, dst.p);
+  }
   G2OHIP_HIP_CHECK(hipGetLastError());
   dst.download(dest_host, n, st_);
   if (lam_pose_ != 0.0 || lam_lm_ != 0.0) {   // virtual damping
@@ -3295,8 +3315,13 @@ void BlockSolver::ba_linearize(bool jacobians) {
   ba_.err_valid = true;
   if (need_jac) ba_.jac_valid = true;
   chi2_valid_ = false;
+  if (profiling) tfe_.start(st_);
   hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid_for(es.n)), dim3(kThreads), 0, st_, es.n, ba_.cams.p, ba_.pts.p, ba_.cam_v.p,
                      ba_.pt_v.p, ba_.meas.p, ba_.f, ba_.cx, ba_.cy, es.own_J0.p, es.own_J1.p, es.own_err.p, (jacobians && !fused) ? 1 : 0);
+  if (profiling) {
+    tfe_.stop(st_);
+    (jacobians ? times.linearize : times.residuals) = tfe_.seconds();
+  }
   G2OHIP_HIP_CHECK(hipGetLastError());
   es.has_err = true;
   if (jacobians) es.has_data = true;
@@ -3307,10 +3332,15 @@ void BlockSolver::ba_update() {
   if (ba_.n_cams <= 0) throw StateFailure("ba_update before ba_set_estimates");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ba_.err_valid = ba_.jac_valid = false;
+  if (profiling) tfe_.start(st_);
   hipLaunchKernelGGL(ba_update_cams_kernel, dim3(grid_for(ba_.n_cams)), dim3(kThreads), 0, st_, ba_.n_cams, ba_.cams.p, ba_.cam_hidx.p,
                      d_x.p);
   hipLaunchKernelGGL(ba_update_pts_kernel, dim3(grid_for((size_t)ba_.n_points * 3)), dim3(kThreads), 0, st_, ba_.n_points, ba_.pts.p,
                      ba_.pt_hidx.p, d_x.p + (size_t)nP_ * p_);
+  if (profiling) {
+    tfe_.stop(st_);
+    times.update = tfe_.seconds();
+  }
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 

@@ -420,6 +420,10 @@ int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out) {
   out->hessianDimension = out->hessianPoseDimension + out->hessianLandmarkDimension;
   fill_chol_stats(b.chol_stats(), out);
   out->iterationsLinearSolver = (size_t)b.pcg_iterations;
+  out->timeResiduals = b.times.residuals;
+  out->timeLinearize = b.times.linearize;
+  out->timeUpdate = b.times.update;
+  out->dependencyFallbacks = b.dependency_fallbacks;
   return G2OHIP_OK;
 }
 

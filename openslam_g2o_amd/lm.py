@@ -193,13 +193,31 @@ def dogleg_solve_iteration(graph, solver, st):
     return OK, current_chi
 
 
-def optimize(graph, solver, iterations, algorithm="lm", **lm_args):
+BATCH_STAT_FIELDS = ("iteration", "numVertices", "numEdges", "chi2", "timeResiduals", "timeLinearize", "timeQuadraticForm",
+                     "timeSchurComplement", "timeSymbolicDecomposition", "timeNumericDecomposition", "timeLinearSolution",
+                     "iterationsLinearSolver", "timeUpdate", "timeIteration", "levenbergIterations", "timeLinearSolver",
+                     "hessianDimension", "hessianPoseDimension", "hessianLandmarkDimension", "choleskyNNZ", "timeMarginals")
+
+
+def format_batch_stats(st):
+    """One line per iteration in the format of `g2o -stats <file>`: operator<<(ostream&, const G2OBatchStatistics&),
+    /root/reference/g2o/core/batch_stats.cpp:49-82 (PTHING(s) = "s= value\t ", same field order)."""
+    def fmt(v):
+        return "%d" % v if isinstance(v, int) else "%g" % v
+    return "".join("%s= %s\t " % (k, fmt(st.get(k, 0))) for k in BATCH_STAT_FIELDS)
+
+
+def optimize(graph, solver, iterations, algorithm="lm", stats=None, num_vertices=0, num_edges=0, **lm_args):
     """SparseOptimizer::optimize (sparse_optimizer.cpp:354-419): returns (#iterations done, chi2 per
-    iteration before its step, lambda per iteration, LM trials per iteration)."""
+    iteration before its step, lambda per iteration, LM trials per iteration).
+    stats: a list that receives one G2OBatchStatistics-like dict per iteration (sparse_optimizer.cpp:379-399; the solver
+    must have profiling on for the per-stage times): write them with format_batch_stats for a `-stats` compatible file."""
+    import time
     st = DoglegState(**lm_args) if algorithm == "dogleg" else LevenbergState(**lm_args)
     chis, lams, trials = [], [], []
     done = 0
     for it in range(iterations):
+        ts = time.perf_counter()
         if algorithm == "dogleg":
             res, _ = dogleg_solve_iteration(graph, solver, st)
             lams.append(st.delta)
@@ -213,6 +231,13 @@ def optimize(graph, solver, iterations, algorithm="lm", **lm_args):
         graph.compute_active_errors()
         chis.append(graph.chi2())
         done += 1
+        if stats is not None:
+            d = dict(solver.stats()) if hasattr(solver, "stats") else {}
+            d.update(iteration=it, numVertices=int(num_vertices), numEdges=int(num_edges), chi2=chis[-1],
+                     timeIteration=time.perf_counter() - ts, levenbergIterations=int(trials[-1]) if algorithm == "lm" else 0)
+            for k in ("hessianDimension", "hessianPoseDimension", "hessianLandmarkDimension", "choleskyNNZ", "iterationsLinearSolver"):
+                d[k] = int(d.get(k, 0))
+            stats.append(d)
         if res != OK:
             break
     return done, chis, lams, trials

@@ -210,3 +210,29 @@ def test_trial_stats_matches_the_three_separate_calls():
     b.restoreDiagonal()
     b.setLambda(3.0, True)
     assert b.solve()
+
+
+def test_batch_statistics_line_is_g2o_stats_compatible():
+    """G2OBatchStatistics (batch_stats.h:40-77) through lm.optimize(stats=...): every field of the `g2o -stats` line, in the
+    reference's order and "name= value<TAB> " format (batch_stats.cpp:49-82); the solver-side fields come from
+    g2ohip_get_stats (incl. the device front end's timeResiduals / timeLinearize / timeUpdate and the dependency-launch
+    fallback counter, expected 0)."""
+    import re
+    pr = ba_case(60, 600)
+    s, g = lm.setup_device_ba(pr)
+    s.setProfiling(True)
+    stats = []
+    n, chis, lams, trials = lm.optimize(g, s, 3, "lm", stats=stats, num_vertices=pr["nP"] + pr["nL"], num_edges=pr["E"])
+    assert len(stats) == n == 3
+    for it, d in enumerate(stats):
+        line = lm.format_batch_stats(d)
+        names = re.findall(r"(\w+)= ", line)
+        assert names == list(lm.BATCH_STAT_FIELDS) and line.count("\t ") == len(names)
+        assert d["iteration"] == it and d["levenbergIterations"] == trials[it] and d["chi2"] == chis[it]
+        assert d["hessianPoseDimension"] == 6 * pr["nP"] and d["hessianLandmarkDimension"] == 3 * pr["nL"]
+        # (the stage timers of the linear solve are filled by solve(); the device-resident trial queues the whole solve
+        # asynchronously -- g2ohip_solve_async -- and leaves them at the last synchronous value)
+        assert d["choleskyNNZ"] > 0 and d["timeIteration"] > 0 and d["timeNumericDecomposition"] >= 0
+        assert d["timeSchurComplement"] >= 0 and d["timeUpdate"] > 0 and d["timeResiduals"] > 0
+        assert d["dependencyFallbacks"] == 0
+
