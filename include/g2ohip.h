@@ -176,7 +176,10 @@ int g2ohip_kernel_time(g2ohip_solver* s, int slot, double* total_seconds, long* 
  * the solve status, the new chi2 and computeScale one after the other): g2ohip_solve_async queues g2ohip_solve and
  * leaves its status on the device; after the caller has updated the estimates and re-evaluated the errors,
  * g2ohip_trial_stats returns that status (solve_ok 1/0), activeRobustChi2 and computeScale(lambda) = x'(lambda x + b)
- * together.  Without a pending g2ohip_solve_async it just evaluates the two sums. */
+ * together.  Without a pending g2ohip_solve_async it just evaluates the two sums.  *solve_ok: 1 solved, 0 not positive
+ * definite, 2 the solve has to be REPEATED (a dependency-driven launch gave up waiting -- never observed, the safety net of
+ * DESIGN.md section 2; g2ohip_solve repeats by itself, the asynchronous pair leaves it to the caller: pop the estimates,
+ * run the trial again). */
 /* The reduced (Schur) system as an operator, never formed (what "linear_solver" 2 iterates on; callers that run their own
  * Krylov loop, e.g. sharded over GPUs with one all-reduce of the product per iteration, use these directly):
  * prepare: Dinv = (Hll + lambda_l I)^-1, bschur = b_p - Hpl Dinv b_l (g2ohip_device_array 100) and the diagonal blocks

@@ -240,7 +240,13 @@ class HipBlockSolver:
     def addEdgeSet(self, error_dim, v0, v1=None):
         v0 = _i32(v0)
         v1 = None if v1 is None else _i32(v1)
-        return _check(self.L.g2ohip_add_edge_set(self.h, error_dim, len(v0), _ip(v0), _ip(v1)), "add_edge_set")
+        if v1 is not None and len(v1) != len(v0):
+            raise ValueError("addEdgeSet: v0 and v1 must have one entry per edge")
+        sid = _check(self.L.g2ohip_add_edge_set(self.h, error_dim, len(v0), _ip(v0), _ip(v1)), "add_edge_set")
+        if not hasattr(self, "_set_sizes"):
+            self._set_sizes = {}
+        self._set_sizes[sid] = len(v0)      # (the wrappers check array lengths against it: the C ABI takes bare pointers)
+        return sid
 
     def buildStructure(self, num_poses, num_landmarks=0, schur=None):
         if schur is None:
@@ -267,6 +273,13 @@ class HipBlockSolver:
             if d is not None:
                 assert dev is None or dev == d, "mixing host and device arrays"
                 dev = d
+        n = getattr(self, "_set_sizes", {}).get(set_id)
+        if n:      # the C ABI takes bare pointers: a short array would be read out of bounds during the upload
+            numel = lambda a: int(a.size) if isinstance(a, np.ndarray) else int(a.numel())
+            ne, no = numel(arrs[3]), numel(arrs[2])
+            d = ne // n
+            if d * n != ne or no != n * d * d or numel(arrs[0]) % (n * d) or (arrs[1] is not None and numel(arrs[1]) % (n * d)):
+                raise ValueError("setEdgeData: array sizes do not fit the %d edges of set %d" % (n, set_id))
         self._keep[set_id] = arrs
         _check(self.L.g2ohip_set_edge_data(self.h, set_id, ptrs[0], ptrs[1], ptrs[2], ptrs[3], int(bool(dev))),
                "setEdgeData")
@@ -356,6 +369,8 @@ class HipBlockSolver:
         """(solve status of a pending solveAsync, chi2, computeScale(lam)) behind one synchronisation."""
         ok, chi, sc = C.c_int(1), C.c_double(0.0), C.c_double(0.0)
         _check(self.L.g2ohip_trial_stats(self.h, float(lam), C.byref(ok), C.byref(chi), C.byref(sc)), "trialStats")
+        if ok.value == 2:
+            return None, chi.value, sc.value      # repeat the trial (see g2ohip_trial_stats)
         return bool(ok.value), chi.value, sc.value
 
     def solveReducedFinishAsync(self):
@@ -474,6 +489,9 @@ class HipBlockSolver:
     def baSetEdges(self, set_id, cam_vertex, point_vertex, meas, info=None, f=1000.0, cx=320.0, cy=240.0):
         cv, pv, m = _i32(cam_vertex), _i32(point_vertex), _f64(meas)
         inf = None if info is None else _f64(info)
+        n = self._set_sizes[set_id]
+        if len(cv) != n or len(pv) != n or m.size != 2 * n or (inf is not None and inf.size != 4 * n):
+            raise ValueError("baSetEdges: arrays must hold one entry per edge of set %d (%d edges)" % (set_id, n))
         _check(self.L.g2ohip_ba_set_edges(self.h, set_id, _ip(cv), _ip(pv), _dp(m), None if inf is None else _dp(inf),
                                           f, cx, cy), "baSetEdges")
 
@@ -561,6 +579,9 @@ class HipBlockSolver:
     def pgSetEdges(self, set_id, edge_type, vi, vj, meas, info):
         vi, vj, meas, info = _i32(vi), _i32(vj), _f64(meas), _f64(info)
         self._pg = (edge_type, 3 if edge_type == 1 else 12)
+        n, d = self._set_sizes[set_id], (3 if edge_type == 1 else 6)
+        if len(vi) != n or len(vj) != n or meas.size != n * self._pg[1] or info.size != n * d * d:
+            raise ValueError("pgSetEdges: arrays must hold one entry per edge of set %d (%d edges)" % (set_id, n))
         _check(self.L.g2ohip_pg_set_edges(self.h, set_id, edge_type, _ip(vi), _ip(vj), _dp(meas), _dp(info)), "pgSetEdges")
 
     def pgSetEstimates(self, poses, hidx):

@@ -254,10 +254,13 @@ class BlockSolver {
   bool mf_ready_ = false;
   int solve_matrix_free();
   void mf_prepare_lists();
+  void ba_validate();
+  void pg_validate();
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
     double f = 0, cx = 0, cy = 0;
     DevBuf<int> cam_v, pt_v, cam_hidx, pt_hidx, edge_hpl;
+    std::vector<int> h_cam_v, h_pt_v, h_cam_hidx, h_pt_hidx;   // host copies: index validation (ba_validate)
     bool omega_identity = false;   // information = identity for the whole set (info == NULL): not read per edge
     bool err_valid = false, jac_valid = false;   // errors / Jacobians of the set match the current estimates
     bool fused_ok = false;   // every Hpl block has exactly one observation: fused on-the-fly assembly allowed
@@ -271,6 +274,7 @@ class BlockSolver {
   struct PgFrontEnd {   // pose-graph front end: type 1 = EdgeSE2 (x, y, theta), 2 = EdgeSE3 (isometries T[12])
     int set = -1, type = 0, nv = 0;
     DevBuf<int> vi, vj, hidx;
+    std::vector<int> h_vi, h_vj, h_hidx;
     DevBuf<double> meas, poses, poses_bak;
     bool has_backup = false;
     bool err_valid = false, jac_valid = false;

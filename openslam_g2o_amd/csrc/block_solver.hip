@@ -3045,7 +3045,7 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
   G2OHIP_HIP_CHECK(hipGetLastError());
   std::vector<double> h((nsets + 1) * kMaxBlocks);
   G2OHIP_HIP_CHECK(hipMemcpyAsync(h.data(), d_red_multi.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
-  bool bad = false;
+  bool bad = false, stalled = false;
   if (sync_status_ >= 0) {
     bad = sync_status_ != 0;
     sync_status_ = -1;
@@ -3053,7 +3053,10 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
   } else if (deferred_status_) {
     bad = chol_->failed(st_);   // synchronises (covers the copy above: same stream)
     deferred_status_ = false;
-    if (bad && chol_->dependency_stall() && ++dependency_fallbacks) invalidate_graphs();   // reported failed; the next solve runs level by level
+    if (bad && chol_->dependency_stall() && ++dependency_fallbacks) {
+      invalidate_graphs();   // the next solve runs level by level
+      stalled = true;        // NOT "not positive definite": the caller repeats the trial (solve() does that itself)
+    }
   } else {
     G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   }
@@ -3072,7 +3075,7 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
       if (esp->external) chi2_valid_ = false;
   }
   *chi2_out = chi2_value_;
-  *ok = bad ? 0 : 1;
+  *ok = stalled ? 2 : (bad ? 0 : 1);
 }
 
 void BlockSolver::multiply_hessian(double* dest_host, const double* src_host) {
@@ -3201,6 +3204,11 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
   ba_.set = set;
   ba_.n_edges = es.n;
   ba_.f = f; ba_.cx = cx; ba_.cy = cy;
+  ba_.h_cam_v.assign(cam_vertex, cam_vertex + n);
+  ba_.h_pt_v.assign(point_vertex, point_vertex + n);
+  ba_validate();
+  ba_.err_valid = ba_.jac_valid = false;
+  es.has_err = false;      // errors of the previous edge data are gone
   ba_.cam_v.upload(cam_vertex, n, st_);
   ba_.pt_v.upload(point_vertex, n, st_);
   ba_.meas.upload(meas, n * 2, st_);
@@ -3278,6 +3286,40 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
 }
 
+// Edge -> estimate indices against the estimate tables and against the edge set's hessian indices: a wrong index would be
+// an out-of-bounds device read in the linearisation kernels, a mismatch a silently inconsistent system.  Runs as soon as
+// both ba_set_edges and ba_set_estimates have been called (in either order).
+void BlockSolver::ba_validate() {
+  if (ba_.set < 0 || ba_.h_cam_v.empty() || ba_.h_cam_hidx.empty()) return;
+  const EdgeSet& es = *sets_[ba_.set];
+  const int nc = (int)ba_.h_cam_hidx.size(), np = (int)ba_.h_pt_hidx.size();
+  for (size_t k = 0; k < ba_.h_cam_v.size(); ++k) {
+    const int c = ba_.h_cam_v[k], q = ba_.h_pt_v[k];
+    if (c < 0 || c >= nc) throw ArgFailure("ba: camera index " + std::to_string(c) + " of edge " + std::to_string(k) + " outside the estimate table");
+    if (q < 0 || q >= np) throw ArgFailure("ba: point index " + std::to_string(q) + " of edge " + std::to_string(k) + " outside the estimate table");
+    const int hc = ba_.h_cam_hidx[c], hp = ba_.h_pt_hidx[q];
+    if (hc >= nP_ || hp >= nL_) throw ArgFailure("ba: hessian index of an estimate outside the structure");
+    const int v1 = hc < 0 ? -1 : hc, v0 = hp < 0 ? -1 : nP_ + hp;
+    if (es.v1[k] != v1 || es.v0[k] != v0)
+      throw ArgFailure("ba: edge " + std::to_string(k) + " connects vertices (" + std::to_string(es.v0[k]) + ", " + std::to_string(es.v1[k]) +
+                       ") in the edge set but estimates with hessian indices (" + std::to_string(v0) + ", " + std::to_string(v1) + ")");
+  }
+}
+
+void BlockSolver::pg_validate() {
+  if (pg_.set < 0 || pg_.h_vi.empty() || pg_.h_hidx.empty()) return;
+  const EdgeSet& es = *sets_[pg_.set];
+  const int nv = (int)pg_.h_hidx.size();
+  for (size_t k = 0; k < pg_.h_vi.size(); ++k) {
+    const int a = pg_.h_vi[k], b = pg_.h_vj[k];
+    if (a < 0 || a >= nv || b < 0 || b >= nv) throw ArgFailure("pg: vertex index of edge " + std::to_string(k) + " outside the estimate table");
+    const int ha = pg_.h_hidx[a], hb = pg_.h_hidx[b];
+    if (ha >= nP_ || hb >= nP_) throw ArgFailure("pg: hessian index of an estimate outside the structure");
+    if (es.v0[k] != (ha < 0 ? -1 : ha) || es.v1[k] != (hb < 0 ? -1 : hb))
+      throw ArgFailure("pg: edge " + std::to_string(k) + ": the estimates' hessian indices differ from the edge set's");
+  }
+}
+
 void BlockSolver::ba_set_estimates(int n_cams, const double* cams, const int* cam_hidx, int n_points, const double* points,
                                    const int* point_hidx) {
   invalidate_graphs();
@@ -3285,6 +3327,9 @@ void BlockSolver::ba_set_estimates(int n_cams, const double* cams, const int* ca
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ba_.n_cams = n_cams;
   ba_.n_points = n_points;
+  ba_.h_cam_hidx.assign(cam_hidx, cam_hidx + n_cams);
+  ba_.h_pt_hidx.assign(point_hidx, point_hidx + n_points);
+  ba_validate();
   ba_.cams.upload(cams, (size_t)n_cams * 12, st_);
   ba_.pts.upload(points, (size_t)n_points * 3, st_);
   ba_.cam_hidx.upload(cam_hidx, n_cams, st_);
@@ -3380,6 +3425,10 @@ void BlockSolver::pg_set_edges(int set, int type, const int* vi, const int* vj, 
   const size_t n = (size_t)es.n, ms = type == 1 ? 3 : 12;
   pg_.set = set;
   pg_.type = type;
+  pg_.h_vi.assign(vi, vi + n);
+  pg_.h_vj.assign(vj, vj + n);
+  pg_.set = set;
+  pg_validate();
   pg_.vi.upload(vi, n, st_);
   pg_.vj.upload(vj, n, st_);
   pg_.meas.upload(meas, n * ms, st_);
@@ -3400,6 +3449,8 @@ void BlockSolver::pg_set_estimates(int nv, const double* poses, const int* hidx)
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t ps = pg_.type == 1 ? 3 : 12;
   pg_.nv = nv;
+  pg_.h_hidx.assign(hidx, hidx + nv);
+  pg_validate();
   pg_.poses.upload(poses, (size_t)nv * ps, st_);
   pg_.hidx.upload(hidx, (size_t)nv, st_);
   pg_.poses_bak.alloc((size_t)nv * ps);

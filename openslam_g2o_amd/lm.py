@@ -56,6 +56,16 @@ def levenberg_solve_iteration(graph, solver, st, iteration):
             solver.restoreDiagonal()
             graph.compute_active_errors()
             ok2, temp_chi, sc = solver.trialStats(st.current_lambda)
+            if ok2 is None:      # the asynchronous solve has to be repeated (g2ohip_trial_stats status 2): redo the trial in
+                graph.pop()      # the synchronous form, which retries by itself -- same values, same decisions
+                graph.push()
+                solver.setLambda(st.current_lambda, True)
+                ok2 = solver.solve()
+                graph.update()
+                solver.restoreDiagonal()
+                graph.compute_active_errors()
+                temp_chi = graph.chi2()
+                sc = solver.computeScale(st.current_lambda) if ok2 else 0.0
         else:
             ok2 = solver.solve()
             graph.update()

@@ -236,3 +236,28 @@ def test_batch_statistics_line_is_g2o_stats_compatible():
         assert d["timeSchurComplement"] >= 0 and d["timeUpdate"] > 0 and d["timeResiduals"] > 0
         assert d["dependencyFallbacks"] == 0
 
+
+
+def test_front_end_rejects_inconsistent_indices():
+    """g2ohip_ba_set_edges / g2ohip_ba_set_estimates validate the edge -> estimate indices and their hessian indices
+    against the edge set (an out-of-range index would be an out-of-bounds device read, a mismatch a silently inconsistent
+    system); the wrappers check array lengths."""
+    from openslam_g2o_amd import capi
+    pr = ba_case(20, 120)
+    s = capi.HipBlockSolver(6, 3, 0)
+    k = s.addEdgeSet(2, pr["v0"], pr["v1"])
+    s.buildStructure(pr["nP"], pr["nL"], True)
+    with pytest.raises(ValueError):
+        s.baSetEdges(k, pr["cam_idx"][:-1], pr["pt_idx"], pr["meas"], None, pr["f"], pr["cx"], pr["cy"])
+    s.baSetEdges(k, pr["cam_idx"], pr["pt_idx"], pr["meas"], None, pr["f"], pr["cx"], pr["cy"])
+    bad = pr["cam_hidx"].copy()
+    bad[5], bad[6] = bad[6], bad[5]                      # two cameras swap their hessian indices
+    with pytest.raises(capi.G2oHipError):
+        s.baSetEstimates(pr["cams"], bad, pr["pts"], np.arange(pr["L"], dtype=np.int32))
+    with pytest.raises(capi.G2oHipError):                # a point table that is too short
+        s.baSetEstimates(pr["cams"], pr["cam_hidx"], pr["pts"][:-3], np.arange(pr["L"] - 3, dtype=np.int32))
+    s.baSetEstimates(pr["cams"], pr["cam_hidx"], pr["pts"], np.arange(pr["L"], dtype=np.int32))
+    s.baLinearize(True)
+    s.buildSystem()
+    s.setLambda(1.0, True)
+    assert s.solve()
