@@ -296,15 +296,16 @@ def main():
     # same command (profiles/r1_pmc_traffic.json, recipe in its _note); null when that file is absent
     # or the workload differs from the profiled one.
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if os.path.exists(pmc_path) and world == 1 and (P, L) == (100000, 1000000):
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % r) for r in (9, 8, 7, 6, 5, 4, 3, 2, 1))
+                     if os.path.exists(q)), "")
+    if pmc_path and world == 1 and (P, L) == (100000, 1000000):
         pmc = json.load(open(pmc_path)).get(dname)
         if pmc:
             traffic = pmc["hbm_bytes_per_step"]
     roofline = dict(kernel=dname, bound="hbm", achieved=dk["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=dk["achieved_GBs"] / HBM_PEAK_GBS, traffic=traffic,
                     algorithmic_bytes_per_launch=kb.get(dname, 0), avg_launch_ms=dk["avg_ms"],
-                    traffic_source="profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, 2x FETCH correction)"
+                    traffic_source="profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, 2x FETCH correction)" % os.path.basename(pmc_path)
                     if traffic else None)
 
     x_gpu = solver.local.x()

@@ -220,6 +220,7 @@ class BlockSolver {
   bool hschur_valid_ = true, virt_now_ = false;
  public:
   size_t dependency_fallbacks = 0;   // dependency-driven launches that gave up and were repeated level by level
+  bool ba_recompute_backsub = true;   // fused BA path: back-substitution from the Jacobians instead of reading Hpl
   bool marginals_reduced = false;   // compute_marginals: invert the reduced pose system instead of Hpp alone (the reference inverts Hpp)
  private:
   hipStream_t side_ = nullptr;
@@ -255,12 +256,17 @@ class BlockSolver {
   int solve_matrix_free();
   void mf_prepare_lists();
   void ba_validate();
+  bool ba_recompute_ok() const;
   void pg_validate();
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
     double f = 0, cx = 0, cy = 0;
     DevBuf<int> cam_v, pt_v, cam_hidx, pt_hidx, edge_hpl;
     std::vector<int> h_cam_v, h_pt_v, h_cam_hidx, h_pt_hidx;   // host copies: index validation (ba_validate)
+    // which estimates the assembled system was built from (back-substitution re-evaluates the Jacobians from them)
+    long est_version = 0, bak_version = 0, sys_version = -1;
+    int sys_kind = 0;
+    double sys_delta = 0.0;
     bool omega_identity = false;   // information = identity for the whole set (info == NULL): not read per edge
     bool err_valid = false, jac_valid = false;   // errors / Jacobians of the set match the current estimates
     bool fused_ok = false;   // every Hpl block has exactly one observation: fused on-the-fly assembly allowed
@@ -268,7 +274,7 @@ class BlockSolver {
     DevBuf<double> meas_pm, omega_pm;   // pose-major copies (observation-list order of the pose side)
     DevBuf<int> pt_pm, cam_pm;
     DevBuf<double> meas_lm, omega_lm;   // landmark-major copies
-    DevBuf<int> cam_lm, pt_lm, hpl_lm;
+    DevBuf<int> cam_lm, pt_lm, hpl_lm, row_lm;   // (row_lm: pose block row of the observation's Hpl block, -1 = fixed pose)
     bool has_backup = false;
   } ba_;
   struct PgFrontEnd {   // pose-graph front end: type 1 = EdgeSE2 (x, y, theta), 2 = EdgeSE3 (isometries T[12])

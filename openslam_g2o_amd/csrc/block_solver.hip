@@ -995,6 +995,66 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landma
     if (G == 1 || (i % G) == g) bl[(size_t)lm * 3 + i] = b[i];
 }
 
+// K13 for the fused EdgeProjectXYZ2UV path: x_l = Dinv (b_l - Hpl' x_p) WITHOUT reading Hpl (block_solver.hpp:459-483).
+// Hpl(pose, lm)' x_p = A' (w Omega) (B x_p): the two Jacobians of an observation are re-evaluated from the estimates the
+// system was built from (12 + 3 + 2 doubles, the poses out of L2) instead of streaming an 18-double block per
+// observation -- the kernel moves a sixth of the bytes.  G lanes per landmark like the assembly.
+template <int G>
+__global__ void __launch_bounds__(kThreads) ba_back_substitute_kernel(
+    int nL, const int* __restrict__ vptr, const double* __restrict__ cams, const double* __restrict__ pts,
+    const int* __restrict__ cam_lm, const int* __restrict__ pt_lm, const double* __restrict__ meas_lm, const double* __restrict__ omega_lm,
+    const int* __restrict__ row_lm, double f, double cx, double cy, int kind, double delta, int ident,
+    const double* __restrict__ Dinv, const double* __restrict__ bl, const double* __restrict__ xp, double* __restrict__ xl) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lm = gt / G, g = gt % G;
+  const bool active = lm < nL;
+  double c[3] = {0.0, 0.0, 0.0};
+  const int k0 = active ? vptr[lm] : 0, k1 = active ? vptr[lm + 1] : 0;
+  for (int k = k0 + g; k < k1; k += G) {
+    const int row = row_lm[k];
+    if (row < 0) continue;   // fixed pose: no Hpl block
+    double T[12], X[3], z2[2], Op[4], xv[6];
+    const double* Xp = pts + (size_t)pt_lm[k] * 3;
+    X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+    load_vec<12>(cams + (size_t)cam_lm[k] * 12, T);
+    load_vec<2>(meas_lm + (size_t)k * 2, z2);
+    load_vec<6>(xp + (size_t)row * 6, xv);
+    if (ident) {
+      Op[0] = Op[3] = 1.0;
+      Op[1] = Op[2] = 0.0;
+    } else {
+      load_vec<4>(omega_lm + (size_t)k * 4, Op);
+    }
+    BaEdgeLin L;
+    ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
+    double t0 = 0.0, t1 = 0.0;   // B x_p
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      t0 += L.B[0 + 2 * a] * xv[a];
+      t1 += L.B[1 + 2 * a] * xv[a];
+    }
+    const double w = L.w;
+    const double u0 = w * (L.O[0] * t0 + L.O[2] * t1), u1 = w * (L.O[1] * t0 + L.O[3] * t1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[j] -= L.A[0 + 2 * j] * u0 + L.A[1 + 2 * j] * u1;
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[j] = group_sum<G>(c[j]);
+  }
+  if (!active || g >= 3) return;
+  double cl[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) cl[j] = c[j] + bl[(size_t)lm * 3 + j];
+  const double* D = Dinv + (size_t)lm * 9;
+  if (G == 1) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xl[(size_t)lm * 3 + i] = D[i] * cl[0] + D[i + 3] * cl[1] + D[i + 6] * cl[2];
+  } else {
+    xl[(size_t)lm * 3 + g] = D[g] * cl[0] + D[g + 3] * cl[1] + D[g + 6] * cl[2];
+  }
+}
+
 // Pose side: G lanes per free pose walk its observations, re-evaluate the pose Jacobian on the fly
 // and reduce Hpp_ii / b_i with DPP butterflies.
 #ifndef G2OHIP_ASMP_OCC
@@ -2066,6 +2126,7 @@ void BlockSolver::build_system() {
 
 void BlockSolver::build_system_impl() {
   if (profiling) tq_.start(st_);
+  ba_.sys_version = -1;   // (set again by the fused BA branch)
   const size_t sizeP = (size_t)nP_ * p_;
   bool any_pose = false, any_lm = false;
   int set_index = -1;
@@ -2075,6 +2136,9 @@ void BlockSolver::build_system_impl() {
     if (es.n == 0) continue;
     if (set_index == ba_.set && ba_fused && ba_.fused_ok && ba_.n_cams > 0) {
       // fused EdgeProjectXYZ2UV path: errors + Jacobians evaluated inside the assembly kernels
+      ba_.sys_version = ba_.est_version;
+      ba_.sys_kind = es.kernel_kind;
+      ba_.sys_delta = es.delta;
       // The two sides write disjoint arrays (Hll / b_l / Hpl and Hpp / b_p): the pose side runs on a side stream
       // next to the landmark side unless one of them is being timed on its own.
       const bool overlap = overlap_assembly && es.touches_pose && !prof.timing(KernelProf::kAsmLandmark) && !prof.timing(KernelProf::kAsmPose);
@@ -2810,6 +2874,21 @@ void BlockSolver::solve_back_substitute_impl() {
   if (profiling) tb_.start(st_);
   const size_t sizeP = (size_t)nP_ * p_;
   prof.begin(KernelProf::kBackSub, st_);
+  if (ba_recompute_ok()) {
+    // fused EdgeProjectXYZ2UV system, estimates unchanged since build_system: Hpl' x_p from the Jacobians, Hpl is not read
+    EdgeSet& es = *sets_[ba_.set];
+    const double avgK = (double)es.n_vl_ent / std::max(1, nL_);
+    const int GL = avgK <= 1.5 ? 1 : (avgK <= 4.0 ? 4 : 8);
+#define G2OHIP_BA_BACK(GG)                                                                                                        \
+  hipLaunchKernelGGL((ba_back_substitute_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p,    \
+                     ba_.cams.p, ba_.pts.p, ba_.cam_lm.p, ba_.pt_lm.p, ba_.meas_lm.p, ba_.omega_lm.p, ba_.row_lm.p, ba_.f,          \
+                     ba_.cx, ba_.cy, es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_x.p,           \
+                     d_x.p + sizeP)
+    if (GL == 1) G2OHIP_BA_BACK(1);
+    else if (GL == 4) G2OHIP_BA_BACK(4);
+    else G2OHIP_BA_BACK(8);
+#undef G2OHIP_BA_BACK
+  } else
 #define G2OHIP_BACK(P_, L_)                                                                                                    \
   if (p_ == P_ && l_ == L_)                                                                                                    \
     hipLaunchKernelGGL((back_substitute_kernel<P_, L_>), dim3(grid_for(nL_)), dim3(kThreads), 0, st_, nL_, d_pl_colptr.p,        \
@@ -3256,7 +3335,7 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
     // the same for the landmark side (observation-list order of the landmarks)
     const size_t nl = es.h_vl_ent.size();
     std::vector<double> mlm(nl * 2), olm(ba_.omega_identity ? 0 : nl * 4);
-    std::vector<int> clm(nl), hlm(nl), plm(nl);
+    std::vector<int> clm(nl), hlm(nl), plm(nl), rlm(nl);
     for (size_t k = 0; k < nl; ++k) {
       const size_t e = (size_t)(es.h_vl_ent[k] >> 1);
       mlm[2 * k] = meas[2 * e];
@@ -3265,6 +3344,7 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
       plm[k] = point_vertex[e];
       const int a = es.v0[e], b = es.v1[e];
       hlm[k] = (a >= 0 && b >= 0) ? find_block(pl_colptr, pl_row, a - nP_, b) : -1;
+      rlm[k] = hlm[k] >= 0 ? b : -1;
       if (!ba_.omega_identity)
         for (int i = 0; i < 4; ++i) olm[4 * k + i] = info[4 * e + i];
     }
@@ -3272,6 +3352,7 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
     ba_.cam_lm.upload(clm, st_);
     ba_.pt_lm.upload(plm, st_);
     ba_.hpl_lm.upload(hlm, st_);
+    ba_.row_lm.upload(rlm, st_);
     if (!ba_.omega_identity) ba_.omega_lm.upload(olm, st_);
     ba_.meas_pm.upload(mpm, st_);
     ba_.pt_pm.upload(ppm, st_);
@@ -3289,6 +3370,19 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
 // Edge -> estimate indices against the estimate tables and against the edge set's hessian indices: a wrong index would be
 // an out-of-bounds device read in the linearisation kernels, a mismatch a silently inconsistent system.  Runs as soon as
 // both ba_set_edges and ba_set_estimates have been called (in either order).
+// May the back-substitution re-evaluate the Jacobians instead of reading Hpl?  The system must come from the fused BA
+// assembly of the CURRENT estimates (an LM trial solves before it updates; a rejected trial pops back to them), with the
+// same robust kernel, and no other edge set may contribute pose-landmark blocks.
+bool BlockSolver::ba_recompute_ok() const {
+  if (!ba_recompute_backsub || !schur_ || p_ != 6 || l_ != 3 || ba_.set < 0 || !ba_fused || !ba_.fused_ok || ba_.n_cams <= 0) return false;
+  if (ba_.sys_version < 0 || ba_.sys_version != ba_.est_version) return false;
+  const EdgeSet& bs = *sets_[ba_.set];
+  if (bs.kernel_kind != ba_.sys_kind || bs.delta != ba_.sys_delta) return false;
+  for (size_t i = 0; i < sets_.size(); ++i)
+    if ((int)i != ba_.set && sets_[i]->n > 0 && sets_[i]->touches_lm) return false;
+  return true;
+}
+
 void BlockSolver::ba_validate() {
   if (ba_.set < 0 || ba_.h_cam_v.empty() || ba_.h_cam_hidx.empty()) return;
   const EdgeSet& es = *sets_[ba_.set];
@@ -3327,6 +3421,7 @@ void BlockSolver::ba_set_estimates(int n_cams, const double* cams, const int* ca
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ba_.n_cams = n_cams;
   ba_.n_points = n_points;
+  ++ba_.est_version;
   ba_.h_cam_hidx.assign(cam_hidx, cam_hidx + n_cams);
   ba_.h_pt_hidx.assign(point_hidx, point_hidx + n_points);
   ba_validate();
@@ -3377,6 +3472,7 @@ void BlockSolver::ba_update() {
   if (ba_.n_cams <= 0) throw StateFailure("ba_update before ba_set_estimates");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ba_.err_valid = ba_.jac_valid = false;
+  ++ba_.est_version;
   if (profiling) tfe_.start(st_);
   hipLaunchKernelGGL(ba_update_cams_kernel, dim3(grid_for(ba_.n_cams)), dim3(kThreads), 0, st_, ba_.n_cams, ba_.cams.p, ba_.cam_hidx.p,
                      d_x.p);
@@ -3397,6 +3493,7 @@ void BlockSolver::ba_push() {
   G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.cams_bak.p, ba_.cams.p, (size_t)ba_.n_cams * 12 * sizeof(double), hipMemcpyDeviceToDevice, st_));
   G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.pts_bak.p, ba_.pts.p, (size_t)ba_.n_points * 3 * sizeof(double), hipMemcpyDeviceToDevice, st_));
   ba_.has_backup = true;
+  ba_.bak_version = ba_.est_version;
 }
 void BlockSolver::ba_pop() {
   if (!ba_.has_backup) throw StateFailure("ba_pop without push");
@@ -3404,6 +3501,7 @@ void BlockSolver::ba_pop() {
   G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.cams.p, ba_.cams_bak.p, (size_t)ba_.n_cams * 12 * sizeof(double), hipMemcpyDeviceToDevice, st_));
   G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.pts.p, ba_.pts_bak.p, (size_t)ba_.n_points * 3 * sizeof(double), hipMemcpyDeviceToDevice, st_));
   ba_.has_backup = false;
+  ba_.est_version = ba_.bak_version;
 }
 void BlockSolver::ba_discard_top() {
   if (!ba_.has_backup) throw StateFailure("ba_discard_top without push");

@@ -1,20 +1,22 @@
 #!/bin/bash
 # Regenerates what profiles/ holds (run on the GPU box from the repo root; results under gpurun_out/refresh/).
+#   bash tools/refresh_profiles.sh r2        (round prefix of the file names)
 set -u
+P=${1:-r2}
 OUT=$PWD/gpurun_out/refresh
 mkdir -p $OUT
-python bench.py --steps 20 --warmup 3 > $OUT/r1_bench.json 2> $OUT/bench.err
-python lm_bench.py > $OUT/r1_lm_config5.json 2> $OUT/lm.err
+python bench.py --steps 20 --warmup 3 > $OUT/${P}_bench.json 2> $OUT/bench.err
+python lm_bench.py > $OUT/${P}_lm_config5.json 2> $OUT/lm.err
 for n in 2 4 8; do python bench.py --emulate 0/$n --no-cpu-baseline --steps 20 --warmup 3 > $OUT/emu_$n.json 2>> $OUT/bench.err; done
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp
 rm -rf /tmp/pk /tmp/pf /tmp/pw
 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/bench.py --no-cpu-baseline --graph off --steps 5 --warmup 2 > $OUT/trace.log 2>&1
-python $R/tools/rocpd_summary.py $(find /tmp/pk -name "*.db" | head -1) $OUT/r1_kernel_stats.csv
-python $R/tools/level_times.py $(find /tmp/pk -name "*.db" | head -1) 2 > $OUT/level_times.txt
+python $R/tools/rocpd_summary.py $(find /tmp/pk -name "*.db" | head -1) $OUT/${P}_kernel_stats.csv
+python $R/tools/level_times.py $(find /tmp/pk -name "*.db" | head -1) 2 > $OUT/${P}_level_times.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o f -- python $R/bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1 > $OUT/pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o w -- python $R/bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1 > $OUT/pmc_w.log 2>&1
-python $R/tools/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) > $OUT/r1_pmc_traffic.json
+python $R/tools/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) > $OUT/${P}_pmc_traffic.json
 cd $R
 ls -la $OUT
