@@ -220,6 +220,7 @@ class BlockSolver {
   bool hschur_valid_ = true, virt_now_ = false;
  public:
   size_t dependency_fallbacks = 0;   // dependency-driven launches that gave up and were repeated level by level
+  bool ba_skip_hpl = true;            // fused BA path: Hpl is not written at all while nobody reads it (ensure_hpl)
   bool ba_recompute_backsub = true;   // fused BA path: back-substitution from the Jacobians instead of reading Hpl
   bool marginals_reduced = false;   // compute_marginals: invert the reduced pose system instead of Hpp alone (the reference inverts Hpp)
  private:
@@ -257,6 +258,10 @@ class BlockSolver {
   void mf_prepare_lists();
   void ba_validate();
   bool ba_recompute_ok() const;
+  bool ba_skip_hpl_ok() const;
+  void ensure_hpl();
+  void launch_ba_landmarks(bool write_hpl);
+  bool hpl_valid_ = true;
   void pg_validate();
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
@@ -274,6 +279,8 @@ class BlockSolver {
     DevBuf<double> meas_pm, omega_pm;   // pose-major copies (observation-list order of the pose side)
     DevBuf<int> pt_pm, cam_pm;
     DevBuf<double> meas_lm, omega_lm;   // landmark-major copies
+    DevBuf<int> cam_q, pt_q;            // per Hpl block (block order): camera / point of its observation
+    DevBuf<double> meas_q, omega_q;
     DevBuf<int> cam_lm, pt_lm, hpl_lm, row_lm;   // (row_lm: pose block row of the observation's Hpl block, -1 = fixed pose)
     bool has_backup = false;
   } ba_;

@@ -914,7 +914,11 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landma
     int nL, const int* __restrict__ vptr, const int* __restrict__ vent, const double* __restrict__ cams, const double* __restrict__ pts,
     const int* __restrict__ cam_lm, const int* __restrict__ pt_lm, const double* __restrict__ meas_lm, const double* __restrict__ omega_lm,
     const int* __restrict__ hpl_lm, double f, double cx, double cy, int kind, double delta, double* __restrict__ Hll,
-    double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ err, int ident, const int* __restrict__ pl_colptr) {
+    double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ err, int ident, const int* __restrict__ pl_colptr,
+    int write_hpl) {
+  // write_hpl == 0: nobody reads Hpl this iteration (the Schur tiles and the back-substitution re-evaluate the Jacobians,
+  // ba_schur_tile_kernel / ba_back_substitute_kernel): only Hll, b_l and the errors are produced -- 0.72 GB less to write
+  // at the metric configuration.
   // The Hpl blocks of a wave's landmarks are contiguous in HBM (block-CCS by landmark column).  Written by
   // their lanes directly they would be 16-byte pieces at a 144-byte stride (64 memory transactions per
   // store instruction); instead the wave collects them in LDS and streams them out fully coalesced.
@@ -963,7 +967,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landma
 #pragma unroll
       for (int a = 0; a < 3; ++a) H[a + 3 * c] += L.A[0 + 2 * a] * OA[0 + 2 * c] + L.A[1 + 2 * a] * OA[1 + 2 * c];
     }
-    const int q = hpl_lm[k];
+    const int q = write_hpl ? hpl_lm[k] : -1;
     if (q >= 0) {   // Hpl(pose, lm) = B' (w Omega) A  (written transposed, block_solver.hpp:240-244)
       double blk[18];
 #pragma unroll
@@ -974,7 +978,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landma
       else store_vec<18>(Hpl + (size_t)q * 18, blk);
     }
   }
-  if (staged) {   // (same wave wrote and reads: LDS operations of a wave complete in order)
+  if (staged && write_hpl) {   // (same wave wrote and reads: LDS operations of a wave complete in order)
     __builtin_amdgcn_wave_barrier();
     const dbl2_u* src = reinterpret_cast<const dbl2_u*>(&stage[wave][0]);
     dbl2_u* dst = reinterpret_cast<dbl2_u*>(Hpl + (size_t)q_base * 18);
@@ -993,6 +997,115 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landma
 #pragma unroll
   for (int i = 0; i < 3; ++i)
     if (G == 1 || (i % G) == g) bl[(size_t)lm * 3 + i] = b[i];
+}
+
+// The same tile pass for the fused EdgeProjectXYZ2UV path WITHOUT reading Hpl: the tile's Hpl blocks are evaluated from
+// the estimates the system was built from, straight into the LDS stage (one lane per block: projection, the two Jacobians,
+// the robust weight, B' (w Omega) A -- ~150 flops against 144 bytes of HBM read per block).  Hpl then never exists in HBM
+// unless somebody asks for it (BlockSolver::ensure_hpl).  Block q of Hpl <-> one observation (ba_set_edges checked that),
+// whose inputs are kept in block order (cam_q, pt_q, meas_q, omega_q).
+template <int G>
+__global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kernel(
+    const int* __restrict__ tile_lm0, const double* __restrict__ cams, const double* __restrict__ pts, const int* __restrict__ cam_q,
+    const int* __restrict__ pt_q, const double* __restrict__ meas_q, const double* __restrict__ omega_q, double f, double cx, double cy,
+    int kind, double delta, int ident, double* __restrict__ Dinv, const double* __restrict__ bl, const int* __restrict__ td_diag,
+    const int* __restrict__ td_ptr, const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm, double* __restrict__ Pd,
+    double* __restrict__ Pr, const double* __restrict__ Hll, const double* __restrict__ lam) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int PD = 6, LD = 3, PL = PD * LD;
+  const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int* tm = tile_lm0 + (size_t)t * 8;   // packed tile record (see build_structure)
+  const int l0 = tm[0], l1 = tm[1], q0 = tm[2], nslots = tm[3], nlm = l1 - l0;
+  const int td0 = tm[4], td1 = tm[5], e0 = tm[6], ne = tm[7];
+  double* Bs = smem;
+  double* Ds = Bs + ((nslots * PL + 1) & ~1);
+  double* bsm = Ds + ((nlm * LD * LD + 1) & ~1);
+  int* ep = reinterpret_cast<int*>(bsm + ((nlm * LD + 1) & ~1));
+  int* dptr = ep + ne;
+  int* ddiag = dptr + (td1 - td0 + 1);
+  unsigned short* el = reinterpret_cast<unsigned short*>(ddiag + (td1 - td0));
+  const int tid = threadIdx.x, NT = blockDim.x;
+  {
+    const double* srcD = Hll + (size_t)l0 * LD * LD;
+    const double* srcb = bl + (size_t)l0 * LD;
+    const int nD = nlm * LD * LD, nb = nlm * LD, ndp = td1 - td0 + 1;
+    constexpr int UD = 3, UE = 4;
+    double vD[UD], vb;
+    int vE[UE], vP, vG;
+    unsigned short vL[UE];
+    // the observation of this lane's block (first pass), requested with everything else the tile stages
+    const int s0 = min(tid, nslots - 1);
+    const int cq = cam_q[q0 + s0], pq = pt_q[q0 + s0];
+#pragma unroll
+    for (int u = 0; u < UD; ++u) vD[u] = srcD[min(tid + u * NT, nD - 1)];
+    vb = srcb[min(tid, nb - 1)];
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+      const int i = min(tid + u * NT, ne - 1);
+      vE[u] = te_pack[e0 + i];
+      vL[u] = te_lm[e0 + i];
+    }
+    vP = td_ptr[td0 + min(tid, ndp - 1)];
+    vG = td_diag[td0 + min(tid, max(ndp - 2, 0))];
+    for (int sb = 0; sb < nslots; sb += NT) {
+      const int s_ = sb + tid;
+      const int sc = min(s_, nslots - 1);
+      const int c_ = sb == 0 ? cq : cam_q[q0 + sc], p_ = sb == 0 ? pq : pt_q[q0 + sc];
+      double T[12], X[3], z2[2], Op[4];
+      load_vec<12>(cams + (size_t)c_ * 12, T);
+      const double* Xp = pts + (size_t)p_ * 3;
+      X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+      load_vec<2>(meas_q + (size_t)(q0 + sc) * 2, z2);
+      if (ident) {
+        Op[0] = Op[3] = 1.0;
+        Op[1] = Op[2] = 0.0;
+      } else {
+        load_vec<4>(omega_q + (size_t)(q0 + sc) * 4, Op);
+      }
+      BaEdgeLin L;
+      ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
+      const double w = L.w;
+      const double O00 = w * L.O[0], O10 = w * L.O[1], O01 = w * L.O[2], O11 = w * L.O[3];
+      double OA[6], blk[18];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        OA[0 + 2 * c] = O00 * L.A[0 + 2 * c] + O01 * L.A[1 + 2 * c];
+        OA[1 + 2 * c] = O10 * L.A[0 + 2 * c] + O11 * L.A[1 + 2 * c];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) blk[a + 6 * c] = L.B[0 + 2 * a] * OA[0 + 2 * c] + L.B[1 + 2 * a] * OA[1 + 2 * c];
+      if (s_ < nslots) store_vec<18>(Bs + s_ * 18, blk);
+    }
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      const int i = tid + u * NT;
+      if (i < nD) Ds[i] = vD[u];
+    }
+    if (tid < nb) bsm[tid] = vb;
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+      const int i = tid + u * NT;
+      if (i < ne) {
+        ep[i] = vE[u];
+        el[i] = vL[u];
+      }
+    }
+    if (tid < ndp) dptr[tid] = vP;
+    if (tid < ndp - 1) ddiag[tid] = vG;
+    if (nD > UD * NT) stage_copy<4>(Ds + UD * NT, srcD + UD * NT, nD - UD * NT, tid, NT);
+    if (nb > NT) stage_copy<2>(bsm + NT, srcb + NT, nb - NT, tid, NT);
+    if (ne > UE * NT) {
+      stage_copy<4>(ep + UE * NT, te_pack + e0 + UE * NT, ne - UE * NT, tid, NT);
+      stage_copy<4>(el + UE * NT, te_lm + e0 + UE * NT, ne - UE * NT, tid, NT);
+    }
+    if (ndp > NT) stage_copy<2>(dptr + NT, td_ptr + td0 + NT, ndp - NT, tid, NT);
+    if (ndp - 1 > NT) stage_copy<2>(ddiag + NT, td_diag + td0 + NT, ndp - 1 - NT, tid, NT);
+  }
+  __syncthreads();
+  schur_tile_invert<LD>(Ds, l0, nlm, Dinv, Hll, lam, tid, NT);
+  schur_tile_dests<PD, LD, G>(Bs, Ds, bsm, ep, dptr, ddiag, el, td0, td1, e0, Pd, Pr, tid, NT);
 }
 
 // K13 for the fused EdgeProjectXYZ2UV path: x_l = Dinv (b_l - Hpl' x_p) WITHOUT reading Hpl (block_solver.hpp:459-483).
@@ -2124,9 +2237,51 @@ void BlockSolver::build_system() {
   system_built_ = true;
 }
 
+// landmark side of the fused BA assembly: Hll, b_l, errors and -- when somebody will read it -- Hpl
+void BlockSolver::launch_ba_landmarks(bool write_hpl) {
+  EdgeSet& es = *sets_[ba_.set];
+  const size_t sizeP = (size_t)nP_ * p_;
+  const double avgK = (double)es.n_vl_ent / std::max(1, nL_);
+  const int GL = avgK <= 1.5 ? 1 : (avgK <= 4.0 ? 4 : 8);   // one observation per lane where possible
+#define G2OHIP_BA_LM(GG)                                                                                                         \
+  hipLaunchKernelGGL((ba_assemble_landmarks_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p, \
+                     es.vl_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_lm.p, ba_.pt_lm.p, ba_.meas_lm.p, ba_.omega_lm.p, ba_.hpl_lm.p, ba_.f, \
+                     ba_.cx, ba_.cy, es.kernel_kind, es.delta, d_Hll.p, d_b.p + sizeP, d_Hpl.p, es.own_err.p, ba_.omega_identity ? 1 : 0, \
+                     d_pl_colptr.p, write_hpl ? 1 : 0)
+  if (GL == 1) G2OHIP_BA_LM(1);
+  else if (GL == 4) G2OHIP_BA_LM(4);
+  else G2OHIP_BA_LM(8);
+#undef G2OHIP_BA_LM
+}
+
+// May the fused BA assembly leave Hpl unwritten?  Only while its two readers on the solve path (Schur tiles,
+// back-substitution) re-evaluate the Jacobians: direct solver, tiled Schur pass that covers every landmark.
+bool BlockSolver::ba_skip_hpl_ok() const {
+  return ba_skip_hpl && schur_ && p_ == 6 && l_ == 3 && linear_solver == 0 && n_tiles_ > 0 && tiles_cover_all_ && fuse_landmark_inverse &&
+         ba_recompute_backsub && ba_.set >= 0 && ba_fused && ba_.fused_ok && ba_.cam_q.p != nullptr && [&] {
+           for (size_t i = 0; i < sets_.size(); ++i)
+             if ((int)i != ba_.set && sets_[i]->n > 0 && sets_[i]->touches_lm) return false;
+           return true;
+         }();
+}
+
+// somebody reads Hpl (copy_values, multiplyHessian, the matrix-free operator, a solve path without the fused kernels)
+// after a build_system that skipped it
+void BlockSolver::ensure_hpl() {
+  if (hpl_valid_) return;
+  if (!ba_recompute_ok())
+    throw StateFailure("Hpl was not materialised by the last build_system and the estimates (or the robust kernel) have changed since: "
+                       "call build_system again, or set option ba_skip_hpl = 0");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  launch_ba_landmarks(true);   // the same kernel with the Hpl stores on (Hll, b_l and the errors come out identical)
+  hpl_valid_ = true;
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
 void BlockSolver::build_system_impl() {
   if (profiling) tq_.start(st_);
   ba_.sys_version = -1;   // (set again by the fused BA branch)
+  hpl_valid_ = true;
   const size_t sizeP = (size_t)nP_ * p_;
   bool any_pose = false, any_lm = false;
   int set_index = -1;
@@ -2152,19 +2307,8 @@ void BlockSolver::build_system_impl() {
         G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_, side_fork_, 0));
       }
       prof.begin(KernelProf::kAsmLandmark, st_);
-      {
-        const double avgK = (double)es.n_vl_ent / std::max(1, nL_);
-        const int GL = avgK <= 1.5 ? 1 : (avgK <= 4.0 ? 4 : 8);   // one observation per lane where possible
-#define G2OHIP_BA_LM(GG)                                                                                                         \
-  hipLaunchKernelGGL((ba_assemble_landmarks_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p, \
-                     es.vl_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_lm.p, ba_.pt_lm.p, ba_.meas_lm.p, ba_.omega_lm.p, ba_.hpl_lm.p, ba_.f, \
-                     ba_.cx, ba_.cy, es.kernel_kind, es.delta, d_Hll.p, d_b.p + sizeP, d_Hpl.p, es.own_err.p, ba_.omega_identity ? 1 : 0, \
-                     d_pl_colptr.p)
-        if (GL == 1) G2OHIP_BA_LM(1);
-        else if (GL == 4) G2OHIP_BA_LM(4);
-        else G2OHIP_BA_LM(8);
-#undef G2OHIP_BA_LM
-      }
+      hpl_valid_ = !ba_skip_hpl_ok();
+      launch_ba_landmarks(hpl_valid_);
       prof.end(KernelProf::kAsmLandmark, st_);
       prof.begin(KernelProf::kAsmPose, st_);
       const int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
@@ -2381,6 +2525,34 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
   const int G = schur_group > 0 ? schur_group : pick_group((double)n_sc_ / std::max<long>(1, n_td_));
   // every landmark lies in exactly one tile, so the tiles can invert the landmark blocks themselves
   const bool fuse_inv = fuse_landmark_inverse && n_tiles_ > 0 && tiles_cover_all_;
+  // fused EdgeProjectXYZ2UV system built from the current estimates: the tiles evaluate their Hpl blocks themselves
+  const bool ba_tiles = fuse_inv && p_ == 6 && l_ == 3 && ba_.cam_q.p != nullptr && ba_recompute_ok();
+  if (!ba_tiles) ensure_hpl();
+  if (ba_tiles) {
+    EdgeSet& es = *sets_[ba_.set];
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    prof.begin(KernelProf::kSchurBlocks, st_);
+#define G2OHIP_BA_TILE(GG)                                                                                                         \
+  hipLaunchKernelGGL((ba_schur_tile_kernel<GG>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p, ba_.cams.p,     \
+                     ba_.pts.p, ba_.cam_q.p, ba_.pt_q.p, ba_.meas_q.p, ba_.omega_q.p, ba_.f, ba_.cx, ba_.cy, es.kernel_kind, es.delta, \
+                     ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p, d_te_pack.p, d_te_lm.p, d_Pd.p,    \
+                     d_Pr.p, d_Hll.p, d_lam.p)
+    if (G <= 1) G2OHIP_BA_TILE(1);
+    else if (G <= 2) G2OHIP_BA_TILE(2);
+    else if (G <= 4) G2OHIP_BA_TILE(4);
+    else if (G <= 8) G2OHIP_BA_TILE(8);
+    else G2OHIP_BA_TILE(16);
+#undef G2OHIP_BA_TILE
+    prof.end(KernelProf::kSchurBlocks, st_);
+  } else
 #define G2OHIP_TILE_ARGS d_tile_lm0.p, d_tile_td0.p, d_pl_colptr.p, d_Hpl.p, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p, d_te_pack.p, \
                          d_te_lm.p, d_Pd.p, d_Pr.p, fuse_inv ? d_Hll.p : (const double*)nullptr, d_lam.p
 #define G2OHIP_SCHUR(P_, L_)                                                                                                   \
@@ -2888,6 +3060,7 @@ void BlockSolver::solve_back_substitute_impl() {
     else if (GL == 4) G2OHIP_BA_BACK(4);
     else G2OHIP_BA_BACK(8);
 #undef G2OHIP_BA_BACK
+  } else if ((ensure_hpl(), false)) {
   } else
 #define G2OHIP_BACK(P_, L_)                                                                                                    \
   if (p_ == P_ && l_ == L_)                                                                                                    \
@@ -2995,6 +3168,7 @@ void BlockSolver::schur_operator_prepare() {
   if (!system_built_) throw StateFailure("schur_operator_prepare before build_system");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   mf_prepare_lists();
+  ensure_hpl();
   const size_t sizeP = (size_t)nP_ * p_;
   const int gl = grid_for(nL_), gp = grid_for(sizeP);
   G2OHIP_MF_DISPATCH(
@@ -3161,6 +3335,7 @@ void BlockSolver::multiply_hessian(double* dest_host, const double* src_host) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t n = vector_size();
+  ensure_hpl();
   DevBuf<double> src, dst, tmp;
   src.upload(src_host, n, st_);
   dst.upload(dest_host, n, st_);
@@ -3256,7 +3431,7 @@ void BlockSolver::copy_values(int which, double* h) {
           for (int i = 0; i < p_; ++i) blk[i * (p_ + 1)] += lam_pose_;
         }
       break;
-    case 1: d_Hpl.download(h, pl_row.size() * p_ * l_, st_); break;
+    case 1: ensure_hpl(); d_Hpl.download(h, pl_row.size() * p_ * l_, st_); break;
     case 2:
       d_Hll.download(h, (size_t)nL_ * l_ * l_, st_);
       if (lam_lm_ != 0.0)
@@ -3316,6 +3491,25 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
     }
     ba_.fused_ok = unique;
     ba_.edge_hpl.upload(edge_hpl, st_);
+    if (unique) {   // the observation behind every Hpl block, in block order (ba_schur_tile_kernel)
+      const size_t nq = std::max<size_t>(pl_row.size(), 1);
+      std::vector<int> cq(nq, 0), pq(nq, 0);
+      std::vector<double> mq(nq * 2, 0.0), oq(info == om.data() ? 0 : nq * 4, 0.0);
+      for (size_t k = 0; k < n; ++k) {
+        const int q = edge_hpl[k];
+        if (q < 0) continue;
+        cq[q] = cam_vertex[k];
+        pq[q] = point_vertex[k];
+        mq[2 * (size_t)q] = meas[2 * k];
+        mq[2 * (size_t)q + 1] = meas[2 * k + 1];
+        if (!oq.empty())
+          for (int i = 0; i < 4; ++i) oq[4 * (size_t)q + i] = info[4 * k + i];
+      }
+      ba_.cam_q.upload(cq, st_);
+      ba_.pt_q.upload(pq, st_);
+      ba_.meas_q.upload(mq, st_);
+      if (!oq.empty()) ba_.omega_q.upload(oq, st_);
+    }
   }
   {
     // pose-major copies of what the pose-side assembly reads per observation (it walks a pose's observation list:
@@ -3708,7 +3902,7 @@ void BlockSolver::device_array(int which, double** ptr, size_t* count) {
   require_structure();
   switch (which) {
     case 0: *ptr = d_Hpp.p; *count = pp_row.size() * p_ * p_; break;
-    case 1: *ptr = d_Hpl.p; *count = pl_row.size() * p_ * l_; break;
+    case 1: ensure_hpl(); *ptr = d_Hpl.p; *count = pl_row.size() * p_ * l_; break;
     case 2: *ptr = d_Hll.p; *count = (size_t)nL_ * l_ * l_; break;
     case 3: ensure_hschur(); *ptr = d_Hschur.p; *count = hs_row.size() * p_ * p_; break;
     case 100: *ptr = d_bschur.p; *count = (size_t)nP_ * p_; break;
