@@ -181,3 +181,73 @@ def ba_oplus(prob, x):
     new["cams"] = _apply_cam_update(prob["cams"], upd)
     new["pts"] = prob["pts"] + xl
     return new
+
+
+def _quat_to_rot(q):
+    """Unit quaternions [n,4] (x, y, z, w) -> rotation matrices [n,3,3]."""
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.empty((len(q), 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - z * w); R[:, 0, 2] = 2 * (x * z + y * w)
+    R[:, 1, 0] = 2 * (x * y + z * w); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - x * w)
+    R[:, 2, 0] = 2 * (x * z - y * w); R[:, 2, 1] = 2 * (y * z + x * w); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def _iso_pack(R, t):
+    """[n,3,3], [n,3] -> [n,12] (R column-major | t): the isometry layout of the device front ends and the oracle."""
+    return np.concatenate([R.transpose(0, 2, 1).reshape(-1, 9), t], axis=1)
+
+
+def make_sphere(nodes_per_level=50, laps=50, radius=100.0, noise_translation=0.01, noise_rotation=0.005, seed=42):
+    """The generator of BASELINE.json's config 2 in its stated size: g2o's `create_sphere` with its defaults
+    (g2o/examples/sphere/create_sphere.cpp:55-57: 50 nodes per lap x 50 laps = 2 500 VertexSE3 on a sphere of radius 100;
+    :99-147 odometry edges between successive vertices and three loop closures per vertex to the lap before; :149-176
+    measurement noise sigma_t = 0.01, sigma_r = 0.005 on the quaternion's vector part with w = 1 - |v| before the
+    normalisation; :178-185 initial estimates by chaining the NOISY odometry), with this module's counter-based RNG instead
+    of the reference's unseeded sampler.  Vertex 0 is fixed.  Returns isometries as [n,12] (R column-major | t)."""
+    n = nodes_per_level * laps
+    idx = np.arange(n)
+    nn, f = idx % nodes_per_level, idx // nodes_per_level
+    az = -np.pi + 2.0 * nn * np.pi / nodes_per_level
+    ay = -0.5 * np.pi + (idx + 1) * np.pi / n                 # (the reference uses the post-incremented id here)
+    cz, sz, cy, sy = np.cos(az), np.sin(az), np.cos(ay), np.sin(ay)
+    Rz = np.zeros((n, 3, 3)); Ry = np.zeros((n, 3, 3))
+    Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1], Rz[:, 2, 2] = cz, -sz, sz, cz, 1.0
+    Ry[:, 0, 0], Ry[:, 0, 2], Ry[:, 2, 0], Ry[:, 2, 2], Ry[:, 1, 1] = cy, sy, -sy, cy, 1.0
+    R = Rz @ Ry
+    t = R[:, :, 0] * radius
+    vi = [np.arange(n - 1)]
+    vj = [np.arange(1, n)]
+    for lap in range(1, laps):
+        for d in (-1, 0, 1):
+            a = (lap - 1) * nodes_per_level + np.arange(nodes_per_level)
+            b = lap * nodes_per_level + np.arange(nodes_per_level) + d
+            if lap == laps - 1 and d == 1:
+                continue
+            vi.append(a)
+            vj.append(b)
+    # (the reference emits the three closures of a vertex together; the order of the edges only matters for the noise stream)
+    vi, vj = np.concatenate(vi).astype(np.int32), np.concatenate(vj).astype(np.int32)
+    E = len(vi)
+    Rt = R.transpose(0, 2, 1)
+    Rm = Rt[vi] @ R[vj]                                          # from^-1 * to
+    tm = np.einsum("nij,nj->ni", Rt[vi], t[vj] - t[vi])
+    rng = CounterRng(seed)
+    qv = np.stack([rng.normal(100 + c, E) for c in range(3)], axis=1) * noise_rotation
+    qw = np.maximum(1.0 - np.linalg.norm(qv, axis=1), 0.0)
+    q = np.concatenate([qv, qw[:, None]], axis=1)
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    Rm = Rm @ _quat_to_rot(q)
+    tm = tm + np.stack([rng.normal(110 + c, E) for c in range(3)], axis=1) * noise_translation
+    # initial estimates: vertex 0 at its true pose, the others by chaining the noisy odometry (EdgeSE3::initialEstimate)
+    Re, te = np.empty_like(R), np.empty_like(t)
+    Re[0], te[0] = R[0], t[0]
+    for i in range(1, n):
+        Re[i] = Re[i - 1] @ Rm[i - 1]
+        te[i] = Re[i - 1] @ tm[i - 1] + te[i - 1]
+    info = np.zeros((6, 6))
+    info[:3, :3] = np.eye(3) / noise_translation ** 2
+    info[3:, 3:] = np.eye(3) / noise_rotation ** 2
+    hidx = np.arange(n, dtype=np.int32) - 1                      # vertex 0 fixed
+    return dict(n=n, nP=n - 1, E=E, vi=vi, vj=vj, poses=_iso_pack(Re, te), poses_true=_iso_pack(R, t), Z=_iso_pack(Rm, tm),
+                omega=np.tile(info.T.reshape(1, 36), (E, 1)), hidx=hidx)

@@ -103,3 +103,45 @@ def test_levenberg_on_device_pose_graphs():
     done3, chis3, lams3, trials3 = lm.optimize(graph3, s3, 4, algorithm="lm")
     assert done3 == 4 and all(b < a for a, b in zip(chis3, chis3[1:]))
     assert abs(lams3[0] / (float(g3["lambda0"])) - 1.0 / 3.0) < 0.34   # lambda0 = tau * max diag, then shrinks by >= 1/3
+
+
+def test_sphere2500_generated_config2():
+    """BASELINE.json config 2 at its stated size: the 2 500-node sphere of g2o's create_sphere defaults
+    (create_sphere.cpp:55-57,99-185; openslam_g2o_amd.synthetic.make_sphere), VertexSE3 / EdgeSE3, BlockSolver_6_3
+    semantics, fp64, one GPU.  First damped system against the CPU oracle (Jacobians, b, dx), then Levenberg-Marquardt on
+    the device down to the noise level: chi2 at the optimum of a graph whose information matches its noise is ~ the degrees
+    of freedom 6 (E - N + 1)."""
+    from openslam_g2o_amd import lm, synthetic as S
+    capi = _capi()
+    g = S.make_sphere()
+    assert g["n"] == 2500 and g["E"] == 9799
+    s, graph = lm.setup_device_pose_graph(2, g["poses"], g["hidx"], g["nP"], g["vi"], g["vj"], g["Z"], g["omega"])
+    graph.linearize()
+    J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
+    dJ0, dJ1, derr = s.edgeData(0, g["E"], 6, 6, 6)
+    assert relerr(dJ0, J0) < TOL_J and relerr(dJ1, J1) < TOL_J and relerr(derr, err) < TOL_J
+    s.buildSystem()
+    o = O.OracleSolver(6, 3, g["nP"], 0, schur=False)
+    k = o.add_edge_set(6, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+    o.set_dims(k, 6, 6)
+    o.build_structure()
+    o.set_edge_data(k, J0, J1, g["omega"], err)
+    o.build_system()
+    assert relerr(s.b(), o.b()) < 1e-11 and abs(s.chi2() - o.chi2()) <= 1e-9 * o.chi2()
+    lam = 1e-5 * o.max_diagonal()
+    assert abs(s.maxDiagonal() - o.max_diagonal()) <= 1e-12 * o.max_diagonal()
+    s.setLambda(lam, True)
+    o.set_lambda(lam, True)
+    assert s.solve() and o.solve()
+    assert relerr(s.x(), o.x()) < 1e-8
+    s.restoreDiagonal()
+    done, chis, lams, trials = lm.optimize(graph, s, 30, algorithm="lm")
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(chis, chis[1:]))
+    dof = 6 * (g["E"] - g["n"] + 1)
+    assert 0.8 * dof < chis[-1] < 1.25 * dof, (chis[-1], dof)
+    est = s.pgGetEstimates()
+    # back on the sphere: the chained-odometry initial guess is off by a multiple of the radius at the far pole, the
+    # optimum by the random walk the measurement noise leaves (gauge: vertex 0)
+    e0 = np.abs(g["poses"][:, 9:] - g["poses_true"][:, 9:]).max()
+    e1 = np.abs(est[:, 9:] - g["poses_true"][:, 9:]).max()
+    assert e1 < 0.2 * e0 and e1 < 20.0, (e0, e1)

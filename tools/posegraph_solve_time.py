@@ -9,7 +9,11 @@ from oracle import oracle as O
 from tests.helpers import manhattan_golden, sphere_golden
 
 def run(name, opts):
-    if name == "sphere":
+    if name == "sphere2500":      # create_sphere defaults (config 2 at its stated size), generated
+        from openslam_g2o_amd import synthetic as S
+        g = S.make_sphere(); p, l, d = 6, 3, 6
+        J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
+    elif name == "sphere":
         g = sphere_golden(); p, l, d = 6, 3, 6
         J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
     else:
@@ -58,6 +62,6 @@ def run(name, opts):
                           "choleskyNNZ": st["choleskyNNZ"]}))
     print("%-10s %-28s %.3f ms/solve  fronts %d levels %d maxdim %d nnz %d" % (name, " ".join(opts), 1e3 * dt, st["numFronts"], st["numLevels"], st["maxFrontDim"], st["choleskyNNZ"]))
 
-for name in ("manhattan", "sphere"):
+for name in ("manhattan", "sphere", "sphere2500"):
     for o in sys.argv[1:] or [""]:
         run(name, [x for x in o.split(",") if x])
