@@ -7,8 +7,8 @@ other tracing domains next to --pmc):
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/f -o f -- python bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/w -o w -- python bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1
   python tools/pmc_traffic.py out/f/f_results.db out/w/w_results.db > profiles/rN_pmc_traffic.json
-Values: KiB per counter summed over the launches of a slot in the LAST bench iteration (identified as
-the last 1/iterations share of each kernel's dispatches; iterations = dispatches of a once-per-iteration kernel).  On gfx950 FETCH_SIZE tallies 64 B per 128 B
+Values: KiB per counter per bench iteration: median over a kernel's launches x its launches per iteration
+(iterations = dispatches of a once-per-iteration kernel).  On gfx950 FETCH_SIZE tallies 64 B per 128 B
 request for wide streaming reads, so hbm_bytes_per_step = (2*FETCH + WRITE) KiB * 1024; hbm_bytes_raw
 leaves FETCH unscaled (gather-type access is uncalibrated: the truth lies between the two)."""
 import json
@@ -44,7 +44,11 @@ def per_kernel(path, iters=None):
     out = {}
     for name, vals in by.items():
         n = len(vals) // iters if len(vals) >= iters else len(vals)
-        out[name] = (sum(vals[-n:]), n)
+        # median per launch x launches per step: a stray launch outside the iterations (e.g. the residual check's
+        # on-demand Hpl materialisation at the end of bench.py) must not stand in for the per-iteration traffic
+        sv = sorted(vals)
+        med = sv[len(sv) // 2]
+        out[name] = (med * n, n)
     return out
 
 
