@@ -2437,7 +2437,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
                          const double* bperm, double* yout, int dep, const int4* big_tiles, int bt_count, const BigLaunch& big,
                          int wide_doubles, bool wv, bool wv_narrow, int wv_pn, int wv_idx_ints, hipStream_t st) {
   if (wv) {   // every front of the launch fits the register-resident wave kernel: one wavefront per task
-    const size_t sh = ((size_t)kWvTiles * 256 + 64 + 2 * kWvT * 64 + 64) * sizeof(double) + (size_t)(2 * 16 * kWvT + 64) * sizeof(int);
+    const size_t sh = ((size_t)kWvTiles * 256 + 64 + 2 * kWvT * 64) * sizeof(double) + (size_t)(8 * 64 + 2 * 16 * kWvT + 2 * 64) * sizeof(int);
     if (wv_narrow)
       hipLaunchKernelGGL((wave_front_kernel<BS, VIRT, true>), dim3(lds_count), dim3(64 * kWvWaves), sh, st, wv_plan(P), lds_begin, dA, bperm, yout, dep);
     else
