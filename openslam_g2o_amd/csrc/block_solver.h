@@ -36,6 +36,7 @@ struct EdgeSet {
   // destination-major contributor lists
   DevBuf<int> vp_ptr, vp_ent, vl_ptr, vl_ent;  // per pose / per landmark: (edge << 1 | side)
   std::vector<int> h_vp_ent, h_vl_ent;         // host copies (pose- / landmark-major copies of per-edge inputs)
+  std::vector<int> h_vl_ptr;                   // ... and the landmark list bounds (lane slots of the fused Schur tiles)
   DevBuf<int> op_dst, op_ptr, op_ent;          // Hpp off-diagonal blocks: dest block id, (edge << 1 | transposed)
   DevBuf<int> ol_dst, ol_ptr, ol_ent;          // Hpl blocks
   int n_op = 0, n_ol = 0;
@@ -94,7 +95,10 @@ class BlockSolver {
   void copy_x(double* h);
   void copy_b(double* h);
   const double* x_device() const { return d_x.p; }
-  const double* b_device() const { return d_b.p; }
+  const double* b_device() {
+    ensure_ll();
+    return d_b.p;
+  }
   void sync();
   void set_stream(hipStream_t st);
   hipStream_t stream() const { return st_; }
@@ -221,6 +225,7 @@ class BlockSolver {
  public:
   size_t dependency_fallbacks = 0;   // dependency-driven launches that gave up and were repeated level by level
   bool ba_skip_hpl = true;            // fused BA path: Hpl is not written at all while nobody reads it (ensure_hpl)
+  bool ba_fuse_landmarks = true;      // ... and the landmark side (Hll, b_l, errors) is assembled by the Schur tiles of the solve
   bool ba_recompute_backsub = true;   // fused BA path: back-substitution from the Jacobians instead of reading Hpl
   bool marginals_reduced = false;   // compute_marginals: invert the reduced pose system instead of Hpp alone (the reference inverts Hpp)
  private:
@@ -237,6 +242,7 @@ class BlockSolver {
   DevBuf<int> d_hs_diag;                   // Hschur block -> pose index when diagonal, else -1
   // Schur tiles: landmark ranges, their destination blocks and LDS-local contributor entries
   DevBuf<int> d_tile_lm0, d_tile_td0, d_td_diag, d_td_ptr, d_te_pack, d_rd_ptr, d_rd_slot;
+  std::vector<int> tile_lm0_h_;   // first landmark of every tile (+ one past the last)
   DevBuf<unsigned short> d_te_lm;
   DevBuf<double> d_Pd, d_Pr;               // per (tile, destination) partial blocks / rhs
   int n_tiles_ = 0;
@@ -259,9 +265,13 @@ class BlockSolver {
   void ba_validate();
   bool ba_recompute_ok() const;
   bool ba_skip_hpl_ok() const;
+  bool ba_fuse_ll_ok() const;
+  int ba_lm_group() const;
   void ensure_hpl();
+  void ensure_ll();
   void launch_ba_landmarks(bool write_hpl);
   bool hpl_valid_ = true;
+  bool ll_valid_ = true;   // Hll, b_l and the errors of the fused BA path match the last build_system
   void pg_validate();
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
@@ -282,6 +292,16 @@ class BlockSolver {
     DevBuf<int> cam_q, pt_q;            // per Hpl block (block order): camera / point of its observation
     DevBuf<double> meas_q, omega_q;
     DevBuf<int> cam_lm, pt_lm, hpl_lm, row_lm;   // (row_lm: pose block row of the observation's Hpl block, -1 = fixed pose)
+    // Schur tiles that assemble their landmarks (ba_schur_tile_kernel<G, true>): lane slots of every tile -- observation
+    // (12 bits, relative to the tile's first one; 0xfff: none) | list length at the first lane of a landmark (8 bits) |
+    // landmark inside the tile at its first lane (12 bits; 0xfff elsewhere); a landmark never straddles a wavefront --
+    // and per tile (first slot, slots, first observation, longest list)
+    DevBuf<int4> ll_rec;      // per lane slot: (slot word, camera, point, Hpl block or -1)
+    DevBuf<int> ll_edge;      // ... edge id (error store)
+    DevBuf<int> ll_row;       // ... pose block row of the observation's Hpl block (-1: fixed pose)
+    DevBuf<double> ll_meas, ll_omega;   // ... measurement, information
+    DevBuf<int4> tile_ll;
+    bool ll_slots_ok = false;
     bool has_backup = false;
   } ba_;
   struct PgFrontEnd {   // pose-graph front end: type 1 = EdgeSE2 (x, y, theta), 2 = EdgeSE3 (isometries T[12])

@@ -902,6 +902,33 @@ __device__ __forceinline__ void ba_edge_linearize(const double* __restrict__ T, 
   L.B[1 + 2 * 3] = 0.0;                  L.B[1 + 2 * 4] = -fz;                  L.B[1 + 2 * 5] = yz * fz;
 }
 
+// One observation's contribution to its landmark: H += A' (w Omega) A, b -= A' (w Omega) r (base_binary_edge.hpp:86-118,
+// landmark half); OA = (w Omega) A is handed back for the Hpl block.  Shared by the stand-alone landmark assembly and by
+// the Schur tiles that assemble their landmarks themselves: the same operations in the same order.
+__device__ __forceinline__ void ba_lm_accumulate(const BaEdgeLin& L, double (&H)[9], double (&b)[3], double (&OA)[6]) {
+  const double w = L.w;
+  const double O00 = w * L.O[0], O10 = w * L.O[1], O01 = w * L.O[2], O11 = w * L.O[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    OA[0 + 2 * c] = O00 * L.A[0 + 2 * c] + O01 * L.A[1 + 2 * c];
+    OA[1 + 2 * c] = O10 * L.A[0 + 2 * c] + O11 * L.A[1 + 2 * c];
+  }
+  const double Or0 = O00 * L.r[0] + O01 * L.r[1], Or1 = O10 * L.r[0] + O11 * L.r[1];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    b[c] -= L.A[0 + 2 * c] * Or0 + L.A[1 + 2 * c] * Or1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) H[a + 3 * c] += L.A[0 + 2 * a] * OA[0 + 2 * c] + L.A[1 + 2 * a] * OA[1 + 2 * c];
+  }
+}
+// Hpl(pose, lm) = B' (w Omega) A, 6 x 3 column-major
+__device__ __forceinline__ void ba_hpl_block(const BaEdgeLin& L, const double (&OA)[6], double (&blk)[18]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int a = 0; a < 6; ++a) blk[a + 6 * c] = L.B[0 + 2 * a] * OA[0 + 2 * c] + L.B[1 + 2 * a] * OA[1 + 2 * c];
+}
+
 // Fused buildSystem for EdgeProjectXYZ2UV graphs, landmark side (K1-K2 of SURVEY.md 2.3 with the
 // reference's per-edge linearizeOplus + constructQuadraticForm, block_solver.hpp:529-532): one thread
 // per landmark walks its observations, evaluates error and Jacobians on the fly (no Jacobian arrays in
@@ -951,29 +978,12 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landma
     BaEdgeLin L;
     ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
     store_vec<2>(err + (size_t)e * 2, L.r);
-    // weighted information
-    const double w = L.w;
-    const double O00 = w * L.O[0], O10 = w * L.O[1], O01 = w * L.O[2], O11 = w * L.O[3];
-    double OA[6];   // (w Omega) A : 2x3
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      OA[0 + 2 * c] = O00 * L.A[0 + 2 * c] + O01 * L.A[1 + 2 * c];
-      OA[1 + 2 * c] = O10 * L.A[0 + 2 * c] + O11 * L.A[1 + 2 * c];
-    }
-    const double Or0 = O00 * L.r[0] + O01 * L.r[1], Or1 = O10 * L.r[0] + O11 * L.r[1];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      b[c] -= L.A[0 + 2 * c] * Or0 + L.A[1 + 2 * c] * Or1;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) H[a + 3 * c] += L.A[0 + 2 * a] * OA[0 + 2 * c] + L.A[1 + 2 * a] * OA[1 + 2 * c];
-    }
+    double OA[6];
+    ba_lm_accumulate(L, H, b, OA);
     const int q = write_hpl ? hpl_lm[k] : -1;
     if (q >= 0) {   // Hpl(pose, lm) = B' (w Omega) A  (written transposed, block_solver.hpp:240-244)
       double blk[18];
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int a = 0; a < 6; ++a) blk[a + 6 * c] = L.B[0 + 2 * a] * OA[0 + 2 * c] + L.B[1 + 2 * a] * OA[1 + 2 * c];
+      ba_hpl_block(L, OA, blk);
       if (staged) store_vec<18>(&stage[wave][(q - q_base) * 18], blk);
       else store_vec<18>(Hpl + (size_t)q * 18, blk);
     }
@@ -1004,13 +1014,20 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landma
 // the robust weight, B' (w Omega) A -- ~150 flops against 144 bytes of HBM read per block).  Hpl then never exists in HBM
 // unless somebody asks for it (BlockSolver::ensure_hpl).  Block q of Hpl <-> one observation (ba_set_edges checked that),
 // whose inputs are kept in block order (cam_q, pt_q, meas_q, omega_q).
-template <int G>
+// FLL: the tile also ASSEMBLES its landmarks (Hll, b_l, the errors: what ba_assemble_landmarks_kernel produces) while it
+// evaluates their observations for the Hpl blocks -- build_system then launches nothing for the landmark side and every
+// observation is evaluated once per iteration instead of twice.  Hll and b_l go to the LDS stage and to HBM (readers: the
+// back-substitution, b, computeScale, multiplyHessian); they are summed in observation-list order, the stand-alone kernel
+// sums per lane group: the two agree to rounding, not bit for bit.
+template <int G, bool FLL>
 __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kernel(
     const int* __restrict__ tile_lm0, const double* __restrict__ cams, const double* __restrict__ pts, const int* __restrict__ cam_q,
     const int* __restrict__ pt_q, const double* __restrict__ meas_q, const double* __restrict__ omega_q, double f, double cx, double cy,
-    int kind, double delta, int ident, double* __restrict__ Dinv, const double* __restrict__ bl, const int* __restrict__ td_diag,
+    int kind, double delta, int ident, double* __restrict__ Dinv, double* bl, const int* __restrict__ td_diag,
     const int* __restrict__ td_ptr, const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm, double* __restrict__ Pd,
-    double* __restrict__ Pr, const double* __restrict__ Hll, const double* __restrict__ lam) {
+    double* __restrict__ Pr, double* Hll, const double* __restrict__ lam, const int4* __restrict__ ll_rec,
+    const int4* __restrict__ tile_ll, const int* __restrict__ ll_edge, double* __restrict__ err) {
+  // (FLL: meas_q / omega_q are the slot-major copies ll_meas / ll_omega; cam_q / pt_q are unused)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int PD = 6, LD = 3, PL = PD * LD;
   const int t = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -1035,55 +1052,136 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
     unsigned short vL[UE];
     // the observation of this lane's block (first pass), requested with everything else the tile stages
     const int s0 = min(tid, nslots - 1);
-    const int cq = cam_q[q0 + s0], pq = pt_q[q0 + s0];
+    int cq = 0, pq = 0;
+    if constexpr (!FLL) {
+      cq = cam_q[q0 + s0];
+      pq = pt_q[q0 + s0];
 #pragma unroll
-    for (int u = 0; u < UD; ++u) vD[u] = srcD[min(tid + u * NT, nD - 1)];
-    vb = srcb[min(tid, nb - 1)];
-#pragma unroll
-    for (int u = 0; u < UE; ++u) {
-      const int i = min(tid + u * NT, ne - 1);
-      vE[u] = te_pack[e0 + i];
-      vL[u] = te_lm[e0 + i];
+      for (int u = 0; u < UD; ++u) vD[u] = srcD[min(tid + u * NT, nD - 1)];
+      vb = srcb[min(tid, nb - 1)];
     }
-    vP = td_ptr[td0 + min(tid, ndp - 1)];
-    vG = td_diag[td0 + min(tid, max(ndp - 2, 0))];
-    for (int sb = 0; sb < nslots; sb += NT) {
-      const int s_ = sb + tid;
-      const int sc = min(s_, nslots - 1);
-      const int c_ = sb == 0 ? cq : cam_q[q0 + sc], p_ = sb == 0 ? pq : pt_q[q0 + sc];
-      double T[12], X[3], z2[2], Op[4];
-      load_vec<12>(cams + (size_t)c_ * 12, T);
-      const double* Xp = pts + (size_t)p_ * 3;
-      X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
-      load_vec<2>(meas_q + (size_t)(q0 + sc) * 2, z2);
-      if (ident) {
-        Op[0] = Op[3] = 1.0;
-        Op[1] = Op[2] = 0.0;
-      } else {
-        load_vec<4>(omega_q + (size_t)(q0 + sc) * 4, Op);
+    auto request_lists = [&]() {
+#pragma unroll
+      for (int u = 0; u < UE; ++u) {
+        const int i = min(tid + u * NT, ne - 1);
+        vE[u] = te_pack[e0 + i];
+        vL[u] = te_lm[e0 + i];
       }
-      BaEdgeLin L;
-      ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
-      const double w = L.w;
-      const double O00 = w * L.O[0], O10 = w * L.O[1], O01 = w * L.O[2], O11 = w * L.O[3];
-      double OA[6], blk[18];
+      vP = td_ptr[td0 + min(tid, ndp - 1)];
+      vG = td_diag[td0 + min(tid, max(ndp - 2, 0))];
+    };
+    request_lists();
+    if constexpr (FLL) {
+      // One lane per OBSERVATION (slot table of the tile: a landmark's observations sit in consecutive lanes of one
+      // wavefront), then the first lane of every landmark gathers the contributions of its list in list order
+      // (ds_bpermute; the order of the reference's edge loop, base_binary_edge.hpp:86-118).
+      const int4 tl = tile_ll[t];   // first slot, slots (a multiple of 64), first observation, longest list
+      for (int sb = 0; sb < tl.y; sb += NT) {
+        const int si = sb + tid;
+        const size_t sg = (size_t)tl.x + min(si, tl.y - 1);
+        int4 rc = ll_rec[sg];
+        if (si >= tl.y) rc.x = -1;
+        const int ent = rc.x;
+        const int krel = ent & 0xfff, K = (ent >> 12) & 0xff, lmi = (ent >> 20) & 0xfff;
+        const bool has = krel != 0xfff, head = lmi != 0xfff;
+        double v[12];   // H (9) | b (3)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        OA[0 + 2 * c] = O00 * L.A[0 + 2 * c] + O01 * L.A[1 + 2 * c];
-        OA[1 + 2 * c] = O10 * L.A[0 + 2 * c] + O11 * L.A[1 + 2 * c];
+        for (int i = 0; i < 12; ++i) v[i] = 0.0;
+        {
+          const int ci = rc.y, pi = rc.z, q = rc.w, e = ll_edge[sg];
+          double T[12], X[3], z2[2], Op[4];
+          const double* Xp = pts + (size_t)pi * 3;
+          X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+          load_vec<12>(cams + (size_t)ci * 12, T);
+          load_vec<2>(meas_q + sg * 2, z2);
+          if (ident) {
+            Op[0] = Op[3] = 1.0;
+            Op[1] = Op[2] = 0.0;
+          } else {
+            load_vec<4>(omega_q + sg * 4, Op);
+          }
+          if (has) {
+            BaEdgeLin L;
+            ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
+            store_vec<2>(err + (size_t)e * 2, L.r);
+            double H[9], b[3], OA[6];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) H[i] = 0.0;
+            b[0] = b[1] = b[2] = 0.0;
+            ba_lm_accumulate(L, H, b, OA);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) v[i] = H[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[9 + i] = b[i];
+            if (q >= 0) {
+              double blk[18];
+              ba_hpl_block(L, OA, blk);
+              store_vec<18>(Bs + (q - q0) * 18, blk);
+            }
+          }
+        }
+        // (a lane that is read with j >= its reader's K is another landmark's: its value is discarded, so the first
+        // lanes may accumulate in place)
+        for (int j = 1; j < tl.w; ++j) {
+          const bool take = head && j < K;
+#pragma unroll
+          for (int i = 0; i < 12; ++i) {
+            const double o = __shfl_down(v[i], j);
+            if (take) v[i] += o;
+          }
+        }
+        if (head) {
+          const int lm = l0 + lmi;
+          double* hd = Hll + (size_t)lm * 9;
+          double* bd = bl + (size_t)lm * 3;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            Ds[lmi * 9 + i] = v[i];
+            hd[i] = v[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            bsm[lmi * 3 + i] = v[9 + i];
+            bd[i] = v[9 + i];
+          }
+        }
+      }
+    } else {
+      for (int sb = 0; sb < nslots; sb += NT) {
+        const int s_ = sb + tid;
+        const int sc = min(s_, nslots - 1);
+        const int c_ = sb == 0 ? cq : cam_q[q0 + sc], p_ = sb == 0 ? pq : pt_q[q0 + sc];
+        double T[12], X[3], z2[2], Op[4];
+        load_vec<12>(cams + (size_t)c_ * 12, T);
+        const double* Xp = pts + (size_t)p_ * 3;
+        X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+        load_vec<2>(meas_q + (size_t)(q0 + sc) * 2, z2);
+        if (ident) {
+          Op[0] = Op[3] = 1.0;
+          Op[1] = Op[2] = 0.0;
+        } else {
+          load_vec<4>(omega_q + (size_t)(q0 + sc) * 4, Op);
+        }
+        BaEdgeLin L;
+        ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
+        const double w = L.w;
+        const double O00 = w * L.O[0], O10 = w * L.O[1], O01 = w * L.O[2], O11 = w * L.O[3];
+        double OA[6], blk[18];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          OA[0 + 2 * c] = O00 * L.A[0 + 2 * c] + O01 * L.A[1 + 2 * c];
+          OA[1 + 2 * c] = O10 * L.A[0 + 2 * c] + O11 * L.A[1 + 2 * c];
+        }
+        ba_hpl_block(L, OA, blk);
+        if (s_ < nslots) store_vec<18>(Bs + s_ * 18, blk);
       }
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int a = 0; a < 6; ++a) blk[a + 6 * c] = L.B[0 + 2 * a] * OA[0 + 2 * c] + L.B[1 + 2 * a] * OA[1 + 2 * c];
-      if (s_ < nslots) store_vec<18>(Bs + s_ * 18, blk);
+      for (int u = 0; u < UD; ++u) {
+        const int i = tid + u * NT;
+        if (i < nD) Ds[i] = vD[u];
+      }
+      if (tid < nb) bsm[tid] = vb;
     }
-#pragma unroll
-    for (int u = 0; u < UD; ++u) {
-      const int i = tid + u * NT;
-      if (i < nD) Ds[i] = vD[u];
-    }
-    if (tid < nb) bsm[tid] = vb;
 #pragma unroll
     for (int u = 0; u < UE; ++u) {
       const int i = tid + u * NT;
@@ -1094,8 +1192,10 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
     }
     if (tid < ndp) dptr[tid] = vP;
     if (tid < ndp - 1) ddiag[tid] = vG;
-    if (nD > UD * NT) stage_copy<4>(Ds + UD * NT, srcD + UD * NT, nD - UD * NT, tid, NT);
-    if (nb > NT) stage_copy<2>(bsm + NT, srcb + NT, nb - NT, tid, NT);
+    if constexpr (!FLL) {
+      if (nD > UD * NT) stage_copy<4>(Ds + UD * NT, srcD + UD * NT, nD - UD * NT, tid, NT);
+      if (nb > NT) stage_copy<2>(bsm + NT, srcb + NT, nb - NT, tid, NT);
+    }
     if (ne > UE * NT) {
       stage_copy<4>(ep + UE * NT, te_pack + e0 + UE * NT, ne - UE * NT, tid, NT);
       stage_copy<4>(el + UE * NT, te_lm + e0 + UE * NT, ne - UE * NT, tid, NT);
@@ -1165,6 +1265,75 @@ __global__ void __launch_bounds__(kThreads) ba_back_substitute_kernel(
     for (int i = 0; i < 3; ++i) xl[(size_t)lm * 3 + i] = D[i] * cl[0] + D[i + 3] * cl[1] + D[i + 6] * cl[2];
   } else {
     xl[(size_t)lm * 3 + g] = D[g] * cl[0] + D[g + 3] * cl[1] + D[g + 6] * cl[2];
+  }
+}
+
+// The same back-substitution over the lane slots of the Schur tiles (one lane per observation, 92 % of the lanes busy
+// where eight lanes per landmark keep five of eight): the first lane of a landmark gathers the terms of its list in
+// list order.
+__global__ void __launch_bounds__(kThreads) ba_back_substitute_slots_kernel(
+    const int* __restrict__ tile_lm0, const int4* __restrict__ tile_ll, const int4* __restrict__ ll_rec, const int* __restrict__ ll_row,
+    const double* __restrict__ ll_meas, const double* __restrict__ ll_omega, const double* __restrict__ cams,
+    const double* __restrict__ pts, double f, double cx, double cy, int kind, double delta, int ident, const double* __restrict__ Dinv,
+    const double* __restrict__ bl, const double* __restrict__ xp, double* __restrict__ xl) {
+  const int t = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  const int l0 = tile_lm0[(size_t)t * 8];
+  const int4 tl = tile_ll[t];   // first slot, slots (a multiple of 64), first observation, longest list
+  for (int sb = 0; sb < tl.y; sb += NT) {
+    const int si = sb + tid;
+    const size_t sg = (size_t)tl.x + min(si, tl.y - 1);
+    int4 rc = ll_rec[sg];
+    if (si >= tl.y) rc.x = -1;
+    const int ent = rc.x;
+    const int krel = ent & 0xfff, K = (ent >> 12) & 0xff, lmi = (ent >> 20) & 0xfff;
+    const bool head = lmi != 0xfff;
+    const int row = krel != 0xfff ? ll_row[sg] : -1;
+    double c[3] = {0.0, 0.0, 0.0};
+    {
+      double T[12], X[3], z2[2], Op[4], xv[6];
+      const double* Xp = pts + (size_t)rc.z * 3;
+      X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+      load_vec<12>(cams + (size_t)rc.y * 12, T);
+      load_vec<2>(ll_meas + sg * 2, z2);
+      load_vec<6>(xp + (size_t)max(row, 0) * 6, xv);
+      if (ident) {
+        Op[0] = Op[3] = 1.0;
+        Op[1] = Op[2] = 0.0;
+      } else {
+        load_vec<4>(ll_omega + sg * 4, Op);
+      }
+      if (row >= 0) {
+        BaEdgeLin L;
+        ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
+        double t0 = 0.0, t1 = 0.0;   // B x_p
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          t0 += L.B[0 + 2 * a] * xv[a];
+          t1 += L.B[1 + 2 * a] * xv[a];
+        }
+        const double w = L.w;
+        const double u0 = w * (L.O[0] * t0 + L.O[2] * t1), u1 = w * (L.O[1] * t0 + L.O[3] * t1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[j] = -(L.A[0 + 2 * j] * u0 + L.A[1 + 2 * j] * u1);
+      }
+    }
+    for (int j = 1; j < tl.w; ++j) {
+      const bool take = head && j < K;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double o = __shfl_down(c[i], j);
+        if (take) c[i] += o;
+      }
+    }
+    if (head) {
+      const int lm = l0 + lmi;
+      double cl[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cl[j] = c[j] + bl[(size_t)lm * 3 + j];
+      const double* D = Dinv + (size_t)lm * 9;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xl[(size_t)lm * 3 + i] = D[i] * cl[0] + D[i + 3] * cl[1] + D[i + 6] * cl[2];
+    }
   }
 }
 
@@ -1827,6 +1996,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       es.vl_ptr.upload(ptr, st_);
       es.vl_ent.upload(ent, st_);
       es.h_vl_ent = ent;
+      es.h_vl_ptr = ptr;
       es.n_vl_ent = (long)ent.size();
       es.first_lm = !seen_lm;
       seen_lm = true;
@@ -1988,6 +2158,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         tile_td0.push_back((int)td_dest.size());
       }
       n_tiles_ = (int)tile_lm0.size() - 1;
+      tile_lm0_h_ = tile_lm0;
       tiles_cover_all_ = tile_lm0.front() == 0 && tile_lm0.back() == nL;
       n_td_ = (long)td_dest.size();
       n_sc_ = (long)te_pack.size();
@@ -2237,12 +2408,17 @@ void BlockSolver::build_system() {
   system_built_ = true;
 }
 
+// lanes per landmark of the fused BA assembly: one observation per lane where possible
+int BlockSolver::ba_lm_group() const {
+  const double avgK = (double)sets_[ba_.set]->n_vl_ent / std::max(1, nL_);
+  return avgK <= 1.5 ? 1 : (avgK <= 4.0 ? 4 : 8);
+}
+
 // landmark side of the fused BA assembly: Hll, b_l, errors and -- when somebody will read it -- Hpl
 void BlockSolver::launch_ba_landmarks(bool write_hpl) {
   EdgeSet& es = *sets_[ba_.set];
   const size_t sizeP = (size_t)nP_ * p_;
-  const double avgK = (double)es.n_vl_ent / std::max(1, nL_);
-  const int GL = avgK <= 1.5 ? 1 : (avgK <= 4.0 ? 4 : 8);   // one observation per lane where possible
+  const int GL = ba_lm_group();
 #define G2OHIP_BA_LM(GG)                                                                                                         \
   hipLaunchKernelGGL((ba_assemble_landmarks_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p, \
                      es.vl_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_lm.p, ba_.pt_lm.p, ba_.meas_lm.p, ba_.omega_lm.p, ba_.hpl_lm.p, ba_.f, \
@@ -2265,6 +2441,23 @@ bool BlockSolver::ba_skip_hpl_ok() const {
          }();
 }
 
+// May build_system leave the whole landmark side (Hll, b_l, the errors) to the Schur tiles of the solve?  They evaluate
+// every observation of their landmarks anyway (ba_schur_tile_kernel<G, true>).
+bool BlockSolver::ba_fuse_ll_ok() const { return ba_fuse_landmarks && ba_.ll_slots_ok && ba_skip_hpl_ok(); }
+
+// somebody reads Hll, b_l or the errors between a build_system that left them to the solve and that solve
+// (maxDiagonal of the first LM iteration, b(), multiplyHessian, chi2 without a linearisation)
+void BlockSolver::ensure_ll() {
+  if (ll_valid_) return;
+  if (!ba_recompute_ok())
+    throw StateFailure("the landmark blocks were left to solve() by the last build_system and the estimates (or the robust kernel) have "
+                       "changed since: call build_system again, or set option ba_fuse_landmarks = 0");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  launch_ba_landmarks(false);
+  ll_valid_ = true;
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
 // somebody reads Hpl (copy_values, multiplyHessian, the matrix-free operator, a solve path without the fused kernels)
 // after a build_system that skipped it
 void BlockSolver::ensure_hpl() {
@@ -2274,14 +2467,14 @@ void BlockSolver::ensure_hpl() {
                        "call build_system again, or set option ba_skip_hpl = 0");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   launch_ba_landmarks(true);   // the same kernel with the Hpl stores on (Hll, b_l and the errors come out identical)
-  hpl_valid_ = true;
+  hpl_valid_ = ll_valid_ = true;
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 
 void BlockSolver::build_system_impl() {
   if (profiling) tq_.start(st_);
   ba_.sys_version = -1;   // (set again by the fused BA branch)
-  hpl_valid_ = true;
+  hpl_valid_ = ll_valid_ = true;
   const size_t sizeP = (size_t)nP_ * p_;
   bool any_pose = false, any_lm = false;
   int set_index = -1;
@@ -2306,10 +2499,13 @@ void BlockSolver::build_system_impl() {
         G2OHIP_HIP_CHECK(hipEventRecord(side_fork_, st_));             // fork before either kernel is queued
         G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_, side_fork_, 0));
       }
-      prof.begin(KernelProf::kAsmLandmark, st_);
       hpl_valid_ = !ba_skip_hpl_ok();
-      launch_ba_landmarks(hpl_valid_);
-      prof.end(KernelProf::kAsmLandmark, st_);
+      ll_valid_ = !ba_fuse_ll_ok();   // false: the Schur tiles of the solve assemble the landmark side
+      if (ll_valid_) {
+        prof.begin(KernelProf::kAsmLandmark, st_);
+        launch_ba_landmarks(hpl_valid_);
+        prof.end(KernelProf::kAsmLandmark, st_);
+      }
       prof.begin(KernelProf::kAsmPose, st_);
       const int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
       hipStream_t sp = overlap ? side_ : st_;   // stream of the pose kernel
@@ -2377,6 +2573,7 @@ double BlockSolver::chi2() {
   require_structure();
   if (chi2_valid_) return chi2_value_;   // same errors, same kernels as the last evaluation (LM asks twice per accepted step)
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (!ll_valid_ && !ba_.err_valid) ensure_ll();   // errors come from a linearisation or from the landmark side of the assembly
   double total = 0.0;
   for (auto& esp : sets_) {
     EdgeSet& es = *esp;
@@ -2460,6 +2657,7 @@ void BlockSolver::restore_diagonal() {
 double BlockSolver::max_diagonal() {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  ensure_ll();
   double m = 0.0;
   {
     int nblocks = std::min(1024, grid_for((size_t)nP_ * p_));
@@ -2493,6 +2691,7 @@ void BlockSolver::copy_diagonal(double* host) {
   require_structure();
   if (!host) throw ArgFailure("copy_diagonal: null pointer");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  ensure_ll();
   const size_t n = vector_size();
   DevBuf<double> tmp;
   tmp.alloc(n);
@@ -2507,6 +2706,7 @@ void BlockSolver::copy_diagonal(double* host) {
 double BlockSolver::compute_scale(double lambda) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  ensure_ll();
   int nblocks = std::min(1024, grid_for(vector_size()));
   hipLaunchKernelGGL(scale_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, vector_size(), d_x.p, d_b.p, lambda, d_red.p);
   return reduce_sum_finish(nblocks);
@@ -2532,24 +2732,41 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
     EdgeSet& es = *sets_[ba_.set];
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define G2OHIP_BA_TILE_ATTR(GG)                                                                                                    \
+  (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<GG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<GG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+      G2OHIP_BA_TILE_ATTR(1);
+      G2OHIP_BA_TILE_ATTR(2);
+      G2OHIP_BA_TILE_ATTR(4);
+      G2OHIP_BA_TILE_ATTR(8);
+      G2OHIP_BA_TILE_ATTR(16);
+#undef G2OHIP_BA_TILE_ATTR
       attr = true;
     }
     prof.begin(KernelProf::kSchurBlocks, st_);
+    const bool fll = !ll_valid_;   // the tiles assemble Hll / b_l / errors themselves
 #define G2OHIP_BA_TILE(GG)                                                                                                         \
-  hipLaunchKernelGGL((ba_schur_tile_kernel<GG>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p, ba_.cams.p,     \
-                     ba_.pts.p, ba_.cam_q.p, ba_.pt_q.p, ba_.meas_q.p, ba_.omega_q.p, ba_.f, ba_.cx, ba_.cy, es.kernel_kind, es.delta, \
-                     ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p, d_te_pack.p, d_te_lm.p, d_Pd.p,    \
-                     d_Pr.p, d_Hll.p, d_lam.p)
+  do {                                                                                                                             \
+    if (fll)                                                                                                                       \
+      hipLaunchKernelGGL((ba_schur_tile_kernel<GG, true>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,        \
+                         ba_.cams.p, ba_.pts.p, (const int*)nullptr, (const int*)nullptr, ba_.ll_meas.p, ba_.ll_omega.p, ba_.f, ba_.cx,  \
+                         ba_.cy,                                                                                                     \
+                         es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
+                         d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, ba_.ll_rec.p, ba_.tile_ll.p, ba_.ll_edge.p,       \
+                         es.own_err.p);                                                                                            \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((ba_schur_tile_kernel<GG, false>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,       \
+                         ba_.cams.p, ba_.pts.p, ba_.cam_q.p, ba_.pt_q.p, ba_.meas_q.p, ba_.omega_q.p, ba_.f, ba_.cx, ba_.cy,           \
+                         es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
+                         d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, (const int4*)nullptr, (const int4*)nullptr,        \
+                         (const int*)nullptr, (double*)nullptr);                                                                   \
+  } while (0)
     if (G <= 1) G2OHIP_BA_TILE(1);
     else if (G <= 2) G2OHIP_BA_TILE(2);
     else if (G <= 4) G2OHIP_BA_TILE(4);
     else if (G <= 8) G2OHIP_BA_TILE(8);
     else G2OHIP_BA_TILE(16);
+    ll_valid_ = true;
 #undef G2OHIP_BA_TILE
     prof.end(KernelProf::kSchurBlocks, st_);
   } else
@@ -2991,6 +3208,7 @@ double BlockSolver::chi2_sharded() {
 double BlockSolver::compute_scale_sharded(double lambda) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  ensure_ll();
   const int nblocks = std::min(1024, grid_for(vector_size()));
   hipLaunchKernelGGL(scale_sharded_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, (size_t)nP_ * p_, vector_size(), d_x.p, d_b.p,
                      lambda, p_, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr, d_red.p);
@@ -3002,6 +3220,7 @@ double BlockSolver::compute_scale_sharded(double lambda) {
 double BlockSolver::max_diagonal_sharded() {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  ensure_ll();
   // pose diagonal: every rank holds its own contributions -> sum over the ranks first, then the maximum
   const size_t np = (size_t)nP_ * p_;
   DevBuf<double> diag;
@@ -3049,8 +3268,12 @@ void BlockSolver::solve_back_substitute_impl() {
   if (ba_recompute_ok()) {
     // fused EdgeProjectXYZ2UV system, estimates unchanged since build_system: Hpl' x_p from the Jacobians, Hpl is not read
     EdgeSet& es = *sets_[ba_.set];
-    const double avgK = (double)es.n_vl_ent / std::max(1, nL_);
-    const int GL = avgK <= 1.5 ? 1 : (avgK <= 4.0 ? 4 : 8);
+    const int GL = ba_lm_group();
+    if (ba_fuse_landmarks && ba_.ll_slots_ok && n_tiles_ > 0) {
+      hipLaunchKernelGGL(ba_back_substitute_slots_kernel, dim3(n_tiles_), dim3(kThreads), 0, st_, d_tile_lm0.p, ba_.tile_ll.p, ba_.ll_rec.p,
+                         ba_.ll_row.p, ba_.ll_meas.p, ba_.ll_omega.p, ba_.cams.p, ba_.pts.p, ba_.f, ba_.cx, ba_.cy, es.kernel_kind,
+                         es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_x.p, d_x.p + sizeP);
+    } else
 #define G2OHIP_BA_BACK(GG)                                                                                                        \
   hipLaunchKernelGGL((ba_back_substitute_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p,    \
                      ba_.cams.p, ba_.pts.p, ba_.cam_lm.p, ba_.pt_lm.p, ba_.meas_lm.p, ba_.omega_lm.p, ba_.row_lm.p, ba_.f,          \
@@ -3394,6 +3617,7 @@ void BlockSolver::copy_x(double* h) {
 }
 void BlockSolver::copy_b(double* h) {
   require_structure();
+  ensure_ll();
   d_b.download(h, vector_size(), st_);
 }
 void BlockSolver::sync() { G2OHIP_HIP_CHECK(hipStreamSynchronize(st_)); }
@@ -3433,6 +3657,7 @@ void BlockSolver::copy_values(int which, double* h) {
       break;
     case 1: ensure_hpl(); d_Hpl.download(h, pl_row.size() * p_ * l_, st_); break;
     case 2:
+      ensure_ll();
       d_Hll.download(h, (size_t)nL_ * l_ * l_, st_);
       if (lam_lm_ != 0.0)
         for (size_t j = 0; j < (size_t)nL_; ++j)
@@ -3541,6 +3766,67 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
       rlm[k] = hlm[k] >= 0 ? b : -1;
       if (!ba_.omega_identity)
         for (int i = 0; i < 4; ++i) olm[4 * k + i] = info[4 * e + i];
+    }
+    // lane slots of the tiles that assemble their own landmarks
+    ba_.ll_slots_ok = false;
+    if (schur_ && n_tiles_ > 0 && tiles_cover_all_ && (int)tile_lm0_h_.size() == n_tiles_ + 1 && (int)es.h_vl_ptr.size() == nL_ + 1) {
+      std::vector<int> slots;
+      std::vector<int4> tl((size_t)n_tiles_);
+      slots.reserve(nl + (size_t)n_tiles_ * 64);
+      bool ok = true;
+      for (int t = 0; t < n_tiles_ && ok; ++t) {
+        const int l0 = tile_lm0_h_[t], l1 = tile_lm0_h_[t + 1];
+        const int kb = es.h_vl_ptr[l0];
+        const size_t s0 = slots.size();
+        int kmax = 0;
+        for (int lm = l0; lm < l1; ++lm) {
+          const int K = es.h_vl_ptr[lm + 1] - es.h_vl_ptr[lm], lmi = lm - l0;
+          if (K > 64 || lmi >= 0xfff || es.h_vl_ptr[lm + 1] - kb >= 0xfff) {
+            ok = false;
+            break;
+          }
+          const int used = (int)((slots.size() - s0) & 63), need = std::max(K, 1);
+          if (used + need > 64) slots.resize(slots.size() + (64 - used), -1);   // (-1: no observation, not a first lane)
+          if (K == 0) slots.push_back(0xfff | (lmi << 20));
+          for (int j = 0; j < K; ++j)
+            slots.push_back((es.h_vl_ptr[lm] + j - kb) | (j == 0 ? (K << 12) | (lmi << 20) : (int)0xfff00000u));
+          kmax = std::max(kmax, K);
+        }
+        const int used = (int)((slots.size() - s0) & 63);
+        if (used) slots.resize(slots.size() + (64 - used), -1);
+        tl[t] = make_int4((int)s0, (int)(slots.size() - s0), kb, kmax);
+      }
+      if (ok && slots.size() < ((size_t)1 << 31)) {
+        // slot-major copies of what a lane reads about its observation: one memory round trip after the tile record
+        if (slots.empty()) slots.push_back(-1);
+        const size_t ns = slots.size();
+        std::vector<int4> rec(ns);
+        std::vector<int> edge(ns, 0), srow(ns, -1);
+        std::vector<double> ms(ns * 2, 0.0), os(ba_.omega_identity ? 0 : ns * 4, 0.0);
+        for (int t = 0; t < n_tiles_; ++t)
+          for (int i = 0; i < tl[t].y; ++i) {
+            const size_t sidx = (size_t)tl[t].x + i;
+            const int w = slots[sidx];
+            rec[sidx] = make_int4(w, 0, 0, -1);
+            if ((w & 0xfff) == 0xfff) continue;
+            const size_t k = (size_t)tl[t].z + (w & 0xfff);
+            rec[sidx] = make_int4(w, clm[k], plm[k], hlm[k]);
+            edge[sidx] = es.h_vl_ent[k] >> 1;
+            srow[sidx] = rlm[k];
+            ms[2 * sidx] = mlm[2 * k];
+            ms[2 * sidx + 1] = mlm[2 * k + 1];
+            if (!ba_.omega_identity)
+              for (int j = 0; j < 4; ++j) os[4 * sidx + j] = olm[4 * k + j];
+          }
+        if (n_tiles_ == 0) rec[0] = make_int4(-1, 0, 0, -1);
+        ba_.ll_rec.upload(rec, st_);
+        ba_.ll_edge.upload(edge, st_);
+        ba_.ll_row.upload(srow, st_);
+        ba_.ll_meas.upload(ms, st_);
+        if (!ba_.omega_identity) ba_.ll_omega.upload(os, st_);
+        ba_.tile_ll.upload(tl, st_);
+        ba_.ll_slots_ok = true;
+      }
     }
     ba_.meas_lm.upload(mlm, st_);
     ba_.cam_lm.upload(clm, st_);
@@ -3882,6 +4168,7 @@ void BlockSolver::copy_edge_data(int set, double* J0, double* J1, double* err) {
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
   EdgeSet& es = *sets_[set];
   if (!es.has_err) throw StateFailure("copy_edge_data: the set has no edge data yet");
+  if (set == ba_.set && !ll_valid_ && !ba_.err_valid) ensure_ll();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t n = (size_t)es.n;
   auto pull = [&](double* dst, const double* src, size_t cnt) {
@@ -3903,7 +4190,7 @@ void BlockSolver::device_array(int which, double** ptr, size_t* count) {
   switch (which) {
     case 0: *ptr = d_Hpp.p; *count = pp_row.size() * p_ * p_; break;
     case 1: ensure_hpl(); *ptr = d_Hpl.p; *count = pl_row.size() * p_ * l_; break;
-    case 2: *ptr = d_Hll.p; *count = (size_t)nL_ * l_ * l_; break;
+    case 2: ensure_ll(); *ptr = d_Hll.p; *count = (size_t)nL_ * l_ * l_; break;
     case 3: ensure_hschur(); *ptr = d_Hschur.p; *count = hs_row.size() * p_ * p_; break;
     case 100: *ptr = d_bschur.p; *count = (size_t)nP_ * p_; break;
     case 101: *ptr = d_x.p; *count = vector_size(); break;

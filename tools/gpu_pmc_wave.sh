@@ -4,7 +4,7 @@
 set -u
 K=${1:-wave_front_kernel}
 R=$PWD
-OUT=$R/gpurun_out/pmcw
+OUT=$R/gpurun_out/pmcw${TAG:-}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -18,7 +18,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
            "SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F64 SQ_INST_CYCLES_SALU"; do
   i=$((i+1))
   rm -rf /tmp/pw$i
-  timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pw$i -o p -- python $R/bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1 > $OUT/pass$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pw$i -o p -- python $R/bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1 ${BENCH_ARGS:-} > $OUT/pass$i.log 2>&1
   python $R/tools/pmc_kernel.py $(find /tmp/pw$i -name "*.db" | head -1) $K >> $OUT/summary.txt 2>> $OUT/err.txt
 done
 cd $R
