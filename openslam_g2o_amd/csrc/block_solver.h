@@ -293,9 +293,9 @@ class BlockSolver {
     DevBuf<double> meas_q, omega_q;
     DevBuf<int> cam_lm, pt_lm, hpl_lm, row_lm;   // (row_lm: pose block row of the observation's Hpl block, -1 = fixed pose)
     // Schur tiles that assemble their landmarks (ba_schur_tile_kernel<G, true>): lane slots of every tile -- observation
-    // (12 bits, relative to the tile's first one; 0xfff: none) | list length at the first lane of a landmark (8 bits) |
-    // landmark inside the tile at its first lane (12 bits; 0xfff elsewhere); a landmark never straddles a wavefront --
-    // and per tile (first slot, slots, first observation, longest list)
+    // (12 bits, relative to the tile's first one; 0xfff: none) | list length (8 bits) | landmark inside the tile at the
+    // first lane of its list, position in the list elsewhere (11 bits) | bit 31: not a first lane; a landmark never
+    // straddles a wavefront -- and per tile (first slot, slots, first observation, longest list)
     DevBuf<int4> ll_rec;      // per lane slot: (slot word, camera, point, Hpl block or -1)
     DevBuf<int> ll_edge;      // ... edge id (error store)
     DevBuf<int> ll_row;       // ... pose block row of the observation's Hpl block (-1: fixed pose)

@@ -1073,17 +1073,17 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
     request_lists();
     if constexpr (FLL) {
       // One lane per OBSERVATION (slot table of the tile: a landmark's observations sit in consecutive lanes of one
-      // wavefront), then the first lane of every landmark gathers the contributions of its list in list order
-      // (ds_bpermute; the order of the reference's edge loop, base_binary_edge.hpp:86-118).
+      // wavefront), then the contributions of a list are summed into its first lane by doubling (ds_bpermute).
       const int4 tl = tile_ll[t];   // first slot, slots (a multiple of 64), first observation, longest list
       for (int sb = 0; sb < tl.y; sb += NT) {
         const int si = sb + tid;
         const size_t sg = (size_t)tl.x + min(si, tl.y - 1);
         int4 rc = ll_rec[sg];
-        if (si >= tl.y) rc.x = -1;
+        if (si >= tl.y) rc.x = (int)0x80000fffu;
         const int ent = rc.x;
-        const int krel = ent & 0xfff, K = (ent >> 12) & 0xff, lmi = (ent >> 20) & 0xfff;
-        const bool has = krel != 0xfff, head = lmi != 0xfff;
+        const int krel = ent & 0xfff, K = (ent >> 12) & 0xff, lmi = (ent >> 20) & 0x7ff;   // (lmi: position in the list on the other lanes)
+        const bool has = krel != 0xfff, head = ent >= 0;
+        const int pos = head ? 0 : lmi;
         double v[12];   // H (9) | b (3)
 #pragma unroll
         for (int i = 0; i < 12; ++i) v[i] = 0.0;
@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
           if (has) {
             BaEdgeLin L;
             ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
-            store_vec<2>(err + (size_t)e * 2, L.r);
+            if (err) store_vec<2>(err + (size_t)e * 2, L.r);
             double H[9], b[3], OA[6];
 #pragma unroll
             for (int i = 0; i < 9; ++i) H[i] = 0.0;
@@ -1120,13 +1120,13 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
             }
           }
         }
-        // (a lane that is read with j >= its reader's K is another landmark's: its value is discarded, so the first
-        // lanes may accumulate in place)
-        for (int j = 1; j < tl.w; ++j) {
-          const bool take = head && j < K;
+        // suffix sums inside a list by doubling: after the step with distance d a lane holds the sum of up to 2 d list
+        // entries from its own on (fixed tree: deterministic)
+        for (int d = 1; d < tl.w; d <<= 1) {
+          const bool take = pos + d < K;
 #pragma unroll
           for (int i = 0; i < 12; ++i) {
-            const double o = __shfl_down(v[i], j);
+            const double o = __shfl_down(v[i], d);
             if (take) v[i] += o;
           }
         }
@@ -1269,8 +1269,7 @@ __global__ void __launch_bounds__(kThreads) ba_back_substitute_kernel(
 }
 
 // The same back-substitution over the lane slots of the Schur tiles (one lane per observation, 92 % of the lanes busy
-// where eight lanes per landmark keep five of eight): the first lane of a landmark gathers the terms of its list in
-// list order.
+// where eight lanes per landmark keep five of eight): the terms of a list are summed into its first lane by doubling.
 __global__ void __launch_bounds__(kThreads) ba_back_substitute_slots_kernel(
     const int* __restrict__ tile_lm0, const int4* __restrict__ tile_ll, const int4* __restrict__ ll_rec, const int* __restrict__ ll_row,
     const double* __restrict__ ll_meas, const double* __restrict__ ll_omega, const double* __restrict__ cams,
@@ -1283,10 +1282,11 @@ __global__ void __launch_bounds__(kThreads) ba_back_substitute_slots_kernel(
     const int si = sb + tid;
     const size_t sg = (size_t)tl.x + min(si, tl.y - 1);
     int4 rc = ll_rec[sg];
-    if (si >= tl.y) rc.x = -1;
+    if (si >= tl.y) rc.x = (int)0x80000fffu;
     const int ent = rc.x;
-    const int krel = ent & 0xfff, K = (ent >> 12) & 0xff, lmi = (ent >> 20) & 0xfff;
-    const bool head = lmi != 0xfff;
+    const int krel = ent & 0xfff, K = (ent >> 12) & 0xff, lmi = (ent >> 20) & 0x7ff;
+    const bool head = ent >= 0;
+    const int pos = head ? 0 : lmi;
     const int row = krel != 0xfff ? ll_row[sg] : -1;
     double c[3] = {0.0, 0.0, 0.0};
     {
@@ -1317,11 +1317,11 @@ __global__ void __launch_bounds__(kThreads) ba_back_substitute_slots_kernel(
         for (int j = 0; j < 3; ++j) c[j] = -(L.A[0 + 2 * j] * u0 + L.A[1 + 2 * j] * u1);
       }
     }
-    for (int j = 1; j < tl.w; ++j) {
-      const bool take = head && j < K;
+    for (int d = 1; d < tl.w; d <<= 1) {
+      const bool take = pos + d < K;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const double o = __shfl_down(c[i], j);
+        const double o = __shfl_down(c[i], d);
         if (take) c[i] += o;
       }
     }
@@ -2753,7 +2753,7 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
                          ba_.cy,                                                                                                     \
                          es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, ba_.ll_rec.p, ba_.tile_ll.p, ba_.ll_edge.p,       \
-                         es.own_err.p);                                                                                            \
+                         ba_.err_valid ? (double*)nullptr : es.own_err.p);   /* (errors of these estimates already there) */       \
     else                                                                                                                           \
       hipLaunchKernelGGL((ba_schur_tile_kernel<GG, false>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,       \
                          ba_.cams.p, ba_.pts.p, ba_.cam_q.p, ba_.pt_q.p, ba_.meas_q.p, ba_.omega_q.p, ba_.f, ba_.cx, ba_.cy,           \
@@ -3770,6 +3770,7 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
     // lane slots of the tiles that assemble their own landmarks
     ba_.ll_slots_ok = false;
     if (schur_ && n_tiles_ > 0 && tiles_cover_all_ && (int)tile_lm0_h_.size() == n_tiles_ + 1 && (int)es.h_vl_ptr.size() == nL_ + 1) {
+      constexpr int kIdleSlot = (int)0x80000fffu;   // no observation, not a first lane, list length 0
       std::vector<int> slots;
       std::vector<int4> tl((size_t)n_tiles_);
       slots.reserve(nl + (size_t)n_tiles_ * 64);
@@ -3781,24 +3782,24 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
         int kmax = 0;
         for (int lm = l0; lm < l1; ++lm) {
           const int K = es.h_vl_ptr[lm + 1] - es.h_vl_ptr[lm], lmi = lm - l0;
-          if (K > 64 || lmi >= 0xfff || es.h_vl_ptr[lm + 1] - kb >= 0xfff) {
+          if (K > 64 || lmi >= 0x7ff || es.h_vl_ptr[lm + 1] - kb >= 0xfff) {
             ok = false;
             break;
           }
           const int used = (int)((slots.size() - s0) & 63), need = std::max(K, 1);
-          if (used + need > 64) slots.resize(slots.size() + (64 - used), -1);   // (-1: no observation, not a first lane)
+          if (used + need > 64) slots.resize(slots.size() + (64 - used), kIdleSlot);
           if (K == 0) slots.push_back(0xfff | (lmi << 20));
           for (int j = 0; j < K; ++j)
-            slots.push_back((es.h_vl_ptr[lm] + j - kb) | (j == 0 ? (K << 12) | (lmi << 20) : (int)0xfff00000u));
+            slots.push_back((es.h_vl_ptr[lm] + j - kb) | (K << 12) | (j == 0 ? (lmi << 20) : (int)(0x80000000u | ((unsigned)j << 20))));
           kmax = std::max(kmax, K);
         }
         const int used = (int)((slots.size() - s0) & 63);
-        if (used) slots.resize(slots.size() + (64 - used), -1);
+        if (used) slots.resize(slots.size() + (64 - used), kIdleSlot);
         tl[t] = make_int4((int)s0, (int)(slots.size() - s0), kb, kmax);
       }
       if (ok && slots.size() < ((size_t)1 << 31)) {
         // slot-major copies of what a lane reads about its observation: one memory round trip after the tile record
-        if (slots.empty()) slots.push_back(-1);
+        if (slots.empty()) slots.push_back(kIdleSlot);
         const size_t ns = slots.size();
         std::vector<int4> rec(ns);
         std::vector<int> edge(ns, 0), srow(ns, -1);
@@ -3818,7 +3819,7 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
             if (!ba_.omega_identity)
               for (int j = 0; j < 4; ++j) os[4 * sidx + j] = olm[4 * k + j];
           }
-        if (n_tiles_ == 0) rec[0] = make_int4(-1, 0, 0, -1);
+        if (n_tiles_ == 0) rec[0] = make_int4(kIdleSlot, 0, 0, -1);
         ba_.ll_rec.upload(rec, st_);
         ba_.ll_edge.upload(edge, st_);
         ba_.ll_row.upload(srow, st_);
