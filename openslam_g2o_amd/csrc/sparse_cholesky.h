@@ -46,6 +46,7 @@ struct CholOptions {
   int wave_front_tasks = 1024;           // launches at least this wide use two waves (128 threads) per front
   size_t wave_front_bytes = 0;           // (unused)
   int wave_narrow_tasks = 0;             // wave-kernel levels with at most this many tasks use the narrow (latency) variant
+  int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
 };
@@ -230,7 +231,9 @@ class SparseCholesky {
   int n_xseg_ = 0;
   [[maybe_unused]] int dbg_launch_ = 0;   // (G2OHIP_CHOL_STAMPS builds)
   size_t xbuf_count_ = 0;
-  void launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep = false);
+  void launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep = false, int parts = 3);
+  hipStream_t side_[2] = {nullptr, nullptr};   // factor_phase: the two halves of a level / the forward step of its large fronts
+  hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false);
   CholPlanDev plan_{};
 };

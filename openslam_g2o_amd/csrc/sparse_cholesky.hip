@@ -2435,8 +2435,14 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
                          int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, int wcap,
                          const double* bperm, double* yout, int dep, const int4* big_tiles, int bt_count, const BigLaunch& big,
-                         int wide_doubles, bool wv, bool wv_narrow, int wv_pn, int wv_idx_ints, hipStream_t st) {
-  if (wv) {   // every front of the launch fits the register-resident wave kernel: one wavefront per task
+                         int wide_doubles, bool wv, bool wv_narrow, int wv_pn, int wv_idx_ints, hipStream_t st, int parts = 3) {
+  // parts: bit 0 = the fronts held in LDS / registers, bit 1 = the scratch-slab fronts (the two halves of a level are
+  // independent: factor_phase may put them on different streams)
+  if (!(parts & 1)) {
+    lds_begin += sm_count;
+    lds_count = 0;
+    sm_count = 0;
+  } else if (wv) {   // every front of the launch fits the register-resident wave kernel: one wavefront per task
     const size_t sh = ((size_t)kWvTiles * 256 + 64 + 2 * kWvT * 64) * sizeof(double) + (size_t)(8 * 64 + 2 * 16 * kWvT + 2 * 64) * sizeof(int);
     if (wv_narrow)
       hipLaunchKernelGGL((wave_front_kernel<BS, VIRT, true>), dim3(lds_count), dim3(64 * kWvWaves), sh, st, wv_plan(P), lds_begin, dA, bperm, yout, dep);
@@ -2463,6 +2469,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
       hipLaunchKernelGGL((front_factor_kernel<BS, true, kFactorThreads, VIRT>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
                          d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
   }
+  if (!(parts & 2)) return;
   if (glb_count > 0 && big.ok) {   // large fronts as whole-GPU passes
     G2OHIP_HIP_CHECK(hipMemsetAsync(d_scratch, 0, (size_t)big.scratch * sizeof(double), st));
     if (big.ba_count > 0)
@@ -2533,7 +2540,7 @@ void SparseCholesky::set_virtual_blocks(const VirtualBlocks& vb, hipStream_t st)
   plan_.vsplit = vb.split ? 1 : 0;
 }
 
-void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep) {
+void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep, int parts) {
 #ifdef G2OHIP_CHOL_STAMPS
   if (d_dbg.p) {
     plan_.dbg = d_dbg.p + 64 * (dbg_launch_++ % 64);
@@ -2550,7 +2557,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
                                LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m,            \
                                LL.sm_idx_ints, LL.max_m, fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr,   \
                                dep ? 1 : 0, d_big_tiles.p + LL.bt_begin, LL.bt_count, big, opt.wide_front_doubles, LL.wv, LL.wv_narrow, LL.wv_pn,   \
-                               LL.wv_idx_ints, st)
+                               LL.wv_idx_ints, st, parts)
   switch (bs_) {
     case 3:
       if (virt) G2OHIP_FACTOR_LEVEL(3, true); else G2OHIP_FACTOR_LEVEL(3, false);
@@ -2601,6 +2608,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     dbg_launch_ = 0;
   }
 #endif
+  bool fwd_pending = false;   // a forward step of large fronts is in flight on side_[1] (event ev_[3])
   for (const FactorGroup& G : groups_[phase]) {
     if (G.dep && dep_off_) {   // (groups only hold levels the fused kernel carries completely)
       for (int l = G.first_level; l <= G.last_level; ++l) launch_factor(launches_[phase][l], dA, fwd, st, false);
@@ -2608,12 +2616,48 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     }
     const LevelLaunch& LL = G.LL;
     const bool fused = fwd && LL.fuse_fwd;
+    const bool big_passes = LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim;
+    if (opt.overlap_level_halves && st != nullptr && big_passes && LL.glb_count > 0 && LL.lds_count > 0 && !G.dep && (fused || !fwd)) {
+      // (levels with large fronts only stay on one stream: a forward step moved to a side stream was measured to cost more
+      // in cross-stream dependencies than the 14 us it hides)
+      // The LDS fronts and the scratch-slab fronts of a level do not depend on each other: the one launch of the former
+      // runs on a side stream next to the chain of whole-GPU passes of the latter; the forward step of the large fronts
+      // runs on a second side stream next to the NEXT level's passes (only that level's LDS launch and forward step
+      // read its update vectors).  Inside a stream capture the side streams become parallel branches of the graph.
+      if (!side_[0]) {
+        for (int i = 0; i < 2; ++i) G2OHIP_HIP_CHECK(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming));
+      }
+      const bool halves = LL.lds_count > 0;
+      if (halves) {
+        G2OHIP_HIP_CHECK(hipEventRecord(ev_[0], st));
+        G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_[0], ev_[0], 0));
+        if (fwd_pending) G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_[0], ev_[3], 0));
+        launch_factor(LL, dA, fused, side_[0], false, 1);
+        G2OHIP_HIP_CHECK(hipEventRecord(ev_[1], side_[0]));
+      }
+      launch_factor(LL, dA, fused, st, false, 2);
+      if (fwd) {
+        G2OHIP_HIP_CHECK(hipEventRecord(ev_[2], st));
+        G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_[1], ev_[2], 0));
+        launch_solve(LL, true, side_[1], /*glb_only=*/true);
+        G2OHIP_HIP_CHECK(hipEventRecord(ev_[3], side_[1]));
+        fwd_pending = true;
+      }
+      if (halves) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[1], 0));
+      continue;
+    }
+    if (fwd_pending) {   // (a level that is not split reads the update vectors on the main stream)
+      G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[3], 0));
+      fwd_pending = false;
+    }
     launch_factor(LL, dA, fused, st, G.dep);
     // what the factor kernel did not carry (fronts too large for LDS, launches outside the fused kernel's
     // limits) gets its forward step inside the same level
     if (fwd && !fused) launch_solve(LL, true, st);
     else if (fwd && LL.glb_count > 0) launch_solve(LL, true, st, /*glb_only=*/true);
   }
+  if (fwd_pending) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[3], 0));
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 

@@ -62,6 +62,6 @@ def run(name, opts):
                           "choleskyNNZ": st["choleskyNNZ"]}))
     print("%-10s %-28s %.3f ms/solve  fronts %d levels %d maxdim %d nnz %d" % (name, " ".join(opts), 1e3 * dt, st["numFronts"], st["numLevels"], st["maxFrontDim"], st["choleskyNNZ"]))
 
-for name in ("manhattan", "sphere", "sphere2500"):
+for name in (os.environ.get("PG_GRAPHS") or "manhattan,sphere,sphere2500").split(","):
     for o in sys.argv[1:] or [""]:
         run(name, [x for x in o.split(",") if x])
