@@ -4117,6 +4117,16 @@ __global__ void hpp_on_schur_pattern_kernel(size_t n, int bb, int pd, const int*
   Hs[t] = v;
 }
 
+// block i of the output <- block at off[i] of the sparse-inverse slab (leading dimension ld[i], transposed if tr[i])
+__global__ void gather_inverse_blocks_kernel(int n, int p, const long long* __restrict__ off, const int* __restrict__ ld,
+                                             const int* __restrict__ tr, const double* __restrict__ Z, double* __restrict__ out) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * p * p) return;
+  const int b = (int)(t / (p * p)), e = (int)(t % (p * p)), i = e % p, j = e / p;
+  if (off[b] < 0) return;
+  out[t] = tr[b] ? Z[off[b] + j + (long long)ld[b] * i] : Z[off[b] + i + (long long)ld[b] * j];
+}
+
 int BlockSolver::compute_marginals(int n, const int* rows, const int* cols, double* out) {
   require_structure();
   if (!system_built_) throw StateFailure("compute_marginals before build_system");
@@ -4138,13 +4148,51 @@ int BlockSolver::compute_marginals(int n, const int* rows, const int* cols, doub
   const double* H = schur_ ? d_Hschur.p : d_Hpp.p;
   chol_->factor(H, st_);
   if (chol_->failed(st_)) return 1;
+  // Blocks inside the pattern of the factor: one top-down pass over the frontal matrices gives ALL of them (sparse
+  // inverse); what lies outside the pattern (fill-free pairs of distant poses) falls back to a pair of triangular
+  // sweeps per requested column.
+  std::vector<char> done(n, 0);
+  if (marginals_recursion && chol_opt.world == 1 && n > 0) {
+    chol_->sparse_inverse(st_);
+    std::vector<long long> off(n, -1);
+    std::vector<int> ldv(n, 0), trv(n, 0);
+    int found = 0;
+    for (int i = 0; i < n; ++i) {
+      bool tr = false;
+      if (chol_->inverse_block(rows[i], cols[i], &off[i], &ldv[i], &tr)) {
+        trv[i] = tr ? 1 : 0;
+        done[i] = 1;
+        ++found;
+      } else {
+        off[i] = -1;
+      }
+    }
+    if (found > 0) {
+      DevBuf<long long> d_off;
+      DevBuf<int> d_ld, d_tr;
+      DevBuf<double> d_out;
+      d_off.upload(off, st_);
+      d_ld.upload(ldv, st_);
+      d_tr.upload(trv, st_);
+      d_out.alloc((size_t)n * p_ * p_);
+      hipLaunchKernelGGL(gather_inverse_blocks_kernel, dim3(grid_for((size_t)n * p_ * p_)), dim3(kThreads), 0, st_, n, p_, d_off.p, d_ld.p,
+                         d_tr.p, chol_->inverse_slab(), d_out.p);
+      std::vector<double> ho((size_t)n * p_ * p_);
+      d_out.download(ho.data(), ho.size(), st_);
+      for (int i = 0; i < n; ++i)
+        if (done[i]) std::copy(ho.begin() + (size_t)i * p_ * p_, ho.begin() + (size_t)(i + 1) * p_ * p_, out + (size_t)i * p_ * p_);
+    }
+    if (found == n) return 0;
+  }
   const size_t np = (size_t)nP_ * p_;
   DevBuf<double> rhs, sol;
   rhs.alloc(np);
   sol.alloc(np);
   std::vector<double> h(np);
-  std::vector<int> order(n);
-  std::iota(order.begin(), order.end(), 0);
+  std::vector<int> order;
+  for (int i = 0; i < n; ++i)
+    if (!done[i]) order.push_back(i);
+  n = (int)order.size();
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cols[a] < cols[b]; });
   for (int i = 0; i < n;) {
     const int c = cols[order[i]];

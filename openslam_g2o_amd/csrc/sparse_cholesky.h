@@ -153,6 +153,13 @@ class SparseCholesky {
   void pack_exchange(hipStream_t st);                             // own subtree roots: U, w -> exchange buffer (others zero)
   void unpack_exchange(hipStream_t st);                           // foreign subtree roots: exchange buffer -> U, w
   void mask_solution(hipStream_t st);                             // zero the entries other ranks own (before the x all-reduce)
+  // ---- entries of the INVERSE on the pattern of L (Takahashi / Erisman-Tinney recursion over the frontal matrices, top
+  // down): after factor(), sparse_inverse() fills one dense m x m "inverse front" per frontal matrix; block (r, c)
+  // (original block indices) of A^-1 is inverse_block(): its address in the slab, or false when (r, c) is not in
+  // the pattern of L + L'.  One GPU only (world == 1).
+  void sparse_inverse(hipStream_t st);
+  bool inverse_block(int r, int c, long long* offset, int* ld, bool* transposed) const;
+  const double* inverse_slab() const { return d_Z.p; }
   double* exchange_buffer(size_t* count) { *count = xbuf_count_; return d_xbuf.p; }
   double* permuted_solution(size_t* count) { *count = (size_t)sym_.nb * bs_; return d_xp.p; }
   int* status_flag() { return d_status.p; }
@@ -191,6 +198,16 @@ class SparseCholesky {
   DevBuf<int> d_f_ns, d_f_nb, d_f_c0, d_rows_off, d_rows, d_rel_off, d_rel, d_asm_off, d_asm_q, d_asm_pos,
       d_child_off, d_children, d_level_fronts, d_perm, d_status;
   DevBuf<long long> d_L_off, d_U_off, d_w_off, d_scratch_off;
+  // sparse inverse: slab of the inverse fronts, per-front offsets / parents, per front level the launch lists
+  DevBuf<double> d_Z;
+  DevBuf<long long> d_zoff;
+  DevBuf<int> d_fparent;
+  DevBuf<int4> d_spinv_work;   // (front, first row / column of the chunk, -, -)
+  std::vector<long long> zoff_h_;
+  struct SpInvLevel { int f_begin, f_count, rc_begin, rc_count; };   // into d_spinv_work: one entry per front, one per 64-row chunk of its boundary
+  std::vector<SpInvLevel> spinv_levels_;
+  bool spinv_planned_ = false;
+  int spinv_npiv_max_ = 0;
   DevBuf<FrontRec> d_rec;
   DevBuf<ChildDesc> d_cdesc;
   DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts;

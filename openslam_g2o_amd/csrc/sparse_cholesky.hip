@@ -1091,6 +1091,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.dbg = nullptr;
   plan_.tl = nullptr;
   plan_.slots = d_slots.p;
+  spinv_planned_ = false;   // (the inverse fronts follow the new tree)
   analyzed_ = !host_only;
   stats_.t_symbolic = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -2659,6 +2660,207 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
   }
   if (fwd_pending) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[3], 0));
   G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sparse inverse (entries of A^-1 on the pattern of L): Z = A^-1 satisfies, for a frontal matrix with pivot columns J,
+// boundary rows B, panel [L11; L21] and Y = L21 L11^-1:
+//     Z_BB  from the parent's inverse front (the boundary rows of a front are rows of its parent),
+//     Z_JB = -Y' Z_BB,        Z_JJ = (L11 L11')^-1 - Z_JB Y.
+// (Takahashi, Fagan & Chin 1973; Erisman & Tinney 1975 -- what CHOLMOD's / CSparse's users get from "sparseinv"; the
+// reference's computeMarginals solves for columns instead, linear_solver.h:62-66 -> MarginalCovarianceCholesky.)  Top
+// down over the front levels, three kernels per level; every front keeps a dense m x m inverse front in d_Z.
+__global__ void __launch_bounds__(256) spinv_gather_y_kernel(CholPlanDev P, int bs, const long long* __restrict__ zoff,
+                                                           const int* __restrict__ fparent, double* __restrict__ Z,
+                                                           const int4* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int4 wk = work[blockIdx.x];
+  const int f = wk.x, a0 = wk.y;
+  const int ns = P.f_ns[f], nb = P.f_nb[f];
+  const int npiv = ns * bs, nbr = nb * bs, m = npiv + nbr;
+  const int p = fparent[f];
+  const int mp = (P.f_ns[p] + P.f_nb[p]) * bs;
+  double* Zf = Z + zoff[f];
+  const double* Zp = Z + zoff[p];
+  const int* rel = P.rel + P.rel_off[f];
+  const double* Lg = P.L + P.L_off[f];
+  double* L11 = sm;                 // npiv x npiv (column-major, ld npiv)
+  double* ys = sm + npiv * npiv;    // 64 rows x (npiv + 1)
+  const int tid = threadIdx.x;
+  for (int i = tid; i < npiv * npiv; i += 256) L11[i] = Lg[(i % npiv) + (size_t)m * (i / npiv)];
+  __syncthreads();
+  const int a = a0 + (tid & 63), part = tid >> 6;
+  if (a < nbr) {
+    const int pa = rel[a / bs] * bs + a % bs;
+    for (int b = part; b < nbr; b += 4) {
+      const int pb = rel[b / bs] * bs + b % bs;
+      Zf[(size_t)(npiv + a) + (size_t)m * (npiv + b)] = Zp[(size_t)pa + (size_t)mp * pb];
+    }
+    if (part == 0) {   // y L11 = l (row a of L21), from the last column to the first
+      double* y = ys + (tid & 63) * (npiv + 1);
+      for (int k = npiv - 1; k >= 0; --k) {
+        double v = Lg[(size_t)(npiv + a) + (size_t)m * k];
+        for (int j = k + 1; j < npiv; ++j) v -= y[j] * L11[j + npiv * k];
+        y[k] = v * Lg[(size_t)m * npiv + k];
+      }
+      for (int k = 0; k < npiv; ++k) Zf[(size_t)(npiv + a) + (size_t)m * k] = y[k];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) spinv_zjb_kernel(CholPlanDev P, int bs, const long long* __restrict__ zoff, double* __restrict__ Z,
+                                                      const int4* __restrict__ work) {
+  const int4 wk = work[blockIdx.x];
+  const int f = wk.x, b0 = wk.y;
+  const int ns = P.f_ns[f], nb = P.f_nb[f];
+  const int npiv = ns * bs, nbr = nb * bs, m = npiv + nbr;
+  double* Zf = Z + zoff[f];
+  const int b = b0 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  if (b >= nbr) return;
+  // Z_JB(k, b) = -sum_a Y(a, k) Z_BB(a, b), this thread's k = part, part + 4, ... (Z_BB symmetric: read along rows)
+  for (int k0 = part; k0 < npiv; k0 += 32) {
+    double acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+    for (int a = 0; a < nbr; ++a) {
+      const double z = Zf[(size_t)(npiv + b) + (size_t)m * (npiv + a)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 4 * u;
+        if (k < npiv) acc[u] += Zf[(size_t)(npiv + a) + (size_t)m * k] * z;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 4 * u;
+      if (k < npiv) Zf[(size_t)k + (size_t)m * (npiv + b)] = -acc[u];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) spinv_zjj_kernel(CholPlanDev P, int bs, const long long* __restrict__ zoff, double* __restrict__ Z,
+                                                      const int4* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int f = work[blockIdx.x].x;
+  const int ns = P.f_ns[f], nb = P.f_nb[f];
+  const int npiv = ns * bs, nbr = nb * bs, m = npiv + nbr;
+  double* Zf = Z + zoff[f];
+  const double* Lg = P.L + P.L_off[f];
+  double* L11 = sm;                  // npiv x npiv
+  double* W = sm + npiv * npiv;      // L11^-1, npiv x npiv (lower triangular)
+  const int tid = threadIdx.x;
+  for (int i = tid; i < npiv * npiv; i += 256) L11[i] = Lg[(i % npiv) + (size_t)m * (i / npiv)];
+  __syncthreads();
+  if (tid < npiv) {   // column tid of W: L11 w = e
+    const int j = tid;
+    for (int i = 0; i < npiv; ++i) {
+      double v = (i == j) ? 1.0 : 0.0;
+      if (i < j) {
+        W[i + npiv * j] = 0.0;
+        continue;
+      }
+      for (int q = j; q < i; ++q) v -= L11[i + npiv * q] * W[q + npiv * j];
+      W[i + npiv * j] = v * Lg[(size_t)m * npiv + i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < npiv * npiv; e += 256) {
+    const int k = e % npiv, l = e / npiv;
+    double s_ = 0.0;
+    for (int i = (k > l ? k : l); i < npiv; ++i) s_ += W[i + npiv * k] * W[i + npiv * l];
+    for (int a = 0; a < nbr; ++a) s_ -= Zf[(size_t)k + (size_t)m * (npiv + a)] * Zf[(size_t)(npiv + a) + (size_t)m * l];
+    L11[e] = s_;   // (L11 is no longer needed: Z_JJ is collected here, the Y block it reads must stay until all are done)
+  }
+  __syncthreads();
+  for (int e = tid; e < npiv * npiv; e += 256) Zf[(size_t)(e % npiv) + (size_t)m * (e / npiv)] = L11[e];
+  for (int e = tid; e < npiv * nbr; e += 256) {   // Z_BJ = Z_JB' in place of Y
+    const int k = e % npiv, a = e / npiv;
+    Zf[(size_t)(npiv + a) + (size_t)m * k] = Zf[(size_t)k + (size_t)m * (npiv + a)];
+  }
+}
+
+void SparseCholesky::sparse_inverse(hipStream_t st) {
+  if (!analyzed_) throw StateFailure("SparseCholesky::sparse_inverse before analyze");
+  if (opt.world > 1) throw StateFailure("SparseCholesky::sparse_inverse: one GPU only");
+  const CholSymbolic& S = sym_;
+  const int nf = (int)S.f_ns.size();
+  if (!spinv_planned_) {
+    zoff_h_.assign(nf + 1, 0);
+    int max_level = 0, max_npiv = 0;
+    for (int f = 0; f < nf; ++f) {
+      const long long m = (long long)(S.f_ns[f] + S.f_nb[f]) * bs_;
+      zoff_h_[f + 1] = zoff_h_[f] + m * m;
+      max_level = std::max(max_level, S.f_level[f]);
+      max_npiv = std::max(max_npiv, S.f_ns[f] * bs_);
+    }
+    if ((size_t)(2 * max_npiv * max_npiv + 64 * (max_npiv + 1)) * sizeof(double) > 150 * 1024)
+      throw StateFailure("SparseCholesky::sparse_inverse: pivot panel too wide for the LDS stage");
+    std::vector<int4> work;
+    spinv_levels_.clear();
+    for (int lev = max_level; lev >= 0; --lev) {   // parents first
+      SpInvLevel L;
+      L.f_begin = (int)work.size();
+      for (int f = 0; f < nf; ++f)
+        if (S.f_level[f] == lev) work.push_back(make_int4(f, 0, 0, 0));
+      L.f_count = (int)work.size() - L.f_begin;
+      L.rc_begin = (int)work.size();
+      for (int i = 0; i < L.f_count; ++i) {
+        const int f = work[L.f_begin + i].x;
+        for (int a0 = 0; a0 < S.f_nb[f] * bs_; a0 += 64) work.push_back(make_int4(f, a0, 0, 0));
+      }
+      L.rc_count = (int)work.size() - L.rc_begin;
+      spinv_levels_.push_back(L);
+    }
+    d_spinv_work.upload(work, st);
+    d_zoff.upload(zoff_h_, st);
+    std::vector<int> par(S.f_parent.begin(), S.f_parent.end());
+    for (int& v : par)
+      if (v < 0) v = 0;   // (roots have no boundary rows: never read)
+    d_fparent.upload(par, st);
+    d_Z.alloc((size_t)std::max<long long>(zoff_h_[nf], 1));
+    (void)hipFuncSetAttribute((const void*)spinv_gather_y_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)spinv_zjj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
+    spinv_npiv_max_ = max_npiv;
+    spinv_planned_ = true;
+  }
+  const size_t sh1 = (size_t)(spinv_npiv_max_ * spinv_npiv_max_ + 64 * (spinv_npiv_max_ + 1)) * sizeof(double);
+  const size_t sh3 = (size_t)(2 * spinv_npiv_max_ * spinv_npiv_max_) * sizeof(double);
+  for (const SpInvLevel& L : spinv_levels_) {
+    if (L.rc_count > 0) {
+      hipLaunchKernelGGL(spinv_gather_y_kernel, dim3(L.rc_count), dim3(256), sh1, st, plan_, bs_, d_zoff.p, d_fparent.p, d_Z.p,
+                         d_spinv_work.p + L.rc_begin);
+      hipLaunchKernelGGL(spinv_zjb_kernel, dim3(L.rc_count), dim3(256), 0, st, plan_, bs_, d_zoff.p, d_Z.p, d_spinv_work.p + L.rc_begin);
+    }
+    if (L.f_count > 0)
+      hipLaunchKernelGGL(spinv_zjj_kernel, dim3(L.f_count), dim3(256), sh3, st, plan_, bs_, d_zoff.p, d_Z.p, d_spinv_work.p + L.f_begin);
+  }
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+bool SparseCholesky::inverse_block(int r, int c, long long* offset, int* ld, bool* transposed) const {
+  const CholSymbolic& S = sym_;
+  if (!spinv_planned_ || r < 0 || c < 0 || r >= S.nb || c >= S.nb) return false;
+  int pr = S.iperm[r], pc = S.iperm[c];
+  const bool tr = pr < pc;   // stored: row >= column (in elimination order)
+  if (tr) std::swap(pr, pc);
+  const int f = (int)(std::upper_bound(S.sn_start.begin(), S.sn_start.end(), pc) - S.sn_start.begin()) - 1;
+  const int c0 = S.sn_start[f], ns = S.f_ns[f];
+  int rowpos;
+  if (pr < c0 + ns) {
+    rowpos = pr - c0;
+  } else {
+    const int* b = S.rows.data() + S.rows_off[f];
+    const int* e = b + S.f_nb[f];
+    const int* it = std::lower_bound(b, e, pr);
+    if (it == e || *it != pr) return false;
+    rowpos = ns + (int)(it - b);
+  }
+  const long long m = (long long)(ns + S.f_nb[f]) * bs_;
+  *offset = zoff_h_[f] + (long long)rowpos * bs_ + m * ((long long)(pc - c0) * bs_);
+  *ld = (int)m;
+  *transposed = tr;
+  return true;
 }
 
 void SparseCholesky::factor(const double* dA, hipStream_t st) {

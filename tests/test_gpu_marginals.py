@@ -89,3 +89,64 @@ def test_ba_pose_marginals_are_the_pose_block_of_the_full_inverse():
     # the solver still solves afterwards
     s.setLambda(1.0, True)
     assert s.solve()
+
+
+def test_sparse_inverse_gives_every_block_of_the_pattern():
+    """computeMarginals by the sparse-inverse recursion over the frontal matrices (one top-down pass for ALL requested
+    blocks): every block of the reduced pattern of a BA system -- diagonal and off-diagonal, both orientations --
+    against the dense inverse of Hpp, and against the column-by-column path (option marginals_recursion = 0)."""
+    from openslam_g2o_amd import capi
+    pr = ba_case(90, 400)
+    s = hip_ba(pr)
+    s.buildSystem()
+    o = oracle_ba(pr)
+    o.build_system()
+    nP = pr["nP"]
+    Hinv = np.linalg.inv(o.dense_full()[:6 * nP, :6 * nP])
+    cp, ri = s.pattern(capi.HSCHUR)
+    rows, cols = [], []
+    for c in range(nP):
+        for q in range(cp[c], cp[c + 1]):
+            rows += [ri[q], c]
+            cols += [c, ri[q]]
+    rows, cols = np.array(rows, np.int32), np.array(cols, np.int32)
+    M = s.computeMarginals(rows, cols)
+    assert M is not None and M.shape == (len(rows), 6, 6)
+    scale = np.abs(Hinv).max()
+    for i in range(len(rows)):
+        ref = Hinv[6 * rows[i]:6 * rows[i] + 6, 6 * cols[i]:6 * cols[i] + 6]
+        assert np.abs(M[i] - ref).max() <= 1e-9 * scale, (rows[i], cols[i])
+    s.setOption("marginals_recursion", 0)
+    sel = np.arange(0, len(rows), 37)
+    M0 = s.computeMarginals(rows[sel], cols[sel])
+    assert np.abs(M0 - M[sel]).max() <= 1e-9 * scale
+    s.setLambda(1.0, True)      # the solver still solves afterwards
+    assert s.solve()
+
+
+def test_sparse_inverse_with_large_fronts_matches_column_solves():
+    """Pose graph with fronts of several hundred rows (scratch-slab fronts: their panels come from the whole-GPU passes):
+    diagonal blocks spread over the tree and a few coupled pairs, recursion against unit right-hand sides; a pair outside
+    the pattern of the factor falls back to the column path inside the same call."""
+    from openslam_g2o_amd import capi
+    from tests.helpers import sphere_golden
+    g = sphere_golden()
+    J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
+    s = capi.HipBlockSolver(6, 3, 0)
+    k = s.addEdgeSet(6, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+    s.buildStructure(g["nP"], 0, False)
+    s.setEdgeData(k, J0, J1, g["omega"], err)
+    s.buildSystem()
+    s.setLambda(1e-3 * s.maxDiagonal(), True)
+    nP = g["nP"]
+    diag = np.arange(0, nP, 97, dtype=np.int32)
+    hi, hj = g["hidx"][g["vi"]], g["hidx"][g["vj"]]
+    keep = (hi >= 0) & (hj >= 0)
+    pi, pj = hi[keep][::701].astype(np.int32), hj[keep][::701].astype(np.int32)   # measured pairs: blocks of the pattern
+    rows = np.concatenate([diag, pi, [0]]).astype(np.int32)
+    cols = np.concatenate([diag, pj, [nP - 1]]).astype(np.int32)
+    M = s.computeMarginals(rows, cols)
+    s.setOption("marginals_recursion", 0)
+    M0 = s.computeMarginals(rows, cols)
+    assert M is not None and M0 is not None
+    assert np.abs(M - M0).max() <= 1e-9 * np.abs(M0).max()
