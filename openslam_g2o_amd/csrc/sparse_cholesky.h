@@ -45,7 +45,6 @@ struct CholOptions {
   int dep_delay = 0;                     // launch-order distance between a task and its parent inside a wide dependency-driven launch
   int wave_front_tasks = 1024;           // launches at least this wide use two waves (128 threads) per front
   size_t wave_front_bytes = 0;           // (unused)
-  int wave_narrow_tasks = 0;             // wave-kernel levels with at most this many tasks use the narrow (latency) variant
   int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
@@ -221,7 +220,6 @@ class SparseCholesky {
     int lds_idx_ints = 0, glb_idx_ints = 0;              // staged index lists (ints) per front, max over the launch
     bool fuse_fwd = true;                                // every LDS front of the launch is within the fused forward sweep's limits
     int sm_count = 0, sm_max_m = 0, sm_idx_ints = 0;     // leading part of the lds range: small fronts, one wave each
-    bool wv_narrow = false;                              // ... and the level is narrow (latency-critical top of the tree): the variant with the larger register budget
     bool wv = false;                                     // every front fits the register-resident wave kernel (wave_front.inc)
     int wv_pn = 0, wv_idx_ints = 0;                      // ... its panel region (doubles) and index tables (ints), max over the launch
     int bt_begin = 0, bt_count = 0;                      // 64 x 64 trailing-update tiles of the scratch-slab fronts (d_big_tiles)

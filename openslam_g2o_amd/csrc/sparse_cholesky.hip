@@ -670,7 +670,6 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           }
         }
       }
-      LL.wv_narrow = LL.wv && (int)lds[l].size() <= opt.wave_narrow_tasks;
       // wide launches run two waves per front (see front_factor_kernel); *_max_m = packed doubles of the largest front
       if (!LL.wv && opt.wave_front_tasks > 0 && LL.lds_count >= opt.wave_front_tasks) LL.sm_count = LL.lds_count;
       for (int i = 0; i < (int)lds[l].size(); ++i) {
@@ -881,7 +880,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         int end = G.LL.lds_begin + G.LL.lds_count;
         while (l1 < nlev && l1 - l < opt.dep_levels) {
           const LevelLaunch& N = launches_[ph][l1];
-          if (!plain(N) || (N.sm_count > 0) != sm || N.wv != wv || N.wv_narrow != G.LL.wv_narrow || N.lds_begin != end) break;
+          if (!plain(N) || (N.sm_count > 0) != sm || N.wv != wv || N.lds_begin != end) break;
           end += N.lds_count;
           ++l1;
         }
@@ -2436,7 +2435,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
                          int lds_idx_ints, int glb_idx_ints, int sm_count, int sm_max_m, int sm_idx_ints, int wcap,
                          const double* bperm, double* yout, int dep, const int4* big_tiles, int bt_count, const BigLaunch& big,
-                         int wide_doubles, bool wv, bool wv_narrow, int wv_pn, int wv_idx_ints, hipStream_t st, int parts = 3) {
+                         int wide_doubles, bool wv, int wv_pn, int wv_idx_ints, hipStream_t st, int parts = 3) {
   // parts: bit 0 = the fronts held in LDS / registers, bit 1 = the scratch-slab fronts (the two halves of a level are
   // independent: factor_phase may put them on different streams)
   if (!(parts & 1)) {
@@ -2445,10 +2444,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     sm_count = 0;
   } else if (wv) {   // every front of the launch fits the register-resident wave kernel: one wavefront per task
     const size_t sh = ((size_t)kWvTiles * 256 + 64 + 2 * kWvT * 64) * sizeof(double) + (size_t)(8 * 64 + 2 * 16 * kWvT + 2 * 64) * sizeof(int);
-    if (wv_narrow)
-      hipLaunchKernelGGL((wave_front_kernel<BS, VIRT, true>), dim3(lds_count), dim3(64 * kWvWaves), sh, st, wv_plan(P), lds_begin, dA, bperm, yout, dep);
-    else
-      hipLaunchKernelGGL((wave_front_kernel<BS, VIRT, false>), dim3(lds_count), dim3(64 * kWvWaves), sh, st, wv_plan(P), lds_begin, dA, bperm, yout, dep);
+    hipLaunchKernelGGL((wave_front_kernel<BS, VIRT>), dim3(lds_count), dim3(64 * kWvWaves), sh, st, wv_plan(P), lds_begin, dA, bperm, yout, dep);
     return;
   }
   if (sm_count > 0) {   // wide launch: two waves per front
@@ -2557,7 +2553,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   launch_factor_level<BS_, V_>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m, \
                                LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m,            \
                                LL.sm_idx_ints, LL.max_m, fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr,   \
-                               dep ? 1 : 0, d_big_tiles.p + LL.bt_begin, LL.bt_count, big, opt.wide_front_doubles, LL.wv, LL.wv_narrow, LL.wv_pn,   \
+                               dep ? 1 : 0, d_big_tiles.p + LL.bt_begin, LL.bt_count, big, opt.wide_front_doubles, LL.wv, LL.wv_pn,   \
                                LL.wv_idx_ints, st, parts)
   switch (bs_) {
     case 3:
