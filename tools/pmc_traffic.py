@@ -39,11 +39,13 @@ def per_kernel(path, iters=None):
     for name, start, val in rows:
         by.setdefault(name, []).append(val)
     if iters is None:   # bench iterations in the trace = dispatches of a kernel that runs once per iteration
-        once = [len(v) for n, v in by.items() if "back_substitute_kernel" in n or "landmark_inverse_kernel" in n]
+        once = [len(v) for n, v in by.items() if "back_substitute" in n or "landmark_inverse_kernel" in n]
         iters = max(once) if once else 1
     out = {}
     for name, vals in by.items():
-        n = len(vals) // iters if len(vals) >= iters else len(vals)
+        if len(vals) < iters:   # not part of the iteration (e.g. the stand-alone landmark assembly behind the residual check)
+            continue
+        n = len(vals) // iters
         # median per launch x launches per step: a stray launch outside the iterations (e.g. the residual check's
         # on-demand Hpl materialisation at the end of bench.py) must not stand in for the per-iteration traffic
         sv = sorted(vals)

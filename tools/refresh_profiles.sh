@@ -15,8 +15,6 @@ rm -rf /tmp/pk /tmp/pf /tmp/pw
 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/bench.py --no-cpu-baseline --graph off --steps 5 --warmup 2 > $OUT/trace.log 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/pk -name "*.db" | head -1) $OUT/${P}_kernel_stats.csv
 python $R/tools/level_times.py $(find /tmp/pk -name "*.db" | head -1) 2 > $OUT/${P}_level_times.txt
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o f -- python $R/bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1 > $OUT/pmc_f.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o w -- python $R/bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1 > $OUT/pmc_w.log 2>&1
-python $R/tools/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) > $OUT/${P}_pmc_traffic.json
 cd $R
+bash tools/gpu_pmc_traffic.sh $P > $OUT/pmc_traffic.log 2>&1
 ls -la $OUT
