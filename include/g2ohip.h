@@ -219,6 +219,9 @@ int g2ohip_device_array(g2ohip_solver* s, int which, double** ptr, size_t* count
  * with the current damping -- what the reference hands to solvePattern (`*_Hpp`, block_solver.hpp:492), also when
  * the Schur complement is on.  Option "marginals_reduced" = 1 (g2ohip_set_option) inverts the reduced pose system
  * instead: the pose marginals with the landmarks integrated out (a deviation from the reference, off by default).
+ * Blocks inside the pattern of the factor come from ONE sparse-inverse pass over the frontal matrices (all of them at
+ * once: what MarginalCovarianceCholesky's recursion computes entry by entry), the others from a pair of triangular
+ * sweeps per column; option "marginals_recursion" = 0 forces the column path.
  * out [n][p*p], column-major blocks.  After g2ohip_build_system.  G2OHIP_OK | G2OHIP_NOT_PD. */
 int g2ohip_compute_marginals(g2ohip_solver* s, int n_blocks, const int32_t* rows, const int32_t* cols, double* out);
 /* The per-edge data the next g2ohip_build_system will consume, copied to the host (inspection / tests of the
