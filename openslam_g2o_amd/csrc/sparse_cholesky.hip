@@ -1123,6 +1123,18 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& r) {
 // Update matrices / vectors travel between workgroups that may run on different XCDs INSIDE one launch
 // (dependency-driven launches): they are written and read with agent-scope accesses (sc1: coherent at the
 // device level) instead of write-back/invalidate fences over the whole L2.
+// Ordering argument of the hand-off (no release / acquire fence is used, deliberately -- a fence writes back and
+// invalidates the whole L2 of the XCD per task):
+//   producer: its st_coh stores are agent-scope (sc1) accesses: they complete in the device-coherent level of the memory
+//             hierarchy; s_waitcnt vmcnt(0) returns when every one of them has been acknowledged there; then the
+//             workgroup barrier; only then ONE lane increments the consumer's counter (agent-scope atomic): the increment
+//             is issued after the acknowledgements in program order, so it cannot become visible before the data;
+//   consumer: one lane polls the counter with agent-scope atomic loads; the workgroup barrier after the poll orders
+//             every wave's ld_coh loads behind it (they are issued after the barrier, a control dependence the hardware
+//             does not speculate across), and ld_coh reads the same device-coherent level, never a stale L1 / L2 line.
+// This relies on gfx9's in-order issue and completion accounting of a wave's vector memory operations (vmcnt) and on sc1
+// accesses being coherent at agent scope; it does not rely on workgroup dispatch order beyond "a child of a task is
+// running or finished when the task starts" (deadlock freedom).
 __device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
