@@ -243,6 +243,8 @@ class BlockSolver {
   DevBuf<int> d_hs_diag;                   // Hschur block -> pose index when diagonal, else -1
   // Schur tiles: landmark ranges, their destination blocks and LDS-local contributor entries
   DevBuf<int> d_tile_lm0, d_tile_td0, d_td_diag, d_td_ptr, d_te_pack, d_rd_ptr, d_rd_slot;
+  DevBuf<int2> d_tile_q2;         // per tile: second Hpl block range (first block, count) -- tiles of a split landmark
+  int n_split_tiles_ = 0;
   std::vector<int> tile_lm0_h_;   // first landmark of every tile (+ one past the last)
   DevBuf<unsigned short> d_te_lm;
   DevBuf<double> d_Pd, d_Pr;               // per (tile, destination) partial blocks / rhs

@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
                                                             const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm,
                                                             double* __restrict__ Pd,
                                                             double* __restrict__ Pr, const double* __restrict__ Hll,
-                                                            const double* __restrict__ lam) {
+                                                            const double* __restrict__ lam, const int2* __restrict__ tile_q2) {
   // Hll != nullptr: the landmark inversion (block_solver.hpp:386-389, with the virtual damping) is done here on
   // the staged blocks -- the tile reads Hll instead of Dinv and writes Dinv (back-substitution needs it) on the way.
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -553,8 +553,9 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
   const int* tm = tile_lm0 + (size_t)t * 8;   // packed tile record (see build_structure)
   const int l0 = tm[0], l1 = tm[1], q0 = tm[2], nslots = tm[3], nlm = l1 - l0;
   const int td0 = tm[4], td1 = tm[5], e0 = tm[6], ne = tm[7];
+  const int2 t2 = tile_q2[t];   // second block range (tiles of a split landmark; count 0 otherwise), staged behind the first
   double* Bs = smem;
-  double* Ds = Bs + ((nslots * PL + 1) & ~1);
+  double* Ds = Bs + (((nslots + t2.y) * PL + 1) & ~1);
   double* bsm = Ds + ((nlm * LD * LD + 1) & ~1);
   int* ep = reinterpret_cast<int*>(bsm + ((nlm * LD + 1) & ~1));
   int* dptr = ep + ne;                                // td_ptr[td0 .. td1]
@@ -614,6 +615,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
     // remainders
     if (n2 > UB * NT) stage_copy<4>(dstB + UB * NT, srcB + UB * NT, n2 - UB * NT, tid, NT);
     if (((nslots * PL) & 1) && tid == 0) Bs[nslots * PL - 1] = Hpl[(size_t)q0 * PL + nslots * PL - 1];
+    for (int i = tid; i < t2.y * PL; i += NT) Bs[nslots * PL + i] = Hpl[(size_t)t2.x * PL + i];
     if (nD > UD * NT) stage_copy<4>(Ds + UD * NT, srcD + UD * NT, nD - UD * NT, tid, NT);
     if (nb > NT) stage_copy<2>(bsm + NT, srcb + NT, nb - NT, tid, NT);
     if (ne > UE * NT) {
@@ -1026,7 +1028,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
     int kind, double delta, int ident, double* __restrict__ Dinv, double* bl, const int* __restrict__ td_diag,
     const int* __restrict__ td_ptr, const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm, double* __restrict__ Pd,
     double* __restrict__ Pr, double* Hll, const double* __restrict__ lam, const int4* __restrict__ ll_rec,
-    const int4* __restrict__ tile_ll, const int* __restrict__ ll_edge, double* __restrict__ err) {
+    const int4* __restrict__ tile_ll, const int* __restrict__ ll_edge, double* __restrict__ err, const int2* __restrict__ tile_q2) {
   // (FLL: meas_q / omega_q are the slot-major copies ll_meas / ll_omega; cam_q / pt_q are unused)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int PD = 6, LD = 3, PL = PD * LD;
@@ -1034,8 +1036,10 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
   const int* tm = tile_lm0 + (size_t)t * 8;   // packed tile record (see build_structure)
   const int l0 = tm[0], l1 = tm[1], q0 = tm[2], nslots = tm[3], nlm = l1 - l0;
   const int td0 = tm[4], td1 = tm[5], e0 = tm[6], ne = tm[7];
+  const int2 t2 = FLL ? make_int2(0, 0) : tile_q2[t];   // second block range of a split landmark's tile (never with FLL)
+  const int ntot = nslots + t2.y;
   double* Bs = smem;
-  double* Ds = Bs + ((nslots * PL + 1) & ~1);
+  double* Ds = Bs + ((ntot * PL + 1) & ~1);
   double* bsm = Ds + ((nlm * LD * LD + 1) & ~1);
   int* ep = reinterpret_cast<int*>(bsm + ((nlm * LD + 1) & ~1));
   int* dptr = ep + ne;
@@ -1147,20 +1151,22 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
         }
       }
     } else {
-      for (int sb = 0; sb < nslots; sb += NT) {
+      for (int sb = 0; sb < ntot; sb += NT) {
         const int s_ = sb + tid;
-        const int sc = min(s_, nslots - 1);
-        const int c_ = sb == 0 ? cq : cam_q[q0 + sc], p_ = sb == 0 ? pq : pt_q[q0 + sc];
+        const int sc = min(s_, ntot - 1);
+        const int qq = sc < nslots ? q0 + sc : t2.x + (sc - nslots);   // Hpl block of this slot
+        const bool pre = sb == 0 && s_ < nslots;
+        const int c_ = pre ? cq : cam_q[qq], p_ = pre ? pq : pt_q[qq];
         double T[12], X[3], z2[2], Op[4];
         load_vec<12>(cams + (size_t)c_ * 12, T);
         const double* Xp = pts + (size_t)p_ * 3;
         X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
-        load_vec<2>(meas_q + (size_t)(q0 + sc) * 2, z2);
+        load_vec<2>(meas_q + (size_t)qq * 2, z2);
         if (ident) {
           Op[0] = Op[3] = 1.0;
           Op[1] = Op[2] = 0.0;
         } else {
-          load_vec<4>(omega_q + (size_t)(q0 + sc) * 4, Op);
+          load_vec<4>(omega_q + (size_t)qq * 4, Op);
         }
         BaEdgeLin L;
         ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
@@ -1173,7 +1179,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
           OA[1 + 2 * c] = O10 * L.A[0 + 2 * c] + O11 * L.A[1 + 2 * c];
         }
         ba_hpl_block(L, OA, blk);
-        if (s_ < nslots) store_vec<18>(Bs + s_ * 18, blk);
+        if (s_ < ntot) store_vec<18>(Bs + s_ * 18, blk);
       }
 #pragma unroll
       for (int u = 0; u < UD; ++u) {
@@ -2101,33 +2107,9 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       struct Ent { int dest, pack; unsigned short lml; };
       std::vector<Ent> ents;
       std::vector<int> order;
-      while (lm < nL) {
-        // greedy tile: as many landmarks as fit the LDS budget (at least one)
-        int l0 = lm;
-        size_t bytes = 0, nent = 0;
-        while (lm < nL) {
-          size_t K = pl_colptr[lm + 1] - pl_colptr[lm];
-          size_t add = K * PL * 8 + DP * 8 + BP * 8 + K * (K + 1) / 2 * (6 + 8);   // blocks, Dinv, b_l, entries (+ per-destination metadata bound)
-          bool ok16 = (size_t)(pl_colptr[lm + 1] - pl_colptr[l0]) < 65536 && (lm + 1 - l0) < 65536;
-          if (lm > l0 && (bytes + add > schur_tile_bytes || !ok16)) break;
-          bytes += add;
-          nent += K * (K + 1) / 2;
-          ++lm;
-        }
-        if ((size_t)(pl_colptr[lm] - pl_colptr[l0]) >= 65536) throw ArgFailure("a landmark is observed by >= 65536 poses: unsupported");
-        max_lds = std::max(max_lds, bytes + 64);
-        ents.clear();
-        ents.reserve(nent);
-        const int q0 = pl_colptr[l0];
-        for (int c = l0; c < lm; ++c)
-          for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
-            for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) {
-              Ent e;
-              e.dest = find_block(hs_colptr, hs_row, pl_row[q2], pl_row[q1]);
-              e.pack = (q1 - q0) | ((q2 - q0) << 16);
-              e.lml = (unsigned short)(c - l0);
-              ents.push_back(e);
-            }
+      // per tile: landmark range, first block range, optional SECOND block range (split landmarks, below)
+      std::vector<int> t_l0, t_l1, t_q0, t_ns, t_q1, t_n1;
+      auto emit_tile = [&](int l0, int l1, int q0, int ns, int q1, int n1) {
         order.resize(ents.size());
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ents[a].dest < ents[b].dest; });  // landmark order kept per dest
@@ -2154,12 +2136,79 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
           }
           td_ptr.push_back((int)te_pack.size());
         }
-        tile_lm0.push_back(lm);
+        t_l0.push_back(l0); t_l1.push_back(l1); t_q0.push_back(q0); t_ns.push_back(ns); t_q1.push_back(q1); t_n1.push_back(n1);
         tile_td0.push_back((int)td_dest.size());
+      };
+      n_split_tiles_ = 0;
+      while (lm < nL) {
+        // greedy tile: as many landmarks as fit the LDS budget
+        int l0 = lm;
+        size_t bytes = 0, nent = 0;
+        {
+          // A landmark seen by so many poses that its blocks and pair list alone exceed the budget (K(K+1)/2 entries:
+          // ~64 poses at 39 KB) is SPLIT: its observation list is cut into chunks, one tile per pair of chunks (A <= B)
+          // stages the blocks of A and of B (two block ranges) and carries the pairs (a in A, b in B).  Every tile
+          // inverts the landmark's block itself (the same bits) and the diagonal chunk pairs carry the right-hand side.
+          const size_t K = pl_colptr[lm + 1] - pl_colptr[lm];
+          const size_t alone = K * PL * 8 + DP * 8 + BP * 8 + K * (K + 1) / 2 * (6 + 8);
+          if (alone > schur_tile_bytes && K > 2) {
+            size_t C = 1;
+            while ((2 * (C + 1)) * PL * 8 + DP * 8 + BP * 8 + (C + 1) * (C + 1) * (6 + 8) <= schur_tile_bytes) ++C;
+            C = std::max<size_t>(C, 1);
+            if (C >= 32768) throw ArgFailure("Schur tile budget too large for 16-bit slot indices");
+            const int qb = pl_colptr[lm];
+            for (size_t a0 = 0; a0 < K; a0 += C)
+              for (size_t b0 = a0; b0 < K; b0 += C) {
+                const int na = (int)std::min(C, K - a0), nb2 = (int)std::min(C, K - b0);
+                const bool same = a0 == b0;
+                ents.clear();
+                for (int a = 0; a < na; ++a)
+                  for (int b = same ? a : 0; b < nb2; ++b) {
+                    const int qa = qb + (int)a0 + a, qbb = qb + (int)b0 + b;
+                    Ent e;
+                    e.dest = find_block(hs_colptr, hs_row, pl_row[qbb], pl_row[qa]);
+                    e.pack = a | ((same ? b : na + b) << 16);
+                    e.lml = 0;
+                    ents.push_back(e);
+                  }
+                const size_t tb = (size_t)(na + (same ? 0 : nb2)) * PL * 8 + DP * 8 + BP * 8 + ents.size() * (6 + 8);
+                max_lds = std::max(max_lds, tb + 64);
+                emit_tile(lm, lm + 1, qb + (int)a0, na, same ? 0 : qb + (int)b0, same ? 0 : nb2);
+                ++n_split_tiles_;
+              }
+            ++lm;
+            continue;
+          }
+        }
+        while (lm < nL) {
+          size_t K = pl_colptr[lm + 1] - pl_colptr[lm];
+          size_t add = K * PL * 8 + DP * 8 + BP * 8 + K * (K + 1) / 2 * (6 + 8);   // blocks, Dinv, b_l, entries (+ per-destination metadata bound)
+          bool ok16 = (size_t)(pl_colptr[lm + 1] - pl_colptr[l0]) < 65536 && (lm + 1 - l0) < 65536;
+          if (lm > l0 && (bytes + add > schur_tile_bytes || !ok16)) break;
+          bytes += add;
+          nent += K * (K + 1) / 2;
+          ++lm;
+        }
+        if ((size_t)(pl_colptr[lm] - pl_colptr[l0]) >= 65536) throw ArgFailure("a landmark is observed by >= 65536 poses: unsupported");
+        max_lds = std::max(max_lds, bytes + 64);
+        ents.clear();
+        ents.reserve(nent);
+        const int q0 = pl_colptr[l0];
+        for (int c = l0; c < lm; ++c)
+          for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
+            for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) {
+              Ent e;
+              e.dest = find_block(hs_colptr, hs_row, pl_row[q2], pl_row[q1]);
+              e.pack = (q1 - q0) | ((q2 - q0) << 16);
+              e.lml = (unsigned short)(c - l0);
+              ents.push_back(e);
+            }
+        emit_tile(l0, lm, q0, pl_colptr[lm] - q0, 0, 0);
+        tile_lm0.push_back(lm);
       }
-      n_tiles_ = (int)tile_lm0.size() - 1;
-      tile_lm0_h_ = tile_lm0;
-      tiles_cover_all_ = tile_lm0.front() == 0 && tile_lm0.back() == nL;
+      n_tiles_ = (int)t_l0.size();
+      tile_lm0_h_ = tile_lm0;   // (tile boundaries: only meaningful while no landmark is split, n_split_tiles_ == 0)
+      tiles_cover_all_ = true;
       n_td_ = (long)td_dest.size();
       n_sc_ = (long)te_pack.size();
       schur_lds_bytes_ = max_lds;
@@ -2175,18 +2224,21 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         // one 32-byte record per tile (l0, l1, first Hpl slot, slots, td0, td1, first entry, entries): a single
         // scalar load instead of three dependent ones
         std::vector<int> meta((size_t)n_tiles_ * 8);
+        std::vector<int2> q2((size_t)std::max(n_tiles_, 1), make_int2(0, 0));
         for (int t = 0; t < n_tiles_; ++t) {
           int* m = &meta[(size_t)t * 8];
-          m[0] = tile_lm0[t];
-          m[1] = tile_lm0[t + 1];
-          m[2] = pl_colptr[m[0]];
-          m[3] = pl_colptr[m[1]] - m[2];
+          m[0] = t_l0[t];
+          m[1] = t_l1[t];
+          m[2] = t_q0[t];
+          m[3] = t_ns[t];
+          q2[t] = make_int2(t_q1[t], t_n1[t]);   // second block range of a split landmark's tile (count 0: none)
           m[4] = tile_td0[t];
           m[5] = tile_td0[t + 1];
           m[6] = td_ptr[m[4]];
           m[7] = td_ptr[m[5]] - m[6];
         }
         d_tile_lm0.upload(meta, st_);
+        d_tile_q2.upload(q2, st_);
       }
       d_tile_td0.upload(tile_td0, st_);
       {
@@ -2753,13 +2805,14 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
                          ba_.cy,                                                                                                     \
                          es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, ba_.ll_rec.p, ba_.tile_ll.p, ba_.ll_edge.p,       \
-                         ba_.err_valid ? (double*)nullptr : es.own_err.p);   /* (errors of these estimates already there) */       \
+                         ba_.err_valid ? (double*)nullptr : es.own_err.p, /* (errors of these estimates already there) */          \
+                         d_tile_q2.p);                                                                                             \
     else                                                                                                                           \
       hipLaunchKernelGGL((ba_schur_tile_kernel<GG, false>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,       \
                          ba_.cams.p, ba_.pts.p, ba_.cam_q.p, ba_.pt_q.p, ba_.meas_q.p, ba_.omega_q.p, ba_.f, ba_.cx, ba_.cy,           \
                          es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, (const int4*)nullptr, (const int4*)nullptr,        \
-                         (const int*)nullptr, (double*)nullptr);                                                                   \
+                         (const int*)nullptr, (double*)nullptr, d_tile_q2.p);                                                      \
   } while (0)
     if (G <= 1) G2OHIP_BA_TILE(1);
     else if (G <= 2) G2OHIP_BA_TILE(2);
@@ -2771,7 +2824,7 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
     prof.end(KernelProf::kSchurBlocks, st_);
   } else
 #define G2OHIP_TILE_ARGS d_tile_lm0.p, d_tile_td0.p, d_pl_colptr.p, d_Hpl.p, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p, d_te_pack.p, \
-                         d_te_lm.p, d_Pd.p, d_Pr.p, fuse_inv ? d_Hll.p : (const double*)nullptr, d_lam.p
+                         d_te_lm.p, d_Pd.p, d_Pr.p, fuse_inv ? d_Hll.p : (const double*)nullptr, d_lam.p, d_tile_q2.p
 #define G2OHIP_SCHUR(P_, L_)                                                                                                   \
   if (p_ == P_ && l_ == L_) {                                                                                                  \
     if (!fuse_inv) {                                                                                                           \
@@ -3769,7 +3822,8 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
     }
     // lane slots of the tiles that assemble their own landmarks
     ba_.ll_slots_ok = false;
-    if (schur_ && n_tiles_ > 0 && tiles_cover_all_ && (int)tile_lm0_h_.size() == n_tiles_ + 1 && (int)es.h_vl_ptr.size() == nL_ + 1) {
+    if (schur_ && n_tiles_ > 0 && tiles_cover_all_ && n_split_tiles_ == 0 && (int)tile_lm0_h_.size() == n_tiles_ + 1 &&
+        (int)es.h_vl_ptr.size() == nL_ + 1) {
       constexpr int kIdleSlot = (int)0x80000fffu;   // no observation, not a first lane, list length 0
       std::vector<int> slots;
       std::vector<int4> tl((size_t)n_tiles_);

@@ -217,6 +217,7 @@ class SparseCholesky {
     int glb_begin = 0, glb_count = 0, glb_max_m = 0;
     int max_panel = 0;                                   // max m*npiv (doubles) for solve kernels
     int max_m = 0;
+    int lds_vec_m = 0;                                   // largest front dimension among the LDS / register fronts only (their vectors in LDS)
     int lds_idx_ints = 0, glb_idx_ints = 0;              // staged index lists (ints) per front, max over the launch
     bool fuse_fwd = true;                                // every LDS front of the launch is within the fused forward sweep's limits
     int sm_count = 0, sm_max_m = 0, sm_idx_ints = 0;     // leading part of the lds range: small fronts, one wave each

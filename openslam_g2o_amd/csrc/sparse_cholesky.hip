@@ -490,6 +490,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   auto front_dim = [&](int f) { return (size_t)(S.f_ns[f] + S.f_nb[f]) * bs; };
   // LDS-resident iff the dense size is within the class limit AND everything the factor kernel keeps in LDS for this
   // front (packed blocks, rhs vectors, mailboxes, index tables) fits the per-workgroup budget
+  long long lds_ints = 0;   // (index part of the last lds_need)
   auto lds_need = [&](int f) {
     const long long nbt = S.f_ns[f] + S.f_nb[f], mm = nbt * bs;
     const long long T_ = (bs % 3 == 0) ? 3 : bs;
@@ -499,10 +500,18 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       const long long nbc = S.f_nb[S.children[ch]];
       ints += nbc * (nbc + 1) / 2 + nbc;
     }
+    lds_ints = 4 * ints;
     return 8 * (nbt * (nbt + 1) / 2 * bs * bs + 2 * mm + 2 * (bs * bs + bs)) + 4 * ints;
   };
+  // A launch sizes its LDS by the largest block part and the largest index part among ITS fronts separately (the kernel
+  // places the index tables behind a launch-uniform block region), so the two parts are capped separately: their sum of
+  // maxima then fits whatever fronts share a launch.  (A front with few rows but a child with hundreds of boundary
+  // blocks -- a landmark seen by hundreds of poses -- used to push a launch beyond 160 KB.)
   auto is_lds = [&](int f) {
-    return front_dim(f) * front_dim(f) * 8 <= opt.lds_front_bytes && lds_need(f) <= (long long)opt.lds_budget_bytes;
+    if (front_dim(f) * front_dim(f) * 8 > opt.lds_front_bytes) return false;
+    const long long total = lds_need(f);
+    const long long cap = (long long)opt.lds_budget_bytes;
+    return total <= cap && lds_ints <= 24 * 1024 && total - lds_ints <= 134 * 1024;   // (158 KB of the CU's 160 KB)
   };
   std::vector<int> chain_next(nf, -1), has_prev(nf, 0);
   if (opt.fuse_chains)
@@ -792,10 +801,12 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   for (int ph = 0; ph < 2; ++ph)
   for (LevelLaunch& LL : launches_[ph]) {
     LL.lds_idx_ints = LL.glb_idx_ints = LL.sm_idx_ints = 0;
+    LL.lds_vec_m = 0;
     for (int q = LL.lds_begin; q < LL.glb_begin + LL.glb_count; ++q) {
       const int t = S.level_fronts[q];
       for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
         const FrontRec& R = recs[S.task_fronts[k]];
+        if (q < LL.glb_begin) LL.lds_vec_m = std::max(LL.lds_vec_m, (R.ns + R.nb) * bs);
         if (q < LL.glb_begin) {   // may the factor kernel carry the forward sweep of this launch?
           const int nthr = LL.sm_count > 0 ? 128 : kFactorThreads;
           bool ok = R.child_cnt <= kFwdChildren && R.ns * bs <= nthr;
@@ -917,6 +928,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
               G.LL.lds_idx_ints = std::max(G.LL.lds_idx_ints, N.lds_idx_ints);
             }
             G.LL.max_m = std::max(G.LL.max_m, N.max_m);
+            G.LL.lds_vec_m = std::max(G.LL.lds_vec_m, N.lds_vec_m);
             G.LL.max_panel = std::max(G.LL.max_panel, N.max_panel);
             G.LL.wv_pn = std::max(G.LL.wv_pn, N.wv_pn);
             G.LL.wv_idx_ints = std::max(G.LL.wv_idx_ints, N.wv_idx_ints);
@@ -2442,6 +2454,12 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   long long scratch;
 };
 
+// a launch the runtime refuses (grid / LDS beyond the limits) is reported with the kernel's name
+#define G2OHIP_LAUNCH_CHECK(name_)                                                                              \
+  do {                                                                                                            \
+    const hipError_t e_ = hipGetLastError();                                                                      \
+    if (e_ != hipSuccess) throw StateFailure(std::string("launch of ") + name_ + " refused: " + hipGetErrorString(e_)); \
+  } while (0)
 template <int BS, bool VIRT>
 void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long long* d_scratch_off, double* d_scratch,
                          const double* dA, int lds_begin, int lds_count, int lds_max_m, int glb_begin, int glb_count,
@@ -2457,6 +2475,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
   } else if (wv) {   // every front of the launch fits the register-resident wave kernel: one wavefront per task
     const size_t sh = ((size_t)kWvTiles * 256 + 64 + 2 * kWvT * 64) * sizeof(double) + (size_t)(8 * 64 + 2 * 16 * kWvT + 2 * 64) * sizeof(int);
     hipLaunchKernelGGL((wave_front_kernel<BS, VIRT>), dim3(lds_count), dim3(64 * kWvWaves), sh, st, wv_plan(P), lds_begin, dA, bperm, yout, dep);
+    G2OHIP_LAUNCH_CHECK("wave_front_kernel");
     return;
   }
   if (sm_count > 0) {   // wide launch: two waves per front
@@ -2464,6 +2483,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(sm_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, true, 128, VIRT>), dim3(sm_count), dim3(128), sh, st, P, lds_begin, dA, d_scratch,
                        d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
+    G2OHIP_LAUNCH_CHECK("front_factor_kernel");
     lds_begin += sm_count;
     lds_count -= sm_count;
   }
@@ -2477,6 +2497,10 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     else
       hipLaunchKernelGGL((front_factor_kernel<BS, true, kFactorThreads, VIRT>), dim3(lds_count), dim3(kFactorThreads), sh, st, P, lds_begin, dA, d_scratch,
                          d_scratch_off + lds_begin, idx_off, wcap, bperm, yout, dep);
+    if (hipPeekAtLastError() != hipSuccess)
+      fprintf(stderr, "g2ohip: LDS front launch: %zu bytes of LDS (blocks %d doubles, vectors %d, index tables %d ints)\n", sh, lds_max_m, wcap,
+              lds_idx_ints);
+    G2OHIP_LAUNCH_CHECK("front_factor_kernel (LDS fronts)");
   }
   if (!(parts & 2)) return;
   if (glb_count > 0 && big.ok) {   // large fronts as whole-GPU passes
@@ -2484,23 +2508,30 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     if (big.ba_count > 0)
       hipLaunchKernelGGL((big_assemble_kernel<BS, VIRT>), dim3(big.ba_count), dim3(256), 0, st, P, big.chunks + big.ba_begin, dA, d_scratch,
                          d_scratch_off);
+    G2OHIP_LAUNCH_CHECK("big_assemble_kernel");
     for (const auto& pass : *big.be_pass)
       if (pass.second > 0)
         hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
                            d_scratch_off);
+    G2OHIP_LAUNCH_CHECK("big_extend_add_kernel");
     hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off);
+    G2OHIP_LAUNCH_CHECK("big_diag_kernel");
     if (big.tr_count > 0)
       hipLaunchKernelGGL((big_trsm_kernel<BS>), dim3(big.tr_count), dim3(256), 0, st, P, big.chunks + big.tr_begin, d_scratch,
                          d_scratch_off);
+    G2OHIP_LAUNCH_CHECK("big_trsm_kernel");
     if (bt_count > 0)
       hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off);
+    G2OHIP_LAUNCH_CHECK("big_front_update_kernel");
   } else if (glb_count > 0) {
     const int idx_off = 2 * (BS * BS + BS);
     size_t sh = (size_t)idx_off * sizeof(double) + (size_t)(glb_idx_ints + 4) * sizeof(int);
     hipLaunchKernelGGL((front_factor_kernel<BS, false, kFactorThreadsGlobal, VIRT>), dim3(glb_count), dim3(kFactorThreadsGlobal), sh, st, P, glb_begin, dA,
                        d_scratch, d_scratch_off + glb_begin, idx_off, 0, (const double*)nullptr, (double*)nullptr, 0);
+    G2OHIP_LAUNCH_CHECK("front_factor_kernel");
     if (bt_count > 0)   // their trailing matrices: one MFMA pass over all of them
       hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off);
+    G2OHIP_LAUNCH_CHECK("big_front_update_kernel");
   }
 }
 
@@ -2564,7 +2595,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
   launch_factor_level<BS_, V_>(fplan, d_level_fronts.p, d_scratch_off.p, d_scratch.p, dA, LL.lds_begin, LL.lds_count, LL.lds_max_m, \
                                LL.glb_begin, LL.glb_count, LL.lds_idx_ints, LL.glb_idx_ints, LL.sm_count, LL.sm_max_m,            \
-                               LL.sm_idx_ints, LL.max_m, fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr,   \
+                               LL.sm_idx_ints, LL.lds_vec_m, fwd ? d_xp.p : (const double*)nullptr, fwd ? d_y.p : (double*)nullptr,   \
                                dep ? 1 : 0, d_big_tiles.p + LL.bt_begin, LL.bt_count, big, opt.wide_front_doubles, LL.wv, LL.wv_pn,   \
                                LL.wv_idx_ints, st, parts)
   switch (bs_) {
@@ -2900,6 +2931,23 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
   int cap = panel ? LL.max_panel : 0;
   int nthreads = LL.max_m <= 64 ? 64 : (LL.max_m <= 128 ? 128 : 256);
   size_t sh = ((size_t)cap + 3 * (size_t)LL.max_m + nthreads + 8) * sizeof(double);
+  if (sh > 64 * 1024) {   // (fronts of several thousand rows: dense couplings, e.g. a landmark seen by hundreds of poses)
+    if (sh > 160 * 1024) throw StateFailure("SparseCholesky: a frontal matrix is too large for the triangular sweeps (more than ~6 500 rows)");
+    static bool attr_done = false;
+    if (!attr_done) {
+#define G2OHIP_SWEEP_ATTR(BS_)                                                                                                 \
+  (void)hipFuncSetAttribute((const void*)front_forward_kernel<BS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+  (void)hipFuncSetAttribute((const void*)front_forward_kernel<BS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void)hipFuncSetAttribute((const void*)front_backward_kernel<BS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void)hipFuncSetAttribute((const void*)front_backward_kernel<BS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+      G2OHIP_SWEEP_ATTR(3);
+      G2OHIP_SWEEP_ATTR(6);
+      G2OHIP_SWEEP_ATTR(7);
+#undef G2OHIP_SWEEP_ATTR
+      (void)hipGetLastError();
+      attr_done = true;
+    }
+  }
 #define G2OHIP_SOLVE_LAUNCH(BS_)                                                                                              \
   if (fwd) {                                                                                                                  \
     if (panel)                                                                                                                \

@@ -114,6 +114,65 @@ def make_ba_problem(P, L, seed=42, spacing=0.5, obs_per_landmark=5, outlier_frac
                 v1=cam_hidx[cam_idx].astype(np.int32))    # vertex 1 = pose (types_six_dof_expmap.h:133)
 
 
+def make_ba_loops(P, L, laps=4, hubs=3, drop=0.2, seed=7, spacing=0.5, f=1000.0, cx=320.0, cy=240.0):
+    """A bundle-adjustment graph that is NOT a band: the camera runs `laps` times back and forth along the same line
+    (poses of different laps stand at the same places and see the same points -- loop closures everywhere, the reduced
+    pose system couples every lap with every other: separators and frontal matrices several times the band case), a
+    fraction `drop` of the observations is missing (ragged observation lists, 2 .. 5 laps long) and `hubs` distant points
+    are seen by every third pose (lists far longer than a wavefront).  Same dictionary as make_ba_problem."""
+    rng = CounterRng(seed)
+    M = max(P // laps, 6)                                   # positions along the line
+    c = np.arange(P, dtype=np.int64)
+    lap = c // M
+    s_c = np.where(lap % 2 == 0, c % M, M - 1 - (c % M))  # position index of pose c
+    pos_of = [np.flatnonzero(s_c == s) for s in range(M)]  # poses standing at position s
+    Lr = L - hubs
+    j = np.arange(Lr, dtype=np.int64)
+    p_j = (j * M) // max(Lr, 1)
+    cam_l, pt_l = [], []
+    keep_u = rng.uniform(30, Lr * 5 * (laps + 1)).reshape(Lr, -1)
+    for jj in range(Lr):
+        obs = np.concatenate([pos_of[s] for s in range(max(p_j[jj] - 2, 0), min(p_j[jj] + 3, M))])
+        obs.sort()
+        k = keep_u[jj, :len(obs)] >= drop
+        if k.sum() < 2:
+            k[:2] = True
+        obs = obs[k]
+        cam_l.append(obs)
+        pt_l.append(np.full(len(obs), jj))
+    for h in range(hubs):
+        obs = np.arange(h, P, 3)
+        cam_l.append(obs)
+        pt_l.append(np.full(len(obs), Lr + h))
+    cam_idx = np.concatenate(cam_l).astype(np.int32)
+    pt_idx = np.concatenate(pt_l).astype(np.int32)
+    E = len(cam_idx)
+    true_pts = np.zeros((L, 3))
+    true_pts[:Lr] = np.stack([p_j * spacing + (rng.uniform(1, Lr) * 2.0 - 1.0), rng.uniform(2, Lr) - 0.5, 3.0 + rng.uniform(3, Lr)], axis=1)
+    for h in range(hubs):
+        true_pts[Lr + h] = [0.5 * M * spacing + 3.0 * (h - hubs / 2.0), 1.0 * h, 60.0 + 5.0 * h]
+    cams_true = np.zeros((P, 12))
+    cams_true[:, 0] = cams_true[:, 4] = cams_true[:, 8] = 1.0
+    cams_true[:, 9] = -s_c * spacing
+    cams_true[:, 10] = -0.03 * lap
+    Xc = true_pts[pt_idx] + cams_true[cam_idx, 9:12]
+    meas = np.stack([Xc[:, 0] / Xc[:, 2] * f + cx, Xc[:, 1] / Xc[:, 2] * f + cy], axis=1)
+    meas[:, 0] += rng.normal(4, E)
+    meas[:, 1] += rng.normal(5, E)
+    pts = true_pts + 0.05 * np.stack([rng.normal(6, L), rng.normal(7, L), rng.normal(8, L)], axis=1)
+    upd = np.zeros((P, 6))
+    upd[:, 0:3] = 0.005 * np.stack([rng.normal(9, P), rng.normal(10, P), rng.normal(11, P)], axis=1)
+    upd[:, 3:6] = 0.01 * np.stack([rng.normal(12, P), rng.normal(13, P), rng.normal(14, P)], axis=1)
+    upd[:2] = 0.0
+    cams = _apply_cam_update(cams_true, upd)
+    cam_hidx = np.arange(P, dtype=np.int32) - 2
+    cam_hidx[:2] = -1
+    nP = P - 2
+    return dict(P=P, L=L, E=E, nP=nP, nL=L, f=f, cx=cx, cy=cy, cams=cams, pts=pts, meas=meas,
+                cam_idx=cam_idx, pt_idx=pt_idx, cam_hidx=cam_hidx,
+                v0=(nP + pt_idx).astype(np.int32), v1=cam_hidx[cam_idx].astype(np.int32))
+
+
 def _apply_cam_update(cams, upd):
     """estimate <- exp(update) * estimate, update = (omega, upsilon)."""
     R, V = _exp_so3(upd[:, 0:3])

@@ -139,6 +139,46 @@ def test_fused_assembly_with_short_and_long_observation_lists(K):
     assert relerr(s.x(), o.x()) < 1e-8
 
 
+@pytest.mark.parametrize("P,L,laps,hubs", [(150, 700, 3, 0), (320, 1500, 5, 0), (320, 1500, 5, 3), (640, 2500, 8, 2)])
+def test_ba_graph_with_loop_closures_and_ragged_lists(P, L, laps, hubs):
+    """Not a band: the camera passes the same places several times (synthetic.make_ba_loops), so the reduced system
+    couples distant poses (frontal matrices of a few hundred rows: the LDS and scratch-slab kernels under the virtual
+    Schur source), observation lists are ragged (2 .. 5 laps) and, with hubs, a few points are seen by more poses than
+    a wavefront has lanes (the tiles then leave the landmark side to the stand-alone kernel).  System, solution and one
+    LM step against the oracle."""
+    from openslam_g2o_amd import capi
+    pr = S.make_ba_loops(P, L, laps=laps, hubs=hubs)
+    Jp, Jc, err = S.ba_linearize(pr)
+    pr.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(pr))
+    o = oracle_ba(pr, huber=2.0)
+    o.build_system()
+    s, g = lm.setup_device_ba(pr, huber_delta=2.0)
+    g.linearize()
+    assert abs(g.chi2() - o.chi2()) <= 1e-10 * o.chi2()
+    s.buildSystem()
+    lam = 1e-4 * o.max_diagonal()
+    s.setLambda(lam, True)
+    o.set_lambda(lam, True)
+    assert s.solve() and o.solve()
+    assert relerr(s.x(), o.x()) < 1e-7
+    x = s.x()
+    assert s.solve() and np.array_equal(s.x(), x)        # bit-repeatable
+    assert relerr(s.values(capi.HSCHUR), o.values("Hschur")) < 1e-11   # (the damped reduced system of this solve)
+    s.restoreDiagonal()
+    o.restore_diagonal()
+    for which, name in ((capi.HPP, "Hpp"), (capi.HPL, "Hpl"), (capi.HLL, "Hll")):
+        assert relerr(s.values(which), o.values(name)) < 1e-11, name
+    assert relerr(s.b(), o.b()) < 1e-12
+    st = s.stats()
+    assert st["maxFrontDim"] > 72                           # (the band case stays at 72)
+    # one LM step on the device
+    chi0 = g.chi2()
+    s.setLambda(lam, True)
+    assert s.solve()
+    g.push(); g.update(); s.restoreDiagonal(); g.compute_active_errors()
+    assert g.chi2() < chi0
+
+
 @pytest.mark.parametrize("K", [1, 2, 5, 11, 23, 70])
 def test_schur_tiles_assemble_their_landmarks(K):
     """Default fused path: build_system launches nothing for the landmark side, the Schur tiles of solve() produce Hll, b_l

@@ -202,6 +202,28 @@ def test_narrow_seam_linear_solver():
     assert st["choleskyNNZ"] > 0 and st["numFronts"] > 0
 
 
+def test_landmark_seen_by_hundreds_of_poses_is_split_over_tiles():
+    """A landmark whose blocks and pair list exceed a tile's LDS budget (here 200+ observations; a tile holds ~64) is cut
+    into chunk-pair tiles with two block ranges each (build_structure).  Generic path: Jacobian arrays over the ABI,
+    Hpl read from memory.  Hschur, Dinv, x against the oracle; the landmark's inverse is written by every one of its
+    tiles (the same bits)."""
+    from openslam_g2o_amd import capi, synthetic as S
+    pr = S.make_ba_loops(640, 900, laps=4, hubs=2)
+    Jp, Jc, err = S.ba_linearize(pr)
+    pr.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(pr))
+    assert np.bincount(pr["pt_idx"]).max() > 200
+    s = hip_ba(pr, huber=1.0)
+    o = oracle_ba(pr, huber=1.0)
+    s.buildSystem()
+    o.build_system()
+    s.setLambda(3.0, True)
+    o.set_lambda(3.0, True)
+    assert s.solve() and o.solve()
+    assert relerr(s.values(capi.HSCHUR), o.values("Hschur")) < 1e-11
+    assert relerr(s.values(capi.DINV), o.values("Dinv")) < 1e-12
+    assert relerr(s.x(), o.x()) < dx_tolerance(o)[0]
+
+
 def test_edge_cases_mixed_sets_fixed_and_unary():
     """Two edge sets (projection edges + 6-dof pose-pose edges), a unary prior set, fixed
     vertices on both sides, a landmark seen once, a pose without landmarks."""
