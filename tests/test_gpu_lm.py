@@ -230,6 +230,21 @@ def test_lm_trajectory_matches_oracle(huber, outliers):
     assert relerr(cams, og.pr["cams"]) < 1e-6 and relerr(pts, og.pr["pts"]) < 1e-6
 
 
+def test_lm_trajectory_on_a_graph_with_loop_closures_matches_oracle():
+    """Levenberg-Marquardt with Huber kernels on the graph that is not a band (loop closures, ragged lists, a hub point
+    seen by more poses than a Schur tile holds): accept / reject decisions, chi2 and lambda against the oracle-driven
+    loop."""
+    pr = S.make_ba_loops(260, 1100, laps=4, hubs=1)
+    s, g = lm.setup_device_ba(pr, huber_delta=1.5)
+    n_gpu, chi_gpu, lam_gpu, tr_gpu = lm.optimize(g, s, 6, "lm")
+    og = OracleBAGraph(pr, 1.5)
+    n_cpu, chi_cpu, lam_cpu, tr_cpu = lm.optimize(og, OracleSolverAdapter(og.o), 6, "lm")
+    assert n_gpu == n_cpu and tr_gpu == tr_cpu
+    assert np.allclose(chi_gpu, chi_cpu, rtol=1e-6, atol=0)
+    assert np.allclose(lam_gpu, lam_cpu, rtol=1e-6, atol=0)
+    assert chi_gpu[-1] < chi_gpu[0]
+
+
 def test_dogleg_trajectory_matches_oracle():
     """OptimizationAlgorithmDogleg restated in lm.py (optimization_algorithm_dogleg.cpp:57-207) over the device-resident
     BA graph against the same driver over the CPU oracle: chi2 trajectory, trust-region radius and step types."""

@@ -25,7 +25,7 @@ def _worker(rank, world, port, P, L, lam, fused, x_exchange, out_dir):
     try:
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
-        pr = ba_case(P, L)
+        pr = _case(P, L)
         s = D.ShardedBlockSolver(6, 3, rank=rank, world=world, comm=D.HostStagedComm(world), mode="subtree", x_exchange=x_exchange)
         info = s.setup_ba(pr, torch_device=dev, fused=fused)
         chis, xs = [], []
@@ -47,6 +47,17 @@ def _worker(rank, world, port, P, L, lam, fused, x_exchange, out_dir):
                  volume=s.exchange_volume(), E_local=info["E_local"])
     finally:
         dist.destroy_process_group()
+
+
+def _case(P, L):
+    """L < 0: the graph with loop closures, ragged lists and a hub point (synthetic.make_ba_loops) instead of the band."""
+    if L > 0:
+        return ba_case(P, L)
+    from openslam_g2o_amd import synthetic as S
+    pr = S.make_ba_loops(P, -L, laps=4, hubs=1)
+    Jp, Jc, err = S.ba_linearize(pr)
+    pr.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(pr))
+    return pr
 
 
 def _free_port():
@@ -87,6 +98,36 @@ def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused, x_exch
         assert int(z["boundary"]) < 0.25 * int(z["nnzb"])                     # most Schur blocks never leave their rank
         edges += int(z["E_local"])
     assert (seen == 1).all() and edges == pr["E"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_subtree_distributed_solve_on_a_graph_with_loop_closures(tmp_path, world):
+    """The same sharded solve on a graph that is not a band: the elimination tree has a dense top (most of it shared), the
+    subtrees are uneven, a hub point couples a third of the poses.  Only correctness is asserted."""
+    import torch.multiprocessing as mp
+    P, L, lam = 420, -1600, 30.0
+    mp.spawn(_worker, args=(world, _free_port(), P, L, lam, True, "halo", str(tmp_path)), nprocs=world, join=True)
+    pr = _case(P, L)
+    o = oracle_ba(pr)
+    o.build_system()
+    chi2 = o.chi2()
+    o.set_lambda(lam, True)
+    assert o.solve()
+    x = o.x()
+    nP = pr["nP"]
+    xp, xl = x[:6 * nP], x[6 * nP:].reshape(-1, 3)
+    seen = np.zeros(pr["nL"], int)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        assert bool(z["ok"])
+        assert abs(float(z["chi2"]) - chi2) <= 1e-9 * chi2
+        assert np.abs(z["xp"] - xp).max() <= 1e-7 * np.abs(xp).max()
+        v = np.repeat(z["valid"], 6)
+        assert np.abs(z["xloc"][v] - xp[v]).max() <= 1e-7 * np.abs(xp).max()
+        idx = z["lm_index"]
+        seen[idx] += 1
+        assert np.abs(z["xl"].reshape(-1, 3) - xl[idx]).max() <= 1e-7 * np.abs(xl).max()
+    assert (seen == 1).all()
 
 
 def _pcg_worker(rank, world, port, P, L, lam, out_dir):
