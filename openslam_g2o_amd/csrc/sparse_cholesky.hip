@@ -1430,7 +1430,17 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
             if (nn[u] > 2) {
               const int* sv = s_v + sv3[u];
               v -= P.vparts[(size_t)sv[3] * BB + pe[u]];
-              for (int k = sv[4] + 3; k < sv[4] + nn[u]; ++k) v -= P.vparts[(size_t)P.vslots[k] * BB + pe[u]];
+              for (int k = sv[4] + 3, kend = sv[4] + nn[u]; k < kend; k += 8) {   // (long lists: eight partials per round trip, list order kept)
+                int sl[8];
+                double pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sl[j] = P.vslots[min(k + j, kend - 1)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = P.vparts[(size_t)sl[j] * BB + pe[u]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                  if (k + j < kend) v -= pv[j];
+              }
             }
             F[dst[u]] = v;
           }
@@ -1905,7 +1915,19 @@ __global__ void __launch_bounds__(256) big_assemble_kernel(CholPlanDev P, const 
         double x = q[u] >= 0 ? P.vbase[(size_t)q[u] * BB + rr + BS * cc] : 0.0;
         if (pos[u] < 0 && rr == cc) x += lam0;
         for (int k = 0; k < n && k < 3; ++k) x -= P.vparts[(size_t)sv[1 + k] * BB + pe];
-        for (int k = sv[4] + 3; k < sv[4] + n; ++k) x -= P.vparts[(size_t)P.vslots[k] * BB + pe];
+        // long lists (a pose pair sharing landmarks of many tiles: graphs with loop closures): slot ids, then values, eight
+        // at a time -- one dependent round trip per eight partials instead of two per partial; subtracted in list order
+        for (int k = sv[4] + 3, kend = sv[4] + n; k < kend; k += 8) {
+          int sl[8];
+          double pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sl[j] = P.vslots[min(k + j, kend - 1)];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = P.vparts[(size_t)sl[j] * BB + pe];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (k + j < kend) x -= pv[j];
+        }
         v[u] = x;
       } else {
         v[u] = A[(size_t)q[u] * BB + rr + BS * cc];
@@ -2454,6 +2476,13 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   long long scratch;
 };
 
+__global__ void __launch_bounds__(256) fill_zero_kernel(double* __restrict__ p, size_t n) {
+  const size_t n2 = n / 2, stride = (size_t)gridDim.x * blockDim.x;
+  double2* p2 = reinterpret_cast<double2*>(p);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += stride) p2[i] = make_double2(0.0, 0.0);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
+}
+
 // a launch the runtime refuses (grid / LDS beyond the limits) is reported with the kernel's name
 #define G2OHIP_LAUNCH_CHECK(name_)                                                                              \
   do {                                                                                                            \
@@ -2504,7 +2533,12 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
   }
   if (!(parts & 2)) return;
   if (glb_count > 0 && big.ok) {   // large fronts as whole-GPU passes
-    G2OHIP_HIP_CHECK(hipMemsetAsync(d_scratch, 0, (size_t)big.scratch * sizeof(double), st));
+    {   // zero the slab (a fill kernel: hipMemsetAsync reaches ~1 TB/s, the slab of a wide level is 100 MB and more)
+      const size_t n2 = ((size_t)big.scratch + 1) / 2;
+      const int blocks = (int)std::min<size_t>((n2 + 256 * 8 - 1) / (256 * 8), 65535 * 4);
+      hipLaunchKernelGGL(fill_zero_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, d_scratch, (size_t)big.scratch);
+      G2OHIP_LAUNCH_CHECK("fill_zero_kernel");
+    }
     if (big.ba_count > 0)
       hipLaunchKernelGGL((big_assemble_kernel<BS, VIRT>), dim3(big.ba_count), dim3(256), 0, st, P, big.chunks + big.ba_begin, dA, d_scratch,
                          d_scratch_off);
