@@ -211,6 +211,7 @@ class SparseCholesky {
   DevBuf<ChildDesc> d_cdesc;
   DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts;
   DevBuf<double> d_L, d_U, d_w, d_y, d_xp, d_scratch;
+  DevBuf<double> d_sweep_vec;   // vectors of the triangular sweeps of fronts too large for LDS
   // per level launch info
   struct LevelLaunch {
     int lds_begin = 0, lds_count = 0, lds_max_m = 0;     // index range in d_level_fronts

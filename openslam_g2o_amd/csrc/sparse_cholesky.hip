@@ -2186,13 +2186,15 @@ __global__ void permute_out_kernel(int nb, int bs, const int* __restrict__ perm,
 template <int BS, bool PANEL_LDS>
 __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, int slot0,
                                                            const double* __restrict__ bperm, double* __restrict__ y, int panel_cap,
-                                                           int mcap) {
+                                                           int mcap, double* gvec) {
+  // gvec != nullptr: the three vectors of a front live in HBM (3 * mcap doubles per workgroup) instead of LDS -- frontal
+  // matrices of more than ~6 500 rows (dense reduced systems); the barriers order the accesses as they order LDS.
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int2 slot = P.slots[slot0 + blockIdx.x];
   const int f_first = __builtin_amdgcn_readfirstlane(slot.x), t0 = 0, t1 = __builtin_amdgcn_readfirstlane(slot.y);
   const int tid = threadIdx.x, NT = blockDim.x;
   double* Lp = smem;
-  double* t = smem + (PANEL_LDS ? panel_cap : 0);
+  double* t = gvec ? gvec + (size_t)blockIdx.x * 3 * mcap : smem + (PANEL_LDS ? panel_cap : 0);
   double* ys = t + mcap;
   double* wprev = ys + mcap;
   int nprev = 0;
@@ -2310,7 +2312,7 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, int s
 template <int BS, bool PANEL_LDS>
 __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int slot0,
                                                             const double* __restrict__ y, double* __restrict__ xp, int panel_cap,
-                                                            int mcap, int dep) {
+                                                            int mcap, int dep, double* gvec) {
   // dep != 0: dependency-driven launch over several levels, parents in front of their children; the top front of
   // a task waits for the parent front's counter, the bottom front releases its children (see the factor kernel).
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -2318,10 +2320,10 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int 
   const int f_first = __builtin_amdgcn_readfirstlane(slot.x), t0 = 0, t1 = __builtin_amdgcn_readfirstlane(slot.y);
   const int tid = threadIdx.x, NT = blockDim.x;
   double* Lp = smem;
-  double* t = smem + (PANEL_LDS ? panel_cap : 0);
+  double* t = gvec ? gvec + (size_t)blockIdx.x * 3 * mcap : smem + (PANEL_LDS ? panel_cap : 0);   // (gvec: see front_forward_kernel)
   double* xs = t + mcap;
-  double* sp = xs + mcap;
-  double* fullprev = sp + NT;
+  double* sp = gvec ? smem + (PANEL_LDS ? panel_cap : 0) : xs + mcap;
+  double* fullprev = gvec ? xs + mcap : sp + NT;
   const int* prel = nullptr;   // this front's relative indices inside its chain parent
   for (int ti = t1 - 1; ti >= t0; --ti) {
     const int f = f_first + ti;
@@ -2965,8 +2967,14 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
   int cap = panel ? LL.max_panel : 0;
   int nthreads = LL.max_m <= 64 ? 64 : (LL.max_m <= 128 ? 128 : 256);
   size_t sh = ((size_t)cap + 3 * (size_t)LL.max_m + nthreads + 8) * sizeof(double);
+  double* gvec = nullptr;
+  if (sh > 160 * 1024) {   // vectors of the fronts in HBM (dense reduced systems: fronts beyond ~6 500 rows)
+    const size_t need = (size_t)count * 3 * (size_t)LL.max_m;
+    if (d_sweep_vec.n < need) d_sweep_vec.alloc(need);
+    gvec = d_sweep_vec.p;
+    sh = ((size_t)cap + nthreads + 8) * sizeof(double);
+  }
   if (sh > 64 * 1024) {   // (fronts of several thousand rows: dense couplings, e.g. a landmark seen by hundreds of poses)
-    if (sh > 160 * 1024) throw StateFailure("SparseCholesky: a frontal matrix is too large for the triangular sweeps (more than ~6 500 rows)");
     static bool attr_done = false;
     if (!attr_done) {
 #define G2OHIP_SWEEP_ATTR(BS_)                                                                                                 \
@@ -2985,14 +2993,14 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
 #define G2OHIP_SOLVE_LAUNCH(BS_)                                                                                              \
   if (fwd) {                                                                                                                  \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m);  \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m, gvec);  \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m); \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m, gvec); \
   } else {                                                                                                                    \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, LL.max_m, depi); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, LL.max_m, depi, gvec); \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, LL.max_m, depi); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, LL.max_m, depi, gvec); \
   }
   switch (bs_) {
     case 3: G2OHIP_SOLVE_LAUNCH(3) break;

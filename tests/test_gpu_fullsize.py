@@ -87,3 +87,27 @@ def test_fill_against_reference_amd_at_test_sizes():
         assert ref["block_columns"] == pr["nP"]
         nnz = s.stats()["choleskyNNZ"]
         assert ref["lnz_block_amd"] <= nnz <= FILL_BOUND * ref["lnz_block_amd"], (P, nnz, ref)
+
+
+def test_dense_reduced_system_with_a_front_beyond_the_lds_limit():
+    """A hub point seen by 1 200 poses couples them all: the reduced system has a dense 7 200-row frontal matrix -- beyond
+    what the triangular sweeps hold in LDS (their vectors go to HBM) and far beyond one Schur tile (the hub is split into
+    chunk-pair tiles).  Size-independent properties: residual of the damped system, repeatability, an LM step."""
+    pr = S.make_ba_loops(3600, 9000, laps=4, hubs=1)
+    s, g = lm.setup_device_ba(pr, huber_delta=1.0)
+    g.linearize()
+    chi0 = g.chi2()
+    s.buildSystem()
+    lam = 1e-4 * s.maxDiagonal()
+    s.setLambda(lam, True)
+    assert s.solve()
+    x, b = s.x(), s.b()
+    r = s.multiplyHessian(x) - b
+    assert np.abs(r).max() <= 1e-10 * np.abs(b).max()
+    assert s.stats()["maxFrontDim"] > 6600
+    assert s.solve() and np.array_equal(s.x(), x)
+    g.push()
+    g.update()
+    s.restoreDiagonal()
+    g.compute_active_errors()
+    assert g.chi2() < chi0
