@@ -2183,18 +2183,19 @@ __global__ void permute_out_kernel(int nb, int bs, const int* __restrict__ perm,
 // reads, reciprocal diagonal), then the rows below are updated in parallel -> one barrier per pivot
 // block.  Inside a chain the update vector w stays in LDS.
 // LDS: [panel (optional)] [t: mcap] [ys: mcap] [wprev: mcap]
-template <int BS, bool PANEL_LDS>
+template <int BS, bool PANEL_LDS, bool GVEC = false>
 __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, int slot0,
                                                            const double* __restrict__ bperm, double* __restrict__ y, int panel_cap,
                                                            int mcap, double* gvec) {
-  // gvec != nullptr: the three vectors of a front live in HBM (3 * mcap doubles per workgroup) instead of LDS -- frontal
+  // GVEC: the three vectors of a front live in HBM (gvec) (3 * mcap doubles per workgroup) instead of LDS -- frontal
   // matrices of more than ~6 500 rows (dense reduced systems); the barriers order the accesses as they order LDS.
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int2 slot = P.slots[slot0 + blockIdx.x];
   const int f_first = __builtin_amdgcn_readfirstlane(slot.x), t0 = 0, t1 = __builtin_amdgcn_readfirstlane(slot.y);
   const int tid = threadIdx.x, NT = blockDim.x;
   double* Lp = smem;
-  double* t = gvec ? gvec + (size_t)blockIdx.x * 3 * mcap : smem + (PANEL_LDS ? panel_cap : 0);
+  // (a compile-time choice: a run-time one would turn every access of the LDS variant into a flat access)
+  double* t = GVEC ? gvec + (size_t)blockIdx.x * 3 * mcap : smem + (PANEL_LDS ? panel_cap : 0);
   double* ys = t + mcap;
   double* wprev = ys + mcap;
   int nprev = 0;
@@ -2309,7 +2310,7 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, int s
 // Backward sweep over one task (chain top first): x1 = L11' \ (y1 - L21' x_boundary); same blocking.
 // Inside a chain the child's boundary values are taken from the parent's vector kept in LDS.
 // LDS: [panel (optional)] [t: mcap] [xs: mcap] [sp: NT] [fullprev: mcap]
-template <int BS, bool PANEL_LDS>
+template <int BS, bool PANEL_LDS, bool GVEC = false>
 __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int slot0,
                                                             const double* __restrict__ y, double* __restrict__ xp, int panel_cap,
                                                             int mcap, int dep, double* gvec) {
@@ -2320,10 +2321,10 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int 
   const int f_first = __builtin_amdgcn_readfirstlane(slot.x), t0 = 0, t1 = __builtin_amdgcn_readfirstlane(slot.y);
   const int tid = threadIdx.x, NT = blockDim.x;
   double* Lp = smem;
-  double* t = gvec ? gvec + (size_t)blockIdx.x * 3 * mcap : smem + (PANEL_LDS ? panel_cap : 0);   // (gvec: see front_forward_kernel)
+  double* t = GVEC ? gvec + (size_t)blockIdx.x * 3 * mcap : smem + (PANEL_LDS ? panel_cap : 0);   // (GVEC: see front_forward_kernel)
   double* xs = t + mcap;
-  double* sp = gvec ? smem + (PANEL_LDS ? panel_cap : 0) : xs + mcap;
-  double* fullprev = gvec ? xs + mcap : sp + NT;
+  double* sp = GVEC ? smem + (PANEL_LDS ? panel_cap : 0) : xs + mcap;
+  double* fullprev = GVEC ? xs + mcap : sp + NT;
   const int* prel = nullptr;   // this front's relative indices inside its chain parent
   for (int ti = t1 - 1; ti >= t0; --ti) {
     const int f = f_first + ti;
@@ -2972,7 +2973,8 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
     const size_t need = (size_t)count * 3 * (size_t)LL.max_m;
     if (d_sweep_vec.n < need) d_sweep_vec.alloc(need);
     gvec = d_sweep_vec.p;
-    sh = ((size_t)cap + nthreads + 8) * sizeof(double);
+    cap = 0;
+    sh = ((size_t)nthreads + 8) * sizeof(double);
   }
   if (sh > 64 * 1024) {   // (fronts of several thousand rows: dense couplings, e.g. a landmark seen by hundreds of poses)
     static bool attr_done = false;
@@ -2991,7 +2993,12 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
     }
   }
 #define G2OHIP_SOLVE_LAUNCH(BS_)                                                                                              \
-  if (fwd) {                                                                                                                  \
+  if (gvec) {   /* (fronts beyond the LDS limit: never with a staged panel) */                                                \
+    if (fwd)                                                                                                                  \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, false, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, 0, LL.max_m, gvec); \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, false, true>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, 0, LL.max_m, depi, gvec); \
+  } else if (fwd) {                                                                                                           \
     if (panel)                                                                                                                \
       hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m, gvec);  \
     else                                                                                                                      \
