@@ -227,6 +227,7 @@ class BlockSolver {
   bool ba_skip_hpl = true;            // fused BA path: Hpl is not written at all while nobody reads it (ensure_hpl)
   bool ba_fuse_landmarks = true;      // ... and the landmark side (Hll, b_l, errors) is assembled by the Schur tiles of the solve
   bool ba_recompute_backsub = true;   // fused BA path: back-substitution from the Jacobians instead of reading Hpl
+  double fuse_reduce_max_partials = 6.0;   // solve() folds the Schur reduction into the factorisation only while a block of the reduced system has at most this many partial blocks on average
   bool marginals_recursion = true;  // compute_marginals: all entries on the pattern of L in one top-down pass (sparse inverse) instead of one pair of sweeps per column
   bool marginals_reduced = false;   // compute_marginals: invert the reduced pose system instead of Hpp alone (the reference inverts Hpp)
  private:

@@ -463,6 +463,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "fuse_schur_reduce")) s->impl->fuse_schur_reduce = value != 0;
   else if (!std::strcmp(name, "marginals_reduced")) s->impl->marginals_reduced = value != 0;
   else if (!std::strcmp(name, "marginals_recursion")) s->impl->marginals_recursion = value != 0;
+  else if (!std::strcmp(name, "fuse_reduce_max_partials")) s->impl->fuse_reduce_max_partials = value;
   else if (!std::strcmp(name, "ba_recompute_backsub")) s->impl->ba_recompute_backsub = value != 0;
   else if (!std::strcmp(name, "ba_skip_hpl")) s->impl->ba_skip_hpl = value != 0;
   else if (!std::strcmp(name, "ba_fuse_landmarks")) s->impl->ba_fuse_landmarks = value != 0;

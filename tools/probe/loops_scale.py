@@ -11,6 +11,9 @@ pr = S.make_ba_loops(P, L, laps=laps, hubs=int(os.environ.get("HUBS", "0")))
 t1 = time.perf_counter()
 s, g = lm.setup_device_ba(pr, huber_delta=1.0)
 s.setOption("use_graph", float(os.environ.get("USE_GRAPH", "1")))
+for kv in os.environ.get("OPTS", "").split():
+    k, v = kv.split("=")
+    s.setOption(k, float(v))
 t2 = time.perf_counter()
 g.linearize(); chi0 = g.chi2()
 s.buildSystem()
