@@ -661,11 +661,32 @@ __global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const 
   if (n > 0) v -= p0;
   if (n > 1) v -= p1;
   if (n > 2) v -= p2;
-  for (int k = k0 + 3; k < k1; ++k) v -= Pd[(size_t)rd_slot[k] * BB + pe];
+  // long lists (loop closures: a pose pair shares landmarks of many tiles): eight partials per pair of round trips
+  for (int k = k0 + 3; k < k1; k += 8) {
+    int sl[8];
+    double pv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sl[j] = rd_slot[min(k + j, k1 - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pv[j] = Pd[(size_t)sl[j] * BB + pe];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (k + j < k1) v -= pv[j];
+  }
   Hs[t] = v;
   if (pose >= 0 && e < PD) {
     double r = b[(size_t)pose * PD + e];
-    for (int k = k0; k < k1; ++k) r -= Pr[(size_t)rd_slot[k] * PD + e];
+    for (int k = k0; k < k1; k += 8) {
+      int sl[8];
+      double pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sl[j] = rd_slot[min(k + j, k1 - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = Pr[(size_t)sl[j] * PD + e];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k + j < k1) r -= pv[j];
+    }
     bschur[(size_t)pose * PD + e] = r;
   }
 }
@@ -681,7 +702,17 @@ __global__ void __launch_bounds__(kThreads) schur_rhs_kernel(int nP, const int* 
   const int pose = t / PD, e = t - pose * PD;
   const int d = pose_diag[pose];
   double r = b[t];
-  for (int k = rd_ptr[d]; k < rd_ptr[d + 1]; ++k) r -= Pr[(size_t)rd_slot[k] * PD + e];
+  for (int k = rd_ptr[d], k1 = rd_ptr[d + 1]; k < k1; k += 8) {   // (eight partials per pair of round trips, list order kept)
+    int sl[8];
+    double pv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sl[j] = rd_slot[min(k + j, k1 - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pv[j] = Pr[(size_t)sl[j] * PD + e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (k + j < k1) r -= pv[j];
+  }
   bschur[t] = r;
 }
 
