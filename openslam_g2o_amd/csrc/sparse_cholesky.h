@@ -45,6 +45,7 @@ struct CholOptions {
   int dep_delay = 0;                     // launch-order distance between a task and its parent inside a wide dependency-driven launch
   int wave_front_tasks = 1024;           // launches at least this wide use two waves (128 threads) per front
   size_t wave_front_bytes = 0;           // (unused)
+  int inplace_chains = 1;                // chains of scratch-slab fronts with identical rows (panels of one large supernode) are factorised in place
   int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
@@ -197,6 +198,7 @@ class SparseCholesky {
   DevBuf<int> d_f_ns, d_f_nb, d_f_c0, d_rows_off, d_rows, d_rel_off, d_rel, d_asm_off, d_asm_q, d_asm_pos,
       d_child_off, d_children, d_level_fronts, d_perm, d_status;
   DevBuf<long long> d_L_off, d_U_off, d_w_off, d_scratch_off;
+  DevBuf<int> d_scratch_ld;   // leading dimension of a scratch-slab front (that of the chain's first front)
   // sparse inverse: slab of the inverse fronts, per-front offsets / parents, per front level the launch lists
   DevBuf<double> d_Z;
   DevBuf<long long> d_zoff;
@@ -218,6 +220,7 @@ class SparseCholesky {
     int glb_begin = 0, glb_count = 0, glb_max_m = 0;
     int max_panel = 0;                                   // max m*npiv (doubles) for solve kernels
     int max_m = 0;
+    int fz_begin = 0, fz_count = 0;                      // zero-fill chunks of the scratch-slab fronts that start a region at this level
     int lds_vec_m = 0;                                   // largest front dimension among the LDS / register fronts only (their vectors in LDS)
     int lds_idx_ints = 0, glb_idx_ints = 0;              // staged index lists (ints) per front, max over the launch
     bool fuse_fwd = true;                                // every LDS front of the launch is within the fused forward sweep's limits

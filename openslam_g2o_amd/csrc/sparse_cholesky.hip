@@ -737,9 +737,99 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       fprintf(stderr, "\n");
     }
   }
+  // --- scratch-slab fronts: where each one lives, and CHAINS factorised in place.
+  // A large supernode is cut into panels of <= max_sn_scalars pivot columns: a chain of fronts, each the only child of
+  // the next, the parent's rows being exactly the child's boundary rows.  Such a parent is factorised IN PLACE in the
+  // trailing part of its child's frontal matrix: the child's rank-npiv update writes there instead of a packed update
+  // matrix, the parent adds its original blocks, and neither the zero fill, nor the extend-add, nor the O(m^2) update
+  // matrix per panel exist (a dense m-row supernode used to cost m^3 / (6 * 48) doubles of update matrices).
+  // Every front that is not such a parent owns a region of the slab for good (no reuse across levels: a chain keeps
+  // its region over several levels).
+  std::vector<int> scratch_ld(scratch_off.size(), 0), inpl_prev(nf, -1), inpl_next(nf, -1);
+  {
+    std::vector<int> slot_of(nf, -1), lvl_of(nf, -1), ph_of(nf, -1);
+    auto level_big = [&](const LevelLaunch& LL) {
+      if (LL.glb_count <= 0 || !opt.big_front_passes || LL.glb_max_m < opt.big_front_min_dim) return false;
+      for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+        const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+        if (S.f_ns[f] * bs > 64 || S.child_off[f + 1] - S.child_off[f] > 16) return false;
+      }
+      return true;
+    };
+    std::vector<std::vector<char>> bigl(2, std::vector<char>(nlev, 0));
+    for (int ph = 0; ph < 2; ++ph)
+      for (int l = 0; l < nlev; ++l) {
+        const LevelLaunch& LL = launches_[ph][l];
+        bigl[ph][l] = level_big(LL) ? 1 : 0;
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          slot_of[f] = q;
+          lvl_of[f] = l;
+          ph_of[f] = ph;
+        }
+      }
+    if (opt.inplace_chains && opt.world == 1)
+      for (int f = 0; f < nf; ++f) {
+        if (slot_of[f] < 0 || S.child_off[f + 1] - S.child_off[f] != 1) continue;
+        const int c = S.children[S.child_off[f]];
+        if (slot_of[c] < 0 || ph_of[c] != ph_of[f] || lvl_of[c] + 1 != lvl_of[f]) continue;
+        if (!bigl[ph_of[f]][lvl_of[f]] || !bigl[ph_of[c]][lvl_of[c]]) continue;
+        if (S.f_ns[f] + S.f_nb[f] != S.f_nb[c]) continue;
+        bool ident = true;
+        for (int k = 0; k < S.f_nb[c] && ident; ++k) ident = S.rel[S.rel_off[c] + k] == k;
+        if (!ident) continue;
+        inpl_prev[f] = c;
+        inpl_next[c] = f;
+      }
+    long long total = 0;
+    for (int ph = 0; ph < 2; ++ph)
+      for (int l = 0; l < nlev; ++l) {   // (levels ascending: a child's region is placed before its in-place parent)
+        LevelLaunch& LL = launches_[ph][l];
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          const long long m = (long long)front_dim(f);
+          if (inpl_prev[f] >= 0) {
+            const int c = inpl_prev[f], qc = slot_of[c];
+            scratch_ld[q] = scratch_ld[qc];
+            scratch_off[q] = scratch_off[qc] + (long long)S.f_ns[c] * bs * (scratch_ld[qc] + 1);
+          } else {
+            scratch_ld[q] = (int)m;
+            scratch_off[q] = total;
+            total += m * m;
+          }
+        }
+      }
+    scratch_max = std::max<long long>(total, 1);
+    if (getenv("G2OHIP_PLAN_DUMP")) {
+      int nglb = 0, nmem = 0, single = 0, rows_ne = 0, not_ident = 0;
+      for (int f = 0; f < nf; ++f) {
+        if (slot_of[f] < 0) continue;
+        ++nglb;
+        if (inpl_prev[f] >= 0) { ++nmem; continue; }
+        if (S.child_off[f + 1] - S.child_off[f] != 1) continue;
+        ++single;
+        const int c = S.children[S.child_off[f]];
+        if (S.f_ns[f] + S.f_nb[f] != S.f_nb[c]) ++rows_ne; else ++not_ident;
+      }
+      fprintf(stderr, "scratch-slab fronts %d, continued in place %d; single-child but not in place %d (rows differ %d, other %d); slab %.1f MB\n", nglb, nmem,
+              single, rows_ne, not_ident, total * 8e-6);
+    }
+    // update matrices: none for a front whose parent continues in place
+    bool any = false;
+    for (int f = 0; f < nf; ++f) any = any || inpl_next[f] >= 0;
+    if (any) {
+      S.U_total = 0;
+      for (int f = 0; f < nf; ++f) {
+        S.U_off[f] = S.U_total;
+        if (inpl_next[f] < 0) S.U_total += (long long)S.f_nb[f] * (S.f_nb[f] + 1) / 2 * bs * bs;
+      }
+      stats_.bytes_U = (size_t)S.U_total * 8;
+    }
+  }
   if (S.level_fronts.empty()) {
     S.level_fronts.push_back(0);
     scratch_off.push_back(0);
+    scratch_ld.push_back(0);
   }
   // --- packed per-front records and per-parent extend-add descriptors
   std::vector<FrontRec> recs(nf);
@@ -830,9 +920,18 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
           const int nt64 = (S.f_nb[f] * bs + 63) / 64;
           for (int ti = 0; ti < nt64; ++ti)
-            for (int tj = 0; tj <= ti; ++tj) bt.push_back(make_int4(q, ti, tj, 0));
+            for (int tj = 0; tj <= ti; ++tj) bt.push_back(make_int4(q, ti, tj, inpl_next[f] >= 0 ? 1 : 0));   // w: update in place
         }
         LL.bt_count = (int)bt.size() - LL.bt_begin;
+        // zero-fill chunks (32 Ki doubles each) of the fronts that start a region at this level
+        LL.fz_begin = (int)bt.size();
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          if (inpl_prev[f] >= 0) continue;
+          const long long mm = (long long)front_dim(f) * (long long)front_dim(f);
+          for (long long c0 = 0; c0 < mm; c0 += 32768) bt.push_back(make_int4(q, (int)(c0 / 32768), (int)std::min<long long>(32768, mm - c0), 0));
+        }
+        LL.fz_count = (int)bt.size() - LL.fz_begin;
         // assembly chunks (32 original blocks each)
         LL.ba_begin = (int)bt.size();
         LL.big_ok = LL.glb_count > 0;
@@ -841,7 +940,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
           if (S.f_ns[f] * bs > 64) LL.big_ok = false;
           const int na = S.asm_off[f + 1] - S.asm_off[f];
-          for (int e = 0; e < na; e += 32) bt.push_back(make_int4(q, e, std::min(32, na - e), 0));
+          for (int e = 0; e < na; e += 32) bt.push_back(make_int4(q, e, std::min(32, na - e), inpl_prev[f] >= 0 ? 1 : 0));   // w: add to what is there
           max_children = std::max(max_children, S.child_off[f + 1] - S.child_off[f]);
         }
         LL.ba_count = (int)bt.size() - LL.ba_begin;
@@ -852,7 +951,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           const int b0 = (int)bt.size();
           for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
             const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
-            if (S.child_off[f] + c >= S.child_off[f + 1]) continue;
+            if (S.child_off[f] + c >= S.child_off[f + 1] || inpl_prev[f] >= 0) continue;   // (in place: the child's update is there)
             const int nbc = S.f_nb[S.children[S.child_off[f] + c]];
             const int nblk = nbc * (nbc + 1) / 2;
             for (int b = 0; b < nblk; b += 64) bt.push_back(make_int4(q, c, b, std::min(64, nblk - b)));
@@ -1062,6 +1161,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_U_off.upload(S.U_off, st);
   d_w_off.upload(S.w_off, st);
   d_scratch_off.upload(scratch_off, st);
+  d_scratch_ld.upload(scratch_ld, st);
   d_L.alloc((size_t)S.L_total);
   d_U.alloc((size_t)S.U_total);
   d_w.alloc((size_t)S.w_total);
@@ -1880,12 +1980,13 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
 // triangle) lives in the level's scratch slab.
 template <int BS, bool VIRT>
 __global__ void __launch_bounds__(256) big_assemble_kernel(CholPlanDev P, const int4* __restrict__ chunks, const double* __restrict__ A,
-                                                          double* __restrict__ scratch, const long long* __restrict__ scratch_off) {
+                                                          double* __restrict__ scratch, const long long* __restrict__ scratch_off,
+                                                          const int* __restrict__ scratch_ld) {
   constexpr int BB = BS * BS, HB = BS / 2;
-  const int4 ck = chunks[blockIdx.x];   // x: launch slot, y: first original block of the chunk, z: blocks
+  const int4 ck = chunks[blockIdx.x];   // x: launch slot, y: first original block of the chunk, z: blocks, w: add (front continued in place)
   const int f = P.slots[ck.x].x;
   const FrontRec rec = load_front_rec(P.rec + f);
-  const int m = (rec.ns + rec.nb) * BS;
+  const int m = scratch_ld[ck.x];   // leading dimension of the front in the slab
   double* F = scratch + scratch_off[ck.x];
   const double lam0 = VIRT ? P.vlam[0] : 0.0;
   const bool vsplit = VIRT && P.vsplit != 0;
@@ -1934,10 +2035,24 @@ __global__ void __launch_bounds__(256) big_assemble_kernel(CholPlanDev P, const 
       }
       dst[u] = (size_t)(lr * BS + r) + (size_t)m * (lc * BS + c);
     }
+    if (ck.w) {   // in place behind the child's update: add
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (base + u * 256 < nel) F[dst[u]] = v[u];
+      for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < nel) F[dst[u]] += v[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < nel) F[dst[u]] = v[u];
+    }
   }
+}
+
+// zero the regions of the fronts that start one at this level (x: launch slot, y: chunk of 32 Ki doubles, z: doubles)
+__global__ void __launch_bounds__(256) big_fill_kernel(const int4* __restrict__ chunks, double* __restrict__ scratch,
+                                                      const long long* __restrict__ scratch_off) {
+  const int4 ck = chunks[blockIdx.x];
+  double* p = scratch + scratch_off[ck.x] + (size_t)ck.y * 32768;
+  for (int i = threadIdx.x; i < ck.z; i += 256) p[i] = 0.0;
 }
 
 template <int BS>
@@ -1982,17 +2097,18 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 }
 template <int BS>
 __global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, double* __restrict__ scratch,
-                                                     const long long* __restrict__ scratch_off) {
+                                                     const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
   constexpr int MAXB = 64 / BS, N = MAXB * BS;
   const int slot = slot0 + blockIdx.x, lane = threadIdx.x;
   const int f = P.slots[slot].x;
   const FrontRec rec = load_front_rec(P.rec + f);
   const int ns = rec.ns, m = (rec.ns + rec.nb) * BS, n = ns * BS;
+  const int ld = scratch_ld[slot];   // leading dimension in the slab (>= m: a front continued in place sits inside its chain's first front)
   double* F = scratch + scratch_off[slot];
   double* Lg = P.L + rec.L_off;
   double r[N];
 #pragma unroll
-  for (int c = 0; c < N; ++c) r[c] = (c < n && lane < n && lane >= c) ? F[(size_t)lane + (size_t)m * c] : 0.0;
+  for (int c = 0; c < N; ++c) r[c] = (c < n && lane < n && lane >= c) ? F[(size_t)lane + (size_t)ld * c] : 0.0;
   bool bad = false;
 #pragma unroll
   for (int jb = 0; jb < MAXB; ++jb) {
@@ -2026,7 +2142,7 @@ __global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, 
 #pragma unroll
     for (int c = 0; c < N; ++c)
       if (c < n) {
-        F[(size_t)lane + (size_t)m * c] = r[c];
+        F[(size_t)lane + (size_t)ld * c] = r[c];
         Lg[(size_t)lane + (size_t)m * c] = r[c];
       }
   }
@@ -2035,7 +2151,7 @@ __global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, 
 // panel rows below the pivot block: x L11' = row, one thread per row, the row in registers
 template <int BS>
 __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4* __restrict__ chunks, double* __restrict__ scratch,
-                                                      const long long* __restrict__ scratch_off) {
+                                                      const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
   __shared__ double S[64 * 65];
   __shared__ double inv[64];
   constexpr int MAXB = 64 / BS;
@@ -2043,6 +2159,7 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4
   const int f = P.slots[ck.x].x;
   const FrontRec rec = load_front_rec(P.rec + f);
   const int ns = rec.ns, m = (rec.ns + rec.nb) * BS, n = ns * BS;
+  const int ld = scratch_ld[ck.x];
   double* F = scratch + scratch_off[ck.x];
   {   // thread = (row, column group of 4): all 16 columns of a thread in one round trip
     const int si = threadIdx.x & 63, sg = threadIdx.x >> 6;
@@ -2050,7 +2167,7 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int j = sg + 4 * u;
-      t[u] = (si < n && j < n) ? F[(size_t)si + (size_t)m * j] : 0.0;
+      t[u] = (si < n && j < n) ? F[(size_t)si + (size_t)ld * j] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u)
@@ -2066,7 +2183,7 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4
 #pragma unroll
   for (int cb = 0; cb < MAXB; ++cb)   // the whole row first: one round trip
 #pragma unroll
-    for (int c = 0; c < BS; ++c) x[cb * BS + c] = (cb < ns) ? F[(size_t)i + (size_t)m * (cb * BS + c)] : 0.0;
+    for (int c = 0; c < BS; ++c) x[cb * BS + c] = (cb < ns) ? F[(size_t)i + (size_t)ld * (cb * BS + c)] : 0.0;
 #pragma unroll
   for (int cb = 0; cb < MAXB; ++cb) {
     if (cb < ns) {
@@ -2083,7 +2200,7 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4
         for (int q = 0; q < c; ++q) v -= x[cb * BS + q] * S[(cb * BS + c) + 65 * (cb * BS + q)];
         v *= inv[cb * BS + c];
         x[cb * BS + c] = v;
-        F[(size_t)i + (size_t)m * (cb * BS + c)] = v;
+        F[(size_t)i + (size_t)ld * (cb * BS + c)] = v;
         Lg[(size_t)i + (size_t)m * (cb * BS + c)] = v;
       }
     }
@@ -2100,15 +2217,16 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 template <int BS>
 __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, const int4* __restrict__ tiles,
-                                                              const double* __restrict__ scratch,
-                                                              const long long* __restrict__ scratch_off) {
+                                                              double* __restrict__ scratch,
+                                                              const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
   constexpr int BB = BS * BS;
-  const int4 td = tiles[blockIdx.x];   // x: launch slot of the front, y / z: tile row / column
+  const int4 td = tiles[blockIdx.x];   // x: launch slot of the front, y / z: tile row / column, w: the parent continues in place
   const int f = P.slots[td.x].x;
   const FrontRec rec = load_front_rec(P.rec + f);
   const int ns = rec.ns, nbd = rec.nb;
-  const int m = (ns + nbd) * BS, npiv = ns * BS, mt = nbd * BS;
-  const double* F = scratch + scratch_off[td.x];
+  const int npiv = ns * BS, mt = nbd * BS;
+  const int m = scratch_ld[td.x];   // leading dimension of the front in the slab
+  double* F = scratch + scratch_off[td.x];
   double* U = P.U + rec.U_off;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
   const int r0 = td.y * 64 + (wave & 1) * 32, c0 = td.z * 64 + (wave >> 1) * 32;
@@ -2156,9 +2274,11 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
         const int r = r0 + 16 * a + lr, c = c0 + 16 * b + lk + 4 * v;
         if (r < mt && c < mt) {
           const int ib = r / BS, jb = c / BS;
-          if (ib >= jb)
-            U[(size_t)(ib * (ib + 1) / 2 + jb) * BB + (r - ib * BS) + BS * (c - jb * BS)] =
-                F[(size_t)(npiv + r) + (size_t)m * (npiv + c)] - acc[a][b][v];
+          if (ib >= jb) {
+            const double x = F[(size_t)(npiv + r) + (size_t)m * (npiv + c)] - acc[a][b][v];
+            if (td.w) F[(size_t)(npiv + r) + (size_t)m * (npiv + c)] = x;   // the parent is factorised here, in place
+            else U[(size_t)(ib * (ib + 1) / 2 + jb) * BB + (r - ib * BS) + BS * (c - jb * BS)] = x;
+          }
         }
       }
 }
@@ -2476,7 +2596,8 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   const int4* chunks;
   int ba_begin, ba_count, tr_begin, tr_count;
   const std::vector<std::pair<int, int>>* be_pass;
-  long long scratch;
+  int fz_begin, fz_count;
+  const int* ld;   // leading dimension per launch slot
 };
 
 __global__ void __launch_bounds__(256) fill_zero_kernel(double* __restrict__ p, size_t n) {
@@ -2536,29 +2657,27 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
   }
   if (!(parts & 2)) return;
   if (glb_count > 0 && big.ok) {   // large fronts as whole-GPU passes
-    {   // zero the slab (a fill kernel: hipMemsetAsync reaches ~1 TB/s, the slab of a wide level is 100 MB and more)
-      const size_t n2 = ((size_t)big.scratch + 1) / 2;
-      const int blocks = (int)std::min<size_t>((n2 + 256 * 8 - 1) / (256 * 8), 65535 * 4);
-      hipLaunchKernelGGL(fill_zero_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, d_scratch, (size_t)big.scratch);
-      G2OHIP_LAUNCH_CHECK("fill_zero_kernel");
+    if (big.fz_count > 0) {   // zero the regions that start at this level (a kernel: hipMemsetAsync reaches ~1 TB/s only)
+      hipLaunchKernelGGL(big_fill_kernel, dim3(big.fz_count), dim3(256), 0, st, big.chunks + big.fz_begin, d_scratch, d_scratch_off);
+      G2OHIP_LAUNCH_CHECK("big_fill_kernel");
     }
     if (big.ba_count > 0)
       hipLaunchKernelGGL((big_assemble_kernel<BS, VIRT>), dim3(big.ba_count), dim3(256), 0, st, P, big.chunks + big.ba_begin, dA, d_scratch,
-                         d_scratch_off);
+                         d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_assemble_kernel");
     for (const auto& pass : *big.be_pass)
       if (pass.second > 0)
         hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
                            d_scratch_off);
     G2OHIP_LAUNCH_CHECK("big_extend_add_kernel");
-    hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off);
+    hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_diag_kernel");
     if (big.tr_count > 0)
       hipLaunchKernelGGL((big_trsm_kernel<BS>), dim3(big.tr_count), dim3(256), 0, st, P, big.chunks + big.tr_begin, d_scratch,
-                         d_scratch_off);
+                         d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_trsm_kernel");
     if (bt_count > 0)
-      hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off);
+      hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_front_update_kernel");
   } else if (glb_count > 0) {
     const int idx_off = 2 * (BS * BS + BS);
@@ -2567,7 +2686,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
                        d_scratch, d_scratch_off + glb_begin, idx_off, 0, (const double*)nullptr, (double*)nullptr, 0);
     G2OHIP_LAUNCH_CHECK("front_factor_kernel");
     if (bt_count > 0)   // their trailing matrices: one MFMA pass over all of them
-      hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off);
+      hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_front_update_kernel");
   }
 }
@@ -2626,7 +2745,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   CholPlanDev fplan = plan_;
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
-                      LL.glb_scratch};
+                      LL.fz_begin, LL.fz_count, d_scratch_ld.p};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
