@@ -17,6 +17,7 @@ constexpr int kFwdChildren = 4;   // fused forward sweep: children per front han
 constexpr int kFactorThreadsGlobal = 512;
 constexpr int kChainU = 6;  // doubles per thread that carry an update matrix from one chain front to the next
 // register-resident wave kernel (wave_front.inc): limits of a front
+constexpr int kFillChunk = 4096;         // doubles zeroed by one workgroup of big_fill_kernel
 constexpr int kWvNPV = 24;             // pivot columns (scalars)
 constexpr int kWvNTL = 3;              // 16-row tiles of boundary rows (48 rows)
 constexpr int kWvT = (kWvNPV + 16 * kWvNTL + 1 + 15) / 16;   // 16 x 16 tiles per side of the front incl. the right-hand side row
@@ -923,13 +924,13 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
             for (int tj = 0; tj <= ti; ++tj) bt.push_back(make_int4(q, ti, tj, inpl_next[f] >= 0 ? 1 : 0));   // w: update in place
         }
         LL.bt_count = (int)bt.size() - LL.bt_begin;
-        // zero-fill chunks (32 Ki doubles each) of the fronts that start a region at this level
+        // zero-fill chunks of the fronts that start a region at this level
         LL.fz_begin = (int)bt.size();
         for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
           if (inpl_prev[f] >= 0) continue;
           const long long mm = (long long)front_dim(f) * (long long)front_dim(f);
-          for (long long c0 = 0; c0 < mm; c0 += 32768) bt.push_back(make_int4(q, (int)(c0 / 32768), (int)std::min<long long>(32768, mm - c0), 0));
+          for (long long c0 = 0; c0 < mm; c0 += kFillChunk) bt.push_back(make_int4(q, (int)(c0 / kFillChunk), (int)std::min<long long>(kFillChunk, mm - c0), 0));
         }
         LL.fz_count = (int)bt.size() - LL.fz_begin;
         // assembly chunks (32 original blocks each)
@@ -2047,11 +2048,12 @@ __global__ void __launch_bounds__(256) big_assemble_kernel(CholPlanDev P, const 
   }
 }
 
-// zero the regions of the fronts that start one at this level (x: launch slot, y: chunk of 32 Ki doubles, z: doubles)
+// zero the regions of the fronts that start one at this level (x: launch slot, y: chunk of kFillChunk doubles, z: doubles)
 __global__ void __launch_bounds__(256) big_fill_kernel(const int4* __restrict__ chunks, double* __restrict__ scratch,
                                                       const long long* __restrict__ scratch_off) {
   const int4 ck = chunks[blockIdx.x];
-  double* p = scratch + scratch_off[ck.x] + (size_t)ck.y * 32768;
+  double* p = scratch + scratch_off[ck.x] + (size_t)ck.y * kFillChunk;
+#pragma unroll 4
   for (int i = threadIdx.x; i < ck.z; i += 256) p[i] = 0.0;
 }
 
