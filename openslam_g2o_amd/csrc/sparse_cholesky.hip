@@ -2097,11 +2097,12 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
   return __hiloint2double(hi, lo);
 }
-template <int BS>
-__global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, double* __restrict__ scratch,
-                                                     const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
+template <int BS, bool COH>
+__device__ __forceinline__ void big_diag_body(const CholPlanDev& P, int slot, int lane, double* __restrict__ scratch,
+                                              const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
+  // COH: the panel block and the reciprocal diagonal go to L with agent-scope stores (read by other workgroups of the
+  // SAME launch: big_panel_kernel)
   constexpr int MAXB = 64 / BS, N = MAXB * BS;
-  const int slot = slot0 + blockIdx.x, lane = threadIdx.x;
   const int f = P.slots[slot].x;
   const FrontRec rec = load_front_rec(P.rec + f);
   const int ns = rec.ns, m = (rec.ns + rec.nb) * BS, n = ns * BS;
@@ -2127,7 +2128,10 @@ __global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, 
         sqrt_and_rsqrt(d, sq, rs);
         const double l = lane > j ? r[j] * rs : (lane == j ? sq : 0.0);   // column j of L (zero above the diagonal)
         r[j] = l;
-        if (lane == j) Lg[(size_t)m * n + j] = rs;
+        if (lane == j) {
+          if (COH) st_coh(Lg + (size_t)m * n + j, rs);
+          else Lg[(size_t)m * n + j] = rs;
+        }
 #pragma unroll
         for (int c = j + 1; c < (jb + 1) * BS; ++c) r[c] -= l * readlane_f64(l, c);
 #pragma unroll
@@ -2145,9 +2149,15 @@ __global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, 
     for (int c = 0; c < N; ++c)
       if (c < n) {
         F[(size_t)lane + (size_t)ld * c] = r[c];
-        Lg[(size_t)lane + (size_t)m * c] = r[c];
+        if (COH) st_coh(Lg + (size_t)lane + (size_t)m * c, r[c]);
+        else Lg[(size_t)lane + (size_t)m * c] = r[c];
       }
   }
+}
+template <int BS>
+__global__ void __launch_bounds__(64) big_diag_kernel(CholPlanDev P, int slot0, double* __restrict__ scratch,
+                                                     const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
+  big_diag_body<BS, false>(P, slot0 + blockIdx.x, threadIdx.x, scratch, scratch_off, scratch_ld);
 }
 
 // panel rows below the pivot block: x L11' = row, one thread per row, the row in registers
@@ -2283,6 +2293,131 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
           }
         }
       }
+}
+
+// Panel solve and trailing update of the scratch-slab fronts of one level in ONE launch (two otherwise: on the critical
+// path of a pose graph every launch is ~5 us of start-up next to a few us of work).  A workgroup owns a 64 x 64 tile of
+// a trailing matrix: it solves ITS 2 x 64 panel rows against L11' itself (the rows of a tile are solved again by the
+// other tiles that need them -- a few thousand redundant FMAs instead of a launch and a round trip through memory),
+// keeps them in LDS as the operands of the MFMA update and -- the tiles of the first tile column -- writes them to L.
+// (A variant that also carried the pivot block, with flags between workgroups, needed the registers of both roles at
+// once: 674 spilled registers, slower than three launches.)
+template <int BS>
+__global__ void __launch_bounds__(256) big_panel_kernel(CholPlanDev P, const int4* __restrict__ tiles, double* __restrict__ scratch,
+                                                       const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
+  extern __shared__ __attribute__((aligned(16))) double psm[];
+  constexpr int BB = BS * BS, MAXB = 64 / BS, NX = MAXB * BS;
+  const int tid = threadIdx.x;
+  const int4 td = tiles[blockIdx.x];   // x: launch slot, y / z: tile row / column, w: the parent continues in place
+  const int slot = td.x;
+  const int f = P.slots[slot].x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int ns = rec.ns, nbd = rec.nb;
+  const int n = ns * BS, mt = nbd * BS, m = n + mt;
+  const int ld = scratch_ld[slot];
+  double* F = scratch + scratch_off[slot];
+  double* Lg = P.L + rec.L_off;
+  double* S = psm;                 // L11, [64][65]
+  double* inv = S + 64 * 65;       // 1 / diagonal
+  double* XR = inv + 64;           // solved rows of the tile's row range, [64][65]: XR[row + 65 k]
+  double* XC = XR + 64 * 65;       // ... of its column range
+  // this thread's panel row (threads 0..63: row range, 64..127: column range), requested before the wait
+  const bool rowthr = tid < 128;
+  const int rloc = tid & 63;
+  const int rglb = (tid < 64 ? td.y : td.z) * 64 + rloc;      // row of the trailing part
+  const bool rok = rowthr && rglb < mt;
+  double x[NX];
+#pragma unroll
+  for (int c = 0; c < NX; ++c) x[c] = (rok && c < n) ? F[(size_t)(n + rglb) + (size_t)ld * c] : 0.0;
+  {   // L11 and the reciprocal diagonal (written by big_diag_kernel, the launch before)
+    constexpr int UL = 16;   // 64 * 64 / 256
+    double t[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int i = min(tid + 256 * u, n * n - 1);
+      t[u] = Lg[(i % n) + (size_t)m * (i / n)];
+    }
+    const double iv = Lg[(size_t)m * n + min(tid, n - 1)];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int i = tid + 256 * u;
+      if (i < n * n) S[(i % n) + 65 * (i / n)] = t[u];
+    }
+    if (tid < n) inv[tid] = iv;
+  }
+  __syncthreads();
+  if (rowthr) {   // x L11' = row (big_trsm_kernel)
+    double* X = tid < 64 ? XR : XC;
+#pragma unroll
+    for (int cb = 0; cb < MAXB; ++cb) {
+      if (cb < ns) {
+#pragma unroll
+        for (int qb = 0; qb < cb; ++qb)
+#pragma unroll
+          for (int c = 0; c < BS; ++c)
+#pragma unroll
+            for (int q = 0; q < BS; ++q) x[cb * BS + c] -= x[qb * BS + q] * S[(cb * BS + c) + 65 * (qb * BS + q)];
+#pragma unroll
+        for (int c = 0; c < BS; ++c) {
+          double v = x[cb * BS + c];
+#pragma unroll
+          for (int q = 0; q < c; ++q) v -= x[cb * BS + q] * S[(cb * BS + c) + 65 * (cb * BS + q)];
+          v *= inv[cb * BS + c];
+          x[cb * BS + c] = v;
+          X[rloc + 65 * (cb * BS + c)] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (td.z == 0)   // the tiles of the first tile column write their rows of the panel to L (coalesced, from LDS)
+    for (int i = tid; i < 64 * n; i += 256) {
+      const int r = i & 63, k = i >> 6;
+      if (td.y * 64 + r < mt) Lg[(size_t)(n + td.y * 64 + r) + (size_t)m * k] = XR[r + 65 * k];
+    }
+  {   // rank-n update of this tile (big_front_update_kernel, operands from LDS)
+    double* U = P.U + rec.U_off;
+    const int wave = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+    const int r0 = (wave & 1) * 32, c0 = (wave >> 1) * 32;           // inside the tile
+    const int R0 = td.y * 64 + r0, C0 = td.z * 64 + c0;               // in the trailing part
+    if (R0 < mt && C0 < mt && C0 <= R0 + 31) {
+      mfma_d4 acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      for (int k0 = 0; k0 < n; k0 += 4) {
+        const int k = min(k0 + lk, n - 1);
+        const double keep = (k0 + lk < n) ? 1.0 : 0.0;
+        double rv[2], cv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          rv[q] = XR[(r0 + 16 * q + lr) + 65 * k] * keep;
+          cv[q] = XC[(c0 + 16 * q + lr) + 65 * k];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[b], rv[a], acc[a][b], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int r = R0 + 16 * a + lr, c = C0 + 16 * b + lk + 4 * v;
+            if (r < mt && c < mt) {
+              const int ib = r / BS, jb = c / BS;
+              if (ib >= jb) {
+                const double y = F[(size_t)(n + r) + (size_t)ld * (n + c)] - acc[a][b][v];
+                if (td.w) F[(size_t)(n + r) + (size_t)ld * (n + c)] = y;
+                else U[(size_t)(ib * (ib + 1) / 2 + jb) * BB + (r - ib * BS) + BS * (c - jb * BS)] = y;
+              }
+            }
+          }
+    }
+  }
 }
 
 // b_perm[new*bs + r] = b[old*bs + r]
@@ -2600,6 +2735,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   const std::vector<std::pair<int, int>>* be_pass;
   int fz_begin, fz_count;
   const int* ld;   // leading dimension per launch slot
+  bool fuse_panel;   // big_panel_kernel instead of big_trsm_kernel + big_front_update_kernel
 };
 
 __global__ void __launch_bounds__(256) fill_zero_kernel(double* __restrict__ p, size_t n) {
@@ -2674,6 +2810,14 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     G2OHIP_LAUNCH_CHECK("big_extend_add_kernel");
     hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_diag_kernel");
+    if (big.fuse_panel) {   // panel solve + update in one launch
+      if (bt_count > 0) {
+        const size_t shp = (size_t)(3 * 64 * 65 + 64) * sizeof(double);
+        hipLaunchKernelGGL((big_panel_kernel<BS>), dim3(bt_count), dim3(256), shp, st, P, big_tiles, d_scratch, d_scratch_off, big.ld);
+        G2OHIP_LAUNCH_CHECK("big_panel_kernel");
+      }
+      return;
+    }
     if (big.tr_count > 0)
       hipLaunchKernelGGL((big_trsm_kernel<BS>), dim3(big.tr_count), dim3(256), 0, st, P, big.chunks + big.tr_begin, d_scratch,
                          d_scratch_off, big.ld);
@@ -2747,7 +2891,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   CholPlanDev fplan = plan_;
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
-                      LL.fz_begin, LL.fz_count, d_scratch_ld.p};
+                      LL.fz_begin, LL.fz_count, d_scratch_ld.p, opt.fuse_panel != 0};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
@@ -2795,6 +2939,10 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, kFactorThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_panel_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_panel_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_panel_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipGetLastError();
     attr_done = true;
   }
   if (phase == 0) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
