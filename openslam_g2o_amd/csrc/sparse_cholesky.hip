@@ -2810,7 +2810,8 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     G2OHIP_LAUNCH_CHECK("big_extend_add_kernel");
     hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_diag_kernel");
-    if (big.fuse_panel) {   // panel solve + update in one launch
+    if (big.fuse_panel && bt_count <= 256) {   // panel solve + update in one launch -- while the level is a latency chain (at most one
+                                               // workgroup per CU); a level that fills the GPU pays for the rows solved more than once
       if (bt_count > 0) {
         const size_t shp = (size_t)(3 * 64 * 65 + 64) * sizeof(double);
         hipLaunchKernelGGL((big_panel_kernel<BS>), dim3(bt_count), dim3(256), shp, st, P, big_tiles, d_scratch, d_scratch_off, big.ld);
