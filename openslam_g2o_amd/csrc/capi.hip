@@ -445,6 +445,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "overlap_level_halves")) s->impl->chol_opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "inplace_chains")) s->impl->chol_opt.inplace_chains = (int)value;
   else if (!std::strcmp(name, "fuse_panel")) s->impl->chol_opt.fuse_panel = (int)value;
+  else if (!std::strcmp(name, "mfma_diag")) s->impl->chol_opt.mfma_diag = (int)value;
   else if (!std::strcmp(name, "dep_delay")) s->impl->chol_opt.dep_delay = (int)value;
   else if (!std::strcmp(name, "dep_backward")) s->impl->chol_opt.dep_backward = (int)value;
   else if (!std::strcmp(name, "big_front_passes")) s->impl->chol_opt.big_front_passes = (int)value;
@@ -765,6 +766,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "overlap_level_halves")) ls->opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "inplace_chains")) ls->opt.inplace_chains = (int)value;
   else if (!std::strcmp(name, "fuse_panel")) ls->opt.fuse_panel = (int)value;
+  else if (!std::strcmp(name, "mfma_diag")) ls->opt.mfma_diag = (int)value;
   else if (!std::strcmp(name, "dep_delay")) ls->opt.dep_delay = (int)value;
   else if (!std::strcmp(name, "dep_backward")) ls->opt.dep_backward = (int)value;
   else if (!std::strcmp(name, "big_front_passes")) ls->opt.big_front_passes = (int)value;

@@ -45,6 +45,7 @@ struct CholOptions {
   int dep_delay = 0;                     // launch-order distance between a task and its parent inside a wide dependency-driven launch
   int wave_front_tasks = 1024;           // launches at least this wide use two waves (128 threads) per front
   size_t wave_front_bytes = 0;           // (unused)
+  int mfma_diag = 1;                     // scratch-slab fronts: pivot block on the matrix cores (four waves) instead of one wave with v_readlane broadcasts
   int fuse_panel = 1;                    // scratch-slab fronts: panel solve and trailing update of a level in one launch
   int inplace_chains = 1;                // chains of scratch-slab fronts with identical rows (panels of one large supernode) are factorised in place
   int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level

@@ -2728,6 +2728,141 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
 
 #include "wave_front.inc"
 
+// Pivot block of a scratch-slab front (n <= 64 columns) on the matrix cores: the blocked right-looking Cholesky of
+// wave_front_kernel restricted to the pivot block -- the symmetric n x n block as ten upper 16 x 16 tiles in accumulator
+// layout dealt to four waves, four columns per step (row panel by symmetry, 4 x 4 pivot block factorised by every lane,
+// scaled panel and rank-4 update one MFMA each).  The one-wave kernel (big_diag_kernel: a row per lane, columns broadcast
+// by v_readlane) needs n^2 / 2 readlane + FMA pairs in ONE instruction stream: 23 us for 48 columns, on the critical path
+// of every level of a pose graph; this one takes about half of that.
+template <int BS>
+__global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int slot0, double* __restrict__ scratch,
+                                                           const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
+  __shared__ double Rb[4 * 64], Lb[4 * 64];
+  constexpr int T = 4, NT = 10, NW = 4, OWN = 3;
+  const int slot = slot0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int f = P.slots[slot].x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int m = (rec.ns + rec.nb) * BS, n = rec.ns * BS;
+  const int ld = scratch_ld[slot];
+  double* F = scratch + scratch_off[slot];
+  double* Lg = P.L + rec.L_off;
+  const int lr = lane & 15, lk = lane >> 4;
+  int oti[OWN], otj[OWN];
+#pragma unroll
+  for (int k = 0; k < OWN; ++k) {
+    const int q = w + NW * k;
+    int tj = 0;
+#pragma unroll
+    for (int c = 1; c < T; ++c)
+      if (q >= c * (c + 1) / 2) tj = c;
+    oti[k] = q < NT ? q - tj * (tj + 1) / 2 : T;
+    otj[k] = q < NT ? tj : T;
+  }
+  wv_d4 S[OWN];
+#pragma unroll
+  for (int k = 0; k < OWN; ++k)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = 16 * oti[k] + lk + 4 * v, c = 16 * otj[k] + lr;
+      const int a = min(r, c), b = max(r, c);                       // F holds the lower triangle
+      S[k][v] = (otj[k] < T && b < n) ? F[(size_t)b + (size_t)ld * a] : 0.0;
+    }
+  bool bad = false;
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb) {
+    const int k0 = 4 * kb;
+    if (k0 < n) {   // (uniform)
+      const int tk = k0 >> 4, vk = (k0 & 15) >> 2, c16 = k0 & 15;
+#pragma unroll
+      for (int k = 0; k < OWN; ++k)
+        if (oti[k] == tk) Rb[otj[k] * 64 + lane] = S[k][vk];
+      __syncthreads();
+      // 4 x 4 pivot block (every lane): D = Ld Ld', W = Ld^-1; this lane's element of the A operand, sqrt and reciprocal
+      double D[4][4], Ld[4][4], rs[4], sq[4], W[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b) D[a][b] = Rb[tk * 64 + (c16 + b) + 16 * a];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (k0 + j < n) {
+          double d = D[j][j];
+          if (!(d > 0.0)) {
+            bad = true;
+            d = 1.0;
+          }
+          sqrt_and_rsqrt(d, sq[j], rs[j]);
+#pragma unroll
+          for (int i = j + 1; i < 4; ++i) Ld[i][j] = D[j][i] * rs[j];
+#pragma unroll
+          for (int c = j + 1; c < 4; ++c)
+#pragma unroll
+            for (int i = c; i < 4; ++i) D[c][i] -= Ld[i][j] * Ld[c][j];
+        } else {
+          sq[j] = 0.0;
+          rs[j] = 0.0;
+#pragma unroll
+          for (int i = j + 1; i < 4; ++i) Ld[i][j] = 0.0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        W[j][j] = rs[j];
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+          double s_ = 0.0;
+#pragma unroll
+          for (int k = j; k < i; ++k) s_ += Ld[i][k] * W[k][j];
+          W[i][j] = -rs[i] * s_;
+        }
+      }
+      double aop = 0.0, sqsel = 0.0, rssel = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k)
+          if (lr == i && lk == k) aop = W[i][k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (lk == k) {
+          sqsel = sq[k];
+          rssel = rs[k];
+        }
+      const int col = k0 + lk;
+      if (w == 0 && lr == 0 && col < n) Lg[(size_t)m * n + col] = rssel;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        if ((t & (NW - 1)) == w && 16 * t < n) {
+          const int row = 16 * t + lr;
+          double v = 0.0;                                                     // (above the diagonal: zeros)
+          if (t >= tk) {
+            const wv_d4 r = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Rb[t * 64 + lane], wv_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            Lb[t * 64 + lane] = r[0];
+            v = r[0];
+            if (t == tk) v = row > col ? v : (row == col ? sqsel : 0.0);
+          }
+          if (col < n && row < n) {
+            Lg[(size_t)row + (size_t)m * col] = v;
+            F[(size_t)row + (size_t)ld * col] = v;
+          }
+        }
+      }
+      __syncthreads();
+      double la[OWN], lb_[OWN];
+#pragma unroll
+      for (int k = 0; k < OWN; ++k) {
+        la[k] = Lb[min(oti[k], T - 1) * 64 + lane];
+        lb_[k] = Lb[min(otj[k], T - 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int k = 0; k < OWN; ++k)
+        if (oti[k] >= tk && otj[k] < T && 16 * otj[k] < n) S[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv_neg(la[k]), lb_[k], S[k], 0, 0, 0);
+    }
+  }
+  if (bad && lane == 0) atomicMax(P.status, 1);
+}
+
 struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one level (LevelLaunch::ba_* / be_pass / tr_*)
   bool ok;
   const int4* chunks;
@@ -2736,6 +2871,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   int fz_begin, fz_count;
   const int* ld;   // leading dimension per launch slot
   bool fuse_panel;   // big_panel_kernel instead of big_trsm_kernel + big_front_update_kernel
+  bool mfma_diag;    // big_diag_mfma_kernel instead of big_diag_kernel
 };
 
 __global__ void __launch_bounds__(256) fill_zero_kernel(double* __restrict__ p, size_t n) {
@@ -2808,7 +2944,10 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
         hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
                            d_scratch_off);
     G2OHIP_LAUNCH_CHECK("big_extend_add_kernel");
-    hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
+    if (big.mfma_diag)
+      hipLaunchKernelGGL((big_diag_mfma_kernel<BS>), dim3(glb_count), dim3(256), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
+    else
+      hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_diag_kernel");
     if (big.fuse_panel && bt_count <= 256) {   // panel solve + update in one launch -- while the level is a latency chain (at most one
                                                // workgroup per CU); a level that fills the GPU pays for the rows solved more than once
@@ -2892,7 +3031,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   CholPlanDev fplan = plan_;
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
-                      LL.fz_begin, LL.fz_count, d_scratch_ld.p, opt.fuse_panel != 0};
+                      LL.fz_begin, LL.fz_count, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
