@@ -372,6 +372,12 @@ int g2ohip_ls_init(g2ohip_linear_solver* ls);
  * x, b: host vectors of n_blocks*block_dim.  G2OHIP_OK | G2OHIP_NOT_PD | error. */
 int g2ohip_ls_solve(g2ohip_linear_solver* ls, int n_blocks, const int32_t* colptr, const int32_t* rowidx,
                     const double* values, double* x, const double* b);
+/* LinearSolver::solvePattern(spinv, blockIndices, A), linear_solver.h:71 / linear_solver_csparse.h:190-221 (factorise,
+ * then MarginalCovarianceCholesky::computeCovariance): blocks (rows[i], cols[i]) of A^-1, out [n_req][bd x bd]
+ * column-major.  Blocks inside the pattern of the factor come from one sparse-inverse pass over the frontal matrices,
+ * the others from unit right-hand sides.  G2OHIP_OK | G2OHIP_NOT_PD | error. */
+int g2ohip_ls_solve_pattern(g2ohip_linear_solver* ls, int n_blocks, const int32_t* colptr, const int32_t* rowidx,
+                            const double* values, int n_req, const int32_t* rows, const int32_t* cols, double* out);
 int g2ohip_ls_get_stats(g2ohip_linear_solver* ls, g2ohip_stats* out);
 int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double value);
 

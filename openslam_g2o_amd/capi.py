@@ -48,7 +48,7 @@ EXPORTS = [
     "g2ohip_b_device", "g2ohip_multiply_hessian", "g2ohip_sync", "g2ohip_set_profiling", "g2ohip_get_stats",
     "g2ohip_set_option", "g2ohip_get_nnzb", "g2ohip_get_pattern", "g2ohip_copy_values", "g2ohip_device_array",
     "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute", "g2ohip_ls_create",
-    "g2ohip_ls_destroy", "g2ohip_ls_init", "g2ohip_ls_solve", "g2ohip_ls_get_stats", "g2ohip_ls_set_option",
+    "g2ohip_ls_destroy", "g2ohip_ls_init", "g2ohip_ls_solve", "g2ohip_ls_solve_pattern", "g2ohip_ls_get_stats", "g2ohip_ls_set_option",
     "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time", "g2ohip_add_schur_pattern",
     "g2ohip_set_lambda_split", "g2ohip_ba_set_edges", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
@@ -169,6 +169,7 @@ def load():
     L.g2ohip_ls_destroy.restype = None
     L.g2ohip_ls_init.argtypes = [vp]
     L.g2ohip_ls_solve.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p]
+    L.g2ohip_ls_solve_pattern.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, C.c_int, c_int_p, c_int_p, c_dbl_p]
     L.g2ohip_ls_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.g2ohip_ls_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     _lib = L
@@ -652,6 +653,21 @@ class HipLinearSolver:
         x = np.zeros(nb * self.bs)
         rc = _check(self.L.g2ohip_ls_solve(self.h, nb, _ip(colptr), _ip(rowidx), _dp(values), _dp(x), _dp(b)), "ls_solve")
         return rc == OK, x
+
+    def solvePattern(self, colptr, rowidx, values, rows, cols):
+        """LinearSolver::solvePattern: blocks (rows[i], cols[i]) of A^-1 as [n][bd][bd] (row, column); None if not PD."""
+        colptr, rowidx, rows, cols = _i32(colptr), _i32(rowidx), _i32(rows), _i32(cols)
+        values = _f64(values)
+        nb = len(colptr) - 1
+        bd = self.bs
+        if len(rows) != len(cols) or len(rowidx) < colptr[nb] or values.size < colptr[nb] * bd * bd:
+            raise ValueError("solvePattern: inconsistent array lengths")
+        out = np.empty((len(rows), bd * bd))
+        rc = _check(self.L.g2ohip_ls_solve_pattern(self.h, nb, _ip(colptr), _ip(rowidx), _dp(values), len(rows), _ip(rows), _ip(cols), _dp(out)),
+                    "ls_solve_pattern")
+        if rc != OK:
+            return None
+        return out.reshape(len(rows), bd, bd).transpose(0, 2, 1).copy()
 
     def stats(self):
         s = Stats()

@@ -217,6 +217,11 @@ class BlockSolverHip : public BlockSolverBase {
     }
     std::vector<double> out(blockIndices.size() * p * p);
     if (g2ohip_compute_marginals(_h, (int)blockIndices.size(), r.data(), c.data(), out.data()) != G2OHIP_OK) return false;
+    // the block layout of the result, as MarginalCovarianceCholesky::computeCovariance sets it up
+    // (marginal_covariance_cholesky.cpp:156-160): one p x p block per pose
+    std::vector<int> rbi(_nP);
+    for (int i = 0; i < _nP; ++i) rbi[i] = (i + 1) * p;
+    if (_nP > 0) spinv = SparseBlockMatrix<MatrixXd>(&rbi[0], &rbi[0], _nP, _nP, true);
     for (size_t i = 0; i < blockIndices.size(); ++i) {
       MatrixXd* blk = spinv.block(r[i], c[i], true);   // allocated p x p, column-major like `out`
       std::memcpy(blk->data(), &out[i * p * p], sizeof(double) * p * p);
@@ -345,7 +350,52 @@ class LinearSolverHip : public LinearSolver<MatrixType> {
     return rc == G2OHIP_OK;
   }
 
+  // blocks of A^-1 (linear_solver.h:71; LinearSolverCSparse::solvePattern, linear_solver_csparse.h:190-221): factorise,
+  // then every requested block on the pattern of the factor from one sparse-inverse pass
+  virtual bool solvePattern(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices,
+                            const SparseBlockMatrix<MatrixType>& A) {
+    if (!_ls) return false;
+    const int nb = (int)A.blockCols().size();
+    exportUpper(A);
+    const int bd = nb > 0 ? A.rows() / nb : 0;
+    std::vector<int32_t> r(blockIndices.size()), c(blockIndices.size());
+    for (size_t i = 0; i < blockIndices.size(); ++i) {
+      r[i] = blockIndices[i].first;
+      c[i] = blockIndices[i].second;
+    }
+    std::vector<double> out(blockIndices.size() * bd * bd);
+    const int rc = g2ohip_ls_solve_pattern(_ls, nb, _colptr.data(), _rowidx.data(), _values.data(), (int)blockIndices.size(), r.data(), c.data(),
+                                           out.data());
+    if (rc != G2OHIP_OK) {
+      if (rc != G2OHIP_NOT_PD) std::cerr << "LinearSolverHip::solvePattern: " << g2ohip_last_error() << std::endl;
+      return false;
+    }
+    spinv = SparseBlockMatrix<MatrixXd>(&A.rowBlockIndices()[0], &A.rowBlockIndices()[0], nb, nb, true);   // marginal_covariance_cholesky.cpp:156-160
+    for (size_t i = 0; i < blockIndices.size(); ++i) {
+      MatrixXd* blk = spinv.block(r[i], c[i], true);
+      std::memcpy(blk->data(), &out[i * bd * bd], sizeof(double) * bd * bd);
+    }
+    return true;
+  }
+
  private:
+  // block-CCS export of the upper triangle: column pointers, row block indices, dense blocks
+  void exportUpper(const SparseBlockMatrix<MatrixType>& A) {
+    const int nb = (int)A.blockCols().size();
+    _colptr.assign(1, 0);
+    _rowidx.clear();
+    _values.clear();
+    for (int c = 0; c < nb; ++c) {
+      const typename SparseBlockMatrix<MatrixType>::IntBlockMap& column = A.blockCols()[c];
+      for (typename SparseBlockMatrix<MatrixType>::IntBlockMap::const_iterator it = column.begin(); it != column.end(); ++it) {
+        if (it->first > c) break;
+        const MatrixType* blk = it->second;
+        _rowidx.push_back(it->first);
+        _values.insert(_values.end(), blk->data(), blk->data() + blk->rows() * blk->cols());
+      }
+      _colptr.push_back((int32_t)_rowidx.size());
+    }
+  }
   g2ohip_linear_solver* _ls;
   std::vector<int32_t> _colptr, _rowidx;
   std::vector<double> _values;

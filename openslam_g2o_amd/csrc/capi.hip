@@ -740,6 +740,92 @@ int g2ohip_ls_solve(g2ohip_linear_solver* ls, int n_blocks, const int32_t* colpt
     return G2OHIP_OK;
   });
 }
+namespace {
+__global__ void ls_gather_inverse_kernel(int n, int p, const long long* __restrict__ off, const int* __restrict__ ld,
+                                         const int* __restrict__ tr, const double* __restrict__ Z, double* __restrict__ out) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * p * p) return;
+  const int b = (int)(t / (p * p)), e = (int)(t % (p * p)), i = e % p, j = e / p;
+  if (off[b] < 0) return;
+  out[t] = tr[b] ? Z[off[b] + j + (long long)ld[b] * i] : Z[off[b] + i + (long long)ld[b] * j];
+}
+__global__ void ls_unit_kernel(double* v, size_t n, size_t k) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t < n) v[t] = t == k ? 1.0 : 0.0;
+}
+}  // namespace
+
+int g2ohip_ls_solve_pattern(g2ohip_linear_solver* ls, int n_blocks, const int32_t* colptr, const int32_t* rowidx, const double* values,
+                            int n_req, const int32_t* rows, const int32_t* cols, double* out) {
+  if (!ls || !colptr || !rowidx || !values || n_blocks <= 0 || n_req < 0 || (n_req > 0 && (!rows || !cols || !out))) return G2OHIP_ERR_ARG;
+  for (int i = 0; i < n_req; ++i)
+    if (rows[i] < 0 || rows[i] >= n_blocks || cols[i] < 0 || cols[i] >= n_blocks) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    G2OHIP_HIP_CHECK(hipSetDevice(ls->device));
+    const int nnzb = colptr[n_blocks];
+    const int bs = ls->bs;
+    if (!ls->chol) {
+      ls->chol = std::make_unique<SparseCholesky>(bs);
+      ls->chol->opt = ls->opt;
+      ls->colptr.assign(colptr, colptr + n_blocks + 1);
+      ls->rowidx.assign(rowidx, rowidx + nnzb);
+      ls->chol->analyze(n_blocks, colptr, rowidx, ls->st);
+    } else if ((int)ls->colptr.size() != n_blocks + 1 || ls->colptr.back() != nnzb) {
+      throw StateFailure("pattern changed without init() (linear_solver.h:86-105)");
+    }
+    ls->dA.upload(values, (size_t)nnzb * bs * bs, ls->st);
+    ls->chol->factor(ls->dA.p, ls->st);
+    if (ls->chol->failed(ls->st)) return G2OHIP_NOT_PD;
+    if (n_req == 0) return G2OHIP_OK;
+    ls->chol->sparse_inverse(ls->st);
+    std::vector<long long> off(n_req, -1);
+    std::vector<int> ldv(n_req, 0), trv(n_req, 0);
+    int found = 0;
+    for (int i = 0; i < n_req; ++i) {
+      bool tr = false;
+      if (ls->chol->inverse_block(rows[i], cols[i], &off[i], &ldv[i], &tr)) {
+        trv[i] = tr ? 1 : 0;
+        ++found;
+      } else {
+        off[i] = -1;
+      }
+    }
+    const size_t pp = (size_t)bs * bs;
+    if (found > 0) {
+      DevBuf<long long> d_off;
+      DevBuf<int> d_ld, d_tr;
+      DevBuf<double> d_out;
+      d_off.upload(off, ls->st);
+      d_ld.upload(ldv, ls->st);
+      d_tr.upload(trv, ls->st);
+      d_out.alloc((size_t)n_req * pp);
+      const size_t total = (size_t)n_req * pp;
+      hipLaunchKernelGGL(ls_gather_inverse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ls->st, n_req, bs, d_off.p, d_ld.p, d_tr.p,
+                         ls->chol->inverse_slab(), d_out.p);
+      std::vector<double> ho(total);
+      d_out.download(ho.data(), total, ls->st);
+      for (int i = 0; i < n_req; ++i)
+        if (off[i] >= 0) std::copy(ho.begin() + (size_t)i * pp, ho.begin() + (size_t)(i + 1) * pp, out + (size_t)i * pp);
+    }
+    if (found < n_req) {   // pairs outside the pattern of the factor: a pair of sweeps per column
+      const size_t n = (size_t)n_blocks * bs;
+      DevBuf<double> rhs, sol;
+      rhs.alloc(n);
+      sol.alloc(n);
+      std::vector<double> h(n);
+      for (int i = 0; i < n_req; ++i) {
+        if (off[i] >= 0) continue;
+        for (int k = 0; k < bs; ++k) {
+          hipLaunchKernelGGL(ls_unit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ls->st, rhs.p, n, (size_t)cols[i] * bs + k);
+          ls->chol->solve(rhs.p, sol.p, ls->st);
+          sol.download(h.data(), n, ls->st);
+          for (int r = 0; r < bs; ++r) out[(size_t)i * pp + r + (size_t)bs * k] = h[(size_t)rows[i] * bs + r];
+        }
+      }
+    }
+    return G2OHIP_OK;
+  });
+}
 int g2ohip_ls_get_stats(g2ohip_linear_solver* ls, g2ohip_stats* out) {
   if (!ls || !out) return G2OHIP_ERR_ARG;
   std::memset(out, 0, sizeof(*out));

@@ -104,8 +104,11 @@ class SparseBlockMatrix {                               // g2o/core/sparse_block
   typedef std::map<int, SparseMatrixBlock*> IntBlockMap; // :73
   int cols() const;                                      // :69
   int rows() const;                                      // :71
+  SparseBlockMatrix();                                   // :88
+  SparseBlockMatrix(const int* rbi, const int* cbi, int rb, int cb, bool hasStorage = true);   // :81
   SparseMatrixBlock* block(int r, int c, bool alloc = false);   // :97
   const std::vector<IntBlockMap>& blockCols() const;     // :178
+  const std::vector<int>& rowBlockIndices() const;       // :182
 };
 
 class Solver {                                          // g2o/core/solver.h:44-149
@@ -153,6 +156,8 @@ class LinearSolver {                                    // g2o/core/linear_solve
   virtual ~LinearSolver();
   virtual bool init() = 0;
   virtual bool solve(const SparseBlockMatrix<MatrixType>& A, double* x, double* b) = 0;
+  virtual bool solvePattern(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices,
+                            const SparseBlockMatrix<MatrixType>& A);   // :71
 };
 
 template <int _PoseDim, int _LandmarkDim>

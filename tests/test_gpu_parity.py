@@ -547,8 +547,18 @@ def test_linear_solver_large_fronts_all_block_sizes(bs, passes):
     assert ls.stats()["maxFrontDim"] >= 240
     xr = np.linalg.solve(A, b)
     assert relerr(x, xr) < 1e-10
+    # LinearSolver::solvePattern: blocks of the inverse -- diagonal ones, pairs of the pattern, and a pair that may lie outside it
+    Ainv = np.linalg.inv(A)
+    pr_ = [(j, j) for j in range(0, nb, 17)] + [(int(row[q]), j) for j in range(0, nb, 23) for q in range(cp[j], cp[j + 1])][:40] + [(nb - 1, 0), (0, nb - 1)]
+    rr, cc = np.array([a for a, _ in pr_], np.int32), np.array([c for _, c in pr_], np.int32)
+    M = ls.solvePattern(cp, row, vals, rr, cc)
+    assert M is not None and M.shape == (len(rr), bs, bs)
+    for i in range(len(rr)):
+        ref = Ainv[rr[i] * bs:(rr[i] + 1) * bs, cc[i] * bs:(cc[i] + 1) * bs]
+        assert np.abs(M[i] - ref).max() <= 1e-10 * np.abs(Ainv).max(), (rr[i], cc[i])
     ok, _ = ls.solve(cp, row, -vals, b)
     assert not ok
+    assert ls.solvePattern(cp, row, -vals, rr[:2], cc[:2]) is None
 
 
 def test_dependency_driven_launches_soak():
