@@ -350,6 +350,30 @@ class LinearSolverHip : public LinearSolver<MatrixType> {
     return rc == G2OHIP_OK;
   }
 
+  // the diagonal blocks of A^-1 (linear_solver.h:64; LinearSolverCSparse::solveBlocks, linear_solver_csparse.h:144-187):
+  // allocated here when the caller passes a null pointer, one bd x bd array per block row (symmetric: layout-free)
+  virtual bool solveBlocks(double**& blocks, const SparseBlockMatrix<MatrixType>& A) {
+    if (!_ls) return false;
+    const int nb = (int)A.blockCols().size();
+    if (nb == 0) return true;
+    exportUpper(A);
+    const int bd = A.rows() / nb;
+    std::vector<int32_t> d(nb);
+    for (int i = 0; i < nb; ++i) d[i] = i;
+    std::vector<double> out((size_t)nb * bd * bd);
+    const int rc = g2ohip_ls_solve_pattern(_ls, nb, _colptr.data(), _rowidx.data(), _values.data(), nb, d.data(), d.data(), out.data());
+    if (rc != G2OHIP_OK) {
+      if (rc != G2OHIP_NOT_PD) std::cerr << "LinearSolverHip::solveBlocks: " << g2ohip_last_error() << std::endl;
+      return false;
+    }
+    if (!blocks) {
+      blocks = new double*[A.rows()];                   // (the reference sizes the pointer array by rows, :160)
+      for (int i = 0; i < nb; ++i) blocks[i] = new double[bd * bd];
+    }
+    for (int i = 0; i < nb; ++i) std::memcpy(blocks[i], &out[(size_t)i * bd * bd], sizeof(double) * bd * bd);
+    return true;
+  }
+
   // blocks of A^-1 (linear_solver.h:71; LinearSolverCSparse::solvePattern, linear_solver_csparse.h:190-221): factorise,
   // then every requested block on the pattern of the factor from one sparse-inverse pass
   virtual bool solvePattern(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices,

@@ -156,6 +156,7 @@ class LinearSolver {                                    // g2o/core/linear_solve
   virtual ~LinearSolver();
   virtual bool init() = 0;
   virtual bool solve(const SparseBlockMatrix<MatrixType>& A, double* x, double* b) = 0;
+  virtual bool solveBlocks(double**& blocks, const SparseBlockMatrix<MatrixType>& A);   // :64
   virtual bool solvePattern(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices,
                             const SparseBlockMatrix<MatrixType>& A);   // :71
 };
