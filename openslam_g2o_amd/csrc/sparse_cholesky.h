@@ -48,6 +48,9 @@ struct CholOptions {
   int mfma_diag = 1;                     // scratch-slab fronts: pivot block on the matrix cores (four waves) instead of one wave with v_readlane broadcasts
   int fuse_panel = 1;                    // scratch-slab fronts: panel solve and trailing update of a level in one launch
   int inplace_chains = 1;                // chains of scratch-slab fronts with identical rows (panels of one large supernode) are factorised in place
+  int hoist_big_assembly = 1;            // zero fill + original blocks of ALL scratch-slab fronts of a phase in two launches up front (their slab regions are never reused)
+  int split_sweeps = 1;                  // forward / backward step of scratch-slab fronts by several workgroups per front (256 boundary rows each)
+  int split_sweeps_min_dim = 512;        // ... on levels whose largest such front has at least this many rows
   int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
@@ -215,6 +218,9 @@ class SparseCholesky {
   DevBuf<ChildDesc> d_cdesc;
   DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts;
   DevBuf<double> d_L, d_U, d_w, d_y, d_xp, d_scratch;
+  int hz_begin_[2] = {0, 0}, hz_count_[2] = {0, 0}, ha_begin_[2] = {0, 0}, ha_count_[2] = {0, 0};   // phase-wide fill / assembly chunks (d_big_tiles)
+  DevBuf<double> d_sw_part;     // multi-workgroup backward step: per row chunk the partial L21' x (64 doubles)
+  DevBuf<int> d_sw_cnt;         // ... and per launch slot the chunks that have delivered (the last one finishes the front and resets it)
   DevBuf<double> d_sweep_vec;   // vectors of the triangular sweeps of fronts too large for LDS
   // per level launch info
   struct LevelLaunch {
@@ -223,6 +229,9 @@ class SparseCholesky {
     int max_panel = 0;                                   // max m*npiv (doubles) for solve kernels
     int max_m = 0;
     int fz_begin = 0, fz_count = 0;                      // zero-fill chunks of the scratch-slab fronts that start a region at this level
+    bool hoisted = false;                                // its fill / assembly chunks are also in the phase-wide lists (hz_ / ha_)
+    int lds_max_panel = 0;                               // max_panel over the LDS / register fronts only
+    int sw_begin = 0, sw_count = 0;                      // row chunks of the scratch-slab fronts for the multi-workgroup sweeps (d_big_tiles); 0: not eligible
     int lds_vec_m = 0;                                   // largest front dimension among the LDS / register fronts only (their vectors in LDS)
     int lds_idx_ints = 0, glb_idx_ints = 0;              // staged index lists (ints) per front, max over the launch
     bool fuse_fwd = true;                                // every LDS front of the launch is within the fused forward sweep's limits

@@ -893,11 +893,13 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   for (LevelLaunch& LL : launches_[ph]) {
     LL.lds_idx_ints = LL.glb_idx_ints = LL.sm_idx_ints = 0;
     LL.lds_vec_m = 0;
+    LL.lds_max_panel = 0;
     for (int q = LL.lds_begin; q < LL.glb_begin + LL.glb_count; ++q) {
       const int t = S.level_fronts[q];
       for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
         const FrontRec& R = recs[S.task_fronts[k]];
         if (q < LL.glb_begin) LL.lds_vec_m = std::max(LL.lds_vec_m, (R.ns + R.nb) * bs);
+        if (q < LL.glb_begin) LL.lds_max_panel = std::max(LL.lds_max_panel, (R.ns + R.nb) * bs * R.ns * bs + R.ns * bs);
         if (q < LL.glb_begin) {   // may the factor kernel carry the forward sweep of this launch?
           const int nthr = LL.sm_count > 0 ? 128 : kFactorThreads;
           bool ok = R.child_cnt <= kFwdChildren && R.ns * bs <= nthr;
@@ -914,6 +916,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   // --- trailing-update tiles of the scratch-slab fronts (big_front_update_kernel), per level launch
   {
     std::vector<int4> bt;
+    int sw_max = 0;
     for (int ph = 0; ph < 2; ++ph)
       for (LevelLaunch& LL : launches_[ph]) {
         LL.bt_begin = (int)bt.size();
@@ -967,9 +970,46 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           for (int r = 0; r < rows; r += 256) bt.push_back(make_int4(q, r, 0, 0));
         }
         LL.tr_count = (int)bt.size() - LL.tr_begin;
+        // row chunks for the multi-workgroup sweeps (big_forward_kernel / big_backward_kernel): the chunks of a front are
+        // contiguous, w = ordinal | count << 16
+        LL.sw_begin = (int)bt.size();
+        bool sw_ok = LL.glb_count > 0;
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count && sw_ok; ++q) {
+          const int t = S.level_fronts[q];
+          if (S.task_ptr[t + 1] - S.task_ptr[t] != 1 || S.f_ns[S.task_fronts[S.task_ptr[t]]] * bs > 64) sw_ok = false;
+        }
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count && sw_ok; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          const int rows = S.f_nb[f] * bs, G = std::max(1, (rows + 255) / 256);
+          for (int g = 0; g < G; ++g) bt.push_back(make_int4(f, g * 256, std::max(0, std::min(256, rows - g * 256)), g | (G << 16)));
+        }
+        LL.sw_count = (int)bt.size() - LL.sw_begin;
+        sw_max = std::max(sw_max, LL.sw_count);
       }
+    // phase-wide copies of the fill and assembly chunks: the regions of the slab are never reused and the original
+    // blocks do not depend on any child, so both passes can run once per phase instead of once per level
+    for (int ph = 0; ph < 2; ++ph) {
+      auto hoistable = [&](const LevelLaunch& LL) {
+        return LL.big_ok && opt.big_front_passes && LL.glb_count > 0 && LL.glb_max_m >= opt.big_front_min_dim;
+      };
+      hz_begin_[ph] = (int)bt.size();
+      for (LevelLaunch& LL : launches_[ph])
+        if (hoistable(LL))
+          for (int i = 0; i < LL.fz_count; ++i) { const int4 c = bt[LL.fz_begin + i]; bt.push_back(c); }
+      hz_count_[ph] = (int)bt.size() - hz_begin_[ph];
+      ha_begin_[ph] = (int)bt.size();
+      for (LevelLaunch& LL : launches_[ph]) {
+        LL.hoisted = hoistable(LL);
+        if (LL.hoisted)
+          for (int i = 0; i < LL.ba_count; ++i) { const int4 c = bt[LL.ba_begin + i]; bt.push_back(c); }
+      }
+      ha_count_[ph] = (int)bt.size() - ha_begin_[ph];
+    }
     if (bt.empty()) bt.push_back(make_int4(0, 0, 0, 0));
     d_big_tiles.upload(bt, st);
+    d_sw_part.alloc((size_t)std::max(sw_max, 1) * 64);
+    d_sw_cnt.alloc((size_t)nf + 1);
+    d_sw_cnt.zero(st);
   }
   // --- factorisation launch groups.  Consecutive levels with the same kernel variant (and nothing the fused
   // kernel cannot carry) may share one launch: workgroups are dispatched in blockIdx order and the slots are in
@@ -2706,6 +2746,226 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int 
   }
 }
 
+// Forward / backward step of the scratch-slab fronts of a level by SEVERAL workgroups per front.  One workgroup per front
+// (front_forward_kernel / front_backward_kernel) pulls the whole m x npiv panel through one CU: ~55 GB/s, 14-16 us for
+// the 2 000-row fronts at the top of a pose graph's tree, on the critical path of every level.  Here a workgroup owns 256
+// boundary rows (chunk (front, first row, rows, ordinal | count << 16)):
+//   forward : every chunk solves the pivot part redundantly (L11 in LDS, same operation order as the one-workgroup
+//             kernel: results are bit-identical to it), then updates its own rows of the update vector;
+//   backward: every chunk reduces its rows of L21' x_boundary to 64 partial sums (lanes along the rows: coalesced), the
+//             chunk that delivers last adds the partials in chunk order and solves with L11' (hand-off as described above
+//             ld_coh: agent-scope stores, vmcnt(0), barrier, one agent-scope increment).
+template <int BS>
+__global__ void __launch_bounds__(256) big_forward_kernel(CholPlanDev P, const int4* __restrict__ chunks, const double* __restrict__ bperm,
+                                                         double* __restrict__ y) {
+  __shared__ double L11[64 * 65], li[64], tJ[64], ys[64], tB[256];
+  const int4 ck = chunks[blockIdx.x];
+  const int f = ck.x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int npiv = rec.ns * BS, m = (rec.ns + rec.nb) * BS, c0 = rec.c0;
+  const int r0 = ck.y, nrows = ck.z;
+  const int tid = threadIdx.x;
+  const double* Lg = P.L + rec.L_off;
+  // Everything that depends on the front record only is requested before the first wait (one round trip): this
+  // thread's row of the panel, the pivot block, the right-hand side and the update vectors of the first two children
+  // (embedded in the record; up to 1 024 boundary rows each).
+  double lv[64];
+  {
+    const double* Lr = Lg + npiv + r0 + min(tid, max(nrows - 1, 0));
+#pragma unroll
+    for (int k = 0; k < 64; ++k) lv[k] = (nrows > 0 && k < npiv) ? Lr[(size_t)m * k] : 0.0;
+  }
+  const int nch = rec.child_cnt;
+  const int n0 = nch > 0 ? rec.ch[0].nbc * BS : 0, n1 = nch > 1 ? rec.ch[1].nbc * BS : 0;
+  const bool fast = nch <= 2 && n0 <= 1024 && n1 <= 1024;
+  double cw[2][4];
+  int cd_[2][4];
+  if (fast) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int nc = c == 0 ? n0 : n1;
+      const double* wc = P.w + rec.ch[c].w_off;
+      const int* rel = P.crel + rec.crel_off + rec.ch[c].crel_start;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = tid + 256 * u;
+        const bool on = i < nc;
+        cw[c][u] = on ? wc[i] : 0.0;
+        cd_[c][u] = on ? rel[i / BS] * BS + i % BS : -1;
+      }
+    }
+  }
+  for (int i = tid; i < npiv * npiv; i += 256) {
+    const int r = i % npiv, c = i / npiv;
+    L11[r + 65 * c] = Lg[r + (size_t)m * c];
+  }
+  if (tid < npiv) {
+    li[tid] = Lg[(size_t)m * npiv + tid];
+    tJ[tid] = bperm[(size_t)c0 * BS + tid];
+  }
+  tB[tid] = 0.0;
+  __syncthreads();
+  // children one at a time (rows of two children may coincide), in child order like the one-workgroup kernel
+  if (fast) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < nch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int d = cd_[c][u];
+          if (d >= 0) {
+            if (d < npiv) {
+              tJ[d] += cw[c][u];
+            } else {
+              const int r = d - npiv - r0;
+              if (r >= 0 && r < nrows) tB[r] += cw[c][u];
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+    for (int ch = 0; ch < nch; ++ch) {
+      const ChildDesc cd = P.cdesc[rec.child_off + ch];
+      const int nbc = cd.nbc * BS;
+      const double* wc = P.w + cd.w_off;
+      const int* rel = P.crel + rec.crel_off + cd.crel_start;
+      for (int i = tid; i < nbc; i += 256) {
+        const int d = rel[i / BS] * BS + i % BS;
+        if (d < npiv) {
+          tJ[d] += wc[i];
+        } else {
+          const int r = d - npiv - r0;
+          if (r >= 0 && r < nrows) tB[r] += wc[i];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int kb = 0; kb < rec.ns; ++kb) {
+    const int k0 = kb * BS;
+    double yv[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      double v = tJ[k0 + c];
+#pragma unroll
+      for (int q = 0; q < c; ++q) v -= L11[(k0 + c) + 65 * (k0 + q)] * yv[q];
+      yv[c] = v * li[k0 + c];
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int c = 0; c < BS; ++c) ys[k0 + c] = yv[c];
+    }
+    const int j = k0 + BS + tid;
+    if (j < npiv) {
+      double v = tJ[j];
+#pragma unroll
+      for (int q = 0; q < BS; ++q) v -= L11[j + 65 * (k0 + q)] * yv[q];
+      tJ[j] = v;
+    }
+    __syncthreads();
+  }
+  if (tid < nrows) {
+    double v = tB[tid];
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+      if (k < npiv) v -= lv[k] * ys[k];
+    P.w[rec.w_off + r0 + tid] = v;
+  }
+  if ((ck.w & 0xffff) == 0 && tid < npiv) y[(size_t)c0 * BS + tid] = ys[tid];
+}
+
+template <int BS>
+__global__ void __launch_bounds__(256) big_backward_kernel(CholPlanDev P, const int4* __restrict__ chunks, const double* __restrict__ y,
+                                                          double* __restrict__ xp, double* __restrict__ part, int* __restrict__ cnt) {
+  __shared__ double L11[64 * 65], li[64], t[64], xs[64], xB[256];
+  __shared__ int last_s;
+  const int4 ck = chunks[blockIdx.x];
+  const int f = ck.x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int npiv = rec.ns * BS, m = (rec.ns + rec.nb) * BS, c0 = rec.c0;
+  const int r0 = ck.y, nrows = ck.z, g = ck.w & 0xffff, G = ck.w >> 16;
+  const double yk = (threadIdx.x < npiv) ? y[(size_t)c0 * BS + threadIdx.x] : 0.0;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double* Lg = P.L + rec.L_off;
+  // wave wv: columns wv, wv + 4, ...; lanes along the rows of the chunk (four rows per lane); all loads in flight first
+  double lv[16][4];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int k = wv + 4 * kk;
+    const double* Lk = Lg + (size_t)m * min(k, npiv - 1) + npiv + r0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lv[kk][u] = (k < npiv && lane + 64 * u < nrows) ? Lk[lane + 64 * u] : 0.0;
+  }
+  {
+    const int* rows = P.rows + rec.rows_off;
+    const int r = r0 + tid;
+    xB[tid] = (tid < nrows) ? ld_coh(xp + (size_t)rows[r / BS] * BS + r % BS) : 0.0;
+  }
+  for (int i = tid; i < npiv * npiv; i += 256) {
+    const int r = i % npiv, c = i / npiv;
+    L11[r + 65 * c] = Lg[r + (size_t)m * c];
+  }
+  if (tid < npiv) li[tid] = Lg[(size_t)m * npiv + tid];
+  __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int k = wv + 4 * kk;
+    double s = (lv[kk][0] * xB[lane] + lv[kk][1] * xB[lane + 64]) + (lv[kk][2] * xB[lane + 128] + lv[kk][3] * xB[lane + 192]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0 && k < npiv) {
+      if (G > 1) st_coh(part + (size_t)blockIdx.x * 64 + k, s);
+      else xs[k] = s;   // (a front of one chunk: no hand-off)
+    }
+  }
+  if (G > 1) {
+    __builtin_amdgcn_s_waitcnt(0);   // the partial sums have been acknowledged at the device-coherent level
+    __syncthreads();
+    if (tid == 0) {
+      const int prev = __hip_atomic_fetch_add(cnt + f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_s = prev == G - 1;
+      if (prev == G - 1) __hip_atomic_store(cnt + f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next solve)
+    }
+    __syncthreads();
+    if (!last_s) return;
+    if (tid < npiv) {
+      double a = 0.0;
+      const double* p0 = part + (size_t)(blockIdx.x - g) * 64 + tid;
+      for (int gg = 0; gg < G; ++gg) a += ld_coh(p0 + (size_t)gg * 64);
+      t[tid] = yk - a;
+    }
+  } else {
+    __syncthreads();
+    if (tid < npiv) t[tid] = yk - xs[tid];
+  }
+  __syncthreads();
+  for (int kb = rec.ns - 1; kb >= 0; --kb) {
+    const int k0 = kb * BS;
+    double xv[BS];
+#pragma unroll
+    for (int c = BS - 1; c >= 0; --c) {
+      double v = t[k0 + c];
+#pragma unroll
+      for (int q = c + 1; q < BS; ++q) v -= L11[(k0 + q) + 65 * (k0 + c)] * xv[q];
+      xv[c] = v * li[k0 + c];
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int c = 0; c < BS; ++c) xs[k0 + c] = xv[c];
+    }
+    if (tid < k0) {
+      double v = t[tid];
+#pragma unroll
+      for (int q = 0; q < BS; ++q) v -= L11[(k0 + q) + 65 * tid] * xv[q];
+      t[tid] = v;
+    }
+    __syncthreads();
+  }
+  if (tid < npiv) st_coh(xp + (size_t)c0 * BS + tid, xs[tid]);
+}
+
 // exchange segments: dir 0 = pack (own subtree roots -> buffer), dir 1 = unpack (foreign roots <- buffer)
 struct SegCopyDev { long long a, b; int n, flags; };
 __global__ void seg_copy_kernel(const SegCopyDev* __restrict__ segs, double* __restrict__ U, double* __restrict__ w,
@@ -2869,6 +3129,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   int ba_begin, ba_count, tr_begin, tr_count;
   const std::vector<std::pair<int, int>>* be_pass;
   int fz_begin, fz_count;
+  bool hoisted = false;   // fill + assembly already done by the phase-wide passes
   const int* ld;   // leading dimension per launch slot
   bool fuse_panel;   // big_panel_kernel instead of big_trsm_kernel + big_front_update_kernel
   bool mfma_diag;    // big_diag_mfma_kernel instead of big_diag_kernel
@@ -2931,11 +3192,11 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
   }
   if (!(parts & 2)) return;
   if (glb_count > 0 && big.ok) {   // large fronts as whole-GPU passes
-    if (big.fz_count > 0) {   // zero the regions that start at this level (a kernel: hipMemsetAsync reaches ~1 TB/s only)
+    if (big.fz_count > 0 && !big.hoisted) {   // zero the regions that start at this level (a kernel: hipMemsetAsync reaches ~1 TB/s only)
       hipLaunchKernelGGL(big_fill_kernel, dim3(big.fz_count), dim3(256), 0, st, big.chunks + big.fz_begin, d_scratch, d_scratch_off);
       G2OHIP_LAUNCH_CHECK("big_fill_kernel");
     }
-    if (big.ba_count > 0)
+    if (big.ba_count > 0 && !big.hoisted)
       hipLaunchKernelGGL((big_assemble_kernel<BS, VIRT>), dim3(big.ba_count), dim3(256), 0, st, P, big.chunks + big.ba_begin, dA, d_scratch,
                          d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_assemble_kernel");
@@ -3031,7 +3292,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   CholPlanDev fplan = plan_;
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
-                      LL.fz_begin, LL.fz_count, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0};
+                      LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
@@ -3094,6 +3355,29 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     dbg_launch_ = 0;
   }
 #endif
+  if (opt.hoist_big_assembly && (hz_count_[phase] > 0 || ha_count_[phase] > 0)) {
+    const bool virt = dA == nullptr;
+    if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
+    if (hz_count_[phase] > 0)
+      hipLaunchKernelGGL(big_fill_kernel, dim3(hz_count_[phase]), dim3(256), 0, st, d_big_tiles.p + hz_begin_[phase], d_scratch.p, d_scratch_off.p);
+    G2OHIP_LAUNCH_CHECK("big_fill_kernel");
+    if (ha_count_[phase] > 0) {
+      const int4* ch = d_big_tiles.p + ha_begin_[phase];
+      CholPlanDev fplan = plan_;
+      fplan.slots = d_fslots.p;   // (as launch_factor)
+#define G2OHIP_HOIST_ASM(BS_)                                                                                                    \
+  if (virt) hipLaunchKernelGGL((big_assemble_kernel<BS_, true>), dim3(ha_count_[phase]), dim3(256), 0, st, fplan, ch, dA, d_scratch.p, d_scratch_off.p, d_scratch_ld.p); \
+  else hipLaunchKernelGGL((big_assemble_kernel<BS_, false>), dim3(ha_count_[phase]), dim3(256), 0, st, fplan, ch, dA, d_scratch.p, d_scratch_off.p, d_scratch_ld.p)
+      switch (bs_) {
+        case 3: G2OHIP_HOIST_ASM(3); break;
+        case 6: G2OHIP_HOIST_ASM(6); break;
+        case 7: G2OHIP_HOIST_ASM(7); break;
+        default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
+      }
+#undef G2OHIP_HOIST_ASM
+      G2OHIP_LAUNCH_CHECK("big_assemble_kernel");
+    }
+  }
   bool fwd_pending = false;   // a forward step of large fronts is in flight on side_[1] (event ev_[3])
   for (const FactorGroup& G : groups_[phase]) {
     if (G.dep && dep_off_) {   // (groups only hold levels the fused kernel carries completely)
@@ -3366,20 +3650,41 @@ void SparseCholesky::factor_solve(const double* dA, const double* d_b, double* d
 
 void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only, bool dep) {
   const size_t panel_limit = 48 * 1024;  // bytes of L panel staged in LDS
-  const int count = glb_only ? LL.glb_count : LL.lds_count + LL.glb_count;
+  int count = glb_only ? LL.glb_count : LL.lds_count + LL.glb_count;
   // dep: backward sweep of a dependency-driven group (no scratch-slab tasks) over the reversed slot list
   const int slot0 = dep ? n_slots_ - (LL.lds_begin + LL.lds_count) : (glb_only ? LL.glb_begin : LL.lds_begin);
   if (count == 0) return;
   CholPlanDev bplan = plan_;
   if (dep) bplan.slots = d_bslots.p;
   const int depi = dep ? 1 : 0;
-  bool panel = (size_t)LL.max_panel * 8 <= panel_limit;
-  int cap = panel ? LL.max_panel : 0;
-  int nthreads = LL.max_m <= 64 ? 64 : (LL.max_m <= 128 ? 128 : 256);
-  size_t sh = ((size_t)cap + 3 * (size_t)LL.max_m + nthreads + 8) * sizeof(double);
+  int max_m = LL.max_m, max_panel = LL.max_panel;
+  if (!dep && opt.split_sweeps && LL.sw_count > 0 && LL.glb_max_m >= opt.split_sweeps_min_dim) {
+    // the scratch-slab fronts of the level: several workgroups per front; the LDS / register fronts (independent of
+    // them: same level) follow in their own launch, sized for themselves
+    const int4* ch = d_big_tiles.p + LL.sw_begin;
+#define G2OHIP_SPLIT_SWEEP(BS_)                                                                                                 \
+  if (fwd) hipLaunchKernelGGL((big_forward_kernel<BS_>), dim3(LL.sw_count), dim3(256), 0, st, plan_, ch, d_xp.p, d_y.p);          \
+  else hipLaunchKernelGGL((big_backward_kernel<BS_>), dim3(LL.sw_count), dim3(256), 0, st, plan_, ch, d_y.p, d_xp.p, d_sw_part.p, d_sw_cnt.p)
+    switch (bs_) {
+      case 3: G2OHIP_SPLIT_SWEEP(3); break;
+      case 6: G2OHIP_SPLIT_SWEEP(6); break;
+      case 7: G2OHIP_SPLIT_SWEEP(7); break;
+      default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
+    }
+#undef G2OHIP_SPLIT_SWEEP
+    G2OHIP_LAUNCH_CHECK("big_forward_kernel / big_backward_kernel");
+    if (glb_only || LL.lds_count == 0) return;
+    count = LL.lds_count;
+    max_m = LL.lds_vec_m;
+    max_panel = LL.lds_max_panel;
+  }
+  bool panel = (size_t)max_panel * 8 <= panel_limit;
+  int cap = panel ? max_panel : 0;
+  int nthreads = max_m <= 64 ? 64 : (max_m <= 128 ? 128 : 256);
+  size_t sh = ((size_t)cap + 3 * (size_t)max_m + nthreads + 8) * sizeof(double);
   double* gvec = nullptr;
   if (sh > 160 * 1024) {   // vectors of the fronts in HBM (dense reduced systems: fronts beyond ~6 500 rows)
-    const size_t need = (size_t)count * 3 * (size_t)LL.max_m;
+    const size_t need = (size_t)count * 3 * (size_t)max_m;
     if (d_sweep_vec.n < need) d_sweep_vec.alloc(need);
     gvec = d_sweep_vec.p;
     cap = 0;
@@ -3404,19 +3709,19 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
 #define G2OHIP_SOLVE_LAUNCH(BS_)                                                                                              \
   if (gvec) {   /* (fronts beyond the LDS limit: never with a staged panel) */                                                \
     if (fwd)                                                                                                                  \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, false, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, 0, LL.max_m, gvec); \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, false, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, 0, max_m, gvec); \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, false, true>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, 0, LL.max_m, depi, gvec); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, false, true>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, 0, max_m, depi, gvec); \
   } else if (fwd) {                                                                                                           \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m, gvec);  \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, max_m, gvec);  \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, LL.max_m, gvec); \
+      hipLaunchKernelGGL((front_forward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, plan_, slot0, d_xp.p, d_y.p, cap, max_m, gvec); \
   } else {                                                                                                                    \
     if (panel)                                                                                                                \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, LL.max_m, depi, gvec); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, true>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, max_m, depi, gvec); \
     else                                                                                                                      \
-      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, LL.max_m, depi, gvec); \
+      hipLaunchKernelGGL((front_backward_kernel<BS_, false>), dim3(count), dim3(nthreads), sh, st, bplan, slot0, d_y.p, d_xp.p, cap, max_m, depi, gvec); \
   }
   switch (bs_) {
     case 3: G2OHIP_SOLVE_LAUNCH(3) break;
