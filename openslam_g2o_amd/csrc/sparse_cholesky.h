@@ -49,6 +49,7 @@ struct CholOptions {
   int fuse_panel = 1;                    // scratch-slab fronts: panel solve and trailing update of a level in one launch
   int inplace_chains = 1;                // chains of scratch-slab fronts with identical rows (panels of one large supernode) are factorised in place
   int hoist_big_assembly = 1;            // zero fill + original blocks of ALL scratch-slab fronts of a phase in two launches up front (their slab regions are never reused)
+  int fuse_big_forward = 1;              // forward step of scratch-slab fronts inside the pivot-block and panel kernels (levels on the fused panel path)
   int split_sweeps = 1;                  // forward / backward step of scratch-slab fronts by several workgroups per front (256 boundary rows each)
   int split_sweeps_min_dim = 512;        // ... on levels whose largest such front has at least this many rows
   int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
@@ -265,7 +266,8 @@ class SparseCholesky {
   void launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep = false, int parts = 3);
   hipStream_t side_[2] = {nullptr, nullptr};   // factor_phase: the two halves of a level / the forward step of its large fronts
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
-  void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false);
+  void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false, bool skip_glb = false);
+  bool big_forward_carried(const LevelLaunch& LL) const;   // the forward step of the level's scratch-slab fronts rides along in their factorisation
   CholPlanDev plan_{};
 };
 

@@ -2335,6 +2335,67 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
       }
 }
 
+// Children's update vectors added to the rows [lo, lo + cnt) of a front's right-hand side kept in LDS (dst[0 .. cnt)),
+// one child at a time and in child order (rows of two children may coincide; same order as front_forward_kernel).  The
+// loads of the first two children (embedded in the front record, up to 1 024 boundary rows each) are issued by
+// fwd_children_prefetch before the caller's own work and consumed here.  All 256 threads of the workgroup call both.
+struct FwdChildPre {
+  double w[2][4];
+  int d[2][4];
+  bool fast;
+};
+template <int BS>
+__device__ __forceinline__ void fwd_children_prefetch(const CholPlanDev& P, const FrontRec& rec, int tid, FwdChildPre& pre) {
+  const int nch = rec.child_cnt;
+  const int n0 = nch > 0 ? rec.ch[0].nbc * BS : 0, n1 = nch > 1 ? rec.ch[1].nbc * BS : 0;
+  pre.fast = nch <= 2 && n0 <= 1024 && n1 <= 1024;
+  if (!pre.fast) return;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int nc = c == 0 ? n0 : n1;
+    const double* wc = P.w + rec.ch[c].w_off;
+    const int* rel = P.crel + rec.crel_off + rec.ch[c].crel_start;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u;
+      const bool on = i < nc;
+      pre.w[c][u] = on ? wc[i] : 0.0;
+      pre.d[c][u] = on ? rel[i / BS] * BS + i % BS : -1;
+    }
+  }
+}
+template <int BS>
+__device__ __forceinline__ void fwd_children_apply(const CholPlanDev& P, const FrontRec& rec, int tid, const FwdChildPre& pre, double* dst,
+                                                   int lo, int cnt, double* dst2 = nullptr, int lo2 = 0, int cnt2 = 0) {
+  // (two disjoint row ranges of the front: dst <- [lo, lo + cnt), dst2 <- [lo2, lo2 + cnt2))
+  const int nch = rec.child_cnt;
+  auto put = [&](int d, double v) {
+    const int r = d - lo, r2 = d - lo2;
+    if (r >= 0 && r < cnt) dst[r] += v;
+    else if (r2 >= 0 && r2 < cnt2) dst2[r2] += v;
+  };
+  if (pre.fast) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < nch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (pre.d[c][u] >= 0) put(pre.d[c][u], pre.w[c][u]);
+        __syncthreads();
+      }
+    }
+  } else {
+    for (int ch = 0; ch < nch; ++ch) {
+      const ChildDesc cd = P.cdesc[rec.child_off + ch];
+      const int nbc = cd.nbc * BS;
+      const double* wc = P.w + cd.w_off;
+      const int* rel = P.crel + rec.crel_off + cd.crel_start;
+      for (int i = tid; i < nbc; i += 256) put(rel[i / BS] * BS + i % BS, wc[i]);
+      __syncthreads();
+    }
+  }
+}
+
 // Panel solve and trailing update of the scratch-slab fronts of one level in ONE launch (two otherwise: on the critical
 // path of a pose graph every launch is ~5 us of start-up next to a few us of work).  A workgroup owns a 64 x 64 tile of
 // a trailing matrix: it solves ITS 2 x 64 panel rows against L11' itself (the rows of a tile are solved again by the
@@ -2342,9 +2403,15 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
 // keeps them in LDS as the operands of the MFMA update and -- the tiles of the first tile column -- writes them to L.
 // (A variant that also carried the pivot block, with flags between workgroups, needed the registers of both roles at
 // once: 674 spilled registers, slower than three launches.)
-template <int BS>
+// FWD: the forward step of the front rides along, no forward launch of its own for the level (12 us on the chain).  The
+// tiles of the first tile column hold L11 and their 64 solved panel rows in LDS: while waves 0-1 solve the panel rows,
+// wave 2 solves the pivot part y = L11^-1 (b + children's w) (one wave, column by column, no barriers; the operation
+// order per row is that of front_forward_kernel: bit-identical), then the rows of the update vector follow:
+// w = (children's w) - L21 y.  Tile (0, 0) stores y.  (Fronts without boundary rows have no tiles: big_diag_mfma_kernel.)
+template <int BS, bool FWD>
 __global__ void __launch_bounds__(256) big_panel_kernel(CholPlanDev P, const int4* __restrict__ tiles, double* __restrict__ scratch,
-                                                       const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
+                                                       const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
+                                                       const double* __restrict__ bperm, double* __restrict__ yout) {
   extern __shared__ __attribute__((aligned(16))) double psm[];
   constexpr int BB = BS * BS, MAXB = 64 / BS, NX = MAXB * BS;
   const int tid = threadIdx.x;
@@ -2361,6 +2428,15 @@ __global__ void __launch_bounds__(256) big_panel_kernel(CholPlanDev P, const int
   double* inv = S + 64 * 65;       // 1 / diagonal
   double* XR = inv + 64;           // solved rows of the tile's row range, [64][65]: XR[row + 65 k]
   double* XC = XR + 64 * 65;       // ... of its column range
+  double* tB = XC + 64 * 65;       // FWD: right-hand side rows of the tile row range, [64]
+  double* ysl = tB + 64;           // FWD: pivot part of the right-hand side, then of the solution, [64]
+  FwdChildPre pre;
+  const bool fwd_rows = FWD && td.z == 0;
+  double bJ = 0.0;
+  if (fwd_rows) {
+    fwd_children_prefetch<BS>(P, rec, tid, pre);
+    if (tid < n) bJ = bperm[(size_t)rec.c0 * BS + tid];
+  }
   // this thread's panel row (threads 0..63: row range, 64..127: column range), requested before the wait
   const bool rowthr = tid < 128;
   const int rloc = tid & 63;
@@ -2384,8 +2460,35 @@ __global__ void __launch_bounds__(256) big_panel_kernel(CholPlanDev P, const int
       if (i < n * n) S[(i % n) + 65 * (i / n)] = t[u];
     }
     if (tid < n) inv[tid] = iv;
+    if (fwd_rows && tid < 64) {
+      tB[tid] = 0.0;
+      ysl[tid] = bJ;
+    }
   }
   __syncthreads();
+  if (fwd_rows) fwd_children_apply<BS>(P, rec, tid, pre, tB, n + td.y * 64, 64, ysl, 0, n);
+  if (fwd_rows && (tid >> 6) == 2) {   // wave 2: y = L11^-1 t, next to the row solves of waves 0-1
+    const int l = tid & 63;
+    double tj = l < n ? ysl[l] : 0.0, yk_mine = 0.0;
+    for (int k0 = 0; k0 < n; k0 += 8) {
+      double sv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sv[u] = (k0 + u < n && l < n) ? S[l + 65 * (k0 + u)] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u;
+        if (k < n) {   // (uniform)
+          const double yk = __shfl(tj, k) * inv[k];
+          if (l == k) yk_mine = yk;
+          if (l > k) tj -= sv[u] * yk;
+        }
+      }
+    }
+    if (l < n) {
+      ysl[l] = yk_mine;
+      if (td.y == 0) yout[(size_t)rec.c0 * BS + l] = yk_mine;
+    }
+  }
   if (rowthr) {   // x L11' = row (big_trsm_kernel)
     double* X = tid < 64 ? XR : XC;
 #pragma unroll
@@ -2415,6 +2518,11 @@ __global__ void __launch_bounds__(256) big_panel_kernel(CholPlanDev P, const int
       const int r = i & 63, k = i >> 6;
       if (td.y * 64 + r < mt) Lg[(size_t)(n + td.y * 64 + r) + (size_t)m * k] = XR[r + 65 * k];
     }
+  if (fwd_rows && tid < 64 && td.y * 64 + tid < mt) {
+    double v = tB[tid];
+    for (int k = 0; k < n; ++k) v -= XR[tid + 65 * k] * ysl[k];
+    P.w[rec.w_off + td.y * 64 + tid] = v;
+  }
   {   // rank-n update of this tile (big_front_update_kernel, operands from LDS)
     double* U = P.U + rec.U_off;
     const int wave = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
@@ -2994,10 +3102,15 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
 // scaled panel and rank-4 update one MFMA each).  The one-wave kernel (big_diag_kernel: a row per lane, columns broadcast
 // by v_readlane) needs n^2 / 2 readlane + FMA pairs in ONE instruction stream: 23 us for 48 columns, on the critical path
 // of every level of a pose graph; this one takes about half of that.
-template <int BS>
+// FWD: the forward step of fronts WITHOUT boundary rows (roots: no panel tiles) rides along; the others: big_panel_kernel.
+// Right-hand side and the children's update vectors are requested before the factorisation, y = L11^-1 t is solved from an
+// LDS copy of the finished pivot block with the operation order of front_forward_kernel.
+template <int BS, bool FWD>
 __global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int slot0, double* __restrict__ scratch,
-                                                           const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
+                                                           const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
+                                                           const double* __restrict__ bperm, double* __restrict__ yout) {
   __shared__ double Rb[4 * 64], Lb[4 * 64];
+  __shared__ double L11s[FWD ? 64 * 65 : 1], lis[FWD ? 64 : 1], tJ[FWD ? 64 : 1];
   constexpr int T = 4, NT = 10, NW = 4, OWN = 3;
   const int slot = slot0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3008,6 +3121,13 @@ __global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int s
   double* F = scratch + scratch_off[slot];
   double* Lg = P.L + rec.L_off;
   const int lr = lane & 15, lk = lane >> 4;
+  FwdChildPre pre;
+  double bJ = 0.0;
+  const bool fwd_here = FWD && rec.nb == 0;   // (fronts with boundary rows: big_panel_kernel)
+  if (fwd_here) {
+    fwd_children_prefetch<BS>(P, rec, tid, pre);
+    if (tid < n) bJ = bperm[(size_t)rec.c0 * BS + tid];
+  }
   int oti[OWN], otj[OWN];
 #pragma unroll
   for (int k = 0; k < OWN; ++k) {
@@ -3121,6 +3241,40 @@ __global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int s
     }
   }
   if (bad && lane == 0) atomicMax(P.status, 1);
+  if (fwd_here) {
+    if (tid < 64) tJ[tid] = bJ;
+    __syncthreads();   // (also: the pivot block written above is visible to the whole workgroup)
+    fwd_children_apply<BS>(P, rec, tid, pre, tJ, 0, n);
+    for (int i = tid; i < n * n; i += 256) {
+      const int r = i % n, c = i / n;
+      L11s[r + 65 * c] = Lg[(size_t)r + (size_t)m * c];
+    }
+    if (tid < n) lis[tid] = Lg[(size_t)m * n + tid];
+    __syncthreads();
+    for (int kb = 0; kb < rec.ns; ++kb) {
+      const int k0 = kb * BS;
+      double yv[BS];
+#pragma unroll
+      for (int c = 0; c < BS; ++c) {
+        double v = tJ[k0 + c];
+#pragma unroll
+        for (int q = 0; q < c; ++q) v -= L11s[(k0 + c) + 65 * (k0 + q)] * yv[q];
+        yv[c] = v * lis[k0 + c];
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < BS; ++c) yout[(size_t)rec.c0 * BS + k0 + c] = yv[c];
+      }
+      const int j = k0 + BS + tid;
+      if (j < n) {
+        double v = tJ[j];
+#pragma unroll
+        for (int q = 0; q < BS; ++q) v -= L11s[j + 65 * (k0 + q)] * yv[q];
+        tJ[j] = v;
+      }
+      __syncthreads();
+    }
+  }
 }
 
 struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one level (LevelLaunch::ba_* / be_pass / tr_*)
@@ -3130,6 +3284,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   const std::vector<std::pair<int, int>>* be_pass;
   int fz_begin, fz_count;
   bool hoisted = false;   // fill + assembly already done by the phase-wide passes
+  bool fwd = false;       // the forward step rides along in the pivot-block and panel kernels (big_forward_carried)
   const int* ld;   // leading dimension per launch slot
   bool fuse_panel;   // big_panel_kernel instead of big_trsm_kernel + big_front_update_kernel
   bool mfma_diag;    // big_diag_mfma_kernel instead of big_diag_kernel
@@ -3205,16 +3360,23 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
         hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
                            d_scratch_off);
     G2OHIP_LAUNCH_CHECK("big_extend_add_kernel");
-    if (big.mfma_diag)
-      hipLaunchKernelGGL((big_diag_mfma_kernel<BS>), dim3(glb_count), dim3(256), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
+    if (big.mfma_diag && big.fwd)
+      hipLaunchKernelGGL((big_diag_mfma_kernel<BS, true>), dim3(glb_count), dim3(256), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld, bperm, yout);
+    else if (big.mfma_diag)
+      hipLaunchKernelGGL((big_diag_mfma_kernel<BS, false>), dim3(glb_count), dim3(256), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld,
+                         (const double*)nullptr, (double*)nullptr);
     else
       hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_diag_kernel");
     if (big.fuse_panel && bt_count <= 256) {   // panel solve + update in one launch -- while the level is a latency chain (at most one
                                                // workgroup per CU); a level that fills the GPU pays for the rows solved more than once
       if (bt_count > 0) {
-        const size_t shp = (size_t)(3 * 64 * 65 + 64) * sizeof(double);
-        hipLaunchKernelGGL((big_panel_kernel<BS>), dim3(bt_count), dim3(256), shp, st, P, big_tiles, d_scratch, d_scratch_off, big.ld);
+        const size_t shp = (size_t)(3 * 64 * 65 + 64 + 128) * sizeof(double);
+        if (big.fwd)
+          hipLaunchKernelGGL((big_panel_kernel<BS, true>), dim3(bt_count), dim3(256), shp, st, P, big_tiles, d_scratch, d_scratch_off, big.ld, bperm, yout);
+        else
+          hipLaunchKernelGGL((big_panel_kernel<BS, false>), dim3(bt_count), dim3(256), shp, st, P, big_tiles, d_scratch, d_scratch_off, big.ld,
+                             (const double*)nullptr, (double*)nullptr);
         G2OHIP_LAUNCH_CHECK("big_panel_kernel");
       }
       return;
@@ -3283,6 +3445,13 @@ void SparseCholesky::set_virtual_blocks(const VirtualBlocks& vb, hipStream_t st)
   plan_.vsplit = vb.split ? 1 : 0;
 }
 
+bool SparseCholesky::big_forward_carried(const LevelLaunch& LL) const {
+  // (the conditions of the pivot-block kernel on the matrix cores, of the fused panel kernel and of single-front tasks with
+  // at most 64 pivot columns)
+  return opt.fuse_big_forward && opt.mfma_diag && opt.fuse_panel && opt.big_front_passes && LL.big_ok && LL.glb_count > 0 &&
+         LL.glb_max_m >= opt.big_front_min_dim && LL.bt_count <= 256 && LL.sw_count > 0;
+}
+
 void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep, int parts) {
 #ifdef G2OHIP_CHOL_STAMPS
   if (d_dbg.p) {
@@ -3292,7 +3461,8 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   CholPlanDev fplan = plan_;
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
-                      LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0};
+                      LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL), d_scratch_ld.p, opt.fuse_panel != 0,
+                      opt.mfma_diag != 0};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
@@ -3340,9 +3510,12 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, kFactorThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<7, true, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)big_panel_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)big_panel_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)big_panel_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_panel_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_panel_kernel<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_panel_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_panel_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_panel_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_panel_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipGetLastError();
     attr_done = true;
   }
@@ -3407,7 +3580,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
         G2OHIP_HIP_CHECK(hipEventRecord(ev_[1], side_[0]));
       }
       launch_factor(LL, dA, fused, st, false, 2);
-      if (fwd) {
+      if (fwd && !big_forward_carried(LL)) {
         G2OHIP_HIP_CHECK(hipEventRecord(ev_[2], st));
         G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_[1], ev_[2], 0));
         launch_solve(LL, true, side_[1], /*glb_only=*/true);
@@ -3424,8 +3597,9 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     launch_factor(LL, dA, fused, st, G.dep);
     // what the factor kernel did not carry (fronts too large for LDS, launches outside the fused kernel's
     // limits) gets its forward step inside the same level
-    if (fwd && !fused) launch_solve(LL, true, st);
-    else if (fwd && LL.glb_count > 0) launch_solve(LL, true, st, /*glb_only=*/true);
+    const bool carried = fwd && big_forward_carried(LL);   // (the scratch-slab fronts' forward step went with their factorisation)
+    if (fwd && !fused) launch_solve(LL, true, st, false, false, /*skip_glb=*/carried);
+    else if (fwd && LL.glb_count > 0 && !carried) launch_solve(LL, true, st, /*glb_only=*/true);
   }
   if (fwd_pending) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[3], 0));
   G2OHIP_HIP_CHECK(hipGetLastError());
@@ -3648,9 +3822,9 @@ void SparseCholesky::factor_solve(const double* dA, const double* d_b, double* d
   solve_end(d_x, st);
 }
 
-void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only, bool dep) {
+void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only, bool dep, bool skip_glb) {
   const size_t panel_limit = 48 * 1024;  // bytes of L panel staged in LDS
-  int count = glb_only ? LL.glb_count : LL.lds_count + LL.glb_count;
+  int count = glb_only ? LL.glb_count : LL.lds_count + (skip_glb ? 0 : LL.glb_count);
   // dep: backward sweep of a dependency-driven group (no scratch-slab tasks) over the reversed slot list
   const int slot0 = dep ? n_slots_ - (LL.lds_begin + LL.lds_count) : (glb_only ? LL.glb_begin : LL.lds_begin);
   if (count == 0) return;
@@ -3658,7 +3832,11 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
   if (dep) bplan.slots = d_bslots.p;
   const int depi = dep ? 1 : 0;
   int max_m = LL.max_m, max_panel = LL.max_panel;
-  if (!dep && opt.split_sweeps && LL.sw_count > 0 && LL.glb_max_m >= opt.split_sweeps_min_dim) {
+  if (skip_glb) {
+    max_m = LL.lds_vec_m;
+    max_panel = LL.lds_max_panel;
+  }
+  if (!dep && !skip_glb && opt.split_sweeps && LL.sw_count > 0 && LL.glb_max_m >= opt.split_sweeps_min_dim) {
     // the scratch-slab fronts of the level: several workgroups per front; the LDS / register fronts (independent of
     // them: same level) follow in their own launch, sized for themselves
     const int4* ch = d_big_tiles.p + LL.sw_begin;
