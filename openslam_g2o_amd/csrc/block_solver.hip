@@ -1395,21 +1395,35 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMP_OCC) ba_assemble_poses_k
   for (int i = 0; i < 6; ++i) b[i] = 0.0;
   const int k0 = active ? vptr[v] : 0, k1 = active ? vptr[v + 1] : 0;
   double T[12];
-  bool haveT = false;
-  for (int k = k0 + g; k < k1; k += G) {   // (pose-major arrays: streaming reads)
-    if (!haveT) {
-      load_vec<12>(cams + (size_t)cam_pm[k] * 12, T);
-      haveT = true;
-    }
+  // Software pipeline over this lane's observations (pose-major arrays: streaming reads; the point is a dependent
+  // gather): the point index is requested two observations ahead, the point, the measurement and the information
+  // matrix one ahead -- with ~2 waves per SIMD nothing else hides the two round trips per observation.
+  const int kf = k0 + g;
+  if (kf < k1) load_vec<12>(cams + (size_t)cam_pm[kf] * 12, T);
+  int pt1 = kf < k1 ? pt_pm[kf] : 0, pt2 = kf + G < k1 ? pt_pm[kf + G] : 0;
+  double Xn[3] = {0.0, 0.0, 0.0}, z2n[2] = {0.0, 0.0}, Opn[4] = {1.0, 0.0, 0.0, 1.0};
+  if (kf < k1) {
+    const double* Xp = pts + (size_t)pt1 * 3;
+    Xn[0] = Xp[0]; Xn[1] = Xp[1]; Xn[2] = Xp[2];
+    load_vec<2>(meas_pm + (size_t)kf * 2, z2n);
+    if (!ident) load_vec<4>(omega_pm + (size_t)kf * 4, Opn);
+  }
+  for (int k = kf; k < k1; k += G) {
     double X[3], z2[2], Op[4];
-    const double* Xp = pts + (size_t)pt_pm[k] * 3;
-    X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
-    load_vec<2>(meas_pm + (size_t)k * 2, z2);
-    if (ident) {
-      Op[0] = Op[3] = 1.0;
-      Op[1] = Op[2] = 0.0;
-    } else {
-      load_vec<4>(omega_pm + (size_t)k * 4, Op);
+    X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
+    z2[0] = z2n[0]; z2[1] = z2n[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Op[i] = Opn[i];
+    {
+      const int kn = k + G, kn2 = k + 2 * G;
+      const int pt3 = kn2 < k1 ? pt_pm[kn2] : 0;
+      if (kn < k1) {
+        const double* Xp = pts + (size_t)pt2 * 3;
+        Xn[0] = Xp[0]; Xn[1] = Xp[1]; Xn[2] = Xp[2];
+        load_vec<2>(meas_pm + (size_t)kn * 2, z2n);
+        if (!ident) load_vec<4>(omega_pm + (size_t)kn * 4, Opn);
+      }
+      pt2 = pt3;
     }
     BaEdgeLin L;
     ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, false, L);

@@ -512,6 +512,60 @@ def test_ba_with_large_fronts(fold):
     assert np.abs(r).max() <= 1e-9 * np.abs(s.b()).max()
 
 
+def _random_block_spd(bs, nb, dens, seed):
+    """Random block-sparse SPD matrix (dense array) and its upper block-CCS arrays (column-major blocks)."""
+    rng = np.random.default_rng(seed)
+    mask = np.triu(rng.random((nb, nb)) < dens, 1)
+    mask |= np.eye(nb, k=1, dtype=bool)                      # connected
+    n = nb * bs
+    A = np.zeros((n, n))
+    for j in range(nb):
+        for i in np.nonzero(mask[:, j])[0]:
+            A[i * bs:(i + 1) * bs, j * bs:(j + 1) * bs] = rng.normal(size=(bs, bs))
+    A = A + A.T
+    A += np.eye(n) * (np.abs(A).sum(axis=1).max() + 1.0)     # strictly diagonally dominant: SPD
+    cp, row, vals = [0], [], []
+    for j in range(nb):
+        for i in range(j + 1):
+            if i == j or mask[i, j]:
+                row.append(i)
+                vals.append(A[i * bs:(i + 1) * bs, j * bs:(j + 1) * bs].T.reshape(-1))
+        cp.append(len(row))
+    return A, np.array(cp, np.int32), np.array(row, np.int32), np.array(vals), rng
+
+
+@pytest.mark.parametrize("bs", [3, 6, 7])
+def test_scratch_slab_sweep_variants(bs):
+    """The forward / backward steps of the scratch-slab fronts exist in several forms (one workgroup per front; several
+    workgroups per front with ticketed partial sums; forward step inside the panel kernel; zero fill + original blocks
+    per level or per phase): every combination against a dense LAPACK solve, and the forms that promise the operation
+    order of the one-workgroup kernel bit for bit against it."""
+    capi = _capi()
+    A, cp, row, vals, rng = _random_block_spd(bs, 200 if bs > 3 else 380, 0.2, 70 + bs)
+    b = rng.normal(size=A.shape[0])
+    xr = np.linalg.solve(A, b)
+    variants = {
+        "default": {},
+        "split everywhere, own forward launch": {"split_sweeps_min_dim": 0, "fuse_big_forward": 0},
+        "forward in the panel kernel, one workgroup backward": {"split_sweeps": 0, "hoist_big_assembly": 0},
+        "one workgroup per front": {"split_sweeps": 0, "fuse_big_forward": 0, "hoist_big_assembly": 0},
+        "two-launch panel": {"fuse_panel": 0},
+    }
+    xs = {}
+    for name, opts in variants.items():
+        ls = capi.HipLinearSolver(bs, 0)
+        for k, v in opts.items():
+            ls.setOption(k, v)
+        ok, x = ls.solve(cp, row, vals, b)
+        assert ok, name
+        assert ls.stats()["maxFrontDim"] >= 512, "the case must reach the multi-workgroup sweeps"
+        assert relerr(x, xr) < 1e-10, name
+        ok, x2 = ls.solve(cp, row, vals, b)
+        assert ok and np.array_equal(x, x2), name + ": not repeatable"
+        xs[name] = x
+    assert np.array_equal(xs["forward in the panel kernel, one workgroup backward"], xs["one workgroup per front"])
+
+
 @pytest.mark.parametrize("bs", [3, 6, 7])
 @pytest.mark.parametrize("passes", [1, 0])
 def test_linear_solver_large_fronts_all_block_sizes(bs, passes):
