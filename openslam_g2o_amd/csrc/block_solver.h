@@ -234,6 +234,8 @@ class BlockSolver {
   hipStream_t side_ = nullptr;
   hipEvent_t side_fork_ = nullptr, side_join_ = nullptr;
   DevBuf<double> d_red_multi;              // trial_stats: partial sums of every reduction of the call
+  double* h_trial_ = nullptr;              // ... their pinned host copy (+ the factorisation status word): ONE synchronisation per trial
+  size_t h_trial_n_ = 0;
   int sync_status_ = -1;                   // status of a solve_async() that had to run synchronously (-1: none)
   bool deferred_status_ = false;           // a solve_async() whose status has not been read yet
   bool chi2_valid_ = false;                // chi2_value_ matches the errors / kernels of every edge set

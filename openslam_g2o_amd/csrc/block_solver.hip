@@ -1890,6 +1890,7 @@ BlockSolver::~BlockSolver() {
   if (side_fork_) (void)hipEventDestroy(side_fork_);
   if (side_join_) (void)hipEventDestroy(side_join_);
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
+  if (h_trial_) (void)hipHostFree(h_trial_);
 }
 
 void BlockSolver::set_stream(hipStream_t st) {
@@ -3621,15 +3622,30 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
 #undef G2OHIP_CHI
   }
   G2OHIP_HIP_CHECK(hipGetLastError());
-  std::vector<double> h((nsets + 1) * kMaxBlocks);
-  G2OHIP_HIP_CHECK(hipMemcpyAsync(h.data(), d_red_multi.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+  // read-back into pinned memory: the partial sums and (asynchronous solve) the status word of the factorisation are two
+  // copies behind each other and ONE synchronisation (a pageable destination made each copy a host round trip of its own)
+  const size_t hn = (nsets + 1) * kMaxBlocks;
+  if (h_trial_n_ < hn + 1) {
+    if (h_trial_) (void)hipHostFree(h_trial_);
+    h_trial_ = nullptr;
+    G2OHIP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_trial_), (hn + 1) * sizeof(double), hipHostMallocDefault));
+    h_trial_n_ = hn + 1;
+  }
+  double* h = h_trial_;
+  size_t copy_n = 0;   // only the slots in use
+  for (size_t k = 0; k <= nsets; ++k)
+    if (nblk[k] > 0) copy_n = (k + 1) * kMaxBlocks;
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(h, d_red_multi.p, copy_n * sizeof(double), hipMemcpyDeviceToHost, st_));
+  int* hstat = reinterpret_cast<int*>(h + hn);
   bool bad = false, stalled = false;
   if (sync_status_ >= 0) {
     bad = sync_status_ != 0;
     sync_status_ = -1;
     G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   } else if (deferred_status_) {
-    bad = chol_->failed(st_);   // synchronises (covers the copy above: same stream)
+    chol_->status_async(hstat, st_);
+    G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+    bad = chol_->failed_with(*hstat, st_);
     deferred_status_ = false;
     if (bad && chol_->dependency_stall() && ++dependency_fallbacks) {
       invalidate_graphs();   // the next solve runs level by level

@@ -187,6 +187,10 @@ class SparseCholesky {
   void set_virtual_split(bool split) { plan_.vsplit = split ? 1 : 0; }
   const int* status_device() const { return d_status.p; }   // 0 ok, 1 non-positive pivot, 2 dependency wait gave up
   bool failed(hipStream_t st);
+  // the same in two halves, for a caller that has its own read-back to synchronise on: status_async enqueues the copy of
+  // the status word into (pinned) host memory, failed_with interprets the value once the stream has been synchronised
+  void status_async(int* host, hipStream_t st) { G2OHIP_HIP_CHECK(hipMemcpyAsync(host, d_status.p, sizeof(int), hipMemcpyDeviceToHost, st)); }
+  bool failed_with(int h, hipStream_t st);
   // true once after failed() saw a dependency-driven launch give up waiting; those launches are off from then on
   // (the caller drops its captured graphs and repeats the solve)
   bool dependency_stall() { const bool v = dep_stalled_; dep_stalled_ = false; return v; }

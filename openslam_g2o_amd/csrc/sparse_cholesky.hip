@@ -3990,6 +3990,10 @@ bool SparseCholesky::failed(hipStream_t st) {
 #endif
   int h = 0;
   d_status.download(&h, 1, st);
+  return failed_with(h, st);
+}
+
+bool SparseCholesky::failed_with(int h, hipStream_t st) {
   if (h != 0 && d_ready.p) d_ready.zero(st);   // an aborted dependency-driven launch may leave counters behind
   if (h == 2) {   // a waiting workgroup gave up (should not happen: see analyze): per-level launches from now on
     if (!dep_off_) fprintf(stderr, "g2ohip: a dependency-driven launch gave up waiting; using one launch per level from now on\n");
