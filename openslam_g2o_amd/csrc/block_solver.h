@@ -290,6 +290,7 @@ class BlockSolver {
     double sys_delta = 0.0;
     bool omega_identity = false;   // information = identity for the whole set (info == NULL): not read per edge
     bool err_valid = false, jac_valid = false;   // errors / Jacobians of the set match the current estimates
+    DevBuf<double> chi_part;                     // per workgroup of ba_linearize_kernel: partial chi2 (folded into d_red_multi)
     bool fused_ok = false;   // every Hpl block has exactly one observation: fused on-the-fly assembly allowed
     DevBuf<double> meas, cams, pts, cams_bak, pts_bak;
     DevBuf<double> meas_pm, omega_pm;   // pose-major copies (observation-list order of the pose side)

@@ -796,13 +796,12 @@ __global__ void __launch_bounds__(kThreads) spmv_pl_landmark_kernel(int nL, int 
 // cams: [n][12] = R (column-major) | t, world -> camera.  Jacobians are written in the layout
 // g2ohip_set_edge_data documents (2x3 point block = J0, 2x6 pose block = J1, column-major).
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads) ba_linearize_kernel(int n, const double* __restrict__ cams, const double* __restrict__ pts,
-                                                              const int* __restrict__ cam_v, const int* __restrict__ pt_v,
-                                                              const double* __restrict__ meas, double f, double cx, double cy,
-                                                              double* __restrict__ Jpt, double* __restrict__ Jcam,
-                                                              double* __restrict__ err, int want_jac) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+__device__ __forceinline__ double ba_linearize_edge(int e, const double* __restrict__ cams, const double* __restrict__ pts,
+                                                    const int* __restrict__ cam_v, const int* __restrict__ pt_v,
+                                                    const double* __restrict__ meas, double f, double cx, double cy,
+                                                    double* __restrict__ Jpt, double* __restrict__ Jcam, double* __restrict__ err,
+                                                    int want_jac, const double* __restrict__ omega, int ident, int kind, double delta,
+                                                    bool want_rho) {
   double T[12], X[3], z2[2];
   load_vec<12>(cams + (size_t)cam_v[e] * 12, T);
   const double* Xp = pts + (size_t)pt_v[e] * 3;
@@ -813,7 +812,18 @@ __global__ void __launch_bounds__(kThreads) ba_linearize_kernel(int n, const dou
   const double z = T[2] * X[0] + T[5] * X[1] + T[8] * X[2] + T[11];
   double r[2] = {z2[0] - (x / z * f + cx), z2[1] - (y / z * f + cy)};
   store_vec<2>(err + (size_t)e * 2, r);
-  if (!want_jac) return;
+  double rho = 0.0;
+  if (want_rho) {   // e' Omega e as chi2_kernel<2> forms it
+    double e2;
+    if (ident) {
+      e2 = r[0] * r[0] + r[1] * r[1];
+    } else {
+      const double* O = omega + (size_t)e * 4;
+      e2 = r[0] * (O[0] * r[0] + O[2] * r[1]) + r[1] * (O[1] * r[0] + O[3] * r[1]);
+    }
+    rho = robust_rho(kind, delta, e2);
+  }
+  if (!want_jac) return rho;
   const double z_2 = z * z;
   const double tmp[6] = {f, 0.0, -x / z * f, 0.0, f, -y / z * f};   // row-major 2x3
   double A[6], B[12];
@@ -832,6 +842,36 @@ __global__ void __launch_bounds__(kThreads) ba_linearize_kernel(int n, const dou
   B[1 + 2 * 3] = 0.0;                    B[1 + 2 * 4] = -1.0 / z * f;               B[1 + 2 * 5] = y / z_2 * f;
   store_vec<6>(Jpt + (size_t)e * 6, A);
   store_vec<12>(Jcam + (size_t)e * 12, B);
+  return rho;
+}
+
+__global__ void __launch_bounds__(kThreads) ba_linearize_kernel(int n, const double* __restrict__ cams, const double* __restrict__ pts,
+                                                              const int* __restrict__ cam_v, const int* __restrict__ pt_v,
+                                                              const double* __restrict__ meas, double f, double cx, double cy,
+                                                              double* __restrict__ Jpt, double* __restrict__ Jcam,
+                                                              double* __restrict__ err, int want_jac,
+                                                              const double* __restrict__ omega, int ident, int kind, double delta,
+                                                              double* __restrict__ chi_part) {
+  // chi_part != nullptr: the robustified chi2 of the edges (sparse_optimizer.cpp:100-114) rides along -- one partial sum
+  // per workgroup, folded to 1 024 by fold_partials_kernel (fixed order); saves the pass of chi2_kernel over the errors
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double rho = 0.0;
+  if (e < n) rho = ba_linearize_edge(e, cams, pts, cam_v, pt_v, meas, f, cx, cy, Jpt, Jcam, err, want_jac, omega, ident, kind, delta, chi_part != nullptr);
+  if (chi_part) {
+    __shared__ double sh[kThreads];
+    sh[threadIdx.x] = rho;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) chi_part[blockIdx.x] = sh[0];
+  }
+}
+__global__ void __launch_bounds__(1024) fold_partials_kernel(const double* __restrict__ src, int n, double* __restrict__ dst) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += src[i];
+  dst[threadIdx.x] = s;
 }
 
 // VertexSE3Expmap::oplusImpl: estimate <- SE3Quat::exp(update) * estimate
@@ -2678,6 +2718,15 @@ double BlockSolver::chi2() {
     if (es.n == 0) continue;
     if (!es.has_err) throw StateFailure("chi2: edge data missing");
     int nblocks = std::min(1024, grid_for(es.n));
+    if (ba_.err_valid && esp.get() == sets_[ba_.set].get()) {   // partial sums left by ba_linearize (same values trial_stats reads)
+      std::vector<double> h(1024);
+      G2OHIP_HIP_CHECK(hipMemcpyAsync(h.data(), d_red_multi.p + (size_t)(ba_.set + 1) * 1024, 1024 * sizeof(double), hipMemcpyDeviceToHost, st_));
+      G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+      double sset = 0.0;
+      for (double v : h) sset += v;
+      total += sset;
+      continue;
+    }
 #define G2OHIP_CHI(d_)                                                                                                      \
   case d_:                                                                                                                  \
     hipLaunchKernelGGL((chi2_kernel<d_>), dim3(nblocks), dim3(kThreads), 0, st_, es.n, es.omega, es.err, es.kernel_kind, es.delta, \
@@ -3605,6 +3654,10 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
     if (es.n == 0) continue;
     if (!es.has_err) throw StateFailure("trial_stats: edge data missing");
     nblk[k + 1] = std::min(kMaxBlocks, grid_for(es.n));
+    if (ba_.err_valid && (int)k == ba_.set) {   // already there: ba_linearize left this set's partial sums in its slot
+      nblk[k + 1] = kMaxBlocks;
+      continue;
+    }
     double* red = d_red_multi.p + (k + 1) * kMaxBlocks;
 #define G2OHIP_CHI(d_)                                                                                                      \
   case d_:                                                                                                                  \
@@ -4056,8 +4109,16 @@ void BlockSolver::ba_linearize(bool jacobians) {
   if (need_jac) ba_.jac_valid = true;
   chi2_valid_ = false;
   if (profiling) tfe_.start(st_);
-  hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid_for(es.n)), dim3(kThreads), 0, st_, es.n, ba_.cams.p, ba_.pts.p, ba_.cam_v.p,
-                     ba_.pt_v.p, ba_.meas.p, ba_.f, ba_.cx, ba_.cy, es.own_J0.p, es.own_J1.p, es.own_err.p, (jacobians && !fused) ? 1 : 0);
+  // the chi2 of these errors rides along: 1 024 partial sums in this set's slot of the trial read-back buffer (chi2() and
+  // trial_stats() take them from there while err_valid holds)
+  constexpr int kMaxBlocks = 1024;
+  const int lgrid = grid_for(es.n);
+  if (d_red_multi.n < (sets_.size() + 1) * kMaxBlocks) d_red_multi.alloc((sets_.size() + 1) * kMaxBlocks);
+  if (ba_.chi_part.n < (size_t)lgrid) ba_.chi_part.alloc(lgrid);
+  hipLaunchKernelGGL(ba_linearize_kernel, dim3(lgrid), dim3(kThreads), 0, st_, es.n, ba_.cams.p, ba_.pts.p, ba_.cam_v.p,
+                     ba_.pt_v.p, ba_.meas.p, ba_.f, ba_.cx, ba_.cy, es.own_J0.p, es.own_J1.p, es.own_err.p, (jacobians && !fused) ? 1 : 0,
+                     es.omega, ba_.omega_identity ? 1 : 0, es.kernel_kind, es.delta, ba_.chi_part.p);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(1024), 0, st_, ba_.chi_part.p, lgrid, d_red_multi.p + (size_t)(ba_.set + 1) * kMaxBlocks);
   if (profiling) {
     tfe_.stop(st_);
     (jacobians ? times.linearize : times.residuals) = tfe_.seconds();
