@@ -50,6 +50,7 @@ struct CholOptions {
   int inplace_chains = 1;                // chains of scratch-slab fronts with identical rows (panels of one large supernode) are factorised in place
   int hoist_big_assembly = 1;            // zero fill + original blocks of ALL scratch-slab fronts of a phase in two launches up front (their slab regions are never reused)
   int fuse_big_forward = 1;              // forward step of scratch-slab fronts inside the pivot-block and panel kernels (levels on the fused panel path)
+  int merge_backward_levels = 1;         // backward step of consecutive levels of scratch-slab fronts in ONE launch (workgroups wait for their parent front's flag)
   int split_sweeps = 1;                  // forward / backward step of scratch-slab fronts by several workgroups per front (256 boundary rows each)
   int split_sweeps_min_dim = 512;        // ... on levels whose largest such front has at least this many rows
   int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
@@ -224,6 +225,11 @@ class SparseCholesky {
   DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts;
   DevBuf<double> d_L, d_U, d_w, d_y, d_xp, d_scratch;
   int hz_begin_[2] = {0, 0}, hz_count_[2] = {0, 0}, ha_begin_[2] = {0, 0}, ha_count_[2] = {0, 0};   // phase-wide fill / assembly chunks (d_big_tiles)
+  // merged backward launches: per phase, runs of consecutive levels (top level first) of scratch-slab fronts only
+  struct BwGroup { int top_level, bottom_level, begin, count; };
+  std::vector<BwGroup> bw_groups_[2];
+  std::vector<int> bw_of_level_[2];   // level -> index into bw_groups_ or -1
+  DevBuf<int> d_sw_flag;              // per front: its pivot part of the solution is in memory (merged launches)
   DevBuf<double> d_sw_part;     // multi-workgroup backward step: per row chunk the partial L21' x (64 doubles)
   DevBuf<int> d_sw_cnt;         // ... and per launch slot the chunks that have delivered (the last one finishes the front and resets it)
   DevBuf<double> d_sweep_vec;   // vectors of the triangular sweeps of fronts too large for LDS

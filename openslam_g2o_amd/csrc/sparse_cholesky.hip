@@ -986,6 +986,46 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         LL.sw_count = (int)bt.size() - LL.sw_begin;
         sw_max = std::max(sw_max, LL.sw_count);
       }
+    // merged backward launches: maximal runs of consecutive levels that hold scratch-slab fronts only, top level first; at most
+    // 256 workgroups per launch (all resident at once: a waiting workgroup never blocks the one it waits for).  Chunk word
+    // w = ordinal | count << 8 | (wait for the parent's flag) << 16 | (raise the own flag) << 17.
+    {
+      std::vector<int> fpar(nf, -1), fgroup(nf, -1);
+      for (int f = 0; f < nf; ++f)
+        for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) fpar[S.children[ch]] = f;
+      for (int ph = 0; ph < 2; ++ph) {
+        bw_groups_[ph].clear();
+        bw_of_level_[ph].assign(nlev, -1);
+        int cur = -1;
+        for (int l = nlev - 1; l >= 0; --l) {
+          const LevelLaunch& LL = launches_[ph][l];
+          bool ok = LL.sw_count > 0 && LL.lds_count == 0 && LL.sw_count <= 256;
+          for (int i = 0; i < LL.sw_count && ok; ++i) ok = (bt[LL.sw_begin + i].w >> 16) < 256;
+          if (!ok) { cur = -1; continue; }
+          if (cur < 0 || bw_groups_[ph][cur].count + LL.sw_count > 256 || bw_groups_[ph][cur].bottom_level != l + 1) {
+            bw_groups_[ph].push_back(BwGroup{l, l, (int)bt.size(), 0});
+            cur = (int)bw_groups_[ph].size() - 1;
+          }
+          BwGroup& G = bw_groups_[ph][cur];
+          G.bottom_level = l;
+          bw_of_level_[ph][l] = cur;
+          for (int i = 0; i < LL.sw_count; ++i) {
+            int4 c = bt[LL.sw_begin + i];
+            const int f = c.x, g = c.w & 0xffff, Gc = c.w >> 16;
+            fgroup[f] = ph * 65536 + cur;
+            const int par = fpar[f];
+            const bool wait = par >= 0 && fgroup[par] == ph * 65536 + cur;
+            c.w = g | (Gc << 8) | (wait ? 1 << 16 : 0) | (1 << 17);
+            bt.push_back(c);
+          }
+          G.count = (int)bt.size() - G.begin;
+        }
+        // (a group of one level gains nothing: leave it to the per-level launch)
+        for (size_t gi = 0; gi < bw_groups_[ph].size(); ++gi)
+          if (bw_groups_[ph][gi].top_level == bw_groups_[ph][gi].bottom_level) bw_of_level_[ph][bw_groups_[ph][gi].top_level] = -1;
+      }
+      d_sw_flag.alloc((size_t)nf + 1);
+    }
     // phase-wide copies of the fill and assembly chunks: the regions of the slab are never reused and the original
     // blocks do not depend on any child, so both passes can run once per phase instead of once per level
     for (int ph = 0; ph < 2; ++ph) {
@@ -1007,7 +1047,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     }
     if (bt.empty()) bt.push_back(make_int4(0, 0, 0, 0));
     d_big_tiles.upload(bt, st);
-    d_sw_part.alloc((size_t)std::max(sw_max, 1) * 64);
+    d_sw_part.alloc((size_t)std::max(sw_max, 256) * 64);
     d_sw_cnt.alloc((size_t)nf + 1);
     d_sw_cnt.zero(st);
   }
@@ -2984,16 +3024,23 @@ __global__ void __launch_bounds__(256) big_forward_kernel(CholPlanDev P, const i
   if ((ck.w & 0xffff) == 0 && tid < npiv) y[(size_t)c0 * BS + tid] = ys[tid];
 }
 
-template <int BS>
+// DEP: ONE launch for several consecutive levels (top level first, at most 256 workgroups: all resident): a chunk whose
+// front's parent is in the same launch waits for the parent's flag -- with its panel, pivot block and records already
+// loaded -- instead of for a launch of its own (per level ~15 us of start-up and dependent round trips -> the hand-off);
+// the chunk that finishes a front raises that front's flag once its x stores have been acknowledged.
+template <int BS, bool DEP>
 __global__ void __launch_bounds__(256) big_backward_kernel(CholPlanDev P, const int4* __restrict__ chunks, const double* __restrict__ y,
-                                                          double* __restrict__ xp, double* __restrict__ part, int* __restrict__ cnt) {
+                                                          double* __restrict__ xp, double* __restrict__ part, int* __restrict__ cnt,
+                                                          int* __restrict__ flag) {
   __shared__ double L11[64 * 65], li[64], t[64], xs[64], xB[256];
   __shared__ int last_s;
   const int4 ck = chunks[blockIdx.x];
   const int f = ck.x;
   const FrontRec rec = load_front_rec(P.rec + f);
   const int npiv = rec.ns * BS, m = (rec.ns + rec.nb) * BS, c0 = rec.c0;
-  const int r0 = ck.y, nrows = ck.z, g = ck.w & 0xffff, G = ck.w >> 16;
+  const int r0 = ck.y, nrows = ck.z;
+  const int g = DEP ? (ck.w & 0xff) : (ck.w & 0xffff), G = DEP ? ((ck.w >> 8) & 0xff) : (ck.w >> 16);
+  const bool wait_parent = DEP && ((ck.w >> 16) & 1), raise_flag = DEP && ((ck.w >> 17) & 1);
   const double yk = (threadIdx.x < npiv) ? y[(size_t)c0 * BS + threadIdx.x] : 0.0;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const double* Lg = P.L + rec.L_off;
@@ -3006,16 +3053,32 @@ __global__ void __launch_bounds__(256) big_backward_kernel(CholPlanDev P, const 
 #pragma unroll
     for (int u = 0; u < 4; ++u) lv[kk][u] = (k < npiv && lane + 64 * u < nrows) ? Lk[lane + 64 * u] : 0.0;
   }
+  int xrow = 0;
   {
     const int* rows = P.rows + rec.rows_off;
     const int r = r0 + tid;
-    xB[tid] = (tid < nrows) ? ld_coh(xp + (size_t)rows[r / BS] * BS + r % BS) : 0.0;
+    if (tid < nrows) xrow = rows[r / BS] * BS + r % BS;
   }
   for (int i = tid; i < npiv * npiv; i += 256) {
     const int r = i % npiv, c = i / npiv;
     L11[r + 65 * c] = Lg[r + (size_t)m * c];
   }
   if (tid < npiv) li[tid] = Lg[(size_t)m * npiv + tid];
+  if (wait_parent) {   // the boundary values come from fronts of this launch: the parent's flag covers all ancestors
+    if (tid == 0) {
+      const int* fl = flag + (rec.pad[1] & 0x00ffffff);
+      int spins = 0;
+      while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > P.dep_spin_limit || ((spins & 255) == 0 && __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
+          __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  xB[tid] = (tid < nrows) ? ld_coh(xp + (size_t)xrow) : 0.0;
   __syncthreads();
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
@@ -3072,6 +3135,11 @@ __global__ void __launch_bounds__(256) big_backward_kernel(CholPlanDev P, const 
     __syncthreads();
   }
   if (tid < npiv) st_coh(xp + (size_t)c0 * BS + tid, xs[tid]);
+  if (raise_flag) {
+    __builtin_amdgcn_s_waitcnt(0);   // the x stores have been acknowledged at the device-coherent level
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag + f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // exchange segments: dir 0 = pack (own subtree roots -> buffer), dir 1 = unpack (foreign roots <- buffer)
@@ -3842,7 +3910,7 @@ void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t s
     const int4* ch = d_big_tiles.p + LL.sw_begin;
 #define G2OHIP_SPLIT_SWEEP(BS_)                                                                                                 \
   if (fwd) hipLaunchKernelGGL((big_forward_kernel<BS_>), dim3(LL.sw_count), dim3(256), 0, st, plan_, ch, d_xp.p, d_y.p);          \
-  else hipLaunchKernelGGL((big_backward_kernel<BS_>), dim3(LL.sw_count), dim3(256), 0, st, plan_, ch, d_y.p, d_xp.p, d_sw_part.p, d_sw_cnt.p)
+  else hipLaunchKernelGGL((big_backward_kernel<BS_, false>), dim3(LL.sw_count), dim3(256), 0, st, plan_, ch, d_y.p, d_xp.p, d_sw_part.p, d_sw_cnt.p, (int*)nullptr)
     switch (bs_) {
       case 3: G2OHIP_SPLIT_SWEEP(3); break;
       case 6: G2OHIP_SPLIT_SWEEP(6); break;
@@ -3922,12 +3990,37 @@ void SparseCholesky::solve_forward_phase(int phase, hipStream_t st) {
 }
 void SparseCholesky::solve_backward_phase(int phase, hipStream_t st) {
   // overwrite d_xp with the solution, highest level first
+  const bool merge = opt.merge_backward_levels && opt.split_sweeps && !dep_off_ && !bw_groups_[phase].empty();
+  bool flags_zeroed = false;
   for (size_t g = groups_[phase].size(); g-- > 0;) {
     const FactorGroup& G = groups_[phase][g];
     if (G.dep && opt.dep_backward && !dep_off_) {
       launch_solve(G.LL, false, st, false, true);
     } else {
-      for (int l = G.last_level; l >= G.first_level; --l) launch_solve(launches_[phase][l], false, st);
+      for (int l = G.last_level; l >= G.first_level; --l) {
+        const int bg = merge ? bw_of_level_[phase][l] : -1;
+        if (bg >= 0) {   // a run of levels of scratch-slab fronts: one launch at its top level, nothing at the others
+          const BwGroup& B = bw_groups_[phase][bg];
+          if (l != B.top_level) continue;
+          if (!flags_zeroed) {
+            d_sw_flag.zero(st);
+            flags_zeroed = true;
+          }
+          const int4* ch = d_big_tiles.p + B.begin;
+#define G2OHIP_MERGED_BACKWARD(BS_) \
+  hipLaunchKernelGGL((big_backward_kernel<BS_, true>), dim3(B.count), dim3(256), 0, st, plan_, ch, d_y.p, d_xp.p, d_sw_part.p, d_sw_cnt.p, d_sw_flag.p)
+          switch (bs_) {
+            case 3: G2OHIP_MERGED_BACKWARD(3); break;
+            case 6: G2OHIP_MERGED_BACKWARD(6); break;
+            case 7: G2OHIP_MERGED_BACKWARD(7); break;
+            default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
+          }
+#undef G2OHIP_MERGED_BACKWARD
+          G2OHIP_LAUNCH_CHECK("big_backward_kernel (merged levels)");
+          continue;
+        }
+        launch_solve(launches_[phase][l], false, st);
+      }
     }
   }
 }
