@@ -986,44 +986,58 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         LL.sw_count = (int)bt.size() - LL.sw_begin;
         sw_max = std::max(sw_max, LL.sw_count);
       }
-    // merged backward launches: maximal runs of consecutive levels that hold scratch-slab fronts only, top level first; at most
-    // 256 workgroups per launch (all resident at once: a waiting workgroup never blocks the one it waits for).  Chunk word
+    // merged backward launches: maximal runs of consecutive levels with scratch-slab fronts (their LDS-class fronts, chains
+    // included, ride along front by front: the kernel works per front, from the L panel in memory), top level first, a
+    // front's chunks behind those of its parent.  A waiting workgroup never blocks the one it waits for: workgroups are
+    // dispatched in order and the parent's come first.  Chunk word
     // w = ordinal | count << 8 | (wait for the parent's flag) << 16 | (raise the own flag) << 17.
     {
+      constexpr int kMaxMerged = 1024;
       std::vector<int> fpar(nf, -1), fgroup(nf, -1);
       for (int f = 0; f < nf; ++f)
         for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) fpar[S.children[ch]] = f;
+      int merged_max = 0;
       for (int ph = 0; ph < 2; ++ph) {
         bw_groups_[ph].clear();
         bw_of_level_[ph].assign(nlev, -1);
         int cur = -1;
         for (int l = nlev - 1; l >= 0; --l) {
           const LevelLaunch& LL = launches_[ph][l];
-          bool ok = LL.sw_count > 0 && LL.lds_count == 0 && LL.sw_count <= 256;
-          for (int i = 0; i < LL.sw_count && ok; ++i) ok = (bt[LL.sw_begin + i].w >> 16) < 256;
-          if (!ok) { cur = -1; continue; }
-          if (cur < 0 || bw_groups_[ph][cur].count + LL.sw_count > 256 || bw_groups_[ph][cur].bottom_level != l + 1) {
+          std::vector<int4> lev;
+          bool ok = LL.glb_count > 0 && opt.big_front_passes != 0;   // (levels of LDS fronts only: the dependency-driven launches)
+          for (int q = LL.lds_begin; q < LL.glb_begin + LL.glb_count && ok; ++q) {
+            const int t = S.level_fronts[q];
+            for (int k = S.task_ptr[t + 1] - 1; k >= S.task_ptr[t] && ok; --k) {   // chain top first
+              const int f = S.task_fronts[k];
+              const int rows = S.f_nb[f] * bs, Gc = std::max(1, (rows + 255) / 256);
+              if (S.f_ns[f] * bs > 64 || Gc > 255) ok = false;
+              for (int g = 0; g < Gc && ok; ++g) lev.push_back(make_int4(f, g * 256, std::max(0, std::min(256, rows - g * 256)), g | (Gc << 8)));
+            }
+          }
+          if (!ok || (int)lev.size() > kMaxMerged) { cur = -1; continue; }
+          if (cur < 0 || bw_groups_[ph][cur].count + (int)lev.size() > kMaxMerged || bw_groups_[ph][cur].bottom_level != l + 1) {
             bw_groups_[ph].push_back(BwGroup{l, l, (int)bt.size(), 0});
             cur = (int)bw_groups_[ph].size() - 1;
           }
           BwGroup& G = bw_groups_[ph][cur];
           G.bottom_level = l;
           bw_of_level_[ph][l] = cur;
-          for (int i = 0; i < LL.sw_count; ++i) {
-            int4 c = bt[LL.sw_begin + i];
-            const int f = c.x, g = c.w & 0xffff, Gc = c.w >> 16;
+          for (int4 c : lev) {
+            const int f = c.x;
             fgroup[f] = ph * 65536 + cur;
             const int par = fpar[f];
             const bool wait = par >= 0 && fgroup[par] == ph * 65536 + cur;
-            c.w = g | (Gc << 8) | (wait ? 1 << 16 : 0) | (1 << 17);
+            c.w |= (wait ? 1 << 16 : 0) | (1 << 17);
             bt.push_back(c);
           }
           G.count = (int)bt.size() - G.begin;
+          merged_max = std::max(merged_max, G.count);
         }
         // (a group of one level gains nothing: leave it to the per-level launch)
         for (size_t gi = 0; gi < bw_groups_[ph].size(); ++gi)
           if (bw_groups_[ph][gi].top_level == bw_groups_[ph][gi].bottom_level) bw_of_level_[ph][bw_groups_[ph][gi].top_level] = -1;
       }
+      sw_max = std::max(sw_max, merged_max);
       d_sw_flag.alloc((size_t)nf + 1);
     }
     // phase-wide copies of the fill and assembly chunks: the regions of the slab are never reused and the original
@@ -1047,7 +1061,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     }
     if (bt.empty()) bt.push_back(make_int4(0, 0, 0, 0));
     d_big_tiles.upload(bt, st);
-    d_sw_part.alloc((size_t)std::max(sw_max, 256) * 64);
+    d_sw_part.alloc((size_t)std::max(sw_max, 1) * 64);
     d_sw_cnt.alloc((size_t)nf + 1);
     d_sw_cnt.zero(st);
   }
