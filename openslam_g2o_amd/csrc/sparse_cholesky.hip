@@ -1038,7 +1038,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           if (bw_groups_[ph][gi].top_level == bw_groups_[ph][gi].bottom_level) bw_of_level_[ph][bw_groups_[ph][gi].top_level] = -1;
       }
       sw_max = std::max(sw_max, merged_max);
-      d_sw_flag.alloc((size_t)nf + 1);
+      d_sw_flag.alloc(((size_t)nf + 256) & ~(size_t)255);   // (a multiple of 1 KB: one fill kernel per zeroing)
     }
     // phase-wide copies of the fill and assembly chunks: the regions of the slab are never reused and the original
     // blocks do not depend on any child, so both passes can run once per phase instead of once per level
@@ -3038,7 +3038,8 @@ __global__ void __launch_bounds__(256) big_forward_kernel(CholPlanDev P, const i
   if ((ck.w & 0xffff) == 0 && tid < npiv) y[(size_t)c0 * BS + tid] = ys[tid];
 }
 
-// DEP: ONE launch for several consecutive levels (top level first, at most 256 workgroups: all resident): a chunk whose
+// DEP: ONE launch for several consecutive levels (top level first; workgroups are dispatched in order, so the one a
+// waiting workgroup needs is running or done -- no deadlock whatever the number resident): a chunk whose
 // front's parent is in the same launch waits for the parent's flag -- with its panel, pivot block and records already
 // loaded -- instead of for a launch of its own (per level ~15 us of start-up and dependent round trips -> the hand-off);
 // the chunk that finishes a front raises that front's flag once its x stores have been acknowledged.

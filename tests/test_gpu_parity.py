@@ -550,6 +550,7 @@ def test_scratch_slab_sweep_variants(bs):
         "forward in the panel kernel, one workgroup backward": {"split_sweeps": 0, "hoist_big_assembly": 0},
         "one workgroup per front": {"split_sweeps": 0, "fuse_big_forward": 0, "hoist_big_assembly": 0},
         "two-launch panel": {"fuse_panel": 0},
+        "a backward launch per level": {"merge_backward_levels": 0},
     }
     xs = {}
     for name, opts in variants.items():
@@ -560,8 +561,9 @@ def test_scratch_slab_sweep_variants(bs):
         assert ok, name
         assert ls.stats()["maxFrontDim"] >= 512, "the case must reach the multi-workgroup sweeps"
         assert relerr(x, xr) < 1e-10, name
-        ok, x2 = ls.solve(cp, row, vals, b)
-        assert ok and np.array_equal(x, x2), name + ": not repeatable"
+        for _ in range(10 if name == "default" else 1):   # (the default form hands results between workgroups inside launches)
+            ok, x2 = ls.solve(cp, row, vals, b)
+            assert ok and np.array_equal(x, x2), name + ": not repeatable"
         xs[name] = x
     assert np.array_equal(xs["forward in the panel kernel, one workgroup backward"], xs["one workgroup per front"])
 
