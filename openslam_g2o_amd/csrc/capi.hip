@@ -738,6 +738,11 @@ int g2ohip_ls_solve(g2ohip_linear_solver* ls, int n_blocks, const int32_t* colpt
     ls->chol->solve(ls->db.p, ls->dx.p, ls->st);
     ls->tl.stop(ls->st);
     bool bad = ls->chol->failed(ls->st);
+    if (bad && ls->chol->dependency_stall()) {   // a dependency-driven launch gave up waiting (not "not positive definite"):
+      ls->chol->factor(ls->dA.p, ls->st);        // the solver has switched to one launch per level -- once more
+      ls->chol->solve(ls->db.p, ls->dx.p, ls->st);
+      bad = ls->chol->failed(ls->st);
+    }
     ls->t_numeric = ls->tn.seconds();
     ls->t_solve = ls->tl.seconds();
     if (bad) return G2OHIP_NOT_PD;

@@ -568,6 +568,24 @@ def test_scratch_slab_sweep_variants(bs):
     assert np.array_equal(xs["forward in the panel kernel, one workgroup backward"], xs["one workgroup per front"])
 
 
+def test_merged_backward_launch_stall_fallback():
+    """A chunk of a merged backward launch that gives up waiting for its parent front (spin limit 0 forces it) flags the
+    solve; the LinearSolver seam repeats it with one launch per level (NOT "not positive definite") and stays there."""
+    capi = _capi()
+    A, cp, row, vals, rng = _random_block_spd(6, 200, 0.2, 91)
+    b = rng.normal(size=A.shape[0])
+    xr = np.linalg.solve(A, b)
+    ls = capi.HipLinearSolver(6, 0)
+    ls.setOption("dep_spin_limit", 0)
+    for _ in range(3):
+        ok, x = ls.solve(cp, row, vals, b)
+        assert ok and relerr(x, xr) < 1e-10
+    ls2 = capi.HipLinearSolver(6, 0)
+    ls2.setOption("merge_backward_levels", 0)
+    ok, x2 = ls2.solve(cp, row, vals, b)
+    assert ok and relerr(x, x2) < 1e-13      # (the fallback also ungroups the sweeps of the LDS fronts: same terms, other partitions)
+
+
 @pytest.mark.parametrize("bs", [3, 6, 7])
 @pytest.mark.parametrize("passes", [1, 0])
 def test_linear_solver_large_fronts_all_block_sizes(bs, passes):
