@@ -2462,14 +2462,15 @@ __device__ __forceinline__ void fwd_children_apply(const CholPlanDev& P, const F
 // wave 2 solves the pivot part y = L11^-1 (b + children's w) (one wave, column by column, no barriers; the operation
 // order per row is that of front_forward_kernel: bit-identical), then the rows of the update vector follow:
 // w = (children's w) - L21 y.  Tile (0, 0) stores y.  (Fronts without boundary rows have no tiles: big_diag_mfma_kernel.)
-template <int BS, bool FWD>
-__global__ void __launch_bounds__(256) big_panel_kernel(CholPlanDev P, const int4* __restrict__ tiles, double* __restrict__ scratch,
-                                                       const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
-                                                       const double* __restrict__ bperm, double* __restrict__ yout) {
-  extern __shared__ __attribute__((aligned(16))) double psm[];
+// DEP (big_level_kernel: pivot blocks and panel tiles of a level in ONE launch): the tile waits for its front's flag -- with
+// its panel rows, the children's vectors and the records already requested -- and reads L11 with device-coherent loads.
+template <int BS, bool FWD, bool DEP>
+__device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 td, double* __restrict__ scratch,
+                                               const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
+                                               const double* __restrict__ bperm, double* __restrict__ yout, double* psm, const int* flag) {
   constexpr int BB = BS * BS, MAXB = 64 / BS, NX = MAXB * BS;
   const int tid = threadIdx.x;
-  const int4 td = tiles[blockIdx.x];   // x: launch slot, y / z: tile row / column, w: the parent continues in place
+  // td: x: launch slot, y / z: tile row / column, w: the parent continues in place
   const int slot = td.x;
   const int f = P.slots[slot].x;
   const FrontRec rec = load_front_rec(P.rec + f);
@@ -2499,15 +2500,30 @@ __global__ void __launch_bounds__(256) big_panel_kernel(CholPlanDev P, const int
   double x[NX];
 #pragma unroll
   for (int c = 0; c < NX; ++c) x[c] = (rok && c < n) ? F[(size_t)(n + rglb) + (size_t)ld * c] : 0.0;
-  {   // L11 and the reciprocal diagonal (written by big_diag_kernel, the launch before)
+  if (DEP) {   // the pivot block of this front is factorised by a workgroup of this launch
+    if (tid == 0) {
+      const int* fl = flag + f;
+      int spins = 0;
+      while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > P.dep_spin_limit || ((spins & 255) == 0 && __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
+          __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  {   // L11 and the reciprocal diagonal (written by the pivot-block kernel: the launch before, or -- DEP -- a workgroup of this one)
     constexpr int UL = 16;   // 64 * 64 / 256
     double t[UL];
 #pragma unroll
     for (int u = 0; u < UL; ++u) {
       const int i = min(tid + 256 * u, n * n - 1);
-      t[u] = Lg[(i % n) + (size_t)m * (i / n)];
+      const double* src = Lg + (i % n) + (size_t)m * (i / n);
+      t[u] = DEP ? ld_coh(src) : *src;
     }
-    const double iv = Lg[(size_t)m * n + min(tid, n - 1)];
+    const double iv = DEP ? ld_coh(Lg + (size_t)m * n + min(tid, n - 1)) : Lg[(size_t)m * n + min(tid, n - 1)];
 #pragma unroll
     for (int u = 0; u < UL; ++u) {
       const int i = tid + 256 * u;
@@ -2620,6 +2636,14 @@ __global__ void __launch_bounds__(256) big_panel_kernel(CholPlanDev P, const int
           }
     }
   }
+}
+
+template <int BS, bool FWD>
+__global__ void __launch_bounds__(256) big_panel_kernel(CholPlanDev P, const int4* __restrict__ tiles, double* __restrict__ scratch,
+                                                       const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
+                                                       const double* __restrict__ bperm, double* __restrict__ yout) {
+  extern __shared__ __attribute__((aligned(16))) double psm[];
+  big_panel_body<BS, FWD, false>(P, tiles[blockIdx.x], scratch, scratch_off, scratch_ld, bperm, yout, psm, nullptr);
 }
 
 // b_perm[new*bs + r] = b[old*bs + r]
@@ -3188,14 +3212,19 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
 // FWD: the forward step of fronts WITHOUT boundary rows (roots: no panel tiles) rides along; the others: big_panel_kernel.
 // Right-hand side and the children's update vectors are requested before the factorisation, y = L11^-1 t is solved from an
 // LDS copy of the finished pivot block with the operation order of front_forward_kernel.
-template <int BS, bool FWD>
-__global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int slot0, double* __restrict__ scratch,
-                                                           const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
-                                                           const double* __restrict__ bperm, double* __restrict__ yout) {
-  __shared__ double Rb[4 * 64], Lb[4 * 64];
-  __shared__ double L11s[FWD ? 64 * 65 : 1], lis[FWD ? 64 : 1], tJ[FWD ? 64 : 1];
+// COH (big_level_kernel): L11 and the reciprocal diagonal go to memory with device-coherent stores -- the panel tiles of the
+// same launch read them.  lds: 512 doubles (FWD: 4 800).
+template <int BS, bool FWD, bool COH>
+__device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const int slot, double* __restrict__ scratch,
+                                                   const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
+                                                   const double* __restrict__ bperm, double* __restrict__ yout, double* lds) {
+  double* Rb = lds;
+  double* Lb = lds + 256;
+  double* L11s = lds + 512;   // (FWD only)
+  double* lis = L11s + 64 * 65;
+  double* tJ = lis + 64;
   constexpr int T = 4, NT = 10, NW = 4, OWN = 3;
-  const int slot = slot0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int f = P.slots[slot].x;
   const FrontRec rec = load_front_rec(P.rec + f);
@@ -3293,7 +3322,10 @@ __global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int s
           rssel = rs[k];
         }
       const int col = k0 + lk;
-      if (w == 0 && lr == 0 && col < n) Lg[(size_t)m * n + col] = rssel;
+      if (w == 0 && lr == 0 && col < n) {
+        if (COH) st_coh(Lg + (size_t)m * n + col, rssel);
+        else Lg[(size_t)m * n + col] = rssel;
+      }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         if ((t & (NW - 1)) == w && 16 * t < n) {
@@ -3306,7 +3338,8 @@ __global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int s
             if (t == tk) v = row > col ? v : (row == col ? sqsel : 0.0);
           }
           if (col < n && row < n) {
-            Lg[(size_t)row + (size_t)m * col] = v;
+            if (COH) st_coh(Lg + (size_t)row + (size_t)m * col, v);
+            else Lg[(size_t)row + (size_t)m * col] = v;
             F[(size_t)row + (size_t)ld * col] = v;
           }
         }
@@ -3360,6 +3393,35 @@ __global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int s
   }
 }
 
+template <int BS, bool FWD>
+__global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int slot0, double* __restrict__ scratch,
+                                                           const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
+                                                           const double* __restrict__ bperm, double* __restrict__ yout) {
+  __shared__ double lds[FWD ? 4800 : 512];
+  big_diag_mfma_body<BS, FWD, false>(P, slot0 + blockIdx.x, scratch, scratch_off, scratch_ld, bperm, yout, lds);
+}
+
+// Pivot blocks and panel tiles of the scratch-slab fronts of a level in ONE launch: workgroups [0, ndiag) factorise the pivot
+// blocks and raise their front's flag, the others are the tiles of big_panel_kernel and wait for it -- their start-up (tile
+// and front records, panel rows, children's vectors: three to four dependent round trips) runs next to the pivot block
+// instead of behind it.  The pivot-block workgroups come first in dispatch order: no deadlock.
+template <int BS, bool FWD>
+__global__ void __launch_bounds__(256) big_level_kernel(CholPlanDev P, int slot0, int ndiag, const int4* __restrict__ tiles,
+                                                       double* __restrict__ scratch, const long long* __restrict__ scratch_off,
+                                                       const int* __restrict__ scratch_ld, const double* __restrict__ bperm,
+                                                       double* __restrict__ yout, int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) double psm[];
+  if ((int)blockIdx.x < ndiag) {
+    const int slot = slot0 + blockIdx.x;
+    big_diag_mfma_body<BS, FWD, true>(P, slot, scratch, scratch_off, scratch_ld, bperm, yout, psm);
+    __builtin_amdgcn_s_waitcnt(0);   // L11 and the reciprocal diagonal have been acknowledged at the device-coherent level
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag + P.slots[slot].x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    big_panel_body<BS, FWD, true>(P, tiles[blockIdx.x - ndiag], scratch, scratch_off, scratch_ld, bperm, yout, psm, flag);
+  }
+}
+
 struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one level (LevelLaunch::ba_* / be_pass / tr_*)
   bool ok;
   const int4* chunks;
@@ -3368,6 +3430,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   int fz_begin, fz_count;
   bool hoisted = false;   // fill + assembly already done by the phase-wide passes
   bool fwd = false;       // the forward step rides along in the pivot-block and panel kernels (big_forward_carried)
+  int* flag = nullptr;    // non-null: pivot blocks and panel tiles of the level in one launch (big_level_kernel), per-front flags
   const int* ld;   // leading dimension per launch slot
   bool fuse_panel;   // big_panel_kernel instead of big_trsm_kernel + big_front_update_kernel
   bool mfma_diag;    // big_diag_mfma_kernel instead of big_diag_kernel
@@ -3443,6 +3506,17 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
         hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
                            d_scratch_off);
     G2OHIP_LAUNCH_CHECK("big_extend_add_kernel");
+    if (big.flag && big.mfma_diag && big.fuse_panel && bt_count > 0 && bt_count <= 256) {
+      const size_t shp = (size_t)(3 * 64 * 65 + 64 + 128) * sizeof(double);   // (the pivot-block role needs 4 800 doubles of it)
+      if (big.fwd)
+        hipLaunchKernelGGL((big_level_kernel<BS, true>), dim3(glb_count + bt_count), dim3(256), shp, st, P, glb_begin, glb_count, big_tiles, d_scratch,
+                           d_scratch_off, big.ld, bperm, yout, big.flag);
+      else
+        hipLaunchKernelGGL((big_level_kernel<BS, false>), dim3(glb_count + bt_count), dim3(256), shp, st, P, glb_begin, glb_count, big_tiles, d_scratch,
+                           d_scratch_off, big.ld, (const double*)nullptr, (double*)nullptr, big.flag);
+      G2OHIP_LAUNCH_CHECK("big_level_kernel");
+      return;
+    }
     if (big.mfma_diag && big.fwd)
       hipLaunchKernelGGL((big_diag_mfma_kernel<BS, true>), dim3(glb_count), dim3(256), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld, bperm, yout);
     else if (big.mfma_diag)
@@ -3544,8 +3618,8 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   CholPlanDev fplan = plan_;
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
-                      LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL), d_scratch_ld.p, opt.fuse_panel != 0,
-                      opt.mfma_diag != 0};
+                      LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL),
+                      (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
@@ -3599,6 +3673,12 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     (void)hipFuncSetAttribute((const void*)big_panel_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)big_panel_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)big_panel_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipGetLastError();
     attr_done = true;
   }
@@ -3611,6 +3691,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     dbg_launch_ = 0;
   }
 #endif
+  if (opt.merge_diag_panel && !dep_off_ && d_sw_flag.p) d_sw_flag.zero(st);   // per-front flags of big_level_kernel
   if (opt.hoist_big_assembly && (hz_count_[phase] > 0 || ha_count_[phase] > 0)) {
     const bool virt = dA == nullptr;
     if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
