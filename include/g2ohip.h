@@ -202,7 +202,7 @@ int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* c
  * dependency-driven launch, 0/1 = one launch per level), "dep_backward" (1), "dep_delay", "dep_spin_limit",
  * "big_front_passes" (1: large fronts as whole-GPU passes with an MFMA update) / "big_front_min_dim" (180);
  * for those passes "inplace_chains", "mfma_diag", "fuse_panel", "overlap_level_halves", "hoist_big_assembly",
- * "fuse_big_forward", "split_sweeps" / "split_sweeps_min_dim" (512), "merge_backward_levels" (all 1: see INTEGRATION.md, options).
+ * "fuse_big_forward", "split_sweeps" / "split_sweeps_min_dim" (512), "merge_backward_levels", "merge_diag_panel" (all 1: see INTEGRATION.md, options).
  * Kernel knobs: "schur_tile_bytes", "schur_group", "fuse_landmark_inverse", "fuse_schur_reduce" (1: g2ohip_solve on
  * one GPU folds the Schur reduction into the factorisation; Hschur is then written only when it is asked for),
  * "ba_fused", "use_graph", "mask_solution". */

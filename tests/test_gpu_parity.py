@@ -551,6 +551,7 @@ def test_scratch_slab_sweep_variants(bs):
         "one workgroup per front": {"split_sweeps": 0, "fuse_big_forward": 0, "hoist_big_assembly": 0},
         "two-launch panel": {"fuse_panel": 0},
         "a backward launch per level": {"merge_backward_levels": 0},
+        "pivot blocks and panel tiles as two launches": {"merge_diag_panel": 0},
     }
     xs = {}
     for name, opts in variants.items():
@@ -566,6 +567,7 @@ def test_scratch_slab_sweep_variants(bs):
             assert ok and np.array_equal(x, x2), name + ": not repeatable"
         xs[name] = x
     assert np.array_equal(xs["forward in the panel kernel, one workgroup backward"], xs["one workgroup per front"])
+    assert np.array_equal(xs["pivot blocks and panel tiles as two launches"], xs["default"])   # same arithmetic, one launch less
 
 
 def test_merged_backward_launch_stall_fallback():
