@@ -3691,7 +3691,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     dbg_launch_ = 0;
   }
 #endif
-  if (opt.merge_diag_panel && !dep_off_ && d_sw_flag.p) d_sw_flag.zero(st);   // per-front flags of big_level_kernel
+  if (opt.merge_diag_panel && !dep_off_ && d_sw_flag.p && ha_count_[phase] > 0) d_sw_flag.zero(st);   // per-front flags of big_level_kernel (phases with scratch-slab levels only)
   if (opt.hoist_big_assembly && (hz_count_[phase] > 0 || ha_count_[phase] > 0)) {
     const bool virt = dA == nullptr;
     if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
