@@ -2500,6 +2500,23 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
   double x[NX];
 #pragma unroll
   for (int c = 0; c < NX; ++c) x[c] = (rok && c < n) ? F[(size_t)(n + rglb) + (size_t)ld * c] : 0.0;
+  // this wave's part of the trailing tile (final before this launch: earlier levels and the extend-add passes wrote it):
+  // requested now, consumed after the update -- one exposed round trip less per level (not with 7 x 7 blocks: no registers left)
+  constexpr bool kPreTile = BS != 7;
+  double fpre[kPreTile ? 16 : 1];
+  if (kPreTile) {
+    const int l_ = tid & 63, lr_ = l_ & 15, lk_ = l_ >> 4, wave_ = tid >> 6;
+    const int R0_ = td.y * 64 + (wave_ & 1) * 32, C0_ = td.z * 64 + (wave_ >> 1) * 32;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = R0_ + 16 * a + lr_, c = C0_ + 16 * b + lk_ + 4 * v;
+          fpre[(a * 2 + b) * 4 + v] = (r < mt && c < mt && r / BS >= c / BS) ? F[(size_t)(n + r) + (size_t)ld * (n + c)] : 0.0;
+        }
+  }
   if (DEP) {   // the pivot block of this front is factorised by a workgroup of this launch
     if (tid == 0) {
       const int* fl = flag + f;
@@ -2628,7 +2645,7 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
             if (r < mt && c < mt) {
               const int ib = r / BS, jb = c / BS;
               if (ib >= jb) {
-                const double y = F[(size_t)(n + r) + (size_t)ld * (n + c)] - acc[a][b][v];
+                const double y = (kPreTile ? fpre[(a * 2 + b) * 4 + v] : F[(size_t)(n + r) + (size_t)ld * (n + c)]) - acc[a][b][v];
                 if (td.w) F[(size_t)(n + r) + (size_t)ld * (n + c)] = y;
                 else U[(size_t)(ib * (ib + 1) / 2 + jb) * BB + (r - ib * BS) + BS * (c - jb * BS)] = y;
               }
