@@ -2532,19 +2532,20 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
     __syncthreads();
   }
   {   // L11 and the reciprocal diagonal (written by the pivot-block kernel: the launch before, or -- DEP -- a workgroup of this one)
-    constexpr int UL = 16;   // 64 * 64 / 256
+    constexpr int UL = 16;   // 64 * 64 / 256: element (tid & 63, tid / 64 + 4 u) of a 64 x 64 grid (no integer divisions on this path)
     double t[UL];
+    const int sr = tid & 63, sc = tid >> 6;
 #pragma unroll
     for (int u = 0; u < UL; ++u) {
-      const int i = min(tid + 256 * u, n * n - 1);
-      const double* src = Lg + (i % n) + (size_t)m * (i / n);
+      const int c = sc + 4 * u;
+      const double* src = Lg + min(sr, n - 1) + (size_t)m * min(c, n - 1);
       t[u] = DEP ? ld_coh(src) : *src;
     }
     const double iv = DEP ? ld_coh(Lg + (size_t)m * n + min(tid, n - 1)) : Lg[(size_t)m * n + min(tid, n - 1)];
 #pragma unroll
     for (int u = 0; u < UL; ++u) {
-      const int i = tid + 256 * u;
-      if (i < n * n) S[(i % n) + 65 * (i / n)] = t[u];
+      const int c = sc + 4 * u;
+      if (sr < n && c < n) S[sr + 65 * c] = t[u];
     }
     if (tid < n) inv[tid] = iv;
     if (fwd_rows && tid < 64) {
@@ -2998,9 +2999,9 @@ __global__ void __launch_bounds__(256) big_forward_kernel(CholPlanDev P, const i
       }
     }
   }
-  for (int i = tid; i < npiv * npiv; i += 256) {
-    const int r = i % npiv, c = i / npiv;
-    L11[r + 65 * c] = Lg[r + (size_t)m * c];
+  for (int c = tid >> 6; c < npiv; c += 4) {   // (column c by wave, rows by lane: no integer divisions)
+    const int r = tid & 63;
+    if (r < npiv) L11[r + 65 * c] = Lg[r + (size_t)m * c];
   }
   if (tid < npiv) {
     li[tid] = Lg[(size_t)m * npiv + tid];
@@ -3115,9 +3116,9 @@ __global__ void __launch_bounds__(256) big_backward_kernel(CholPlanDev P, const 
     const int r = r0 + tid;
     if (tid < nrows) xrow = rows[r / BS] * BS + r % BS;
   }
-  for (int i = tid; i < npiv * npiv; i += 256) {
-    const int r = i % npiv, c = i / npiv;
-    L11[r + 65 * c] = Lg[r + (size_t)m * c];
+  for (int c = tid >> 6; c < npiv; c += 4) {   // (column c by wave, rows by lane: no integer divisions)
+    const int r = tid & 63;
+    if (r < npiv) L11[r + 65 * c] = Lg[r + (size_t)m * c];
   }
   if (tid < npiv) li[tid] = Lg[(size_t)m * npiv + tid];
   if (wait_parent) {   // the boundary values come from fronts of this launch: the parent's flag covers all ancestors
