@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--dump-xp", default="", help="rank 0 saves the pose increment to this .npy (cross-run comparison)")
     args = ap.parse_args()
 
+    from openslam_g2o_amd.launch import relaunch_if_needed
+    relaunch_if_needed(args.gpus, __file__)       # plain `python bench.py --gpus N`: one rank per GPU via torch.distributed.run
+
     import torch
     from openslam_g2o_amd import capi, synthetic as S
     from openslam_g2o_amd import distributed as D
@@ -159,12 +162,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     emulate = None
     if args.emulate:
         emulate = tuple(int(v) for v in args.emulate.split("/"))
+    comm_note = None
+    if world > 1 and args.comm == "rccl" and torch.cuda.device_count() < world:
+        # fewer GPUs than ranks (a 1-GPU box): RCCL refuses two ranks per device -> functional run through host staging
+        comm_note = "rccl requested, %d GPU(s) visible for %d ranks: ranks share cuda:0, exchange staged through gloo" % (
+            torch.cuda.device_count(), world)
+        if rank == 0:
+            sys.stderr.write("bench: " + comm_note + "\n")
+        args.comm = "staged"
     if args.comm == "staged":
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -268,13 +279,17 @@ def main():
         ok = step() and ok
     barrier()
 
+    ktimes = solver.local.kernelTimes(reset=True)
+    ktimes.update(dom_timed)
+    rank_tables = None
+    if world > 1:
+        mine = {name: round(1e3 * tot / n, 5) for name, (tot, n) in ktimes.items()}
+        rank_tables = [None] * world
+        dist.all_gather_object(rank_tables, mine)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-
-    ktimes = solver.local.kernelTimes(reset=True)
-    ktimes.update(dom_timed)
     st = solver.local.stats()
     S_blocks = solver.local.nnzb(capi.HSCHUR)
     pp_nnzb = solver.local.nnzb(capi.HPP)
@@ -337,6 +352,11 @@ def main():
         out["collectives"] = lib_comm
         out["shard"] = dict(rank0_edges=E_loc, rank0_landmarks=L_loc, exchange_doubles_per_solve=solver.exchange_volume(),
                             comm=args.comm)
+        if comm_note:
+            out["shard"]["comm_note"] = comm_note
+        if rank_tables:
+            out["per_rank_kernel_ms"] = rank_tables      # one table per rank, same slots as "kernels"
+            out["all_reduce_ms"] = {k: [t.get(k) for t in rank_tables] for k in sorted(rank_tables[0]) if k.startswith("exchange(")}
         if solver.mode == "subtree":
             out["shard"].update(boundary_blocks=int(len(solver.boundary)), reduced_blocks=int(solver.nnzb_reduced),
                                 poses_per_rank=np.bincount(solver.pose_owner + 1).tolist())

@@ -4,8 +4,8 @@ config 5 -- 100k-pose / 1M-landmark BA, Huber kernel (delta = 1), 5 % outliers, 
 with estimates, errors and Jacobians resident on the device.  Prints one JSON line on rank 0.
 
     python lm_bench.py                                  one GPU
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 lm_bench.py --gpus N
-                                                        N GPUs: sharded buildSystem / Schur / subtree-distributed Cholesky,
+    python lm_bench.py --gpus N                         N GPUs (re-executes itself under torch.distributed.run; also
+                                                        accepts being started by a launcher): sharded buildSystem / Schur / subtree-distributed Cholesky,
                                                         collectives inside libg2ohip (RCCL), one process per GPU
 """
 import argparse
@@ -26,12 +26,14 @@ def main():
     ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
                     help="staged: gloo + host staging with every rank on cuda:0 (functional check on a 1-GPU box)")
     args = ap.parse_args()
+    from openslam_g2o_amd.launch import relaunch_if_needed
+    relaunch_if_needed(args.gpus, __file__)
     from openslam_g2o_amd import capi, lm, synthetic as S
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     prob = S.make_ba_problem(args.poses, args.landmarks, outlier_frac=0.05)
     sync = None
     if world == 1:
@@ -44,6 +46,8 @@ def main():
         import torch.distributed as dist
         from openslam_g2o_amd import distributed as D
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.comm == "rccl" and torch.cuda.device_count() < world:
+            args.comm = "staged"      # a 1-GPU box: RCCL refuses two ranks per device
         if args.comm == "staged":
             local_rank = 0
         torch.cuda.set_device(local_rank)

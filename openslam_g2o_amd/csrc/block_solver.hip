@@ -3330,23 +3330,29 @@ int BlockSolver::solve_sharded() {
   // (1) local Schur pass; boundary blocks of the reduced system + boundary right-hand sides summed over the ranks
   solve_schur();
   if (ex_.nbb > 0 || ex_.nbp > 0) {
+    prof.begin(KernelProf::kExBoundary, st_);   // (pack + all-reduce + unpack: what the exchange costs the solve)
     exchange_pack(1);
     comm.all_reduce(ex_.buf1.p, (size_t)ex_.nbb * p_ * p_ + (size_t)ex_.nbp * p_, 0, st_);
     exchange_unpack(1);
+    prof.end(KernelProf::kExBoundary, st_);
   }
   // (2) own subtrees: factor + forward sweep; update matrices / vectors of the subtree roots summed (separator-sized)
   solve_reduced_local();
   {
     size_t n = 0;
     double* xb = chol_->exchange_buffer(&n);
+    prof.begin(KernelProf::kExRoots, st_);
     comm.all_reduce(xb, n, 0, st_);
+    prof.end(KernelProf::kExRoots, st_);
   }
   // (3) shared top of the tree (redundant), backward sweep down the own subtrees; halo x_p + failure flags summed
   solve_reduced_shared();
   solve_reduced_finish_async();
+  prof.begin(KernelProf::kExHalo, st_);
   exchange_pack(3);
   comm.all_reduce(ex_.buf3.p, (size_t)ex_.nh * p_ + 1, 0, st_);
   exchange_unpack(3);
+  prof.end(KernelProf::kExHalo, st_);
   solve_back_substitute();           // (harmless after a failed factorisation: the caller discards x)
   return exchange_status();
 }

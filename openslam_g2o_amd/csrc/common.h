@@ -131,11 +131,12 @@ __device__ __forceinline__ void stage_copy(T* __restrict__ dst, const T* __restr
 // Per-kernel timing with HIP events on the launch stream (enabled by g2ohip_set_profiling).
 struct KernelProf {
   enum Slot { kAsmPose = 0, kAsmLandmark, kAsmOffPP, kAsmOffPL, kLmInverse, kSchurBlocks, kSchurRhs, kCholFactor, kCholSolve,
-              kBackSub, kLambda, kNumSlots };
+              kBackSub, kLambda, kExBoundary, kExRoots, kExHalo, kNumSlots };
   static const char* name(int s) {
     static const char* n[] = {"assemble_vertex(pose)", "assemble_vertex(landmark)", "assemble_offdiag(Hpp)", "assemble_offdiag(Hpl)",
                               "landmark_inverse", "schur_tiles", "schur_reduce", "chol_factor(all levels)", "chol_solve(all levels)",
-                              "back_substitute", "set_lambda/restore"};
+                              "back_substitute", "set_lambda/restore", "exchange(boundary blocks + b_p)", "exchange(subtree roots)",
+                              "exchange(halo x_p + status)"};
     return (s >= 0 && s < kNumSlots) ? n[s] : "?";
   }
   bool enabled = false;

@@ -7,6 +7,8 @@ import numpy as np
 from openslam_g2o_amd import g2o_io, synthetic as S
 from oracle import oracle as O
 
+TOL_DX = 1e-8          # stated fp64 tolerance on dx where the system is well conditioned
+
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -76,3 +78,21 @@ def sphere_golden():
     g["poses"] = O.se3_from_qt(g["estimates"], normalize=False)
     g["Z"] = O.se3_from_qt(g["meas"], normalize=True)
     return g
+
+
+def dx_tolerance(o):
+    """max(TOL_DX, 4 cond eps) with cond of the oracle's (damped) reduced pose system, dense."""
+    cp, ri = o.pattern("hs")
+    p = o.p
+    nb = len(cp) - 1
+    H = np.zeros((nb * p, nb * p))
+    V = o.values("Hschur").reshape(-1, p, p)
+    for c in range(nb):
+        for q in range(cp[c], cp[c + 1]):
+            r = ri[q]
+            blk = V[q].T                                  # column-major block
+            H[r * p:(r + 1) * p, c * p:(c + 1) * p] = blk
+            H[c * p:(c + 1) * p, r * p:(r + 1) * p] = blk.T
+    ev = np.linalg.eigvalsh(H)
+    cond = ev[-1] / ev[0]
+    return max(TOL_DX, 4.0 * cond * np.finfo(float).eps), cond

@@ -10,7 +10,7 @@ import socket
 import numpy as np
 import pytest
 
-from tests.helpers import ba_case, oracle_ba, relerr
+from tests.helpers import ba_case, dx_tolerance, oracle_ba, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -78,6 +78,7 @@ def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused, x_exch
     o.set_lambda(lam, True)
     assert o.solve()
     x = o.x()
+    tol = dx_tolerance(o)[0]          # SURVEY 8d's 1e-8, or the cond-scaled bound where the reduced system is ill-conditioned
     nP = pr["nP"]
     xp, xl = x[:6 * nP], x[6 * nP:].reshape(-1, 3)
     seen = np.zeros(pr["nL"], int)
@@ -86,13 +87,13 @@ def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused, x_exch
         z = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
         assert bool(z["ok"])
         assert abs(float(z["chi2"]) - chi2) <= 1e-9 * chi2
-        assert np.abs(z["xp"] - xp).max() <= 1e-7 * np.abs(xp).max()          # gathered x_p
+        assert np.abs(z["xp"] - xp).max() <= tol * np.abs(x).max()          # gathered x_p
         v = np.repeat(z["valid"], 6) if x_exchange == "halo" else np.ones(6 * nP, bool)
-        assert np.abs(z["xloc"][v] - xp[v]).max() <= 1e-7 * np.abs(xp).max()  # own + shared + halo poses without the gather
+        assert np.abs(z["xloc"][v] - xp[v]).max() <= tol * np.abs(x).max()  # own + shared + halo poses without the gather
         assert int(z["halo"]) < 0.1 * nP and int(z["bposes"]) < 0.2 * nP
         idx = z["lm_index"]
         seen[idx] += 1
-        assert np.abs(z["xl"].reshape(-1, 3) - xl[idx]).max() <= 1e-7 * np.abs(xl).max()   # x_l sharded by owner
+        assert np.abs(z["xl"].reshape(-1, 3) - xl[idx]).max() <= tol * np.abs(x).max()   # x_l sharded by owner
         owned = z["owned"]
         assert owned[1:].min() > 0.6 * nP / world and owned[0] < 0.2 * nP      # balanced subtrees, small shared top
         assert int(z["boundary"]) < 0.25 * int(z["nnzb"])                     # most Schur blocks never leave their rank
@@ -114,6 +115,7 @@ def test_subtree_distributed_solve_on_a_graph_with_loop_closures(tmp_path, world
     o.set_lambda(lam, True)
     assert o.solve()
     x = o.x()
+    tol = dx_tolerance(o)[0]          # SURVEY 8d's 1e-8, or the cond-scaled bound where the reduced system is ill-conditioned
     nP = pr["nP"]
     xp, xl = x[:6 * nP], x[6 * nP:].reshape(-1, 3)
     seen = np.zeros(pr["nL"], int)
@@ -121,12 +123,12 @@ def test_subtree_distributed_solve_on_a_graph_with_loop_closures(tmp_path, world
         z = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
         assert bool(z["ok"])
         assert abs(float(z["chi2"]) - chi2) <= 1e-9 * chi2
-        assert np.abs(z["xp"] - xp).max() <= 1e-7 * np.abs(xp).max()
+        assert np.abs(z["xp"] - xp).max() <= tol * np.abs(x).max()
         v = np.repeat(z["valid"], 6)
-        assert np.abs(z["xloc"][v] - xp[v]).max() <= 1e-7 * np.abs(xp).max()
+        assert np.abs(z["xloc"][v] - xp[v]).max() <= tol * np.abs(x).max()
         idx = z["lm_index"]
         seen[idx] += 1
-        assert np.abs(z["xl"].reshape(-1, 3) - xl[idx]).max() <= 1e-7 * np.abs(xl).max()
+        assert np.abs(z["xl"].reshape(-1, 3) - xl[idx]).max() <= tol * np.abs(x).max()
     assert (seen == 1).all()
 
 
@@ -169,6 +171,7 @@ def test_sharded_matrix_free_pcg_matches_oracle(tmp_path, world):
     o.set_lambda(lam, True)
     assert o.solve()
     x = o.x()
+    tol = dx_tolerance(o)[0]          # SURVEY 8d's 1e-8, or the cond-scaled bound where the reduced system is ill-conditioned
     nP = pr["nP"]
     xp, xl = x[:6 * nP], x[6 * nP:].reshape(-1, 3)
     its = []
@@ -265,4 +268,24 @@ def test_library_comm_over_rccl_single_rank():
     assert abs(chi - o.chi2()) <= 1e-9 * chi and abs(md - o.max_diagonal()) <= 1e-12 * md
     o.set_lambda(7.0, True)
     assert o.solve()
-    assert relerr(x, o.x()) < 1e-7 and abs(sc - o.compute_scale(7.0)) <= 1e-6 * abs(sc)
+    assert relerr(x, o.x()) < dx_tolerance(o)[0] and abs(sc - o.compute_scale(7.0)) <= 1e-6 * abs(sc)
+
+
+def test_bench_launches_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no launcher in front, WORLD_SIZE unset) starts one rank per GPU itself; on this
+    1-GPU box the two ranks share cuda:0 and the exchange is staged through gloo.  Rank 0 prints the one JSON line with
+    the collectives' kind, a kernel table per rank and the three all-reduce times."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--comm", "staged", "--poses", "3000",
+                        "--landmarks", "30000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [q for q in r.stdout.splitlines() if q.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["solve_ok"] and out["collectives"] == "host"
+    assert len(out["per_rank_kernel_ms"]) == 2
+    assert len(out["all_reduce_ms"]) == 3 and all(len(v) == 2 and v[0] is not None for v in out["all_reduce_ms"].values())

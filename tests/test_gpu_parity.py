@@ -22,27 +22,9 @@ from tests.helpers import GOLD, ba_case, hip_ba, manhattan_golden, oracle_ba, re
 pytestmark = pytest.mark.gpu
 
 TOL_MAT = 1e-12
-TOL_DX = 1e-8          # stated fp64 tolerance on dx where the system is well conditioned
+from tests.helpers import TOL_DX, dx_tolerance  # noqa: E402,F401
 TOL_RES = 1e-11
 TOL_CHI = 1e-9
-
-
-def dx_tolerance(o):
-    """max(TOL_DX, 4 cond eps) with cond of the oracle's (damped) reduced pose system, dense."""
-    cp, ri = o.pattern("hs")
-    p = o.p
-    nb = len(cp) - 1
-    H = np.zeros((nb * p, nb * p))
-    V = o.values("Hschur").reshape(-1, p, p)
-    for c in range(nb):
-        for q in range(cp[c], cp[c + 1]):
-            r = ri[q]
-            blk = V[q].T                                  # column-major block
-            H[r * p:(r + 1) * p, c * p:(c + 1) * p] = blk
-            H[c * p:(c + 1) * p, r * p:(r + 1) * p] = blk.T
-    ev = np.linalg.eigvalsh(H)
-    cond = ev[-1] / ev[0]
-    return max(TOL_DX, 4.0 * cond * np.finfo(float).eps), cond
 
 
 def _capi():
