@@ -57,11 +57,14 @@ struct CholOptions {
   int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
+  int band_kernel = 1;                   // leaf chains of a band (+ one dense border) on the sliding-window kernel (band_chain.inc)
+  int band_waves = 4;                    // ... its workgroup size in wavefronts (2, 3 or 4)
 };
 
 struct CholStats {
   size_t nnzL = 0;        // scalar nnz(L) incl. diagonal
   size_t n_fronts = 0, n_levels = 0, n_tasks = 0, max_front_dim = 0;
+  size_t n_band = 0;      // leaf chains on the band kernel
   double flops = 0;       // factorisation flops (dense-front count)
   double t_symbolic = 0;  // seconds, host
   size_t bytes_L = 0, bytes_U = 0;
@@ -110,6 +113,21 @@ struct FrontRec {
                                  // pad[1]: parent front (bits 0-23) | children to wait for (24-30) | signal the parent (31)
 };
 
+// One leaf CHAIN of fronts whose rows are a band (every pivot block couples to at most the next four blocks) plus one
+// dense border of at most four blocks: what nested dissection leaves at the bottom of the tree of a camera trajectory.
+// band_chain.inc factorises such a chain on a sliding window of 16-column tiles.
+struct BandChainRec {
+  int f_first, nfronts;   // the chain's fronts (consecutive)
+  int nblk, nS, nR;       // pivot blocks; border blocks; blocks of the band that stay (the boundary rows that continue the band)
+  int ntiles;             // 16-row tiles of the band that hold original entries
+  int tab_off, tab_n;     // per-chain tables (ints): front records | front of every pivot block | tile pointers | tile lists
+  int ent0, nent;         // original blocks of the chain (three int4 each)
+  int c0;                 // first pivot block column (permuted order)
+  int ublk;               // 8 x 4 bits: boundary position (in the last front) of the staying band blocks (0-3) and of the border blocks (4-7)
+  int pad[4];
+};
+constexpr int kBandFrontInts = 17;   // first pivot block, pivot scalars, L offset (2), m, local row of band blocks +0..+7, of border blocks 0..3
+
 struct CholPlanDev {
   const int2* slots;                   // launch slot -> (first front id, chain length)
   const int *task_ptr, *task_fronts;   // task t = chain of fronts task_fronts[task_ptr[t] .. task_ptr[t+1])
@@ -133,6 +151,11 @@ struct CholPlanDev {
   int dep_spin_limit;
   long long* dbg;   // G2OHIP_CHOL_STAMPS builds only: per-launch wall-clock stamps of workgroup 0
   long long* tl;    // ... and (start, end) wall-clock of every workgroup of the wave-kernel launch
+  // band chains (band_chain.inc)
+  const BandChainRec* band_rec;
+  const int* band_tab;
+  const int4* band_ent;    // (q, pos, -, -), (-, -, -, first row: band scalar or 0x10000 | border scalar), (first column, -, -, -)  -- plain source
+  const int4* band_entv;   // the same with the virtual source's fields (set_virtual_blocks)
 };
 
 class SparseCholesky {
@@ -259,7 +282,7 @@ class SparseCholesky {
     bool big_ok = false;
   };
   std::vector<LevelLaunch> launches_[2];   // [0] own tasks, [1] shared top-of-tree tasks
-  struct FactorGroup { LevelLaunch LL; int first_level, last_level; bool dep; };
+  struct FactorGroup { LevelLaunch LL; int first_level, last_level; bool dep; int band_count = 0, band_rec0 = 0, band_ent_cap = 0, band_tab_cap = 0; };
   std::vector<FactorGroup> groups_[2];     // factorisation launches: runs of levels (dep: one launch, in-kernel dependencies)
   DevBuf<int> d_ready;
   struct SegCopy { long long a, b; int n, flags; };  // exchange segment: a = offset in U (or w: flag 2), b = offset in xbuf; flag 1 = mine
@@ -268,6 +291,11 @@ class SparseCholesky {
   DevBuf<long long> d_dbg;
   DevBuf<int2> d_slots, d_fslots, d_bslots;
   DevBuf<int> d_asm_vq, d_asm_vpos, d_asm_v, d_asm_r8;
+  DevBuf<BandChainRec> d_band_rec;
+  DevBuf<int> d_band_tab;
+  DevBuf<int4> d_band_ent, d_band_entv;
+  std::vector<int4> band_ent_h_;        // host copy of d_band_ent (set_virtual_blocks derives d_band_entv from it)
+  std::vector<int> band_ent_asm_;       // assembly entry (index into asm_q) of every band entry
   DevBuf<int4> d_big_tiles;
   int n_slots_ = 0;
   bool dep_off_ = false, dep_stalled_ = false;

@@ -121,9 +121,51 @@ void nested_dissection(int n, const std::vector<int>& xadj, const std::vector<in
       nlev = nl2;
     }
     if (sz <= leaf || nlev < 3) {
-      // leaf: BFS (Cuthill-McKee like) order from the peripheral node
-      for (int k = 0; k < sz; ++k) perm[it.base + k] = W.queue[k];
+      // leaf: Cuthill-McKee order.  Start = the node of minimum degree (inside the region) in the last level of the
+      // level structure (George & Liu's choice of a pseudo-peripheral node); the unnumbered neighbours of a node
+      // are numbered by increasing degree.  On a band (a stretch of a camera trajectory) this is the natural order
+      // from one end, in either direction: every column then reaches at most `half-width` blocks down, which is
+      // what the sliding-window kernel (band_chain.inc) relies on; the plain queue order above numbers the
+      // neighbours of the start node farthest first.
+      auto deg = [&](int v) {
+        int d = 0;
+        for (int q = xadj[v]; q < xadj[v + 1]; ++q)
+          if (W.region[adj[q]] == it.rid) ++d;
+        return d;
+      };
+      int start = W.queue.back();
+      {
+        const int last_level = W.level[start];
+        int best = deg(start);
+        for (int k = sz - 1; k >= 0 && W.level[W.queue[k]] == last_level; --k) {
+          const int d = deg(W.queue[k]);
+          if (d < best || (d == best && W.queue[k] < start)) {
+            best = d;
+            start = W.queue[k];
+          }
+        }
+      }
       W.clear_levels();
+      std::vector<int> order;
+      order.reserve(sz);
+      order.push_back(start);
+      W.level[start] = 0;
+      std::vector<std::pair<int, int>> nbr;
+      for (size_t head = 0; head < order.size(); ++head) {
+        const int v = order[head];
+        nbr.clear();
+        for (int q = xadj[v]; q < xadj[v + 1]; ++q) {
+          const int u = adj[q];
+          if (W.region[u] == it.rid && W.level[u] < 0) {
+            W.level[u] = W.level[v] + 1;
+            nbr.emplace_back(deg(u), u);
+          }
+        }
+        std::sort(nbr.begin(), nbr.end());
+        for (const auto& pr : nbr) order.push_back(pr.second);
+      }
+      for (int k = 0; k < sz; ++k) perm[it.base + k] = order[k];
+      for (int v : order) W.level[v] = -1;
       continue;
     }
     // level sizes
@@ -1171,6 +1213,232 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       l = l1;
     }
   }
+  // --- band chains (band_chain.inc): leaf tasks whose rows are a band of half-width <= 4 blocks plus one border of <= 4
+  // blocks.  They go to the head of level 0 of their launch group and are factorised by the sliding-window kernel in a
+  // launch of their own in front of the group's (the parents' dependency counters are bumped the same way).
+  {
+    std::vector<BandChainRec> brecs;
+    std::vector<int> btab;
+    band_ent_h_.clear();
+    band_ent_asm_.clear();
+    constexpr int kMaxFr = 24, kMaxBlk = 72, kMaxEnt = 224;
+    struct BandInfo {
+      BandChainRec rec;
+      std::vector<int> tab, ent_asm;
+      std::vector<int4> ent;
+    };
+    int why_cnt[32] = {0};
+    auto why = [&](int c) { ++why_cnt[c & 31]; return false; };
+    auto try_band = [&](int t, BandInfo& out) -> bool {
+      if (bs != 6 || !opt.band_kernel) return why(1);
+      const int k0 = S.task_ptr[t], k1 = S.task_ptr[t + 1];
+      const int nfr = k1 - k0;
+      if (nfr < 1 || nfr > kMaxFr) return why(2);
+      const int f0 = S.task_fronts[k0], fl = S.task_fronts[k1 - 1];
+      if (S.child_off[f0 + 1] != S.child_off[f0]) return why(3);   // a leaf of the tree
+      for (int k = k0 + 1; k < k1; ++k)
+        if (S.task_fronts[k] != S.task_fronts[k - 1] + 1) return why(4);
+      const int base = S.sn_start[f0], nblk = S.sn_start[fl + 1] - base;
+      if (nblk < 1 || nblk > kMaxBlk) return why(5);
+      // boundary rows of the last front: border = those the first front has already, the rest continues the band
+      const int* Bl = S.rows.data() + S.rows_off[fl];
+      const int nbl = S.f_nb[fl];
+      const int* B0 = S.rows.data() + S.rows_off[f0];
+      const int nb0 = S.f_nb[f0];
+      std::vector<int> Sset, Rset;
+      for (int k = 0; k < nbl; ++k) (std::binary_search(B0, B0 + nb0, Bl[k]) && nfr > 1 ? Sset : Rset).push_back(Bl[k]);
+      if (nfr == 1) {   // one front: every boundary row may be band or border; the nearest four continue the band
+        Sset.clear();
+        Rset.assign(Bl, Bl + nbl);
+      }
+      // the staying band rows in the order they are met (first column that couples to them)
+      {
+        std::vector<std::pair<int, int>> key;
+        for (int r : Rset) {
+          int first = nblk;
+          for (int j = base; j < base + nblk && first == nblk; ++j)
+            if (std::binary_search(st_[j].begin(), st_[j].end(), r)) first = j - base;
+          key.emplace_back(first, r);
+        }
+        std::sort(key.begin(), key.end());
+        for (size_t k = 0; k < key.size(); ++k) Rset[k] = key[k].second;
+        if (nfr == 1 && Rset.size() > 4) {   // the ones met first stay band rows, the others are the border
+          Sset.assign(Rset.begin() + 4, Rset.end());
+          Rset.resize(4);
+          std::sort(Sset.begin(), Sset.end());
+        }
+      }
+      if (Sset.size() > 4 || Rset.size() > 4) return why(6);
+      auto cls = [&](int r, int& bandblk, int& borderk) -> bool {
+        bandblk = borderk = -1;
+        if (r >= base && r < base + nblk) {
+          bandblk = r - base;
+          return true;
+        }
+        for (size_t k = 0; k < Rset.size(); ++k)
+          if (Rset[k] == r) {
+            bandblk = nblk + (int)k;
+            return true;
+          }
+        for (size_t k = 0; k < Sset.size(); ++k)
+          if (Sset[k] == r) {
+            borderk = (int)k;
+            return true;
+          }
+        return false;
+      };
+      for (int j = base; j < base + nblk; ++j)
+        for (int i : st_[j]) {
+          int bb, bk;
+          if (!cls(i, bb, bk)) return why(8);
+          if (bb >= 0 && bb - (j - base) > 4) {
+            static int shown = 0;
+            if (getenv("G2OHIP_BAND_DEBUG") && shown++ < 3) {
+              fprintf(stderr, "band reject: chain of %d blocks, col %d row class %d; pivots (original ids):", nblk, j - base, bb);
+              for (int q = 0; q < nblk; ++q) fprintf(stderr, " %d", S.perm[base + q]);
+              fprintf(stderr, " | R:");
+              for (int r : Rset) fprintf(stderr, " %d", S.perm[r]);
+              fprintf(stderr, " | S:");
+              for (int r : Sset) fprintf(stderr, " %d", S.perm[r]);
+              fprintf(stderr, "\n");
+            }
+            return why(9);   // beyond the window of its column
+          }
+        }
+      BandChainRec& R = out.rec;
+      std::memset(&R, 0, sizeof(R));
+      R.f_first = f0;
+      R.nfronts = nfr;
+      R.nblk = nblk;
+      R.nS = (int)Sset.size();
+      R.nR = (int)Rset.size();
+      R.c0 = base;
+      out.tab.clear();
+      out.ent.clear();
+      out.ent_asm.clear();
+      std::vector<int> colfront(nblk, 0);
+      for (int fi = 0; fi < nfr; ++fi) {
+        const int f = f0 + fi, pb = S.sn_start[f] - base, ns = S.f_ns[f];
+        const long long Loff = S.L_off[f];
+        int fr[kBandFrontInts];
+        fr[0] = pb;
+        fr[1] = ns * bs;
+        fr[2] = (int)(unsigned int)(Loff & 0xffffffffLL);
+        fr[3] = (int)(Loff >> 32);
+        fr[4] = (ns + S.f_nb[f]) * bs;
+        for (int d = 0; d < 8; ++d) {
+          const int bb = pb + d;
+          int prow = -1;
+          if (bb < nblk) prow = base + bb;
+          else if (bb - nblk < (int)Rset.size()) prow = Rset[bb - nblk];
+          fr[5 + d] = prow >= 0 ? local_pos(f, prow) : -1;
+        }
+        for (int k = 0; k < 4; ++k) {
+          fr[13 + k] = k < (int)Sset.size() ? local_pos(f, Sset[k]) : -1;
+          if (k < (int)Sset.size() && fr[13 + k] < 0) return why(10);   // (the border is carried by every front)
+        }
+        out.tab.insert(out.tab.end(), fr, fr + kBandFrontInts);
+        for (int c = 0; c < ns; ++c) colfront[pb + c] = fi;
+        for (int e = S.asm_off[f]; e < S.asm_off[f + 1]; ++e) {
+          const int pos = S.asm_pos[e], lr = pos & 0x7fff, lc = (pos >> 15) & 0x7fff;
+          int bb = -1, bk = -1;
+          if (lr < ns) bb = pb + lr;
+          else if (!cls(S.rows[S.rows_off[f] + lr - ns], bb, bk)) return why(11);
+          const int C0 = (pb + lc) * bs;
+          const int R0 = bb >= 0 ? bb * bs : (0x10000 | (bk * bs));
+          if (bb >= 0 && (bb < pb + lc || bb - (pb + lc) > 4)) return why(12);
+          out.ent.push_back(make_int4(S.asm_q[e], pos, 0, 0));
+          out.ent.push_back(make_int4(0, 0, 0, R0));
+          out.ent.push_back(make_int4(C0, 0, 0, 0));
+          out.ent_asm.push_back(e);
+        }
+      }
+      const int nent = (int)out.ent_asm.size();
+      if (nent > kMaxEnt) return why(13);
+      R.nent = nent;
+      R.ntiles = ((nblk + (int)Rset.size()) * bs + 15) / 16;
+      out.tab.insert(out.tab.end(), colfront.begin(), colfront.end());
+      std::vector<std::vector<int>> lists(R.ntiles);
+      for (int i = 0; i < nent; ++i) {
+        const int R0 = out.ent[3 * i + 1].w, C0 = out.ent[3 * i + 2].x;
+        const int a = (R0 & 0x10000) ? C0 : R0;   // border entries enter with their columns, band entries with their rows
+        for (int j = a / 16; j <= (a + bs - 1) / 16; ++j) {
+          if (j >= R.ntiles) return why(14);
+          lists[j].push_back(i);
+        }
+      }
+      int run = 0;
+      for (int j = 0; j < R.ntiles; ++j) {
+        out.tab.push_back(run);
+        run += (int)lists[j].size();
+      }
+      out.tab.push_back(run);
+      for (int j = 0; j < R.ntiles; ++j) out.tab.insert(out.tab.end(), lists[j].begin(), lists[j].end());
+      R.tab_n = (int)out.tab.size();
+      const int nsl = S.f_ns[fl];
+      for (size_t k = 0; k < Rset.size(); ++k) R.ublk |= (local_pos(fl, Rset[k]) - nsl) << (4 * (int)k);
+      for (size_t k = 0; k < Sset.size(); ++k) R.ublk |= (local_pos(fl, Sset[k]) - nsl) << (4 * (4 + (int)k));
+      return true;
+    };
+    int n_band = 0, n_leaf = 0;
+    for (int ph = 0; ph < 2; ++ph)
+      for (FactorGroup& G : groups_[ph]) {
+        if (G.first_level != 0 || !G.LL.wv) continue;
+        const LevelLaunch& L0 = launches_[ph][0];
+        const int b0 = L0.lds_begin, cnt = L0.lds_count;
+        std::vector<int> head, tail;
+        std::vector<BandInfo> infos;
+        for (int i = 0; i < cnt; ++i) {
+          const int t = factor_order[b0 + i];
+          BandInfo bi;
+          ++n_leaf;
+          if (try_band(t, bi)) {
+            head.push_back(t);
+            infos.push_back(std::move(bi));
+          } else {
+            tail.push_back(t);
+          }
+        }
+        if (head.empty()) continue;
+        std::copy(head.begin(), head.end(), factor_order.begin() + b0);
+        std::copy(tail.begin(), tail.end(), factor_order.begin() + b0 + head.size());
+        G.band_count = (int)head.size();
+        G.band_rec0 = (int)brecs.size();
+        for (BandInfo& bi : infos) {
+          bi.rec.tab_off = (int)btab.size();
+          bi.rec.ent0 = (int)band_ent_asm_.size();
+          btab.insert(btab.end(), bi.tab.begin(), bi.tab.end());
+          band_ent_h_.insert(band_ent_h_.end(), bi.ent.begin(), bi.ent.end());
+          band_ent_asm_.insert(band_ent_asm_.end(), bi.ent_asm.begin(), bi.ent_asm.end());
+          G.band_ent_cap = std::max(G.band_ent_cap, bi.rec.nent);
+          G.band_tab_cap = std::max(G.band_tab_cap, bi.rec.tab_n);
+          brecs.push_back(bi.rec);
+        }
+        n_band += G.band_count;
+      }
+    stats_.n_band = (size_t)n_band;
+    if (getenv("G2OHIP_PLAN_DUMP")) {
+      fprintf(stderr, "band chains rejected by rule:");
+      for (int c = 0; c < 32; ++c)
+        if (why_cnt[c]) fprintf(stderr, " %d:%d", c, why_cnt[c]);
+      fprintf(stderr, "\n");
+    }
+    if (getenv("G2OHIP_PLAN_DUMP")) fprintf(stderr, "band chains: %d of %d leaf tasks (entries %zu, table ints %zu)\n", n_band, n_leaf, band_ent_asm_.size(), btab.size());
+    if (brecs.empty()) {
+      BandChainRec z;
+      std::memset(&z, 0, sizeof(z));
+      brecs.push_back(z);
+    }
+    if (btab.empty()) btab.push_back(0);
+    if (band_ent_h_.empty()) band_ent_h_.push_back(make_int4(0, 0, 0, 0));
+    d_band_rec.upload(brecs, st);
+    d_band_tab.upload(btab, st);
+    d_band_ent.upload(band_ent_h_, st);
+    plan_.band_rec = d_band_rec.p;
+    plan_.band_tab = d_band_tab.p;
+    plan_.band_ent = d_band_ent.p;
+    plan_.band_entv = nullptr;
+  }
   d_ready.alloc((size_t)std::max(nf, 1));
   d_ready.zero(st);
   d_task_ptr.upload(S.task_ptr, st);
@@ -1258,6 +1526,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_scratch_off.upload(scratch_off, st);
   d_scratch_ld.upload(scratch_ld, st);
   d_L.alloc((size_t)S.L_total);
+  d_L.zero(st);   // (band_chain.inc never writes the structural zeros of a panel)
   d_U.alloc((size_t)S.U_total);
   d_w.alloc((size_t)S.w_total);
   d_y.alloc((size_t)nb * bs);
@@ -3220,6 +3489,7 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
 }
 
 #include "wave_front.inc"
+#include "band_chain.inc"
 
 // Pivot block of a scratch-slab front (n <= 64 columns) on the matrix cores: the blocked right-looking Cholesky of
 // wave_front_kernel restricted to the pivot block -- the symmetric n x n block as ten upper 16 x 16 tiles in accumulator
@@ -3607,6 +3877,17 @@ void SparseCholesky::set_virtual_blocks(const VirtualBlocks& vb, hipStream_t st)
     d_asm_r8.upload(r8, st);
     plan_.asm_r8 = d_asm_r8.p;
   }
+  if (!band_ent_asm_.empty()) {   // the band chains' copies of their original-block records (band_chain.inc)
+    std::vector<int4> ev(band_ent_h_);
+    for (size_t i = 0; i < band_ent_asm_.size(); ++i) {
+      const int e = band_ent_asm_[i];
+      const int* r = &v[(size_t)e * kVirtInts];
+      ev[3 * i] = make_int4(vq[e], vpos[e], r[0], r[1]);
+      ev[3 * i + 1] = make_int4(r[2], r[3], r[4], band_ent_h_[3 * i + 1].w);
+    }
+    d_band_entv.upload(ev, st);
+    plan_.band_entv = d_band_entv.p;
+  }
   d_asm_vq.upload(vq, st);
   d_asm_vpos.upload(vpos, st);
   d_asm_v.upload(v, st);
@@ -3776,7 +4057,33 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
       G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[3], 0));
       fwd_pending = false;
     }
-    launch_factor(LL, dA, fused, st, G.dep);
+    if (G.band_count > 0 && opt.band_kernel && bs_ == 6) {
+      // the band chains of level 0 first, in a launch of their own (they bump their parents' counters like the others)
+      const bool virt = dA == nullptr;
+      if (virt && (!has_virtual_blocks() || !plan_.band_entv)) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
+      const BandPlanArgs B{plan_.band_rec, plan_.band_tab, virt ? plan_.band_entv : plan_.band_ent, G.band_ent_cap, G.band_tab_cap};
+      const size_t sh = (size_t)(5 * 256 + 10 * 64) * sizeof(double) + (size_t)G.band_ent_cap * 3 * sizeof(int4) + (size_t)G.band_tab_cap * sizeof(int);
+      const double* bp = fused ? d_xp.p : (const double*)nullptr;
+      double* yo = fused ? d_y.p : (double*)nullptr;
+      const WvPlan wp = wv_plan(plan_);
+      const int dep_i = G.dep ? 1 : 0;
+#define G2OHIP_BAND_LAUNCH(V_, NW_) \
+  hipLaunchKernelGGL((band_chain_kernel<6, V_, NW_>), dim3(G.band_count), dim3(64 * NW_), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i)
+      const int nw = opt.band_waves;
+      if (virt) {
+        if (nw == 2) G2OHIP_BAND_LAUNCH(true, 2); else if (nw == 3) G2OHIP_BAND_LAUNCH(true, 3); else G2OHIP_BAND_LAUNCH(true, 4);
+      } else {
+        if (nw == 2) G2OHIP_BAND_LAUNCH(false, 2); else if (nw == 3) G2OHIP_BAND_LAUNCH(false, 3); else G2OHIP_BAND_LAUNCH(false, 4);
+      }
+#undef G2OHIP_BAND_LAUNCH
+      G2OHIP_LAUNCH_CHECK("band_chain_kernel");
+      LevelLaunch rest = LL;
+      rest.lds_begin += G.band_count;
+      rest.lds_count -= G.band_count;
+      if (rest.lds_count > 0) launch_factor(rest, dA, fused, st, G.dep);
+    } else {
+      launch_factor(LL, dA, fused, st, G.dep);
+    }
     // what the factor kernel did not carry (fronts too large for LDS, launches outside the fused kernel's
     // limits) gets its forward step inside the same level
     const bool carried = fwd && big_forward_carried(LL);   // (the scratch-slab fronts' forward step went with their factorisation)

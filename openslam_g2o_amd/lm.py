@@ -283,12 +283,15 @@ class DeviceBAGraph:
         self.s.baDiscardTop()
 
 
-def setup_device_ba(prob, huber_delta=0.0, device=0):
+def setup_device_ba(prob, huber_delta=0.0, device=0, options=None):
     """Build a HipBlockSolver for an openslam_g2o_amd.synthetic BA problem with the estimates, errors
-    and Jacobians produced on the device.  Returns (solver, graph)."""
+    and Jacobians produced on the device.  Returns (solver, graph).  options: g2ohip_set_option pairs that have to be
+    in place before buildStructure (ordering / kernel selection knobs)."""
     import numpy as np
     from . import capi
     s = capi.HipBlockSolver(6, 3, device)
+    for name, value in (options or {}).items():
+        s.setOption(name, value)
     k = s.addEdgeSet(2, prob["v0"], prob["v1"])
     s.buildStructure(prob["nP"], prob["nL"], True)
     s.baSetEdges(k, prob["cam_idx"], prob["pt_idx"], prob["meas"], None, prob["f"], prob["cx"], prob["cy"])
