@@ -58,7 +58,7 @@ struct CholOptions {
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
   int band_kernel = 1;                   // leaf chains of a band (+ one dense border) on the sliding-window kernel (band_chain.inc)
-  int band_waves = 4;                    // ... its workgroup size in wavefronts (2, 3 or 4)
+  int band_waves = 1;                    // ... wavefronts per chain: 1 (the whole window in one wave's registers) or 2, 3, 4 (tiles dealt to the waves)
 };
 
 struct CholStats {

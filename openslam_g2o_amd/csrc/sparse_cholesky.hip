@@ -4070,7 +4070,11 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
 #define G2OHIP_BAND_LAUNCH(V_, NW_) \
   hipLaunchKernelGGL((band_chain_kernel<6, V_, NW_>), dim3(G.band_count), dim3(64 * NW_), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i)
       const int nw = opt.band_waves;
-      if (virt) {
+      if (nw <= 1) {   // one wave per chain
+        const size_t sh1 = (size_t)(5 * 256) * sizeof(double) + (size_t)G.band_ent_cap * 3 * sizeof(int4) + (size_t)G.band_tab_cap * sizeof(int);
+        if (virt) hipLaunchKernelGGL((band_wave_kernel<6, true>), dim3(G.band_count), dim3(64), sh1, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
+        else hipLaunchKernelGGL((band_wave_kernel<6, false>), dim3(G.band_count), dim3(64), sh1, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
+      } else if (virt) {
         if (nw == 2) G2OHIP_BAND_LAUNCH(true, 2); else if (nw == 3) G2OHIP_BAND_LAUNCH(true, 3); else G2OHIP_BAND_LAUNCH(true, 4);
       } else {
         if (nw == 2) G2OHIP_BAND_LAUNCH(false, 2); else if (nw == 3) G2OHIP_BAND_LAUNCH(false, 3); else G2OHIP_BAND_LAUNCH(false, 4);

@@ -20,7 +20,7 @@ def _solve(pr, lam, options, huber=0.0):
     return ok, s.x(), s.stats()
 
 
-@pytest.mark.parametrize("P,L,waves,fold", [(60, 600, 4, 1), (257, 2600, 4, 1), (257, 2600, 3, 1), (257, 2600, 2, 1), (1500, 15000, 4, 0),
+@pytest.mark.parametrize("P,L,waves,fold", [(60, 600, 1, 1), (257, 2600, 1, 1), (257, 2600, 1, 0), (1500, 15000, 1, 1), (4000, 40000, 1, 0), (60, 600, 4, 1), (257, 2600, 4, 1), (257, 2600, 3, 1), (257, 2600, 2, 1), (1500, 15000, 4, 0),
                                              (1500, 15000, 2, 0), (4000, 40000, 4, 1), (4000, 40000, 3, 0)])
 def test_band_kernel_matches_the_general_kernel_and_the_oracle(P, L, waves, fold):
     pr = ba_case(P, L)
