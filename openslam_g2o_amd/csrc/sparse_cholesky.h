@@ -58,7 +58,6 @@ struct CholOptions {
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
   int band_kernel = 1;                   // leaf chains of a band (+ one dense border) on the sliding-window kernel (band_chain.inc)
-  int band_waves = 1;                    // ... wavefronts per chain: 1 (the whole window in one wave's registers) or 2, 3, 4 (tiles dealt to the waves)
 };
 
 struct CholStats {
@@ -120,8 +119,8 @@ struct BandChainRec {
   int f_first, nfronts;   // the chain's fronts (consecutive)
   int nblk, nS, nR;       // pivot blocks; border blocks; blocks of the band that stay (the boundary rows that continue the band)
   int ntiles;             // 16-row tiles of the band that hold original entries
-  int tab_off, tab_n;     // per-chain tables (ints): front records | front of every pivot block | tile pointers | tile lists
-  int ent0, nent;         // original blocks of the chain (three int4 each)
+  int tab_off, tab_n;     // per-chain tables (ints): front records | one record per pivot block (at pad[1]) | tile -> first record (at pad[0])
+  int ent0, nent;         // records of the chain's original blocks, by band tile (two int4 each)
   int c0;                 // first pivot block column (permuted order)
   int ublk;               // 8 x 4 bits: boundary position (in the last front) of the staying band blocks (0-3) and of the border blocks (4-7)
   int pad[4];
@@ -154,7 +153,7 @@ struct CholPlanDev {
   // band chains (band_chain.inc)
   const BandChainRec* band_rec;
   const int* band_tab;
-  const int4* band_ent;    // (q, pos, -, -), (-, -, -, first row: band scalar or 0x10000 | border scalar), (first column, -, -, -)  -- plain source
+  const int4* band_ent;    // records of the original blocks per chain and band tile (two int4 each, see the analysis) -- plain source
   const int4* band_entv;   // the same with the virtual source's fields (set_virtual_blocks)
 };
 

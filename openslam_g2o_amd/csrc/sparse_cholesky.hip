@@ -1355,9 +1355,21 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       }
       const int nent = (int)out.ent_asm.size();
       if (nent > kMaxEnt) return why(13);
-      R.nent = nent;
       R.ntiles = ((nblk + (int)Rset.size()) * bs + 15) / 16;
-      out.tab.insert(out.tab.end(), colfront.begin(), colfront.end());
+      // table: front records | (16-byte aligned) one record per pivot block | tile -> first record
+      while (out.tab.size() % 4) out.tab.push_back(0);
+      R.pad[1] = (int)out.tab.size();
+      for (int cb = 0; cb < nblk; ++cb) {
+        const int fi = colfront[cb];
+        int fr[5];
+        for (int q = 0; q < 5; ++q) fr[q] = out.tab[(size_t)kBandFrontInts * fi + q];   // (copied: the vector grows below)
+        out.tab.push_back(fr[2]);
+        out.tab.push_back(fr[3]);
+        out.tab.push_back(fr[4]);
+        out.tab.push_back(fr[0] | ((fr[1]) << 8) | (fi << 16));
+      }
+      // per band tile the records of the blocks with rows (border blocks: columns) in it: (source offset, -, -, -), (flags, -,
+      // first row relative to the tile | border row, first column relative to the window | to the tile)
       std::vector<std::vector<int>> lists(R.ntiles);
       for (int i = 0; i < nent; ++i) {
         const int R0 = out.ent[3 * i + 1].w, C0 = out.ent[3 * i + 2].x;
@@ -1367,13 +1379,30 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           lists[j].push_back(i);
         }
       }
+      R.pad[0] = (int)out.tab.size();
       int run = 0;
+      std::vector<int4> recs2;
+      std::vector<int> recs_asm;
       for (int j = 0; j < R.ntiles; ++j) {
         out.tab.push_back(run);
+        if ((int)lists[j].size() > 32) return why(15);   // (kBandListCap)
         run += (int)lists[j].size();
+        const int lo = 16 * j;
+        for (int i : lists[j]) {
+          const int4 e0 = out.ent[3 * i];
+          const int R0 = out.ent[3 * i + 1].w, C0 = out.ent[3 * i + 2].x;
+          const bool border = (R0 & 0x10000) != 0;
+          const int flags = ((e0.y >> 30) & 1) | (border ? 4 : 0) | ((!border && R0 == C0) ? 8 : 0);
+          if ((long long)e0.x * bs * bs > 0x7fffff00LL) return why(16);
+          recs2.push_back(make_int4(e0.x * bs * bs, 0, 0, 0));
+          recs2.push_back(make_int4(flags, 0, border ? (R0 & 0xffff) : R0 - lo, border ? C0 - lo : C0 - (lo - 32)));
+          recs_asm.push_back(out.ent_asm[i]);
+        }
       }
       out.tab.push_back(run);
-      for (int j = 0; j < R.ntiles; ++j) out.tab.insert(out.tab.end(), lists[j].begin(), lists[j].end());
+      out.ent.swap(recs2);
+      out.ent_asm.swap(recs_asm);
+      R.nent = run;
       R.tab_n = (int)out.tab.size();
       const int nsl = S.f_ns[fl];
       for (size_t k = 0; k < Rset.size(); ++k) R.ublk |= (local_pos(fl, Rset[k]) - nsl) << (4 * (int)k);
@@ -3877,16 +3906,25 @@ void SparseCholesky::set_virtual_blocks(const VirtualBlocks& vb, hipStream_t st)
     d_asm_r8.upload(r8, st);
     plan_.asm_r8 = d_asm_r8.p;
   }
-  if (!band_ent_asm_.empty()) {   // the band chains' copies of their original-block records (band_chain.inc)
+  if (!band_ent_asm_.empty()) {   // the band chains' records of their original blocks (band_chain.inc), virtual source
     std::vector<int4> ev(band_ent_h_);
+    const long long bb = (long long)bs_ * bs_;
+    bool fits = true;
     for (size_t i = 0; i < band_ent_asm_.size(); ++i) {
       const int e = band_ent_asm_[i];
-      const int* r = &v[(size_t)e * kVirtInts];
-      ev[3 * i] = make_int4(vq[e], vpos[e], r[0], r[1]);
-      ev[3 * i + 1] = make_int4(r[2], r[3], r[4], band_ent_h_[3 * i + 1].w);
+      const int* r = &v[(size_t)e * kVirtInts];   // count, three partial slots, first list index
+      for (int k = 1; k <= 3; ++k) fits = fits && (long long)r[k] * bb < 0xfffff000LL;
+      fits = fits && (long long)vq[e] * bb < 0x7ffff000LL;
+      ev[2 * i] = make_int4(vq[e] >= 0 ? (int)(vq[e] * bb) : -1, (int)(unsigned int)(r[1] * bb), (int)(unsigned int)(r[2] * bb), (int)(unsigned int)(r[3] * bb));
+      const int4 h1 = band_ent_h_[2 * i + 1];
+      ev[2 * i + 1] = make_int4((h1.x & 0xff) | (vpos[e] < 0 ? 2 : 0) | (r[0] << 8), r[4], h1.z, h1.w);
     }
-    d_band_entv.upload(ev, st);
-    plan_.band_entv = d_band_entv.p;
+    if (fits) {
+      d_band_entv.upload(ev, st);
+      plan_.band_entv = d_band_entv.p;
+    } else {
+      plan_.band_entv = nullptr;   // (offsets beyond 32 bits: the general kernel takes these chains)
+    }
   }
   d_asm_vq.upload(vq, st);
   d_asm_vpos.upload(vpos, st);
@@ -4057,30 +4095,21 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
       G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[3], 0));
       fwd_pending = false;
     }
-    if (G.band_count > 0 && opt.band_kernel && bs_ == 6) {
+    const bool band_src = dA != nullptr || plan_.band_entv != nullptr;   // (a virtual source whose offsets fit the records)
+    if (G.band_count > 0 && opt.band_kernel && bs_ == 6 && band_src) {
       // the band chains of level 0 first, in a launch of their own (they bump their parents' counters like the others)
       const bool virt = dA == nullptr;
-      if (virt && (!has_virtual_blocks() || !plan_.band_entv)) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
-      const BandPlanArgs B{plan_.band_rec, plan_.band_tab, virt ? plan_.band_entv : plan_.band_ent, G.band_ent_cap, G.band_tab_cap};
-      const size_t sh = (size_t)(5 * 256 + 10 * 64) * sizeof(double) + (size_t)G.band_ent_cap * 3 * sizeof(int4) + (size_t)G.band_tab_cap * sizeof(int);
+      if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
+      const BandPlanArgs B{plan_.band_rec, plan_.band_tab, virt ? plan_.band_entv : plan_.band_ent, 0, G.band_tab_cap,
+                           getenv("G2OHIP_BAND_ABL") ? atoi(getenv("G2OHIP_BAND_ABL")) : 0};
+      const size_t sh = (size_t)(5 * 256) * sizeof(double) + (size_t)(4 * kBandListCap) * sizeof(int4) + (size_t)(64 + 96 + G.band_tab_cap + 4) * sizeof(int);
       const double* bp = fused ? d_xp.p : (const double*)nullptr;
       double* yo = fused ? d_y.p : (double*)nullptr;
       const WvPlan wp = wv_plan(plan_);
       const int dep_i = G.dep ? 1 : 0;
-#define G2OHIP_BAND_LAUNCH(V_, NW_) \
-  hipLaunchKernelGGL((band_chain_kernel<6, V_, NW_>), dim3(G.band_count), dim3(64 * NW_), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i)
-      const int nw = opt.band_waves;
-      if (nw <= 1) {   // one wave per chain
-        const size_t sh1 = (size_t)(5 * 256) * sizeof(double) + (size_t)G.band_ent_cap * 3 * sizeof(int4) + (size_t)G.band_tab_cap * sizeof(int);
-        if (virt) hipLaunchKernelGGL((band_wave_kernel<6, true>), dim3(G.band_count), dim3(64), sh1, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
-        else hipLaunchKernelGGL((band_wave_kernel<6, false>), dim3(G.band_count), dim3(64), sh1, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
-      } else if (virt) {
-        if (nw == 2) G2OHIP_BAND_LAUNCH(true, 2); else if (nw == 3) G2OHIP_BAND_LAUNCH(true, 3); else G2OHIP_BAND_LAUNCH(true, 4);
-      } else {
-        if (nw == 2) G2OHIP_BAND_LAUNCH(false, 2); else if (nw == 3) G2OHIP_BAND_LAUNCH(false, 3); else G2OHIP_BAND_LAUNCH(false, 4);
-      }
-#undef G2OHIP_BAND_LAUNCH
-      G2OHIP_LAUNCH_CHECK("band_chain_kernel");
+      if (virt) hipLaunchKernelGGL((band_wave_kernel<6, true>), dim3(G.band_count), dim3(64), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
+      else hipLaunchKernelGGL((band_wave_kernel<6, false>), dim3(G.band_count), dim3(64), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
+      G2OHIP_LAUNCH_CHECK("band_wave_kernel");
       LevelLaunch rest = LL;
       rest.lds_begin += G.band_count;
       rest.lds_count -= G.band_count;

@@ -1,8 +1,8 @@
 #!/bin/bash
-# band-chain kernel: its tests, then the bench with band_kernel on (2 / 3 / 4 waves) and off
+# band-chain kernel: its tests, then the bench with band_kernel off and on
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_band_chain.py -m gpu -x -q > gpurun_out/band_tests.log 2>&1; tail -25 gpurun_out/band_tests.log
-for opt in ${OPTS:-"band_kernel=0" "band_waves=1" "band_waves=4"}; do
+for opt in ${OPTS:-"band_kernel=0" "band_kernel=1"}; do
   timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --opt $opt > gpurun_out/band_$opt.log 2>&1
   python - "$opt" <<EOP
 import json, sys

@@ -1,9 +1,9 @@
 #!/bin/bash
 # per-kernel durations of the factor slot with the band kernel (kernel trace, plain launches)
 R=$PWD; mkdir -p $R/gpurun_out; export TMPDIR=/tmp; cd /tmp
-for nw in ${NWS:-4 3 2}; do
+for nw in ${NWS:-1}; do
   rm -rf /tmp/bp$nw
-  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/bp$nw -o p -- python $R/bench.py --no-cpu-baseline --graph off --steps 10 --warmup 2 --opt band_waves=$nw ${BENCH_ARGS:-} > $R/gpurun_out/bandprof_$nw.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/bp$nw -o p -- python $R/bench.py --no-cpu-baseline --graph off --steps 10 --warmup 2 --opt band_kernel=$nw ${BENCH_ARGS:-} > $R/gpurun_out/bandprof_$nw.log 2>&1
   python $R/tools/rocpd_summary.py $(find /tmp/bp$nw -name "*.db" | head -1) $R/gpurun_out/bandprof_$nw.csv
   echo "== band_waves=$nw"; head -8 $R/gpurun_out/bandprof_$nw.csv | cut -c1-60,200-
   python - <<EOP
