@@ -302,6 +302,8 @@ class SparseCholesky {
   [[maybe_unused]] int dbg_launch_ = 0;   // (G2OHIP_CHOL_STAMPS builds)
   size_t xbuf_count_ = 0;
   void launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep = false, int parts = 3);
+  bool band_usable(const FactorGroup& G, const double* dA) const;
+  void launch_band(const FactorGroup& G, const double* dA, bool fused, hipStream_t st, bool dep);   // the group's band chains (band_chain.inc)
   hipStream_t side_[2] = {nullptr, nullptr};   // factor_phase: the two halves of a level / the forward step of its large fronts
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false, bool skip_glb = false);

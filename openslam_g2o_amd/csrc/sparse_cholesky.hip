@@ -351,7 +351,11 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     // duplicates cannot occur: the pattern has unique (r,c)
   }
   std::vector<int> perm0;
-  nested_dissection(nb, xadj, adj, opt.nd_leaf, perm0);
+  // leaf size: large systems get about as many leaves as the band kernel has chain slots (256 CUs x 8 one-wave chains, one
+  // round instead of two and one tree level less: 0.53 -> 0.48 ms at the metric configuration), within what a chain may hold
+  int nd_leaf = opt.nd_leaf;
+  if (opt.band_kernel && bs == 6) nd_leaf = std::min(std::max(nd_leaf, (nb + 2047) / 2048), 128);
+  nested_dissection(nb, xadj, adj, nd_leaf, perm0);
   // --- etree + postorder, compose
   std::vector<int> iperm(nb), cp, ci, rp, ri, parent, post;
   for (int k = 0; k < nb; ++k) iperm[perm0[k]] = k;
@@ -1221,7 +1225,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     std::vector<int> btab;
     band_ent_h_.clear();
     band_ent_asm_.clear();
-    constexpr int kMaxFr = 24, kMaxBlk = 72, kMaxEnt = 224;
+    constexpr int kMaxFr = 48, kMaxBlk = 160, kMaxEnt = 4096;
     struct BandInfo {
       BandChainRec rec;
       std::vector<int> tab, ent_asm;
@@ -3981,6 +3985,26 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
 #undef G2OHIP_FACTOR_LEVEL
 }
 
+bool SparseCholesky::band_usable(const FactorGroup& G, const double* dA) const {
+  // (a virtual source whose offsets do not fit the 32-bit records leaves the chains to the general kernel)
+  return G.band_count > 0 && opt.band_kernel && bs_ == 6 && (dA != nullptr || plan_.band_entv != nullptr);
+}
+
+void SparseCholesky::launch_band(const FactorGroup& G, const double* dA, bool fused, hipStream_t st, bool dep) {
+  const bool virt = dA == nullptr;
+  if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
+  const BandPlanArgs B{plan_.band_rec, plan_.band_tab, virt ? plan_.band_entv : plan_.band_ent, 0, G.band_tab_cap,
+                       getenv("G2OHIP_BAND_ABL") ? atoi(getenv("G2OHIP_BAND_ABL")) : 0};
+  const size_t sh = (size_t)(5 * 256) * sizeof(double) + (size_t)(4 * kBandListCap) * sizeof(int4) + (size_t)(64 + 96 + G.band_tab_cap + 4) * sizeof(int);
+  const double* bp = fused ? d_xp.p : (const double*)nullptr;
+  double* yo = fused ? d_y.p : (double*)nullptr;
+  const WvPlan wp = wv_plan(plan_);
+  const int dep_i = dep ? 1 : 0;
+  if (virt) hipLaunchKernelGGL((band_wave_kernel<6, true>), dim3(G.band_count), dim3(64), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
+  else hipLaunchKernelGGL((band_wave_kernel<6, false>), dim3(G.band_count), dim3(64), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
+  G2OHIP_LAUNCH_CHECK("band_wave_kernel");
+}
+
 void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, bool fwd) {
   if (!analyzed_) throw StateFailure("SparseCholesky::factor before analyze");
   static bool attr_done = false;
@@ -4055,7 +4079,16 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
   bool fwd_pending = false;   // a forward step of large fronts is in flight on side_[1] (event ev_[3])
   for (const FactorGroup& G : groups_[phase]) {
     if (G.dep && dep_off_) {   // (groups only hold levels the fused kernel carries completely)
-      for (int l = G.first_level; l <= G.last_level; ++l) launch_factor(launches_[phase][l], dA, fwd, st, false);
+      for (int l = G.first_level; l <= G.last_level; ++l) {
+        LevelLaunch one = launches_[phase][l];
+        if (l == G.first_level && band_usable(G, dA)) {   // (the same kernels as the grouped launch: results stay bit-identical)
+          launch_band(G, dA, fwd, st, false);
+          one.lds_begin += G.band_count;
+          one.lds_count -= G.band_count;
+          if (one.lds_count <= 0) continue;
+        }
+        launch_factor(one, dA, fwd, st, false);
+      }
       continue;
     }
     const LevelLaunch& LL = G.LL;
@@ -4095,21 +4128,9 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
       G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[3], 0));
       fwd_pending = false;
     }
-    const bool band_src = dA != nullptr || plan_.band_entv != nullptr;   // (a virtual source whose offsets fit the records)
-    if (G.band_count > 0 && opt.band_kernel && bs_ == 6 && band_src) {
+    if (band_usable(G, dA)) {
       // the band chains of level 0 first, in a launch of their own (they bump their parents' counters like the others)
-      const bool virt = dA == nullptr;
-      if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
-      const BandPlanArgs B{plan_.band_rec, plan_.band_tab, virt ? plan_.band_entv : plan_.band_ent, 0, G.band_tab_cap,
-                           getenv("G2OHIP_BAND_ABL") ? atoi(getenv("G2OHIP_BAND_ABL")) : 0};
-      const size_t sh = (size_t)(5 * 256) * sizeof(double) + (size_t)(4 * kBandListCap) * sizeof(int4) + (size_t)(64 + 96 + G.band_tab_cap + 4) * sizeof(int);
-      const double* bp = fused ? d_xp.p : (const double*)nullptr;
-      double* yo = fused ? d_y.p : (double*)nullptr;
-      const WvPlan wp = wv_plan(plan_);
-      const int dep_i = G.dep ? 1 : 0;
-      if (virt) hipLaunchKernelGGL((band_wave_kernel<6, true>), dim3(G.band_count), dim3(64), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
-      else hipLaunchKernelGGL((band_wave_kernel<6, false>), dim3(G.band_count), dim3(64), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
-      G2OHIP_LAUNCH_CHECK("band_wave_kernel");
+      launch_band(G, dA, fused, st, G.dep);
       LevelLaunch rest = LL;
       rest.lds_begin += G.band_count;
       rest.lds_count -= G.band_count;

@@ -1,0 +1,629 @@
+// TEST INFRASTRUCTURE ONLY -- a small, self-written host with g2o's PUBLIC INTERFACE (class names, member names and
+// signatures as in the reference headers cited per declaration; paths relative to /root/reference), so that the adapter
+// openslam_g2o_amd/cpp/g2o_hip_solver.h + solver_hip.cpp can be COMPILED, LINKED into a *_solver_*.so, dlopen()ed, found
+// through the optimisation-algorithm factory and driven through the g2o::Solver / g2o::LinearSolver vtables on a GPU in a
+// container that has neither g2o's dependencies (Eigen3) nor a g2o build.  The bodies are this repository's own minimal
+// implementations (std::vector storage, no Eigen); they are what a test needs, not a replacement for g2o:
+//   * Eigen::Matrix: fixed- and dynamic-size column-major storage with the handful of members the adapter touches;
+//   * HyperGraph / OptimizableGraph / SparseOptimizer: vector-backed graph, index mapping (sparse_optimizer.cpp:166-190),
+//     computeActiveErrors / activeRobustChi2 / update / push / pop;
+//   * BaseVertex / BaseBinaryEdge, JacobianWorkspace, the five robust kernels;
+//   * SparseBlockMatrix, Solver, BlockSolver<Traits> (CPU assembly + Schur complement over a LinearSolver: the narrow
+//     seam's host), LinearSolver;
+//   * OptimizationAlgorithm{GaussNewton, Levenberg, Dogleg (construction only)}, the factory, the registration macros.
+// Nothing here is shipped or linked into libg2ohip.so.
+#ifndef G2O_MINI_H
+#define G2O_MINI_H
+#include <algorithm>
+#include <cassert>
+#include <cfloat>
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+#include <iostream>
+#include <list>
+#include <map>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace Eigen {
+template <typename S, int R, int C>
+class Matrix {                                          // fixed size, column-major (Eigen's default, config.h.in:16-20)
+ public:
+  enum { RowsAtCompileTime = R, ColsAtCompileTime = C };
+  Matrix() { setZero(); }
+  S* data() { return d_; }
+  const S* data() const { return d_; }
+  int rows() const { return R; }
+  int cols() const { return C; }
+  S& operator()(int i, int j) { return d_[i + R * j]; }
+  const S& operator()(int i, int j) const { return d_[i + R * j]; }
+  S& operator[](int i) { return d_[i]; }
+  const S& operator[](int i) const { return d_[i]; }
+  void setZero() { for (int i = 0; i < R * C; ++i) d_[i] = S(0); }
+  void setIdentity() { setZero(); for (int i = 0; i < (R < C ? R : C); ++i) d_[i + R * i] = S(1); }
+ private:
+  S d_[R * C];
+};
+template <typename S>
+class Matrix<S, -1, -1> {                               // dynamic size
+ public:
+  enum { RowsAtCompileTime = -1, ColsAtCompileTime = -1 };
+  Matrix() : r_(0), c_(0) {}
+  Matrix(int r, int c) : d_((size_t)r * c, S(0)), r_(r), c_(c) {}
+  void resize(int r, int c) { d_.assign((size_t)r * c, S(0)); r_ = r; c_ = c; }
+  S* data() { return d_.data(); }
+  const S* data() const { return d_.data(); }
+  int rows() const { return r_; }
+  int cols() const { return c_; }
+  S& operator()(int i, int j) { return d_[i + (size_t)r_ * j]; }
+  const S& operator()(int i, int j) const { return d_[i + (size_t)r_ * j]; }
+  void setZero() { std::fill(d_.begin(), d_.end(), S(0)); }
+ private:
+  std::vector<S> d_;
+  int r_, c_;
+};
+typedef Matrix<double, -1, -1> MatrixXd;
+typedef Matrix<double, 2, 1> Vector2d;
+typedef Matrix<double, 3, 1> Vector3d;
+typedef Matrix<double, 2, 2> Matrix2d;
+typedef Matrix<double, 3, 3> Matrix3d;
+class Quaterniond {                                     // the two members the adapter's fast path uses
+ public:
+  Quaterniond() : w_(1), x_(0), y_(0), z_(0) {}
+  Quaterniond(double w, double x, double y, double z) : w_(w), x_(x), y_(y), z_(z) {}
+  explicit Quaterniond(const Matrix3d& R);
+  Matrix3d toRotationMatrix() const;
+  double w() const { return w_; }
+  double x() const { return x_; }
+  double y() const { return y_; }
+  double z() const { return z_; }
+ private:
+  double w_, x_, y_, z_;
+};
+}  // namespace Eigen
+
+namespace g2o {
+using Eigen::MatrixXd;
+using Eigen::Vector2d;
+using Eigen::Vector3d;
+typedef Eigen::Matrix<double, 6, 1> Vector6d;
+
+double get_monotonic_time();                            // g2o/stuff/timeutil.h:88
+
+struct G2OBatchStatistics {                             // g2o/core/batch_stats.h:40-77
+  G2OBatchStatistics() { std::memset(this, 0, sizeof(*this)); }
+  int iteration, numVertices, numEdges;
+  double chi2, timeResiduals, timeLinearize, timeQuadraticForm;
+  int levenbergIterations;
+  double timeSchurComplement, timeSymbolicDecomposition, timeNumericDecomposition, timeLinearSolution, timeLinearSolver;
+  int iterationsLinearSolver;
+  double timeUpdate, timeIteration, timeMarginals;
+  size_t hessianDimension, hessianPoseDimension, hessianLandmarkDimension, choleskyNNZ;
+  static G2OBatchStatistics* globalStats();
+  static void setGlobalStats(G2OBatchStatistics* b);
+};
+
+class JacobianWorkspace {                               // g2o/core/jacobian_workspace.h:51-95
+ public:
+  double* workspaceForVertex(int vertexIndex) { return _ws[vertexIndex].data(); }
+  void allocate(int maxVertices, int maxDoubles) { _ws.assign(maxVertices, std::vector<double>(maxDoubles, 0.0)); }
+ private:
+  std::vector<std::vector<double> > _ws;
+};
+
+class RobustKernel {                                    // g2o/core/robust_kernel.h:53-78
+ public:
+  RobustKernel() : _delta(1.0) {}
+  virtual ~RobustKernel() {}
+  virtual void robustify(double squaredError, double rho[3]) const = 0;   // rho, rho', rho''
+  virtual void setDelta(double delta) { _delta = delta; }
+  double delta() const { return _delta; }
+ protected:
+  double _delta;
+};
+class RobustKernelHuber : public RobustKernel {         // g2o/core/robust_kernel_impl.h:77, .cpp:65-78
+ public:
+  virtual void robustify(double e2, double rho[3]) const {
+    const double dsqr = _delta * _delta;
+    if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; }
+    else { const double sqrte = std::sqrt(e2); rho[0] = 2 * sqrte * _delta - dsqr; rho[1] = _delta / sqrte; rho[2] = -0.5 * rho[1] / e2; }
+  }
+};
+class RobustKernelPseudoHuber : public RobustKernel {   // :94, .cpp:80-89
+ public:
+  virtual void robustify(double e2, double rho[3]) const {
+    const double dsqr = _delta * _delta, dsqrReci = 1. / dsqr, aux1 = dsqrReci * e2 + 1.0, aux2 = std::sqrt(aux1);
+    rho[0] = 2 * dsqr * (aux2 - 1); rho[1] = 1. / aux2; rho[2] = -0.5 * dsqrReci * rho[1] / aux1;
+  }
+};
+class RobustKernelCauchy : public RobustKernel {        // :108, .cpp:91-99
+ public:
+  virtual void robustify(double e2, double rho[3]) const {
+    const double dsqr = _delta * _delta, dsqrReci = 1. / dsqr, aux = dsqrReci * e2 + 1.0;
+    rho[0] = dsqr * std::log(aux); rho[1] = 1. / aux; rho[2] = -dsqrReci * rho[1] * rho[1];
+  }
+};
+class RobustKernelSaturated : public RobustKernel {     // :119, .cpp:101-113
+ public:
+  virtual void robustify(double e2, double rho[3]) const {
+    const double dsqr = _delta * _delta;
+    if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; } else { rho[0] = dsqr; rho[1] = 0.; rho[2] = 0.; }
+  }
+};
+class RobustKernelDCS : public RobustKernel {           // :132, .cpp:116-126
+ public:
+  virtual void robustify(double e2, double rho[3]) const {
+    const double phi = _delta, scale = (2.0 * phi) / (phi + e2);
+    if (scale >= 1.0) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; }
+    else { rho[0] = scale * e2 * scale; rho[1] = scale * scale; rho[2] = 0.; }
+  }
+};
+
+class HyperGraph {                                      // g2o/core/hyper_graph.h
+ public:
+  class Vertex {
+   public:
+    explicit Vertex(int id = -1) : _id(id) {}
+    virtual ~Vertex() {}
+    int id() const { return _id; }
+    void setId(int id) { _id = id; }
+   protected:
+    int _id;
+  };
+  class Edge {
+   public:
+    virtual ~Edge() {}
+    const std::vector<Vertex*>& vertices() const { return _vertices; }   // :140
+    std::vector<Vertex*>& vertices() { return _vertices; }
+    Vertex* vertex(size_t i) { return _vertices[i]; }                    // :147-148
+    const Vertex* vertex(size_t i) const { return _vertices[i]; }
+    void setVertex(size_t i, Vertex* v) { _vertices[i] = v; }
+    void resize(size_t n) { _vertices.resize(n, 0); }
+   protected:
+    std::vector<Vertex*> _vertices;
+  };
+  typedef std::set<Edge*> EdgeSet;                      // :90
+  virtual ~HyperGraph() {}
+};
+
+class OptimizableGraph : public HyperGraph {            // g2o/core/optimizable_graph.h
+ public:
+  class Vertex : public HyperGraph::Vertex {
+   public:
+    Vertex() : _hessianIndex(-1), _fixed(false), _marginalized(false), _dimension(0), _colInHessian(-1) {}
+    virtual void mapHessianMemory(double* d) = 0;       // :161
+    virtual double& hessian(int i, int j) = 0;          // :141 (read by computeLambdaInit)
+    virtual double& b(int i) = 0;
+    virtual void clearQuadraticForm() = 0;
+    virtual void oplusImpl(const double* v) = 0;        // :363
+    virtual void push() = 0;                            // :230
+    virtual void pop() = 0;
+    virtual void discardTop() = 0;
+    void oplus(const double* v) { oplusImpl(v); }       // :277
+    int hessianIndex() const { return _hessianIndex; }  // :299
+    void setHessianIndex(int ti) { _hessianIndex = ti; }
+    bool fixed() const { return _fixed; }               // :306
+    void setFixed(bool f) { _fixed = f; }
+    bool marginalized() const { return _marginalized; } // :311
+    void setMarginalized(bool m) { _marginalized = m; }
+    int dimension() const { return _dimension; }        // :316
+    void setColInHessian(int c) { _colInHessian = c; }  // :322
+    int colInHessian() const { return _colInHessian; }
+   protected:
+    int _hessianIndex;
+    bool _fixed, _marginalized;
+    int _dimension, _colInHessian;
+  };
+  class Edge : public HyperGraph::Edge {
+   public:
+    Edge() : _dimension(-1), _robustKernel(0) {}
+    virtual ~Edge() { delete _robustKernel; }
+    virtual void computeError() = 0;                    // :419
+    virtual double chi2() const = 0;                    // :435
+    RobustKernel* robustKernel() const { return _robustKernel; }   // :416
+    void setRobustKernel(RobustKernel* k) { delete _robustKernel; _robustKernel = k; }
+    virtual const double* errorData() const = 0;        // :423
+    virtual const double* informationData() const = 0;  // :427
+    virtual void linearizeOplus(JacobianWorkspace& jacobianWorkspace) = 0;   // :455
+    int dimension() const { return _dimension; }        // :473
+   protected:
+    int _dimension;
+    RobustKernel* _robustKernel;
+  };
+  typedef std::vector<OptimizableGraph::Vertex*> VertexContainer;   // :121
+  typedef std::vector<OptimizableGraph::Edge*> EdgeContainer;       // :123
+  virtual ~OptimizableGraph();
+  bool addVertex(Vertex* v) { _vertices[v->id()] = v; return true; }   // :520 (takes ownership)
+  bool addEdge(Edge* e) { _edges.push_back(e); return true; }          // :527
+  Vertex* vertex(int id) { std::map<int, Vertex*>::iterator it = _vertices.find(id); return it == _vertices.end() ? 0 : it->second; }
+  const std::map<int, Vertex*>& vertices() const { return _vertices; }
+  const EdgeContainer& edges() const { return _edges; }
+  JacobianWorkspace& jacobianWorkspace() { return _jacobianWorkspace; }   // :660
+ protected:
+  std::map<int, Vertex*> _vertices;                     // (id order: what buildIndexMapping's sort produces, sparse_optimizer.cpp:481-486)
+  EdgeContainer _edges;
+  JacobianWorkspace _jacobianWorkspace;
+};
+
+// ---- fixed-size vertex / edge bases (g2o/core/base_vertex.h:62-110, base_binary_edge.h) -------------------------------
+template <int D, typename T>
+class BaseVertex : public OptimizableGraph::Vertex {
+ public:
+  static const int Dimension = D;
+  typedef T EstimateType;
+  BaseVertex() : _hessian(0) { _dimension = D; for (int i = 0; i < D; ++i) _b[i] = 0.0; }
+  virtual void mapHessianMemory(double* d) { _hessian = d; }            // base_vertex.hpp:51-55
+  virtual double& hessian(int i, int j) { return _hessian[i + D * j]; }
+  virtual double& b(int i) { return _b[i]; }
+  virtual void clearQuadraticForm() { for (int i = 0; i < D; ++i) _b[i] = 0.0; }
+  const EstimateType& estimate() const { return _estimate; }
+  void setEstimate(const EstimateType& et) { _estimate = et; }
+  virtual void push() { _backup.push_back(_estimate); }                 // base_vertex.h:96-99
+  virtual void pop() { _estimate = _backup.back(); _backup.pop_back(); }
+  virtual void discardTop() { _backup.pop_back(); }
+ protected:
+  double* _hessian;
+  double _b[D];
+  EstimateType _estimate;
+  std::vector<EstimateType> _backup;
+};
+
+template <int D, typename E, typename VertexXi, typename VertexXj>
+class BaseBinaryEdge : public OptimizableGraph::Edge {
+ public:
+  static const int Dimension = D;
+  typedef E Measurement;
+  typedef Eigen::Matrix<double, D, 1> ErrorVector;
+  typedef Eigen::Matrix<double, D, D> InformationType;
+  BaseBinaryEdge() { _dimension = D; resize(2); _information.setIdentity(); }
+  virtual void linearizeOplus() = 0;                    // (the analytic Jacobians of the derived type -> _jacobianOplusXi / Xj)
+  virtual void linearizeOplus(JacobianWorkspace& ws) {  // base_binary_edge.hpp:122-128: Jacobians land in the workspace
+    linearizeOplus();
+    std::memcpy(ws.workspaceForVertex(0), _jacobianOplusXi.data(), sizeof(double) * D * VertexXi::Dimension);
+    std::memcpy(ws.workspaceForVertex(1), _jacobianOplusXj.data(), sizeof(double) * D * VertexXj::Dimension);
+  }
+  virtual double chi2() const {                         // base_edge.h:58-61
+    double s = 0.0;
+    for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) s += _error[i] * _information(i, j) * _error[j];
+    return s;
+  }
+  virtual const double* errorData() const { return _error.data(); }
+  virtual const double* informationData() const { return _information.data(); }
+  const Measurement& measurement() const { return _measurement; }
+  void setMeasurement(const Measurement& m) { _measurement = m; }
+  const InformationType& information() const { return _information; }
+  void setInformation(const InformationType& i) { _information = i; }
+  const ErrorVector& error() const { return _error; }
+ protected:
+  Measurement _measurement;
+  InformationType _information;
+  ErrorVector _error;
+  Eigen::Matrix<double, D, VertexXi::Dimension> _jacobianOplusXi;
+  Eigen::Matrix<double, D, VertexXj::Dimension> _jacobianOplusXj;
+};
+
+class OptimizationAlgorithm;
+
+class SparseOptimizer : public OptimizableGraph {       // g2o/core/sparse_optimizer.h
+ public:
+  SparseOptimizer() : _algorithm(0), _verbose(false) {}
+  virtual ~SparseOptimizer();
+  const VertexContainer& indexMapping() const { return _ivMap; }     // :192
+  const EdgeContainer& activeEdges() const { return _activeEdges; }  // :196
+  bool initializeOptimization(int level = 0);           // sparse_optimizer.cpp:199-267, buildIndexMapping :166-190
+  int optimize(int iterations, bool online = false);    // :354-419
+  void computeActiveErrors();                           // :61-76
+  double activeRobustChi2() const;                      // :100-114
+  void update(const double* update);                    // :421-434
+  void push();                                          // :599
+  void pop();
+  void discardTop();
+  void setAlgorithm(OptimizationAlgorithm* algorithm);  // :569 (takes ownership)
+  OptimizationAlgorithm* algorithm() const { return _algorithm; }
+  void setVerbose(bool v) { _verbose = v; }
+  bool verbose() const { return _verbose; }
+ protected:
+  VertexContainer _ivMap;
+  EdgeContainer _activeEdges;
+  OptimizationAlgorithm* _algorithm;
+  bool _verbose;
+};
+
+template <class MatrixType>
+class SparseBlockMatrix {                               // g2o/core/sparse_block_matrix.h:61-220
+ public:
+  typedef MatrixType SparseMatrixBlock;
+  typedef std::map<int, SparseMatrixBlock*> IntBlockMap; // :73
+  SparseBlockMatrix() : _hasStorage(true) {}             // :88
+  SparseBlockMatrix(const int* rbi, const int* cbi, int rb, int cb, bool hasStorage = true)   // :81
+      : _rowBlockIndices(rbi, rbi + rb), _colBlockIndices(cbi, cbi + cb), _blockCols(cb), _hasStorage(hasStorage) {}
+  SparseBlockMatrix(const SparseBlockMatrix& o) : _hasStorage(true) { *this = o; }
+  SparseBlockMatrix& operator=(const SparseBlockMatrix& o) {
+    if (this == &o) return *this;
+    clearBlocks();
+    _rowBlockIndices = o._rowBlockIndices;
+    _colBlockIndices = o._colBlockIndices;
+    _blockCols.assign(o._blockCols.size(), IntBlockMap());
+    for (size_t c = 0; c < o._blockCols.size(); ++c)
+      for (typename IntBlockMap::const_iterator it = o._blockCols[c].begin(); it != o._blockCols[c].end(); ++it)
+        _blockCols[c][it->first] = new SparseMatrixBlock(*it->second);
+    return *this;
+  }
+  ~SparseBlockMatrix() { clearBlocks(); }
+  int cols() const { return _colBlockIndices.empty() ? 0 : _colBlockIndices.back(); }   // :69
+  int rows() const { return _rowBlockIndices.empty() ? 0 : _rowBlockIndices.back(); }   // :71
+  int rowsOfBlock(int r) const { return r ? _rowBlockIndices[r] - _rowBlockIndices[r - 1] : _rowBlockIndices[0]; }
+  int colsOfBlock(int c) const { return c ? _colBlockIndices[c] - _colBlockIndices[c - 1] : _colBlockIndices[0]; }
+  int rowBaseOfBlock(int r) const { return r ? _rowBlockIndices[r - 1] : 0; }
+  int colBaseOfBlock(int c) const { return c ? _colBlockIndices[c - 1] : 0; }
+  SparseMatrixBlock* block(int r, int c, bool alloc = false) {   // :97
+    typename IntBlockMap::iterator it = _blockCols[c].find(r);
+    if (it != _blockCols[c].end()) return it->second;
+    if (!alloc) return 0;
+    SparseMatrixBlock* b = newBlock(rowsOfBlock(r), colsOfBlock(c), (SparseMatrixBlock*)0);
+    _blockCols[c][r] = b;
+    return b;
+  }
+  void clear() {                                        // :92 (zero the values, keep the pattern)
+    for (size_t c = 0; c < _blockCols.size(); ++c)
+      for (typename IntBlockMap::iterator it = _blockCols[c].begin(); it != _blockCols[c].end(); ++it) it->second->setZero();
+  }
+  const std::vector<IntBlockMap>& blockCols() const { return _blockCols; }   // :178
+  std::vector<IntBlockMap>& blockCols() { return _blockCols; }
+  const std::vector<int>& rowBlockIndices() const { return _rowBlockIndices; }   // :182
+  const std::vector<int>& colBlockIndices() const { return _colBlockIndices; }
+ private:
+  template <typename S, int R, int C>
+  static Eigen::Matrix<S, R, C>* newBlock(int, int, Eigen::Matrix<S, R, C>*) { return new Eigen::Matrix<S, R, C>(); }
+  static Eigen::MatrixXd* newBlock(int r, int c, Eigen::MatrixXd*) { return new Eigen::MatrixXd(r, c); }
+  void clearBlocks() {
+    for (size_t c = 0; c < _blockCols.size(); ++c)
+      for (typename IntBlockMap::iterator it = _blockCols[c].begin(); it != _blockCols[c].end(); ++it) delete it->second;
+    _blockCols.clear();
+  }
+  std::vector<int> _rowBlockIndices, _colBlockIndices;   // cumulative ends (:212-213)
+  std::vector<IntBlockMap> _blockCols;
+  bool _hasStorage;
+};
+
+class Solver {                                          // g2o/core/solver.h:44-149
+ public:
+  Solver() : _optimizer(0), _x(0), _b(0), _xSize(0), _maxXSize(0), _isLevenberg(false), _additionalVectorSpace(0) {}
+  virtual ~Solver() { delete[] _x; delete[] _b; }       // solver.cpp:40-44
+  virtual bool init(SparseOptimizer* optimizer, bool online = false) = 0;
+  virtual bool buildStructure(bool zeroBlocks = false) = 0;
+  virtual bool updateStructure(const std::vector<HyperGraph::Vertex*>& vset, const HyperGraph::EdgeSet& edges) = 0;
+  virtual bool buildSystem() = 0;
+  virtual bool solve() = 0;
+  virtual bool computeMarginals(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices) = 0;
+  virtual bool setLambda(double lambda, bool backup = false) = 0;
+  virtual void restoreDiagonal() = 0;
+  double* x() { return _x; }
+  double* b() { return _b; }
+  size_t vectorSize() const { return _xSize; }
+  SparseOptimizer* optimizer() const { return _optimizer; }
+  void setLevenberg(bool l) { _isLevenberg = l; }
+  virtual bool supportsSchur() { return false; }
+  virtual bool schur() = 0;
+  virtual void setSchur(bool s) = 0;
+  virtual void setWriteDebug(bool) = 0;
+  virtual bool writeDebug() const = 0;
+  virtual bool saveHessian(const std::string&) const = 0;
+ protected:
+  SparseOptimizer* _optimizer;
+  double* _x;
+  double* _b;
+  size_t _xSize, _maxXSize;
+  bool _isLevenberg;
+  size_t _additionalVectorSpace;
+  void resizeVector(size_t sx) {                        // solver.cpp:46-70
+    const size_t oldSize = _xSize;
+    _xSize = sx;
+    sx += _additionalVectorSpace;
+    if (_maxXSize < sx) {
+      _maxXSize = 2 * sx;
+      delete[] _x;
+      _x = new double[_maxXSize];
+      std::memset(_x, 0, sizeof(double) * _maxXSize);
+      if (_b) {
+        double* nb = new double[_maxXSize];
+        std::memcpy(nb, _b, oldSize * sizeof(double));
+        delete[] _b;
+        _b = nb;
+      } else {
+        _b = new double[_maxXSize];
+        std::memset(_b, 0, sizeof(double) * _maxXSize);
+      }
+    }
+  }
+ private:
+  Solver(const Solver&);
+  Solver& operator=(const Solver&);
+};
+
+class BlockSolverBase : public Solver {                 // g2o/core/block_solver.h:83-91
+ public:
+  virtual ~BlockSolverBase() {}
+  virtual void multiplyHessian(double* dest, const double* src) const = 0;
+};
+
+template <typename MatrixType>
+class LinearSolver {                                    // g2o/core/linear_solver.h:40-81
+ public:
+  LinearSolver() {}
+  virtual ~LinearSolver() {}
+  virtual bool init() = 0;
+  virtual bool solve(const SparseBlockMatrix<MatrixType>& A, double* x, double* b) = 0;
+  virtual bool solveBlocks(double**& blocks, const SparseBlockMatrix<MatrixType>& A) { (void)blocks; (void)A; return false; }   // :64
+  virtual bool solvePattern(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices,
+                            const SparseBlockMatrix<MatrixType>& A) { (void)spinv; (void)blockIndices; (void)A; return false; }   // :71
+};
+
+template <int _PoseDim, int _LandmarkDim>
+struct BlockSolverTraits {                              // g2o/core/block_solver.h:43-57
+  static const int PoseDim = _PoseDim;
+  static const int LandmarkDim = _LandmarkDim;
+  typedef Eigen::Matrix<double, PoseDim, PoseDim> PoseMatrixType;
+  typedef Eigen::Matrix<double, LandmarkDim, LandmarkDim> LandmarkMatrixType;
+  typedef Eigen::Matrix<double, PoseDim, LandmarkDim> PoseLandmarkMatrixType;
+  typedef LinearSolver<PoseMatrixType> LinearSolverType;
+};
+
+// The narrow seam's host: what g2o::BlockSolver does around its LinearSolver (block_solver.hpp:142-295, 353-604), written
+// for this test host over plain vectors -- CPU assembly of Hpp / Hpl / Hll / b from the edges' Jacobians, damping, Schur
+// complement, the LinearSolver call on the reduced pose system, landmark back-substitution.
+template <typename Traits>
+class BlockSolver : public BlockSolverBase {            // g2o/core/block_solver.h:98-178
+ public:
+  static const int PoseDim = Traits::PoseDim;
+  static const int LandmarkDim = Traits::LandmarkDim;
+  typedef typename Traits::PoseMatrixType PoseMatrixType;
+  typedef typename Traits::LandmarkMatrixType LandmarkMatrixType;
+  typedef typename Traits::PoseLandmarkMatrixType PoseLandmarkMatrixType;
+  typedef typename Traits::LinearSolverType LinearSolverType;
+  explicit BlockSolver(LinearSolverType* linearSolver) : _linearSolver(linearSolver), _Hschur(0), _doSchur(true), _nP(0), _nL(0) {}   // :116 (takes ownership)
+  virtual ~BlockSolver() { delete _linearSolver; delete _Hschur; }   // block_solver.hpp:135-140
+  virtual bool init(SparseOptimizer* optimizer, bool online = false) {
+    (void)online;
+    _optimizer = optimizer;
+    return _linearSolver->init();
+  }
+  virtual bool buildStructure(bool zeroBlocks = false);
+  virtual bool updateStructure(const std::vector<HyperGraph::Vertex*>&, const HyperGraph::EdgeSet&) { return false; }
+  virtual bool buildSystem();
+  virtual bool solve();
+  virtual bool computeMarginals(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices);
+  virtual bool setLambda(double lambda, bool backup = false);
+  virtual void restoreDiagonal();
+  virtual bool supportsSchur() { return true; }
+  virtual bool schur() { return _doSchur; }
+  virtual void setSchur(bool s) { _doSchur = s; }
+  virtual void setWriteDebug(bool) {}
+  virtual bool writeDebug() const { return false; }
+  virtual bool saveHessian(const std::string&) const { return false; }
+  virtual void multiplyHessian(double* dest, const double* src) const;
+  LinearSolverType* linearSolver() const { return _linearSolver; }
+ private:
+  struct Obs { int pose, lm; PoseLandmarkMatrixType B; };   // Hpl block of one (pose, landmark) pair
+  LinearSolverType* _linearSolver;
+  SparseBlockMatrix<PoseMatrixType>* _Hschur;           // pattern Hpp + co-observation pairs; holds Hpp when there is no Schur step
+  std::vector<PoseMatrixType> _Hpp_diag;
+  std::map<std::pair<int, int>, PoseMatrixType> _Hpp_off;   // (r < c)
+  std::vector<LandmarkMatrixType> _Hll;
+  std::vector<Obs> _obs;
+  std::map<std::pair<int, int>, int> _obsIndex;
+  std::vector<std::vector<int> > _lmObs;                // observations per landmark, ascending pose
+  std::vector<double> _diagBackup, _mirror;
+  bool _doSchur;
+  int _nP, _nL;
+};
+
+class OptimizationAlgorithm {                           // g2o/core/optimization_algorithm.h:46-110
+ public:
+  enum SolverResult { Terminate = 2, OK = 1, Fail = -1 };
+  OptimizationAlgorithm() : _optimizer(0) {}
+  virtual ~OptimizationAlgorithm() {}
+  virtual bool init(bool online = false) = 0;
+  virtual SolverResult solve(int iteration, bool online = false) = 0;
+  virtual bool computeMarginals(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices) = 0;
+  void setOptimizer(SparseOptimizer* optimizer) { _optimizer = optimizer; }
+  SparseOptimizer* optimizer() const { return _optimizer; }
+ protected:
+  SparseOptimizer* _optimizer;
+};
+class OptimizationAlgorithmWithHessian : public OptimizationAlgorithm {   // optimization_algorithm_with_hessian.h, .cpp:50-73
+ public:
+  explicit OptimizationAlgorithmWithHessian(Solver* solver) : _solver(solver) {}
+  virtual ~OptimizationAlgorithmWithHessian() { delete _solver; }          // .cpp:45-48
+  virtual bool init(bool online = false);
+  virtual bool computeMarginals(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices) {
+    return _solver ? _solver->computeMarginals(spinv, blockIndices) : false;
+  }
+  Solver* solver() { return _solver; }
+ protected:
+  Solver* _solver;
+};
+class OptimizationAlgorithmGaussNewton : public OptimizationAlgorithmWithHessian {   // optimization_algorithm_gauss_newton.h:46
+ public:
+  explicit OptimizationAlgorithmGaussNewton(Solver* solver) : OptimizationAlgorithmWithHessian(solver) {}
+  virtual SolverResult solve(int iteration, bool online = false);
+};
+class OptimizationAlgorithmLevenberg : public OptimizationAlgorithmWithHessian {     // optimization_algorithm_levenberg.h:45
+ public:
+  explicit OptimizationAlgorithmLevenberg(Solver* solver)
+      : OptimizationAlgorithmWithHessian(solver), _currentLambda(-1.), _tau(1e-5), _goodStepLowerScale(1. / 3.), _goodStepUpperScale(2. / 3.), _ni(2.),
+        _userLambdaInit(0.), _maxTrialsAfterFailure(10), _levenbergIterations(0) {}
+  virtual SolverResult solve(int iteration, bool online = false);
+  double currentLambda() const { return _currentLambda; }
+  int levenbergIteration() { return _levenbergIterations; }
+  void setUserLambdaInit(double l) { _userLambdaInit = l; }
+ protected:
+  double computeLambdaInit() const;                     // .cpp:149-163
+  double computeScale() const;                          // .cpp:165-172
+  double _currentLambda, _tau, _goodStepLowerScale, _goodStepUpperScale, _ni, _userLambdaInit;
+  int _maxTrialsAfterFailure, _levenbergIterations;
+};
+class OptimizationAlgorithmDogleg : public OptimizationAlgorithmWithHessian {        // optimization_algorithm_dogleg.h:57
+ public:
+  explicit OptimizationAlgorithmDogleg(BlockSolverBase* solver) : OptimizationAlgorithmWithHessian(solver) {}
+  virtual SolverResult solve(int, bool = false) { return Fail; }   // (construction through the factory is what the host exercises)
+};
+
+struct OptimizationAlgorithmProperty {                  // g2o/core/optimization_algorithm_property.h:39-55
+  std::string name, desc, type;
+  bool requiresMarginalize;
+  int poseDim, landmarkDim;
+  OptimizationAlgorithmProperty() : name(), desc(), type(), requiresMarginalize(false), poseDim(-1), landmarkDim(-1) {}
+  OptimizationAlgorithmProperty(const std::string& name_, const std::string& desc_, const std::string& type_, bool requiresMarginalize_, int poseDim_,
+                                int landmarkDim_)
+      : name(name_), desc(desc_), type(type_), requiresMarginalize(requiresMarginalize_), poseDim(poseDim_), landmarkDim(landmarkDim_) {}
+};
+
+class AbstractOptimizationAlgorithmCreator {            // g2o/core/optimization_algorithm_factory.h:55-66
+ public:
+  explicit AbstractOptimizationAlgorithmCreator(const OptimizationAlgorithmProperty& p) : _property(p) {}
+  virtual ~AbstractOptimizationAlgorithmCreator() {}
+  virtual OptimizationAlgorithm* construct() = 0;
+  const OptimizationAlgorithmProperty& property() const { return _property; }
+ protected:
+  OptimizationAlgorithmProperty _property;
+};
+
+class OptimizationAlgorithmFactory {                    // optimization_algorithm_factory.h:75-118
+ public:
+  typedef std::list<AbstractOptimizationAlgorithmCreator*> CreatorList;
+  static OptimizationAlgorithmFactory* instance();
+  void registerSolver(AbstractOptimizationAlgorithmCreator* c);
+  void unregisterSolver(AbstractOptimizationAlgorithmCreator* c);
+  OptimizationAlgorithm* construct(const std::string& tag, OptimizationAlgorithmProperty& solverProperty) const;
+  void listSolvers(std::ostream& os) const;
+  const CreatorList& creatorList() const { return _creator; }
+ protected:
+  CreatorList _creator;
+};
+
+class RegisterOptimizationAlgorithmProxy {              // optimization_algorithm_factory.h:120-141
+ public:
+  explicit RegisterOptimizationAlgorithmProxy(AbstractOptimizationAlgorithmCreator* c) : _creator(c) {
+    OptimizationAlgorithmFactory::instance()->registerSolver(c);
+  }
+  ~RegisterOptimizationAlgorithmProxy() { OptimizationAlgorithmFactory::instance()->unregisterSolver(_creator); }
+ private:
+  AbstractOptimizationAlgorithmCreator* _creator;
+};
+
+}  // namespace g2o
+
+// optimization_algorithm_factory.h:153-162 (non-MSVC branch)
+#define G2O_REGISTER_OPTIMIZATION_LIBRARY(libraryname) \
+  extern "C" void g2o_optimization_library_##libraryname(void) {}
+#define G2O_REGISTER_OPTIMIZATION_ALGORITHM(optimizername, instance)    \
+  extern "C" void g2o_optimization_algorithm_##optimizername(void) {}   \
+  static g2o::RegisterOptimizationAlgorithmProxy g_optimization_algorithm_proxy_##optimizername(instance);
+
+#include "g2o_mini_block_solver.hpp"
+
+#endif
