@@ -13,6 +13,7 @@
 #define G2O_HIP_SOLVER_H
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <map>
@@ -28,20 +29,31 @@
 #include "g2o/core/robust_kernel_impl.h"
 #include "g2o/core/sparse_optimizer.h"
 #include "g2o/stuff/timeutil.h"
+#include "g2o/types/sba/types_six_dof_expmap.h"   // EdgeProjectXYZ2UV, VertexSE3Expmap, VertexSBAPointXYZ (device fast path)
 #include "g2ohip.h"
 
 namespace g2o {
 
 // ---------------------------------------------------------------------------------------------------------
-// Wide seam.  The edges keep producing errors and Jacobians on the CPU (computeError / linearizeOplus of the
-// consumer's edge types); assembly, damping, Schur complement, factorisation and back-substitution run on the
-// device.  Edges are grouped into homogeneous SETS (error dimension, vertex dimensions, unary / binary, robust
+// Wide seam.  Edges are grouped into homogeneous SETS (error dimension, vertex dimensions, unary / binary, robust
 // kernel): one g2ohip edge set per group, flat arrays in the group's edge order.
+//   generic path: the edges keep producing errors and Jacobians on the CPU (computeError / linearizeOplus of the
+//     consumer's edge types) and the adapter uploads them every iteration (E * (d*dim0 + d*dim1 + d*d + d) doubles:
+//     1.0 GB at the metric configuration); assembly, damping, Schur complement, factorisation and back-substitution
+//     run on the device;
+//   fast path (default; setFastPath(false) or G2OHIP_ADAPTER_FASTPATH=0 turn it off): a group whose edges are all
+//     g2o::EdgeProjectXYZ2UV over VertexSBAPointXYZ / VertexSE3Expmap with one CameraParameters is bound to the
+//     library's device-resident bundle-adjustment front end (g2ohip_ba_*): the measurements go to the device once, per
+//     iteration only the ESTIMATES are uploaded (12 doubles per camera + 3 per point: 34 MB at the metric
+//     configuration) and the errors / Jacobians of types_six_dof_expmap.cpp:288-326 are evaluated inside the
+//     assembly kernels.  chi2 (computeActiveErrors / activeRobustChi2) stays with the optimizer on the CPU.
 // ---------------------------------------------------------------------------------------------------------
 template <int p, int l>
 class BlockSolverHip : public BlockSolverBase {
  public:
-  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0) {
+  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroup(-1) {
+    const char* fp = std::getenv("G2OHIP_ADAPTER_FASTPATH");
+    if (fp && fp[0] == '0') _fastPath = false;
     if (g2ohip_create(&_h, p, l, device) != G2OHIP_OK) {
       std::cerr << "BlockSolverHip: " << g2ohip_last_error() << std::endl;   // (no exceptions on this path)
       _h = 0;
@@ -128,16 +140,28 @@ class BlockSolverHip : public BlockSolverBase {
       g.set = g2ohip_add_edge_set(_h, g.key.d, n, g.v0.data(), g.key.dim1 ? g.v1.data() : 0);
       if (g.set < 0) return fail("add_edge_set");
       if (g.key.kernel > 0 && g2ohip_set_robust_kernel(_h, g.set, g.key.kernel, g.key.delta) != G2OHIP_OK) return fail("set_robust_kernel");
-      g.J0.assign((size_t)n * g.key.d * g.key.dim0, 0.0);
-      g.J1.assign((size_t)n * g.key.d * g.key.dim1, 0.0);
+      // The library takes a side's dimension from the hessian indices; a side whose vertices are ALL fixed (e.g. a
+      // localisation graph over fixed points) is taken as a pose side there (p columns), whatever the vertex type: the
+      // buffers are sized for the larger of the two so that g2ohip_set_edge_data never reads past their end.
+      const int w0 = g.key.dim0 > p ? g.key.dim0 : p, w1 = g.key.dim1 ? (g.key.dim1 > p ? g.key.dim1 : p) : 0;
+      g.J0.assign((size_t)n * g.key.d * w0, 0.0);
+      g.J1.assign((size_t)n * g.key.d * w1, 0.0);
       g.Om.assign((size_t)n * g.key.d * g.key.d, 0.0);
       g.err.assign((size_t)n * g.key.d, 0.0);
     }
     if (g2ohip_build_structure(_h, _nP, _nL, _doSchur ? 1 : 0) != G2OHIP_OK) return fail("build_structure");
     resizeVector(g2ohip_vector_size(_h));              // Solver::_x, _b (solver.cpp:46-70)
     _diag.assign(g2ohip_vector_size(_h), 0.0);
+    _fastGroup = -1;
+    if (_fastPath)
+      for (size_t gi = 0; gi < _groups.size() && _fastGroup < 0; ++gi)
+        if (bindProjectXYZ2UV(_groups[gi])) _fastGroup = (int)gi;
     return true;
   }
+
+  //! device-resident front end for homogeneous EdgeProjectXYZ2UV groups (on by default)
+  void setFastPath(bool on) { _fastPath = on; }
+  bool fastPathActive() const { return _fastGroup >= 0; }
 
   // online growth: the reference aborts for Schur too (block_solver.hpp:313-316)
   virtual bool updateStructure(const std::vector<HyperGraph::Vertex*>& vset, const HyperGraph::EdgeSet& edges) {
@@ -153,6 +177,10 @@ class BlockSolverHip : public BlockSolverBase {
     JacobianWorkspace& ws = _optimizer->jacobianWorkspace();
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       Group& g = _groups[gi];
+      if ((int)gi == _fastGroup) {                     // estimates up, errors + Jacobians on the device
+        if (!uploadEstimates()) return false;
+        continue;
+      }
       const int d = g.key.d, d0 = g.key.dim0, d1 = g.key.dim1;
       for (size_t k = 0; k < g.edges.size(); ++k) {
         OptimizableGraph::Edge* e = g.edges[k];
@@ -260,7 +288,7 @@ class BlockSolverHip : public BlockSolverBase {
     std::vector<OptimizableGraph::Edge*> edges;
     std::vector<int32_t> v0, v1;
     std::vector<double> J0, J1, Om, err;
-    Group() : set(-1) {}
+    Group() : key(), set(-1) {}
   };
 
   // robust kernel -> the kind numbers of g2ohip_set_robust_kernel (robust_kernel_impl.h:77-140); 0: none, -1: unknown
@@ -293,12 +321,108 @@ class BlockSolverHip : public BlockSolverBase {
     return false;
   }
 
+  // ---- fast path: a group of EdgeProjectXYZ2UV (types_six_dof_expmap.h:133-153; vertex 0 = VertexSBAPointXYZ, vertex 1 =
+  // VertexSE3Expmap) with one CameraParameters is handed to g2ohip_ba_set_edges; false = leave the group on the generic path
+  bool bindProjectXYZ2UV(Group& g) {
+    if (p != 6 || l != 3 || g.key.d != 2 || g.key.dim0 != 3 || g.key.dim1 != 6 || g.edges.empty()) return false;
+    const CameraParameters* cam0 = 0;
+    for (size_t k = 0; k < g.edges.size(); ++k) {
+      if (typeid(*g.edges[k]) != typeid(EdgeProjectXYZ2UV)) return false;
+      const EdgeProjectXYZ2UV* e = static_cast<const EdgeProjectXYZ2UV*>(g.edges[k]);
+      if (typeid(*e->vertex(0)) != typeid(VertexSBAPointXYZ) || typeid(*e->vertex(1)) != typeid(VertexSE3Expmap)) return false;
+      const CameraParameters* c = e->_cam;
+      if (!c) return false;
+      if (!cam0) cam0 = c;
+      if (c->focal_length != cam0->focal_length || c->principle_point[0] != cam0->principle_point[0] ||
+          c->principle_point[1] != cam0->principle_point[1])
+        return false;
+    }
+    // estimate tables over every vertex the group touches (fixed ones included), in order of first appearance
+    _cams.clear();
+    _points.clear();
+    std::map<const HyperGraph::Vertex*, int> camIndex, pointIndex;
+    const size_t n = g.edges.size();
+    std::vector<int32_t> camOf(n), pointOf(n);
+    std::vector<double> meas(2 * n), info(4 * n);
+    bool identity = true;
+    for (size_t k = 0; k < n; ++k) {
+      EdgeProjectXYZ2UV* e = static_cast<EdgeProjectXYZ2UV*>(g.edges[k]);
+      VertexSBAPointXYZ* vp = static_cast<VertexSBAPointXYZ*>(e->vertex(0));
+      VertexSE3Expmap* vc = static_cast<VertexSE3Expmap*>(e->vertex(1));
+      std::map<const HyperGraph::Vertex*, int>::iterator ic = camIndex.find(vc);
+      if (ic == camIndex.end()) {
+        ic = camIndex.insert(std::make_pair((const HyperGraph::Vertex*)vc, (int)_cams.size())).first;
+        _cams.push_back(vc);
+      }
+      std::map<const HyperGraph::Vertex*, int>::iterator ip = pointIndex.find(vp);
+      if (ip == pointIndex.end()) {
+        ip = pointIndex.insert(std::make_pair((const HyperGraph::Vertex*)vp, (int)_points.size())).first;
+        _points.push_back(vp);
+      }
+      camOf[k] = ic->second;
+      pointOf[k] = ip->second;
+      meas[2 * k] = e->measurement()[0];
+      meas[2 * k + 1] = e->measurement()[1];
+      const double* om = e->informationData();            // 2 x 2, column-major
+      for (int q = 0; q < 4; ++q) info[4 * k + q] = om[q];
+      identity = identity && om[0] == 1.0 && om[1] == 0.0 && om[2] == 0.0 && om[3] == 1.0;
+    }
+    _camHidx.resize(_cams.size());
+    _pointHidx.resize(_points.size());
+    for (size_t i = 0; i < _cams.size(); ++i) {
+      _camHidx[i] = _cams[i]->hessianIndex();
+      if (_camHidx[i] >= _nP) return false;               // a marginalized camera: not this front end's layout
+    }
+    for (size_t i = 0; i < _points.size(); ++i) {
+      const int hi = _points[i]->hessianIndex();
+      if (hi >= 0 && hi < _nP) return false;              // a point that is not marginalized: likewise
+      _pointHidx[i] = hi < 0 ? -1 : hi - _nP;
+    }
+    if (g2ohip_ba_set_edges(_h, g.set, camOf.data(), pointOf.data(), meas.data(), identity ? 0 : info.data(), cam0->focal_length,
+                            cam0->principle_point[0], cam0->principle_point[1]) != G2OHIP_OK) {
+      std::cerr << "BlockSolverHip: fast path not available (" << g2ohip_last_error() << "), using the generic path" << std::endl;
+      return false;
+    }
+    _camBuf.assign(12 * _cams.size(), 0.0);
+    _pointBuf.assign(3 * _points.size(), 0.0);
+    if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
+      std::cerr << "BlockSolverHip: device front end (g2ohip_ba_*) for " << n << " EdgeProjectXYZ2UV, " << _cams.size() << " cameras, " << _points.size()
+                << " points" << std::endl;
+    return true;
+  }
+
+  // setEstimate of every camera (R column-major | t, world -> camera as VertexSE3Expmap holds it) and point, then the
+  // device evaluates errors and Jacobians (computeActiveErrors + linearizeOplus of the group)
+  bool uploadEstimates() {
+    for (size_t i = 0; i < _cams.size(); ++i) {
+      const SE3Quat& T = _cams[i]->estimate();
+      const Eigen::Matrix3d R = T.rotation().toRotationMatrix();
+      double* c = &_camBuf[12 * i];
+      for (int col = 0; col < 3; ++col)
+        for (int row = 0; row < 3; ++row) c[row + 3 * col] = R(row, col);
+      for (int row = 0; row < 3; ++row) c[9 + row] = T.translation()[row];
+    }
+    for (size_t i = 0; i < _points.size(); ++i)
+      for (int row = 0; row < 3; ++row) _pointBuf[3 * i + row] = _points[i]->estimate()[row];
+    if (g2ohip_ba_set_estimates(_h, (int)_cams.size(), _camBuf.data(), _camHidx.data(), (int)_points.size(), _pointBuf.data(), _pointHidx.data()) != G2OHIP_OK)
+      return fail("ba_set_estimates");
+    if (g2ohip_ba_linearize(_h, 1) != G2OHIP_OK) return fail("ba_linearize");
+    return true;
+  }
+
   g2ohip_solver* _h;
   bool _doSchur, _writeDebug;
   int _nP, _nL;
   std::vector<Group> _groups;
   std::vector<double> _diagMirror, _diag;
+  bool _fastPath;
+  int _fastGroup;                                      // index into _groups of the group on the device front end, or -1
+  std::vector<VertexSE3Expmap*> _cams;
+  std::vector<VertexSBAPointXYZ*> _points;
+  std::vector<int32_t> _camHidx, _pointHidx;
+  std::vector<double> _camBuf, _pointBuf;
 };
+
 
 // ---------------------------------------------------------------------------------------------------------
 // Narrow seam: g2o's own CPU assembly and Schur complement stay, only the sparse Cholesky solve moves to the device
@@ -322,29 +446,16 @@ class LinearSolverHip : public LinearSolver<MatrixType> {
   virtual bool solve(const SparseBlockMatrix<MatrixType>& A, double* x, double* b) {
     if (!_ls) return false;
     const int nb = (int)A.blockCols().size();
-    _colptr.assign(1, 0);
-    _rowidx.clear();
-    _values.clear();
-    for (int c = 0; c < nb; ++c) {
-      const typename SparseBlockMatrix<MatrixType>::IntBlockMap& column = A.blockCols()[c];
-      for (typename SparseBlockMatrix<MatrixType>::IntBlockMap::const_iterator it = column.begin(); it != column.end(); ++it) {
-        if (it->first > c) break;                      // upper triangle, ascending rows (std::map)
-        const MatrixType* blk = it->second;
-        _rowidx.push_back(it->first);
-        _values.insert(_values.end(), blk->data(), blk->data() + blk->rows() * blk->cols());   // column-major (Eigen default)
-      }
-      _colptr.push_back((int32_t)_rowidx.size());
-    }
-    const double t = get_monotonic_time();
+    exportUpper(A);
     const int rc = g2ohip_ls_solve(_ls, nb, _colptr.data(), _rowidx.data(), _values.data(), x, b);
     G2OBatchStatistics* gs = G2OBatchStatistics::globalStats();
     if (gs) {
       g2ohip_stats st;
-      if (g2ohip_ls_get_stats(_ls, &st) == G2OHIP_OK) {
-        gs->timeSymbolicDecomposition = st.timeSymbolicDecomposition;
+      if (g2ohip_ls_get_stats(_ls, &st) == G2OHIP_OK) {   // the numeric factorisation alone, as LinearSolverCSparse times it
+        gs->timeSymbolicDecomposition = st.timeSymbolicDecomposition;   // (linear_solver_csparse.h:122-139)
+        gs->timeNumericDecomposition = st.timeNumericDecomposition;
         gs->choleskyNNZ = st.choleskyNNZ;
       }
-      gs->timeNumericDecomposition = get_monotonic_time() - t;
     }
     if (rc != G2OHIP_OK && rc != G2OHIP_NOT_PD) std::cerr << "LinearSolverHip::solve: " << g2ohip_last_error() << std::endl;
     return rc == G2OHIP_OK;

@@ -4333,7 +4333,14 @@ int BlockSolver::compute_marginals(int n, const int* rows, const int* cols, doub
   }
   const double* H = schur_ ? d_Hschur.p : d_Hpp.p;
   chol_->factor(H, st_);
-  if (chol_->failed(st_)) return 1;
+  if (chol_->failed(st_)) {
+    // a dependency-driven launch that gave up waiting is not "not positive definite": the factorisation has switched to
+    // one launch per level -- once more (as g2ohip_solve does)
+    if (!(chol_->dependency_stall() && ++dependency_fallbacks)) return 1;
+    invalidate_graphs();
+    chol_->factor(H, st_);
+    if (chol_->failed(st_)) return 1;
+  }
   // Blocks inside the pattern of the factor: one top-down pass over the frontal matrices gives ALL of them (sparse
   // inverse); what lies outside the pattern (fill-free pairs of distant poses) falls back to a pair of triangular
   // sweeps per requested column.

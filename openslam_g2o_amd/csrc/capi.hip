@@ -27,6 +27,10 @@ struct g2ohip_linear_solver {
   std::unique_ptr<SparseCholesky> chol;
   CholOptions opt;
   std::vector<int> colptr, rowidx;  // pattern the symbolic factorisation was built for
+  // a second analysis for solvePattern() on a DIFFERENT pattern between two init() calls: g2o's BlockSolver factorises
+  // Hschur in solve() and hands Hpp (a sub-pattern) to solvePattern() of the same LinearSolver (block_solver.hpp:489-499)
+  std::unique_ptr<SparseCholesky> chol2;
+  std::vector<int> colptr2, rowidx2;
   DevBuf<double> dA, db, dx;
   EventTimer tn, tl;
   double t_numeric = 0, t_solve = 0;
@@ -712,8 +716,35 @@ int g2ohip_ls_init(g2ohip_linear_solver* ls) {
   ls->chol.reset();
   ls->colptr.clear();
   ls->rowidx.clear();
+  ls->chol2.reset();
+  ls->colptr2.clear();
+  ls->rowidx2.clear();
   return G2OHIP_OK;
 }
+namespace {
+bool same_pattern(const std::vector<int>& cp, const std::vector<int>& ri, int n_blocks, const int32_t* colptr, const int32_t* rowidx) {
+  return (int)cp.size() == n_blocks + 1 && std::memcmp(cp.data(), colptr, sizeof(int) * (n_blocks + 1)) == 0 && (int)ri.size() == colptr[n_blocks] &&
+         std::memcmp(ri.data(), rowidx, sizeof(int) * ri.size()) == 0;
+}
+void analyze_into(g2ohip_linear_solver* ls, std::unique_ptr<SparseCholesky>& chol, std::vector<int>& cp, std::vector<int>& ri, int n_blocks,
+                  const int32_t* colptr, const int32_t* rowidx) {
+  chol = std::make_unique<SparseCholesky>(ls->bs);
+  chol->opt = ls->opt;
+  cp.assign(colptr, colptr + n_blocks + 1);
+  ri.assign(rowidx, rowidx + colptr[n_blocks]);
+  chol->analyze(n_blocks, colptr, rowidx, ls->st);
+}
+// factorise; a dependency-driven launch that gave up waiting is not "not positive definite": once more, level by level
+bool factor_checked(SparseCholesky& chol, const double* dA, hipStream_t st) {
+  chol.factor(dA, st);
+  bool bad = chol.failed(st);
+  if (bad && chol.dependency_stall()) {
+    chol.factor(dA, st);
+    bad = chol.failed(st);
+  }
+  return !bad;
+}
+}  // namespace
 int g2ohip_ls_solve(g2ohip_linear_solver* ls, int n_blocks, const int32_t* colptr, const int32_t* rowidx, const double* values,
                     double* x, const double* b) {
   if (!ls || !colptr || !rowidx || !values || !x || !b || n_blocks <= 0) return G2OHIP_ERR_ARG;
@@ -721,15 +752,10 @@ int g2ohip_ls_solve(g2ohip_linear_solver* ls, int n_blocks, const int32_t* colpt
     G2OHIP_HIP_CHECK(hipSetDevice(ls->device));
     const int nnzb = colptr[n_blocks];
     const int bs = ls->bs;
-    if (!ls->chol) {  // first call after init(): symbolic factorisation (linear_solver_csparse.h:110-112)
-      ls->chol = std::make_unique<SparseCholesky>(bs);
-      ls->chol->opt = ls->opt;
-      ls->colptr.assign(colptr, colptr + n_blocks + 1);
-      ls->rowidx.assign(rowidx, rowidx + nnzb);
-      ls->chol->analyze(n_blocks, colptr, rowidx, ls->st);
-    } else if ((int)ls->colptr.size() != n_blocks + 1 || ls->colptr.back() != nnzb) {
-      throw StateFailure("pattern changed without init() (linear_solver.h:86-105)");
-    }
+    // first call after init(): symbolic factorisation (linear_solver_csparse.h:110-112).  The pattern has to stay the same
+    // until the next init() (linear_solver.h:86-105); a different one is analysed anew instead of being factorised with a
+    // stale structure
+    if (!ls->chol || !same_pattern(ls->colptr, ls->rowidx, n_blocks, colptr, rowidx)) analyze_into(ls, ls->chol, ls->colptr, ls->rowidx, n_blocks, colptr, rowidx);
     const size_t n = (size_t)n_blocks * bs;
     ls->dA.upload(values, (size_t)nnzb * bs * bs, ls->st);
     ls->db.upload(b, n, ls->st);
@@ -777,26 +803,26 @@ int g2ohip_ls_solve_pattern(g2ohip_linear_solver* ls, int n_blocks, const int32_
     G2OHIP_HIP_CHECK(hipSetDevice(ls->device));
     const int nnzb = colptr[n_blocks];
     const int bs = ls->bs;
-    if (!ls->chol) {
-      ls->chol = std::make_unique<SparseCholesky>(bs);
-      ls->chol->opt = ls->opt;
-      ls->colptr.assign(colptr, colptr + n_blocks + 1);
-      ls->rowidx.assign(rowidx, rowidx + nnzb);
-      ls->chol->analyze(n_blocks, colptr, rowidx, ls->st);
-    } else if ((int)ls->colptr.size() != n_blocks + 1 || ls->colptr.back() != nnzb) {
-      throw StateFailure("pattern changed without init() (linear_solver.h:86-105)");
+    // the pattern of solve() -> its analysis; another pattern (BlockSolver::computeMarginals hands Hpp to the LinearSolver
+    // that factorised Hschur, without init(): block_solver.hpp:489-499) -> a second analysis kept next to it
+    SparseCholesky* ch = nullptr;
+    if (!ls->chol) analyze_into(ls, ls->chol, ls->colptr, ls->rowidx, n_blocks, colptr, rowidx);
+    if (same_pattern(ls->colptr, ls->rowidx, n_blocks, colptr, rowidx)) {
+      ch = ls->chol.get();
+    } else {
+      if (!ls->chol2 || !same_pattern(ls->colptr2, ls->rowidx2, n_blocks, colptr, rowidx)) analyze_into(ls, ls->chol2, ls->colptr2, ls->rowidx2, n_blocks, colptr, rowidx);
+      ch = ls->chol2.get();
     }
     ls->dA.upload(values, (size_t)nnzb * bs * bs, ls->st);
-    ls->chol->factor(ls->dA.p, ls->st);
-    if (ls->chol->failed(ls->st)) return G2OHIP_NOT_PD;
+    if (!factor_checked(*ch, ls->dA.p, ls->st)) return G2OHIP_NOT_PD;
     if (n_req == 0) return G2OHIP_OK;
-    ls->chol->sparse_inverse(ls->st);
+    ch->sparse_inverse(ls->st);
     std::vector<long long> off(n_req, -1);
     std::vector<int> ldv(n_req, 0), trv(n_req, 0);
     int found = 0;
     for (int i = 0; i < n_req; ++i) {
       bool tr = false;
-      if (ls->chol->inverse_block(rows[i], cols[i], &off[i], &ldv[i], &tr)) {
+      if (ch->inverse_block(rows[i], cols[i], &off[i], &ldv[i], &tr)) {
         trv[i] = tr ? 1 : 0;
         ++found;
       } else {
@@ -814,7 +840,7 @@ int g2ohip_ls_solve_pattern(g2ohip_linear_solver* ls, int n_blocks, const int32_
       d_out.alloc((size_t)n_req * pp);
       const size_t total = (size_t)n_req * pp;
       hipLaunchKernelGGL(ls_gather_inverse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ls->st, n_req, bs, d_off.p, d_ld.p, d_tr.p,
-                         ls->chol->inverse_slab(), d_out.p);
+                         ch->inverse_slab(), d_out.p);
       std::vector<double> ho(total);
       d_out.download(ho.data(), total, ls->st);
       for (int i = 0; i < n_req; ++i)
@@ -830,7 +856,7 @@ int g2ohip_ls_solve_pattern(g2ohip_linear_solver* ls, int n_blocks, const int32_
         if (off[i] >= 0) continue;
         for (int k = 0; k < bs; ++k) {
           hipLaunchKernelGGL(ls_unit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ls->st, rhs.p, n, (size_t)cols[i] * bs + k);
-          ls->chol->solve(rhs.p, sol.p, ls->st);
+          ch->solve(rhs.p, sol.p, ls->st);
           sol.download(h.data(), n, ls->st);
           for (int r = 0; r < bs; ++r) out[(size_t)i * pp + r + (size_t)bs * k] = h[(size_t)rows[i] * bs + r];
         }

@@ -1,0 +1,176 @@
+// TEST INFRASTRUCTURE ONLY: the host program of the adapter test (tests/test_gpu_adapter.py).  It does what the g2o CLI
+// does with a solver plugin (/root/reference/g2o/apps/g2o_cli/g2o_common.cpp:81-167, dl_wrapper.cpp:118, g2o.cpp:131-159):
+// dlopen the *_solver_*.so, look the optimisation algorithm up BY NAME in the factory the plugin registered with, hand it to
+// a SparseOptimizer holding a bundle-adjustment graph, and iterate -- everything through the g2o::OptimizationAlgorithm /
+// g2o::Solver / g2o::LinearSolver vtables.
+//   g2o_host <problem.txt> <plugin.so> <solver name> <iterations> <out.json> [marginals]
+// problem.txt: ncams npts nedges f cx cy huber_delta | per camera: fixed R(9, column-major) t(3) | per point: fixed xyz | per
+// edge: cam point u v
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <sstream>
+
+#include "g2o/types/sba/types_six_dof_expmap.h"
+
+using namespace g2o;
+
+int main(int argc, char** argv) {
+  if (argc < 6) {
+    std::cerr << "usage: g2o_host problem.txt plugin.so solver iterations out.json [marginals]" << std::endl;
+    return 2;
+  }
+  const std::string solverName = argv[3];
+  const int iterations = std::atoi(argv[4]);
+  const bool marginals = argc > 6 && std::string(argv[6]) == "marginals";
+  // ---- plugin: static RegisterOptimizationAlgorithmProxy objects run inside dlopen (optimization_algorithm_factory.h:120-130)
+  void* lib = dlopen(argv[2], RTLD_LAZY | RTLD_GLOBAL);
+  if (!lib) {
+    std::cerr << "dlopen: " << dlerror() << std::endl;
+    return 3;
+  }
+  if (!dlsym(lib, "g2o_optimization_library_hip") || !dlsym(lib, ("g2o_optimization_algorithm_" + solverName).c_str())) {
+    std::cerr << "the plugin does not export the registration anchors" << std::endl;
+    return 3;
+  }
+  OptimizationAlgorithmProperty prop;
+  OptimizationAlgorithm* algo = OptimizationAlgorithmFactory::instance()->construct(solverName, prop);
+  if (!algo) {
+    std::cerr << "solver " << solverName << " is not registered; known:" << std::endl;
+    OptimizationAlgorithmFactory::instance()->listSolvers(std::cerr);
+    return 3;
+  }
+  // ---- graph
+  std::ifstream in(argv[1]);
+  int ncams, npts, nedges;
+  double f, cx, cy, huber;
+  in >> ncams >> npts >> nedges >> f >> cx >> cy >> huber;
+  SparseOptimizer optimizer;
+  Vector2d pp;
+  pp[0] = cx;
+  pp[1] = cy;
+  CameraParameters cam(f, pp, 0.);
+  std::vector<VertexSE3Expmap*> cams(ncams);
+  std::vector<VertexSBAPointXYZ*> pts(npts);
+  for (int i = 0; i < ncams; ++i) {
+    int fixed;
+    Eigen::Matrix3d R;
+    Vector3d t;
+    in >> fixed;
+    for (int k = 0; k < 9; ++k) in >> R.data()[k];
+    for (int k = 0; k < 3; ++k) in >> t[k];
+    VertexSE3Expmap* v = new VertexSE3Expmap();
+    v->setId(i);
+    v->setFixed(fixed != 0);
+    v->setEstimate(SE3Quat(R, t));
+    optimizer.addVertex(v);
+    cams[i] = v;
+  }
+  for (int i = 0; i < npts; ++i) {
+    int fixed;
+    Vector3d x;
+    in >> fixed >> x[0] >> x[1] >> x[2];
+    VertexSBAPointXYZ* v = new VertexSBAPointXYZ();
+    v->setId(ncams + i);
+    v->setFixed(fixed != 0);
+    v->setMarginalized(true);                            // g2o.cpp:307-319: everything that is not a pose
+    v->setEstimate(x);
+    optimizer.addVertex(v);
+    pts[i] = v;
+  }
+  for (int k = 0; k < nedges; ++k) {
+    int ci, pi;
+    Vector2d z;
+    in >> ci >> pi >> z[0] >> z[1];
+    EdgeProjectXYZ2UV* e = new EdgeProjectXYZ2UV();
+    e->setVertex(0, pts[pi]);
+    e->setVertex(1, cams[ci]);
+    e->setMeasurement(z);
+    e->_cam = &cam;
+    if (huber > 0) {
+      RobustKernelHuber* rk = new RobustKernelHuber();
+      rk->setDelta(huber);
+      e->setRobustKernel(rk);
+    }
+    optimizer.addEdge(e);
+  }
+  if (!in) {
+    std::cerr << "problem file truncated" << std::endl;
+    return 2;
+  }
+  optimizer.setAlgorithm(algo);                          // (the optimizer owns the algorithm, the algorithm its Solver)
+  optimizer.initializeOptimization();
+  std::ostringstream js;
+  js << std::setprecision(17);
+  js << "{\"solver\": \"" << solverName << "\", \"property\": {\"name\": \"" << prop.name << "\", \"type\": \"" << prop.type << "\", \"requiresMarginalize\": "
+     << (prop.requiresMarginalize ? "true" : "false") << ", \"poseDim\": " << prop.poseDim << ", \"landmarkDim\": " << prop.landmarkDim << "}";
+  OptimizationAlgorithmWithHessian* awh = dynamic_cast<OptimizationAlgorithmWithHessian*>(algo);
+  if (marginals) {
+    // computeMarginals through the Solver seam on the system of the initial estimate (block_solver.hpp:489-499)
+    if (!awh || !algo->init()) return 4;
+    Solver* s = awh->solver();
+    if (!s->buildStructure()) return 4;
+    optimizer.computeActiveErrors();
+    s->buildSystem();
+    const bool ok = s->solve();
+    std::vector<std::pair<int, int> > blocks;
+    const int nP = (int)(s->vectorSize() - 3 * (size_t)npts) / 6;   // (no fixed points in this mode)
+    for (int i = 0; i < nP && i < 6; ++i) blocks.push_back(std::make_pair(i, i));
+    if (nP > 3) blocks.push_back(std::make_pair(0, 3));
+    SparseBlockMatrix<MatrixXd> spinv;
+    const bool okm = algo->computeMarginals(spinv, blocks);
+    js << ", \"solve_ok\": " << (ok ? "true" : "false") << ", \"marginals_ok\": " << (okm ? "true" : "false") << ", \"blocks\": [";
+    for (size_t b = 0; b < blocks.size() && okm; ++b) {
+      MatrixXd* m = spinv.block(blocks[b].first, blocks[b].second);
+      js << (b ? ", " : "") << "{\"r\": " << blocks[b].first << ", \"c\": " << blocks[b].second << ", \"v\": [";
+      for (int q = 0; q < 36; ++q) js << (q ? ", " : "") << (m ? m->data()[q] : 0.0);
+      js << "]}";
+    }
+    js << "], \"x\": [";
+    for (size_t i = 0; i < s->vectorSize(); ++i) js << (i ? ", " : "") << s->x()[i];
+    js << "]}";
+  } else {
+    // SparseOptimizer::optimize (sparse_optimizer.cpp:354-419) unrolled so that chi2 and lambda of every iteration are kept
+    if (!algo->init()) return 4;
+    OptimizationAlgorithmLevenberg* lm = dynamic_cast<OptimizationAlgorithmLevenberg*>(algo);
+    std::vector<double> chis, lams;
+    std::vector<int> trials;
+    optimizer.computeActiveErrors();
+    const double chi0 = optimizer.activeRobustChi2();
+    int done = 0;
+    for (int i = 0; i < iterations; ++i) {
+      const OptimizationAlgorithm::SolverResult r = algo->solve(i);
+      if (r == OptimizationAlgorithm::Fail) break;
+      optimizer.computeActiveErrors();
+      chis.push_back(optimizer.activeRobustChi2());
+      lams.push_back(lm ? lm->currentLambda() : 0.0);
+      trials.push_back(lm ? lm->levenbergIteration() : 1);
+      ++done;
+      if (r == OptimizationAlgorithm::Terminate) break;
+    }
+    js << ", \"iterations\": " << done << ", \"chi2_initial\": " << chi0 << ", \"chi2\": [";
+    for (size_t i = 0; i < chis.size(); ++i) js << (i ? ", " : "") << chis[i];
+    js << "], \"lambda\": [";
+    for (size_t i = 0; i < lams.size(); ++i) js << (i ? ", " : "") << lams[i];
+    js << "], \"trials\": [";
+    for (size_t i = 0; i < trials.size(); ++i) js << (i ? ", " : "") << trials[i];
+    js << "], \"cams\": [";
+    for (int i = 0; i < ncams; ++i) {
+      const SE3Quat& T = cams[i]->estimate();
+      for (int k = 0; k < 9; ++k) js << (i || k ? ", " : "") << T.rotationMatrix().data()[k];
+      for (int k = 0; k < 3; ++k) js << ", " << T.translation()[k];
+    }
+    js << "], \"points\": [";
+    for (int i = 0; i < npts; ++i)
+      for (int k = 0; k < 3; ++k) js << (i || k ? ", " : "") << pts[i]->estimate()[k];
+    js << "]}";
+  }
+  std::ofstream(argv[5]) << js.str() << std::endl;
+  // (the optimizer's destructor deletes the algorithm, that one the Solver, that one its LinearSolver: the ownership chain of
+  // sparse_optimizer.cpp:56-59 / optimization_algorithm_with_hessian.cpp:45-48 / block_solver.hpp:135-140 runs here, with the
+  // plugin still loaded)
+  return 0;
+}

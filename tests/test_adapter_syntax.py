@@ -1,15 +1,16 @@
 """CPU: the g2o adapter (openslam_g2o_amd/cpp/g2o_hip_solver.h) and the plugin registration (solver_hip.cpp) are
-type-checked with `g++ -fsyntax-only` against tests/cpp/g2o_decl -- declarations of the g2o members they touch,
-written from the reference's public headers (Eigen / g2o are not installable here).  Catches signature drift
-between the adapter, include/g2ohip.h and the g2o interface (solver.h:44-149, linear_solver.h:40-81,
-optimization_algorithm_factory.h:120-162)."""
+compiled against tests/cpp/mini_g2o -- this repository's own small implementation of the g2o interfaces they touch,
+written from the reference's public headers (Eigen / g2o are not installable here) -- with -Wall -Wextra -Werror, and
+LINKED with libg2ohip.so into libg2o_solver_hip.so.  Catches signature drift between the adapter, include/g2ohip.h and
+the g2o interface (solver.h:44-149, linear_solver.h:40-81, optimization_algorithm_factory.h:120-162).  The plugin is
+EXECUTED on the GPU by tests/test_gpu_adapter.py."""
 import os
 import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "openslam_g2o_amd", "cpp")
-DECL = os.path.join(ROOT, "tests", "cpp", "g2o_decl")
+DECL = os.path.join(ROOT, "tests", "cpp", "mini_g2o")
 
 
 def _check(src, std="c++11"):
@@ -52,3 +53,20 @@ def test_adapter_calls_only_declared_abi_functions():
     declared = set(re.findall(r"\b(g2ohip_\w+)\s*\(", hdr))
     used = set(re.findall(r"\b(g2ohip_\w+)\s*\(", open(os.path.join(CPP, "g2o_hip_solver.h")).read()))
     assert used and used <= declared, used - declared
+
+
+def test_plugin_links_and_exports_the_registration_anchors():
+    """`make -C tests/cpp/mini_g2o`: the plugin links against libg2ohip.so and the test host's core library; its file name
+    matches *_solver_*.so and it exports the extern "C" anchors of G2O_REGISTER_OPTIMIZATION_LIBRARY / _ALGORITHM
+    (optimization_algorithm_factory.h:153-162) -- the only C symbols a g2o plugin has."""
+    host = os.path.join(ROOT, "tests", "cpp", "mini_g2o")
+    r = subprocess.run(["make", "-s", "-C", host], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    so = os.path.join(host, "build", "libg2o_solver_hip.so")
+    assert os.path.exists(so) and os.path.exists(os.path.join(host, "build", "g2o_host"))
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    assert " T g2o_optimization_library_hip" in syms
+    for name in ("lm_fix6_3_hip", "lm_fix6_3_hipls", "gn_fix6_3_hip", "dl_fix6_3_hip", "lm_fix3_2_hip", "lm_fix7_3_hip"):
+        assert " T g2o_optimization_algorithm_%s" % name in syms, name
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "libg2ohip.so" in needed and "libg2o_mini_core.so" in needed

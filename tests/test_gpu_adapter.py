@@ -1,0 +1,139 @@
+"""The g2o adapter EXECUTED: openslam_g2o_amd/cpp/solver_hip.cpp + g2o_hip_solver.h are compiled against the test host
+tests/cpp/mini_g2o (this repository's own small implementation of the g2o interfaces the adapter touches -- Eigen and g2o
+cannot be installed here), linked with libg2ohip.so into libg2o_solver_hip.so, loaded with dlopen by a host program and
+found BY NAME through the optimisation-algorithm factory, the way the g2o CLI finds a solver plugin
+(g2o_common.cpp:81-167, optimization_algorithm_factory.h:120-162).  Levenberg-Marquardt then runs through the
+g2o::OptimizationAlgorithm -> g2o::Solver (wide seam, generic path and device fast path) and g2o::BlockSolver ->
+g2o::LinearSolver (narrow seam) vtables on the GPU; chi2, lambda, trial counts and the final estimates are compared with the
+same loop driven through the CPU oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from openslam_g2o_amd import lm, synthetic as S
+from tests.helpers import ba_case, oracle_ba, relerr
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_DIR = os.path.join(ROOT, "tests", "cpp", "mini_g2o")
+BUILD = os.path.join(HOST_DIR, "build")
+
+
+@pytest.fixture(scope="module")
+def host():
+    subprocess.run(["make", "-s", "-C", HOST_DIR], check=True, capture_output=True, text=True)
+    return os.path.join(BUILD, "g2o_host"), os.path.join(BUILD, "libg2o_solver_hip.so")
+
+
+def _write_problem(path, pr, huber=0.0, fix_points=False):
+    with open(path, "w") as f:
+        f.write("%d %d %d %.17g %.17g %.17g %.17g\n" % (pr["P"], pr["L"], pr["E"], pr["f"], pr["cx"], pr["cy"], huber))
+        for i in range(pr["P"]):
+            f.write("%d %s\n" % (1 if pr["cam_hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in pr["cams"][i])))
+        for j in range(pr["L"]):
+            f.write("%d %s\n" % (1 if fix_points else 0, " ".join("%.17g" % v for v in pr["pts"][j])))
+        for k in range(pr["E"]):
+            f.write("%d %d %.17g %.17g\n" % (pr["cam_idx"][k], pr["pt_idx"][k], pr["meas"][k][0], pr["meas"][k][1]))
+
+
+def _run(host, problem, solver, iterations, out, env=None, mode=None):
+    exe, plugin = host
+    e = dict(os.environ)
+    e["G2OHIP_ADAPTER_VERBOSE"] = "1"
+    e.update(env or {})
+    cmd = [exe, problem, plugin, solver, str(iterations), out] + ([mode] if mode else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    return json.load(open(out)), r.stderr
+
+
+def _oracle_lm(pr, iterations, huber=0.0):
+    from tests.test_gpu_lm import OracleBAGraph, OracleSolverAdapter
+    g = OracleBAGraph(pr, huber=huber)
+    g.compute_active_errors = g.compute_active_errors   # (protocol object)
+    g.linearize()
+    chi0 = g.chi2()
+    n, chis, lams, trials = lm.optimize(g, OracleSolverAdapter(g.o), iterations, "lm")
+    return chi0, n, chis, lams, trials, g.pr["cams"], g.pr["pts"]
+
+
+@pytest.mark.parametrize("huber", [0.0, 1.0])
+def test_levenberg_marquardt_through_the_g2o_vtables(host, tmp_path, huber):
+    pr = ba_case(40, 400, outlier_frac=0.05 if huber > 0 else 0.0)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr, huber)
+    chi0, n_o, chis_o, lams_o, trials_o, cams_o, pts_o = _oracle_lm(pr, 5, huber)
+    runs = {}
+    for tag, solver, env in (("wide-fast", "lm_fix6_3_hip", {}), ("wide-generic", "lm_fix6_3_hip", {"G2OHIP_ADAPTER_FASTPATH": "0"}),
+                             ("narrow", "lm_fix6_3_hipls", {})):
+        out, err = _run(host, prob, solver, 5, str(tmp_path / (tag + ".json")), env)
+        runs[tag] = out
+        # registered through the factory with the property table of solver_csparse.cpp:117-140
+        assert out["property"] == {"name": solver, "type": "MI355X HIP", "requiresMarginalize": True, "poseDim": 6, "landmarkDim": 3}
+        assert ("device front end (g2ohip_ba_*) for %d EdgeProjectXYZ2UV" % pr["E"] in err) == (tag == "wide-fast"), err[-500:]
+        assert abs(out["chi2_initial"] - chi0) <= 1e-9 * chi0
+        assert out["iterations"] == n_o and out["trials"] == trials_o, (tag, out["trials"], trials_o)
+        assert np.allclose(out["chi2"], chis_o, rtol=1e-7, atol=0), (tag, out["chi2"], chis_o)
+        assert np.allclose(out["lambda"], lams_o, rtol=1e-7, atol=0), (tag, out["lambda"], lams_o)
+        assert relerr(np.array(out["cams"]).reshape(-1, 12), cams_o) < 1e-7 and relerr(np.array(out["points"]).reshape(-1, 3), pts_o) < 1e-7
+    assert runs["wide-fast"]["chi2"][-1] < 0.6 * chi0
+    # the device front end and the uploaded Jacobians walk the same trajectory
+    assert np.allclose(runs["wide-fast"]["chi2"], runs["wide-generic"]["chi2"], rtol=1e-9, atol=0)
+
+
+def test_gauss_newton_and_dogleg_creators_construct(host, tmp_path):
+    pr = ba_case(12, 100)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr)
+    out, _ = _run(host, prob, "gn_fix6_3_hip", 3, str(tmp_path / "gn.json"))
+    assert out["iterations"] == 3 and out["chi2"][-1] < out["chi2_initial"]
+    out, _ = _run(host, prob, "gn_fix6_3_hipls", 2, str(tmp_path / "gnls.json"))
+    assert out["iterations"] == 2 and out["chi2"][-1] < out["chi2_initial"]
+    out, _ = _run(host, prob, "dl_fix6_3_hip", 0, str(tmp_path / "dl.json"))     # constructed via dynamic_cast<BlockSolverBase*>
+    assert out["property"]["name"] == "dl_fix6_3_hip"
+
+
+@pytest.mark.parametrize("solver", ["lm_fix6_3_hip", "lm_fix6_3_hipls"])
+def test_compute_marginals_through_the_seams(host, tmp_path, solver):
+    """Solver::computeMarginals: on the narrow seam g2o's BlockSolver calls solve(Hschur) and then solvePattern(Hpp) on the
+    SAME LinearSolver without init() (block_solver.hpp:489-499) -- a second pattern between two init() calls."""
+    pr = ba_case(30, 300)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr)
+    out, _ = _run(host, prob, solver, 0, str(tmp_path / "m.json"), mode="marginals")
+    assert out["solve_ok"] and out["marginals_ok"]
+    o = oracle_ba(pr)
+    o.build_system()
+    assert o.solve()
+    assert relerr(np.array(out["x"]), o.x()) < 1e-7
+    nP = pr["nP"]
+    cp, ri = o.pattern("pp")
+    V = o.values("Hpp").reshape(-1, 6, 6)
+    H = np.zeros((6 * nP, 6 * nP))
+    for c in range(nP):
+        for q in range(cp[c], cp[c + 1]):
+            r = ri[q]
+            H[6 * r:6 * r + 6, 6 * c:6 * c + 6] = V[q].T
+            H[6 * c:6 * c + 6, 6 * r:6 * r + 6] = V[q]
+    Hi = np.linalg.inv(H)
+    assert len(out["blocks"]) >= 6
+    for b in out["blocks"]:
+        got = np.array(b["v"]).reshape(6, 6).T          # column-major
+        ref = Hi[6 * b["r"]:6 * b["r"] + 6, 6 * b["c"]:6 * b["c"] + 6]
+        assert np.abs(got - ref).max() <= 1e-8 * np.abs(Hi).max(), (b["r"], b["c"])
+
+
+def test_localisation_graph_with_every_point_fixed(host, tmp_path):
+    """All vertices of one side of a group fixed (EdgeProjectXYZ2UV over fixed points): the generic path's Jacobian buffers
+    are sized for what the library reads (round-2 advisor finding), the fast path declines (no marginalized point)."""
+    pr = ba_case(10, 120)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr, fix_points=True)
+    for env in ({}, {"G2OHIP_ADAPTER_FASTPATH": "0"}):
+        out, _ = _run(host, prob, "lm_fix6_3_hip", 3, str(tmp_path / "loc.json"), env)
+        assert out["iterations"] >= 1 and out["chi2"][-1] < out["chi2_initial"]
+        assert np.abs(np.array(out["points"]).reshape(-1, 3) - pr["pts"]).max() == 0.0      # fixed points did not move
