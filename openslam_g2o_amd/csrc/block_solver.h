@@ -96,7 +96,7 @@ class BlockSolver {
   void copy_b(double* h);
   const double* x_device() const { return d_x.p; }
   const double* b_device() {
-    ensure_ll();
+    ensure_bl();
     return d_b.p;
   }
   void sync();
@@ -226,6 +226,7 @@ class BlockSolver {
   size_t dependency_fallbacks = 0;   // dependency-driven launches that gave up and were repeated level by level
   bool ba_skip_hpl = true;            // fused BA path: Hpl is not written at all while nobody reads it (ensure_hpl)
   bool ba_fuse_landmarks = true;      // ... and the landmark side (Hll, b_l, errors) is assembled by the Schur tiles of the solve
+  int ba_store_ll = 0;                // ... which then also write Hll and the errors to memory (0: only b_l and Dinv, what the solve reads)
   bool ba_recompute_backsub = true;   // fused BA path: back-substitution from the Jacobians instead of reading Hpl
   double fuse_reduce_max_partials = 6.0;   // solve() folds the Schur reduction into the factorisation only while a block of the reduced system has at most this many partial blocks on average
   bool marginals_recursion = true;  // compute_marginals: all entries on the pattern of L in one top-down pass (sparse inverse) instead of one pair of sweeps per column
@@ -275,9 +276,11 @@ class BlockSolver {
   int ba_lm_group() const;
   void ensure_hpl();
   void ensure_ll();
+  void ensure_bl();
   void launch_ba_landmarks(bool write_hpl);
   bool hpl_valid_ = true;
   bool ll_valid_ = true;   // Hll, b_l and the errors of the fused BA path match the last build_system
+  bool ll_hbm_partial_ = false;   // ... but the Schur tiles that assembled them wrote b_l only (Hll and the errors stayed on chip)
   void pg_validate();
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;

@@ -1099,8 +1099,10 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
     int kind, double delta, int ident, double* __restrict__ Dinv, double* bl, const int* __restrict__ td_diag,
     const int* __restrict__ td_ptr, const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm, double* __restrict__ Pd,
     double* __restrict__ Pr, double* Hll, const double* __restrict__ lam, const int4* __restrict__ ll_rec,
-    const int4* __restrict__ tile_ll, const int* __restrict__ ll_edge, double* __restrict__ err, const int2* __restrict__ tile_q2) {
-  // (FLL: meas_q / omega_q are the slot-major copies ll_meas / ll_omega; cam_q / pt_q are unused)
+    const int4* __restrict__ tile_ll, const int* __restrict__ ll_edge, double* __restrict__ err, const int2* __restrict__ tile_q2,
+    int store_hll) {
+  // (FLL: meas_q / omega_q are the slot-major copies ll_meas / ll_omega; cam_q / pt_q are unused; store_hll = 0: Hll stays in
+  // the LDS stage -- the solve path reads Dinv and b_l only --, err = nullptr: the errors are not written either)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int PD = 6, LD = 3, PL = PD * LD;
   const int t = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -1212,7 +1214,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
 #pragma unroll
           for (int i = 0; i < 9; ++i) {
             Ds[lmi * 9 + i] = v[i];
-            hd[i] = v[i];
+            if (store_hll) hd[i] = v[i];
           }
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
@@ -2586,14 +2588,20 @@ bool BlockSolver::ba_fuse_ll_ok() const { return ba_fuse_landmarks && ba_.ll_slo
 // somebody reads Hll, b_l or the errors between a build_system that left them to the solve and that solve
 // (maxDiagonal of the first LM iteration, b(), multiplyHessian, chi2 without a linearisation)
 void BlockSolver::ensure_ll() {
-  if (ll_valid_) return;
+  if (ll_valid_ && !ll_hbm_partial_) return;
   if (!ba_recompute_ok())
     throw StateFailure("the landmark blocks were left to solve() by the last build_system and the estimates (or the robust kernel) have "
                        "changed since: call build_system again, or set option ba_fuse_landmarks = 0");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   launch_ba_landmarks(false);
   ll_valid_ = true;
+  ll_hbm_partial_ = false;
   G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+// readers of b_l alone (b(), computeScale): the Schur tiles of the solve always leave it in memory
+void BlockSolver::ensure_bl() {
+  if (!ll_valid_) ensure_ll();
 }
 
 // somebody reads Hpl (copy_values, multiplyHessian, the matrix-free operator, a solve path without the fused kernels)
@@ -2606,6 +2614,7 @@ void BlockSolver::ensure_hpl() {
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   launch_ba_landmarks(true);   // the same kernel with the Hpl stores on (Hll, b_l and the errors come out identical)
   hpl_valid_ = ll_valid_ = true;
+  ll_hbm_partial_ = false;
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 
@@ -2613,6 +2622,7 @@ void BlockSolver::build_system_impl() {
   if (profiling) tq_.start(st_);
   ba_.sys_version = -1;   // (set again by the fused BA branch)
   hpl_valid_ = ll_valid_ = true;
+  ll_hbm_partial_ = false;
   const size_t sizeP = (size_t)nP_ * p_;
   bool any_pose = false, any_lm = false;
   int set_index = -1;
@@ -2711,7 +2721,7 @@ double BlockSolver::chi2() {
   require_structure();
   if (chi2_valid_) return chi2_value_;   // same errors, same kernels as the last evaluation (LM asks twice per accepted step)
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  if (!ll_valid_ && !ba_.err_valid) ensure_ll();   // errors come from a linearisation or from the landmark side of the assembly
+  if ((!ll_valid_ || ll_hbm_partial_) && !ba_.err_valid) ensure_ll();   // errors come from a linearisation or from the landmark side of the assembly
   double total = 0.0;
   for (auto& esp : sets_) {
     EdgeSet& es = *esp;
@@ -2853,7 +2863,7 @@ void BlockSolver::copy_diagonal(double* host) {
 double BlockSolver::compute_scale(double lambda) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  ensure_ll();
+  ensure_bl();
   int nblocks = std::min(1024, grid_for(vector_size()));
   hipLaunchKernelGGL(scale_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, vector_size(), d_x.p, d_b.p, lambda, d_red.p);
   return reduce_sum_finish(nblocks);
@@ -2891,7 +2901,11 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
       attr = true;
     }
     prof.begin(KernelProf::kSchurBlocks, st_);
-    const bool fll = !ll_valid_;   // the tiles assemble Hll / b_l / errors themselves
+    const bool fll = !ll_valid_ || ll_hbm_partial_;   // the tiles assemble Hll / b_l / errors themselves (again, if the last ones kept Hll on chip)
+    // ... and write to HBM only what the solve path reads (Dinv, b_l) unless option ba_store_ll asks for Hll and the errors
+    // too: 150 MB less to write at the metric configuration; a later reader (maxDiagonal, multiplyHessian, chi2 without a
+    // linearisation, inspection) has them recomputed by ensure_ll()
+    const bool store_ll = ba_store_ll != 0;
 #define G2OHIP_BA_TILE(GG)                                                                                                         \
   do {                                                                                                                             \
     if (fll)                                                                                                                       \
@@ -2900,14 +2914,14 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
                          ba_.cy,                                                                                                     \
                          es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, ba_.ll_rec.p, ba_.tile_ll.p, ba_.ll_edge.p,       \
-                         ba_.err_valid ? (double*)nullptr : es.own_err.p, /* (errors of these estimates already there) */          \
-                         d_tile_q2.p);                                                                                             \
+                         (ba_.err_valid || !store_ll) ? (double*)nullptr : es.own_err.p, /* (errors of these estimates already there) */ \
+                         d_tile_q2.p, store_ll ? 1 : 0);                                                                           \
     else                                                                                                                           \
       hipLaunchKernelGGL((ba_schur_tile_kernel<GG, false>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,       \
                          ba_.cams.p, ba_.pts.p, ba_.cam_q.p, ba_.pt_q.p, ba_.meas_q.p, ba_.omega_q.p, ba_.f, ba_.cx, ba_.cy,           \
                          es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, (const int4*)nullptr, (const int4*)nullptr,        \
-                         (const int*)nullptr, (double*)nullptr, d_tile_q2.p);                                                      \
+                         (const int*)nullptr, (double*)nullptr, d_tile_q2.p, 1);                                                   \
   } while (0)
     if (G <= 1) G2OHIP_BA_TILE(1);
     else if (G <= 2) G2OHIP_BA_TILE(2);
@@ -2915,6 +2929,7 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
     else if (G <= 8) G2OHIP_BA_TILE(8);
     else G2OHIP_BA_TILE(16);
     ll_valid_ = true;
+    ll_hbm_partial_ = fll && !store_ll;
 #undef G2OHIP_BA_TILE
     prof.end(KernelProf::kSchurBlocks, st_);
   } else
@@ -3366,7 +3381,7 @@ double BlockSolver::chi2_sharded() {
 double BlockSolver::compute_scale_sharded(double lambda) {
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  ensure_ll();
+  ensure_bl();
   const int nblocks = std::min(1024, grid_for(vector_size()));
   hipLaunchKernelGGL(scale_sharded_partial_kernel, dim3(nblocks), dim3(kThreads), 0, st_, (size_t)nP_ * p_, vector_size(), d_x.p, d_b.p,
                      lambda, p_, chol_opt.world > 1 ? d_lam_mask.p : (const unsigned char*)nullptr, d_red.p);
@@ -3794,7 +3809,7 @@ void BlockSolver::copy_x(double* h) {
 }
 void BlockSolver::copy_b(double* h) {
   require_structure();
-  ensure_ll();
+  ensure_bl();
   d_b.download(h, vector_size(), st_);
 }
 void BlockSolver::sync() { G2OHIP_HIP_CHECK(hipStreamSynchronize(st_)); }
@@ -4410,7 +4425,7 @@ void BlockSolver::copy_edge_data(int set, double* J0, double* J1, double* err) {
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
   EdgeSet& es = *sets_[set];
   if (!es.has_err) throw StateFailure("copy_edge_data: the set has no edge data yet");
-  if (set == ba_.set && !ll_valid_ && !ba_.err_valid) ensure_ll();
+  if (set == ba_.set && (!ll_valid_ || ll_hbm_partial_) && !ba_.err_valid) ensure_ll();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t n = (size_t)es.n;
   auto pull = [&](double* dst, const double* src, size_t cnt) {

@@ -1336,6 +1336,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           if (bb < nblk) prow = base + bb;
           else if (bb - nblk < (int)Rset.size()) prow = Rset[bb - nblk];
           fr[5 + d] = prow >= 0 ? local_pos(f, prow) : -1;
+          // the kernel addresses a row that is a pivot of the chain as (band position - first pivot of the front): the band rows
+          // of a front have to be contiguous (no holes in the band)
+          if (bb < nblk && fr[5 + d] >= 0 && fr[5 + d] != d) return why(17);
         }
         for (int k = 0; k < 4; ++k) {
           fr[13 + k] = k < (int)Sset.size() ? local_pos(f, Sset[k]) : -1;
