@@ -71,6 +71,7 @@ typedef struct g2ohip_stats {
   double timeUpdate;                 /* device front end: last oplus over all vertices (SparseOptimizer::update) */
   size_t dependencyFallbacks;        /* dependency-driven launches that gave up waiting and were repeated level by level (0 expected) */
   size_t bandChains;                 /* leaf chains of the elimination tree factorised by the sliding-window band kernel */
+  size_t bandCholeskyNNZ, bandPivots; /* ... their share of choleskyNNZ and of the pivot columns (scalars) */
 } g2ohip_stats;
 /* (G2OBatchStatistics::timeIteration / levenbergIterations / chi2 belong to the caller's optimisation loop:
  *  openslam_g2o_amd/lm.py fills them and prints the `g2o -stats` line, batch_stats.cpp:49-82.) */

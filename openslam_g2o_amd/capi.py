@@ -34,7 +34,7 @@ class Stats(C.Structure):
         "timeLinearSolution", "timeLinearSolver", "timeBackSubstitution")] + [(n, C.c_size_t) for n in (
             "hessianDimension", "hessianPoseDimension", "hessianLandmarkDimension", "choleskyNNZ", "numFronts",
             "numLevels", "maxFrontDim", "iterationsLinearSolver")] + [(n, C.c_double) for n in (
-                "timeResiduals", "timeLinearize", "timeUpdate")] + [("dependencyFallbacks", C.c_size_t), ("bandChains", C.c_size_t)]
+                "timeResiduals", "timeLinearize", "timeUpdate")] + [("dependencyFallbacks", C.c_size_t), ("bandChains", C.c_size_t), ("bandCholeskyNNZ", C.c_size_t), ("bandPivots", C.c_size_t)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -221,6 +221,11 @@ class HipBlockSolver:
         _check(self.L.g2ohip_create(C.byref(self.h), pose_dim, landmark_dim, device), "g2ohip_create")
         self._keep = {}
         self.nP = self.nL = 0
+        # G2OHIP_OPTIONS="name=value,...": options for every solver of the process (experiments and bisecting: e.g. run a test
+        # with band_kernel=0); an explicit setOption afterwards still wins
+        for kv in filter(None, os.environ.get("G2OHIP_OPTIONS", "").split(",")):
+            name, value = kv.split("=")
+            self.setOption(name.strip(), float(value))
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:

@@ -163,7 +163,7 @@ class BlockSolver {
   // host patterns
   std::vector<int> pp_colptr, pp_row, pp_diag, pl_colptr, pl_row, hs_colptr, hs_row;
   // device matrices
-  enum Seg { kSegFactor = 0, kSegBackward, kSegLocal, kSegShared, kSegSharedBack, kNumSeg };
+  enum Seg { kSegFactor = 0, kSegBackward, kSegLocal, kSegShared, kSegSharedBack, kSegFactorBand, kSegFactorRest, kNumSeg };
   struct GraphSeg {
     hipGraph_t g = nullptr;
     hipGraphExec_t e = nullptr;

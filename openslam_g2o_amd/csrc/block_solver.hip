@@ -3095,13 +3095,34 @@ void BlockSolver::solve_reduced_device() {
   // The two launch-bound sequences (one launch per tree level) are hipGraph segments; the timing events sit
   // between the segments, so per-slot times stay available while the graphs replay.
   if (profiling) tn_.start(st_);
-  prof.begin(KernelProf::kCholFactor, st_);
-  run_seg(kSegFactor, [&] {
+  if (chol_->has_band_chains(0) && prof.enabled && prof.only < 0) {
+    // every kernel slot is being timed: the factorisation is two kernels (the band chains, the tree levels above them);
+    // plain launches with the events right around the band chains' launch -- its slot is that kernel alone, the other
+    // slot everything else of the sequence (right-hand side in, the other levels)
+    prof.begin(KernelProf::kCholFactor, st_);
+    chol_->band_hook = [this](int after) {
+      if (!after) {
+        prof.end(KernelProf::kCholFactor, st_);
+        prof.begin(KernelProf::kCholBand, st_);
+      } else {
+        prof.end(KernelProf::kCholBand, st_);
+        prof.begin(KernelProf::kCholFactor, st_, /*cont=*/true);
+      }
+    };
     chol_->solve_begin(bred, st_);
     chol_->factor_phase(Hred, 0, st_, true);
     chol_->factor_phase(Hred, 1, st_, true);
-  });
-  prof.end(KernelProf::kCholFactor, st_);
+    chol_->band_hook = nullptr;
+    prof.end(KernelProf::kCholFactor, st_);
+  } else {
+    prof.begin(KernelProf::kCholFactor, st_);
+    run_seg(kSegFactor, [&] {
+      chol_->solve_begin(bred, st_);
+      chol_->factor_phase(Hred, 0, st_, true);
+      chol_->factor_phase(Hred, 1, st_, true);
+    });
+    prof.end(KernelProf::kCholFactor, st_);
+  }
   if (profiling) {
     tn_.stop(st_);
     tl_.start(st_);

@@ -407,6 +407,8 @@ static void fill_chol_stats(const CholStats* cs, g2ohip_stats* out) {
   out->numLevels = cs->n_levels;
   out->maxFrontDim = cs->max_front_dim;
   out->bandChains = cs->n_band;
+  out->bandCholeskyNNZ = cs->nnzL_band;
+  out->bandPivots = cs->piv_band;
 }
 
 int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out) {

@@ -131,17 +131,17 @@ __device__ __forceinline__ void stage_copy(T* __restrict__ dst, const T* __restr
 // Per-kernel timing with HIP events on the launch stream (enabled by g2ohip_set_profiling).
 struct KernelProf {
   enum Slot { kAsmPose = 0, kAsmLandmark, kAsmOffPP, kAsmOffPL, kLmInverse, kSchurBlocks, kSchurRhs, kCholFactor, kCholSolve,
-              kBackSub, kLambda, kExBoundary, kExRoots, kExHalo, kNumSlots };
+              kBackSub, kLambda, kExBoundary, kExRoots, kExHalo, kCholBand, kNumSlots };
   static const char* name(int s) {
     static const char* n[] = {"assemble_vertex(pose)", "assemble_vertex(landmark)", "assemble_offdiag(Hpp)", "assemble_offdiag(Hpl)",
                               "landmark_inverse", "schur_tiles", "schur_reduce", "chol_factor(all levels)", "chol_solve(all levels)",
                               "back_substitute", "set_lambda/restore", "exchange(boundary blocks + b_p)", "exchange(subtree roots)",
-                              "exchange(halo x_p + status)"};
+                              "exchange(halo x_p + status)", "chol_factor(band chains)"};
     return (s >= 0 && s < kNumSlots) ? n[s] : "?";
   }
   bool enabled = false;
   int only = -1;   // >= 0: time this slot only (two events per iteration instead of ~20: the records are not free)
-  struct Pair { hipEvent_t a, b; };
+  struct Pair { hipEvent_t a, b; bool cont; };   // cont: the slot was interrupted by another one and goes on (not a new launch)
   std::vector<Pair> pending[kNumSlots];
   std::vector<hipEvent_t> pool;
   double total[kNumSlots] = {0};
@@ -151,9 +151,9 @@ struct KernelProf {
     hipEvent_t e; G2OHIP_HIP_CHECK(hipEventCreate(&e)); return e;
   }
   bool timing(int slot) const { return enabled && (only < 0 || slot == only); }
-  void begin(int slot, hipStream_t st) {
+  void begin(int slot, hipStream_t st, bool cont = false) {
     if (!enabled || (only >= 0 && slot != only)) return;
-    Pair p{get(), get()};
+    Pair p{get(), get(), cont};
     G2OHIP_HIP_CHECK(hipEventRecord(p.a, st));
     pending[slot].push_back(p);
   }
@@ -169,7 +169,7 @@ struct KernelProf {
         G2OHIP_HIP_CHECK(hipEventSynchronize(p.b));
         G2OHIP_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
         total[s] += 1e-3 * ms;
-        launches[s]++;
+        if (!p.cont) launches[s]++;
         pool.push_back(p.a);
         pool.push_back(p.b);
       }

@@ -21,6 +21,8 @@
 //   * "not positive definite" (pivot <= 0, csparse_helper.cpp:136) is a device flag read back
 //     once per solve.
 #pragma once
+#include <functional>
+
 #include "common.h"
 
 namespace g2ohip {
@@ -64,6 +66,7 @@ struct CholStats {
   size_t nnzL = 0;        // scalar nnz(L) incl. diagonal
   size_t n_fronts = 0, n_levels = 0, n_tasks = 0, max_front_dim = 0;
   size_t n_band = 0;      // leaf chains on the band kernel
+  size_t nnzL_band = 0, piv_band = 0;   // ... their share of nnz(L) and of the pivot columns (scalars)
   double flops = 0;       // factorisation flops (dense-front count)
   double t_symbolic = 0;  // seconds, host
   size_t bytes_L = 0, bytes_U = 0;
@@ -174,7 +177,12 @@ class SparseCholesky {
   // x = A \ b with device vectors of nb*bs (original block order).  Asynchronous.
   void solve(const double* d_b, double* d_x, hipStream_t st);
   // ---- phased interface for the multi-GPU path (phase 0: this rank's subtrees, phase 1: shared top)
-  void factor_phase(const double* dA, int phase, hipStream_t st, bool fwd = false);   // fwd: fused forward sweep (after solve_begin)
+  // fwd: fused forward sweep (after solve_begin); parts: bit 0 = the band chains' launch (band_chain.inc), bit 1 = everything
+  // else -- two calls with 1 and 2 let a caller time the two halves separately
+  void factor_phase(const double* dA, int phase, hipStream_t st, bool fwd = false, int parts = 3);
+  bool has_band_chains(int phase) const;
+  // called with 0 right before and 1 right after the band chains' launch (per-kernel timing by the caller; plain launches only)
+  std::function<void(int)> band_hook;
   void factor_solve(const double* dA, const double* d_b, double* d_x, hipStream_t st);
   void solve_begin(const double* d_b, hipStream_t st);            // permute the right-hand side in
   void solve_forward_phase(int phase, hipStream_t st);

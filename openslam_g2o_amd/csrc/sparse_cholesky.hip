@@ -1370,10 +1370,13 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         const int fi = colfront[cb];
         int fr[5];
         for (int q = 0; q < 5; ++q) fr[q] = out.tab[(size_t)kBandFrontInts * fi + q];   // (copied: the vector grows below)
+        // band rows of the front that are pivots of the chain: its own pivots and the contiguous run behind them
+        int nbp = 0;
+        while (nbp < 8 && fr[0] + nbp < nblk && out.tab[(size_t)kBandFrontInts * fi + 5 + nbp] == nbp) ++nbp;
         out.tab.push_back(fr[2]);
         out.tab.push_back(fr[3]);
         out.tab.push_back(fr[4]);
-        out.tab.push_back(fr[0] | ((fr[1]) << 8) | (fi << 16));
+        out.tab.push_back(fr[0] | ((fr[1]) << 8) | (fi << 16) | (nbp << 24));
       }
       // per band tile the records of the blocks with rows (border blocks: columns) in it: (source offset, -, -, -), (flags, -,
       // first row relative to the tile | border row, first column relative to the window | to the tile)
@@ -1453,6 +1456,13 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         n_band += G.band_count;
       }
     stats_.n_band = (size_t)n_band;
+    stats_.nnzL_band = stats_.piv_band = 0;
+    for (const BandChainRec& r : brecs)
+      for (int f = r.f_first; f < r.f_first + r.nfronts; ++f) {
+        const size_t m = (size_t)(S.f_ns[f] + S.f_nb[f]) * bs, np = (size_t)S.f_ns[f] * bs;
+        stats_.nnzL_band += np * m - np * (np - 1) / 2;
+        stats_.piv_band += np;
+      }
     if (getenv("G2OHIP_PLAN_DUMP")) {
       fprintf(stderr, "band chains rejected by rule:");
       for (int c = 0; c < 32; ++c)
@@ -4003,12 +4013,20 @@ void SparseCholesky::launch_band(const FactorGroup& G, const double* dA, bool fu
   double* yo = fused ? d_y.p : (double*)nullptr;
   const WvPlan wp = wv_plan(plan_);
   const int dep_i = dep ? 1 : 0;
+  if (band_hook) band_hook(0);
   if (virt) hipLaunchKernelGGL((band_wave_kernel<6, true>), dim3(G.band_count), dim3(64), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
   else hipLaunchKernelGGL((band_wave_kernel<6, false>), dim3(G.band_count), dim3(64), sh, st, wp, B, G.band_rec0, dA, bp, yo, dep_i);
   G2OHIP_LAUNCH_CHECK("band_wave_kernel");
+  if (band_hook) band_hook(1);
 }
 
-void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, bool fwd) {
+bool SparseCholesky::has_band_chains(int phase) const {
+  for (const FactorGroup& G : groups_[phase])
+    if (G.band_count > 0 && opt.band_kernel && bs_ == 6) return true;
+  return false;
+}
+
+void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, bool fwd, int parts) {
   if (!analyzed_) throw StateFailure("SparseCholesky::factor before analyze");
   static bool attr_done = false;
   if (!attr_done) {
@@ -4046,7 +4064,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     (void)hipGetLastError();
     attr_done = true;
   }
-  if (phase == 0) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
+  if (phase == 0 && (parts & 1)) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
 #ifdef G2OHIP_CHOL_STAMPS
   if (phase == 0) {
     if (!d_dbg.p) d_dbg.alloc(64 * 64 + 2 * (size_t)n_slots_ + 2);
@@ -4055,8 +4073,8 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     dbg_launch_ = 0;
   }
 #endif
-  if (opt.merge_diag_panel && !dep_off_ && d_sw_flag.p && ha_count_[phase] > 0) d_sw_flag.zero(st);   // per-front flags of big_level_kernel (phases with scratch-slab levels only)
-  if (opt.hoist_big_assembly && (hz_count_[phase] > 0 || ha_count_[phase] > 0)) {
+  if ((parts & 2) && opt.merge_diag_panel && !dep_off_ && d_sw_flag.p && ha_count_[phase] > 0) d_sw_flag.zero(st);   // per-front flags of big_level_kernel (phases with scratch-slab levels only)
+  if ((parts & 2) && opt.hoist_big_assembly && (hz_count_[phase] > 0 || ha_count_[phase] > 0)) {
     const bool virt = dA == nullptr;
     if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
     if (hz_count_[phase] > 0)
@@ -4085,17 +4103,18 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
       for (int l = G.first_level; l <= G.last_level; ++l) {
         LevelLaunch one = launches_[phase][l];
         if (l == G.first_level && band_usable(G, dA)) {   // (the same kernels as the grouped launch: results stay bit-identical)
-          launch_band(G, dA, fwd, st, false);
+          if (parts & 1) launch_band(G, dA, fwd, st, false);
           one.lds_begin += G.band_count;
           one.lds_count -= G.band_count;
           if (one.lds_count <= 0) continue;
         }
-        launch_factor(one, dA, fwd, st, false);
+        if (parts & 2) launch_factor(one, dA, fwd, st, false);
       }
       continue;
     }
     const LevelLaunch& LL = G.LL;
     const bool fused = fwd && LL.fuse_fwd;
+    if (!(parts & 2) && !band_usable(G, dA)) continue;   // (a band-only call: nothing else of this group)
     const bool big_passes = LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim;
     if (opt.overlap_level_halves && st != nullptr && big_passes && LL.glb_count > 0 && LL.lds_count > 0 && !G.dep && (fused || !fwd)) {
       // (levels with large fronts only stay on one stream: a forward step moved to a side stream was measured to cost more
@@ -4133,7 +4152,8 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     }
     if (band_usable(G, dA)) {
       // the band chains of level 0 first, in a launch of their own (they bump their parents' counters like the others)
-      launch_band(G, dA, fused, st, G.dep);
+      if (parts & 1) launch_band(G, dA, fused, st, G.dep);
+      if (!(parts & 2)) continue;
       LevelLaunch rest = LL;
       rest.lds_begin += G.band_count;
       rest.lds_count -= G.band_count;

@@ -21,6 +21,7 @@ SLOTS = [("assemble_vertex(pose)", ("ba_assemble_poses", "assemble_vertex_kernel
          ("landmark_inverse", ("landmark_inverse",)),
          ("schur_tiles", ("schur_tile_kernel",)),
          ("schur_reduce", ("schur_reduce_kernel", "schur_rhs_kernel")),
+         ("chol_factor(band chains)", ("band_wave_kernel",)),
          ("chol_factor(all levels)", ("front_factor_kernel", "wave_front_kernel")),
          ("chol_solve(all levels)", ("front_forward_kernel", "front_backward_kernel", "permute_in_kernel", "permute_out_kernel")),
          ("back_substitute", ("back_substitute",)),
