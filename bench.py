@@ -256,7 +256,7 @@ def main():
     # warm-up with every kernel slot timed: finds the dominant slot; the timed region then carries HIP events
     # around that slot only (event records are not free: ~20 per iteration cost ~0.1 ms of a 2.6 ms iteration)
     ok = True
-    n_find = max(args.warmup - 2, 1)                       # warm-up steps with every slot timed (they find the dominant kernel) ...
+    n_find = max(args.warmup - 1, 2)                       # warm-up steps with every slot timed: the LAST one finds the dominant kernel ...
     for i in range(n_find):
         if i == n_find - 1:
             solver.local.kernelTimes(reset=True)           # (the first steps carry one-time costs: code loading, graph capture)

@@ -493,14 +493,16 @@ __device__ __forceinline__ void schur_tile_dests(const double* Bs, const double*
       // this lane's rows of W * B_s2'
       double B2[PL];
       lds_block<PL>(Bs + s2 * PL, B2);
+      // (accumulated term by term: three fused multiply-adds per element and entry, no separate add -- the kernel is bound by
+      // instruction issue)
 #pragma unroll
       for (int c = 0; c < PD; ++c)
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
-          double v = 0.0;
+          double v = acc[rr + NR * c];
 #pragma unroll
-          for (int kk = 0; kk < LD; ++kk) v += W[rr + NR * kk] * B2[c + PD * kk];
-          acc[rr + NR * c] += v;
+          for (int kk = 0; kk < LD; ++kk) v = fma(W[rr + NR * kk], B2[c + PD * kk], v);
+          acc[rr + NR * c] = v;
         }
     }
     if (GE > 1) {   // lanes with the same gc are GC apart

@@ -354,7 +354,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   // leaf size: large systems get about as many leaves as the band kernel has chain slots (256 CUs x 8 one-wave chains, one
   // round instead of two and one tree level less: 0.53 -> 0.48 ms at the metric configuration), within what a chain may hold
   int nd_leaf = opt.nd_leaf;
-  if (opt.band_kernel && bs == 6) nd_leaf = std::min(std::max(nd_leaf, (nb + 2047) / 2048), 128);
+  if (opt.band_kernel && bs == 6) nd_leaf = std::min(std::max(nd_leaf, (nb / std::max(opt.world, 1) + 2047) / 2048), 128);   // (per rank: its share of the chains)
   nested_dissection(nb, xadj, adj, nd_leaf, perm0);
   // --- etree + postorder, compose
   std::vector<int> iperm(nb), cp, ci, rp, ri, parent, post;

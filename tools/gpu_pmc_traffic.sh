@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic per kernel slot (two PMC passes) -> gpurun_out/refresh/<prefix>_pmc_traffic.json
-P=${1:-r2}; R=$PWD; OUT=$R/gpurun_out/refresh; mkdir -p $OUT
+P=${1:-r3}; R=$PWD; OUT=$R/gpurun_out/refresh; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/pf /tmp/pw
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o f -- python $R/bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1 > $OUT/pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o w -- python $R/bench.py --no-cpu-baseline --graph off --steps 2 --warmup 1 > $OUT/pmc_w.log 2>&1

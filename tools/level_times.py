@@ -7,7 +7,7 @@ kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 rows = list(db.execute("select s.display_name, d.start, d.end, d.grid_size_x, d.workgroup_size_x, d.group_segment_size from %s d join %s s on d.kernel_id=s.id order by d.start" % (kd, ks)))
 nlev = int(sys.argv[2])
-for key in ("wave_front", "front_factor", "front_forward", "front_backward"):
+for key in ("band_wave", "wave_front", "front_factor", "front_forward", "front_backward"):
     sel = [r for r in rows if key in r[0]][-nlev:]
     if not sel:
         continue
