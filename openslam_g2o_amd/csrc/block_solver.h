@@ -250,7 +250,7 @@ class BlockSolver {
   DevBuf<int2> d_tile_q2;         // per tile: second Hpl block range (first block, count) -- tiles of a split landmark
   int n_split_tiles_ = 0;
   std::vector<int> tile_lm0_h_;   // first landmark of every tile (+ one past the last)
-  DevBuf<unsigned short> d_te_lm;
+  DevBuf<unsigned short> d_te_lm, d_slot_lm;
   DevBuf<double> d_Pd, d_Pr;               // per (tile, destination) partial blocks / rhs
   int n_tiles_ = 0;
   long n_td_ = 0;

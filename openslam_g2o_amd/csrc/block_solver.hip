@@ -406,39 +406,143 @@ __global__ void __launch_bounds__(kThreads) landmark_inverse_kernel(int nL, cons
 // loads (Hpl is read once per iteration instead of once per pose pair), together with Dinv, b_l and the
 // tile's contributor entries.  Each destination block touched by the tile is owned by G lanes that walk
 // its entry list out of LDS (no atomics, fixed order) and write one partial block to HBM.
-// Shared by the two tile kernels: (optional) landmark inversion on the staged blocks, then the destination loop.
-// (optional) landmark inversion on the staged blocks; ends with the Dinv write (after a barrier)
+// Shared by the two tile kernels: (optional) landmark inversion on the staged blocks, the symmetric split of Dinv, then the
+// destination loop.
+//
+// Symmetric split.  Every entry of a destination is (B_s1 Dinv) B_s2' with the two Hpl blocks of ONE landmark, so with
+// Dinv = C Sg C' (C lower triangular, Sg = diag(+-1): the L D L' factors of the 3x3 block, |D|^(1/2) folded into C) and
+//   V_s = B_s C        (each staged block is transformed ONCE, in place)
+// an entry is V_s1 Sg V_s2' and the right-hand side term is V_s (Sg C' b_l).  The destination loop then needs no product with
+// Dinv per entry: PD*LD fewer multiply-adds per lane and entry (a third of them) and LD*LD fewer LDS reads, at no extra LDS
+// for the blocks.  Sg is the identity unless the damped landmark block is not positive definite (negative lambda,
+// block_solver.hpp:563-604 allows it): a per-tile flag makes the loop apply the signs then.
 template <int LD>
-__device__ __forceinline__ void schur_tile_invert(double* Ds, int l0, int nlm, double* __restrict__ Dinv, const double* __restrict__ Hll,
-                                                  const double* __restrict__ lam, int tid, int NT) {
-  if (Hll) {
-    const double lambda = lam[1];
-    for (int j = tid; j < nlm; j += NT) {
-      double D[LD * LD], R[LD * LD];
+struct TileSplit {
+  static constexpr int CP = (LD * LD + LD + 1) & ~1;   // doubles per landmark: C (column major, lower part used) | signs
+};
+// R (symmetric, its lower triangle is read) = Lm diag(d) Lm' -> C = Lm |d|^(1/2) (column major, zeros above the diagonal),
+// sg = sign(d), u = Sg C' b
+template <int LD>
+__device__ __forceinline__ bool landmark_split(const double* R, const double* b, double* C, double* sg, double* u) {
+  double Lm[LD * LD], d[LD];
 #pragma unroll
-      for (int i = 0; i < LD * LD; ++i) D[i] = Ds[j * (LD * LD) + i];
+  for (int c = 0; c < LD; ++c) {
+    double dc = R[c + LD * c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) dc -= Lm[c + LD * k] * Lm[c + LD * k] * d[k];
+    d[c] = dc;
+    const double idc = 1.0 / dc;
+#pragma unroll
+    for (int r = c + 1; r < LD; ++r) {
+      double v = R[r + LD * c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) v -= Lm[r + LD * k] * Lm[c + LD * k] * d[k];
+      Lm[r + LD * c] = v * idc;
+    }
+    Lm[c + LD * c] = 1.0;
+  }
+  bool neg = false;
+#pragma unroll
+  for (int c = 0; c < LD; ++c) {
+    const double sq = sqrt(fabs(d[c]));
+    sg[c] = d[c] < 0.0 ? -1.0 : 1.0;
+    neg = neg || d[c] < 0.0;
+    double uu = 0.0;
+#pragma unroll
+    for (int r = 0; r < LD; ++r) {
+      const double cv = r >= c ? Lm[r + LD * c] * sq : 0.0;
+      C[r + LD * c] = cv;
+      if (r >= c) uu += cv * b[r];
+    }
+    u[c] = sg[c] * uu;
+  }
+  return neg;
+}
+// V = B C in place (C lower triangular)
+template <int PD, int LD>
+__device__ __forceinline__ void block_times_split(double* Bslot, const double* C) {
+  double B[PD * LD];
+  lds_block<PD * LD>(Bslot, B);
+#pragma unroll
+  for (int c = 0; c < LD; ++c)
+#pragma unroll
+    for (int r = 0; r < PD; ++r) {
+      double v = B[r + PD * c] * C[c + LD * c];
+#pragma unroll
+      for (int k = c + 1; k < LD; ++k) v = fma(B[r + PD * k], C[k + LD * c], v);
+      Bslot[r + PD * c] = v;
+    }
+}
+__device__ __forceinline__ bool tile_flag(const int* f) {
+  int v = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; ++w) v |= f[w];
+  return v != 0;
+}
+template <int PD, int LD>
+__device__ __forceinline__ void schur_tile_prepare(double* Bs, double* Ds, double* bsm, double* Cs, int* neg_flag, int l0, int nlm, int ntot,
+                                                   int slot_lm_first, const unsigned short* __restrict__ slot_lm, int q0, int nslots,
+                                                   double* __restrict__ Dinv, const double* __restrict__ Hll,
+                                                   const double* __restrict__ lam, int tid, int NT) {
+  constexpr int CP = TileSplit<LD>::CP;
+  const double lambda = Hll ? lam[1] : 0.0;
+  for (int j = tid; j < nlm; j += NT) {
+    double D[LD * LD], R[LD * LD];
+#pragma unroll
+    for (int i = 0; i < LD * LD; ++i) D[i] = Ds[j * (LD * LD) + i];
+    if (Hll) {
 #pragma unroll
       for (int i = 0; i < LD; ++i) D[i * (LD + 1)] += lambda;
       small_inverse<LD>(D, R);
 #pragma unroll
       for (int i = 0; i < LD * LD; ++i) Ds[j * (LD * LD) + i] = R[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < LD * LD; ++i) R[i] = D[i];
     }
-    __syncthreads();
+    double C[LD * LD], sg[LD], u[LD], b[LD];
+#pragma unroll
+    for (int c = 0; c < LD; ++c) b[c] = bsm[j * LD + c];
+    const bool neg = landmark_split<LD>(R, b, C, sg, u);
+#pragma unroll
+    for (int i = 0; i < LD * LD; ++i) Cs[j * CP + i] = C[i];
+#pragma unroll
+    for (int c = 0; c < LD; ++c) {
+      Cs[j * CP + LD * LD + c] = sg[c];
+      bsm[j * LD + c] = u[c];
+    }
+    if (neg) *neg_flag = 1;
+  }
+  __syncthreads();
+  if (Hll) {
     double* dstD = Dinv + (size_t)l0 * LD * LD;
     for (int i = tid; i < nlm * LD * LD; i += NT) dstD[i] = Ds[i];
   }
+  // V_s = B_s C, one lane per staged block
+  for (int sb = 0; sb < ntot; sb += NT) {
+    const int s_ = sb + tid;
+    if (s_ < ntot) {
+      int lm = 0;
+      if (nlm > 1) lm = sb == 0 ? slot_lm_first : (int)slot_lm[q0 + s_];   // (a tile with a second block range holds one landmark)
+      double C[LD * LD];
+#pragma unroll
+      for (int i = 0; i < LD * LD; ++i) C[i] = Cs[lm * CP + i];
+      block_times_split<PD, LD>(Bs + s_ * (PD * LD), C);
+    }
+  }
+  __syncthreads();
+  (void)nslots;
 }
 
 // the destination loop (no barrier inside)
 template <int PD, int LD, int G, class EL>
-__device__ __forceinline__ void schur_tile_dests(const double* Bs, const double* Ds, const double* bsm, const int* ep, const int* dptr,
-                                                 const int* ddiag, const EL* el, int td0, int td1, int e0, double* __restrict__ Pd,
-                                                 double* __restrict__ Pr, int tid, int NT) {
+__device__ __forceinline__ void schur_tile_dests(const double* Bs, const double* Cs, const double* bsm, bool neg, const int* ep,
+                                                 const int* dptr, const int* ddiag, const EL* el, int td0, int td1, int e0,
+                                                 double* __restrict__ Pd, double* __restrict__ Pr, int tid, int NT) {
   constexpr int PL = PD * LD;
   // G lanes per destination block = GC row parts x GE entry parts: a lane owns NR = PD/GC ROWS of the block
   // (PD*PD/GC accumulator registers: what keeps 3 workgroups on a CU) and walks every GE-th entry.  With the row
-  // split a lane only needs its own rows of W = B_s1 Dinv (NR*LD*LD FMAs instead of PD*LD*LD): the kernel is
-  // bound by VALU issue, and this takes a quarter of its FMAs away.  The GE partial sums are combined with DPP
+  // split a lane only needs its own rows of V_s1: the kernel is bound by VALU issue.  The GE partial sums are combined with DPP
   // (fixed order: deterministic).  Partial block layout in Pd: [row part][column][row inside the part].
   constexpr int GC = (PD % 2 == 0 && G >= 2) ? 2 : 1, GE = G / GC, NR = PD / GC;
   static_assert(GE == 1 || GE == 2 || GE == 4 || GE == 8 || (GC == 1 && GE == 16), "unsupported lane group");
@@ -462,32 +566,29 @@ __device__ __forceinline__ void schur_tile_dests(const double* Bs, const double*
     for (int k = k0 + ge; k < k1; k += GE) {
       const int pk = ep[k], lm = el[k];
       const int s1 = pk & 0xffff, s2 = (pk >> 16) & 0xffff;
-      double W[NR * LD];   // W[rr + NR * c] = (B_s1 Dinv)(gc*NR + rr, c)
+      double W[NR * LD];   // W[rr + NR * c] = V_s1(gc*NR + rr, c)   (V = B C: schur_tile_prepare)
       {
-        double B1[NR * LD], Di[LD * LD];
-#pragma unroll
-        for (int i = 0; i < LD * LD; ++i) Di[i] = Ds[lm * (LD * LD) + i];
         const double* B1p = Bs + s1 * PL + gc * NR;
 #pragma unroll
         for (int kk = 0; kk < LD; ++kk)
 #pragma unroll
-          for (int rr = 0; rr < NR; ++rr) B1[rr + NR * kk] = B1p[rr + PD * kk];
-#pragma unroll
-        for (int c = 0; c < LD; ++c)
-#pragma unroll
-          for (int rr = 0; rr < NR; ++rr) {
-            double v = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < LD; ++kk) v += B1[rr + NR * kk] * Di[kk + LD * c];
-            W[rr + NR * c] = v;
-          }
+          for (int rr = 0; rr < NR; ++rr) W[rr + NR * kk] = B1p[rr + PD * kk];
       }
-      if (diag) {   // s1 == s2: rhs contribution B (Dinv b_l) = W b_l, this lane's rows
+      if (diag) {   // s1 == s2: rhs contribution B (Dinv b_l) = V (Sg C' b_l), this lane's rows
 #pragma unroll
         for (int c = 0; c < LD; ++c) {
           const double bv = bsm[lm * LD + c];
 #pragma unroll
           for (int rr = 0; rr < NR; ++rr) cacc[rr] += W[rr + NR * c] * bv;
+        }
+      }
+      if (neg) {   // (tile with a landmark block that is not positive definite: V_s1 Sg)
+        constexpr int CP = TileSplit<LD>::CP;
+#pragma unroll
+        for (int c = 0; c < LD; ++c) {
+          const double sv = Cs[lm * CP + LD * LD + c];
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) W[rr + NR * c] *= sv;
         }
       }
       // this lane's rows of W * B_s2'
@@ -546,7 +647,8 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
                                                             const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm,
                                                             double* __restrict__ Pd,
                                                             double* __restrict__ Pr, const double* __restrict__ Hll,
-                                                            const double* __restrict__ lam, const int2* __restrict__ tile_q2) {
+                                                            const double* __restrict__ lam, const int2* __restrict__ tile_q2,
+                                                            const unsigned short* __restrict__ slot_lm) {
   // Hll != nullptr: the landmark inversion (block_solver.hpp:386-389, with the virtual damping) is done here on
   // the staged blocks -- the tile reads Hll instead of Dinv and writes Dinv (back-substitution needs it) on the way.
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -559,11 +661,15 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
   double* Bs = smem;
   double* Ds = Bs + (((nslots + t2.y) * PL + 1) & ~1);
   double* bsm = Ds + ((nlm * LD * LD + 1) & ~1);
-  int* ep = reinterpret_cast<int*>(bsm + ((nlm * LD + 1) & ~1));
+  double* Cs = bsm + ((nlm * LD + 1) & ~1);           // symmetric split of Dinv (schur_tile_prepare)
+  int* ep = reinterpret_cast<int*>(Cs + nlm * TileSplit<LD>::CP);
   int* dptr = ep + ne;                                // td_ptr[td0 .. td1]
   int* ddiag = dptr + (td1 - td0 + 1);                // destination is a diagonal block?
-  unsigned short* el = reinterpret_cast<unsigned short*>(ddiag + (td1 - td0));
+  int* neg_flag = ddiag + (td1 - td0);
+  unsigned short* el = reinterpret_cast<unsigned short*>(neg_flag + kThreads / 64);
   const int tid = threadIdx.x, NT = blockDim.x;
+  if ((tid & 63) == 0) neg_flag[tid >> 6] = 0;   // one flag per wave: cleared and set in the wave's own program order
+  const int slot_lm_first = slot_lm[q0 + min(tid, nslots - 1)];
   {
     // All global loads of the tile are issued before the first LDS store (one HBM round trip in total);
     // anything beyond the unrolled part (only with an enlarged tile budget) goes through stage_copy.
@@ -628,8 +734,8 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) schur_tile_kernel(
     if (ndp - 1 > NT) stage_copy<2>(ddiag + NT, td_diag + td0 + NT, ndp - 1 - NT, tid, NT);
   }
   __syncthreads();
-  schur_tile_invert<LD>(Ds, l0, nlm, Dinv, Hll, lam, tid, NT);
-  schur_tile_dests<PD, LD, G>(Bs, Ds, bsm, ep, dptr, ddiag, el, td0, td1, e0, Pd, Pr, tid, NT);
+  schur_tile_prepare<PD, LD>(Bs, Ds, bsm, Cs, neg_flag, l0, nlm, nslots + t2.y, slot_lm_first, slot_lm, q0, nslots, Dinv, Hll, lam, tid, NT);
+  schur_tile_dests<PD, LD, G>(Bs, Cs, bsm, tile_flag(neg_flag), ep, dptr, ddiag, el, td0, td1, e0, Pd, Pr, tid, NT);
 }
 
 // K5+K7+K8, pass 2: Hschur(d) = Hpp(d) - sum_tiles partial(d) (fixed tile order), bschur = b_p - sum partial_rhs
@@ -1102,7 +1208,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
     const int* __restrict__ td_ptr, const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm, double* __restrict__ Pd,
     double* __restrict__ Pr, double* Hll, const double* __restrict__ lam, const int4* __restrict__ ll_rec,
     const int4* __restrict__ tile_ll, const int* __restrict__ ll_edge, double* __restrict__ err, const int2* __restrict__ tile_q2,
-    int store_hll) {
+    int store_hll, const unsigned short* __restrict__ slot_lm) {
   // (FLL: meas_q / omega_q are the slot-major copies ll_meas / ll_omega; cam_q / pt_q are unused; store_hll = 0: Hll stays in
   // the LDS stage -- the solve path reads Dinv and b_l only --, err = nullptr: the errors are not written either)
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1116,11 +1222,15 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
   double* Bs = smem;
   double* Ds = Bs + ((ntot * PL + 1) & ~1);
   double* bsm = Ds + ((nlm * LD * LD + 1) & ~1);
-  int* ep = reinterpret_cast<int*>(bsm + ((nlm * LD + 1) & ~1));
+  double* Cs = bsm + ((nlm * LD + 1) & ~1);
+  int* ep = reinterpret_cast<int*>(Cs + nlm * TileSplit<LD>::CP);
   int* dptr = ep + ne;
   int* ddiag = dptr + (td1 - td0 + 1);
-  unsigned short* el = reinterpret_cast<unsigned short*>(ddiag + (td1 - td0));
+  int* neg_flag = ddiag + (td1 - td0);
+  unsigned short* el = reinterpret_cast<unsigned short*>(neg_flag + kThreads / 64);
   const int tid = threadIdx.x, NT = blockDim.x;
+  if ((tid & 63) == 0) neg_flag[tid >> 6] = 0;   // one flag per wave: cleared and set in the wave's own program order
+  const int slot_lm_first = FLL ? 0 : (int)slot_lm[q0 + min(tid, nslots - 1)];
   {
     const double* srcD = Hll + (size_t)l0 * LD * LD;
     const double* srcb = bl + (size_t)l0 * LD;
@@ -1179,7 +1289,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
           } else {
             load_vec<4>(omega_q + sg * 4, Op);
           }
-          if (has) {
+          if (has && !(store_hll & 8)) {
             BaEdgeLin L;
             ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, true, L);
             if (err) store_vec<2>(err + (size_t)e * 2, L.r);
@@ -1200,29 +1310,48 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
           }
         }
         // suffix sums inside a list by doubling: after the step with distance d a lane holds the sum of up to 2 d list
-        // entries from its own on (fixed tree: deterministic)
-        for (int d = 1; d < tl.w; d <<= 1) {
+        // entries from its own on (fixed tree: deterministic); as many steps as the longest list of this WAVE needs
+        for (int d = 1; __any(pos + d < K); d <<= 1) {
           const bool take = pos + d < K;
+          double o[12];   // (all twelve exchanges in flight at once, then branch-free adds)
 #pragma unroll
-          for (int i = 0; i < 12; ++i) {
-            const double o = __shfl_down(v[i], d);
-            if (take) v[i] += o;
-          }
+          for (int i = 0; i < 12; ++i) o[i] = __shfl_down(v[i], d);
+#pragma unroll
+          for (int i = 0; i < 12; ++i) v[i] += take ? o[i] : 0.0;
         }
+        // The list head inverts the damped block (block_solver.hpp:386-389) and splits the inverse (schur_tile_prepare's
+        // comment); the lanes of the list fetch C from it and turn their staged block into V = B C on the spot: no pass over
+        // the blocks and no barrier for it.
+        double C[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) C[i] = 0.0;
         if (head) {
           const int lm = l0 + lmi;
-          double* hd = Hll + (size_t)lm * 9;
           double* bd = bl + (size_t)lm * 3;
+          if (store_hll & 1) {
+            double* hd = Hll + (size_t)lm * 9;
 #pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            Ds[lmi * 9 + i] = v[i];
-            if (store_hll) hd[i] = v[i];
+            for (int i = 0; i < 9; ++i) hd[i] = v[i];
           }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) bd[i] = v[9 + i];
+          double R[9], sg[3], u[3];
+          const double lambda = lam[1];
+          v[0] += lambda; v[4] += lambda; v[8] += lambda;
+          small_inverse<3>(v, R);
+          store_vec<9>(Dinv + (size_t)lm * 9, R);
+          if (landmark_split<3>(R, v + 9, C, sg, u)) neg_flag[tid >> 6] = 1;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            bsm[lmi * 3 + i] = v[9 + i];
-            bd[i] = v[9 + i];
+            Cs[lmi * TileSplit<3>::CP + 9 + i] = sg[i];
+            bsm[lmi * 3 + i] = u[i];
           }
+        }
+        {
+          const int src = (int)(threadIdx.x & 63) - pos;
+          C[0] = __shfl(C[0], src); C[1] = __shfl(C[1], src); C[2] = __shfl(C[2], src);
+          C[4] = __shfl(C[4], src); C[5] = __shfl(C[5], src); C[8] = __shfl(C[8], src);
+          if (has && rc.w >= 0) block_times_split<6, 3>(Bs + (rc.w - q0) * 18, C);
         }
       }
     } else {
@@ -1285,8 +1414,8 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
     if (ndp - 1 > NT) stage_copy<2>(ddiag + NT, td_diag + td0 + NT, ndp - 1 - NT, tid, NT);
   }
   __syncthreads();
-  schur_tile_invert<LD>(Ds, l0, nlm, Dinv, Hll, lam, tid, NT);
-  schur_tile_dests<PD, LD, G>(Bs, Ds, bsm, ep, dptr, ddiag, el, td0, td1, e0, Pd, Pr, tid, NT);
+  if (!FLL) schur_tile_prepare<PD, LD>(Bs, Ds, bsm, Cs, neg_flag, l0, nlm, ntot, slot_lm_first, slot_lm, q0, nslots, Dinv, Hll, lam, tid, NT);
+  if (!(store_hll & 2)) schur_tile_dests<PD, LD, G>(Bs, Cs, bsm, tile_flag(neg_flag), ep, dptr, ddiag, el, td0, td1, e0, Pd, Pr, tid, NT);
 }
 
 // K13 for the fused EdgeProjectXYZ2UV path: x_l = Dinv (b_l - Hpl' x_p) WITHOUT reading Hpl (block_solver.hpp:459-483).
@@ -2183,8 +2312,10 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     hs_src_h_ = hs_src;
     // ---- landmark-range tiles for the Schur outer products (schur_tile_kernel)
     {
-      const size_t PL = (size_t)p * l, DP = ((size_t)l * l + 1) & ~(size_t)1, BP = ((size_t)l + 1) & ~(size_t)1;
+      // (DP: Dinv and its symmetric split C | signs, schur_tile_prepare)
+      const size_t PL = (size_t)p * l, DP = (((size_t)l * l + 1) & ~(size_t)1) + (((size_t)l * l + l + 1) & ~(size_t)1), BP = ((size_t)l + 1) & ~(size_t)1;
       std::vector<int> tile_lm0, tile_td0, td_dest, td_ptr, te_pack;
+      std::vector<unsigned short> slot_lm(pl_row.size() + 1, 0);   // landmark of an Hpl block, relative to its tile (0 for a split landmark)
       std::vector<unsigned short> te_lm;
       std::vector<int> rd_cnt(hs_nnzb, 0);
       std::vector<int> hs_row_is_diag(hs_nnzb, 0);
@@ -2293,6 +2424,8 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
               e.lml = (unsigned short)(c - l0);
               ents.push_back(e);
             }
+        for (int c = l0; c < lm; ++c)
+          for (int q = pl_colptr[c]; q < pl_colptr[c + 1]; ++q) slot_lm[q] = (unsigned short)(c - l0);
         emit_tile(l0, lm, q0, pl_colptr[lm] - q0, 0, 0);
         tile_lm0.push_back(lm);
       }
@@ -2339,6 +2472,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       d_td_ptr.upload(td_ptr, st_);
       d_te_pack.upload(te_pack, st_);
       d_te_lm.upload(te_lm, st_);
+      d_slot_lm.upload(slot_lm, st_);
       d_rd_ptr.upload(rd_ptr, st_);
       d_rd_slot.upload(rd_slot, st_);
       rd_ptr_h_ = rd_ptr;
@@ -2908,6 +3042,7 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
     // too: 150 MB less to write at the metric configuration; a later reader (maxDiagonal, multiplyHessian, chi2 without a
     // linearisation, inspection) has them recomputed by ensure_ll()
     const bool store_ll = ba_store_ll != 0;
+    static const int schur_abl = getenv("G2OHIP_SCHUR_ABL") ? atoi(getenv("G2OHIP_SCHUR_ABL")) & ~1 : 0;   // (timing experiments only)
 #define G2OHIP_BA_TILE(GG)                                                                                                         \
   do {                                                                                                                             \
     if (fll)                                                                                                                       \
@@ -2917,13 +3052,13 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
                          es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, ba_.ll_rec.p, ba_.tile_ll.p, ba_.ll_edge.p,       \
                          (ba_.err_valid || !store_ll) ? (double*)nullptr : es.own_err.p, /* (errors of these estimates already there) */ \
-                         d_tile_q2.p, store_ll ? 1 : 0);                                                                           \
+                         d_tile_q2.p, (store_ll ? 1 : 0) | schur_abl, d_slot_lm.p);                                                                        \
     else                                                                                                                           \
       hipLaunchKernelGGL((ba_schur_tile_kernel<GG, false>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,       \
                          ba_.cams.p, ba_.pts.p, ba_.cam_q.p, ba_.pt_q.p, ba_.meas_q.p, ba_.omega_q.p, ba_.f, ba_.cx, ba_.cy,           \
                          es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, (const int4*)nullptr, (const int4*)nullptr,        \
-                         (const int*)nullptr, (double*)nullptr, d_tile_q2.p, 1);                                                   \
+                         (const int*)nullptr, (double*)nullptr, d_tile_q2.p, 1, d_slot_lm.p);                                              \
   } while (0)
     if (G <= 1) G2OHIP_BA_TILE(1);
     else if (G <= 2) G2OHIP_BA_TILE(2);
@@ -2936,7 +3071,7 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
     prof.end(KernelProf::kSchurBlocks, st_);
   } else
 #define G2OHIP_TILE_ARGS d_tile_lm0.p, d_tile_td0.p, d_pl_colptr.p, d_Hpl.p, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p, d_te_pack.p, \
-                         d_te_lm.p, d_Pd.p, d_Pr.p, fuse_inv ? d_Hll.p : (const double*)nullptr, d_lam.p, d_tile_q2.p
+                         d_te_lm.p, d_Pd.p, d_Pr.p, fuse_inv ? d_Hll.p : (const double*)nullptr, d_lam.p, d_tile_q2.p, d_slot_lm.p
 #define G2OHIP_SCHUR(P_, L_)                                                                                                   \
   if (p_ == P_ && l_ == L_) {                                                                                                  \
     if (!fuse_inv) {                                                                                                           \
