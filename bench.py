@@ -224,6 +224,10 @@ def main():
     # falls back to the torch.distributed formulation of the same exchange if the library communicator cannot be
     # brought up (the reason goes to stderr and into the JSON line)
     lib_comm = "n/a"
+    if emulate and solver.mode == "subtree" and solver._native_exchange():
+        # the library's own sharded solve (g2ohip_solve_sharded: every phase queued by one call) with the all-reduces skipped
+        solver.local.setOption("comm_emulate", 1)
+        solver._lib_comm = lib_comm = "none (emulation: all-reduces skipped)"
     if (world > 1 or emulate) and solver.mode == "subtree" and not emulate:
         try:
             lib_comm = "rccl" if args.comm == "rccl" else "host"

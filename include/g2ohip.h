@@ -29,6 +29,8 @@ extern "C" {
 
 #define G2OHIP_OK 0
 #define G2OHIP_NOT_PD 1            /* Cholesky hit a pivot <= 0: solve() == false (csparse_helper.cpp:136) */
+#define G2OHIP_REPEAT 2            /* phased sharded solve only (g2ohip_exchange_status): a rank's dependency-driven launch gave
+                                      up waiting; run the phases of this solve again on EVERY rank (g2ohip_solve_sharded does) */
 #define G2OHIP_ERR_ARG (-1)
 #define G2OHIP_ERR_HIP (-2)
 #define G2OHIP_ERR_STATE (-3)
@@ -274,7 +276,8 @@ int g2ohip_solve_reduced_finish(g2ohip_solver* s);
  *   g2ohip_solve_schur, g2ohip_exchange_pack(1), [all-reduce g2ohip_device_array 105], g2ohip_exchange_unpack(1),
  *   g2ohip_solve_reduced_local, [all-reduce 103], g2ohip_solve_reduced_shared, g2ohip_solve_reduced_finish_async,
  *   g2ohip_exchange_pack(3), [all-reduce 106: halo x_p + failure flags], g2ohip_exchange_unpack(3),
- *   g2ohip_solve_back_substitute, g2ohip_exchange_status  (the only synchronisation; G2OHIP_NOT_PD if any rank failed). */
+ *   g2ohip_solve_back_substitute, g2ohip_exchange_status  (the only synchronisation; G2OHIP_NOT_PD if any rank failed,
+ *   G2OHIP_REPEAT -- on every rank alike -- if the phases are to be run again: see the define). */
 int g2ohip_exchange_setup(g2ohip_solver* s, int n_blocks, const int32_t* block_idx, const double* block_keep, int n_poses,
                           const int32_t* pose_idx, const double* pose_keep, int n_halo, const int32_t* halo_idx, const double* halo_mine);
 int g2ohip_exchange_pack(g2ohip_solver* s, int which);

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("G2OHIP_LIB") or os.path.join(_HERE, "lib", "libg2ohip
 c_int_p = C.POINTER(C.c_int32)
 c_dbl_p = C.POINTER(C.c_double)
 
-OK, NOT_PD = 0, 1
+OK, NOT_PD, REPEAT = 0, 1, 2
 HPP, HPL, HLL, HSCHUR, DINV = 0, 1, 2, 3, 4
 ARR_BSCHUR, ARR_X, ARR_B, ARR_EXCHANGE, ARR_XP, ARR_XBOUNDARY, ARR_XHALO, ARR_SCHUR_DIAG = 100, 101, 102, 103, 104, 105, 106, 107
 KERNEL_NONE, KERNEL_HUBER, KERNEL_PSEUDOHUBER, KERNEL_CAUCHY, KERNEL_SATURATED, KERNEL_DCS = 0, 1, 2, 3, 4, 5
@@ -395,7 +395,10 @@ class HipBlockSolver:
         _check(self.L.g2ohip_exchange_unpack(self.h, which), "exchangeUnpack")
 
     def exchangeStatus(self):
-        return _check(self.L.g2ohip_exchange_status(self.h), "exchangeStatus") == OK
+        """True: solved; False: not positive definite on some rank; REPEAT (2): run the phases of this solve again on every
+        rank (a dependency-driven launch gave up waiting somewhere; include/g2ohip.h G2OHIP_REPEAT)."""
+        rc = _check(self.L.g2ohip_exchange_status(self.h), "exchangeStatus")
+        return REPEAT if rc == REPEAT else rc == OK
 
     def solveBackSubstitute(self):
         _check(self.L.g2ohip_solve_back_substitute(self.h), "solveBackSubstitute")

@@ -126,6 +126,8 @@ class BlockSolver {
   SolverTimes times;
   CholOptions chol_opt;
   size_t schur_tile_bytes = 39 * 1024;     // LDS budget of one Schur tile
+  int comm_emulate = 0;                    // TIMING ONLY: solve_sharded of one rank of an N-rank job run alone, the all-reduces skipped
+                                           // (results are wrong; bench.py --emulate r/N: the per-rank time an N-GPU run is bounded by)
   bool ba_fused = true;                    // evaluate BA errors/Jacobians inside the assembly kernels (no J arrays)
   // hipGraph replay of the launch-bound kernel sequences (one launch per tree level: factorisation with the
   // fused forward sweep, backward sweep): ~30 launches per iteration, which is what limits a rank once the
@@ -200,7 +202,8 @@ class BlockSolver {
   Comm comm;
   void comm_init_rccl(int rank, int world, const char* id128);
   void comm_all_reduce(double* dev, size_t n, int op);
-  int solve_sharded();                       // Schur pass, three all-reduces, subtree-distributed factorisation, back-substitution
+  int solve_sharded();
+  int solve_sharded_once();                       // Schur pass, three all-reduces, subtree-distributed factorisation, back-substitution
   double chi2_sharded();                     // activeRobustChi2 over all ranks
   double max_diagonal_sharded();             // computeLambdaInit's maximum over the SUMMED pose diagonal and all landmarks
   double compute_scale_sharded(double lambda);

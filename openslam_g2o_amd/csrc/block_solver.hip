@@ -3356,7 +3356,9 @@ __global__ void exchange_halo_kernel(int nh, int p, const int* __restrict__ halo
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > nh * p) return;
   if (t == nh * p) {
-    if (!unpack) buf[t] = (*status != 0) ? 1.0 : 0.0;
+    // (summed over the ranks: not positive definite counts 1, a dependency-driven launch that gave up waiting 1024 --
+    // the solve is to be REPEATED then, not reported failed)
+    if (!unpack) buf[t] = *status == 2 ? 1024.0 : (*status != 0 ? 1.0 : 0.0);
     return;
   }
   double* target = x + (size_t)halo[t / p] * p + t % p;
@@ -3440,7 +3442,9 @@ int BlockSolver::exchange_status() {
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   if (flag != 0.0) {   // some rank failed; the local cleanup (dependency counters, stall fallback) runs where it applies
     if (chol_->failed(st_) && chol_->dependency_stall() && ++dependency_fallbacks) invalidate_graphs();
-    return 1;
+    // a stall anywhere (safety net of the dependency-driven launches): every rank sees the same sum and repeats the solve;
+    // the rank that stalled runs one launch per level from now on.  Distinct from "not positive definite".
+    return flag >= 1024.0 ? 2 : 1;
   }
   return 0;
 }
@@ -3495,10 +3499,11 @@ void BlockSolver::comm_all_reduce(double* dev, size_t n, int op) {
   comm.all_reduce(dev, n, op, st_);
 }
 
-int BlockSolver::solve_sharded() {
+int BlockSolver::solve_sharded_once() {
   require_structure();
   if (!schur_) throw StateFailure("solve_sharded: the sharded path needs the Schur complement");
-  if (comm.kind() == Comm::kNone && chol_opt.world > 1) throw StateFailure("solve_sharded: no communicator (g2ohip_comm_init_*)");
+  if (comm.kind() == Comm::kNone && chol_opt.world > 1 && !comm_emulate)
+    throw StateFailure("solve_sharded: no communicator (g2ohip_comm_init_*)");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   // (1) local Schur pass; boundary blocks of the reduced system + boundary right-hand sides summed over the ranks
   solve_schur();
@@ -3528,6 +3533,12 @@ int BlockSolver::solve_sharded() {
   prof.end(KernelProf::kExHalo, st_);
   solve_back_substitute();           // (harmless after a failed factorisation: the caller discards x)
   return exchange_status();
+}
+
+int BlockSolver::solve_sharded() {
+  int rc = solve_sharded_once();
+  for (int again = 0; rc == 2 && again < 2; ++again) rc = solve_sharded_once();   // (every rank takes the same branch: the flag is a sum)
+  return rc == 0 ? 0 : 1;
 }
 
 double BlockSolver::chi2_sharded() {

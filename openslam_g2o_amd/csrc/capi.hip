@@ -302,7 +302,10 @@ int g2ohip_exchange_unpack(g2ohip_solver* s, int which) {
 }
 int g2ohip_exchange_status(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
-  return guarded([&] { return s->impl->exchange_status() ? G2OHIP_NOT_PD : G2OHIP_OK; });
+  return guarded([&] {
+    const int rc = s->impl->exchange_status();
+    return rc == 0 ? G2OHIP_OK : (rc == 2 ? G2OHIP_REPEAT : G2OHIP_NOT_PD);
+  });
 }
 int g2ohip_get_partition(g2ohip_solver* s, int32_t* pose_owner, int32_t* block_consumer) {
   REQUIRE_HANDLE(s);
@@ -468,6 +471,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "dep_spin_limit")) s->impl->chol_opt.dep_spin_limit = (int)value;
   else if (!std::strcmp(name, "wave_front_bytes")) s->impl->chol_opt.wave_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_tile_bytes")) s->impl->schur_tile_bytes = (size_t)value;
+  else if (!std::strcmp(name, "comm_emulate")) s->impl->comm_emulate = (int)value;
   else if (!std::strcmp(name, "schur_group")) s->impl->schur_group = (int)value;
   else if (!std::strcmp(name, "mask_solution")) s->impl->mask_solution = value != 0;
   else if (!std::strcmp(name, "schur_sort_dests")) s->impl->schur_sort_dests = value != 0;

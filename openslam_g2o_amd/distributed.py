@@ -395,20 +395,24 @@ class ShardedBlockSolver:
         """Three latency-sized collectives: boundary Hschur blocks + boundary b_p | subtree roots | halo x_p + status."""
         if self._native_exchange():
             L = self.local
-            L.solveSchur()
-            if len(self.boundary) or len(self.bposes):
-                L.exchangePack(1)
-                self.comm.all_reduce_sum([self._nbuf1])
-                L.exchangeUnpack(1)
-            L.solveReducedLocal()
-            self.comm.all_reduce_sum([self._nxbuf])
-            L.solveReducedShared()
-            L.solveReducedFinishAsync()
-            L.exchangePack(3)
-            self.comm.all_reduce_sum([self._nbuf3])
-            L.exchangeUnpack(3)
-            L.solveBackSubstitute()           # (harmless after a failed factorisation: the caller discards x)
-            return L.exchangeStatus()
+            for _ in range(3):                    # (REPEAT: the status word is a sum over the ranks, every rank loops alike)
+                L.solveSchur()
+                if len(self.boundary) or len(self.bposes):
+                    L.exchangePack(1)
+                    self.comm.all_reduce_sum([self._nbuf1])
+                    L.exchangeUnpack(1)
+                L.solveReducedLocal()
+                self.comm.all_reduce_sum([self._nxbuf])
+                L.solveReducedShared()
+                L.solveReducedFinishAsync()
+                L.exchangePack(3)
+                self.comm.all_reduce_sum([self._nbuf3])
+                L.exchangeUnpack(3)
+                L.solveBackSubstitute()           # (harmless after a failed factorisation: the caller discards x)
+                ok = L.exchangeStatus()
+                if ok is True or ok is False:
+                    return ok
+            return False
         import torch
         t = self._subtree_tensors()
         p = self.p

@@ -184,7 +184,9 @@ def test_sharded_matrix_free_pcg_matches_oracle(tmp_path, world):
     assert len(set(its)) == 1 and its[0] > 0                                      # every rank took the same decisions
 
 
-def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir):
+def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir, stall_rank=-1):
+    if rank == stall_rank:       # this rank's dependency-driven launches give up at once (the safety net under test)
+        os.environ["G2OHIP_OPTIONS"] = "dep_spin_limit=0"
     import torch
     import torch.distributed as dist
     from openslam_g2o_amd import capi, distributed as D, lm
@@ -204,9 +206,27 @@ def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir):
         done, chis, lams, trials = lm.optimize(g, s, n_it, "lm")
         cams, pts = s.local.baGetEstimates()
         np.savez(os.path.join(out_dir, "lm%d.npz" % rank), done=done, chis=chis, lams=lams, trials=trials, cams=cams, pts=pts,
-                 lm_index=s.lm_index, pose_owner=s.pose_owner, halo=s.halo)
+                 lm_index=s.lm_index, pose_owner=s.pose_owner, halo=s.halo, fallbacks=s.local.stats()["dependencyFallbacks"])
     finally:
         dist.destroy_process_group()
+
+
+def test_a_stall_on_one_rank_repeats_the_solve_on_all_ranks(tmp_path):
+    """A dependency-driven launch that gives up waiting on ONE rank (spin limit 0 there) must not look like "not positive
+    definite" to the LM loop: the status word all ranks share tells the two apart (G2OHIP_REPEAT), every rank runs the
+    solve again, the stalled rank with one launch per level -- same trials and chi2 as the single-rank run."""
+    import torch.multiprocessing as mp
+    from openslam_g2o_amd import lm
+    world, P, L, n_it = 2, 400, 3600, 4
+    mp.spawn(_lm_worker, args=(world, _free_port(), P, L, 0.0, 0.0, n_it, str(tmp_path), 1), nprocs=world, join=True)
+    pr = ba_case(P, L)
+    s1, g1 = lm.setup_device_ba(pr)
+    done1, chis1, lams1, trials1 = lm.optimize(g1, s1, n_it, "lm")
+    z = [np.load(os.path.join(str(tmp_path), "lm%d.npz" % r)) for r in range(world)]
+    assert int(z[1]["fallbacks"]) >= 1 and int(z[0]["fallbacks"]) == 0
+    for r in range(world):
+        assert int(z[r]["done"]) == done1 and list(z[r]["trials"]) == trials1
+        assert np.allclose(z[r]["chis"], chis1, rtol=1e-6, atol=0) and np.allclose(z[r]["lams"], lams1, rtol=1e-6, atol=0)
 
 
 @pytest.mark.parametrize("world", [2, 3])
