@@ -39,6 +39,9 @@ struct CholOptions {
   int rank = 0, world = 1;   // multi-GPU: this rank factorises its own subtrees + (redundantly) the shared top of the tree
   int dep_levels = 16;                   // > 1: up to this many consecutive task levels share ONE launch; a parent task waits for its
                                          // children through device-scope counters instead of the launch boundary
+  int fuse_fwd_any = 1;                  // forward sweep fused into the factor kernel whatever the number / size of a front's children
+  int lds_mfma = (4 << 16) | 96;                     // LDS fronts with at least (low 16 bits) boundary rows and (high bits) pivot blocks: pivot steps update the panel only, ONE MFMA rank-npiv
+                                         // update of the trailing matrix afterwards (0: off -- every pivot block updates the whole trailing matrix)
   int dep_spin_limit = 1 << 21;          // polls (~0.2 us each) before a waiting workgroup gives up and flags status 2
   int big_front_min_dim = 180;           // ... for the launches whose largest front has at least this many rows
   int wide_front_doubles = 5000;         // launches whose largest LDS front has this many packed doubles (100 rows) use 512 threads per front
@@ -151,6 +154,7 @@ struct CholPlanDev {
   int* status;
   int* ready;        // dependency-driven launches: children finished so far, per front
   int dep_spin_limit;
+  int lds_mfma;
   long long* dbg;   // G2OHIP_CHOL_STAMPS builds only: per-launch wall-clock stamps of workgroup 0
   long long* tl;    // ... and (start, end) wall-clock of every workgroup of the wave-kernel launch
   // band chains (band_chain.inc)

@@ -948,8 +948,13 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         if (q < LL.glb_begin) LL.lds_max_panel = std::max(LL.lds_max_panel, (R.ns + R.nb) * bs * R.ns * bs + R.ns * bs);
         if (q < LL.glb_begin) {   // may the factor kernel carry the forward sweep of this launch?
           const int nthr = LL.sm_count > 0 ? 128 : kFactorThreads;
-          bool ok = R.child_cnt <= kFwdChildren && R.ns * bs <= nthr;
-          for (int c = 0; c < R.child_cnt && ok; ++c) ok = cdesc[R.child_off + c].nbc * bs <= nthr;
+          // (any number of children, any boundary size: the fifth and later children and those with more boundary rows
+          // than threads are added by a loop; one right-hand side value per thread in the pivot part)
+          const bool ok = R.ns * bs <= nthr && (opt.fuse_fwd_any || [&] {
+            bool o = R.child_cnt <= kFwdChildren;
+            for (int c = 0; c < R.child_cnt && o; ++c) o = cdesc[R.child_off + c].nbc * bs <= nthr;
+            return o;
+          }());
           if (!ok) LL.fuse_fwd = false;
         }
         if (q < LL.glb_begin) LL.wv_idx_ints = std::max(LL.wv_idx_ints, (2 + kVirtInts) * R.asm_cnt + R.cmap_cnt + R.crel_cnt);
@@ -1609,6 +1614,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.status = d_status.p;
   plan_.ready = d_ready.p;
   plan_.dep_spin_limit = opt.dep_spin_limit;
+  plan_.lds_mfma = opt.lds_mfma;
   plan_.dbg = nullptr;
   plan_.tl = nullptr;
   plan_.slots = d_slots.p;
@@ -1679,6 +1685,8 @@ __device__ __forceinline__ ChildDesc load_child_desc(const ChildDesc* p) {
   for (int i = 0; i < (int)(sizeof(ChildDesc) / sizeof(int)); ++i) ri[i] = rp[i];
   return cd;
 }
+
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 // One workgroup factorises one TASK = a chain of frontal matrices f1 -> f2 -> ... in which every
 // front is the only child of the next one; the update matrix travels from front to front in
@@ -1883,6 +1891,7 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
           wn[c] = nbc_c * BS;
           wcrel[c] = crel_c;
           woff[c] = woff_c;
+          if (wn[c] > NT && !(carried && c == 0)) wn[c] = -wn[c];   // more boundary rows than threads: added by the loop in add_child_vec
           if (EARLY_W && tid < wn[c] && !(carried && c == 0)) wv[c] = ld_coh(P.w + woff_c + tid);
         }
       }
@@ -1990,10 +1999,23 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
     // time: rows may coincide); returns true when the fast path handled them
     auto add_child_vec = [&](int ch) {
       if (!fwd) return;
+      bool generic = ch >= kFwdChildren;
 #pragma unroll
       for (int c = 0; c < kFwdChildren; ++c)   // (compile-time register index)
-        if (c == ch && tid < wn[c])
-          tv[s_crel[wcrel[c] + tid / BS] * BS + tid % BS] += (carried && c == 0) ? wprev[tid] : (EARLY_W ? wv[c] : ld_coh(P.w + woff[c] + tid));
+        if (c == ch) {
+          if (carried && c == 0) {   // (the chain predecessor's vector, in LDS)
+            for (int i = tid; i < wn[c]; i += NT) tv[s_crel[wcrel[c] + i / BS] * BS + i % BS] += wprev[i];
+          } else if (wn[c] < 0) {
+            generic = true;
+          } else if (tid < wn[c]) {
+            tv[s_crel[wcrel[c] + tid / BS] * BS + tid % BS] += EARLY_W ? wv[c] : ld_coh(P.w + woff[c] + tid);
+          }
+        }
+      if (generic) {   // a fifth or later child, or one with more boundary rows than threads: straight from memory
+        const ChildDesc cd = load_child_desc(P.cdesc + rec.child_off + ch);
+        const int n = cd.nbc * BS;
+        for (int i = tid; i < n; i += NT) tv[s_crel[cd.crel_start + i / BS] * BS + i % BS] += ld_coh(P.w + cd.w_off + i);
+      }
     };
     // ---- extend-add of the children (sequential over children: destinations may overlap).  Update
     // matrices are packed lower-triangular blocks (row-major block order); cmap gives, per packed
@@ -2189,6 +2211,10 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
         }
       }
     };
+    // LDS fronts with a boundary worth it: the pivot steps update the remaining PANEL columns only (as for the scratch-slab
+    // fronts) and the trailing matrix gets ONE rank-npiv update on the matrix cores afterwards -- the trailing matrix is
+    // read and written once per front instead of once per pivot block
+    const bool mfma_tail = USE_LDS && P.lds_mfma != 0 && NT >= 64 && nbd * BS >= (P.lds_mfma & 0xffff) && ns >= (P.lds_mfma >> 16);
     if (ns > 0) {
       if (tid < 64) diag_factor(0, sd, std::false_type());
       __syncthreads();
@@ -2287,7 +2313,7 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
             tv[j] = v;
           }
         }
-        if constexpr (USE_LDS) {
+        if (USE_LDS && !mfma_tail) {
           for (int idx = first; idx < ntiles; idx += stride) update_tile(s_tri[idx]);
         } else {
           // scratch-slab (large) fronts: only the remaining PANEL columns are updated here; the rank-npiv update
@@ -2304,6 +2330,67 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
       }
       __syncthreads();
       STAMP();
+    }
+    if constexpr (USE_LDS) {
+      if (mfma_tail) {
+        // F22 -= L21 L21' as 16 x 16 tiles of v_mfma_f64_16x16x4_f64 (K = npiv), operands read from the packed blocks in
+        // LDS.  Result element D[lane/16 + 4v][lane%16]: rows from the first operand, columns from the second.
+        const int mt = nbd * BS, nt16 = (mt + 15) >> 4, ks = (npiv + 3) >> 2;
+        const int wave = tid >> 6, nw = NT >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+        // per lane and k-step: offset of panel column k inside a block row (blocks (bi, 0..ns-1) are contiguous), and
+        // whether the column exists -- the same for every tile: computed once per front (first six k-steps in registers)
+        int koff[6];
+        bool kon[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int k = 4 * u + lk, kk = min(k, npiv - 1), kb_ = kk / BS;
+          koff[u] = kb_ * BB + BS * (kk - kb_ * BS);
+          kon[u] = k < npiv;
+        }
+        // result columns of this lane inside a tile column: c = 16 tj + lk + 4 v
+        // a wave owns whole tile ROWS (ti = wave, wave + nw, ...: the row-side operand and its block row are per-row work)
+        for (int ti = nt16 - 1 - wave; ti >= 0; ti -= nw) {   // (longest rows first)
+          const int rr = min(ti * 16 + lr, mt - 1), rrb = rr / BS, rri = rr - rrb * BS;
+          const double* Ar = F + blk_off(ns + rrb, 0) + rri;
+          const bool row_ok = ti * 16 + lr < mt;
+          double av[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) av[u] = Ar[koff[u]];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) av[u] = kon[u] ? av[u] : 0.0;
+          const int rowbase = blk_off(ns + rrb, ns) + rri;   // block (rrb, jb) of the trailing part: + jb * BB + BS * (c - jb BS)
+          for (int tj = 0; tj <= ti; ++tj) {
+            const int rc = min(tj * 16 + lr, mt - 1), rcb = rc / BS;
+            const double* Ac = F + blk_off(ns + rcb, 0) + (rc - rcb * BS);
+            double bv[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) bv[u] = Ac[koff[u]];
+            // destinations requested with the operands
+            int dst[4];
+            double cur[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int c0_ = tj * 16 + lk + 4 * v, c = min(c0_, mt - 1), jb = c / BS;
+              const bool ok = row_ok && c0_ < mt && rrb >= jb;
+              dst[v] = ok ? rowbase + jb * BB + BS * (c - jb * BS) : sink;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cur[v] = F[dst[v]];
+            mfma_d4 acc = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 6; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kon[u] ? bv[u] : 0.0, av[u], acc, 0, 0, 0);
+            for (int s0 = 6; s0 < ks; ++s0) {   // (supernodes of more than 24 pivot columns)
+              const int k = 4 * s0 + lk, kk = min(k, npiv - 1), kb_ = kk / BS;
+              const int off = kb_ * BB + BS * (kk - kb_ * BS);
+              const double a_ = Ar[off], b_ = Ac[off];
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < npiv ? b_ : 0.0, k < npiv ? a_ : 0.0, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) F[dst[v]] = cur[v] - acc[v];
+          }
+        }
+        __syncthreads();
+      }
     }
     // ---- forward-sweep results: y (pivot part) to HBM, w (boundary part) to the next chain front or to HBM
     if (fwd) {
@@ -2635,7 +2722,6 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4
 // (L2-resident, 128-byte coalesced: 16 consecutive rows per k).  Layout of the instruction (probed on gfx950,
 // tools/probe/mfma_f64_layout.hip): A[i][k] from lane i + 16k, B[j][k] from lane j + 16k, D[lane/16 + 4v][lane%16]
 // in register v.  The ROW of the trailing matrix rides on j (lanes 0..15: consecutive addresses), the column on i.
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 template <int BS>
 __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, const int4* __restrict__ tiles,
                                                               double* __restrict__ scratch,
