@@ -37,7 +37,7 @@ struct CholOptions {
   bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task
   int max_chain_fronts = 0;  // > 0: chains longer than this are cut into equal segments
   int rank = 0, world = 1;   // multi-GPU: this rank factorises its own subtrees + (redundantly) the shared top of the tree
-  int dep_levels = 16;                   // > 1: up to this many consecutive task levels share ONE launch; a parent task waits for its
+  int dep_levels = 64;                   // > 1: up to this many consecutive task levels share ONE launch; a parent task waits for its
                                          // children through device-scope counters instead of the launch boundary
   int fuse_fwd_any = 1;                  // forward sweep fused into the factor kernel whatever the number / size of a front's children
   int lds_mfma = (4 << 16) | 96;                     // LDS fronts with at least (low 16 bits) boundary rows and (high bits) pivot blocks: pivot steps update the panel only, ONE MFMA rank-npiv
