@@ -133,6 +133,9 @@ class BlockSolver {
   // fused forward sweep, backward sweep): ~30 launches per iteration, which is what limits a rank once the
   // per-rank work shrinks (multi-GPU).  Needs a non-default stream.  Timing events sit between the graphs.
   bool use_graph = false;
+  int sharded_graph = 1;                   // solve_sharded as ONE hipGraph (the collectives inside it): 1 = when nothing has to cross the
+                                           // host (comm_emulate), 2 = with RCCL as well (ncclAllReduce captured into the graph; not
+                                           // exercised on hardware here -- opt-in); 0 = one graph per phase, plain launches in between
   void invalidate_graphs();
   int linear_solver = 0;                   // 0: multifrontal block Cholesky, 1: block-Jacobi PCG (LinearSolverPCG) on Hschur,
                                            // 2: the same PCG matrix-free (Schur complement never formed; Schur mode only)
@@ -165,7 +168,8 @@ class BlockSolver {
   // host patterns
   std::vector<int> pp_colptr, pp_row, pp_diag, pl_colptr, pl_row, hs_colptr, hs_row;
   // device matrices
-  enum Seg { kSegFactor = 0, kSegBackward, kSegLocal, kSegShared, kSegSharedBack, kSegFactorBand, kSegFactorRest, kNumSeg };
+  enum Seg { kSegFactor = 0, kSegBackward, kSegLocal, kSegShared, kSegSharedBack, kSegFactorBand, kSegFactorRest, kSegShardedAll, kNumSeg };
+  bool in_outer_seg_ = false;   // an enclosing segment is being captured / run: inner run_seg calls are transparent
   struct GraphSeg {
     hipGraph_t g = nullptr;
     hipGraphExec_t e = nullptr;

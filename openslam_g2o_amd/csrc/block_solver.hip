@@ -2629,10 +2629,15 @@ void BlockSolver::invalidate_graphs() {
 
 template <class F>
 void BlockSolver::run_seg(int id, F&& body) {
-  if (!use_graph || st_ == nullptr) {
+  if (!use_graph || st_ == nullptr || in_outer_seg_) {
     body();
     return;
   }
+  struct Outer {   // the whole-solve segment makes the segments inside it transparent
+    bool& f; bool on;
+    Outer(bool& f_, bool on_) : f(f_), on(on_) { if (on) f = true; }
+    ~Outer() { if (on) f = false; }
+  } outer(in_outer_seg_, id == kSegShardedAll && segs_[id].state >= 1);
   GraphSeg& sg = segs_[id];
   if (sg.state == 0) {   // first use: one-time initialisation (function attributes, lazy analysis) runs outside a capture
     body();
@@ -3505,6 +3510,7 @@ int BlockSolver::solve_sharded_once() {
   if (comm.kind() == Comm::kNone && chol_opt.world > 1 && !comm_emulate)
     throw StateFailure("solve_sharded: no communicator (g2ohip_comm_init_*)");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  auto whole_solve = [&] {
   // (1) local Schur pass; boundary blocks of the reduced system + boundary right-hand sides summed over the ranks
   solve_schur();
   if (ex_.nbb > 0 || ex_.nbp > 0) {
@@ -3532,6 +3538,19 @@ int BlockSolver::solve_sharded_once() {
   exchange_unpack(3);
   prof.end(KernelProf::kExHalo, st_);
   solve_back_substitute();           // (harmless after a failed factorisation: the caller discards x)
+  };
+  // One hipGraph for the whole sequence when nothing in it has to cross the host: a rank's kernels are short at N = 8
+  // (0.4 ms in total) and the launch boundaries between the phases were a third of its time.  The events of the kernel
+  // timers cannot live inside a captured graph: with profiling on the phases run as before.
+  const bool one_graph = sharded_graph > 0 && use_graph && !prof.enabled && !profiling &&
+                         ((comm.kind() == Comm::kNone) || (comm.kind() == Comm::kRccl && sharded_graph >= 2));
+  if (getenv("G2OHIP_GRAPH_DEBUG")) {
+    static int once = 0;
+    if (once++ < 8) fprintf(stderr, "solve_sharded: one_graph %d (sharded_graph %d use_graph %d prof %d profiling %d comm %d) state %d\n", (int)one_graph, sharded_graph,
+                            (int)use_graph, (int)prof.enabled, (int)profiling, (int)comm.kind(), segs_[kSegShardedAll].state);
+  }
+  if (one_graph) run_seg(kSegShardedAll, whole_solve);
+  else whole_solve();
   return exchange_status();
 }
 

@@ -294,6 +294,46 @@ def test_large_scale_properties():
     assert st["hessianPoseDimension"] == 6 * pr["nP"] and st["choleskyNNZ"] > 0
 
 
+@pytest.mark.parametrize("graph", ["manhattan", "sphere"])
+def test_front_kernel_variants_agree_on_the_pose_graphs(graph):
+    """Round-3 variants of the LDS-front kernel against the earlier ones on the two golden pose graphs: the forward sweep
+    fused into the factor kernel whatever the number / size of a front's children (fuse_fwd_any: the fifth and later children
+    and those with more boundary rows than threads are added by a loop), all LDS levels in dependency-driven launches
+    (dep_levels 64 against 16 and against one launch per level), the trailing matrix updated ONCE per front on the matrix
+    cores (lds_mfma) against once per pivot block on the VALU.  Same solution to rounding, and the reference's."""
+    capi = _capi()
+    from tests.helpers import sphere_golden
+    if graph == "manhattan":
+        g = manhattan_golden(); p, l, d = 3, 2, 3
+        J0, J1, err = O.se2_edges(g["estimates"], g["vi"], g["vj"], g["meas"])
+    else:
+        g = sphere_golden(); p, l, d = 6, 3, 6
+        J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
+    xs, stats = [], []
+    variants = ({}, {"fuse_fwd_any": 0, "dep_levels": 16, "lds_mfma": 0}, {"dep_levels": 0}, {"lds_mfma": (1 << 16) | 24}, {"lds_mfma": 0})
+    for opts in variants:
+        s = capi.HipBlockSolver(p, l, 0)
+        for k_, v_ in opts.items():
+            s.setOption(k_, v_)
+        k = s.addEdgeSet(d, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+        s.buildStructure(g["nP"], 0, False)
+        s.setEdgeData(k, J0, J1, g["omega"], err)
+        s.buildSystem()
+        s.setLambda(float(g["lambda0"]), True)
+        two = []
+        for _ in range(2):
+            assert s.solve(), opts
+            two.append(s.x())
+        assert np.array_equal(two[0], two[1])             # repeatable bit for bit
+        s.restoreDiagonal()
+        xs.append(two[0])
+        stats.append(s.stats())
+    assert relerr(xs[0], g["x_lm0"]) < 1e-8
+    for x in xs[1:]:
+        assert relerr(x, xs[0]) < 1e-11
+    assert all(st["dependencyFallbacks"] == 0 for st in stats)
+
+
 def test_sphere_golden_no_schur():
     """Config 2 input (sphere, 2 200 VertexSE3 / 8 647 EdgeSE3, BlockSolver_6_3 semantics, fp64,
     1 GPU): first-iteration x against the reference CSparse golden vectors, then three damped
