@@ -234,6 +234,20 @@ int g2ohip_compute_marginals(g2ohip_solver* s, int n_blocks, const int32_t* rows
  * device-side producers): J0 [n][d*dim0], J1 [n][d*dim1], err [n][d]; any pointer may be NULL. */
 int g2ohip_copy_edge_data(g2ohip_solver* s, int set, double* J0, double* J1, double* err);
 
+/* Drops every edge set (and the device front-end bindings) of the handle: the next g2ohip_add_edge_set starts a new
+ * graph.  What BlockSolver::buildStructure does implicitly when it is called again (block_solver.hpp:142-204 deallocates
+ * and rebuilds Hpp / Hll / Hpl): a second optimize() on the same solver, or a rebuild after online growth. */
+int g2ohip_clear_edge_sets(g2ohip_solver* s);
+
+/* Solver::updateStructure(vset, edges), block_solver.hpp:297-351: online growth WITHOUT Schur complement.  The new pose
+ * vertices take the hessian indices [num_poses, num_poses + num_new_poses) (SparseOptimizer::updateInitialization appends them
+ * to the index mapping, sparse_optimizer.cpp:269-352); the new edges are appended to an existing edge set (same error
+ * dimension and vertex classes; for another edge type call g2ohip_add_edge_set first and pass n_new_edges = 0 here).  The
+ * structure is rebuilt from the enlarged topology: g2ohip_vector_size grows, per-edge data of the touched set has to be
+ * handed over again for ALL its edges (old ones first).  G2OHIP_ERR_UNSUPPORTED where the reference aborts (a system with
+ * marginalised vertices, :313-316). */
+int g2ohip_update_structure(g2ohip_solver* s, int num_new_poses, int set, int n_new_edges, const int32_t* v0, const int32_t* v1);
+
 /* Multi-GPU sharding support (openslam_g2o_amd/distributed.py).  Each rank holds a landmark
  * shard; to give every rank the SAME Hschur block layout (so the partial Schur complements
  * can be summed element-wise by one RCCL all-reduce) the union pattern is declared up front:

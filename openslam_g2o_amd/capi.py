@@ -23,6 +23,7 @@ c_int_p = C.POINTER(C.c_int32)
 c_dbl_p = C.POINTER(C.c_double)
 
 OK, NOT_PD, REPEAT = 0, 1, 2
+ERR_UNSUPPORTED = -4
 HPP, HPL, HLL, HSCHUR, DINV = 0, 1, 2, 3, 4
 ARR_BSCHUR, ARR_X, ARR_B, ARR_EXCHANGE, ARR_XP, ARR_XBOUNDARY, ARR_XHALO, ARR_SCHUR_DIAG = 100, 101, 102, 103, 104, 105, 106, 107
 KERNEL_NONE, KERNEL_HUBER, KERNEL_PSEUDOHUBER, KERNEL_CAUCHY, KERNEL_SATURATED, KERNEL_DCS = 0, 1, 2, 3, 4, 5
@@ -59,7 +60,7 @@ EXPORTS = [
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
     "g2ohip_compute_marginals", "g2ohip_set_x", "g2ohip_copy_diagonal",
     "g2ohip_comm_unique_id", "g2ohip_comm_init_rccl", "g2ohip_comm_init_host", "g2ohip_comm_destroy", "g2ohip_comm_all_reduce",
-    "g2ohip_solve_sharded", "g2ohip_chi2_sharded", "g2ohip_max_diagonal_sharded", "g2ohip_compute_scale_sharded",
+    "g2ohip_update_structure", "g2ohip_clear_edge_sets", "g2ohip_solve_sharded", "g2ohip_chi2_sharded", "g2ohip_max_diagonal_sharded", "g2ohip_compute_scale_sharded",
 ]
 
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_int)
@@ -157,6 +158,7 @@ def load():
     L.g2ohip_comm_init_host.argtypes = [vp, C.c_int, C.c_int, HOST_ALLREDUCE_FN, vp]
     L.g2ohip_comm_destroy.argtypes = [vp]
     L.g2ohip_comm_all_reduce.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.g2ohip_update_structure.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.g2ohip_solve_sharded.argtypes = [vp]
     L.g2ohip_chi2_sharded.argtypes = [vp, c_dbl_p]
     L.g2ohip_max_diagonal_sharded.argtypes = [vp, c_dbl_p]
@@ -482,6 +484,27 @@ class HipBlockSolver:
 
     def setStream(self, raw_stream):
         _check(self.L.g2ohip_set_stream(self.h, C.c_void_p(raw_stream)), "setStream")
+
+    def clearEdgeSets(self):
+        _check(self.L.g2ohip_clear_edge_sets(self.h), "clearEdgeSets")
+        self._set_sizes = {}
+        self.nP = self.nL = 0
+
+    def updateStructure(self, new_poses, set_id=-1, v0=None, v1=None):
+        """Solver::updateStructure (block_solver.hpp:297-351): new pose vertices behind the existing ones, new edges appended to
+        edge set set_id.  False where the reference refuses (Schur complement active)."""
+        n = 0 if v0 is None else len(v0)
+        a0 = _i32(v0) if n else None
+        a1 = _i32(v1) if (n and v1 is not None) else None
+        rc = self.L.g2ohip_update_structure(self.h, int(new_poses), int(set_id), n, a0.ctypes.data if n else None,
+                                            a1.ctypes.data if a1 is not None else None)
+        if rc == ERR_UNSUPPORTED:
+            return False
+        _check(rc, "updateStructure")
+        self.nP += int(new_poses)
+        if n:
+            self._set_sizes[set_id] += n
+        return True
 
     def setProfiling(self, on):
         self.L.g2ohip_set_profiling(self.h, int(on))

@@ -75,6 +75,7 @@ class BlockSolverHip : public BlockSolverBase {
     (void)zeroBlocks;
     if (!_h || !_optimizer) return false;
     if (g2ohip_init(_h) != G2OHIP_OK) return fail("init");
+    if (g2ohip_clear_edge_sets(_h) != G2OHIP_OK) return fail("clear_edge_sets");   // (a second optimize(), online growth: a new graph)
     _groups.clear();
     // poses first, then marginalized vertices, each in index order (sparse_optimizer.cpp:174-187)
     _nP = _nL = 0;
@@ -163,11 +164,22 @@ class BlockSolverHip : public BlockSolverBase {
   void setFastPath(bool on) { _fastPath = on; }
   bool fastPathActive() const { return _fastGroup >= 0; }
 
-  // online growth: the reference aborts for Schur too (block_solver.hpp:313-316)
+  // Online growth (block_solver.hpp:297-351).  SparseOptimizer::updateInitialization has appended the new vertices to
+  // indexMapping() and the new edges to activeEdges() before it calls this (sparse_optimizer.cpp:269-352), so the index
+  // arrays are simply read again: the library rebuilds contributor lists, pattern and symbolic analysis from them.  With
+  // marginalised vertices the reference aborts (:313-316); here the call reports failure.
   virtual bool updateStructure(const std::vector<HyperGraph::Vertex*>& vset, const HyperGraph::EdgeSet& edges) {
-    (void)vset;
     (void)edges;
-    return false;
+    for (size_t i = 0; i < vset.size(); ++i)
+      if (static_cast<OptimizableGraph::Vertex*>(vset[i])->marginalized()) {
+        std::cerr << "updateStructure(): Schur not supported" << std::endl;
+        return false;
+      }
+    if (_doSchur && _nL > 0) {
+      std::cerr << "updateStructure(): Schur not supported" << std::endl;
+      return false;
+    }
+    return buildStructure(false);
   }
 
   // block_solver.hpp:501-560.  After it returns b() holds -J' Omega e (poses then landmarks) and H is assembled on

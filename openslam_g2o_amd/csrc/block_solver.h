@@ -54,9 +54,11 @@ class BlockSolver {
   ~BlockSolver();
 
   void init();
+  void clear_edge_sets();
   int add_edge_set(int d, int n, const int* v0, const int* v1);
   void add_schur_pattern(int n, const int* rows, const int* cols);
   void build_structure(int nP, int nL, bool do_schur);
+  bool update_structure(int new_poses, int set, int n, const int* v0, const int* v1);
   void set_edge_data(int set, const double* J0, const double* J1, const double* omega, const double* err, bool on_device);
   void set_robust_kernel(int set, int kind, double delta);
   void build_system();

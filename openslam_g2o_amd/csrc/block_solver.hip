@@ -2080,6 +2080,20 @@ void BlockSolver::init() {
   system_built_ = false;
 }
 
+// A new graph behind the same handle (a second optimize() of a g2o optimizer calls buildStructure again, the online
+// growth re-registers everything): every edge set, the extra pattern of the reduced system and the bindings of the device
+// front ends are dropped.
+void BlockSolver::clear_edge_sets() {
+  invalidate_graphs();
+  if (chol_) chol_->reset();
+  sets_.clear();
+  extra_hs_.clear();
+  ba_ = BaFrontEnd();
+  pg_ = PgFrontEnd();
+  structured_ = false;
+  system_built_ = false;
+}
+
 int BlockSolver::add_edge_set(int d, int n, const int* v0, const int* v1) {
   if (d <= 0 || d > 7 || n < 0 || !v0) throw ArgFailure("add_edge_set: bad arguments");
   auto es = std::make_unique<EdgeSet>();
@@ -2092,6 +2106,34 @@ int BlockSolver::add_edge_set(int d, int n, const int* v0, const int* v1) {
   sets_.push_back(std::move(es));
   structured_ = false;
   return (int)sets_.size() - 1;
+}
+
+// Solver::updateStructure (block_solver.hpp:297-351): online growth of a system WITHOUT Schur complement -- new pose
+// vertices at the end of the index mapping, new edges appended to an existing edge set.  The reference allocates the new
+// blocks in Hpp and leaves the symbolic factorisation to the linear solver's next solve; here the structure (contributor
+// lists, pattern, ordering, symbolic analysis) is rebuilt from the enlarged topology.  Returns false where the reference
+// aborts (marginalised vertices, :313-316).
+bool BlockSolver::update_structure(int new_poses, int set, int n, const int* v0, const int* v1) {
+  require_structure();
+  if (new_poses < 0 || n < 0 || (n > 0 && !v0)) throw ArgFailure("update_structure: bad arguments");
+  if (schur_ || nL_ > 0) return false;
+  if (n > 0) {
+    if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("update_structure: no such edge set");
+    EdgeSet& es = *sets_[set];
+    if (es.unary != (v1 == nullptr)) throw ArgFailure("update_structure: the set's edges have a different number of vertices");
+    const int nP_new = nP_ + new_poses;
+    for (int k = 0; k < n; ++k)
+      if (v0[k] >= nP_new || (v1 && v1[k] >= nP_new) || v0[k] < -1 || (v1 && v1[k] < -1)) throw ArgFailure("update_structure: vertex index out of range");
+    es.v0.insert(es.v0.end(), v0, v0 + n);
+    if (v1) es.v1.insert(es.v1.end(), v1, v1 + n);
+    else es.v1.insert(es.v1.end(), n, -1);
+    es.n += n;
+    es.has_data = es.has_err = false;          // the per-edge arrays are sized for the old edge count: set_edge_data again
+    es.J0 = es.J1 = es.omega = es.err = nullptr;
+    es.external = false;
+  }
+  build_structure(nP_ + new_poses, 0, false);
+  return true;
 }
 
 void BlockSolver::add_schur_pattern(int n, const int* rows, const int* cols) {

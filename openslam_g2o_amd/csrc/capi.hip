@@ -172,6 +172,25 @@ int g2ohip_add_schur_pattern(g2ohip_solver* s, int n_blocks, const int32_t* rows
   });
 }
 
+int g2ohip_clear_edge_sets(g2ohip_solver* s) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->clear_edge_sets();
+    return G2OHIP_OK;
+  });
+}
+
+int g2ohip_update_structure(g2ohip_solver* s, int num_new_poses, int set, int n_new_edges, const int32_t* v0, const int32_t* v1) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    if (!s->impl->update_structure(num_new_poses, set, n_new_edges, v0, v1)) {
+      set_error("updateStructure(): Schur not supported");   // (the reference's message, block_solver.hpp:314)
+      return G2OHIP_ERR_UNSUPPORTED;
+    }
+    return G2OHIP_OK;
+  });
+}
+
 int g2ohip_restore_diagonal(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

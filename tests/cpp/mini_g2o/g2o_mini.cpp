@@ -83,6 +83,22 @@ bool SparseOptimizer::initializeOptimization(int) {
   return true;
 }
 
+// sparse_optimizer.cpp:445-479: the new edges become active, the new free vertices take the next hessian indices, the
+// algorithm (-> its Solver) grows the structure
+bool SparseOptimizer::updateInitialization(HyperGraph::VertexSet& vset, HyperGraph::EdgeSet& eset) {
+  std::vector<HyperGraph::Vertex*> newVertices;
+  for (HyperGraph::EdgeSet::iterator it = eset.begin(); it != eset.end(); ++it) _activeEdges.push_back(static_cast<OptimizableGraph::Edge*>(*it));
+  for (HyperGraph::VertexSet::iterator it = vset.begin(); it != vset.end(); ++it) {
+    OptimizableGraph::Vertex* v = static_cast<OptimizableGraph::Vertex*>(*it);
+    if (v->fixed()) { v->setHessianIndex(-1); continue; }
+    if (v->marginalized()) return false;                 // (the reference aborts)
+    v->setHessianIndex((int)_ivMap.size());
+    _ivMap.push_back(v);
+    newVertices.push_back(v);
+  }
+  return _algorithm && _algorithm->updateStructure(newVertices, eset);
+}
+
 void SparseOptimizer::computeActiveErrors() {
   for (size_t k = 0; k < _activeEdges.size(); ++k) _activeEdges[k]->computeError();
 }

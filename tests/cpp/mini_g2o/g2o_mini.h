@@ -186,6 +186,7 @@ class HyperGraph {                                      // g2o/core/hyper_graph.
     std::vector<Vertex*> _vertices;
   };
   typedef std::set<Edge*> EdgeSet;                      // :90
+  typedef std::set<Vertex*> VertexSet;                  // :89
   virtual ~HyperGraph() {}
 };
 
@@ -314,6 +315,7 @@ class SparseOptimizer : public OptimizableGraph {       // g2o/core/sparse_optim
   const VertexContainer& indexMapping() const { return _ivMap; }     // :192
   const EdgeContainer& activeEdges() const { return _activeEdges; }  // :196
   bool initializeOptimization(int level = 0);           // sparse_optimizer.cpp:199-267, buildIndexMapping :166-190
+  bool updateInitialization(HyperGraph::VertexSet& vset, HyperGraph::EdgeSet& eset);   // :445-479 (online growth)
   int optimize(int iterations, bool online = false);    // :354-419
   void computeActiveErrors();                           // :61-76
   double activeRobustChi2() const;                      // :100-114
@@ -529,6 +531,7 @@ class OptimizationAlgorithm {                           // g2o/core/optimization
   virtual bool init(bool online = false) = 0;
   virtual SolverResult solve(int iteration, bool online = false) = 0;
   virtual bool computeMarginals(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices) = 0;
+  virtual bool updateStructure(const std::vector<HyperGraph::Vertex*>& vset, const HyperGraph::EdgeSet& edges) = 0;   // :76
   void setOptimizer(SparseOptimizer* optimizer) { _optimizer = optimizer; }
   SparseOptimizer* optimizer() const { return _optimizer; }
  protected:
@@ -541,6 +544,9 @@ class OptimizationAlgorithmWithHessian : public OptimizationAlgorithm {   // opt
   virtual bool init(bool online = false);
   virtual bool computeMarginals(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices) {
     return _solver ? _solver->computeMarginals(spinv, blockIndices) : false;
+  }
+  virtual bool updateStructure(const std::vector<HyperGraph::Vertex*>& vset, const HyperGraph::EdgeSet& edges) {   // .cpp:91-94
+    return _solver ? _solver->updateStructure(vset, edges) : false;
   }
   Solver* solver() { return _solver; }
  protected:

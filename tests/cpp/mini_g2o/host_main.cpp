@@ -26,6 +26,11 @@ int main(int argc, char** argv) {
   const std::string solverName = argv[3];
   const int iterations = std::atoi(argv[4]);
   const bool marginals = argc > 6 && std::string(argv[6]) == "marginals";
+  // "online:N": the first N cameras and their observations are optimised first, then the rest is added through
+  // SparseOptimizer::updateInitialization -> OptimizationAlgorithm::updateStructure -> Solver::updateStructure
+  // (sparse_optimizer.cpp:445-479) and the optimisation goes on; every point has to be fixed (no Schur complement)
+  int onlineFirst = -1;
+  if (argc > 6 && std::string(argv[6]).compare(0, 7, "online:") == 0) onlineFirst = std::atoi(argv[6] + 7);
   // ---- plugin: static RegisterOptimizationAlgorithmProxy objects run inside dlopen (optimization_algorithm_factory.h:120-130)
   void* lib = dlopen(argv[2], RTLD_LAZY | RTLD_GLOBAL);
   if (!lib) {
@@ -55,6 +60,7 @@ int main(int argc, char** argv) {
   CameraParameters cam(f, pp, 0.);
   std::vector<VertexSE3Expmap*> cams(ncams);
   std::vector<VertexSBAPointXYZ*> pts(npts);
+  std::vector<EdgeProjectXYZ2UV*> heldEdges;             // (online mode: added later)
   for (int i = 0; i < ncams; ++i) {
     int fixed;
     Eigen::Matrix3d R;
@@ -66,7 +72,7 @@ int main(int argc, char** argv) {
     v->setId(i);
     v->setFixed(fixed != 0);
     v->setEstimate(SE3Quat(R, t));
-    optimizer.addVertex(v);
+    if (onlineFirst < 0 || i < onlineFirst) optimizer.addVertex(v);
     cams[i] = v;
   }
   for (int i = 0; i < npts; ++i) {
@@ -95,7 +101,8 @@ int main(int argc, char** argv) {
       rk->setDelta(huber);
       e->setRobustKernel(rk);
     }
-    optimizer.addEdge(e);
+    if (onlineFirst < 0 || ci < onlineFirst) optimizer.addEdge(e);
+    else heldEdges.push_back(e);
   }
   if (!in) {
     std::cerr << "problem file truncated" << std::endl;
@@ -150,6 +157,46 @@ int main(int argc, char** argv) {
       trials.push_back(lm ? lm->levenbergIteration() : 1);
       ++done;
       if (r == OptimizationAlgorithm::Terminate) break;
+    }
+    if (argc > 6 && std::string(argv[6]) == "twice") {
+      // a second optimize() on the same optimizer / solver: iteration 0 again, so buildStructure runs a second time
+      // (optimization_algorithm_levenberg.cpp:62-68) -- the plugin has to start a new graph behind the same handle
+      if (!algo->init()) return 4;
+      for (int i = 0; i < iterations; ++i) {
+        const OptimizationAlgorithm::SolverResult r = algo->solve(i);
+        if (r == OptimizationAlgorithm::Fail) break;
+        optimizer.computeActiveErrors();
+        chis.push_back(optimizer.activeRobustChi2());
+        lams.push_back(lm ? lm->currentLambda() : 0.0);
+        trials.push_back(lm ? lm->levenbergIteration() : 1);
+        ++done;
+        if (r == OptimizationAlgorithm::Terminate) break;
+      }
+    }
+    if (onlineFirst >= 0) {
+      HyperGraph::VertexSet vset;
+      HyperGraph::EdgeSet eset;
+      for (int i = onlineFirst; i < ncams; ++i) {
+        optimizer.addVertex(cams[i]);
+        vset.insert(cams[i]);
+      }
+      for (size_t k = 0; k < heldEdges.size(); ++k) {
+        optimizer.addEdge(heldEdges[k]);
+        eset.insert(heldEdges[k]);
+      }
+      if (!optimizer.updateInitialization(vset, eset)) {
+        std::cerr << "updateInitialization failed" << std::endl;
+        return 5;
+      }
+      for (int i = 0; i < iterations; ++i) {               // (iteration numbers go on: the structure is not built again)
+        const OptimizationAlgorithm::SolverResult r = algo->solve(iterations + i);
+        if (r == OptimizationAlgorithm::Fail) break;
+        optimizer.computeActiveErrors();
+        chis.push_back(optimizer.activeRobustChi2());
+        lams.push_back(lm ? lm->currentLambda() : 0.0);
+        trials.push_back(lm ? lm->levenbergIteration() : 1);
+        ++done;
+      }
     }
     js << ", \"iterations\": " << done << ", \"chi2_initial\": " << chi0 << ", \"chi2\": [";
     for (size_t i = 0; i < chis.size(); ++i) js << (i ? ", " : "") << chis[i];

@@ -137,3 +137,46 @@ def test_localisation_graph_with_every_point_fixed(host, tmp_path):
         out, _ = _run(host, prob, "lm_fix6_3_hip", 3, str(tmp_path / "loc.json"), env)
         assert out["iterations"] >= 1 and out["chi2"][-1] < out["chi2_initial"]
         assert np.abs(np.array(out["points"]).reshape(-1, 3) - pr["pts"]).max() == 0.0      # fixed points did not move
+
+
+def test_online_growth_through_update_structure(host, tmp_path):
+    """Solver::updateStructure through the vtables (block_solver.hpp:297-351; SparseOptimizer::updateInitialization,
+    sparse_optimizer.cpp:445-479): a localisation graph (every point fixed: no Schur complement) is optimised for its first
+    cameras, grown by the others, and optimised on.  With fixed points the cameras are independent of each other, so every
+    camera must end where the same number of Gauss-Newton steps takes it in a run over the whole graph."""
+    pr = ba_case(12, 150)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr, fix_points=True)
+    n_first, it = 7, 2
+    grown, err = _run(host, prob, "gn_fix6_3_hip", it, str(tmp_path / "on.json"), mode="online:%d" % n_first)
+    assert grown["iterations"] == 2 * it
+    short, _ = _run(host, prob, "gn_fix6_3_hip", it, str(tmp_path / "a.json"))
+    long_, _ = _run(host, prob, "gn_fix6_3_hip", 2 * it, str(tmp_path / "b.json"))
+    cg, cs, cl = (np.array(o["cams"]).reshape(-1, 12) for o in (grown, short, long_))
+    free = pr["cam_hidx"] >= 0
+    first = np.arange(pr["P"]) < n_first
+    assert np.abs(cg[first & free] - cl[first & free]).max() < 1e-9      # 2 + 2 steps
+    assert np.abs(cg[~first & free] - cs[~first & free]).max() < 1e-9    # added later: 2 steps
+    assert np.abs(cg[~free] - pr["cams"][~free]).max() == 0.0            # fixed cameras did not move
+    assert grown["chi2"][-1] <= grown["chi2"][it] * (1 + 1e-9)            # (chi2_initial counts the first graph's edges only)
+    # a graph with marginalised points: the growth is refused (the reference aborts), the host reports it
+    prob2 = str(tmp_path / "q.txt")
+    _write_problem(prob2, pr)
+    exe, plugin = host
+    r = subprocess.run([exe, prob2, plugin, "gn_fix6_3_hip", "1", str(tmp_path / "c.json"), "online:%d" % n_first], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 5 and "Schur not supported" in r.stderr
+
+
+@pytest.mark.parametrize("solver", ["lm_fix6_3_hip", "lm_fix6_3_hipls"])
+def test_a_second_optimize_on_the_same_solver(host, tmp_path, solver):
+    """optimize() twice on one optimizer: buildStructure runs again at the second iteration 0
+    (optimization_algorithm_levenberg.cpp:62-68) and the plugin starts a new graph behind the same handle (wide seam:
+    g2ohip_clear_edge_sets; narrow seam: the pattern is analysed again).  Both runs make progress, nothing fails."""
+    pr = ba_case(10, 120)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr)
+    out, _ = _run(host, prob, solver, 3, str(tmp_path / "t.json"), mode="twice")
+    once, _ = _run(host, prob, solver, 3, str(tmp_path / "o.json"))
+    assert out["iterations"] >= once["iterations"] + 1
+    assert np.allclose(out["chi2"][:once["iterations"]], once["chi2"], rtol=1e-9, atol=0)
+    assert out["chi2"][-1] <= out["chi2"][once["iterations"] - 1] * (1 + 1e-12)

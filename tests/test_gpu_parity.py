@@ -294,6 +294,44 @@ def test_large_scale_properties():
     assert st["hessianPoseDimension"] == 6 * pr["nP"] and st["choleskyNNZ"] > 0
 
 
+def test_update_structure_grows_a_pose_graph_online():
+    """Solver::updateStructure (block_solver.hpp:297-351): the manhattan graph built for its first 3 000 poses, solved, then
+    grown by the remaining poses and edges (g2ohip_update_structure) -- the solution equals the one of a solver built on the
+    whole graph and the reference's golden vector; with a Schur complement the call refuses like the reference."""
+    capi = _capi()
+    g = manhattan_golden()
+    J0, J1, err = O.se2_edges(g["estimates"], g["vi"], g["vj"], g["meas"])
+    h0, h1 = g["hidx"][g["vi"]], g["hidx"][g["vj"]]
+    n0 = 3000
+    first = (h0 < n0) & (h1 < n0)
+    order = np.concatenate([np.nonzero(first)[0], np.nonzero(~first)[0]])
+    nf = int(first.sum())
+    s = capi.HipBlockSolver(3, 2, 0)
+    k = s.addEdgeSet(3, h0[order[:nf]], h1[order[:nf]])
+    s.buildStructure(n0, 0, False)
+    s.setEdgeData(k, J0[order[:nf]], J1[order[:nf]], g["omega"][order[:nf]], err[order[:nf]])
+    s.buildSystem()
+    s.setLambda(float(g["lambda0"]), True)
+    assert s.solve() and len(s.x()) == 3 * n0
+    s.restoreDiagonal()
+    assert s.updateStructure(g["nP"] - n0, k, h0[order[nf:]], h1[order[nf:]])
+    assert len(s.b()) == 3 * g["nP"]
+    s.setEdgeData(k, J0[order], J1[order], g["omega"][order], err[order])
+    s.buildSystem()
+    assert s.nnzb(capi.HPP) == 8949
+    assert relerr(s.b(), g["b0"]) < TOL_MAT
+    s.setLambda(float(g["lambda0"]), True)
+    assert s.solve()
+    assert relerr(s.x(), g["x_lm0"]) < 1e-8
+    s.restoreDiagonal()
+    # vertices only (no edges yet): structure grows, the new diagonal blocks are empty
+    assert s.updateStructure(0)
+    # a system with marginalised vertices: refused (the reference aborts)
+    pr = ba_case(20, 200)
+    sb = hip_ba(pr)
+    assert sb.updateStructure(1) is False
+
+
 @pytest.mark.parametrize("graph", ["manhattan", "sphere"])
 def test_front_kernel_variants_agree_on_the_pose_graphs(graph):
     """Round-3 variants of the LDS-front kernel against the earlier ones on the two golden pose graphs: the forward sweep
