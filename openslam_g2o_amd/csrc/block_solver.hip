@@ -2052,6 +2052,10 @@ BlockSolver::BlockSolver(int p, int l, int device) : p_(p), l_(l), device_(devic
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) num_cus_ = prop.multiProcessorCount;
+    // The code objects are gfx950 only, and the in-launch hand-offs (relaxed agent-scope counters around sc1 data, in-order
+    // workgroup dispatch) are reasoned for that target: refuse anything else instead of failing at the first launch.
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      throw HipFailure(std::string("libg2ohip is built for gfx950 (MI355X); device reports ") + prop.gcnArchName);
   }
   if (!(p == 3 || p == 6 || p == 7)) throw ArgFailure("pose_dim must be 3, 6 or 7");
   if (!(l == 2 || l == 3 || l == 0)) throw ArgFailure("landmark_dim must be 2 or 3");

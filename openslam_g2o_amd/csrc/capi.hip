@@ -488,6 +488,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "wide_front_doubles")) s->impl->chol_opt.wide_front_doubles = (int)value;
   else if (!std::strcmp(name, "big_front_min_dim")) s->impl->chol_opt.big_front_min_dim = (int)value;
   else if (!std::strcmp(name, "dep_spin_limit")) s->impl->chol_opt.dep_spin_limit = (int)value;
+  else if (!std::strcmp(name, "dep_acq_rel")) s->impl->chol_opt.dep_acq_rel = (int)value;
   else if (!std::strcmp(name, "lds_mfma")) s->impl->chol_opt.lds_mfma = (int)value;
   else if (!std::strcmp(name, "fuse_fwd_any")) s->impl->chol_opt.fuse_fwd_any = (int)value;
   else if (!std::strcmp(name, "wave_front_bytes")) s->impl->chol_opt.wave_front_bytes = (size_t)value;
@@ -934,6 +935,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "wide_front_doubles")) ls->opt.wide_front_doubles = (int)value;
   else if (!std::strcmp(name, "big_front_min_dim")) ls->opt.big_front_min_dim = (int)value;
   else if (!std::strcmp(name, "dep_spin_limit")) ls->opt.dep_spin_limit = (int)value;
+  else if (!std::strcmp(name, "dep_acq_rel")) ls->opt.dep_acq_rel = (int)value;
   else if (!std::strcmp(name, "lds_mfma")) ls->opt.lds_mfma = (int)value;
   else if (!std::strcmp(name, "fuse_fwd_any")) ls->opt.fuse_fwd_any = (int)value;
   else if (!std::strcmp(name, "wave_front_bytes")) ls->opt.wave_front_bytes = (size_t)value;

@@ -42,6 +42,7 @@ struct CholOptions {
   int fuse_fwd_any = 1;                  // forward sweep fused into the factor kernel whatever the number / size of a front's children
   int lds_mfma = (4 << 16) | 96;                     // LDS fronts with at least (low 16 bits) boundary rows and (high bits) pivot blocks: pivot steps update the panel only, ONE MFMA rank-npiv
                                          // update of the trailing matrix afterwards (0: off -- every pivot block updates the whole trailing matrix)
+  int dep_acq_rel = 0;                   // A/B validation of the hand-offs: release increment / acquire poll on the factor launches' counters
   int dep_spin_limit = 1 << 21;          // polls (~0.2 us each) before a waiting workgroup gives up and flags status 2
   int big_front_min_dim = 180;           // ... for the launches whose largest front has at least this many rows
   int wide_front_doubles = 5000;         // launches whose largest LDS front has this many packed doubles (100 rows) use 512 threads per front
@@ -154,6 +155,7 @@ struct CholPlanDev {
   int* status;
   int* ready;        // dependency-driven launches: children finished so far, per front
   int dep_spin_limit;
+  int dep_acq_rel;
   int lds_mfma;
   long long* dbg;   // G2OHIP_CHOL_STAMPS builds only: per-launch wall-clock stamps of workgroup 0
   long long* tl;    // ... and (start, end) wall-clock of every workgroup of the wave-kernel launch

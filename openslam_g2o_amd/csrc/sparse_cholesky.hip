@@ -1614,6 +1614,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.status = d_status.p;
   plan_.ready = d_ready.p;
   plan_.dep_spin_limit = opt.dep_spin_limit;
+  plan_.dep_acq_rel = opt.dep_acq_rel;
   plan_.lds_mfma = opt.lds_mfma;
   plan_.dbg = nullptr;
   plan_.tl = nullptr;
@@ -1663,6 +1664,18 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& r) {
 // This relies on gfx9's in-order issue and completion accounting of a wave's vector memory operations (vmcnt) and on sc1
 // accesses being coherent at agent scope; it does not rely on workgroup dispatch order beyond "a child of a task is
 // running or finished when the task starts" (deadlock freedom).
+// Dependency counters of the grouped factor launches.  The product path uses relaxed agent-scope atomics: the data a counter
+// guards is written with sc1 stores that have been acknowledged (s_waitcnt vmcnt(0)) before the increment and read with sc1
+// loads after the poll, so no cache has to be written back or invalidated.  acq_rel (option dep_acq_rel, for A/B
+// validation of that reasoning): the textbook release increment / acquire poll instead, i.e. an L2 write-back and an
+// invalidate per task.
+__device__ __forceinline__ void dep_add(int* c, int v, int acq_rel) {
+  if (acq_rel) (void)__hip_atomic_fetch_add(c, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  else (void)__hip_atomic_fetch_add(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int dep_poll(const int* c, int acq_rel) {
+  return acq_rel ? __hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1844,7 +1857,7 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
     const int dep_wait = dep ? ((rec.pad[1] >> 24) & 0x7f) : 0;
     if (dep_wait > 0 && tid == 0) {
       int spins = 0;
-      while (__hip_atomic_load(P.ready + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < dep_wait) {
+      while (dep_poll(P.ready + f, P.dep_acq_rel) < dep_wait) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > P.dep_spin_limit || ((spins & 255) == 0 && __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
           __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2453,7 +2466,7 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
     if (dep_signal) {
       __builtin_amdgcn_s_waitcnt(0);   // every wave: its own (coherent) U / w stores have been acknowledged
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(P.ready + (rec.pad[1] & 0x00ffffff), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) dep_add(P.ready + (rec.pad[1] & 0x00ffffff), 1, P.dep_acq_rel);
       write_panel();
     }
     __syncthreads();   // F and the LDS tables are reused by the next front of the chain

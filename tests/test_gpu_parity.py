@@ -501,7 +501,7 @@ def test_dependency_driven_launches_and_stall_fallback():
     pr = ba_case(600, 6000)
     xs = []
     cases = ({"dep_levels": 0}, {"dep_levels": 16, "dep_backward": 0}, {"dep_levels": 16, "dep_spin_limit": 0},
-             {"dep_levels": 16}, {"dep_levels": 3, "use_graph": 1})
+             {"dep_levels": 16}, {"dep_levels": 3, "use_graph": 1}, {"dep_levels": 16, "dep_backward": 0, "dep_acq_rel": 1})
     for opts in cases:
         s = hip_ba(pr, options=opts)
         assert s.stats()["numLevels"] >= 4
@@ -518,6 +518,7 @@ def test_dependency_driven_launches_and_stall_fallback():
     # group's workgroup size, which changes the partition (not the terms) of its dot products
     assert np.array_equal(xs[1], xs[0]) and np.array_equal(xs[2], xs[0])
     assert relerr(xs[3], xs[0]) < 1e-13 and relerr(xs[4], xs[0]) < 1e-13
+    assert np.array_equal(xs[5], xs[0])   # release / acquire on the counters instead of relaxed atomics around sc1 data: the same bits
     o = oracle_ba(pr)
     o.build_system()
     o.set_lambda(10.0, True)
