@@ -2931,6 +2931,13 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
           fpre[(a * 2 + b) * 4 + v] = (r < mt && c < mt && r / BS >= c / BS) ? F[(size_t)(n + r) + (size_t)ld * (n + c)] : 0.0;
         }
   }
+#ifdef G2OHIP_CHOL_STAMPS
+  int nst_ = 0;
+#define BSTAMP() do { if (P.dbg && blockIdx.x == gridDim.x - 1 && tid == 0 && nst_ < 40) P.dbg[4 + nst_++] = wall_clock64(); } while (0)
+#else
+#define BSTAMP() do {} while (0)
+#endif
+  BSTAMP();
   if (DEP) {   // the pivot block of this front is factorised by a workgroup of this launch
     if (tid == 0) {
       const int* fl = flag + f;
@@ -2945,6 +2952,7 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
     }
     __syncthreads();
   }
+  BSTAMP();
   {   // L11 and the reciprocal diagonal (written by the pivot-block kernel: the launch before, or -- DEP -- a workgroup of this one)
     constexpr int UL = 16;   // 64 * 64 / 256: element (tid & 63, tid / 64 + 4 u) of a 64 x 64 grid (no integer divisions on this path)
     double t[UL];
@@ -2968,6 +2976,7 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
     }
   }
   __syncthreads();
+  BSTAMP();
   if (fwd_rows) fwd_children_apply<BS>(P, rec, tid, pre, tB, n + td.y * 64, 64, ysl, 0, n);
   if (fwd_rows && (tid >> 6) == 2) {   // wave 2: y = L11^-1 t, next to the row solves of waves 0-1
     const int l = tid & 63;
@@ -3015,6 +3024,7 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
     }
   }
   __syncthreads();
+  BSTAMP();
   if (td.z == 0)   // the tiles of the first tile column write their rows of the panel to L (coalesced, from LDS)
     for (int i = tid; i < 64 * n; i += 256) {
       const int r = i & 63, k = i >> 6;
@@ -3068,6 +3078,11 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
           }
     }
   }
+  __syncthreads();
+  BSTAMP();
+#ifdef G2OHIP_CHOL_STAMPS
+  if (P.dbg && blockIdx.x == gridDim.x - 1 && tid == 0) { P.dbg[0] = nst_; P.dbg[1] = td.y; P.dbg[2] = td.z; P.dbg[3] = n * 1000 + mt; }
+#endif
 }
 
 template <int BS, bool FWD>
@@ -3656,7 +3671,7 @@ __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const i
   double* L11s = lds + 512;   // (FWD only)
   double* lis = L11s + 64 * 65;
   double* tJ = lis + 64;
-  constexpr int T = 4, NT = 10, NW = 4, OWN = 3;
+  constexpr int T = 4, NT = 10;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int f = P.slots[slot].x;
@@ -3673,122 +3688,116 @@ __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const i
     fwd_children_prefetch<BS>(P, rec, tid, pre);
     if (tid < n) bJ = bperm[(size_t)rec.c0 * BS + tid];
   }
-  int oti[OWN], otj[OWN];
-#pragma unroll
-  for (int k = 0; k < OWN; ++k) {
-    const int q = w + NW * k;
-    int tj = 0;
-#pragma unroll
-    for (int c = 1; c < T; ++c)
-      if (q >= c * (c + 1) / 2) tj = c;
-    oti[k] = q < NT ? q - tj * (tj + 1) / 2 : T;
-    otj[k] = q < NT ? tj : T;
-  }
-  wv_d4 S[OWN];
-#pragma unroll
-  for (int k = 0; k < OWN; ++k)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int r = 16 * oti[k] + lk + 4 * v, c = 16 * otj[k] + lr;
-      const int a = min(r, c), b = max(r, c);                       // F holds the lower triangle
-      S[k][v] = (otj[k] < T && b < n) ? F[(size_t)b + (size_t)ld * a] : 0.0;
-    }
+  // ONE wave factorises the pivot block (n <= 64: the ten upper 16 x 16 tiles in its registers), the others go on to the
+  // barrier: no LDS, no barrier inside a 4-column step -- the 4 x 4 pivot block comes through v_readlane, the scaled panel
+  // rows are register 0 of an MFMA and at once the operand of the update (the k-block of band_chain.inc; four waves with
+  // two barriers per step took 1.25 us per step, this one 0.5).  Tile (ti, tj), ti <= tj, is S[tj (tj + 1) / 2 + ti].
   bool bad = false;
+  if (w == 0) {
+    wv_d4 S[NT];
 #pragma unroll
-  for (int kb = 0; kb < 16; ++kb) {
-    const int k0 = 4 * kb;
-    if (k0 < n) {   // (uniform)
-      const int tk = k0 >> 4, vk = (k0 & 15) >> 2, c16 = k0 & 15;
+    for (int tj = 0; tj < T; ++tj)
 #pragma unroll
-      for (int k = 0; k < OWN; ++k)
-        if (oti[k] == tk) Rb[otj[k] * 64 + lane] = S[k][vk];
-      __syncthreads();
-      // 4 x 4 pivot block (every lane): D = Ld Ld', W = Ld^-1; this lane's element of the A operand, sqrt and reciprocal
-      double D[4][4], Ld[4][4], rs[4], sq[4], W[4][4];
+      for (int ti = 0; ti <= tj; ++ti)
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = a; b < 4; ++b) D[a][b] = Rb[tk * 64 + (c16 + b) + 16 * a];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (k0 + j < n) {
-          double d = D[j][j];
-          if (!(d > 0.0)) {
-            bad = true;
-            d = 1.0;
-          }
-          sqrt_and_rsqrt(d, sq[j], rs[j]);
-#pragma unroll
-          for (int i = j + 1; i < 4; ++i) Ld[i][j] = D[j][i] * rs[j];
-#pragma unroll
-          for (int c = j + 1; c < 4; ++c)
-#pragma unroll
-            for (int i = c; i < 4; ++i) D[c][i] -= Ld[i][j] * Ld[c][j];
-        } else {
-          sq[j] = 0.0;
-          rs[j] = 0.0;
-#pragma unroll
-          for (int i = j + 1; i < 4; ++i) Ld[i][j] = 0.0;
+        for (int v = 0; v < 4; ++v) {
+          const int r = 16 * ti + lk + 4 * v, c = 16 * tj + lr;
+          const int a = min(r, c), b = max(r, c);                       // F holds the lower triangle
+          S[tj * (tj + 1) / 2 + ti][v] = (b < n) ? F[(size_t)b + (size_t)ld * a] : 0.0;
         }
-      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        W[j][j] = rs[j];
+    for (int kb = 0; kb < 16; ++kb) {
+      const int k0 = 4 * kb;
+      if (k0 < n) {   // (uniform)
+        const int tk = k0 >> 4, vk = (k0 & 15) >> 2, c16 = k0 & 15;
+        const int qd = tk * (tk + 1) / 2 + tk;
+        // 4 x 4 pivot block (uniform values): D = Ld Ld', W = Ld^-1
+        double D[4][4], Ld[4][4], rs[4], sq[4], W[4][4];
 #pragma unroll
-        for (int i = j + 1; i < 4; ++i) {
-          double s_ = 0.0;
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int k = j; k < i; ++k) s_ += Ld[i][k] * W[k][j];
-          W[i][j] = -rs[i] * s_;
-        }
-      }
-      double aop = 0.0, sqsel = 0.0, rssel = 0.0;
+          for (int b = a; b < 4; ++b) D[a][b] = readlane_f64(S[qd][vk], (c16 + b) + 16 * a);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          if (k0 + j < n) {
+            double d = D[j][j];
+            if (!(d > 0.0)) {
+              bad = true;
+              d = 1.0;
+            }
+            sqrt_and_rsqrt(d, sq[j], rs[j]);
 #pragma unroll
-        for (int k = 0; k <= i; ++k)
-          if (lr == i && lk == k) aop = W[i][k];
+            for (int i = j + 1; i < 4; ++i) Ld[i][j] = D[j][i] * rs[j];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (lk == k) {
-          sqsel = sq[k];
-          rssel = rs[k];
-        }
-      const int col = k0 + lk;
-      if (w == 0 && lr == 0 && col < n) {
-        if (COH) st_coh(Lg + (size_t)m * n + col, rssel);
-        else Lg[(size_t)m * n + col] = rssel;
-      }
+            for (int c = j + 1; c < 4; ++c)
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        if ((t & (NW - 1)) == w && 16 * t < n) {
-          const int row = 16 * t + lr;
-          double v = 0.0;                                                     // (above the diagonal: zeros)
-          if (t >= tk) {
-            const wv_d4 r = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Rb[t * 64 + lane], wv_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-            Lb[t * 64 + lane] = r[0];
-            v = r[0];
-            if (t == tk) v = row > col ? v : (row == col ? sqsel : 0.0);
-          }
-          if (col < n && row < n) {
-            if (COH) st_coh(Lg + (size_t)row + (size_t)m * col, v);
-            else Lg[(size_t)row + (size_t)m * col] = v;
-            F[(size_t)row + (size_t)ld * col] = v;
+              for (int i = c; i < 4; ++i) D[c][i] -= Ld[i][j] * Ld[c][j];
+          } else {
+            sq[j] = 0.0;
+            rs[j] = 0.0;
+#pragma unroll
+            for (int i = j + 1; i < 4; ++i) Ld[i][j] = 0.0;
           }
         }
-      }
-      __syncthreads();
-      double la[OWN], lb_[OWN];
 #pragma unroll
-      for (int k = 0; k < OWN; ++k) {
-        la[k] = Lb[min(oti[k], T - 1) * 64 + lane];
-        lb_[k] = Lb[min(otj[k], T - 1) * 64 + lane];
-      }
+        for (int j = 0; j < 4; ++j) {
+          W[j][j] = rs[j];
 #pragma unroll
-      for (int k = 0; k < OWN; ++k)
-        if (oti[k] >= tk && otj[k] < T && 16 * otj[k] < n) S[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv_neg(la[k]), lb_[k], S[k], 0, 0, 0);
+          for (int i = j + 1; i < 4; ++i) {
+            double s_ = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) s_ += Ld[i][k] * W[k][j];
+            W[i][j] = -rs[i] * s_;
+          }
+        }
+        double aop = 0.0, sqsel = 0.0, rssel = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int k = 0; k <= i; ++k)
+            if (lr == i && lk == k) aop = W[i][k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (lk == k) {
+            sqsel = sq[k];
+            rssel = rs[k];
+          }
+        const int col = k0 + lk;
+        if (lr == 0 && col < n) {
+          if (COH) st_coh(Lg + (size_t)m * n + col, rssel);
+          else Lg[(size_t)m * n + col] = rssel;
+        }
+        double Lp[T];   // scaled panel rows of the tile columns: operand layout of the update
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          Lp[t] = 0.0;
+          if (16 * t < n) {
+            const int row = 16 * t + lr;
+            double v = 0.0;                                                     // (above the diagonal: zeros)
+            if (t >= tk) {
+              const wv_d4 r = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, S[t * (t + 1) / 2 + tk][vk], wv_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+              Lp[t] = r[0];
+              v = r[0];
+              if (t == tk) v = row > col ? v : (row == col ? sqsel : 0.0);
+            }
+            if (col < n && row < n) {
+              if (COH) st_coh(Lg + (size_t)row + (size_t)m * col, v);
+              else Lg[(size_t)row + (size_t)m * col] = v;
+              F[(size_t)row + (size_t)ld * col] = v;
+            }
+          }
+        }
+#pragma unroll
+        for (int tj = 0; tj < T; ++tj)
+#pragma unroll
+          for (int ti = 0; ti <= tj; ++ti)
+            if (ti >= tk && 16 * tj < n)
+              S[tj * (tj + 1) / 2 + ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv_neg(Lp[ti]), Lp[tj], S[tj * (tj + 1) / 2 + ti], 0, 0, 0);
+      }
     }
   }
+  (void)Rb;
+  (void)Lb;
   if (bad && lane == 0) atomicMax(P.status, 1);
   if (fwd_here) {
     if (tid < 64) tJ[tid] = bJ;
