@@ -546,15 +546,23 @@ __device__ __forceinline__ void schur_tile_dests(const double* Bs, const double*
   // (fixed order: deterministic).  Partial block layout in Pd: [row part][column][row inside the part].
   constexpr int GC = (PD % 2 == 0 && G >= 2) ? 2 : 1, GE = G / GC, NR = PD / GC;
   static_assert(GE == 1 || GE == 2 || GE == 4 || GE == 8 || (GC == 1 && GE == 16), "unsupported lane group");
+  // GE <= 4 with the row split: the entry parts are the two LOW lane bits (gc is bit 2), so both steps of the sum are quad
+  // permutations -- one DPP move per half register instead of two for the lane ^ 4 step
+  constexpr bool QUAD = GC == 2 && (GE == 2 || GE == 4);
   auto ge_sum = [](double v) {   // sum over the GE lanes that share gc
     if (GC == 1) return group_sum<GE>(v);
+    if (QUAD) {
+      v += dpp_permute<0xB1>(v);                                     // lane ^ 1
+      if (GE == 4) v += dpp_permute<0x4E>(v);                        // lane ^ 2
+      return v;
+    }
     v += dpp_permute<0x4E>(v);                                       // lane ^ 2
     if (GE >= 4) v += dpp_permute<0x141>(dpp_permute<0x1B>(v));      // lane ^ 4 = (lane ^ 3) ^ 7
     if (GE >= 8) v += dpp_permute<0x128>(v);                         // row_ror:8 = lane ^ 8 inside a 16-lane row
     return v;
   };
   const int grp = tid / G, g = tid % G, ngroups = NT / G;
-  const int gc = g % GC, ge = g / GC;
+  const int gc = QUAD ? g / GE : g % GC, ge = QUAD ? g % GE : g / GC;
   for (int ld = td0 + grp; ld < td1; ld += ngroups) {
     double acc[NR * PD], cacc[NR];   // acc[rr + NR * c]: row gc*NR + rr, column c
 #pragma unroll
