@@ -1281,9 +1281,9 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
         const int krel = ent & 0xfff, K = (ent >> 12) & 0xff, lmi = (ent >> 20) & 0x7ff;   // (lmi: position in the list on the other lanes)
         const bool has = krel != 0xfff, head = ent >= 0;
         const int pos = head ? 0 : lmi;
-        double v[12];   // H (9) | b (3)
+        double v[9];   // lower triangle of H (6: the block is symmetric) | b (3)
 #pragma unroll
-        for (int i = 0; i < 12; ++i) v[i] = 0.0;
+        for (int i = 0; i < 9; ++i) v[i] = 0.0;
         {
           const int ci = rc.y, pi = rc.z, q = rc.w, e = ll_edge[sg];
           double T[12], X[3], z2[2], Op[4];
@@ -1306,10 +1306,9 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
             for (int i = 0; i < 9; ++i) H[i] = 0.0;
             b[0] = b[1] = b[2] = 0.0;
             ba_lm_accumulate(L, H, b, OA);
+            v[0] = H[0]; v[1] = H[1]; v[2] = H[2]; v[3] = H[4]; v[4] = H[5]; v[5] = H[8];   // (column-major lower triangle)
 #pragma unroll
-            for (int i = 0; i < 9; ++i) v[i] = H[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) v[9 + i] = b[i];
+            for (int i = 0; i < 3; ++i) v[6 + i] = b[i];
             if (q >= 0) {
               double blk[18];
               ba_hpl_block(L, OA, blk);
@@ -1321,11 +1320,11 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
         // entries from its own on (fixed tree: deterministic); as many steps as the longest list of this WAVE needs
         for (int d = 1; __any(pos + d < K); d <<= 1) {
           const bool take = pos + d < K;
-          double o[12];   // (all twelve exchanges in flight at once, then branch-free adds)
+          double o[9];   // (all nine exchanges in flight at once, then branch-free adds)
 #pragma unroll
-          for (int i = 0; i < 12; ++i) o[i] = __shfl_down(v[i], d);
+          for (int i = 0; i < 9; ++i) o[i] = __shfl_down(v[i], d);
 #pragma unroll
-          for (int i = 0; i < 12; ++i) v[i] += take ? o[i] : 0.0;
+          for (int i = 0; i < 9; ++i) v[i] += take ? o[i] : 0.0;
         }
         // The list head inverts the damped block (block_solver.hpp:386-389) and splits the inverse (schur_tile_prepare's
         // comment); the lanes of the list fetch C from it and turn their staged block into V = B C on the spot: no pass over
@@ -1336,19 +1335,20 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
         if (head) {
           const int lm = l0 + lmi;
           double* bd = bl + (size_t)lm * 3;
+          double Hf[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
           if (store_hll & 1) {
             double* hd = Hll + (size_t)lm * 9;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) hd[i] = v[i];
+            for (int i = 0; i < 9; ++i) hd[i] = Hf[i];
           }
 #pragma unroll
-          for (int i = 0; i < 3; ++i) bd[i] = v[9 + i];
+          for (int i = 0; i < 3; ++i) bd[i] = v[6 + i];
           double R[9], sg[3], u[3];
           const double lambda = lam[1];
-          v[0] += lambda; v[4] += lambda; v[8] += lambda;
-          small_inverse<3>(v, R);
+          Hf[0] += lambda; Hf[4] += lambda; Hf[8] += lambda;
+          small_inverse<3>(Hf, R);
           store_vec<9>(Dinv + (size_t)lm * 9, R);
-          if (landmark_split<3>(R, v + 9, C, sg, u)) neg_flag[tid >> 6] = 1;
+          if (landmark_split<3>(R, v + 6, C, sg, u)) neg_flag[tid >> 6] = 1;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             Cs[lmi * TileSplit<3>::CP + 9 + i] = sg[i];
