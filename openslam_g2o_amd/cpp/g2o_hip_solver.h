@@ -30,6 +30,7 @@
 #include "g2o/core/sparse_optimizer.h"
 #include "g2o/stuff/timeutil.h"
 #include "g2o/types/sba/types_six_dof_expmap.h"   // EdgeProjectXYZ2UV, VertexSE3Expmap, VertexSBAPointXYZ (device fast path)
+#include "g2o/types/slam2d/edge_se2.h"            // EdgeSE2, VertexSE2 (device fast path for planar pose graphs)
 #include "g2ohip.h"
 
 namespace g2o {
@@ -51,7 +52,7 @@ namespace g2o {
 template <int p, int l>
 class BlockSolverHip : public BlockSolverBase {
  public:
-  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroup(-1) {
+  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroup(-1), _fastKind(0) {
     const char* fp = std::getenv("G2OHIP_ADAPTER_FASTPATH");
     if (fp && fp[0] == '0') _fastPath = false;
     if (g2ohip_create(&_h, p, l, device) != G2OHIP_OK) {
@@ -154,9 +155,17 @@ class BlockSolverHip : public BlockSolverBase {
     resizeVector(g2ohip_vector_size(_h));              // Solver::_x, _b (solver.cpp:46-70)
     _diag.assign(g2ohip_vector_size(_h), 0.0);
     _fastGroup = -1;
+    _fastKind = 0;
     if (_fastPath)
-      for (size_t gi = 0; gi < _groups.size() && _fastGroup < 0; ++gi)
-        if (bindProjectXYZ2UV(_groups[gi])) _fastGroup = (int)gi;
+      for (size_t gi = 0; gi < _groups.size() && _fastGroup < 0; ++gi) {
+        if (bindProjectXYZ2UV(_groups[gi])) {
+          _fastGroup = (int)gi;
+          _fastKind = 1;
+        } else if (bindSE2(_groups[gi])) {
+          _fastGroup = (int)gi;
+          _fastKind = 2;
+        }
+      }
     return true;
   }
 
@@ -190,7 +199,7 @@ class BlockSolverHip : public BlockSolverBase {
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       Group& g = _groups[gi];
       if ((int)gi == _fastGroup) {                     // estimates up, errors + Jacobians on the device
-        if (!uploadEstimates()) return false;
+        if (!(_fastKind == 2 ? uploadPosesSE2() : uploadEstimates())) return false;
         continue;
       }
       const int d = g.key.d, d0 = g.key.dim0, d1 = g.key.dim1;
@@ -405,6 +414,60 @@ class BlockSolverHip : public BlockSolverBase {
 
   // setEstimate of every camera (R column-major | t, world -> camera as VertexSE3Expmap holds it) and point, then the
   // device evaluates errors and Jacobians (computeActiveErrors + linearizeOplus of the group)
+  // A homogeneous group of EdgeSE2 over VertexSE2 (types/slam2d/edge_se2.h:41-57, vertex_se2.h:41-59; p = 3): error,
+  // Jacobians (edge_se2.cpp:76-99) and the quadratic forms are evaluated on the device from the estimates (x, y, theta) --
+  // g2ohip_pg_* with type 1.  The types are recognised by typeid: no member of them is called that is not inline.
+  bool bindSE2(Group& g) {
+    if (p != 3 || g.key.d != 3 || g.key.dim0 != 3 || g.key.dim1 != 3 || g.edges.empty()) return false;
+    for (size_t k = 0; k < g.edges.size(); ++k) {
+      if (typeid(*g.edges[k]) != typeid(EdgeSE2)) return false;
+      if (typeid(*g.edges[k]->vertex(0)) != typeid(VertexSE2) || typeid(*g.edges[k]->vertex(1)) != typeid(VertexSE2)) return false;
+    }
+    _pgVerts.clear();
+    std::map<const HyperGraph::Vertex*, int> index;
+    const size_t n = g.edges.size();
+    std::vector<int32_t> vi(n), vj(n);
+    std::vector<double> meas(3 * n), info(9 * n);
+    for (size_t k = 0; k < n; ++k) {
+      EdgeSE2* e = static_cast<EdgeSE2*>(g.edges[k]);
+      for (int side = 0; side < 2; ++side) {
+        VertexSE2* v = static_cast<VertexSE2*>(e->vertex(side));
+        std::map<const HyperGraph::Vertex*, int>::iterator it = index.find(v);
+        if (it == index.end()) {
+          it = index.insert(std::make_pair((const HyperGraph::Vertex*)v, (int)_pgVerts.size())).first;
+          _pgVerts.push_back(v);
+        }
+        (side ? vj : vi)[k] = it->second;
+      }
+      meas[3 * k] = e->measurement().translation()[0];
+      meas[3 * k + 1] = e->measurement().translation()[1];
+      meas[3 * k + 2] = e->measurement().rotation().angle();
+      const double* om = e->informationData();            // 3 x 3, column-major
+      for (int q = 0; q < 9; ++q) info[9 * k + q] = om[q];
+    }
+    _pgHidx.resize(_pgVerts.size());
+    for (size_t i = 0; i < _pgVerts.size(); ++i) _pgHidx[i] = _pgVerts[i]->hessianIndex();
+    _pgBuf.assign(3 * _pgVerts.size(), 0.0);
+    if (g2ohip_pg_set_edges(_h, g.set, 1, vi.data(), vj.data(), meas.data(), info.data()) != G2OHIP_OK) {
+      std::cerr << "BlockSolverHip: fast path not available (" << g2ohip_last_error() << "), using the generic path" << std::endl;
+      return false;
+    }
+    if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
+      std::cerr << "BlockSolverHip: device fast path for " << n << " EdgeSE2 edges over " << _pgVerts.size() << " vertices" << std::endl;
+    return true;
+  }
+  bool uploadPosesSE2() {
+    for (size_t i = 0; i < _pgVerts.size(); ++i) {
+      const SE2& T = _pgVerts[i]->estimate();
+      _pgBuf[3 * i] = T.translation()[0];
+      _pgBuf[3 * i + 1] = T.translation()[1];
+      _pgBuf[3 * i + 2] = T.rotation().angle();
+    }
+    if (g2ohip_pg_set_estimates(_h, (int)_pgVerts.size(), _pgBuf.data(), _pgHidx.data()) != G2OHIP_OK) return fail("pg_set_estimates");
+    if (g2ohip_pg_linearize(_h, 1) != G2OHIP_OK) return fail("pg_linearize");
+    return true;
+  }
+
   bool uploadEstimates() {
     for (size_t i = 0; i < _cams.size(); ++i) {
       const SE3Quat& T = _cams[i]->estimate();
@@ -429,6 +492,10 @@ class BlockSolverHip : public BlockSolverBase {
   std::vector<double> _diagMirror, _diag;
   bool _fastPath;
   int _fastGroup;                                      // index into _groups of the group on the device front end, or -1
+  int _fastKind;                                       // 1: EdgeProjectXYZ2UV (g2ohip_ba_*), 2: EdgeSE2 (g2ohip_pg_*, type 1)
+  std::vector<VertexSE2*> _pgVerts;
+  std::vector<int32_t> _pgHidx;
+  std::vector<double> _pgBuf;
   std::vector<VertexSE3Expmap*> _cams;
   std::vector<VertexSBAPointXYZ*> _points;
   std::vector<int32_t> _camHidx, _pointHidx;

@@ -6,6 +6,8 @@
 //   g2o_host <problem.txt> <plugin.so> <solver name> <iterations> <out.json> [marginals]
 // problem.txt: ncams npts nedges f cx cy huber_delta | per camera: fixed R(9, column-major) t(3) | per point: fixed xyz | per
 // edge: cam point u v
+//   g2o_host <graph.txt> <plugin.so> <solver name> <iterations> <out.json> se2
+// graph.txt (planar pose graph): nverts nedges | per vertex: fixed x y theta | per edge: i j x y theta info(9, column-major)
 #include <dlfcn.h>
 
 #include <cstdio>
@@ -15,6 +17,7 @@
 #include <sstream>
 
 #include "g2o/types/sba/types_six_dof_expmap.h"
+#include "g2o/types/slam2d/edge_se2.h"
 
 using namespace g2o;
 
@@ -47,6 +50,73 @@ int main(int argc, char** argv) {
     std::cerr << "solver " << solverName << " is not registered; known:" << std::endl;
     OptimizationAlgorithmFactory::instance()->listSolvers(std::cerr);
     return 3;
+  }
+  if (argc > 6 && std::string(argv[6]) == "se2") {
+    // ---- planar pose graph (config 1: VertexSE2 / EdgeSE2, BlockSolver_3_2 shape, no marginalised vertex)
+    std::ifstream in(argv[1]);
+    int nv, ne;
+    in >> nv >> ne;
+    SparseOptimizer optimizer;
+    std::vector<VertexSE2*> verts(nv);
+    for (int i = 0; i < nv; ++i) {
+      int fixed;
+      double x, y, th;
+      in >> fixed >> x >> y >> th;
+      VertexSE2* v = new VertexSE2();
+      v->setId(i);
+      v->setFixed(fixed != 0);
+      v->setEstimate(SE2(x, y, th));
+      optimizer.addVertex(v);
+      verts[i] = v;
+    }
+    for (int k = 0; k < ne; ++k) {
+      int i, j;
+      double x, y, th;
+      in >> i >> j >> x >> y >> th;
+      EdgeSE2::InformationType info;
+      for (int q = 0; q < 9; ++q) in >> info.data()[q];
+      EdgeSE2* e = new EdgeSE2();
+      e->setVertex(0, verts[i]);
+      e->setVertex(1, verts[j]);
+      e->setMeasurement(SE2(x, y, th));
+      e->setInformation(info);
+      optimizer.addEdge(e);
+    }
+    if (!in) {
+      std::cerr << "graph file truncated" << std::endl;
+      return 2;
+    }
+    optimizer.setAlgorithm(algo);
+    optimizer.initializeOptimization();
+    if (!algo->init()) return 4;
+    OptimizationAlgorithmLevenberg* lm = dynamic_cast<OptimizationAlgorithmLevenberg*>(algo);
+    std::vector<double> chis, lams;
+    optimizer.computeActiveErrors();
+    const double chi0 = optimizer.activeRobustChi2();
+    int done = 0;
+    for (int i = 0; i < iterations; ++i) {
+      const OptimizationAlgorithm::SolverResult r = algo->solve(i);
+      if (r == OptimizationAlgorithm::Fail) break;
+      optimizer.computeActiveErrors();
+      chis.push_back(optimizer.activeRobustChi2());
+      lams.push_back(lm ? lm->currentLambda() : 0.0);
+      ++done;
+      if (r == OptimizationAlgorithm::Terminate) break;
+    }
+    std::ostringstream js;
+    js << std::setprecision(17);
+    js << "{\"solver\": \"" << solverName << "\", \"iterations\": " << done << ", \"chi2_initial\": " << chi0 << ", \"chi2\": [";
+    for (size_t i = 0; i < chis.size(); ++i) js << (i ? ", " : "") << chis[i];
+    js << "], \"lambda\": [";
+    for (size_t i = 0; i < lams.size(); ++i) js << (i ? ", " : "") << lams[i];
+    js << "], \"poses\": [";
+    for (int i = 0; i < nv; ++i) {
+      const Vector3d v = verts[i]->estimate().toVector();
+      js << (i ? ", " : "") << v[0] << ", " << v[1] << ", " << v[2];
+    }
+    js << "]}";
+    std::ofstream(argv[5]) << js.str() << std::endl;
+    return 0;
   }
   // ---- graph
   std::ifstream in(argv[1]);

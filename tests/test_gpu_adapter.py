@@ -180,3 +180,40 @@ def test_a_second_optimize_on_the_same_solver(host, tmp_path, solver):
     assert out["iterations"] >= once["iterations"] + 1
     assert np.allclose(out["chi2"][:once["iterations"]], once["chi2"], rtol=1e-9, atol=0)
     assert out["chi2"][-1] <= out["chi2"][once["iterations"] - 1] * (1 + 1e-12)
+
+
+@pytest.mark.parametrize("solver", ["gn_fix3_2_hip", "lm_fix3_2_hip", "lm_fix3_2_hipls"])
+def test_planar_pose_graph_through_the_g2o_vtables(host, tmp_path, solver):
+    """BASELINE.json config 1 (manhattan3500: VertexSE2 / EdgeSE2, BlockSolver_3_2 shape, no Schur complement) through the
+    plugin: found by name, driven through the OptimizationAlgorithm -> Solver vtables.  The wide seam runs twice -- the
+    device fast path (EdgeSE2 groups bound to g2ohip_pg_*: only the estimates cross PCIe) and the generic path (the host's
+    linearizeOplus, Jacobians uploaded) -- and the narrow seam once; Gauss-Newton reproduces the reference's chi2 trajectory
+    (golden vectors of the reference's own CSparse run), Levenberg-Marquardt descends monotonically towards the known optimum."""
+    from tests.helpers import manhattan_golden
+    g = manhattan_golden()
+    path = str(tmp_path / "m.txt")
+    with open(path, "w") as f:
+        nv, ne = len(g["estimates"]), len(g["vi"])
+        f.write("%d %d\n" % (nv, ne))
+        for i in range(nv):
+            f.write("%d %s\n" % (1 if g["hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in g["estimates"][i])))
+        for k in range(ne):
+            f.write("%d %d %s %s\n" % (g["vi"][k], g["vj"][k], " ".join("%.17g" % v for v in g["meas"][k]),
+                                       " ".join("%.17g" % v for v in np.asarray(g["omega"][k]).reshape(-1))))
+    runs = []
+    for env in (({}, {"G2OHIP_ADAPTER_FASTPATH": "0"}) if solver.endswith("_hip") else ({},)):
+        out, err = _run(host, path, solver, 8 if solver.startswith("lm") else 4, str(tmp_path / "o.json"), env, mode="se2")
+        if solver.endswith("_hip"):
+            assert ("device fast path for" in err) == (not env)
+        runs.append(out)
+    for out in runs:
+        if solver.startswith("gn"):
+            assert out["iterations"] == 4
+            assert abs(out["chi2_initial"] - g["chi2_gn"][0]) <= 1e-6 * g["chi2_gn"][0]
+            assert np.allclose(out["chi2"], g["chi2_gn"][1:5], rtol=1e-6, atol=0)
+        else:
+            assert out["chi2"][-1] < 0.05 * out["chi2_initial"] and all(b <= a * (1 + 1e-12) for a, b in zip(out["chi2"], out["chi2"][1:]))
+            # (5 668 -> 175 in eight iterations; the optimum of this file is 146.08)
+    if len(runs) == 2:      # fast path == generic path
+        assert np.allclose(runs[0]["chi2"], runs[1]["chi2"], rtol=1e-9, atol=0)
+        assert np.abs(np.array(runs[0]["poses"]) - np.array(runs[1]["poses"])).max() < 1e-7
