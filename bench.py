@@ -337,9 +337,18 @@ def main():
     pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % r) for r in (9, 8, 7, 6, 5, 4, 3, 2, 1))
                      if os.path.exists(q)), "")
     if pmc_path and world == 1 and (P, L) == (100000, 1000000):
-        pmc = json.load(open(pmc_path)).get(dname)
+        pmc_all = json.load(open(pmc_path))
+        pmc = pmc_all.get(dname)
         if pmc:
             traffic = pmc["hbm_bytes_per_step"]
+        # next to the rate of WORK (un-fused algorithmic bytes / time, which a fused kernel can push past what any copy
+        # reaches) the rate of TRAFFIC the counters saw for the same kernel: bytes actually moved / time
+        for name, row in per_kernel.items():
+            q = pmc_all.get(name)
+            if isinstance(q, dict) and row["avg_ms"] > 0:
+                per_launch = q["hbm_bytes_per_step"] / max(row["launches_per_step"], 1e-9)   # (per launch of the SLOT, like avg_ms)
+                row["pmc_traffic_GB"] = per_launch / 1e9
+                row["pmc_GBs"] = per_launch / 1e9 / (1e-3 * row["avg_ms"])
     roofline = dict(kernel=dname, bound="hbm", achieved=dk["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=dk["achieved_GBs"] / HBM_PEAK_GBS, traffic=traffic,
                     algorithmic_bytes_per_launch=kb.get(dname, 0), avg_launch_ms=dk["avg_ms"],
