@@ -294,6 +294,53 @@ def test_large_scale_properties():
     assert st["hessianPoseDimension"] == 6 * pr["nP"] and st["choleskyNNZ"] > 0
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_indefinite_landmark_blocks_take_the_signed_split(fused):
+    """block_solver.hpp:563-604 allows negative damping.  With the landmark diagonal damped by a NEGATIVE value between the
+    eigenvalues of the landmark blocks, Dinv is indefinite: the Schur tiles' symmetric split Dinv = C Sg C' then carries
+    signs (Sg != I, the per-tile flag path).  A large pose damping keeps the reduced system positive definite, so the solve
+    succeeds and must equal the oracle's and a dense solve of the full damped system."""
+    pr = ba_case(40, 400)
+    s = hip_ba(pr) if fused else hip_ba(pr, options={"ba_fused": 0})
+    o = oracle_ba(pr)
+    s.buildSystem()
+    o.build_system()
+    Hll = o.values("Hll").reshape(-1, 3, 3)
+    ev = np.linalg.eigvalsh(Hll)
+    # -lam_l inside the widest gap of the eigenvalue spectrum that still splits the eigenvalues of >= 50 blocks (no block
+    # gets close to singular), and a pose damping that dominates B Dinv B'
+    allev = np.sort(ev.reshape(-1))
+    best = None
+    for a, b in zip(allev[:-1], allev[1:]):
+        mid = 0.5 * (a + b)
+        indef = int(((ev[:, 0] < mid) & (ev[:, 2] > mid)).sum())
+        if indef >= 50 and (best is None or (b - a) / mid > best[0]):
+            best = ((b - a) / mid, mid, indef)
+    assert best is not None
+    lam_l = -float(best[1])
+    gap = float(np.abs(ev + lam_l).min())
+    Hd = o.dense_full()
+    lam_p = 100.0 * float(np.abs(Hd).max()) ** 2 / gap
+    H = Hd.copy()
+    nP6 = 6 * o.nP
+    H[np.arange(nP6), np.arange(nP6)] += lam_p
+    H[np.arange(nP6, H.shape[0]), np.arange(nP6, H.shape[0])] += lam_l
+    xd = np.linalg.solve(H, o.b())
+    s.setLambdaSplit(lam_p, lam_l, True)
+    o.set_lambda_split(lam_p, lam_l, True)
+    assert s.solve() and o.solve()
+    s.restoreDiagonal()
+    tol = 1e-9 * max(1.0, float(np.abs(Hd).max()) / gap)         # (conditioning of the damped landmark blocks)
+    assert relerr(o.x(), xd) < tol
+    assert relerr(s.x(), xd) < tol and relerr(s.x(), o.x()) < tol
+    # and back to an ordinary solve afterwards (the flag is per solve)
+    s.setLambda(5.0, True)
+    o.restore_diagonal()
+    o.set_lambda(5.0, True)
+    assert s.solve() and o.solve()
+    assert relerr(s.x(), o.x()) < 1e-9
+
+
 def test_update_structure_grows_a_pose_graph_online():
     """Solver::updateStructure (block_solver.hpp:297-351): the manhattan graph built for its first 3 000 poses, solved, then
     grown by the remaining poses and edges (g2ohip_update_structure) -- the solution equals the one of a solver built on the
