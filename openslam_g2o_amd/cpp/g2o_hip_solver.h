@@ -31,6 +31,7 @@
 #include "g2o/stuff/timeutil.h"
 #include "g2o/types/sba/types_six_dof_expmap.h"   // EdgeProjectXYZ2UV, VertexSE3Expmap, VertexSBAPointXYZ (device fast path)
 #include "g2o/types/slam2d/edge_se2.h"            // EdgeSE2, VertexSE2 (device fast path for planar pose graphs)
+#include "g2o/types/slam3d/edge_se3.h"            // EdgeSE3, VertexSE3 (device fast path for 3-D pose graphs)
 #include "g2ohip.h"
 
 namespace g2o {
@@ -164,6 +165,9 @@ class BlockSolverHip : public BlockSolverBase {
         } else if (bindSE2(_groups[gi])) {
           _fastGroup = (int)gi;
           _fastKind = 2;
+        } else if (bindSE3(_groups[gi])) {
+          _fastGroup = (int)gi;
+          _fastKind = 3;
         }
       }
     return true;
@@ -199,7 +203,7 @@ class BlockSolverHip : public BlockSolverBase {
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       Group& g = _groups[gi];
       if ((int)gi == _fastGroup) {                     // estimates up, errors + Jacobians on the device
-        if (!(_fastKind == 2 ? uploadPosesSE2() : uploadEstimates())) return false;
+        if (!(_fastKind == 2 ? uploadPosesSE2() : (_fastKind == 3 ? uploadPosesSE3() : uploadEstimates()))) return false;
         continue;
       }
       const int d = g.key.d, d0 = g.key.dim0, d1 = g.key.dim1;
@@ -468,6 +472,57 @@ class BlockSolverHip : public BlockSolverBase {
     return true;
   }
 
+  // A homogeneous group of EdgeSE3 over VertexSE3 (types/slam3d/edge_se3.cpp:48-75, vertex_se3.h:107-116; p = 6): g2ohip_pg_*
+  // with type 2, estimates and measurements as isometries [12] = R (column-major) | t.
+  static void isometryTo12(const Eigen::Isometry3d& T, double* c) {
+    for (int col = 0; col < 3; ++col)
+      for (int row = 0; row < 3; ++row) c[row + 3 * col] = T.linear()(row, col);
+    for (int row = 0; row < 3; ++row) c[9 + row] = T.translation()[row];
+  }
+  bool bindSE3(Group& g) {
+    if (p != 6 || g.key.d != 6 || g.key.dim0 != 6 || g.key.dim1 != 6 || g.edges.empty()) return false;
+    for (size_t k = 0; k < g.edges.size(); ++k) {
+      if (typeid(*g.edges[k]) != typeid(EdgeSE3)) return false;
+      if (typeid(*g.edges[k]->vertex(0)) != typeid(VertexSE3) || typeid(*g.edges[k]->vertex(1)) != typeid(VertexSE3)) return false;
+    }
+    _pg3Verts.clear();
+    std::map<const HyperGraph::Vertex*, int> index;
+    const size_t n = g.edges.size();
+    std::vector<int32_t> vi(n), vj(n);
+    std::vector<double> meas(12 * n), info(36 * n);
+    for (size_t k = 0; k < n; ++k) {
+      EdgeSE3* e = static_cast<EdgeSE3*>(g.edges[k]);
+      for (int side = 0; side < 2; ++side) {
+        VertexSE3* v = static_cast<VertexSE3*>(e->vertex(side));
+        std::map<const HyperGraph::Vertex*, int>::iterator it = index.find(v);
+        if (it == index.end()) {
+          it = index.insert(std::make_pair((const HyperGraph::Vertex*)v, (int)_pg3Verts.size())).first;
+          _pg3Verts.push_back(v);
+        }
+        (side ? vj : vi)[k] = it->second;
+      }
+      isometryTo12(e->measurement(), &meas[12 * k]);
+      const double* om = e->informationData();            // 6 x 6, column-major
+      for (int q = 0; q < 36; ++q) info[36 * k + q] = om[q];
+    }
+    _pgHidx.resize(_pg3Verts.size());
+    for (size_t i = 0; i < _pg3Verts.size(); ++i) _pgHidx[i] = _pg3Verts[i]->hessianIndex();
+    _pgBuf.assign(12 * _pg3Verts.size(), 0.0);
+    if (g2ohip_pg_set_edges(_h, g.set, 2, vi.data(), vj.data(), meas.data(), info.data()) != G2OHIP_OK) {
+      std::cerr << "BlockSolverHip: fast path not available (" << g2ohip_last_error() << "), using the generic path" << std::endl;
+      return false;
+    }
+    if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
+      std::cerr << "BlockSolverHip: device fast path for " << n << " EdgeSE3 edges over " << _pg3Verts.size() << " vertices" << std::endl;
+    return true;
+  }
+  bool uploadPosesSE3() {
+    for (size_t i = 0; i < _pg3Verts.size(); ++i) isometryTo12(_pg3Verts[i]->estimate(), &_pgBuf[12 * i]);
+    if (g2ohip_pg_set_estimates(_h, (int)_pg3Verts.size(), _pgBuf.data(), _pgHidx.data()) != G2OHIP_OK) return fail("pg_set_estimates");
+    if (g2ohip_pg_linearize(_h, 1) != G2OHIP_OK) return fail("pg_linearize");
+    return true;
+  }
+
   bool uploadEstimates() {
     for (size_t i = 0; i < _cams.size(); ++i) {
       const SE3Quat& T = _cams[i]->estimate();
@@ -492,8 +547,9 @@ class BlockSolverHip : public BlockSolverBase {
   std::vector<double> _diagMirror, _diag;
   bool _fastPath;
   int _fastGroup;                                      // index into _groups of the group on the device front end, or -1
-  int _fastKind;                                       // 1: EdgeProjectXYZ2UV (g2ohip_ba_*), 2: EdgeSE2 (g2ohip_pg_*, type 1)
+  int _fastKind;                                       // 1: EdgeProjectXYZ2UV (g2ohip_ba_*), 2 / 3: EdgeSE2 / EdgeSE3 (g2ohip_pg_*, type 1 / 2)
   std::vector<VertexSE2*> _pgVerts;
+  std::vector<VertexSE3*> _pg3Verts;
   std::vector<int32_t> _pgHidx;
   std::vector<double> _pgBuf;
   std::vector<VertexSE3Expmap*> _cams;

@@ -18,6 +18,7 @@
 
 #include "g2o/types/sba/types_six_dof_expmap.h"
 #include "g2o/types/slam2d/edge_se2.h"
+#include "g2o/types/slam3d/edge_se3.h"
 
 using namespace g2o;
 
@@ -50,6 +51,81 @@ int main(int argc, char** argv) {
     std::cerr << "solver " << solverName << " is not registered; known:" << std::endl;
     OptimizationAlgorithmFactory::instance()->listSolvers(std::cerr);
     return 3;
+  }
+  if (argc > 6 && std::string(argv[6]) == "se3") {
+    // ---- 3-D pose graph (config 2: VertexSE3 / EdgeSE3, BlockSolver_6_3 shape without marginalised vertices)
+    // graph.txt: nverts nedges | per vertex: fixed R(9, column-major) t(3) | per edge: i j R(9) t(3) info(36, column-major)
+    std::ifstream in(argv[1]);
+    int nv, ne;
+    in >> nv >> ne;
+    SparseOptimizer optimizer;
+    std::vector<VertexSE3*> verts(nv);
+    for (int i = 0; i < nv; ++i) {
+      int fixed;
+      Eigen::Matrix3d R;
+      Vector3d t;
+      in >> fixed;
+      for (int k = 0; k < 9; ++k) in >> R.data()[k];
+      for (int k = 0; k < 3; ++k) in >> t[k];
+      VertexSE3* v = new VertexSE3();
+      v->setId(i);
+      v->setFixed(fixed != 0);
+      v->setEstimate(Eigen::Isometry3d(R, t));
+      optimizer.addVertex(v);
+      verts[i] = v;
+    }
+    for (int k = 0; k < ne; ++k) {
+      int i, j;
+      Eigen::Matrix3d R;
+      Vector3d t;
+      in >> i >> j;
+      for (int q = 0; q < 9; ++q) in >> R.data()[q];
+      for (int q = 0; q < 3; ++q) in >> t[q];
+      EdgeSE3::InformationType info;
+      for (int q = 0; q < 36; ++q) in >> info.data()[q];
+      EdgeSE3* e = new EdgeSE3();
+      e->setVertex(0, verts[i]);
+      e->setVertex(1, verts[j]);
+      e->setMeasurement(Eigen::Isometry3d(R, t));
+      e->setInformation(info);
+      optimizer.addEdge(e);
+    }
+    if (!in) {
+      std::cerr << "graph file truncated" << std::endl;
+      return 2;
+    }
+    optimizer.setAlgorithm(algo);
+    optimizer.initializeOptimization();
+    if (!algo->init()) return 4;
+    OptimizationAlgorithmLevenberg* lm = dynamic_cast<OptimizationAlgorithmLevenberg*>(algo);
+    std::vector<double> chis, lams;
+    optimizer.computeActiveErrors();
+    const double chi0 = optimizer.activeRobustChi2();
+    int done = 0;
+    for (int i = 0; i < iterations; ++i) {
+      const OptimizationAlgorithm::SolverResult r = algo->solve(i);
+      if (r == OptimizationAlgorithm::Fail) break;
+      optimizer.computeActiveErrors();
+      chis.push_back(optimizer.activeRobustChi2());
+      lams.push_back(lm ? lm->currentLambda() : 0.0);
+      ++done;
+      if (r == OptimizationAlgorithm::Terminate) break;
+    }
+    std::ostringstream js;
+    js << std::setprecision(17);
+    js << "{\"solver\": \"" << solverName << "\", \"iterations\": " << done << ", \"chi2_initial\": " << chi0 << ", \"chi2\": [";
+    for (size_t i = 0; i < chis.size(); ++i) js << (i ? ", " : "") << chis[i];
+    js << "], \"lambda\": [";
+    for (size_t i = 0; i < lams.size(); ++i) js << (i ? ", " : "") << lams[i];
+    js << "], \"poses\": [";
+    for (int i = 0; i < nv; ++i) {
+      const Eigen::Isometry3d& T = verts[i]->estimate();
+      for (int k = 0; k < 9; ++k) js << (i || k ? ", " : "") << T.linear().data()[k];
+      for (int k = 0; k < 3; ++k) js << ", " << T.translation()[k];
+    }
+    js << "]}";
+    std::ofstream(argv[5]) << js.str() << std::endl;
+    return 0;
   }
   if (argc > 6 && std::string(argv[6]) == "se2") {
     // ---- planar pose graph (config 1: VertexSE2 / EdgeSE2, BlockSolver_3_2 shape, no marginalised vertex)

@@ -217,3 +217,35 @@ def test_planar_pose_graph_through_the_g2o_vtables(host, tmp_path, solver):
     if len(runs) == 2:      # fast path == generic path
         assert np.allclose(runs[0]["chi2"], runs[1]["chi2"], rtol=1e-9, atol=0)
         assert np.abs(np.array(runs[0]["poses"]) - np.array(runs[1]["poses"])).max() < 1e-7
+
+
+def test_3d_pose_graph_through_the_g2o_vtables(host, tmp_path):
+    """BASELINE.json config 2 (sphere: VertexSE3 / EdgeSE3, BlockSolver_6_3 shape, no Schur complement) through the plugin
+    and the vtables, Levenberg-Marquardt: on the device fast path (EdgeSE3 groups bound to g2ohip_pg_* type 2: analytic
+    Jacobians of isometry3d_gradients.h restated on the device) and on the generic path (the test host's EdgeSE3 has NUMERIC
+    Jacobians, as BaseBinaryEdge provides when a type brings none).  chi2 of the initial guess and after the first damped
+    step (lambda = 1e-5 max diag: computeLambdaInit) equal the golden trajectory of the reference's CSparse path; the two
+    paths agree to what central differences allow."""
+    from tests.helpers import sphere_golden
+    g = sphere_golden()
+    path = str(tmp_path / "s.txt")
+    with open(path, "w") as f:
+        nv, ne = len(g["poses"]), len(g["vi"])
+        f.write("%d %d\n" % (nv, ne))
+        for i in range(nv):
+            f.write("%d %s\n" % (1 if g["hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in np.asarray(g["poses"][i]).reshape(-1))))
+        for k in range(ne):
+            f.write("%d %d %s %s\n" % (g["vi"][k], g["vj"][k], " ".join("%.17g" % v for v in np.asarray(g["Z"][k]).reshape(-1)),
+                                       " ".join("%.17g" % v for v in np.asarray(g["omega"][k]).reshape(-1))))
+    runs = []
+    for env in ({}, {"G2OHIP_ADAPTER_FASTPATH": "0"}):
+        out, err = _run(host, path, "lm_fix6_3_hip", 3, str(tmp_path / "o.json"), env, mode="se3")
+        assert ("device fast path for" in err) == (not env)
+        assert out["iterations"] == 3
+        assert abs(out["chi2_initial"] - g["chi2_lm"][0]) <= 1e-6 * g["chi2_lm"][0]
+        assert 0 < out["lambda"][0] < float(g["lambda0"])            # (accepted first step: lambda0 times at most 2/3, at least 1/3)
+        assert all(b < a for a, b in zip([out["chi2_initial"]] + out["chi2"], out["chi2"]))
+        runs.append(out)
+    assert abs(runs[0]["chi2"][0] - g["chi2_lm"][1]) <= 1e-6 * g["chi2_lm"][1]        # analytic Jacobians on the device
+    assert abs(runs[1]["chi2"][0] - g["chi2_lm"][1]) <= 1e-3 * g["chi2_lm"][1]        # numeric Jacobians on the host
+    assert np.allclose(runs[0]["chi2"], runs[1]["chi2"], rtol=1e-2, atol=0)
