@@ -1569,9 +1569,12 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMP_OCC) ba_assemble_poses_k
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int v = gt / G, g = gt % G;
   const bool active = v < nP;
-  double H[36], b[6];
+  // the pose block B' (w Omega) B is symmetric: its upper triangle (21 values, (a, c) with a <= c at c (c + 1) / 2 + a) is
+  // accumulated and summed over the lane group, the store mirrors it -- 15 accumulators (30 registers), 30 multiply-adds per
+  // observation and a third of the butterfly less
+  double H[21], b[6];
 #pragma unroll
-  for (int i = 0; i < 36; ++i) H[i] = 0.0;
+  for (int i = 0; i < 21; ++i) H[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) b[i] = 0.0;
   const int k0 = active ? vptr[v] : 0, k1 = active ? vptr[v + 1] : 0;
@@ -1616,12 +1619,12 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMP_OCC) ba_assemble_poses_k
       const double OB0 = O00 * L.B[0 + 2 * c] + O01 * L.B[1 + 2 * c], OB1 = O10 * L.B[0 + 2 * c] + O11 * L.B[1 + 2 * c];
       b[c] -= L.B[0 + 2 * c] * Or0 + L.B[1 + 2 * c] * Or1;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) H[a + 6 * c] += L.B[0 + 2 * a] * OB0 + L.B[1 + 2 * a] * OB1;
+      for (int a = 0; a <= c; ++a) H[c * (c + 1) / 2 + a] += L.B[0 + 2 * a] * OB0 + L.B[1 + 2 * a] * OB1;
     }
   }
   if (G > 1) {
 #pragma unroll
-    for (int i = 0; i < 36; ++i) H[i] = group_sum<G>(H[i]);
+    for (int i = 0; i < 21; ++i) H[i] = group_sum<G>(H[i]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = group_sum<G>(b[i]);
   }
@@ -1630,7 +1633,11 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMP_OCC) ba_assemble_poses_k
   double* bd = bp + (size_t)v * 6;
 #pragma unroll
   for (int i = 0; i < 36; ++i)
-    if (G == 1 || (i % G) == g) Hd[i] = accumulate ? Hd[i] + H[i] : H[i];
+    if (G == 1 || (i % G) == g) {
+      const int r_ = i % 6, c_ = i / 6, lo = r_ < c_ ? r_ : c_, hi = r_ < c_ ? c_ : r_;
+      const double hv = H[hi * (hi + 1) / 2 + lo];
+      Hd[i] = accumulate ? Hd[i] + hv : hv;
+    }
 #pragma unroll
   for (int i = 0; i < 6; ++i)
     if (G == 1 || (i % G) == g) bd[i] = accumulate ? bd[i] + b[i] : b[i];
