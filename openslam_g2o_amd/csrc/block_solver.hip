@@ -2864,9 +2864,12 @@ void BlockSolver::build_system_impl() {
                      ba_.cams.p, ba_.pts.p, ba_.cam_pm.p, ba_.pt_pm.p, ba_.meas_pm.p, ba_.omega_pm.p, ba_.f, ba_.cx, ba_.cy,       \
                      es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, ba_.omega_identity ? 1 : 0)
       if (es.touches_pose) {
-        if (G <= 1) G2OHIP_BA_POSE(1);
-        else if (G <= 4) G2OHIP_BA_POSE(4);
-        else G2OHIP_BA_POSE(8);
+        static const int g_env = getenv("G2OHIP_POSE_GROUP") ? atoi(getenv("G2OHIP_POSE_GROUP")) : 0;   // (experiments)
+        const int Gp = g_env > 0 ? g_env : G;
+        if (Gp <= 1) G2OHIP_BA_POSE(1);
+        else if (Gp <= 4) G2OHIP_BA_POSE(4);
+        else if (Gp <= 8) G2OHIP_BA_POSE(8);
+        else G2OHIP_BA_POSE(16);
       }
 #undef G2OHIP_BA_POSE
       if (overlap) {
