@@ -1282,6 +1282,11 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
         const bool has = krel != 0xfff, head = ent >= 0;
         const int pos = head ? 0 : lmi;
         double v[9];   // lower triangle of H (6: the block is symmetric) | b (3)
+        double Bk[12], OAk[6];   // pose Jacobian and (w Omega) A of this lane's observation, kept for its V block
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Bk[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) OAk[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) v[i] = 0.0;
         {
@@ -1309,10 +1314,11 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
             v[0] = H[0]; v[1] = H[1]; v[2] = H[2]; v[3] = H[4]; v[4] = H[5]; v[5] = H[8];   // (column-major lower triangle)
 #pragma unroll
             for (int i = 0; i < 3; ++i) v[6 + i] = b[i];
-            if (q >= 0) {
-              double blk[18];
-              ba_hpl_block(L, OA, blk);
-              store_vec<18>(Bs + (q - q0) * 18, blk);
+            if (q >= 0) {   // (the Hpl block B' (w Omega) A is never formed: V = B' ((w Omega) A C) once C is known, below)
+#pragma unroll
+              for (int i = 0; i < 12; ++i) Bk[i] = L.B[i];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) OAk[i] = OA[i];
             }
           }
         }
@@ -1359,7 +1365,23 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
           const int src = (int)(threadIdx.x & 63) - pos;
           C[0] = __shfl(C[0], src); C[1] = __shfl(C[1], src); C[2] = __shfl(C[2], src);
           C[4] = __shfl(C[4], src); C[5] = __shfl(C[5], src); C[8] = __shfl(C[8], src);
-          if (has && rc.w >= 0) block_times_split<6, 3>(Bs + (rc.w - q0) * 18, C);
+          if (has && rc.w >= 0) {
+            double OAC[6], V[18];   // (w Omega) A C: 2 x 3, C lower triangular
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                double t = OAk[r + 2 * c] * C[c + 3 * c];
+#pragma unroll
+                for (int k = c + 1; k < 3; ++k) t = fma(OAk[r + 2 * k], C[k + 3 * c], t);
+                OAC[r + 2 * c] = t;
+              }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+              for (int a = 0; a < 6; ++a) V[a + 6 * c] = Bk[0 + 2 * a] * OAC[0 + 2 * c] + Bk[1 + 2 * a] * OAC[1 + 2 * c];
+            store_vec<18>(Bs + (rc.w - q0) * 18, V);
+          }
         }
       }
     } else {
