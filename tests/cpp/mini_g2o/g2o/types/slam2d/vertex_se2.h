@@ -6,13 +6,9 @@
 namespace g2o {
 class VertexSE2 : public BaseVertex<3, SE2> {
  public:
-  virtual void oplusImpl(const double* update) {
-    Vector2d t = _estimate.translation();
-    t[0] += update[0];
-    t[1] += update[1];
-    const double angle = normalize_theta(_estimate.rotation().angle() + update[2]);
-    _estimate.setTranslation(t);
-    _estimate.setRotation(Rotation2Dd(angle));
+  virtual void oplusImpl(const double* d) {   // additive on all three coordinates, the angle wrapped into [-pi, pi)
+    const SE2& T = _estimate;
+    _estimate = SE2(T.translation()[0] + d[0], T.translation()[1] + d[1], normalize_theta(T.rotation().angle() + d[2]));
   }
 };
 }  // namespace g2o
