@@ -202,14 +202,19 @@ int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* c
  * (linear_solver_pcg.h:74-85); iterations of the last solve in g2ohip_stats.iterationsLinearSolver.
  * Ordering / symbolic knobs (before g2ohip_build_structure): "nd_leaf" (nested-dissection leaf size in blocks, 32),
  * "max_sn_scalars" (48) / "max_sn_scalars_lds" (24: fronts that fit LDS), "relax_zeros", "relax_front_bytes",
- * "lds_front_bytes", "fuse_chains", "wave_front_tasks", "dep_levels" (16: task levels that may share one
- * dependency-driven launch, 0/1 = one launch per level), "dep_backward" (1), "dep_delay", "dep_spin_limit",
+ * "lds_front_bytes", "fuse_chains", "wave_front_tasks", "dep_levels" (64: task levels that may share one
+ * dependency-driven launch, 0/1 = one launch per level), "dep_backward" (1), "dep_delay", "dep_spin_limit", "dep_acq_rel" (0; 1 =
+ * release / acquire on the dependency counters, for A/B validation), "band_kernel" (1: leaf chains of a band in the one-wave
+ * sliding-window kernel), "fuse_fwd_any" (1: forward sweep fused into the factor kernel whatever a front's children),
+ * "lds_mfma" ((4 << 16) | 96: LDS fronts with at least that many pivot blocks / boundary rows get one MFMA trailing update),
  * "big_front_passes" (1: large fronts as whole-GPU passes with an MFMA update) / "big_front_min_dim" (180);
  * for those passes "inplace_chains", "mfma_diag", "fuse_panel", "overlap_level_halves", "hoist_big_assembly",
  * "fuse_big_forward", "split_sweeps" / "split_sweeps_min_dim" (512), "merge_backward_levels", "merge_diag_panel" (all 1: see INTEGRATION.md, options).
  * Kernel knobs: "schur_tile_bytes", "schur_group", "fuse_landmark_inverse", "fuse_schur_reduce" (1: g2ohip_solve on
  * one GPU folds the Schur reduction into the factorisation; Hschur is then written only when it is asked for),
- * "ba_fused", "use_graph", "mask_solution". */
+ * "ba_fused", "ba_store_ll" (0: Hll and the errors of the fused BA path reach HBM only when a reader asks), "use_graph",
+ * "mask_solution", "sharded_graph" (1: g2ohip_solve_sharded as one hipGraph where nothing crosses the host; 2: with RCCL too),
+ * "comm_emulate" (timing only).  G2OHIP_OPTIONS="name=value,..." in the environment sets options for every solver of a process. */
 int g2ohip_set_option(g2ohip_solver* s, const char* name, double value);
 
 /* Inspection for parity tests (saveHessian-like, block_solver.hpp:628-632): block patterns
