@@ -213,7 +213,8 @@ int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* c
  * Kernel knobs: "schur_tile_bytes", "schur_group", "fuse_landmark_inverse", "fuse_schur_reduce" (1: g2ohip_solve on
  * one GPU folds the Schur reduction into the factorisation; Hschur is then written only when it is asked for),
  * "ba_fused", "ba_store_ll" (0: Hll and the errors of the fused BA path reach HBM only when a reader asks), "use_graph",
- * "mask_solution", "sharded_graph" (1: g2ohip_solve_sharded as one hipGraph where nothing crosses the host; 2: with RCCL too),
+ * "mask_solution", "sharded_virtual" (1: on a rank the factorisation reads Hpp and the partial blocks itself, only the boundary
+ * blocks of the reduced system are reduced and exchanged as blocks), "sharded_graph" (1: g2ohip_solve_sharded as one hipGraph where nothing crosses the host; 2: with RCCL too),
  * "comm_emulate" (timing only).  G2OHIP_OPTIONS="name=value,..." in the environment sets options for every solver of a process. */
 int g2ohip_set_option(g2ohip_solver* s, const char* name, double value);
 

@@ -135,6 +135,8 @@ class BlockSolver {
   // fused forward sweep, backward sweep): ~30 launches per iteration, which is what limits a rank once the
   // per-rank work shrinks (multi-GPU).  Needs a non-default stream.  Timing events sit between the graphs.
   bool use_graph = false;
+  int sharded_virtual = 1;                 // sharded solve: the factorisation reads Hpp + partial blocks itself (as on one GPU); only the
+                                           // boundary blocks of the reduced system are reduced, exchanged and read back as blocks
   int sharded_graph = 1;                   // solve_sharded as ONE hipGraph (the collectives inside it): 1 = when nothing has to cross the
                                            // host (comm_emulate), 2 = with RCCL as well (ncclAllReduce captured into the graph; not
                                            // exercised on hardware here -- opt-in); 0 = one graph per phase, plain launches in between
@@ -220,6 +222,12 @@ class BlockSolver {
     DevBuf<double> hkeep, bkeep, hmine, buf1, buf3;
   } ex_;
   void solve_back_substitute_impl();
+  void launch_boundary_reduce();
+  void drop_graph_segments();
+  bool sv_ready_ = false, sv_now_ = false;
+  size_t hpp_blocks_ = 0;
+  std::vector<int> sv_base_, sv_diag_, sv_ptr_, sv_slot_;
+  DevBuf<int> d_sv_slot;
   void solve_reduced_local_impl();
   void solve_reduced_shared_impl();
   DevBuf<unsigned char> d_lam_mask;

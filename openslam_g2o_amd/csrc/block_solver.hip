@@ -2587,7 +2587,10 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   d_pp_diag.upload(pp_diag, st_);
   d_pp_colptr.upload(pp_colptr, st_);
   d_pp_row.upload(pp_row, st_);
-  d_Hpp.alloc((size_t)pp_nnzb * p * p);
+  // multi-rank + Schur: room behind Hpp for the reduced-system blocks that are summed over the ranks (block d of Hschur at
+  // pp_nnzb + d): the virtual source of the factorisation reads them there (exchange_setup, sharded_virtual)
+  hpp_blocks_ = (size_t)pp_nnzb;
+  d_Hpp.alloc(((size_t)pp_nnzb + ((schur_ && chol_opt.world > 1) ? hs_row.size() : 0)) * p * p);
   d_bkP.alloc((size_t)nP * p);
   d_b.alloc(vector_size());
   d_x.alloc(vector_size());
@@ -2703,6 +2706,10 @@ void BlockSolver::invalidate_graphs() {
   chi2_valid_ = false;
   ba_.err_valid = ba_.jac_valid = false;
   pg_.err_valid = pg_.jac_valid = false;
+  drop_graph_segments();
+}
+
+void BlockSolver::drop_graph_segments() {   // (the captured launch sequences only: what the kernels read has not changed)
   for (GraphSeg& sg : segs_) {
     if (sg.e) (void)hipGraphExecDestroy(sg.e);
     if (sg.g) (void)hipGraphDestroy(sg.g);
@@ -3100,7 +3107,32 @@ void BlockSolver::solve_schur() {
   require_structure();
   if (!schur_) return;
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  solve_schur_impl();
+  const bool sv = sv_ready_ && sharded_virtual && chol_opt.world > 1 && linear_solver == 0 && fuse_schur_reduce;
+  if (sv != sv_now_) drop_graph_segments();   // (the factor segments are specific to the source of the matrix)
+  sv_now_ = sv;
+  solve_schur_impl(!sv);
+  if (sv && ex_.nbb > 0) launch_boundary_reduce();
+}
+
+// sharded_virtual: the boundary blocks of the reduced system (and the right-hand side of their diagonal ones) from this rank's
+// Hpp and partial blocks, into the region behind Hpp -- schur_reduce_kernel over the boundary list
+void BlockSolver::launch_boundary_reduce() {
+  const int G = schur_group > 0 ? schur_group : pick_group((double)n_sc_ / std::max<long>(1, n_td_));
+  const bool split = (p_ % 2 == 0) && G >= 2;
+  double* Hs = d_Hpp.p + hpp_blocks_ * (size_t)p_ * p_;
+  const int n_red = ex_.nbb;
+#define G2OHIP_RED(P_, NRP_)                                                                                                  \
+  hipLaunchKernelGGL((schur_reduce_kernel<P_, NRP_>), dim3(grid_for((size_t)n_red * P_ * P_)), dim3(kThreads), 0, st_, n_red,     \
+                     d_rd_ptr.p, d_rd_slot.p, d_hs_src.p, d_Hpp.p, d_Pd.p, Hs, d_hs_diag.p, d_Pr.p, d_b.p, d_bschur.p, d_lam.p,  \
+                     d_lam_mask.p, ex_.bblock.p, (int)std::max<long>(1, n_td_))
+  switch (p_) {
+    case 3: G2OHIP_RED(3, 3); break;
+    case 6: if (split) G2OHIP_RED(6, 3); else G2OHIP_RED(6, 6); break;
+    case 7: G2OHIP_RED(7, 7); break;
+    default: throw ArgFailure("unsupported pose dimension for Schur");
+  }
+#undef G2OHIP_RED
+  G2OHIP_HIP_CHECK(hipGetLastError());
 }
 
 void BlockSolver::solve_schur_impl(bool want_matrix) {
@@ -3383,7 +3415,7 @@ void BlockSolver::solve_reduced_local_impl() {
   prof.begin(KernelProf::kCholFactor, st_);
   run_seg(kSegLocal, [&] {
     chol_->solve_begin(schur_ ? d_bschur.p : d_b.p, st_);
-    chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 0, st_, true);   // forward sweep fused in
+    chol_->factor_phase(schur_ ? (sv_now_ ? (const double*)nullptr : d_Hschur.p) : d_Hpp.p, 0, st_, true);   // forward sweep fused in (nullptr: virtual source)
     chol_->pack_exchange(st_);
   });
   prof.end(KernelProf::kCholFactor, st_);
@@ -3400,7 +3432,7 @@ void BlockSolver::solve_reduced_shared_impl() {
   prof.begin(KernelProf::kCholFactor, st_);
   run_seg(kSegShared, [&] {
     chol_->unpack_exchange(st_);
-    chol_->factor_phase(schur_ ? d_Hschur.p : d_Hpp.p, 1, st_, true);
+    chol_->factor_phase(schur_ ? (sv_now_ ? (const double*)nullptr : d_Hschur.p) : d_Hpp.p, 1, st_, true);
   });
   prof.end(KernelProf::kCholFactor, st_);
   prof.begin(KernelProf::kCholSolve, st_);
@@ -3485,6 +3517,52 @@ void BlockSolver::exchange_setup(int nbb, const int* bblock, const double* hkeep
   ex_.buf1.zero(st_);
   ex_.buf3.alloc((size_t)nh * p_ + 1);
   ex_.buf3.zero(st_);
+  // Virtual source on a rank (sharded_virtual): as on one GPU the fronts are assembled from Hpp and the tiles' partial blocks
+  // and Hschur is not written -- except the boundary blocks, whose value is a sum over ranks: those are reduced locally
+  // into the region behind Hpp, summed there by the exchange and read from there by the factorisation (no partials, no
+  // damping of their own: the sum holds both).
+  sv_ready_ = false;
+  if (sharded_virtual && schur_ && chol_opt.world > 1 && n_tiles_ > 0 && !rd_ptr_h_.empty() && fuse_schur_reduce && linear_solver == 0 &&
+      d_Hpp.n >= (hpp_blocks_ + hs_row.size()) * (size_t)p_ * p_ &&
+      (double)n_td_ <= fuse_reduce_max_partials * (double)std::max<size_t>(hs_row.size(), 1)) {
+    const int nb = (int)hs_row.size();
+    std::vector<char> isb(nb, 0);
+    for (int k = 0; k < nbb; ++k) {
+      if (bblock[k] < 0 || bblock[k] >= nb) throw ArgFailure("exchange_setup: block index out of range");
+      isb[bblock[k]] = 1;
+    }
+    sv_base_.assign(nb, -1);
+    sv_diag_.assign(nb, -1);
+    sv_ptr_.assign(nb + 1, 0);
+    sv_slot_.clear();
+    for (int d = 0; d < nb; ++d) {
+      if (isb[d]) {
+        sv_base_[d] = (int)hpp_blocks_ + d;
+      } else {
+        sv_base_[d] = hs_src_h_[d];
+        sv_diag_[d] = hs_diag_h_[d];
+        for (int k = rd_ptr_h_[d]; k < rd_ptr_h_[d + 1]; ++k) sv_slot_.push_back(rd_slot_h_[k]);
+      }
+      sv_ptr_[d + 1] = (int)sv_slot_.size();
+    }
+    if (sv_slot_.empty()) sv_slot_.push_back(0);
+    d_sv_slot.upload(sv_slot_, st_);
+    SparseCholesky::VirtualBlocks vb;
+    vb.base_idx = sv_base_.data();
+    vb.is_diag = sv_diag_.data();
+    vb.part_ptr = sv_ptr_.data();
+    vb.part_slot = sv_slot_.data();
+    vb.d_part_slot = d_sv_slot.p;
+    vb.base = d_Hpp.p;
+    vb.parts = d_Pd.p;
+    vb.lam = d_lam.p;
+    vb.zero_slot = (int)std::max<long>(n_td_, 1);
+    vb.split = false;   // (set per solve: launch_schur_reduce)
+    chol_->set_virtual_blocks(vb, st_);
+    G2OHIP_HIP_CHECK(hipMemsetAsync(d_Hpp.p + hpp_blocks_ * (size_t)p_ * p_, 0, hs_row.size() * (size_t)p_ * p_ * sizeof(double), st_));
+    sv_ready_ = true;
+    drop_graph_segments();
+  }
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
 }
 
@@ -3494,7 +3572,8 @@ void BlockSolver::exchange_pack(int which) {
     const int n = ex_.nbb * p_ * p_ + ex_.nbp * p_;
     if (n > 0)
       hipLaunchKernelGGL(exchange_boundary_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st_, ex_.nbb, ex_.nbp, p_ * p_, p_, ex_.bblock.p,
-                         ex_.bpose.p, ex_.hkeep.p, ex_.bkeep.p, d_Hschur.p, d_bschur.p, ex_.buf1.p, 0);
+                         ex_.bpose.p, ex_.hkeep.p, ex_.bkeep.p, sv_now_ ? d_Hpp.p + hpp_blocks_ * (size_t)p_ * p_ : d_Hschur.p, d_bschur.p,
+                         ex_.buf1.p, 0);
   } else if (which == 3) {
     hipLaunchKernelGGL(exchange_halo_kernel, dim3(grid_for(ex_.nh * p_ + 1)), dim3(kThreads), 0, st_, ex_.nh, p_, ex_.halo.p, ex_.hmine.p,
                        d_x.p, ex_.buf3.p, chol_->status_device(), 0);
@@ -3510,7 +3589,8 @@ void BlockSolver::exchange_unpack(int which) {
     const int n = ex_.nbb * p_ * p_ + ex_.nbp * p_;
     if (n > 0)
       hipLaunchKernelGGL(exchange_boundary_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st_, ex_.nbb, ex_.nbp, p_ * p_, p_, ex_.bblock.p,
-                         ex_.bpose.p, ex_.hkeep.p, ex_.bkeep.p, d_Hschur.p, d_bschur.p, ex_.buf1.p, 1);
+                         ex_.bpose.p, ex_.hkeep.p, ex_.bkeep.p, sv_now_ ? d_Hpp.p + hpp_blocks_ * (size_t)p_ * p_ : d_Hschur.p, d_bschur.p,
+                         ex_.buf1.p, 1);
   } else if (which == 3) {
     hipLaunchKernelGGL(exchange_halo_kernel, dim3(grid_for(ex_.nh * p_ + 1)), dim3(kThreads), 0, st_, ex_.nh, p_, ex_.halo.p, ex_.hmine.p,
                        d_x.p, ex_.buf3.p, chol_->status_device(), 1);
