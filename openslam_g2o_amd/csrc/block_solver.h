@@ -35,6 +35,8 @@ struct EdgeSet {
   bool has_err = false;    // errors + information available (enough for chi2)
   // destination-major contributor lists
   DevBuf<int> vp_ptr, vp_ent, vl_ptr, vl_ent;  // per pose / per landmark: (edge << 1 | side)
+  DevBuf<int> vp_act;                          // poses with at least one entry (when that is not all of them)
+  int n_vp_act = 0;
   std::vector<int> h_vp_ent, h_vl_ent;         // host copies (pose- / landmark-major copies of per-edge inputs)
   std::vector<int> h_vl_ptr;                   // ... and the landmark list bounds (lane slots of the fused Schur tiles)
   DevBuf<int> op_dst, op_ptr, op_ent;          // Hpp off-diagonal blocks: dest block id, (edge << 1 | transposed)

@@ -1587,10 +1587,13 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMP_OCC) ba_assemble_poses_k
     int nP, const int* __restrict__ vptr, const double* __restrict__ cams, const double* __restrict__ pts,
     const int* __restrict__ cam_pm, const int* __restrict__ pt_pm, const double* __restrict__ meas_pm, const double* __restrict__ omega_pm,
     double f, double cx, double cy, int kind, double delta, double* __restrict__ Hpp, const int* __restrict__ diag_blk,
-    double* __restrict__ bp, int accumulate, int ident) {
+    double* __restrict__ bp, int accumulate, int ident, const int* __restrict__ act) {
+  // act != nullptr: nP poses of a list (a rank of a sharded job holds observations of a fraction of the poses; the blocks
+  // of the others are zero from build_structure on and nobody writes them)
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const int v = gt / G, g = gt % G;
-  const bool active = v < nP;
+  const int vi_ = gt / G, g = gt % G;
+  const bool active = vi_ < nP;
+  const int v = (act && active) ? act[vi_] : vi_;
   // the pose block B' (w Omega) B is symmetric: its upper triangle (21 values, (a, c) with a <= c at c (c + 1) / 2 + a) is
   // accumulated and summed over the lane group, the store mirrors it -- 15 accumulators (30 registers), 30 multiply-adds per
   // observation and a third of the butterfly less
@@ -2294,6 +2297,13 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       group_by(nP, dp, pp_, ptr, ent);
       es.vp_ptr.upload(ptr, st_);
       es.vp_ent.upload(ent, st_);
+      {
+        std::vector<int> act;
+        for (int v = 0; v < nP; ++v)
+          if (ptr[v + 1] > ptr[v]) act.push_back(v);
+        es.n_vp_act = (int)act.size() < nP ? (int)act.size() : 0;   // (0: every pose has entries, no list needed)
+        if (es.n_vp_act > 0) es.vp_act.upload(act, st_);
+      }
       es.h_vp_ent = ent;
       es.n_vp_ent = (long)ent.size();
       es.first_pose = !seen_pose;
@@ -2888,10 +2898,16 @@ void BlockSolver::build_system_impl() {
       prof.begin(KernelProf::kAsmPose, st_);
       const int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
       hipStream_t sp = overlap ? side_ : st_;   // stream of the pose kernel
+      // (a rank of a sharded job: only the poses it has observations of -- the only pose-side set, so nothing else ever
+      // writes the blocks of the others)
+      const bool compact = es.n_vp_act > 0 && sets_.size() == 1 && chol_opt.world > 1;
+      const int nPk = compact ? es.n_vp_act : nP_;
+      const int* pact = compact ? es.vp_act.p : (const int*)nullptr;
 #define G2OHIP_BA_POSE(GG)                                                                                                       \
-  hipLaunchKernelGGL((ba_assemble_poses_kernel<GG>), dim3(grid_for((size_t)nP_ * GG)), dim3(kThreads), 0, sp, nP_, es.vp_ptr.p,  \
+  hipLaunchKernelGGL((ba_assemble_poses_kernel<GG>), dim3(grid_for((size_t)nPk * GG)), dim3(kThreads), 0, sp, nPk, es.vp_ptr.p,  \
                      ba_.cams.p, ba_.pts.p, ba_.cam_pm.p, ba_.pt_pm.p, ba_.meas_pm.p, ba_.omega_pm.p, ba_.f, ba_.cx, ba_.cy,       \
-                     es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, ba_.omega_identity ? 1 : 0)
+                     es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, ba_.omega_identity ? 1 : 0,     \
+                     pact)
       if (es.touches_pose) {
         static const int g_env = getenv("G2OHIP_POSE_GROUP") ? atoi(getenv("G2OHIP_POSE_GROUP")) : 0;   // (experiments)
         const int Gp = g_env > 0 ? g_env : G;
