@@ -215,7 +215,9 @@ int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* c
  * "ba_fused", "ba_store_ll" (0: Hll and the errors of the fused BA path reach HBM only when a reader asks), "use_graph",
  * "mask_solution", "sharded_virtual" (1: on a rank the factorisation reads Hpp and the partial blocks itself, only the boundary
  * blocks of the reduced system are reduced and exchanged as blocks), "sharded_graph" (1: g2ohip_solve_sharded as one hipGraph where nothing crosses the host; 2: with RCCL too),
- * "comm_emulate" (timing only).  G2OHIP_OPTIONS="name=value,..." in the environment sets options for every solver of a process. */
+ * "comm_emulate" (timing only).  G2OHIP_OPTIONS="name=value,..." in the environment sets options for every solver of a process: g2ohip_create and
+ * g2ohip_ls_create apply it (so the g2o plugin sees it too); a malformed or, for g2ohip_create, unknown entry fails the
+ * creation with G2OHIP_ERR_ARG; an explicit g2ohip_set_option afterwards wins. */
 int g2ohip_set_option(g2ohip_solver* s, const char* name, double value);
 
 /* Inspection for parity tests (saveHessian-like, block_solver.hpp:628-632): block patterns
@@ -250,7 +252,9 @@ int g2ohip_clear_edge_sets(g2ohip_solver* s);
  * to the index mapping, sparse_optimizer.cpp:269-352); the new edges are appended to an existing edge set (same error
  * dimension and vertex classes; for another edge type call g2ohip_add_edge_set first and pass n_new_edges = 0 here).  The
  * structure is rebuilt from the enlarged topology: g2ohip_vector_size grows, per-edge data of the touched set has to be
- * handed over again for ALL its edges (old ones first).  G2OHIP_ERR_UNSUPPORTED where the reference aborts (a system with
+ * handed over again for ALL its edges (old ones first); a device front end bound to the touched set (g2ohip_pg_set_edges)
+ * is unbound -- call g2ohip_pg_set_edges + g2ohip_pg_set_estimates again after growth (g2ohip_pg_linearize returns
+ * G2OHIP_ERR_STATE until then).  G2OHIP_ERR_UNSUPPORTED where the reference aborts (a system with
  * marginalised vertices, :313-316). */
 int g2ohip_update_structure(g2ohip_solver* s, int num_new_poses, int set, int n_new_edges, const int32_t* v0, const int32_t* v1);
 

@@ -223,11 +223,7 @@ class HipBlockSolver:
         _check(self.L.g2ohip_create(C.byref(self.h), pose_dim, landmark_dim, device), "g2ohip_create")
         self._keep = {}
         self.nP = self.nL = 0
-        # G2OHIP_OPTIONS="name=value,...": options for every solver of the process (experiments and bisecting: e.g. run a test
-        # with band_kernel=0); an explicit setOption afterwards still wins
-        for kv in filter(None, os.environ.get("G2OHIP_OPTIONS", "").split(",")):
-            name, value = kv.split("=")
-            self.setOption(name.strip(), float(value))
+        # (G2OHIP_OPTIONS="name=value,..." in the environment is applied by g2ohip_create itself)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:

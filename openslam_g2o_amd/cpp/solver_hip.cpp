@@ -71,8 +71,15 @@ G2OHIP_REGISTER(lm_fix7_3_hip, "Levenberg: multifrontal block Cholesky on MI355X
 G2OHIP_REGISTER(dl_fix3_2_hip, "Dogleg: multifrontal block Cholesky on MI355X (fixed blocksize)", 3, 2);
 G2OHIP_REGISTER(dl_fix6_3_hip, "Dogleg: multifrontal block Cholesky on MI355X (fixed blocksize)", 6, 3);
 G2OHIP_REGISTER(dl_fix7_3_hip, "Dogleg: multifrontal block Cholesky on MI355X (fixed blocksize)", 7, 3);
+// the narrow seam under every method x shape the CSparse plugin registers with a fixed block size (solver_csparse.cpp:117-140)
+G2OHIP_REGISTER(gn_fix3_2_hipls, "Gauss-Newton: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 3, 2);
 G2OHIP_REGISTER(gn_fix6_3_hipls, "Gauss-Newton: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 6, 3);
-G2OHIP_REGISTER(lm_fix6_3_hipls, "Levenberg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 6, 3);
+G2OHIP_REGISTER(gn_fix7_3_hipls, "Gauss-Newton: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 7, 3);
 G2OHIP_REGISTER(lm_fix3_2_hipls, "Levenberg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 3, 2);
+G2OHIP_REGISTER(lm_fix6_3_hipls, "Levenberg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 6, 3);
+G2OHIP_REGISTER(lm_fix7_3_hipls, "Levenberg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 7, 3);
+G2OHIP_REGISTER(dl_fix3_2_hipls, "Dogleg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 3, 2);
+G2OHIP_REGISTER(dl_fix6_3_hipls, "Dogleg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 6, 3);
+G2OHIP_REGISTER(dl_fix7_3_hipls, "Dogleg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 7, 3);
 
 }  // namespace g2o

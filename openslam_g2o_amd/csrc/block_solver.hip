@@ -2175,6 +2175,10 @@ bool BlockSolver::update_structure(int new_poses, int set, int n, const int* v0,
     es.has_data = es.has_err = false;          // the per-edge arrays are sized for the old edge count: set_edge_data again
     es.J0 = es.J1 = es.omega = es.err = nullptr;
     es.external = false;
+    // a device front end bound to the set holds vi / vj / measurements and the own_* arrays for the OLD edge count:
+    // drop the binding (pg_set_edges / ba_set_edges again after growth), pg_linearize refuses until then
+    if (set == pg_.set) pg_ = PgFrontEnd();
+    if (set == ba_.set) ba_.set = -1;
   }
   build_structure(nP_ + new_poses, 0, false);
   return true;
@@ -2302,7 +2306,11 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         for (int v = 0; v < nP; ++v)
           if (ptr[v + 1] > ptr[v]) act.push_back(v);
         es.n_vp_act = (int)act.size() < nP ? (int)act.size() : 0;   // (0: every pose has entries, no list needed)
-        if (es.n_vp_act > 0) es.vp_act.upload(act, st_);
+        if (es.n_vp_act > 0) {   // the poses WITHOUT entries follow the active ones (their blocks are re-zeroed per build_system)
+          for (int v = 0; v < nP; ++v)
+            if (ptr[v + 1] == ptr[v]) act.push_back(v);
+          es.vp_act.upload(act, st_);
+        }
       }
       es.h_vp_ent = ent;
       es.n_vp_ent = (long)ent.size();
@@ -2859,6 +2867,19 @@ void BlockSolver::ensure_hpl() {
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 
+// A rank of a sharded job assembles only the poses it has observations of; the diagonal blocks and b segments of the others
+// must read as zero.  They are zero after build_structure and no kernel of the library writes them, but the compact pose
+// kernel no longer heals them the way the full one did (round-3 advisor finding): re-zero them per build_system.
+__global__ void zero_inactive_poses_kernel(int n, int p, const int* __restrict__ list, const int* __restrict__ pp_diag,
+                                           double* __restrict__ Hpp, double* __restrict__ b) {
+  const int per = p * p + p;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * per) return;
+  const int v = list[t / per], e = (int)(t % per);
+  if (e < p * p) Hpp[(size_t)pp_diag[v] * p * p + e] = 0.0;
+  else b[(size_t)v * p + (e - p * p)] = 0.0;
+}
+
 void BlockSolver::build_system_impl() {
   if (profiling) tq_.start(st_);
   ba_.sys_version = -1;   // (set again by the fused BA branch)
@@ -2908,6 +2929,9 @@ void BlockSolver::build_system_impl() {
                      ba_.cams.p, ba_.pts.p, ba_.cam_pm.p, ba_.pt_pm.p, ba_.meas_pm.p, ba_.omega_pm.p, ba_.f, ba_.cx, ba_.cy,       \
                      es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, ba_.omega_identity ? 1 : 0,     \
                      pact)
+      if (compact && es.first_pose)
+        hipLaunchKernelGGL(zero_inactive_poses_kernel, dim3(grid_for((size_t)(nP_ - nPk) * (p_ * p_ + p_))), dim3(kThreads), 0, sp, nP_ - nPk, p_,
+                           es.vp_act.p + nPk, d_pp_diag.p, d_Hpp.p, d_b.p);
       if (es.touches_pose) {
         static const int g_env = getenv("G2OHIP_POSE_GROUP") ? atoi(getenv("G2OHIP_POSE_GROUP")) : 0;   // (experiments)
         const int Gp = g_env > 0 ? g_env : G;
@@ -3159,7 +3183,10 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
   const bool fuse_inv = fuse_landmark_inverse && n_tiles_ > 0 && tiles_cover_all_;
   // fused EdgeProjectXYZ2UV system built from the current estimates: the tiles evaluate their Hpl blocks themselves
   const bool ba_tiles = fuse_inv && p_ == 6 && l_ == 3 && ba_.cam_q.p != nullptr && ba_recompute_ok();
-  if (!ba_tiles) ensure_hpl();
+  if (!ba_tiles) {   // the generic tiles read Hpl, Hll and b_l from memory: both must be there (a fused solve with
+    ensure_hpl();    // ba_store_ll = 0 leaves Hll partial, and with ba_skip_hpl = 0 ensure_hpl alone returns at once)
+    ensure_ll();
+  }
   if (ba_tiles) {
     EdgeSet& es = *sets_[ba_.set];
     static bool attr = false;
@@ -4617,6 +4644,7 @@ void BlockSolver::pg_linearize(bool jacobians) {
   if (pg_.set < 0 || pg_.nv <= 0) throw StateFailure("pg_linearize: call pg_set_edges and pg_set_estimates first");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   EdgeSet& es = *sets_[pg_.set];
+  if ((int)pg_.h_vi.size() != es.n) throw StateFailure("pg_linearize: the edge set has grown since pg_set_edges (g2ohip_update_structure): call pg_set_edges again");
   if (pg_.err_valid && (!jacobians || pg_.jac_valid)) {   // the estimates have not moved since the last evaluation
     if (jacobians) es.has_data = true;
     return;

@@ -3,7 +3,9 @@
 // (the reference path itself uses `false` + cerr).
 #include "../../include/g2ohip.h"
 
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "block_solver.h"
 
@@ -62,6 +64,42 @@ int guarded(F&& f) {
   }
 }  // namespace
 
+// G2OHIP_OPTIONS="name=value,..." in the environment: options for every solver handle of the process, applied at creation
+// (an explicit g2ohip_set_option afterwards still wins).  Parsed HERE so that C / C++ consumers -- the g2o plugin -- see it
+// too.  A malformed entry fails the creation with G2OHIP_ERR_ARG and a message; `unknown_ok` lets the narrow-seam handle
+// skip names that only the block solver knows.
+template <class Setter>
+static int apply_env_options(Setter&& set, bool unknown_ok) {
+  const char* env = std::getenv("G2OHIP_OPTIONS");
+  if (!env || !*env) return G2OHIP_OK;
+  std::string all(env);
+  size_t pos = 0;
+  while (pos <= all.size()) {
+    size_t end = all.find(',', pos);
+    if (end == std::string::npos) end = all.size();
+    std::string kv = all.substr(pos, end - pos);
+    pos = end + 1;
+    const size_t a = kv.find_first_not_of(" \t"), b = kv.find_last_not_of(" \t");
+    if (a == std::string::npos) continue;
+    kv = kv.substr(a, b - a + 1);
+    const size_t eq = kv.find('=');
+    char* stop = nullptr;
+    const double v = eq == std::string::npos ? 0.0 : std::strtod(kv.c_str() + eq + 1, &stop);
+    if (eq == std::string::npos || eq == 0 || stop == kv.c_str() + eq + 1 || (stop && *stop && *stop != ' ')) {
+      set_error("G2OHIP_OPTIONS: malformed entry '" + kv + "' (want name=value)");
+      return G2OHIP_ERR_ARG;
+    }
+    std::string name = kv.substr(0, eq);
+    name.erase(name.find_last_not_of(" \t") + 1);
+    const int rc = set(name.c_str(), v);
+    if (rc != G2OHIP_OK && !unknown_ok) {
+      set_error("G2OHIP_OPTIONS: unknown option '" + name + "'");
+      return rc;
+    }
+  }
+  return G2OHIP_OK;
+}
+
 extern "C" {
 
 const char* g2ohip_last_error(void) { return last_error_ref().c_str(); }
@@ -78,6 +116,9 @@ int g2ohip_create(g2ohip_solver** out, int pose_dim, int landmark_dim, int devic
   return guarded([&] {
     auto h = std::make_unique<g2ohip_solver>();
     h->impl = std::make_unique<BlockSolver>(pose_dim, landmark_dim, device);
+    g2ohip_solver* raw = h.get();
+    const int rc = apply_env_options([&](const char* n, double v) { return g2ohip_set_option(raw, n, v); }, false);
+    if (rc != G2OHIP_OK) return rc;
     *out = h.release();
     return G2OHIP_OK;
   });
@@ -733,6 +774,12 @@ int g2ohip_ls_create(g2ohip_linear_solver** out, int block_dim, int device) {
     h->device = device;
     G2OHIP_HIP_CHECK(hipSetDevice(device));
     G2OHIP_HIP_CHECK(hipStreamCreate(&h->st));
+    g2ohip_linear_solver* raw = h.get();
+    const int rc = apply_env_options([&](const char* n, double v) { return g2ohip_ls_set_option(raw, n, v); }, true);
+    if (rc != G2OHIP_OK) {
+      (void)hipStreamDestroy(h->st);
+      return rc;
+    }
     *out = h.release();
     return G2OHIP_OK;
   });

@@ -41,9 +41,9 @@ def test_registered_names_follow_the_cli_convention():
     and the documented file name matches *_solver_*.so (g2o_common.cpp:82)."""
     text = open(os.path.join(CPP, "solver_hip.cpp")).read()
     names = [n for n in re.findall(r"G2OHIP_REGISTER\((\w+),", text) if n != "name"]   # (the macro definition itself)
-    assert len(names) >= 9 and len(set(names)) == len(names)
-    for n in names:
-        assert re.fullmatch(r"(gn|lm|dl)_fix(3_2|6_3|7_3)_(hip|hipls)", n), n
+    # every method x fixed shape the CSparse plugin registers (solver_csparse.cpp:117-140), under both seams
+    assert set(names) == {"%s_fix%s_%s" % (m, sh, seam) for m in ("gn", "lm", "dl") for sh in ("3_2", "6_3", "7_3") for seam in ("hip", "hipls")}
+    assert len(set(names)) == len(names)
     assert "G2O_REGISTER_OPTIMIZATION_LIBRARY(hip)" in text
     assert re.search(r"lib\w*_solver_\w+\.so", text)
 
@@ -66,7 +66,7 @@ def test_plugin_links_and_exports_the_registration_anchors():
     assert os.path.exists(so) and os.path.exists(os.path.join(host, "build", "g2o_host"))
     syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
     assert " T g2o_optimization_library_hip" in syms
-    for name in ("lm_fix6_3_hip", "lm_fix6_3_hipls", "gn_fix6_3_hip", "dl_fix6_3_hip", "lm_fix3_2_hip", "lm_fix7_3_hip"):
+    for name in ("lm_fix6_3_hip", "lm_fix6_3_hipls", "gn_fix6_3_hip", "dl_fix6_3_hip", "lm_fix3_2_hip", "lm_fix7_3_hip", "dl_fix7_3_hipls", "gn_fix3_2_hipls"):
         assert " T g2o_optimization_algorithm_%s" % name in syms, name
     needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
     assert "libg2ohip.so" in needed and "libg2o_mini_core.so" in needed

@@ -784,3 +784,27 @@ def test_robust_kernels_other_than_huber(kind):
     assert relerr(sf.b(), o.b()) < 1e-11 and abs(sf.chi2() - o.chi2()) <= 1e-11 * o.chi2()
     with pytest.raises(Exception):
         s.setRobustKernel(0, 9, 1.0)
+
+
+def test_env_options_are_applied_by_the_library(monkeypatch):
+    """G2OHIP_OPTIONS is parsed inside g2ohip_create / g2ohip_ls_create (round-3 advisor finding: C and C++ consumers such as
+    the g2o plugin ignored it when only the Python wrapper read it): a valid list changes the kernels used (same solution),
+    a malformed or unknown entry fails the creation with G2OHIP_ERR_ARG and a message."""
+    capi = _capi()
+    pr = ba_case(30, 300)
+    ref = hip_ba(pr)
+    ref.buildSystem()
+    assert ref.solve()
+    monkeypatch.setenv("G2OHIP_OPTIONS", " band_kernel=0, wave_kernel = 0 ")
+    s = hip_ba(pr)
+    s.buildSystem()
+    assert s.solve()
+    assert relerr(s.x(), ref.x()) < 1e-9
+    monkeypatch.setenv("G2OHIP_OPTIONS", "band_kernel=0,ba_fused=1")   # the narrow seam skips block-solver-only names
+    capi.HipLinearSolver(3)
+    monkeypatch.setenv("G2OHIP_OPTIONS", "band_kernel")
+    with pytest.raises(capi.G2oHipError, match="malformed"):
+        capi.HipBlockSolver(6, 3, 0)
+    monkeypatch.setenv("G2OHIP_OPTIONS", "no_such_option=1")
+    with pytest.raises(capi.G2oHipError, match="unknown option"):
+        capi.HipBlockSolver(6, 3, 0)

@@ -145,3 +145,40 @@ def test_sphere2500_generated_config2():
     e0 = np.abs(g["poses"][:, 9:] - g["poses_true"][:, 9:]).max()
     e1 = np.abs(est[:, 9:] - g["poses_true"][:, 9:]).max()
     assert e1 < 0.2 * e0 and e1 < 20.0, (e0, e1)
+
+
+def test_growth_unbinds_the_device_front_end():
+    """g2ohip_update_structure on a set the pose-graph front end is bound to (round-3 advisor finding): the binding holds
+    vi / vj / measurements and Jacobian arrays for the OLD edge count, so it is dropped -- pg_linearize refuses with a state
+    error instead of running over the grown set -- and after pg_set_edges / pg_set_estimates for the whole set the device
+    producers give the reference's b and Gauss-Newton step (block_solver.hpp:297-351; the online use of this entry point)."""
+    capi = _capi()
+    g = manhattan_golden()
+    vi, vj = g["vi"], g["vj"]
+    h0, h1 = g["hidx"][vi], g["hidx"][vj]
+    n0 = 3000
+    first = (h0 < n0) & (h1 < n0)
+    order = np.concatenate([np.nonzero(first)[0], np.nonzero(~first)[0]])
+    nf = int(first.sum())
+    # estimate table of the first n0 free poses (+ the fixed one): vertices with hessian index < n0
+    keep = np.nonzero(g["hidx"] < n0)[0]
+    remap = -np.ones(len(g["hidx"]), np.int32)
+    remap[keep] = np.arange(len(keep), dtype=np.int32)
+    s = capi.HipBlockSolver(3, 2, 0)
+    k = s.addEdgeSet(3, h0[order[:nf]], h1[order[:nf]])
+    s.buildStructure(n0, 0, False)
+    s.pgSetEdges(k, 1, remap[vi[order[:nf]]], remap[vj[order[:nf]]], g["meas"][order[:nf]], g["omega"][order[:nf]])
+    s.pgSetEstimates(g["estimates"][keep], g["hidx"][keep])
+    s.pgLinearize(True)
+    s.buildSystem()
+    assert s.solve()
+    assert s.updateStructure(g["nP"] - n0, k, h0[order[nf:]], h1[order[nf:]])
+    with pytest.raises(capi.G2oHipError):
+        s.pgLinearize(True)
+    s.pgSetEdges(k, 1, vi[order], vj[order], g["meas"][order], g["omega"][order])
+    s.pgSetEstimates(g["estimates"], g["hidx"])
+    s.pgLinearize(True)
+    s.buildSystem()
+    assert relerr(s.b(), g["b0"]) < 1e-11
+    assert s.solve()
+    assert relerr(s.x(), g["x_gn0"]) < 1e-8
