@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
                     help="staged: gloo + host staging with every rank on cuda:0 (functional check of the N>1 path on a "
                          "1-GPU box; its timing is meaningless)")
+    ap.add_argument("--check-oracle", action="store_true", help="N > 1: gather the pose increment of the last solve on rank 0 and compare it "
+                    "with one CPU oracle iteration on the whole graph (dx_pose_rel_err in the JSON line); for sizes the oracle "
+                    "finishes in seconds")
     ap.add_argument("--emulate", default="", help="R/W: run rank R of a W-rank job alone with a no-op exchange (results are "
                     "meaningless, per-rank kernel and wall time without communication are not) -- sizing tool for 1-GPU boxes")
     ap.add_argument("--graph", choices=["on", "off"], default="on",
@@ -300,6 +303,9 @@ def main():
         mine = {name: round(1e3 * tot / n, 5) for name, (tot, n) in ktimes.items()}
         rank_tables = [None] * world
         dist.all_gather_object(rank_tables, mine)
+    xp_all = None
+    if args.check_oracle and world > 1:
+        xp_all = solver.gather_x_poses()            # collective: every rank takes part (x of the last damped solve)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -336,7 +342,7 @@ def main():
     traffic = None
     pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % r) for r in (9, 8, 7, 6, 5, 4, 3, 2, 1))
                      if os.path.exists(q)), "")
-    if pmc_path and world == 1 and (P, L) == (100000, 1000000):
+    if pmc_path and world == 1 and not emulate and (P, L) == (100000, 1000000):   # (the counters were taken on the whole graph on one GPU)
         pmc_all = json.load(open(pmc_path))
         pmc = pmc_all.get(dname)
         if pmc:
@@ -443,6 +449,10 @@ def main():
         out["chi2_before"] = float(np.sum(S.ba_linearize(prob, jac=False) ** 2))
         out["chi2_after_gpu"], out["chi2_after_cpu"] = chi_g, chi_c
         out["chi2_rel_err"] = abs(chi_g - chi_c) / chi_c
+    if xp_all is not None:
+        cb, x_cpu = cpu_baseline(prob, lam, include_linearize=fused, reps=1)
+        xo = x_cpu[:6 * prob["nP"]]
+        out["dx_pose_rel_err"] = float(np.abs(xp_all - xo).max() / np.abs(xo).max())
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

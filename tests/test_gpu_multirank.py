@@ -312,21 +312,27 @@ def test_library_comm_over_rccl_single_rank():
     assert relerr(x, o.x()) < dx_tolerance(o)[0] and abs(sc - o.compute_scale(7.0)) <= 1e-6 * abs(sc)
 
 
-def test_bench_launches_its_own_ranks():
-    """Plain `python bench.py --gpus 2` (no launcher in front, WORLD_SIZE unset) starts one rank per GPU itself; on this
-    1-GPU box the two ranks share cuda:0 and the exchange is staged through gloo.  Rank 0 prints the one JSON line with
-    the collectives' kind, a kernel table per rank and the three all-reduce times."""
+@pytest.mark.parametrize("ranks,poses", [(2, 3000), (8, 8000)])
+def test_bench_launches_its_own_ranks(ranks, poses):
+    """Plain `python bench.py --gpus N` (no launcher in front, WORLD_SIZE unset) starts one rank per GPU itself; on this
+    1-GPU box the ranks share cuda:0 and the exchange is staged through gloo.  Rank 0 prints the one JSON line with
+    the collectives' kind, a kernel table per rank and the three all-reduce times.  N = 8 is the shape of the driver's scaling
+    run: rank -> device mapping, the partition at world 8 (every rank owns poses) and the JSON line are proven here, and the
+    gathered pose increment is held to the CPU oracle on the whole graph (--check-oracle)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--comm", "staged", "--poses", "3000",
-                        "--landmarks", "30000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=root,
-                       capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--comm", "staged", "--poses", str(poses),
+                        "--landmarks", str(10 * poses), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--check-oracle"], env=env,
+                       cwd=root, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [q for q in r.stdout.splitlines() if q.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["solve_ok"] and out["collectives"] == "host"
-    assert len(out["per_rank_kernel_ms"]) == 2
-    assert len(out["all_reduce_ms"]) == 3 and all(len(v) == 2 and v[0] is not None for v in out["all_reduce_ms"].values())
+    assert out["n_gpus"] == ranks and out["solve_ok"] and out["collectives"] == "host"
+    assert len(out["per_rank_kernel_ms"]) == ranks
+    assert len(out["all_reduce_ms"]) == 3 and all(len(v) == ranks and v[0] is not None for v in out["all_reduce_ms"].values())
+    per_rank = out["shard"]["poses_per_rank"]          # [shared, rank 0, rank 1, ...]
+    assert len(per_rank) == ranks + 1 and all(n > 0 for n in per_rank[1:]) and sum(per_rank) == out["config"]["poses"] - 2
+    assert out["dx_pose_rel_err"] < 1e-8
