@@ -244,6 +244,9 @@ class BlockSolver {
  public:
   size_t dependency_fallbacks = 0;   // dependency-driven launches that gave up and were repeated level by level
   bool ba_skip_hpl = true;            // fused BA path: Hpl is not written at all while nobody reads it (ensure_hpl)
+  bool ba_lazy_pose = false;          // fused BA path: the pose side of the assembly runs inside the solve, on a side stream next to the Schur tiles (ensure_pp).
+                                      // Measured round 4: the tiles take 0.402 instead of 0.347 ms with the pose kernel next to them, the iteration 1.231
+                                      // instead of 1.207 ms -- both kernels are bound by instruction issue on the same CUs; off, kept for A/B
   bool ba_fuse_landmarks = true;      // ... and the landmark side (Hll, b_l, errors) is assembled by the Schur tiles of the solve
   int ba_store_ll = 0;                // ... which then also write Hll and the errors to memory (0: only b_l and Dinv, what the solve reads)
   bool ba_recompute_backsub = true;   // fused BA path: back-substitution from the Jacobians instead of reading Hpl
@@ -294,10 +297,14 @@ class BlockSolver {
   bool ba_fuse_ll_ok() const;
   int ba_lm_group() const;
   void ensure_hpl();
+  void ensure_pp();
+  void ensure_side();
+  void launch_ba_poses(hipStream_t sp);
   void ensure_ll();
   void ensure_bl();
   void launch_ba_landmarks(bool write_hpl);
   bool hpl_valid_ = true;
+  bool pp_valid_ = true;   // Hpp's diagonal blocks and b_p of the fused BA path match the last build_system (false: left to the next solve)
   bool ll_valid_ = true;   // Hll, b_l and the errors of the fused BA path match the last build_system
   bool ll_hbm_partial_ = false;   // ... but the Schur tiles that assembled them wrote b_l only (Hll and the errors stayed on chip)
   void pg_validate();

@@ -2199,6 +2199,7 @@ void BlockSolver::require_structure() const {
 
 void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   invalidate_graphs();
+  pp_valid_ = true;
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   nP_ = nP;
   nL_ = nL;
@@ -2880,10 +2881,57 @@ __global__ void zero_inactive_poses_kernel(int n, int p, const int* __restrict__
   else b[(size_t)v * p + (e - p * p)] = 0.0;
 }
 
+// pose side of the fused BA assembly (Hpp diagonal blocks, b_p) on stream sp
+void BlockSolver::launch_ba_poses(hipStream_t sp) {
+  EdgeSet& es = *sets_[ba_.set];
+  const int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
+  // (a rank of a sharded job: only the poses it has observations of -- the only pose-side set, so nothing else ever
+  // writes the blocks of the others)
+  const bool compact = es.n_vp_act > 0 && sets_.size() == 1 && chol_opt.world > 1;
+  const int nPk = compact ? es.n_vp_act : nP_;
+  const int* pact = compact ? es.vp_act.p : (const int*)nullptr;
+#define G2OHIP_BA_POSE(GG)                                                                                                       \
+  hipLaunchKernelGGL((ba_assemble_poses_kernel<GG>), dim3(grid_for((size_t)nPk * GG)), dim3(kThreads), 0, sp, nPk, es.vp_ptr.p,  \
+                     ba_.cams.p, ba_.pts.p, ba_.cam_pm.p, ba_.pt_pm.p, ba_.meas_pm.p, ba_.omega_pm.p, ba_.f, ba_.cx, ba_.cy,       \
+                     es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, ba_.omega_identity ? 1 : 0,     \
+                     pact)
+  if (compact && es.first_pose)
+    hipLaunchKernelGGL(zero_inactive_poses_kernel, dim3(grid_for((size_t)(nP_ - nPk) * (p_ * p_ + p_))), dim3(kThreads), 0, sp, nP_ - nPk, p_,
+                       es.vp_act.p + nPk, d_pp_diag.p, d_Hpp.p, d_b.p);
+  if (es.touches_pose) {
+    static const int g_env = getenv("G2OHIP_POSE_GROUP") ? atoi(getenv("G2OHIP_POSE_GROUP")) : 0;   // (experiments)
+    const int Gp = g_env > 0 ? g_env : G;
+    if (Gp <= 1) G2OHIP_BA_POSE(1);
+    else if (Gp <= 4) G2OHIP_BA_POSE(4);
+    else if (Gp <= 8) G2OHIP_BA_POSE(8);
+    else G2OHIP_BA_POSE(16);
+  }
+#undef G2OHIP_BA_POSE
+}
+
+// a reader of Hpp / b_p before the solve that was to run the pose side (build_system_impl, `lazy`)
+void BlockSolver::ensure_pp() {
+  if (pp_valid_) return;
+  if (!ba_recompute_ok())
+    throw StateFailure("the pose blocks were left to solve() by the last build_system and the estimates (or the robust kernel) have "
+                       "changed since: call build_system again, or set option ba_lazy_pose = 0");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  launch_ba_poses(st_);
+  pp_valid_ = true;
+  G2OHIP_HIP_CHECK(hipGetLastError());
+}
+
+void BlockSolver::ensure_side() {
+  if (side_) return;
+  G2OHIP_HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+  G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&side_fork_, hipEventDisableTiming));
+  G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&side_join_, hipEventDisableTiming));
+}
+
 void BlockSolver::build_system_impl() {
   if (profiling) tq_.start(st_);
   ba_.sys_version = -1;   // (set again by the fused BA branch)
-  hpl_valid_ = ll_valid_ = true;
+  hpl_valid_ = ll_valid_ = pp_valid_ = true;
   ll_hbm_partial_ = false;
   const size_t sizeP = (size_t)nP_ * p_;
   bool any_pose = false, any_lm = false;
@@ -2901,11 +2949,7 @@ void BlockSolver::build_system_impl() {
       // next to the landmark side unless one of them is being timed on its own.
       const bool overlap = overlap_assembly && es.touches_pose && !prof.timing(KernelProf::kAsmLandmark) && !prof.timing(KernelProf::kAsmPose);
       if (overlap) {
-        if (!side_) {
-          G2OHIP_HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
-          G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&side_fork_, hipEventDisableTiming));
-          G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&side_join_, hipEventDisableTiming));
-        }
+        ensure_side();
         G2OHIP_HIP_CHECK(hipEventRecord(side_fork_, st_));             // fork before either kernel is queued
         G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_, side_fork_, 0));
       }
@@ -2916,31 +2960,19 @@ void BlockSolver::build_system_impl() {
         launch_ba_landmarks(hpl_valid_);
         prof.end(KernelProf::kAsmLandmark, st_);
       }
+      // The pose side (Hpp diagonal blocks, b_p) is read by nothing the Schur tiles of the solve do: where the solve will run
+      // them (the tiles assemble the landmark side themselves), the pose kernel is left to that solve, which runs it on a side
+      // stream NEXT TO the tiles (ensure_pp() for any reader that comes first: maxDiagonal, b(), multiplyHessian, ...).
+      const bool lazy = ba_lazy_pose && !ll_valid_ && es.touches_pose && es.first_pose && chol_opt.world == 1 && linear_solver == 0 &&
+                        !prof.timing(KernelProf::kAsmPose) && [&] {
+                          for (size_t i = 0; i < sets_.size(); ++i)
+                            if ((int)i != ba_.set && sets_[i]->n > 0 && sets_[i]->touches_pose) return false;
+                          return true;
+                        }();
+      pp_valid_ = !lazy;
+      if (lazy) continue;
       prof.begin(KernelProf::kAsmPose, st_);
-      const int G = pick_group((double)es.n_vp_ent / std::max(1, nP_));
-      hipStream_t sp = overlap ? side_ : st_;   // stream of the pose kernel
-      // (a rank of a sharded job: only the poses it has observations of -- the only pose-side set, so nothing else ever
-      // writes the blocks of the others)
-      const bool compact = es.n_vp_act > 0 && sets_.size() == 1 && chol_opt.world > 1;
-      const int nPk = compact ? es.n_vp_act : nP_;
-      const int* pact = compact ? es.vp_act.p : (const int*)nullptr;
-#define G2OHIP_BA_POSE(GG)                                                                                                       \
-  hipLaunchKernelGGL((ba_assemble_poses_kernel<GG>), dim3(grid_for((size_t)nPk * GG)), dim3(kThreads), 0, sp, nPk, es.vp_ptr.p,  \
-                     ba_.cams.p, ba_.pts.p, ba_.cam_pm.p, ba_.pt_pm.p, ba_.meas_pm.p, ba_.omega_pm.p, ba_.f, ba_.cx, ba_.cy,       \
-                     es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, ba_.omega_identity ? 1 : 0,     \
-                     pact)
-      if (compact && es.first_pose)
-        hipLaunchKernelGGL(zero_inactive_poses_kernel, dim3(grid_for((size_t)(nP_ - nPk) * (p_ * p_ + p_))), dim3(kThreads), 0, sp, nP_ - nPk, p_,
-                           es.vp_act.p + nPk, d_pp_diag.p, d_Hpp.p, d_b.p);
-      if (es.touches_pose) {
-        static const int g_env = getenv("G2OHIP_POSE_GROUP") ? atoi(getenv("G2OHIP_POSE_GROUP")) : 0;   // (experiments)
-        const int Gp = g_env > 0 ? g_env : G;
-        if (Gp <= 1) G2OHIP_BA_POSE(1);
-        else if (Gp <= 4) G2OHIP_BA_POSE(4);
-        else if (Gp <= 8) G2OHIP_BA_POSE(8);
-        else G2OHIP_BA_POSE(16);
-      }
-#undef G2OHIP_BA_POSE
+      launch_ba_poses(overlap ? side_ : st_);
       if (overlap) {
         G2OHIP_HIP_CHECK(hipEventRecord(side_join_, side_));
         G2OHIP_HIP_CHECK(hipStreamWaitEvent(st_, side_join_, 0));
@@ -3086,6 +3118,7 @@ void BlockSolver::restore_diagonal() {
 }
 
 double BlockSolver::max_diagonal() {
+  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ensure_ll();
@@ -3119,6 +3152,7 @@ __global__ void gather_diag_kernel(int nv, int dim, const double* __restrict__ H
 }
 
 void BlockSolver::copy_diagonal(double* host) {
+  ensure_pp();
   require_structure();
   if (!host) throw ArgFailure("copy_diagonal: null pointer");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
@@ -3135,6 +3169,7 @@ void BlockSolver::copy_diagonal(double* host) {
 }
 
 double BlockSolver::compute_scale(double lambda) {
+  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ensure_bl();
@@ -3186,6 +3221,17 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
   if (!ba_tiles) {   // the generic tiles read Hpl, Hll and b_l from memory: both must be there (a fused solve with
     ensure_hpl();    // ba_store_ll = 0 leaves Hll partial, and with ba_skip_hpl = 0 ensure_hpl alone returns at once)
     ensure_ll();
+    ensure_pp();
+  }
+  bool pose_forked = false;
+  if (ba_tiles && !pp_valid_) {   // the pose side of the assembly next to the tiles (it reads what they read, writes Hpp / b_p)
+    ensure_side();
+    G2OHIP_HIP_CHECK(hipEventRecord(side_fork_, st_));
+    G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_, side_fork_, 0));
+    launch_ba_poses(side_);
+    G2OHIP_HIP_CHECK(hipEventRecord(side_join_, side_));
+    pp_valid_ = true;
+    pose_forked = true;
   }
   if (ba_tiles) {
     EdgeSet& es = *sets_[ba_.set];
@@ -3277,6 +3323,7 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
   G2OHIP_SCHUR(3, 3) { throw ArgFailure("unsupported (pose_dim, landmark_dim) for Schur"); }
 #undef G2OHIP_SCHUR
 #undef G2OHIP_TILE_ARGS
+  if (pose_forked) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st_, side_join_, 0));   // Hpp / b_p are read from here on
   prof.begin(KernelProf::kSchurRhs, st_);
   launch_schur_reduce(want_matrix);
   prof.end(KernelProf::kSchurRhs, st_);
@@ -3330,6 +3377,7 @@ void BlockSolver::launch_schur_reduce(bool matrix) {
 
 // somebody reads Hschur (copy_values, PCG, marginals, multi-GPU exchange) after a solve() that skipped it
 void BlockSolver::ensure_hschur() {
+  ensure_pp();
   if (!schur_ || hschur_valid_) return;
   launch_schur_reduce(true);
   G2OHIP_HIP_CHECK(hipGetLastError());
@@ -3776,6 +3824,7 @@ double BlockSolver::chi2_sharded() {
 }
 
 double BlockSolver::compute_scale_sharded(double lambda) {
+  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ensure_bl();
@@ -3788,6 +3837,7 @@ double BlockSolver::compute_scale_sharded(double lambda) {
 }
 
 double BlockSolver::max_diagonal_sharded() {
+  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ensure_ll();
@@ -3957,6 +4007,7 @@ void BlockSolver::mf_prepare_lists() {
 
 // Dinv = (Hll + lam_l I)^-1, bschur = b_p - Hpl Dinv b_l, diagonal blocks of the reduced system (device array 107)
 void BlockSolver::schur_operator_prepare() {
+  ensure_pp();
   require_structure();
   if (!system_built_) throw StateFailure("schur_operator_prepare before build_system");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
@@ -4056,6 +4107,7 @@ void BlockSolver::solve_async() {
 }
 
 void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* scale_out) {
+  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   constexpr int kMaxBlocks = 1024;
@@ -4144,6 +4196,7 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
 }
 
 void BlockSolver::multiply_hessian(double* dest_host, const double* src_host) {
+  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t n = vector_size();
@@ -4205,6 +4258,7 @@ void BlockSolver::copy_x(double* h) {
   d_x.download(h, vector_size(), st_);
 }
 void BlockSolver::copy_b(double* h) {
+  ensure_pp();
   require_structure();
   ensure_bl();
   d_b.download(h, vector_size(), st_);
@@ -4233,6 +4287,7 @@ void BlockSolver::get_pattern(int which, int* colptr, int* rowidx) const {
   std::copy(ri->begin(), ri->end(), rowidx);
 }
 void BlockSolver::copy_values(int which, double* h) {
+  ensure_pp();
   require_structure();
   switch (which) {
     case 0:
@@ -4727,6 +4782,7 @@ __global__ void gather_inverse_blocks_kernel(int n, int p, const long long* __re
 }
 
 int BlockSolver::compute_marginals(int n, const int* rows, const int* cols, double* out) {
+  ensure_pp();
   require_structure();
   if (!system_built_) throw StateFailure("compute_marginals before build_system");
   if (n < 0 || (n > 0 && (!rows || !cols || !out))) throw ArgFailure("compute_marginals: bad arguments");
@@ -4841,6 +4897,7 @@ void BlockSolver::copy_edge_data(int set, double* J0, double* J1, double* err) {
 }
 
 void BlockSolver::device_array(int which, double** ptr, size_t* count) {
+  ensure_pp();
   require_structure();
   switch (which) {
     case 0: *ptr = d_Hpp.p; *count = pp_row.size() * p_ * p_; break;

@@ -550,6 +550,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "fuse_reduce_max_partials")) s->impl->fuse_reduce_max_partials = value;
   else if (!std::strcmp(name, "ba_recompute_backsub")) s->impl->ba_recompute_backsub = value != 0;
   else if (!std::strcmp(name, "ba_skip_hpl")) s->impl->ba_skip_hpl = value != 0;
+  else if (!std::strcmp(name, "ba_lazy_pose")) s->impl->ba_lazy_pose = value != 0;
   else if (!std::strcmp(name, "ba_fuse_landmarks")) s->impl->ba_fuse_landmarks = value != 0;
   else if (!std::strcmp(name, "ba_store_ll")) s->impl->ba_store_ll = (int)value;
   else if (!std::strcmp(name, "overlap_assembly")) s->impl->overlap_assembly = value != 0;

@@ -4175,7 +4175,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
   if (phase == 0 && (parts & 1)) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
 #ifdef G2OHIP_CHOL_STAMPS
   if (phase == 0) {
-    if (!d_dbg.p) d_dbg.alloc(64 * 64 + 2 * (size_t)n_slots_ + 2);
+    if (!d_dbg.p) d_dbg.alloc(64 * 64 + 6 * (size_t)n_slots_ + 6);
     G2OHIP_HIP_CHECK(hipMemsetAsync(d_dbg.p, 0, 64 * 64 * sizeof(long long), st));
     plan_.tl = d_dbg.p + 64 * 64;
     dbg_launch_ = 0;
@@ -4664,10 +4664,10 @@ void SparseCholesky::mask_solution(hipStream_t st) {
 bool SparseCholesky::failed(hipStream_t st) {
 #ifdef G2OHIP_CHOL_STAMPS
   if (d_dbg.p && getenv("G2OHIP_CHOL_TIMELINE")) {   // (start, end) of every workgroup of the last wave-kernel launch, 10 ns ticks
-    std::vector<long long> h(64 * 64 + 2 * (size_t)n_slots_);
+    std::vector<long long> h(64 * 64 + 6 * (size_t)n_slots_);
     d_dbg.download(h.data(), h.size(), st);
     if (FILE* fp = fopen(getenv("G2OHIP_CHOL_TIMELINE"), "w")) {
-      for (int q = 0; q < n_slots_; ++q) fprintf(fp, "%d %lld %lld\n", q, h[64 * 64 + 2 * q], h[64 * 64 + 2 * q + 1]);
+      for (int q = 0; q < n_slots_; ++q) fprintf(fp, "%d %lld %lld %lld %lld %lld\n", q, h[64 * 64 + 6 * q], h[64 * 64 + 6 * q + 1], h[64 * 64 + 6 * q + 2], h[64 * 64 + 6 * q + 3], h[64 * 64 + 6 * q + 4]);   // slot, start, end, children there (last front), last front, its parent front
       fclose(fp);
     }
   }

@@ -217,11 +217,12 @@ def format_batch_stats(st):
     return "".join("%s= %s\t " % (k, fmt(st.get(k, 0))) for k in BATCH_STAT_FIELDS)
 
 
-def optimize(graph, solver, iterations, algorithm="lm", stats=None, num_vertices=0, num_edges=0, **lm_args):
+def optimize(graph, solver, iterations, algorithm="lm", stats=None, num_vertices=0, num_edges=0, times=None, **lm_args):
     """SparseOptimizer::optimize (sparse_optimizer.cpp:354-419): returns (#iterations done, chi2 per
     iteration before its step, lambda per iteration, LM trials per iteration).
     stats: a list that receives one G2OBatchStatistics-like dict per iteration (sparse_optimizer.cpp:379-399; the solver
-    must have profiling on for the per-stage times): write them with format_batch_stats for a `-stats` compatible file."""
+    must have profiling on for the per-stage times): write them with format_batch_stats for a `-stats` compatible file.
+    times: a list that receives the wall-clock seconds of every iteration (each ends with a read-back, so they are exact)."""
     import time
     st = DoglegState(**lm_args) if algorithm == "dogleg" else LevenbergState(**lm_args)
     chis, lams, trials = [], [], []
@@ -241,6 +242,8 @@ def optimize(graph, solver, iterations, algorithm="lm", stats=None, num_vertices
         graph.compute_active_errors()
         chis.append(graph.chi2())
         done += 1
+        if times is not None:
+            times.append(time.perf_counter() - ts)
         if stats is not None:
             d = dict(solver.stats()) if hasattr(solver, "stats") else {}
             d.update(iteration=it, numVertices=int(num_vertices), numEdges=int(num_edges), chi2=chis[-1],
