@@ -345,6 +345,14 @@ int g2ohip_solve_schur(g2ohip_solver* s);            /* K5-K8: Hschur, bschur, D
 int g2ohip_solve_reduced(g2ohip_solver* s);          /* K9-K12: x_p = Hschur \ bschur        */
 int g2ohip_solve_back_substitute(g2ohip_solver* s);  /* K13: x_l = Dinv (b_l - Hpl' x_p)     */
 
+/* ---- page-locked host buffers ---------------------------------------------------------------
+ * The boundary takes plain host pointers (Solver::_x / _b are `new double[]` of g2o's own Solver::resizeVector,
+ * g2o/core/solver.cpp:46-70).  Pageable memory crosses PCIe through the driver's staging copy (~6-10 GB/s); a caller that
+ * keeps handing over the SAME buffers every iteration -- the adapter: estimates up, b / x / diagonal down -- registers them
+ * once (hipHostRegister) and the copies run at the link rate.  Unregister before the buffer is freed or reallocated. */
+int g2ohip_host_register(g2ohip_solver* s, void* ptr, size_t bytes);
+int g2ohip_host_unregister(g2ohip_solver* s, void* ptr);
+
 /* ---- device-resident bundle-adjustment front end (a "next" row) -----
  * For graphs of EdgeProjectXYZ2UV (g2o/types/sba/types_six_dof_expmap.h:127-150) the library can
  * produce errors and Jacobians itself and keep the vertex estimates on the device, so a whole
@@ -356,6 +364,15 @@ int g2ohip_solve_back_substitute(g2ohip_solver* s);  /* K13: x_l = Dinv (b_l - H
  * (NULL = identity), CameraParameters (focal_length, principle_point). After g2ohip_build_structure. */
 int g2ohip_ba_set_edges(g2ohip_solver* s, int set, const int32_t* cam_vertex, const int32_t* point_vertex, const double* meas,
                         const double* info, double focal_length, double cx, double cy);
+/* The same with EDGE CLASSES: the edges of one set may differ in their CameraParameters (every EdgeProjectXYZ2UV carries
+ * its own _cam, types_six_dof_expmap.h:133-153) and in their robust kernel (OptimizableGraph::Edge::setRobustKernel,
+ * optimizable_graph.h:436-443; base_binary_edge.hpp:92-112 asks each edge for its own).  class_params [n_classes][5] =
+ * (focal_length, principle_point x, y, robust kernel kind as in g2ohip_set_robust_kernel, delta), edge_class [n] the class of
+ * every edge (NULL with one class).  1 <= n_classes <= 128; with more than one class the set must be on the fused path
+ * (one observation per (pose, landmark) pair, no fixed landmark) -- G2OHIP_ERR_ARG otherwise, and
+ * g2ohip_set_robust_kernel on the set is refused (G2OHIP_ERR_STATE) while the classes are bound. */
+int g2ohip_ba_set_edges_classes(g2ohip_solver* s, int set, const int32_t* cam_vertex, const int32_t* point_vertex, const double* meas,
+                                const double* info, int n_classes, const double* class_params, const int32_t* edge_class);
 /* setEstimate for every vertex + the index mapping: cam_hidx[v] = hessianIndex (-1 fixed),
  * point_hidx[v] = landmark index (0-based, i.e. hessianIndex - num_poses) or -1. */
 int g2ohip_ba_set_estimates(g2ohip_solver* s, int n_cams, const double* cams, const int32_t* cam_hidx, int n_points,

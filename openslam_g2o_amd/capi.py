@@ -51,7 +51,7 @@ EXPORTS = [
     "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute", "g2ohip_ls_create",
     "g2ohip_ls_destroy", "g2ohip_ls_init", "g2ohip_ls_solve", "g2ohip_ls_solve_pattern", "g2ohip_ls_get_stats", "g2ohip_ls_set_option",
     "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time", "g2ohip_add_schur_pattern",
-    "g2ohip_set_lambda_split", "g2ohip_ba_set_edges", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
+    "g2ohip_set_lambda_split", "g2ohip_host_register", "g2ohip_host_unregister", "g2ohip_ba_set_edges", "g2ohip_ba_set_edges_classes", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
     "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
     "g2ohip_schur_operator_prepare", "g2ohip_schur_operator_apply", "g2ohip_solve_async", "g2ohip_trial_stats", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
@@ -140,6 +140,7 @@ def load():
     L.g2ohip_add_schur_pattern.argtypes = [vp, C.c_int, c_int_p, c_int_p]
     L.g2ohip_set_lambda_split.argtypes = [vp, C.c_double, C.c_double, C.c_int]
     L.g2ohip_ba_set_edges.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, C.c_double, C.c_double, C.c_double]
+    L.g2ohip_ba_set_edges_classes.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, c_int_p]
     L.g2ohip_ba_set_estimates.argtypes = [vp, C.c_int, c_dbl_p, c_int_p, C.c_int, c_dbl_p, c_int_p]
     L.g2ohip_ba_get_estimates.argtypes = [vp, c_dbl_p, c_dbl_p]
     L.g2ohip_ba_linearize.argtypes = [vp, C.c_int]
@@ -522,6 +523,17 @@ class HipBlockSolver:
             raise ValueError("baSetEdges: arrays must hold one entry per edge of set %d (%d edges)" % (set_id, n))
         _check(self.L.g2ohip_ba_set_edges(self.h, set_id, _ip(cv), _ip(pv), _dp(m), None if inf is None else _dp(inf),
                                           f, cx, cy), "baSetEdges")
+
+    def baSetEdgesClasses(self, set_id, cam_vertex, point_vertex, meas, class_params, edge_class, info=None):
+        """class_params [n_classes][5] = (f, cx, cy, robust kernel kind, delta); edge_class [n] (g2ohip_ba_set_edges_classes)."""
+        cv, pv, m = _i32(cam_vertex), _i32(point_vertex), _f64(meas)
+        inf = None if info is None else _f64(info)
+        cp, ec = _f64(class_params), _i32(edge_class)
+        n = self._set_sizes[set_id]
+        if len(cv) != n or len(pv) != n or m.size != 2 * n or len(ec) != n or cp.size % 5 or (inf is not None and inf.size != 4 * n):
+            raise ValueError("baSetEdgesClasses: arrays must hold one entry per edge of set %d (%d edges)" % (set_id, n))
+        _check(self.L.g2ohip_ba_set_edges_classes(self.h, set_id, _ip(cv), _ip(pv), _dp(m), None if inf is None else _dp(inf),
+                                                  cp.size // 5, _dp(cp), _ip(ec)), "baSetEdgesClasses")
 
     def baSetEstimates(self, cams, cam_hidx, points, point_hidx):
         cams, points = _f64(cams), _f64(points)

@@ -29,9 +29,29 @@
 #include "g2o/core/robust_kernel_impl.h"
 #include "g2o/core/sparse_optimizer.h"
 #include "g2o/stuff/timeutil.h"
-#include "g2o/types/sba/types_six_dof_expmap.h"   // EdgeProjectXYZ2UV, VertexSE3Expmap, VertexSBAPointXYZ (device fast path)
-#include "g2o/types/slam2d/edge_se2.h"            // EdgeSE2, VertexSE2 (device fast path for planar pose graphs)
-#include "g2o/types/slam3d/edge_se3.h"            // EdgeSE3, VertexSE3 (device fast path for 3-D pose graphs)
+// The device fast paths recognise g2o's edge / vertex types by typeid.  Those classes have out-of-line virtuals, so their
+// typeinfo objects live in libg2o_types_sba / _slam2d / _slam3d: a plugin built with a fast path has to LINK the matching
+// type library (g2o_cli loads plugins with dlopen(RTLD_LAZY) and no RTLD_GLOBAL, dl_wrapper.cpp:118 -- an unresolved typeinfo
+// makes the whole plugin fail to load).  Each fast path is a compile-time switch (default on); with all three off the plugin
+// depends on libg2o_core and libg2ohip only and still offers the generic path and the narrow seam.
+#ifndef G2OHIP_FASTPATH_SBA
+#define G2OHIP_FASTPATH_SBA 1
+#endif
+#ifndef G2OHIP_FASTPATH_SLAM2D
+#define G2OHIP_FASTPATH_SLAM2D 1
+#endif
+#ifndef G2OHIP_FASTPATH_SLAM3D
+#define G2OHIP_FASTPATH_SLAM3D 1
+#endif
+#if G2OHIP_FASTPATH_SBA
+#include "g2o/types/sba/types_six_dof_expmap.h"   // EdgeProjectXYZ2UV, VertexSE3Expmap, VertexSBAPointXYZ (link types_sba)
+#endif
+#if G2OHIP_FASTPATH_SLAM2D
+#include "g2o/types/slam2d/edge_se2.h"            // EdgeSE2, VertexSE2 (link types_slam2d)
+#endif
+#if G2OHIP_FASTPATH_SLAM3D
+#include "g2o/types/slam3d/edge_se3.h"            // EdgeSE3, VertexSE3 (link types_slam3d)
+#endif
 #include "g2ohip.h"
 
 namespace g2o {
@@ -43,17 +63,21 @@ namespace g2o {
 //     consumer's edge types) and the adapter uploads them every iteration (E * (d*dim0 + d*dim1 + d*d + d) doubles:
 //     1.0 GB at the metric configuration); assembly, damping, Schur complement, factorisation and back-substitution
 //     run on the device;
-//   fast path (default; setFastPath(false) or G2OHIP_ADAPTER_FASTPATH=0 turn it off): a group whose edges are all
-//     g2o::EdgeProjectXYZ2UV over VertexSBAPointXYZ / VertexSE3Expmap with one CameraParameters is bound to the
-//     library's device-resident bundle-adjustment front end (g2ohip_ba_*): the measurements go to the device once, per
-//     iteration only the ESTIMATES are uploaded (12 doubles per camera + 3 per point: 34 MB at the metric
-//     configuration) and the errors / Jacobians of types_six_dof_expmap.cpp:288-326 are evaluated inside the
-//     assembly kernels.  chi2 (computeActiveErrors / activeRobustChi2) stays with the optimizer on the CPU.
+//   fast path (default; setFastPath(false) or G2OHIP_ADAPTER_FASTPATH=0 turn it off): EVERY g2o::EdgeProjectXYZ2UV over
+//     VertexSBAPointXYZ / VertexSE3Expmap is bound to the library's device-resident bundle-adjustment front end
+//     (g2ohip_ba_*) as ONE edge set, whatever CameraParameters (each edge carries its own _cam,
+//     types_six_dof_expmap.h:133-153) and whatever robust kernel it has: the distinct (focal length, principal point,
+//     kernel, delta) combinations become edge classes (g2ohip_ba_set_edges_classes, up to 128).  The measurements go to
+//     the device once, per iteration only the ESTIMATES are uploaded (12 doubles per camera + 3 per point: 34 MB at
+//     the metric configuration) and the errors / Jacobians of types_six_dof_expmap.cpp:288-326 are evaluated inside the
+//     assembly kernels.  Next to it ONE homogeneous group of EdgeSE2 or EdgeSE3 may sit on the pose-graph front end
+//     (g2ohip_pg_*); every other group (priors, other edge types, a second pose-graph group) stays generic.
+//     chi2 (computeActiveErrors / activeRobustChi2) stays with the optimizer on the CPU.
 // ---------------------------------------------------------------------------------------------------------
 template <int p, int l>
 class BlockSolverHip : public BlockSolverBase {
  public:
-  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroup(-1), _fastKind(0) {
+  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0) {
     const char* fp = std::getenv("G2OHIP_ADAPTER_FASTPATH");
     if (fp && fp[0] == '0') _fastPath = false;
     if (g2ohip_create(&_h, p, l, device) != G2OHIP_OK) {
@@ -75,6 +99,14 @@ class BlockSolverHip : public BlockSolverBase {
   // (optimization_algorithm_levenberg.cpp:62-68), so the edge sets are registered exactly once per init()
   virtual bool buildStructure(bool zeroBlocks = false) {
     (void)zeroBlocks;
+    return buildStructureImpl(_fastPath, _fastPath);
+  }
+
+ private:
+  // tryBA: merge every EdgeProjectXYZ2UV into one edge set with classes for the BA front end; tryPG: offer the groups to
+  // the pose-graph front end.  A front end that refuses (a marginalised camera, a fixed point on the fused path, more than
+  // 128 classes, ...) sends the call back here without it: the edges then go to their generic per-key groups.
+  bool buildStructureImpl(bool tryBA, bool tryPG) {
     if (!_h || !_optimizer) return false;
     if (g2ohip_init(_h) != G2OHIP_OK) return fail("init");
     if (g2ohip_clear_edge_sets(_h) != G2OHIP_OK) return fail("clear_edge_sets");   // (a second optimize(), online growth: a new graph)
@@ -108,6 +140,9 @@ class BlockSolverHip : public BlockSolverBase {
     }
     // group the active edges
     std::map<GroupKey, size_t> index;
+    int baGroup = -1;
+    std::map<ClassKey, int> classIndex;
+    _baClasses.clear();
     for (size_t k = 0; k < _optimizer->activeEdges().size(); ++k) {
       OptimizableGraph::Edge* e = _optimizer->activeEdges()[k];
       const size_t nv = e->vertices().size();
@@ -126,6 +161,30 @@ class BlockSolverHip : public BlockSolverBase {
         std::cerr << "BlockSolverHip: robust kernel " << typeid(*e->robustKernel()).name() << " has no device counterpart" << std::endl;
         return false;
       }
+      ClassKey ck;
+      if (tryBA && projectEdgeClass(e, key, ck)) {         // one set for all of them, the differences become classes
+        if (baGroup < 0) {
+          baGroup = (int)_groups.size();
+          _groups.push_back(Group());
+          _groups.back().key = key;
+          _groups.back().key.kernel = 0;                   // (the class table owns the kernels)
+          _groups.back().key.delta = 0.0;
+          _groups.back().fast = 1;
+        }
+        typename std::map<ClassKey, int>::iterator ic = classIndex.find(ck);
+        if (ic == classIndex.end()) {
+          if (classIndex.size() >= 128) return buildStructureImpl(false, tryPG);
+          ic = classIndex.insert(std::make_pair(ck, (int)classIndex.size())).first;
+          const double row[5] = {ck.f, ck.cx, ck.cy, (double)ck.kernel, ck.delta};
+          _baClasses.insert(_baClasses.end(), row, row + 5);
+        }
+        Group& g = _groups[baGroup];
+        g.edges.push_back(e);
+        g.cls.push_back(ic->second);
+        g.v0.push_back(v0->hessianIndex());
+        g.v1.push_back(v1->hessianIndex());
+        continue;
+      }
       typename std::map<GroupKey, size_t>::iterator it = index.find(key);
       if (it == index.end()) {
         it = index.insert(std::make_pair(key, _groups.size())).first;
@@ -142,7 +201,7 @@ class BlockSolverHip : public BlockSolverBase {
       const int n = (int)g.edges.size();
       g.set = g2ohip_add_edge_set(_h, g.key.d, n, g.v0.data(), g.key.dim1 ? g.v1.data() : 0);
       if (g.set < 0) return fail("add_edge_set");
-      if (g.key.kernel > 0 && g2ohip_set_robust_kernel(_h, g.set, g.key.kernel, g.key.delta) != G2OHIP_OK) return fail("set_robust_kernel");
+      if (g.key.kernel > 0 && !g.fast && g2ohip_set_robust_kernel(_h, g.set, g.key.kernel, g.key.delta) != G2OHIP_OK) return fail("set_robust_kernel");
       // The library takes a side's dimension from the hessian indices; a side whose vertices are ALL fixed (e.g. a
       // localisation graph over fixed points) is taken as a pose side there (p columns), whatever the vertex type: the
       // buffers are sized for the larger of the two so that g2ohip_set_edge_data never reads past their end.
@@ -155,27 +214,31 @@ class BlockSolverHip : public BlockSolverBase {
     if (g2ohip_build_structure(_h, _nP, _nL, _doSchur ? 1 : 0) != G2OHIP_OK) return fail("build_structure");
     resizeVector(g2ohip_vector_size(_h));              // Solver::_x, _b (solver.cpp:46-70)
     _diag.assign(g2ohip_vector_size(_h), 0.0);
-    _fastGroup = -1;
-    _fastKind = 0;
-    if (_fastPath)
-      for (size_t gi = 0; gi < _groups.size() && _fastGroup < 0; ++gi) {
-        if (bindProjectXYZ2UV(_groups[gi])) {
-          _fastGroup = (int)gi;
-          _fastKind = 1;
-        } else if (bindSE2(_groups[gi])) {
-          _fastGroup = (int)gi;
-          _fastKind = 2;
-        } else if (bindSE3(_groups[gi])) {
-          _fastGroup = (int)gi;
-          _fastKind = 3;
+    _fastGroups = 0;
+    if (baGroup >= 0) {
+      if (!bindProjectXYZ2UV(_groups[baGroup])) return buildStructureImpl(false, tryPG);   // everything generic (the set is re-registered per key)
+      ++_fastGroups;
+    }
+    if (tryPG)
+      for (size_t gi = 0; gi < _groups.size(); ++gi) {     // the pose-graph front end holds one set
+        Group& g = _groups[gi];
+        if (g.fast) continue;
+        if (bindSE2(g)) g.fast = 2;
+        else if (bindSE3(g)) g.fast = 3;
+        if (g.fast) {
+          ++_fastGroups;
+          break;
         }
       }
     return true;
   }
 
+ public:
+
   //! device-resident front end for homogeneous EdgeProjectXYZ2UV groups (on by default)
   void setFastPath(bool on) { _fastPath = on; }
-  bool fastPathActive() const { return _fastGroup >= 0; }
+  bool fastPathActive() const { return _fastGroups > 0; }
+  int fastGroups() const { return _fastGroups; }       // edge sets bound to a device front end (BA: 1 for all its classes)
 
   // Online growth (block_solver.hpp:297-351).  SparseOptimizer::updateInitialization has appended the new vertices to
   // indexMapping() and the new edges to activeEdges() before it calls this (sparse_optimizer.cpp:269-352), so the index
@@ -202,8 +265,8 @@ class BlockSolverHip : public BlockSolverBase {
     JacobianWorkspace& ws = _optimizer->jacobianWorkspace();
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       Group& g = _groups[gi];
-      if ((int)gi == _fastGroup) {                     // estimates up, errors + Jacobians on the device
-        if (!(_fastKind == 2 ? uploadPosesSE2() : (_fastKind == 3 ? uploadPosesSE3() : uploadEstimates()))) return false;
+      if (g.fast) {                                    // estimates up, errors + Jacobians on the device
+        if (!(g.fast == 2 ? uploadPosesSE2() : (g.fast == 3 ? uploadPosesSE3() : uploadEstimates()))) return false;
         continue;
       }
       const int d = g.key.d, d0 = g.key.dim0, d1 = g.key.dim1;
@@ -310,10 +373,22 @@ class BlockSolverHip : public BlockSolverBase {
   struct Group {
     GroupKey key;
     int set;
+    int fast;                                            // 0: generic path; device front end 1: EdgeProjectXYZ2UV (g2ohip_ba_*), 2 / 3: EdgeSE2 / EdgeSE3 (g2ohip_pg_*, type 1 / 2)
     std::vector<OptimizableGraph::Edge*> edges;
-    std::vector<int32_t> v0, v1;
+    std::vector<int32_t> v0, v1, cls;                    // (cls: edge class of a BA group's edges)
     std::vector<double> J0, J1, Om, err;
-    Group() : key(), set(-1) {}
+    Group() : key(), set(-1), fast(0) {}
+  };
+  struct ClassKey {                                      // what distinguishes two EdgeProjectXYZ2UV on the device: intrinsics + robust kernel
+    double f, cx, cy, delta;
+    int kernel;
+    bool operator<(const ClassKey& o) const {
+      if (f != o.f) return f < o.f;
+      if (cx != o.cx) return cx < o.cx;
+      if (cy != o.cy) return cy < o.cy;
+      if (kernel != o.kernel) return kernel < o.kernel;
+      return delta < o.delta;
+    }
   };
 
   // robust kernel -> the kind numbers of g2ohip_set_robust_kernel (robust_kernel_impl.h:77-140); 0: none, -1: unknown
@@ -346,22 +421,25 @@ class BlockSolverHip : public BlockSolverBase {
     return false;
   }
 
-  // ---- fast path: a group of EdgeProjectXYZ2UV (types_six_dof_expmap.h:133-153; vertex 0 = VertexSBAPointXYZ, vertex 1 =
-  // VertexSE3Expmap) with one CameraParameters is handed to g2ohip_ba_set_edges; false = leave the group on the generic path
+  // ---- fast path: EdgeProjectXYZ2UV (types_six_dof_expmap.h:133-153; vertex 0 = VertexSBAPointXYZ, vertex 1 = VertexSE3Expmap).
+  // projectEdgeClass: is this edge one, and which (intrinsics, robust kernel) class does it belong to
+#if G2OHIP_FASTPATH_SBA
+  static bool projectEdgeClass(OptimizableGraph::Edge* e, const GroupKey& key, ClassKey& ck) {
+    if (p != 6 || l != 3 || key.d != 2 || key.dim0 != 3 || key.dim1 != 6) return false;
+    if (typeid(*e) != typeid(EdgeProjectXYZ2UV)) return false;
+    if (typeid(*e->vertex(0)) != typeid(VertexSBAPointXYZ) || typeid(*e->vertex(1)) != typeid(VertexSE3Expmap)) return false;
+    const CameraParameters* c = static_cast<const EdgeProjectXYZ2UV*>(e)->_cam;
+    if (!c) return false;
+    ck.f = c->focal_length;
+    ck.cx = c->principle_point[0];
+    ck.cy = c->principle_point[1];
+    ck.kernel = key.kernel;
+    ck.delta = key.kernel ? key.delta : 0.0;
+    return true;
+  }
+  // the merged group is handed to g2ohip_ba_set_edges_classes; false = the front end refused, the caller regroups generically
   bool bindProjectXYZ2UV(Group& g) {
-    if (p != 6 || l != 3 || g.key.d != 2 || g.key.dim0 != 3 || g.key.dim1 != 6 || g.edges.empty()) return false;
-    const CameraParameters* cam0 = 0;
-    for (size_t k = 0; k < g.edges.size(); ++k) {
-      if (typeid(*g.edges[k]) != typeid(EdgeProjectXYZ2UV)) return false;
-      const EdgeProjectXYZ2UV* e = static_cast<const EdgeProjectXYZ2UV*>(g.edges[k]);
-      if (typeid(*e->vertex(0)) != typeid(VertexSBAPointXYZ) || typeid(*e->vertex(1)) != typeid(VertexSE3Expmap)) return false;
-      const CameraParameters* c = e->_cam;
-      if (!c) return false;
-      if (!cam0) cam0 = c;
-      if (c->focal_length != cam0->focal_length || c->principle_point[0] != cam0->principle_point[0] ||
-          c->principle_point[1] != cam0->principle_point[1])
-        return false;
-    }
+    if (g.edges.empty()) return false;
     // estimate tables over every vertex the group touches (fixed ones included), in order of first appearance
     _cams.clear();
     _points.clear();
@@ -403,8 +481,9 @@ class BlockSolverHip : public BlockSolverBase {
       if (hi >= 0 && hi < _nP) return false;              // a point that is not marginalized: likewise
       _pointHidx[i] = hi < 0 ? -1 : hi - _nP;
     }
-    if (g2ohip_ba_set_edges(_h, g.set, camOf.data(), pointOf.data(), meas.data(), identity ? 0 : info.data(), cam0->focal_length,
-                            cam0->principle_point[0], cam0->principle_point[1]) != G2OHIP_OK) {
+    const int nClasses = (int)(_baClasses.size() / 5);
+    if (g2ohip_ba_set_edges_classes(_h, g.set, camOf.data(), pointOf.data(), meas.data(), identity ? 0 : info.data(), nClasses, _baClasses.data(),
+                                    g.cls.data()) != G2OHIP_OK) {
       std::cerr << "BlockSolverHip: fast path not available (" << g2ohip_last_error() << "), using the generic path" << std::endl;
       return false;
     }
@@ -412,15 +491,21 @@ class BlockSolverHip : public BlockSolverBase {
     _pointBuf.assign(3 * _points.size(), 0.0);
     if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
       std::cerr << "BlockSolverHip: device front end (g2ohip_ba_*) for " << n << " EdgeProjectXYZ2UV, " << _cams.size() << " cameras, " << _points.size()
-                << " points" << std::endl;
+                << " points, " << nClasses << " edge class" << (nClasses == 1 ? "" : "es") << std::endl;
     return true;
   }
+#else
+  static bool projectEdgeClass(OptimizableGraph::Edge*, const GroupKey&, ClassKey&) { return false; }
+  bool bindProjectXYZ2UV(Group&) { return false; }
+  bool uploadEstimates() { return false; }
+#endif
 
   // setEstimate of every camera (R column-major | t, world -> camera as VertexSE3Expmap holds it) and point, then the
   // device evaluates errors and Jacobians (computeActiveErrors + linearizeOplus of the group)
   // A homogeneous group of EdgeSE2 over VertexSE2 (types/slam2d/edge_se2.h:41-57, vertex_se2.h:41-59; p = 3): error,
   // Jacobians (edge_se2.cpp:76-99) and the quadratic forms are evaluated on the device from the estimates (x, y, theta) --
   // g2ohip_pg_* with type 1.  The types are recognised by typeid: no member of them is called that is not inline.
+#if G2OHIP_FASTPATH_SLAM2D
   bool bindSE2(Group& g) {
     if (p != 3 || g.key.d != 3 || g.key.dim0 != 3 || g.key.dim1 != 3 || g.edges.empty()) return false;
     for (size_t k = 0; k < g.edges.size(); ++k) {
@@ -471,7 +556,12 @@ class BlockSolverHip : public BlockSolverBase {
     if (g2ohip_pg_linearize(_h, 1) != G2OHIP_OK) return fail("pg_linearize");
     return true;
   }
+#else
+  bool bindSE2(Group&) { return false; }
+  bool uploadPosesSE2() { return false; }
+#endif
 
+#if G2OHIP_FASTPATH_SLAM3D
   // A homogeneous group of EdgeSE3 over VertexSE3 (types/slam3d/edge_se3.cpp:48-75, vertex_se3.h:107-116; p = 6): g2ohip_pg_*
   // with type 2, estimates and measurements as isometries [12] = R (column-major) | t.
   static void isometryTo12(const Eigen::Isometry3d& T, double* c) {
@@ -522,7 +612,12 @@ class BlockSolverHip : public BlockSolverBase {
     if (g2ohip_pg_linearize(_h, 1) != G2OHIP_OK) return fail("pg_linearize");
     return true;
   }
+#else
+  bool bindSE3(Group&) { return false; }
+  bool uploadPosesSE3() { return false; }
+#endif
 
+#if G2OHIP_FASTPATH_SBA
   bool uploadEstimates() {
     for (size_t i = 0; i < _cams.size(); ++i) {
       const SE3Quat& T = _cams[i]->estimate();
@@ -539,6 +634,7 @@ class BlockSolverHip : public BlockSolverBase {
     if (g2ohip_ba_linearize(_h, 1) != G2OHIP_OK) return fail("ba_linearize");
     return true;
   }
+#endif
 
   g2ohip_solver* _h;
   bool _doSchur, _writeDebug;
@@ -546,14 +642,20 @@ class BlockSolverHip : public BlockSolverBase {
   std::vector<Group> _groups;
   std::vector<double> _diagMirror, _diag;
   bool _fastPath;
-  int _fastGroup;                                      // index into _groups of the group on the device front end, or -1
-  int _fastKind;                                       // 1: EdgeProjectXYZ2UV (g2ohip_ba_*), 2 / 3: EdgeSE2 / EdgeSE3 (g2ohip_pg_*, type 1 / 2)
+  int _fastGroups;                                     // groups bound to a device front end (Group::fast)
+  std::vector<double> _baClasses;                      // class table of the BA group: (f, cx, cy, kernel kind, delta) per class
+#if G2OHIP_FASTPATH_SLAM2D
   std::vector<VertexSE2*> _pgVerts;
+#endif
+#if G2OHIP_FASTPATH_SLAM3D
   std::vector<VertexSE3*> _pg3Verts;
+#endif
   std::vector<int32_t> _pgHidx;
   std::vector<double> _pgBuf;
+#if G2OHIP_FASTPATH_SBA
   std::vector<VertexSE3Expmap*> _cams;
   std::vector<VertexSBAPointXYZ*> _points;
+#endif
   std::vector<int32_t> _camHidx, _pointHidx;
   std::vector<double> _camBuf, _pointBuf;
 };

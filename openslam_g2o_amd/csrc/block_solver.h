@@ -117,6 +117,8 @@ class BlockSolver {
   // loop needs no host round trip of Jacobians or estimates
   void ba_set_edges(int set, const int* cam_vertex, const int* point_vertex, const double* meas, const double* info, double f,
                     double cx, double cy);
+  void ba_set_edges_classes(int set, const int* cam_vertex, const int* point_vertex, const double* meas, const double* info, double f,
+                            double cx, double cy, int n_classes, const double* class_params, const int* edge_class);
   void ba_set_estimates(int n_cams, const double* cams, const int* cam_hidx, int n_points, const double* points, const int* point_hidx);
   void ba_get_estimates(double* cams, double* points);
   void ba_linearize(bool jacobians);
@@ -311,6 +313,9 @@ class BlockSolver {
   struct BaFrontEnd {
     int set = -1, n_edges = 0, n_cams = 0, n_points = 0;
     double f = 0, cx = 0, cy = 0;
+    int n_classes = 1;          // edge classes (ba_set_edges_classes): > 1 = the class of an observation rides in the top byte of its
+    DevBuf<double> ctab;        // camera index, ctab[5 c] = (f, cx, cy, robust kernel kind, delta)
+    std::vector<double> h_ctab;
     DevBuf<int> cam_v, pt_v, cam_hidx, pt_hidx, edge_hpl;
     std::vector<int> h_cam_v, h_pt_v, h_cam_hidx, h_pt_hidx;   // host copies: index validation (ba_validate)
     // which estimates the assembled system was built from (back-substitution re-evaluates the Jacobians from them)

@@ -115,6 +115,23 @@ __device__ __forceinline__ double robust_rho(int kind, double delta, double e2) 
   }
 }
 
+// Edge classes of the BA front end (g2ohip_ba_set_edges_classes): observations that differ in camera intrinsics
+// (EdgeProjectXYZ2UV::_cam, g2o/types/sba/types_six_dof_expmap.h:133-153) or in their robust kernel
+// (OptimizableGraph::Edge::robustKernel, optimizable_graph.h:436-443) share ONE edge set; the class of an observation
+// rides in the top byte of its camera index in every device copy, ctab[5 c] = (f, cx, cy, kernel kind, delta).  CLS = false
+// (one class, the common case): the five values stay kernel arguments (scalar registers), nothing is decoded.
+template <bool CLS>
+__device__ __forceinline__ int ba_edge_class(int camword, const double* __restrict__ ctab, double& f, double& cx, double& cy, int& kind,
+                                             double& delta) {
+  if constexpr (CLS) {
+    const double* t = ctab + 5 * (size_t)((unsigned)camword >> 24);
+    f = t[0]; cx = t[1]; cy = t[2]; kind = (int)t[3]; delta = t[4];
+    return camword & 0xffffff;
+  } else {
+    return camword;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // K2, vertex part: H_vv (+)= sum_e J' (rho' Omega) J ;  b_v (+)= sum_e J' (-rho' Omega e)
 // base_binary_edge.hpp:54-120 / base_unary_edge.hpp:42-72, destination-major: G lanes share
@@ -917,9 +934,11 @@ __device__ __forceinline__ double ba_linearize_edge(int e, const double* __restr
                                                     const double* __restrict__ meas, double f, double cx, double cy,
                                                     double* __restrict__ Jpt, double* __restrict__ Jcam, double* __restrict__ err,
                                                     int want_jac, const double* __restrict__ omega, int ident, int kind, double delta,
-                                                    bool want_rho) {
+                                                    bool want_rho, const double* __restrict__ ctab) {
   double T[12], X[3], z2[2];
-  load_vec<12>(cams + (size_t)cam_v[e] * 12, T);
+  int cw = cam_v[e];
+  if (ctab) cw = ba_edge_class<true>(cw, ctab, f, cx, cy, kind, delta);
+  load_vec<12>(cams + (size_t)cw * 12, T);
   const double* Xp = pts + (size_t)pt_v[e] * 3;
   X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
   load_vec<2>(meas + (size_t)e * 2, z2);
@@ -967,12 +986,12 @@ __global__ void __launch_bounds__(kThreads) ba_linearize_kernel(int n, const dou
                                                               double* __restrict__ Jpt, double* __restrict__ Jcam,
                                                               double* __restrict__ err, int want_jac,
                                                               const double* __restrict__ omega, int ident, int kind, double delta,
-                                                              double* __restrict__ chi_part) {
+                                                              double* __restrict__ chi_part, const double* __restrict__ ctab) {
   // chi_part != nullptr: the robustified chi2 of the edges (sparse_optimizer.cpp:100-114) rides along -- one partial sum
   // per workgroup, folded to 1 024 by fold_partials_kernel (fixed order); saves the pass of chi2_kernel over the errors
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   double rho = 0.0;
-  if (e < n) rho = ba_linearize_edge(e, cams, pts, cam_v, pt_v, meas, f, cx, cy, Jpt, Jcam, err, want_jac, omega, ident, kind, delta, chi_part != nullptr);
+  if (e < n) rho = ba_linearize_edge(e, cams, pts, cam_v, pt_v, meas, f, cx, cy, Jpt, Jcam, err, want_jac, omega, ident, kind, delta, chi_part != nullptr, ctab);
   if (chi_part) {
     __shared__ double sh[kThreads];
     sh[threadIdx.x] = rho;
@@ -1125,13 +1144,13 @@ __device__ __forceinline__ void ba_hpl_block(const BaEdgeLin& L, const double (&
 #ifndef G2OHIP_ASMLM_OCC
 #define G2OHIP_ASMLM_OCC 4   // 126 VGPRs, 36 KB LDS: 4 workgroups per CU
 #endif
-template <int G>
+template <int G, bool CLS = false>
 __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landmarks_kernel(
     int nL, const int* __restrict__ vptr, const int* __restrict__ vent, const double* __restrict__ cams, const double* __restrict__ pts,
     const int* __restrict__ cam_lm, const int* __restrict__ pt_lm, const double* __restrict__ meas_lm, const double* __restrict__ omega_lm,
     const int* __restrict__ hpl_lm, double f, double cx, double cy, int kind, double delta, double* __restrict__ Hll,
     double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ err, int ident, const int* __restrict__ pl_colptr,
-    int write_hpl) {
+    int write_hpl, const double* __restrict__ ctab) {
   // write_hpl == 0: nobody reads Hpl this iteration (the Schur tiles and the back-substitution re-evaluate the Jacobians,
   // ba_schur_tile_kernel / ba_back_substitute_kernel): only Hll, b_l and the errors are produced -- 0.72 GB less to write
   // at the metric configuration.
@@ -1156,7 +1175,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landma
     double T[12], X[3], z2[2], Op[4];
     const double* Xp = pts + (size_t)pt_lm[k] * 3;
     X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
-    load_vec<12>(cams + (size_t)cam_lm[k] * 12, T);
+    load_vec<12>(cams + (size_t)ba_edge_class<CLS>(cam_lm[k], ctab, f, cx, cy, kind, delta) * 12, T);
     load_vec<2>(meas_lm + (size_t)k * 2, z2);
     if (ident) {   // information().setIdentity() declared for the whole set: no per-edge read
       Op[0] = Op[3] = 1.0;
@@ -1208,7 +1227,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMLM_OCC) ba_assemble_landma
 // observation is evaluated once per iteration instead of twice.  Hll and b_l go to the LDS stage and to HBM (readers: the
 // back-substitution, b, computeScale, multiplyHessian); they are summed in observation-list order, the stand-alone kernel
 // sums per lane group: the two agree to rounding, not bit for bit.
-template <int G, bool FLL>
+template <int G, bool FLL, bool CLS = false>
 __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kernel(
     const int* __restrict__ tile_lm0, const double* __restrict__ cams, const double* __restrict__ pts, const int* __restrict__ cam_q,
     const int* __restrict__ pt_q, const double* __restrict__ meas_q, const double* __restrict__ omega_q, double f, double cx, double cy,
@@ -1216,7 +1235,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
     const int* __restrict__ td_ptr, const int* __restrict__ te_pack, const unsigned short* __restrict__ te_lm, double* __restrict__ Pd,
     double* __restrict__ Pr, double* Hll, const double* __restrict__ lam, const int4* __restrict__ ll_rec,
     const int4* __restrict__ tile_ll, const int* __restrict__ ll_edge, double* __restrict__ err, const int2* __restrict__ tile_q2,
-    int store_hll, const unsigned short* __restrict__ slot_lm) {
+    int store_hll, const unsigned short* __restrict__ slot_lm, const double* __restrict__ ctab) {
   // (FLL: meas_q / omega_q are the slot-major copies ll_meas / ll_omega; cam_q / pt_q are unused; store_hll = 0: Hll stays in
   // the LDS stage -- the solve path reads Dinv and b_l only --, err = nullptr: the errors are not written either)
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1290,7 +1309,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
 #pragma unroll
         for (int i = 0; i < 9; ++i) v[i] = 0.0;
         {
-          const int ci = rc.y, pi = rc.z, q = rc.w, e = ll_edge[sg];
+          const int ci = ba_edge_class<CLS>(rc.y, ctab, f, cx, cy, kind, delta), pi = rc.z, q = rc.w, e = ll_edge[sg];
           double T[12], X[3], z2[2], Op[4];
           const double* Xp = pts + (size_t)pi * 3;
           X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
@@ -1390,7 +1409,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
         const int sc = min(s_, ntot - 1);
         const int qq = sc < nslots ? q0 + sc : t2.x + (sc - nslots);   // Hpl block of this slot
         const bool pre = sb == 0 && s_ < nslots;
-        const int c_ = pre ? cq : cam_q[qq], p_ = pre ? pq : pt_q[qq];
+        const int c_ = ba_edge_class<CLS>(pre ? cq : cam_q[qq], ctab, f, cx, cy, kind, delta), p_ = pre ? pq : pt_q[qq];
         double T[12], X[3], z2[2], Op[4];
         load_vec<12>(cams + (size_t)c_ * 12, T);
         const double* Xp = pts + (size_t)p_ * 3;
@@ -1452,12 +1471,13 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
 // Hpl(pose, lm)' x_p = A' (w Omega) (B x_p): the two Jacobians of an observation are re-evaluated from the estimates the
 // system was built from (12 + 3 + 2 doubles, the poses out of L2) instead of streaming an 18-double block per
 // observation -- the kernel moves a sixth of the bytes.  G lanes per landmark like the assembly.
-template <int G>
+template <int G, bool CLS = false>
 __global__ void __launch_bounds__(kThreads) ba_back_substitute_kernel(
     int nL, const int* __restrict__ vptr, const double* __restrict__ cams, const double* __restrict__ pts,
     const int* __restrict__ cam_lm, const int* __restrict__ pt_lm, const double* __restrict__ meas_lm, const double* __restrict__ omega_lm,
     const int* __restrict__ row_lm, double f, double cx, double cy, int kind, double delta, int ident,
-    const double* __restrict__ Dinv, const double* __restrict__ bl, const double* __restrict__ xp, double* __restrict__ xl) {
+    const double* __restrict__ Dinv, const double* __restrict__ bl, const double* __restrict__ xp, double* __restrict__ xl,
+    const double* __restrict__ ctab) {
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int lm = gt / G, g = gt % G;
   const bool active = lm < nL;
@@ -1469,7 +1489,7 @@ __global__ void __launch_bounds__(kThreads) ba_back_substitute_kernel(
     double T[12], X[3], z2[2], Op[4], xv[6];
     const double* Xp = pts + (size_t)pt_lm[k] * 3;
     X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
-    load_vec<12>(cams + (size_t)cam_lm[k] * 12, T);
+    load_vec<12>(cams + (size_t)ba_edge_class<CLS>(cam_lm[k], ctab, f, cx, cy, kind, delta) * 12, T);
     load_vec<2>(meas_lm + (size_t)k * 2, z2);
     load_vec<6>(xp + (size_t)row * 6, xv);
     if (ident) {
@@ -1510,11 +1530,12 @@ __global__ void __launch_bounds__(kThreads) ba_back_substitute_kernel(
 
 // The same back-substitution over the lane slots of the Schur tiles (one lane per observation, 92 % of the lanes busy
 // where eight lanes per landmark keep five of eight): the terms of a list are summed into its first lane by doubling.
+template <bool CLS>
 __global__ void __launch_bounds__(kThreads) ba_back_substitute_slots_kernel(
     const int* __restrict__ tile_lm0, const int4* __restrict__ tile_ll, const int4* __restrict__ ll_rec, const int* __restrict__ ll_row,
     const double* __restrict__ ll_meas, const double* __restrict__ ll_omega, const double* __restrict__ cams,
     const double* __restrict__ pts, double f, double cx, double cy, int kind, double delta, int ident, const double* __restrict__ Dinv,
-    const double* __restrict__ bl, const double* __restrict__ xp, double* __restrict__ xl) {
+    const double* __restrict__ bl, const double* __restrict__ xp, double* __restrict__ xl, const double* __restrict__ ctab) {
   const int t = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   const int l0 = tile_lm0[(size_t)t * 8];
   const int4 tl = tile_ll[t];   // first slot, slots (a multiple of 64), first observation, longest list
@@ -1533,7 +1554,7 @@ __global__ void __launch_bounds__(kThreads) ba_back_substitute_slots_kernel(
       double T[12], X[3], z2[2], Op[4], xv[6];
       const double* Xp = pts + (size_t)rc.z * 3;
       X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
-      load_vec<12>(cams + (size_t)rc.y * 12, T);
+      load_vec<12>(cams + (size_t)ba_edge_class<CLS>(rc.y, ctab, f, cx, cy, kind, delta) * 12, T);
       load_vec<2>(ll_meas + sg * 2, z2);
       load_vec<6>(xp + (size_t)max(row, 0) * 6, xv);
       if (ident) {
@@ -1582,12 +1603,12 @@ __global__ void __launch_bounds__(kThreads) ba_back_substitute_slots_kernel(
 #ifndef G2OHIP_ASMP_OCC
 #define G2OHIP_ASMP_OCC 2
 #endif
-template <int G>
+template <int G, bool CLS = false>
 __global__ void __launch_bounds__(kThreads, G2OHIP_ASMP_OCC) ba_assemble_poses_kernel(
     int nP, const int* __restrict__ vptr, const double* __restrict__ cams, const double* __restrict__ pts,
     const int* __restrict__ cam_pm, const int* __restrict__ pt_pm, const double* __restrict__ meas_pm, const double* __restrict__ omega_pm,
     double f, double cx, double cy, int kind, double delta, double* __restrict__ Hpp, const int* __restrict__ diag_blk,
-    double* __restrict__ bp, int accumulate, int ident, const int* __restrict__ act) {
+    double* __restrict__ bp, int accumulate, int ident, const int* __restrict__ act, const double* __restrict__ ctab) {
   // act != nullptr: nP poses of a list (a rank of a sharded job holds observations of a fraction of the poses; the blocks
   // of the others are zero from build_structure on and nobody writes them)
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1608,7 +1629,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMP_OCC) ba_assemble_poses_k
   // gather): the point index is requested two observations ahead, the point, the measurement and the information
   // matrix one ahead -- with ~2 waves per SIMD nothing else hides the two round trips per observation.
   const int kf = k0 + g;
-  if (kf < k1) load_vec<12>(cams + (size_t)cam_pm[kf] * 12, T);
+  if (kf < k1) load_vec<12>(cams + (size_t)(cam_pm[kf] & (CLS ? 0xffffff : -1)) * 12, T);
   int pt1 = kf < k1 ? pt_pm[kf] : 0, pt2 = kf + G < k1 ? pt_pm[kf + G] : 0;
   double Xn[3] = {0.0, 0.0, 0.0}, z2n[2] = {0.0, 0.0}, Opn[4] = {1.0, 0.0, 0.0, 1.0};
   if (kf < k1) {
@@ -1634,6 +1655,7 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_ASMP_OCC) ba_assemble_poses_k
       }
       pt2 = pt3;
     }
+    if constexpr (CLS) (void)ba_edge_class<true>(cam_pm[k], ctab, f, cx, cy, kind, delta);   // (a pose's observations share the camera, not the class)
     BaEdgeLin L;
     ba_edge_linearize(T, X, z2, Op, f, cx, cy, kind, delta, false, L);
     const double w = L.w;
@@ -2716,6 +2738,8 @@ void BlockSolver::set_robust_kernel(int set, int kind, double delta) {
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
   if (kind < 0 || kind > 5) throw ArgFailure("unsupported robust kernel");
   if (kind != 0 && !(delta > 0.0)) throw ArgFailure("robust kernel: delta must be positive");
+  if (set == ba_.set && ba_.n_classes > 1)
+    throw StateFailure("set_robust_kernel: the set is bound to the BA front end with edge classes, which carry their own kernels (ba_set_edges_classes)");
   sets_[set]->kernel_kind = kind;
   sets_[set]->delta = delta;
 }
@@ -2809,15 +2833,20 @@ void BlockSolver::launch_ba_landmarks(bool write_hpl) {
   EdgeSet& es = *sets_[ba_.set];
   const size_t sizeP = (size_t)nP_ * p_;
   const int GL = ba_lm_group();
-#define G2OHIP_BA_LM(GG)                                                                                                         \
-  hipLaunchKernelGGL((ba_assemble_landmarks_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p, \
+#define G2OHIP_BA_LM_(GG, CC)                                                                                                    \
+  hipLaunchKernelGGL((ba_assemble_landmarks_kernel<GG, CC>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p, \
                      es.vl_ent.p, ba_.cams.p, ba_.pts.p, ba_.cam_lm.p, ba_.pt_lm.p, ba_.meas_lm.p, ba_.omega_lm.p, ba_.hpl_lm.p, ba_.f, \
                      ba_.cx, ba_.cy, es.kernel_kind, es.delta, d_Hll.p, d_b.p + sizeP, d_Hpl.p, es.own_err.p, ba_.omega_identity ? 1 : 0, \
-                     d_pl_colptr.p, write_hpl ? 1 : 0)
-  if (GL == 1) G2OHIP_BA_LM(1);
+                     d_pl_colptr.p, write_hpl ? 1 : 0, ba_.ctab.p)
+#define G2OHIP_BA_LM(GG) G2OHIP_BA_LM_(GG, false)
+  if (ba_.n_classes > 1) {   // (edge classes: one lane-group width is instantiated)
+    if (GL == 1) G2OHIP_BA_LM_(1, true);
+    else G2OHIP_BA_LM_(8, true);
+  } else if (GL == 1) G2OHIP_BA_LM(1);
   else if (GL == 4) G2OHIP_BA_LM(4);
   else G2OHIP_BA_LM(8);
 #undef G2OHIP_BA_LM
+#undef G2OHIP_BA_LM_
 }
 
 // May the fused BA assembly leave Hpl unwritten?  Only while its two readers on the solve path (Schur tiles,
@@ -2890,23 +2919,26 @@ void BlockSolver::launch_ba_poses(hipStream_t sp) {
   const bool compact = es.n_vp_act > 0 && sets_.size() == 1 && chol_opt.world > 1;
   const int nPk = compact ? es.n_vp_act : nP_;
   const int* pact = compact ? es.vp_act.p : (const int*)nullptr;
-#define G2OHIP_BA_POSE(GG)                                                                                                       \
-  hipLaunchKernelGGL((ba_assemble_poses_kernel<GG>), dim3(grid_for((size_t)nPk * GG)), dim3(kThreads), 0, sp, nPk, es.vp_ptr.p,  \
+#define G2OHIP_BA_POSE_(GG, CC)                                                                                                  \
+  hipLaunchKernelGGL((ba_assemble_poses_kernel<GG, CC>), dim3(grid_for((size_t)nPk * GG)), dim3(kThreads), 0, sp, nPk, es.vp_ptr.p,  \
                      ba_.cams.p, ba_.pts.p, ba_.cam_pm.p, ba_.pt_pm.p, ba_.meas_pm.p, ba_.omega_pm.p, ba_.f, ba_.cx, ba_.cy,       \
                      es.kernel_kind, es.delta, d_Hpp.p, d_pp_diag.p, d_b.p, es.first_pose ? 0 : 1, ba_.omega_identity ? 1 : 0,     \
-                     pact)
+                     pact, ba_.ctab.p)
+#define G2OHIP_BA_POSE(GG) G2OHIP_BA_POSE_(GG, false)
   if (compact && es.first_pose)
     hipLaunchKernelGGL(zero_inactive_poses_kernel, dim3(grid_for((size_t)(nP_ - nPk) * (p_ * p_ + p_))), dim3(kThreads), 0, sp, nP_ - nPk, p_,
                        es.vp_act.p + nPk, d_pp_diag.p, d_Hpp.p, d_b.p);
   if (es.touches_pose) {
     static const int g_env = getenv("G2OHIP_POSE_GROUP") ? atoi(getenv("G2OHIP_POSE_GROUP")) : 0;   // (experiments)
     const int Gp = g_env > 0 ? g_env : G;
-    if (Gp <= 1) G2OHIP_BA_POSE(1);
+    if (ba_.n_classes > 1) G2OHIP_BA_POSE_(8, true);   // (edge classes: one lane-group width is instantiated)
+    else if (Gp <= 1) G2OHIP_BA_POSE(1);
     else if (Gp <= 4) G2OHIP_BA_POSE(4);
     else if (Gp <= 8) G2OHIP_BA_POSE(8);
     else G2OHIP_BA_POSE(16);
   }
 #undef G2OHIP_BA_POSE
+#undef G2OHIP_BA_POSE_
 }
 
 // a reader of Hpp / b_p before the solve that was to run the pose side (build_system_impl, `lazy`)
@@ -2940,6 +2972,8 @@ void BlockSolver::build_system_impl() {
     EdgeSet& es = *esp;
     ++set_index;
     if (es.n == 0) continue;
+    if (set_index == ba_.set && ba_.n_classes > 1 && !(ba_fused && ba_.fused_ok && ba_.n_cams > 0))
+      throw StateFailure("build_system: a BA edge set with edge classes needs the fused path (option ba_fused) and its estimates");
     if (set_index == ba_.set && ba_fused && ba_.fused_ok && ba_.n_cams > 0) {
       // fused EdgeProjectXYZ2UV path: errors + Jacobians evaluated inside the assembly kernels
       ba_.sys_version = ba_.est_version;
@@ -3027,6 +3061,7 @@ double BlockSolver::chi2() {
   require_structure();
   if (chi2_valid_) return chi2_value_;   // same errors, same kernels as the last evaluation (LM asks twice per accepted step)
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (ba_.set >= 0 && ba_.n_classes > 1 && !ba_.err_valid) ba_linearize(false);   // (edge classes: the per-class kernels live in the BA kernels only)
   if ((!ll_valid_ || ll_hbm_partial_) && !ba_.err_valid) ensure_ll();   // errors come from a linearisation or from the landmark side of the assembly
   double total = 0.0;
   for (auto& esp : sets_) {
@@ -3240,6 +3275,8 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
 #define G2OHIP_BA_TILE_ATTR(GG)                                                                                                    \
   (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<GG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<GG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       G2OHIP_BA_TILE_ATTR(1);
       G2OHIP_BA_TILE_ATTR(2);
       G2OHIP_BA_TILE_ATTR(4);
@@ -3255,24 +3292,26 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
     // linearisation, inspection) has them recomputed by ensure_ll()
     const bool store_ll = ba_store_ll != 0;
     static const int schur_abl = getenv("G2OHIP_SCHUR_ABL") ? atoi(getenv("G2OHIP_SCHUR_ABL")) & ~1 : 0;   // (timing experiments only)
-#define G2OHIP_BA_TILE(GG)                                                                                                         \
+#define G2OHIP_BA_TILE(GG) G2OHIP_BA_TILE_(GG, false)
+#define G2OHIP_BA_TILE_(GG, CC)                                                                                                    \
   do {                                                                                                                             \
     if (fll)                                                                                                                       \
-      hipLaunchKernelGGL((ba_schur_tile_kernel<GG, true>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,        \
+      hipLaunchKernelGGL((ba_schur_tile_kernel<GG, true, CC>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,        \
                          ba_.cams.p, ba_.pts.p, (const int*)nullptr, (const int*)nullptr, ba_.ll_meas.p, ba_.ll_omega.p, ba_.f, ba_.cx,  \
                          ba_.cy,                                                                                                     \
                          es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, ba_.ll_rec.p, ba_.tile_ll.p, ba_.ll_edge.p,       \
                          (ba_.err_valid || !store_ll) ? (double*)nullptr : es.own_err.p, /* (errors of these estimates already there) */ \
-                         d_tile_q2.p, (store_ll ? 1 : 0) | schur_abl, d_slot_lm.p);                                                                        \
+                         d_tile_q2.p, (store_ll ? 1 : 0) | schur_abl, d_slot_lm.p, ba_.ctab.p);                                            \
     else                                                                                                                           \
-      hipLaunchKernelGGL((ba_schur_tile_kernel<GG, false>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,       \
+      hipLaunchKernelGGL((ba_schur_tile_kernel<GG, false, CC>), dim3(n_tiles_), dim3(kThreads), schur_lds_bytes_, st_, d_tile_lm0.p,       \
                          ba_.cams.p, ba_.pts.p, ba_.cam_q.p, ba_.pt_q.p, ba_.meas_q.p, ba_.omega_q.p, ba_.f, ba_.cx, ba_.cy,           \
                          es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p,     \
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, (const int4*)nullptr, (const int4*)nullptr,        \
-                         (const int*)nullptr, (double*)nullptr, d_tile_q2.p, 1, d_slot_lm.p);                                              \
+                         (const int*)nullptr, (double*)nullptr, d_tile_q2.p, 1, d_slot_lm.p, ba_.ctab.p);                                  \
   } while (0)
-    if (G <= 1) G2OHIP_BA_TILE(1);
+    if (ba_.n_classes > 1) G2OHIP_BA_TILE_(8, true);   // (edge classes: one lane-group width is instantiated)
+    else if (G <= 1) G2OHIP_BA_TILE(1);
     else if (G <= 2) G2OHIP_BA_TILE(2);
     else if (G <= 4) G2OHIP_BA_TILE(4);
     else if (G <= 8) G2OHIP_BA_TILE(8);
@@ -3280,6 +3319,7 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
     ll_valid_ = true;
     ll_hbm_partial_ = fll && !store_ll;
 #undef G2OHIP_BA_TILE
+#undef G2OHIP_BA_TILE_
     prof.end(KernelProf::kSchurBlocks, st_);
   } else
 #define G2OHIP_TILE_ARGS d_tile_lm0.p, d_tile_td0.p, d_pl_colptr.p, d_Hpl.p, d_Dinv.p, d_b.p + sizeP, d_td_diag.p, d_td_ptr.p, d_te_pack.p, \
@@ -3890,19 +3930,26 @@ void BlockSolver::solve_back_substitute_impl() {
     EdgeSet& es = *sets_[ba_.set];
     const int GL = ba_lm_group();
     if (ba_fuse_landmarks && ba_.ll_slots_ok && n_tiles_ > 0) {
-      hipLaunchKernelGGL(ba_back_substitute_slots_kernel, dim3(n_tiles_), dim3(kThreads), 0, st_, d_tile_lm0.p, ba_.tile_ll.p, ba_.ll_rec.p,
-                         ba_.ll_row.p, ba_.ll_meas.p, ba_.ll_omega.p, ba_.cams.p, ba_.pts.p, ba_.f, ba_.cx, ba_.cy, es.kernel_kind,
-                         es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_x.p, d_x.p + sizeP);
+#define G2OHIP_BA_BACK_SLOTS(CC)                                                                                                   \
+  hipLaunchKernelGGL((ba_back_substitute_slots_kernel<CC>), dim3(n_tiles_), dim3(kThreads), 0, st_, d_tile_lm0.p, ba_.tile_ll.p,    \
+                     ba_.ll_rec.p, ba_.ll_row.p, ba_.ll_meas.p, ba_.ll_omega.p, ba_.cams.p, ba_.pts.p, ba_.f, ba_.cx, ba_.cy,       \
+                     es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_x.p, d_x.p + sizeP, ba_.ctab.p)
+      if (ba_.n_classes > 1) G2OHIP_BA_BACK_SLOTS(true);
+      else G2OHIP_BA_BACK_SLOTS(false);
+#undef G2OHIP_BA_BACK_SLOTS
     } else
-#define G2OHIP_BA_BACK(GG)                                                                                                        \
-  hipLaunchKernelGGL((ba_back_substitute_kernel<GG>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p,    \
+#define G2OHIP_BA_BACK(GG) G2OHIP_BA_BACK_(GG, false)
+#define G2OHIP_BA_BACK_(GG, CC)                                                                                                    \
+  hipLaunchKernelGGL((ba_back_substitute_kernel<GG, CC>), dim3(grid_for((size_t)nL_ * GG)), dim3(kThreads), 0, st_, nL_, es.vl_ptr.p, \
                      ba_.cams.p, ba_.pts.p, ba_.cam_lm.p, ba_.pt_lm.p, ba_.meas_lm.p, ba_.omega_lm.p, ba_.row_lm.p, ba_.f,          \
                      ba_.cx, ba_.cy, es.kernel_kind, es.delta, ba_.omega_identity ? 1 : 0, d_Dinv.p, d_b.p + sizeP, d_x.p,           \
-                     d_x.p + sizeP)
-    if (GL == 1) G2OHIP_BA_BACK(1);
+                     d_x.p + sizeP, ba_.ctab.p)
+    if (ba_.n_classes > 1) G2OHIP_BA_BACK_(8, true);
+    else if (GL == 1) G2OHIP_BA_BACK(1);
     else if (GL == 4) G2OHIP_BA_BACK(4);
     else G2OHIP_BA_BACK(8);
 #undef G2OHIP_BA_BACK
+#undef G2OHIP_BA_BACK_
   } else if ((ensure_hpl(), false)) {
   } else
 #define G2OHIP_BACK(P_, L_)                                                                                                    \
@@ -4119,6 +4166,7 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
   hipLaunchKernelGGL(scale_partial_kernel, dim3(nblk[0]), dim3(kThreads), 0, st_, vector_size(), d_x.p, d_b.p, lambda, d_red_multi.p);
   // slots 1..: chi2 of every edge set (same kernels as chi2())
   const bool need_chi = !chi2_valid_;
+  if (need_chi && ba_.set >= 0 && ba_.n_classes > 1 && !ba_.err_valid) ba_linearize(false);
   for (size_t k = 0; k < nsets && need_chi; ++k) {
     EdgeSet& es = *sets_[k];
     if (es.n == 0) continue;
@@ -4315,6 +4363,15 @@ void BlockSolver::copy_values(int which, double* h) {
 // ---- bundle-adjustment front end -------------------------------------------------------------
 void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_vertex, const double* meas, const double* info,
                                double f, double cx, double cy) {
+  ba_set_edges_classes(set, cam_vertex, point_vertex, meas, info, f, cx, cy, 1, nullptr, nullptr);
+}
+
+// Edge classes: class_params[5 c] = (focal length, principal point x, y, robust kernel kind, delta) of class c, edge_class[k]
+// the class of edge k.  One class (n_classes == 1, both arrays may be null): the intrinsics are the three scalars and the
+// robust kernel is the edge set's (set_robust_kernel), exactly ba_set_edges.  More: class 0 also takes its values from the
+// table; set_robust_kernel on the set is refused while the classes are bound (the table owns the kernels).
+void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int* point_vertex, const double* meas, const double* info,
+                                       double f, double cx, double cy, int n_classes, const double* class_params, const int* edge_class) {
   invalidate_graphs();
   require_structure();
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
@@ -4324,13 +4381,40 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
   if (!cam_vertex || !point_vertex || !meas) throw ArgFailure("ba_set_edges: null array");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t n = (size_t)es.n;
+  if (n_classes < 1 || n_classes > 128) throw ArgFailure("ba_set_edges_classes: 1 to 128 edge classes");
+  if (n_classes > 1 && (!class_params || !edge_class)) throw ArgFailure("ba_set_edges_classes: null class table");
+  std::vector<int> camc;   // camera index | class << 24: what every device copy of the camera index carries
+  if (n_classes > 1) {
+    for (int c = 0; c < n_classes; ++c) {
+      const double kd = class_params[5 * c + 3];
+      if (!(kd == 0.0 || kd == 1.0 || kd == 2.0 || kd == 3.0 || kd == 4.0 || kd == 5.0)) throw ArgFailure("ba_set_edges_classes: robust kernel kind of a class must be 0..5");
+    }
+    camc.resize(n);
+    for (size_t k = 0; k < n; ++k) {
+      if (edge_class[k] < 0 || edge_class[k] >= n_classes) throw ArgFailure("ba_set_edges_classes: class of edge " + std::to_string(k) + " outside the table");
+      if (cam_vertex[k] < 0 || cam_vertex[k] >= (1 << 24)) throw ArgFailure("ba_set_edges_classes: camera indices are limited to 2^24 with edge classes");
+      camc[k] = cam_vertex[k] | (edge_class[k] << 24);
+    }
+  }
   ba_.set = set;
   ba_.n_edges = es.n;
   ba_.f = f; ba_.cx = cx; ba_.cy = cy;
+  ba_.n_classes = n_classes;
+  if (n_classes > 1) {
+    ba_.h_ctab.assign(class_params, class_params + 5 * (size_t)n_classes);
+    ba_.ctab.upload(ba_.h_ctab, st_);
+    ba_.f = class_params[0]; ba_.cx = class_params[1]; ba_.cy = class_params[2];
+    es.kernel_kind = (int)class_params[3];
+    es.delta = class_params[4];
+  } else {
+    ba_.h_ctab.clear();
+  }
   ba_.h_cam_v.assign(cam_vertex, cam_vertex + n);
   ba_.h_pt_v.assign(point_vertex, point_vertex + n);
   ba_validate();
+  if (n_classes > 1) cam_vertex = camc.data();   // (validated plain; from here on the indices carry the class)
   ba_.err_valid = ba_.jac_valid = false;
+  chi2_valid_ = false;
   es.has_err = false;      // errors of the previous edge data are gone
   ba_.cam_v.upload(cam_vertex, n, st_);
   ba_.pt_v.upload(point_vertex, n, st_);
@@ -4359,6 +4443,10 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
       seen[q] = 1;
     }
     ba_.fused_ok = unique;
+    if (n_classes > 1 && !unique) {
+      ba_ = BaFrontEnd();
+      throw ArgFailure("ba_set_edges_classes: edge classes need the fused path (one observation per (pose, landmark) pair, no fixed landmark)");
+    }
     ba_.edge_hpl.upload(edge_hpl, st_);
     if (unique) {   // the observation behind every Hpl block, in block order (ba_schur_tile_kernel)
       const size_t nq = std::max<size_t>(pl_row.size(), 1);
@@ -4542,9 +4630,24 @@ void BlockSolver::pg_validate() {
 
 void BlockSolver::ba_set_estimates(int n_cams, const double* cams, const int* cam_hidx, int n_points, const double* points,
                                    const int* point_hidx) {
-  invalidate_graphs();
   if (n_cams <= 0 || n_points <= 0 || !cams || !points || !cam_hidx || !point_hidx) throw ArgFailure("ba_set_estimates: bad arguments");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  // The caller of every iteration (the g2o adapter: setEstimate of all vertices before buildSystem) hands over the same
+  // tables with new values: only the estimates move -- no index check, no re-upload of the index mapping, and the captured
+  // launch sequences stay (the device addresses are the same).
+  if (n_cams == ba_.n_cams && n_points == ba_.n_points && ba_.cams.p && ba_.pts.p && (int)ba_.h_cam_hidx.size() == n_cams &&
+      (int)ba_.h_pt_hidx.size() == n_points && std::memcmp(ba_.h_cam_hidx.data(), cam_hidx, sizeof(int) * (size_t)n_cams) == 0 &&
+      std::memcmp(ba_.h_pt_hidx.data(), point_hidx, sizeof(int) * (size_t)n_points) == 0) {
+    ++ba_.est_version;
+    ba_.err_valid = ba_.jac_valid = false;
+    chi2_valid_ = false;
+    ba_.has_backup = false;
+    ba_.cams.upload(cams, (size_t)n_cams * 12, st_);
+    ba_.pts.upload(points, (size_t)n_points * 3, st_);
+    G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+    return;
+  }
+  invalidate_graphs();
   ba_.n_cams = n_cams;
   ba_.n_points = n_points;
   ++ba_.est_version;
@@ -4590,7 +4693,8 @@ void BlockSolver::ba_linearize(bool jacobians) {
   if (ba_.chi_part.n < (size_t)lgrid) ba_.chi_part.alloc(lgrid);
   hipLaunchKernelGGL(ba_linearize_kernel, dim3(lgrid), dim3(kThreads), 0, st_, es.n, ba_.cams.p, ba_.pts.p, ba_.cam_v.p,
                      ba_.pt_v.p, ba_.meas.p, ba_.f, ba_.cx, ba_.cy, es.own_J0.p, es.own_J1.p, es.own_err.p, (jacobians && !fused) ? 1 : 0,
-                     es.omega, ba_.omega_identity ? 1 : 0, es.kernel_kind, es.delta, ba_.chi_part.p);
+                     es.omega, ba_.omega_identity ? 1 : 0, es.kernel_kind, es.delta, ba_.chi_part.p,
+                     ba_.n_classes > 1 ? ba_.ctab.p : (const double*)nullptr);
   hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(1024), 0, st_, ba_.chi_part.p, lgrid, d_red_multi.p + (size_t)(ba_.set + 1) * kMaxBlocks);
   if (profiling) {
     tfe_.stop(st_);
@@ -4678,8 +4782,15 @@ void BlockSolver::pg_set_estimates(int nv, const double* poses, const int* hidx)
   if (pg_.type == 0) throw StateFailure("pg_set_estimates: call pg_set_edges first");
   if (nv <= 0 || !poses || !hidx) throw ArgFailure("pg_set_estimates: bad arguments");
   pg_.err_valid = pg_.jac_valid = false;
+  chi2_valid_ = false;
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t ps = pg_.type == 1 ? 3 : 12;
+  if (nv == pg_.nv && pg_.poses.p && (int)pg_.h_hidx.size() == nv && std::memcmp(pg_.h_hidx.data(), hidx, sizeof(int) * (size_t)nv) == 0) {
+    pg_.has_backup = false;   // (same tables, new values: see ba_set_estimates)
+    pg_.poses.upload(poses, (size_t)nv * ps, st_);
+    G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+    return;
+  }
   pg_.nv = nv;
   pg_.h_hidx.assign(hidx, hidx + nv);
   pg_validate();

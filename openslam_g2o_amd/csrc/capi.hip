@@ -599,12 +599,44 @@ int g2ohip_device_array(g2ohip_solver* s, int which, double** ptr, size_t* count
   });
 }
 
+// ---- page-locked host buffers -------------------------------------------------------------
+int g2ohip_host_register(g2ohip_solver* s, void* ptr, size_t bytes) {
+  REQUIRE_HANDLE(s);
+  if (!ptr || !bytes) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    G2OHIP_HIP_CHECK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_host_unregister(g2ohip_solver* s, void* ptr) {
+  REQUIRE_HANDLE(s);
+  if (!ptr) return G2OHIP_ERR_ARG;
+  return guarded([&] {
+    G2OHIP_HIP_CHECK(hipHostUnregister(ptr));
+    return G2OHIP_OK;
+  });
+}
+
 // ---- device-resident bundle-adjustment front end ---------------------------------------
 int g2ohip_ba_set_edges(g2ohip_solver* s, int set, const int32_t* cam_vertex, const int32_t* point_vertex, const double* meas,
                         const double* info, double f, double cx, double cy) {
   REQUIRE_HANDLE(s);
   return guarded([&] {
     s->impl->ba_set_edges(set, cam_vertex, point_vertex, meas, info, f, cx, cy);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ba_set_edges_classes(g2ohip_solver* s, int set, const int32_t* cam_vertex, const int32_t* point_vertex, const double* meas,
+                                const double* info, int n_classes, const double* class_params, const int32_t* edge_class) {
+  REQUIRE_HANDLE(s);
+  if (n_classes < 1 || !class_params) {
+    set_error("ba_set_edges_classes: at least one class with its parameters");
+    return G2OHIP_ERR_ARG;
+  }
+  return guarded([&] {
+    s->impl->ba_set_edges_classes(set, cam_vertex, point_vertex, meas, info, class_params[0], class_params[1], class_params[2], n_classes,
+                                  class_params, edge_class);
+    if (n_classes == 1) s->impl->set_robust_kernel(set, (int)class_params[3], class_params[4]);
     return G2OHIP_OK;
   });
 }

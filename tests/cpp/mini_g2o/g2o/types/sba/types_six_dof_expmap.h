@@ -23,6 +23,7 @@ class CameraParameters {                                // types_six_dof_expmap.
 };
 class VertexSE3Expmap : public BaseVertex<6, SE3Quat> { // :91-109
  public:
+  virtual bool write(std::ostream& os) const;           // types_six_dof_expmap.cpp:88-103 (out of line: libg2o_mini_types_sba.so)
   virtual void oplusImpl(const double* update_) {
     Vector6d u;
     for (int i = 0; i < 6; ++i) u[i] = update_[i];
@@ -31,11 +32,13 @@ class VertexSE3Expmap : public BaseVertex<6, SE3Quat> { // :91-109
 };
 class VertexSBAPointXYZ : public BaseVertex<3, Vector3d> {   // types_sba.h:92-118
  public:
+  virtual bool write(std::ostream& os) const;
   virtual void oplusImpl(const double* update) { for (int i = 0; i < 3; ++i) _estimate[i] += update[i]; }
 };
 class EdgeProjectXYZ2UV : public BaseBinaryEdge<2, Vector2d, VertexSBAPointXYZ, VertexSE3Expmap> {   // :133-153
  public:
   EdgeProjectXYZ2UV() : _cam(0) {}
+  virtual bool write(std::ostream& os) const;
   virtual void computeError() {
     const VertexSE3Expmap* v1 = static_cast<const VertexSE3Expmap*>(_vertices[1]);
     const VertexSBAPointXYZ* v2 = static_cast<const VertexSBAPointXYZ*>(_vertices[0]);

@@ -6,6 +6,7 @@
 namespace g2o {
 class EdgeSE2 : public BaseBinaryEdge<3, SE2, VertexSE2, VertexSE2> {
  public:
+  virtual bool write(std::ostream& os) const;           // edge_se2.cpp:54-62 (out of line: libg2o_mini_types_slam2d.so)
   virtual void computeError() {
     const VertexSE2* v1 = static_cast<const VertexSE2*>(_vertices[0]);
     const VertexSE2* v2 = static_cast<const VertexSE2*>(_vertices[1]);

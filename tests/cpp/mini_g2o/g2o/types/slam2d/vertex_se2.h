@@ -6,6 +6,7 @@
 namespace g2o {
 class VertexSE2 : public BaseVertex<3, SE2> {
  public:
+  virtual bool write(std::ostream& os) const;           // vertex_se2.cpp:50-55 (out of line: libg2o_mini_types_slam2d.so)
   virtual void oplusImpl(const double* d) {   // additive on all three coordinates, the angle wrapped into [-pi, pi)
     const SE2& T = _estimate;
     _estimate = SE2(T.translation()[0] + d[0], T.translation()[1] + d[1], normalize_theta(T.rotation().angle() + d[2]));

@@ -66,6 +66,7 @@ inline Eigen::Isometry3d fromVectorMQT(const Vector6d& v) {
 }  // namespace internal
 class VertexSE3 : public BaseVertex<6, Eigen::Isometry3d> {
  public:
+  virtual bool write(std::ostream& os) const;           // vertex_se3.cpp:62-68 (out of line: libg2o_mini_types_slam3d.so)
   virtual void oplusImpl(const double* update) {
     Vector6d v;
     for (int i = 0; i < 6; ++i) v[i] = update[i];

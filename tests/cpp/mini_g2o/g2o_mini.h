@@ -200,6 +200,8 @@ class OptimizableGraph : public HyperGraph {            // g2o/core/optimizable_
     virtual double& b(int i) = 0;
     virtual void clearQuadraticForm() = 0;
     virtual void oplusImpl(const double* v) = 0;        // :363
+    virtual bool write(std::ostream& os) const = 0;     // :345 (pure in g2o too: every type library defines it out of line --
+                                                        // the KEY FUNCTION that puts a type's vtable and typeinfo into its library)
     virtual void push() = 0;                            // :230
     virtual void pop() = 0;
     virtual void discardTop() = 0;
@@ -223,6 +225,7 @@ class OptimizableGraph : public HyperGraph {            // g2o/core/optimizable_
     Edge() : _dimension(-1), _robustKernel(0) {}
     virtual ~Edge() { delete _robustKernel; }
     virtual void computeError() = 0;                    // :419
+    virtual bool write(std::ostream& os) const = 0;     // :487 (see Vertex::write)
     virtual double chi2() const = 0;                    // :435
     RobustKernel* robustKernel() const { return _robustKernel; }   // :416
     void setRobustKernel(RobustKernel* k) { delete _robustKernel; _robustKernel = k; }

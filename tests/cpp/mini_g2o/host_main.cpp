@@ -6,6 +6,8 @@
 //   g2o_host <problem.txt> <plugin.so> <solver name> <iterations> <out.json> [marginals]
 // problem.txt: ncams npts nedges f cx cy huber_delta | per camera: fixed R(9, column-major) t(3) | per point: fixed xyz | per
 // edge: cam point u v
+//   ... [classes]: header + "f2 cx2 cy2", per edge: cam point u v second_camera(0/1) huber_delta(0 = none) -- edges with their own
+//   CameraParameters and their own robust kernel (types_six_dof_expmap.h:133-153, optimizable_graph.h:436-443)
 //   g2o_host <graph.txt> <plugin.so> <solver name> <iterations> <out.json> se2
 // graph.txt (planar pose graph): nverts nedges | per vertex: fixed x y theta | per edge: i j x y theta info(9, column-major)
 #include <dlfcn.h>
@@ -36,7 +38,7 @@ int main(int argc, char** argv) {
   int onlineFirst = -1;
   if (argc > 6 && std::string(argv[6]).compare(0, 7, "online:") == 0) onlineFirst = std::atoi(argv[6] + 7);
   // ---- plugin: static RegisterOptimizationAlgorithmProxy objects run inside dlopen (optimization_algorithm_factory.h:120-130)
-  void* lib = dlopen(argv[2], RTLD_LAZY | RTLD_GLOBAL);
+  void* lib = dlopen(argv[2], RTLD_LAZY);   // (as dl_wrapper.cpp:118: no RTLD_GLOBAL -- the plugin has to bring its own dependencies)
   if (!lib) {
     std::cerr << "dlopen: " << dlerror() << std::endl;
     return 3;
@@ -52,7 +54,8 @@ int main(int argc, char** argv) {
     OptimizationAlgorithmFactory::instance()->listSolvers(std::cerr);
     return 3;
   }
-  if (argc > 6 && std::string(argv[6]) == "se3") {
+  const bool se3Fixed = argc > 6 && std::string(argv[6]).compare(0, 10, "se3lambda:") == 0;   // "se3lambda:<value>": see below
+  if ((argc > 6 && std::string(argv[6]) == "se3") || se3Fixed) {
     // ---- 3-D pose graph (config 2: VertexSE3 / EdgeSE3, BlockSolver_6_3 shape without marginalised vertices)
     // graph.txt: nverts nedges | per vertex: fixed R(9, column-major) t(3) | per edge: i j R(9) t(3) info(36, column-major)
     std::ifstream in(argv[1]);
@@ -102,6 +105,30 @@ int main(int argc, char** argv) {
     optimizer.computeActiveErrors();
     const double chi0 = optimizer.activeRobustChi2();
     int done = 0;
+    if (se3Fixed) {
+      // damped steps with ONE fixed lambda through the Solver vtable -- the steps of the golden trajectory of
+      // tests/golden/make_golden.py (the reference's CSparse solve of (H + lambda I) x = b, lambda = 1e-5 max diag of the
+      // first system): buildSystem / setLambda / solve / restoreDiagonal as optimization_algorithm_levenberg.cpp:79-101
+      // calls them, then SparseOptimizer::update
+      const double lambda = std::atof(argv[6] + 10);
+      OptimizationAlgorithmWithHessian* awh = dynamic_cast<OptimizationAlgorithmWithHessian*>(algo);
+      if (!awh) return 4;
+      Solver* sv = awh->solver();
+      if (!sv->buildStructure()) return 4;
+      for (int i = 0; i < iterations; ++i) {
+        optimizer.computeActiveErrors();
+        sv->buildSystem();
+        if (!sv->setLambda(lambda, true)) return 4;
+        const bool ok = sv->solve();
+        sv->restoreDiagonal();
+        if (!ok) break;
+        optimizer.update(sv->x());
+        optimizer.computeActiveErrors();
+        chis.push_back(optimizer.activeRobustChi2());
+        lams.push_back(lambda);
+        ++done;
+      }
+    } else
     for (int i = 0; i < iterations; ++i) {
       const OptimizationAlgorithm::SolverResult r = algo->solve(i);
       if (r == OptimizationAlgorithm::Fail) break;
@@ -199,11 +226,16 @@ int main(int argc, char** argv) {
   int ncams, npts, nedges;
   double f, cx, cy, huber;
   in >> ncams >> npts >> nedges >> f >> cx >> cy >> huber;
+  const bool classes = argc > 6 && std::string(argv[6]) == "classes";
+  double f2 = f, cx2 = cx, cy2 = cy;
+  if (classes) in >> f2 >> cx2 >> cy2;
   SparseOptimizer optimizer;
-  Vector2d pp;
+  Vector2d pp, pp2;
   pp[0] = cx;
   pp[1] = cy;
-  CameraParameters cam(f, pp, 0.);
+  pp2[0] = cx2;
+  pp2[1] = cy2;
+  CameraParameters cam(f, pp, 0.), cam2(f2, pp2, 0.);
   std::vector<VertexSE3Expmap*> cams(ncams);
   std::vector<VertexSBAPointXYZ*> pts(npts);
   std::vector<EdgeProjectXYZ2UV*> heldEdges;             // (online mode: added later)
@@ -237,14 +269,17 @@ int main(int argc, char** argv) {
     int ci, pi;
     Vector2d z;
     in >> ci >> pi >> z[0] >> z[1];
+    int second = 0;
+    double edgeHuber = huber;
+    if (classes) in >> second >> edgeHuber;
     EdgeProjectXYZ2UV* e = new EdgeProjectXYZ2UV();
     e->setVertex(0, pts[pi]);
     e->setVertex(1, cams[ci]);
     e->setMeasurement(z);
-    e->_cam = &cam;
-    if (huber > 0) {
+    e->_cam = second ? &cam2 : &cam;
+    if (edgeHuber > 0) {
       RobustKernelHuber* rk = new RobustKernelHuber();
-      rk->setDelta(huber);
+      rk->setDelta(edgeHuber);
       e->setRobustKernel(rk);
     }
     if (onlineFirst < 0 || ci < onlineFirst) optimizer.addEdge(e);

@@ -1,0 +1,236 @@
+"""Edge classes of the device-resident BA front end (g2ohip_ba_set_edges_classes): the observations of ONE edge set differ in
+their CameraParameters (every EdgeProjectXYZ2UV carries its own _cam, g2o/types/sba/types_six_dof_expmap.h:133-153) and in
+their robust kernel (each edge asks its own, base_binary_edge.hpp:92-112) and still run on the fused device path.  The oracle
+sees the same graph the way the reference does: per-edge Jacobians from the per-edge intrinsics, one edge set per kernel."""
+import numpy as np
+import pytest
+
+from openslam_g2o_amd import capi, lm, synthetic as S
+from oracle import oracle as O
+from tests.helpers import ba_case, dx_tolerance, relerr
+
+pytestmark = pytest.mark.gpu
+
+# (f, cx, cy, kernel kind, delta): two cameras x {none, Huber, Cauchy}
+CLASSES = np.array([[1000.0, 320.0, 240.0, 0, 0.0],
+                    [1000.0, 320.0, 240.0, 1, 1.0],
+                    [640.0, 300.5, 255.25, 0, 0.0],
+                    [640.0, 300.5, 255.25, 1, 1.5],
+                    [640.0, 300.5, 255.25, 3, 2.0]])
+
+
+def _class_problem(P, L, K, seed=5):
+    """A synthetic BA problem whose observations are dealt to CLASSES: odd cameras carry the second CameraParameters, the
+    measurements are re-projected with the intrinsics of their class (same geometry, same outliers in pixels / f)."""
+    pr = ba_case(P, L, seed=seed, outlier_frac=0.05, obs_per_landmark=K)
+    rng = np.random.RandomState(seed)
+    second = (pr["cam_idx"] % 2) == 1
+    cls = np.where(second, 2 + rng.randint(0, 3, pr["E"]), rng.randint(0, 2, pr["E"])).astype(np.int32)
+    f0, c0 = pr["f"], np.array([pr["cx"], pr["cy"]])
+    meas = pr["meas"].copy()
+    fk, ck = CLASSES[cls, 0], CLASSES[cls, 1:3]
+    meas = (meas - c0) / f0 * fk[:, None] + ck
+    pr["meas"] = meas
+    pr["edge_class"] = cls
+    return pr
+
+
+def _linearize_classes(pr):
+    """Per-edge error + Jacobians with the intrinsics of the edge's class (numpy, synthetic.ba_linearize per class)."""
+    E = pr["E"]
+    Jp, Jc, err = np.zeros((E, 6)), np.zeros((E, 12)), np.zeros((E, 2))
+    for c in range(len(CLASSES)):
+        sel = np.nonzero(pr["edge_class"] == c)[0]
+        if not len(sel):
+            continue
+        sub = dict(pr, f=CLASSES[c, 0], cx=CLASSES[c, 1], cy=CLASSES[c, 2], cam_idx=pr["cam_idx"][sel], pt_idx=pr["pt_idx"][sel],
+                   meas=pr["meas"][sel])
+        a, b, e = S.ba_linearize(sub)
+        Jp[sel], Jc[sel], err[sel] = a, b, e
+    return Jp, Jc, err
+
+
+def _oracle(pr):
+    """One oracle edge set per class (the reference's edges each carry their kernel; sets are this repository's grouping)."""
+    Jp, Jc, err = _linearize_classes(pr)
+    o = O.OracleSolver(6, 3, pr["nP"], pr["nL"], True)
+    sets = []
+    for c in range(len(CLASSES)):
+        sel = np.nonzero(pr["edge_class"] == c)[0]
+        if not len(sel):
+            continue
+        k = o.add_edge_set(2, pr["v0"][sel], pr["v1"][sel])
+        o.set_dims(k, 3, 6)
+        sets.append((k, c, sel))
+    o.build_structure()
+    om = S.ba_omega(pr)
+    for k, c, sel in sets:
+        o.set_edge_data(k, Jp[sel], Jc[sel], om[sel], err[sel], CLASSES[c, 4])
+        if CLASSES[c, 3] > 0:
+            o.set_robust_kernel(k, int(CLASSES[c, 3]))
+    return o
+
+
+class OracleClassBAGraph:
+    """lm's graph protocol on the CPU oracle for a BA graph with edge classes: the oracle's own EdgeProjectXYZ2UV producers
+    (oracle/g2o_oracle_types.c) per class, one oracle edge set per class with that class's robust kernel."""
+
+    def __init__(self, pr):
+        self.pr = dict(pr)
+        self.o = O.OracleSolver(6, 3, pr["nP"], pr["nL"], True)
+        self.sets = []
+        for c in range(len(CLASSES)):
+            sel = np.nonzero(pr["edge_class"] == c)[0]
+            if len(sel):
+                k = self.o.add_edge_set(2, pr["v0"][sel], pr["v1"][sel])
+                self.o.set_dims(k, 3, 6)
+                self.sets.append((k, c, sel))
+        self.o.build_structure()
+        self.omega = S.ba_omega(pr)
+        self.stack = []
+        self.lm_hidx = np.arange(pr["L"], dtype=np.int32)
+        self._J = {}
+
+    def _edges(self, c, sel, jac):
+        p = self.pr
+        return O.ba_edges(p["cams"], p["pts"], p["cam_idx"][sel], p["pt_idx"][sel], p["meas"][sel], CLASSES[c, 0], CLASSES[c, 1], CLASSES[c, 2],
+                          jac=jac)
+
+    def _set(self, k, c, sel, Jp, Jc, err):
+        self.o.set_edge_data(k, Jp, Jc, self.omega[sel], err, CLASSES[c, 4])
+        if CLASSES[c, 3] > 0:
+            self.o.set_robust_kernel(k, int(CLASSES[c, 3]))
+
+    def linearize(self):
+        for k, c, sel in self.sets:
+            Jp, Jc, err = self._edges(c, sel, True)
+            self._J[k] = (Jp, Jc)
+            self._set(k, c, sel, Jp, Jc, err)
+
+    def compute_active_errors(self):
+        for k, c, sel in self.sets:
+            self._set(k, c, sel, self._J[k][0], self._J[k][1], self._edges(c, sel, False))
+
+    def chi2(self):
+        return self.o.chi2()
+
+    def update(self):
+        p = self.pr
+        p["cams"], p["pts"] = O.ba_oplus(p["cams"], p["pts"], p["cam_hidx"], self.lm_hidx, self.o.x(), 6 * p["nP"])
+
+    def push(self):
+        self.stack.append((self.pr["cams"].copy(), self.pr["pts"].copy()))
+
+    def pop(self):
+        self.pr["cams"], self.pr["pts"] = self.stack.pop()
+
+    def discard_top(self):
+        self.stack.pop()
+
+
+def _device(pr, options=None):
+    s = capi.HipBlockSolver(6, 3, 0)
+    for name, value in (options or {}).items():
+        s.setOption(name, value)
+    k = s.addEdgeSet(2, pr["v0"], pr["v1"])
+    s.buildStructure(pr["nP"], pr["nL"], True)
+    s.baSetEdgesClasses(k, pr["cam_idx"], pr["pt_idx"], pr["meas"], CLASSES, pr["edge_class"])
+    s.baSetEstimates(pr["cams"], pr["cam_hidx"], pr["pts"], np.arange(pr["L"], dtype=np.int32))
+    return s, lm.DeviceBAGraph(s), k
+
+
+@pytest.mark.parametrize("K", [1, 5, 23])
+@pytest.mark.parametrize("fuse_landmarks", [1, 0])
+def test_two_cameras_and_three_kernels_in_one_set_match_the_oracle(K, fuse_landmarks):
+    pr = _class_problem(40, 90 if K > 5 else 400, K)
+    o = _oracle(pr)
+    o.build_system()
+    o.set_lambda(5.0, True)
+    assert o.solve()
+    tol, _ = dx_tolerance(o)
+    xo = o.x().copy()
+    o.restore_diagonal()
+    s, g, k = _device(pr, {"ba_fuse_landmarks": fuse_landmarks})
+    g.linearize()
+    assert abs(s.chi2() - o.chi2()) <= 1e-12 * o.chi2()      # per-class rho in the linearisation kernel
+    s.buildSystem()
+    s.setLambda(5.0, True)
+    assert s.solve()
+    x = s.x()
+    s.restoreDiagonal()
+    assert relerr(s.b(), o.b()) < 1e-12
+    assert relerr(s.values(capi.HLL), o.values("Hll")) < 1e-12
+    assert relerr(s.values(capi.HPP), o.values("Hpp")) < 1e-12
+    assert relerr(s.values(capi.HPL), o.values("Hpl")) < 1e-12
+    assert relerr(x, xo) < tol
+    # one LM trial on the device: the update changes chi2 to what numpy evaluates from the moved estimates
+    g.push()
+    g.update()
+    g.compute_active_errors()
+    cams, pts = s.baGetEstimates()
+    moved = dict(pr, cams=cams, pts=pts)
+    _, _, err = _linearize_classes(moved)
+    e2 = (err * err).sum(axis=1)
+    rho = np.zeros_like(e2)
+    for c in range(len(CLASSES)):
+        sel = pr["edge_class"] == c
+        kind, d = int(CLASSES[c, 3]), CLASSES[c, 4]
+        if kind == 0:
+            rho[sel] = e2[sel]
+        elif kind == 1:
+            rho[sel] = np.where(e2[sel] <= d * d, e2[sel], 2 * np.sqrt(e2[sel]) * d - d * d)
+        else:
+            rho[sel] = d * d * np.log(e2[sel] / (d * d) + 1.0)
+    assert abs(s.chi2() - rho.sum()) <= 1e-10 * rho.sum()
+    g.pop()
+
+
+def test_the_class_table_owns_the_kernels_and_needs_the_fused_path():
+    pr = _class_problem(20, 100, 5)
+    s, g, k = _device(pr)
+    with pytest.raises(capi.G2oHipError):
+        s.setRobustKernel(k, capi.KERNEL_HUBER, 1.0)
+    s.setOption("ba_fused", 0)
+    with pytest.raises(capi.G2oHipError):
+        g.linearize()
+        s.buildSystem()
+    # a class outside the table
+    s2 = capi.HipBlockSolver(6, 3, 0)
+    k2 = s2.addEdgeSet(2, pr["v0"], pr["v1"])
+    s2.buildStructure(pr["nP"], pr["nL"], True)
+    bad = pr["edge_class"].copy()
+    bad[3] = len(CLASSES)
+    with pytest.raises(capi.G2oHipError):
+        s2.baSetEdgesClasses(k2, pr["cam_idx"], pr["pt_idx"], pr["meas"], CLASSES, bad)
+    # one class through the same entry point == baSetEdges + setRobustKernel
+    one = np.array([[pr["f"], pr["cx"], pr["cy"], 1, 1.0]])
+    pr1 = ba_case(20, 100, outlier_frac=0.05)
+    sa, ga = lm.setup_device_ba(pr1, huber_delta=1.0)
+    sb = capi.HipBlockSolver(6, 3, 0)
+    kb = sb.addEdgeSet(2, pr1["v0"], pr1["v1"])
+    sb.buildStructure(pr1["nP"], pr1["nL"], True)
+    sb.baSetEdgesClasses(kb, pr1["cam_idx"], pr1["pt_idx"], pr1["meas"], one, np.zeros(pr1["E"], dtype=np.int32))
+    sb.baSetEstimates(pr1["cams"], pr1["cam_hidx"], pr1["pts"], np.arange(pr1["L"], dtype=np.int32))
+    gb = lm.DeviceBAGraph(sb)
+    for s_, g_ in ((sa, ga), (sb, gb)):
+        g_.linearize()
+        s_.buildSystem()
+        s_.setLambda(1.0, True)
+        assert s_.solve()
+    assert np.array_equal(sa.x(), sb.x())
+
+
+def test_lm_trajectory_with_edge_classes_matches_the_oracle():
+    """Levenberg-Marquardt (optimization_algorithm_levenberg.cpp:57-172) over the mixed graph, everything on the device, against
+    the same loop on the oracle: chi2 per iteration, lambda sequence, trials per iteration."""
+    from tests.test_gpu_lm import OracleSolverAdapter
+    pr = _class_problem(40, 400, 5)
+    go = OracleClassBAGraph(pr)
+    n_o, chis_o, lams_o, trials_o = lm.optimize(go, OracleSolverAdapter(go.o), 6, "lm")
+    s, g, _ = _device(pr)
+    n, chis, lams, trials = lm.optimize(g, s, 6, "lm")
+    assert n == n_o and trials == trials_o
+    assert np.allclose(chis, chis_o, rtol=1e-7, atol=0) and np.allclose(lams, lams_o, rtol=1e-7, atol=0)
+    assert chis[-1] < 0.7 * chis[0]
+    cams, pts = s.baGetEstimates()
+    assert relerr(cams, go.pr["cams"]) < 1e-7 and relerr(pts, go.pr["pts"]) < 1e-7
