@@ -80,12 +80,42 @@ class BlockSolverHip : public BlockSolverBase {
   explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0) {
     const char* fp = std::getenv("G2OHIP_ADAPTER_FASTPATH");
     if (fp && fp[0] == '0') _fastPath = false;
+    const char* pin = std::getenv("G2OHIP_ADAPTER_PINNED");
+    _pin = !(pin && pin[0] == '0');
+    const char* tm = std::getenv("G2OHIP_ADAPTER_TIMING");
+    _timing = tm && tm[0] != '0';
+    std::memset(&_phase, 0, sizeof(_phase));
     if (g2ohip_create(&_h, p, l, device) != G2OHIP_OK) {
       std::cerr << "BlockSolverHip: " << g2ohip_last_error() << std::endl;   // (no exceptions on this path)
       _h = 0;
     }
   }
-  virtual ~BlockSolverHip() { if (_h) g2ohip_destroy(_h); }
+  virtual ~BlockSolverHip() {
+    if (_timing && _phase.buildSystems > 0) printPhases(std::cerr);
+    unpinAll();
+    if (_h) g2ohip_destroy(_h);
+  }
+
+  // Where the time of buildSystem() / solve() goes, accumulated over the calls (G2OHIP_ADAPTER_TIMING=1 also synchronises the
+  // device between the phases so that each one is charged to its own line; printed as one JSON line by the destructor)
+  struct Phases {
+    double hostLinearize;    // generic path: linearizeOplus of every edge + gathering the Jacobians (CPU)
+    double upload;           // estimates (fast path) or Jacobians / information / errors (generic path) to the device
+    double deviceBuild;      // g2ohip_build_system: errors + Jacobians (fast path) and the assembly, on the device
+    double downloadB;        // b() and the diagonal mirror computeLambdaInit reads, to the host
+    double deviceSolve;      // g2ohip_solve: Schur complement, factorisation, sweeps, back-substitution
+    double downloadX;        // x() to the host
+    int buildSystems, solves;
+  };
+  const Phases& phases() const { return _phase; }
+  void printPhases(std::ostream& os) const {
+    const double nb = _phase.buildSystems > 0 ? _phase.buildSystems : 1, ns = _phase.solves > 0 ? _phase.solves : 1;
+    os << "{\"g2ohip_adapter_phases_ms\": {\"buildSystem_calls\": " << _phase.buildSystems << ", \"solve_calls\": " << _phase.solves
+       << ", \"host_linearize\": " << 1e3 * _phase.hostLinearize / nb << ", \"upload\": " << 1e3 * _phase.upload / nb << ", \"device_build\": "
+       << 1e3 * _phase.deviceBuild / nb << ", \"download_b_diag\": " << 1e3 * _phase.downloadB / nb << ", \"device_solve\": "
+       << 1e3 * _phase.deviceSolve / ns << ", \"download_x\": " << 1e3 * _phase.downloadX / ns << ", \"pinned\": " << (_pin ? 1 : 0)
+       << ", \"fast_groups\": " << _fastGroups << "}}" << std::endl;
+  }
 
   // block_solver.hpp:606-620: store the optimizer, drop numeric / symbolic state
   virtual bool init(SparseOptimizer* optimizer, bool online = false) {
@@ -108,6 +138,7 @@ class BlockSolverHip : public BlockSolverBase {
   // 128 classes, ...) sends the call back here without it: the edges then go to their generic per-key groups.
   bool buildStructureImpl(bool tryBA, bool tryPG) {
     if (!_h || !_optimizer) return false;
+    unpinAll();                                        // (the buffers below are about to be reallocated)
     if (g2ohip_init(_h) != G2OHIP_OK) return fail("init");
     if (g2ohip_clear_edge_sets(_h) != G2OHIP_OK) return fail("clear_edge_sets");   // (a second optimize(), online growth: a new graph)
     _groups.clear();
@@ -214,6 +245,9 @@ class BlockSolverHip : public BlockSolverBase {
     if (g2ohip_build_structure(_h, _nP, _nL, _doSchur ? 1 : 0) != G2OHIP_OK) return fail("build_structure");
     resizeVector(g2ohip_vector_size(_h));              // Solver::_x, _b (solver.cpp:46-70)
     _diag.assign(g2ohip_vector_size(_h), 0.0);
+    pinDoubles(_x, g2ohip_vector_size(_h));            // what crosses PCIe every iteration is page-locked once (g2ohip_host_register)
+    pinDoubles(_b, g2ohip_vector_size(_h));
+    pinDoubles(_diag.data(), _diag.size());
     _fastGroups = 0;
     if (baGroup >= 0) {
       if (!bindProjectXYZ2UV(_groups[baGroup])) return buildStructureImpl(false, tryPG);   // everything generic (the set is re-registered per key)
@@ -263,10 +297,12 @@ class BlockSolverHip : public BlockSolverBase {
   virtual bool buildSystem() {
     if (!_h) return false;
     JacobianWorkspace& ws = _optimizer->jacobianWorkspace();
+    double t = get_monotonic_time();
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       Group& g = _groups[gi];
       if (g.fast) {                                    // estimates up, errors + Jacobians on the device
         if (!(g.fast == 2 ? uploadPosesSE2() : (g.fast == 3 ? uploadPosesSE3() : uploadEstimates()))) return false;
+        _phase.upload += lap(t);
         continue;
       }
       const int d = g.key.d, d0 = g.key.dim0, d1 = g.key.dim1;
@@ -280,12 +316,18 @@ class BlockSolverHip : public BlockSolverBase {
         std::memcpy(&g.Om[k * d * d], e->informationData(), sizeof(double) * d * d);
         std::memcpy(&g.err[k * d], e->errorData(), sizeof(double) * d);
       }
+      _phase.hostLinearize += lap(t);
       if (g2ohip_set_edge_data(_h, g.set, g.J0.data(), d1 ? g.J1.data() : 0, g.Om.data(), g.err.data(), /*on_device*/ 0) != G2OHIP_OK)
         return fail("set_edge_data");
+      _phase.upload += lap(t);
     }
     if (g2ohip_build_system(_h) != G2OHIP_OK) return fail("build_system");
+    if (_timing) g2ohip_sync(_h);
+    _phase.deviceBuild += lap(t);
     if (g2ohip_copy_b(_h, _b) != G2OHIP_OK) return fail("copy_b");          // LM reads b() (levenberg.cpp:169)
     refreshDiagonalMirror();
+    _phase.downloadB += lap(t);
+    ++_phase.buildSystems;
     return true;
   }
 
@@ -293,13 +335,16 @@ class BlockSolverHip : public BlockSolverBase {
   // positive definite
   virtual bool solve() {
     if (!_h) return false;
-    const double t = get_monotonic_time();
+    double t = get_monotonic_time();
     const int rc = g2ohip_solve(_h);
     if (rc != G2OHIP_OK) {
       if (rc != G2OHIP_NOT_PD) fail("solve");
       return false;
     }
+    _phase.deviceSolve += lap(t);
     if (g2ohip_copy_x(_h, _x) != G2OHIP_OK) return fail("copy_x");
+    _phase.downloadX += lap(t);
+    ++_phase.solves;
     G2OBatchStatistics* gs = G2OBatchStatistics::globalStats();
     if (gs) {                                          // batch_stats.h:40-77
       g2ohip_stats st;
@@ -313,7 +358,7 @@ class BlockSolverHip : public BlockSolverBase {
         gs->hessianLandmarkDimension = st.hessianLandmarkDimension;
         gs->hessianDimension = st.hessianPoseDimension + st.hessianLandmarkDimension;
       }
-      (void)t;   // timeLinearSolution is accumulated by the algorithm around solve() (levenberg.cpp:105)
+      // (timeLinearSolution is accumulated by the algorithm around solve(), levenberg.cpp:105)
     }
     return true;
   }
@@ -416,6 +461,22 @@ class BlockSolverHip : public BlockSolverBase {
     }
   }
 
+  static double lap(double& t) {
+    const double now = get_monotonic_time(), d = now - t;
+    t = now;
+    return d;
+  }
+  // page-locked registration of a buffer that crosses PCIe every iteration; a refusal (the driver's limit on locked memory) is
+  // not an error: the copies then go through the driver's staging buffer as before
+  void pinDoubles(double* ptr, size_t n) {
+    if (!_pin || !ptr || !n) return;
+    if (g2ohip_host_register(_h, ptr, n * sizeof(double)) == G2OHIP_OK) _pinned.push_back(ptr);
+  }
+  void unpinAll() {
+    for (size_t i = 0; i < _pinned.size(); ++i) g2ohip_host_unregister(_h, _pinned[i]);
+    _pinned.clear();
+  }
+
   bool fail(const char* what) const {
     std::cerr << "BlockSolverHip::" << what << ": " << g2ohip_last_error() << std::endl;
     return false;
@@ -489,6 +550,8 @@ class BlockSolverHip : public BlockSolverBase {
     }
     _camBuf.assign(12 * _cams.size(), 0.0);
     _pointBuf.assign(3 * _points.size(), 0.0);
+    pinDoubles(_camBuf.data(), _camBuf.size());
+    pinDoubles(_pointBuf.data(), _pointBuf.size());
     if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
       std::cerr << "BlockSolverHip: device front end (g2ohip_ba_*) for " << n << " EdgeProjectXYZ2UV, " << _cams.size() << " cameras, " << _points.size()
                 << " points, " << nClasses << " edge class" << (nClasses == 1 ? "" : "es") << std::endl;
@@ -543,6 +606,7 @@ class BlockSolverHip : public BlockSolverBase {
     }
     if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
       std::cerr << "BlockSolverHip: device fast path for " << n << " EdgeSE2 edges over " << _pgVerts.size() << " vertices" << std::endl;
+    pinDoubles(_pgBuf.data(), _pgBuf.size());          // (only once the front end has taken the group: the buffer stays)
     return true;
   }
   bool uploadPosesSE2() {
@@ -604,6 +668,7 @@ class BlockSolverHip : public BlockSolverBase {
     }
     if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
       std::cerr << "BlockSolverHip: device fast path for " << n << " EdgeSE3 edges over " << _pg3Verts.size() << " vertices" << std::endl;
+    pinDoubles(_pgBuf.data(), _pgBuf.size());
     return true;
   }
   bool uploadPosesSE3() {
@@ -643,6 +708,9 @@ class BlockSolverHip : public BlockSolverBase {
   std::vector<double> _diagMirror, _diag;
   bool _fastPath;
   int _fastGroups;                                     // groups bound to a device front end (Group::fast)
+  bool _pin, _timing;
+  std::vector<void*> _pinned;                          // buffers registered with g2ohip_host_register
+  Phases _phase;
   std::vector<double> _baClasses;                      // class table of the BA group: (f, cx, cy, kernel kind, delta) per class
 #if G2OHIP_FASTPATH_SLAM2D
   std::vector<VertexSE2*> _pgVerts;

@@ -114,12 +114,12 @@ def make_ba_problem(P, L, seed=42, spacing=0.5, obs_per_landmark=5, outlier_frac
                 v1=cam_hidx[cam_idx].astype(np.int32))    # vertex 1 = pose (types_six_dof_expmap.h:133)
 
 
-def make_ba_loops(P, L, laps=4, hubs=3, drop=0.2, seed=7, spacing=0.5, f=1000.0, cx=320.0, cy=240.0):
+def make_ba_loops(P, L, laps=4, hubs=3, drop=0.2, seed=7, spacing=0.5, f=1000.0, cx=320.0, cy=240.0, hub_stride=3):
     """A bundle-adjustment graph that is NOT a band: the camera runs `laps` times back and forth along the same line
     (poses of different laps stand at the same places and see the same points -- loop closures everywhere, the reduced
     pose system couples every lap with every other: separators and frontal matrices several times the band case), a
     fraction `drop` of the observations is missing (ragged observation lists, 2 .. 5 laps long) and `hubs` distant points
-    are seen by every third pose (lists far longer than a wavefront).  Same dictionary as make_ba_problem."""
+    are seen by every third pose (`hub_stride`; lists far longer than a wavefront).  Same dictionary as make_ba_problem."""
     rng = CounterRng(seed)
     M = max(P // laps, 6)                                   # positions along the line
     c = np.arange(P, dtype=np.int64)
@@ -141,7 +141,7 @@ def make_ba_loops(P, L, laps=4, hubs=3, drop=0.2, seed=7, spacing=0.5, f=1000.0,
         cam_l.append(obs)
         pt_l.append(np.full(len(obs), jj))
     for h in range(hubs):
-        obs = np.arange(h, P, 3)
+        obs = np.arange(h, P, hub_stride)
         cam_l.append(obs)
         pt_l.append(np.full(len(obs), Lr + h))
     cam_idx = np.concatenate(cam_l).astype(np.int32)

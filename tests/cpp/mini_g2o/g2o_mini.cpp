@@ -187,10 +187,17 @@ double OptimizationAlgorithmLevenberg::computeScale() const {
 // :57-146
 OptimizationAlgorithm::SolverResult OptimizationAlgorithmLevenberg::solve(int iteration, bool) {
   if (iteration == 0 && !_solver->buildStructure()) return Fail;
+  double t = get_monotonic_time();                       // the BatchStatistics fields as optimization_algorithm_levenberg.cpp:70-113 fills them
   _optimizer->computeActiveErrors();
+  G2OBatchStatistics* globalStats = G2OBatchStatistics::globalStats();
+  if (globalStats) {
+    globalStats->timeResiduals = get_monotonic_time() - t;
+    t = get_monotonic_time();
+  }
   double currentChi = _optimizer->activeRobustChi2();
   double tempChi = currentChi;
   _solver->buildSystem();
+  if (globalStats) globalStats->timeQuadraticForm = get_monotonic_time() - t;
   if (iteration == 0) {
     _currentLambda = computeLambdaInit();
     _ni = 2;
@@ -199,9 +206,18 @@ OptimizationAlgorithm::SolverResult OptimizationAlgorithmLevenberg::solve(int it
   int qmax = 0;
   do {
     _optimizer->push();
+    if (globalStats) {
+      globalStats->levenbergIterations++;
+      t = get_monotonic_time();
+    }
     _solver->setLambda(_currentLambda, true);
     const bool ok2 = _solver->solve();
+    if (globalStats) {
+      globalStats->timeLinearSolution += get_monotonic_time() - t;
+      t = get_monotonic_time();
+    }
     _optimizer->update(_solver->x());
+    if (globalStats) globalStats->timeUpdate = get_monotonic_time() - t;
     _solver->restoreDiagonal();
     _optimizer->computeActiveErrors();
     tempChi = _optimizer->activeRobustChi2();

@@ -221,6 +221,109 @@ int main(int argc, char** argv) {
     std::ofstream(argv[5]) << js.str() << std::endl;
     return 0;
   }
+  if (argc > 6 && std::string(argv[6]).compare(0, 6, "bench:") == 0) {
+    // ---- "bench:<cameras>:<points>:<observations per point>": SparseOptimizer::optimize() on a synthetic bundle-adjustment graph
+    // built in memory (the geometry of openslam_g2o_amd/synthetic.make_ba_problem: a camera moving along a line, every point seen
+    // by K consecutive cameras), timed per phase: BatchStatistics of the algorithm (optimization_algorithm_levenberg.cpp:70-113)
+    // around the adapter's own split (G2OHIP_ADAPTER_TIMING=1 prints it when the solver is destroyed).  argv[1] is ignored.
+    int P = 0, L = 0, K = 5;
+    if (std::sscanf(argv[6] + 6, "%d:%d:%d", &P, &L, &K) < 2 || P < K || L < 1) return 2;
+    unsigned long long rs = 0x9E3779B97F4A7C15ull;
+    struct Rng {
+      unsigned long long& s;
+      double uni() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) * (1.0 / 9007199254740992.0); }
+      double nrm() { double a = 0; for (int i = 0; i < 12; ++i) a += uni(); return a - 6.0; }
+    } rng = {rs};
+    const double f = 1000., cx = 320., cy = 240., spacing = 0.5;
+    Vector2d pp;
+    pp[0] = cx;
+    pp[1] = cy;
+    CameraParameters cam(f, pp, 0.);
+    SparseOptimizer optimizer;
+    const double t0 = get_monotonic_time();
+    std::vector<VertexSE3Expmap*> cams(P);
+    for (int i = 0; i < P; ++i) {
+      Eigen::Matrix3d R;
+      R.setIdentity();
+      Vector3d t;
+      t[0] = -i * spacing; t[1] = 0; t[2] = 0;
+      VertexSE3Expmap* v = new VertexSE3Expmap();
+      v->setId(i);
+      v->setFixed(i < 2);
+      SE3Quat T(R, t);
+      if (i >= 2) {
+        Vector6d u;
+        for (int k = 0; k < 3; ++k) u[k] = 0.005 * rng.nrm();
+        for (int k = 3; k < 6; ++k) u[k] = 0.01 * rng.nrm();
+        T = SE3Quat::exp(u) * T;
+      }
+      v->setEstimate(T);
+      optimizer.addVertex(v);
+      cams[i] = v;
+    }
+    size_t nedges = 0;
+    for (int j = 0; j < L; ++j) {
+      const long long c = (long long)j * P / L;
+      long long lo = c - K / 2;
+      if (lo < 0) lo = 0;
+      if (lo > P - K) lo = P - K;
+      Vector3d X, Xn;
+      X[0] = c * spacing + (rng.uni() * 3.0 - 1.5);
+      X[1] = rng.uni() - 0.5;
+      X[2] = 3.0 + rng.uni();
+      for (int k = 0; k < 3; ++k) Xn[k] = X[k] + 0.05 * rng.nrm();
+      VertexSBAPointXYZ* v = new VertexSBAPointXYZ();
+      v->setId(P + j);
+      v->setMarginalized(true);
+      v->setEstimate(Xn);
+      optimizer.addVertex(v);
+      for (int k = 0; k < K; ++k) {
+        const int ci = (int)(lo + k);
+        Vector2d z;
+        const double xc = X[0] - ci * spacing, yc = X[1], zc = X[2];
+        z[0] = xc / zc * f + cx + rng.nrm();
+        z[1] = yc / zc * f + cy + rng.nrm();
+        EdgeProjectXYZ2UV* e = new EdgeProjectXYZ2UV();
+        e->setVertex(0, v);
+        e->setVertex(1, cams[ci]);
+        e->setMeasurement(z);
+        e->_cam = &cam;
+        optimizer.addEdge(e);
+        ++nedges;
+      }
+    }
+    const double tGraph = get_monotonic_time() - t0;
+    optimizer.setAlgorithm(algo);
+    double t1 = get_monotonic_time();
+    optimizer.initializeOptimization();
+    const double tInit = get_monotonic_time() - t1;
+    if (!algo->init()) return 4;
+    optimizer.computeActiveErrors();
+    const double chi0 = optimizer.activeRobustChi2();
+    std::ostringstream js;
+    js << std::setprecision(9);
+    js << "{\"solver\": \"" << solverName << "\", \"cameras\": " << P << ", \"points\": " << L << ", \"edges\": " << nedges << ", \"graph_s\": " << tGraph
+       << ", \"initializeOptimization_s\": " << tInit << ", \"chi2_initial\": " << chi0 << ", \"iterations\": [";
+    for (int i = 0; i < iterations; ++i) {
+      G2OBatchStatistics st;
+      G2OBatchStatistics::setGlobalStats(&st);
+      t1 = get_monotonic_time();
+      const OptimizationAlgorithm::SolverResult r = algo->solve(i);
+      const double tIter = get_monotonic_time() - t1;
+      G2OBatchStatistics::setGlobalStats(0);
+      if (r == OptimizationAlgorithm::Fail) return 5;
+      t1 = get_monotonic_time();
+      optimizer.computeActiveErrors();
+      const double chi = optimizer.activeRobustChi2();
+      const double tChi = get_monotonic_time() - t1;
+      js << (i ? ", " : "") << "{\"iteration_s\": " << tIter << ", \"timeResiduals\": " << st.timeResiduals << ", \"timeQuadraticForm\": " << st.timeQuadraticForm
+         << ", \"timeLinearSolution\": " << st.timeLinearSolution << ", \"timeUpdate\": " << st.timeUpdate << ", \"levenbergIterations\": " << st.levenbergIterations
+         << ", \"computeActiveErrors_plus_chi2_s\": " << tChi << ", \"chi2\": " << chi << "}";
+    }
+    js << "]}";
+    std::ofstream(argv[5]) << js.str() << std::endl;
+    return 0;
+  }
   // ---- graph
   std::ifstream in(argv[1]);
   int ncams, npts, nedges;

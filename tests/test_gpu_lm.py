@@ -139,15 +139,16 @@ def test_fused_assembly_with_short_and_long_observation_lists(K):
     assert relerr(s.x(), o.x()) < 1e-8
 
 
-@pytest.mark.parametrize("P,L,laps,hubs", [(150, 700, 3, 0), (320, 1500, 5, 0), (320, 1500, 5, 3), (640, 2500, 8, 2)])
-def test_ba_graph_with_loop_closures_and_ragged_lists(P, L, laps, hubs):
+@pytest.mark.parametrize("P,L,laps,hubs,stride", [(150, 700, 3, 0, 3), (320, 1500, 5, 0, 3), (320, 1500, 5, 3, 3), (640, 2500, 8, 2, 3),
+                                                    (2400, 12000, 6, 3, 24)])
+def test_ba_graph_with_loop_closures_and_ragged_lists(P, L, laps, hubs, stride):
     """Not a band: the camera passes the same places several times (synthetic.make_ba_loops), so the reduced system
     couples distant poses (frontal matrices of a few hundred rows: the LDS and scratch-slab kernels under the virtual
     Schur source), observation lists are ragged (2 .. 5 laps) and, with hubs, a few points are seen by more poses than
     a wavefront has lanes (the tiles then leave the landmark side to the stand-alone kernel).  System, solution and one
     LM step against the oracle."""
     from openslam_g2o_amd import capi
-    pr = S.make_ba_loops(P, L, laps=laps, hubs=hubs)
+    pr = S.make_ba_loops(P, L, laps=laps, hubs=hubs, hub_stride=stride)   # (the last case: 2 398 free poses, hubs seen by 100 poses each)
     Jp, Jc, err = S.ba_linearize(pr)
     pr.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(pr))
     o = oracle_ba(pr, huber=2.0)
