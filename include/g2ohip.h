@@ -74,6 +74,7 @@ typedef struct g2ohip_stats {
   size_t dependencyFallbacks;        /* dependency-driven launches that gave up waiting and were repeated level by level (0 expected) */
   size_t bandChains;                 /* leaf chains of the elimination tree factorised by the sliding-window band kernel */
   size_t bandCholeskyNNZ, bandPivots; /* ... their share of choleskyNNZ and of the pivot columns (scalars) */
+  size_t shardedCollectives;         /* all-reduces of the last g2ohip_solve_sharded (2 with option sharded_merge where the partition allows, else 3) */
 } g2ohip_stats;
 /* (G2OBatchStatistics::timeIteration / levenbergIterations / chi2 belong to the caller's optimisation loop:
  *  openslam_g2o_amd/lm.py fills them and prints the `g2o -stats` line, batch_stats.cpp:49-82.) */
@@ -215,6 +216,8 @@ int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* c
  * "ba_fused", "ba_store_ll" (0: Hll and the errors of the fused BA path reach HBM only when a reader asks), "use_graph",
  * "mask_solution", "sharded_virtual" (1: on a rank the factorisation reads Hpp and the partial blocks itself, only the boundary
  * blocks of the reduced system are reduced and exchanged as blocks), "sharded_graph" (1: g2ohip_solve_sharded as one hipGraph where nothing crosses the host; 2: with RCCL too),
+ * "sharded_merge" (1: the boundary blocks / b_p of a sharded solve travel in the all-reduce of the subtree roots -- two collectives per
+ * solve instead of three -- whenever only the shared top of the tree consumes them; 0: always three),
  * "comm_emulate" (timing only).  G2OHIP_OPTIONS="name=value,..." in the environment sets options for every solver of a process: g2ohip_create and
  * g2ohip_ls_create apply it (so the g2o plugin sees it too); a malformed or, for g2ohip_create, unknown entry fails the
  * creation with G2OHIP_ERR_ARG; an explicit g2ohip_set_option afterwards wins. */

@@ -141,6 +141,9 @@ class BlockSolver {
   bool use_graph = false;
   int sharded_virtual = 1;                 // sharded solve: the factorisation reads Hpp + partial blocks itself (as on one GPU); only the
                                            // boundary blocks of the reduced system are reduced, exchanged and read back as blocks
+  int sharded_merge = 1;                   // sharded solve: TWO all-reduces instead of three -- the boundary blocks and b_p travel with the
+                                           // subtree roots (after the own subtrees) whenever only the shared top of the tree consumes them
+  size_t sharded_collectives = 0;          // all-reduces issued by the last solve_sharded_once (stats)
   int sharded_graph = 1;                   // solve_sharded as ONE hipGraph (the collectives inside it): 1 = when nothing has to cross the
                                            // host (comm_emulate), 2 = with RCCL as well (ncclAllReduce captured into the graph; not
                                            // exercised on hardware here -- opt-in); 0 = one graph per phase, plain launches in between
@@ -224,6 +227,8 @@ class BlockSolver {
     int nbb = 0, nbp = 0, nh = 0;
     DevBuf<int> bblock, bpose, halo;
     DevBuf<double> hkeep, bkeep, hmine, buf1, buf3;
+    bool merged = false;      // the boundary blocks / b_p ride in the all-reduce of the subtree roots (sharded_merge)
+    double* tail = nullptr;   // ... their place behind the Cholesky's exchange buffer
   } ex_;
   void solve_back_substitute_impl();
   void launch_boundary_reduce();

@@ -3624,6 +3624,7 @@ void BlockSolver::exchange_setup(int nbb, const int* bblock, const double* hkeep
                                  const int* halo, const double* hmine) {
   require_structure();
   if (nbb < 0 || nbp < 0 || nh < 0) throw ArgFailure("exchange_setup: negative count");
+  drop_graph_segments();   // (buffers move: the captured launch sequences hold their addresses; what the kernels read has not changed)
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ex_.nbb = nbb;
   ex_.nbp = nbp;
@@ -3646,6 +3647,22 @@ void BlockSolver::exchange_setup(int nbb, const int* bblock, const double* hkeep
   up_d(ex_.hmine, hmine, nh);
   ex_.buf1.alloc((size_t)std::max(1, nbb * p_ * p_ + nbp * p_));
   ex_.buf1.zero(st_);
+  // Two collectives instead of three: the first all-reduce (boundary blocks of the reduced system, boundary b_p) can wait for
+  // the second (update matrices / vectors of the subtree roots) when nothing a rank factorises on its OWN reads the summed
+  // values -- every boundary block is assembled by a front of the shared top, every boundary pose is eliminated there.  With
+  // landmarks dealt by their first OWNED observing pose that holds whenever no landmark spans two subtrees (a band: always).
+  ex_.merged = false;
+  ex_.tail = nullptr;
+  if (sharded_merge && chol_ && chol_opt.world > 1 && schur_) {
+    const CholSymbolic& S = chol_->symbolic();
+    bool ok = (int)S.block_consumer.size() == (int)hs_row.size() && (int)S.pose_owner.size() == nP_;
+    for (int k = 0; k < nbb && ok; ++k) ok = bblock[k] >= 0 && bblock[k] < (int)S.block_consumer.size() && S.block_consumer[bblock[k]] < 0;
+    for (int k = 0; k < nbp && ok; ++k) ok = bpose[k] >= 0 && bpose[k] < nP_ && S.pose_owner[bpose[k]] < 0;
+    if (ok && nbb * p_ * p_ + nbp * p_ > 0) {
+      ex_.tail = chol_->reserve_exchange_tail((size_t)nbb * p_ * p_ + (size_t)nbp * p_);
+      ex_.merged = true;
+    }
+  }
   ex_.buf3.alloc((size_t)nh * p_ + 1);
   ex_.buf3.zero(st_);
   // Virtual source on a rank (sharded_virtual): as on one GPU the fronts are assembled from Hpp and the tiles' partial blocks
@@ -3704,7 +3721,7 @@ void BlockSolver::exchange_pack(int which) {
     if (n > 0)
       hipLaunchKernelGGL(exchange_boundary_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st_, ex_.nbb, ex_.nbp, p_ * p_, p_, ex_.bblock.p,
                          ex_.bpose.p, ex_.hkeep.p, ex_.bkeep.p, sv_now_ ? d_Hpp.p + hpp_blocks_ * (size_t)p_ * p_ : d_Hschur.p, d_bschur.p,
-                         ex_.buf1.p, 0);
+                         ex_.merged ? ex_.tail : ex_.buf1.p, 0);
   } else if (which == 3) {
     hipLaunchKernelGGL(exchange_halo_kernel, dim3(grid_for(ex_.nh * p_ + 1)), dim3(kThreads), 0, st_, ex_.nh, p_, ex_.halo.p, ex_.hmine.p,
                        d_x.p, ex_.buf3.p, chol_->status_device(), 0);
@@ -3721,7 +3738,7 @@ void BlockSolver::exchange_unpack(int which) {
     if (n > 0)
       hipLaunchKernelGGL(exchange_boundary_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st_, ex_.nbb, ex_.nbp, p_ * p_, p_, ex_.bblock.p,
                          ex_.bpose.p, ex_.hkeep.p, ex_.bkeep.p, sv_now_ ? d_Hpp.p + hpp_blocks_ * (size_t)p_ * p_ : d_Hschur.p, d_bschur.p,
-                         ex_.buf1.p, 1);
+                         ex_.merged ? ex_.tail : ex_.buf1.p, 1);
   } else if (which == 3) {
     hipLaunchKernelGGL(exchange_halo_kernel, dim3(grid_for(ex_.nh * p_ + 1)), dim3(kThreads), 0, st_, ex_.nh, p_, ex_.halo.p, ex_.hmine.p,
                        d_x.p, ex_.buf3.p, chol_->status_device(), 1);
@@ -3810,11 +3827,17 @@ int BlockSolver::solve_sharded_once() {
   auto whole_solve = [&] {
   // (1) local Schur pass; boundary blocks of the reduced system + boundary right-hand sides summed over the ranks
   solve_schur();
-  if (ex_.nbb > 0 || ex_.nbp > 0) {
+  sharded_collectives = 0;
+  const size_t n1 = (size_t)ex_.nbb * p_ * p_ + (size_t)ex_.nbp * p_;
+  const bool merged = ex_.merged && n1 > 0;
+  if (n1 > 0) {
     prof.begin(KernelProf::kExBoundary, st_);   // (pack + all-reduce + unpack: what the exchange costs the solve)
-    exchange_pack(1);
-    comm.all_reduce(ex_.buf1.p, (size_t)ex_.nbb * p_ * p_ + (size_t)ex_.nbp * p_, 0, st_);
-    exchange_unpack(1);
+    exchange_pack(1);                           // (merged: into the tail of the subtree-root buffer; summed with it below)
+    if (!merged) {
+      comm.all_reduce(ex_.buf1.p, n1, 0, st_);
+      ++sharded_collectives;
+      exchange_unpack(1);
+    }
     prof.end(KernelProf::kExBoundary, st_);
   }
   // (2) own subtrees: factor + forward sweep; update matrices / vectors of the subtree roots summed (separator-sized)
@@ -3823,7 +3846,13 @@ int BlockSolver::solve_sharded_once() {
     size_t n = 0;
     double* xb = chol_->exchange_buffer(&n);
     prof.begin(KernelProf::kExRoots, st_);
-    comm.all_reduce(xb, n, 0, st_);
+    comm.all_reduce(xb, n + (merged ? n1 : 0), 0, st_);
+    ++sharded_collectives;
+    if (merged) {
+      exchange_unpack(1);
+      chol_->solve_begin(d_bschur.p, st_);   // the permuted right-hand side again: b of the shared poses is complete only now (the
+                                             // forward sweep of the own subtrees has read its part and left it untouched)
+    }
     prof.end(KernelProf::kExRoots, st_);
   }
   // (3) shared top of the tree (redundant), backward sweep down the own subtrees; halo x_p + failure flags summed
@@ -3832,6 +3861,7 @@ int BlockSolver::solve_sharded_once() {
   prof.begin(KernelProf::kExHalo, st_);
   exchange_pack(3);
   comm.all_reduce(ex_.buf3.p, (size_t)ex_.nh * p_ + 1, 0, st_);
+  ++sharded_collectives;
   exchange_unpack(3);
   prof.end(KernelProf::kExHalo, st_);
   solve_back_substitute();           // (harmless after a failed factorisation: the caller discards x)
@@ -5020,7 +5050,7 @@ void BlockSolver::device_array(int which, double** ptr, size_t* count) {
     case 102: *ptr = d_b.p; *count = vector_size(); break;
     case 103: *ptr = chol_->exchange_buffer(count); break;      // subtree-root update matrices + vectors
     case 104: *ptr = chol_->permuted_solution(count); break;   // x_p in elimination order (masked before the all-reduce)
-    case 105: *ptr = ex_.buf1.p; *count = (size_t)std::max(1, ex_.nbb * p_ * p_ + ex_.nbp * p_); break;   // exchange_setup buffers
+    case 105: *ptr = ex_.merged ? ex_.tail : ex_.buf1.p; *count = (size_t)std::max(1, ex_.nbb * p_ * p_ + ex_.nbp * p_); break;   // exchange_setup buffers (what exchange_pack(1) fills)
     case 106: *ptr = ex_.buf3.p; *count = (size_t)ex_.nh * p_ + 1; break;
     case 107: *ptr = d_mf_diag.p; *count = mf_ready_ ? (size_t)nP_ * p_ * p_ : 0; break;   // schur_operator_prepare: diagonal blocks
     default: throw ArgFailure("bad array selector");

@@ -494,6 +494,7 @@ int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out) {
   out->timeLinearize = b.times.linearize;
   out->timeUpdate = b.times.update;
   out->dependencyFallbacks = b.dependency_fallbacks;
+  out->shardedCollectives = b.sharded_collectives;
   return G2OHIP_OK;
 }
 
@@ -556,6 +557,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "overlap_assembly")) s->impl->overlap_assembly = value != 0;
   else if (!std::strcmp(name, "use_graph")) s->impl->use_graph = value != 0;
   else if (!std::strcmp(name, "sharded_graph")) s->impl->sharded_graph = (int)value;
+  else if (!std::strcmp(name, "sharded_merge")) s->impl->sharded_merge = (int)value;
   else if (!std::strcmp(name, "sharded_virtual")) s->impl->sharded_virtual = (int)value;
   else if (!std::strcmp(name, "ba_fused")) s->impl->ba_fused = value != 0;
   else {

@@ -205,6 +205,9 @@ class SparseCholesky {
   bool inverse_block(int r, int c, long long* offset, int* ld, bool* transposed) const;
   const double* inverse_slab() const { return d_Z.p; }
   double* exchange_buffer(size_t* count) { *count = xbuf_count_; return d_xbuf.p; }
+  // room for `n` more doubles BEHIND the subtree-root segments of the exchange buffer (the caller's own payload travels in
+  // the same all-reduce: BlockSolver's boundary blocks); pack_exchange clears and fills the head only
+  double* reserve_exchange_tail(size_t n);
   double* permuted_solution(size_t* count) { *count = (size_t)sym_.nb * bs_; return d_xp.p; }
   int* status_flag() { return d_status.p; }
   // Synchronises st and returns true when the last factorisation met a pivot <= 0.

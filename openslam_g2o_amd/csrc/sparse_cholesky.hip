@@ -4644,6 +4644,15 @@ void SparseCholesky::solve(const double* d_b, double* d_x, hipStream_t st) {
   solve_backward_phase(0, st);
   solve_end(d_x, st);
 }
+double* SparseCholesky::reserve_exchange_tail(size_t n) {
+  if (d_xbuf.n < xbuf_count_ + n || !d_xbuf.p) {
+    DevBuf<double> bigger;
+    bigger.alloc(xbuf_count_ + n);
+    G2OHIP_HIP_CHECK(hipMemset(bigger.p, 0, (xbuf_count_ + n) * sizeof(double)));
+    d_xbuf = std::move(bigger);
+  }
+  return d_xbuf.p + xbuf_count_;
+}
 void SparseCholesky::pack_exchange(hipStream_t st) {
   if (n_xseg_ == 0) return;
   G2OHIP_HIP_CHECK(hipMemsetAsync(d_xbuf.p, 0, xbuf_count_ * sizeof(double), st));

@@ -205,7 +205,9 @@ def test_sharded_matrix_free_pcg_matches_oracle(tmp_path, world):
     assert len(set(its)) == 1 and its[0] > 0                                      # every rank took the same decisions
 
 
-def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir, stall_rank=-1):
+def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir, stall_rank=-1, options=""):
+    if options:
+        os.environ["G2OHIP_OPTIONS"] = options
     if rank == stall_rank:       # this rank's dependency-driven launches give up at once (the safety net under test)
         os.environ["G2OHIP_OPTIONS"] = "dep_spin_limit=0"
     import torch
@@ -227,7 +229,8 @@ def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir, stall_ra
         done, chis, lams, trials = lm.optimize(g, s, n_it, "lm")
         cams, pts = s.local.baGetEstimates()
         np.savez(os.path.join(out_dir, "lm%d.npz" % rank), done=done, chis=chis, lams=lams, trials=trials, cams=cams, pts=pts,
-                 lm_index=s.lm_index, pose_owner=s.pose_owner, halo=s.halo, fallbacks=s.local.stats()["dependencyFallbacks"])
+                 lm_index=s.lm_index, pose_owner=s.pose_owner, halo=s.halo, fallbacks=s.local.stats()["dependencyFallbacks"],
+                 collectives=s.local.stats()["shardedCollectives"])
     finally:
         dist.destroy_process_group()
 
@@ -272,6 +275,7 @@ def test_sharded_lm_with_huber_matches_single_rank_and_oracle(tmp_path, world):
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "lm%d.npz" % r))
         assert int(z["done"]) == done1 and list(z["trials"]) == trials1       # same accept / reject decisions on every rank
+        assert int(z["collectives"]) == 2        # (a band: the boundary blocks ride with the subtree roots, sharded_merge)
         assert np.allclose(z["chis"], chis1, rtol=1e-6, atol=0) and np.allclose(z["chis"], chis_o, rtol=1e-6, atol=0)
         assert np.allclose(z["lams"], lams1, rtol=1e-6, atol=0)
         # estimates: the landmarks a rank owns, the cameras it owns / shares / needs (halo)
@@ -283,6 +287,28 @@ def test_sharded_lm_with_huber_matches_single_rank_and_oracle(tmp_path, world):
         cam_ok[free] = valid[pr["cam_hidx"][free]]
         assert relerr(z["cams"][cam_ok], cams1[cam_ok]) < 1e-6
     assert chis1[-1] < chis1[0]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_collectives_per_sharded_solve_equal_three(tmp_path, world):
+    """Option sharded_merge (default 1): the all-reduce of the boundary blocks / b_p is folded into the one of the subtree roots when
+    only the shared top of the tree consumes them (the Schur off-diagonal contributions are what crosses ranks) -- two
+    latency-sized collectives per solve instead of three.  Same LM trajectory and estimates as with three (sharded_merge = 0)."""
+    import torch.multiprocessing as mp
+    P, L, n_it = 640, 5000, 4
+    runs = {}
+    for merge in (1, 0):
+        d = tmp_path / ("m%d" % merge)
+        d.mkdir()
+        mp.spawn(_lm_worker, args=(world, _free_port(), P, L, 1.0, 0.05, n_it, str(d), -1, "sharded_merge=%d" % merge), nprocs=world, join=True)
+        runs[merge] = [np.load(os.path.join(str(d), "lm%d.npz" % r)) for r in range(world)]
+    for r in range(world):
+        a, b = runs[1][r], runs[0][r]
+        assert int(a["collectives"]) == 2 and int(b["collectives"]) == 3
+        assert int(a["done"]) == int(b["done"]) and list(a["trials"]) == list(b["trials"])
+        assert np.allclose(a["chis"], b["chis"], rtol=1e-9, atol=0) and np.allclose(a["lams"], b["lams"], rtol=1e-9, atol=0)
+        assert relerr(a["pts"], b["pts"]) < 1e-9
+    assert runs[1][0]["chis"][-1] < runs[1][0]["chis"][0]
 
 
 def test_library_comm_over_rccl_single_rank():
