@@ -43,7 +43,7 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "g2ohip_last_error", "g2ohip_device_count", "g2ohip_create", "g2ohip_destroy", "g2ohip_set_stream", "g2ohip_init",
-    "g2ohip_add_edge_set", "g2ohip_build_structure", "g2ohip_set_edge_data", "g2ohip_set_robust_kernel",
+    "g2ohip_add_edge_set", "g2ohip_build_structure", "g2ohip_set_edge_data", "g2ohip_set_robust_kernel", "g2ohip_set_robust_kernel_per_edge",
     "g2ohip_build_system", "g2ohip_chi2", "g2ohip_set_lambda", "g2ohip_restore_diagonal", "g2ohip_max_diagonal",
     "g2ohip_compute_scale", "g2ohip_solve", "g2ohip_vector_size", "g2ohip_copy_x", "g2ohip_copy_b", "g2ohip_x_device",
     "g2ohip_b_device", "g2ohip_multiply_hessian", "g2ohip_sync", "g2ohip_set_profiling", "g2ohip_get_stats",
@@ -101,6 +101,7 @@ def load():
     L.g2ohip_build_structure.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.g2ohip_set_edge_data.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int]
     L.g2ohip_set_robust_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_double]
+    L.g2ohip_set_robust_kernel_per_edge.argtypes = [vp, C.c_int, c_int_p, c_dbl_p]
     L.g2ohip_build_system.argtypes = [vp]
     L.g2ohip_chi2.argtypes = [vp, c_dbl_p]
     L.g2ohip_set_lambda.argtypes = [vp, C.c_double, C.c_int]
@@ -291,6 +292,16 @@ class HipBlockSolver:
 
     def setRobustKernel(self, set_id, kind, delta=1.0):
         _check(self.L.g2ohip_set_robust_kernel(self.h, set_id, kind, delta), "setRobustKernel")
+
+    def setRobustKernelPerEdge(self, set_id, kinds, deltas):
+        """One robust kernel per edge (kinds [n] as KERNEL_*, deltas [n]); kinds=None returns to the set-level kernel."""
+        if kinds is None:
+            _check(self.L.g2ohip_set_robust_kernel_per_edge(self.h, set_id, None, None), "setRobustKernelPerEdge")
+            return
+        k, d = _i32(kinds), _f64(deltas)
+        if len(k) != self._set_sizes[set_id] or len(d) != len(k):
+            raise ValueError("setRobustKernelPerEdge: one entry per edge of set %d" % set_id)
+        _check(self.L.g2ohip_set_robust_kernel_per_edge(self.h, set_id, _ip(k), _dp(d)), "setRobustKernelPerEdge")
 
     def buildSystem(self):
         _check(self.L.g2ohip_build_system(self.h), "buildSystem")

@@ -224,6 +224,8 @@ class BlockSolverHip : public BlockSolverBase {
       }
       Group& g = _groups[it->second];
       g.edges.push_back(e);
+      g.rkKind.push_back(key.kernel);
+      g.rkDelta.push_back(key.kernel ? key.delta : 0.0);
       g.v0.push_back(v0->hessianIndex());              // -1 when fixed (optimizable_graph.h:299)
       if (v1) g.v1.push_back(v1->hessianIndex());
     }
@@ -232,7 +234,15 @@ class BlockSolverHip : public BlockSolverBase {
       const int n = (int)g.edges.size();
       g.set = g2ohip_add_edge_set(_h, g.key.d, n, g.v0.data(), g.key.dim1 ? g.v1.data() : 0);
       if (g.set < 0) return fail("add_edge_set");
-      if (g.key.kernel > 0 && !g.fast && g2ohip_set_robust_kernel(_h, g.set, g.key.kernel, g.key.delta) != G2OHIP_OK) return fail("set_robust_kernel");
+      if (!g.fast) {                                     // one kernel for the set where the edges agree, else one per edge
+        bool uniform = true;
+        for (size_t k = 1; k < g.rkKind.size() && uniform; ++k) uniform = g.rkKind[k] == g.rkKind[0] && g.rkDelta[k] == g.rkDelta[0];
+        if (uniform && !g.rkKind.empty() && g.rkKind[0] > 0) {
+          if (g2ohip_set_robust_kernel(_h, g.set, g.rkKind[0], g.rkDelta[0]) != G2OHIP_OK) return fail("set_robust_kernel");
+        } else if (!uniform) {
+          if (g2ohip_set_robust_kernel_per_edge(_h, g.set, g.rkKind.data(), g.rkDelta.data()) != G2OHIP_OK) return fail("set_robust_kernel_per_edge");
+        }
+      }
       // The library takes a side's dimension from the hessian indices; a side whose vertices are ALL fixed (e.g. a
       // localisation graph over fixed points) is taken as a pose side there (p columns), whatever the vertex type: the
       // buffers are sized for the larger of the two so that g2ohip_set_edge_data never reads past their end.
@@ -407,12 +417,12 @@ class BlockSolverHip : public BlockSolverBase {
   struct GroupKey {
     int d, dim0, dim1, kernel;
     double delta;
+    // (kernel / delta: of the edge being classified -- NOT part of the ordering: in g2o the robust kernel belongs to the edge,
+    // so edges that differ in it only share a group and the group hands the library one kernel per edge)
     bool operator<(const GroupKey& o) const {
       if (d != o.d) return d < o.d;
       if (dim0 != o.dim0) return dim0 < o.dim0;
-      if (dim1 != o.dim1) return dim1 < o.dim1;
-      if (kernel != o.kernel) return kernel < o.kernel;
-      return delta < o.delta;
+      return dim1 < o.dim1;
     }
   };
   struct Group {
@@ -420,7 +430,8 @@ class BlockSolverHip : public BlockSolverBase {
     int set;
     int fast;                                            // 0: generic path; device front end 1: EdgeProjectXYZ2UV (g2ohip_ba_*), 2 / 3: EdgeSE2 / EdgeSE3 (g2ohip_pg_*, type 1 / 2)
     std::vector<OptimizableGraph::Edge*> edges;
-    std::vector<int32_t> v0, v1, cls;                    // (cls: edge class of a BA group's edges)
+    std::vector<int32_t> v0, v1, cls, rkKind;            // (cls: edge class of a BA group's edges; rkKind / rkDelta: robust kernel per edge)
+    std::vector<double> rkDelta;
     std::vector<double> J0, J1, Om, err;
     Group() : key(), set(-1), fast(0) {}
   };

@@ -27,6 +27,7 @@ struct EdgeSet {
   std::vector<int> v0, v1;
   int kernel_kind = 0;
   double delta = 1.0;
+  DevBuf<double> rk;       // per-edge robust kernels [n][2] = (kind, delta), or empty: the set-level pair above (set_robust_kernel_per_edge)
   // per-iteration data (device); either own buffers or caller-owned device pointers
   const double *J0 = nullptr, *J1 = nullptr, *omega = nullptr, *err = nullptr;
   DevBuf<double> own_J0, own_J1, own_omega, own_err;
@@ -63,6 +64,7 @@ class BlockSolver {
   bool update_structure(int new_poses, int set, int n, const int* v0, const int* v1);
   void set_edge_data(int set, const double* J0, const double* J1, const double* omega, const double* err, bool on_device);
   void set_robust_kernel(int set, int kind, double delta);
+  void set_robust_kernel_per_edge(int set, const int* kind, const double* delta);
   void build_system();
   double chi2();
   void set_lambda(double lambda, bool backup);

@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(kThreads) assemble_vertex_kernel(int nV, const
                                        const double* __restrict__ J0, const double* __restrict__ J1,
                                        const double* __restrict__ omega, const double* __restrict__ err, int kind, double delta,
                                        double* __restrict__ H, const int* __restrict__ diag_blk, double* __restrict__ b,
-                                       int accumulate) {
+                                       int accumulate, const double* __restrict__ rk) {
+  // rk != nullptr: every edge of the set brings its own robust kernel, rk[2 e] = kind, rk[2 e + 1] = delta (set_robust_kernel_per_edge)
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int v = gt / G, g = gt % G;
   const bool active = v < nV;
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(kThreads) assemble_vertex_kernel(int nV, const
       Or[i] = t;
       e2 += r[i] * t;
     }
-    const double w = robust_weight(kind, delta, e2);
+    const double w = rk ? robust_weight((int)rk[2 * e], rk[2 * e + 1], e2) : robust_weight(kind, delta, e2);
     // b += J' (-w O r)
 #pragma unroll
     for (int c = 0; c < DV; ++c) {
@@ -227,7 +228,7 @@ template <int D, int DR, int DC>
 __global__ void __launch_bounds__(kThreads) assemble_offdiag_kernel(int nDst, const int* __restrict__ dst, const int* __restrict__ ptr,
                                         const int* __restrict__ ent, const double* __restrict__ J0, const double* __restrict__ J1,
                                         const double* __restrict__ omega, const double* __restrict__ err, int kind, double delta,
-                                        double* __restrict__ H, int accumulate) {
+                                        double* __restrict__ H, int accumulate, const double* __restrict__ rk) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nDst) return;
   double acc[DR * DC];
@@ -245,6 +246,10 @@ __global__ void __launch_bounds__(kThreads) assemble_offdiag_kernel(int nDst, co
     load_vec<D * DR>(Lp, Lm);
     load_vec<D * DC>(Rp, Rm);
     double w = 1.0;
+    if (rk) {   // (per-edge kernels)
+      kind = (int)rk[2 * e];
+      delta = rk[2 * e + 1];
+    }
     if (kind != 0) {
       const double* rp = err + e * D;
       double e2 = 0.0;
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(kThreads) assemble_offdiag_kernel(int nDst, co
 // chi2 partial sums: sum_e rho(e' Omega e)  (sparse_optimizer.cpp:100-114)
 template <int D>
 __global__ void __launch_bounds__(kThreads) chi2_kernel(int n, const double* __restrict__ omega, const double* __restrict__ err, int kind, double delta,
-                            double* __restrict__ partial) {
+                            double* __restrict__ partial, const double* __restrict__ rk) {
   __shared__ double sh[kThreads];
   double s = 0.0;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)n; e += (size_t)gridDim.x * blockDim.x) {
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(kThreads) chi2_kernel(int n, const double* __r
       for (int j = 0; j < D; ++j) t += O[i + D * j] * r[j];
       e2 += r[i] * t;
     }
-    s += robust_rho(kind, delta, e2);
+    s += rk ? robust_rho((int)rk[2 * e], rk[2 * e + 1], e2) : robust_rho(kind, delta, e2);
   }
   sh[threadIdx.x] = s;
   __syncthreads();
@@ -2008,7 +2013,7 @@ void launch_vertex(int G, int nV, const int* vptr, const int* vent, const EdgeSe
   if (nV == 0) return;
 #define G2OHIP_LV(GG)                                                                                                    \
   hipLaunchKernelGGL((assemble_vertex_kernel<D, DV, GG>), dim3(grid_for((size_t)nV * GG)), dim3(kThreads), 0, st, nV, vptr, \
-                     vent, es.J0, es.J1, es.omega, es.err, es.kernel_kind, es.delta, H, diag_blk, b, accumulate)
+                     vent, es.J0, es.J1, es.omega, es.err, es.kernel_kind, es.delta, H, diag_blk, b, accumulate, es.rk.p)
   if (G <= 1)
     G2OHIP_LV(1);
   else if (G <= 4)
@@ -2045,7 +2050,7 @@ void dispatch_offdiag(int D, int DR, int DC, int nDst, const int* dst, const int
 #define G2OHIP_CASE(d_, r_, c_)                                                                                         \
   if (D == d_ && DR == r_ && DC == c_) {                                                                                \
     hipLaunchKernelGGL((assemble_offdiag_kernel<d_, r_, c_>), dim3(grid_for(nDst)), dim3(kThreads), 0, st, nDst, dst, ptr, \
-                       ent, es.J0, es.J1, es.omega, es.err, es.kernel_kind, es.delta, H, accumulate);                    \
+                       ent, es.J0, es.J1, es.omega, es.err, es.kernel_kind, es.delta, H, accumulate, es.rk.p);          \
     return;                                                                                                             \
   }
   G2OHIP_CASE(2, 3, 2);
@@ -2742,6 +2747,33 @@ void BlockSolver::set_robust_kernel(int set, int kind, double delta) {
     throw StateFailure("set_robust_kernel: the set is bound to the BA front end with edge classes, which carry their own kernels (ba_set_edges_classes)");
   sets_[set]->kernel_kind = kind;
   sets_[set]->delta = delta;
+  sets_[set]->rk.release();   // (a set-level kernel replaces per-edge ones)
+}
+
+// Every edge its own robust kernel (in g2o the kernel is a member of the EDGE, optimizable_graph.h:436-443: a pose graph with
+// kernels on its loop closures only is ONE homogeneous set of EdgeSE2 / EdgeSE3 here).  kind == nullptr: back to the set-level kernel.
+void BlockSolver::set_robust_kernel_per_edge(int set, const int* kind, const double* delta) {
+  invalidate_graphs();
+  if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
+  EdgeSet& es = *sets_[set];
+  if (!kind) {
+    es.rk.release();
+    return;
+  }
+  if (!delta) throw ArgFailure("set_robust_kernel_per_edge: null delta array");
+  if (set == ba_.set && ba_.set >= 0)
+    throw StateFailure("set_robust_kernel_per_edge: the set is bound to the BA front end; per-edge kernels go through ba_set_edges_classes there");
+  std::vector<double> h((size_t)es.n * 2);
+  for (int k = 0; k < es.n; ++k) {
+    if (kind[k] < 0 || kind[k] > 5) throw ArgFailure("unsupported robust kernel for edge " + std::to_string(k));
+    if (kind[k] != 0 && !(delta[k] > 0.0)) throw ArgFailure("robust kernel: delta must be positive (edge " + std::to_string(k) + ")");
+    h[2 * (size_t)k] = kind[k];
+    h[2 * (size_t)k + 1] = delta[k];
+  }
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (h.empty()) h.assign(2, 0.0);
+  es.rk.upload(h, st_);
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
 }
 
 void BlockSolver::invalidate_graphs() {
@@ -3081,7 +3113,7 @@ double BlockSolver::chi2() {
 #define G2OHIP_CHI(d_)                                                                                                      \
   case d_:                                                                                                                  \
     hipLaunchKernelGGL((chi2_kernel<d_>), dim3(nblocks), dim3(kThreads), 0, st_, es.n, es.omega, es.err, es.kernel_kind, es.delta, \
-                       d_red.p);                                                                                            \
+                       d_red.p, es.rk.p);                                                                                   \
     break
     switch (es.d) {
       G2OHIP_CHI(1);
@@ -4209,7 +4241,7 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
     double* red = d_red_multi.p + (k + 1) * kMaxBlocks;
 #define G2OHIP_CHI(d_)                                                                                                      \
   case d_:                                                                                                                  \
-    hipLaunchKernelGGL((chi2_kernel<d_>), dim3(nblk[k + 1]), dim3(kThreads), 0, st_, es.n, es.omega, es.err, es.kernel_kind, es.delta, red); \
+    hipLaunchKernelGGL((chi2_kernel<d_>), dim3(nblk[k + 1]), dim3(kThreads), 0, st_, es.n, es.omega, es.err, es.kernel_kind, es.delta, red, es.rk.p); \
     break
     switch (es.d) {
       G2OHIP_CHI(1);

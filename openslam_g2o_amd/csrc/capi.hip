@@ -172,6 +172,14 @@ int g2ohip_set_robust_kernel(g2ohip_solver* s, int set, int kind, double delta) 
   });
 }
 
+int g2ohip_set_robust_kernel_per_edge(g2ohip_solver* s, int set, const int32_t* kind, const double* delta) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_robust_kernel_per_edge(set, kind, delta);
+    return G2OHIP_OK;
+  });
+}
+
 int g2ohip_build_system(g2ohip_solver* s) {
   REQUIRE_HANDLE(s);
   return guarded([&] {
@@ -517,6 +525,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "overlap_level_halves")) s->impl->chol_opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "split_sweeps")) s->impl->chol_opt.split_sweeps = (int)value;
   else if (!std::strcmp(name, "merge_diag_panel")) s->impl->chol_opt.merge_diag_panel = (int)value;
+  else if (!std::strcmp(name, "big_merge_tiles")) s->impl->chol_opt.big_merge_tiles = (int)value;
   else if (!std::strcmp(name, "merge_backward_levels")) s->impl->chol_opt.merge_backward_levels = (int)value;
   else if (!std::strcmp(name, "fuse_big_forward")) s->impl->chol_opt.fuse_big_forward = (int)value;
   else if (!std::strcmp(name, "hoist_big_assembly")) s->impl->chol_opt.hoist_big_assembly = (int)value;
@@ -1005,6 +1014,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "overlap_level_halves")) ls->opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "split_sweeps")) ls->opt.split_sweeps = (int)value;
   else if (!std::strcmp(name, "merge_diag_panel")) ls->opt.merge_diag_panel = (int)value;
+  else if (!std::strcmp(name, "big_merge_tiles")) ls->opt.big_merge_tiles = (int)value;
   else if (!std::strcmp(name, "merge_backward_levels")) ls->opt.merge_backward_levels = (int)value;
   else if (!std::strcmp(name, "fuse_big_forward")) ls->opt.fuse_big_forward = (int)value;
   else if (!std::strcmp(name, "hoist_big_assembly")) ls->opt.hoist_big_assembly = (int)value;

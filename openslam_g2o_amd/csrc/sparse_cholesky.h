@@ -56,6 +56,8 @@ struct CholOptions {
   int inplace_chains = 1;                // chains of scratch-slab fronts with identical rows (panels of one large supernode) are factorised in place
   int hoist_big_assembly = 1;            // zero fill + original blocks of ALL scratch-slab fronts of a phase in two launches up front (their slab regions are never reused)
   int fuse_big_forward = 1;              // forward step of scratch-slab fronts inside the pivot-block and panel kernels (levels on the fused panel path)
+  int big_merge_tiles = 256;             // scratch-slab levels of at most this many 64 x 64 tiles run the fused panel kernel (panel solve + update
+                                         // [+ pivot blocks, merge_diag_panel] in one launch); wider levels the separate whole-GPU passes
   int merge_diag_panel = 1;              // pivot blocks and panel tiles of a level of scratch-slab fronts in ONE launch (tiles wait for their front's flag)
   int merge_backward_levels = 1;         // backward step of consecutive levels of scratch-slab fronts in ONE launch (workgroups wait for their parent front's flag)
   int split_sweeps = 1;                  // forward / backward step of scratch-slab fronts by several workgroups per front (256 boundary rows each)

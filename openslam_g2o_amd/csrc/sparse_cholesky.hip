@@ -3876,6 +3876,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   const int* ld;   // leading dimension per launch slot
   bool fuse_panel;   // big_panel_kernel instead of big_trsm_kernel + big_front_update_kernel
   bool mfma_diag;    // big_diag_mfma_kernel instead of big_diag_kernel
+  int merge_tiles = 256;   // the fused panel kernel on levels of at most this many tiles (CholOptions::big_merge_tiles)
 };
 
 __global__ void __launch_bounds__(256) fill_zero_kernel(double* __restrict__ p, size_t n) {
@@ -3948,7 +3949,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
         hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
                            d_scratch_off);
     G2OHIP_LAUNCH_CHECK("big_extend_add_kernel");
-    if (big.flag && big.mfma_diag && big.fuse_panel && bt_count > 0 && bt_count <= 256) {
+    if (big.flag && big.mfma_diag && big.fuse_panel && bt_count > 0 && bt_count <= big.merge_tiles) {
       const size_t shp = (size_t)(3 * 64 * 65 + 64 + 128) * sizeof(double);   // (the pivot-block role needs 4 800 doubles of it)
       if (big.fwd)
         hipLaunchKernelGGL((big_level_kernel<BS, true>), dim3(glb_count + bt_count), dim3(256), shp, st, P, glb_begin, glb_count, big_tiles, d_scratch,
@@ -3967,7 +3968,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     else
       hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_diag_kernel");
-    if (big.fuse_panel && bt_count <= 256) {   // panel solve + update in one launch -- while the level is a latency chain (at most one
+    if (big.fuse_panel && bt_count <= big.merge_tiles) {   // panel solve + update in one launch -- while the level is a latency chain (at most one
                                                // workgroup per CU); a level that fills the GPU pays for the rows solved more than once
       if (bt_count > 0) {
         const size_t shp = (size_t)(3 * 64 * 65 + 64 + 128) * sizeof(double);
@@ -4068,7 +4069,7 @@ bool SparseCholesky::big_forward_carried(const LevelLaunch& LL) const {
   // (the conditions of the pivot-block kernel on the matrix cores, of the fused panel kernel and of single-front tasks with
   // at most 64 pivot columns)
   return opt.fuse_big_forward && opt.mfma_diag && opt.fuse_panel && opt.big_front_passes && LL.big_ok && LL.glb_count > 0 &&
-         LL.glb_max_m >= opt.big_front_min_dim && LL.bt_count <= 256 && LL.sw_count > 0;
+         LL.glb_max_m >= opt.big_front_min_dim && LL.bt_count <= opt.big_merge_tiles && LL.sw_count > 0;
 }
 
 void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep, int parts) {
@@ -4081,7 +4082,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
                       LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL),
-                      (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0};
+                      (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, opt.big_merge_tiles};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \

@@ -154,7 +154,10 @@ int main(int argc, char** argv) {
     std::ofstream(argv[5]) << js.str() << std::endl;
     return 0;
   }
-  if (argc > 6 && std::string(argv[6]) == "se2") {
+  // "se2huber:<delta>": the same graph with a Huber kernel on its LOOP CLOSURES only (edges between non-consecutive vertices) -- one
+  // homogeneous group of EdgeSE2 whose edges differ in their robust kernel
+  const bool se2Huber = argc > 6 && std::string(argv[6]).compare(0, 9, "se2huber:") == 0;
+  if ((argc > 6 && std::string(argv[6]) == "se2") || se2Huber) {
     // ---- planar pose graph (config 1: VertexSE2 / EdgeSE2, BlockSolver_3_2 shape, no marginalised vertex)
     std::ifstream in(argv[1]);
     int nv, ne;
@@ -183,6 +186,11 @@ int main(int argc, char** argv) {
       e->setVertex(1, verts[j]);
       e->setMeasurement(SE2(x, y, th));
       e->setInformation(info);
+      if (se2Huber && std::abs(i - j) != 1) {
+        RobustKernelHuber* rk = new RobustKernelHuber();
+        rk->setDelta(std::atof(argv[6] + 9));
+        e->setRobustKernel(rk);
+      }
       optimizer.addEdge(e);
     }
     if (!in) {

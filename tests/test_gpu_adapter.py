@@ -127,6 +127,34 @@ def test_two_camera_parameters_and_a_robust_kernel_on_half_the_edges_stay_on_the
     assert np.allclose(runs["fast"]["chi2"], runs["generic"]["chi2"], rtol=1e-9, atol=0)
 
 
+def test_pose_graph_with_kernels_on_its_loop_closures_binds_as_one_group(host, tmp_path):
+    """manhattan3500 with a Huber kernel on the loop closures only, through the vtables: ONE group of EdgeSE2 whose edges differ
+    in their robust kernel -- bound to the pose-graph front end with one kernel per edge (g2ohip_set_robust_kernel_per_edge); the
+    fast path and the generic path (the same per-edge kernels over uploaded Jacobians) walk one trajectory, which differs from
+    the plain graph's."""
+    from tests.helpers import manhattan_golden
+    g = manhattan_golden()
+    path = str(tmp_path / "m.txt")
+    with open(path, "w") as f:
+        nv, ne = len(g["estimates"]), len(g["vi"])
+        f.write("%d %d\n" % (nv, ne))
+        for i in range(nv):
+            f.write("%d %s\n" % (1 if g["hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in g["estimates"][i])))
+        for k in range(ne):
+            f.write("%d %d %s %s\n" % (g["vi"][k], g["vj"][k], " ".join("%.17g" % v for v in g["meas"][k]),
+                                       " ".join("%.17g" % v for v in np.asarray(g["omega"][k]).reshape(-1))))
+    runs = []
+    for env in ({}, {"G2OHIP_ADAPTER_FASTPATH": "0"}):
+        out, err = _run(host, path, "lm_fix3_2_hip", 6, str(tmp_path / "o.json"), env, mode="se2huber:1.5")
+        assert ("device fast path for %d EdgeSE2" % len(g["vi"]) in err) == (not env), err[-400:]
+        assert out["iterations"] == 6 and all(b <= a * (1 + 1e-12) for a, b in zip([out["chi2_initial"]] + out["chi2"], out["chi2"]))
+        runs.append(out)
+    assert np.allclose(runs[0]["chi2"], runs[1]["chi2"], rtol=1e-9, atol=0)
+    assert np.abs(np.array(runs[0]["poses"]) - np.array(runs[1]["poses"])).max() < 1e-7
+    plain, _ = _run(host, path, "lm_fix3_2_hip", 6, str(tmp_path / "p.json"), {}, mode="se2")
+    assert runs[0]["chi2_initial"] < plain["chi2_initial"] * (1 - 1e-3)      # (the kernels bite: robustified chi2 of the same graph)
+
+
 def test_gauss_newton_and_dogleg_creators_construct(host, tmp_path):
     pr = ba_case(12, 100)
     prob = str(tmp_path / "p.txt")

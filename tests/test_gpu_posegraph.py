@@ -182,3 +182,51 @@ def test_growth_unbinds_the_device_front_end():
     assert relerr(s.b(), g["b0"]) < 1e-11
     assert s.solve()
     assert relerr(s.x(), g["x_gn0"]) < 1e-8
+
+
+def test_robust_kernels_on_the_loop_closures_only_stay_one_device_set():
+    """In g2o the robust kernel is a member of the EDGE (optimizable_graph.h:436-443): a pose graph with Huber on its loop
+    closures is still one homogeneous set of EdgeSE2.  g2ohip_set_robust_kernel_per_edge on the set bound to the pose-graph front
+    end, against the oracle with the two kinds of edges as two sets (b, H, chi2, the damped step and three LM-style iterations)."""
+    capi = _capi()
+    g = manhattan_golden()
+    loop = np.abs(g["vi"].astype(np.int64) - g["vj"]) != 1
+    kinds = np.where(loop, capi.KERNEL_HUBER, 0).astype(np.int32)
+    deltas = np.where(loop, 1.5, 0.0)
+    s = capi.HipBlockSolver(3, 2, 0)
+    k = s.addEdgeSet(3, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+    s.buildStructure(g["nP"], 0, False)
+    s.pgSetEdges(k, 1, g["vi"], g["vj"], g["meas"], g["omega"])
+    s.setRobustKernelPerEdge(k, kinds, deltas)
+    s.pgSetEstimates(g["estimates"], g["hidx"])
+    est = g["estimates"].copy()
+    for it in range(3):
+        s.pgLinearize(True)
+        s.buildSystem()
+        J0, J1, err = O.se2_edges(est, g["vi"], g["vj"], g["meas"])
+        o = O.OracleSolver(3, 2, g["nP"], 0, schur=False)
+        sets = []
+        for sel, huber in ((np.flatnonzero(~loop), 0.0), (np.flatnonzero(loop), 1.5)):
+            ko = o.add_edge_set(3, g["hidx"][g["vi"][sel]], g["hidx"][g["vj"][sel]])
+            o.set_dims(ko, 3, 3)
+            sets.append((ko, sel, huber))
+        o.build_structure()
+        for ko, sel, huber in sets:
+            o.set_edge_data(ko, J0[sel], J1[sel], g["omega"][sel], err[sel], huber)
+        o.build_system()
+        assert abs(s.chi2() - o.chi2()) <= 1e-12 * o.chi2()
+        assert relerr(s.b(), o.b()) < 1e-11
+        assert relerr(s.values(capi.HPP), o.values("Hpp")) < 1e-11
+        lam = 1e-3 * o.max_diagonal()
+        s.setLambda(lam, True)
+        o.set_lambda(lam, True)
+        assert s.solve() and o.solve()
+        assert relerr(s.x(), o.x()) < 1e-8
+        s.restoreDiagonal()
+        s.pgUpdate()
+        est = O.se2_oplus(est, g["hidx"], o.x())
+    # the kernels matter (chi2 differs from the plain graph's) and can be taken back
+    s.pgLinearize(False)
+    robust = s.chi2()
+    s.setRobustKernelPerEdge(k, None, None)
+    assert s.chi2() > robust * (1 + 1e-6)
