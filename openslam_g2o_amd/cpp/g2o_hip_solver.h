@@ -173,6 +173,8 @@ class BlockSolverHip : public BlockSolverBase {
     std::map<GroupKey, size_t> index;
     int baGroup = -1;
     std::map<ClassKey, int> classIndex;
+    ClassKey lastCk = ClassKey();
+    int lastClass = -1;
     _baClasses.clear();
     for (size_t k = 0; k < _optimizer->activeEdges().size(); ++k) {
       OptimizableGraph::Edge* e = _optimizer->activeEdges()[k];
@@ -202,16 +204,24 @@ class BlockSolverHip : public BlockSolverBase {
           _groups.back().key.delta = 0.0;
           _groups.back().fast = 1;
         }
-        typename std::map<ClassKey, int>::iterator ic = classIndex.find(ck);
-        if (ic == classIndex.end()) {
-          if (classIndex.size() >= 128) return buildStructureImpl(false, tryPG);
-          ic = classIndex.insert(std::make_pair(ck, (int)classIndex.size())).first;
-          const double row[5] = {ck.f, ck.cx, ck.cy, (double)ck.kernel, ck.delta};
-          _baClasses.insert(_baClasses.end(), row, row + 5);
+        int cid;
+        if (lastClass >= 0 && !(ck < lastCk) && !(lastCk < ck)) {   // (runs of edges of one class: no map lookup)
+          cid = lastClass;
+        } else {
+          typename std::map<ClassKey, int>::iterator ic = classIndex.find(ck);
+          if (ic == classIndex.end()) {
+            if (classIndex.size() >= 128) return buildStructureImpl(false, tryPG);
+            ic = classIndex.insert(std::make_pair(ck, (int)classIndex.size())).first;
+            const double row[5] = {ck.f, ck.cx, ck.cy, (double)ck.kernel, ck.delta};
+            _baClasses.insert(_baClasses.end(), row, row + 5);
+          }
+          cid = ic->second;
+          lastCk = ck;
+          lastClass = cid;
         }
         Group& g = _groups[baGroup];
         g.edges.push_back(e);
-        g.cls.push_back(ic->second);
+        g.cls.push_back(cid);
         g.v0.push_back(v0->hessianIndex());
         g.v1.push_back(v1->hessianIndex());
         continue;
@@ -472,6 +482,32 @@ class BlockSolverHip : public BlockSolverBase {
     }
   }
 
+  // vertex -> position in an estimate table, in order of first appearance: free vertices are keyed by their hessianIndex (an
+  // array lookup), only the fixed ones -- they have none -- go through a map (5 M std::map lookups cost a second at the metric size)
+  struct SlotTable {
+    std::vector<int> byHidx;
+    std::map<const HyperGraph::Vertex*, int> fixed;
+    int count;
+    explicit SlotTable(size_t n) : byHidx(n, -1), count(0) {}
+    int slot(const OptimizableGraph::Vertex* v, bool& isNew) {
+      const int hi = v->hessianIndex();
+      isNew = false;
+      if (hi >= 0 && (size_t)hi < byHidx.size()) {
+        if (byHidx[hi] < 0) {
+          byHidx[hi] = count++;
+          isNew = true;
+        }
+        return byHidx[hi];
+      }
+      std::map<const HyperGraph::Vertex*, int>::iterator it = fixed.find(v);
+      if (it == fixed.end()) {
+        it = fixed.insert(std::make_pair((const HyperGraph::Vertex*)v, count++)).first;
+        isNew = true;
+      }
+      return it->second;
+    }
+  };
+
   static double lap(double& t) {
     const double now = get_monotonic_time(), d = now - t;
     t = now;
@@ -515,7 +551,7 @@ class BlockSolverHip : public BlockSolverBase {
     // estimate tables over every vertex the group touches (fixed ones included), in order of first appearance
     _cams.clear();
     _points.clear();
-    std::map<const HyperGraph::Vertex*, int> camIndex, pointIndex;
+    SlotTable camIndex((size_t)_nP + _nL), pointIndex((size_t)_nP + _nL);
     const size_t n = g.edges.size();
     std::vector<int32_t> camOf(n), pointOf(n);
     std::vector<double> meas(2 * n), info(4 * n);
@@ -524,18 +560,11 @@ class BlockSolverHip : public BlockSolverBase {
       EdgeProjectXYZ2UV* e = static_cast<EdgeProjectXYZ2UV*>(g.edges[k]);
       VertexSBAPointXYZ* vp = static_cast<VertexSBAPointXYZ*>(e->vertex(0));
       VertexSE3Expmap* vc = static_cast<VertexSE3Expmap*>(e->vertex(1));
-      std::map<const HyperGraph::Vertex*, int>::iterator ic = camIndex.find(vc);
-      if (ic == camIndex.end()) {
-        ic = camIndex.insert(std::make_pair((const HyperGraph::Vertex*)vc, (int)_cams.size())).first;
-        _cams.push_back(vc);
-      }
-      std::map<const HyperGraph::Vertex*, int>::iterator ip = pointIndex.find(vp);
-      if (ip == pointIndex.end()) {
-        ip = pointIndex.insert(std::make_pair((const HyperGraph::Vertex*)vp, (int)_points.size())).first;
-        _points.push_back(vp);
-      }
-      camOf[k] = ic->second;
-      pointOf[k] = ip->second;
+      bool isNew;
+      camOf[k] = camIndex.slot(vc, isNew);
+      if (isNew) _cams.push_back(vc);
+      pointOf[k] = pointIndex.slot(vp, isNew);
+      if (isNew) _points.push_back(vp);
       meas[2 * k] = e->measurement()[0];
       meas[2 * k + 1] = e->measurement()[1];
       const double* om = e->informationData();            // 2 x 2, column-major
@@ -587,7 +616,7 @@ class BlockSolverHip : public BlockSolverBase {
       if (typeid(*g.edges[k]->vertex(0)) != typeid(VertexSE2) || typeid(*g.edges[k]->vertex(1)) != typeid(VertexSE2)) return false;
     }
     _pgVerts.clear();
-    std::map<const HyperGraph::Vertex*, int> index;
+    SlotTable index((size_t)_nP + _nL);
     const size_t n = g.edges.size();
     std::vector<int32_t> vi(n), vj(n);
     std::vector<double> meas(3 * n), info(9 * n);
@@ -595,12 +624,9 @@ class BlockSolverHip : public BlockSolverBase {
       EdgeSE2* e = static_cast<EdgeSE2*>(g.edges[k]);
       for (int side = 0; side < 2; ++side) {
         VertexSE2* v = static_cast<VertexSE2*>(e->vertex(side));
-        std::map<const HyperGraph::Vertex*, int>::iterator it = index.find(v);
-        if (it == index.end()) {
-          it = index.insert(std::make_pair((const HyperGraph::Vertex*)v, (int)_pgVerts.size())).first;
-          _pgVerts.push_back(v);
-        }
-        (side ? vj : vi)[k] = it->second;
+        bool isNew;
+        (side ? vj : vi)[k] = index.slot(v, isNew);
+        if (isNew) _pgVerts.push_back(v);
       }
       meas[3 * k] = e->measurement().translation()[0];
       meas[3 * k + 1] = e->measurement().translation()[1];
@@ -651,7 +677,7 @@ class BlockSolverHip : public BlockSolverBase {
       if (typeid(*g.edges[k]->vertex(0)) != typeid(VertexSE3) || typeid(*g.edges[k]->vertex(1)) != typeid(VertexSE3)) return false;
     }
     _pg3Verts.clear();
-    std::map<const HyperGraph::Vertex*, int> index;
+    SlotTable index((size_t)_nP + _nL);
     const size_t n = g.edges.size();
     std::vector<int32_t> vi(n), vj(n);
     std::vector<double> meas(12 * n), info(36 * n);
@@ -659,12 +685,9 @@ class BlockSolverHip : public BlockSolverBase {
       EdgeSE3* e = static_cast<EdgeSE3*>(g.edges[k]);
       for (int side = 0; side < 2; ++side) {
         VertexSE3* v = static_cast<VertexSE3*>(e->vertex(side));
-        std::map<const HyperGraph::Vertex*, int>::iterator it = index.find(v);
-        if (it == index.end()) {
-          it = index.insert(std::make_pair((const HyperGraph::Vertex*)v, (int)_pg3Verts.size())).first;
-          _pg3Verts.push_back(v);
-        }
-        (side ? vj : vi)[k] = it->second;
+        bool isNew;
+        (side ? vj : vi)[k] = index.slot(v, isNew);
+        if (isNew) _pg3Verts.push_back(v);
       }
       isometryTo12(e->measurement(), &meas[12 * k]);
       const double* om = e->informationData();            // 6 x 6, column-major
