@@ -136,6 +136,8 @@ class BlockSolver {
   size_t schur_tile_bytes = 39 * 1024;     // LDS budget of one Schur tile
   int comm_emulate = 0;                    // TIMING ONLY: solve_sharded of one rank of an N-rank job run alone, the all-reduces skipped
                                            // (results are wrong; bench.py --emulate r/N: the per-rank time an N-GPU run is bounded by)
+  bool rhs_prefill = true;                 // solve(): schur_rhs_kernel also writes the permuted right-hand side and clears the factorisation's status word
+  bool rhs_prefilled_ = false;             // ... and has done so for the next solve_reduced_device
   bool ba_fused = true;                    // evaluate BA errors/Jacobians inside the assembly kernels (no J arrays)
   // hipGraph replay of the launch-bound kernel sequences (one launch per tree level: factorisation with the
   // fused forward sweep, backward sweep): ~30 launches per iteration, which is what limits a rank once the
@@ -181,7 +183,7 @@ class BlockSolver {
   // host patterns
   std::vector<int> pp_colptr, pp_row, pp_diag, pl_colptr, pl_row, hs_colptr, hs_row;
   // device matrices
-  enum Seg { kSegFactor = 0, kSegBackward, kSegLocal, kSegShared, kSegSharedBack, kSegFactorBand, kSegFactorRest, kSegShardedAll, kNumSeg };
+  enum Seg { kSegFactor = 0, kSegBackward, kSegLocal, kSegShared, kSegSharedBack, kSegFactorBand, kSegFactorRest, kSegShardedAll, kSegFactorPre, kNumSeg };
   bool in_outer_seg_ = false;   // an enclosing segment is being captured / run: inner run_seg calls are transparent
   struct GraphSeg {
     hipGraph_t g = nullptr;

@@ -835,8 +835,12 @@ __global__ void __launch_bounds__(kThreads) schur_reduce_kernel(int nDst, const 
 template <int PD>
 __global__ void __launch_bounds__(kThreads) schur_rhs_kernel(int nP, const int* __restrict__ pose_diag, const int* __restrict__ rd_ptr,
                                                            const int* __restrict__ rd_slot, const double* __restrict__ Pr,
-                                                           const double* __restrict__ b, double* __restrict__ bschur) {
+                                                           const double* __restrict__ b, double* __restrict__ bschur,
+                                                           const int* __restrict__ iperm, double* __restrict__ xp, int* __restrict__ status) {
+  // iperm / xp: the right-hand side also goes out in elimination order (what SparseCholesky::solve_begin would produce), status:
+  // the factorisation's status word is cleared here -- two launches less in front of the factorisation
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (status && t == 0) *status = 0;
   if (t >= nP * PD) return;
   const int pose = t / PD, e = t - pose * PD;
   const int d = pose_diag[pose];
@@ -853,6 +857,7 @@ __global__ void __launch_bounds__(kThreads) schur_rhs_kernel(int nP, const int* 
       if (k + j < k1) r -= pv[j];
   }
   bschur[t] = r;
+  if (xp) xp[(size_t)iperm[pose] * PD + e] = r;
 }
 
 // K13: x_l = Dinv (b_l - Hpl' x_p)   (block_solver.hpp:459-483)
@@ -3457,10 +3462,16 @@ void BlockSolver::launch_schur_reduce(bool matrix) {
   chol_->set_virtual_split(split);
   if (!matrix) {
     hschur_valid_ = false;
+    // one GPU, direct solver: the kernel writes the permuted right-hand side and clears the status word for the factorisation
+    // that follows (solve_reduced_device then starts with the band chains: no permute_in launch, no memset)
+    const bool pre = rhs_prefill && chol_opt.world <= 1 && linear_solver == 0;
+    size_t xpn = 0;
+    rhs_prefilled_ = pre;
 #define G2OHIP_RHS(P_)                                                                                                        \
   case P_:                                                                                                                    \
     hipLaunchKernelGGL((schur_rhs_kernel<P_>), dim3(grid_for((size_t)nP_ * P_)), dim3(kThreads), 0, st_, nP_, d_pose_diag.p, d_rd_ptr.p, \
-                       d_rd_slot.p, d_Pr.p, d_b.p, d_bschur.p);                                                                \
+                       d_rd_slot.p, d_Pr.p, d_b.p, d_bschur.p, pre ? chol_->inverse_permutation_device() : (const int*)nullptr,        \
+                       pre ? chol_->permuted_solution(&xpn) : (double*)nullptr, pre ? chol_->status_word_device() : (int*)nullptr);      \
     break
     switch (p_) {
       G2OHIP_RHS(3);
@@ -3573,6 +3584,7 @@ void BlockSolver::solve_reduced_device() {
         prof.begin(KernelProf::kCholFactor, st_, /*cont=*/true);
       }
     };
+    rhs_prefilled_ = false;   // (every slot timed: the plain sequence)
     chol_->solve_begin(bred, st_);
     chol_->factor_phase(Hred, 0, st_, true);
     chol_->factor_phase(Hred, 1, st_, true);
@@ -3580,8 +3592,11 @@ void BlockSolver::solve_reduced_device() {
     prof.end(KernelProf::kCholFactor, st_);
   } else {
     prof.begin(KernelProf::kCholFactor, st_);
-    run_seg(kSegFactor, [&] {
-      chol_->solve_begin(bred, st_);
+    const bool pre = rhs_prefilled_ && schur_ && virt_now_;   // (launch_schur_reduce has written the permuted right-hand side and cleared the status word)
+    rhs_prefilled_ = false;
+    run_seg(pre ? kSegFactorPre : kSegFactor, [&] {
+      if (!pre) chol_->solve_begin(bred, st_);
+      chol_->skip_status_clear = pre;
       chol_->factor_phase(Hred, 0, st_, true);
       chol_->factor_phase(Hred, 1, st_, true);
     });

@@ -211,6 +211,11 @@ class SparseCholesky {
   // the same all-reduce: BlockSolver's boundary blocks); pack_exchange clears and fills the head only
   double* reserve_exchange_tail(size_t n);
   double* permuted_solution(size_t* count) { *count = (size_t)sym_.nb * bs_; return d_xp.p; }
+  // A caller that produces the right-hand side itself may write it permuted (xp[iperm[old] * bs + r]) and clear the status word
+  // in the same kernel: solve_begin and the memset of factor_phase(phase 0) are then two launches less (skip_status_clear)
+  const int* inverse_permutation_device() const { return d_iperm.p; }
+  int* status_word_device() { return d_status.p; }
+  bool skip_status_clear = false;   // consumed by the next factor_phase(phase 0)
   int* status_flag() { return d_status.p; }
   // Synchronises st and returns true when the last factorisation met a pivot <= 0.
   // The matrix to factorise given as  A[q] = base[base_idx[q]] (+ lam[0] on the diagonal of diagonal blocks)
@@ -249,7 +254,7 @@ class SparseCholesky {
   CholStats stats_;
   // device plan
   DevBuf<int> d_f_ns, d_f_nb, d_f_c0, d_rows_off, d_rows, d_rel_off, d_rel, d_asm_off, d_asm_q, d_asm_pos,
-      d_child_off, d_children, d_level_fronts, d_perm, d_status;
+      d_child_off, d_children, d_level_fronts, d_perm, d_iperm, d_status;
   DevBuf<long long> d_L_off, d_U_off, d_w_off, d_scratch_off;
   DevBuf<int> d_scratch_ld;   // leading dimension of a scratch-slab front (that of the chain's first front)
   // sparse inverse: slab of the inverse fronts, per-front offsets / parents, per front level the launch lists

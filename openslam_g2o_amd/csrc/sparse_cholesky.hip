@@ -1571,6 +1571,12 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     n_slots_ = (int)slots.size();
   }
   d_perm.upload(S.perm, st);
+  {
+    std::vector<int> ip(S.perm.size(), 0);
+    for (size_t k = 0; k < S.perm.size(); ++k) ip[S.perm[k]] = (int)k;
+    if (ip.empty()) ip.push_back(0);
+    d_iperm.upload(ip, st);
+  }
   d_L_off.upload(S.L_off, st);
   d_U_off.upload(S.U_off, st);
   d_w_off.upload(S.w_off, st);
@@ -4173,7 +4179,10 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     (void)hipGetLastError();
     attr_done = true;
   }
-  if (phase == 0 && (parts & 1)) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
+  if (phase == 0 && (parts & 1)) {
+    if (!skip_status_clear) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
+    skip_status_clear = false;
+  }
 #ifdef G2OHIP_CHOL_STAMPS
   if (phase == 0) {
     if (!d_dbg.p) d_dbg.alloc(64 * 64 + 6 * (size_t)n_slots_ + 6);

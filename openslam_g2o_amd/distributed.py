@@ -287,8 +287,13 @@ class ShardedBlockSolver:
                 self._torch_device = torch_device
             else:
                 self._torch_device = None
-            self.local.baSetEdges(self.set_id, prob["cam_idx"][mine], loc[prob["pt_idx"][mine]].astype(np.int32),
-                                  prob["meas"][mine], None, prob["f"], prob["cx"], prob["cy"])
+            if "edge_class" in prob:    # edge classes (several CameraParameters / per-edge robust kernels, g2ohip_ba_set_edges_classes):
+                # every rank holds the whole class table, its edges carry their class
+                self.local.baSetEdgesClasses(self.set_id, prob["cam_idx"][mine], loc[prob["pt_idx"][mine]].astype(np.int32),
+                                             prob["meas"][mine], prob["classes"], prob["edge_class"][mine])
+            else:
+                self.local.baSetEdges(self.set_id, prob["cam_idx"][mine], loc[prob["pt_idx"][mine]].astype(np.int32),
+                                      prob["meas"][mine], None, prob["f"], prob["cx"], prob["cy"])
             self.local.baSetEstimates(prob["cams"], prob["cam_hidx"], prob["pts"][my], np.arange(len(my), dtype=np.int32))
             self.local.baLinearize(True)
             return dict(E_local=int(mine.sum()), L_local=int(len(my)), lm0=int(lm0), lm1=int(lm1))

@@ -311,6 +311,49 @@ def test_two_collectives_per_sharded_solve_equal_three(tmp_path, world):
     assert runs[1][0]["chis"][-1] < runs[1][0]["chis"][0]
 
 
+def _lm_classes_worker(rank, world, port, P, L, n_it, out_dir):
+    import torch
+    import torch.distributed as dist
+    from openslam_g2o_amd import distributed as D, lm
+    from tests.test_gpu_edge_classes import CLASSES, _class_problem
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        pr = _class_problem(P, L, 5)
+        pr["classes"] = CLASSES
+        s = D.ShardedBlockSolver(6, 3, rank=rank, world=world, comm=D.HostStagedComm(world), mode="subtree")
+        s.setup_ba(pr, torch_device=torch.device("cuda", 0), fused=True)
+        assert s.attach_library_comm("host")
+        done, chis, lams, trials = lm.optimize(D.ShardedBAGraph(s), s, n_it, "lm")
+        cams, pts = s.local.baGetEstimates()
+        np.savez(os.path.join(out_dir, "c%d.npz" % rank), done=done, chis=chis, lams=lams, trials=trials, pts=pts, lm_index=s.lm_index)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_lm_with_edge_classes_matches_the_single_rank_run(tmp_path):
+    """Two CameraParameters and three robust kernels in one edge set (edge classes), sharded over two ranks: every rank holds the class
+    table, its observations carry their class; the LM trajectory equals the single-rank device run (itself held to the oracle by
+    tests/test_gpu_edge_classes.py)."""
+    import torch.multiprocessing as mp
+    from openslam_g2o_amd import capi, lm
+    from tests.test_gpu_edge_classes import _class_problem, _device
+    world, P, L, n_it = 2, 400, 3600, 5
+    mp.spawn(_lm_classes_worker, args=(world, _free_port(), P, L, n_it, str(tmp_path)), nprocs=world, join=True)
+    pr = _class_problem(P, L, 5)
+    s1, g1, _ = _device(pr)
+    done1, chis1, lams1, trials1 = lm.optimize(g1, s1, n_it, "lm")
+    _, pts1 = s1.baGetEstimates()
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "c%d.npz" % r))
+        assert int(z["done"]) == done1 and list(z["trials"]) == trials1
+        assert np.allclose(z["chis"], chis1, rtol=1e-6, atol=0) and np.allclose(z["lams"], lams1, rtol=1e-6, atol=0)
+        assert relerr(z["pts"], pts1[z["lm_index"]]) < 1e-6
+    assert chis1[-1] < chis1[0]
+
+
 def test_library_comm_over_rccl_single_rank():
     """g2ohip_comm_init_rccl / ncclAllReduce inside the library on the one GPU a test box has (world 1): the sharded solve
     through RCCL equals the plain solve."""
