@@ -56,6 +56,10 @@ struct CholOptions {
   int inplace_chains = 1;                // chains of scratch-slab fronts with identical rows (panels of one large supernode) are factorised in place
   int hoist_big_assembly = 1;            // zero fill + original blocks of ALL scratch-slab fronts of a phase in two launches up front (their slab regions are never reused)
   int fuse_big_forward = 1;              // forward step of scratch-slab fronts inside the pivot-block and panel kernels (levels on the fused panel path)
+  int big_group = 8;                     // panels of a long in-place chain (one large supernode) are grouped: inside a group a panel's rank-npiv update
+                                         // touches only the columns of the group's remaining panels, the rest of the trailing matrix gets ONE rank-(group)
+                                         // update behind the group's last panel -- a quarter of the passes over a frontal matrix that lives in HBM (1: off)
+  int big_group_min_rows = 1536;         // ... for chains whose first front has at least this many rows (smaller ones are latency chains, not traffic)
   int big_merge_tiles = 256;             // scratch-slab levels of at most this many 64 x 64 tiles run the fused panel kernel (panel solve + update
                                          // [+ pivot blocks, merge_diag_panel] in one launch); wider levels the separate whole-GPU passes
   int merge_diag_panel = 1;              // pivot blocks and panel tiles of a level of scratch-slab fronts in ONE launch (tiles wait for their front's flag)
@@ -296,6 +300,8 @@ class SparseCholesky {
     int sm_count = 0, sm_max_m = 0, sm_idx_ints = 0;     // leading part of the lds range: small fronts, one wave each
     bool wv = false;                                     // every front fits the register-resident wave kernel (wave_front.inc)
     int wv_pn = 0, wv_idx_ints = 0;                      // ... its panel region (doubles) and index tables (ints), max over the launch
+    bool grouped = false;                                // a front of the launch is the LAST panel of a group of an in-place chain (its tiles carry the group's columns: separate kernels)
+    bool group_in = false;                               // ... a panel INSIDE a group (its tiles stop at the group's end: the fused kernels clip)
     int bt_begin = 0, bt_count = 0;                      // 64 x 64 trailing-update tiles of the scratch-slab fronts (d_big_tiles)
     // scratch-slab fronts as whole-GPU passes (all ranges index d_big_tiles): assembly chunks, one extend-add pass
     // per child ordinal, row chunks of the panel solve; big_ok: every such front has at most 64 pivot columns
@@ -331,7 +337,8 @@ class SparseCholesky {
   hipStream_t side_[2] = {nullptr, nullptr};   // factor_phase: the two halves of a level / the forward step of its large fronts
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false, bool skip_glb = false);
-  bool big_forward_carried(const LevelLaunch& LL) const;   // the forward step of the level's scratch-slab fronts rides along in their factorisation
+  bool big_forward_carried(const LevelLaunch& LL) const;
+  int merge_tiles_of(const LevelLaunch& LL) const { return (LL.grouped || LL.group_in) ? -1 : opt.big_merge_tiles; }   // (grouped chains: the separate kernels)   // the forward step of the level's scratch-slab fronts rides along in their factorisation
   CholPlanDev plan_{};
 };
 

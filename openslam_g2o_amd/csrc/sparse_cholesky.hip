@@ -964,6 +964,32 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       }
     }
   }
+  // --- grouped in-place chains.  The panels of one large supernode (a chain continued in place) each made a pass over the
+  // whole trailing matrix: (m - k)^2 / 2 doubles read and written per 48 columns -- 460 GB for a 20 000-row front, which is
+  // what its 250 ms were.  Panels are grouped by big_group: a panel inside a group updates only the columns of the group's
+  // remaining panels (what their pivot blocks and panel rows need), the group's LAST panel updates everything behind the group
+  // with all the group's pivot columns at once (they are adjacent columns of the same frontal matrix).
+  std::vector<int> grp_prev(nf, 0), grp_rem(nf, 0);
+  if (opt.big_group > 1)
+    for (int f0 = 0; f0 < nf; ++f0) {
+      if (inpl_prev[f0] >= 0 || inpl_next[f0] < 0) continue;   // (chain heads only)
+      if (front_dim(f0) < opt.big_group_min_rows) continue;
+      std::vector<int> chain;
+      for (int f = f0; f >= 0; f = inpl_next[f]) chain.push_back(f);
+      for (size_t g0 = 0; g0 < chain.size(); g0 += (size_t)opt.big_group) {
+        const size_t g1 = std::min(chain.size(), g0 + (size_t)opt.big_group);
+        int total = 0;
+        for (size_t i = g0; i < g1; ++i) total += S.f_ns[chain[i]] * bs;
+        if (total >= (1 << 15)) continue;
+        int before = 0;
+        for (size_t i = g0; i < g1; ++i) {
+          const int f = chain[i], np_ = S.f_ns[f] * bs;
+          if (i + 1 == g1) grp_prev[f] = before;                 // the group's last panel: all of the group's columns
+          else grp_rem[f] = total - before - np_;                // inside the group: up to the group's end
+          before += np_;
+        }
+      }
+    }
   // --- trailing-update tiles of the scratch-slab fronts (big_front_update_kernel), per level launch
   {
     std::vector<int4> bt;
@@ -974,8 +1000,15 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
           const int nt64 = (S.f_nb[f] * bs + 63) / 64;
+          // w: bit 0 = update in place (the parent continues in this frontal matrix); grouped chains (grp_prev / grp_rem, below):
+          // bits 1..15 = pivot columns of the group's earlier panels that ride along (the group's last panel), bits 16..31 = the
+          // update stops at this column of the trailing matrix (a panel inside a group: the columns of the group's remaining panels)
+          const int w = (inpl_next[f] >= 0 ? 1 : 0) | (grp_prev[f] << 1) | (grp_rem[f] << 16);
+          if (grp_prev[f] > 0) LL.grouped = true;
+          if (grp_rem[f] > 0) LL.group_in = true;
+          const int ntc = grp_rem[f] > 0 ? std::min(nt64, (grp_rem[f] + 63) / 64) : nt64;
           for (int ti = 0; ti < nt64; ++ti)
-            for (int tj = 0; tj <= ti; ++tj) bt.push_back(make_int4(q, ti, tj, inpl_next[f] >= 0 ? 1 : 0));   // w: update in place
+            for (int tj = 0; tj <= std::min(ti, ntc - 1); ++tj) bt.push_back(make_int4(q, ti, tj, w));
         }
         LL.bt_count = (int)bt.size() - LL.bt_begin;
         // zero-fill chunks of the fronts that start a region at this level
@@ -2746,17 +2779,20 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
                                                               double* __restrict__ scratch,
                                                               const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
   constexpr int BB = BS * BS;
-  const int4 td = tiles[blockIdx.x];   // x: launch slot of the front, y / z: tile row / column, w: the parent continues in place
+  const int4 td = tiles[blockIdx.x];   // x: launch slot of the front, y / z: tile row / column, w: bit 0 the parent continues in place,
+                                       // bits 1..15 pivot columns of the group's earlier panels, bits 16..31 column limit (grouped chains)
   const int f = P.slots[td.x].x;
   const FrontRec rec = load_front_rec(P.rec + f);
   const int ns = rec.ns, nbd = rec.nb;
   const int npiv = ns * BS, mt = nbd * BS;
+  const int kprev = (td.w >> 1) & 0x7fff, climit = ((unsigned)td.w >> 16) ? (int)((unsigned)td.w >> 16) : mt;
+  const bool inplace = td.w & 1;
   const int m = scratch_ld[td.x];   // leading dimension of the front in the slab
   double* F = scratch + scratch_off[td.x];
   double* U = P.U + rec.U_off;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
   const int r0 = td.y * 64 + (wave & 1) * 32, c0 = td.z * 64 + (wave >> 1) * 32;
-  if (r0 >= mt || c0 >= mt || c0 > r0 + 31) return;   // outside, or entirely above the diagonal
+  if (r0 >= mt || c0 >= climit || c0 > r0 + 31) return;   // outside, or entirely above the diagonal
   mfma_d4 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -2771,7 +2807,9 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
   }
   // KS k-steps of operands are requested together (a step per round trip would make the kernel a chain of L2 latencies)
   constexpr int KS = 6;
-  for (int k00 = 0; k00 < npiv; k00 += 4 * KS) {
+  // (kprev > 0: the pivot columns of the group's earlier panels sit right in front of this front's in the same frontal matrix --
+  // columns -kprev .. -1 relative to it -- and their rows are these rows: one rank-(kprev + npiv) update)
+  for (int k00 = -kprev; k00 < npiv; k00 += 4 * KS) {
     double rv[KS][2], cv[KS][2];
 #pragma unroll
     for (int s_ = 0; s_ < KS; ++s_) {
@@ -2780,8 +2818,8 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
       const double keep = (k0 + lk < npiv) ? 1.0 : 0.0;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        rv[s_][q] = Lr[q][(size_t)m * k] * keep;
-        cv[s_][q] = Lc[q][(size_t)m * k];
+        rv[s_][q] = Lr[q][(long long)m * k] * keep;
+        cv[s_][q] = Lc[q][(long long)m * k];
       }
     }
 #pragma unroll
@@ -2798,11 +2836,11 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int r = r0 + 16 * a + lr, c = c0 + 16 * b + lk + 4 * v;
-        if (r < mt && c < mt) {
+        if (r < mt && c < climit) {
           const int ib = r / BS, jb = c / BS;
           if (ib >= jb) {
             const double x = F[(size_t)(npiv + r) + (size_t)m * (npiv + c)] - acc[a][b][v];
-            if (td.w) F[(size_t)(npiv + r) + (size_t)m * (npiv + c)] = x;   // the parent is factorised here, in place
+            if (inplace) F[(size_t)(npiv + r) + (size_t)m * (npiv + c)] = x;   // the parent is factorised here, in place
             else U[(size_t)(ib * (ib + 1) / 2 + jb) * BB + (r - ib * BS) + BS * (c - jb * BS)] = x;
           }
         }
@@ -2890,12 +2928,16 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
                                                const double* __restrict__ bperm, double* __restrict__ yout, double* psm, const int* flag) {
   constexpr int BB = BS * BS, MAXB = 64 / BS, NX = MAXB * BS;
   const int tid = threadIdx.x;
-  // td: x: launch slot, y / z: tile row / column, w: the parent continues in place
+  // td: x: launch slot, y / z: tile row / column, w: bit 0 the parent continues in place (the panels of a GROUPED in-place chain never
+  // come here: the group's last panel reads the earlier panels' solved rows from the frontal matrix, where big_trsm_kernel leaves them
+  // and this kernel does not -- its tiles read the unsolved rows of the same launch; measured: it would buy 2 ms of 28)
   const int slot = td.x;
   const int f = P.slots[slot].x;
   const FrontRec rec = load_front_rec(P.rec + f);
   const int ns = rec.ns, nbd = rec.nb;
   const int n = ns * BS, mt = nbd * BS, m = n + mt;
+  const int climit = ((unsigned)td.w >> 16) ? (int)((unsigned)td.w >> 16) : mt;
+  const bool inplace = td.w & 1;
   const int ld = scratch_ld[slot];
   double* F = scratch + scratch_off[slot];
   double* Lg = P.L + rec.L_off;
@@ -2934,7 +2976,7 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int r = R0_ + 16 * a + lr_, c = C0_ + 16 * b + lk_ + 4 * v;
-          fpre[(a * 2 + b) * 4 + v] = (r < mt && c < mt && r / BS >= c / BS) ? F[(size_t)(n + r) + (size_t)ld * (n + c)] : 0.0;
+          fpre[(a * 2 + b) * 4 + v] = (r < mt && c < climit && r / BS >= c / BS) ? F[(size_t)(n + r) + (size_t)ld * (n + c)] : 0.0;
         }
   }
 #ifdef G2OHIP_CHOL_STAMPS
@@ -3046,7 +3088,7 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
     const int wave = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
     const int r0 = (wave & 1) * 32, c0 = (wave >> 1) * 32;           // inside the tile
     const int R0 = td.y * 64 + r0, C0 = td.z * 64 + c0;               // in the trailing part
-    if (R0 < mt && C0 < mt && C0 <= R0 + 31) {
+    if (R0 < mt && C0 < climit && C0 <= R0 + 31) {
       mfma_d4 acc[2][2];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -3073,11 +3115,11 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int r = R0 + 16 * a + lr, c = C0 + 16 * b + lk + 4 * v;
-            if (r < mt && c < mt) {
+            if (r < mt && c < climit) {
               const int ib = r / BS, jb = c / BS;
               if (ib >= jb) {
                 const double y = (kPreTile ? fpre[(a * 2 + b) * 4 + v] : F[(size_t)(n + r) + (size_t)ld * (n + c)]) - acc[a][b][v];
-                if (td.w) F[(size_t)(n + r) + (size_t)ld * (n + c)] = y;
+                if (inplace) F[(size_t)(n + r) + (size_t)ld * (n + c)] = y;
                 else U[(size_t)(ib * (ib + 1) / 2 + jb) * BB + (r - ib * BS) + BS * (c - jb * BS)] = y;
               }
             }
@@ -4075,7 +4117,7 @@ bool SparseCholesky::big_forward_carried(const LevelLaunch& LL) const {
   // (the conditions of the pivot-block kernel on the matrix cores, of the fused panel kernel and of single-front tasks with
   // at most 64 pivot columns)
   return opt.fuse_big_forward && opt.mfma_diag && opt.fuse_panel && opt.big_front_passes && LL.big_ok && LL.glb_count > 0 &&
-         LL.glb_max_m >= opt.big_front_min_dim && LL.bt_count <= opt.big_merge_tiles && LL.sw_count > 0;
+         LL.glb_max_m >= opt.big_front_min_dim && LL.bt_count <= merge_tiles_of(LL) && LL.sw_count > 0;
 }
 
 void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep, int parts) {
@@ -4088,7 +4130,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
                       LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL),
-                      (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, opt.big_merge_tiles};
+                      (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, merge_tiles_of(LL)};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \

@@ -206,6 +206,49 @@ def test_landmark_seen_by_hundreds_of_poses_is_split_over_tiles():
     assert relerr(s.x(), o.x()) < dx_tolerance(o)[0]
 
 
+@pytest.mark.parametrize("group", [2, 4, 7])
+def test_grouped_trailing_updates_of_an_in_place_chain_equal_the_panel_by_panel_ones(group):
+    """A large supernode is a chain of 48-column panels factorised in place in one frontal matrix.  Option big_group: a panel inside
+    a group updates only the columns of the group's remaining panels, the group's last panel applies the whole group to the rest of
+    the trailing matrix (rank-(group x 48) instead of `group` passes over it; csparse_helper.cpp:88-143 computes the same sums column
+    by column).  big_group_min_rows lowered so that the hub front of this graph (every third pose sees the hub points: a dense
+    supernode of 1 000+ rows) and the sphere's 882-row separators take the grouped path; x against the oracle / the golden vector and
+    against big_group = 1 (same matrix, another summation order of the trailing updates: rounding only)."""
+    from openslam_g2o_amd import capi, synthetic as S
+    from tests.helpers import sphere_golden
+    pr = S.make_ba_loops(640, 900, laps=4, hubs=2)
+    Jp, Jc, err = S.ba_linearize(pr)
+    pr.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(pr))
+    o = oracle_ba(pr, huber=1.0)
+    o.build_system()
+    o.set_lambda(3.0, True)
+    assert o.solve()
+    xs = {}
+    for g in (1, group):
+        s = hip_ba(pr, huber=1.0, options={"big_group": g, "big_group_min_rows": 64})
+        s.buildSystem()
+        s.setLambda(3.0, True)
+        assert s.solve()
+        xs[g] = s.x()
+        assert s.stats()["maxFrontDim"] > 1000
+        assert relerr(xs[g], o.x()) < dx_tolerance(o)[0]
+        x2 = s.x()
+        assert s.solve() and np.array_equal(s.x(), x2)            # bit-repeatable
+    assert relerr(xs[group], xs[1]) < 1e-9 and not np.array_equal(xs[group], xs[1])   # (the grouped path really ran)
+    # config 2 (no Schur complement): the sphere's separators
+    gs = sphere_golden()
+    J0, J1, e = O.se3_edges(gs["poses"], gs["vi"], gs["vj"], gs["Z"])
+    s = capi.HipBlockSolver(6, 3, 0)
+    s.setOption("big_group", group)
+    s.setOption("big_group_min_rows", 64)
+    k = s.addEdgeSet(6, gs["hidx"][gs["vi"]], gs["hidx"][gs["vj"]])
+    s.buildStructure(gs["nP"], 0, False)
+    s.setEdgeData(k, J0, J1, gs["omega"], e)
+    s.buildSystem()
+    assert s.solve()
+    assert relerr(s.x(), gs["x_gn0"]) < 1e-7
+
+
 def test_edge_cases_mixed_sets_fixed_and_unary():
     """Two edge sets (projection edges + 6-dof pose-pose edges), a unary prior set, fixed
     vertices on both sides, a landmark seen once, a pose without landmarks."""
