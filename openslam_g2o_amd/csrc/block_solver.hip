@@ -3355,6 +3355,8 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
   (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<GG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
       (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       G2OHIP_BA_TILE_ATTR(1);
       G2OHIP_BA_TILE_ATTR(2);
       G2OHIP_BA_TILE_ATTR(4);
@@ -3388,8 +3390,10 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
                          d_te_pack.p, d_te_lm.p, d_Pd.p, d_Pr.p, d_Hll.p, d_lam.p, (const int4*)nullptr, (const int4*)nullptr,        \
                          (const int*)nullptr, (double*)nullptr, d_tile_q2.p, 1, d_slot_lm.p, ba_.ctab.p);                                  \
   } while (0)
-    if (ba_.n_classes > 1) G2OHIP_BA_TILE_(8, true);   // (edge classes: one lane-group width is instantiated)
-    else if (G <= 1) G2OHIP_BA_TILE(1);
+    if (ba_.n_classes > 1) {   // edge classes: two lane-group widths are instantiated -- the ones on either side of the row split of the
+      if (G <= 1) G2OHIP_BA_TILE_(1, true);   // partial blocks (launch_schur_reduce and the factorisation read the layout G implies)
+      else G2OHIP_BA_TILE_(8, true);
+    } else if (G <= 1) G2OHIP_BA_TILE(1);
     else if (G <= 2) G2OHIP_BA_TILE(2);
     else if (G <= 4) G2OHIP_BA_TILE(4);
     else if (G <= 8) G2OHIP_BA_TILE(8);

@@ -139,10 +139,11 @@ def _device(pr, options=None):
     return s, lm.DeviceBAGraph(s), k
 
 
-@pytest.mark.parametrize("K", [1, 5, 23])
+@pytest.mark.parametrize("K", [1, 5, 23, 70])
 @pytest.mark.parametrize("fuse_landmarks", [1, 0])
 def test_two_cameras_and_three_kernels_in_one_set_match_the_oracle(K, fuse_landmarks):
-    pr = _class_problem(40, 90 if K > 5 else 400, K)
+    # (K = 70: lists longer than a wavefront -- the tiles leave the landmark side to the stand-alone kernel, also with classes)
+    pr = _class_problem(80, 60, K) if K >= 70 else _class_problem(40, 90 if K > 5 else 400, K)
     o = _oracle(pr)
     o.build_system()
     o.set_lambda(5.0, True)
