@@ -527,6 +527,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "merge_diag_panel")) s->impl->chol_opt.merge_diag_panel = (int)value;
   else if (!std::strcmp(name, "big_merge_tiles")) s->impl->chol_opt.big_merge_tiles = (int)value;
   else if (!std::strcmp(name, "big_group")) s->impl->chol_opt.big_group = (int)value;
+  else if (!std::strcmp(name, "group_forward_side")) s->impl->chol_opt.group_forward_side = (int)value;
   else if (!std::strcmp(name, "big_group_min_rows")) s->impl->chol_opt.big_group_min_rows = (int)value;
   else if (!std::strcmp(name, "merge_backward_levels")) s->impl->chol_opt.merge_backward_levels = (int)value;
   else if (!std::strcmp(name, "fuse_big_forward")) s->impl->chol_opt.fuse_big_forward = (int)value;
@@ -1019,6 +1020,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "merge_diag_panel")) ls->opt.merge_diag_panel = (int)value;
   else if (!std::strcmp(name, "big_merge_tiles")) ls->opt.big_merge_tiles = (int)value;
   else if (!std::strcmp(name, "big_group")) ls->opt.big_group = (int)value;
+  else if (!std::strcmp(name, "group_forward_side")) ls->opt.group_forward_side = (int)value;
   else if (!std::strcmp(name, "big_group_min_rows")) ls->opt.big_group_min_rows = (int)value;
   else if (!std::strcmp(name, "merge_backward_levels")) ls->opt.merge_backward_levels = (int)value;
   else if (!std::strcmp(name, "fuse_big_forward")) ls->opt.fuse_big_forward = (int)value;

@@ -59,6 +59,7 @@ struct CholOptions {
   int big_group = 8;                     // panels of a long in-place chain (one large supernode) are grouped: inside a group a panel's rank-npiv update
                                          // touches only the columns of the group's remaining panels, the rest of the trailing matrix gets ONE rank-(group)
                                          // update behind the group's last panel -- a quarter of the passes over a frontal matrix that lives in HBM (1: off)
+  int group_forward_side = 1;            // ... and the forward steps of such panels run on a side stream next to the next panel's factorisation
   int big_group_min_rows = 1536;         // ... for chains whose first front has at least this many rows (smaller ones are latency chains, not traffic)
   int big_merge_tiles = 256;             // scratch-slab levels of at most this many 64 x 64 tiles run the fused panel kernel (panel solve + update
                                          // [+ pivot blocks, merge_diag_panel] in one launch); wider levels the separate whole-GPU passes

@@ -4306,6 +4306,23 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
       if (halves) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[1], 0));
       continue;
     }
+    if (opt.group_forward_side && st != nullptr && big_passes && (LL.grouped || LL.group_in) && LL.lds_count == 0 && LL.glb_count > 0 && !G.dep && fwd &&
+        !big_forward_carried(LL)) {
+      // Panels of a grouped in-place chain: the forward step of a panel (20 us of a 65 us level) needs the panel's solved rows and the
+      // previous panel's update vector, nothing of the next panel's factorisation -- it runs on the side stream next to it (inside a
+      // stream capture: a parallel branch of the graph); the first level that is not such a panel waits for it (fwd_pending below).
+      if (!side_[0]) {
+        for (int i = 0; i < 2; ++i) G2OHIP_HIP_CHECK(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming));
+      }
+      launch_factor(LL, dA, false, st, false, 2);
+      G2OHIP_HIP_CHECK(hipEventRecord(ev_[2], st));
+      G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_[1], ev_[2], 0));
+      launch_solve(LL, true, side_[1], /*glb_only=*/true);
+      G2OHIP_HIP_CHECK(hipEventRecord(ev_[3], side_[1]));
+      fwd_pending = true;
+      continue;
+    }
     if (fwd_pending) {   // (a level that is not split reads the update vectors on the main stream)
       G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[3], 0));
       fwd_pending = false;
