@@ -4306,7 +4306,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
       if (halves) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[1], 0));
       continue;
     }
-    if (opt.group_forward_side && st != nullptr && big_passes && (LL.grouped || LL.group_in) && LL.lds_count == 0 && LL.glb_count > 0 && !G.dep && fwd &&
+    if (opt.group_forward_side && st != nullptr && big_passes && (LL.grouped || LL.group_in || opt.group_forward_side >= 2) && LL.lds_count == 0 && LL.glb_count > 0 && !G.dep && fwd &&
         !big_forward_carried(LL)) {
       // Panels of a grouped in-place chain: the forward step of a panel (20 us of a 65 us level) needs the panel's solved rows and the
       // previous panel's update vector, nothing of the next panel's factorisation -- it runs on the side stream next to it (inside a
