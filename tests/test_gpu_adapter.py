@@ -155,6 +155,37 @@ def test_pose_graph_with_kernels_on_its_loop_closures_binds_as_one_group(host, t
     assert runs[0]["chi2_initial"] < plain["chi2_initial"] * (1 - 1e-3)      # (the kernels bite: robustified chi2 of the same graph)
 
 
+def test_edge_classes_refused_by_the_front_end_fall_back_to_generic_groups(host, tmp_path):
+    """Edge classes need the fused device path; a FIXED point takes a landmark off it (its edges would be skipped by the landmark-major
+    kernels), so g2ohip_ba_set_edges_classes refuses the merged group.  The adapter then registers the edges again as generic groups
+    (one per shape, one robust kernel per edge) -- same trajectory as with the fast path switched off, and the plugin says so."""
+    from tests.test_gpu_edge_classes import CLASSES
+    pr = ba_case(30, 200, outlier_frac=0.05)
+    second = (pr["cam_idx"] % 2) == 1
+    robust = (np.arange(pr["E"]) % 2) == 1
+    cls = (2 * second + robust).astype(np.int32)
+    pr["meas"] = (pr["meas"] - np.array([pr["cx"], pr["cy"]])) / pr["f"] * CLASSES[cls, 0][:, None] + CLASSES[cls, 1:3]
+    prob = str(tmp_path / "p.txt")
+    with open(prob, "w") as f:
+        f.write("%d %d %d %.17g %.17g %.17g 0 %.17g %.17g %.17g\n" % (pr["P"], pr["L"], pr["E"], *CLASSES[0, :3], *CLASSES[2, :3]))
+        for i in range(pr["P"]):
+            f.write("%d %s\n" % (1 if pr["cam_hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in pr["cams"][i])))
+        for j in range(pr["L"]):
+            f.write("%d %s\n" % (1 if j == 3 else 0, " ".join("%.17g" % v for v in pr["pts"][j])))     # point 3 is fixed
+        for k in range(pr["E"]):
+            f.write("%d %d %.17g %.17g %d %.17g\n" % (pr["cam_idx"][k], pr["pt_idx"][k], pr["meas"][k][0], pr["meas"][k][1], int(second[k]),
+                                                   CLASSES[cls[k], 4]))
+    runs = {}
+    for tag, env in (("fast", {}), ("generic", {"G2OHIP_ADAPTER_FASTPATH": "0"})):
+        out, err = _run(host, prob, "lm_fix6_3_hip", 4, str(tmp_path / (tag + ".json")), env, mode="classes")
+        runs[tag] = out
+        assert "device front end (g2ohip_ba_*)" not in err
+        assert ("fast path not available" in err) == (tag == "fast"), err[-600:]
+        assert out["iterations"] == 4 and out["chi2"][-1] < out["chi2_initial"]
+    assert np.allclose(runs["fast"]["chi2"], runs["generic"]["chi2"], rtol=1e-12, atol=0)
+    assert runs["fast"]["trials"] == runs["generic"]["trials"]
+
+
 def test_gauss_newton_and_dogleg_creators_construct(host, tmp_path):
     pr = ba_case(12, 100)
     prob = str(tmp_path / "p.txt")
