@@ -121,7 +121,8 @@ int g2ohip_set_robust_kernel(g2ohip_solver* s, int set, int kind, double delta);
 /* The same per EDGE: in g2o the robust kernel is a member of the edge (optimizable_graph.h:436-443, asked per edge by
  * base_binary_edge.hpp:92-112), so a pose graph with kernels on its loop closures only is still ONE set of EdgeSE2 / EdgeSE3.
  * kind [n], delta [n] (kind 0 = none for that edge); kind == NULL returns to the set-level kernel.  Not for a set bound to the
- * BA front end (g2ohip_ba_set_edges_classes carries the kernels there: G2OHIP_ERR_STATE). */
+ * BA front end (g2ohip_ba_set_edges_classes carries the kernels there: G2OHIP_ERR_STATE).  Edges appended later by
+ * g2ohip_update_structure start with no kernel until this is called again for the grown set. */
 int g2ohip_set_robust_kernel_per_edge(g2ohip_solver* s, int set, const int32_t* kind, const double* delta);
 
 /* Solver::buildSystem(), block_solver.hpp:501-560 (clear + per-edge constructQuadraticForm +

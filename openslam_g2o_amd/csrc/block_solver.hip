@@ -2242,6 +2242,16 @@ bool BlockSolver::update_structure(int new_poses, int set, int n, const int* v0,
     // drop the binding (pg_set_edges / ba_set_edges again after growth), pg_linearize refuses until then
     if (set == pg_.set) pg_ = PgFrontEnd();
     if (set == ba_.set) ba_.set = -1;
+    // per-edge robust kernels cover the old edge count: the new edges get "none" (kind 0) until set_robust_kernel_per_edge is
+    // called again -- the array is extended on the device so that no kernel reads past its end
+    if (es.rk.p) {
+      DevBuf<double> grown;
+      grown.alloc((size_t)es.n * 2);
+      G2OHIP_HIP_CHECK(hipMemsetAsync(grown.p, 0, (size_t)es.n * 2 * sizeof(double), st_));
+      G2OHIP_HIP_CHECK(hipMemcpyAsync(grown.p, es.rk.p, (size_t)(es.n - n) * 2 * sizeof(double), hipMemcpyDeviceToDevice, st_));
+      G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+      es.rk = std::move(grown);
+    }
   }
   build_structure(nP_ + new_poses, 0, false);
   return true;
