@@ -2141,6 +2141,28 @@ void group_by(int ndst, const std::vector<int>& dest, const std::vector<int>& pa
 
 }  // namespace
 
+// One-time per process: dynamic-LDS limit of the fused BA tile kernels.  Called when a BA front end is bound (set-up time) so
+// that the first solve of a process does not pay for it, and again at the launch site as a no-op.
+static void prepare_ba_tile_kernels() {
+  static bool attr = false;
+  if (!attr) {
+#define G2OHIP_BA_TILE_ATTR(GG)                                                                                                    \
+  (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<GG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<GG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    G2OHIP_BA_TILE_ATTR(1);
+    G2OHIP_BA_TILE_ATTR(2);
+    G2OHIP_BA_TILE_ATTR(4);
+    G2OHIP_BA_TILE_ATTR(8);
+    G2OHIP_BA_TILE_ATTR(16);
+#undef G2OHIP_BA_TILE_ATTR
+    attr = true;
+  }
+}
+
 // =====================================================================================
 // BlockSolver
 // =====================================================================================
@@ -3358,23 +3380,7 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
   }
   if (ba_tiles) {
     EdgeSet& es = *sets_[ba_.set];
-    static bool attr = false;
-    if (!attr) {
-#define G2OHIP_BA_TILE_ATTR(GG)                                                                                                    \
-  (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<GG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-  (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<GG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)ba_schur_tile_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      G2OHIP_BA_TILE_ATTR(1);
-      G2OHIP_BA_TILE_ATTR(2);
-      G2OHIP_BA_TILE_ATTR(4);
-      G2OHIP_BA_TILE_ATTR(8);
-      G2OHIP_BA_TILE_ATTR(16);
-#undef G2OHIP_BA_TILE_ATTR
-      attr = true;
-    }
+    prepare_ba_tile_kernels();
     prof.begin(KernelProf::kSchurBlocks, st_);
     const bool fll = !ll_valid_ || ll_hbm_partial_;   // the tiles assemble Hll / b_l / errors themselves (again, if the last ones kept Hll on chip)
     // ... and write to HBM only what the solve path reads (Dinv, b_l) unless option ba_store_ll asks for Hll and the errors
@@ -4710,6 +4716,7 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
   es.own_err.alloc(n * 2);
   es.J0 = es.own_J0.p; es.J1 = es.own_J1.p; es.omega = es.own_omega.p; es.err = es.own_err.p;
   es.has_data = false;   // becomes valid with the first ba_linearize
+  prepare_ba_tile_kernels();
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
 }
 

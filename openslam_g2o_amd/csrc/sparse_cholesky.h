@@ -339,6 +339,7 @@ class SparseCholesky {
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false, bool skip_glb = false);
   bool big_forward_carried(const LevelLaunch& LL) const;
+  static void prepare_kernels();
   int merge_tiles_of(const LevelLaunch& LL) const { return (LL.grouped || LL.group_in) ? -1 : opt.big_merge_tiles; }   // (grouped chains: the separate kernels)   // the forward step of the level's scratch-slab fronts rides along in their factorisation
   CholPlanDev plan_{};
 };

@@ -1660,6 +1660,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.slots = d_slots.p;
   spinv_planned_ = false;   // (the inverse fronts follow the new tree)
   analyzed_ = !host_only;
+  if (!host_only) prepare_kernels();
   stats_.t_symbolic = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -4183,8 +4184,10 @@ bool SparseCholesky::has_band_chains(int phase) const {
   return false;
 }
 
-void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, bool fwd, int parts) {
-  if (!analyzed_) throw StateFailure("SparseCholesky::factor before analyze");
+// One-time per process: dynamic-LDS limits of the factor kernels (hipFuncSetAttribute also makes the runtime load this file's code
+// object).  Called at the end of analyze() so that the first factorisation of a process does not pay for it (4 ms of the first
+// solve of a Levenberg-Marquardt run were these calls), and again from factor_phase as a no-op.
+void SparseCholesky::prepare_kernels() {
   static bool attr_done = false;
   if (!attr_done) {
     // allow > 64 KiB dynamic LDS for the LDS-resident front kernels
@@ -4221,6 +4224,11 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     (void)hipGetLastError();
     attr_done = true;
   }
+}
+
+void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, bool fwd, int parts) {
+  if (!analyzed_) throw StateFailure("SparseCholesky::factor before analyze");
+  prepare_kernels();
   if (phase == 0 && (parts & 1)) {
     if (!skip_status_clear) G2OHIP_HIP_CHECK(hipMemsetAsync(d_status.p, 0, sizeof(int), st));
     skip_status_clear = false;
