@@ -67,6 +67,7 @@ struct CholOptions {
   int merge_backward_levels = 1;         // backward step of consecutive levels of scratch-slab fronts in ONE launch (workgroups wait for their parent front's flag)
   int split_sweeps = 1;                  // forward / backward step of scratch-slab fronts by several workgroups per front (256 boundary rows each)
   int split_sweeps_min_dim = 512;        // ... on levels whose largest such front has at least this many rows
+  int lazy_level_joins = 1;              // ... the two streams wait for each other only where a front has a child on the other one (0: at every such level)
   int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
@@ -310,6 +311,10 @@ class SparseCholesky {
     std::vector<std::pair<int, int>> be_pass;
     long long glb_scratch = 0;                           // doubles of the scratch slab this launch uses
     bool big_ok = false;
+    // levels whose LDS fronts run on a side stream next to the scratch-slab passes (overlap_level_halves): split_ok = the level
+    // qualifies by its structure; fork = an LDS front of it has a child that ran on the main stream since the side stream last
+    // waited for it; join = a front of the main part has a child that ran on the side stream since the main stream last did
+    bool split_ok = false, fork = false, join = false;
   };
   std::vector<LevelLaunch> launches_[2];   // [0] own tasks, [1] shared top-of-tree tasks
   struct FactorGroup { LevelLaunch LL; int first_level, last_level; bool dep; int band_count = 0, band_rec0 = 0, band_ent_cap = 0, band_tab_cap = 0; };

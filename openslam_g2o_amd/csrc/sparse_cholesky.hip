@@ -1149,6 +1149,44 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     d_sw_cnt.alloc((size_t)nf + 1);
     d_sw_cnt.zero(st);
   }
+  // --- levels split over two streams: where the streams have to wait for each other (LevelLaunch::fork / join).  The side stream
+  // runs the LDS fronts of the split levels in level order, the main stream everything else: a wait is needed only where a front
+  // has a child on the OTHER stream that the last wait does not cover yet (a cross-stream wait costs ~10 us on the chain of
+  // whole-GPU passes even when its event fired long ago: the queue drains at the barrier packet).
+  for (int ph = 0; ph < 2; ++ph) {
+    auto in_phase = [&](int t) { return ph == 0 ? (S.task_owner[t] == opt.rank) : (S.task_owner[t] == -1); };
+    std::vector<char> on_side(ntask, 0);
+    int fork_cover = -1, join_cover = 0, nsplit = 0, nfork = 0, njoin = 0;
+    for (int l = 0; l < nlev; ++l) {
+      LevelLaunch& LL = launches_[ph][l];
+      LL.split_ok = LL.glb_count > 0 && LL.lds_count > 0 && LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim;
+      auto child_on = [&](int q0, int q1, bool side, int since) {
+        for (int q = q0; q < q1; ++q) {
+          const int t = S.level_fronts[q];
+          for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
+            const int f = S.task_fronts[k];
+            for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) {
+              const int ct = task_of[S.children[ch]];
+              if (ct != t && in_phase(ct) && (on_side[ct] != 0) == side && task_level[ct] >= since) return true;
+            }
+          }
+        }
+        return false;
+      };
+      LL.join = child_on(LL.split_ok ? LL.glb_begin : LL.lds_begin, LL.glb_begin + LL.glb_count, true, join_cover);
+      if (LL.join) join_cover = l;
+      LL.fork = false;
+      if (LL.split_ok) {
+        LL.fork = fork_cover < 0 || child_on(LL.lds_begin, LL.lds_begin + LL.lds_count, false, fork_cover);
+        if (LL.fork) fork_cover = l;
+        for (int q = LL.lds_begin; q < LL.lds_begin + LL.lds_count; ++q) on_side[S.level_fronts[q]] = 1;
+        ++nsplit;
+      }
+      nfork += LL.fork;
+      njoin += LL.join;
+    }
+    if (getenv("G2OHIP_PLAN_DUMP") && nsplit > 0) fprintf(stderr, "phase %d: %d split levels, %d forks, %d joins\n", ph, nsplit, nfork, njoin);
+  }
   // --- factorisation launch groups.  Consecutive levels with the same kernel variant (and nothing the fused
   // kernel cannot carry) may share one launch: workgroups are dispatched in blockIdx order and the slots are in
   // level order, so every child of a waiting parent is already running or done (no deadlock); the parent
@@ -1206,6 +1244,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
               G.LL.lds_idx_ints = std::max(G.LL.lds_idx_ints, N.lds_idx_ints);
             }
             G.LL.max_m = std::max(G.LL.max_m, N.max_m);
+            G.LL.join = G.LL.join || N.join;
             G.LL.lds_vec_m = std::max(G.LL.lds_vec_m, N.lds_vec_m);
             G.LL.max_panel = std::max(G.LL.max_panel, N.max_panel);
             G.LL.wv_pn = std::max(G.LL.wv_pn, N.wv_pn);
@@ -4266,8 +4305,13 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     }
   }
   bool fwd_pending = false;   // a forward step of large fronts is in flight on side_[1] (event ev_[3])
+  bool side_dirty = false, side_used = false, side_unsure = false;   // side_[0]: work the main stream has not waited for (ev_[1]) / used in this call / plan flags void
   for (const FactorGroup& G : groups_[phase]) {
     if (G.dep && dep_off_) {   // (groups only hold levels the fused kernel carries completely)
+      if (side_dirty) {
+        G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[1], 0));
+        side_dirty = false;
+      }
       for (int l = G.first_level; l <= G.last_level; ++l) {
         LevelLaunch one = launches_[phase][l];
         if (l == G.first_level && band_usable(G, dA)) {   // (the same kernels as the grouped launch: results stay bit-identical)
@@ -4295,14 +4339,22 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
         for (int i = 0; i < 2; ++i) G2OHIP_HIP_CHECK(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
         for (int i = 0; i < 4; ++i) G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming));
       }
-      const bool halves = LL.lds_count > 0;
-      if (halves) {
+      // (lazy: the streams wait for each other only where the tree asks for it -- LevelLaunch::fork / join; the first use of the side
+      // stream in a call always forks: inside a stream capture that is what makes it part of the graph)
+      const bool lazy = opt.lazy_level_joins && LL.split_ok && !side_unsure;
+      if (side_dirty && (!lazy || LL.join)) {
+        G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[1], 0));
+        side_dirty = false;
+      }
+      if (!lazy || LL.fork || !side_used) {
         G2OHIP_HIP_CHECK(hipEventRecord(ev_[0], st));
         G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_[0], ev_[0], 0));
-        if (fwd_pending) G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_[0], ev_[3], 0));
-        launch_factor(LL, dA, fused, side_[0], false, 1);
-        G2OHIP_HIP_CHECK(hipEventRecord(ev_[1], side_[0]));
+        side_unsure = false;
       }
+      if (fwd_pending) G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_[0], ev_[3], 0));
+      launch_factor(LL, dA, fused, side_[0], false, 1);
+      G2OHIP_HIP_CHECK(hipEventRecord(ev_[1], side_[0]));
+      side_dirty = side_used = true;
       launch_factor(LL, dA, fused, st, false, 2);
       if (fwd && !big_forward_carried(LL)) {
         G2OHIP_HIP_CHECK(hipEventRecord(ev_[2], st));
@@ -4311,9 +4363,17 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
         G2OHIP_HIP_CHECK(hipEventRecord(ev_[3], side_[1]));
         fwd_pending = true;
       }
-      if (halves) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[1], 0));
+      if (!lazy) {
+        G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[1], 0));
+        side_dirty = false;
+      }
       continue;
     }
+    if (side_dirty && (!opt.lazy_level_joins || LL.join || LL.split_ok || side_unsure)) {   // (a front of this level has a child on the side stream)
+      G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[1], 0));
+      side_dirty = false;
+    }
+    if (LL.split_ok) side_unsure = true;   // (a level the plan put on the side stream ran here: its fork / join flags no longer describe the streams)
     if (opt.group_forward_side && st != nullptr && big_passes && (LL.grouped || LL.group_in || opt.group_forward_side >= 2) && LL.lds_count == 0 && LL.glb_count > 0 && !G.dep && fwd &&
         !big_forward_carried(LL)) {
       // Panels of a grouped in-place chain: the forward step of a panel (20 us of a 65 us level) needs the panel's solved rows and the
@@ -4353,6 +4413,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     else if (fwd && LL.glb_count > 0 && !carried) launch_solve(LL, true, st, /*glb_only=*/true);
   }
   if (fwd_pending) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[3], 0));
+  if (side_dirty) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st, ev_[1], 0));
   G2OHIP_HIP_CHECK(hipGetLastError());
 }
 

@@ -230,3 +230,30 @@ def test_robust_kernels_on_the_loop_closures_only_stay_one_device_set():
     robust = s.chi2()
     s.setRobustKernelPerEdge(k, None, None)
     assert s.chi2() > robust * (1 + 1e-6)
+
+
+def test_lazy_stream_joins_of_split_levels_equal_the_joins_at_every_level():
+    """Levels with LDS fronts AND scratch-slab fronts run on two streams (sparse_cholesky.hip: LevelLaunch::fork / join): with
+    `lazy_level_joins` the streams wait for each other only where a front has a child on the other one.  Same kernels, same operation
+    order: the solutions are bit-identical to the ones with a fork and a join at every such level, with and without graph replay,
+    and repeatable (a missing dependency would show as a race)."""
+    capi = _capi()
+    g = sphere_golden()
+    J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
+    xs = []
+    for lazy, graph in ((0, 0), (1, 0), (1, 1), (0, 1)):
+        s = capi.HipBlockSolver(6, 3, 0)
+        s.setOption("lazy_level_joins", lazy)
+        k = s.addEdgeSet(6, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
+        s.buildStructure(g["nP"], 0, False)
+        s.setEdgeData(k, J0, J1, g["omega"], err)
+        s.setOption("use_graph", graph)
+        s.buildSystem()
+        lam = 1e-5 * s.maxDiagonal()
+        for _ in range(6):
+            s.setLambda(lam, True)
+            assert s.solve()
+            s.restoreDiagonal()
+            xs.append(s.x().copy())
+    for x in xs[1:]:
+        assert np.array_equal(x, xs[0])
