@@ -139,9 +139,10 @@ def main():
     ap.add_argument("--edge-data", choices=["fused", "arrays"], default="fused",
                     help="fused: estimates + measurements resident in HBM, errors/Jacobians evaluated inside buildSystem "
                          "(what the reference's buildSystem does per edge); arrays: precomputed Jacobian arrays resident in HBM")
-    ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
+    ap.add_argument("--comm", choices=["rccl", "staged", "peer"], default="rccl",
                     help="staged: gloo + host staging with every rank on cuda:0 (functional check of the N>1 path on a "
-                         "1-GPU box; its timing is meaningless)")
+                         "1-GPU box; its timing is meaningless); peer: the library's opt-in peer-mailbox exchange "
+                         "(g2ohip_comm_init_peer: hipIpc handles, stores over xGMI) instead of RCCL for the solve's all-reduces")
     ap.add_argument("--check-oracle", action="store_true", help="N > 1: gather the pose increment of the last solve on rank 0 and compare it "
                     "with one CPU oracle iteration on the whole graph (dx_pose_rel_err in the JSON line); for sizes the oracle "
                     "finishes in seconds")
@@ -172,10 +173,14 @@ def main():
     if args.emulate:
         emulate = tuple(int(v) for v in args.emulate.split("/"))
     comm_note = None
+    comm_asked = args.comm
+    if args.comm == "peer":      # process group and rank -> device mapping as for rccl; only the library's communicator differs
+        args.comm = "rccl"
     if world > 1 and args.comm == "rccl" and torch.cuda.device_count() < world:
         # fewer GPUs than ranks (a 1-GPU box): RCCL refuses two ranks per device -> functional run through host staging
-        comm_note = "rccl requested, %d GPU(s) visible for %d ranks: ranks share cuda:0, exchange staged through gloo" % (
-            torch.cuda.device_count(), world)
+        comm_note = "%s requested, %d GPU(s) visible for %d ranks: ranks share cuda:0, %s" % (
+            comm_asked, torch.cuda.device_count(), world,
+            "mailboxes on the one device" if comm_asked == "peer" else "exchange staged through gloo")
         if rank == 0:
             sys.stderr.write("bench: " + comm_note + "\n")
         args.comm = "staged"
@@ -233,7 +238,7 @@ def main():
         solver._lib_comm = lib_comm = "none (emulation: all-reduces skipped)"
     if (world > 1 or emulate) and solver.mode == "subtree" and not emulate:
         try:
-            lib_comm = "rccl" if args.comm == "rccl" else "host"
+            lib_comm = "peer" if comm_asked == "peer" else ("rccl" if args.comm == "rccl" else "host")
             if not solver.attach_library_comm(lib_comm):
                 lib_comm = "torch (library communicator not applicable)"
             else:
@@ -390,7 +395,7 @@ def main():
     if world > 1 or emulate:
         out["collectives"] = lib_comm
         out["shard"] = dict(rank0_edges=E_loc, rank0_landmarks=L_loc, exchange_doubles_per_solve=solver.exchange_volume(),
-                            comm=args.comm)
+                            comm=comm_asked if comm_asked == "peer" else args.comm)
         if comm_note:
             out["shard"]["comm_note"] = comm_note
         if rank_tables:

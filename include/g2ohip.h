@@ -328,7 +328,13 @@ int g2ohip_get_partition(g2ohip_solver* s, int32_t* pose_owner, int32_t* block_c
  *   itself has no link dependency on it;
  *   host callback: g2ohip_comm_init_host with an in-place all-reduce over host memory (op 0 = sum, 1 = max; MPI_Allreduce
  *   fits directly): device buffers are staged through pinned memory.  For ranks sharing one GPU (tests) and boxes
- *   without peer access; not a performance path.
+ *   without peer access; not a performance path;
+ *   peer mailboxes (opt-in): g2ohip_comm_init_peer -- every rank exports a device mailbox (hipIpcGetMemHandle; the handles
+ *   travel through the host all-reduce once), an all-reduce is one kernel that stores the payload into the rank's slot of
+ *   every peer's mailbox over xGMI and one that waits for all slots and adds them in rank order: two launches for the
+ *   latency-sized payloads of the sharded solve instead of a ring.  slot_doubles = capacity of a slot (larger payloads go
+ *   in pieces).  A peer that does not deliver within the wait limit (5 s) fails the call that next synchronises
+ *   (G2OHIP_ERR_STATE) instead of hanging the device.  Verified with several processes on one GPU only; RCCL is the default.
  * g2ohip_solve_sharded then runs the whole linear solve (BlockSolver::solve, block_solver.hpp:353-486, on the sharded
  * system): local Schur pass | all-reduce of the boundary blocks of the reduced system and boundary b_p | own subtrees of
  * the elimination tree | all-reduce of the subtree roots' update matrices | shared top + backward sweep | all-reduce of
@@ -340,6 +346,7 @@ typedef int (*g2ohip_host_allreduce_fn)(void* ctx, double* host_buffer, size_t c
 int g2ohip_comm_unique_id(char* id128);
 int g2ohip_comm_init_rccl(g2ohip_solver* s, int rank, int world, const char* id128);
 int g2ohip_comm_init_host(g2ohip_solver* s, int rank, int world, g2ohip_host_allreduce_fn fn, void* ctx);
+int g2ohip_comm_init_peer(g2ohip_solver* s, int rank, int world, g2ohip_host_allreduce_fn fn, void* ctx, size_t slot_doubles);
 int g2ohip_comm_destroy(g2ohip_solver* s);
 int g2ohip_comm_all_reduce(g2ohip_solver* s, double* device_buffer, size_t count, int op);   /* in place, on the solver's stream */
 int g2ohip_solve_sharded(g2ohip_solver* s);

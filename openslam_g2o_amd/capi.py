@@ -59,7 +59,7 @@ EXPORTS = [
     "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
     "g2ohip_compute_marginals", "g2ohip_set_x", "g2ohip_copy_diagonal",
-    "g2ohip_comm_unique_id", "g2ohip_comm_init_rccl", "g2ohip_comm_init_host", "g2ohip_comm_destroy", "g2ohip_comm_all_reduce",
+    "g2ohip_comm_unique_id", "g2ohip_comm_init_rccl", "g2ohip_comm_init_host", "g2ohip_comm_init_peer", "g2ohip_comm_destroy", "g2ohip_comm_all_reduce",
     "g2ohip_update_structure", "g2ohip_clear_edge_sets", "g2ohip_solve_sharded", "g2ohip_chi2_sharded", "g2ohip_max_diagonal_sharded", "g2ohip_compute_scale_sharded",
 ]
 
@@ -158,6 +158,7 @@ def load():
     L.g2ohip_comm_unique_id.argtypes = [C.c_char_p]
     L.g2ohip_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.g2ohip_comm_init_host.argtypes = [vp, C.c_int, C.c_int, HOST_ALLREDUCE_FN, vp]
+    L.g2ohip_comm_init_peer.argtypes = [vp, C.c_int, C.c_int, HOST_ALLREDUCE_FN, vp, C.c_size_t]
     L.g2ohip_comm_destroy.argtypes = [vp]
     L.g2ohip_comm_all_reduce.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.g2ohip_update_structure.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -436,6 +437,20 @@ class HipBlockSolver:
                 return 1
         self._host_comm_cb = HOST_ALLREDUCE_FN(tramp)      # keep the trampoline alive as long as the handle
         _check(self.L.g2ohip_comm_init_host(self.h, rank, world, self._host_comm_cb, None), "commInitHost")
+
+    def commInitPeer(self, rank, world, fn, slot_doubles=1 << 18):
+        """Peer mailboxes over hipIpc handles (opt-in, see g2ohip.h); fn as in commInitHost: it carries the handles once and the
+        host scalars afterwards."""
+        def tramp(ctx, ptr, n, op):
+            try:
+                fn(np.ctypeslib.as_array(ptr, shape=(n,)), op)
+                return 0
+            except Exception:      # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_comm_cb = HOST_ALLREDUCE_FN(tramp)
+        _check(self.L.g2ohip_comm_init_peer(self.h, rank, world, self._host_comm_cb, None, int(slot_doubles)), "commInitPeer")
 
     def commDestroy(self):
         _check(self.L.g2ohip_comm_destroy(self.h), "commDestroy")

@@ -220,6 +220,7 @@ class BlockSolver {
   // Collectives inside the library (comm.h): the whole sharded solve and the LM scalars without a Python / torch layer.
   Comm comm;
   void comm_init_rccl(int rank, int world, const char* id128);
+  void comm_init_peer(int rank, int world, HostAllReduceFn fn, void* ctx, size_t slot_doubles);
   void comm_all_reduce(double* dev, size_t n, int op);
   int solve_sharded();
   int solve_sharded_once();                       // Schur pass, three all-reduces, subtree-distributed factorisation, back-substitution

@@ -3921,6 +3921,10 @@ void BlockSolver::comm_init_rccl(int rank, int world, const char* id128) {
   G2OHIP_HIP_CHECK(hipSetDevice(device_));   // the communicator binds to the current device
   comm.init_rccl(rank, world, id128);
 }
+void BlockSolver::comm_init_peer(int rank, int world, HostAllReduceFn fn, void* ctx, size_t slot_doubles) {
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));   // the mailbox lives on the solver's device
+  comm.init_peer(rank, world, fn, ctx, slot_doubles);
+}
 void BlockSolver::comm_all_reduce(double* dev, size_t n, int op) {
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   comm.all_reduce(dev, n, op, st_);
@@ -3986,7 +3990,9 @@ int BlockSolver::solve_sharded_once() {
   }
   if (one_graph) run_seg(kSegShardedAll, whole_solve);
   else whole_solve();
-  return exchange_status();
+  const int rc = exchange_status();   // (synchronises)
+  comm.poll_error();
+  return rc;
 }
 
 int BlockSolver::solve_sharded() {

@@ -719,6 +719,10 @@ int g2ohip_comm_init_host(g2ohip_solver* s, int rank, int world, g2ohip_host_all
   if (!s || !fn || world < 1 || rank < 0 || rank >= world) return G2OHIP_ERR_ARG;
   return guarded([&] { s->impl->comm.init_host(rank, world, fn, ctx); return G2OHIP_OK; });
 }
+int g2ohip_comm_init_peer(g2ohip_solver* s, int rank, int world, g2ohip_host_allreduce_fn fn, void* ctx, size_t slot_doubles) {
+  if (!s || !fn || world < 1 || rank < 0 || rank >= world) return G2OHIP_ERR_ARG;
+  return guarded([&] { s->impl->comm_init_peer(rank, world, fn, ctx, slot_doubles); return G2OHIP_OK; });
+}
 int g2ohip_comm_destroy(g2ohip_solver* s) {
   if (!s) return G2OHIP_ERR_ARG;
   return guarded([&] { s->impl->comm.destroy(); return G2OHIP_OK; });

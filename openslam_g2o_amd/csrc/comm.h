@@ -5,11 +5,22 @@
 //   * host callback: the caller supplies an all-reduce over host memory (MPI, gloo, a test harness); device buffers are
 //     staged through pinned memory.  For several ranks sharing one GPU (RCCL refuses that) and for boxes without peer
 //     access.  Not a performance path.
+//   * peer mailboxes (opt-in): every rank owns a device buffer with one slot per rank and parity, exported with
+//     hipIpcGetMemHandle and mapped by the others; an all-reduce is ONE kernel that stores the rank's payload into its slot of
+//     every peer's mailbox (over xGMI: plain stores, a system-scope fence, then the slot's sequence number) and ONE kernel that
+//     waits for the sequence numbers of all slots and adds them in rank order (every rank forms the same sums).  Two launches and
+//     one xGMI latency instead of a ring of 2 (N - 1) steps for the latency-sized payloads of the sharded solve (94 KB).
+//     The handles travel through the caller's host all-reduce once; the host scalars keep using it.  Exercised with several
+//     processes on ONE GPU only (tests/test_gpu_multirank.py): the coherence of a mailbox polled by its owner while a peer
+//     writes it over xGMI can only be established on a multi-GPU node -- hence opt-in, RCCL stays the default.
 // The sharded solve (BlockSolver::solve_sharded) needs three latency-sized all-reduces per solve.
 #pragma once
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "common.h"
 
@@ -17,9 +28,67 @@ namespace g2ohip {
 
 typedef int (*HostAllReduceFn)(void* ctx, double* host_buffer, size_t count, int op);   // in place; op 0 = sum, 1 = max
 
+namespace {
+constexpr int kPeerMaxWorld = 16;
+constexpr int kPeerHeader = 64;   // doubles in front of the slots: 2 x world sequence numbers (64 bit), padded to 512 B
+struct PeerTable { double* box[kPeerMaxWorld]; };
+
+// layout of a rank's mailbox: [sequence numbers: parity x world][slots: parity x world x cap doubles]
+__device__ __forceinline__ unsigned long long* peer_seq(double* box, int parity, int world, int r) {
+  return reinterpret_cast<unsigned long long*>(box) + (size_t)parity * world + r;
+}
+
+// blockIdx.y = peer: this rank's payload into its slot of the peer's mailbox; the last workgroup of a peer publishes the sequence number
+__global__ void __launch_bounds__(256) peer_put_kernel(PeerTable T, const double* __restrict__ src, size_t n, size_t cap, int world, int rank, int parity,
+                                                       unsigned long long seq, unsigned int* __restrict__ cnt) {
+  const int q = blockIdx.y;
+  double* dst = T.box[q] + kPeerHeader + ((size_t)parity * world + rank) * cap;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+  __threadfence_system();   // this thread's stores have reached the peer
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int done = __hip_atomic_fetch_add(cnt + q, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (done == gridDim.x) {
+      __hip_atomic_store(cnt + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(peer_seq(T.box[q], parity, world, rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// waits until every rank's slot carries `seq`, then dst = slot 0 (+|max) slot 1 ... in rank order (bit-identical on all ranks).
+// The wait is bounded (ticks of the 100 MHz wall clock): a peer that never arrives raises *err instead of hanging the GPU.
+__global__ void __launch_bounds__(256) peer_sum_kernel(double* box, double* __restrict__ dst, size_t n, size_t cap, int world, int parity, unsigned long long seq,
+                                                       int op, long long tick_limit, int* err) {
+  if ((int)threadIdx.x < world) {
+    const unsigned long long* fl = peer_seq(box, parity, world, threadIdx.x);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > tick_limit) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+  const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(box + kPeerHeader + (size_t)parity * world * cap);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    // system-scope loads: the slots were written by other devices (or processes), not through this device's caches
+    double acc = __longlong_as_double((long long)__hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    for (int q = 1; q < world; ++q) {
+      const double v = __longlong_as_double((long long)__hip_atomic_load(slots + (size_t)q * cap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      acc = op == 1 ? fmax(acc, v) : acc + v;
+    }
+    dst[i] = acc;
+  }
+}
+}  // namespace
+
 class Comm {
  public:
-  enum Kind { kNone = 0, kRccl = 1, kHost = 2 };
+  enum Kind { kNone = 0, kRccl = 1, kHost = 2, kPeer = 3 };
   ~Comm() { destroy(); }
   Kind kind() const { return kind_; }
   int rank() const { return rank_; }
@@ -50,9 +119,92 @@ class Comm {
     rank_ = rank;
     world_ = world;
   }
+  // Peer mailboxes: `cap` doubles per slot (larger payloads go in pieces); fn = the host all-reduce the handles (and later the
+  // host scalars) travel through.  Collective: every rank of the world calls it, with the same cap.
+  void init_peer(int rank, int world, HostAllReduceFn fn, void* ctx, size_t cap) {
+    destroy();
+    if (!fn) throw ArgFailure("comm_init_peer: null callback");
+    if (world < 1 || world > kPeerMaxWorld) throw ArgFailure("comm_init_peer: 1 <= world <= 16");
+    if (cap < 1024) cap = 1024;
+    fn_ = fn;
+    ctx_ = ctx;
+    rank_ = rank;
+    world_ = world;
+    peer_cap_ = cap;
+    const size_t doubles = kPeerHeader + 2 * (size_t)world * cap;
+    // uncached (fine-grained) device memory when the runtime exports it, plain device memory otherwise
+    void* p = nullptr;
+    hipIpcMemHandle_t mine;
+    bool have = false;
+    if (hipExtMallocWithFlags(&p, doubles * sizeof(double), hipDeviceMallocUncached) == hipSuccess && p) {
+      if (hipIpcGetMemHandle(&mine, p) == hipSuccess) have = true;
+      else {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        p = nullptr;
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+    if (!have) {
+      G2OHIP_HIP_CHECK(hipMalloc(&p, doubles * sizeof(double)));
+      G2OHIP_HIP_CHECK(hipIpcGetMemHandle(&mine, p));
+    }
+    peer_box_[rank] = static_cast<double*>(p);
+    if (std::getenv("G2OHIP_COMM_DEBUG")) fprintf(stderr, "comm_init_peer: rank %d mailbox %s, %zu KB\n", rank, have ? "uncached (fine-grained)" : "plain device memory", doubles / 128);
+    G2OHIP_HIP_CHECK(hipMemset(p, 0, doubles * sizeof(double)));
+    G2OHIP_HIP_CHECK(hipDeviceSynchronize());
+    G2OHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&peer_cnt_), kPeerMaxWorld * sizeof(unsigned int)));
+    G2OHIP_HIP_CHECK(hipMemset(peer_cnt_, 0, kPeerMaxWorld * sizeof(unsigned int)));
+    G2OHIP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&peer_err_), sizeof(int), hipHostMallocMapped));
+    *peer_err_ = 0;
+    // all-gather of the handles through the host all-reduce: one double per byte, a rank fills its own row (the call is also
+    // the barrier behind which every mailbox is zeroed)
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t");
+    std::vector<double> hb((size_t)world * 64, 0.0);
+    const unsigned char* mb = reinterpret_cast<const unsigned char*>(&mine);
+    for (int i = 0; i < 64; ++i) hb[(size_t)rank * 64 + i] = mb[i];
+    if (world > 1 && fn_(ctx_, hb.data(), hb.size(), 0) != 0) throw StateFailure("comm_init_peer: host all-reduce callback failed");
+    for (int q = 0; q < world; ++q) {
+      if (q == rank) continue;
+      hipIpcMemHandle_t h;
+      unsigned char* hbq = reinterpret_cast<unsigned char*>(&h);
+      for (int i = 0; i < 64; ++i) hbq[i] = (unsigned char)hb[(size_t)q * 64 + i];
+      void* pq = nullptr;
+      G2OHIP_HIP_CHECK(hipIpcOpenMemHandle(&pq, h, hipIpcMemLazyEnablePeerAccess));
+      peer_box_[q] = static_cast<double*>(pq);
+    }
+    peer_seq_ = 0;
+    kind_ = kPeer;
+    // nobody stores into a mailbox before every rank has mapped them all (a peer's first put may otherwise race a late memset-free
+    // start-up elsewhere: cheap insurance)
+    double one = 1.0;
+    if (world > 1 && fn_(ctx_, &one, 1, 0) != 0) throw StateFailure("comm_init_peer: host all-reduce callback failed");
+  }
+  // (after a synchronisation of the stream the collectives ran on) a peer never arrived within the wait limit
+  void poll_error() {
+    if (kind_ == kPeer && peer_err_ && *peer_err_) {
+      *peer_err_ = 0;
+      throw StateFailure("peer exchange: a rank did not deliver its payload within the wait limit");
+    }
+  }
+  void set_peer_wait_seconds(double s) { peer_wait_ticks_ = (long long)(s * 1e8); }
   void destroy() {
     if (kind_ == kRccl && comm_) (void)api().comm_destroy(comm_);
     comm_ = nullptr;
+    if (kind_ == kPeer) {
+      (void)hipDeviceSynchronize();
+      for (int q = 0; q < world_; ++q) {
+        if (!peer_box_[q]) continue;
+        if (q == rank_) (void)hipFree(peer_box_[q]);
+        else (void)hipIpcCloseMemHandle(peer_box_[q]);
+        peer_box_[q] = nullptr;
+      }
+      if (peer_cnt_) (void)hipFree(peer_cnt_);
+      if (peer_err_) (void)hipHostFree(peer_err_);
+      peer_cnt_ = nullptr;
+      peer_err_ = nullptr;
+    }
     if (stage_) (void)hipHostFree(stage_);
     stage_ = nullptr;
     stage_n_ = 0;
@@ -67,6 +219,21 @@ class Comm {
       check(api().all_reduce(dev, dev, n, /*ncclDouble*/ 8, op == 1 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, comm_, st), "ncclAllReduce");
       return;
     }
+    if (kind_ == kPeer) {
+      PeerTable T;
+      for (int q = 0; q < kPeerMaxWorld; ++q) T.box[q] = q < world_ ? peer_box_[q] : nullptr;
+      for (size_t off = 0; off < n; off += peer_cap_) {
+        const size_t m = std::min(peer_cap_, n - off);
+        const unsigned long long seq = ++peer_seq_;
+        const int parity = (int)(seq & 1);
+        const int nb = (int)std::min<size_t>(64, (m + 1023) / 1024);
+        hipLaunchKernelGGL(peer_put_kernel, dim3(nb, world_), dim3(256), 0, st, T, dev + off, m, peer_cap_, world_, rank_, parity, seq, peer_cnt_);
+        hipLaunchKernelGGL(peer_sum_kernel, dim3(nb), dim3(256), 0, st, peer_box_[rank_], dev + off, m, peer_cap_, world_, parity, seq, op, peer_wait_ticks_,
+                           peer_err_);
+      }
+      G2OHIP_HIP_CHECK(hipGetLastError());
+      return;
+    }
     ensure_stage(n);
     G2OHIP_HIP_CHECK(hipMemcpyAsync(stage_, dev, n * sizeof(double), hipMemcpyDeviceToHost, st));
     G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
@@ -76,7 +243,11 @@ class Comm {
   // a few host scalars (chi2, computeScale, the maximal diagonal entry); synchronises
   void all_reduce_host(double* host, size_t n, int op, hipStream_t st) {
     if (n == 0 || kind_ == kNone) return;
-    if (kind_ == kHost) {
+    if (kind_ == kHost || kind_ == kPeer) {
+      if (kind_ == kPeer) {   // (the callers have synchronised the stream or are about to: report a missed delivery here)
+        G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
+        poll_error();
+      }
       if (fn_(ctx_, host, n, op) != 0) throw StateFailure("host all-reduce callback failed");
       return;
     }
@@ -137,6 +308,12 @@ class Comm {
   double* stage_ = nullptr;
   size_t stage_n_ = 0;
   DevBuf<double> scal_;
+  double* peer_box_[kPeerMaxWorld] = {nullptr};   // [rank_] = own mailbox, the others mapped through hipIpcOpenMemHandle
+  size_t peer_cap_ = 0;
+  unsigned long long peer_seq_ = 0;
+  unsigned int* peer_cnt_ = nullptr;
+  int* peer_err_ = nullptr;
+  long long peer_wait_ticks_ = 5LL * 100000000LL;   // 5 s of the 100 MHz wall clock
 };
 
 }  // namespace g2ohip

@@ -535,6 +535,8 @@ class ShardedBlockSolver:
         """Give the local solver its own communicator and let the library run the whole sharded solve and the LM scalars.
         kind "rccl": ncclCommInitRank inside the library (the unique id travels through torch.distributed once);
         "host": an all-reduce over host memory through torch.distributed (gloo) -- ranks sharing one GPU, tests;
+        "peer": mailboxes in device memory exported with hipIpc handles and written by the peers directly (opt-in; the handles
+        and the host scalars travel through torch.distributed);
         "auto": rccl when the process group's backend is nccl, host otherwise.  Returns True when attached."""
         if self.mode != "subtree" or self.x_exchange != "halo" or not hasattr(self.local, "solveSharded"):
             return False
@@ -556,12 +558,19 @@ class ShardedBlockSolver:
                 uid = self.local.commUniqueId()
             self.local.commInitRccl(self.rank, self.world, uid)
         else:
+            host_group = None
+            if have_pg and self.world > 1 and dist.get_backend() == "nccl":
+                host_group = dist.new_group(backend="gloo")     # (host memory does not travel through RCCL)
+
             def host_all_reduce(buf, op):
                 if self.world <= 1:
                     return
                 t = torch.from_numpy(buf)          # shares the pinned staging memory: reduced in place
-                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
-            self.local.commInitHost(self.rank, self.world, host_all_reduce)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=host_group)
+            if kind == "peer":
+                self.local.commInitPeer(self.rank, self.world, host_all_reduce)
+            else:
+                self.local.commInitHost(self.rank, self.world, host_all_reduce)
         self._lib_comm = kind
         return True
 

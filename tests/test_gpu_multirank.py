@@ -205,7 +205,7 @@ def test_sharded_matrix_free_pcg_matches_oracle(tmp_path, world):
     assert len(set(its)) == 1 and its[0] > 0                                      # every rank took the same decisions
 
 
-def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir, stall_rank=-1, options=""):
+def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir, stall_rank=-1, options="", lib_comm="host"):
     if options:
         os.environ["G2OHIP_OPTIONS"] = options
     if rank == stall_rank:       # this rank's dependency-driven launches give up at once (the safety net under test)
@@ -222,7 +222,7 @@ def _lm_worker(rank, world, port, P, L, huber, outliers, n_it, out_dir, stall_ra
         pr = ba_case(P, L, outlier_frac=outliers)
         s = D.ShardedBlockSolver(6, 3, rank=rank, world=world, comm=D.HostStagedComm(world), mode="subtree")
         s.setup_ba(pr, torch_device=dev, fused=True)
-        assert s.attach_library_comm("host")      # collectives inside libg2ohip (host callback: the ranks share one GPU)
+        assert s.attach_library_comm(lib_comm)    # collectives inside libg2ohip (host callback: the ranks share one GPU)
         if huber > 0:
             s.setRobustKernel(capi.KERNEL_HUBER, huber)
         g = D.ShardedBAGraph(s)
@@ -287,6 +287,31 @@ def test_sharded_lm_with_huber_matches_single_rank_and_oracle(tmp_path, world):
         cam_ok[free] = valid[pr["cam_hidx"][free]]
         assert relerr(z["cams"][cam_ok], cams1[cam_ok]) < 1e-6
     assert chis1[-1] < chis1[0]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_mailbox_exchange_equals_the_staged_one(tmp_path, world):
+    """g2ohip_comm_init_peer (opt-in): the all-reduces of the sharded solve as stores into the peers' device mailboxes (hipIpc handles)
+    plus a wait-and-add kernel, instead of RCCL or the host staging.  The ranks are processes sharing one GPU here (what can be
+    checked on this box: handles, sequence numbers, parities, slot sums); the Huber LM trajectory, the trial counts and the estimates
+    equal the ones of the staged exchange."""
+    import torch.multiprocessing as mp
+    P, L, huber, outliers, n_it = 400, 3600, 1.0, 0.05, 5
+    z = {}
+    for kind in ("host", "peer"):
+        d = os.path.join(str(tmp_path), kind)
+        os.makedirs(d)
+        mp.spawn(_lm_worker, args=(world, _free_port(), P, L, huber, outliers, n_it, d, -1, "", kind), nprocs=world, join=True)
+        z[kind] = [np.load(os.path.join(d, "lm%d.npz" % r)) for r in range(world)]
+    for r in range(world):
+        a, b = z["host"][r], z["peer"][r]
+        assert int(a["done"]) == int(b["done"]) and list(a["trials"]) == list(b["trials"])
+        assert np.allclose(a["chis"], b["chis"], rtol=1e-9, atol=0) and np.allclose(a["lams"], b["lams"], rtol=1e-9, atol=0)
+        assert relerr(b["pts"], a["pts"]) < 1e-8 and relerr(b["cams"], a["cams"]) < 1e-8
+        assert int(b["collectives"]) == 2
+    # every rank formed the same sums (slots added in rank order): the shared quantities are bit-identical across the ranks
+    for r in range(1, world):
+        assert np.array_equal(z["peer"][r]["chis"], z["peer"][0]["chis"]) and np.array_equal(z["peer"][r]["lams"], z["peer"][0]["lams"])
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -381,25 +406,26 @@ def test_library_comm_over_rccl_single_rank():
     assert relerr(x, o.x()) < dx_tolerance(o)[0] and abs(sc - o.compute_scale(7.0)) <= 1e-6 * abs(sc)
 
 
-@pytest.mark.parametrize("ranks,poses", [(2, 3000), (8, 8000)])
-def test_bench_launches_its_own_ranks(ranks, poses):
+@pytest.mark.parametrize("ranks,poses,comm", [(2, 3000, "staged"), (8, 8000, "staged"), (4, 4000, "peer")])
+def test_bench_launches_its_own_ranks(ranks, poses, comm):
     """Plain `python bench.py --gpus N` (no launcher in front, WORLD_SIZE unset) starts one rank per GPU itself; on this
     1-GPU box the ranks share cuda:0 and the exchange is staged through gloo.  Rank 0 prints the one JSON line with
     the collectives' kind, a kernel table per rank and the three all-reduce times.  N = 8 is the shape of the driver's scaling
     run: rank -> device mapping, the partition at world 8 (every rank owns poses) and the JSON line are proven here, and the
-    gathered pose increment is held to the CPU oracle on the whole graph (--check-oracle)."""
+    gathered pose increment is held to the CPU oracle on the whole graph (--check-oracle).  `--comm peer`: the same through the
+    library's peer-mailbox exchange (the mailboxes of all ranks on the one device here)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--comm", "staged", "--poses", str(poses),
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--comm", comm, "--poses", str(poses),
                         "--landmarks", str(10 * poses), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--check-oracle"], env=env,
                        cwd=root, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [q for q in r.stdout.splitlines() if q.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == ranks and out["solve_ok"] and out["collectives"] == "host"
+    assert out["n_gpus"] == ranks and out["solve_ok"] and out["collectives"] == ("peer" if comm == "peer" else "host")
     assert len(out["per_rank_kernel_ms"]) == ranks
     assert len(out["all_reduce_ms"]) == 3 and all(len(v) == ranks and v[0] is not None for v in out["all_reduce_ms"].values())
     per_rank = out["shard"]["poses_per_rank"]          # [shared, rank 0, rank 1, ...]
