@@ -149,7 +149,7 @@ class BlockSolver {
                                            // subtree roots (after the own subtrees) whenever only the shared top of the tree consumes them
   size_t sharded_collectives = 0;          // all-reduces issued by the last solve_sharded_once (stats)
   int sharded_graph = 1;                   // solve_sharded as ONE hipGraph (the collectives inside it): 1 = when nothing has to cross the
-                                           // host (comm_emulate), 2 = with RCCL as well (ncclAllReduce captured into the graph; not
+                                           // host (comm_emulate, the peer mailboxes: their two kernels per all-reduce), 2 = with RCCL as well (ncclAllReduce captured into the graph; not
                                            // exercised on hardware here -- opt-in); 0 = one graph per phase, plain launches in between
   void invalidate_graphs();
   int linear_solver = 0;                   // 0: multifrontal block Cholesky, 1: block-Jacobi PCG (LinearSolverPCG) on Hschur,

@@ -3982,7 +3982,7 @@ int BlockSolver::solve_sharded_once() {
   // (0.4 ms in total) and the launch boundaries between the phases were a third of its time.  The events of the kernel
   // timers cannot live inside a captured graph: with profiling on the phases run as before.
   const bool one_graph = sharded_graph > 0 && use_graph && !prof.enabled && !profiling &&
-                         ((comm.kind() == Comm::kNone) || (comm.kind() == Comm::kRccl && sharded_graph >= 2));
+                         ((comm.kind() == Comm::kNone) || comm.kind() == Comm::kPeer || (comm.kind() == Comm::kRccl && sharded_graph >= 2));
   if (getenv("G2OHIP_GRAPH_DEBUG")) {
     static int once = 0;
     if (once++ < 8) fprintf(stderr, "solve_sharded: one_graph %d (sharded_graph %d use_graph %d prof %d profiling %d comm %d) state %d\n", (int)one_graph, sharded_graph,

@@ -39,8 +39,12 @@ __device__ __forceinline__ unsigned long long* peer_seq(double* box, int parity,
 }
 
 // blockIdx.y = peer: this rank's payload into its slot of the peer's mailbox; the last workgroup of a peer publishes the sequence number
-__global__ void __launch_bounds__(256) peer_put_kernel(PeerTable T, const double* __restrict__ src, size_t n, size_t cap, int world, int rank, int parity,
-                                                       unsigned long long seq, unsigned int* __restrict__ cnt) {
+// The sequence number of a call lives in device memory (*dev_seq + 1; bumped by the last workgroup of the call's peer_sum_kernel), not
+// in a kernel argument: the two launches can be replayed from a captured graph.
+__global__ void __launch_bounds__(256) peer_put_kernel(PeerTable T, const double* __restrict__ src, size_t n, size_t cap, int world, int rank,
+                                                       const unsigned long long* __restrict__ dev_seq, unsigned int* __restrict__ cnt) {
+  const unsigned long long seq = __hip_atomic_load(dev_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int parity = (int)(seq & 1);
   const int q = blockIdx.y;
   double* dst = T.box[q] + kPeerHeader + ((size_t)parity * world + rank) * cap;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
@@ -58,8 +62,10 @@ __global__ void __launch_bounds__(256) peer_put_kernel(PeerTable T, const double
 
 // waits until every rank's slot carries `seq`, then dst = slot 0 (+|max) slot 1 ... in rank order (bit-identical on all ranks).
 // The wait is bounded (ticks of the 100 MHz wall clock): a peer that never arrives raises *err instead of hanging the GPU.
-__global__ void __launch_bounds__(256) peer_sum_kernel(double* box, double* __restrict__ dst, size_t n, size_t cap, int world, int parity, unsigned long long seq,
-                                                       int op, long long tick_limit, int* err) {
+__global__ void __launch_bounds__(256) peer_sum_kernel(double* box, double* __restrict__ dst, size_t n, size_t cap, int world, unsigned long long* dev_seq,
+                                                       unsigned int* __restrict__ cnt, int op, long long tick_limit, int* err) {
+  const unsigned long long seq = __hip_atomic_load(dev_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int parity = (int)(seq & 1);
   if ((int)threadIdx.x < world) {
     const unsigned long long* fl = peer_seq(box, parity, world, threadIdx.x);
     const long long t0 = wall_clock64();
@@ -82,6 +88,14 @@ __global__ void __launch_bounds__(256) peer_sum_kernel(double* box, double* __re
       acc = op == 1 ? fmax(acc, v) : acc + v;
     }
     dst[i] = acc;
+  }
+  __syncthreads();   // (every thread of the workgroup has read the sequence number)
+  if (threadIdx.x == 0) {
+    const unsigned int done = __hip_atomic_fetch_add(cnt + kPeerMaxWorld, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (done == gridDim.x) {   // the last workgroup of the call: the next call's number
+      __hip_atomic_store(cnt + kPeerMaxWorld, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dev_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 }  // namespace
@@ -154,8 +168,9 @@ class Comm {
     if (std::getenv("G2OHIP_COMM_DEBUG")) fprintf(stderr, "comm_init_peer: rank %d mailbox %s, %zu KB\n", rank, have ? "uncached (fine-grained)" : "plain device memory", doubles / 128);
     G2OHIP_HIP_CHECK(hipMemset(p, 0, doubles * sizeof(double)));
     G2OHIP_HIP_CHECK(hipDeviceSynchronize());
-    G2OHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&peer_cnt_), kPeerMaxWorld * sizeof(unsigned int)));
-    G2OHIP_HIP_CHECK(hipMemset(peer_cnt_, 0, kPeerMaxWorld * sizeof(unsigned int)));
+    // [0, 16): finished workgroups of a put per peer; [16]: ... of a sum; behind them (8-byte aligned) the sequence number of the last call
+    G2OHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&peer_cnt_), (kPeerMaxWorld + 4) * sizeof(unsigned int)));
+    G2OHIP_HIP_CHECK(hipMemset(peer_cnt_, 0, (kPeerMaxWorld + 4) * sizeof(unsigned int)));
     G2OHIP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&peer_err_), sizeof(int), hipHostMallocMapped));
     *peer_err_ = 0;
     // all-gather of the handles through the host all-reduce: one double per byte, a rank fills its own row (the call is also
@@ -174,7 +189,6 @@ class Comm {
       G2OHIP_HIP_CHECK(hipIpcOpenMemHandle(&pq, h, hipIpcMemLazyEnablePeerAccess));
       peer_box_[q] = static_cast<double*>(pq);
     }
-    peer_seq_ = 0;
     kind_ = kPeer;
     // nobody stores into a mailbox before every rank has mapped them all (a peer's first put may otherwise race a late memset-free
     // start-up elsewhere: cheap insurance)
@@ -224,12 +238,11 @@ class Comm {
       for (int q = 0; q < kPeerMaxWorld; ++q) T.box[q] = q < world_ ? peer_box_[q] : nullptr;
       for (size_t off = 0; off < n; off += peer_cap_) {
         const size_t m = std::min(peer_cap_, n - off);
-        const unsigned long long seq = ++peer_seq_;
-        const int parity = (int)(seq & 1);
+        unsigned long long* dev_seq = reinterpret_cast<unsigned long long*>(peer_cnt_ + kPeerMaxWorld + 2);
         const int nb = (int)std::min<size_t>(64, (m + 1023) / 1024);
-        hipLaunchKernelGGL(peer_put_kernel, dim3(nb, world_), dim3(256), 0, st, T, dev + off, m, peer_cap_, world_, rank_, parity, seq, peer_cnt_);
-        hipLaunchKernelGGL(peer_sum_kernel, dim3(nb), dim3(256), 0, st, peer_box_[rank_], dev + off, m, peer_cap_, world_, parity, seq, op, peer_wait_ticks_,
-                           peer_err_);
+        hipLaunchKernelGGL(peer_put_kernel, dim3(nb, world_), dim3(256), 0, st, T, dev + off, m, peer_cap_, world_, rank_, dev_seq, peer_cnt_);
+        hipLaunchKernelGGL(peer_sum_kernel, dim3(nb), dim3(256), 0, st, peer_box_[rank_], dev + off, m, peer_cap_, world_, dev_seq, peer_cnt_, op,
+                           peer_wait_ticks_, peer_err_);
       }
       G2OHIP_HIP_CHECK(hipGetLastError());
       return;
@@ -310,7 +323,6 @@ class Comm {
   DevBuf<double> scal_;
   double* peer_box_[kPeerMaxWorld] = {nullptr};   // [rank_] = own mailbox, the others mapped through hipIpcOpenMemHandle
   size_t peer_cap_ = 0;
-  unsigned long long peer_seq_ = 0;
   unsigned int* peer_cnt_ = nullptr;
   int* peer_err_ = nullptr;
   long long peer_wait_ticks_ = 5LL * 100000000LL;   // 5 s of the 100 MHz wall clock

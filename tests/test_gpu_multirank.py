@@ -301,7 +301,9 @@ def test_peer_mailbox_exchange_equals_the_staged_one(tmp_path, world):
     for kind in ("host", "peer"):
         d = os.path.join(str(tmp_path), kind)
         os.makedirs(d)
-        mp.spawn(_lm_worker, args=(world, _free_port(), P, L, huber, outliers, n_it, d, -1, "", kind), nprocs=world, join=True)
+        # (graph replay on: with the mailboxes the whole sharded solve, the two launches of every all-reduce included, is ONE captured
+        # graph -- the sequence numbers live in device memory)
+        mp.spawn(_lm_worker, args=(world, _free_port(), P, L, huber, outliers, n_it, d, -1, "use_graph=1", kind), nprocs=world, join=True)
         z[kind] = [np.load(os.path.join(d, "lm%d.npz" % r)) for r in range(world)]
     for r in range(world):
         a, b = z["host"][r], z["peer"][r]
