@@ -524,6 +524,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "band_kernel")) s->impl->chol_opt.band_kernel = (int)value;
   else if (!std::strcmp(name, "overlap_level_halves")) s->impl->chol_opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "lazy_level_joins")) s->impl->chol_opt.lazy_level_joins = (int)value;
+  else if (!std::strcmp(name, "big_gather")) s->impl->chol_opt.big_gather = (int)value;
   else if (!std::strcmp(name, "split_sweeps")) s->impl->chol_opt.split_sweeps = (int)value;
   else if (!std::strcmp(name, "merge_diag_panel")) s->impl->chol_opt.merge_diag_panel = (int)value;
   else if (!std::strcmp(name, "big_merge_tiles")) s->impl->chol_opt.big_merge_tiles = (int)value;
@@ -1022,6 +1023,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "band_kernel")) ls->opt.band_kernel = (int)value;
   else if (!std::strcmp(name, "overlap_level_halves")) ls->opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "lazy_level_joins")) ls->opt.lazy_level_joins = (int)value;
+  else if (!std::strcmp(name, "big_gather")) ls->opt.big_gather = (int)value;
   else if (!std::strcmp(name, "split_sweeps")) ls->opt.split_sweeps = (int)value;
   else if (!std::strcmp(name, "merge_diag_panel")) ls->opt.merge_diag_panel = (int)value;
   else if (!std::strcmp(name, "big_merge_tiles")) ls->opt.big_merge_tiles = (int)value;

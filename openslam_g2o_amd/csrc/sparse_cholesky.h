@@ -67,6 +67,8 @@ struct CholOptions {
   int merge_backward_levels = 1;         // backward step of consecutive levels of scratch-slab fronts in ONE launch (workgroups wait for their parent front's flag)
   int split_sweeps = 1;                  // forward / backward step of scratch-slab fronts by several workgroups per front (256 boundary rows each)
   int split_sweeps_min_dim = 512;        // ... on levels whose largest such front has at least this many rows
+  int big_gather = 1;                    // scratch-slab levels in the merged pivot-block / panel launch: the children's update matrices are added where the
+                                         // frontal matrix is loaded (inverse block maps) instead of by one extend-add pass per child ordinal in front of it
   int lazy_level_joins = 1;              // ... the two streams wait for each other only where a front has a child on the other one (0: at every such level)
   int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
@@ -149,6 +151,8 @@ struct CholPlanDev {
   const ChildDesc* cdesc;
   const int* crel;
   const int* cmap;   // per parent: child's packed U block -> (row | col << 16) block of the parent front
+  const int* cinv;       // scratch-slab fronts whose children are gathered at load time: per child ordinal, front block -> the child's boundary block (-1: none)
+  const int* cinv_off;   // ... per front: offset into cinv (-1: no table), [child][ns + nb]
   const int* tri;    // row-major enumeration of a lower triangle: idx -> (i | j << 16)
   const int *f_ns, *f_nb, *f_c0, *rows_off, *rows, *rel_off, *rel;
   const long long *L_off, *U_off, *w_off;
@@ -275,7 +279,7 @@ class SparseCholesky {
   int spinv_npiv_max_ = 0;
   DevBuf<FrontRec> d_rec;
   DevBuf<ChildDesc> d_cdesc;
-  DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts;
+  DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts, d_cinv, d_cinv_off;
   DevBuf<double> d_L, d_U, d_w, d_y, d_xp, d_scratch;
   int hz_begin_[2] = {0, 0}, hz_count_[2] = {0, 0}, ha_begin_[2] = {0, 0}, ha_count_[2] = {0, 0};   // phase-wide fill / assembly chunks (d_big_tiles)
   // merged backward launches: per phase, runs of consecutive levels (top level first) of scratch-slab fronts only
@@ -315,6 +319,7 @@ class SparseCholesky {
     // qualifies by its structure; fork = an LDS front of it has a child that ran on the main stream since the side stream last
     // waited for it; join = a front of the main part has a child that ran on the side stream since the main stream last did
     bool split_ok = false, fork = false, join = false;
+    bool gather = false;                                 // every scratch-slab front of the level can gather its children's update matrices at load time (cinv tables): no extend-add passes
   };
   std::vector<LevelLaunch> launches_[2];   // [0] own tasks, [1] shared top-of-tree tasks
   struct FactorGroup { LevelLaunch LL; int first_level, last_level; bool dep; int band_count = 0, band_rec0 = 0, band_ent_cap = 0, band_tab_cap = 0; };

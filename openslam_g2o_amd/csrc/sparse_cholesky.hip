@@ -14,6 +14,9 @@ namespace g2ohip {
 
 constexpr int kFactorThreads = 256;
 constexpr int kFwdChildren = 4;   // fused forward sweep: children per front handled by the factor kernel
+constexpr int kGatherChildren = 4;   // scratch-slab fronts: children whose update matrices the merged level launch gathers at load time
+constexpr int kGatherInts = 1024;                      // ... inverse maps of a front (children x blocks) staged in LDS
+constexpr int kGatherLdsOff = 3 * 64 * 65 + 64 + 128;   // ... behind the level launch's own regions (doubles)
 constexpr int kFactorThreadsGlobal = 512;
 constexpr int kChainU = 6;  // doubles per thread that carry an update matrix from one chain front to the next
 // register-resident wave kernel (wave_front.inc): limits of a front
@@ -991,6 +994,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       }
     }
   // --- trailing-update tiles of the scratch-slab fronts (big_front_update_kernel), per level launch
+  std::vector<int> cinv, cinv_off(nf, -1);
   {
     std::vector<int4> bt;
     int sw_max = 0;
@@ -1033,6 +1037,22 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         }
         LL.ba_count = (int)bt.size() - LL.ba_begin;
         if (max_children > 16) LL.big_ok = false;   // (one launch per child ordinal)
+        // inverse block maps for the gather at load time (big_level_kernel): front block -> child's boundary block
+        LL.gather = LL.big_ok && max_children <= kGatherChildren;
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count && LL.gather; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          const int nch = S.child_off[f + 1] - S.child_off[f], mb = S.f_ns[f] + S.f_nb[f];
+          if (nch == 0 || inpl_prev[f] >= 0) continue;
+          if (nch * mb > kGatherInts) LL.gather = false;   // (the maps of a front are staged in LDS)
+          cinv_off[f] = (int)cinv.size();
+          for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) {
+            const int c = S.children[ch];
+            const size_t b0 = cinv.size();
+            cinv.resize(b0 + mb, -1);
+            const int* rl = S.rel.data() + S.rel_off[c];
+            for (int k = 0; k < S.f_nb[c]; ++k) cinv[b0 + rl[k]] = k;
+          }
+        }
         // extend-add passes: pass c handles child c of every front (the children of one front may hit the same blocks)
         LL.be_pass.clear();
         for (int c = 0; c < max_children && LL.big_ok; ++c) {
@@ -1569,6 +1589,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_rec.upload(recs, st);
   d_cdesc.upload(cdesc, st);
   d_crel.upload(crel, st);
+  if (cinv.empty()) cinv.push_back(-1);
+  d_cinv.upload(cinv, st);
+  d_cinv_off.upload(cinv_off, st);
   d_cmap.upload(cmap, st);
   d_tri.upload(tri, st);
   // --- multi-GPU exchange plan: update matrices / vectors of the subtree roots, solution mask
@@ -1669,6 +1692,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.rec = d_rec.p;
   plan_.cdesc = d_cdesc.p;
   plan_.crel = d_crel.p;
+  plan_.cinv = d_cinv.p;
+  plan_.cinv_off = d_cinv_off.p;
   plan_.cmap = d_cmap.p;
   plan_.tri = d_tri.p;
   plan_.f_ns = d_f_ns.p;
@@ -2948,6 +2973,39 @@ __device__ __forceinline__ void fwd_children_apply(const CholPlanDev& P, const F
   }
 }
 
+// Children's update matrices gathered where the frontal matrix is loaded (big_level_kernel<.., GATH>) instead of by one extend-add
+// pass per child ordinal in front of the level's launch (two launches of ~6 us on every level of a pose graph's chain): the value at
+// front position (r, c), block of r >= block of c, plus the children's entries there in child order -- the very sums the passes
+// form, bit for bit.  inv: per child ordinal, front block -> the child's boundary block or -1 (CholPlanDev::cinv).
+struct GatherCtx {
+  const int* inv;   // (in LDS: staged by gather_stage)
+  const ChildDesc* cd;
+  const double* U;
+  int nch, mb;
+};
+// whole workgroup; the caller puts a barrier between this and the first gather_add
+__device__ __forceinline__ GatherCtx gather_stage(const CholPlanDev& P, int f, const FrontRec& rec, int* sinv) {
+  GatherCtx g;
+  const int off = P.cinv_off[f];
+  g.nch = off >= 0 ? rec.child_cnt : 0;
+  g.mb = rec.ns + rec.nb;
+  g.inv = sinv;
+  g.cd = P.cdesc + rec.child_off;
+  g.U = P.U;
+  const int* src = P.cinv + max(off, 0);
+  for (int i = threadIdx.x; i < g.nch * g.mb; i += blockDim.x) sinv[i] = src[i];
+  return g;
+}
+// branch-free (the loads of a child's entries for all the caller's values are in flight together): the entry or, where the child
+// has none, a dummy load of its first double and the value unchanged
+template <int BS>
+__device__ __forceinline__ double gather_child(const GatherCtx& g, int ch, const double* __restrict__ Uc, double v, int rb, int cb, int e) {
+  const int ci = g.inv[ch * g.mb + rb], cj = g.inv[ch * g.mb + cb];
+  const bool ok = (ci | cj) >= 0;
+  const double u = Uc[ok ? (size_t)(ci * (ci + 1) / 2 + cj) * (BS * BS) + e : (size_t)0];
+  return ok ? v + u : v;
+}
+
 // Panel solve and trailing update of the scratch-slab fronts of one level in ONE launch (two otherwise: on the critical
 // path of a pose graph every launch is ~5 us of start-up next to a few us of work).  A workgroup owns a 64 x 64 tile of
 // a trailing matrix: it solves ITS 2 x 64 panel rows against L11' itself (the rows of a tile are solved again by the
@@ -2962,7 +3020,7 @@ __device__ __forceinline__ void fwd_children_apply(const CholPlanDev& P, const F
 // w = (children's w) - L21 y.  Tile (0, 0) stores y.  (Fronts without boundary rows have no tiles: big_diag_mfma_kernel.)
 // DEP (big_level_kernel: pivot blocks and panel tiles of a level in ONE launch): the tile waits for its front's flag -- with
 // its panel rows, the children's vectors and the records already requested -- and reads L11 with device-coherent loads.
-template <int BS, bool FWD, bool DEP>
+template <int BS, bool FWD, bool DEP, bool GATH = false>
 __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 td, double* __restrict__ scratch,
                                                const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
                                                const double* __restrict__ bperm, double* __restrict__ yout, double* psm, const int* flag) {
@@ -3002,6 +3060,35 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
   double x[NX];
 #pragma unroll
   for (int c = 0; c < NX; ++c) x[c] = (rok && c < n) ? F[(size_t)(n + rglb) + (size_t)ld * c] : 0.0;
+  GatherCtx gc{nullptr, nullptr, nullptr, 0, 0};
+  if (GATH) {   // the children's entries of this panel row (the extend-add passes' sums: own value first, then child by child)
+    gc = gather_stage(P, f, rec, reinterpret_cast<int*>(psm + kGatherLdsOff));
+    __syncthreads();
+    const int rb = ns + rglb / BS, re = rglb % BS;
+#ifdef G2OHIP_GATH_ABL
+    if (!(G2OHIP_GATH_ABL & 2))
+#endif
+    for (int ch = 0; ch < gc.nch; ++ch) {
+      const int ci = rok ? gc.inv[ch * gc.mb + rb] : -1;
+      const double* Uc = gc.U + gc.cd[ch].U_off;
+      // (all the child's entries of the row requested before the first one is added: one round trip per child, not one per block)
+      double u[NX];
+      unsigned okm = 0;
+#pragma unroll
+      for (int cb = 0; cb < MAXB; ++cb) {
+        const int cj = cb < ns ? gc.inv[ch * gc.mb + cb] : -1;
+        const bool ok = (ci | cj) >= 0;
+        okm |= ok ? 1u << cb : 0u;
+        const double* ub = Uc + (ok ? (size_t)(ci * (ci + 1) / 2 + cj) * BB + re : (size_t)0);
+#pragma unroll
+        for (int e = 0; e < BS; ++e) u[cb * BS + e] = ub[ok ? BS * e : 0];
+      }
+#pragma unroll
+      for (int cb = 0; cb < MAXB; ++cb)
+#pragma unroll
+        for (int e = 0; e < BS; ++e) x[cb * BS + e] = ((okm >> cb) & 1u) ? x[cb * BS + e] + u[cb * BS + e] : x[cb * BS + e];
+    }
+  }
   // this wave's part of the trailing tile (final before this launch: earlier levels and the extend-add passes wrote it):
   // requested now, consumed after the update -- one exposed round trip less per level (not with 7 x 7 blocks: no registers left)
   constexpr bool kPreTile = BS != 7;
@@ -3018,6 +3105,30 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
           const int r = R0_ + 16 * a + lr_, c = C0_ + 16 * b + lk_ + 4 * v;
           fpre[(a * 2 + b) * 4 + v] = (r < mt && c < climit && r / BS >= c / BS) ? F[(size_t)(n + r) + (size_t)ld * (n + c)] : 0.0;
         }
+#ifdef G2OHIP_GATH_ABL
+    if (!(G2OHIP_GATH_ABL & 4))
+#endif
+    if (GATH)
+      for (int ch = 0; ch < gc.nch; ++ch) {   // (requested together, added afterwards: one round trip per child)
+        const double* Uc = gc.U + gc.cd[ch].U_off;
+        double u[16];
+        unsigned okm = 0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int r = min(R0_ + 16 * a + lr_, mt - 1), c = min(C0_ + 16 * b + lk_ + 4 * v, mt - 1);
+              const bool in = R0_ + 16 * a + lr_ < mt && C0_ + 16 * b + lk_ + 4 * v < climit && r / BS >= c / BS;
+              const int ci = gc.inv[ch * gc.mb + ns + r / BS], cj = gc.inv[ch * gc.mb + ns + c / BS];
+              const bool ok = in && (ci | cj) >= 0;
+              okm |= ok ? 1u << ((a * 2 + b) * 4 + v) : 0u;
+              u[(a * 2 + b) * 4 + v] = Uc[ok ? (size_t)(ci * (ci + 1) / 2 + cj) * BB + (r % BS) + BS * (c % BS) : (size_t)0];
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fpre[i] = ((okm >> i) & 1u) ? fpre[i] + u[i] : fpre[i];
+      }
   }
 #ifdef G2OHIP_CHOL_STAMPS
   int nst_ = 0;
@@ -3158,7 +3269,10 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
             if (r < mt && c < climit) {
               const int ib = r / BS, jb = c / BS;
               if (ib >= jb) {
-                const double y = (kPreTile ? fpre[(a * 2 + b) * 4 + v] : F[(size_t)(n + r) + (size_t)ld * (n + c)]) - acc[a][b][v];
+                double y0 = kPreTile ? fpre[(a * 2 + b) * 4 + v] : F[(size_t)(n + r) + (size_t)ld * (n + c)];
+                if (GATH && !kPreTile)
+                  for (int ch = 0; ch < gc.nch; ++ch) y0 = gather_child<BS>(gc, ch, gc.U + gc.cd[ch].U_off, y0, ns + ib, ns + jb, (r - ib * BS) + BS * (c - jb * BS));
+                const double y = y0 - acc[a][b][v];
                 if (inplace) F[(size_t)(n + r) + (size_t)ld * (n + c)] = y;
                 else U[(size_t)(ib * (ib + 1) / 2 + jb) * BB + (r - ib * BS) + BS * (c - jb * BS)] = y;
               }
@@ -3750,7 +3864,7 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
 // LDS copy of the finished pivot block with the operation order of front_forward_kernel.
 // COH (big_level_kernel): L11 and the reciprocal diagonal go to memory with device-coherent stores -- the panel tiles of the
 // same launch read them.  lds: 512 doubles (FWD: 4 800).
-template <int BS, bool FWD, bool COH>
+template <int BS, bool FWD, bool COH, bool GATH = false>
 __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const int slot, double* __restrict__ scratch,
                                                    const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
                                                    const double* __restrict__ bperm, double* __restrict__ yout, double* lds) {
@@ -3781,6 +3895,33 @@ __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const i
   // rows are register 0 of an MFMA and at once the operand of the update (the k-block of band_chain.inc; four waves with
   // two barriers per step took 1.25 us per step, this one 0.5).  Tile (ti, tj), ti <= tj, is S[tj (tj + 1) / 2 + ti].
   bool bad = false;
+  if (GATH) {   // the pivot block with the children's entries added, by the whole workgroup, into LDS (the later L11 copy's place)
+    const GatherCtx gc = gather_stage(P, f, rec, reinterpret_cast<int*>(lds + kGatherLdsOff));
+    __syncthreads();
+    constexpr int UG = 16;   // 64 * 64 / 256
+    double t[UG];
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const int r = tid & 63, c = (tid >> 6) + 4 * u;
+      t[u] = (r < n && c <= r) ? F[(size_t)r + (size_t)ld * c] : 0.0;
+    }
+#ifdef G2OHIP_GATH_ABL
+    if (!(G2OHIP_GATH_ABL & 1))
+#endif
+    for (int ch = 0; ch < gc.nch; ++ch) {
+      const double* Uc = gc.U + gc.cd[ch].U_off;
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        const int r = min(tid & 63, n - 1), c = min((tid >> 6) + 4 * u, n - 1);
+        const bool in = (tid & 63) < n && (tid >> 6) + 4 * u <= (tid & 63);
+        const double g_ = gather_child<BS>(gc, ch, Uc, t[u], r / BS, in ? c / BS : r / BS, (r % BS) + BS * (c % BS));
+        t[u] = in ? g_ : t[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UG; ++u) L11s[(tid & 63) + 65 * ((tid >> 6) + 4 * u)] = t[u];
+    __syncthreads();
+  }
   if (w == 0) {
     wv_d4 S[NT];
 #pragma unroll
@@ -3791,7 +3932,7 @@ __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const i
         for (int v = 0; v < 4; ++v) {
           const int r = 16 * ti + lk + 4 * v, c = 16 * tj + lr;
           const int a = min(r, c), b = max(r, c);                       // F holds the lower triangle
-          S[tj * (tj + 1) / 2 + ti][v] = (b < n) ? F[(size_t)b + (size_t)ld * a] : 0.0;
+          S[tj * (tj + 1) / 2 + ti][v] = (b < n) ? (GATH ? L11s[b + 65 * a] : F[(size_t)b + (size_t)ld * a]) : 0.0;
         }
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
@@ -3935,7 +4076,7 @@ __global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int s
 // blocks and raise their front's flag, the others are the tiles of big_panel_kernel and wait for it -- their start-up (tile
 // and front records, panel rows, children's vectors: three to four dependent round trips) runs next to the pivot block
 // instead of behind it.  The pivot-block workgroups come first in dispatch order: no deadlock.
-template <int BS, bool FWD>
+template <int BS, bool FWD, bool GATH>
 __global__ void __launch_bounds__(256) big_level_kernel(CholPlanDev P, int slot0, int ndiag, const int4* __restrict__ tiles,
                                                        double* __restrict__ scratch, const long long* __restrict__ scratch_off,
                                                        const int* __restrict__ scratch_ld, const double* __restrict__ bperm,
@@ -3943,12 +4084,12 @@ __global__ void __launch_bounds__(256) big_level_kernel(CholPlanDev P, int slot0
   extern __shared__ __attribute__((aligned(16))) double psm[];
   if ((int)blockIdx.x < ndiag) {
     const int slot = slot0 + blockIdx.x;
-    big_diag_mfma_body<BS, FWD, true>(P, slot, scratch, scratch_off, scratch_ld, bperm, yout, psm);
+    big_diag_mfma_body<BS, FWD, true, GATH>(P, slot, scratch, scratch_off, scratch_ld, bperm, yout, psm);
     __builtin_amdgcn_s_waitcnt(0);   // L11 and the reciprocal diagonal have been acknowledged at the device-coherent level
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag + P.slots[slot].x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    big_panel_body<BS, FWD, true>(P, tiles[blockIdx.x - ndiag], scratch, scratch_off, scratch_ld, bperm, yout, psm, flag);
+    big_panel_body<BS, FWD, true, GATH>(P, tiles[blockIdx.x - ndiag], scratch, scratch_off, scratch_ld, bperm, yout, psm, flag);
   }
 }
 
@@ -3965,6 +4106,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   bool fuse_panel;   // big_panel_kernel instead of big_trsm_kernel + big_front_update_kernel
   bool mfma_diag;    // big_diag_mfma_kernel instead of big_diag_kernel
   int merge_tiles = 256;   // the fused panel kernel on levels of at most this many tiles (CholOptions::big_merge_tiles)
+  bool gather = false;     // the merged level launch gathers the children's update matrices itself: no extend-add passes (LevelLaunch::gather)
 };
 
 __global__ void __launch_bounds__(256) fill_zero_kernel(double* __restrict__ p, size_t n) {
@@ -4032,19 +4174,26 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
       hipLaunchKernelGGL((big_assemble_kernel<BS, VIRT>), dim3(big.ba_count), dim3(256), 0, st, P, big.chunks + big.ba_begin, dA, d_scratch,
                          d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_assemble_kernel");
-    for (const auto& pass : *big.be_pass)
-      if (pass.second > 0)
-        hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
-                           d_scratch_off);
+    const bool level_launch = big.flag && big.mfma_diag && big.fuse_panel && bt_count > 0 && bt_count <= big.merge_tiles;
+    bool any_pass = false;
+    for (const auto& pass : *big.be_pass) any_pass = any_pass || pass.second > 0;
+    const bool gather = level_launch && big.gather && any_pass;   // (the level's launch adds the children's update matrices where it loads the fronts)
+    if (!gather)
+      for (const auto& pass : *big.be_pass)
+        if (pass.second > 0)
+          hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
+                             d_scratch_off);
     G2OHIP_LAUNCH_CHECK("big_extend_add_kernel");
-    if (big.flag && big.mfma_diag && big.fuse_panel && bt_count > 0 && bt_count <= big.merge_tiles) {
-      const size_t shp = (size_t)(3 * 64 * 65 + 64 + 128) * sizeof(double);   // (the pivot-block role needs 4 800 doubles of it)
-      if (big.fwd)
-        hipLaunchKernelGGL((big_level_kernel<BS, true>), dim3(glb_count + bt_count), dim3(256), shp, st, P, glb_begin, glb_count, big_tiles, d_scratch,
-                           d_scratch_off, big.ld, bperm, yout, big.flag);
-      else
-        hipLaunchKernelGGL((big_level_kernel<BS, false>), dim3(glb_count + bt_count), dim3(256), shp, st, P, glb_begin, glb_count, big_tiles, d_scratch,
-                           d_scratch_off, big.ld, (const double*)nullptr, (double*)nullptr, big.flag);
+    if (level_launch) {
+      const size_t shp = (size_t)(3 * 64 * 65 + 64 + 128) * sizeof(double) + (gather ? kGatherInts * sizeof(int) : 0);   // (the pivot-block role needs 4 800 doubles of it)
+#define G2OHIP_BIG_LEVEL(FW_, GA_, B_, Y_)                                                                                                     \
+  hipLaunchKernelGGL((big_level_kernel<BS, FW_, GA_>), dim3(glb_count + bt_count), dim3(256), shp, st, P, glb_begin, glb_count, big_tiles, d_scratch, \
+                     d_scratch_off, big.ld, B_, Y_, big.flag)
+      if (big.fwd && gather) G2OHIP_BIG_LEVEL(true, true, bperm, yout);
+      else if (big.fwd) G2OHIP_BIG_LEVEL(true, false, bperm, yout);
+      else if (gather) G2OHIP_BIG_LEVEL(false, true, (const double*)nullptr, (double*)nullptr);
+      else G2OHIP_BIG_LEVEL(false, false, (const double*)nullptr, (double*)nullptr);
+#undef G2OHIP_BIG_LEVEL
       G2OHIP_LAUNCH_CHECK("big_level_kernel");
       return;
     }
@@ -4170,7 +4319,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
                       LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL),
-                      (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, merge_tiles_of(LL)};
+                      (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, merge_tiles_of(LL), LL.gather && opt.big_gather != 0};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
@@ -4254,12 +4403,18 @@ void SparseCholesky::prepare_kernels() {
     (void)hipFuncSetAttribute((const void*)big_panel_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)big_panel_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)big_panel_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)big_level_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)big_level_kernel<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)big_level_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)big_level_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)big_level_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)big_level_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<3, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<6, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<6, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<7, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<7, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<3, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<6, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<7, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)big_level_kernel<7, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipGetLastError();
     attr_done = true;
   }

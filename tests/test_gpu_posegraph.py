@@ -232,18 +232,22 @@ def test_robust_kernels_on_the_loop_closures_only_stay_one_device_set():
     assert s.chi2() > robust * (1 + 1e-6)
 
 
-def test_lazy_stream_joins_of_split_levels_equal_the_joins_at_every_level():
-    """Levels with LDS fronts AND scratch-slab fronts run on two streams (sparse_cholesky.hip: LevelLaunch::fork / join): with
-    `lazy_level_joins` the streams wait for each other only where a front has a child on the other one.  Same kernels, same operation
-    order: the solutions are bit-identical to the ones with a fork and a join at every such level, with and without graph replay,
-    and repeatable (a missing dependency would show as a race)."""
+def test_lazy_stream_joins_and_gathered_children_equal_the_plain_level_schedule():
+    """Two schedule options of the scratch-slab levels (sparse_cholesky.hip), both with the same kernels' arithmetic in the same order:
+    * levels with LDS fronts AND scratch-slab fronts run on two streams (LevelLaunch::fork / join): with `lazy_level_joins` the streams
+      wait for each other only where a front has a child on the other one;
+    * `big_gather`: the merged pivot-block / panel launch of a level adds the children's update matrices where it loads the frontal
+      matrix (inverse block maps, own value first, then child by child) instead of one extend-add pass per child ordinal in front of it.
+    The solutions are bit-identical to the ones with a fork and a join at every such level and with the passes, with and without graph
+    replay, and repeatable (a missing dependency would show as a race)."""
     capi = _capi()
     g = sphere_golden()
     J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
     xs = []
-    for lazy, graph in ((0, 0), (1, 0), (1, 1), (0, 1)):
+    for lazy, gather, graph in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 0, 1)):
         s = capi.HipBlockSolver(6, 3, 0)
         s.setOption("lazy_level_joins", lazy)
+        s.setOption("big_gather", gather)
         k = s.addEdgeSet(6, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
         s.buildStructure(g["nP"], 0, False)
         s.setEdgeData(k, J0, J1, g["omega"], err)
