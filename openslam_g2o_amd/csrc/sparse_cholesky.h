@@ -151,8 +151,9 @@ struct CholPlanDev {
   const ChildDesc* cdesc;
   const int* crel;
   const int* cmap;   // per parent: child's packed U block -> (row | col << 16) block of the parent front
-  const int* cinv;       // scratch-slab fronts whose children are gathered at load time: per child ordinal, front block -> the child's boundary block (-1: none)
-  const int* cinv_off;   // ... per front: offset into cinv (-1: no table), [child][ns + nb]
+  const int* cinv;         // scratch-slab fronts whose children are gathered at load time: per front a header (children, offsets of their update
+                           // matrices) and per child ordinal the map front block -> the child's boundary block (-1: none)
+  const int2* cinv_slot;   // ... per launch slot: (offset into cinv or -1, ints)
   const int* tri;    // row-major enumeration of a lower triangle: idx -> (i | j << 16)
   const int *f_ns, *f_nb, *f_c0, *rows_off, *rows, *rel_off, *rel;
   const long long *L_off, *U_off, *w_off;
@@ -279,7 +280,8 @@ class SparseCholesky {
   int spinv_npiv_max_ = 0;
   DevBuf<FrontRec> d_rec;
   DevBuf<ChildDesc> d_cdesc;
-  DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts, d_cinv, d_cinv_off;
+  DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts, d_cinv;
+  DevBuf<int2> d_cinv_slot;
   DevBuf<double> d_L, d_U, d_w, d_y, d_xp, d_scratch;
   int hz_begin_[2] = {0, 0}, hz_count_[2] = {0, 0}, ha_begin_[2] = {0, 0}, ha_count_[2] = {0, 0};   // phase-wide fill / assembly chunks (d_big_tiles)
   // merged backward launches: per phase, runs of consecutive levels (top level first) of scratch-slab fronts only

@@ -15,7 +15,8 @@ namespace g2ohip {
 constexpr int kFactorThreads = 256;
 constexpr int kFwdChildren = 4;   // fused forward sweep: children per front handled by the factor kernel
 constexpr int kGatherChildren = 4;   // scratch-slab fronts: children whose update matrices the merged level launch gathers at load time
-constexpr int kGatherInts = 1024;                      // ... inverse maps of a front (children x blocks) staged in LDS
+constexpr int kGatherInts = 1024;                      // ... gather table of a front (header + children x blocks) staged in LDS
+constexpr int kGatherHeader = 16;                      // ... its header: children, offsets of their update matrices
 constexpr int kGatherLdsOff = 3 * 64 * 65 + 64 + 128;   // ... behind the level launch's own regions (doubles)
 constexpr int kFactorThreadsGlobal = 512;
 constexpr int kChainU = 6;  // doubles per thread that carry an update matrix from one chain front to the next
@@ -994,7 +995,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
       }
     }
   // --- trailing-update tiles of the scratch-slab fronts (big_front_update_kernel), per level launch
-  std::vector<int> cinv, cinv_off(nf, -1);
+  std::vector<int> cinv;
+  std::vector<int2> cinv_slot(S.level_fronts.size(), make_int2(-1, 0));   // per launch slot: (offset into cinv, ints) of the front's gather table
   {
     std::vector<int4> bt;
     int sw_max = 0;
@@ -1043,15 +1045,19 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
           const int nch = S.child_off[f + 1] - S.child_off[f], mb = S.f_ns[f] + S.f_nb[f];
           if (nch == 0 || inpl_prev[f] >= 0) continue;
-          if (nch * mb > kGatherInts) LL.gather = false;   // (the maps of a front are staged in LDS)
-          cinv_off[f] = (int)cinv.size();
+          if (kGatherHeader + nch * mb > kGatherInts) LL.gather = false;   // (the table of a front is staged in LDS)
+          // table: [0] children, [1 + 2 c], [2 + 2 c] offset of child c's update matrix (low, high word), [kGatherHeader + c mb + b] the maps
+          const size_t t0 = cinv.size();
+          cinv.resize(t0 + kGatherHeader + (size_t)nch * mb, -1);
+          cinv[t0] = nch;
           for (int ch = S.child_off[f]; ch < S.child_off[f + 1]; ++ch) {
-            const int c = S.children[ch];
-            const size_t b0 = cinv.size();
-            cinv.resize(b0 + mb, -1);
+            const int c = S.children[ch], k0 = ch - S.child_off[f];
+            cinv[t0 + 1 + 2 * k0] = (int)(unsigned int)(S.U_off[c] & 0xffffffffLL);
+            cinv[t0 + 2 + 2 * k0] = (int)(S.U_off[c] >> 32);
             const int* rl = S.rel.data() + S.rel_off[c];
-            for (int k = 0; k < S.f_nb[c]; ++k) cinv[b0 + rl[k]] = k;
+            for (int k = 0; k < S.f_nb[c]; ++k) cinv[t0 + kGatherHeader + (size_t)k0 * mb + rl[k]] = k;
           }
+          cinv_slot[q] = make_int2((int)t0, kGatherHeader + nch * mb);
         }
         // extend-add passes: pass c handles child c of every front (the children of one front may hit the same blocks)
         LL.be_pass.clear();
@@ -1590,8 +1596,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_cdesc.upload(cdesc, st);
   d_crel.upload(crel, st);
   if (cinv.empty()) cinv.push_back(-1);
+  if (cinv_slot.empty()) cinv_slot.push_back(make_int2(-1, 0));
   d_cinv.upload(cinv, st);
-  d_cinv_off.upload(cinv_off, st);
+  d_cinv_slot.upload(cinv_slot, st);
   d_cmap.upload(cmap, st);
   d_tri.upload(tri, st);
   // --- multi-GPU exchange plan: update matrices / vectors of the subtree roots, solution mask
@@ -1693,7 +1700,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.cdesc = d_cdesc.p;
   plan_.crel = d_crel.p;
   plan_.cinv = d_cinv.p;
-  plan_.cinv_off = d_cinv_off.p;
+  plan_.cinv_slot = d_cinv_slot.p;
   plan_.cmap = d_cmap.p;
   plan_.tri = d_tri.p;
   plan_.f_ns = d_f_ns.p;
@@ -2978,29 +2985,28 @@ __device__ __forceinline__ void fwd_children_apply(const CholPlanDev& P, const F
 // front position (r, c), block of r >= block of c, plus the children's entries there in child order -- the very sums the passes
 // form, bit for bit.  inv: per child ordinal, front block -> the child's boundary block or -1 (CholPlanDev::cinv).
 struct GatherCtx {
-  const int* inv;   // (in LDS: staged by gather_stage)
-  const ChildDesc* cd;
+  const int* tab;   // the front's table in LDS (gather_stage): [0] children, [1 + 2 c], [2 + 2 c] offset of child c's update matrix, maps from kGatherHeader
   const double* U;
-  int nch, mb;
+  int on, mb;
+  __device__ __forceinline__ int children() const { return on ? tab[0] : 0; }   // (after the barrier behind gather_stage)
+  __device__ __forceinline__ const double* child_U(int ch) const {
+    return U + (((long long)tab[2 + 2 * ch] << 32) | (long long)(unsigned int)tab[1 + 2 * ch]);
+  }
+  __device__ __forceinline__ int inv(int ch, int b) const { return tab[kGatherHeader + ch * mb + b]; }
 };
-// whole workgroup; the caller puts a barrier between this and the first gather_add
-__device__ __forceinline__ GatherCtx gather_stage(const CholPlanDev& P, int f, const FrontRec& rec, int* sinv) {
-  GatherCtx g;
-  const int off = P.cinv_off[f];
-  g.nch = off >= 0 ? rec.child_cnt : 0;
-  g.mb = rec.ns + rec.nb;
-  g.inv = sinv;
-  g.cd = P.cdesc + rec.child_off;
-  g.U = P.U;
-  const int* src = P.cinv + max(off, 0);
-  for (int i = threadIdx.x; i < g.nch * g.mb; i += blockDim.x) sinv[i] = src[i];
-  return g;
+// whole workgroup; the table is addressed by the LAUNCH SLOT (requested next to the front record, not behind it); the caller puts a
+// barrier between this and the first use
+__device__ __forceinline__ GatherCtx gather_stage(const CholPlanDev& P, int slot, int mb, int* sinv) {
+  const int2 cs = P.cinv_slot[slot];
+  const int* src = P.cinv + max(cs.x, 0);
+  for (int i = threadIdx.x; i < cs.y; i += blockDim.x) sinv[i] = src[i];
+  return GatherCtx{sinv, P.U, cs.x >= 0 ? 1 : 0, mb};
 }
 // branch-free (the loads of a child's entries for all the caller's values are in flight together): the entry or, where the child
 // has none, a dummy load of its first double and the value unchanged
 template <int BS>
 __device__ __forceinline__ double gather_child(const GatherCtx& g, int ch, const double* __restrict__ Uc, double v, int rb, int cb, int e) {
-  const int ci = g.inv[ch * g.mb + rb], cj = g.inv[ch * g.mb + cb];
+  const int ci = g.inv(ch, rb), cj = g.inv(ch, cb);
   const bool ok = (ci | cj) >= 0;
   const double u = Uc[ok ? (size_t)(ci * (ci + 1) / 2 + cj) * (BS * BS) + e : (size_t)0];
   return ok ? v + u : v;
@@ -3060,23 +3066,22 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
   double x[NX];
 #pragma unroll
   for (int c = 0; c < NX; ++c) x[c] = (rok && c < n) ? F[(size_t)(n + rglb) + (size_t)ld * c] : 0.0;
-  GatherCtx gc{nullptr, nullptr, nullptr, 0, 0};
+  GatherCtx gc{nullptr, nullptr, 0, 0};
+  int gnch = 0;
   if (GATH) {   // the children's entries of this panel row (the extend-add passes' sums: own value first, then child by child)
-    gc = gather_stage(P, f, rec, reinterpret_cast<int*>(psm + kGatherLdsOff));
+    gc = gather_stage(P, slot, ns + nbd, reinterpret_cast<int*>(psm + kGatherLdsOff));
     __syncthreads();
+    gnch = gc.children();
     const int rb = ns + rglb / BS, re = rglb % BS;
-#ifdef G2OHIP_GATH_ABL
-    if (!(G2OHIP_GATH_ABL & 2))
-#endif
-    for (int ch = 0; ch < gc.nch; ++ch) {
-      const int ci = rok ? gc.inv[ch * gc.mb + rb] : -1;
-      const double* Uc = gc.U + gc.cd[ch].U_off;
+    for (int ch = 0; ch < gnch; ++ch) {
+      const int ci = rok ? gc.inv(ch, rb) : -1;
+      const double* Uc = gc.child_U(ch);
       // (all the child's entries of the row requested before the first one is added: one round trip per child, not one per block)
       double u[NX];
       unsigned okm = 0;
 #pragma unroll
       for (int cb = 0; cb < MAXB; ++cb) {
-        const int cj = cb < ns ? gc.inv[ch * gc.mb + cb] : -1;
+        const int cj = cb < ns ? gc.inv(ch, cb) : -1;
         const bool ok = (ci | cj) >= 0;
         okm |= ok ? 1u << cb : 0u;
         const double* ub = Uc + (ok ? (size_t)(ci * (ci + 1) / 2 + cj) * BB + re : (size_t)0);
@@ -3105,12 +3110,9 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
           const int r = R0_ + 16 * a + lr_, c = C0_ + 16 * b + lk_ + 4 * v;
           fpre[(a * 2 + b) * 4 + v] = (r < mt && c < climit && r / BS >= c / BS) ? F[(size_t)(n + r) + (size_t)ld * (n + c)] : 0.0;
         }
-#ifdef G2OHIP_GATH_ABL
-    if (!(G2OHIP_GATH_ABL & 4))
-#endif
     if (GATH)
-      for (int ch = 0; ch < gc.nch; ++ch) {   // (requested together, added afterwards: one round trip per child)
-        const double* Uc = gc.U + gc.cd[ch].U_off;
+      for (int ch = 0; ch < gnch; ++ch) {   // (requested together, added afterwards: one round trip per child)
+        const double* Uc = gc.child_U(ch);
         double u[16];
         unsigned okm = 0;
 #pragma unroll
@@ -3121,7 +3123,7 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
             for (int v = 0; v < 4; ++v) {
               const int r = min(R0_ + 16 * a + lr_, mt - 1), c = min(C0_ + 16 * b + lk_ + 4 * v, mt - 1);
               const bool in = R0_ + 16 * a + lr_ < mt && C0_ + 16 * b + lk_ + 4 * v < climit && r / BS >= c / BS;
-              const int ci = gc.inv[ch * gc.mb + ns + r / BS], cj = gc.inv[ch * gc.mb + ns + c / BS];
+              const int ci = gc.inv(ch, ns + r / BS), cj = gc.inv(ch, ns + c / BS);
               const bool ok = in && (ci | cj) >= 0;
               okm |= ok ? 1u << ((a * 2 + b) * 4 + v) : 0u;
               u[(a * 2 + b) * 4 + v] = Uc[ok ? (size_t)(ci * (ci + 1) / 2 + cj) * BB + (r % BS) + BS * (c % BS) : (size_t)0];
@@ -3271,7 +3273,7 @@ __device__ __forceinline__ void big_panel_body(const CholPlanDev& P, const int4 
               if (ib >= jb) {
                 double y0 = kPreTile ? fpre[(a * 2 + b) * 4 + v] : F[(size_t)(n + r) + (size_t)ld * (n + c)];
                 if (GATH && !kPreTile)
-                  for (int ch = 0; ch < gc.nch; ++ch) y0 = gather_child<BS>(gc, ch, gc.U + gc.cd[ch].U_off, y0, ns + ib, ns + jb, (r - ib * BS) + BS * (c - jb * BS));
+                  for (int ch = 0; ch < gnch; ++ch) y0 = gather_child<BS>(gc, ch, gc.child_U(ch), y0, ns + ib, ns + jb, (r - ib * BS) + BS * (c - jb * BS));
                 const double y = y0 - acc[a][b][v];
                 if (inplace) F[(size_t)(n + r) + (size_t)ld * (n + c)] = y;
                 else U[(size_t)(ib * (ib + 1) / 2 + jb) * BB + (r - ib * BS) + BS * (c - jb * BS)] = y;
@@ -3896,8 +3898,9 @@ __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const i
   // two barriers per step took 1.25 us per step, this one 0.5).  Tile (ti, tj), ti <= tj, is S[tj (tj + 1) / 2 + ti].
   bool bad = false;
   if (GATH) {   // the pivot block with the children's entries added, by the whole workgroup, into LDS (the later L11 copy's place)
-    const GatherCtx gc = gather_stage(P, f, rec, reinterpret_cast<int*>(lds + kGatherLdsOff));
+    const GatherCtx gc = gather_stage(P, slot, rec.ns + rec.nb, reinterpret_cast<int*>(lds + kGatherLdsOff));
     __syncthreads();
+    const int gnch = gc.children();
     constexpr int UG = 16;   // 64 * 64 / 256
     double t[UG];
 #pragma unroll
@@ -3905,11 +3908,8 @@ __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const i
       const int r = tid & 63, c = (tid >> 6) + 4 * u;
       t[u] = (r < n && c <= r) ? F[(size_t)r + (size_t)ld * c] : 0.0;
     }
-#ifdef G2OHIP_GATH_ABL
-    if (!(G2OHIP_GATH_ABL & 1))
-#endif
-    for (int ch = 0; ch < gc.nch; ++ch) {
-      const double* Uc = gc.U + gc.cd[ch].U_off;
+    for (int ch = 0; ch < gnch; ++ch) {
+      const double* Uc = gc.child_U(ch);
 #pragma unroll
       for (int u = 0; u < UG; ++u) {
         const int r = min(tid & 63, n - 1), c = min((tid >> 6) + 4 * u, n - 1);
