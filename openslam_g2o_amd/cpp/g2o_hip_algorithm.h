@@ -1,0 +1,232 @@
+// Device-resident drivers for the g2o plugin: OptimizationAlgorithmLevenberg / GaussNewton whose solve() keeps the WHOLE
+// iteration on the MI355X when every active edge sits on one of BlockSolverHip's device front ends (EdgeProjectXYZ2UV bundle
+// adjustment, EdgeSE2 / EdgeSE3 pose graphs), and is g2o's own host loop otherwise.
+//
+// Why: behind g2o's host loop the device works 2 ms of a 277 ms Levenberg-Marquardt iteration at the metric configuration
+// (INTEGRATION.md): computeActiveErrors twice, activeRobustChi2 twice, update, push / pop and the estimate gather walk 5 M
+// edges and 1.1 M vertices on one CPU core around every solve.  Those are members of SparseOptimizer, not of the Solver seam;
+// the seam ONE level up -- OptimizationAlgorithm::solve (optimization_algorithm.h:46-110), found through the same factory --
+// is where a plugin may replace them.  Here the estimates go up once per optimize() (iteration 0), every trial runs on the
+// device (g2ohip_ba_* / g2ohip_pg_*: errors, chi2, oplus, the estimate stack; one host synchronisation per trial:
+// g2ohip_solve_async / g2ohip_trial_stats) and the accepted estimates come back into the vertices at the end of each
+// solve(), so that everything g2o or its user does between iterations (verbose output, actions, computeActiveErrors,
+// save) sees what it would have seen.  The decisions are those of optimization_algorithm_levenberg.cpp:57-146 and
+// optimization_algorithm_gauss_newton.cpp:50-93, taken on the same numbers.
+//   G2OHIP_ADAPTER_DEVICE_LOOP=0   always g2o's host loop (A/B)
+//   G2OHIP_ADAPTER_WRITEBACK=0     estimates are NOT written back after every iteration (timing experiments only: the
+//                                  vertices then keep their initial estimates)
+// Not mirrored from the host loop: the edges' _error members are not refreshed (computeActiveErrors() does that on demand)
+// and the vertices' own backup stacks are not touched (push / pop happen on the device).
+#ifndef G2O_HIP_ALGORITHM_H
+#define G2O_HIP_ALGORITHM_H
+
+#include <cstdlib>
+#include <iostream>
+#include <limits>
+
+#include "g2o/core/batch_stats.h"
+#include "g2o/core/optimization_algorithm_gauss_newton.h"
+#include "g2o/core/optimization_algorithm_levenberg.h"
+#include "g2o/core/sparse_optimizer.h"
+#include "g2o/stuff/timeutil.h"
+#include "g2o_hip_solver.h"
+
+namespace g2o {
+
+namespace hip_detail {
+inline bool envOff(const char* name) {
+  const char* v = std::getenv(name);
+  return v && v[0] == '0';
+}
+// iteration 0 of a device-resident run: is the structure built, and may the device loop take the graph?
+inline bool wantDeviceLoop(const char* who, Solver* solver, HipDeviceGraph* dev) {
+  const bool on = solver && dev && dev->deviceResident() && !envOff("G2OHIP_ADAPTER_DEVICE_LOOP");
+  if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
+    std::cerr << who << ": " << (on ? "device-resident iteration (errors, chi2, oplus and the estimate stack on the GPU)"
+                                    : "g2o's host loop (not every active edge is on a device front end, or G2OHIP_ADAPTER_DEVICE_LOOP=0)")
+              << std::endl;
+  return on;
+}
+}  // namespace hip_detail
+
+class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg {
+ public:
+  explicit OptimizationAlgorithmLevenbergHip(Solver* solver)
+      : OptimizationAlgorithmLevenberg(solver), _dev(dynamic_cast<HipDeviceGraph*>(solver)), _resident(false),
+        _writeBack(!hip_detail::envOff("G2OHIP_ADAPTER_WRITEBACK")) {}
+
+  //! did the last solve() run on the device?
+  bool deviceLoopActive() const { return _resident; }
+
+  virtual SolverResult solve(int iteration, bool online = false) {
+    if (iteration == 0 && !online) {                     // levenberg.cpp:62-68
+      if (!_solver->buildStructure()) {
+        std::cerr << "OptimizationAlgorithmLevenbergHip::solve: Failure while building CCS structure" << std::endl;
+        return OptimizationAlgorithm::Fail;
+      }
+    }
+    if (iteration == 0 || online || !_resident) _resident = hip_detail::wantDeviceLoop("OptimizationAlgorithmLevenbergHip", _solver, _dev);
+    // (`online` only guards buildStructure in the host loop, levenberg.cpp:62: the structure exists by now)
+    if (!_resident) return OptimizationAlgorithmLevenberg::solve(iteration, true);
+
+    double t = get_monotonic_time();
+    G2OBatchStatistics* globalStats = G2OBatchStatistics::globalStats();
+    // a new optimize() (the caller may have changed the vertices), online growth, or a structure rebuilt under us
+    if (iteration == 0 || online || !_dev->devEstimatesValid()) {
+      if (!_dev->devSetEstimates()) return OptimizationAlgorithm::Fail;
+    }
+    if (!_dev->devLinearize(true)) return OptimizationAlgorithm::Fail;       // computeActiveErrors + what buildSystem linearises
+    double currentChi = 0.;
+    if (!_dev->devChi2(currentChi)) return OptimizationAlgorithm::Fail;      // activeRobustChi2
+    if (globalStats) {
+      globalStats->timeResiduals = get_monotonic_time() - t;
+      t = get_monotonic_time();
+    }
+    double tempChi = currentChi;
+    if (!_dev->devBuildSystem()) return OptimizationAlgorithm::Fail;
+    if (globalStats) globalStats->timeQuadraticForm = get_monotonic_time() - t;
+
+    if (iteration == 0) {                                // computeLambdaInit, levenberg.cpp:149-163
+      double maxDiagonal = 0.;
+      if (userLambdaInit() > 0) {
+        _currentLambda = userLambdaInit();
+      } else {
+        if (!_dev->devMaxDiagonal(maxDiagonal)) return OptimizationAlgorithm::Fail;
+        _currentLambda = _tau * maxDiagonal;
+      }
+      _ni = 2;
+    }
+
+    double rho = 0;
+    int& qmax = _levenbergIterations;
+    qmax = 0;
+    do {
+      if (!_dev->devPush()) return OptimizationAlgorithm::Fail;
+      if (globalStats) {
+        globalStats->levenbergIterations++;
+        t = get_monotonic_time();
+      }
+      _solver->setLambda(_currentLambda, true);
+      // solve, update, restoreDiagonal, computeActiveErrors queued back to back; status, chi2 and computeScale in ONE read-back
+      double scale = 0.;
+      int ok2 = -1;
+      if (_dev->devSolveAsync() && _dev->devUpdate()) {
+        _solver->restoreDiagonal();
+        if (_dev->devLinearize(false)) ok2 = _dev->devTrialStats(_currentLambda, tempChi, scale);
+      }
+      if (ok2 == 2) {                                    // (a dependency-driven launch gave up waiting: the trial again, synchronously)
+        if (!_dev->devPop() || !_dev->devPush()) return OptimizationAlgorithm::Fail;
+        _solver->setLambda(_currentLambda, true);
+        ok2 = _dev->devSolve();
+        if (ok2 >= 0 && _dev->devUpdate()) {
+          _solver->restoreDiagonal();
+          if (!_dev->devLinearize(false) || !_dev->devChi2(tempChi)) ok2 = -1;
+          else if (ok2 == 1 && !_dev->devComputeScale(_currentLambda, scale)) ok2 = -1;
+        } else {
+          ok2 = -1;
+        }
+      }
+      if (ok2 < 0) {
+        _dev->devPop();
+        finish(globalStats);
+        return OptimizationAlgorithm::Fail;
+      }
+      if (globalStats) globalStats->timeLinearSolution += get_monotonic_time() - t;
+
+      if (!ok2) {
+        tempChi = std::numeric_limits<double>::max();
+        scale = 0.;
+      }
+      rho = (currentChi - tempChi);
+      scale += 1e-3;                                     // make sure it's non-zero :)   (levenberg.cpp:121)
+      rho /= scale;
+
+      if (rho > 0 && tempChi - tempChi == 0.) {          // last step was good (and chi2 finite)
+        double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+        alpha = (alpha < _goodStepUpperScale) ? alpha : _goodStepUpperScale;
+        const double scaleFactor = (_goodStepLowerScale > alpha) ? _goodStepLowerScale : alpha;
+        _currentLambda *= scaleFactor;
+        _ni = 2;
+        currentChi = tempChi;
+        if (!_dev->devDiscardTop()) return OptimizationAlgorithm::Fail;
+      } else {
+        _currentLambda *= _ni;
+        _ni *= 2;
+        if (!_dev->devPop()) return OptimizationAlgorithm::Fail;   // restore the last state before trying to optimize
+      }
+      qmax++;
+    } while (rho < 0 && qmax < maxTrialsAfterFailure() && !_optimizer->terminate());
+
+    if (!finish(globalStats)) return OptimizationAlgorithm::Fail;
+    if (qmax == maxTrialsAfterFailure() || rho == 0) return Terminate;
+    return OK;
+  }
+
+ private:
+  // the accepted estimates into the vertices (what SparseOptimizer::update / pop left there in the host loop)
+  bool finish(G2OBatchStatistics* globalStats) {
+    const double t = get_monotonic_time();
+    const bool ok = !_writeBack || _dev->devGetEstimates();
+    if (globalStats) globalStats->timeUpdate = get_monotonic_time() - t;
+    return ok;
+  }
+  HipDeviceGraph* _dev;
+  bool _resident, _writeBack;
+};
+
+class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNewton {
+ public:
+  explicit OptimizationAlgorithmGaussNewtonHip(Solver* solver)
+      : OptimizationAlgorithmGaussNewton(solver), _dev(dynamic_cast<HipDeviceGraph*>(solver)), _resident(false),
+        _writeBack(!hip_detail::envOff("G2OHIP_ADAPTER_WRITEBACK")) {}
+
+  bool deviceLoopActive() const { return _resident; }
+
+  virtual SolverResult solve(int iteration, bool online = false) {
+    // (gauss_newton.cpp:57-71 evaluates the errors before it builds the structure -- for max-mixture components; none of the
+    // edge types a device front end takes reads them there, and the host loop below evaluates them again)
+    if (iteration == 0 && !online) {
+      if (!_solver->buildStructure()) {
+        std::cerr << "OptimizationAlgorithmGaussNewtonHip::solve: Failure while building CCS structure" << std::endl;
+        return OptimizationAlgorithm::Fail;
+      }
+    }
+    if (iteration == 0 || online || !_resident) _resident = hip_detail::wantDeviceLoop("OptimizationAlgorithmGaussNewtonHip", _solver, _dev);
+    if (!_resident) return OptimizationAlgorithmGaussNewton::solve(iteration, true);
+
+    double t = get_monotonic_time();
+    G2OBatchStatistics* globalStats = G2OBatchStatistics::globalStats();
+    if (iteration == 0 || online || !_dev->devEstimatesValid()) {
+      if (!_dev->devSetEstimates()) return OptimizationAlgorithm::Fail;
+    }
+    if (!_dev->devLinearize(true)) return OptimizationAlgorithm::Fail;
+    if (globalStats) {
+      globalStats->timeResiduals = get_monotonic_time() - t;
+      t = get_monotonic_time();
+    }
+    if (!_dev->devBuildSystem()) return OptimizationAlgorithm::Fail;
+    if (globalStats) {
+      globalStats->timeQuadraticForm = get_monotonic_time() - t;
+      t = get_monotonic_time();
+    }
+    const int ok = _dev->devSolve();
+    if (globalStats) {
+      globalStats->timeLinearSolution = get_monotonic_time() - t;
+      t = get_monotonic_time();
+    }
+    // (the host loop applies x() even after a failed solve and then reports Fail, gauss_newton.cpp:86-92; the increment of a
+    // factorisation that broke down is not applied here)
+    if (ok == 1 && !_dev->devUpdate()) return OptimizationAlgorithm::Fail;
+    if (ok == 1 && _writeBack && !_dev->devGetEstimates()) return OptimizationAlgorithm::Fail;
+    if (globalStats) globalStats->timeUpdate = get_monotonic_time() - t;
+    return ok == 1 ? OK : Fail;
+  }
+
+ private:
+  HipDeviceGraph* _dev;
+  bool _resident, _writeBack;
+};
+
+}  // namespace g2o
+
+#endif

@@ -18,6 +18,7 @@
 #include <iostream>
 #include <map>
 #include <string>
+#include <thread>
 #include <typeinfo>
 #include <utility>
 #include <vector>
@@ -57,6 +58,34 @@
 namespace g2o {
 
 // ---------------------------------------------------------------------------------------------------------
+// What a device-resident iteration needs from the solver BESIDES g2o::Solver: the graph-side operations of
+// OptimizationAlgorithmLevenberg / GaussNewton::solve that SparseOptimizer runs on the host (computeActiveErrors,
+// activeRobustChi2, update, push / pop / discardTop: sparse_optimizer.cpp:61-114,421-434,599-650) executed on the estimates the
+// device front ends hold.  Implemented by BlockSolverHip when EVERY active edge sits on a device front end; used by
+// OptimizationAlgorithmLevenbergHip / GaussNewtonHip (g2o_hip_algorithm.h), which fall back to g2o's host loop otherwise.
+// ---------------------------------------------------------------------------------------------------------
+class HipDeviceGraph {
+ public:
+  virtual ~HipDeviceGraph() {}
+  virtual bool deviceResident() const = 0;             // every active edge is bound to a device front end
+  virtual bool devEstimatesValid() const = 0;          // the device holds estimates for the current structure
+  virtual bool devSetEstimates() = 0;                  // vertices -> device (setEstimate of every vertex the front ends know)
+  virtual bool devGetEstimates() = 0;                  // device -> vertices (the free ones)
+  virtual bool devLinearize(bool jacobians) = 0;       // computeActiveErrors (+ linearizeOplus) at the device estimates
+  virtual bool devChi2(double& chi2) = 0;              // activeRobustChi2 of the errors last evaluated
+  virtual bool devBuildSystem() = 0;                   // Solver::buildSystem without the b / diagonal read-back
+  virtual bool devMaxDiagonal(double& d) = 0;          // what computeLambdaInit reads (levenberg.cpp:149-163)
+  virtual bool devComputeScale(double lambda, double& scale) = 0;   // computeScale (levenberg.cpp:165-172)
+  virtual int devSolve() = 0;                          // Solver::solve without the x read-back: 1 solved, 0 not positive definite, -1 error
+  virtual bool devSolveAsync() = 0;                    // the same, queued; status with the trial's sums:
+  virtual int devTrialStats(double lambda, double& chi2, double& scale) = 0;   // 1 / 0 as devSolve, 2 repeat the trial, -1 error
+  virtual bool devUpdate() = 0;                        // SparseOptimizer::update(x) with the resident x
+  virtual bool devPush() = 0;
+  virtual bool devPop() = 0;
+  virtual bool devDiscardTop() = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------
 // Wide seam.  Edges are grouped into homogeneous SETS (error dimension, vertex dimensions, unary / binary, robust
 // kernel): one g2ohip edge set per group, flat arrays in the group's edge order.
 //   generic path: the edges keep producing errors and Jacobians on the CPU (computeError / linearizeOplus of the
@@ -75,13 +104,18 @@ namespace g2o {
 //     chi2 (computeActiveErrors / activeRobustChi2) stays with the optimizer on the CPU.
 // ---------------------------------------------------------------------------------------------------------
 template <int p, int l>
-class BlockSolverHip : public BlockSolverBase {
+class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
  public:
-  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0) {
+  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0), _devValid(false) {
     const char* fp = std::getenv("G2OHIP_ADAPTER_FASTPATH");
     if (fp && fp[0] == '0') _fastPath = false;
     const char* pin = std::getenv("G2OHIP_ADAPTER_PINNED");
     _pin = !(pin && pin[0] == '0');
+    const char* th = std::getenv("G2OHIP_ADAPTER_THREADS");   // host threads of the estimate gather / write-back loops (default 8, 1 = serial)
+    _threads = th ? std::atoi(th) : 8;
+    const unsigned hc = std::thread::hardware_concurrency();
+    if (hc > 0 && _threads > (int)hc) _threads = (int)hc;
+    if (_threads < 1) _threads = 1;
     const char* tm = std::getenv("G2OHIP_ADAPTER_TIMING");
     _timing = tm && tm[0] != '0';
     std::memset(&_phase, 0, sizeof(_phase));
@@ -142,6 +176,7 @@ class BlockSolverHip : public BlockSolverBase {
     if (g2ohip_init(_h) != G2OHIP_OK) return fail("init");
     if (g2ohip_clear_edge_sets(_h) != G2OHIP_OK) return fail("clear_edge_sets");   // (a second optimize(), online growth: a new graph)
     _groups.clear();
+    _devValid = false;                                 // (the front ends are about to be bound again: no estimates behind them yet)
     // poses first, then marginalized vertices, each in index order (sparse_optimizer.cpp:174-187)
     _nP = _nL = 0;
     size_t diagDoubles = 0;
@@ -322,6 +357,7 @@ class BlockSolverHip : public BlockSolverBase {
       Group& g = _groups[gi];
       if (g.fast) {                                    // estimates up, errors + Jacobians on the device
         if (!(g.fast == 2 ? uploadPosesSE2() : (g.fast == 3 ? uploadPosesSE3() : uploadEstimates()))) return false;
+        _devValid = true;
         _phase.upload += lap(t);
         continue;
       }
@@ -421,6 +457,75 @@ class BlockSolverHip : public BlockSolverBase {
   // BlockSolverBase (block_solver.h:83-91), used by OptimizationAlgorithmDogleg: dest = H * src
   virtual void multiplyHessian(double* dest, const double* src) const { if (_h) g2ohip_multiply_hessian(_h, dest, src); }
 
+  // ---- HipDeviceGraph: the graph side of an iteration on the device front ends (g2ohip_ba_* / g2ohip_pg_*)
+  virtual bool deviceResident() const { return _h && !_groups.empty() && _fastGroups == (int)_groups.size(); }
+  virtual bool devEstimatesValid() const { return _devValid; }
+  virtual bool devSetEstimates() {
+    double t = get_monotonic_time();
+    for (size_t gi = 0; gi < _groups.size(); ++gi) {
+      const int fast = _groups[gi].fast;
+      if (!(fast == 1 ? setEstimatesBA() : (fast == 2 ? setPosesSE2() : (fast == 3 ? setPosesSE3() : false)))) return false;
+    }
+    _devValid = true;
+    _phase.upload += lap(t);
+    return true;
+  }
+  virtual bool devGetEstimates() {
+    double t = get_monotonic_time();
+    for (size_t gi = 0; gi < _groups.size(); ++gi) {
+      const int fast = _groups[gi].fast;
+      if (!(fast == 1 ? getEstimatesBA() : (fast == 2 ? getPosesSE2() : (fast == 3 ? getPosesSE3() : false)))) return false;
+    }
+    _phase.downloadX += lap(t);
+    return true;
+  }
+  virtual bool devLinearize(bool jacobians) {
+    for (size_t gi = 0; gi < _groups.size(); ++gi) {
+      const int fast = _groups[gi].fast;
+      if (fast == 1 ? g2ohip_ba_linearize(_h, jacobians ? 1 : 0) != G2OHIP_OK : g2ohip_pg_linearize(_h, jacobians ? 1 : 0) != G2OHIP_OK) return fail("linearize");
+    }
+    return true;
+  }
+  virtual bool devChi2(double& chi2) { return g2ohip_chi2(_h, &chi2) == G2OHIP_OK || fail("chi2"); }
+  virtual bool devBuildSystem() {
+    double t = get_monotonic_time();
+    if (g2ohip_build_system(_h) != G2OHIP_OK) return fail("build_system");
+    if (_timing) g2ohip_sync(_h);
+    _phase.deviceBuild += lap(t);
+    ++_phase.buildSystems;
+    return true;
+  }
+  virtual bool devMaxDiagonal(double& d) { return g2ohip_max_diagonal(_h, &d) == G2OHIP_OK || fail("max_diagonal"); }
+  virtual bool devComputeScale(double lambda, double& scale) { return g2ohip_compute_scale(_h, lambda, &scale) == G2OHIP_OK || fail("compute_scale"); }
+  virtual int devSolve() {
+    double t = get_monotonic_time();
+    const int rc = g2ohip_solve(_h);
+    _phase.deviceSolve += lap(t);
+    ++_phase.solves;
+    if (rc == G2OHIP_OK) return 1;
+    if (rc == G2OHIP_NOT_PD) return 0;
+    fail("solve");
+    return -1;
+  }
+  virtual bool devSolveAsync() {
+    ++_phase.solves;
+    return g2ohip_solve_async(_h) == G2OHIP_OK || fail("solve_async");
+  }
+  virtual int devTrialStats(double lambda, double& chi2, double& scale) {
+    double t = get_monotonic_time();
+    int ok = 0;
+    if (g2ohip_trial_stats(_h, lambda, &ok, &chi2, &scale) != G2OHIP_OK) {
+      fail("trial_stats");
+      return -1;
+    }
+    _phase.deviceSolve += lap(t);                      // (the one synchronisation of a trial: solve, update and errors end here)
+    return ok;
+  }
+  virtual bool devUpdate() { return forEachFrontEnd(g2ohip_ba_update, g2ohip_pg_update, "update"); }
+  virtual bool devPush() { return forEachFrontEnd(g2ohip_ba_push, g2ohip_pg_push, "push"); }
+  virtual bool devPop() { return forEachFrontEnd(g2ohip_ba_pop, g2ohip_pg_pop, "pop"); }
+  virtual bool devDiscardTop() { return forEachFrontEnd(g2ohip_ba_discard_top, g2ohip_pg_discard_top, "discard_top"); }
+
   g2ohip_solver* handle() const { return _h; }
 
  private:
@@ -507,6 +612,33 @@ class BlockSolverHip : public BlockSolverBase {
       return it->second;
     }
   };
+
+  // fn(begin, end) over [0, n) on up to _threads host threads: the loops that read or write one estimate per vertex (1.1 M
+  // vertices at the metric configuration; setEstimate touches the vertex it is called on only)
+  template <class Fn>
+  void parallelFor(size_t n, Fn fn) const {
+    const size_t nt = (_threads > 1 && n >= 8192) ? (size_t)_threads : 1;
+    if (nt == 1) {
+      fn((size_t)0, n);
+      return;
+    }
+    const size_t chunk = (n + nt - 1) / nt;
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; ++t) {
+      const size_t b = t * chunk, e = b + chunk < n ? b + chunk : n;
+      if (b < e) pool.push_back(std::thread(fn, b, e));
+    }
+    fn((size_t)0, chunk < n ? chunk : n);
+    for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
+  }
+
+  bool forEachFrontEnd(int (*ba)(g2ohip_solver*), int (*pg)(g2ohip_solver*), const char* what) {
+    for (size_t gi = 0; gi < _groups.size(); ++gi) {
+      const int fast = _groups[gi].fast;
+      if (fast && (fast == 1 ? ba(_h) : pg(_h)) != G2OHIP_OK) return fail(what);
+    }
+    return true;
+  }
 
   static double lap(double& t) {
     const double now = get_monotonic_time(), d = now - t;
@@ -646,7 +778,7 @@ class BlockSolverHip : public BlockSolverBase {
     pinDoubles(_pgBuf.data(), _pgBuf.size());          // (only once the front end has taken the group: the buffer stays)
     return true;
   }
-  bool uploadPosesSE2() {
+  bool setPosesSE2() {
     for (size_t i = 0; i < _pgVerts.size(); ++i) {
       const SE2& T = _pgVerts[i]->estimate();
       _pgBuf[3 * i] = T.translation()[0];
@@ -654,12 +786,24 @@ class BlockSolverHip : public BlockSolverBase {
       _pgBuf[3 * i + 2] = T.rotation().angle();
     }
     if (g2ohip_pg_set_estimates(_h, (int)_pgVerts.size(), _pgBuf.data(), _pgHidx.data()) != G2OHIP_OK) return fail("pg_set_estimates");
+    return true;
+  }
+  bool uploadPosesSE2() {
+    if (!setPosesSE2()) return false;
     if (g2ohip_pg_linearize(_h, 1) != G2OHIP_OK) return fail("pg_linearize");
+    return true;
+  }
+  bool getPosesSE2() {                                   // device -> setEstimate of the free vertices (fixed ones never change)
+    if (g2ohip_pg_get_estimates(_h, _pgBuf.data()) != G2OHIP_OK) return fail("pg_get_estimates");
+    for (size_t i = 0; i < _pgVerts.size(); ++i)
+      if (_pgHidx[i] >= 0) _pgVerts[i]->setEstimate(SE2(_pgBuf[3 * i], _pgBuf[3 * i + 1], _pgBuf[3 * i + 2]));
     return true;
   }
 #else
   bool bindSE2(Group&) { return false; }
   bool uploadPosesSE2() { return false; }
+  bool setPosesSE2() { return false; }
+  bool getPosesSE2() { return false; }
 #endif
 
 #if G2OHIP_FASTPATH_SLAM3D
@@ -705,34 +849,88 @@ class BlockSolverHip : public BlockSolverBase {
     pinDoubles(_pgBuf.data(), _pgBuf.size());
     return true;
   }
-  bool uploadPosesSE3() {
+  bool setPosesSE3() {
     for (size_t i = 0; i < _pg3Verts.size(); ++i) isometryTo12(_pg3Verts[i]->estimate(), &_pgBuf[12 * i]);
     if (g2ohip_pg_set_estimates(_h, (int)_pg3Verts.size(), _pgBuf.data(), _pgHidx.data()) != G2OHIP_OK) return fail("pg_set_estimates");
+    return true;
+  }
+  bool uploadPosesSE3() {
+    if (!setPosesSE3()) return false;
     if (g2ohip_pg_linearize(_h, 1) != G2OHIP_OK) return fail("pg_linearize");
+    return true;
+  }
+  bool getPosesSE3() {
+    if (g2ohip_pg_get_estimates(_h, _pgBuf.data()) != G2OHIP_OK) return fail("pg_get_estimates");
+    for (size_t i = 0; i < _pg3Verts.size(); ++i) {
+      if (_pgHidx[i] < 0) continue;
+      Eigen::Isometry3d T = _pg3Verts[i]->estimate();   // (keeps whatever the type holds besides R | t)
+      const double* c = &_pgBuf[12 * i];
+      for (int col = 0; col < 3; ++col)
+        for (int row = 0; row < 3; ++row) T.linear()(row, col) = c[row + 3 * col];
+      for (int row = 0; row < 3; ++row) T.translation()[row] = c[9 + row];
+      _pg3Verts[i]->setEstimate(T);
+    }
     return true;
   }
 #else
   bool bindSE3(Group&) { return false; }
   bool uploadPosesSE3() { return false; }
+  bool setPosesSE3() { return false; }
+  bool getPosesSE3() { return false; }
 #endif
 
 #if G2OHIP_FASTPATH_SBA
-  bool uploadEstimates() {
-    for (size_t i = 0; i < _cams.size(); ++i) {
-      const SE3Quat& T = _cams[i]->estimate();
-      const Eigen::Matrix3d R = T.rotation().toRotationMatrix();
-      double* c = &_camBuf[12 * i];
-      for (int col = 0; col < 3; ++col)
-        for (int row = 0; row < 3; ++row) c[row + 3 * col] = R(row, col);
-      for (int row = 0; row < 3; ++row) c[9 + row] = T.translation()[row];
-    }
-    for (size_t i = 0; i < _points.size(); ++i)
-      for (int row = 0; row < 3; ++row) _pointBuf[3 * i + row] = _points[i]->estimate()[row];
+  bool setEstimatesBA() {
+    parallelFor(_cams.size(), [this](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        const SE3Quat& T = _cams[i]->estimate();
+        const Eigen::Matrix3d R = T.rotation().toRotationMatrix();
+        double* c = &_camBuf[12 * i];
+        for (int col = 0; col < 3; ++col)
+          for (int row = 0; row < 3; ++row) c[row + 3 * col] = R(row, col);
+        for (int row = 0; row < 3; ++row) c[9 + row] = T.translation()[row];
+      }
+    });
+    parallelFor(_points.size(), [this](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i)
+        for (int row = 0; row < 3; ++row) _pointBuf[3 * i + row] = _points[i]->estimate()[row];
+    });
     if (g2ohip_ba_set_estimates(_h, (int)_cams.size(), _camBuf.data(), _camHidx.data(), (int)_points.size(), _pointBuf.data(), _pointHidx.data()) != G2OHIP_OK)
       return fail("ba_set_estimates");
+    return true;
+  }
+  bool uploadEstimates() {
+    if (!setEstimatesBA()) return false;
     if (g2ohip_ba_linearize(_h, 1) != G2OHIP_OK) return fail("ba_linearize");
     return true;
   }
+  bool getEstimatesBA() {                                // device -> setEstimate of the free cameras and points
+    if (g2ohip_ba_get_estimates(_h, _camBuf.data(), _pointBuf.data()) != G2OHIP_OK) return fail("ba_get_estimates");
+    parallelFor(_cams.size(), [this](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        if (_camHidx[i] < 0) continue;
+        const double* c = &_camBuf[12 * i];
+        Eigen::Matrix3d R;
+        Eigen::Vector3d t;
+        for (int col = 0; col < 3; ++col)
+          for (int row = 0; row < 3; ++row) R(row, col) = c[row + 3 * col];
+        for (int row = 0; row < 3; ++row) t[row] = c[9 + row];
+        _cams[i]->setEstimate(SE3Quat(R, t));           // (se3quat.h:58-60: quaternion of R, normalised)
+      }
+    });
+    parallelFor(_points.size(), [this](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        if (_pointHidx[i] < 0) continue;
+        Eigen::Vector3d x;
+        for (int row = 0; row < 3; ++row) x[row] = _pointBuf[3 * i + row];
+        _points[i]->setEstimate(x);
+      }
+    });
+    return true;
+  }
+#else
+  bool setEstimatesBA() { return false; }
+  bool getEstimatesBA() { return false; }
 #endif
 
   g2ohip_solver* _h;
@@ -742,7 +940,9 @@ class BlockSolverHip : public BlockSolverBase {
   std::vector<double> _diagMirror, _diag;
   bool _fastPath;
   int _fastGroups;                                     // groups bound to a device front end (Group::fast)
+  bool _devValid;                                      // the front ends hold estimates for the current structure
   bool _pin, _timing;
+  int _threads;
   std::vector<void*> _pinned;                          // buffers registered with g2ohip_host_register
   Phases _phase;
   std::vector<double> _baClasses;                      // class table of the BA group: (f, cx, cy, kernel kind, delta) per class

@@ -1,6 +1,8 @@
 // g2o plugin: registers the MI355X solvers with g2o's OptimizationAlgorithmFactory so that
 //   g2o -solver lm_fix6_3_hip ...      (wide seam: BlockSolverHip)
 //   g2o -solver lm_fix6_3_hipls ...    (narrow seam: g2o's BlockSolver + LinearSolverHip)
+//   g2o -solver lm_fix6_3_hipdev ...   (BlockSolverHip under the device-resident Levenberg / Gauss-Newton loop of
+//                                       g2o_hip_algorithm.h: the whole iteration on the GPU where the graph allows it)
 // work once the shared object -- its file name has to match *_solver_*.so, e.g. libg2o_solver_hip.so -- sits in
 // G2O_SOLVERS_DIR or next to the CLI library, or is passed with -solverlib
 // (/root/reference/g2o/apps/g2o_cli/g2o_common.cpp:81-167, dl_wrapper.cpp:118).
@@ -15,6 +17,7 @@
 #include "g2o/core/optimization_algorithm_factory.h"
 #include "g2o/core/optimization_algorithm_gauss_newton.h"
 #include "g2o/core/optimization_algorithm_levenberg.h"
+#include "g2o_hip_algorithm.h"
 #include "g2o_hip_solver.h"
 
 namespace g2o {
@@ -31,7 +34,7 @@ Solver* allocNarrow() {
   return new SolverType(new LinearSolverHip<typename SolverType::PoseMatrixType>(p));
 }
 
-// "<method>_<shape>_<hip|hipls>": method gn | lm | dl, shape fix3_2 | fix6_3 | fix7_3
+// "<method>_<shape>_<hip|hipls|hipdev>": method gn | lm | dl (hipdev: gn | lm), shape fix3_2 | fix6_3 | fix7_3
 OptimizationAlgorithm* createSolver(const std::string& fullSolverName) {
   const std::string method = fullSolverName.substr(0, 2);
   const std::string::size_type us = fullSolverName.rfind('_');
@@ -42,6 +45,12 @@ OptimizationAlgorithm* createSolver(const std::string& fullSolverName) {
   else if (shape == "fix6_3") s = narrow ? allocNarrow<6, 3>() : allocWide<6, 3>();
   else if (shape == "fix7_3") s = narrow ? allocNarrow<7, 3>() : allocWide<7, 3>();
   if (!s) return 0;
+  if (seam == "hipdev") {
+    if (method == "gn") return new OptimizationAlgorithmGaussNewtonHip(s);
+    if (method == "lm") return new OptimizationAlgorithmLevenbergHip(s);
+    delete s;
+    return 0;
+  }
   if (method == "gn") return new OptimizationAlgorithmGaussNewton(s);
   if (method == "lm") return new OptimizationAlgorithmLevenberg(s);
   if (method == "dl") return new OptimizationAlgorithmDogleg(dynamic_cast<BlockSolverBase*>(s));
@@ -81,5 +90,12 @@ G2OHIP_REGISTER(lm_fix7_3_hipls, "Levenberg: g2o block solver over the MI355X Ch
 G2OHIP_REGISTER(dl_fix3_2_hipls, "Dogleg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 3, 2);
 G2OHIP_REGISTER(dl_fix6_3_hipls, "Dogleg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 6, 3);
 G2OHIP_REGISTER(dl_fix7_3_hipls, "Dogleg: g2o block solver over the MI355X Cholesky (LinearSolver seam)", 7, 3);
+// the wide seam under the device-resident drivers (g2o_hip_algorithm.h): errors, chi2, oplus and the estimate stack on the device too
+G2OHIP_REGISTER(gn_fix3_2_hipdev, "Gauss-Newton: device-resident iteration on MI355X (fixed blocksize)", 3, 2);
+G2OHIP_REGISTER(gn_fix6_3_hipdev, "Gauss-Newton: device-resident iteration on MI355X (fixed blocksize)", 6, 3);
+G2OHIP_REGISTER(gn_fix7_3_hipdev, "Gauss-Newton: device-resident iteration on MI355X (fixed blocksize)", 7, 3);
+G2OHIP_REGISTER(lm_fix3_2_hipdev, "Levenberg: device-resident iteration on MI355X (fixed blocksize)", 3, 2);
+G2OHIP_REGISTER(lm_fix6_3_hipdev, "Levenberg: device-resident iteration on MI355X (fixed blocksize)", 6, 3);
+G2OHIP_REGISTER(lm_fix7_3_hipdev, "Levenberg: device-resident iteration on MI355X (fixed blocksize)", 7, 3);
 
 }  // namespace g2o

@@ -159,8 +159,8 @@ bool OptimizationAlgorithmWithHessian::init(bool online) {
 }
 
 // optimization_algorithm_gauss_newton.cpp:50-93
-OptimizationAlgorithm::SolverResult OptimizationAlgorithmGaussNewton::solve(int iteration, bool) {
-  if (iteration == 0 && !_solver->buildStructure()) return Fail;
+OptimizationAlgorithm::SolverResult OptimizationAlgorithmGaussNewton::solve(int iteration, bool online) {
+  if (iteration == 0 && !online && !_solver->buildStructure()) return Fail;   // gauss_newton.cpp:65
   _optimizer->computeActiveErrors();
   _solver->buildSystem();
   if (!_solver->solve()) return Fail;
@@ -185,8 +185,8 @@ double OptimizationAlgorithmLevenberg::computeScale() const {
   return scale;
 }
 // :57-146
-OptimizationAlgorithm::SolverResult OptimizationAlgorithmLevenberg::solve(int iteration, bool) {
-  if (iteration == 0 && !_solver->buildStructure()) return Fail;
+OptimizationAlgorithm::SolverResult OptimizationAlgorithmLevenberg::solve(int iteration, bool online) {
+  if (iteration == 0 && !online && !_solver->buildStructure()) return Fail;   // levenberg.cpp:62
   double t = get_monotonic_time();                       // the BatchStatistics fields as optimization_algorithm_levenberg.cpp:70-113 fills them
   _optimizer->computeActiveErrors();
   G2OBatchStatistics* globalStats = G2OBatchStatistics::globalStats();

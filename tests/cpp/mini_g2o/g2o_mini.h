@@ -330,7 +330,10 @@ class SparseOptimizer : public OptimizableGraph {       // g2o/core/sparse_optim
   OptimizationAlgorithm* algorithm() const { return _algorithm; }
   void setVerbose(bool v) { _verbose = v; }
   bool verbose() const { return _verbose; }
+  bool terminate() { return _forceStopFlag ? (*_forceStopFlag) : false; }   // sparse_optimizer.h:218
+  void setForceStopFlag(bool* flag) { _forceStopFlag = flag; }           // :215
  protected:
+  bool* _forceStopFlag = 0;
   VertexContainer _ivMap;
   EdgeContainer _activeEdges;
   OptimizationAlgorithm* _algorithm;
@@ -569,6 +572,9 @@ class OptimizationAlgorithmLevenberg : public OptimizationAlgorithmWithHessian {
   double currentLambda() const { return _currentLambda; }
   int levenbergIteration() { return _levenbergIterations; }
   void setUserLambdaInit(double l) { _userLambdaInit = l; }
+  double userLambdaInit() { return _userLambdaInit; }                 // optimization_algorithm_levenberg.h:64
+  int maxTrialsAfterFailure() const { return _maxTrialsAfterFailure; }   // :61
+  void setMaxTrialsAfterFailure(int n) { _maxTrialsAfterFailure = n; }
  protected:
   double computeLambdaInit() const;                     // .cpp:149-163
   double computeScale() const;                          // .cpp:165-172
