@@ -470,3 +470,60 @@ def test_device_resident_levenberg_on_the_3d_pose_graph(host, tmp_path):
     assert abs(out["chi2"][0] - g["chi2_lm"][1]) <= 1e-6 * g["chi2_lm"][1]
     assert np.allclose(out["chi2"], ref["chi2"], rtol=1e-9, atol=0) and np.allclose(out["lambda"], ref["lambda"], rtol=1e-9, atol=0)
     assert relerr(out["poses"], ref["poses"]) < 1e-9
+
+
+def test_device_resident_levenberg_with_edge_classes_and_per_edge_kernels(host, tmp_path):
+    """The graphs whose groups differ per EDGE -- two CameraParameters with Huber on every other edge (four BA edge classes),
+    manhattan3500 with Huber on its loop closures only (one robust kernel per edge on the pose-graph front end) -- under the
+    device-resident driver: chi2 on the device honours the classes / per-edge kernels, the trajectory is the host loop's."""
+    from tests.helpers import manhattan_golden
+    from tests.test_gpu_edge_classes import CLASSES
+    pr = ba_case(40, 400, outlier_frac=0.05)
+    second = (pr["cam_idx"] % 2) == 1
+    robust = (np.arange(pr["E"]) % 2) == 1
+    cls = (2 * second + robust).astype(np.int32)
+    f0, c0 = pr["f"], np.array([pr["cx"], pr["cy"]])
+    meas = (pr["meas"] - c0) / f0 * CLASSES[cls, 0][:, None] + CLASSES[cls, 1:3]
+    prob = str(tmp_path / "p.txt")
+    with open(prob, "w") as f:
+        f.write("%d %d %d %.17g %.17g %.17g 0 %.17g %.17g %.17g\n" % (pr["P"], pr["L"], pr["E"], *CLASSES[0, :3], *CLASSES[2, :3]))
+        for i in range(pr["P"]):
+            f.write("%d %s\n" % (1 if pr["cam_hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in pr["cams"][i])))
+        for j in range(pr["L"]):
+            f.write("0 %s\n" % " ".join("%.17g" % v for v in pr["pts"][j]))
+        for k in range(pr["E"]):
+            f.write("%d %d %.17g %.17g %d %.17g\n" % (pr["cam_idx"][k], pr["pt_idx"][k], meas[k][0], meas[k][1], int(second[k]), CLASSES[cls[k], 4]))
+    ref, _ = _run(host, prob, "lm_fix6_3_hip", 5, str(tmp_path / "r.json"), mode="classes")
+    out, err = _run(host, prob, "lm_fix6_3_hipdev", 5, str(tmp_path / "o.json"), mode="classes")
+    assert DEV_ON in err and "4 edge classes" in err
+    assert out["trials"] == ref["trials"] and np.allclose(out["chi2"], ref["chi2"], rtol=1e-9, atol=0)
+    assert np.allclose(out["lambda"], ref["lambda"], rtol=1e-9, atol=0) and relerr(np.array(out["cams"]), np.array(ref["cams"])) < 1e-9
+
+    g = manhattan_golden()
+    path = str(tmp_path / "m.txt")
+    with open(path, "w") as f:
+        nv, ne = len(g["estimates"]), len(g["vi"])
+        f.write("%d %d\n" % (nv, ne))
+        for i in range(nv):
+            f.write("%d %s\n" % (1 if g["hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in g["estimates"][i])))
+        for k in range(ne):
+            f.write("%d %d %s %s\n" % (g["vi"][k], g["vj"][k], " ".join("%.17g" % v for v in g["meas"][k]),
+                                       " ".join("%.17g" % v for v in np.asarray(g["omega"][k]).reshape(-1))))
+    ref, _ = _run(host, path, "lm_fix3_2_hip", 6, str(tmp_path / "r2.json"), mode="se2huber:1.5")
+    out, err = _run(host, path, "lm_fix3_2_hipdev", 6, str(tmp_path / "o2.json"), mode="se2huber:1.5")
+    assert DEV_ON in err and out["iterations"] == 6
+    assert np.allclose(out["chi2"], ref["chi2"], rtol=1e-9, atol=0)
+    assert np.abs(np.array(out["poses"]) - np.array(ref["poses"])).max() < 1e-8
+
+
+def test_device_resident_gauss_newton_through_online_growth(host, tmp_path):
+    """updateInitialization + solve(iteration > 0) under gn_fix6_3_hipdev on the localisation graph of the online test: the
+    graph is generic (fixed points), so the driver stays on g2o's host loop through the rebuilt structure and ends where
+    gn_fix6_3_hip ends."""
+    pr = ba_case(12, 150)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr, fix_points=True)
+    ref, _ = _run(host, prob, "gn_fix6_3_hip", 2, str(tmp_path / "r.json"), mode="online:7")
+    out, err = _run(host, prob, "gn_fix6_3_hipdev", 2, str(tmp_path / "o.json"), mode="online:7")
+    assert DEV_OFF in err and DEV_ON not in err and out["iterations"] == ref["iterations"] == 4
+    assert np.abs(np.array(out["cams"]) - np.array(ref["cams"])).max() < 1e-12
