@@ -172,6 +172,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   // 128 classes, ...) sends the call back here without it: the edges then go to their generic per-key groups.
   bool buildStructureImpl(bool tryBA, bool tryPG) {
     if (!_h || !_optimizer) return false;
+    double tSetup = get_monotonic_time(), setupMs[4] = {0., 0., 0., 0.};   // grouping | edge sets + buffers | g2ohip_build_structure | front ends
     unpinAll();                                        // (the buffers below are about to be reallocated)
     if (g2ohip_init(_h) != G2OHIP_OK) return fail("init");
     if (g2ohip_clear_edge_sets(_h) != G2OHIP_OK) return fail("clear_edge_sets");   // (a second optimize(), online growth: a new graph)
@@ -274,6 +275,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
       g.v0.push_back(v0->hessianIndex());              // -1 when fixed (optimizable_graph.h:299)
       if (v1) g.v1.push_back(v1->hessianIndex());
     }
+    setupMs[0] = 1e3 * lap(tSetup);
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       Group& g = _groups[gi];
       const int n = (int)g.edges.size();
@@ -288,16 +290,16 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
           if (g2ohip_set_robust_kernel_per_edge(_h, g.set, g.rkKind.data(), g.rkDelta.data()) != G2OHIP_OK) return fail("set_robust_kernel_per_edge");
         }
       }
-      // The library takes a side's dimension from the hessian indices; a side whose vertices are ALL fixed (e.g. a
-      // localisation graph over fixed points) is taken as a pose side there (p columns), whatever the vertex type: the
-      // buffers are sized for the larger of the two so that g2ohip_set_edge_data never reads past their end.
-      const int w0 = g.key.dim0 > p ? g.key.dim0 : p, w1 = g.key.dim1 ? (g.key.dim1 > p ? g.key.dim1 : p) : 0;
-      g.J0.assign((size_t)n * g.key.d * w0, 0.0);
-      g.J1.assign((size_t)n * g.key.d * w1, 0.0);
-      g.Om.assign((size_t)n * g.key.d * g.key.d, 0.0);
-      g.err.assign((size_t)n * g.key.d, 0.0);
+      // (the staging buffers of the generic path -- 0.96 GB at the metric configuration -- are allocated by the first buildSystem
+      // that finds the group still generic: a group on a device front end never needs them)
+      g.J0.clear();
+      g.J1.clear();
+      g.Om.clear();
+      g.err.clear();
     }
+    setupMs[1] = 1e3 * lap(tSetup);
     if (g2ohip_build_structure(_h, _nP, _nL, _doSchur ? 1 : 0) != G2OHIP_OK) return fail("build_structure");
+    setupMs[2] = 1e3 * lap(tSetup);
     resizeVector(g2ohip_vector_size(_h));              // Solver::_x, _b (solver.cpp:46-70)
     _diag.assign(g2ohip_vector_size(_h), 0.0);
     pinDoubles(_x, g2ohip_vector_size(_h));            // what crosses PCIe every iteration is page-locked once (g2ohip_host_register)
@@ -319,6 +321,10 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
           break;
         }
       }
+    setupMs[3] = 1e3 * lap(tSetup);
+    if (_timing)
+      std::cerr << "{\"g2ohip_adapter_setup_ms\": {\"grouping\": " << setupMs[0] << ", \"edge_sets_and_buffers\": " << setupMs[1]
+                << ", \"build_structure\": " << setupMs[2] << ", \"front_ends_and_pinning\": " << setupMs[3] << "}}" << std::endl;
     return true;
   }
 
@@ -362,6 +368,17 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
         continue;
       }
       const int d = g.key.d, d0 = g.key.dim0, d1 = g.key.dim1;
+      if (g.err.empty() && !g.edges.empty()) {
+        // The library takes a side's dimension from the hessian indices; a side whose vertices are ALL fixed (e.g. a
+        // localisation graph over fixed points) is taken as a pose side there (p columns), whatever the vertex type: the
+        // buffers are sized for the larger of the two so that g2ohip_set_edge_data never reads past their end.
+        const size_t n = g.edges.size();
+        const int w0 = d0 > p ? d0 : p, w1 = d1 ? (d1 > p ? d1 : p) : 0;
+        g.J0.assign(n * d * w0, 0.0);
+        g.J1.assign(n * d * w1, 0.0);
+        g.Om.assign(n * d * d, 0.0);
+        g.err.assign(n * d, 0.0);
+      }
       for (size_t k = 0; k < g.edges.size(); ++k) {
         OptimizableGraph::Edge* e = g.edges[k];
         e->linearizeOplus(ws);                         // block_solver.hpp:531 (the error is current: computeActiveErrors)

@@ -2378,31 +2378,54 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   for (auto& esp : sets_) {
     EdgeSet& es = *esp;
     std::vector<int> dp, pp_, dl, pl_, dop, pop, dol, pol;
-    for (std::vector<int>* v : {&dp, &pp_, &dl, &pl_, &dop, &pop, &dol, &pol}) v->reserve((size_t)es.n);   // (5 M push_backs each at the metric configuration)
-    for (int k = 0; k < es.n; ++k) {
-      int a = es.v0[k], b = es.v1[k];
-      if (a >= 0) {
-        if (is_lm(a)) { dl.push_back(a - nP); pl_.push_back(k << 1); }
-        else { dp.push_back(a); pp_.push_back(k << 1); }
-      }
-      if (b >= 0) {
-        if (is_lm(b)) { dl.push_back(b - nP); pl_.push_back((k << 1) | 1); }
-        else { dp.push_back(b); pp_.push_back((k << 1) | 1); }
-      }
-      if (a >= 0 && b >= 0) {
-        if (!is_lm(a) && !is_lm(b)) {
-          int tr = a > b;
-          int q = find_block(pp_colptr, pp_row, std::max(a, b), std::min(a, b));
-          dop.push_back(q);
-          pop.push_back((k << 1) | tr);
-        } else {
-          int pose = is_lm(a) ? b : a, lm = (is_lm(a) ? a : b) - nP;
-          int tr = is_lm(a) ? 1 : 0;  // vertex 0 marginalized -> write transposed (block_solver.hpp:240-244)
-          dol.push_back(find_block(pl_colptr, pl_row, lm, pose));
-          pol.push_back((k << 1) | tr);
+    {
+      // (5 M push_backs each and as many block searches at the metric configuration: contiguous chunks of the edge list on the
+      // host threads, every chunk into its own lists, concatenated in chunk order -- the edge order of the sequential loop)
+      struct Part { std::vector<int> v[8]; };
+      const size_t nch = std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), ((size_t)es.n + 65535) / 65536));
+      std::vector<Part> parts(nch);
+      host_parallel_chunks((size_t)es.n, nch, [&](size_t c, size_t kb, size_t ke) {
+        std::vector<int>&dp = parts[c].v[0], &pp_ = parts[c].v[1], &dl = parts[c].v[2], &pl_ = parts[c].v[3], &dop = parts[c].v[4],
+                        &pop = parts[c].v[5], &dol = parts[c].v[6], &pol = parts[c].v[7];
+        for (int i = 0; i < 8; ++i) parts[c].v[i].reserve(ke - kb);
+        for (int k = (int)kb; k < (int)ke; ++k) {
+          int a = es.v0[k], b = es.v1[k];
+          if (a >= 0) {
+            if (is_lm(a)) { dl.push_back(a - nP); pl_.push_back(k << 1); }
+            else { dp.push_back(a); pp_.push_back(k << 1); }
+          }
+          if (b >= 0) {
+            if (is_lm(b)) { dl.push_back(b - nP); pl_.push_back((k << 1) | 1); }
+            else { dp.push_back(b); pp_.push_back((k << 1) | 1); }
+          }
+          if (a >= 0 && b >= 0) {
+            if (!is_lm(a) && !is_lm(b)) {
+              int tr = a > b;
+              int q = find_block(pp_colptr, pp_row, std::max(a, b), std::min(a, b));
+              dop.push_back(q);
+              pop.push_back((k << 1) | tr);
+            } else {
+              int pose = is_lm(a) ? b : a, lm = (is_lm(a) ? a : b) - nP;
+              int tr = is_lm(a) ? 1 : 0;  // vertex 0 marginalized -> write transposed (block_solver.hpp:240-244)
+              dol.push_back(find_block(pl_colptr, pl_row, lm, pose));
+              pol.push_back((k << 1) | tr);
+            }
+          }
         }
+      });
+      std::vector<int>* outs[8] = {&dp, &pp_, &dl, &pl_, &dop, &pop, &dol, &pol};
+      for (int i = 0; i < 8; ++i) {
+        if (nch == 1) {
+          outs[i]->swap(parts[0].v[i]);
+          continue;
+        }
+        size_t tot = 0;
+        for (size_t c = 0; c < nch; ++c) tot += parts[c].v[i].size();
+        outs[i]->reserve(tot);
+        for (size_t c = 0; c < nch; ++c) outs[i]->insert(outs[i]->end(), parts[c].v[i].begin(), parts[c].v[i].end());
       }
     }
+    lap("contributor lists: edge walk");
     es.touches_pose = !dp.empty();
     es.touches_lm = !dl.empty();
     std::vector<int> ptr, ent;
@@ -2436,6 +2459,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       es.first_lm = !seen_lm;
       seen_lm = true;
     }
+    lap("contributor lists: per vertex");
     if (!dop.empty()) {
       es.first_op = !seen_op;
       seen_op = true;
@@ -2449,8 +2473,9 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         dst_list.erase(std::unique(dst_list.begin(), dst_list.end()), dst_list.end());
       }
       std::vector<int> local(dop.size());
-      for (size_t k = 0; k < dop.size(); ++k)
-        local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dop[k]) - dst_list.begin());
+      host_parallel_for(dop.size(), [&](size_t b_, size_t e_) {
+        for (size_t k = b_; k < e_; ++k) local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dop[k]) - dst_list.begin());
+      });
       group_by((int)dst_list.size(), local, pop, ptr, ent);
       es.n_op = (int)dst_list.size();
       es.op_dst.upload(dst_list, st_);
@@ -2470,8 +2495,13 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         dst_list.erase(std::unique(dst_list.begin(), dst_list.end()), dst_list.end());
       }
       std::vector<int> local(dol.size());
-      for (size_t k = 0; k < dol.size(); ++k)
-        local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dol[k]) - dst_list.begin());
+      if (es.first_ol) {
+        local = dol;   // (the destination list is every block in order: the position of a block is the block)
+      } else {
+        host_parallel_for(dol.size(), [&](size_t b_, size_t e_) {
+          for (size_t k = b_; k < e_; ++k) local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dol[k]) - dst_list.begin());
+        });
+      }
       group_by((int)dst_list.size(), local, pol, ptr, ent);
       es.n_ol = (int)dst_list.size();
       es.ol_dst.upload(dst_list, st_);
@@ -2480,7 +2510,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     }
     es.has_data = false;
   }
-  lap("contributor lists");
+  lap("contributor lists: per off-diagonal block");
   // ---- Schur structure (block_solver.hpp:256-292)
   n_sc_ = 0;
   if (schur_) {
@@ -2531,45 +2561,18 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       size_t max_lds = 0;
       int lm = 0;
       struct Ent { int dest, pack; unsigned short lml; };
-      std::vector<Ent> ents;
-      std::vector<int> order;
       // per tile: landmark range, first block range, optional SECOND block range (split landmarks, below)
       std::vector<int> t_l0, t_l1, t_q0, t_ns, t_q1, t_n1;
-      auto emit_tile = [&](int l0, int l1, int q0, int ns, int q1, int n1) {
-        order.resize(ents.size());
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ents[a].dest < ents[b].dest; });  // landmark order kept per dest
-        // runs of equal destination, longest first: the lane groups of one wave run in lockstep, so a wave should
-        // hold destinations with similar entry counts (the order of the partials of a destination over the tiles,
-        // and the entry order inside a destination, are unaffected: results do not change)
-        std::vector<std::pair<int, int>> runs;   // (begin, end) into order
-        for (size_t k = 0; k < order.size();) {
-          size_t k2 = k + 1;
-          while (k2 < order.size() && ents[order[k2]].dest == ents[order[k]].dest) ++k2;
-          runs.emplace_back((int)k, (int)k2);
-          k = k2;
-        }
-        if (schur_sort_dests)
-          std::stable_sort(runs.begin(), runs.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
-            return (x.second - x.first) > (y.second - y.first);
-          });
-        for (const auto& run : runs) {
-          td_dest.push_back(ents[order[run.first]].dest);
-          rd_cnt[ents[order[run.first]].dest]++;
-          for (int k = run.first; k < run.second; ++k) {
-            te_pack.push_back(ents[order[k]].pack);
-            te_lm.push_back(ents[order[k]].lml);
-          }
-          td_ptr.push_back((int)te_pack.size());
-        }
-        t_l0.push_back(l0); t_l1.push_back(l1); t_q0.push_back(q0); t_ns.push_back(ns); t_q1.push_back(q1); t_n1.push_back(n1);
-        tile_td0.push_back((int)td_dest.size());
-      };
+      // Three passes: (A) the tile boundaries -- a sequential greedy walk over the landmarks that only counts --, (B) the entry
+      // lists of the tiles on the host threads (15 M entries, a block search and a sort key each, at the metric configuration:
+      // a tile is independent of the others), (C) the concatenation in tile order.
+      struct TileDesc { int l0, l1, q0, ns, q1, n1; bool split, same; int a0, b0, na, nb2; };
+      std::vector<TileDesc> descs;
       n_split_tiles_ = 0;
       while (lm < nL) {
         // greedy tile: as many landmarks as fit the LDS budget
         int l0 = lm;
-        size_t bytes = 0, nent = 0;
+        size_t bytes = 0;
         {
           // A landmark seen by so many poses that its blocks and pair list alone exceed the budget (K(K+1)/2 entries:
           // ~64 poses at 39 KB) is SPLIT: its observation list is cut into chunks, one tile per pair of chunks (A <= B)
@@ -2587,19 +2590,10 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
               for (size_t b0 = a0; b0 < K; b0 += C) {
                 const int na = (int)std::min(C, K - a0), nb2 = (int)std::min(C, K - b0);
                 const bool same = a0 == b0;
-                ents.clear();
-                for (int a = 0; a < na; ++a)
-                  for (int b = same ? a : 0; b < nb2; ++b) {
-                    const int qa = qb + (int)a0 + a, qbb = qb + (int)b0 + b;
-                    Ent e;
-                    e.dest = find_block(hs_colptr, hs_row, pl_row[qbb], pl_row[qa]);
-                    e.pack = a | ((same ? b : na + b) << 16);
-                    e.lml = 0;
-                    ents.push_back(e);
-                  }
-                const size_t tb = (size_t)(na + (same ? 0 : nb2)) * PL * 8 + DP * 8 + BP * 8 + ents.size() * (6 + 8);
+                const size_t nents = same ? (size_t)na * (na + 1) / 2 : (size_t)na * nb2;
+                const size_t tb = (size_t)(na + (same ? 0 : nb2)) * PL * 8 + DP * 8 + BP * 8 + nents * (6 + 8);
                 max_lds = std::max(max_lds, tb + 64);
-                emit_tile(lm, lm + 1, qb + (int)a0, na, same ? 0 : qb + (int)b0, same ? 0 : nb2);
+                descs.push_back(TileDesc{lm, lm + 1, qb + (int)a0, na, same ? 0 : qb + (int)b0, same ? 0 : nb2, true, same, (int)a0, (int)b0, na, nb2});
                 ++n_split_tiles_;
               }
             ++lm;
@@ -2612,27 +2606,109 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
           bool ok16 = (size_t)(pl_colptr[lm + 1] - pl_colptr[l0]) < 65536 && (lm + 1 - l0) < 65536;
           if (lm > l0 && (bytes + add > schur_tile_bytes || !ok16)) break;
           bytes += add;
-          nent += K * (K + 1) / 2;
           ++lm;
         }
         if ((size_t)(pl_colptr[lm] - pl_colptr[l0]) >= 65536) throw ArgFailure("a landmark is observed by >= 65536 poses: unsupported");
         max_lds = std::max(max_lds, bytes + 64);
-        ents.clear();
-        ents.reserve(nent);
         const int q0 = pl_colptr[l0];
-        for (int c = l0; c < lm; ++c)
-          for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
-            for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) {
-              Ent e;
-              e.dest = find_block(hs_colptr, hs_row, pl_row[q2], pl_row[q1]);
-              e.pack = (q1 - q0) | ((q2 - q0) << 16);
-              e.lml = (unsigned short)(c - l0);
-              ents.push_back(e);
-            }
-        for (int c = l0; c < lm; ++c)
-          for (int q = pl_colptr[c]; q < pl_colptr[c + 1]; ++q) slot_lm[q] = (unsigned short)(c - l0);
-        emit_tile(l0, lm, q0, pl_colptr[lm] - q0, 0, 0);
+        descs.push_back(TileDesc{l0, lm, q0, pl_colptr[lm] - q0, 0, 0, false, false, 0, 0, 0, 0});
         tile_lm0.push_back(lm);
+      }
+      struct TileOut {
+        std::vector<int> dest, cnt, pack;   // destinations of the tile (longest run first), entries per destination, entries
+        std::vector<unsigned short> lml;
+      };
+      std::vector<TileOut> outs(descs.size());
+      const bool sort_dests = schur_sort_dests;
+      host_parallel_for(descs.size(), [&](size_t tb_, size_t te_) {
+        std::vector<Ent> ents;
+        std::vector<int> order;
+        std::vector<std::pair<int, int>> runs;   // (begin, end) into order
+        for (size_t ti = tb_; ti < te_; ++ti) {
+          const TileDesc& td = descs[ti];
+          ents.clear();
+          if (td.split) {
+            const int qb = td.q0 - td.a0;
+            for (int a = 0; a < td.na; ++a)
+              for (int b = td.same ? a : 0; b < td.nb2; ++b) {
+                const int qa = qb + td.a0 + a, qbb = qb + td.b0 + b;
+                Ent e;
+                e.dest = find_block(hs_colptr, hs_row, pl_row[qbb], pl_row[qa]);
+                e.pack = a | ((td.same ? b : td.na + b) << 16);
+                e.lml = 0;
+                ents.push_back(e);
+              }
+          } else {
+            for (int c = td.l0; c < td.l1; ++c)
+              for (int q1 = pl_colptr[c]; q1 < pl_colptr[c + 1]; ++q1)
+                for (int q2 = q1; q2 < pl_colptr[c + 1]; ++q2) {
+                  Ent e;
+                  e.dest = find_block(hs_colptr, hs_row, pl_row[q2], pl_row[q1]);
+                  e.pack = (q1 - td.q0) | ((q2 - td.q0) << 16);
+                  e.lml = (unsigned short)(c - td.l0);
+                  ents.push_back(e);
+                }
+            for (int c = td.l0; c < td.l1; ++c)
+              for (int q = pl_colptr[c]; q < pl_colptr[c + 1]; ++q) slot_lm[q] = (unsigned short)(c - td.l0);
+          }
+          order.resize(ents.size());
+          std::iota(order.begin(), order.end(), 0);
+          std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ents[a].dest < ents[b].dest; });  // landmark order kept per dest
+          // runs of equal destination, longest first: the lane groups of one wave run in lockstep, so a wave should
+          // hold destinations with similar entry counts (the order of the partials of a destination over the tiles,
+          // and the entry order inside a destination, are unaffected: results do not change)
+          runs.clear();
+          for (size_t k = 0; k < order.size();) {
+            size_t k2 = k + 1;
+            while (k2 < order.size() && ents[order[k2]].dest == ents[order[k]].dest) ++k2;
+            runs.emplace_back((int)k, (int)k2);
+            k = k2;
+          }
+          if (sort_dests)
+            std::stable_sort(runs.begin(), runs.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
+              return (x.second - x.first) > (y.second - y.first);
+            });
+          TileOut& o = outs[ti];
+          o.dest.reserve(runs.size());
+          o.cnt.reserve(runs.size());
+          o.pack.reserve(ents.size());
+          o.lml.reserve(ents.size());
+          for (const auto& run : runs) {
+            o.dest.push_back(ents[order[run.first]].dest);
+            o.cnt.push_back(run.second - run.first);
+            for (int k = run.first; k < run.second; ++k) {
+              o.pack.push_back(ents[order[k]].pack);
+              o.lml.push_back(ents[order[k]].lml);
+            }
+          }
+        }
+      }, 8);
+      {
+        size_t ntd = 0, nte = 0;
+        for (const TileOut& o : outs) {
+          ntd += o.dest.size();
+          nte += o.pack.size();
+        }
+        td_dest.reserve(ntd);
+        td_ptr.reserve(ntd + 1);
+        te_pack.reserve(nte);
+        te_lm.reserve(nte);
+      }
+      for (size_t ti = 0; ti < descs.size(); ++ti) {
+        const TileDesc& td = descs[ti];
+        TileOut& o = outs[ti];
+        for (size_t r = 0; r < o.dest.size(); ++r) {
+          td_dest.push_back(o.dest[r]);
+          rd_cnt[o.dest[r]]++;
+          td_ptr.push_back(td_ptr.back() + o.cnt[r]);
+        }
+        te_pack.insert(te_pack.end(), o.pack.begin(), o.pack.end());
+        te_lm.insert(te_lm.end(), o.lml.begin(), o.lml.end());
+        t_l0.push_back(td.l0); t_l1.push_back(td.l1); t_q0.push_back(td.q0); t_ns.push_back(td.ns); t_q1.push_back(td.q1); t_n1.push_back(td.n1);
+        tile_td0.push_back((int)td_dest.size());
+        std::vector<int>().swap(o.dest);   // (release as we go)
+        std::vector<int>().swap(o.pack);
+        std::vector<unsigned short>().swap(o.lml);
       }
       n_tiles_ = (int)t_l0.size();
       tile_lm0_h_ = tile_lm0;   // (tile boundaries: only meaningful while no landmark is split, n_split_tiles_ == 0)
@@ -4567,7 +4643,9 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
   ba_.omega_identity = info == nullptr;
   if (!info) {
     om.assign(n * 4, 0.0);
-    for (size_t k = 0; k < n; ++k) om[4 * k] = om[4 * k + 3] = 1.0;   // information().setIdentity()
+    host_parallel_for(n, [&](size_t b_, size_t e_) {
+      for (size_t k = b_; k < e_; ++k) om[4 * k] = om[4 * k + 3] = 1.0;   // information().setIdentity()
+    });
     info = om.data();
   }
   es.own_omega.upload(info, n * 4, st_);
@@ -4578,11 +4656,15 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
     bool unique = es.first_lm && es.first_ol;
     for (size_t k = 0; k < n; ++k)
       if (es.v0[k] < 0) unique = false;   // a fixed landmark: its edges would be skipped by the landmark-major kernel
+    host_parallel_for(n, [&](size_t b_, size_t e_) {   // (the searches in parallel, the duplicate check in edge order)
+      for (size_t k = b_; k < e_; ++k) {
+        const int a = es.v0[k], b = es.v1[k];
+        if (a >= 0 && b >= 0) edge_hpl[k] = find_block(pl_colptr, pl_row, a - nP_, b);
+      }
+    });
     for (size_t k = 0; k < n; ++k) {
-      const int a = es.v0[k], b = es.v1[k];
-      if (a < 0 || b < 0) continue;
-      const int q = find_block(pl_colptr, pl_row, a - nP_, b);
-      edge_hpl[k] = q;
+      const int q = edge_hpl[k];
+      if (q < 0) continue;
       if (seen[q]) unique = false;
       seen[q] = 1;
     }
@@ -4596,16 +4678,18 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
       const size_t nq = std::max<size_t>(pl_row.size(), 1);
       std::vector<int> cq(nq, 0), pq(nq, 0);
       std::vector<double> mq(nq * 2, 0.0), oq(info == om.data() ? 0 : nq * 4, 0.0);
-      for (size_t k = 0; k < n; ++k) {
-        const int q = edge_hpl[k];
-        if (q < 0) continue;
-        cq[q] = cam_vertex[k];
-        pq[q] = point_vertex[k];
-        mq[2 * (size_t)q] = meas[2 * k];
-        mq[2 * (size_t)q + 1] = meas[2 * k + 1];
-        if (!oq.empty())
-          for (int i = 0; i < 4; ++i) oq[4 * (size_t)q + i] = info[4 * k + i];
-      }
+      host_parallel_for(n, [&](size_t b_, size_t e_) {   // (unique: every q is written by one edge)
+        for (size_t k = b_; k < e_; ++k) {
+          const int q = edge_hpl[k];
+          if (q < 0) continue;
+          cq[q] = cam_vertex[k];
+          pq[q] = point_vertex[k];
+          mq[2 * (size_t)q] = meas[2 * k];
+          mq[2 * (size_t)q + 1] = meas[2 * k + 1];
+          if (!oq.empty())
+            for (int i = 0; i < 4; ++i) oq[4 * (size_t)q + i] = info[4 * k + i];
+        }
+      });
       ba_.cam_q.upload(cq, st_);
       ba_.pt_q.upload(pq, st_);
       ba_.meas_q.upload(mq, st_);
@@ -4618,31 +4702,35 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
     const size_t nk = es.h_vp_ent.size();
     std::vector<double> mpm(nk * 2), opm(ba_.omega_identity ? 0 : nk * 4);
     std::vector<int> ppm(nk), cpm(nk);
-    for (size_t k = 0; k < nk; ++k) {
-      const size_t e = (size_t)(es.h_vp_ent[k] >> 1);
-      mpm[2 * k] = meas[2 * e];
-      mpm[2 * k + 1] = meas[2 * e + 1];
-      ppm[k] = point_vertex[e];
-      cpm[k] = cam_vertex[e];
-      if (!ba_.omega_identity)
-        for (int i = 0; i < 4; ++i) opm[4 * k + i] = info[4 * e + i];
-    }
+    host_parallel_for(nk, [&](size_t b_, size_t e_) {
+      for (size_t k = b_; k < e_; ++k) {
+        const size_t e = (size_t)(es.h_vp_ent[k] >> 1);
+        mpm[2 * k] = meas[2 * e];
+        mpm[2 * k + 1] = meas[2 * e + 1];
+        ppm[k] = point_vertex[e];
+        cpm[k] = cam_vertex[e];
+        if (!ba_.omega_identity)
+          for (int i = 0; i < 4; ++i) opm[4 * k + i] = info[4 * e + i];
+      }
+    });
     // the same for the landmark side (observation-list order of the landmarks)
     const size_t nl = es.h_vl_ent.size();
     std::vector<double> mlm(nl * 2), olm(ba_.omega_identity ? 0 : nl * 4);
     std::vector<int> clm(nl), hlm(nl), plm(nl), rlm(nl);
-    for (size_t k = 0; k < nl; ++k) {
-      const size_t e = (size_t)(es.h_vl_ent[k] >> 1);
-      mlm[2 * k] = meas[2 * e];
-      mlm[2 * k + 1] = meas[2 * e + 1];
-      clm[k] = cam_vertex[e];
-      plm[k] = point_vertex[e];
-      const int a = es.v0[e], b = es.v1[e];
-      hlm[k] = (a >= 0 && b >= 0) ? find_block(pl_colptr, pl_row, a - nP_, b) : -1;
-      rlm[k] = hlm[k] >= 0 ? b : -1;
-      if (!ba_.omega_identity)
-        for (int i = 0; i < 4; ++i) olm[4 * k + i] = info[4 * e + i];
-    }
+    host_parallel_for(nl, [&](size_t b_, size_t e_) {
+      for (size_t k = b_; k < e_; ++k) {
+        const size_t e = (size_t)(es.h_vl_ent[k] >> 1);
+        mlm[2 * k] = meas[2 * e];
+        mlm[2 * k + 1] = meas[2 * e + 1];
+        clm[k] = cam_vertex[e];
+        plm[k] = point_vertex[e];
+        const int a = es.v0[e], b = es.v1[e];
+        hlm[k] = (a >= 0 && b >= 0) ? find_block(pl_colptr, pl_row, a - nP_, b) : -1;
+        rlm[k] = hlm[k] >= 0 ? b : -1;
+        if (!ba_.omega_identity)
+          for (int i = 0; i < 4; ++i) olm[4 * k + i] = info[4 * e + i];
+      }
+    });
     // lane slots of the tiles that assemble their own landmarks
     ba_.ll_slots_ok = false;
     if (schur_ && n_tiles_ > 0 && tiles_cover_all_ && n_split_tiles_ == 0 && (int)tile_lm0_h_.size() == n_tiles_ + 1 &&
@@ -4681,21 +4769,23 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
         std::vector<int4> rec(ns);
         std::vector<int> edge(ns, 0), srow(ns, -1);
         std::vector<double> ms(ns * 2, 0.0), os(ba_.omega_identity ? 0 : ns * 4, 0.0);
-        for (int t = 0; t < n_tiles_; ++t)
-          for (int i = 0; i < tl[t].y; ++i) {
-            const size_t sidx = (size_t)tl[t].x + i;
-            const int w = slots[sidx];
-            rec[sidx] = make_int4(w, 0, 0, -1);
-            if ((w & 0xfff) == 0xfff) continue;
-            const size_t k = (size_t)tl[t].z + (w & 0xfff);
-            rec[sidx] = make_int4(w, clm[k], plm[k], hlm[k]);
-            edge[sidx] = es.h_vl_ent[k] >> 1;
-            srow[sidx] = rlm[k];
-            ms[2 * sidx] = mlm[2 * k];
-            ms[2 * sidx + 1] = mlm[2 * k + 1];
-            if (!ba_.omega_identity)
-              for (int j = 0; j < 4; ++j) os[4 * sidx + j] = olm[4 * k + j];
-          }
+        host_parallel_for((size_t)n_tiles_, [&](size_t t0_, size_t t1_) {   // (a tile's slots are its own)
+          for (size_t t = t0_; t < t1_; ++t)
+            for (int i = 0; i < tl[t].y; ++i) {
+              const size_t sidx = (size_t)tl[t].x + i;
+              const int w = slots[sidx];
+              rec[sidx] = make_int4(w, 0, 0, -1);
+              if ((w & 0xfff) == 0xfff) continue;
+              const size_t k = (size_t)tl[t].z + (w & 0xfff);
+              rec[sidx] = make_int4(w, clm[k], plm[k], hlm[k]);
+              edge[sidx] = es.h_vl_ent[k] >> 1;
+              srow[sidx] = rlm[k];
+              ms[2 * sidx] = mlm[2 * k];
+              ms[2 * sidx + 1] = mlm[2 * k + 1];
+              if (!ba_.omega_identity)
+                for (int j = 0; j < 4; ++j) os[4 * sidx + j] = olm[4 * k + j];
+            }
+        }, 64);
         if (n_tiles_ == 0) rec[0] = make_int4(kIdleSlot, 0, 0, -1);
         ba_.ll_rec.upload(rec, st_);
         ba_.ll_edge.upload(edge, st_);

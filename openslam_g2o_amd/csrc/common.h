@@ -4,8 +4,11 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <exception>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace g2ohip {
@@ -30,6 +33,49 @@ struct StateFailure : std::runtime_error {
       throw ::g2ohip::HipFailure(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
                                  ":" + std::to_string(__LINE__) + ")");                              \
   } while (0)
+
+// fn(begin, end) over [0, n) on up to G2OHIP_HOST_THREADS (default 8, at most the hardware's) host threads: the one-time set-up
+// loops over the edges / observations of a graph (5 M at the metric configuration).  Chunks are contiguous and in order, so a
+// caller that gives every chunk its own output and concatenates them keeps the sequential order.  No HIP calls inside fn.
+inline int host_threads() {
+  static const int nt = [] {
+    const char* e = std::getenv("G2OHIP_HOST_THREADS");
+    int v = e ? std::atoi(e) : 8;
+    const unsigned hc = std::thread::hardware_concurrency();
+    if (hc > 0 && v > (int)hc) v = (int)hc;
+    return v < 1 ? 1 : v;
+  }();
+  return nt;
+}
+template <class Fn>
+inline void host_parallel_chunks(size_t n, size_t nchunks, Fn fn) {   // fn(chunk, begin, end)
+  if (nchunks < 1) nchunks = 1;
+  const size_t step = (n + nchunks - 1) / nchunks;
+  if (nchunks == 1 || n == 0) {
+    fn((size_t)0, (size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  std::vector<std::exception_ptr> err(nchunks);
+  auto body = [&](size_t c) {
+    const size_t b = c * step < n ? c * step : n, e = b + step < n ? b + step : n;
+    try {
+      fn(c, b, e);
+    } catch (...) {
+      err[c] = std::current_exception();
+    }
+  };
+  for (size_t c = 1; c < nchunks; ++c) pool.emplace_back(body, c);
+  body(0);
+  for (auto& t : pool) t.join();
+  for (auto& e : err)
+    if (e) std::rethrow_exception(e);
+}
+template <class Fn>
+inline void host_parallel_for(size_t n, Fn fn, size_t grain = (size_t)1 << 15) {   // fn(begin, end)
+  const size_t nt = (size_t)host_threads(), want = (n + grain - 1) / grain;
+  host_parallel_chunks(n, want < nt ? want : nt, [&](size_t, size_t b, size_t e) { fn(b, e); });
+}
 
 // When set, DevBuf operations are skipped: lets the host-only symbolic analysis (partition queries, CPU
 // tests) share the code path of the device build without touching HIP.
