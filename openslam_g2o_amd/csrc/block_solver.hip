@@ -445,16 +445,36 @@ struct TileSplit {
 };
 // R (symmetric, its lower triangle is read) = Lm diag(d) Lm' -> C = Lm |d|^(1/2) (column major, zeros above the diagonal),
 // sg = sign(d), u = Sg C' b
+// sqrt(a) and 1 / sqrt(a), a > 0: v_rsq_f64 seed, two Goldschmidt steps, one Newton correction (the recipe of the f64 sqrt
+// expansion, which then also has the reciprocal root: ~1-2 ulp each).  A pivot of the split needs sqrt |d| and 1 / d = sign(d) /
+// sqrt|d|^2: one of these instead of a division (~25 instructions) and a square root (~20) per pivot -- the list heads of the
+// tile kernel run this with a fifth of their lanes active, the whole wave pays
+__device__ __forceinline__ void bs_sqrt_and_rsqrt(double a, double& s, double& r) {
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  const double dd = fma(-g, g, a);
+  g = fma(dd, h, g);
+  s = g;
+  r = h + h;
+}
 template <int LD>
 __device__ __forceinline__ bool landmark_split(const double* R, const double* b, double* C, double* sg, double* u) {
-  double Lm[LD * LD], d[LD];
+  double Lm[LD * LD], d[LD], sqd[LD];
 #pragma unroll
   for (int c = 0; c < LD; ++c) {
     double dc = R[c + LD * c];
 #pragma unroll
     for (int k = 0; k < c; ++k) dc -= Lm[c + LD * k] * Lm[c + LD * k] * d[k];
     d[c] = dc;
-    const double idc = 1.0 / dc;
+    double rsd;
+    bs_sqrt_and_rsqrt(fabs(dc), sqd[c], rsd);
+    const double idc = copysign(rsd * rsd, dc);
 #pragma unroll
     for (int r = c + 1; r < LD; ++r) {
       double v = R[r + LD * c];
@@ -467,7 +487,7 @@ __device__ __forceinline__ bool landmark_split(const double* R, const double* b,
   bool neg = false;
 #pragma unroll
   for (int c = 0; c < LD; ++c) {
-    const double sq = sqrt(fabs(d[c]));
+    const double sq = sqd[c];
     sg[c] = d[c] < 0.0 ? -1.0 : 1.0;
     neg = neg || d[c] < 0.0;
     double uu = 0.0;
