@@ -103,6 +103,17 @@ int g2ohip_init(g2ohip_solver* s);
  *   v1 == NULL: unary edges (BaseUnaryEdge, base_unary_edge.hpp:42-72).
  * Returns the set id (>= 0) or an error code (< 0).  Must precede g2ohip_build_structure. */
 int g2ohip_add_edge_set(g2ohip_solver* s, int error_dim, int n_edges, const int32_t* v0, const int32_t* v1);
+/* n-ary edges (BaseMultiEdge::constructQuadraticForm, base_multi_edge.hpp:170-222: H_ii and b_i once per vertex, H_ij once per
+ * pair i < j, the robust weight of the edge on all of them): ONE binary edge set per vertex pair (i, j) of the edges, each handed
+ * the pair's two Jacobians and the edges' information / error / robust kernel, with the parts another pair already contributes
+ * switched off -- G2OHIP_PART_NO_VERTEX0 / _NO_VERTEX1: no diagonal block and no right-hand side for that side of the set,
+ * G2OHIP_PART_NO_CHI2: the set's edges are not counted in g2ohip_chi2 / g2ohip_trial_stats.  E.g. three vertices: pair (0, 1)
+ * whole, pair (0, 2) with NO_VERTEX0 | NO_VERTEX1 | NO_CHI2, pair (1, 2) with NO_VERTEX0 | NO_CHI2 (vertex 2's own terms).  Generic path on one GPU;
+ * before g2ohip_build_structure. */
+#define G2OHIP_PART_NO_VERTEX0 1
+#define G2OHIP_PART_NO_VERTEX1 2
+#define G2OHIP_PART_NO_CHI2 4
+int g2ohip_set_edge_set_parts(g2ohip_solver* s, int set, int parts);
 
 /* Solver::buildStructure(), block_solver.hpp:142-295.  do_schur mirrors setSchur()
  * (OptimizationAlgorithmWithHessian::init, optimization_algorithm_with_hessian.cpp:55-69). */

@@ -25,6 +25,7 @@ c_dbl_p = C.POINTER(C.c_double)
 OK, NOT_PD, REPEAT = 0, 1, 2
 ERR_UNSUPPORTED = -4
 HPP, HPL, HLL, HSCHUR, DINV = 0, 1, 2, 3, 4
+PART_NO_VERTEX0, PART_NO_VERTEX1, PART_NO_CHI2 = 1, 2, 4      # g2ohip_set_edge_set_parts
 ARR_BSCHUR, ARR_X, ARR_B, ARR_EXCHANGE, ARR_XP, ARR_XBOUNDARY, ARR_XHALO, ARR_SCHUR_DIAG = 100, 101, 102, 103, 104, 105, 106, 107
 KERNEL_NONE, KERNEL_HUBER, KERNEL_PSEUDOHUBER, KERNEL_CAUCHY, KERNEL_SATURATED, KERNEL_DCS = 0, 1, 2, 3, 4, 5
 
@@ -50,7 +51,7 @@ EXPORTS = [
     "g2ohip_set_option", "g2ohip_get_nnzb", "g2ohip_get_pattern", "g2ohip_copy_values", "g2ohip_device_array",
     "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute", "g2ohip_ls_create",
     "g2ohip_ls_destroy", "g2ohip_ls_init", "g2ohip_ls_solve", "g2ohip_ls_solve_pattern", "g2ohip_ls_get_stats", "g2ohip_ls_set_option",
-    "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time", "g2ohip_add_schur_pattern",
+    "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time", "g2ohip_add_schur_pattern", "g2ohip_set_edge_set_parts",
     "g2ohip_set_lambda_split", "g2ohip_host_register", "g2ohip_host_unregister", "g2ohip_ba_set_edges", "g2ohip_ba_set_edges_classes", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
     "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
@@ -139,6 +140,7 @@ def load():
     L.g2ohip_copy_values.argtypes = [vp, C.c_int, c_dbl_p]
     L.g2ohip_device_array.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.g2ohip_add_schur_pattern.argtypes = [vp, C.c_int, c_int_p, c_int_p]
+    L.g2ohip_set_edge_set_parts.argtypes = [vp, C.c_int, C.c_int]
     L.g2ohip_set_lambda_split.argtypes = [vp, C.c_double, C.c_double, C.c_int]
     L.g2ohip_ba_set_edges.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, C.c_double, C.c_double, C.c_double]
     L.g2ohip_ba_set_edges_classes.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, c_int_p]
@@ -320,6 +322,10 @@ class HipBlockSolver:
     def setLambdaSplit(self, lam_pose, lam_landmark, backup=False):
         _check(self.L.g2ohip_set_lambda_split(self.h, lam_pose, lam_landmark, int(backup)), "setLambdaSplit")
         return True
+
+    def setEdgeSetParts(self, set_id, parts):
+        """One binary set per vertex pair of n-ary edges (BaseMultiEdge): PART_NO_VERTEX0 / PART_NO_VERTEX1 / PART_NO_CHI2."""
+        _check(self.L.g2ohip_set_edge_set_parts(self.h, set_id, int(parts)), "setEdgeSetParts")
 
     def addSchurPattern(self, rows, cols):
         rows, cols = _i32(rows), _i32(cols)

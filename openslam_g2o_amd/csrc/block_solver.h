@@ -24,6 +24,7 @@ namespace g2ohip {
 struct EdgeSet {
   int d = 0, n = 0, dim0 = 0, dim1 = 0;
   bool unary = false;
+  int parts = 0;           // G2OHIP_PART_* bits: what of its quadratic form the set does NOT contribute (set_edge_set_parts)
   std::vector<int> v0, v1;
   int kernel_kind = 0;
   double delta = 1.0;
@@ -59,6 +60,7 @@ class BlockSolver {
   void init();
   void clear_edge_sets();
   int add_edge_set(int d, int n, const int* v0, const int* v1);
+  void set_edge_set_parts(int set, int parts);
   void add_schur_pattern(int n, const int* rows, const int* cols);
   void build_structure(int nP, int nL, bool do_schur);
   bool update_structure(int new_poses, int set, int n, const int* v0, const int* v1);

@@ -2257,6 +2257,21 @@ int BlockSolver::add_edge_set(int d, int n, const int* v0, const int* v1) {
   return (int)sets_.size() - 1;
 }
 
+// An edge set that stands for ONE PAIR of vertices of n-ary edges (BaseMultiEdge, base_multi_edge.hpp:170-222: H_ii and b_i once
+// per vertex, H_ij once per pair i < j, chi2 once per edge): the caller registers a binary set per pair and switches off what
+// another pair of the same edges already contributes.  Bits: 1 / 2 = no diagonal block and no right-hand side for vertex 0 /
+// vertex 1, 4 = not counted in chi2.
+void BlockSolver::set_edge_set_parts(int set, int parts) {
+  if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("set_edge_set_parts: bad edge set id");
+  if (parts < 0 || parts > 7) throw ArgFailure("set_edge_set_parts: parts is a combination of the bits 1, 2, 4");
+  if (sets_[set]->unary && (parts & 2)) throw ArgFailure("set_edge_set_parts: a unary set has no vertex 1");
+  if (sets_[set]->parts != parts) {
+    sets_[set]->parts = parts;
+    structured_ = false;
+    chi2_valid_ = false;
+  }
+}
+
 // Solver::updateStructure (block_solver.hpp:297-351): online growth of a system WITHOUT Schur complement -- new pose
 // vertices at the end of the index mapping, new edges appended to an existing edge set.  The reference allocates the new
 // blocks in Hpp and leaves the symbolic factorisation to the linear solver's next solve; here the structure (contributor
@@ -2410,11 +2425,11 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         for (int i = 0; i < 8; ++i) parts[c].v[i].reserve(ke - kb);
         for (int k = (int)kb; k < (int)ke; ++k) {
           int a = es.v0[k], b = es.v1[k];
-          if (a >= 0) {
+          if (a >= 0 && !(es.parts & 1)) {   // (parts: the diagonal block / right-hand side of this side come from another set)
             if (is_lm(a)) { dl.push_back(a - nP); pl_.push_back(k << 1); }
             else { dp.push_back(a); pp_.push_back(k << 1); }
           }
-          if (b >= 0) {
+          if (b >= 0 && !(es.parts & 2)) {
             if (is_lm(b)) { dl.push_back(b - nP); pl_.push_back((k << 1) | 1); }
             else { dp.push_back(b); pp_.push_back((k << 1) | 1); }
           }
@@ -3272,7 +3287,7 @@ double BlockSolver::chi2() {
   double total = 0.0;
   for (auto& esp : sets_) {
     EdgeSet& es = *esp;
-    if (es.n == 0) continue;
+    if (es.n == 0 || (es.parts & 4)) continue;   // (parts bit 4: the edges of this set are counted by another one)
     if (!es.has_err) throw StateFailure("chi2: edge data missing");
     int nblocks = std::min(1024, grid_for(es.n));
     if (ba_.err_valid && esp.get() == sets_[ba_.set].get()) {   // partial sums left by ba_linearize (same values trial_stats reads)
@@ -4409,7 +4424,7 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
   if (need_chi && ba_.set >= 0 && ba_.n_classes > 1 && !ba_.err_valid) ba_linearize(false);
   for (size_t k = 0; k < nsets && need_chi; ++k) {
     EdgeSet& es = *sets_[k];
-    if (es.n == 0) continue;
+    if (es.n == 0 || (es.parts & 4)) continue;
     if (!es.has_err) throw StateFailure("trial_stats: edge data missing");
     nblk[k + 1] = std::min(kMaxBlocks, grid_for(es.n));
     if (ba_.err_valid && (int)k == ba_.set) {   // already there: ba_linearize left this set's partial sums in its slot

@@ -147,6 +147,14 @@ int g2ohip_add_edge_set(g2ohip_solver* s, int error_dim, int n_edges, const int3
   return guarded([&] { return s->impl->add_edge_set(error_dim, n_edges, v0, v1); });
 }
 
+int g2ohip_set_edge_set_parts(g2ohip_solver* s, int set, int parts) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_edge_set_parts(set, parts);
+    return G2OHIP_OK;
+  });
+}
+
 int g2ohip_build_structure(g2ohip_solver* s, int num_poses, int num_landmarks, int do_schur) {
   REQUIRE_HANDLE(s);
   return guarded([&] {
