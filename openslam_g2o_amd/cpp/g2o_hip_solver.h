@@ -156,6 +156,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     (void)online;
     _optimizer = optimizer;
     _groups.clear();
+    _multi.clear();
     return _h && g2ohip_init(_h) == G2OHIP_OK;
   }
 
@@ -177,6 +178,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     if (g2ohip_init(_h) != G2OHIP_OK) return fail("init");
     if (g2ohip_clear_edge_sets(_h) != G2OHIP_OK) return fail("clear_edge_sets");   // (a second optimize(), online growth: a new graph)
     _groups.clear();
+    _multi.clear();
     _devValid = false;                                 // (the front ends are about to be bound again: no estimates behind them yet)
     // poses first, then marginalized vertices, each in index order (sparse_optimizer.cpp:174-187)
     _nP = _nL = 0;
@@ -215,9 +217,37 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     for (size_t k = 0; k < _optimizer->activeEdges().size(); ++k) {
       OptimizableGraph::Edge* e = _optimizer->activeEdges()[k];
       const size_t nv = e->vertices().size();
-      if (nv < 1 || nv > 2) {
-        std::cerr << "BlockSolverHip: edges with " << nv << " vertices are not supported (BaseMultiEdge)" << std::endl;
+      if (nv < 1 || nv > (size_t)kMaxMultiVertices) {
+        std::cerr << "BlockSolverHip: edges with " << nv << " vertices are not supported (1 to " << kMaxMultiVertices << ")" << std::endl;
         return false;
+      }
+      if (nv > 2) {
+        // BaseMultiEdge (base_multi_edge.hpp:170-222): one binary edge set per vertex pair, see MultiGroup
+        MultiGroup* mg = 0;
+        int kind;
+        double delta;
+        kernelOf(e->robustKernel(), kind, delta);
+        if (kind < 0) {
+          std::cerr << "BlockSolverHip: robust kernel " << typeid(*e->robustKernel()).name() << " has no device counterpart" << std::endl;
+          return false;
+        }
+        for (size_t m = 0; m < _multi.size() && !mg; ++m) {
+          bool same = _multi[m].d == e->dimension() && _multi[m].arity == (int)nv;
+          for (size_t i = 0; i < nv && same; ++i) same = _multi[m].dims[i] == static_cast<OptimizableGraph::Vertex*>(e->vertex(i))->dimension();
+          if (same) mg = &_multi[m];
+        }
+        if (!mg) {
+          _multi.push_back(MultiGroup());
+          mg = &_multi.back();
+          mg->d = e->dimension();
+          mg->arity = (int)nv;
+          for (size_t i = 0; i < nv; ++i) mg->dims[i] = static_cast<OptimizableGraph::Vertex*>(e->vertex(i))->dimension();
+        }
+        mg->edges.push_back(e);
+        mg->rkKind.push_back(kind);
+        mg->rkDelta.push_back(kind ? delta : 0.0);
+        for (size_t i = 0; i < nv; ++i) mg->v[i].push_back(static_cast<OptimizableGraph::Vertex*>(e->vertex(i))->hessianIndex());
+        continue;
       }
       OptimizableGraph::Vertex* v0 = static_cast<OptimizableGraph::Vertex*>(e->vertex(0));
       OptimizableGraph::Vertex* v1 = nv == 2 ? static_cast<OptimizableGraph::Vertex*>(e->vertex(1)) : 0;
@@ -296,6 +326,34 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
       g.J1.clear();
       g.Om.clear();
       g.err.clear();
+    }
+    for (size_t m = 0; m < _multi.size(); ++m) {
+      MultiGroup& mg = _multi[m];
+      const int n = (int)mg.edges.size();
+      bool uniform = true;
+      for (size_t k = 1; k < mg.rkKind.size() && uniform; ++k) uniform = mg.rkKind[k] == mg.rkKind[0] && mg.rkDelta[k] == mg.rkDelta[0];
+      mg.pairs.clear();
+      for (int i = 0; i < mg.arity; ++i)
+        for (int j = i + 1; j < mg.arity; ++j) {
+          typename MultiGroup::Pair pr;
+          pr.i = i;
+          pr.j = j;
+          // vertex i's own terms (H_ii, b_i) come from the pair (i, i + 1), the last vertex's from the pair (arity - 2, arity - 1),
+          // chi2 from the pair (0, 1): everything once, as base_multi_edge.hpp:170-222 adds it
+          pr.parts = (j == i + 1 ? 0 : G2OHIP_PART_NO_VERTEX0) | ((i == mg.arity - 2 && j == mg.arity - 1) ? 0 : G2OHIP_PART_NO_VERTEX1) |
+                     ((i == 0 && j == 1) ? 0 : G2OHIP_PART_NO_CHI2);
+          pr.set = g2ohip_add_edge_set(_h, mg.d, n, mg.v[i].data(), mg.v[j].data());
+          if (pr.set < 0) return fail("add_edge_set");
+          if (g2ohip_set_edge_set_parts(_h, pr.set, pr.parts) != G2OHIP_OK) return fail("set_edge_set_parts");
+          if (uniform && !mg.rkKind.empty() && mg.rkKind[0] > 0) {
+            if (g2ohip_set_robust_kernel(_h, pr.set, mg.rkKind[0], mg.rkDelta[0]) != G2OHIP_OK) return fail("set_robust_kernel");
+          } else if (!uniform) {
+            if (g2ohip_set_robust_kernel_per_edge(_h, pr.set, mg.rkKind.data(), mg.rkDelta.data()) != G2OHIP_OK) return fail("set_robust_kernel_per_edge");
+          }
+          mg.pairs.push_back(pr);
+        }
+      mg.Om.clear();
+      mg.err.clear();
     }
     setupMs[1] = 1e3 * lap(tSetup);
     if (g2ohip_build_structure(_h, _nP, _nL, _doSchur ? 1 : 0) != G2OHIP_OK) return fail("build_structure");
@@ -394,6 +452,39 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
         return fail("set_edge_data");
       _phase.upload += lap(t);
     }
+    for (size_t m = 0; m < _multi.size(); ++m) {         // n-ary edges: linearised once, their Jacobians dealt to the pair sets
+      MultiGroup& mg = _multi[m];
+      const int d = mg.d;
+      const size_t n = mg.edges.size();
+      if (mg.err.empty() && n) {
+        mg.Om.assign(n * d * d, 0.0);
+        mg.err.assign(n * d, 0.0);
+        for (size_t q = 0; q < mg.pairs.size(); ++q) {
+          typename MultiGroup::Pair& pr = mg.pairs[q];
+          pr.J0.assign(n * d * (mg.dims[pr.i] > p ? mg.dims[pr.i] : p), 0.0);   // (sized as the generic groups' buffers, above)
+          pr.J1.assign(n * d * (mg.dims[pr.j] > p ? mg.dims[pr.j] : p), 0.0);
+        }
+      }
+      for (size_t k = 0; k < n; ++k) {
+        OptimizableGraph::Edge* e = mg.edges[k];
+        e->linearizeOplus(ws);
+        for (size_t q = 0; q < mg.pairs.size(); ++q) {
+          typename MultiGroup::Pair& pr = mg.pairs[q];
+          const int di = mg.dims[pr.i], dj = mg.dims[pr.j];
+          if (mg.v[pr.i][k] >= 0) std::memcpy(&pr.J0[k * d * di], ws.workspaceForVertex(pr.i), sizeof(double) * d * di);
+          if (mg.v[pr.j][k] >= 0) std::memcpy(&pr.J1[k * d * dj], ws.workspaceForVertex(pr.j), sizeof(double) * d * dj);
+        }
+        std::memcpy(&mg.Om[k * d * d], e->informationData(), sizeof(double) * d * d);
+        std::memcpy(&mg.err[k * d], e->errorData(), sizeof(double) * d);
+      }
+      _phase.hostLinearize += lap(t);
+      for (size_t q = 0; q < mg.pairs.size(); ++q) {
+        typename MultiGroup::Pair& pr = mg.pairs[q];
+        if (g2ohip_set_edge_data(_h, pr.set, pr.J0.data(), pr.J1.data(), mg.Om.data(), mg.err.data(), /*on_device*/ 0) != G2OHIP_OK)
+          return fail("set_edge_data");
+      }
+      _phase.upload += lap(t);
+    }
     if (g2ohip_build_system(_h) != G2OHIP_OK) return fail("build_system");
     if (_timing) g2ohip_sync(_h);
     _phase.deviceBuild += lap(t);
@@ -475,7 +566,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   virtual void multiplyHessian(double* dest, const double* src) const { if (_h) g2ohip_multiply_hessian(_h, dest, src); }
 
   // ---- HipDeviceGraph: the graph side of an iteration on the device front ends (g2ohip_ba_* / g2ohip_pg_*)
-  virtual bool deviceResident() const { return _h && !_groups.empty() && _fastGroups == (int)_groups.size(); }
+  virtual bool deviceResident() const { return _h && !_groups.empty() && _multi.empty() && _fastGroups == (int)_groups.size(); }
   virtual bool devEstimatesValid() const { return _devValid; }
   virtual bool devSetEstimates() {
     double t = get_monotonic_time();
@@ -566,6 +657,22 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     std::vector<double> rkDelta;
     std::vector<double> J0, J1, Om, err;
     Group() : key(), set(-1), fast(0) {}
+  };
+  // n-ary edges of one shape (error dimension, number of vertices, their dimensions): BaseMultiEdge::constructQuadraticForm
+  // (base_multi_edge.hpp:170-222) adds H_ii, b_i per vertex and H_ij per vertex pair; here every pair (i, j) is ONE binary edge
+  // set of the library over the edges' vertices i and j, and g2ohip_set_edge_set_parts switches off what another pair of the
+  // same edges already contributes.  The host linearises an edge once and deals its Jacobians to the pair sets.
+  enum { kMaxMultiVertices = 4 };
+  struct MultiGroup {
+    struct Pair {
+      int i, j, set, parts;
+      std::vector<double> J0, J1;
+    };
+    int d, arity, dims[kMaxMultiVertices];
+    std::vector<OptimizableGraph::Edge*> edges;
+    std::vector<int32_t> v[kMaxMultiVertices], rkKind;
+    std::vector<double> rkDelta, Om, err;
+    std::vector<Pair> pairs;
   };
   struct ClassKey {                                      // what distinguishes two EdgeProjectXYZ2UV on the device: intrinsics + robust kernel
     double f, cx, cy, delta;
@@ -954,6 +1061,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   bool _doSchur, _writeDebug;
   int _nP, _nL;
   std::vector<Group> _groups;
+  std::vector<MultiGroup> _multi;                      // n-ary edge groups (generic path)
   std::vector<double> _diagMirror, _diag;
   bool _fastPath;
   int _fastGroups;                                     // groups bound to a device front end (Group::fast)

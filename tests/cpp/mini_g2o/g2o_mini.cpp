@@ -79,7 +79,9 @@ bool SparseOptimizer::initializeOptimization(int) {
   for (size_t i = 0; i < _ivMap.size(); ++i) maxDim = std::max(maxDim, _ivMap[i]->dimension());
   for (std::map<int, Vertex*>::iterator it = _vertices.begin(); it != _vertices.end(); ++it) maxDim = std::max(maxDim, it->second->dimension());
   for (size_t k = 0; k < _activeEdges.size(); ++k) maxErr = std::max(maxErr, _activeEdges[k]->dimension());
-  _jacobianWorkspace.allocate(2, maxDim * maxErr);
+  int maxVerts = 2;                                      // (jacobian_workspace.cpp:50-70: sized by the widest active edge)
+  for (size_t k = 0; k < _activeEdges.size(); ++k) maxVerts = std::max(maxVerts, (int)_activeEdges[k]->vertices().size());
+  _jacobianWorkspace.allocate(maxVerts, maxDim * maxErr);
   return true;
 }
 

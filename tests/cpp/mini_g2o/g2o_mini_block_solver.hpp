@@ -79,24 +79,26 @@ bool BlockSolver<Traits>::buildStructure(bool) {
   }
   for (size_t k = 0; k < _optimizer->activeEdges().size(); ++k) {
     OptimizableGraph::Edge* e = _optimizer->activeEdges()[k];
-    if (e->vertices().size() != 2) continue;
-    OptimizableGraph::Vertex* a = static_cast<OptimizableGraph::Vertex*>(e->vertex(0));
-    OptimizableGraph::Vertex* b = static_cast<OptimizableGraph::Vertex*>(e->vertex(1));
-    const int ia = a->hessianIndex(), ib = b->hessianIndex();
-    if (ia < 0 || ib < 0) continue;
-    const bool la = ia >= _nP, lb = ib >= _nP;
-    if (!la && !lb) {
-      if (ia != ib) _Hpp_off[std::make_pair(std::min(ia, ib), std::max(ia, ib))] = PoseMatrixType();
-    } else if (la != lb) {
-      const int pose = la ? ib : ia, lm = (la ? ia : ib) - _nP;
-      if (!_obsIndex.count(std::make_pair(pose, lm))) {
-        _obsIndex[std::make_pair(pose, lm)] = (int)_obs.size();
-        Obs o;
-        o.pose = pose;
-        o.lm = lm;
-        _obs.push_back(o);
+    for (size_t sa = 0; sa < e->vertices().size(); ++sa)   // every vertex pair of the edge (block_solver.hpp:206-254)
+      for (size_t sb = sa + 1; sb < e->vertices().size(); ++sb) {
+        OptimizableGraph::Vertex* a = static_cast<OptimizableGraph::Vertex*>(e->vertex((int)sa));
+        OptimizableGraph::Vertex* b = static_cast<OptimizableGraph::Vertex*>(e->vertex((int)sb));
+        const int ia = a->hessianIndex(), ib = b->hessianIndex();
+        if (ia < 0 || ib < 0) continue;
+        const bool la = ia >= _nP, lb = ib >= _nP;
+        if (!la && !lb) {
+          if (ia != ib) _Hpp_off[std::make_pair(std::min(ia, ib), std::max(ia, ib))] = PoseMatrixType();
+        } else if (la != lb) {
+          const int pose = la ? ib : ia, lm = (la ? ia : ib) - _nP;
+          if (!_obsIndex.count(std::make_pair(pose, lm))) {
+            _obsIndex[std::make_pair(pose, lm)] = (int)_obs.size();
+            Obs o;
+            o.pose = pose;
+            o.lm = lm;
+            _obs.push_back(o);
+          }
+        }
       }
-    }
   }
   for (size_t q = 0; q < _obs.size(); ++q) _lmObs[_obs[q].lm].push_back((int)q);
   for (int j = 0; j < _nL; ++j) std::sort(_lmObs[j].begin(), _lmObs[j].end(), [&](int x, int y) { return _obs[x].pose < _obs[y].pose; });
@@ -138,7 +140,8 @@ bool BlockSolver<Traits>::buildSystem() {
       w = rho[1];
     }
     const int nv = (int)e->vertices().size();
-    int idx[2], dim[2];
+    int idx[8], dim[8];
+    if (nv > 8) return false;
     for (int s = 0; s < nv; ++s) {
       OptimizableGraph::Vertex* v = static_cast<OptimizableGraph::Vertex*>(e->vertex(s));
       idx[s] = v->hessianIndex();

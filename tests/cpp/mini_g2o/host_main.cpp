@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iomanip>
 #include <sstream>
@@ -23,6 +24,28 @@
 #include "g2o/types/slam3d/edge_se3.h"
 
 using namespace g2o;
+
+// Test edge with THREE vertices (what g2o/types/sclam2d/edge_se2_sensor_calib.h:40-55 computes: odometry seen through a sensor
+// mounted with an unknown offset -- two poses and the calibration vertex every edge shares), numeric Jacobians of BaseMultiEdge
+class EdgeSE2SensorCalib : public BaseMultiEdge<3, SE2> {
+ public:
+  EdgeSE2SensorCalib() { resize(3); }
+  virtual bool write(std::ostream& os) const { (void)os; return false; }
+  void setMeasurement(const SE2& m) {
+    _measurement = m;
+    _inverseMeasurement = m.inverse();
+  }
+  virtual void computeError() {
+    const VertexSE2* v1 = static_cast<const VertexSE2*>(_vertices[0]);
+    const VertexSE2* v2 = static_cast<const VertexSE2*>(_vertices[1]);
+    const VertexSE2* off = static_cast<const VertexSE2*>(_vertices[2]);
+    const SE2 delta = _inverseMeasurement * ((v1->estimate() * off->estimate()).inverse() * v2->estimate() * off->estimate());
+    const Vector3d e = delta.toVector();
+    for (int i = 0; i < 3; ++i) _error[i] = e[i];
+  }
+ private:
+  SE2 _inverseMeasurement;
+};
 
 int main(int argc, char** argv) {
   if (argc < 6) {
@@ -157,12 +180,16 @@ int main(int argc, char** argv) {
   // "se2huber:<delta>": the same graph with a Huber kernel on its LOOP CLOSURES only (edges between non-consecutive vertices) -- one
   // homogeneous group of EdgeSE2 whose edges differ in their robust kernel
   const bool se2Huber = argc > 6 && std::string(argv[6]).compare(0, 9, "se2huber:") == 0;
-  if ((argc > 6 && std::string(argv[6]) == "se2") || se2Huber) {
+  // "se2calib[:<delta>]": every odometry edge of the file becomes an EdgeSE2SensorCalib over (pose i, pose j, the sensor offset) --
+  // a graph of THREE-vertex edges that all share one vertex; loop closures stay EdgeSE2 (with a Huber kernel when delta is given)
+  const bool se2Calib = argc > 6 && std::string(argv[6]).compare(0, 8, "se2calib") == 0;
+  if ((argc > 6 && std::string(argv[6]) == "se2") || se2Huber || se2Calib) {
     // ---- planar pose graph (config 1: VertexSE2 / EdgeSE2, BlockSolver_3_2 shape, no marginalised vertex)
     std::ifstream in(argv[1]);
     int nv, ne;
     in >> nv >> ne;
     SparseOptimizer optimizer;
+    VertexSE2* calib = 0;
     std::vector<VertexSE2*> verts(nv);
     for (int i = 0; i < nv; ++i) {
       int fixed;
@@ -181,6 +208,27 @@ int main(int argc, char** argv) {
       in >> i >> j >> x >> y >> th;
       EdgeSE2::InformationType info;
       for (int q = 0; q < 9; ++q) in >> info.data()[q];
+      if (se2Calib && std::abs(i - j) == 1) {
+        if (!calib) {
+          calib = new VertexSE2();
+          calib->setId(nv);
+          calib->setEstimate(SE2(0.02, -0.01, 0.015));    // (the file's odometry is that of an unmounted sensor: the optimum is near the identity)
+          optimizer.addVertex(calib);
+        }
+        EdgeSE2SensorCalib* ec = new EdgeSE2SensorCalib();
+        ec->setVertex(0, verts[i]);
+        ec->setVertex(1, verts[j]);
+        ec->setVertex(2, calib);
+        ec->setMeasurement(SE2(x, y, th));
+        ec->setInformation(info);
+        if (std::strlen(argv[6]) > 9 && (k % 3) == 0) {   // a robust kernel on every third of them: per-edge kernels on the pair sets
+          RobustKernelHuber* rk = new RobustKernelHuber();
+          rk->setDelta(std::atof(argv[6] + 9));
+          ec->setRobustKernel(rk);
+        }
+        optimizer.addEdge(ec);
+        continue;
+      }
       EdgeSE2* e = new EdgeSE2();
       e->setVertex(0, verts[i]);
       e->setVertex(1, verts[j]);
@@ -225,7 +273,12 @@ int main(int argc, char** argv) {
       const Vector3d v = verts[i]->estimate().toVector();
       js << (i ? ", " : "") << v[0] << ", " << v[1] << ", " << v[2];
     }
-    js << "]}";
+    js << "]";
+    if (calib) {
+      const Vector3d v = calib->estimate().toVector();
+      js << ", \"calib\": [" << v[0] << ", " << v[1] << ", " << v[2] << "]";
+    }
+    js << "}";
     std::ofstream(argv[5]) << js.str() << std::endl;
     return 0;
   }

@@ -527,3 +527,41 @@ def test_device_resident_gauss_newton_through_online_growth(host, tmp_path):
     out, err = _run(host, prob, "gn_fix6_3_hipdev", 2, str(tmp_path / "o.json"), mode="online:7")
     assert DEV_OFF in err and DEV_ON not in err and out["iterations"] == ref["iterations"] == 4
     assert np.abs(np.array(out["cams"]) - np.array(ref["cams"])).max() < 1e-12
+
+
+@pytest.mark.parametrize("mode", ["se2calib", "se2calib:1.5"])
+def test_three_vertex_edges_through_the_g2o_vtables(host, tmp_path, mode):
+    """BaseMultiEdge through the plugin: the odometry edges of manhattan3500 as THREE-vertex edges (pose, pose, one shared
+    sensor-offset vertex: what g2o/types/sclam2d/edge_se2_sensor_calib.h computes; numeric Jacobians of BaseMultiEdge), the
+    loop closures as EdgeSE2.  The wide seam registers one binary edge set per vertex pair of the three-vertex edges
+    (g2ohip_set_edge_set_parts) and assembles on the device; the narrow seam assembles in the test host's own BlockSolver on
+    the CPU and only factorises on the device: the two walk one Levenberg-Marquardt trajectory.  The second mode puts a
+    Huber kernel on every third three-vertex edge (one robust kernel per edge on all three pair sets)."""
+    from tests.helpers import manhattan_golden
+    g = manhattan_golden()
+    path = str(tmp_path / "m.txt")
+    keep = 600                                               # the first 600 poses and the edges among them
+    sel = [k for k in range(len(g["vi"])) if g["vi"][k] < keep and g["vj"][k] < keep]
+    with open(path, "w") as f:
+        f.write("%d %d\n" % (keep, len(sel)))
+        for i in range(keep):
+            f.write("%d %s\n" % (1 if g["hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in g["estimates"][i])))
+        for k in sel:
+            f.write("%d %d %s %s\n" % (g["vi"][k], g["vj"][k], " ".join("%.17g" % v for v in g["meas"][k]),
+                                       " ".join("%.17g" % v for v in np.asarray(g["omega"][k]).reshape(-1))))
+    wide, err = _run(host, path, "lm_fix3_2_hip", 6, str(tmp_path / "w.json"), mode=mode)
+    narrow, _ = _run(host, path, "lm_fix3_2_hipls", 6, str(tmp_path / "n.json"), mode=mode)
+    dev, errd = _run(host, path, "lm_fix3_2_hipdev", 6, str(tmp_path / "d.json"), mode=mode)
+    assert DEV_OFF in errd                                   # (n-ary edges are generic: the device-resident driver runs the host loop)
+    assert wide["iterations"] == narrow["iterations"] == 6
+    assert abs(wide["chi2_initial"] - narrow["chi2_initial"]) <= 1e-12 * narrow["chi2_initial"]
+    assert wide["chi2"][-1] < 0.2 * wide["chi2_initial"] and all(b <= a * (1 + 1e-12) for a, b in zip(wide["chi2"], wide["chi2"][1:]))
+    # the first step: the same Jacobians (the host's, numeric) into two assemblies -- equal to rounding
+    assert abs(wide["chi2"][0] - narrow["chi2"][0]) <= 1e-11 * narrow["chi2"][0], (wide["chi2"], narrow["chi2"])
+    # later steps: the central differences (delta 1e-9: ~1e-7 of noise in a Jacobian) amplify the rounding differences of the two states
+    assert np.allclose(wide["chi2"], narrow["chi2"], rtol=5e-6, atol=0), (wide["chi2"], narrow["chi2"])
+    assert np.allclose(wide["lambda"], narrow["lambda"], rtol=1e-3, atol=0)
+    assert np.abs(np.array(wide["poses"]) - np.array(narrow["poses"])).max() < 1e-3      # (poses of a 30 m trajectory, not converged yet)
+    assert np.abs(np.array(wide["calib"]) - np.array(narrow["calib"])).max() < 1e-3
+    assert np.allclose(dev["chi2"], wide["chi2"], rtol=1e-12, atol=0)
+    assert np.abs(np.array(wide["calib"])).max() < 0.05      # (the file's odometry needs no offset: the calibration vertex goes back towards it)
