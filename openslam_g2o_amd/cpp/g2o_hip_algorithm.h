@@ -39,13 +39,17 @@ inline bool envOff(const char* name) {
   return v && v[0] == '0';
 }
 // iteration 0 of a device-resident run: is the structure built, and may the device loop take the graph?
-inline bool wantDeviceLoop(const char* who, Solver* solver, HipDeviceGraph* dev) {
-  const bool on = solver && dev && dev->deviceResident() && !envOff("G2OHIP_ADAPTER_DEVICE_LOOP");
+inline bool canDeviceLoop(Solver* solver, HipDeviceGraph* dev) { return solver && dev && dev->deviceResident() && !envOff("G2OHIP_ADAPTER_DEVICE_LOOP"); }
+// Decided where the structure may have changed (iteration 0, online); in between only taken back: a structure rebuilt under the
+// algorithm (updateInitialization followed by solve(iteration > 0)) that is no longer all on the device must not stay on the loop
+inline bool decideDeviceLoop(const char* who, Solver* solver, HipDeviceGraph* dev, bool resident, bool decide) {
+  const bool can = canDeviceLoop(solver, dev);
+  if (!decide) return resident && can;
   if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
-    std::cerr << who << ": " << (on ? "device-resident iteration (errors, chi2, oplus and the estimate stack on the GPU)"
-                                    : "g2o's host loop (not every active edge is on a device front end, or G2OHIP_ADAPTER_DEVICE_LOOP=0)")
+    std::cerr << who << ": " << (can ? "device-resident iteration (errors, chi2, oplus and the estimate stack on the GPU)"
+                                     : "g2o's host loop (not every active edge is on a device front end, or G2OHIP_ADAPTER_DEVICE_LOOP=0)")
               << std::endl;
-  return on;
+  return can;
 }
 }  // namespace hip_detail
 
@@ -65,7 +69,7 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
         return OptimizationAlgorithm::Fail;
       }
     }
-    if (iteration == 0 || online || !_resident) _resident = hip_detail::wantDeviceLoop("OptimizationAlgorithmLevenbergHip", _solver, _dev);
+    _resident = hip_detail::decideDeviceLoop("OptimizationAlgorithmLevenbergHip", _solver, _dev, _resident, iteration == 0 || online);
     // (`online` only guards buildStructure in the host loop, levenberg.cpp:62: the structure exists by now)
     if (!_resident) return OptimizationAlgorithmLevenberg::solve(iteration, true);
 
@@ -191,7 +195,7 @@ class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNew
         return OptimizationAlgorithm::Fail;
       }
     }
-    if (iteration == 0 || online || !_resident) _resident = hip_detail::wantDeviceLoop("OptimizationAlgorithmGaussNewtonHip", _solver, _dev);
+    _resident = hip_detail::decideDeviceLoop("OptimizationAlgorithmGaussNewtonHip", _solver, _dev, _resident, iteration == 0 || online);
     if (!_resident) return OptimizationAlgorithmGaussNewton::solve(iteration, true);
 
     double t = get_monotonic_time();

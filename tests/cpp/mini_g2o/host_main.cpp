@@ -183,7 +183,11 @@ int main(int argc, char** argv) {
   // "se2calib[:<delta>]": every odometry edge of the file becomes an EdgeSE2SensorCalib over (pose i, pose j, the sensor offset) --
   // a graph of THREE-vertex edges that all share one vertex; loop closures stay EdgeSE2 (with a Huber kernel when delta is given)
   const bool se2Calib = argc > 6 && std::string(argv[6]).compare(0, 8, "se2calib") == 0;
-  if ((argc > 6 && std::string(argv[6]) == "se2") || se2Huber || se2Calib) {
+  // "se2online:<n>": the vertices < n and the edges among them first; then the rest is added, updateInitialization, and the
+  // optimisation goes on (iteration numbers continue: the structure is grown, not rebuilt by the algorithm)
+  int se2First = -1;
+  if (argc > 6 && std::string(argv[6]).compare(0, 10, "se2online:") == 0) se2First = std::atoi(argv[6] + 10);
+  if ((argc > 6 && std::string(argv[6]) == "se2") || se2Huber || se2Calib || se2First >= 0) {
     // ---- planar pose graph (config 1: VertexSE2 / EdgeSE2, BlockSolver_3_2 shape, no marginalised vertex)
     std::ifstream in(argv[1]);
     int nv, ne;
@@ -199,9 +203,10 @@ int main(int argc, char** argv) {
       v->setId(i);
       v->setFixed(fixed != 0);
       v->setEstimate(SE2(x, y, th));
-      optimizer.addVertex(v);
+      if (se2First < 0 || i < se2First) optimizer.addVertex(v);
       verts[i] = v;
     }
+    std::vector<EdgeSE2*> heldSE2;
     for (int k = 0; k < ne; ++k) {
       int i, j;
       double x, y, th;
@@ -239,7 +244,8 @@ int main(int argc, char** argv) {
         rk->setDelta(std::atof(argv[6] + 9));
         e->setRobustKernel(rk);
       }
-      optimizer.addEdge(e);
+      if (se2First < 0 || (i < se2First && j < se2First)) optimizer.addEdge(e);
+      else heldSE2.push_back(e);
     }
     if (!in) {
       std::cerr << "graph file truncated" << std::endl;
@@ -261,6 +267,30 @@ int main(int argc, char** argv) {
       lams.push_back(lm ? lm->currentLambda() : 0.0);
       ++done;
       if (r == OptimizationAlgorithm::Terminate) break;
+    }
+    if (se2First >= 0) {
+      HyperGraph::VertexSet vset;
+      HyperGraph::EdgeSet eset;
+      for (int i = se2First; i < nv; ++i) {
+        optimizer.addVertex(verts[i]);
+        vset.insert(verts[i]);
+      }
+      for (size_t k = 0; k < heldSE2.size(); ++k) {
+        optimizer.addEdge(heldSE2[k]);
+        eset.insert(heldSE2[k]);
+      }
+      if (!optimizer.updateInitialization(vset, eset)) {
+        std::cerr << "updateInitialization failed" << std::endl;
+        return 5;
+      }
+      for (int i = 0; i < iterations; ++i) {
+        const OptimizationAlgorithm::SolverResult r = algo->solve(iterations + i);
+        if (r == OptimizationAlgorithm::Fail) break;
+        optimizer.computeActiveErrors();
+        chis.push_back(optimizer.activeRobustChi2());
+        lams.push_back(lm ? lm->currentLambda() : 0.0);
+        ++done;
+      }
     }
     std::ostringstream js;
     js << std::setprecision(17);

@@ -565,3 +565,29 @@ def test_three_vertex_edges_through_the_g2o_vtables(host, tmp_path, mode):
     assert np.abs(np.array(wide["calib"]) - np.array(narrow["calib"])).max() < 1e-3
     assert np.allclose(dev["chi2"], wide["chi2"], rtol=1e-12, atol=0)
     assert np.abs(np.array(wide["calib"])).max() < 0.05      # (the file's odometry needs no offset: the calibration vertex goes back towards it)
+
+
+@pytest.mark.parametrize("solver", ["gn_fix3_2_hipdev", "lm_fix3_2_hipdev"])
+def test_device_resident_drivers_through_online_growth_of_a_pose_graph(host, tmp_path, solver):
+    """Incremental SLAM under the device-resident drivers: manhattan3500 optimised for its first 3 000 poses, grown by the
+    rest (SparseOptimizer::updateInitialization -> Solver::updateStructure: the structure is rebuilt, the pose-graph front end
+    bound again, the device's estimates are gone), optimised on with iteration numbers > 0.  The driver has to notice that
+    the device holds no estimates for the new structure and send the vertices' again; the run ends where the host loop over
+    the same solver ends."""
+    from tests.helpers import manhattan_golden
+    g = manhattan_golden()
+    path = str(tmp_path / "m.txt")
+    with open(path, "w") as f:
+        nv, ne = len(g["estimates"]), len(g["vi"])
+        f.write("%d %d\n" % (nv, ne))
+        for i in range(nv):
+            f.write("%d %s\n" % (1 if g["hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in g["estimates"][i])))
+        for k in range(ne):
+            f.write("%d %d %s %s\n" % (g["vi"][k], g["vj"][k], " ".join("%.17g" % v for v in g["meas"][k]),
+                                       " ".join("%.17g" % v for v in np.asarray(g["omega"][k]).reshape(-1))))
+    ref, _ = _run(host, path, solver.replace("hipdev", "hip"), 3, str(tmp_path / "r.json"), mode="se2online:3000")
+    out, err = _run(host, path, solver, 3, str(tmp_path / "o.json"), mode="se2online:3000")
+    assert DEV_ON in err and DEV_OFF not in err
+    assert out["iterations"] == ref["iterations"] == 6
+    assert np.allclose(out["chi2"], ref["chi2"], rtol=1e-9, atol=0), (out["chi2"], ref["chi2"])
+    assert np.abs(np.array(out["poses"]) - np.array(ref["poses"])).max() < 1e-8
