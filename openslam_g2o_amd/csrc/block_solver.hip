@@ -634,8 +634,12 @@ __device__ __forceinline__ void schur_tile_dests(const double* Bs, const double*
     for (int r = 0; r < NR; ++r) cacc[r] = 0.0;
     const bool diag = ddiag[ld - td0] != 0;
     const int k0 = dptr[ld - td0] - e0, k1 = dptr[ld - td0 + 1] - e0;
+    // (the entry word of the NEXT iteration is requested one iteration ahead: entry -> slot addresses -> blocks is a chain of two
+    // LDS round trips per iteration otherwise; reading past the list ends inside the tile's own LDS tables and is never used)
+    int pk_next = ep[k0 + ge];
     for (int k = k0 + ge; k < k1; k += GE) {
-      const int pk = ep[k], lm = el[k];
+      const int pk = pk_next, lm = el[k];
+      pk_next = ep[k + GE];
       const int s1 = pk & 0xffff, s2 = (pk >> 16) & 0xffff;
       double W[NR * LD];   // W[rr + NR * c] = V_s1(gc*NR + rr, c)   (V = B C: schur_tile_prepare)
       typedef VSlot<PD, LD, GC> VS;
