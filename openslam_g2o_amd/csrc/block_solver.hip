@@ -1407,12 +1407,15 @@ __global__ void __launch_bounds__(kThreads, G2OHIP_SCHUR_OCC) ba_schur_tile_kern
         // suffix sums inside a list by doubling: after the step with distance d a lane holds the sum of up to 2 d list
         // entries from its own on (fixed tree: deterministic); as many steps as the longest list of this WAVE needs
         for (int d = 1; __any(pos + d < K); d <<= 1) {
-          const bool take = pos + d < K;
+          const double take = pos + d < K ? 1.0 : 0.0;
           double o[9];   // (all nine exchanges in flight at once, then branch-free adds)
 #pragma unroll
           for (int i = 0; i < 9; ++i) o[i] = __shfl_down(v[i], d);
+          // v + o or v, as ONE fused multiply-add per value (o * 1 is exact, so the sum is the plain one bit for bit) instead of two
+          // selects and an add: the vector units are what this phase is short of.  (A non-finite term of a neighbouring list would
+          // leak through 0 * o -- such a system is lost anyway: its right-hand side is not finite.)
 #pragma unroll
-          for (int i = 0; i < 9; ++i) v[i] += take ? o[i] : 0.0;
+          for (int i = 0; i < 9; ++i) v[i] = fma(o[i], take, v[i]);
         }
         // The list head inverts the damped block (block_solver.hpp:386-389) and splits the inverse (schur_tile_prepare's
         // comment); the lanes of the list fetch C from it and turn their staged block into V = B C on the spot: no pass over
