@@ -591,3 +591,27 @@ def test_device_resident_drivers_through_online_growth_of_a_pose_graph(host, tmp
     assert out["iterations"] == ref["iterations"] == 6
     assert np.allclose(out["chi2"], ref["chi2"], rtol=1e-9, atol=0), (out["chi2"], ref["chi2"])
     assert np.abs(np.array(out["poses"]) - np.array(ref["poses"])).max() < 1e-8
+
+
+def test_device_resident_levenberg_at_a_size_where_the_host_loops_are_threaded(host, tmp_path):
+    """The estimate gather / write-back loops of the adapter run on several host threads from 8 192 vertices on
+    (G2OHIP_ADAPTER_THREADS).  The host's bench mode (a synthetic band graph built in memory: 2 000 cameras, 20 000 points,
+    100 000 observations) under lm_fix6_3_hipdev with 8 threads and with 1, and under the host loop: chi2 after every iteration --
+    evaluated by the HOST on the written-back vertices -- is the same."""
+    exe, plugin = host
+
+    def run(solver, threads):
+        out = str(tmp_path / ("%s_%d.json" % (solver, threads)))
+        e = dict(os.environ, G2OHIP_ADAPTER_THREADS=str(threads))
+        r = subprocess.run([exe, "none", plugin, solver, "4", out, "bench:2000:20000:5"], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        d = json.load(open(out))
+        return d["chi2_initial"], [it["chi2"] for it in d["iterations"]]
+
+    c0_ref, ref = run("lm_fix6_3_hip", 8)
+    c0_a, a = run("lm_fix6_3_hipdev", 8)
+    c0_b, b = run("lm_fix6_3_hipdev", 1)
+    assert c0_ref == c0_a == c0_b and len(ref) == 4
+    assert ref[-1] < 0.1 * c0_ref
+    assert np.allclose(a, ref, rtol=1e-7, atol=0), (a, ref)     # (bench mode prints 9 digits)
+    assert a == b
