@@ -214,7 +214,107 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     ClassKey lastCk = ClassKey();
     int lastClass = -1;
     _baClasses.clear();
+    // Large graphs: the EdgeProjectXYZ2UV edges are classified on the host threads first (5 M edges x a handful of virtual calls and
+    // typeid comparisons is 0.15 s on one core) -- contiguous chunks of the edge list, every chunk its own class list in order of
+    // first appearance, merged in chunk order: the class numbers and the edge order of the sequential loop.  Everything else
+    // (and every graph below G2OHIP_ADAPTER_PAR_MIN edges, default 200 000) takes the loop below.
+    std::vector<unsigned char> taken;
+    {
+      const size_t nE = _optimizer->activeEdges().size();
+      const char* pm = std::getenv("G2OHIP_ADAPTER_PAR_MIN");
+      const size_t parMin = pm ? (size_t)std::atol(pm) : 200000;
+      if (tryBA && p == 6 && l == 3 && _threads > 1 && nE >= parMin && nE >= 8192) {
+        struct Chunk {
+          std::vector<ClassKey> cks;
+          std::vector<int32_t> cls, v0, v1;
+          std::vector<OptimizableGraph::Edge*> edges;
+          bool bad;
+          Chunk() : bad(false) {}
+        };
+        const size_t nt = (size_t)_threads, step = (nE + nt - 1) / nt;   // (the chunking of parallelFor)
+        std::vector<Chunk> chunks(nt);
+        taken.assign(nE, 0);
+        const OptimizableGraph::EdgeContainer& act = _optimizer->activeEdges();
+        parallelFor(nE, [&](size_t b, size_t e_) {
+          Chunk& c = chunks[b / step];
+          int last = -1;
+          for (size_t k = b; k < e_; ++k) {
+            OptimizableGraph::Edge* e = act[k];
+            if (e->vertices().size() != 2) continue;
+            OptimizableGraph::Vertex* v0 = static_cast<OptimizableGraph::Vertex*>(e->vertex(0));
+            OptimizableGraph::Vertex* v1 = static_cast<OptimizableGraph::Vertex*>(e->vertex(1));
+            GroupKey key;
+            key.d = e->dimension();
+            key.dim0 = v0->dimension();
+            key.dim1 = v1->dimension();
+            kernelOf(e->robustKernel(), key.kernel, key.delta);
+            if (key.kernel < 0) {
+              c.bad = true;                                // (reported by the loop below)
+              return;
+            }
+            ClassKey ck;
+            if (!projectEdgeClass(e, key, ck)) continue;
+            if (last < 0 || ck < c.cks[last] || c.cks[last] < ck) {
+              last = -1;
+              for (size_t q = 0; q < c.cks.size() && last < 0; ++q)
+                if (!(ck < c.cks[q]) && !(c.cks[q] < ck)) last = (int)q;
+              if (last < 0) {
+                last = (int)c.cks.size();
+                c.cks.push_back(ck);
+              }
+            }
+            c.edges.push_back(e);
+            c.cls.push_back(last);
+            c.v0.push_back(v0->hessianIndex());
+            c.v1.push_back(v1->hessianIndex());
+            taken[k] = 1;
+          }
+        });
+        bool bad = false;
+        size_t total = 0;
+        for (size_t c = 0; c < nt; ++c) {
+          bad = bad || chunks[c].bad;
+          total += chunks[c].edges.size();
+        }
+        if (bad || total == 0) {
+          taken.clear();
+        } else {
+          baGroup = (int)_groups.size();
+          _groups.push_back(Group());
+          Group& g = _groups.back();
+          g.key.d = 2;
+          g.key.dim0 = 3;
+          g.key.dim1 = 6;
+          g.key.kernel = 0;                                // (the class table owns the kernels)
+          g.key.delta = 0.0;
+          g.fast = 1;
+          g.edges.reserve(total);
+          g.cls.reserve(total);
+          g.v0.reserve(total);
+          g.v1.reserve(total);
+          for (size_t c = 0; c < nt; ++c) {
+            Chunk& ch = chunks[c];
+            std::vector<int> remap(ch.cks.size());
+            for (size_t q = 0; q < ch.cks.size(); ++q) {
+              typename std::map<ClassKey, int>::iterator ic = classIndex.find(ch.cks[q]);
+              if (ic == classIndex.end()) {
+                if (classIndex.size() >= 128) return buildStructureImpl(false, tryPG);
+                ic = classIndex.insert(std::make_pair(ch.cks[q], (int)classIndex.size())).first;
+                const double row[5] = {ch.cks[q].f, ch.cks[q].cx, ch.cks[q].cy, (double)ch.cks[q].kernel, ch.cks[q].delta};
+                _baClasses.insert(_baClasses.end(), row, row + 5);
+              }
+              remap[q] = ic->second;
+            }
+            g.edges.insert(g.edges.end(), ch.edges.begin(), ch.edges.end());
+            g.v0.insert(g.v0.end(), ch.v0.begin(), ch.v0.end());
+            g.v1.insert(g.v1.end(), ch.v1.begin(), ch.v1.end());
+            for (size_t k = 0; k < ch.cls.size(); ++k) g.cls.push_back(remap[ch.cls[k]]);
+          }
+        }
+      }
+    }
     for (size_t k = 0; k < _optimizer->activeEdges().size(); ++k) {
+      if (!taken.empty() && taken[k]) continue;
       OptimizableGraph::Edge* e = _optimizer->activeEdges()[k];
       const size_t nv = e->vertices().size();
       if (nv < 1 || nv > (size_t)kMaxMultiVertices) {

@@ -615,3 +615,34 @@ def test_device_resident_levenberg_at_a_size_where_the_host_loops_are_threaded(h
     assert ref[-1] < 0.1 * c0_ref
     assert np.allclose(a, ref, rtol=1e-7, atol=0), (a, ref)     # (bench mode prints 9 digits)
     assert a == b
+
+
+def test_threaded_edge_classification_equals_the_sequential_grouping(host, tmp_path):
+    """From G2OHIP_ADAPTER_PAR_MIN edges on (default 200 000) the adapter classifies the EdgeProjectXYZ2UV edges on its host
+    threads -- chunks of the edge list with their own class lists, merged in chunk order.  A graph of 15 000 observations with
+    two CameraParameters and Huber on every other edge (four classes that every chunk meets in another order), forced through
+    the threaded path, walks the trajectory of the sequential grouping, under the host loop and the device-resident driver."""
+    from tests.test_gpu_edge_classes import CLASSES
+    pr = ba_case(300, 3000, outlier_frac=0.05)
+    second = ((pr["cam_idx"] // 7) % 2) == 1
+    robust = (np.arange(pr["E"]) % 2) == 1
+    cls = (2 * second + robust).astype(np.int32)
+    f0, c0 = pr["f"], np.array([pr["cx"], pr["cy"]])
+    meas = (pr["meas"] - c0) / f0 * CLASSES[cls, 0][:, None] + CLASSES[cls, 1:3]
+    prob = str(tmp_path / "p.txt")
+    with open(prob, "w") as f:
+        f.write("%d %d %d %.17g %.17g %.17g 0 %.17g %.17g %.17g\n" % (pr["P"], pr["L"], pr["E"], *CLASSES[0, :3], *CLASSES[2, :3]))
+        for i in range(pr["P"]):
+            f.write("%d %s\n" % (1 if pr["cam_hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in pr["cams"][i])))
+        for j in range(pr["L"]):
+            f.write("0 %s\n" % " ".join("%.17g" % v for v in pr["pts"][j]))
+        for k in range(pr["E"]):
+            f.write("%d %d %.17g %.17g %d %.17g\n" % (pr["cam_idx"][k], pr["pt_idx"][k], meas[k][0], meas[k][1], int(second[k]), CLASSES[cls[k], 4]))
+    assert pr["E"] >= 8192
+    for solver in ("lm_fix6_3_hip", "lm_fix6_3_hipdev"):
+        seq, err0 = _run(host, prob, solver, 4, str(tmp_path / "s.json"), mode="classes")
+        par, err1 = _run(host, prob, solver, 4, str(tmp_path / "t.json"), {"G2OHIP_ADAPTER_PAR_MIN": "1"}, mode="classes")
+        assert "4 edge classes" in err0 and "4 edge classes" in err1
+        assert par["trials"] == seq["trials"]
+        assert np.allclose(par["chi2"], seq["chi2"], rtol=1e-10, atol=0) and np.allclose(par["lambda"], seq["lambda"], rtol=1e-10, atol=0)
+        assert relerr(np.array(par["cams"]), np.array(seq["cams"])) < 1e-10
