@@ -355,6 +355,17 @@ __global__ void __launch_bounds__(kThreads) maxdiag_partial_kernel(int nV, int d
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
+// [n] 2 x 2 identity matrices (EdgeProjectXYZ2UV sets whose information matrices were declared the identity)
+__global__ void __launch_bounds__(kThreads) identity2_kernel(size_t n, double* __restrict__ om) {
+  const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  dbl2_u a, b;
+  a.x = 1.0; a.y = 0.0;
+  b.x = 0.0; b.y = 1.0;
+  reinterpret_cast<dbl2_u*>(om + 4 * k)[0] = a;
+  reinterpret_cast<dbl2_u*>(om + 4 * k)[1] = b;
+}
+
 // K4: setLambda / restoreDiagonal (block_solver.hpp:563-604)
 __global__ void __launch_bounds__(kThreads) lambda_kernel(int nV, int dv, double* __restrict__ H, const int* __restrict__ diag_blk, double* __restrict__ backup,
                               double lambda, int do_backup, int restore, const unsigned char* __restrict__ mask = nullptr) {
@@ -4710,16 +4721,13 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
   ba_.cam_v.upload(cam_vertex, n, st_);
   ba_.pt_v.upload(point_vertex, n, st_);
   ba_.meas.upload(meas, n * 2, st_);
-  std::vector<double> om;
   ba_.omega_identity = info == nullptr;
-  if (!info) {
-    om.assign(n * 4, 0.0);
-    host_parallel_for(n, [&](size_t b_, size_t e_) {
-      for (size_t k = b_; k < e_; ++k) om[4 * k] = om[4 * k + 3] = 1.0;   // information().setIdentity()
-    });
-    info = om.data();
+  if (!info) {   // information().setIdentity(): written on the device (160 MB less to fill and to send at the metric configuration)
+    es.own_omega.alloc(n * 4);
+    if (n) hipLaunchKernelGGL(identity2_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st_, n, es.own_omega.p);
+  } else {
+    es.own_omega.upload(info, n * 4, st_);
   }
-  es.own_omega.upload(info, n * 4, st_);
   {
     // Hpl block written by each edge; the fused assembly requires one observation per (pose, landmark) pair
     std::vector<int> edge_hpl(n, -1);
@@ -4748,7 +4756,7 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
     if (unique) {   // the observation behind every Hpl block, in block order (ba_schur_tile_kernel)
       const size_t nq = std::max<size_t>(pl_row.size(), 1);
       std::vector<int> cq(nq, 0), pq(nq, 0);
-      std::vector<double> mq(nq * 2, 0.0), oq(info == om.data() ? 0 : nq * 4, 0.0);
+      std::vector<double> mq(nq * 2, 0.0), oq(!info ? 0 : nq * 4, 0.0);
       host_parallel_for(n, [&](size_t b_, size_t e_) {   // (unique: every q is written by one edge)
         for (size_t k = b_; k < e_; ++k) {
           const int q = edge_hpl[k];
