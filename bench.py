@@ -139,6 +139,10 @@ def main():
     ap.add_argument("--edge-data", choices=["fused", "arrays"], default="fused",
                     help="fused: estimates + measurements resident in HBM, errors/Jacobians evaluated inside buildSystem "
                          "(what the reference's buildSystem does per edge); arrays: precomputed Jacobian arrays resident in HBM")
+    ap.add_argument("--information", choices=["identity", "edge"], default="identity",
+                    help="identity: information().setIdentity() declared for the whole edge set, as SURVEY.md 8d's workload has it (the fused "
+                         "kernels then do not read it); edge: a different symmetric positive definite 2 x 2 information matrix per edge, "
+                         "read per observation by every kernel (and by the CPU baseline)")
     ap.add_argument("--comm", choices=["rccl", "staged", "peer"], default="rccl",
                     help="staged: gloo + host staging with every rank on cuda:0 (functional check of the N>1 path on a "
                          "1-GPU box; its timing is meaningless); peer: the library's opt-in peer-mailbox exchange "
@@ -202,6 +206,11 @@ def main():
     prob = S.make_ba_problem(P, L)                      # identical on every rank (counter-based RNG)
     fused = args.edge_data == "fused"
     prob["omega"] = S.ba_omega(prob)
+    if args.information == "edge":
+        rng = np.random.RandomState(7)
+        a, b_, c = rng.uniform(0.5, 2.0, prob["E"]), rng.uniform(0.5, 2.0, prob["E"]), rng.uniform(-0.3, 0.3, prob["E"])
+        prob["omega"] = np.ascontiguousarray(np.stack([a, c, c, b_], axis=1))   # column-major 2 x 2, eigenvalues >= 0.2
+        prob["info"] = prob["omega"]
     if not fused:
         Jp, Jc, err = S.ba_linearize(prob)
         prob.update(Jp=Jp, Jc=Jc, err=err)
@@ -330,15 +339,27 @@ def main():
         band = 8 * st["bandCholeskyNNZ"] + (tot - 8 * st["choleskyNNZ"]) * st["bandPivots"] / n_sc
         kb["chol_factor(band chains)"] = band
         kb["chol_factor(all levels)"] = tot - band
+    om_bytes = 0 if args.information == "identity" else 8 * 4      # the per-observation information matrix, where it is read
+    fused_kb = {}
     if fused:
         kb["assemble_vertex(landmark)"] = kb["fused:assemble_vertex(landmark)"]
-        kb["assemble_vertex(pose)"] = kb["fused:assemble_vertex(pose)"]
+        kb["assemble_vertex(pose)"] = kb["fused:assemble_vertex(pose)"] + E_loc * om_bytes
+        # The fused kernels do not read Hpl: what they move by construction (estimates, measurements, results; index tables
+        # excluded like everywhere) is far below the un-fused stage formulas of SURVEY.md 8d, which stay the yardstick of
+        # `roofline` (work done per second).  back_substitute is reported on ITS OWN bytes -- on the un-fused formula
+        # (an Hpl read it does not make) the slot printed more than the HBM peak.
+        p_, l_, d_ = 6, 3, 2
+        fused_kb["schur_tiles"] = E_loc * (8 * d_ + om_bytes) + L_loc * 8 * (l_ + l_ * l_ + l_) + prob["nP"] * 8 * 12 + S_blocks * 8 * p_ * p_
+        fused_kb["back_substitute"] = E_loc * (8 * d_ + om_bytes) + L_loc * 8 * (l_ + l_ * l_ + 2 * l_) + prob["nP"] * 8 * (12 + p_)
+        kb["back_substitute"] = fused_kb["back_substitute"]
     per_kernel = {}
     for name, (tot, n) in ktimes.items():
         avg = tot / n
         per_kernel[name] = dict(avg_ms=1e3 * avg, launches_per_step=n / args.steps,
                                 algorithmic_GB=kb.get(name, 0) / 1e9,
                                 achieved_GBs=(kb.get(name, 0) / 1e9 / avg) if avg > 0 else 0.0)
+        if name in fused_kb:
+            per_kernel[name]["fused_algorithmic_GB"] = fused_kb[name] / 1e9   # bytes this (fused) kernel moves by construction
     dname = dom_name if dom_name in per_kernel else max(per_kernel.items(), key=lambda kv: kv[1]["avg_ms"] * kv[1]["launches_per_step"])[0]
     dk = per_kernel[dname]
     # HBM bytes per launch from the PMC counters: collected by a separate rocprofv3 --pmc pass of this
@@ -379,7 +400,9 @@ def main():
                                "BlockSolver_6_3 semantics, Schur + multifrontal block Cholesky, lambda=%g" % (P, L, prob["E"], lam),
                    "poses": P, "landmarks": L, "edges": prob["E"], "parallelism": solver.parallelism(),
                    "edge_data": "estimates+measurements in HBM, errors/Jacobians evaluated inside buildSystem" if fused
-                   else "precomputed Jacobian arrays in HBM"},
+                   else "precomputed Jacobian arrays in HBM",
+                   "information": "identity, declared for the whole edge set (not read per edge)" if args.information == "identity"
+                   else "one 2 x 2 matrix per edge, read per observation"},
         "solve_ok": bool(ok),
         "launch": ("hipGraph replay of the launch sequences (elimination-tree levels grouped into dependency-driven launches)" if use_graph else "plain launches") +
                   "; timed region: HIP events around the dominant kernel slot only (roofline); the other per-kernel times come "
@@ -450,8 +473,12 @@ def main():
         # chi2 after applying each update (host-side error evaluation of the updated state)
         e_g = S.ba_linearize(S.ba_oplus(prob, x_gpu), jac=False)
         e_c = S.ba_linearize(S.ba_oplus(prob, x_cpu), jac=False)
-        chi_g, chi_c = float(np.sum(e_g * e_g)), float(np.sum(e_c * e_c))
-        out["chi2_before"] = float(np.sum(S.ba_linearize(prob, jac=False) ** 2))
+        Om = prob["omega"]
+
+        def chi_of(e):   # sum of e' Omega e (column-major 2 x 2 per edge)
+            return float(np.sum(e[:, 0] * (Om[:, 0] * e[:, 0] + Om[:, 2] * e[:, 1]) + e[:, 1] * (Om[:, 1] * e[:, 0] + Om[:, 3] * e[:, 1])))
+        chi_g, chi_c = chi_of(e_g), chi_of(e_c)
+        out["chi2_before"] = chi_of(S.ba_linearize(prob, jac=False))
         out["chi2_after_gpu"], out["chi2_after_cpu"] = chi_g, chi_c
         out["chi2_rel_err"] = abs(chi_g - chi_c) / chi_c
     if xp_all is not None:

@@ -105,6 +105,7 @@ class BlockSolver {
   const double* x_device() const { return d_x.p; }
   const double* b_device() {
     ensure_bl();
+    ensure_pp();   // (ba_lazy_pose: the pose half of b is otherwise the previous iteration's until the next solve)
     return d_b.p;
   }
   void sync();
@@ -234,6 +235,7 @@ class BlockSolver {
     int nbb = 0, nbp = 0, nh = 0;
     DevBuf<int> bblock, bpose, halo;
     DevBuf<double> hkeep, bkeep, hmine, buf1, buf3;
+    bool valid = false;       // exchange_setup has been called for the current structure (build_structure resets the whole record)
     bool merged = false;      // the boundary blocks / b_p ride in the all-reduce of the subtree roots (sharded_merge)
     double* tail = nullptr;   // ... their place behind the Cholesky's exchange buffer
   } ex_;
@@ -306,6 +308,7 @@ class BlockSolver {
   int solve_matrix_free();
   void mf_prepare_lists();
   void ba_validate();
+  void ba_validate_edges(const struct EdgeSet& es, const int* cam_v, const int* pt_v, size_t n) const;
   bool ba_recompute_ok() const;
   bool ba_skip_hpl_ok() const;
   bool ba_fuse_ll_ok() const;

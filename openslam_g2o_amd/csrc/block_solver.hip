@@ -2891,6 +2891,9 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   mf_ready_ = false;
   chol_ = std::make_unique<SparseCholesky>(p);
   chol_->opt = chol_opt;
+  // (the exchange of a sharded job was set up for the previous structure: its index lists address the old pattern and a merged
+  // payload (sharded_merge) lives behind the previous Cholesky's exchange buffer -- gone with it)
+  ex_ = Exchange();
   if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
   else chol_->analyze(nP, pp_colptr.data(), pp_row.data(), st_);
   lap("symbolic analysis");
@@ -3895,6 +3898,7 @@ void BlockSolver::exchange_setup(int nbb, const int* bblock, const double* hkeep
   ex_.nbb = nbb;
   ex_.nbp = nbp;
   ex_.nh = nh;
+  ex_.valid = true;
   auto up_i = [&](DevBuf<int>& d, const int* h, int n) {
     std::vector<int> v(h, h + n);
     if (v.empty()) v.push_back(0);
@@ -4093,6 +4097,8 @@ int BlockSolver::solve_sharded_once() {
   if (!schur_) throw StateFailure("solve_sharded: the sharded path needs the Schur complement");
   if (comm.kind() == Comm::kNone && chol_opt.world > 1 && !comm_emulate)
     throw StateFailure("solve_sharded: no communicator (g2ohip_comm_init_*)");
+  if (chol_opt.world > 1 && !ex_.valid)
+    throw StateFailure("solve_sharded: g2ohip_exchange_setup has not been called for the current structure (build_structure drops the exchange)");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   auto whole_solve = [&] {
   // (1) local Schur pass; boundary blocks of the reduced system + boundary right-hand sides summed over the ranks
@@ -4146,8 +4152,14 @@ int BlockSolver::solve_sharded_once() {
     if (once++ < 8) fprintf(stderr, "solve_sharded: one_graph %d (sharded_graph %d use_graph %d prof %d profiling %d comm %d) state %d\n", (int)one_graph, sharded_graph,
                             (int)use_graph, (int)prof.enabled, (int)profiling, (int)comm.kind(), segs_[kSegShardedAll].state);
   }
-  if (one_graph) run_seg(kSegShardedAll, whole_solve);
-  else whole_solve();
+  if (one_graph) {
+    // (ba_lazy_pose: whether the pose side of the assembly runs inside solve_schur is a HOST decision (pp_valid_) that a captured
+    // body would freeze at capture time -- inside the one graph the pose side is never conditional: it runs in front of it)
+    ensure_pp();
+    run_seg(kSegShardedAll, whole_solve);
+  } else {
+    whole_solve();
+  }
   const int rc = exchange_status();   // (synchronises)
   comm.poll_error();
   return rc;
@@ -4685,11 +4697,16 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
   const size_t n = (size_t)es.n;
   if (n_classes < 1 || n_classes > 128) throw ArgFailure("ba_set_edges_classes: 1 to 128 edge classes");
   if (n_classes > 1 && (!class_params || !edge_class)) throw ArgFailure("ba_set_edges_classes: null class table");
+  // Everything that can refuse the binding is checked BEFORE the front end or the edge set is changed: a failed call leaves both
+  // as they were.
+  if (es.rk.p)   // (symmetric with set_robust_kernel_per_edge, which refuses a bound set: the fused kernels never read es.rk)
+    throw StateFailure("ba_set_edges: the set carries per-edge robust kernels (set_robust_kernel_per_edge); on the BA front end they go through ba_set_edges_classes -- clear them first");
   std::vector<int> camc;   // camera index | class << 24: what every device copy of the camera index carries
   if (n_classes > 1) {
     for (int c = 0; c < n_classes; ++c) {
       const double kd = class_params[5 * c + 3];
       if (!(kd == 0.0 || kd == 1.0 || kd == 2.0 || kd == 3.0 || kd == 4.0 || kd == 5.0)) throw ArgFailure("ba_set_edges_classes: robust kernel kind of a class must be 0..5");
+      if (kd != 0.0 && !(class_params[5 * c + 4] > 0.0)) throw ArgFailure("ba_set_edges_classes: robust kernel delta of class " + std::to_string(c) + " must be positive");
     }
     camc.resize(n);
     for (size_t k = 0; k < n; ++k) {
@@ -4697,6 +4714,29 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
       if (cam_vertex[k] < 0 || cam_vertex[k] >= (1 << 24)) throw ArgFailure("ba_set_edges_classes: camera indices are limited to 2^24 with edge classes");
       camc[k] = cam_vertex[k] | (edge_class[k] << 24);
     }
+  }
+  ba_validate_edges(es, cam_vertex, point_vertex, n);
+  // Hpl block written by each edge; the fused assembly requires one observation per (pose, landmark) pair
+  std::vector<int> edge_hpl(n, -1);
+  bool unique = es.first_lm && es.first_ol;
+  {
+    std::vector<char> seen(pl_row.size(), 0);
+    for (size_t k = 0; k < n; ++k)
+      if (es.v0[k] < 0) unique = false;   // a fixed landmark: its edges would be skipped by the landmark-major kernel
+    host_parallel_for(n, [&](size_t b_, size_t e_) {   // (the searches in parallel, the duplicate check in edge order)
+      for (size_t k = b_; k < e_; ++k) {
+        const int a = es.v0[k], b = es.v1[k];
+        if (a >= 0 && b >= 0) edge_hpl[k] = find_block(pl_colptr, pl_row, a - nP_, b);
+      }
+    });
+    for (size_t k = 0; k < n; ++k) {
+      const int q = edge_hpl[k];
+      if (q < 0) continue;
+      if (seen[q]) unique = false;
+      seen[q] = 1;
+    }
+    if (n_classes > 1 && !unique)
+      throw ArgFailure("ba_set_edges_classes: edge classes need the fused path (one observation per (pose, landmark) pair, no fixed landmark)");
   }
   ba_.set = set;
   ba_.n_edges = es.n;
@@ -4713,7 +4753,6 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
   }
   ba_.h_cam_v.assign(cam_vertex, cam_vertex + n);
   ba_.h_pt_v.assign(point_vertex, point_vertex + n);
-  ba_validate();
   if (n_classes > 1) cam_vertex = camc.data();   // (validated plain; from here on the indices carry the class)
   ba_.err_valid = ba_.jac_valid = false;
   chi2_valid_ = false;
@@ -4729,29 +4768,7 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
     es.own_omega.upload(info, n * 4, st_);
   }
   {
-    // Hpl block written by each edge; the fused assembly requires one observation per (pose, landmark) pair
-    std::vector<int> edge_hpl(n, -1);
-    std::vector<char> seen(pl_row.size(), 0);
-    bool unique = es.first_lm && es.first_ol;
-    for (size_t k = 0; k < n; ++k)
-      if (es.v0[k] < 0) unique = false;   // a fixed landmark: its edges would be skipped by the landmark-major kernel
-    host_parallel_for(n, [&](size_t b_, size_t e_) {   // (the searches in parallel, the duplicate check in edge order)
-      for (size_t k = b_; k < e_; ++k) {
-        const int a = es.v0[k], b = es.v1[k];
-        if (a >= 0 && b >= 0) edge_hpl[k] = find_block(pl_colptr, pl_row, a - nP_, b);
-      }
-    });
-    for (size_t k = 0; k < n; ++k) {
-      const int q = edge_hpl[k];
-      if (q < 0) continue;
-      if (seen[q]) unique = false;
-      seen[q] = 1;
-    }
     ba_.fused_ok = unique;
-    if (n_classes > 1 && !unique) {
-      ba_ = BaFrontEnd();
-      throw ArgFailure("ba_set_edges_classes: edge classes need the fused path (one observation per (pose, landmark) pair, no fixed landmark)");
-    }
     ba_.edge_hpl.upload(edge_hpl, st_);
     if (unique) {   // the observation behind every Hpl block, in block order (ba_schur_tile_kernel)
       const size_t nq = std::max<size_t>(pl_row.size(), 1);
@@ -4913,10 +4930,15 @@ bool BlockSolver::ba_recompute_ok() const {
 
 void BlockSolver::ba_validate() {
   if (ba_.set < 0 || ba_.h_cam_v.empty() || ba_.h_cam_hidx.empty()) return;
-  const EdgeSet& es = *sets_[ba_.set];
+  ba_validate_edges(*sets_[ba_.set], ba_.h_cam_v.data(), ba_.h_pt_v.data(), ba_.h_cam_v.size());
+}
+// the edges' (camera, point) indices against the estimate tables and the edge set's vertices (nothing to check before the
+// estimates are there: ba_set_estimates validates then)
+void BlockSolver::ba_validate_edges(const EdgeSet& es, const int* cam_v, const int* pt_v, size_t n) const {
+  if (n == 0 || ba_.h_cam_hidx.empty()) return;
   const int nc = (int)ba_.h_cam_hidx.size(), np = (int)ba_.h_pt_hidx.size();
-  for (size_t k = 0; k < ba_.h_cam_v.size(); ++k) {
-    const int c = ba_.h_cam_v[k], q = ba_.h_pt_v[k];
+  for (size_t k = 0; k < n; ++k) {
+    const int c = cam_v[k], q = pt_v[k];
     if (c < 0 || c >= nc) throw ArgFailure("ba: camera index " + std::to_string(c) + " of edge " + std::to_string(k) + " outside the estimate table");
     if (q < 0 || q >= np) throw ArgFailure("ba: point index " + std::to_string(q) + " of edge " + std::to_string(k) + " outside the estimate table");
     const int hc = ba_.h_cam_hidx[c], hp = ba_.h_pt_hidx[q];

@@ -488,6 +488,7 @@ static void fill_chol_stats(const CholStats* cs, g2ohip_stats* out) {
   out->bandChains = cs->n_band;
   out->bandCholeskyNNZ = cs->nnzL_band;
   out->bandPivots = cs->piv_band;
+  out->treeBackwardGroups = cs->n_tree_groups;
 }
 
 int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out) {
@@ -530,6 +531,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "dep_levels")) s->impl->chol_opt.dep_levels = (int)value;
   else if (!std::strcmp(name, "wave_kernel")) s->impl->chol_opt.wave_kernel = (int)value;
   else if (!std::strcmp(name, "band_kernel")) s->impl->chol_opt.band_kernel = (int)value;
+  else if (!std::strcmp(name, "tree_backward")) s->impl->chol_opt.tree_backward = (int)value;
   else if (!std::strcmp(name, "overlap_level_halves")) s->impl->chol_opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "lazy_level_joins")) s->impl->chol_opt.lazy_level_joins = (int)value;
   else if (!std::strcmp(name, "big_gather")) s->impl->chol_opt.big_gather = (int)value;
@@ -1029,6 +1031,7 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "dep_levels")) ls->opt.dep_levels = (int)value;
   else if (!std::strcmp(name, "wave_kernel")) ls->opt.wave_kernel = (int)value;
   else if (!std::strcmp(name, "band_kernel")) ls->opt.band_kernel = (int)value;
+  else if (!std::strcmp(name, "tree_backward")) ls->opt.tree_backward = (int)value;
   else if (!std::strcmp(name, "overlap_level_halves")) ls->opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "lazy_level_joins")) ls->opt.lazy_level_joins = (int)value;
   else if (!std::strcmp(name, "big_gather")) ls->opt.big_gather = (int)value;

@@ -145,55 +145,80 @@ class Comm {
     rank_ = rank;
     world_ = world;
     peer_cap_ = cap;
-    const size_t doubles = kPeerHeader + 2 * (size_t)world * cap;
-    // uncached (fine-grained) device memory when the runtime exports it, plain device memory otherwise
-    void* p = nullptr;
+    kind_ = kPeer;   // from here on destroy() releases whatever has been set up so far
+    // A rank whose local set-up fails does not throw in front of a collective call (its peers would wait there for ever): it
+    // remembers why, takes part in the handle exchange with an empty row and in the final barrier, which sums a failure flag --
+    // every rank then releases what it holds and fails together.
+    std::string why;
     hipIpcMemHandle_t mine;
-    bool have = false;
-    if (hipExtMallocWithFlags(&p, doubles * sizeof(double), hipDeviceMallocUncached) == hipSuccess && p) {
-      if (hipIpcGetMemHandle(&mine, p) == hipSuccess) have = true;
-      else {
+    std::memset(&mine, 0, sizeof(mine));
+    const size_t doubles = kPeerHeader + 2 * (size_t)world * cap;
+    try {
+      // uncached (fine-grained) device memory when the runtime exports it, plain device memory otherwise
+      void* p = nullptr;
+      bool have = false;
+      if (hipExtMallocWithFlags(&p, doubles * sizeof(double), hipDeviceMallocUncached) == hipSuccess && p) {
+        if (hipIpcGetMemHandle(&mine, p) == hipSuccess) have = true;
+        else {
+          (void)hipGetLastError();
+          (void)hipFree(p);
+          p = nullptr;
+        }
+      } else {
         (void)hipGetLastError();
-        (void)hipFree(p);
-        p = nullptr;
       }
-    } else {
-      (void)hipGetLastError();
+      if (!have) {
+        G2OHIP_HIP_CHECK(hipMalloc(&p, doubles * sizeof(double)));
+        peer_box_[rank] = static_cast<double*>(p);
+        G2OHIP_HIP_CHECK(hipIpcGetMemHandle(&mine, p));
+      }
+      peer_box_[rank] = static_cast<double*>(p);
+      if (std::getenv("G2OHIP_COMM_DEBUG")) fprintf(stderr, "comm_init_peer: rank %d mailbox %s, %zu KB\n", rank, have ? "uncached (fine-grained)" : "plain device memory", doubles / 128);
+      G2OHIP_HIP_CHECK(hipMemset(p, 0, doubles * sizeof(double)));
+      G2OHIP_HIP_CHECK(hipDeviceSynchronize());
+      // [0, 16): finished workgroups of a put per peer; [16]: ... of a sum; behind them (8-byte aligned) the sequence number of the last call
+      G2OHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&peer_cnt_), (kPeerMaxWorld + 4) * sizeof(unsigned int)));
+      G2OHIP_HIP_CHECK(hipMemset(peer_cnt_, 0, (kPeerMaxWorld + 4) * sizeof(unsigned int)));
+      G2OHIP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&peer_err_), sizeof(int), hipHostMallocMapped));
+      *peer_err_ = 0;
+    } catch (const std::exception& e) {
+      why = e.what();
     }
-    if (!have) {
-      G2OHIP_HIP_CHECK(hipMalloc(&p, doubles * sizeof(double)));
-      G2OHIP_HIP_CHECK(hipIpcGetMemHandle(&mine, p));
-    }
-    peer_box_[rank] = static_cast<double*>(p);
-    if (std::getenv("G2OHIP_COMM_DEBUG")) fprintf(stderr, "comm_init_peer: rank %d mailbox %s, %zu KB\n", rank, have ? "uncached (fine-grained)" : "plain device memory", doubles / 128);
-    G2OHIP_HIP_CHECK(hipMemset(p, 0, doubles * sizeof(double)));
-    G2OHIP_HIP_CHECK(hipDeviceSynchronize());
-    // [0, 16): finished workgroups of a put per peer; [16]: ... of a sum; behind them (8-byte aligned) the sequence number of the last call
-    G2OHIP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&peer_cnt_), (kPeerMaxWorld + 4) * sizeof(unsigned int)));
-    G2OHIP_HIP_CHECK(hipMemset(peer_cnt_, 0, (kPeerMaxWorld + 4) * sizeof(unsigned int)));
-    G2OHIP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&peer_err_), sizeof(int), hipHostMallocMapped));
-    *peer_err_ = 0;
     // all-gather of the handles through the host all-reduce: one double per byte, a rank fills its own row (the call is also
     // the barrier behind which every mailbox is zeroed)
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t");
     std::vector<double> hb((size_t)world * 64, 0.0);
     const unsigned char* mb = reinterpret_cast<const unsigned char*>(&mine);
     for (int i = 0; i < 64; ++i) hb[(size_t)rank * 64 + i] = mb[i];
-    if (world > 1 && fn_(ctx_, hb.data(), hb.size(), 0) != 0) throw StateFailure("comm_init_peer: host all-reduce callback failed");
-    for (int q = 0; q < world; ++q) {
+    if (world > 1 && fn_(ctx_, hb.data(), hb.size(), 0) != 0) {
+      destroy();
+      throw StateFailure("comm_init_peer: host all-reduce callback failed");
+    }
+    for (int q = 0; q < world && why.empty(); ++q) {
       if (q == rank) continue;
       hipIpcMemHandle_t h;
       unsigned char* hbq = reinterpret_cast<unsigned char*>(&h);
       for (int i = 0; i < 64; ++i) hbq[i] = (unsigned char)hb[(size_t)q * 64 + i];
       void* pq = nullptr;
-      G2OHIP_HIP_CHECK(hipIpcOpenMemHandle(&pq, h, hipIpcMemLazyEnablePeerAccess));
+      const hipError_t e = hipIpcOpenMemHandle(&pq, h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        why = std::string("hipIpcOpenMemHandle (mailbox of rank ") + std::to_string(q) + "): " + hipGetErrorString(e);
+        break;
+      }
       peer_box_[q] = static_cast<double*>(pq);
     }
-    kind_ = kPeer;
     // nobody stores into a mailbox before every rank has mapped them all (a peer's first put may otherwise race a late memset-free
-    // start-up elsewhere: cheap insurance)
-    double one = 1.0;
-    if (world > 1 && fn_(ctx_, &one, 1, 0) != 0) throw StateFailure("comm_init_peer: host all-reduce callback failed");
+    // start-up elsewhere: cheap insurance); the same call tells every rank whether any of them failed
+    double bad = why.empty() ? 0.0 : 1.0;
+    if (world > 1 && fn_(ctx_, &bad, 1, 0) != 0) {
+      destroy();
+      throw StateFailure("comm_init_peer: host all-reduce callback failed");
+    }
+    if (bad > 0.0) {
+      destroy();
+      throw StateFailure("comm_init_peer: " + (why.empty() ? std::string("another rank could not set up its mailboxes") : why));
+    }
   }
   // (after a synchronisation of the stream the collectives ran on) a peer never arrived within the wait limit
   void poll_error() {

@@ -74,6 +74,8 @@ struct CholOptions {
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
   int band_kernel = 1;                   // leaf chains of a band (+ one dense border) on the sliding-window kernel (band_chain.inc)
+  int tree_backward = 1;                 // backward sweep of the tree levels of a dependency-driven group by GROUPS of fronts: one sixteen-wave workgroup
+                                         // per subtree of up to sixteen small fronts, hand-offs inside a group through LDS (tree_backward_kernel)
 };
 
 struct CholStats {
@@ -81,6 +83,7 @@ struct CholStats {
   size_t n_fronts = 0, n_levels = 0, n_tasks = 0, max_front_dim = 0;
   size_t n_band = 0;      // leaf chains on the band kernel
   size_t nnzL_band = 0, piv_band = 0;   // ... their share of nnz(L) and of the pivot columns (scalars)
+  size_t n_tree_groups = 0;   // groups of fronts of the backward sweep (tree_backward_kernel)
   double flops = 0;       // factorisation flops (dense-front count)
   double t_symbolic = 0;  // seconds, host
   size_t bytes_L = 0, bytes_U = 0;
@@ -142,6 +145,8 @@ struct BandChainRec {
   int ublk;               // 8 x 4 bits: boundary position (in the last front) of the staying band blocks (0-3) and of the border blocks (4-7)
   int pad[4];
 };
+// tree_backward_kernel: the fronts it takes (pivot columns, boundary rows: scalars) and the fronts (waves) of a group
+constexpr int kTreePiv = 24, kTreeBnd = 48, kTreeWaves = 16;
 constexpr int kBandFrontInts = 17;   // first pivot block, pivot scalars, L offset (2), m, local row of band blocks +0..+7, of border blocks 0..3
 
 struct CholPlanDev {
@@ -324,9 +329,15 @@ class SparseCholesky {
     bool gather = false;                                 // every scratch-slab front of the level can gather its children's update matrices at load time (cinv tables): no extend-add passes
   };
   std::vector<LevelLaunch> launches_[2];   // [0] own tasks, [1] shared top-of-tree tasks
-  struct FactorGroup { LevelLaunch LL; int first_level, last_level; bool dep; int band_count = 0, band_rec0 = 0, band_ent_cap = 0, band_tab_cap = 0; };
+  struct FactorGroup {
+    LevelLaunch LL; int first_level, last_level; bool dep; int band_count = 0, band_rec0 = 0, band_ent_cap = 0, band_tab_cap = 0;
+    int tb_grp0 = 0, tb_ngrp = 0, tb_low = 0;   // tree_backward: its groups (d_tb_grec), the launch slots (lowest levels) left to the per-task kernel
+  };
   std::vector<FactorGroup> groups_[2];     // factorisation launches: runs of levels (dep: one launch, in-kernel dependencies)
   DevBuf<int> d_ready;
+  DevBuf<int4> d_tb_grec;    // tree_backward: per group (first entry of d_tb_front, fronts, levels, front to wait for)
+  DevBuf<int2> d_tb_front;   // ... per group front (front, level inside the group | tasks to release << 8), level by level
+  DevBuf<int> d_tb_rows;     // ... the boundary row lists (indexed like d_rows) with the rows a front of the same group owns replaced by -1 - (offset in LDS)
   struct SegCopy { long long a, b; int n, flags; };  // exchange segment: a = offset in U (or w: flag 2), b = offset in xbuf; flag 1 = mine
   DevBuf<SegCopy> d_xseg;
   DevBuf<double> d_xbuf, d_xmask;
@@ -349,7 +360,7 @@ class SparseCholesky {
   void launch_band(const FactorGroup& G, const double* dA, bool fused, hipStream_t st, bool dep);   // the group's band chains (band_chain.inc)
   hipStream_t side_[2] = {nullptr, nullptr};   // factor_phase: the two halves of a level / the forward step of its large fronts
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
-  void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false, bool skip_glb = false);
+  void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false, bool skip_glb = false, int dep_tail = 0);
   bool big_forward_carried(const LevelLaunch& LL) const;
   static void prepare_kernels();
   int merge_tiles_of(const LevelLaunch& LL) const { return (LL.grouped || LL.group_in) ? -1 : opt.big_merge_tiles; }   // (grouped chains: the separate kernels)   // the forward step of the level's scratch-slab fronts rides along in their factorisation

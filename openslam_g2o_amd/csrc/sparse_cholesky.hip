@@ -1590,6 +1590,122 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   }
   d_ready.alloc((size_t)std::max(nf, 1));
   d_ready.zero(st);
+  // --- backward sweep of the tree levels by groups of fronts (tree_backward_kernel).  In a dependency-driven group the levels
+  // above the leaf level whose fronts are all small (kTreePiv pivot columns, kTreeBnd boundary rows) are cut into groups top
+  // down: a root and whole levels of descendants while they fit sixteen waves (the first group of a tree is made shallower so
+  // that the groups below it are full: four levels of a binary tree); the fronts of the next level start groups of their own.
+  // Groups are listed parents first (the launch order the no-deadlock argument needs).
+  {
+    std::vector<int4> grec;
+    std::vector<int2> gfr;
+    std::vector<int> grows(S.rows);
+    if (grows.empty()) grows.push_back(0);
+    for (int ph = 0; ph < 2; ++ph)
+      for (FactorGroup& G : groups_[ph]) {
+        G.tb_grp0 = (int)grec.size();
+        G.tb_ngrp = G.tb_low = 0;
+        if (!opt.tree_backward || !G.dep || !opt.dep_backward || G.LL.glb_count > 0) continue;
+        auto small = [&](int f) { return S.f_ns[f] * bs <= kTreePiv && S.f_nb[f] * bs <= kTreeBnd && S.f_ns[f] > 0; };
+        int lc = G.last_level + 1;
+        for (int l = G.last_level; l > G.first_level; --l) {
+          const LevelLaunch& N = launches_[ph][l];
+          bool ok = true;
+          for (int q = N.lds_begin; q < N.lds_begin + N.lds_count && ok; ++q) {
+            const int t = S.level_fronts[q];
+            for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) ok = ok && small(S.task_fronts[k]);
+          }
+          if (!ok) break;
+          lc = l;
+        }
+        if (G.last_level + 1 - lc < 2) continue;
+        std::vector<int> in_tree(nf, 0);
+        for (int l = lc; l <= G.last_level; ++l) {
+          const LevelLaunch& N = launches_[ph][l];
+          for (int q = N.lds_begin; q < N.lds_begin + N.lds_count; ++q) {
+            const int t = S.level_fronts[q];
+            for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) in_tree[S.task_fronts[k]] = 1;
+          }
+        }
+        std::vector<std::vector<int>> kids(nf);
+        std::vector<int> height(nf, 0), roots;
+        for (int f2 = 0; f2 < nf; ++f2) {   // (fronts are numbered children first)
+          if (!in_tree[f2]) continue;
+          height[f2] = std::max(height[f2], 1);
+          const int pf = S.f_parent[f2];
+          if (pf >= 0 && in_tree[pf]) {
+            kids[pf].push_back(f2);
+            height[pf] = std::max(height[pf], height[f2] + 1);
+          } else {
+            roots.push_back(f2);
+          }
+        }
+        // depth of the deepest full group: the largest d with 2^d - 1 <= sixteen fronts
+        constexpr int kDepth = 4;
+        std::vector<int> grp_of(nf, -1), pos_of(nf, 0);
+        std::vector<int> queue(roots);
+        for (size_t qi = 0; qi < queue.size(); ++qi) {
+          const int r = queue[qi];
+          const int gid = (int)grec.size();
+          const int depth_cap = (height[r] - 1) % kDepth + 1;
+          std::vector<int> level(1, r), next;
+          const int first = (int)gfr.size();
+          int cnt = 0, nl = 0;
+          while (!level.empty()) {
+            for (int f2 : level) {
+              grp_of[f2] = gid;
+              pos_of[f2] = cnt++;
+              gfr.push_back(make_int2(f2, nl));
+            }
+            ++nl;
+            next.clear();
+            for (int f2 : level)
+              for (int c : kids[f2]) next.push_back(c);
+            if (next.empty()) break;
+            if (nl >= depth_cap || cnt + (int)next.size() > kTreeWaves) {
+              for (int c : next) queue.push_back(c);   // groups of their own
+              break;
+            }
+            level.swap(next);
+          }
+          const int pf = S.f_parent[r];
+          grec.push_back(make_int4(first, cnt, nl, (pf >= 0 && in_tree[pf]) ? pf : -1));
+        }
+        G.tb_ngrp = (int)grec.size() - G.tb_grp0;
+        for (int l = G.first_level; l < lc; ++l) G.tb_low += launches_[ph][l].lds_count;
+        // what a front releases: the groups rooted below it and the tasks of the per-task launch that wait for it; where the
+        // boundary values of a front come from
+        std::vector<int> rel(nf, 0);
+        for (int f2 = 0; f2 < nf; ++f2) {
+          const int pf = S.f_parent[f2];
+          if (pf < 0 || !in_tree[pf]) continue;
+          if (in_tree[f2]) {
+            if (grp_of[f2] != grp_of[pf]) ++rel[pf];
+          } else {
+            const int t = task_of[f2];
+            const bool top = S.task_fronts[S.task_ptr[t + 1] - 1] == f2;
+            if (top && task_level[t] >= G.first_level && task_level[t] < lc && (recs[f2].pad[0] & 2)) ++rel[pf];
+          }
+        }
+        for (int e = grec[G.tb_grp0].x; e < (int)gfr.size(); ++e) {
+          const int f2 = gfr[e].x;
+          if (rel[f2] > 0x7fffff) throw StateFailure("tree_backward: release count out of range");
+          gfr[e].y |= rel[f2] << 8;
+          for (int j = 0; j < S.f_nb[f2]; ++j) {
+            const int r = S.rows[S.rows_off[f2] + j], o = sn_of[r];
+            if (grp_of[o] == grp_of[f2]) grows[S.rows_off[f2] + j] = -1 - (pos_of[o] * kTreePiv + (r - S.sn_start[o]) * bs);
+          }
+        }
+        if (getenv("G2OHIP_PLAN_DUMP"))
+          fprintf(stderr, "phase %d tree backward: levels %d..%d in %d groups (%d fronts), %d slots left to the per-task kernel\n", ph, lc, G.last_level,
+                  G.tb_ngrp, (int)gfr.size() - grec[G.tb_grp0].x, G.tb_low);
+      }
+    stats_.n_tree_groups = grec.size();
+    if (grec.empty()) grec.push_back(make_int4(0, 0, 0, -1));
+    if (gfr.empty()) gfr.push_back(make_int2(0, 0));
+    d_tb_grec.upload(grec, st);
+    d_tb_front.upload(gfr, st);
+    d_tb_rows.upload(grows, st);
+  }
   d_task_ptr.upload(S.task_ptr, st);
   d_task_fronts.upload(S.task_fronts, st);
   d_rec.upload(recs, st);
@@ -3441,6 +3557,15 @@ __global__ void __launch_bounds__(256) front_forward_kernel(CholPlanDev P, int s
   }
 }
 
+// Row parts of the boundary product t[k] -= sum_i L[i,k] t[i] of the backward sweep: NT / npiv lanes per pivot column; small
+// fronts (kTreePiv pivot columns, kTreeBnd boundary rows at most) use the largest power of two <= min(that, 4) so that
+// tree_backward_kernel (two lanes per column, rows by parity) adds the same partial sums in the same order.
+__host__ __device__ __forceinline__ int bw_parts(int NT, int npiv, int m) {
+  int parts = NT / npiv > 0 ? NT / npiv : 1;
+  if (npiv <= kTreePiv && m - npiv <= kTreeBnd) parts = parts >= 4 ? 4 : (parts >= 2 ? 2 : 1);
+  return parts;
+}
+
 // Backward sweep over one task (chain top first): x1 = L11' \ (y1 - L21' x_boundary); same blocking.
 // Inside a chain the child's boundary values are taken from the parent's vector kept in LDS.
 // LDS: [panel (optional)] [t: mcap] [xs: mcap] [sp: NT] [fullprev: mcap]
@@ -3504,7 +3629,9 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int 
     __syncthreads();
     // boundary contribution t[k] -= sum_{i>=npiv} L[i,k] t[i]: (k, part) decomposition + LDS reduction
     {
-      const int parts = NT / npiv > 0 ? NT / npiv : 1;
+      // (small fronts -- the ones tree_backward_kernel also handles: at most 24 pivot columns and 48 boundary rows -- split the
+      // rows into 4, 2 or 1 parts, whatever the workgroup size allows more of: the two kernels form the same sums in the same order)
+      const int parts = bw_parts(NT, npiv, m);
       const int k = tid % npiv, part = tid / npiv;
       double s = 0.0;
       if (part < parts && NT >= npiv)
@@ -3580,6 +3707,131 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int 
     if (dep_release > 0) __builtin_amdgcn_s_waitcnt(0);   // every wave: its x stores have been acknowledged
     __syncthreads();
     if (dep_release > 0 && tid == 0) __hip_atomic_fetch_add(P.ready + f, dep_release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Backward sweep of the TREE levels by groups of fronts (option tree_backward).  The per-task kernel above pays a hand-off
+// between workgroups per level of the elimination tree (the parent's x stored with agent-scope stores and acknowledged, a counter,
+// the child's coherent loads: ~4-6 us of the ~11 us a level costs, profiles/r4_tree_handoff.txt) for a 24 x 24 triangular solve
+// and a 24 x 48 product.  Here ONE workgroup of sixteen waves owns a GROUP: a front and its descendants down to a depth at
+// which at most sixteen fronts are reached (four levels of a binary tree), one wave per front.  Before the group waits for the
+// front above its root, every wave has requested its whole L panel into REGISTERS (lane (k, h): column k, rows of parity h --
+// 24 + 24 doubles) and its index table; after the wait one round of coherent loads fetches the boundary values that come from
+// fronts above the group; inside the group the pivot solutions travel through LDS and the levels are separated by workgroup
+// barriers only.  A front releases the tasks below the group through the same `ready` counters as the per-task kernel (which
+// sweeps the levels below: the long leaf chains).  Sums and their order are those of front_backward_kernel (bw_parts), bit for bit.
+struct TreeGroupRec {
+  int first, count, nlev, wait_front;   // entries of the group in the front list; levels; front above the root to wait for (-1: none)
+};
+template <int BS>
+__global__ void __launch_bounds__(kTreeWaves * 64) tree_backward_kernel(CholPlanDev P, const TreeGroupRec* __restrict__ groups,
+                                                                       const int2* __restrict__ gfront, const int* __restrict__ grows,
+                                                                       const double* __restrict__ y, double* __restrict__ xp, int nt_ref) {
+  constexpr int NSMAX = kTreePiv / BS, JH = kTreeBnd / 2;
+  __shared__ double xg[kTreeWaves * kTreePiv];
+  __shared__ double tw[kTreeWaves][kTreeBnd];
+  const TreeGroupRec g = groups[blockIdx.x];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool active = wave < g.count;
+  const int2 gf = gfront[g.first + (active ? wave : 0)];   // (front, level inside the group | tasks to release << 8)
+  const int f = __builtin_amdgcn_readfirstlane(gf.x), lev = __builtin_amdgcn_readfirstlane(gf.y) & 0xff,
+            release = __builtin_amdgcn_readfirstlane(gf.y) >> 8;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int ns = rec.ns, npiv = ns * BS, nbs = rec.nb * BS, m = npiv + nbs, c0 = rec.c0;
+  const int k = lane >> 1, h = lane & 1;
+  const bool col = k < npiv;
+  const double* Lg = P.L + rec.L_off;
+  const double* Lk = Lg + (size_t)m * (col ? k : 0);
+  // the panel: nothing of it depends on the fronts above
+  double L21[JH], L11[kTreePiv];
+#pragma unroll
+  for (int j = 0; j < JH; ++j) {
+    const int i = npiv + h + 2 * j;
+    const double v = Lk[min(i, m - 1)];
+    L21[j] = (col && i < m) ? v : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < kTreePiv; ++q) {
+    const double v = Lk[min(q, m - 1)];
+    L11[q] = (col && q < npiv) ? v : 0.0;
+  }
+  const double linv = col ? Lg[(size_t)m * npiv + k] : 0.0;
+  const double yk = col ? y[(size_t)c0 * BS + k] : 0.0;
+  const int src = lane < nbs ? grows[rec.rows_off + lane / BS] : 0;   // >= 0: block row in memory, < 0: -1 - (offset in xg)
+  const int off = lane % BS;
+  if (g.wait_front >= 0) {
+    if (tid == 0) {
+      int* flag = P.ready + g.wait_front;
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > P.dep_spin_limit || ((spins & 255) == 0 && __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
+          __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __hip_atomic_fetch_add(flag, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the last child leaves it at zero
+    }
+    __syncthreads();
+  }
+  const double xb = (active && lane < nbs && src >= 0) ? ld_coh(xp + (size_t)src * BS + off) : 0.0;
+  const int parts = bw_parts(nt_ref, max(npiv, 1), m);
+  for (int l = 0; l < g.nlev; ++l) {
+    if (active && lev == l) {
+      if (lane < kTreeBnd) tw[wave][lane] = lane < nbs ? (src < 0 ? xg[-1 - src + off] : xb) : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // (same wave writes and reads: LDS operations of a wave complete in order)
+      double sa = 0.0, sb = 0.0;
+      if (parts == 4) {   // part p of front_backward_kernel = rows p, p + 4, ...: the even / odd registers of lane (k, p & 1)
+#pragma unroll
+        for (int j = 0; j < JH; ++j) {
+          const double tv = tw[wave][h + 2 * j];
+          if (j & 1) sb = fma(L21[j], tv, sb);
+          else sa = fma(L21[j], tv, sa);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < JH; ++j) sa = fma(L21[j], tw[wave][h + 2 * j], sa);
+      }
+      const double oa = __shfl_xor(sa, 1), ob = __shfl_xor(sb, 1);
+      double a = 0.0;
+      a += sa;
+      a += oa;
+      if (parts == 4) {
+        a += sb;
+        a += ob;
+      }
+      double z = yk - a, xout = 0.0;
+#pragma unroll
+      for (int kb = NSMAX - 1; kb >= 0; --kb) {
+        if (kb < ns) {
+          const int k0 = kb * BS;
+          double xs[BS];
+#pragma unroll
+          for (int c = BS - 1; c >= 0; --c) {
+            double v = z;
+#pragma unroll
+            for (int q = c + 1; q < BS; ++q) v = fma(-L11[k0 + q], xs[q], v);
+            const double xc = v * linv;
+            xs[c] = readlane_f64(xc, 2 * (k0 + c));
+            if (k == k0 + c) xout = xc;
+          }
+          double zz = z;
+#pragma unroll
+          for (int q = 0; q < BS; ++q) zz = fma(-L11[k0 + q], xs[q], zz);
+          z = k < k0 ? zz : z;
+        }
+      }
+      if (col && h == 0) {
+        xg[wave * kTreePiv + k] = xout;
+        st_coh(xp + (size_t)c0 * BS + k, xout);
+      }
+      if (release > 0) {   // tasks below the group (other groups, the per-task launch) wait for this front
+        __builtin_amdgcn_s_waitcnt(0);   // the x stores have been acknowledged
+        if (lane == 0) __hip_atomic_fetch_add(P.ready + f, release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -4789,11 +5041,16 @@ void SparseCholesky::factor_solve(const double* dA, const double* d_b, double* d
   solve_end(d_x, st);
 }
 
-void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only, bool dep, bool skip_glb) {
+void SparseCholesky::launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only, bool dep, bool skip_glb, int dep_tail) {
   const size_t panel_limit = 48 * 1024;  // bytes of L panel staged in LDS
   int count = glb_only ? LL.glb_count : LL.lds_count + (skip_glb ? 0 : LL.glb_count);
-  // dep: backward sweep of a dependency-driven group (no scratch-slab tasks) over the reversed slot list
-  const int slot0 = dep ? n_slots_ - (LL.lds_begin + LL.lds_count) : (glb_only ? LL.glb_begin : LL.lds_begin);
+  // dep: backward sweep of a dependency-driven group (no scratch-slab tasks) over the reversed slot list; dep_tail > 0: only its
+  // last dep_tail slots (the lowest levels: the ones above them were swept by tree_backward_kernel)
+  int slot0 = dep ? n_slots_ - (LL.lds_begin + LL.lds_count) : (glb_only ? LL.glb_begin : LL.lds_begin);
+  if (dep && dep_tail > 0) {
+    slot0 += count - dep_tail;
+    count = dep_tail;
+  }
   if (count == 0) return;
   CholPlanDev bplan = plan_;
   if (dep) bplan.slots = d_bslots.p;
@@ -4894,7 +5151,23 @@ void SparseCholesky::solve_backward_phase(int phase, hipStream_t st) {
   for (size_t g = groups_[phase].size(); g-- > 0;) {
     const FactorGroup& G = groups_[phase][g];
     if (G.dep && opt.dep_backward && !dep_off_) {
-      launch_solve(G.LL, false, st, false, true);
+      if (G.tb_ngrp > 0) {   // the tree levels by groups of fronts, then the levels below them task by task
+        const int nt_ref = G.LL.max_m <= 64 ? 64 : (G.LL.max_m <= 128 ? 128 : 256);   // (launch_solve's workgroup size: bw_parts)
+        const TreeGroupRec* gr = reinterpret_cast<const TreeGroupRec*>(d_tb_grec.p) + G.tb_grp0;
+#define G2OHIP_TREE_BACKWARD(BS_) \
+  hipLaunchKernelGGL((tree_backward_kernel<BS_>), dim3(G.tb_ngrp), dim3(kTreeWaves * 64), 0, st, plan_, gr, d_tb_front.p, d_tb_rows.p, d_y.p, d_xp.p, nt_ref)
+        switch (bs_) {
+          case 3: G2OHIP_TREE_BACKWARD(3); break;
+          case 6: G2OHIP_TREE_BACKWARD(6); break;
+          case 7: G2OHIP_TREE_BACKWARD(7); break;
+          default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
+        }
+#undef G2OHIP_TREE_BACKWARD
+        G2OHIP_LAUNCH_CHECK("tree_backward_kernel");
+        if (G.tb_low > 0) launch_solve(G.LL, false, st, false, true, false, G.tb_low);
+      } else {
+        launch_solve(G.LL, false, st, false, true);
+      }
     } else {
       for (int l = G.last_level; l >= G.first_level; --l) {
         const int bg = merge ? bw_of_level_[phase][l] : -1;

@@ -292,8 +292,11 @@ class ShardedBlockSolver:
                 self.local.baSetEdgesClasses(self.set_id, prob["cam_idx"][mine], loc[prob["pt_idx"][mine]].astype(np.int32),
                                              prob["meas"][mine], prob["classes"], prob["edge_class"][mine])
             else:
+                # prob["info"]: a per-edge information matrix ([E][4], column-major 2 x 2) read by the kernels; absent:
+                # information().setIdentity() declared for the whole set (no per-edge read)
+                info = None if prob.get("info") is None else np.ascontiguousarray(prob["info"][mine])
                 self.local.baSetEdges(self.set_id, prob["cam_idx"][mine], loc[prob["pt_idx"][mine]].astype(np.int32),
-                                      prob["meas"][mine], None, prob["f"], prob["cx"], prob["cy"])
+                                      prob["meas"][mine], info, prob["f"], prob["cx"], prob["cy"])
             self.local.baSetEstimates(prob["cams"], prob["cam_hidx"], prob["pts"][my], np.arange(len(my), dtype=np.int32))
             self.local.baLinearize(True)
             return dict(E_local=int(mine.sum()), L_local=int(len(my)), lm0=int(lm0), lm1=int(lm1))

@@ -46,6 +46,20 @@ typedef struct {
   char *tr01;                   /* edge writes the off-diagonal block transposed */
 } OrcSet;
 
+/* n-ary edges (BaseMultiEdge, g2o/core/base_multi_edge.h): `arity` vertices per edge, one Jacobian array per vertex position,
+ * the off-diagonal blocks of an edge kept in the order of internal::computeUpperTriangleIndex (base_multi_edge.hpp:28-32) */
+#define ORC_MAX_MSETS 8
+#define ORC_MAX_ARITY 4
+#define ORC_MAX_PAIRS (ORC_MAX_ARITY * (ORC_MAX_ARITY - 1) / 2)
+typedef struct {
+  int d, n, arity;
+  int *v;                       /* [n][arity] hessian indices, -1 == fixed */
+  const double *J[ORC_MAX_ARITY], *omega, *err;
+  double delta; int kernel_kind; /* delta <= 0: no robust kernel */
+  long *odiag; char *kdiag;     /* [n][arity]: the vertex's diagonal block (1 Hpp, 2 Hll) */
+  long *ooff; char *koff, *troff; /* [n][ORC_MAX_PAIRS] at computeUpperTriangleIndex(i, j): _hessian[idx] (.transposed) */
+} OrcMulti;
+
 typedef struct {
   int n;                        /* scalar dimension */
   int nb, bs;                   /* blocks, block size */
@@ -62,6 +76,7 @@ typedef struct {
   int p, l, nP, nL, doSchur;
   int sizeP, sizeL;
   int nsets; OrcSet sets[ORC_MAX_SETS];
+  int nmsets; OrcMulti msets[ORC_MAX_MSETS];
   int *pp_colptr, *pp_row, *pp_diag; int pp_nnzb; double *Hpp;
   int *pl_colptr, *pl_row; int pl_nnzb; double *Hpl;
   double *Hll;
@@ -151,6 +166,28 @@ void orc_set_dims(Orc* s, int set, int dim0, int dim1) { s->sets[set].dim0 = dim
 
 static int vdim(const Orc* s, int idx) { return idx < s->nP ? s->p : s->l; }
 
+/* internal::computeUpperTriangleIndex, base_multi_edge.hpp:28-32 (i < j) */
+static int upper_triangle_index(int i, int j) { int elemsUpToCol = ((j - 1) * j) / 2; return elemsUpToCol + i; }
+
+/* An edge set of n-ary edges (BaseMultiEdge<D, E>): v[n][arity] hessian indices, -1 fixed; vertex dimensions follow the index
+ * (pose / landmark).  Returns the multi-set id. */
+int orc_add_multi_edge_set(Orc* s, int d, int n, int arity, const int* v) {
+  if (s->nmsets >= ORC_MAX_MSETS || arity < 2 || arity > ORC_MAX_ARITY) return -1;
+  OrcMulti* e = &s->msets[s->nmsets];
+  memset(e, 0, sizeof(*e));
+  e->d = d; e->n = n; e->arity = arity;
+  e->v = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1) * arity);
+  memcpy(e->v, v, sizeof(int) * (size_t)n * arity);
+  return s->nmsets++;
+}
+/* J[i]: [n][d x dim_i] column-major Jacobians of vertex position i (_jacobianOplus[i]); delta > 0: robust kernel `kind`
+ * (0 / 1 Huber, as orc_set_robust_kernel) */
+void orc_set_multi_edge_data(Orc* s, int mset, const double* const* J, const double* omega, const double* err, double delta, int kind) {
+  OrcMulti* e = &s->msets[mset];
+  for (int i = 0; i < e->arity; ++i) e->J[i] = J[i];
+  e->omega = omega; e->err = err; e->delta = delta; e->kernel_kind = kind;
+}
+
 /* block_solver.hpp:142-295 */
 int orc_build_structure(Orc* s) {
   const int nP = s->nP, nL = s->nL, p = s->p, l = s->l;
@@ -163,6 +200,17 @@ int orc_build_structure(Orc* s) {
       int ma = a >= nP, mb = b >= nP;
       if (!ma && !mb) npairs_pp++; else if (ma != mb) npairs_pl++; else return -2; /* landmark-landmark edge: asserted away at :383 */
     }
+  }
+  for (int si = 0; si < s->nmsets; ++si) {      /* every vertex pair (i < j) of an n-ary edge: block_solver.hpp:208-251 */
+    OrcMulti* e = &s->msets[si];
+    for (int k = 0; k < e->n; ++k)
+      for (int i = 0; i < e->arity; ++i)
+        for (int j = i + 1; j < e->arity; ++j) {
+          int a = e->v[(size_t)k * e->arity + i], b = e->v[(size_t)k * e->arity + j];
+          if (a < 0 || b < 0) continue;
+          int ma = a >= nP, mb = b >= nP;
+          if (!ma && !mb) npairs_pp++; else if (ma != mb) npairs_pl++; else return -2;
+        }
   }
   long long* kpp = (long long*)malloc(sizeof(long long) * (size_t)(npairs_pp + 1));
   long long* kpl = (long long*)malloc(sizeof(long long) * (size_t)(npairs_pl + 1));
@@ -177,6 +225,18 @@ int orc_build_structure(Orc* s) {
       if (!ma && !mb) { int r = a < b ? a : b, c = a < b ? b : a; kpp[ipp++] = (long long)c * nP + r; }
       else { int pose = ma ? b : a, lm = (ma ? a : b) - nP; kpl[ipl++] = (long long)lm * nP + pose; }
     }
+  }
+  for (int si = 0; si < s->nmsets; ++si) {
+    OrcMulti* e = &s->msets[si];
+    for (int k = 0; k < e->n; ++k)
+      for (int i = 0; i < e->arity; ++i)
+        for (int j = i + 1; j < e->arity; ++j) {
+          int a = e->v[(size_t)k * e->arity + i], b = e->v[(size_t)k * e->arity + j];
+          if (a < 0 || b < 0) continue;
+          int ma = a >= nP, mb = b >= nP;
+          if (!ma && !mb) { int r = a < b ? a : b, c = a < b ? b : a; kpp[ipp++] = (long long)c * nP + r; }
+          else { int pose = ma ? b : a, lm = (ma ? a : b) - nP; kpl[ipl++] = (long long)lm * nP + pose; }
+        }
   }
   keys_to_ccs(kpp, ipp, nP, nP, &s->pp_colptr, &s->pp_row, &s->pp_nnzb);
   if (nL > 0) keys_to_ccs(kpl, ipl, nP, nL, &s->pl_colptr, &s->pl_row, &s->pl_nnzb);
@@ -216,6 +276,37 @@ int orc_build_structure(Orc* s) {
           e->o01[k] = (long)find_row(s->pl_colptr, s->pl_row, lm, pose) * p * l;
         }
       }
+    }
+  }
+  /* n-ary edges: mapHessianMemory(d, i, j, rowMajor) for every free pair, base_multi_edge.hpp:128-160 via block_solver.hpp:208-251 */
+  for (int si = 0; si < s->nmsets; ++si) {
+    OrcMulti* e = &s->msets[si];
+    const int ar = e->arity;
+    size_t n = (size_t)(e->n > 0 ? e->n : 1);
+    e->odiag = (long*)malloc(sizeof(long) * n * ar); e->kdiag = (char*)calloc(n * ar, 1);
+    e->ooff = (long*)malloc(sizeof(long) * n * ORC_MAX_PAIRS); e->koff = (char*)calloc(n * ORC_MAX_PAIRS, 1); e->troff = (char*)calloc(n * ORC_MAX_PAIRS, 1);
+    for (int k = 0; k < e->n; ++k) {
+      for (int i = 0; i < ar; ++i) {
+        int a = e->v[(size_t)k * ar + i];
+        e->odiag[(size_t)k * ar + i] = -1;
+        if (a >= 0) { if (a < nP) { e->kdiag[(size_t)k * ar + i] = 1; e->odiag[(size_t)k * ar + i] = (long)s->pp_diag[a] * p * p; } else { e->kdiag[(size_t)k * ar + i] = 2; e->odiag[(size_t)k * ar + i] = (long)(a - nP) * l * l; } }
+      }
+      for (int i = 0; i < ar; ++i)
+        for (int j = i + 1; j < ar; ++j) {
+          const size_t q = (size_t)k * ORC_MAX_PAIRS + upper_triangle_index(i, j);
+          int a = e->v[(size_t)k * ar + i], b = e->v[(size_t)k * ar + j];
+          e->ooff[q] = -1;
+          if (a < 0 || b < 0) continue;
+          int ma = a >= nP, mb = b >= nP;
+          if (!ma && !mb) {                         /* :221-229: transposedBlock = ind1 > ind2 */
+            int tr = a > b; int r = tr ? b : a, c = tr ? a : b;
+            e->koff[q] = 1; e->troff[q] = (char)tr; e->ooff[q] = (long)find_row(s->pp_colptr, s->pp_row, c, r) * p * p;
+          } else {                                  /* :237-249: v1 marginalized -> the block is written transposed */
+            int pose = ma ? b : a, lm = (ma ? a : b) - nP;
+            e->koff[q] = 3; e->troff[q] = (char)ma;
+            e->ooff[q] = (long)find_row(s->pl_colptr, s->pl_row, lm, pose) * p * l;
+          }
+        }
     }
   }
   if (!s->doSchur) return 0;
@@ -359,6 +450,45 @@ int orc_build_system(Orc* s) {
 #endif
     }
   }
+  /* n-ary edges: BaseMultiEdge::constructQuadraticForm (base_multi_edge.hpp:35-49) + computeQuadraticForm (:170-222) */
+  for (int si = 0; si < s->nmsets; ++si) {
+    OrcMulti* e = &s->msets[si];
+    const int d = e->d, ar = e->arity;
+    for (int k = 0; k < e->n; ++k) {
+      const double* O = e->omega + (size_t)k * d * d;
+      const double* r = e->err + (size_t)k * d;
+      double omega_r[8], Ow[64];
+      for (int i = 0; i < d; ++i) { double t = 0; for (int j = 0; j < d; ++j) t += O[i + d * j] * r[j]; omega_r[i] = -t; }   /* - _information * _error */
+      const double* Ouse = O;
+      if (e->delta > 0) {                          /* :38-45 */
+        double c = 0, rho[3];
+        for (int i = 0; i < d; ++i) { double t = 0; for (int j = 0; j < d; ++j) t += O[i + d * j] * r[j]; c += r[i] * t; }
+        robustify(e->kernel_kind > 0 ? e->kernel_kind : 1, e->delta, c, rho);
+        for (int i = 0; i < d; ++i) omega_r[i] *= rho[1];
+        for (int i = 0; i < d * d; ++i) Ow[i] = rho[1] * O[i];
+        Ouse = Ow;
+      }
+      for (int i = 0; i < ar; ++i) {               /* :173-221 */
+        const int a = e->v[(size_t)k * ar + i];
+        if (a < 0) continue;                       /* istatus = !from->fixed() */
+        const int da = vdim(s, a);
+        const double* A = e->J[i] + (size_t)k * d * da;
+        double* bv = s->b + (a < s->nP ? (size_t)a * p : (size_t)s->sizeP + (size_t)(a - s->nP) * l);
+        atob(A, da, Ouse, A, da, d, blkptr(s, e->kdiag[(size_t)k * ar + i], e->odiag[(size_t)k * ar + i]));   /* fromMap += AtO * A */
+        atx(A, d, da, omega_r, bv);                                                                           /* fromB += A' weightedError */
+        for (int j = i + 1; j < ar; ++j) {
+          const int bidx = e->v[(size_t)k * ar + j];
+          if (bidx < 0) continue;                  /* jstatus */
+          const int db = vdim(s, bidx);
+          const double* B = e->J[j] + (size_t)k * d * db;
+          const size_t q = (size_t)k * ORC_MAX_PAIRS + upper_triangle_index(i, j);
+          double* H = blkptr(s, e->koff[q], e->ooff[q]);
+          if (e->troff[q]) atob(B, db, Ouse, A, da, d, H);   /* hhelper.transposed: += B' AtO' */
+          else atob(A, da, Ouse, B, db, d, H);               /* += AtO * B */
+        }
+      }
+    }
+  }
   return 0;
 }
 
@@ -370,6 +500,17 @@ double orc_chi2(Orc* s) {
     for (int k = 0; k < e->n; ++k) {
       double c = edge_chi2(e, k);
       if (e->huber_delta > 0) { double rho[3]; robustify(e->kernel_kind > 0 ? e->kernel_kind : 1, e->huber_delta, c, rho); c = rho[0]; }
+      chi += c;
+    }
+  }
+  for (int si = 0; si < s->nmsets; ++si) {
+    OrcMulti* e = &s->msets[si];
+    const int d = e->d;
+    for (int k = 0; k < e->n; ++k) {
+      const double* O = e->omega + (size_t)k * d * d; const double* r = e->err + (size_t)k * d;
+      double c = 0;
+      for (int i = 0; i < d; ++i) { double t = 0; for (int j = 0; j < d; ++j) t += O[i + d * j] * r[j]; c += r[i] * t; }
+      if (e->delta > 0) { double rho[3]; robustify(e->kernel_kind > 0 ? e->kernel_kind : 1, e->delta, c, rho); c = rho[0]; }
       chi += c;
     }
   }
@@ -795,6 +936,7 @@ double orc_time(Orc* s, int which) { return which == 0 ? s->t_schur : which == 1
 void orc_destroy(Orc* s) {
   if (!s) return;
   for (int si = 0; si < s->nsets; ++si) { OrcSet* e = &s->sets[si]; free(e->v0); free(e->v1); free(e->o00); free(e->o11); free(e->o01); free(e->k00); free(e->k11); free(e->k01); free(e->tr01); }
+  for (int si = 0; si < s->nmsets; ++si) { OrcMulti* e = &s->msets[si]; free(e->v); free(e->odiag); free(e->kdiag); free(e->ooff); free(e->koff); free(e->troff); }
   free(s->pp_colptr); free(s->pp_row); free(s->pp_diag); free(s->Hpp); free(s->pl_colptr); free(s->pl_row); free(s->Hpl); free(s->Hll);
   free(s->hs_colptr); free(s->hs_row); free(s->Hschur); free(s->Dinv); free(s->coeff); free(s->bschur); free(s->x); free(s->b); free(s->bkP); free(s->bkL);
   OrcChol* C = &s->chol;

@@ -67,6 +67,8 @@ def _proto(L):
         L.orc_build_structure.argtypes = [C.c_void_p]
         L.orc_set_edge_data.argtypes = [C.c_void_p, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, C.c_double]
         L.orc_build_system.argtypes = [C.c_void_p]
+        L.orc_add_multi_edge_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int_p]
+        L.orc_set_multi_edge_data.argtypes = [C.c_void_p, C.c_int, C.POINTER(c_dbl_p), c_dbl_p, c_dbl_p, C.c_double, C.c_int]
         L.orc_chi2.restype = C.c_double
         L.orc_chi2.argtypes = [C.c_void_p]
         L.orc_set_robust_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -181,6 +183,21 @@ class OracleSolver:
         J1 = None if J1 is None else _f64(J1)
         self._keep = [k for k in self._keep if k[0] != s] + [(s, J0, J1, omega, err)]
         self.L.orc_set_edge_data(self.h, s, _dp(J0), _dp(J1), _dp(omega), _dp(err), float(huber_delta))
+
+    def add_multi_edge_set(self, d, verts):
+        """n-ary edges (BaseMultiEdge): verts [n][arity] hessian indices (-1 fixed).  Before build_structure."""
+        verts = _i32(verts)
+        m = self.L.orc_add_multi_edge_set(self.h, d, verts.shape[0], verts.shape[1], _ip(verts))
+        assert m >= 0
+        return m
+
+    def set_multi_edge_data(self, m, J, omega, err, delta=0.0, kind=1):
+        """J: one [n][d * dim_i] array (column-major d x dim_i Jacobians) per vertex position."""
+        J = [_f64(j) for j in J]
+        omega, err = _f64(omega), _f64(err)
+        ptrs = (c_dbl_p * len(J))(*[_dp(j) for j in J])
+        self._keep.append(("m%d" % m, J, omega, err, ptrs))
+        self.L.orc_set_multi_edge_data(self.h, m, ptrs, _dp(omega), _dp(err), float(delta), int(kind))
 
     def set_robust_kernel(self, s, kind):
         """1 Huber (default), 2 PseudoHuber, 3 Cauchy, 4 Saturated, 5 DCS; delta = the huber_delta of set_edge_data."""

@@ -86,3 +86,24 @@ def test_graph_with_loop_closures_uses_the_general_kernels():
     o.set_lambda(30.0, True)
     assert ok and o.solve()
     assert relerr(x, o.x()) < dx_tolerance(o)[0]
+
+
+@pytest.mark.parametrize("P,L,huber", [(257, 2600, 0.0), (1500, 15000, 0.0), (4000, 40000, 0.0), (9000, 45000, 1.0)])
+def test_tree_levels_swept_by_groups_of_fronts_equal_the_task_by_task_sweep_bit_for_bit(P, L, huber):
+    """Backward sweep of the tree levels by groups of fronts in one workgroup (tree_backward_kernel, option tree_backward) against
+    the per-task sweep with a hand-off between workgroups per level: the same partial sums in the same order (bw_parts), so the
+    solution is identical bit for bit; against the oracle to the usual tolerance."""
+    pr = ba_case(P, L, outlier_frac=0.05 if huber else 0.0)
+    lam = 25.0
+    ok1, x1, st1 = _solve(pr, lam, {"tree_backward": 1}, huber=huber)
+    ok0, x0, st0 = _solve(pr, lam, {"tree_backward": 0}, huber=huber)
+    assert ok0 and ok1
+    assert st1["numFronts"] == st0["numFronts"]
+    if P >= 1500:
+        assert st1["treeBackwardGroups"] > 0 and st0["treeBackwardGroups"] == 0     # (the kernel under test really ran)
+    assert np.array_equal(x1, x0)
+    o = oracle_ba(pr, huber=huber)
+    o.build_system()
+    o.set_lambda(lam, True)
+    assert o.solve()
+    assert relerr(x1, o.x()) < (dx_tolerance(o)[0] if P <= 300 else 1e-7)

@@ -221,6 +221,41 @@ def test_the_class_table_owns_the_kernels_and_needs_the_fused_path():
     assert np.array_equal(sa.x(), sb.x())
 
 
+def test_binding_refuses_what_the_fused_kernels_would_ignore_and_a_refused_binding_changes_nothing():
+    """Per-edge robust kernels (g2ohip_set_robust_kernel_per_edge) are read by the generic kernels only: a set that carries them is
+    refused by the BA front end instead of being assembled with the set-level kernel while chi2 still weighs per edge.  A class
+    with a robust kernel needs a positive delta.  A refused call leaves the set's own kernel and the bound front end alone."""
+    pr = ba_case(20, 100, outlier_frac=0.05)
+    s = capi.HipBlockSolver(6, 3, 0)
+    k = s.addEdgeSet(2, pr["v0"], pr["v1"])
+    s.buildStructure(pr["nP"], pr["nL"], True)
+    s.setRobustKernelPerEdge(k, np.ones(pr["E"], dtype=np.int32), np.full(pr["E"], 1.0))
+    with pytest.raises(capi.G2oHipError):
+        s.baSetEdges(k, pr["cam_idx"], pr["pt_idx"], pr["meas"], None, pr["f"], pr["cx"], pr["cy"])
+    s.setRobustKernelPerEdge(k, None, None)
+    s.baSetEdges(k, pr["cam_idx"], pr["pt_idx"], pr["meas"], None, pr["f"], pr["cx"], pr["cy"])
+    s.baSetEstimates(pr["cams"], pr["cam_hidx"], pr["pts"], np.arange(pr["L"], dtype=np.int32))
+    s.setRobustKernel(k, capi.KERNEL_HUBER, 1.0)
+    g = lm.DeviceBAGraph(s)
+    g.compute_active_errors()
+    chi_huber = g.chi2()
+    # a Huber class without a delta, then a class outside the table: refused, and the Huber kernel of the set is still in force
+    zero_delta = np.array([[pr["f"], pr["cx"], pr["cy"], 0, 0.0], [pr["f"], pr["cx"], pr["cy"], 1, 0.0]])
+    cls = (np.arange(pr["E"]) % 2).astype(np.int32)
+    with pytest.raises(capi.G2oHipError):
+        s.baSetEdgesClasses(k, pr["cam_idx"], pr["pt_idx"], pr["meas"], zero_delta, cls)
+    two = np.array([[pr["f"], pr["cx"], pr["cy"], 0, 0.0], [pr["f"], pr["cx"], pr["cy"], 3, 2.0]])
+    bad = cls.copy()
+    bad[7] = 2
+    with pytest.raises(capi.G2oHipError):
+        s.baSetEdgesClasses(k, pr["cam_idx"], pr["pt_idx"], pr["meas"], two, bad)
+    g.compute_active_errors()
+    assert g.chi2() == chi_huber
+    ref, gref = lm.setup_device_ba(pr, huber_delta=1.0)
+    gref.compute_active_errors()
+    assert gref.chi2() == chi_huber
+
+
 def test_lm_trajectory_with_edge_classes_matches_the_oracle():
     """Levenberg-Marquardt (optimization_algorithm_levenberg.cpp:57-172) over the mixed graph, everything on the device, against
     the same loop on the oracle: chi2 per iteration, lambda sequence, trials per iteration."""

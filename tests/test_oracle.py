@@ -245,3 +245,44 @@ def test_ba_projection_jacobian_against_central_differences():
         Rk = E[:3, :3] @ R[k]
         tk = E[:3, :3] @ t[k] + E[:3, 3]
         assert np.abs(cams2[k, :9].reshape(3, 3).T - Rk).max() < 1e-12 and np.abs(cams2[k, 9:] - tk).max() < 1e-12
+
+
+@pytest.mark.parametrize("huber", [0.0, 0.8])
+@pytest.mark.parametrize("with_landmark", [False, True])
+def test_n_ary_edges_of_the_oracle_equal_the_dense_quadratic_form(huber, with_landmark):
+    """BaseMultiEdge::constructQuadraticForm as the oracle restates it (orc_add_multi_edge_set: the computeUpperTriangleIndex
+    block table and the transposed helper blocks of base_multi_edge.hpp:128-222 over block_solver.hpp:208-251) against a dense
+    NumPy assembly of the same quadratic form: H through every stored block, b, chi2 and the solution."""
+    from tests.test_gpu_multi_edge import _dense, oracle_ternary, ternary_problem
+    T = ternary_problem(with_landmark)
+    o = oracle_ternary(T, huber)
+    o.build_system()
+    n_tot = int(T["dims"].sum())
+    H, b, chi = _dense(n_tot, T["dims"], T["offs"], T["v"], T["J"], T["omega"], T["err"], huber)
+    H += 2.0 * np.eye(n_tot)
+    assert abs(o.chi2() - chi) <= 1e-12 * chi
+    assert np.abs(o.b() - b).max() <= 1e-12 * np.abs(b).max()
+    p, l, nP, nL = T["p"], T["l"], T["nP"], T["nL"]
+    Ho = np.zeros_like(H)
+    cp, ri = o.pattern("pp")
+    V = o.values("Hpp").reshape(-1, p, p)
+    for c in range(nP):
+        for q in range(cp[c], cp[c + 1]):
+            r = ri[q]
+            Ho[r * p:(r + 1) * p, c * p:(c + 1) * p] = V[q].T            # (column-major blocks)
+            Ho[c * p:(c + 1) * p, r * p:(r + 1) * p] = V[q]
+    if nL:
+        cp, ri = o.pattern("pl")
+        V = o.values("Hpl").reshape(-1, l, p)
+        D = o.values("Hll").reshape(-1, l, l)
+        for c in range(nL):
+            a = nP * p + c * l
+            Ho[a:a + l, a:a + l] = D[c].T
+            for q in range(cp[c], cp[c + 1]):
+                r = ri[q]
+                Ho[r * p:(r + 1) * p, a:a + l] = V[q].T
+                Ho[a:a + l, r * p:(r + 1) * p] = V[q]
+    assert np.abs(Ho - H).max() <= 1e-12 * np.abs(H).max()
+    assert o.solve()
+    xs = np.linalg.solve(H, b)
+    assert np.abs(o.x() - xs).max() <= 1e-9 * np.abs(xs).max()
