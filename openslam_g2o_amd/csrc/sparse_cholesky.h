@@ -75,7 +75,8 @@ struct CholOptions {
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
   int band_kernel = 1;                   // leaf chains of a band (+ one dense border) on the sliding-window kernel (band_chain.inc)
   int tree_backward = 1;                 // backward sweep of the tree levels of a dependency-driven group by GROUPS of fronts: one sixteen-wave workgroup
-                                         // per subtree of up to sixteen small fronts, hand-offs inside a group through LDS (tree_backward_kernel)
+                                         // per subtree of up to sixteen small fronts, hand-offs inside a group through LDS (tree_backward_kernel); 2: also
+                                         // the leaf chains below them by one wave per chain (chain_backward_kernel: measured slower, see there); 0: task by task
 };
 
 struct CholStats {
@@ -147,6 +148,7 @@ struct BandChainRec {
 };
 // tree_backward_kernel: the fronts it takes (pivot columns, boundary rows: scalars) and the fronts (waves) of a group
 constexpr int kTreePiv = 24, kTreeBnd = 48, kTreeWaves = 16;
+constexpr int kChainCap = 1536;   // chain_backward_kernel: pivot scalars of a leaf chain kept in LDS (12 KB)
 constexpr int kBandFrontInts = 17;   // first pivot block, pivot scalars, L offset (2), m, local row of band blocks +0..+7, of border blocks 0..3
 
 struct CholPlanDev {
@@ -332,6 +334,7 @@ class SparseCholesky {
   struct FactorGroup {
     LevelLaunch LL; int first_level, last_level; bool dep; int band_count = 0, band_rec0 = 0, band_ent_cap = 0, band_tab_cap = 0;
     int tb_grp0 = 0, tb_ngrp = 0, tb_low = 0;   // tree_backward: its groups (d_tb_grec), the launch slots (lowest levels) left to the per-task kernel
+    int tb_chain_cap = 0;                       // > 0: those slots are leaf chains swept by chain_backward_kernel (one wave each); the most pivot scalars of a chain
   };
   std::vector<FactorGroup> groups_[2];     // factorisation launches: runs of levels (dep: one launch, in-kernel dependencies)
   DevBuf<int> d_ready;

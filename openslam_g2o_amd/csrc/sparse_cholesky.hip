@@ -1672,6 +1672,42 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         }
         G.tb_ngrp = (int)grec.size() - G.tb_grp0;
         for (int l = G.first_level; l < lc; ++l) G.tb_low += launches_[ph][l].lds_count;
+        // the leaf level below the tree levels on chain_backward_kernel: ONE level (every front above a chain is in the tree
+        // launch or in an earlier one), small fronts only, the chain's pivots within the LDS budget
+        G.tb_chain_cap = 0;
+        if (opt.tree_backward == 2 && lc == G.first_level + 1) {
+          const LevelLaunch& N = launches_[ph][G.first_level];
+          int cap = 0;
+          bool ok = N.lds_count > 0;
+          for (int q = N.lds_begin; q < N.lds_begin + N.lds_count && ok; ++q) {
+            const int t = S.level_fronts[q];
+            int sum = 0;
+            for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
+              ok = ok && small(S.task_fronts[k]);
+              sum += S.f_ns[S.task_fronts[k]] * bs;
+            }
+            cap = std::max(cap, sum);
+          }
+          if (ok && cap <= kChainCap) G.tb_chain_cap = cap;
+        }
+        if (G.tb_chain_cap > 0) {   // where the boundary values of a chain's fronts come from: the chain's own pivots (LDS, top front first) or memory
+          const LevelLaunch& N = launches_[ph][G.first_level];
+          for (int q = N.lds_begin; q < N.lds_begin + N.lds_count; ++q) {
+            const int t = S.level_fronts[q];
+            std::vector<std::pair<int, int>> own;   // (front, offset of its pivots)
+            int xoff = 0;
+            for (int k = S.task_ptr[t + 1] - 1; k >= S.task_ptr[t]; --k) {
+              const int f2 = S.task_fronts[k];
+              for (int j = 0; j < S.f_nb[f2]; ++j) {
+                const int r = S.rows[S.rows_off[f2] + j], o = sn_of[r];
+                for (const auto& pr : own)
+                  if (pr.first == o) grows[S.rows_off[f2] + j] = -1 - (pr.second + (r - S.sn_start[o]) * bs);
+              }
+              own.emplace_back(f2, xoff);
+              xoff += S.f_ns[f2] * bs;
+            }
+          }
+        }
         // what a front releases: the groups rooted below it and the tasks of the per-task launch that wait for it; where the
         // boundary values of a front come from
         std::vector<int> rel(nf, 0);
@@ -1683,7 +1719,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           } else {
             const int t = task_of[f2];
             const bool top = S.task_fronts[S.task_ptr[t + 1] - 1] == f2;
-            if (top && task_level[t] >= G.first_level && task_level[t] < lc && (recs[f2].pad[0] & 2)) ++rel[pf];
+            // (the chains of chain_backward_kernel start behind the tree launch: they wait for nothing)
+            if (G.tb_chain_cap == 0 && top && task_level[t] >= G.first_level && task_level[t] < lc && (recs[f2].pad[0] & 2)) ++rel[pf];
           }
         }
         for (int e = grec[G.tb_grp0].x; e < (int)gfr.size(); ++e) {
@@ -1695,9 +1732,24 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
             if (grp_of[o] == grp_of[f2]) grows[S.rows_off[f2] + j] = -1 - (pos_of[o] * kTreePiv + (r - S.sn_start[o]) * bs);
           }
         }
-        if (getenv("G2OHIP_PLAN_DUMP"))
+        if (getenv("G2OHIP_PLAN_DUMP")) {
           fprintf(stderr, "phase %d tree backward: levels %d..%d in %d groups (%d fronts), %d slots left to the per-task kernel\n", ph, lc, G.last_level,
                   G.tb_ngrp, (int)gfr.size() - grec[G.tb_grp0].x, G.tb_low);
+          int mx = 0;
+          long long tot = 0, cnt = 0;
+          std::vector<int> hist(8, 0);
+          for (int l = G.first_level; l < lc; ++l)
+            for (int q = launches_[ph][l].lds_begin; q < launches_[ph][l].lds_begin + launches_[ph][l].lds_count; ++q) {
+              const int t = S.level_fronts[q], n = S.task_ptr[t + 1] - S.task_ptr[t];
+              mx = std::max(mx, n);
+              tot += n;
+              ++cnt;
+              ++hist[std::min(7, n / 8)];
+            }
+          fprintf(stderr, "  tasks below: %lld, fronts per task avg %.1f max %d; by length /8:", cnt, cnt ? (double)tot / cnt : 0.0, mx);
+          for (int v : hist) fprintf(stderr, " %d", v);
+          fprintf(stderr, "\n");
+        }
       }
     stats_.n_tree_groups = grec.size();
     if (grec.empty()) grec.push_back(make_int4(0, 0, 0, -1));
@@ -3723,6 +3775,90 @@ __global__ void __launch_bounds__(256) front_backward_kernel(CholPlanDev P, int 
 struct TreeGroupRec {
   int first, count, nlev, wait_front;   // entries of the group in the front list; levels; front above the root to wait for (-1: none)
 };
+// A small front's panel in one wave's registers: lane (k, h) = (lane >> 1, lane & 1) holds of column k the rows of parity h below
+// the pivot block (L21[j]: row npiv + h + 2 j) and the whole pivot-block column (L11[q]: row q), the reciprocal diagonal, y.
+template <int BS>
+struct TreePanel {
+  static constexpr int JH = kTreeBnd / 2, NSMAX = kTreePiv / BS;
+  double L21[JH], L11[kTreePiv], linv, yk;
+  int ns, npiv, nbs, m, c0;
+};
+template <int BS>
+__device__ __forceinline__ void tree_panel_load(const CholPlanDev& P, const FrontRec& rec, const double* __restrict__ y, int lane, TreePanel<BS>& T) {
+  T.ns = rec.ns;
+  T.npiv = rec.ns * BS;
+  T.nbs = rec.nb * BS;
+  T.m = T.npiv + T.nbs;
+  T.c0 = rec.c0;
+  const int k = lane >> 1, h = lane & 1, m = T.m, npiv = T.npiv;
+  const bool col = k < npiv;
+  const double* Lg = P.L + rec.L_off;
+  const double* Lk = Lg + (size_t)m * (col ? k : 0);
+#pragma unroll
+  for (int j = 0; j < TreePanel<BS>::JH; ++j) {
+    const int i = npiv + h + 2 * j;
+    const double v = Lk[min(i, m - 1)];
+    T.L21[j] = (col && i < m) ? v : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < kTreePiv; ++q) {
+    const double v = Lk[min(q, m - 1)];
+    T.L11[q] = (col && q < npiv) ? v : 0.0;
+  }
+  T.linv = col ? Lg[(size_t)m * npiv + k] : 0.0;
+  T.yk = col ? y[(size_t)rec.c0 * BS + k] : 0.0;
+}
+// x1 = L11' \ (y1 - L21' t) with the boundary values t[0 .. 48) in LDS (written by this wave): the pivot solution of column k in
+// the lanes (k, *).  The sums and their order are front_backward_kernel's (parts = bw_parts of its workgroup size).
+template <int BS>
+__device__ __forceinline__ double tree_front_solve(const TreePanel<BS>& T, const double* tw, int lane, int parts) {
+  constexpr int JH = TreePanel<BS>::JH, NSMAX = TreePanel<BS>::NSMAX;
+  const int k = lane >> 1, h = lane & 1;
+  double sa = 0.0, sb = 0.0;
+  if (parts == 4) {   // part p of front_backward_kernel = rows p, p + 4, ...: the even / odd registers of lane (k, p & 1)
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+      const double tv = tw[h + 2 * j];
+      if (j & 1) sb = fma(T.L21[j], tv, sb);
+      else sa = fma(T.L21[j], tv, sa);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < JH; ++j) sa = fma(T.L21[j], tw[h + 2 * j], sa);
+  }
+  const double oa = __shfl_xor(sa, 1), ob = __shfl_xor(sb, 1);
+  double a = 0.0;
+  a += sa;
+  a += oa;
+  if (parts == 4) {
+    a += sb;
+    a += ob;
+  }
+  double z = T.yk - a, xout = 0.0;
+#pragma unroll
+  for (int kb = NSMAX - 1; kb >= 0; --kb) {
+    if (kb < T.ns) {
+      const int k0 = kb * BS;
+      double xs[BS];
+#pragma unroll
+      for (int c = BS - 1; c >= 0; --c) {
+        double v = z;
+#pragma unroll
+        for (int q = c + 1; q < BS; ++q) v = fma(-T.L11[k0 + q], xs[q], v);
+        const double xc = v * T.linv;
+        xs[c] = readlane_f64(xc, 2 * (k0 + c));
+        if (k == k0 + c) xout = xc;
+      }
+      double zz = z;
+#pragma unroll
+      for (int q = 0; q < BS; ++q) zz = fma(-T.L11[k0 + q], xs[q], zz);
+      z = k < k0 ? zz : z;
+    }
+  }
+  return xout;
+}
+// (the body below is tree_panel_load + tree_front_solve written out: as calls the compiler spills 65 registers at the 128 this
+// sixteen-wave workgroup may use per lane)
 template <int BS>
 __global__ void __launch_bounds__(kTreeWaves * 64) tree_backward_kernel(CholPlanDev P, const TreeGroupRec* __restrict__ groups,
                                                                        const int2* __restrict__ gfront, const int* __restrict__ grows,
@@ -3832,6 +3968,128 @@ __global__ void __launch_bounds__(kTreeWaves * 64) tree_backward_kernel(CholPlan
       }
     }
     __syncthreads();
+  }
+}
+
+// The LEAF chains below the tree levels (option tree_backward = 2; launched behind tree_backward_kernel: every front above a
+// chain is done): ONE wave per chain walks its fronts top down with the same register panel and the same sums; the pivot
+// solutions of the chain stay in LDS for the fronts below, the values from the fronts above the chain are plain loads.
+// The panel of a front is contiguous in memory (m x npiv column-major + the reciprocal diagonal): it is requested as a LINEAR
+// copy (64 consecutive doubles per instruction) one front AHEAD, written to LDS with the column stride padded to an odd
+// number, and the lanes take their column / parity layout from there -- read straight from memory in that layout (a stride of
+// m doubles between lanes) every 64-byte line came through the 32 KB L1 eight times with eight waves per CU streaming 14 KB
+// panels through it: 160 us for the 2 048 chains of the metric configuration against 97 us for the per-task kernel.  The
+// index table and the boundary values of a front are requested one / two fronts ahead as well (a dependent pair of loads).
+struct ChainMini {   // what the sweep needs of a FrontRec (scalar loads: 6 registers instead of 32 per record in flight)
+  int ns, nb, c0, rows_off;
+  long long L_off;
+};
+__device__ __forceinline__ ChainMini load_chain_mini(const FrontRec* p) {
+  const __attribute__((address_space(4))) int* rp = (const __attribute__((address_space(4))) int*)reinterpret_cast<uintptr_t>(p);
+  ChainMini r;
+  r.ns = rp[offsetof(FrontRec, ns) / 4];
+  r.nb = rp[offsetof(FrontRec, nb) / 4];
+  r.c0 = rp[offsetof(FrontRec, c0) / 4];
+  r.rows_off = rp[offsetof(FrontRec, rows_off) / 4];
+  const unsigned int lo = (unsigned int)rp[offsetof(FrontRec, L_off) / 4], hi = (unsigned int)rp[offsetof(FrontRec, L_off) / 4 + 1];
+  r.L_off = (long long)(((unsigned long long)hi << 32) | lo);
+  return r;
+}
+template <int BS>
+__global__ void __launch_bounds__(64) chain_backward_kernel(CholPlanDev P, const int2* __restrict__ chains, const int* __restrict__ grows,
+                                                           const double* __restrict__ y, double* __restrict__ xp, int nt_ref) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int MP = kTreePiv + kTreeBnd + 1;                                   // padded column stride of the staged panel
+  constexpr int NPRE = ((kTreePiv + kTreeBnd) * kTreePiv + kTreePiv + 63) / 64;   // doubles per lane of a linear panel copy
+  constexpr int JH = TreePanel<BS>::JH;
+  double* tw = smem;                              // boundary values of the current front
+  double* pan = smem + kTreeBnd;                  // the current front's panel, column c at c * MP (column npiv: the reciprocal diagonal)
+  double* xs = pan + (kTreePiv + 1) * MP;         // pivot solutions of the chain so far, top front first
+  const int2 ch = chains[blockIdx.x];
+  const int f_first = __builtin_amdgcn_readfirstlane(ch.x), nfr = __builtin_amdgcn_readfirstlane(ch.y);
+  const int lane = threadIdx.x;
+  const int k = lane >> 1, h = lane & 1, off = lane % BS, blk = lane / BS;
+  double pre[NPRE];
+  auto request_panel = [&](const ChainMini& r) {
+    const int m = (r.ns + r.nb) * BS, tot = m * r.ns * BS + r.ns * BS;
+    const double* Lg = P.L + r.L_off;
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) pre[u] = Lg[min(lane + 64 * u, tot - 1)];
+  };
+  int ti = nfr - 1;
+  ChainMini r0 = load_chain_mini(P.rec + f_first + ti);
+  ChainMini r1 = load_chain_mini(P.rec + f_first + max(ti - 1, 0));
+  request_panel(r0);
+  double yk0 = k < r0.ns * BS ? y[(size_t)r0.c0 * BS + k] : 0.0;
+  int src0 = lane < r0.nb * BS ? grows[r0.rows_off + blk] : 0;                   // >= 0: block row in memory, < 0: -1 - (offset in xs)
+  int src1 = lane < r1.nb * BS ? grows[r1.rows_off + blk] : 0;
+  double xb0 = (lane < r0.nb * BS && src0 >= 0) ? xp[(size_t)src0 * BS + off] : 0.0;
+  int xoff = 0;
+  for (; ti >= 0; --ti) {
+    TreePanel<BS> T;
+    T.ns = r0.ns;
+    T.npiv = r0.ns * BS;
+    T.nbs = r0.nb * BS;
+    T.m = T.npiv + T.nbs;
+    T.c0 = r0.c0;
+    const int m = T.m, npiv = T.npiv, tot = m * npiv + npiv;
+    {   // the linear copy into the padded layout: element e = column e / m, row e % m
+      int col = lane / m, row = lane - col * m;
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        if (lane + 64 * u < tot) pan[col * MP + row] = pre[u];
+        row += 64;
+        while (row >= m) {
+          row -= m;
+          ++col;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // the next front's panel, right-hand side and boundary values; the index table of the one after it
+    ChainMini r2 = r1;
+    double yk1 = 0.0, xb1 = 0.0;
+    int src2 = 0;
+    if (ti > 0) {
+      request_panel(r1);
+      yk1 = k < r1.ns * BS ? y[(size_t)r1.c0 * BS + k] : 0.0;
+      xb1 = (lane < r1.nb * BS && src1 >= 0) ? xp[(size_t)src1 * BS + off] : 0.0;
+      r2 = load_chain_mini(P.rec + f_first + max(ti - 2, 0));
+      src2 = lane < r2.nb * BS ? grows[r2.rows_off + blk] : 0;
+    }
+    const bool colk = k < npiv;
+    const double* pk = pan + (colk ? k : 0) * MP;
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+      const int i = npiv + h + 2 * j;
+      const double v = pk[min(i, m - 1)];
+      T.L21[j] = (colk && i < m) ? v : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < kTreePiv; ++q) {
+      const double v = pk[min(q, m - 1)];
+      T.L11[q] = (colk && q < npiv) ? v : 0.0;
+    }
+    T.linv = colk ? pan[npiv * MP + k] : 0.0;
+    T.yk = yk0;
+    if (lane < kTreeBnd) tw[lane] = lane < T.nbs ? (src0 < 0 ? xs[-1 - src0 + off] : xb0) : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double xout = tree_front_solve<BS>(T, tw, lane, bw_parts(nt_ref, max(npiv, 1), m));
+    if (colk && h == 0) {
+      xs[xoff + k] = xout;
+      xp[(size_t)T.c0 * BS + k] = xout;
+    }
+    xoff += npiv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    r0 = r1;
+    r1 = r2;
+    yk0 = yk1;
+    xb0 = xb1;
+    src0 = src1;
+    src1 = src2;
   }
 }
 
@@ -5164,7 +5422,22 @@ void SparseCholesky::solve_backward_phase(int phase, hipStream_t st) {
         }
 #undef G2OHIP_TREE_BACKWARD
         G2OHIP_LAUNCH_CHECK("tree_backward_kernel");
-        if (G.tb_low > 0) launch_solve(G.LL, false, st, false, true, false, G.tb_low);
+        if (G.tb_low > 0 && G.tb_chain_cap > 0) {
+          const int2* chains = d_bslots.p + (n_slots_ - (G.LL.lds_begin + G.LL.lds_count)) + (G.LL.lds_count - G.tb_low);   // (the last slots of the reversed list)
+          const size_t sh = (size_t)(kTreeBnd + (kTreePiv + 1) * (kTreePiv + kTreeBnd + 1) + G.tb_chain_cap) * sizeof(double);
+#define G2OHIP_CHAIN_BACKWARD(BS_) \
+  hipLaunchKernelGGL((chain_backward_kernel<BS_>), dim3(G.tb_low), dim3(64), sh, st, plan_, chains, d_tb_rows.p, d_y.p, d_xp.p, nt_ref)
+          switch (bs_) {
+            case 3: G2OHIP_CHAIN_BACKWARD(3); break;
+            case 6: G2OHIP_CHAIN_BACKWARD(6); break;
+            case 7: G2OHIP_CHAIN_BACKWARD(7); break;
+            default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
+          }
+#undef G2OHIP_CHAIN_BACKWARD
+          G2OHIP_LAUNCH_CHECK("chain_backward_kernel");
+        } else if (G.tb_low > 0) {
+          launch_solve(G.LL, false, st, false, true, false, G.tb_low);
+        }
       } else {
         launch_solve(G.LL, false, st, false, true);
       }

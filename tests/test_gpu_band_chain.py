@@ -95,13 +95,14 @@ def test_tree_levels_swept_by_groups_of_fronts_equal_the_task_by_task_sweep_bit_
     solution is identical bit for bit; against the oracle to the usual tolerance."""
     pr = ba_case(P, L, outlier_frac=0.05 if huber else 0.0)
     lam = 25.0
-    ok1, x1, st1 = _solve(pr, lam, {"tree_backward": 1}, huber=huber)
+    ok1, x1, st1 = _solve(pr, lam, {"tree_backward": 1}, huber=huber)     # tree levels by groups, leaf chains task by task (the default)
+    ok2, x2, st2 = _solve(pr, lam, {"tree_backward": 2}, huber=huber)     # ... leaf chains one wave each
     ok0, x0, st0 = _solve(pr, lam, {"tree_backward": 0}, huber=huber)
-    assert ok0 and ok1
+    assert ok0 and ok1 and ok2
     assert st1["numFronts"] == st0["numFronts"]
     if P >= 1500:
-        assert st1["treeBackwardGroups"] > 0 and st0["treeBackwardGroups"] == 0     # (the kernel under test really ran)
-    assert np.array_equal(x1, x0)
+        assert st1["treeBackwardGroups"] > 0 and st2["treeBackwardGroups"] > 0 and st0["treeBackwardGroups"] == 0     # (the kernels under test really ran)
+    assert np.array_equal(x1, x0) and np.array_equal(x2, x0)
     o = oracle_ba(pr, huber=huber)
     o.build_system()
     o.set_lambda(lam, True)

@@ -3,7 +3,7 @@
 OUT=gpurun_out/r5_paths.jsonl
 : > $OUT
 python tools/paths_bench.py >> $OUT 2> gpurun_out/r5_paths.err
-for variant in "--edge-data arrays" "--information edge" "--edge-data arrays --information edge" ""; do
+for variant in "--edge-data arrays --no-cpu-baseline" "--information edge" "--edge-data arrays --information edge --no-cpu-baseline" ""; do
   python bench.py --steps 20 --warmup 5 $variant 2>> gpurun_out/r5_paths.err | python -c "
 import json, sys
 d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
