@@ -406,6 +406,15 @@ int g2ohip_ba_set_edges_classes(g2ohip_solver* s, int set, const int32_t* cam_ve
 int g2ohip_ba_set_estimates(g2ohip_solver* s, int n_cams, const double* cams, const int32_t* cam_hidx, int n_points,
                             const double* points, const int32_t* point_hidx);
 int g2ohip_ba_get_estimates(g2ohip_solver* s, double* cams, double* points);
+/* The same read-back (what SparseOptimizer::update leaves in the vertices, sparse_optimizer.cpp:422-432, fetched for the caller's
+ * setEstimate loop) started ASYNCHRONOUSLY behind everything queued so far -- typically right after g2ohip_ba_update of an LM
+ * trial -- on a copy stream of the library, in pieces: piece 0 = the cameras, pieces 1 .. point_pieces (<= 16) = the points in
+ * equal ranges.  g2ohip_ba_fetch_estimates_wait(piece) returns once that piece is in the caller's buffer (page-locked buffers,
+ * g2ohip_host_register, make the copy truly asynchronous): the caller writes piece k into its vertices while piece k + 1 is
+ * still in flight and the device evaluates the trial's errors.  The buffers must stay untouched until the last piece has been
+ * waited for or the next g2ohip_ba_set_estimates; device-side writers of the estimates (update, pop) wait for the copy themselves. */
+int g2ohip_ba_fetch_estimates_begin(g2ohip_solver* s, double* cams, double* points, int point_pieces);
+int g2ohip_ba_fetch_estimates_wait(g2ohip_solver* s, int piece);
 /* computeActiveErrors() (+ linearizeOplus() when jacobians != 0) into the set's edge data
  * (sparse_optimizer.cpp:61-76, types_six_dof_expmap.cpp:288-326). */
 int g2ohip_ba_linearize(g2ohip_solver* s, int jacobians);

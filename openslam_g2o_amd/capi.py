@@ -52,7 +52,7 @@ EXPORTS = [
     "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute", "g2ohip_ls_create",
     "g2ohip_ls_destroy", "g2ohip_ls_init", "g2ohip_ls_solve", "g2ohip_ls_solve_pattern", "g2ohip_ls_get_stats", "g2ohip_ls_set_option",
     "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time", "g2ohip_add_schur_pattern", "g2ohip_set_edge_set_parts",
-    "g2ohip_set_lambda_split", "g2ohip_host_register", "g2ohip_host_unregister", "g2ohip_ba_set_edges", "g2ohip_ba_set_edges_classes", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates",
+    "g2ohip_set_lambda_split", "g2ohip_host_register", "g2ohip_host_unregister", "g2ohip_ba_set_edges", "g2ohip_ba_set_edges_classes", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates", "g2ohip_ba_fetch_estimates_begin", "g2ohip_ba_fetch_estimates_wait",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
     "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
     "g2ohip_schur_operator_prepare", "g2ohip_schur_operator_apply", "g2ohip_solve_async", "g2ohip_trial_stats", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
@@ -146,6 +146,8 @@ def load():
     L.g2ohip_ba_set_edges_classes.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, c_int_p]
     L.g2ohip_ba_set_estimates.argtypes = [vp, C.c_int, c_dbl_p, c_int_p, C.c_int, c_dbl_p, c_int_p]
     L.g2ohip_ba_get_estimates.argtypes = [vp, c_dbl_p, c_dbl_p]
+    L.g2ohip_ba_fetch_estimates_begin.argtypes = [vp, c_dbl_p, c_dbl_p, C.c_int]
+    L.g2ohip_ba_fetch_estimates_wait.argtypes = [vp, C.c_int]
     L.g2ohip_ba_linearize.argtypes = [vp, C.c_int]
     for n in ("g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top", "g2ohip_pg_update", "g2ohip_pg_push",
               "g2ohip_pg_pop", "g2ohip_pg_discard_top"):
@@ -579,6 +581,16 @@ class HipBlockSolver:
         pts = np.empty((self._ba_n[1], 3))
         _check(self.L.g2ohip_ba_get_estimates(self.h, _dp(cams), _dp(pts)), "baGetEstimates")
         return cams, pts
+
+    def baFetchEstimatesBegin(self, pieces=4):
+        """Asynchronous read-back of the estimates in 1 + pieces pieces (cameras, then point ranges); baFetchEstimatesWait(k)
+        returns the arrays once piece k has arrived (the arrays are complete after the last piece)."""
+        self._fetch = (np.empty((self._ba_n[0], 12)), np.empty((self._ba_n[1], 3)), pieces)
+        _check(self.L.g2ohip_ba_fetch_estimates_begin(self.h, _dp(self._fetch[0]), _dp(self._fetch[1]), pieces), "baFetchEstimatesBegin")
+
+    def baFetchEstimatesWait(self, piece):
+        _check(self.L.g2ohip_ba_fetch_estimates_wait(self.h, piece), "baFetchEstimatesWait")
+        return self._fetch[0], self._fetch[1]
 
     def baLinearize(self, jacobians=True):
         _check(self.L.g2ohip_ba_linearize(self.h, int(jacobians)), "baLinearize")

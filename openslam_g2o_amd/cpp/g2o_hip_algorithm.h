@@ -57,7 +57,7 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
  public:
   explicit OptimizationAlgorithmLevenbergHip(Solver* solver)
       : OptimizationAlgorithmLevenberg(solver), _dev(dynamic_cast<HipDeviceGraph*>(solver)), _resident(false),
-        _writeBack(!hip_detail::envOff("G2OHIP_ADAPTER_WRITEBACK")) {}
+        _writeBack(!hip_detail::envOff("G2OHIP_ADAPTER_WRITEBACK")), _fetched(false), _accepted(false) {}
 
   //! did the last solve() run on the device?
   bool deviceLoopActive() const { return _resident; }
@@ -104,7 +104,13 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
     double rho = 0;
     int& qmax = _levenbergIterations;
     qmax = 0;
+    _fetched = false;
+    _accepted = false;
     do {
+      if (_fetched) {                                    // (the read-back of a rejected trial: its buffers are about to be reused)
+        _dev->devFetchCancel();
+        _fetched = false;
+      }
       if (!_dev->devPush()) return OptimizationAlgorithm::Fail;
       if (globalStats) {
         globalStats->levenbergIterations++;
@@ -115,10 +121,15 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
       double scale = 0.;
       int ok2 = -1;
       if (_dev->devSolveAsync() && _dev->devUpdate()) {
+        // the trial's estimates start their way to the host next to its error evaluation (written into the vertices by
+        // finish() if the trial is accepted)
+        if (_writeBack) _fetched = _dev->devFetchBegin();
         _solver->restoreDiagonal();
         if (_dev->devLinearize(false)) ok2 = _dev->devTrialStats(_currentLambda, tempChi, scale);
       }
       if (ok2 == 2) {                                    // (a dependency-driven launch gave up waiting: the trial again, synchronously)
+        if (_fetched) _dev->devFetchCancel();
+        _fetched = false;
         if (!_dev->devPop() || !_dev->devPush()) return OptimizationAlgorithm::Fail;
         _solver->setLambda(_currentLambda, true);
         ok2 = _dev->devSolve();
@@ -152,6 +163,7 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
         _currentLambda *= scaleFactor;
         _ni = 2;
         currentChi = tempChi;
+        _accepted = true;
         if (!_dev->devDiscardTop()) return OptimizationAlgorithm::Fail;
       } else {
         _currentLambda *= _ni;
@@ -168,14 +180,20 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
 
  private:
   // the accepted estimates into the vertices (what SparseOptimizer::update / pop left there in the host loop)
+  // (the loop ends with an accepted trial or with the estimates popped back to what the vertices already hold: only an accepted
+  // trial has anything to write; its read-back has been in flight since its update)
   bool finish(G2OBatchStatistics* globalStats) {
     const double t = get_monotonic_time();
-    const bool ok = !_writeBack || _dev->devGetEstimates();
+    bool ok = true;
+    if (_fetched && !_accepted) _dev->devFetchCancel();
+    else if (_writeBack && _accepted) ok = _fetched ? _dev->devFetchEnd() : _dev->devGetEstimates();
+    _fetched = false;
     if (globalStats) globalStats->timeUpdate = get_monotonic_time() - t;
     return ok;
   }
   HipDeviceGraph* _dev;
   bool _resident, _writeBack;
+  bool _fetched, _accepted;   // the current trial's estimates are on their way to the host; a trial of this iteration was accepted
 };
 
 class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNewton {
@@ -221,7 +239,7 @@ class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNew
     // (the host loop applies x() even after a failed solve and then reports Fail, gauss_newton.cpp:86-92; the increment of a
     // factorisation that broke down is not applied here)
     if (ok == 1 && !_dev->devUpdate()) return OptimizationAlgorithm::Fail;
-    if (ok == 1 && _writeBack && !_dev->devGetEstimates()) return OptimizationAlgorithm::Fail;
+    if (ok == 1 && _writeBack && !(_dev->devFetchBegin() ? _dev->devFetchEnd() : _dev->devGetEstimates())) return OptimizationAlgorithm::Fail;
     if (globalStats) globalStats->timeUpdate = get_monotonic_time() - t;
     return ok == 1 ? OK : Fail;
   }

@@ -126,6 +126,9 @@ class BlockSolver {
                             double cx, double cy, int n_classes, const double* class_params, const int* edge_class);
   void ba_set_estimates(int n_cams, const double* cams, const int* cam_hidx, int n_points, const double* points, const int* point_hidx);
   void ba_get_estimates(double* cams, double* points);
+  void ba_fetch_begin(double* cams, double* points, int point_pieces);   // the same, asynchronous and in pieces (see the definition)
+  void ba_fetch_wait(int piece);
+  static constexpr int kFetchMaxPieces = 17;
   void ba_linearize(bool jacobians);
   void ba_update();
   void ba_push();
@@ -272,6 +275,10 @@ class BlockSolver {
  private:
   hipStream_t side_ = nullptr;
   hipEvent_t side_fork_ = nullptr, side_join_ = nullptr;
+  hipStream_t fetch_st_ = nullptr;                         // ba_fetch_begin: the copy stream of the asynchronous estimate read-back
+  hipEvent_t fetch_fork_ = nullptr, fetch_ev_[kFetchMaxPieces] = {};
+  int fetch_pieces_ = 0;
+  void ba_fetch_fence();
   DevBuf<double> d_red_multi;              // trial_stats: partial sums of every reduction of the call
   double* h_trial_ = nullptr;              // ... their pinned host copy (+ the factorisation status word): ONE synchronisation per trial
   size_t h_trial_n_ = 0;

@@ -21,9 +21,12 @@ constexpr int kThreads = 256;
 // round trip (ds_bpermute) per step.  Every lane of the group ends up with the total.
 template <int CTRL>
 __device__ __forceinline__ double dpp_permute(double v) {
+  // (every control used here -- quad_perm, row_half_mirror, row_mirror, row_ror -- reads a valid lane on every lane: with
+  // bound_ctrl the "old" operand is dead and the compiler drops the two v_mov that zeroed it in front of every pair of DPP moves;
+  // the destination loop's epilogue of the Schur tiles was 168 moves for 42 additions per destination)
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi2, lo2);
 }
 template <int G>
@@ -2255,6 +2258,12 @@ BlockSolver::BlockSolver(int p, int l, int device) : p_(p), l_(l), device_(devic
 
 BlockSolver::~BlockSolver() {
   invalidate_graphs();
+  if (fetch_st_) {
+    (void)hipStreamSynchronize(fetch_st_);
+    (void)hipStreamDestroy(fetch_st_);
+    (void)hipEventDestroy(fetch_fork_);
+    for (int k = 0; k < kFetchMaxPieces; ++k) (void)hipEventDestroy(fetch_ev_[k]);
+  }
   if (side_) (void)hipStreamDestroy(side_);
   if (side_fork_) (void)hipEventDestroy(side_fork_);
   if (side_join_) (void)hipEventDestroy(side_join_);
@@ -4968,6 +4977,10 @@ void BlockSolver::ba_set_estimates(int n_cams, const double* cams, const int* ca
                                    const int* point_hidx) {
   if (n_cams <= 0 || n_points <= 0 || !cams || !points || !cam_hidx || !point_hidx) throw ArgFailure("ba_set_estimates: bad arguments");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (fetch_pieces_ > 0) {   // (a read-back still in flight targets the caller's buffers -- possibly the very ones handed over here)
+    G2OHIP_HIP_CHECK(hipStreamSynchronize(fetch_st_));
+    fetch_pieces_ = 0;
+  }
   // The caller of every iteration (the g2o adapter: setEstimate of all vertices before buildSystem) hands over the same
   // tables with new values: only the estimates move -- no index check, no re-upload of the index mapping, and the captured
   // launch sequences stay (the device addresses are the same).
@@ -5004,6 +5017,42 @@ void BlockSolver::ba_get_estimates(double* cams, double* points) {
   if (ba_.n_cams <= 0) throw StateFailure("ba_get_estimates before ba_set_estimates");
   if (cams) ba_.cams.download(cams, (size_t)ba_.n_cams * 12, st_);
   if (points) ba_.pts.download(points, (size_t)ba_.n_points * 3, st_);
+}
+
+// The same read-back started ASYNCHRONOUSLY behind everything queued on the solver's stream so far (the caller: right after
+// ba_update of an LM trial), on a copy stream of its own, in pieces with an event each: piece 0 = the cameras, pieces 1 .. n = the
+// points in n equal ranges.  ba_fetch_wait(k) returns once piece k is in the caller's buffer, so the caller writes piece k into
+// its vertices while piece k + 1 is still crossing PCIe -- and the whole copy runs next to the error evaluation of the trial.
+// Anything that WRITES the estimates afterwards (update, pop, set_estimates) makes the solver's stream wait for the copy first.
+void BlockSolver::ba_fetch_begin(double* cams, double* points, int point_pieces) {
+  if (ba_.n_cams <= 0) throw StateFailure("ba_fetch_begin before ba_set_estimates");
+  if (!cams || !points || point_pieces < 1 || point_pieces > kFetchMaxPieces - 1) throw ArgFailure("ba_fetch_begin: bad arguments");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  if (!fetch_st_) {
+    G2OHIP_HIP_CHECK(hipStreamCreateWithFlags(&fetch_st_, hipStreamNonBlocking));
+    G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&fetch_fork_, hipEventDisableTiming));
+    for (int k = 0; k < kFetchMaxPieces; ++k) G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&fetch_ev_[k], hipEventDisableTiming));
+  }
+  G2OHIP_HIP_CHECK(hipEventRecord(fetch_fork_, st_));
+  G2OHIP_HIP_CHECK(hipStreamWaitEvent(fetch_st_, fetch_fork_, 0));
+  G2OHIP_HIP_CHECK(hipMemcpyAsync(cams, ba_.cams.p, (size_t)ba_.n_cams * 12 * sizeof(double), hipMemcpyDeviceToHost, fetch_st_));
+  G2OHIP_HIP_CHECK(hipEventRecord(fetch_ev_[0], fetch_st_));
+  const size_t np = (size_t)ba_.n_points, step = (np + point_pieces - 1) / point_pieces;
+  for (int k = 0; k < point_pieces; ++k) {
+    const size_t b = std::min(np, k * step), e = std::min(np, b + step);
+    if (e > b) G2OHIP_HIP_CHECK(hipMemcpyAsync(points + 3 * b, ba_.pts.p + 3 * b, (e - b) * 3 * sizeof(double), hipMemcpyDeviceToHost, fetch_st_));
+    G2OHIP_HIP_CHECK(hipEventRecord(fetch_ev_[1 + k], fetch_st_));
+  }
+  fetch_pieces_ = 1 + point_pieces;
+}
+void BlockSolver::ba_fetch_wait(int piece) {
+  if (fetch_pieces_ <= 0) throw StateFailure("ba_fetch_wait without ba_fetch_begin");
+  if (piece < 0 || piece >= fetch_pieces_) throw ArgFailure("ba_fetch_wait: no such piece");
+  G2OHIP_HIP_CHECK(hipEventSynchronize(fetch_ev_[piece]));
+}
+// (the solver's stream is about to overwrite the estimates: a read-back in flight has to see the old ones)
+void BlockSolver::ba_fetch_fence() {
+  if (fetch_pieces_ > 0) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st_, fetch_ev_[fetch_pieces_ - 1], 0));
 }
 
 void BlockSolver::ba_linearize(bool jacobians) {
@@ -5047,6 +5096,7 @@ void BlockSolver::ba_update() {
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ba_.err_valid = ba_.jac_valid = false;
   ++ba_.est_version;
+  ba_fetch_fence();
   if (profiling) tfe_.start(st_);
   hipLaunchKernelGGL(ba_update_cams_kernel, dim3(grid_for(ba_.n_cams)), dim3(kThreads), 0, st_, ba_.n_cams, ba_.cams.p, ba_.cam_hidx.p,
                      d_x.p);
@@ -5072,6 +5122,7 @@ void BlockSolver::ba_push() {
 void BlockSolver::ba_pop() {
   if (!ba_.has_backup) throw StateFailure("ba_pop without push");
   ba_.err_valid = ba_.jac_valid = false;
+  ba_fetch_fence();
   G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.cams.p, ba_.cams_bak.p, (size_t)ba_.n_cams * 12 * sizeof(double), hipMemcpyDeviceToDevice, st_));
   G2OHIP_HIP_CHECK(hipMemcpyAsync(ba_.pts.p, ba_.pts_bak.p, (size_t)ba_.n_points * 3 * sizeof(double), hipMemcpyDeviceToDevice, st_));
   ba_.has_backup = false;

@@ -682,6 +682,20 @@ int g2ohip_ba_get_estimates(g2ohip_solver* s, double* cams, double* points) {
     return G2OHIP_OK;
   });
 }
+int g2ohip_ba_fetch_estimates_begin(g2ohip_solver* s, double* cams, double* points, int point_pieces) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_fetch_begin(cams, points, point_pieces);
+    return G2OHIP_OK;
+  });
+}
+int g2ohip_ba_fetch_estimates_wait(g2ohip_solver* s, int piece) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_fetch_wait(piece);
+    return G2OHIP_OK;
+  });
+}
 int g2ohip_ba_linearize(g2ohip_solver* s, int jacobians) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

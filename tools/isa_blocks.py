@@ -20,7 +20,9 @@ for l in lines[start + 1:]:
 blocks.append(cur)
 order = {b["name"]: i for i, b in enumerate(blocks)}
 def cls(op):
-    if op.startswith("v_fma_f64") or op.startswith("v_mul_f64") or op.startswith("v_add_f64"): return "f64"
+    if op.startswith(("v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_pk_fma_f64", "v_pk_mul_f64", "v_pk_add_f64")): return "f64"
+    if op.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr", "v_cndmask", "v_readlane", "v_readfirstlane", "v_permlane", "v_bfe", "v_lshl", "v_and_b32", "v_or_b32")) or "_dpp" in op: return "move"
+    if op.startswith(("v_add_u32", "v_add_co", "v_addc", "v_mad_u32", "v_mul_lo", "v_mul_u32", "v_sub_u32", "v_mad_i32", "v_lshl_add", "v_add3", "v_mul_hi", "v_min_", "v_max_", "v_ashr", "v_lshr", "v_cmp")): return "int"
     if op.startswith("v_div") or op.startswith("v_rcp") or op.startswith("v_rsq") or op.startswith("v_sqrt"): return "div"
     if op.startswith("ds_"): return "lds"
     if op.startswith("global_") or op.startswith("buffer_") or op.startswith("flat_"): return "mem"
