@@ -203,9 +203,9 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     _pin = !(pin && pin[0] == '0');
     const char* th = std::getenv("G2OHIP_ADAPTER_THREADS");   // host threads of the estimate gather / write-back loops (1 = serial)
     const unsigned hc = std::thread::hardware_concurrency();
-    // (default: a quarter of the hardware threads, 8 to 64 -- the write-back of 1.1 M vertices is a cache miss per vertex and
-    // scales with the threads: 1.8 / 1.0 ms on 16 / 32 of the 256 threads of the measurement host)
-    _threads = th ? std::atoi(th) : (int)std::min(64u, std::max(8u, hc / 4));
+    // (default: an eighth of the hardware threads, 8 to 32 -- the write-back of 1.1 M vertices is a cache miss per vertex and
+    // scales with the threads up to there: 1.8 / 1.05 / 1.06 ms on 16 / 32 / 64 of the 256 threads of the measurement host)
+    _threads = th ? std::atoi(th) : (int)std::min(32u, std::max(8u, hc / 8));
     if (hc > 0 && _threads > (int)hc) _threads = (int)hc;
     if (_threads < 1) _threads = 1;
     const char* tm = std::getenv("G2OHIP_ADAPTER_TIMING");

@@ -154,6 +154,10 @@ class BlockSolver {
   int sharded_merge = 1;                   // sharded solve: TWO all-reduces instead of three -- the boundary blocks and b_p travel with the
                                            // subtree roots (after the own subtrees) whenever only the shared top of the tree consumes them
   size_t sharded_collectives = 0;          // all-reduces issued by the last solve_sharded_once (stats)
+  int sharded_selftest = 1;                // the first solve_sharded of a structure runs twice (as configured / reference schedule) and falls back to the
+                                           // reference schedule when the two disagree (see solve_sharded)
+  bool selftest_fallback() const { return selftest_fallback_; }
+  int selftest_break = 0;                  // (tests only) rank 0 corrupts its copy of the configured variant's solution: the self-test must fall back on EVERY rank
   int sharded_graph = 1;                   // solve_sharded as ONE hipGraph (the collectives inside it): 1 = when nothing has to cross the
                                            // host (comm_emulate, the peer mailboxes: their two kernels per all-reduce), 2 = with RCCL as well (ncclAllReduce captured into the graph; not
                                            // exercised on hardware here -- opt-in); 0 = one graph per phase, plain launches in between
@@ -242,6 +246,8 @@ class BlockSolver {
     bool merged = false;      // the boundary blocks / b_p ride in the all-reduce of the subtree roots (sharded_merge)
     double* tail = nullptr;   // ... their place behind the Cholesky's exchange buffer
   } ex_;
+  bool selftest_done_ = false, selftest_fallback_ = false;
+  int solve_sharded_repeat();
   void solve_back_substitute_impl();
   void launch_boundary_reduce();
   void drop_graph_segments();

@@ -2903,6 +2903,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   // (the exchange of a sharded job was set up for the previous structure: its index lists address the old pattern and a merged
   // payload (sharded_merge) lives behind the previous Cholesky's exchange buffer -- gone with it)
   ex_ = Exchange();
+  selftest_done_ = false;
   if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
   else chol_->analyze(nP, pp_colptr.data(), pp_row.data(), st_);
   lap("symbolic analysis");
@@ -4174,10 +4175,62 @@ int BlockSolver::solve_sharded_once() {
   return rc;
 }
 
-int BlockSolver::solve_sharded() {
+int BlockSolver::solve_sharded_repeat() {
   int rc = solve_sharded_once();
   for (int again = 0; rc == 2 && again < 2; ++again) rc = solve_sharded_once();   // (every rank takes the same branch: the flag is a sum)
   return rc == 0 ? 0 : 1;
+}
+
+// Start-up self-test of the sharded schedule (option sharded_selftest, default on; the first solve_sharded of a structure with a
+// real communicator): the two-collective merge (sharded_merge) and the solve captured as one hipGraph with the collectives
+// inside (sharded_graph) are the variants that no multi-GPU hardware has run before a job meets them.  The first solve is
+// therefore done TWICE -- as configured, and with the three-collective, uncaptured reference schedule -- and the two
+// solutions are compared on every rank (the verdict is a max over the ranks, so all of them take the same branch).  If they
+// differ beyond rounding (or one of them is not finite) the job continues on the reference schedule with a note on stderr
+// instead of failing on plumbing; otherwise the configured variant stays.  Costs one extra solve per structure.
+int BlockSolver::solve_sharded() {
+  const bool real_comm = comm.kind() != Comm::kNone && chol_opt.world > 1 && !comm_emulate;
+  const bool variant = ex_.merged || (sharded_graph > 0 && use_graph);
+  if (!sharded_selftest || selftest_done_ || !real_comm || !variant) return solve_sharded_repeat();
+  selftest_done_ = true;
+  const int rc1 = solve_sharded_repeat();
+  const size_t n = vector_size();
+  std::vector<double> x1(n), x0(n);
+  d_x.download(x1.data(), n, st_);
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+  if (selftest_break && comm.rank() == 0)
+    for (size_t i = 0; i < n; ++i) x1[i] *= 2.0;
+  const bool merged_was = ex_.merged;
+  const int graph_was = sharded_graph;
+  ex_.merged = false;
+  sharded_graph = 0;
+  drop_graph_segments();
+  const int rc0 = solve_sharded_repeat();
+  d_x.download(x0.data(), n, st_);
+  G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+  double scale = 0.0, diff = 0.0;
+  bool finite = true;
+  for (size_t i = 0; i < n; ++i) {
+    finite = finite && std::isfinite(x0[i]) && std::isfinite(x1[i]);
+    scale = std::max(scale, std::fabs(x0[i]));
+    diff = std::max(diff, std::fabs(x0[i] - x1[i]));
+  }
+  // (both solves failed the same way -- not positive definite -- is agreement: x is meaningless then)
+  double bad = (rc0 != rc1 || (rc0 == 0 && (!finite || diff > 1e-6 * std::max(scale, 1e-300)))) ? 1.0 : 0.0;
+  comm.all_reduce_host(&bad, 1, 1, st_);
+  if (bad > 0.0) {
+    if (comm.rank() == 0)
+      fprintf(stderr, "g2ohip: the sharded solve's start-up self-test failed (merged collectives %d, one-graph capture %d: |dx| %.3e against %.3e, "
+              "status %d / %d): continuing on the three-collective, uncaptured schedule (sharded_merge = 0, sharded_graph = 0)\n",
+              (int)merged_was, graph_was, diff, scale, rc1, rc0);
+    selftest_fallback_ = true;   // (exchange_setup keeps the merge off from now on)
+    sharded_merge = 0;
+  } else {
+    ex_.merged = merged_was;
+    sharded_graph = graph_was;
+    drop_graph_segments();
+  }
+  return rc0;
 }
 
 double BlockSolver::chi2_sharded() {

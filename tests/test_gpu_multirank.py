@@ -338,6 +338,28 @@ def test_two_collectives_per_sharded_solve_equal_three(tmp_path, world):
     assert runs[1][0]["chis"][-1] < runs[1][0]["chis"][0]
 
 
+def test_start_up_self_test_falls_back_to_the_reference_schedule_on_every_rank(tmp_path):
+    """The first sharded solve of a structure runs twice -- as configured (two merged collectives) and on the three-collective,
+    uncaptured reference schedule -- and the job continues on the reference schedule if the two disagree (option sharded_selftest,
+    block_solver.hip: solve_sharded): here rank 0 is told to corrupt its copy of the first solution (sharded_selftest_break), the
+    verdict is a maximum over the ranks, so BOTH ranks fall back: three collectives per solve from then on, and the LM run equals
+    the undisturbed one (two collectives: the self-test passed and the configured schedule stayed)."""
+    import torch.multiprocessing as mp
+    world, P, L, n_it = 2, 640, 5000, 4
+    runs = {}
+    for tag, opts in (("ok", "sharded_merge=1"), ("broken", "sharded_merge=1,sharded_selftest_break=1"), ("off", "sharded_merge=1,sharded_selftest=0,sharded_selftest_break=1")):
+        d = tmp_path / tag
+        d.mkdir()
+        mp.spawn(_lm_worker, args=(world, _free_port(), P, L, 1.0, 0.05, n_it, str(d), -1, opts), nprocs=world, join=True)
+        runs[tag] = [np.load(os.path.join(str(d), "lm%d.npz" % r)) for r in range(world)]
+    for r in range(world):
+        a, b, c = runs["ok"][r], runs["broken"][r], runs["off"][r]
+        assert int(a["collectives"]) == 2 and int(b["collectives"]) == 3 and int(c["collectives"]) == 2    # (off: nothing is compared)
+        assert int(a["done"]) == int(b["done"]) and list(a["trials"]) == list(b["trials"])
+        assert np.allclose(a["chis"], b["chis"], rtol=1e-9, atol=0) and np.allclose(a["lams"], b["lams"], rtol=1e-9, atol=0)
+        assert relerr(a["pts"], b["pts"]) < 1e-9 and relerr(a["pts"], c["pts"]) < 1e-9
+
+
 def _lm_classes_worker(rank, world, port, P, L, n_it, out_dir):
     import torch
     import torch.distributed as dist
