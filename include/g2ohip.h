@@ -129,6 +129,10 @@ int g2ohip_build_structure(g2ohip_solver* s, int num_poses, int num_landmarks, i
  * g2ohip_build_system returns (zero-copy); otherwise host arrays, copied to the device. */
 int g2ohip_set_edge_data(g2ohip_solver* s, int set, const double* J0, const double* J1, const double* omega,
                          const double* err, int on_device);
+/* The errors of a set alone ([n][error_dim], host array) after g2ohip_set_edge_data with host arrays: what computeActiveErrors
+ * (sparse_optimizer.cpp:61-74) leaves in the edges at TRIAL estimates -- chi2 of a Levenberg-Marquardt trial reads nothing else;
+ * the Jacobians and information matrices stay what the system was built from. */
+int g2ohip_set_edge_errors(g2ohip_solver* s, int set, const double* err);
 /* OptimizableGraph::Edge::setRobustKernel (g2o.cpp:322-336); delta as RobustKernel::setDelta. */
 int g2ohip_set_robust_kernel(g2ohip_solver* s, int set, int kind, double delta);
 /* The same per EDGE: in g2o the robust kernel is a member of the edge (optimizable_graph.h:436-443, asked per edge by

@@ -44,7 +44,7 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "g2ohip_last_error", "g2ohip_device_count", "g2ohip_create", "g2ohip_destroy", "g2ohip_set_stream", "g2ohip_init",
-    "g2ohip_add_edge_set", "g2ohip_build_structure", "g2ohip_set_edge_data", "g2ohip_set_robust_kernel", "g2ohip_set_robust_kernel_per_edge",
+    "g2ohip_add_edge_set", "g2ohip_build_structure", "g2ohip_set_edge_data", "g2ohip_set_edge_errors", "g2ohip_set_robust_kernel", "g2ohip_set_robust_kernel_per_edge",
     "g2ohip_build_system", "g2ohip_chi2", "g2ohip_set_lambda", "g2ohip_restore_diagonal", "g2ohip_max_diagonal",
     "g2ohip_compute_scale", "g2ohip_solve", "g2ohip_vector_size", "g2ohip_copy_x", "g2ohip_copy_b", "g2ohip_x_device",
     "g2ohip_b_device", "g2ohip_multiply_hessian", "g2ohip_sync", "g2ohip_set_profiling", "g2ohip_get_stats",
@@ -146,6 +146,7 @@ def load():
     L.g2ohip_ba_set_edges_classes.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, c_int_p]
     L.g2ohip_ba_set_estimates.argtypes = [vp, C.c_int, c_dbl_p, c_int_p, C.c_int, c_dbl_p, c_int_p]
     L.g2ohip_ba_get_estimates.argtypes = [vp, c_dbl_p, c_dbl_p]
+    L.g2ohip_set_edge_errors.argtypes = [vp, C.c_int, c_dbl_p]
     L.g2ohip_ba_fetch_estimates_begin.argtypes = [vp, c_dbl_p, c_dbl_p, C.c_int]
     L.g2ohip_ba_fetch_estimates_wait.argtypes = [vp, C.c_int]
     L.g2ohip_ba_linearize.argtypes = [vp, C.c_int]

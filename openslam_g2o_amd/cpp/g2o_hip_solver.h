@@ -196,7 +196,7 @@ class HipDeviceGraph {
 template <int p, int l>
 class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
  public:
-  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0), _devValid(false) {
+  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0), _devValid(false), _hybrid(false), _touchedPushed(false), _fetchBegun(false) {
     const char* fp = std::getenv("G2OHIP_ADAPTER_FASTPATH");
     if (fp && fp[0] == '0') _fastPath = false;
     const char* pin = std::getenv("G2OHIP_ADAPTER_PINNED");
@@ -575,6 +575,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
           break;
         }
       }
+    planHybrid();
     setupMs[3] = 1e3 * lap(tSetup);
     if (_timing)
       std::cerr << "{\"g2ohip_adapter_setup_ms\": {\"grouping\": " << setupMs[0] << ", \"edge_sets_and_buffers\": " << setupMs[1]
@@ -609,18 +610,15 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
 
   // block_solver.hpp:501-560.  After it returns b() holds -J' Omega e (poses then landmarks) and H is assembled on
   // the device.  The reference returns 0 and nobody checks (optimization_algorithm_levenberg.cpp:81).
-  virtual bool buildSystem() {
-    if (!_h) return false;
+  // The groups no device front end takes (and the n-ary edges): errors / Jacobians by the edges' own computeError /
+  // linearizeOplus on the host, flat arrays to the library.  computeErrors: the caller is a device-resident driver (nobody ran
+  // computeActiveErrors on the host); jacobians = false: the errors alone (chi2 of a Levenberg-Marquardt trial).
+  bool hostGeneric(bool computeErrors, bool jacobians) {
     JacobianWorkspace& ws = _optimizer->jacobianWorkspace();
     double t = get_monotonic_time();
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       Group& g = _groups[gi];
-      if (g.fast) {                                    // estimates up, errors + Jacobians on the device
-        if (!(g.fast == 2 ? uploadPosesSE2() : (g.fast == 3 ? uploadPosesSE3() : uploadEstimates()))) return false;
-        _devValid = true;
-        _phase.upload += lap(t);
-        continue;
-      }
+      if (g.fast) continue;
       const int d = g.key.d, d0 = g.key.dim0, d1 = g.key.dim1;
       if (g.err.empty() && !g.edges.empty()) {
         // The library takes a side's dimension from the hessian indices; a side whose vertices are ALL fixed (e.g. a
@@ -635,7 +633,12 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
       }
       for (size_t k = 0; k < g.edges.size(); ++k) {
         OptimizableGraph::Edge* e = g.edges[k];
-        e->linearizeOplus(ws);                         // block_solver.hpp:531 (the error is current: computeActiveErrors)
+        if (computeErrors) e->computeError();
+        if (!jacobians) {
+          std::memcpy(&g.err[k * d], e->errorData(), sizeof(double) * d);
+          continue;
+        }
+        e->linearizeOplus(ws);                         // block_solver.hpp:531
         // Jacobians sit column-major (d x dim) in the workspace (base_binary_edge.h: Map onto workspaceForVertex(i));
         // a fixed vertex has no Jacobian and is never read on the device (index -1)
         if (g.v0[k] >= 0) std::memcpy(&g.J0[k * d * d0], ws.workspaceForVertex(0), sizeof(double) * d * d0);
@@ -644,8 +647,11 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
         std::memcpy(&g.err[k * d], e->errorData(), sizeof(double) * d);
       }
       _phase.hostLinearize += lap(t);
-      if (g2ohip_set_edge_data(_h, g.set, g.J0.data(), d1 ? g.J1.data() : 0, g.Om.data(), g.err.data(), /*on_device*/ 0) != G2OHIP_OK)
+      if (!jacobians) {
+        if (g2ohip_set_edge_errors(_h, g.set, g.err.data()) != G2OHIP_OK) return fail("set_edge_errors");
+      } else if (g2ohip_set_edge_data(_h, g.set, g.J0.data(), d1 ? g.J1.data() : 0, g.Om.data(), g.err.data(), /*on_device*/ 0) != G2OHIP_OK) {
         return fail("set_edge_data");
+      }
       _phase.upload += lap(t);
     }
     for (size_t m = 0; m < _multi.size(); ++m) {         // n-ary edges: linearised once, their Jacobians dealt to the pair sets
@@ -663,6 +669,11 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
       }
       for (size_t k = 0; k < n; ++k) {
         OptimizableGraph::Edge* e = mg.edges[k];
+        if (computeErrors) e->computeError();
+        if (!jacobians) {
+          std::memcpy(&mg.err[k * d], e->errorData(), sizeof(double) * d);
+          continue;
+        }
         e->linearizeOplus(ws);
         for (size_t q = 0; q < mg.pairs.size(); ++q) {
           typename MultiGroup::Pair& pr = mg.pairs[q];
@@ -676,10 +687,29 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
       _phase.hostLinearize += lap(t);
       for (size_t q = 0; q < mg.pairs.size(); ++q) {
         typename MultiGroup::Pair& pr = mg.pairs[q];
-        if (g2ohip_set_edge_data(_h, pr.set, pr.J0.data(), pr.J1.data(), mg.Om.data(), mg.err.data(), /*on_device*/ 0) != G2OHIP_OK)
+        if (!jacobians) {
+          if (g2ohip_set_edge_errors(_h, pr.set, mg.err.data()) != G2OHIP_OK) return fail("set_edge_errors");
+        } else if (g2ohip_set_edge_data(_h, pr.set, pr.J0.data(), pr.J1.data(), mg.Om.data(), mg.err.data(), /*on_device*/ 0) != G2OHIP_OK) {
           return fail("set_edge_data");
+        }
       }
       _phase.upload += lap(t);
+    }
+    return true;
+  }
+
+  virtual bool buildSystem() {
+    if (!_h) return false;
+    // (the host-linearised groups first: handing a set its data for the first time drops the front ends' cached evaluations)
+    if (!hostGeneric(/*computeErrors=*/false, /*jacobians=*/true)) return false;   // (the errors are current: computeActiveErrors)
+    double t = get_monotonic_time();
+    for (size_t gi = 0; gi < _groups.size(); ++gi) {
+      Group& g = _groups[gi];
+      if (g.fast) {                                    // estimates up, errors + Jacobians on the device
+        if (!(g.fast == 2 ? uploadPosesSE2() : (g.fast == 3 ? uploadPosesSE3() : uploadEstimates()))) return false;
+        _devValid = true;
+        _phase.upload += lap(t);
+      }
     }
     if (g2ohip_build_system(_h) != G2OHIP_OK) return fail("build_system");
     if (_timing) g2ohip_sync(_h);
@@ -762,13 +792,17 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   virtual void multiplyHessian(double* dest, const double* src) const { if (_h) g2ohip_multiply_hessian(_h, dest, src); }
 
   // ---- HipDeviceGraph: the graph side of an iteration on the device front ends (g2ohip_ba_* / g2ohip_pg_*)
-  virtual bool deviceResident() const { return _h && !_groups.empty() && _multi.empty() && _fastGroups == (int)_groups.size(); }
+  // every active edge on a device front end -- or (hybrid) the bundle-adjustment front end plus groups the host linearises
+  // whose free vertices are all cameras / points of that front end
+  virtual bool deviceResident() const { return _h && !_groups.empty() && ((_multi.empty() && _fastGroups == (int)_groups.size()) || _hybrid); }
+  bool hybridLoop() const { return _hybrid; }
   virtual bool devEstimatesValid() const { return _devValid; }
   virtual bool devSetEstimates() {
     double t = get_monotonic_time();
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       const int fast = _groups[gi].fast;
-      if (!(fast == 1 ? setEstimatesBA() : (fast == 2 ? setPosesSE2() : (fast == 3 ? setPosesSE3() : false)))) return false;
+      if (!fast) continue;                               // (hybrid loop: a host-linearised group has nothing on the device)
+      if (!(fast == 1 ? setEstimatesBA() : (fast == 2 ? setPosesSE2() : setPosesSE3()))) return false;
     }
     _devValid = true;
     _phase.upload += lap(t);
@@ -778,7 +812,8 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     double t = get_monotonic_time();
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       const int fast = _groups[gi].fast;
-      if (!(fast == 1 ? getEstimatesBA() : (fast == 2 ? getPosesSE2() : (fast == 3 ? getPosesSE3() : false)))) return false;
+      if (!fast) continue;
+      if (!(fast == 1 ? getEstimatesBA() : (fast == 2 ? getPosesSE2() : getPosesSE3()))) return false;
     }
     _phase.downloadX += lap(t);
     return true;
@@ -789,13 +824,21 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
 #if G2OHIP_FASTPATH_SBA
     if (!_pin) return false;                           // (pageable buffers: the "asynchronous" copy would block the caller)
     for (size_t gi = 0; gi < _groups.size(); ++gi)
-      if (_groups[gi].fast == 1) return g2ohip_ba_fetch_estimates_begin(_h, _camBuf.data(), _pointBuf.data(), kFetchPieces) == G2OHIP_OK || fail("ba_fetch_estimates_begin");
+      if (_groups[gi].fast == 1) {
+        if (g2ohip_ba_fetch_estimates_begin(_h, _camBuf.data(), _pointBuf.data(), kFetchPieces) != G2OHIP_OK) return fail("ba_fetch_estimates_begin");
+        _fetchBegun = true;
+        return true;
+      }
 #endif
     return false;
   }
-  virtual void devFetchCancel() { (void)g2ohip_ba_fetch_estimates_wait(_h, kFetchPieces); }
+  virtual void devFetchCancel() {
+    (void)g2ohip_ba_fetch_estimates_wait(_h, kFetchPieces);
+    _fetchBegun = false;
+  }
   virtual bool devFetchEnd() {
     double t = get_monotonic_time();
+    _fetchBegun = false;
 #if G2OHIP_FASTPATH_SBA
     // ONE parallel region: the calling thread waits for the pieces and announces them, every thread writes its share of a
     // piece as soon as it is there (a region per piece paid the hand-out five times)
@@ -836,8 +879,17 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     return true;
   }
   virtual bool devLinearize(bool jacobians) {
+    if (_hybrid) {
+      // Hybrid loop: the groups no front end takes are linearised by their own edge types on the host.  With the Jacobians
+      // (iteration start) the vertices hold the current estimates (write-back of the previous iteration); for the errors of a
+      // TRIAL the vertices those edges touch -- usually a handful -- get the trial estimates from the device first, under a
+      // push() that devPop / devDiscardTop resolve with the device's own stack.
+      if (!jacobians && !refreshTouched()) return false;
+      if (!hostGeneric(/*computeErrors=*/true, jacobians)) return false;
+    }
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       const int fast = _groups[gi].fast;
+      if (!fast) continue;
       if (fast == 1 ? g2ohip_ba_linearize(_h, jacobians ? 1 : 0) != G2OHIP_OK : g2ohip_pg_linearize(_h, jacobians ? 1 : 0) != G2OHIP_OK) return fail("linearize");
     }
     return true;
@@ -879,8 +931,18 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   }
   virtual bool devUpdate() { return forEachFrontEnd(g2ohip_ba_update, g2ohip_pg_update, "update"); }
   virtual bool devPush() { return forEachFrontEnd(g2ohip_ba_push, g2ohip_pg_push, "push"); }
-  virtual bool devPop() { return forEachFrontEnd(g2ohip_ba_pop, g2ohip_pg_pop, "pop"); }
-  virtual bool devDiscardTop() { return forEachFrontEnd(g2ohip_ba_discard_top, g2ohip_pg_discard_top, "discard_top"); }
+  virtual bool devPop() {
+    if (_touchedPushed)
+      for (size_t i = 0; i < _touched.size(); ++i) _touched[i].v->pop();
+    _touchedPushed = false;
+    return forEachFrontEnd(g2ohip_ba_pop, g2ohip_pg_pop, "pop");
+  }
+  virtual bool devDiscardTop() {
+    if (_touchedPushed)
+      for (size_t i = 0; i < _touched.size(); ++i) _touched[i].v->discardTop();
+    _touchedPushed = false;
+    return forEachFrontEnd(g2ohip_ba_discard_top, g2ohip_pg_discard_top, "discard_top");
+  }
 
   g2ohip_solver* handle() const { return _h; }
 
@@ -1304,9 +1366,72 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
       _points[i]->setEstimate(x);
     }
   }
+  // Hybrid loop: may the device-resident drivers take a graph that has host-linearised groups next to the bundle-adjustment
+  // front end?  Yes when every FREE vertex those groups touch is a camera or a point of the front end (the device updates and
+  // stacks it; a vertex no front end knows would miss its oplus) and no pose-graph front end is bound next to it.
+  // G2OHIP_ADAPTER_HYBRID=0: never (such graphs then run g2o's host loop, as before).
+  void planHybrid() {
+    _hybrid = false;
+    _touchedPushed = false;
+    _touched.clear();
+    const char* hy = std::getenv("G2OHIP_ADAPTER_HYBRID");
+    if (hy && hy[0] == '0') return;
+    bool haveBA = false, other = !_multi.empty();
+    for (size_t gi = 0; gi < _groups.size(); ++gi) {
+      if (_groups[gi].fast == 1) haveBA = true;
+      else if (_groups[gi].fast == 0) other = true;
+      else return;
+    }
+    if (!haveBA || !other) return;
+    std::vector<int> camOf(_nP > 0 ? _nP : 1, -1), ptOf(_nL > 0 ? _nL : 1, -1);
+    for (size_t i = 0; i < _cams.size(); ++i)
+      if (_camHidx[i] >= 0 && _camHidx[i] < _nP) camOf[_camHidx[i]] = (int)i;
+    for (size_t i = 0; i < _points.size(); ++i)
+      if (_pointHidx[i] >= 0 && _pointHidx[i] < _nL) ptOf[_pointHidx[i]] = (int)i;
+    std::map<OptimizableGraph::Vertex*, Touched> seen;
+    std::vector<OptimizableGraph::Edge*> es;
+    for (size_t gi = 0; gi < _groups.size(); ++gi)
+      if (!_groups[gi].fast) es.insert(es.end(), _groups[gi].edges.begin(), _groups[gi].edges.end());
+    for (size_t m = 0; m < _multi.size(); ++m) es.insert(es.end(), _multi[m].edges.begin(), _multi[m].edges.end());
+    for (size_t k = 0; k < es.size(); ++k)
+      for (size_t i = 0; i < es[k]->vertices().size(); ++i) {
+        OptimizableGraph::Vertex* v = static_cast<OptimizableGraph::Vertex*>(es[k]->vertex(i));
+        const int h = v->hessianIndex();
+        if (h < 0 || seen.count(v)) continue;          // (a fixed vertex keeps its estimate)
+        Touched t;
+        t.v = v;
+        t.kind = v->marginalized() ? 1 : 0;
+        t.idx = t.kind ? (h - _nP >= 0 && h - _nP < _nL ? ptOf[h - _nP] : -1) : (h < _nP ? camOf[h] : -1);
+        if (t.idx < 0) return;                         // a vertex the front end does not hold
+        if (t.kind ? static_cast<OptimizableGraph::Vertex*>(_points[t.idx]) != v : static_cast<OptimizableGraph::Vertex*>(_cams[t.idx]) != v) return;
+        seen[v] = t;
+      }
+    for (typename std::map<OptimizableGraph::Vertex*, Touched>::const_iterator it = seen.begin(); it != seen.end(); ++it) _touched.push_back(it->second);
+    _hybrid = true;
+    if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
+      std::cerr << "BlockSolverHip: hybrid device loop -- " << es.size() << " host-linearised edges over " << _touched.size() << " free vertices of the device front end" << std::endl;
+  }
+  // the trial estimates of the touched vertices from the device (the read-back started behind the trial's update, or a plain one)
+  bool refreshTouched() {
+    if (_touched.empty()) return true;
+    if (_fetchBegun) {
+      if (g2ohip_ba_fetch_estimates_wait(_h, kFetchPieces) != G2OHIP_OK) return fail("ba_fetch_estimates_wait");
+    } else if (g2ohip_ba_get_estimates(_h, _camBuf.data(), _pointBuf.data()) != G2OHIP_OK) {
+      return fail("ba_get_estimates");
+    }
+    for (size_t i = 0; i < _touched.size(); ++i) {
+      _touched[i].v->push();
+      if (_touched[i].kind) scatterPointsRange((size_t)_touched[i].idx, (size_t)_touched[i].idx + 1);
+      else scatterCamsRange((size_t)_touched[i].idx, (size_t)_touched[i].idx + 1);
+    }
+    _touchedPushed = true;
+    return true;
+  }
 #else
   bool setEstimatesBA() { return false; }
   bool getEstimatesBA() { return false; }
+  void planHybrid() { _hybrid = false; }
+  bool refreshTouched() { return true; }
 #endif
 
   g2ohip_solver* _h;
@@ -1320,6 +1445,13 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   bool _devValid;                                      // the front ends hold estimates for the current structure
   bool _pin, _timing;
   int _threads;
+  // hybrid loop (deviceResident with host-linearised groups): the free vertices those groups touch, as (vertex, camera / point, index)
+  struct Touched {
+    OptimizableGraph::Vertex* v;
+    int kind, idx;                                     // 0: _cams[idx], 1: _points[idx]
+  };
+  std::vector<Touched> _touched;
+  bool _hybrid, _touchedPushed, _fetchBegun;
   enum { kFetchPieces = 4 };                           // point ranges of the pipelined write-back (devFetchBegin / devFetchEnd)
   mutable HipWorkers _workers;                         // persistent helper threads of parallelFor
   std::vector<void*> _pinned;                          // buffers registered with g2ohip_host_register

@@ -65,6 +65,7 @@ class BlockSolver {
   void build_structure(int nP, int nL, bool do_schur);
   bool update_structure(int new_poses, int set, int n, const int* v0, const int* v1);
   void set_edge_data(int set, const double* J0, const double* J1, const double* omega, const double* err, bool on_device);
+  void set_edge_errors(int set, const double* err);
   void set_robust_kernel(int set, int kind, double delta);
   void set_robust_kernel_per_edge(int set, const int* kind, const double* delta);
   void build_system();

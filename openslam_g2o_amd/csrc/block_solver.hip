@@ -2960,12 +2960,16 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
 }
 
 void BlockSolver::set_edge_data(int set, const double* J0, const double* J1, const double* omega, const double* err, bool on_device) {
-  invalidate_graphs();
   require_structure();
   if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
   EdgeSet& es = *sets_[set];
   if (!J0 || !omega || !err || (!es.unary && !J1)) throw ArgFailure("set_edge_data: null array");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  // Host arrays handed over again for a set that already has its own device copies (a g2o adapter's generic group, every
+  // iteration): the device addresses stay, only what the kernels READ changes -- the captured launch sequences and the cached
+  // evaluations of the device front ends (other sets) stay valid; chi2 does not.
+  const double *pJ0 = es.J0, *pJ1 = es.J1, *pO = es.omega, *pE = es.err;
+  const bool had = es.has_data && !es.external;
   es.external = on_device;
   if (on_device) {
     es.J0 = J0;
@@ -2983,7 +2987,23 @@ void BlockSolver::set_edge_data(int set, const double* J0, const double* J1, con
     es.omega = es.own_omega.p;
     es.err = es.own_err.p;
   }
+  if (had && !on_device && pJ0 == es.J0 && pJ1 == es.J1 && pO == es.omega && pE == es.err) chi2_valid_ = false;
+  else invalidate_graphs();
   es.has_data = true;
+  es.has_err = true;
+}
+
+// The errors of a set alone (computeActiveErrors at trial estimates: the Jacobians and information matrices stay what the system
+// was built from).  Host array, the set's own device copy.
+void BlockSolver::set_edge_errors(int set, const double* err) {
+  require_structure();
+  if (set < 0 || set >= (int)sets_.size()) throw ArgFailure("bad edge set id");
+  EdgeSet& es = *sets_[set];
+  if (!err) throw ArgFailure("set_edge_errors: null array");
+  if (!es.has_data || es.external || !es.own_err.p) throw StateFailure("set_edge_errors: the set has no host-supplied edge data (set_edge_data first)");
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  es.own_err.upload(err, (size_t)es.n * es.d, st_);
+  chi2_valid_ = false;
   es.has_err = true;
 }
 

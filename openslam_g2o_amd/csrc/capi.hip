@@ -172,6 +172,14 @@ int g2ohip_set_edge_data(g2ohip_solver* s, int set, const double* J0, const doub
   });
 }
 
+int g2ohip_set_edge_errors(g2ohip_solver* s, int set, const double* err) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->set_edge_errors(set, err);
+    return G2OHIP_OK;
+  });
+}
+
 int g2ohip_set_robust_kernel(g2ohip_solver* s, int set, int kind, double delta) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

@@ -309,6 +309,59 @@ class BaseBinaryEdge : public OptimizableGraph::Edge {
   Eigen::Matrix<double, D, VertexXj::Dimension> _jacobianOplusXj;
 };
 
+// unary edges (g2o/core/base_unary_edge.h:48-106): one vertex; the Jacobian by central differences unless the derived type
+// overrides linearizeOplus() (base_unary_edge.hpp:74-117: delta 1e-9, push / oplus / computeError / pop), through the workspace
+template <int D, typename E, typename VertexXi>
+class BaseUnaryEdge : public OptimizableGraph::Edge {
+ public:
+  static const int Dimension = D;
+  typedef E Measurement;
+  typedef Eigen::Matrix<double, D, 1> ErrorVector;
+  typedef Eigen::Matrix<double, D, D> InformationType;
+  BaseUnaryEdge() { _dimension = D; resize(1); _information.setIdentity(); }
+  virtual void linearizeOplus(JacobianWorkspace& ws) {
+    VertexXi* vi = static_cast<VertexXi*>(_vertices[0]);
+    if (vi->fixed()) return;
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    const ErrorVector errorBeforeNumeric = _error;
+    double* J = ws.workspaceForVertex(0);                 // D x dim, column-major
+    double add[VertexXi::Dimension];
+    for (int c = 0; c < VertexXi::Dimension; ++c) add[c] = 0.0;
+    for (int c = 0; c < VertexXi::Dimension; ++c) {
+      vi->push();
+      add[c] = delta;
+      vi->oplus(add);
+      computeError();
+      const ErrorVector ep = _error;
+      vi->pop();
+      vi->push();
+      add[c] = -delta;
+      vi->oplus(add);
+      computeError();
+      vi->pop();
+      add[c] = 0.0;
+      for (int r = 0; r < D; ++r) J[r + D * c] = scalar * (ep[r] - _error[r]);
+    }
+    _error = errorBeforeNumeric;
+  }
+  virtual double chi2() const {
+    double s = 0.0;
+    for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) s += _error[i] * _information(i, j) * _error[j];
+    return s;
+  }
+  virtual const double* errorData() const { return _error.data(); }
+  virtual const double* informationData() const { return _information.data(); }
+  const Measurement& measurement() const { return _measurement; }
+  void setMeasurement(const Measurement& m) { _measurement = m; }
+  const InformationType& information() const { return _information; }
+  void setInformation(const InformationType& i) { _information = i; }
+  const ErrorVector& error() const { return _error; }
+ protected:
+  Measurement _measurement;
+  InformationType _information;
+  ErrorVector _error;
+};
+
 // n-ary edges (g2o/core/base_multi_edge.h:49-116): any number of vertices, Jacobians by central differences on every
 // free vertex (base_multi_edge.hpp:58-130: delta 1e-9, push / oplus / computeError / pop), delivered through the workspace
 template <int D, typename E>

@@ -27,6 +27,25 @@ using namespace g2o;
 
 // Test edge with THREE vertices (what g2o/types/sclam2d/edge_se2_sensor_calib.h:40-55 computes: odometry seen through a sensor
 // mounted with an unknown offset -- two poses and the calibration vertex every edge shares), numeric Jacobians of BaseMultiEdge
+// A unary prior on a camera pose, the way a user's own edge type would define it (BaseUnaryEdge with the numeric Jacobian of
+// base_unary_edge.hpp:74-117): e = (t - t_prior | vee(R R_prior' - R_prior R') / 2).  No device front end knows this type: the
+// adapter linearises it on the host -- next to a bundle-adjustment graph on the device it is what the hybrid loop is for.
+class EdgeCameraPrior : public BaseUnaryEdge<6, SE3Quat, VertexSE3Expmap> {
+ public:
+  virtual bool write(std::ostream&) const { return false; }
+  virtual void computeError() {
+    const SE3Quat& T = static_cast<const VertexSE3Expmap*>(_vertices[0])->estimate();
+    const Eigen::Matrix3d &R = T.rotationMatrix(), &Rp = _measurement.rotationMatrix();
+    double M[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) M[i][j] = R(i, 0) * Rp(j, 0) + R(i, 1) * Rp(j, 1) + R(i, 2) * Rp(j, 2);   // R Rp'
+    for (int i = 0; i < 3; ++i) _error[i] = T.translation()[i] - _measurement.translation()[i];
+    _error[3] = 0.5 * (M[2][1] - M[1][2]);
+    _error[4] = 0.5 * (M[0][2] - M[2][0]);
+    _error[5] = 0.5 * (M[1][0] - M[0][1]);
+  }
+};
+
 class EdgeSE2SensorCalib : public BaseMultiEdge<3, SE2> {
  public:
   EdgeSE2SensorCalib() { resize(3); }
@@ -382,6 +401,31 @@ int main(int argc, char** argv) {
         optimizer.addEdge(e);
         ++nedges;
       }
+    }
+    // "bench:P:L:K:prior": a unary prior on the first free camera (an edge type no device front end knows); ":huber": a Huber
+    // kernel (delta 1) on every projection edge
+    const std::string benchOpts(argv[6]);
+    if (benchOpts.find(":huber") != std::string::npos) {
+      for (size_t k = 0; k < optimizer.edges().size(); ++k) {
+        RobustKernelHuber* rk = new RobustKernelHuber();
+        rk->setDelta(1.0);
+        optimizer.edges()[k]->setRobustKernel(rk);
+      }
+    }
+    if (benchOpts.find(":prior") != std::string::npos) {
+      EdgeCameraPrior* e = new EdgeCameraPrior();
+      e->setVertex(0, cams[2]);
+      Eigen::Matrix3d R;
+      R.setIdentity();
+      Vector3d t;
+      t[0] = -2 * spacing; t[1] = 0; t[2] = 0;
+      e->setMeasurement(SE3Quat(R, t));
+      Eigen::Matrix<double, 6, 6> info;
+      info.setIdentity();
+      for (int i = 0; i < 6; ++i) info(i, i) = 100.0;
+      e->setInformation(info);
+      optimizer.addEdge(e);
+      ++nedges;
     }
     const double tGraph = get_monotonic_time() - t0;
     optimizer.setAlgorithm(algo);

@@ -646,3 +646,33 @@ def test_threaded_edge_classification_equals_the_sequential_grouping(host, tmp_p
         assert par["trials"] == seq["trials"]
         assert np.allclose(par["chi2"], seq["chi2"], rtol=1e-10, atol=0) and np.allclose(par["lambda"], seq["lambda"], rtol=1e-10, atol=0)
         assert relerr(np.array(par["cams"]), np.array(seq["cams"])) < 1e-10
+
+
+def test_hybrid_device_loop_with_a_prior_edge_no_front_end_knows(host, tmp_path):
+    """One edge type outside the device front ends used to send lm_fix*_hipdev back to g2o's host loop for the WHOLE graph.  The
+    hybrid loop keeps the bundle-adjustment group on the device and linearises only the foreign edges on the host (their vertices'
+    trial estimates read back per trial, under push / pop): a user-defined unary prior on one camera (EdgeCameraPrior of the test
+    host: BaseUnaryEdge, numeric Jacobian) next to 100 000 Huber-weighted observations walks the trajectory of the host loop
+    (lm_fix6_3_hip: g2o's own Levenberg-Marquardt over the same solver), chi2 evaluated by the host on the written-back vertices;
+    G2OHIP_ADAPTER_HYBRID=0 is the old behaviour (host loop, same trajectory)."""
+    exe, plugin = host
+
+    def run(solver, env=None):
+        out = str(tmp_path / ("%s_%d.json" % (solver, len(env or {}))))
+        e = dict(os.environ, G2OHIP_ADAPTER_VERBOSE="1")
+        e.update(env or {})
+        r = subprocess.run([exe, "none", plugin, solver, "5", out, "bench:2000:20000:5:prior:huber"], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        d = json.load(open(out))
+        return d["chi2_initial"], [it["chi2"] for it in d["iterations"]], [it["levenbergIterations"] for it in d["iterations"]], r.stderr
+
+    c0_ref, ref, tr_ref, _ = run("lm_fix6_3_hip")
+    c0_h, hyb, tr_h, err_h = run("lm_fix6_3_hipdev")
+    c0_o, off, tr_o, err_o = run("lm_fix6_3_hipdev", {"G2OHIP_ADAPTER_HYBRID": "0"})
+    assert "hybrid device loop -- 1 host-linearised edges over 1 free vertices" in err_h and DEV_ON in err_h
+    assert "hybrid device loop" not in err_o and DEV_OFF in err_o
+    assert c0_ref == c0_h == c0_o and len(ref) == 5
+    assert ref[-1] < 0.1 * c0_ref
+    assert tr_h == tr_ref and tr_o == tr_ref
+    assert np.allclose(hyb, ref, rtol=1e-7, atol=0), (hyb, ref)     # (bench mode prints 9 digits)
+    assert np.allclose(off, ref, rtol=1e-7, atol=0)
