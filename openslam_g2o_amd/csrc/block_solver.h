@@ -155,6 +155,7 @@ class BlockSolver {
   int sharded_merge = 1;                   // sharded solve: TWO all-reduces instead of three -- the boundary blocks and b_p travel with the
                                            // subtree roots (after the own subtrees) whenever only the shared top of the tree consumes them
   size_t sharded_collectives = 0;          // all-reduces issued by the last solve_sharded_once (stats)
+  bool setup_overlap = true;               // build_structure: the symbolic analysis of the reduced system on a thread of its own next to the Schur tiles' set-up
   int sharded_selftest = 1;                // the first solve_sharded of a structure runs twice (as configured / reference schedule) and falls back to the
                                            // reference schedule when the two disagree (see solve_sharded)
   bool selftest_fallback() const { return selftest_fallback_; }

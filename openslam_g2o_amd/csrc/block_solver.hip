@@ -2404,6 +2404,13 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     fprintf(stderr, "build_structure: %-34s %.3f s\n", what, t - lap_t);
     lap_t = t;
   };
+  std::unique_ptr<SparseCholesky> new_chol;   // (Schur mode: analysed on a thread of its own, below)
+  std::thread analysis_thread;
+  std::exception_ptr analysis_error;
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() { if (t.joinable()) t.join(); }   // (an exception on this thread must not leave the other one running into freed vectors)
+  } analysis_joiner{analysis_thread};
   // ---- validate sets, vertex classes
   for (auto& esp : sets_) {
     EdgeSet& es = *esp;
@@ -2618,6 +2625,20 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
         },
         nP, nP, hs_colptr, hs_row);
     lap("Schur pattern");
+    // The symbolic analysis of the reduced system (nested dissection, supernodes, frontal matrices, launch plans: 0.08 s at the
+    // metric configuration) needs nothing but this pattern: it runs on a thread of its own next to the Schur tiles' set-up below.
+    new_chol = std::make_unique<SparseCholesky>(p);
+    new_chol->opt = chol_opt;
+    if (setup_overlap) {
+      analysis_thread = std::thread([&] {
+        try {
+          G2OHIP_HIP_CHECK(hipSetDevice(device_));
+          new_chol->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
+        } catch (...) {
+          analysis_error = std::current_exception();
+        }
+      });
+    }
     const int hs_nnzb = (int)hs_row.size();
     rd_ptr_h_.clear();
     rd_slot_h_.clear();
@@ -2898,15 +2919,21 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   pcg_hpp_.reset();
   mh_hpp_.reset();
   mf_ready_ = false;
-  chol_ = std::make_unique<SparseCholesky>(p);
-  chol_->opt = chol_opt;
+  if (analysis_thread.joinable()) {
+    analysis_thread.join();
+    if (analysis_error) std::rethrow_exception(analysis_error);
+    chol_ = std::move(new_chol);
+  } else {
+    chol_ = new_chol ? std::move(new_chol) : std::make_unique<SparseCholesky>(p);
+    chol_->opt = chol_opt;
+    if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
+    else chol_->analyze(nP, pp_colptr.data(), pp_row.data(), st_);
+  }
   // (the exchange of a sharded job was set up for the previous structure: its index lists address the old pattern and a merged
   // payload (sharded_merge) lives behind the previous Cholesky's exchange buffer -- gone with it)
   ex_ = Exchange();
   selftest_done_ = false;
-  if (schur_) chol_->analyze(nP, hs_colptr.data(), hs_row.data(), st_);
-  else chol_->analyze(nP, pp_colptr.data(), pp_row.data(), st_);
-  lap("symbolic analysis");
+  lap("symbolic analysis (what the tiles' set-up did not hide)");
   n_active_ = -1;
   hschur_valid_ = true;
   {

@@ -593,6 +593,7 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "sharded_graph")) s->impl->sharded_graph = (int)value;
   else if (!std::strcmp(name, "sharded_merge")) s->impl->sharded_merge = (int)value;
   else if (!std::strcmp(name, "sharded_selftest")) s->impl->sharded_selftest = (int)value;
+  else if (!std::strcmp(name, "setup_overlap")) s->impl->setup_overlap = value != 0.0;
   else if (!std::strcmp(name, "sharded_selftest_break")) s->impl->selftest_break = (int)value;   // (tests: corrupt the first variant solve)
   else if (!std::strcmp(name, "rhs_prefill")) s->impl->rhs_prefill = value != 0.0;
   else if (!std::strcmp(name, "sharded_virtual")) s->impl->sharded_virtual = (int)value;

@@ -32,9 +32,11 @@ np.savez(sys.argv[1], x=x, b=s.b(), chi2=np.array([s.chi2()]), hs=np.asarray(hs)
 """
 
 
-def _run(tmp_path, threads):
-    out = str(tmp_path / ("t%d.npz" % threads))
+def _run(tmp_path, threads, options=""):
+    out = str(tmp_path / ("t%d%s.npz" % (threads, "o" if options else "")))
     env = dict(os.environ, G2OHIP_HOST_THREADS=str(threads))
+    if options:
+        env["G2OHIP_OPTIONS"] = options
     r = subprocess.run([sys.executable, "-c", SCRIPT % ROOT, out], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(out)
@@ -42,6 +44,8 @@ def _run(tmp_path, threads):
 
 def test_setup_tables_do_not_depend_on_the_number_of_host_threads(tmp_path):
     a, b = _run(tmp_path, 1), _run(tmp_path, 8)
+    c = _run(tmp_path, 8, "setup_overlap=0")     # (the symbolic analysis behind the Schur tiles' set-up instead of next to it)
     for k in ("x", "b", "chi2", "hs"):
         assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], c[k]), k
     assert np.isfinite(a["x"]).all() and np.abs(a["x"]).max() > 0

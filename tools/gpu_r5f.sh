@@ -1,7 +1,7 @@
 #!/bin/bash
 make -s -C tests/cpp/mini_g2o || exit 1
 B=tests/cpp/mini_g2o/build
-for th in "" 128; do
+for th in ""; do
 env G2OHIP_ADAPTER_TIMING=1 G2OHIP_SETUP_TIMING=1 ${th:+G2OHIP_ADAPTER_THREADS=$th} $B/g2o_host none $B/libg2o_solver_hip.so lm_fix6_3_hipdev 8 /tmp/ab.json bench:100000:1000000:5 2> gpurun_out/r5f_setup_$th.err
 python3 - <<EOP
 import json
