@@ -18,7 +18,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <functional>
+#include <iomanip>
 #include <iostream>
 #include <map>
 #include <mutex>
@@ -737,6 +739,10 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     const int rc = g2ohip_solve(_h);
     if (rc != G2OHIP_OK) {
       if (rc != G2OHIP_NOT_PD) fail("solve");
+      else if (_writeDebug) {   // linear_solver_csparse.h:127-133: the matrix the Cholesky was given, loadable by Octave
+        std::cerr << "Cholesky failure, writing debug.txt (Hessian loadable by Octave)" << std::endl;
+        writeOctave("debug.txt", (_doSchur && _nL > 0) ? G2OHIP_HSCHUR : G2OHIP_HPP, /*fixed=*/false);
+      }
       return false;
     }
     _phase.deviceSolve += lap(t);
@@ -795,7 +801,9 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   virtual void setSchur(bool s) { _doSchur = s; }
   virtual void setWriteDebug(bool b) { _writeDebug = b; }
   virtual bool writeDebug() const { return _writeDebug; }
-  virtual bool saveHessian(const std::string& fileName) const { (void)fileName; return false; }
+  // block_solver.hpp:628-632: _Hpp->writeOctave(fileName, true) -- the upper blocks of Hpp as an Octave sparse matrix (both triangles,
+  // sorted by column, nine fixed digits: sparse_block_matrix.hpp:548-589)
+  virtual bool saveHessian(const std::string& fileName) const { return _h && writeOctave(fileName, G2OHIP_HPP, /*fixed=*/true); }
   // BlockSolverBase (block_solver.h:83-91), used by OptimizationAlgorithmDogleg: dest = H * src
   virtual void multiplyHessian(double* dest, const double* src) const { if (_h) g2ohip_multiply_hessian(_h, dest, src); }
 
@@ -1073,6 +1081,49 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
       if (fast && (fast == 1 ? ba(_h) : pg(_h)) != G2OHIP_OK) return fail(what);
     }
     return true;
+  }
+
+  // A block matrix of the library (upper triangle, p x p blocks) as the text file the reference's writeOctave / writeCs2Octave produce
+  // (csparse_helper.cpp:145-197): "r c value" with one-based indices, both triangles, sorted by column then row.
+  bool writeOctave(const std::string& fileName, int which, bool fixed) const {
+    int nnzb = 0;
+    if (g2ohip_get_nnzb(_h, which, &nnzb) != G2OHIP_OK || nnzb <= 0) return false;
+    std::vector<int32_t> colptr(_nP + 1), rowidx(nnzb);
+    std::vector<double> val((size_t)nnzb * p * p);
+    if (g2ohip_get_pattern(_h, which, colptr.data(), rowidx.data()) != G2OHIP_OK || g2ohip_copy_values(_h, which, val.data()) != G2OHIP_OK) return false;
+    struct Entry {
+      int r, c;
+      double x;
+      bool operator<(const Entry& o) const { return c < o.c || (c == o.c && r < o.r); }
+    };
+    std::vector<Entry> entries;
+    for (int c = 0; c < _nP; ++c)
+      for (int q = colptr[c]; q < colptr[c + 1]; ++q) {
+        const int r = rowidx[q];
+        for (int cc = 0; cc < p; ++cc)
+          for (int rr = 0; rr < p; ++rr) {
+            const double x = val[(size_t)q * p * p + rr + p * cc];   // (column-major blocks)
+            if (r == c && rr > cc) continue;                          // (the diagonal blocks hold both halves: once)
+            Entry e = {r * p + rr, c * p + cc, x};
+            entries.push_back(e);
+            if (e.r != e.c) {
+              Entry m = {e.c, e.r, x};
+              entries.push_back(m);
+            }
+          }
+      }
+    std::sort(entries.begin(), entries.end());
+    std::string name = fileName;
+    const std::string::size_type lastDot = name.find_last_of('.');
+    if (lastDot != std::string::npos) name = name.substr(0, lastDot);
+    std::ofstream fout(fileName.c_str());
+    fout << "# name: " << name << std::endl << "# type: sparse matrix" << std::endl << "# nnz: " << entries.size() << std::endl;
+    fout << "# rows: " << _nP * p << std::endl << "# columns: " << _nP * p << std::endl;
+    fout << std::setprecision(9);
+    if (fixed) fout << std::fixed;
+    fout << std::endl;
+    for (size_t i = 0; i < entries.size(); ++i) fout << entries[i].r + 1 << " " << entries[i].c + 1 << " " << entries[i].x << std::endl;
+    return fout.good();
   }
 
   static double lap(double& t) {

@@ -632,7 +632,14 @@ int main(int argc, char** argv) {
     js << "], \"points\": [";
     for (int i = 0; i < npts; ++i)
       for (int k = 0; k < 3; ++k) js << (i || k ? ", " : "") << pts[i]->estimate()[k];
-    js << "]}";
+    js << "]";
+    // G2OHIP_TEST_SAVE_HESSIAN=<file>: Solver::saveHessian through the vtable (`g2o -solver ... ` has no switch for it, a
+    // user's program calls it on the solver; block_solver.hpp:628-632)
+    if (const char* hf = std::getenv("G2OHIP_TEST_SAVE_HESSIAN")) {
+      OptimizationAlgorithmWithHessian* wh = dynamic_cast<OptimizationAlgorithmWithHessian*>(algo);
+      js << ", \"saveHessian\": " << ((wh && wh->solver() && wh->solver()->saveHessian(hf)) ? "true" : "false");
+    }
+    js << "}";
   }
   std::ofstream(argv[5]) << js.str() << std::endl;
   // (the optimizer's destructor deletes the algorithm, that one the Solver, that one its LinearSolver: the ownership chain of

@@ -676,3 +676,37 @@ def test_hybrid_device_loop_with_a_prior_edge_no_front_end_knows(host, tmp_path)
     assert tr_h == tr_ref and tr_o == tr_ref
     assert np.allclose(hyb, ref, rtol=1e-7, atol=0), (hyb, ref)     # (bench mode prints 9 digits)
     assert np.allclose(off, ref, rtol=1e-7, atol=0)
+
+
+def test_save_hessian_writes_the_octave_file_of_the_reference(host, tmp_path):
+    """Solver::saveHessian (block_solver.hpp:628-632 -> SparseBlockMatrix::writeOctave(fileName, true), sparse_block_matrix.hpp:548-589)
+    through the vtable: header, one-based "r c value" triplets of BOTH triangles sorted by column, and the values = Hpp of the last
+    buildSystem -- rebuilt here by the oracle at the written-back estimates (LM ends an iteration on an accepted step, so the last
+    system was linearised at the estimates of the iteration before: one iteration is run and compared at the INITIAL estimates)."""
+    pr = ba_case(12, 80)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr)
+    hfile = str(tmp_path / "hpp.txt")
+    out, err = _run(host, prob, "lm_fix6_3_hip", 1, str(tmp_path / "o.json"), {"G2OHIP_TEST_SAVE_HESSIAN": hfile})
+    assert out["saveHessian"] is True
+    lines = open(hfile).read().split("\n")
+    assert lines[0] == "# name: " + hfile[:-4] and lines[1] == "# type: sparse matrix"
+    nnz, rows, cols = (int(lines[k].split(": ")[1]) for k in (2, 3, 4))
+    assert rows == cols == 6 * pr["nP"]
+    trip = np.array([[float(v) for v in l.split()] for l in lines[6:] if l.strip()])
+    assert len(trip) == nnz
+    r, c = trip[:, 0].astype(int) - 1, trip[:, 1].astype(int) - 1
+    assert np.all(np.diff(c * rows + r) > 0)                      # sorted by column, then row; no duplicates
+    H = np.zeros((rows, cols))
+    H[r, c] = trip[:, 2]
+    assert np.array_equal(H, H.T)
+    o = oracle_ba(pr)
+    o.build_system()
+    cp, ri = o.pattern("pp")
+    V = o.values("Hpp").reshape(-1, 6, 6)
+    Ho = np.zeros_like(H)
+    for col in range(pr["nP"]):
+        for q in range(cp[col], cp[col + 1]):
+            Ho[ri[q] * 6:ri[q] * 6 + 6, col * 6:col * 6 + 6] = V[q].T
+            Ho[col * 6:col * 6 + 6, ri[q] * 6:ri[q] * 6 + 6] = V[q]
+    assert np.abs(H - Ho).max() <= 1e-8 * np.abs(Ho).max() + 5e-10      # (nine fixed digits in the file)
