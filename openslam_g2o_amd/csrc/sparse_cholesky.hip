@@ -4188,7 +4188,11 @@ __global__ void __launch_bounds__(64) chain_backward_kernel(CholPlanDev P, const
     if (lane < kTreeBnd) tw[lane] = lane < T.nbs ? (src0 < 0 ? xs[-1 - src0 + off] : xb0) : 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef G2OHIP_CHAIN_ABL   // (timing experiment, wrong results: the memory side of the sweep alone)
+    const double xout = T.L21[0] + T.L11[0] + T.linv + T.yk + tw[lane & 31];
+#else
     const double xout = tree_front_solve<BS>(T, tw, lane, bw_parts(nt_ref, max(npiv, 1), m));
+#endif
     if (colk && h == 0) {
       xs[xoff + k] = xout;
       xp[(size_t)T.c0 * BS + k] = xout;
