@@ -207,7 +207,11 @@ int g2ohip_kernel_time(g2ohip_solver* s, int slot, double* total_seconds, long* 
  * together.  Without a pending g2ohip_solve_async it just evaluates the two sums.  *solve_ok: 1 solved, 0 not positive
  * definite, 2 the solve has to be REPEATED (a dependency-driven launch gave up waiting -- never observed, the safety net of
  * DESIGN.md section 2; g2ohip_solve repeats by itself, the asynchronous pair leaves it to the caller: pop the estimates,
- * run the trial again). */
+ * run the trial again).
+ * g2ohip_trial_stats_begin queues the sums and their read-back WITHOUT waiting; the next g2ohip_trial_stats then only waits and
+ * returns them (its lambda is ignored).  For a caller with host work to overlap: the adapter's LM driver queues the first trial of
+ * the NEXT iteration this way and writes the accepted estimates into g2o's vertices (SparseOptimizer::update's effect,
+ * sparse_optimizer.cpp:421-437) while the device works. */
 /* The reduced (Schur) system as an operator, never formed (what "linear_solver" 2 iterates on; callers that run their own
  * Krylov loop, e.g. sharded over GPUs with one all-reduce of the product per iteration, use these directly):
  * prepare: Dinv = (Hll + lambda_l I)^-1, bschur = b_p - Hpl Dinv b_l (g2ohip_device_array 100) and the diagonal blocks
@@ -216,6 +220,7 @@ int g2ohip_kernel_time(g2ohip_solver* s, int slot, double* total_seconds, long* 
 int g2ohip_schur_operator_prepare(g2ohip_solver* s);
 int g2ohip_schur_operator_apply(g2ohip_solver* s, const double* in_device, double* out_device);
 int g2ohip_solve_async(g2ohip_solver* s);
+int g2ohip_trial_stats_begin(g2ohip_solver* s, double lambda);
 int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* chi2, double* scale);
 /* Options (name, value).  Linear solver of the reduced system: "linear_solver" 0 = multifrontal block Cholesky
  * (replaces LinearSolverCSparse / LinearSolverCholmod), 1 = block-Jacobi preconditioned CG (replaces

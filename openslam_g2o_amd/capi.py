@@ -55,7 +55,7 @@ EXPORTS = [
     "g2ohip_set_lambda_split", "g2ohip_host_register", "g2ohip_host_unregister", "g2ohip_ba_set_edges", "g2ohip_ba_set_edges_classes", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates", "g2ohip_ba_fetch_estimates_begin", "g2ohip_ba_fetch_estimates_wait",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
     "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
-    "g2ohip_schur_operator_prepare", "g2ohip_schur_operator_apply", "g2ohip_solve_async", "g2ohip_trial_stats", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
+    "g2ohip_schur_operator_prepare", "g2ohip_schur_operator_apply", "g2ohip_solve_async", "g2ohip_trial_stats_begin", "g2ohip_trial_stats", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
     "g2ohip_get_partition", "g2ohip_partition_poses",
     "g2ohip_pg_set_edges", "g2ohip_pg_set_estimates", "g2ohip_pg_get_estimates", "g2ohip_pg_linearize", "g2ohip_pg_update",
     "g2ohip_pg_push", "g2ohip_pg_pop", "g2ohip_pg_discard_top", "g2ohip_copy_edge_data",
@@ -118,6 +118,7 @@ def load():
         getattr(L, n).argtypes = [vp]
     L.g2ohip_exchange_setup.argtypes = [vp, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_dbl_p]
     L.g2ohip_trial_stats.argtypes = [vp, C.c_double, c_int_p, c_dbl_p, c_dbl_p]
+    L.g2ohip_trial_stats_begin.argtypes = [vp, C.c_double]
     L.g2ohip_schur_operator_prepare.argtypes = [vp]
     L.g2ohip_schur_operator_apply.argtypes = [vp, C.c_void_p, C.c_void_p]
     L.g2ohip_exchange_pack.argtypes = [vp, C.c_int]
@@ -390,6 +391,10 @@ class HipBlockSolver:
 
     def solveAsync(self):
         _check(self.L.g2ohip_solve_async(self.h), "solveAsync")
+
+    def trialStatsBegin(self, lam):
+        """Queue the sums of trialStats and their read-back without waiting; the next trialStats returns them."""
+        _check(self.L.g2ohip_trial_stats_begin(self.h, float(lam)), "trialStatsBegin")
 
     def trialStats(self, lam):
         """(solve status of a pending solveAsync, chi2, computeScale(lam)) behind one synchronisation."""

@@ -13,6 +13,8 @@
 // save) sees what it would have seen.  The decisions are those of optimization_algorithm_levenberg.cpp:57-146 and
 // optimization_algorithm_gauss_newton.cpp:50-93, taken on the same numbers.
 //   G2OHIP_ADAPTER_DEVICE_LOOP=0   always g2o's host loop (A/B)
+//   G2OHIP_ADAPTER_LOOKAHEAD=0     the LM driver does not queue the next iteration's first trial before the write-back (A/B; see
+//                                  lookAhead below: same numbers, the device idles during the write-back)
 //   G2OHIP_ADAPTER_WRITEBACK=0     estimates are NOT written back after every iteration (timing experiments only: the
 //                                  vertices then keep their initial estimates)
 // Not mirrored from the host loop: the edges' _error members are not refreshed (computeActiveErrors() does that on demand)
@@ -57,7 +59,7 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
  public:
   explicit OptimizationAlgorithmLevenbergHip(Solver* solver)
       : OptimizationAlgorithmLevenberg(solver), _dev(dynamic_cast<HipDeviceGraph*>(solver)), _resident(false),
-        _writeBack(!hip_detail::envOff("G2OHIP_ADAPTER_WRITEBACK")), _fetched(false), _accepted(false) {}
+        _writeBack(!hip_detail::envOff("G2OHIP_ADAPTER_WRITEBACK")), _fetched(false), _accepted(false), _lookChi(0.) {}
 
   //! did the last solve() run on the device?
   bool deviceLoopActive() const { return _resident; }
@@ -75,57 +77,65 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
 
     double t = get_monotonic_time();
     G2OBatchStatistics* globalStats = G2OBatchStatistics::globalStats();
-    // a new optimize() (the caller may have changed the vertices), online growth, or a structure rebuilt under us
-    if (iteration == 0 || online || !_dev->devEstimatesValid()) {
-      if (!_dev->devSetEstimates()) return OptimizationAlgorithm::Fail;
-    }
-    if (!_dev->devLinearize(true)) return OptimizationAlgorithm::Fail;       // computeActiveErrors + what buildSystem linearises
+    // The previous solve() of this optimize() may have queued this iteration's head (see lookAhead): errors, chi2, buildSystem
+    // and the first trial at _currentLambda are in flight or done.  Anything but the next iteration of the same run drops it.
+    const bool consume = _dev->devLookAheadPending() && iteration > 0 && !online && _dev->devEstimatesValid();
+    if (!consume) _dev->devDropLookAhead();
     double currentChi = 0.;
-    if (!_dev->devChi2(currentChi)) return OptimizationAlgorithm::Fail;      // activeRobustChi2
-    if (globalStats) {
-      globalStats->timeResiduals = get_monotonic_time() - t;
-      t = get_monotonic_time();
+    if (consume) {
+      _dev->devSetLookAheadPending(false);              // (from here on the solver's entry points are this driver's own calls)
+      currentChi = _lookChi;
+    } else {
+      // a new optimize() (the caller may have changed the vertices), online growth, or a structure rebuilt under us
+      if (iteration == 0 || online || !_dev->devEstimatesValid()) {
+        if (!_dev->devSetEstimates()) return OptimizationAlgorithm::Fail;
+      }
+      if (!_dev->devLinearize(true)) return OptimizationAlgorithm::Fail;       // computeActiveErrors + what buildSystem linearises
+      if (!_dev->devChi2(currentChi)) return OptimizationAlgorithm::Fail;      // activeRobustChi2
+      if (globalStats) {
+        globalStats->timeResiduals = get_monotonic_time() - t;
+        t = get_monotonic_time();
+      }
+      if (!_dev->devBuildSystem()) return OptimizationAlgorithm::Fail;
+      if (globalStats) globalStats->timeQuadraticForm = get_monotonic_time() - t;
+
+      if (iteration == 0) {                                // computeLambdaInit, levenberg.cpp:149-163
+        double maxDiagonal = 0.;
+        if (userLambdaInit() > 0) {
+          _currentLambda = userLambdaInit();
+        } else {
+          if (!_dev->devMaxDiagonal(maxDiagonal)) return OptimizationAlgorithm::Fail;
+          _currentLambda = _tau * maxDiagonal;
+        }
+        _ni = 2;
+      }
+      _fetched = false;
     }
     double tempChi = currentChi;
-    if (!_dev->devBuildSystem()) return OptimizationAlgorithm::Fail;
-    if (globalStats) globalStats->timeQuadraticForm = get_monotonic_time() - t;
-
-    if (iteration == 0) {                                // computeLambdaInit, levenberg.cpp:149-163
-      double maxDiagonal = 0.;
-      if (userLambdaInit() > 0) {
-        _currentLambda = userLambdaInit();
-      } else {
-        if (!_dev->devMaxDiagonal(maxDiagonal)) return OptimizationAlgorithm::Fail;
-        _currentLambda = _tau * maxDiagonal;
-      }
-      _ni = 2;
-    }
 
     double rho = 0;
     int& qmax = _levenbergIterations;
     qmax = 0;
-    _fetched = false;
     _accepted = false;
+    bool queued = consume;                               // the first trial is already on the device
     do {
-      if (_fetched) {                                    // (the read-back of a rejected trial: its buffers are about to be reused)
-        _dev->devFetchCancel();
-        _fetched = false;
-      }
-      if (!_dev->devPush()) return OptimizationAlgorithm::Fail;
+      double scale = 0.;
+      int ok2 = -1;
       if (globalStats) {
         globalStats->levenbergIterations++;
         t = get_monotonic_time();
       }
-      _solver->setLambda(_currentLambda, true);
-      // solve, update, restoreDiagonal, computeActiveErrors queued back to back; status, chi2 and computeScale in ONE read-back
-      double scale = 0.;
-      int ok2 = -1;
-      if (_dev->devSolveAsync() && _dev->devUpdate()) {
-        // the trial's estimates start their way to the host next to its error evaluation (written into the vertices by
-        // finish() if the trial is accepted)
-        if (_writeBack) _fetched = _dev->devFetchBegin();
-        _solver->restoreDiagonal();
-        if (_dev->devLinearize(false)) ok2 = _dev->devTrialStats(_currentLambda, tempChi, scale);
+      if (queued) {
+        queued = false;
+        ok2 = _dev->devTrialStats(_currentLambda, tempChi, scale);
+      } else {
+        if (_fetched) {                                    // (the read-back of a rejected trial: its buffers are about to be reused)
+          _dev->devFetchCancel();
+          _fetched = false;
+        }
+        if (!_dev->devPush()) return OptimizationAlgorithm::Fail;
+        // solve, update, restoreDiagonal, computeActiveErrors queued back to back; status, chi2 and computeScale in ONE read-back
+        if (queueTrial(/*fetch=*/true)) ok2 = _dev->devTrialStats(_currentLambda, tempChi, scale);
       }
       if (ok2 == 2) {                                    // (a dependency-driven launch gave up waiting: the trial again, synchronously)
         if (_fetched) _dev->devFetchCancel();
@@ -143,7 +153,7 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
       }
       if (ok2 < 0) {
         _dev->devPop();
-        finish(globalStats);
+        finish(globalStats, false, currentChi);
         return OptimizationAlgorithm::Fail;
       }
       if (globalStats) globalStats->timeLinearSolution += get_monotonic_time() - t;
@@ -173,20 +183,59 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
       qmax++;
     } while (rho < 0 && qmax < maxTrialsAfterFailure() && !_optimizer->terminate());
 
-    if (!finish(globalStats)) return OptimizationAlgorithm::Fail;
-    if (qmax == maxTrialsAfterFailure() || rho == 0) return Terminate;
+    const bool goesOn = !(qmax == maxTrialsAfterFailure() || rho == 0);
+    // (iteration 0 never looks ahead: a caller that runs optimize(1) in a loop would pay for a trial it always drops)
+    if (!finish(globalStats, goesOn && iteration > 0 && !online, currentChi)) return OptimizationAlgorithm::Fail;
+    if (!goesOn) return Terminate;
     return OK;
   }
 
  private:
+  // One trial behind devPush(), queued without a synchronisation: setLambda, solve, update, (the read-back of the trial's
+  // estimates starts next to its error evaluation), restoreDiagonal, computeActiveErrors.  levenberg.cpp:98-117.
+  bool queueTrial(bool fetch) {
+    _solver->setLambda(_currentLambda, true);
+    if (!_dev->devSolveAsync() || !_dev->devUpdate()) return false;
+    if (fetch && _writeBack) _fetched = _dev->devFetchBegin();
+    _solver->restoreDiagonal();
+    return _dev->devLinearize(false);
+  }
+  // The head of the NEXT solve(), queued before the accepted estimates are written into the vertices: the same calls in the same
+  // order as solve() makes them (devLinearize / devChi2 find the trial's evaluation still valid: no kernel, no synchronisation),
+  // so the numbers are those of the run without look-ahead.  The read-back of THIS trial's estimates has to wait until the
+  // write-back has emptied the host buffers: begun by finish().
+  bool lookAhead(double& chi) {
+    _dev->devSetQueueing(true);
+    bool ok = _dev->devLinearize(true) && _dev->devChi2(chi) && _dev->devBuildSystem() && _dev->devPush();
+    if (ok) ok = queueTrial(/*fetch=*/false) && _dev->devTrialStatsBegin(_currentLambda);
+    _dev->devSetQueueing(false);
+    return ok;
+  }
   // the accepted estimates into the vertices (what SparseOptimizer::update / pop left there in the host loop)
   // (the loop ends with an accepted trial or with the estimates popped back to what the vertices already hold: only an accepted
   // trial has anything to write; its read-back has been in flight since its update)
-  bool finish(G2OBatchStatistics* globalStats) {
+  bool finish(G2OBatchStatistics* globalStats, bool mayLookAhead, double currentChi) {
     const double t = get_monotonic_time();
     bool ok = true;
-    if (_fetched && !_accepted) _dev->devFetchCancel();
-    else if (_writeBack && _accepted) ok = _fetched ? _dev->devFetchEnd() : _dev->devGetEstimates();
+    if (_fetched && !_accepted) {
+      _dev->devFetchCancel();
+    } else if (_writeBack && _accepted) {
+      bool ahead = mayLookAhead && _fetched && _dev->devCanLookAhead();
+      if (ahead) {
+        double chi = 0.;
+        if (!lookAhead(chi)) return false;
+        _lookChi = chi;
+        (void)currentChi;                                // (== chi: the accepted trial's sum, cached by the library)
+      }
+      ok = _fetched ? _dev->devFetchEnd() : _dev->devGetEstimates();
+      _fetched = false;
+      if (ahead) {
+        _fetched = _dev->devFetchBegin();                // the queued trial's estimates, behind its update
+        _dev->devSetLookAheadPending(true);
+      }
+      if (globalStats) globalStats->timeUpdate = get_monotonic_time() - t;
+      return ok;
+    }
     _fetched = false;
     if (globalStats) globalStats->timeUpdate = get_monotonic_time() - t;
     return ok;
@@ -194,6 +243,7 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
   HipDeviceGraph* _dev;
   bool _resident, _writeBack;
   bool _fetched, _accepted;   // the current trial's estimates are on their way to the host; a trial of this iteration was accepted
+  double _lookChi;            // chi2 at the estimates the queued look-ahead trial starts from
 };
 
 class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNewton {

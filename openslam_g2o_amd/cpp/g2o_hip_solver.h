@@ -175,6 +175,18 @@ class HipDeviceGraph {
   virtual bool devPush() = 0;
   virtual bool devPop() = 0;
   virtual bool devDiscardTop() = 0;
+  // Look-ahead (Levenberg-Marquardt driver): once a trial has been accepted the driver queues the head of the NEXT solve() --
+  // errors, buildSystem, push, setLambda, solve, update, errors, the trial's sums (devTrialStatsBegin: no synchronisation) --
+  // BEFORE it writes the accepted estimates into the vertices, so that the device works while the host stores.  The solver
+  // remembers that such a trial is in flight (devSetLookAheadPending); the next solve() of the same optimize() consumes it,
+  // anything else that enters the solver first (a new optimize(), computeMarginals, buildSystem, the destructor) drops it:
+  // the sums are drained and the estimates popped, the device holds what the vertices hold (devDropLookAhead).
+  virtual bool devCanLookAhead() const { return false; }
+  virtual bool devTrialStatsBegin(double /*lambda*/) { return false; }
+  virtual bool devLookAheadPending() const { return false; }
+  virtual void devSetLookAheadPending(bool) {}
+  virtual void devDropLookAhead() {}
+  virtual void devSetQueueing(bool) {}               // (while the look-ahead is being queued: no timing synchronisation)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -198,7 +210,9 @@ class HipDeviceGraph {
 template <int p, int l>
 class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
  public:
-  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0), _devValid(false), _hybrid(false), _touchedPushed(false), _fetchBegun(false) {
+  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0), _devValid(false), _hybrid(false), _touchedPushed(false), _fetchBegun(false), _lookPending(false), _lookEnabled(true), _queueing(false) {
+    const char* la = std::getenv("G2OHIP_ADAPTER_LOOKAHEAD");   // 0: the LM driver never queues the next iteration's first trial early (A/B)
+    if (la && la[0] == '0') _lookEnabled = false;
     const char* fp = std::getenv("G2OHIP_ADAPTER_FASTPATH");
     if (fp && fp[0] == '0') _fastPath = false;
     const char* pin = std::getenv("G2OHIP_ADAPTER_PINNED");
@@ -219,6 +233,9 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     }
   }
   virtual ~BlockSolverHip() {
+    devDropLookAhead();
+    if (_lookQueued > 0 && std::getenv("G2OHIP_ADAPTER_VERBOSE"))
+      std::cerr << "BlockSolverHip: look-ahead trials queued " << _lookQueued << ", dropped " << _lookDropped << std::endl;
     if (_timing && _phase.buildSystems > 0) printPhases(std::cerr);
     unpinAll();
     if (_h) g2ohip_destroy(_h);
@@ -252,6 +269,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   // block_solver.hpp:606-620: store the optimizer, drop numeric / symbolic state
   virtual bool init(SparseOptimizer* optimizer, bool online = false) {
     (void)online;
+    devDropLookAhead();
     _optimizer = optimizer;
     _groups.clear();
     _multi.clear();
@@ -262,6 +280,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   // (optimization_algorithm_levenberg.cpp:62-68), so the edge sets are registered exactly once per init()
   virtual bool buildStructure(bool zeroBlocks = false) {
     (void)zeroBlocks;
+    devDropLookAhead();
     return buildStructureImpl(_fastPath, _fastPath);
   }
 
@@ -606,6 +625,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   // marginalised vertices the reference aborts (:313-316); here the call reports failure.
   virtual bool updateStructure(const std::vector<HyperGraph::Vertex*>& vset, const HyperGraph::EdgeSet& edges) {
     (void)edges;
+    devDropLookAhead();
     for (size_t i = 0; i < vset.size(); ++i)
       if (static_cast<OptimizableGraph::Vertex*>(vset[i])->marginalized()) {
         std::cerr << "updateStructure(): Schur not supported" << std::endl;
@@ -710,6 +730,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
 
   virtual bool buildSystem() {
     if (!_h) return false;
+    devDropLookAhead();
     // (the host-linearised groups first: handing a set its data for the first time drops the front ends' cached evaluations)
     if (!hostGeneric(/*computeErrors=*/false, /*jacobians=*/true)) return false;   // (the errors are current: computeActiveErrors)
     double t = get_monotonic_time();
@@ -735,6 +756,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   // positive definite
   virtual bool solve() {
     if (!_h) return false;
+    devDropLookAhead();
     double t = get_monotonic_time();
     const int rc = g2ohip_solve(_h);
     if (rc != G2OHIP_OK) {
@@ -768,12 +790,19 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   }
 
   // block_solver.hpp:563-604: lambda on every scalar diagonal entry of Hpp and Hll; exact restore
-  virtual bool setLambda(double lambda, bool backup = false) { return _h && g2ohip_set_lambda(_h, lambda, backup ? 1 : 0) == G2OHIP_OK; }
-  virtual void restoreDiagonal() { if (_h) g2ohip_restore_diagonal(_h); }
+  virtual bool setLambda(double lambda, bool backup = false) {
+    devDropLookAhead();
+    return _h && g2ohip_set_lambda(_h, lambda, backup ? 1 : 0) == G2OHIP_OK;
+  }
+  virtual void restoreDiagonal() {
+    devDropLookAhead();
+    if (_h) g2ohip_restore_diagonal(_h);
+  }
 
   // block_solver.hpp:489-498: blocks of the inverse of Hpp
   virtual bool computeMarginals(SparseBlockMatrix<MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices) {
     if (!_h) return false;
+    devDropLookAhead();
     const double t = get_monotonic_time();
     std::vector<int32_t> r(blockIndices.size()), c(blockIndices.size());
     for (size_t i = 0; i < blockIndices.size(); ++i) {
@@ -803,9 +832,15 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   virtual bool writeDebug() const { return _writeDebug; }
   // block_solver.hpp:628-632: _Hpp->writeOctave(fileName, true) -- the upper blocks of Hpp as an Octave sparse matrix (both triangles,
   // sorted by column, nine fixed digits: sparse_block_matrix.hpp:548-589)
-  virtual bool saveHessian(const std::string& fileName) const { return _h && writeOctave(fileName, G2OHIP_HPP, /*fixed=*/true); }
+  virtual bool saveHessian(const std::string& fileName) const {
+    const_cast<BlockSolverHip*>(this)->devDropLookAhead();
+    return _h && writeOctave(fileName, G2OHIP_HPP, /*fixed=*/true);
+  }
   // BlockSolverBase (block_solver.h:83-91), used by OptimizationAlgorithmDogleg: dest = H * src
-  virtual void multiplyHessian(double* dest, const double* src) const { if (_h) g2ohip_multiply_hessian(_h, dest, src); }
+  virtual void multiplyHessian(double* dest, const double* src) const {
+    const_cast<BlockSolverHip*>(this)->devDropLookAhead();
+    if (_h) g2ohip_multiply_hessian(_h, dest, src);
+  }
 
   // ---- HipDeviceGraph: the graph side of an iteration on the device front ends (g2ohip_ba_* / g2ohip_pg_*)
   // every active edge on a device front end -- or (hybrid) the bundle-adjustment front end plus groups the host linearises
@@ -914,11 +949,38 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   virtual bool devBuildSystem() {
     double t = get_monotonic_time();
     if (g2ohip_build_system(_h) != G2OHIP_OK) return fail("build_system");
-    if (_timing) g2ohip_sync(_h);
+    if (_timing && !_queueing) g2ohip_sync(_h);
     _phase.deviceBuild += lap(t);
     ++_phase.buildSystems;
     return true;
   }
+  // look-ahead (see HipDeviceGraph): only the bundle-adjustment front end with its pipelined write-back -- a pose-graph group's
+  // estimates are read back whole at the end of devFetchEnd, i.e. AFTER a queued update would have moved them, and the hybrid
+  // loop's host groups read the vertices the write-back is still filling
+  virtual bool devCanLookAhead() const {
+    if (!_lookEnabled || !_pin || _hybrid || !_multi.empty() || _groups.empty()) return false;
+    for (size_t gi = 0; gi < _groups.size(); ++gi)
+      if (_groups[gi].fast != 1) return false;
+    return true;
+  }
+  virtual bool devTrialStatsBegin(double lambda) { return g2ohip_trial_stats_begin(_h, lambda) == G2OHIP_OK || fail("trial_stats_begin"); }
+  virtual bool devLookAheadPending() const { return _lookPending; }
+  virtual void devSetLookAheadPending(bool on) {
+    _lookPending = on;
+    if (on) ++_lookQueued;
+  }
+  virtual void devSetQueueing(bool on) { _queueing = on; }
+  virtual void devDropLookAhead() {
+    if (!_lookPending) return;
+    _lookPending = false;
+    int ok = 0;
+    double chi2 = 0., scale = 0.;
+    (void)g2ohip_trial_stats(_h, 0., &ok, &chi2, &scale);   // (drains the queued read-back)
+    if (_fetchBegun) devFetchCancel();
+    (void)devPop();                                     // the device holds what the vertices hold again
+    ++_lookDropped;
+  }
+  int lookAheadsDropped() const { return _lookDropped; }
   virtual bool devMaxDiagonal(double& d) { return g2ohip_max_diagonal(_h, &d) == G2OHIP_OK || fail("max_diagonal"); }
   virtual bool devComputeScale(double lambda, double& scale) { return g2ohip_compute_scale(_h, lambda, &scale) == G2OHIP_OK || fail("compute_scale"); }
   virtual int devSolve() {
@@ -1533,6 +1595,8 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   };
   std::vector<Touched> _touched;
   bool _hybrid, _touchedPushed, _fetchBegun;
+  int _lookDropped = 0, _lookQueued = 0;
+  bool _lookPending, _lookEnabled, _queueing;          // look-ahead trial in flight | allowed (G2OHIP_ADAPTER_LOOKAHEAD) | being queued (no timing synchronisation)
   enum { kFetchPieces = 4 };                           // point ranges of the pipelined write-back (devFetchBegin / devFetchEnd)
   mutable HipWorkers _workers;                         // persistent helper threads of parallelFor
   std::vector<void*> _pinned;                          // buffers registered with g2ohip_host_register

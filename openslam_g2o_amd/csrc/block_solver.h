@@ -223,6 +223,7 @@ class BlockSolver {
   void schur_operator_apply(const double* din, double* dout);
   void solve_async();
   void trial_stats(double lambda, int* ok, double* chi2, double* scale);
+  void trial_stats_begin(double lambda);   // the queued half of trial_stats (kernels + read-back, no synchronisation)
   void exchange_setup(int nbb, const int* bblock, const double* hkeep, int nbp, const int* bpose, const double* bkeep, int nh,
                       const int* halo, const double* hmine);
   void exchange_pack(int which);     // 1: boundary Hschur blocks + boundary bschur -> buffer 105; 3: halo x (masked) + status -> 106
@@ -291,6 +292,13 @@ class BlockSolver {
   double* h_trial_ = nullptr;              // ... their pinned host copy (+ the factorisation status word): ONE synchronisation per trial
   size_t h_trial_n_ = 0;
   int sync_status_ = -1;                   // status of a solve_async() that had to run synchronously (-1: none)
+  struct TrialPending {                    // trial_stats_begin() -> trial_stats()
+    bool begun = false, bad = false, need_chi = false;
+    int mode = 0;                          // 1: the status word of an asynchronous solve is part of the read-back
+    size_t hn = 0;
+    std::vector<int> nblk;
+  } trial_;
+  hipEvent_t trial_ev_ = nullptr;
   bool deferred_status_ = false;           // a solve_async() whose status has not been read yet
   bool chi2_valid_ = false;                // chi2_value_ matches the errors / kernels of every edge set
   double chi2_value_ = 0.0;

@@ -2264,6 +2264,10 @@ BlockSolver::~BlockSolver() {
     (void)hipEventDestroy(fetch_fork_);
     for (int k = 0; k < kFetchMaxPieces; ++k) (void)hipEventDestroy(fetch_ev_[k]);
   }
+  if (trial_ev_) {
+    (void)hipEventSynchronize(trial_ev_);
+    (void)hipEventDestroy(trial_ev_);
+  }
   if (side_) (void)hipStreamDestroy(side_);
   if (side_fork_) (void)hipEventDestroy(side_fork_);
   if (side_join_) (void)hipEventDestroy(side_join_);
@@ -2933,6 +2937,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   // payload (sharded_merge) lives behind the previous Cholesky's exchange buffer -- gone with it)
   ex_ = Exchange();
   selftest_done_ = false;
+  trial_.begun = false;   // (a read-back queued for the previous structure is dropped)
   lap("symbolic analysis (what the tiles' set-up did not hide)");
   n_active_ = -1;
   hschur_valid_ = true;
@@ -4576,14 +4581,20 @@ void BlockSolver::solve_async() {
   deferred_status_ = true;
 }
 
-void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* scale_out) {
+// The queued half of trial_stats(): the reduction kernels, the read-back of their partial sums and of the status word of an
+// asynchronous solve into pinned memory, and an event behind them.  A caller that has host work of its own (the adapter's
+// look-ahead: the write-back of the accepted estimates into the vertices while the device runs the NEXT iteration's first
+// trial) calls this, does that work, and calls trial_stats() -- which then only waits for the event and sums.
+void BlockSolver::trial_stats_begin(double lambda) {
+  if (trial_.begun) throw StateFailure("trial_stats_begin: the previous one has not been read (trial_stats)");
   ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   constexpr int kMaxBlocks = 1024;
   const size_t nsets = sets_.size();
   if (d_red_multi.n < (nsets + 1) * kMaxBlocks) d_red_multi.alloc((nsets + 1) * kMaxBlocks);
-  std::vector<int> nblk(nsets + 1, 0);
+  std::vector<int>& nblk = trial_.nblk;
+  nblk.assign(nsets + 1, 0);
   // slot 0: computeScale (optimization_algorithm_levenberg.cpp:165-172)
   nblk[0] = std::min(kMaxBlocks, grid_for(vector_size()));
   hipLaunchKernelGGL(scale_partial_kernel, dim3(nblk[0]), dim3(kThreads), 0, st_, vector_size(), d_x.p, d_b.p, lambda, d_red_multi.p);
@@ -4631,22 +4642,41 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
     if (nblk[k] > 0) copy_n = (k + 1) * kMaxBlocks;
   G2OHIP_HIP_CHECK(hipMemcpyAsync(h, d_red_multi.p, copy_n * sizeof(double), hipMemcpyDeviceToHost, st_));
   int* hstat = reinterpret_cast<int*>(h + hn);
-  bool bad = false, stalled = false;
+  trial_.mode = 0;
+  trial_.bad = false;
   if (sync_status_ >= 0) {
-    bad = sync_status_ != 0;
+    trial_.bad = sync_status_ != 0;
     sync_status_ = -1;
-    G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   } else if (deferred_status_) {
     chol_->status_async(hstat, st_);
-    G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
-    bad = chol_->failed_with(*hstat, st_);
     deferred_status_ = false;
+    trial_.mode = 1;
+  }
+  if (!trial_ev_) G2OHIP_HIP_CHECK(hipEventCreateWithFlags(&trial_ev_, hipEventDisableTiming));
+  G2OHIP_HIP_CHECK(hipEventRecord(trial_ev_, st_));
+  trial_.need_chi = need_chi;
+  trial_.hn = hn;
+  trial_.begun = true;
+}
+
+void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* scale_out) {
+  if (!trial_.begun) trial_stats_begin(lambda);
+  constexpr int kMaxBlocks = 1024;
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  trial_.begun = false;
+  G2OHIP_HIP_CHECK(hipEventSynchronize(trial_ev_));
+  const size_t nsets = trial_.nblk.size() - 1;
+  const std::vector<int>& nblk = trial_.nblk;
+  const bool need_chi = trial_.need_chi;
+  const double* h = h_trial_;
+  bool bad = trial_.bad, stalled = false;
+  if (trial_.mode == 1) {
+    const int* hstat = reinterpret_cast<const int*>(h + trial_.hn);
+    bad = chol_->failed_with(*hstat, st_);
     if (bad && chol_->dependency_stall() && ++dependency_fallbacks) {
       invalidate_graphs();   // the next solve runs level by level
       stalled = true;        // NOT "not positive definite": the caller repeats the trial (solve() does that itself)
     }
-  } else {
-    G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   }
   auto sum = [&](size_t slot) {
     double s = 0.0;

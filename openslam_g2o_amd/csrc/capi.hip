@@ -344,6 +344,13 @@ int g2ohip_solve_async(g2ohip_solver* s) {
     return G2OHIP_OK;
   });
 }
+int g2ohip_trial_stats_begin(g2ohip_solver* s, double lambda) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->trial_stats_begin(lambda);
+    return G2OHIP_OK;
+  });
+}
 int g2ohip_trial_stats(g2ohip_solver* s, double lambda, int* solve_ok, double* chi2, double* scale) {
   REQUIRE_HANDLE(s);
   return guarded([&] {

@@ -395,6 +395,30 @@ def test_device_resident_levenberg_walks_the_host_loops_trajectory(host, tmp_pat
         assert relerr(np.array(out["cams"]), np.array(ref["cams"])) < 1e-9 and relerr(np.array(out["points"]), np.array(ref["points"])) < 1e-9
 
 
+@pytest.mark.parametrize("huber", [0.0, 1.0])
+def test_look_ahead_trial_of_the_device_resident_levenberg_changes_no_number(host, tmp_path, huber):
+    """From iteration 1 on OptimizationAlgorithmLevenbergHip queues the head of the NEXT solve() (errors, buildSystem, push,
+    setLambda, solve, update, errors, the trial's sums without a synchronisation) before it writes the accepted estimates into the
+    vertices; the next solve() consumes that trial, anything else drops it (estimates popped).  The calls and their order are
+    those of the run without look-ahead (G2OHIP_ADAPTER_LOOKAHEAD=0): chi2, lambda, trial counts and the final estimates are
+    EQUAL, with accepted and with rejected look-ahead trials; the trial queued by the last iteration is dropped by the
+    destructor, the one queued before a second optimize() by its iteration 0."""
+    pr = ba_case(40, 400, outlier_frac=0.05 if huber > 0 else 0.0)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr, huber)
+    for mode, n in ((None, 8), ("twice", 4)):
+        off, err0 = _run(host, prob, "lm_fix6_3_hipdev", n, str(tmp_path / "off.json"), {"G2OHIP_ADAPTER_LOOKAHEAD": "0"}, mode=mode)
+        on, err1 = _run(host, prob, "lm_fix6_3_hipdev", n, str(tmp_path / "on.json"), mode=mode)
+        assert "look-ahead trials queued" not in err0
+        line = [ln for ln in err1.splitlines() if "look-ahead trials queued" in ln]
+        assert line, err1[-800:]
+        queued, dropped = [int(w.strip(",")) for w in line[-1].split() if w.strip(",").isdigit()]
+        assert queued >= 2 and 1 <= dropped <= (1 if mode is None else 2), line
+        assert on["iterations"] == off["iterations"] and on["trials"] == off["trials"], (on["trials"], off["trials"])
+        assert on["chi2"] == off["chi2"] and on["lambda"] == off["lambda"], (on["chi2"], off["chi2"])
+        assert on["cams"] == off["cams"] and on["points"] == off["points"]
+
+
 def test_device_resident_levenberg_uploads_again_on_a_second_optimize(host, tmp_path):
     """A second optimize() starts at iteration 0 again: the structure is rebuilt, the front ends are bound again and the
     vertices' estimates (the result of the first run) go up again -- the two runs chain like the host loop's."""
