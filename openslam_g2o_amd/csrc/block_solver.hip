@@ -3,6 +3,7 @@
 #include "block_solver.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -4819,6 +4820,77 @@ void BlockSolver::ba_set_edges(int set, const int* cam_vertex, const int* point_
   ba_set_edges_classes(set, cam_vertex, point_vertex, meas, info, f, cx, cy, 1, nullptr, nullptr);
 }
 
+// ---- permuted copies of the per-observation inputs, gathered ON THE DEVICE from the arrays in edge order (ba_set_edges): the
+// host used to fill and upload each of them (0.6 GB over PCIe at the metric configuration)
+// per Hpl block (block order; every block has one observation): scatter by the edge's block
+__global__ void ba_gather_blocks_kernel(size_t n, const int* __restrict__ edge_hpl, const int* __restrict__ cam_v, const int* __restrict__ pt_v,
+                                        const double* __restrict__ meas, const double* __restrict__ omega, int* __restrict__ cam_q,
+                                        int* __restrict__ pt_q, double* __restrict__ meas_q, double* __restrict__ omega_q) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int q = edge_hpl[k];
+  if (q < 0) return;
+  cam_q[q] = cam_v[k];
+  pt_q[q] = pt_v[k];
+  meas_q[2 * (size_t)q] = meas[2 * k];
+  meas_q[2 * (size_t)q + 1] = meas[2 * k + 1];
+  if (omega_q)
+    for (int i = 0; i < 4; ++i) omega_q[4 * (size_t)q + i] = omega[4 * k + i];
+}
+// observation-list order of a vertex side (ent = edge << 1 | side); hpl / row only for the landmark side
+__global__ void ba_gather_lists_kernel(size_t n, const int* __restrict__ ent, const int* __restrict__ cam_v, const int* __restrict__ pt_v,
+                                       const double* __restrict__ meas, const double* __restrict__ omega, const int* __restrict__ edge_hpl,
+                                       const int* __restrict__ v1, int* __restrict__ cam_o, int* __restrict__ pt_o,
+                                       double* __restrict__ meas_o, double* __restrict__ omega_o, int* __restrict__ hpl_o,
+                                       int* __restrict__ row_o) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const size_t e = (size_t)(ent[k] >> 1);
+  cam_o[k] = cam_v[e];
+  pt_o[k] = pt_v[e];
+  meas_o[2 * k] = meas[2 * e];
+  meas_o[2 * k + 1] = meas[2 * e + 1];
+  if (omega_o)
+    for (int i = 0; i < 4; ++i) omega_o[4 * k + i] = omega[4 * e + i];
+  if (hpl_o) {
+    const int h = edge_hpl[e];
+    hpl_o[k] = h;
+    row_o[k] = h >= 0 ? v1[e] : -1;
+  }
+}
+// lane slots of the tiles: what a lane reads about its observation, slot-major (one workgroup per tile)
+__global__ void ba_gather_slots_kernel(const int4* __restrict__ tile_ll, const int* __restrict__ slots, const int* __restrict__ vl_ent,
+                                       const int* __restrict__ cam_lm, const int* __restrict__ pt_lm, const int* __restrict__ hpl_lm,
+                                       const int* __restrict__ row_lm, const double* __restrict__ meas_lm, const double* __restrict__ omega_lm,
+                                       int4* __restrict__ rec, int* __restrict__ edge, int* __restrict__ srow, double* __restrict__ ms,
+                                       double* __restrict__ os) {
+  const int4 tl = tile_ll[blockIdx.x];
+  for (int i = threadIdx.x; i < tl.y; i += blockDim.x) {
+    const size_t sidx = (size_t)tl.x + i;
+    const int w = slots[sidx];
+    int4 r = make_int4(w, 0, 0, -1);
+    int ed = 0, row = -1;
+    double m0 = 0.0, m1 = 0.0, o[4] = {0.0, 0.0, 0.0, 0.0};
+    if ((w & 0xfff) != 0xfff) {
+      const size_t k = (size_t)tl.z + (w & 0xfff);
+      r = make_int4(w, cam_lm[k], pt_lm[k], hpl_lm[k]);
+      ed = vl_ent[k] >> 1;
+      row = row_lm[k];
+      m0 = meas_lm[2 * k];
+      m1 = meas_lm[2 * k + 1];
+      if (os)
+        for (int j = 0; j < 4; ++j) o[j] = omega_lm[4 * k + j];
+    }
+    rec[sidx] = r;
+    edge[sidx] = ed;
+    srow[sidx] = row;
+    ms[2 * sidx] = m0;
+    ms[2 * sidx + 1] = m1;
+    if (os)
+      for (int j = 0; j < 4; ++j) os[4 * sidx + j] = o[j];
+  }
+}
+
 // Edge classes: class_params[5 c] = (focal length, principal point x, y, robust kernel kind, delta) of class c, edge_class[k]
 // the class of edge k.  One class (n_classes == 1, both arrays may be null): the intrinsics are the three scalars and the
 // robust kernel is the edge set's (set_robust_kernel), exactly ba_set_edges.  More: class 0 also takes its values from the
@@ -4834,6 +4906,15 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
   if (!cam_vertex || !point_vertex || !meas) throw ArgFailure("ba_set_edges: null array");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t n = (size_t)es.n;
+  const bool lapt = getenv("G2OHIP_SETUP_TIMING") != nullptr;
+  auto lap_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double lap_t = lap_now();
+  auto lap = [&](const char* what) {
+    if (!lapt) return;
+    const double t = lap_now();
+    fprintf(stderr, "ba_set_edges: %-37s %.3f s\n", what, t - lap_t);
+    lap_t = t;
+  };
   if (n_classes < 1 || n_classes > 128) throw ArgFailure("ba_set_edges_classes: 1 to 128 edge classes");
   if (n_classes > 1 && (!class_params || !edge_class)) throw ArgFailure("ba_set_edges_classes: null class table");
   // Everything that can refuse the binding is checked BEFORE the front end or the edge set is changed: a failed call leaves both
@@ -4877,6 +4958,7 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
     if (n_classes > 1 && !unique)
       throw ArgFailure("ba_set_edges_classes: edge classes need the fused path (one observation per (pose, landmark) pair, no fixed landmark)");
   }
+  lap("validation + Hpl block per edge");
   ba_.set = set;
   ba_.n_edges = es.n;
   ba_.f = f; ba_.cx = cx; ba_.cy = cy;
@@ -4906,149 +4988,160 @@ void BlockSolver::ba_set_edges_classes(int set, const int* cam_vertex, const int
   } else {
     es.own_omega.upload(info, n * 4, st_);
   }
+  lap("uploads in edge order");
+  const double* d_omega = ba_.omega_identity ? (const double*)nullptr : es.own_omega.p;   // (identity: not read, no permuted copies)
+  auto zero_alloc = [&](auto& buf, size_t count) {
+    buf.alloc(std::max<size_t>(count, 1));
+    buf.zero(st_);
+  };
   {
     ba_.fused_ok = unique;
     ba_.edge_hpl.upload(edge_hpl, st_);
-    if (unique) {   // the observation behind every Hpl block, in block order (ba_schur_tile_kernel)
+    if (unique) {   // the observation behind every Hpl block, in block order (ba_schur_tile_kernel); blocks without one stay zero
       const size_t nq = std::max<size_t>(pl_row.size(), 1);
-      std::vector<int> cq(nq, 0), pq(nq, 0);
-      std::vector<double> mq(nq * 2, 0.0), oq(!info ? 0 : nq * 4, 0.0);
-      host_parallel_for(n, [&](size_t b_, size_t e_) {   // (unique: every q is written by one edge)
-        for (size_t k = b_; k < e_; ++k) {
-          const int q = edge_hpl[k];
-          if (q < 0) continue;
-          cq[q] = cam_vertex[k];
-          pq[q] = point_vertex[k];
-          mq[2 * (size_t)q] = meas[2 * k];
-          mq[2 * (size_t)q + 1] = meas[2 * k + 1];
-          if (!oq.empty())
-            for (int i = 0; i < 4; ++i) oq[4 * (size_t)q + i] = info[4 * k + i];
-        }
-      });
-      ba_.cam_q.upload(cq, st_);
-      ba_.pt_q.upload(pq, st_);
-      ba_.meas_q.upload(mq, st_);
-      if (!oq.empty()) ba_.omega_q.upload(oq, st_);
+      zero_alloc(ba_.cam_q, nq);
+      zero_alloc(ba_.pt_q, nq);
+      zero_alloc(ba_.meas_q, nq * 2);
+      if (d_omega) zero_alloc(ba_.omega_q, nq * 4);
+      if (n)
+        hipLaunchKernelGGL(ba_gather_blocks_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st_, n, ba_.edge_hpl.p, ba_.cam_v.p, ba_.pt_v.p,
+                           ba_.meas.p, d_omega, ba_.cam_q.p, ba_.pt_q.p, ba_.meas_q.p, d_omega ? ba_.omega_q.p : (double*)nullptr);
     }
   }
+  lap("copies in Hpl block order");
   {
     // pose-major copies of what the pose-side assembly reads per observation (it walks a pose's observation list:
-    // through the edge id these would be 16-byte gathers at an 80-byte stride)
-    const size_t nk = es.h_vp_ent.size();
-    std::vector<double> mpm(nk * 2), opm(ba_.omega_identity ? 0 : nk * 4);
-    std::vector<int> ppm(nk), cpm(nk);
-    host_parallel_for(nk, [&](size_t b_, size_t e_) {
-      for (size_t k = b_; k < e_; ++k) {
-        const size_t e = (size_t)(es.h_vp_ent[k] >> 1);
-        mpm[2 * k] = meas[2 * e];
-        mpm[2 * k + 1] = meas[2 * e + 1];
-        ppm[k] = point_vertex[e];
-        cpm[k] = cam_vertex[e];
-        if (!ba_.omega_identity)
-          for (int i = 0; i < 4; ++i) opm[4 * k + i] = info[4 * e + i];
-      }
-    });
-    // the same for the landmark side (observation-list order of the landmarks)
-    const size_t nl = es.h_vl_ent.size();
-    std::vector<double> mlm(nl * 2), olm(ba_.omega_identity ? 0 : nl * 4);
-    std::vector<int> clm(nl), hlm(nl), plm(nl), rlm(nl);
-    host_parallel_for(nl, [&](size_t b_, size_t e_) {
-      for (size_t k = b_; k < e_; ++k) {
-        const size_t e = (size_t)(es.h_vl_ent[k] >> 1);
-        mlm[2 * k] = meas[2 * e];
-        mlm[2 * k + 1] = meas[2 * e + 1];
-        clm[k] = cam_vertex[e];
-        plm[k] = point_vertex[e];
-        const int a = es.v0[e], b = es.v1[e];
-        hlm[k] = (a >= 0 && b >= 0) ? find_block(pl_colptr, pl_row, a - nP_, b) : -1;
-        rlm[k] = hlm[k] >= 0 ? b : -1;
-        if (!ba_.omega_identity)
-          for (int i = 0; i < 4; ++i) olm[4 * k + i] = info[4 * e + i];
-      }
-    });
+    // through the edge id these would be 16-byte gathers at an 80-byte stride), and the same for the landmark side
+    // (observation-list order of the landmarks) with the Hpl block and its pose block row
+    const size_t nk = es.h_vp_ent.size(), nl = es.h_vl_ent.size();
+    DevBuf<int> d_v1;
+    d_v1.upload(es.v1, st_);
+    ba_.meas_pm.alloc(std::max<size_t>(nk * 2, 1));
+    ba_.pt_pm.alloc(std::max<size_t>(nk, 1));
+    ba_.cam_pm.alloc(std::max<size_t>(nk, 1));
+    if (d_omega) ba_.omega_pm.alloc(std::max<size_t>(nk * 4, 1));
+    if (nk)
+      hipLaunchKernelGGL(ba_gather_lists_kernel, dim3(grid_for(nk)), dim3(kThreads), 0, st_, nk, es.vp_ent.p, ba_.cam_v.p, ba_.pt_v.p, ba_.meas.p,
+                         d_omega, (const int*)nullptr, (const int*)nullptr, ba_.cam_pm.p, ba_.pt_pm.p, ba_.meas_pm.p,
+                         d_omega ? ba_.omega_pm.p : (double*)nullptr, (int*)nullptr, (int*)nullptr);
+    ba_.meas_lm.alloc(std::max<size_t>(nl * 2, 1));
+    ba_.cam_lm.alloc(std::max<size_t>(nl, 1));
+    ba_.pt_lm.alloc(std::max<size_t>(nl, 1));
+    ba_.hpl_lm.alloc(std::max<size_t>(nl, 1));
+    ba_.row_lm.alloc(std::max<size_t>(nl, 1));
+    if (d_omega) ba_.omega_lm.alloc(std::max<size_t>(nl * 4, 1));
+    if (nl)
+      hipLaunchKernelGGL(ba_gather_lists_kernel, dim3(grid_for(nl)), dim3(kThreads), 0, st_, nl, es.vl_ent.p, ba_.cam_v.p, ba_.pt_v.p, ba_.meas.p,
+                         d_omega, ba_.edge_hpl.p, d_v1.p, ba_.cam_lm.p, ba_.pt_lm.p, ba_.meas_lm.p,
+                         d_omega ? ba_.omega_lm.p : (double*)nullptr, ba_.hpl_lm.p, ba_.row_lm.p);
+    G2OHIP_HIP_CHECK(hipGetLastError());
+    lap("pose-major + landmark-major copies");
     // lane slots of the tiles that assemble their own landmarks
     ba_.ll_slots_ok = false;
     if (schur_ && n_tiles_ > 0 && tiles_cover_all_ && n_split_tiles_ == 0 && (int)tile_lm0_h_.size() == n_tiles_ + 1 &&
         (int)es.h_vl_ptr.size() == nL_ + 1) {
       constexpr int kIdleSlot = (int)0x80000fffu;   // no observation, not a first lane, list length 0
-      std::vector<int> slots;
+      // two passes over the tiles on the host threads: slots per tile (a landmark never straddles a wavefront), then the words
       std::vector<int4> tl((size_t)n_tiles_);
-      slots.reserve(nl + (size_t)n_tiles_ * 64);
-      bool ok = true;
-      for (int t = 0; t < n_tiles_ && ok; ++t) {
+      std::vector<int> cnt((size_t)n_tiles_, 0);
+      std::atomic<bool> okf(true);
+      auto walk = [&](int t, int* out, int& kmax) {   // out == nullptr: count only; returns the slots of tile t (-1: does not fit the word)
         const int l0 = tile_lm0_h_[t], l1 = tile_lm0_h_[t + 1];
         const int kb = es.h_vl_ptr[l0];
-        const size_t s0 = slots.size();
-        int kmax = 0;
+        int used = 0, total = 0;
+        kmax = 0;
         for (int lm = l0; lm < l1; ++lm) {
           const int K = es.h_vl_ptr[lm + 1] - es.h_vl_ptr[lm], lmi = lm - l0;
-          if (K > 64 || lmi >= 0x7ff || es.h_vl_ptr[lm + 1] - kb >= 0xfff) {
-            ok = false;
-            break;
+          if (K > 64 || lmi >= 0x7ff || es.h_vl_ptr[lm + 1] - kb >= 0xfff) return -1;
+          const int need = std::max(K, 1);
+          if (used + need > 64) {
+            if (out)
+              for (int i = used; i < 64; ++i) out[total + i - used] = kIdleSlot;
+            total += 64 - used;
+            used = 0;
           }
-          const int used = (int)((slots.size() - s0) & 63), need = std::max(K, 1);
-          if (used + need > 64) slots.resize(slots.size() + (64 - used), kIdleSlot);
-          if (K == 0) slots.push_back(0xfff | (lmi << 20));
-          for (int j = 0; j < K; ++j)
-            slots.push_back((es.h_vl_ptr[lm] + j - kb) | (K << 12) | (j == 0 ? (lmi << 20) : (int)(0x80000000u | ((unsigned)j << 20))));
+          if (out) {
+            if (K == 0) out[total] = 0xfff | (lmi << 20);
+            for (int j = 0; j < K; ++j)
+              out[total + j] = (es.h_vl_ptr[lm] + j - kb) | (K << 12) | (j == 0 ? (lmi << 20) : (int)(0x80000000u | ((unsigned)j << 20)));
+          }
+          total += need;
+          used = (used + need) & 63;
           kmax = std::max(kmax, K);
         }
-        const int used = (int)((slots.size() - s0) & 63);
-        if (used) slots.resize(slots.size() + (64 - used), kIdleSlot);
-        tl[t] = make_int4((int)s0, (int)(slots.size() - s0), kb, kmax);
+        if (used) {
+          if (out)
+            for (int i = used; i < 64; ++i) out[total + i - used] = kIdleSlot;
+          total += 64 - used;
+        }
+        return total;
+      };
+      host_parallel_for((size_t)n_tiles_, [&](size_t t0_, size_t t1_) {
+        for (size_t t = t0_; t < t1_; ++t) {
+          int kmax = 0;
+          const int c = walk((int)t, nullptr, kmax);
+          if (c < 0) okf.store(false);
+          cnt[t] = std::max(c, 0);
+        }
+      }, 64);
+      size_t ns = 0;
+      for (int t = 0; t < n_tiles_; ++t) {
+        tl[t].x = (int)ns;
+        ns += (size_t)cnt[t];
       }
-      if (ok && slots.size() < ((size_t)1 << 31)) {
-        // slot-major copies of what a lane reads about its observation: one memory round trip after the tile record
-        if (slots.empty()) slots.push_back(kIdleSlot);
-        const size_t ns = slots.size();
-        std::vector<int4> rec(ns);
-        std::vector<int> edge(ns, 0), srow(ns, -1);
-        std::vector<double> ms(ns * 2, 0.0), os(ba_.omega_identity ? 0 : ns * 4, 0.0);
+      if (okf.load() && ns < ((size_t)1 << 31)) {
+        std::vector<int> slots(std::max<size_t>(ns, 1), kIdleSlot);
         host_parallel_for((size_t)n_tiles_, [&](size_t t0_, size_t t1_) {   // (a tile's slots are its own)
-          for (size_t t = t0_; t < t1_; ++t)
-            for (int i = 0; i < tl[t].y; ++i) {
-              const size_t sidx = (size_t)tl[t].x + i;
-              const int w = slots[sidx];
-              rec[sidx] = make_int4(w, 0, 0, -1);
-              if ((w & 0xfff) == 0xfff) continue;
-              const size_t k = (size_t)tl[t].z + (w & 0xfff);
-              rec[sidx] = make_int4(w, clm[k], plm[k], hlm[k]);
-              edge[sidx] = es.h_vl_ent[k] >> 1;
-              srow[sidx] = rlm[k];
-              ms[2 * sidx] = mlm[2 * k];
-              ms[2 * sidx + 1] = mlm[2 * k + 1];
-              if (!ba_.omega_identity)
-                for (int j = 0; j < 4; ++j) os[4 * sidx + j] = olm[4 * k + j];
-            }
+          for (size_t t = t0_; t < t1_; ++t) {
+            int kmax = 0;
+            walk((int)t, slots.data() + tl[t].x, kmax);
+            tl[t] = make_int4(tl[t].x, cnt[t], es.h_vl_ptr[tile_lm0_h_[t]], kmax);
+          }
         }, 64);
-        if (n_tiles_ == 0) rec[0] = make_int4(kIdleSlot, 0, 0, -1);
-        ba_.ll_rec.upload(rec, st_);
-        ba_.ll_edge.upload(edge, st_);
-        ba_.ll_row.upload(srow, st_);
-        ba_.ll_meas.upload(ms, st_);
-        if (!ba_.omega_identity) ba_.ll_omega.upload(os, st_);
+        // slot-major copies of what a lane reads about its observation (one memory round trip after the tile record), gathered
+        // on the device from the landmark-major arrays
+        const size_t nsa = slots.size();
+        DevBuf<int> d_slots;
+        d_slots.upload(slots, st_);
         ba_.tile_ll.upload(tl, st_);
+        ba_.ll_rec.alloc(nsa);
+        ba_.ll_edge.alloc(nsa);
+        ba_.ll_row.alloc(nsa);
+        ba_.ll_meas.alloc(nsa * 2);
+        if (d_omega) ba_.ll_omega.alloc(nsa * 4);
+        if (ns == 0) {   // (no tile has a slot: the one idle record)
+          const int4 idle = make_int4(kIdleSlot, 0, 0, -1);
+          const int none = -1;
+          ba_.ll_rec.upload(&idle, 1, st_);
+          ba_.ll_row.upload(&none, 1, st_);
+          ba_.ll_edge.zero(st_);
+          ba_.ll_meas.zero(st_);
+        } else {
+          hipLaunchKernelGGL(ba_gather_slots_kernel, dim3(n_tiles_), dim3(kThreads), 0, st_, ba_.tile_ll.p, d_slots.p, es.vl_ent.p, ba_.cam_lm.p,
+                             ba_.pt_lm.p, ba_.hpl_lm.p, ba_.row_lm.p, ba_.meas_lm.p, d_omega ? ba_.omega_lm.p : (const double*)nullptr,
+                             ba_.ll_rec.p, ba_.ll_edge.p, ba_.ll_row.p, ba_.ll_meas.p, d_omega ? ba_.ll_omega.p : (double*)nullptr);
+        }
+        G2OHIP_HIP_CHECK(hipGetLastError());
+        G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));   // (d_slots, d_v1 die with this scope)
         ba_.ll_slots_ok = true;
       }
     }
-    ba_.meas_lm.upload(mlm, st_);
-    ba_.cam_lm.upload(clm, st_);
-    ba_.pt_lm.upload(plm, st_);
-    ba_.hpl_lm.upload(hlm, st_);
-    ba_.row_lm.upload(rlm, st_);
-    if (!ba_.omega_identity) ba_.omega_lm.upload(olm, st_);
-    ba_.meas_pm.upload(mpm, st_);
-    ba_.pt_pm.upload(ppm, st_);
-    ba_.cam_pm.upload(cpm, st_);
-    if (!ba_.omega_identity) ba_.omega_pm.upload(opm, st_);
+    lap("lane slots of the tiles");
+    G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
   }
-  es.own_J0.alloc(n * 6);
-  es.own_J1.alloc(n * 12);
+  lap("pose-major / landmark-major uploads");
+  // (the Jacobian arrays -- 144 bytes per observation, 0.72 GB at the metric configuration -- only where something reads them: the
+  // fused kernels evaluate the Jacobians themselves; otherwise ba_linearize allocates them when it is first asked for them)
+  if (!(ba_fused && ba_.fused_ok)) {
+    es.own_J0.alloc(n * 6);
+    es.own_J1.alloc(n * 12);
+  }
   es.own_err.alloc(n * 2);
   es.J0 = es.own_J0.p; es.J1 = es.own_J1.p; es.omega = es.own_omega.p; es.err = es.own_err.p;
   es.has_data = false;   // becomes valid with the first ba_linearize
   prepare_ba_tile_kernels();
   G2OHIP_HIP_CHECK(hipStreamSynchronize(st_));
+  lap("buffers, kernel attributes, sync");
 }
 
 // Edge -> estimate indices against the estimate tables and against the edge set's hessian indices: a wrong index would be
@@ -5199,6 +5292,13 @@ void BlockSolver::ba_linearize(bool jacobians) {
   ba_.err_valid = true;
   if (need_jac) ba_.jac_valid = true;
   chi2_valid_ = false;
+  if (need_jac && (es.own_J0.n < (size_t)es.n * 6 || es.own_J1.n < (size_t)es.n * 12)) {   // (left out by ba_set_edges on the fused path)
+    es.own_J0.alloc((size_t)es.n * 6);
+    es.own_J1.alloc((size_t)es.n * 12);
+    es.J0 = es.own_J0.p;
+    es.J1 = es.own_J1.p;
+    invalidate_graphs();
+  }
   if (profiling) tfe_.start(st_);
   // the chi2 of these errors rides along: 1 024 partial sums in this set's slot of the trial read-back buffer (chi2() and
   // trial_stats() take them from there while err_valid holds)
@@ -5514,7 +5614,7 @@ void BlockSolver::copy_edge_data(int set, double* J0, double* J1, double* err) {
     if (!dst || !src || cnt == 0) return;
     G2OHIP_HIP_CHECK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyDeviceToHost, st_));
   };
-  if (es.has_data) {
+  if (es.has_data && !(set == ba_.set && !ba_.jac_valid)) {
     pull(J0, es.J0, n * es.d * es.dim0);
     if (!es.unary) pull(J1, es.J1, n * es.d * es.dim1);
   } else if (J0 || J1) {
