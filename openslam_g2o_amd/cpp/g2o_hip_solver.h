@@ -300,30 +300,51 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     // poses first, then marginalized vertices, each in index order (sparse_optimizer.cpp:174-187)
     _nP = _nL = 0;
     size_t diagDoubles = 0;
-    for (size_t i = 0; i < _optimizer->indexMapping().size(); ++i) {
-      OptimizableGraph::Vertex* v = _optimizer->indexMapping()[i];
-      const bool lm = v->marginalized();
-      if (v->dimension() != (lm ? l : p)) {
-        std::cerr << "BlockSolverHip: vertex dimension " << v->dimension() << " does not fit <" << p << "," << l << ">" << std::endl;
+    const size_t nV = _optimizer->indexMapping().size();
+    {
+      // (1.1 M vertex objects at the metric configuration, a cache miss each: walked on the host threads; the order -- poses, then
+      // marginalised vertices -- makes a vertex's place in the mirror a function of its index, checked below)
+      std::atomic<long long> nPose(0), nLm(0), firstLm((long long)nV), lastPose(-1);
+      std::atomic<int> badDim(0);
+      parallelFor(nV, [&](size_t b, size_t e) {
+        long long np = 0, nl = 0, fl = (long long)nV, lp = -1;
+        for (size_t i = b; i < e; ++i) {
+          OptimizableGraph::Vertex* v = _optimizer->indexMapping()[i];
+          const bool lm = v->marginalized();
+          if (v->dimension() != (lm ? l : p)) badDim.store(v->dimension() ? v->dimension() : -1);
+          if (lm) { ++nl; fl = std::min(fl, (long long)i); } else { ++np; lp = (long long)i; }
+        }
+        nPose += np;
+        nLm += nl;
+        long long cur = firstLm.load();
+        while (fl < cur && !firstLm.compare_exchange_weak(cur, fl)) {}
+        cur = lastPose.load();
+        while (lp > cur && !lastPose.compare_exchange_weak(cur, lp)) {}
+      });
+      if (badDim.load()) {
+        std::cerr << "BlockSolverHip: vertex dimension " << badDim.load() << " does not fit <" << p << "," << l << ">" << std::endl;
         return false;
       }
-      (lm ? _nL : _nP)++;
-      diagDoubles += (size_t)v->dimension() * v->dimension();
+      _nP = (int)nPose.load();
+      _nL = (int)nLm.load();
+      if (lastPose.load() >= firstLm.load()) {
+        std::cerr << "BlockSolverHip: indexMapping() does not hold the poses before the marginalized vertices" << std::endl;
+        return false;
+      }
+      diagDoubles = (size_t)_nP * p * p + (size_t)_nL * l * l;
     }
     // host mirror of the diagonal blocks: OptimizationAlgorithmLevenberg::computeLambdaInit reads v->hessian(j, j)
     // through the vertices' mapped memory (optimization_algorithm_levenberg.cpp:149-163, base_vertex.h:62-110)
     _diagMirror.assign(diagDoubles, 0.0);
-    {
-      size_t off = 0;
-      int col = 0;
-      for (size_t i = 0; i < _optimizer->indexMapping().size(); ++i) {
+    parallelFor(nV, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
         OptimizableGraph::Vertex* v = _optimizer->indexMapping()[i];
-        v->setColInHessian(col);                       // block_solver.hpp:170,177
+        const size_t nP = (size_t)_nP;
+        const size_t off = i < nP ? i * p * p : nP * p * p + (i - nP) * l * l;
+        v->setColInHessian((int)(i < nP ? i * p : nP * p + (i - nP) * l));   // block_solver.hpp:170,177
         v->mapHessianMemory(&_diagMirror[off]);
-        col += v->dimension();
-        off += (size_t)v->dimension() * v->dimension();
       }
-    }
+    });
     // group the active edges
     std::map<GroupKey, size_t> index;
     int baGroup = -1;
@@ -1270,14 +1291,22 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     const bool identity = _baIdentity;
     _camHidx.resize(_cams.size());
     _pointHidx.resize(_points.size());
-    for (size_t i = 0; i < _cams.size(); ++i) {
-      _camHidx[i] = _cams[i]->hessianIndex();
-      if (_camHidx[i] >= _nP) return false;               // a marginalized camera: not this front end's layout
-    }
-    for (size_t i = 0; i < _points.size(); ++i) {
-      const int hi = _points[i]->hessianIndex();
-      if (hi >= 0 && hi < _nP) return false;              // a point that is not marginalized: likewise
-      _pointHidx[i] = hi < 0 ? -1 : hi - _nP;
+    {
+      std::atomic<int> foreign(0);
+      parallelFor(_cams.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+          _camHidx[i] = _cams[i]->hessianIndex();
+          if (_camHidx[i] >= _nP) foreign.store(1);       // a marginalized camera: not this front end's layout
+        }
+      });
+      parallelFor(_points.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+          const int hi = _points[i]->hessianIndex();
+          if (hi >= 0 && hi < _nP) foreign.store(1);      // a point that is not marginalized: likewise
+          _pointHidx[i] = hi < 0 ? -1 : hi - _nP;
+        }
+      });
+      if (foreign.load()) return false;
     }
     const int nClasses = (int)(_baClasses.size() / 5);
     if (g2ohip_ba_set_edges_classes(_h, g.set, camOf.data(), pointOf.data(), meas.data(), identity ? 0 : info.data(), nClasses, _baClasses.data(),

@@ -2416,6 +2416,9 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     std::thread& t;
     ~Joiner() { if (t.joinable()) t.join(); }   // (an exception on this thread must not leave the other one running into freed vectors)
   } analysis_joiner{analysis_thread};
+  std::thread lists_thread;
+  std::exception_ptr lists_error;
+  Joiner lists_joiner{lists_thread};
   // ---- validate sets, vertex classes
   for (auto& esp : sets_) {
     EdgeSet& es = *esp;
@@ -2471,149 +2474,174 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   pp_diag.resize(nP);
   for (int c = 0; c < nP; ++c) pp_diag[c] = find_block(pp_colptr, pp_row, c, c);
   lap("Hpp / Hpl patterns");
-  // ---- contributor lists per set
-  bool seen_pose = false, seen_lm = false, seen_op = false, seen_ol = false;
-  std::vector<int> offdiag_blocks;
-  offdiag_blocks.reserve(pp_nnzb - nP);
-  for (int c = 0; c < nP; ++c)
-    for (int q = pp_colptr[c]; q < pp_colptr[c + 1]; ++q)
-      if (pp_row[q] != c) offdiag_blocks.push_back(q);
-  for (auto& esp : sets_) {
-    EdgeSet& es = *esp;
-    std::vector<int> dp, pp_, dl, pl_, dop, pop, dol, pol;
-    {
-      // (5 M push_backs each and as many block searches at the metric configuration: contiguous chunks of the edge list on the
-      // host threads, every chunk into its own lists, concatenated in chunk order -- the edge order of the sequential loop)
-      struct Part { std::vector<int> v[8]; };
-      const size_t nch = std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), ((size_t)es.n + 65535) / 65536));
-      std::vector<Part> parts(nch);
-      host_parallel_chunks((size_t)es.n, nch, [&](size_t c, size_t kb, size_t ke) {
-        std::vector<int>&dp = parts[c].v[0], &pp_ = parts[c].v[1], &dl = parts[c].v[2], &pl_ = parts[c].v[3], &dop = parts[c].v[4],
-                        &pop = parts[c].v[5], &dol = parts[c].v[6], &pol = parts[c].v[7];
-        for (int i = 0; i < 8; ++i) parts[c].v[i].reserve(ke - kb);
-        for (int k = (int)kb; k < (int)ke; ++k) {
-          int a = es.v0[k], b = es.v1[k];
-          if (a >= 0 && !(es.parts & 1)) {   // (parts: the diagonal block / right-hand side of this side come from another set)
-            if (is_lm(a)) { dl.push_back(a - nP); pl_.push_back(k << 1); }
-            else { dp.push_back(a); pp_.push_back(k << 1); }
-          }
-          if (b >= 0 && !(es.parts & 2)) {
-            if (is_lm(b)) { dl.push_back(b - nP); pl_.push_back((k << 1) | 1); }
-            else { dp.push_back(b); pp_.push_back((k << 1) | 1); }
-          }
-          if (a >= 0 && b >= 0) {
-            if (!is_lm(a) && !is_lm(b)) {
-              int tr = a > b;
-              int q = find_block(pp_colptr, pp_row, std::max(a, b), std::min(a, b));
-              dop.push_back(q);
-              pop.push_back((k << 1) | tr);
-            } else {
-              int pose = is_lm(a) ? b : a, lm = (is_lm(a) ? a : b) - nP;
-              int tr = is_lm(a) ? 1 : 0;  // vertex 0 marginalized -> write transposed (block_solver.hpp:240-244)
-              dol.push_back(find_block(pl_colptr, pl_row, lm, pose));
-              pol.push_back((k << 1) | tr);
+  // ---- contributor lists per set: they need the two patterns and nothing else, and nothing below needs them -- on a thread of
+  // their own next to the Schur pattern and the tiles' set-up (option setup_overlap)
+  const bool lists_threaded = setup_overlap && schur_;
+  auto build_lists = [&, pp_nnzb, pl_nnzb, lists_threaded] {
+    double lt = lap_now();
+    auto llap = [&](const char* what) {
+      if (!lapt) return;
+      const double t = lap_now();
+      fprintf(stderr, "build_structure: %-34s %.3f s%s\n", what, t - lt, lists_threaded ? " (on a thread of its own)" : "");
+      lt = t;
+    };
+    // ---- contributor lists per set
+    bool seen_pose = false, seen_lm = false, seen_op = false, seen_ol = false;
+    std::vector<int> offdiag_blocks;
+    offdiag_blocks.reserve(pp_nnzb - nP);
+    for (int c = 0; c < nP; ++c)
+      for (int q = pp_colptr[c]; q < pp_colptr[c + 1]; ++q)
+        if (pp_row[q] != c) offdiag_blocks.push_back(q);
+    for (auto& esp : sets_) {
+      EdgeSet& es = *esp;
+      std::vector<int> dp, pp_, dl, pl_, dop, pop, dol, pol;
+      {
+        // (5 M push_backs each and as many block searches at the metric configuration: contiguous chunks of the edge list on the
+        // host threads, every chunk into its own lists, concatenated in chunk order -- the edge order of the sequential loop)
+        struct Part { std::vector<int> v[8]; };
+        const size_t nch = std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), ((size_t)es.n + 65535) / 65536));
+        std::vector<Part> parts(nch);
+        host_parallel_chunks((size_t)es.n, nch, [&](size_t c, size_t kb, size_t ke) {
+          std::vector<int>&dp = parts[c].v[0], &pp_ = parts[c].v[1], &dl = parts[c].v[2], &pl_ = parts[c].v[3], &dop = parts[c].v[4],
+                          &pop = parts[c].v[5], &dol = parts[c].v[6], &pol = parts[c].v[7];
+          for (int i = 0; i < 8; ++i) parts[c].v[i].reserve(ke - kb);
+          for (int k = (int)kb; k < (int)ke; ++k) {
+            int a = es.v0[k], b = es.v1[k];
+            if (a >= 0 && !(es.parts & 1)) {   // (parts: the diagonal block / right-hand side of this side come from another set)
+              if (is_lm(a)) { dl.push_back(a - nP); pl_.push_back(k << 1); }
+              else { dp.push_back(a); pp_.push_back(k << 1); }
+            }
+            if (b >= 0 && !(es.parts & 2)) {
+              if (is_lm(b)) { dl.push_back(b - nP); pl_.push_back((k << 1) | 1); }
+              else { dp.push_back(b); pp_.push_back((k << 1) | 1); }
+            }
+            if (a >= 0 && b >= 0) {
+              if (!is_lm(a) && !is_lm(b)) {
+                int tr = a > b;
+                int q = find_block(pp_colptr, pp_row, std::max(a, b), std::min(a, b));
+                dop.push_back(q);
+                pop.push_back((k << 1) | tr);
+              } else {
+                int pose = is_lm(a) ? b : a, lm = (is_lm(a) ? a : b) - nP;
+                int tr = is_lm(a) ? 1 : 0;  // vertex 0 marginalized -> write transposed (block_solver.hpp:240-244)
+                dol.push_back(find_block(pl_colptr, pl_row, lm, pose));
+                pol.push_back((k << 1) | tr);
+              }
             }
           }
-        }
-      });
-      std::vector<int>* outs[8] = {&dp, &pp_, &dl, &pl_, &dop, &pop, &dol, &pol};
-      for (int i = 0; i < 8; ++i) {
-        if (nch == 1) {
-          outs[i]->swap(parts[0].v[i]);
-          continue;
-        }
-        size_t tot = 0;
-        for (size_t c = 0; c < nch; ++c) tot += parts[c].v[i].size();
-        outs[i]->reserve(tot);
-        for (size_t c = 0; c < nch; ++c) outs[i]->insert(outs[i]->end(), parts[c].v[i].begin(), parts[c].v[i].end());
-      }
-    }
-    lap("contributor lists: edge walk");
-    es.touches_pose = !dp.empty();
-    es.touches_lm = !dl.empty();
-    std::vector<int> ptr, ent;
-    if (es.touches_pose) {
-      group_by(nP, dp, pp_, ptr, ent);
-      es.vp_ptr.upload(ptr, st_);
-      es.vp_ent.upload(ent, st_);
-      {
-        std::vector<int> act;
-        for (int v = 0; v < nP; ++v)
-          if (ptr[v + 1] > ptr[v]) act.push_back(v);
-        es.n_vp_act = (int)act.size() < nP ? (int)act.size() : 0;   // (0: every pose has entries, no list needed)
-        if (es.n_vp_act > 0) {   // the poses WITHOUT entries follow the active ones (their blocks are re-zeroed per build_system)
-          for (int v = 0; v < nP; ++v)
-            if (ptr[v + 1] == ptr[v]) act.push_back(v);
-          es.vp_act.upload(act, st_);
-        }
-      }
-      es.h_vp_ent = ent;
-      es.n_vp_ent = (long)ent.size();
-      es.first_pose = !seen_pose;
-      seen_pose = true;
-    }
-    if (es.touches_lm) {
-      group_by(nL, dl, pl_, ptr, ent);
-      es.vl_ptr.upload(ptr, st_);
-      es.vl_ent.upload(ent, st_);
-      es.h_vl_ent = ent;
-      es.h_vl_ptr = ptr;
-      es.n_vl_ent = (long)ent.size();
-      es.first_lm = !seen_lm;
-      seen_lm = true;
-    }
-    lap("contributor lists: per vertex");
-    if (!dop.empty()) {
-      es.first_op = !seen_op;
-      seen_op = true;
-      // destination list: all off-diagonal blocks for the first pose-pose set (so every block is written),
-      // only the touched ones afterwards
-      std::vector<int> dst_list;
-      if (es.first_op) dst_list = offdiag_blocks;
-      else {
-        dst_list = dop;
-        std::sort(dst_list.begin(), dst_list.end());
-        dst_list.erase(std::unique(dst_list.begin(), dst_list.end()), dst_list.end());
-      }
-      std::vector<int> local(dop.size());
-      host_parallel_for(dop.size(), [&](size_t b_, size_t e_) {
-        for (size_t k = b_; k < e_; ++k) local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dop[k]) - dst_list.begin());
-      });
-      group_by((int)dst_list.size(), local, pop, ptr, ent);
-      es.n_op = (int)dst_list.size();
-      es.op_dst.upload(dst_list, st_);
-      es.op_ptr.upload(ptr, st_);
-      es.op_ent.upload(ent, st_);
-    }
-    if (!dol.empty()) {
-      es.first_ol = !seen_ol;
-      seen_ol = true;
-      std::vector<int> dst_list;
-      if (es.first_ol) {
-        dst_list.resize(pl_nnzb);
-        std::iota(dst_list.begin(), dst_list.end(), 0);
-      } else {
-        dst_list = dol;
-        std::sort(dst_list.begin(), dst_list.end());
-        dst_list.erase(std::unique(dst_list.begin(), dst_list.end()), dst_list.end());
-      }
-      std::vector<int> local(dol.size());
-      if (es.first_ol) {
-        local = dol;   // (the destination list is every block in order: the position of a block is the block)
-      } else {
-        host_parallel_for(dol.size(), [&](size_t b_, size_t e_) {
-          for (size_t k = b_; k < e_; ++k) local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dol[k]) - dst_list.begin());
         });
+        std::vector<int>* outs[8] = {&dp, &pp_, &dl, &pl_, &dop, &pop, &dol, &pol};
+        for (int i = 0; i < 8; ++i) {
+          if (nch == 1) {
+            outs[i]->swap(parts[0].v[i]);
+            continue;
+          }
+          size_t tot = 0;
+          for (size_t c = 0; c < nch; ++c) tot += parts[c].v[i].size();
+          outs[i]->reserve(tot);
+          for (size_t c = 0; c < nch; ++c) outs[i]->insert(outs[i]->end(), parts[c].v[i].begin(), parts[c].v[i].end());
+        }
       }
-      group_by((int)dst_list.size(), local, pol, ptr, ent);
-      es.n_ol = (int)dst_list.size();
-      es.ol_dst.upload(dst_list, st_);
-      es.ol_ptr.upload(ptr, st_);
-      es.ol_ent.upload(ent, st_);
+      llap("contributor lists: edge walk");
+      es.touches_pose = !dp.empty();
+      es.touches_lm = !dl.empty();
+      std::vector<int> ptr, ent;
+      if (es.touches_pose) {
+        group_by(nP, dp, pp_, ptr, ent);
+        es.vp_ptr.upload(ptr, st_);
+        es.vp_ent.upload(ent, st_);
+        {
+          std::vector<int> act;
+          for (int v = 0; v < nP; ++v)
+            if (ptr[v + 1] > ptr[v]) act.push_back(v);
+          es.n_vp_act = (int)act.size() < nP ? (int)act.size() : 0;   // (0: every pose has entries, no list needed)
+          if (es.n_vp_act > 0) {   // the poses WITHOUT entries follow the active ones (their blocks are re-zeroed per build_system)
+            for (int v = 0; v < nP; ++v)
+              if (ptr[v + 1] == ptr[v]) act.push_back(v);
+            es.vp_act.upload(act, st_);
+          }
+        }
+        es.h_vp_ent = ent;
+        es.n_vp_ent = (long)ent.size();
+        es.first_pose = !seen_pose;
+        seen_pose = true;
+      }
+      if (es.touches_lm) {
+        group_by(nL, dl, pl_, ptr, ent);
+        es.vl_ptr.upload(ptr, st_);
+        es.vl_ent.upload(ent, st_);
+        es.h_vl_ent = ent;
+        es.h_vl_ptr = ptr;
+        es.n_vl_ent = (long)ent.size();
+        es.first_lm = !seen_lm;
+        seen_lm = true;
+      }
+      llap("contributor lists: per vertex");
+      if (!dop.empty()) {
+        es.first_op = !seen_op;
+        seen_op = true;
+        // destination list: all off-diagonal blocks for the first pose-pose set (so every block is written),
+        // only the touched ones afterwards
+        std::vector<int> dst_list;
+        if (es.first_op) dst_list = offdiag_blocks;
+        else {
+          dst_list = dop;
+          std::sort(dst_list.begin(), dst_list.end());
+          dst_list.erase(std::unique(dst_list.begin(), dst_list.end()), dst_list.end());
+        }
+        std::vector<int> local(dop.size());
+        host_parallel_for(dop.size(), [&](size_t b_, size_t e_) {
+          for (size_t k = b_; k < e_; ++k) local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dop[k]) - dst_list.begin());
+        });
+        group_by((int)dst_list.size(), local, pop, ptr, ent);
+        es.n_op = (int)dst_list.size();
+        es.op_dst.upload(dst_list, st_);
+        es.op_ptr.upload(ptr, st_);
+        es.op_ent.upload(ent, st_);
+      }
+      if (!dol.empty()) {
+        es.first_ol = !seen_ol;
+        seen_ol = true;
+        std::vector<int> dst_list;
+        if (es.first_ol) {
+          dst_list.resize(pl_nnzb);
+          std::iota(dst_list.begin(), dst_list.end(), 0);
+        } else {
+          dst_list = dol;
+          std::sort(dst_list.begin(), dst_list.end());
+          dst_list.erase(std::unique(dst_list.begin(), dst_list.end()), dst_list.end());
+        }
+        std::vector<int> local(dol.size());
+        if (es.first_ol) {
+          local = dol;   // (the destination list is every block in order: the position of a block is the block)
+        } else {
+          host_parallel_for(dol.size(), [&](size_t b_, size_t e_) {
+            for (size_t k = b_; k < e_; ++k) local[k] = (int)(std::lower_bound(dst_list.begin(), dst_list.end(), dol[k]) - dst_list.begin());
+          });
+        }
+        group_by((int)dst_list.size(), local, pol, ptr, ent);
+        es.n_ol = (int)dst_list.size();
+        es.ol_dst.upload(dst_list, st_);
+        es.ol_ptr.upload(ptr, st_);
+        es.ol_ent.upload(ent, st_);
+      }
+      es.has_data = false;
     }
-    es.has_data = false;
+    llap("contributor lists: per off-diagonal block");
+  };
+  if (lists_threaded) {
+    lists_thread = std::thread([&] {
+      try {
+        G2OHIP_HIP_CHECK(hipSetDevice(device_));
+        build_lists();
+      } catch (...) {
+        lists_error = std::current_exception();
+      }
+    });
+  } else {
+    build_lists();
+    lap_t = lap_now();
   }
-  lap("contributor lists: per off-diagonal block");
   // ---- Schur structure (block_solver.hpp:256-292)
   n_sc_ = 0;
   if (schur_) {
@@ -2918,6 +2946,11 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   G2OHIP_HIP_CHECK(hipMemsetAsync(d_b.p, 0, vector_size() * sizeof(double), st_));
   G2OHIP_HIP_CHECK(hipMemsetAsync(d_x.p, 0, vector_size() * sizeof(double), st_));
   lap("Schur tiles + uploads");
+  if (lists_thread.joinable()) {
+    lists_thread.join();
+    if (lists_error) std::rethrow_exception(lists_error);
+    lap("contributor lists (what the tiles' set-up did not hide)");
+  }
   // ---- symbolic factorisation of the system the linear solver will see
   pcg_.reset();
   pcg_mf_.reset();
