@@ -250,7 +250,7 @@ class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNew
  public:
   explicit OptimizationAlgorithmGaussNewtonHip(Solver* solver)
       : OptimizationAlgorithmGaussNewton(solver), _dev(dynamic_cast<HipDeviceGraph*>(solver)), _resident(false),
-        _writeBack(!hip_detail::envOff("G2OHIP_ADAPTER_WRITEBACK")) {}
+        _writeBack(!hip_detail::envOff("G2OHIP_ADAPTER_WRITEBACK")), _fetched(false) {}
 
   bool deviceLoopActive() const { return _resident; }
 
@@ -268,28 +268,73 @@ class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNew
 
     double t = get_monotonic_time();
     G2OBatchStatistics* globalStats = G2OBatchStatistics::globalStats();
-    if (iteration == 0 || online || !_dev->devEstimatesValid()) {
-      if (!_dev->devSetEstimates()) return OptimizationAlgorithm::Fail;
+    // (look-ahead as in the Levenberg-Marquardt driver: the previous solve() of this run may have queued this iteration --
+    // errors, buildSystem, push, solve, update, errors, the status read-back -- before it wrote its estimates into the vertices)
+    const bool consume = _dev->devLookAheadPending() && iteration > 0 && !online && _dev->devEstimatesValid();
+    if (!consume) _dev->devDropLookAhead();
+    int ok = -1;
+    bool fetched = false;
+    if (consume) {
+      _dev->devSetLookAheadPending(false);
+      double chi = 0., scale = 0.;
+      ok = _dev->devTrialStats(0., chi, scale);          // (the status of the queued solve; the sums ride along unused)
+      if (ok == 1) {
+        if (!_dev->devDiscardTop()) return OptimizationAlgorithm::Fail;
+        fetched = _fetched;
+      } else {
+        if (_fetched) _dev->devFetchCancel();
+        if (!_dev->devPop()) return OptimizationAlgorithm::Fail;     // the increment of a factorisation that broke down is not applied
+        if (ok == 2) {                                     // (a dependency-driven launch gave up waiting: again, synchronously)
+          ok = _dev->devSolve();
+          if (ok == 1 && !_dev->devUpdate()) return OptimizationAlgorithm::Fail;
+        }
+      }
+      _fetched = false;
+      if (globalStats) {
+        globalStats->timeLinearSolution = get_monotonic_time() - t;
+        t = get_monotonic_time();
+      }
+    } else {
+      if (iteration == 0 || online || !_dev->devEstimatesValid()) {
+        if (!_dev->devSetEstimates()) return OptimizationAlgorithm::Fail;
+      }
+      if (!_dev->devLinearize(true)) return OptimizationAlgorithm::Fail;
+      if (globalStats) {
+        globalStats->timeResiduals = get_monotonic_time() - t;
+        t = get_monotonic_time();
+      }
+      if (!_dev->devBuildSystem()) return OptimizationAlgorithm::Fail;
+      if (globalStats) {
+        globalStats->timeQuadraticForm = get_monotonic_time() - t;
+        t = get_monotonic_time();
+      }
+      ok = _dev->devSolve();
+      if (globalStats) {
+        globalStats->timeLinearSolution = get_monotonic_time() - t;
+        t = get_monotonic_time();
+      }
+      // (the host loop applies x() even after a failed solve and then reports Fail, gauss_newton.cpp:86-92; the increment of a
+      // factorisation that broke down is not applied here)
+      if (ok == 1 && !_dev->devUpdate()) return OptimizationAlgorithm::Fail;
     }
-    if (!_dev->devLinearize(true)) return OptimizationAlgorithm::Fail;
-    if (globalStats) {
-      globalStats->timeResiduals = get_monotonic_time() - t;
-      t = get_monotonic_time();
+    if (ok < 0) return OptimizationAlgorithm::Fail;
+    if (ok == 1 && _writeBack) {
+      if (!fetched) fetched = _dev->devFetchBegin();
+      // (iteration 0 never looks ahead: optimize(1) in a loop would always drop the queued iteration)
+      const bool ahead = fetched && iteration > 0 && !online && _dev->devCanLookAhead();
+      if (ahead) {
+        _dev->devSetQueueing(true);
+        const bool q = _dev->devLinearize(true) && _dev->devBuildSystem() && _dev->devPush() && _dev->devSolveAsync() && _dev->devUpdate() &&
+                       _dev->devLinearize(false) && _dev->devTrialStatsBegin(0.);
+        _dev->devSetQueueing(false);
+        if (!q) return OptimizationAlgorithm::Fail;
+      }
+      if (!(fetched ? _dev->devFetchEnd() : _dev->devGetEstimates())) return OptimizationAlgorithm::Fail;
+      if (ahead) {
+        _fetched = _dev->devFetchBegin();                  // the queued iteration's estimates, behind its update
+        _dev->devSetLookAheadPending(true);
+      }
     }
-    if (!_dev->devBuildSystem()) return OptimizationAlgorithm::Fail;
-    if (globalStats) {
-      globalStats->timeQuadraticForm = get_monotonic_time() - t;
-      t = get_monotonic_time();
-    }
-    const int ok = _dev->devSolve();
-    if (globalStats) {
-      globalStats->timeLinearSolution = get_monotonic_time() - t;
-      t = get_monotonic_time();
-    }
-    // (the host loop applies x() even after a failed solve and then reports Fail, gauss_newton.cpp:86-92; the increment of a
-    // factorisation that broke down is not applied here)
-    if (ok == 1 && !_dev->devUpdate()) return OptimizationAlgorithm::Fail;
-    if (ok == 1 && _writeBack && !(_dev->devFetchBegin() ? _dev->devFetchEnd() : _dev->devGetEstimates())) return OptimizationAlgorithm::Fail;
     if (globalStats) globalStats->timeUpdate = get_monotonic_time() - t;
     return ok == 1 ? OK : Fail;
   }
@@ -297,6 +342,7 @@ class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNew
  private:
   HipDeviceGraph* _dev;
   bool _resident, _writeBack;
+  bool _fetched;              // the queued iteration's estimates are on their way to the host
 };
 
 }  // namespace g2o

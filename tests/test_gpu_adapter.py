@@ -395,20 +395,21 @@ def test_device_resident_levenberg_walks_the_host_loops_trajectory(host, tmp_pat
         assert relerr(np.array(out["cams"]), np.array(ref["cams"])) < 1e-9 and relerr(np.array(out["points"]), np.array(ref["points"])) < 1e-9
 
 
-@pytest.mark.parametrize("huber", [0.0, 1.0])
-def test_look_ahead_trial_of_the_device_resident_levenberg_changes_no_number(host, tmp_path, huber):
+@pytest.mark.parametrize("solver,huber", [("lm_fix6_3_hipdev", 0.0), ("lm_fix6_3_hipdev", 1.0), ("gn_fix6_3_hipdev", 0.0)])
+def test_look_ahead_trial_of_the_device_resident_drivers_changes_no_number(host, tmp_path, solver, huber):
     """From iteration 1 on OptimizationAlgorithmLevenbergHip queues the head of the NEXT solve() (errors, buildSystem, push,
     setLambda, solve, update, errors, the trial's sums without a synchronisation) before it writes the accepted estimates into the
     vertices; the next solve() consumes that trial, anything else drops it (estimates popped).  The calls and their order are
     those of the run without look-ahead (G2OHIP_ADAPTER_LOOKAHEAD=0): chi2, lambda, trial counts and the final estimates are
     EQUAL, with accepted and with rejected look-ahead trials; the trial queued by the last iteration is dropped by the
-    destructor, the one queued before a second optimize() by its iteration 0."""
+    destructor, the one queued before a second optimize() by its iteration 0.  The Gauss-Newton driver queues its next iteration
+    the same way (push, solve, update; the status comes back with the next solve())."""
     pr = ba_case(40, 400, outlier_frac=0.05 if huber > 0 else 0.0)
     prob = str(tmp_path / "p.txt")
     _write_problem(prob, pr, huber)
     for mode, n in ((None, 8), ("twice", 4)):
-        off, err0 = _run(host, prob, "lm_fix6_3_hipdev", n, str(tmp_path / "off.json"), {"G2OHIP_ADAPTER_LOOKAHEAD": "0"}, mode=mode)
-        on, err1 = _run(host, prob, "lm_fix6_3_hipdev", n, str(tmp_path / "on.json"), mode=mode)
+        off, err0 = _run(host, prob, solver, n, str(tmp_path / "off.json"), {"G2OHIP_ADAPTER_LOOKAHEAD": "0"}, mode=mode)
+        on, err1 = _run(host, prob, solver, n, str(tmp_path / "on.json"), mode=mode)
         assert "look-ahead trials queued" not in err0
         line = [ln for ln in err1.splitlines() if "look-ahead trials queued" in ln]
         assert line, err1[-800:]
