@@ -2630,7 +2630,7 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
     llap("contributor lists: per off-diagonal block");
   };
   if (lists_threaded) {
-    lists_thread = std::thread([&] {
+    lists_thread = std::thread([this, build_lists, &lists_error] {   // (the closure by value: it is declared after the joiner)
       try {
         G2OHIP_HIP_CHECK(hipSetDevice(device_));
         build_lists();
