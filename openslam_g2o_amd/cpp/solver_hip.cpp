@@ -19,6 +19,7 @@
 #include "g2o/core/optimization_algorithm_levenberg.h"
 #include "g2o_hip_algorithm.h"
 #include "g2o_hip_solver.h"
+#include "g2o_hip_var_solver.h"
 
 namespace g2o {
 
@@ -34,14 +35,15 @@ Solver* allocNarrow() {
   return new SolverType(new LinearSolverHip<typename SolverType::PoseMatrixType>(p));
 }
 
-// "<method>_<shape>_<hip|hipls|hipdev>": method gn | lm | dl (hipdev: gn | lm), shape fix3_2 | fix6_3 | fix7_3
+// "<method>_<shape>_<hip|hipls|hipdev>": method gn | lm | dl (hipdev: gn | lm), shape fix3_2 | fix6_3 | fix7_3 | var (hip, hipdev)
 OptimizationAlgorithm* createSolver(const std::string& fullSolverName) {
   const std::string method = fullSolverName.substr(0, 2);
   const std::string::size_type us = fullSolverName.rfind('_');
   const std::string shape = fullSolverName.substr(3, us - 3), seam = fullSolverName.substr(us + 1);
   const bool narrow = seam == "hipls";
   Solver* s = 0;
-  if (shape == "fix3_2") s = narrow ? allocNarrow<3, 2>() : allocWide<3, 2>();
+  if (shape == "var") s = narrow ? 0 : new BlockSolverHipVar();   // (the narrow seam's variable shape is g2o's own BlockSolverX over a LinearSolver)
+  else if (shape == "fix3_2") s = narrow ? allocNarrow<3, 2>() : allocWide<3, 2>();
   else if (shape == "fix6_3") s = narrow ? allocNarrow<6, 3>() : allocWide<6, 3>();
   else if (shape == "fix7_3") s = narrow ? allocNarrow<7, 3>() : allocWide<7, 3>();
   if (!s) return 0;
@@ -97,5 +99,13 @@ G2OHIP_REGISTER(gn_fix7_3_hipdev, "Gauss-Newton: device-resident iteration on MI
 G2OHIP_REGISTER(lm_fix3_2_hipdev, "Levenberg: device-resident iteration on MI355X (fixed blocksize)", 3, 2);
 G2OHIP_REGISTER(lm_fix6_3_hipdev, "Levenberg: device-resident iteration on MI355X (fixed blocksize)", 6, 3);
 G2OHIP_REGISTER(lm_fix7_3_hipdev, "Levenberg: device-resident iteration on MI355X (fixed blocksize)", 7, 3);
+
+// the names of the variable-block-size solver (solver_csparse.cpp:54-59 registers gn_var / lm_var / dl_var): the shape is read off the
+// graph at Solver::init (g2o_hip_var_solver.h)
+G2OHIP_REGISTER(gn_var_hip, "Gauss-Newton: multifrontal block Cholesky on MI355X (shape 3-2 / 6-3 / 7-3 read off the graph)", -1, -1);
+G2OHIP_REGISTER(lm_var_hip, "Levenberg: multifrontal block Cholesky on MI355X (shape 3-2 / 6-3 / 7-3 read off the graph)", -1, -1);
+G2OHIP_REGISTER(dl_var_hip, "Dogleg: multifrontal block Cholesky on MI355X (shape 3-2 / 6-3 / 7-3 read off the graph)", -1, -1);
+G2OHIP_REGISTER(gn_var_hipdev, "Gauss-Newton: device-resident iteration on MI355X (shape read off the graph)", -1, -1);
+G2OHIP_REGISTER(lm_var_hipdev, "Levenberg: device-resident iteration on MI355X (shape read off the graph)", -1, -1);
 
 }  // namespace g2o

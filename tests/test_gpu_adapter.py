@@ -320,6 +320,40 @@ def test_planar_pose_graph_through_the_g2o_vtables(host, tmp_path, solver):
         assert np.abs(np.array(runs[0]["poses"]) - np.array(runs[1]["poses"])).max() < 1e-7
 
 
+def test_variable_shape_solver_names_read_the_shape_off_the_graph(host, tmp_path):
+    """gn_var / lm_var / dl_var are the names g2o registers for BlockSolverX (solver_csparse.cpp:54-59) and what most g2o
+    applications ask for.  `*_var_hip` / `*_var_hipdev` pick 3-2 / 6-3 / 7-3 from the dimensions of the graph's vertices when
+    the algorithm initialises the solver and forward to the fixed-shape device solver: the SAME numbers as the fixed names, on a
+    bundle-adjustment graph (6-3, host loop and device-resident driver) and on the planar pose graph (3-2, no marginalised
+    vertex); the property reports variable dimensions (-1)."""
+    pr = ba_case(30, 300)
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr)
+    for var, fix in (("lm_var_hip", "lm_fix6_3_hip"), ("lm_var_hipdev", "lm_fix6_3_hipdev"), ("dl_var_hip", "dl_fix6_3_hip")):
+        a, erra = _run(host, prob, var, 4, str(tmp_path / "a.json"))
+        b, _ = _run(host, prob, fix, 4, str(tmp_path / "b.json"))
+        assert a["property"]["name"] == var and a["property"]["poseDim"] == -1 and a["property"]["landmarkDim"] == -1
+        assert a["iterations"] == b["iterations"] and a["trials"] == b["trials"]
+        assert a["chi2"] == b["chi2"] and a["lambda"] == b["lambda"] and a["cams"] == b["cams"] and a["points"] == b["points"]
+        if var.endswith("hipdev"):
+            assert DEV_ON in erra
+    from tests.helpers import manhattan_golden
+    g = manhattan_golden()
+    path = str(tmp_path / "m.txt")
+    with open(path, "w") as f:
+        nv, ne = len(g["estimates"]), len(g["vi"])
+        f.write("%d %d\n" % (nv, ne))
+        for i in range(nv):
+            f.write("%d %s\n" % (1 if g["hidx"][i] < 0 else 0, " ".join("%.17g" % v for v in g["estimates"][i])))
+        for k in range(ne):
+            f.write("%d %d %s %s\n" % (g["vi"][k], g["vj"][k], " ".join("%.17g" % v for v in g["meas"][k]),
+                                       " ".join("%.17g" % v for v in np.asarray(g["omega"][k]).reshape(-1))))
+    a, _ = _run(host, path, "gn_var_hip", 4, str(tmp_path / "a.json"), mode="se2")
+    b, _ = _run(host, path, "gn_fix3_2_hip", 4, str(tmp_path / "b.json"), mode="se2")
+    assert a["chi2"] == b["chi2"] and a["poses"] == b["poses"]
+    assert np.allclose(a["chi2"], g["chi2_gn"][1:5], rtol=1e-6, atol=0)
+
+
 def test_3d_pose_graph_through_the_g2o_vtables(host, tmp_path):
     """BASELINE.json config 2 (sphere: VertexSE3 / EdgeSE3, BlockSolver_6_3 shape, no Schur complement) through the plugin
     and the vtables, Levenberg-Marquardt: on the device fast path (EdgeSE3 groups bound to g2ohip_pg_* type 2: analytic

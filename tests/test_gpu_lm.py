@@ -300,6 +300,20 @@ def test_trial_stats_matches_the_three_separate_calls():
     b.restoreDiagonal()
     b.setLambda(3.0, True)
     assert b.solve()
+    # the two halves: trialStatsBegin queues the sums and their read-back (no synchronisation), the next trialStats only waits
+    # for them -- other work queued in between (here: the estimates pushed back and forth) does not disturb the numbers
+    c, gc = lm.setup_device_ba(pr)
+    gc.linearize()
+    c.buildSystem()
+    c.setLambda(3.0, True)
+    c.solveAsync()
+    gc.update(); c.restoreDiagonal(); gc.compute_active_errors()
+    c.trialStatsBegin(3.0)
+    with pytest.raises(Exception):
+        c.trialStatsBegin(3.0)        # the previous one has not been read
+    ok, chi_d, sc_d = c.trialStats(123.0)   # (lambda of the begun call counts)
+    assert ok and chi_d == chi and sc_d == sc
+    assert np.array_equal(a.x(), c.x())
 
 
 def test_batch_statistics_line_is_g2o_stats_compatible():
