@@ -416,6 +416,11 @@ int g2ohip_ba_set_edges_classes(g2ohip_solver* s, int set, const int32_t* cam_ve
 int g2ohip_ba_set_estimates(g2ohip_solver* s, int n_cams, const double* cams, const int32_t* cam_hidx, int n_points,
                             const double* points, const int32_t* point_hidx);
 int g2ohip_ba_get_estimates(g2ohip_solver* s, double* cams, double* points);
+/* The estimates of SELECTED vertices (indices into the arrays of g2ohip_ba_set_estimates): cams [n_cams][12], points [n_points][3].
+ * What a caller with a few host-side edges reads of an LM trial -- BaseUnaryEdge / BaseMultiEdge::computeError
+ * (base_unary_edge.hpp:42-72) need the estimates of the vertices THEY touch, not all 1.1 M -- next to the full read-back. */
+int g2ohip_ba_get_estimates_of(g2ohip_solver* s, int n_cams, const int32_t* cam_index, double* cams, int n_points, const int32_t* point_index,
+                               double* points);
 /* The same read-back (what SparseOptimizer::update leaves in the vertices, sparse_optimizer.cpp:422-432, fetched for the caller's
  * setEstimate loop) started ASYNCHRONOUSLY behind everything queued so far -- typically right after g2ohip_ba_update of an LM
  * trial -- on a copy stream of the library, in pieces: piece 0 = the cameras, pieces 1 .. point_pieces (<= 16) = the points in

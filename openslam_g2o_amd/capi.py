@@ -52,7 +52,7 @@ EXPORTS = [
     "g2ohip_solve_schur", "g2ohip_solve_reduced", "g2ohip_solve_back_substitute", "g2ohip_ls_create",
     "g2ohip_ls_destroy", "g2ohip_ls_init", "g2ohip_ls_solve", "g2ohip_ls_solve_pattern", "g2ohip_ls_get_stats", "g2ohip_ls_set_option",
     "g2ohip_kernel_slots", "g2ohip_kernel_name", "g2ohip_kernel_time", "g2ohip_add_schur_pattern", "g2ohip_set_edge_set_parts",
-    "g2ohip_set_lambda_split", "g2ohip_host_register", "g2ohip_host_unregister", "g2ohip_ba_set_edges", "g2ohip_ba_set_edges_classes", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates", "g2ohip_ba_fetch_estimates_begin", "g2ohip_ba_fetch_estimates_wait",
+    "g2ohip_set_lambda_split", "g2ohip_host_register", "g2ohip_host_unregister", "g2ohip_ba_set_edges", "g2ohip_ba_set_edges_classes", "g2ohip_ba_set_estimates", "g2ohip_ba_get_estimates", "g2ohip_ba_get_estimates_of", "g2ohip_ba_fetch_estimates_begin", "g2ohip_ba_fetch_estimates_wait",
     "g2ohip_ba_linearize", "g2ohip_ba_update", "g2ohip_ba_push", "g2ohip_ba_pop", "g2ohip_ba_discard_top",
     "g2ohip_set_partition", "g2ohip_solve_reduced_local", "g2ohip_solve_reduced_shared", "g2ohip_solve_reduced_finish",
     "g2ohip_schur_operator_prepare", "g2ohip_schur_operator_apply", "g2ohip_solve_async", "g2ohip_trial_stats_begin", "g2ohip_trial_stats", "g2ohip_solve_reduced_finish_async", "g2ohip_exchange_setup", "g2ohip_exchange_pack", "g2ohip_exchange_unpack", "g2ohip_exchange_status",
@@ -147,6 +147,7 @@ def load():
     L.g2ohip_ba_set_edges_classes.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, c_int_p]
     L.g2ohip_ba_set_estimates.argtypes = [vp, C.c_int, c_dbl_p, c_int_p, C.c_int, c_dbl_p, c_int_p]
     L.g2ohip_ba_get_estimates.argtypes = [vp, c_dbl_p, c_dbl_p]
+    L.g2ohip_ba_get_estimates_of.argtypes = [vp, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_dbl_p]
     L.g2ohip_set_edge_errors.argtypes = [vp, C.c_int, c_dbl_p]
     L.g2ohip_ba_fetch_estimates_begin.argtypes = [vp, c_dbl_p, c_dbl_p, C.c_int]
     L.g2ohip_ba_fetch_estimates_wait.argtypes = [vp, C.c_int]
@@ -586,6 +587,13 @@ class HipBlockSolver:
         cams = np.empty((self._ba_n[0], 12))
         pts = np.empty((self._ba_n[1], 3))
         _check(self.L.g2ohip_ba_get_estimates(self.h, _dp(cams), _dp(pts)), "baGetEstimates")
+        return cams, pts
+
+    def baGetEstimatesOf(self, cam_index, point_index):
+        """Estimates of selected cameras / points (indices into the arrays of baSetEstimates)."""
+        ci, pi = _i32(cam_index), _i32(point_index)
+        cams, pts = np.empty((len(ci), 12)), np.empty((len(pi), 3))
+        _check(self.L.g2ohip_ba_get_estimates_of(self.h, len(ci), _ip(ci), _dp(cams), len(pi), _ip(pi), _dp(pts)), "baGetEstimatesOf")
         return cams, pts
 
     def baFetchEstimatesBegin(self, pieces=4):

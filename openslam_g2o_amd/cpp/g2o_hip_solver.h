@@ -1579,22 +1579,41 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
         seen[v] = t;
       }
     for (typename std::map<OptimizableGraph::Vertex*, Touched>::const_iterator it = seen.begin(); it != seen.end(); ++it) _touched.push_back(it->second);
+    _touchedCams.clear();
+    _touchedPoints.clear();
+    for (size_t i = 0; i < _touched.size(); ++i) (_touched[i].kind ? _touchedPoints : _touchedCams).push_back(_touched[i].idx);
+    _touchedCamEst.assign(12 * _touchedCams.size() + 1, 0.);
+    _touchedPointEst.assign(3 * _touchedPoints.size() + 1, 0.);
     _hybrid = true;
     if (std::getenv("G2OHIP_ADAPTER_VERBOSE"))
       std::cerr << "BlockSolverHip: hybrid device loop -- " << es.size() << " host-linearised edges over " << _touched.size() << " free vertices of the device front end" << std::endl;
   }
   // the trial estimates of the touched vertices from the device (the read-back started behind the trial's update, or a plain one)
+  // (only THEIR estimates cross PCIe here -- g2ohip_ba_get_estimates_of, a gather and a copy of a few hundred bytes --: the full
+  // read-back of the trial, 34 MB at the metric configuration, keeps running next to the host's error evaluation instead of
+  // being waited for in front of it)
   bool refreshTouched() {
     if (_touched.empty()) return true;
-    if (_fetchBegun) {
-      if (g2ohip_ba_fetch_estimates_wait(_h, kFetchPieces) != G2OHIP_OK) return fail("ba_fetch_estimates_wait");
-    } else if (g2ohip_ba_get_estimates(_h, _camBuf.data(), _pointBuf.data()) != G2OHIP_OK) {
-      return fail("ba_get_estimates");
-    }
+    if (g2ohip_ba_get_estimates_of(_h, (int)_touchedCams.size(), _touchedCams.data(), _touchedCamEst.data(), (int)_touchedPoints.size(),
+                                   _touchedPoints.data(), _touchedPointEst.data()) != G2OHIP_OK)
+      return fail("ba_get_estimates_of");
+    size_t ic = 0, ip = 0;
     for (size_t i = 0; i < _touched.size(); ++i) {
       _touched[i].v->push();
-      if (_touched[i].kind) scatterPointsRange((size_t)_touched[i].idx, (size_t)_touched[i].idx + 1);
-      else scatterCamsRange((size_t)_touched[i].idx, (size_t)_touched[i].idx + 1);
+      if (_touched[i].kind) {
+        const double* xs = &_touchedPointEst[3 * ip++];
+        Eigen::Vector3d x;
+        for (int row = 0; row < 3; ++row) x[row] = xs[row];
+        _points[_touched[i].idx]->setEstimate(x);
+      } else {
+        const double* c = &_touchedCamEst[12 * ic++];
+        Eigen::Matrix3d R;
+        Eigen::Vector3d t;
+        for (int col = 0; col < 3; ++col)
+          for (int row = 0; row < 3; ++row) R(row, col) = c[row + 3 * col];
+        for (int row = 0; row < 3; ++row) t[row] = c[9 + row];
+        _cams[_touched[i].idx]->setEstimate(SE3Quat(R, t));
+      }
     }
     _touchedPushed = true;
     return true;
@@ -1623,6 +1642,8 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     int kind, idx;                                     // 0: _cams[idx], 1: _points[idx]
   };
   std::vector<Touched> _touched;
+  std::vector<int32_t> _touchedCams, _touchedPoints;   // their indices in _cams / _points, in the order of _touched
+  std::vector<double> _touchedCamEst, _touchedPointEst;
   bool _hybrid, _touchedPushed, _fetchBegun;
   int _lookDropped = 0, _lookQueued = 0;
   bool _lookPending, _lookEnabled, _queueing;          // look-ahead trial in flight | allowed (G2OHIP_ADAPTER_LOOKAHEAD) | being queued (no timing synchronisation)

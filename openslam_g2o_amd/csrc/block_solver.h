@@ -127,6 +127,7 @@ class BlockSolver {
                             double cx, double cy, int n_classes, const double* class_params, const int* edge_class);
   void ba_set_estimates(int n_cams, const double* cams, const int* cam_hidx, int n_points, const double* points, const int* point_hidx);
   void ba_get_estimates(double* cams, double* points);
+  void ba_get_estimates_of(int n_cams, const int* cam_idx, double* cams, int n_points, const int* point_idx, double* points);   // selected vertices
   void ba_fetch_begin(double* cams, double* points, int point_pieces);   // the same, asynchronous and in pieces (see the definition)
   void ba_fetch_wait(int piece);
   static constexpr int kFetchMaxPieces = 17;
@@ -380,6 +381,8 @@ class BlockSolver {
     DevBuf<int> ll_row;       // ... pose block row of the observation's Hpl block (-1: fixed pose)
     DevBuf<double> ll_meas, ll_omega;   // ... measurement, information
     DevBuf<int4> tile_ll;
+    DevBuf<int> sel_idx;      // ba_get_estimates_of: the selected cameras | points
+    DevBuf<double> sel_out;
     bool ll_slots_ok = false;
     bool has_backup = false;
   } ba_;

@@ -5275,6 +5275,44 @@ void BlockSolver::ba_get_estimates(double* cams, double* points) {
   if (points) ba_.pts.download(points, (size_t)ba_.n_points * 3, st_);
 }
 
+// The estimates of SELECTED vertices (what a caller with a few host-side edges needs of a trial: the adapter's hybrid loop reads the
+// handful of cameras / points its host-linearised edges touch here instead of waiting for the whole read-back): one gather
+// kernel, one small copy, one synchronisation.
+__global__ void ba_gather_estimates_kernel(int nc, int np, const int* __restrict__ idx, const double* __restrict__ cams,
+                                           const double* __restrict__ pts, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nc * 12) out[t] = cams[(size_t)idx[t / 12] * 12 + t % 12];
+  else if (t < nc * 12 + np * 3) {
+    const int u = t - nc * 12;
+    out[t] = pts[(size_t)idx[nc + u / 3] * 3 + u % 3];
+  }
+}
+
+void BlockSolver::ba_get_estimates_of(int n_cams, const int* cam_idx, double* cams, int n_points, const int* point_idx, double* points) {
+  if (ba_.n_cams <= 0) throw StateFailure("ba_get_estimates_of before ba_set_estimates");
+  if (n_cams < 0 || n_points < 0 || (n_cams > 0 && (!cam_idx || !cams)) || (n_points > 0 && (!point_idx || !points)))
+    throw ArgFailure("ba_get_estimates_of: bad arguments");
+  for (int i = 0; i < n_cams; ++i)
+    if (cam_idx[i] < 0 || cam_idx[i] >= ba_.n_cams) throw ArgFailure("ba_get_estimates_of: camera index out of range");
+  for (int i = 0; i < n_points; ++i)
+    if (point_idx[i] < 0 || point_idx[i] >= ba_.n_points) throw ArgFailure("ba_get_estimates_of: point index out of range");
+  const size_t n = (size_t)n_cams * 12 + (size_t)n_points * 3;
+  if (n == 0) return;
+  G2OHIP_HIP_CHECK(hipSetDevice(device_));
+  std::vector<int> idx((size_t)n_cams + n_points);
+  std::copy(cam_idx, cam_idx + n_cams, idx.begin());
+  std::copy(point_idx, point_idx + n_points, idx.begin() + n_cams);
+  ba_.sel_idx.upload(idx, st_);
+  ba_.sel_out.alloc(n);
+  hipLaunchKernelGGL(ba_gather_estimates_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st_, n_cams, n_points, ba_.sel_idx.p, ba_.cams.p,
+                     ba_.pts.p, ba_.sel_out.p);
+  G2OHIP_HIP_CHECK(hipGetLastError());
+  std::vector<double> h(n);
+  ba_.sel_out.download(h.data(), n, st_);   // (synchronises)
+  std::copy(h.begin(), h.begin() + (size_t)n_cams * 12, cams);
+  std::copy(h.begin() + (size_t)n_cams * 12, h.end(), points);
+}
+
 // The same read-back started ASYNCHRONOUSLY behind everything queued on the solver's stream so far (the caller: right after
 // ba_update of an LM trial), on a copy stream of its own, in pieces with an event each: piece 0 = the cameras, pieces 1 .. n = the
 // points in n equal ranges.  ba_fetch_wait(k) returns once piece k is in the caller's buffer, so the caller writes piece k into

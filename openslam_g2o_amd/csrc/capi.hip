@@ -702,6 +702,14 @@ int g2ohip_ba_get_estimates(g2ohip_solver* s, double* cams, double* points) {
     return G2OHIP_OK;
   });
 }
+int g2ohip_ba_get_estimates_of(g2ohip_solver* s, int n_cams, const int32_t* cam_index, double* cams, int n_points, const int32_t* point_index,
+                               double* points) {
+  REQUIRE_HANDLE(s);
+  return guarded([&] {
+    s->impl->ba_get_estimates_of(n_cams, cam_index, cams, n_points, point_index, points);
+    return G2OHIP_OK;
+  });
+}
 int g2ohip_ba_fetch_estimates_begin(g2ohip_solver* s, double* cams, double* points, int point_pieces) {
   REQUIRE_HANDLE(s);
   return guarded([&] {
