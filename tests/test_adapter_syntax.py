@@ -37,14 +37,16 @@ def test_adapter_overrides_every_pure_virtual_of_the_seams(tmp_path):
 
 
 def test_registered_names_follow_the_cli_convention():
-    """`g2o -solver <name>`: names are <gn|lm|dl>_fix<p>_<l>_<hip|hipls> and <gn|lm>_fix<p>_<l>_hipdev, the library anchor is g2o_optimization_library_hip,
+    """`g2o -solver <name>`: names are <gn|lm|dl>_fix<p>_<l>_<hip|hipls>, <gn|lm>_fix<p>_<l>_hipdev and <gn|lm|dl>_var_hip / <gn|lm>_var_hipdev, the library anchor is g2o_optimization_library_hip,
     and the documented file name matches *_solver_*.so (g2o_common.cpp:82)."""
     text = open(os.path.join(CPP, "solver_hip.cpp")).read()
     names = [n for n in re.findall(r"G2OHIP_REGISTER\((\w+),", text) if n != "name"]   # (the macro definition itself)
     # every method x fixed shape the CSparse plugin registers (solver_csparse.cpp:117-140), under both seams
     # + the device-resident Gauss-Newton / Levenberg drivers over the wide seam (g2o_hip_algorithm.h)
     assert set(names) == ({"%s_fix%s_%s" % (m, sh, seam) for m in ("gn", "lm", "dl") for sh in ("3_2", "6_3", "7_3") for seam in ("hip", "hipls")}
-                          | {"%s_fix%s_hipdev" % (m, sh) for m in ("gn", "lm") for sh in ("3_2", "6_3", "7_3")})
+                          | {"%s_fix%s_hipdev" % (m, sh) for m in ("gn", "lm") for sh in ("3_2", "6_3", "7_3")}
+                          # + the names of the variable-block-size solver (solver_csparse.cpp:54-59), shape read off the graph (g2o_hip_var_solver.h)
+                          | {"gn_var_hip", "lm_var_hip", "dl_var_hip", "gn_var_hipdev", "lm_var_hipdev"})
     assert len(set(names)) == len(names)
     assert "G2O_REGISTER_OPTIMIZATION_LIBRARY(hip)" in text
     assert re.search(r"lib\w*_solver_\w+\.so", text)
