@@ -193,21 +193,29 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
  private:
   // One trial behind devPush(), queued without a synchronisation: setLambda, solve, update, (the read-back of the trial's
   // estimates starts next to its error evaluation), restoreDiagonal, computeActiveErrors.  levenberg.cpp:98-117.
-  bool queueTrial(bool fetch) {
+  bool queueTrialSolve(bool fetch) {
     _solver->setLambda(_currentLambda, true);
     if (!_dev->devSolveAsync() || !_dev->devUpdate()) return false;
     if (fetch && _writeBack) _fetched = _dev->devFetchBegin();
     _solver->restoreDiagonal();
-    return _dev->devLinearize(false);
+    return true;
   }
+  bool queueTrial(bool fetch) { return queueTrialSolve(fetch) && _dev->devLinearize(false); }
   // The head of the NEXT solve(), queued before the accepted estimates are written into the vertices: the same calls in the same
   // order as solve() makes them (devLinearize / devChi2 find the trial's evaluation still valid: no kernel, no synchronisation),
   // so the numbers are those of the run without look-ahead.  The read-back of THIS trial's estimates has to wait until the
-  // write-back has emptied the host buffers: begun by finish().
-  bool lookAhead(double& chi) {
+  // write-back has emptied the host buffers: begun by finish().  Two halves: up to the trial's update, and its error evaluation
+  // with the sums -- the hybrid loop's host edges evaluate their errors on the host, behind a synchronisation: there the
+  // write-back goes in between.
+  bool lookAheadSolve(double& chi) {
     _dev->devSetQueueing(true);
-    bool ok = _dev->devLinearize(true) && _dev->devChi2(chi) && _dev->devBuildSystem() && _dev->devPush();
-    if (ok) ok = queueTrial(/*fetch=*/false) && _dev->devTrialStatsBegin(_currentLambda);
+    const bool ok = _dev->devLinearize(true) && _dev->devChi2(chi) && _dev->devBuildSystem() && _dev->devPush() && queueTrialSolve(/*fetch=*/false);
+    _dev->devSetQueueing(false);
+    return ok;
+  }
+  bool lookAheadErrors() {
+    _dev->devSetQueueing(true);                          // (hybrid loop: the host edges' trial errors must leave no trace in the vertices)
+    const bool ok = _dev->devLinearize(false) && _dev->devTrialStatsBegin(_currentLambda);
     _dev->devSetQueueing(false);
     return ok;
   }
@@ -220,16 +228,19 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
     if (_fetched && !_accepted) {
       _dev->devFetchCancel();
     } else if (_writeBack && _accepted) {
-      bool ahead = mayLookAhead && _fetched && _dev->devCanLookAhead();
+      const bool ahead = mayLookAhead && _fetched && _dev->devCanLookAhead();
+      const bool hybrid = ahead && _dev->devHybrid();
       if (ahead) {
         double chi = 0.;
-        if (!lookAhead(chi)) return false;
+        if (!lookAheadSolve(chi)) return false;
+        if (!hybrid && !lookAheadErrors()) return false;
         _lookChi = chi;
         (void)currentChi;                                // (== chi: the accepted trial's sum, cached by the library)
       }
       ok = _fetched ? _dev->devFetchEnd() : _dev->devGetEstimates();
       _fetched = false;
       if (ahead) {
+        if (hybrid && !lookAheadErrors()) return false;
         _fetched = _dev->devFetchBegin();                // the queued trial's estimates, behind its update
         _dev->devSetLookAheadPending(true);
       }

@@ -182,6 +182,7 @@ class HipDeviceGraph {
   // anything else that enters the solver first (a new optimize(), computeMarginals, buildSystem, the destructor) drops it:
   // the sums are drained and the estimates popped, the device holds what the vertices hold (devDropLookAhead).
   virtual bool devCanLookAhead() const { return false; }
+  virtual bool devHybrid() const { return false; }     // host-linearised groups next to the front end: they read (a few of) the vertices
   virtual bool devTrialStatsBegin(double /*lambda*/) { return false; }
   virtual bool devLookAheadPending() const { return false; }
   virtual void devSetLookAheadPending(bool) {}
@@ -958,6 +959,10 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
       // push() that devPop / devDiscardTop resolve with the device's own stack.
       if (!jacobians && !refreshTouched()) return false;
       if (!hostGeneric(/*computeErrors=*/true, jacobians)) return false;
+      // the errors of a LOOK-AHEAD trial: the caller must not find the speculative estimates in its vertices (nor their errors in
+      // its edges) when solve() returns -- the touched vertices go back to the accepted estimates at once; if the next solve()
+      // accepts the trial, devDiscardTop writes the cached trial estimates into them
+      if (!jacobians && _queueing) touchedBackToAccepted();
     }
     for (size_t gi = 0; gi < _groups.size(); ++gi) {
       const int fast = _groups[gi].fast;
@@ -976,14 +981,20 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     return true;
   }
   // look-ahead (see HipDeviceGraph): only the bundle-adjustment front end with its pipelined write-back -- a pose-graph group's
-  // estimates are read back whole at the end of devFetchEnd, i.e. AFTER a queued update would have moved them, and the hybrid
-  // loop's host groups read the vertices the write-back is still filling
+  // estimates are read back whole at the end of devFetchEnd, i.e. AFTER a queued update would have moved them.  The hybrid loop's
+  // host groups read only the vertices they touch, and those hold the accepted estimates already (refreshTouched of the accepted
+  // trial, kept by discardTop): the driver queues the trial up to its update, writes back, and evaluates the host errors then.
   virtual bool devCanLookAhead() const {
-    if (!_lookEnabled || !_pin || _hybrid || !_multi.empty() || _groups.empty()) return false;
-    for (size_t gi = 0; gi < _groups.size(); ++gi)
-      if (_groups[gi].fast != 1) return false;
-    return true;
+    if (!_lookEnabled || !_pin || _groups.empty()) return false;
+    if (!_hybrid && !_multi.empty()) return false;
+    bool ba = false;
+    for (size_t gi = 0; gi < _groups.size(); ++gi) {
+      if (_groups[gi].fast == 1) ba = true;
+      else if (_groups[gi].fast != 0 || !_hybrid) return false;
+    }
+    return ba;
   }
+  virtual bool devHybrid() const { return _hybrid; }
   virtual bool devTrialStatsBegin(double lambda) { return g2ohip_trial_stats_begin(_h, lambda) == G2OHIP_OK || fail("trial_stats_begin"); }
   virtual bool devLookAheadPending() const { return _lookPending; }
   virtual void devSetLookAheadPending(bool on) {
@@ -1034,12 +1045,18 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     if (_touchedPushed)
       for (size_t i = 0; i < _touched.size(); ++i) _touched[i].v->pop();
     _touchedPushed = false;
+    _touchedSpec = false;                                // (a look-ahead trial that was rejected or dropped: the vertices never saw it)
     return forEachFrontEnd(g2ohip_ba_pop, g2ohip_pg_pop, "pop");
   }
   virtual bool devDiscardTop() {
     if (_touchedPushed)
       for (size_t i = 0; i < _touched.size(); ++i) _touched[i].v->discardTop();
     _touchedPushed = false;
+    if (_touchedSpec) {                                  // an accepted look-ahead trial: its estimates of the touched vertices, from the cache
+      setTouchedFromCache();
+      hostErrorsOnly();
+      _touchedSpec = false;
+    }
     return forEachFrontEnd(g2ohip_ba_discard_top, g2ohip_pg_discard_top, "discard_top");
   }
 
@@ -1589,17 +1606,9 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
       std::cerr << "BlockSolverHip: hybrid device loop -- " << es.size() << " host-linearised edges over " << _touched.size() << " free vertices of the device front end" << std::endl;
   }
   // the trial estimates of the touched vertices from the device (the read-back started behind the trial's update, or a plain one)
-  // (only THEIR estimates cross PCIe here -- g2ohip_ba_get_estimates_of, a gather and a copy of a few hundred bytes --: the full
-  // read-back of the trial, 34 MB at the metric configuration, keeps running next to the host's error evaluation instead of
-  // being waited for in front of it)
-  bool refreshTouched() {
-    if (_touched.empty()) return true;
-    if (g2ohip_ba_get_estimates_of(_h, (int)_touchedCams.size(), _touchedCams.data(), _touchedCamEst.data(), (int)_touchedPoints.size(),
-                                   _touchedPoints.data(), _touchedPointEst.data()) != G2OHIP_OK)
-      return fail("ba_get_estimates_of");
+  void setTouchedFromCache() {
     size_t ic = 0, ip = 0;
     for (size_t i = 0; i < _touched.size(); ++i) {
-      _touched[i].v->push();
       if (_touched[i].kind) {
         const double* xs = &_touchedPointEst[3 * ip++];
         Eigen::Vector3d x;
@@ -1615,6 +1624,32 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
         _cams[_touched[i].idx]->setEstimate(SE3Quat(R, t));
       }
     }
+  }
+  // computeError of the host-linearised edges at what the vertices hold now (their _error members only: nothing goes to the device)
+  void hostErrorsOnly() {
+    for (size_t gi = 0; gi < _groups.size(); ++gi)
+      if (!_groups[gi].fast)
+        for (size_t k = 0; k < _groups[gi].edges.size(); ++k) _groups[gi].edges[k]->computeError();
+    for (size_t m = 0; m < _multi.size(); ++m)
+      for (size_t k = 0; k < _multi[m].edges.size(); ++k) _multi[m].edges[k]->computeError();
+  }
+  void touchedBackToAccepted() {
+    if (_touchedPushed)
+      for (size_t i = 0; i < _touched.size(); ++i) _touched[i].v->pop();
+    _touchedPushed = false;
+    _touchedSpec = true;
+    hostErrorsOnly();
+  }
+  // (only THEIR estimates cross PCIe here -- g2ohip_ba_get_estimates_of, a gather and a copy of a few hundred bytes --: the full
+  // read-back of the trial, 34 MB at the metric configuration, keeps running next to the host's error evaluation instead of
+  // being waited for in front of it)
+  bool refreshTouched() {
+    if (_touched.empty()) return true;
+    if (g2ohip_ba_get_estimates_of(_h, (int)_touchedCams.size(), _touchedCams.data(), _touchedCamEst.data(), (int)_touchedPoints.size(),
+                                   _touchedPoints.data(), _touchedPointEst.data()) != G2OHIP_OK)
+      return fail("ba_get_estimates_of");
+    for (size_t i = 0; i < _touched.size(); ++i) _touched[i].v->push();
+    setTouchedFromCache();
     _touchedPushed = true;
     return true;
   }
@@ -1623,6 +1658,9 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   bool getEstimatesBA() { return false; }
   void planHybrid() { _hybrid = false; }
   bool refreshTouched() { return true; }
+  void setTouchedFromCache() {}
+  void hostErrorsOnly() {}
+  void touchedBackToAccepted() {}
 #endif
 
   g2ohip_solver* _h;
@@ -1645,6 +1683,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   std::vector<int32_t> _touchedCams, _touchedPoints;   // their indices in _cams / _points, in the order of _touched
   std::vector<double> _touchedCamEst, _touchedPointEst;
   bool _hybrid, _touchedPushed, _fetchBegun;
+  bool _touchedSpec = false;                           // the cache holds the touched vertices' estimates of a look-ahead trial the vertices have not seen
   int _lookDropped = 0, _lookQueued = 0;
   bool _lookPending, _lookEnabled, _queueing;          // look-ahead trial in flight | allowed (G2OHIP_ADAPTER_LOOKAHEAD) | being queued (no timing synchronisation)
   enum { kFetchPieces = 4 };                           // point ranges of the pipelined write-back (devFetchBegin / devFetchEnd)

@@ -113,6 +113,7 @@ class BlockSolverHipVar : public BlockSolverBase, public HipDeviceGraph {
   virtual bool devPop() { return _dev && _dev->devPop(); }
   virtual bool devDiscardTop() { return _dev && _dev->devDiscardTop(); }
   virtual bool devCanLookAhead() const { return _dev && _dev->devCanLookAhead(); }
+  virtual bool devHybrid() const { return _dev && _dev->devHybrid(); }
   virtual bool devTrialStatsBegin(double lambda) { return _dev && _dev->devTrialStatsBegin(lambda); }
   virtual bool devLookAheadPending() const { return _dev && _dev->devLookAheadPending(); }
   virtual void devSetLookAheadPending(bool on) { if (_dev) _dev->devSetLookAheadPending(on); }

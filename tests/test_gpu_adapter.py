@@ -717,7 +717,7 @@ def test_hybrid_device_loop_with_a_prior_edge_no_front_end_knows(host, tmp_path)
     exe, plugin = host
 
     def run(solver, env=None):
-        out = str(tmp_path / ("%s_%d.json" % (solver, len(env or {}))))
+        out = str(tmp_path / ("%s_%d.json" % (solver, len(env or {}))))      # (one file per run)
         e = dict(os.environ, G2OHIP_ADAPTER_VERBOSE="1")
         e.update(env or {})
         r = subprocess.run([exe, "none", plugin, solver, "5", out, "bench:2000:20000:5:prior:huber"], capture_output=True, text=True, env=e, timeout=600)
@@ -735,6 +735,13 @@ def test_hybrid_device_loop_with_a_prior_edge_no_front_end_knows(host, tmp_path)
     assert tr_h == tr_ref and tr_o == tr_ref
     assert np.allclose(hyb, ref, rtol=1e-7, atol=0), (hyb, ref)     # (bench mode prints 9 digits)
     assert np.allclose(off, ref, rtol=1e-7, atol=0)
+    # the look-ahead trial under the hybrid loop: the host edges' trial errors are evaluated behind the write-back, the touched
+    # vertices go back to the accepted estimates before solve() returns (the host's chi2 between the iterations sees them) and get
+    # the trial's from the cache when it is accepted -- the numbers of the run without look-ahead
+    assert "look-ahead trials queued" in err_h
+    c0_n, nol, tr_n, err_n = run("lm_fix6_3_hipdev", {"G2OHIP_ADAPTER_LOOKAHEAD": "0", "G2OHIP_X": "1"})
+    assert "look-ahead trials queued" not in err_n
+    assert nol == hyb and tr_n == tr_h
 
 
 def test_save_hessian_writes_the_octave_file_of_the_reference(host, tmp_path):
