@@ -450,7 +450,10 @@ int main(int argc, char** argv) {
       const OptimizationAlgorithm::SolverResult r = algo->solve(i);
       const double tIter = get_monotonic_time() - t1;
       G2OBatchStatistics::setGlobalStats(0);
-      if (r == OptimizationAlgorithm::Fail) return 5;
+      if (r == OptimizationAlgorithm::Fail) {
+        std::cerr << "bench: solve(" << i << ") returned Fail" << std::endl;
+        return 5;
+      }
       t1 = get_monotonic_time();
       double chi = 0.;
       if (!tight || i == iterations - 1) {
