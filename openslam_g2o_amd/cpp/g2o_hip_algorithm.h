@@ -232,15 +232,20 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
       const bool hybrid = ahead && _dev->devHybrid();
       if (ahead) {
         double chi = 0.;
-        if (!lookAheadSolve(chi)) return false;
-        if (!hybrid && !lookAheadErrors()) return false;
+        if (!lookAheadSolve(chi) || (!hybrid && !lookAheadErrors())) {
+          (void)_dev->devPop();                          // (a device error half-way: the estimate stack must not keep the trial's level)
+          return false;
+        }
         _lookChi = chi;
         (void)currentChi;                                // (== chi: the accepted trial's sum, cached by the library)
       }
       ok = _fetched ? _dev->devFetchEnd() : _dev->devGetEstimates();
       _fetched = false;
       if (ahead) {
-        if (hybrid && !lookAheadErrors()) return false;
+        if (hybrid && !lookAheadErrors()) {
+          (void)_dev->devPop();
+          return false;
+        }
         _fetched = _dev->devFetchBegin();                // the queued trial's estimates, behind its update
         _dev->devSetLookAheadPending(true);
       }
@@ -338,7 +343,10 @@ class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNew
         const bool q = _dev->devLinearize(true) && _dev->devBuildSystem() && _dev->devPush() && _dev->devSolveAsync() && _dev->devUpdate() &&
                        _dev->devLinearize(false) && _dev->devTrialStatsBegin(0.);
         _dev->devSetQueueing(false);
-        if (!q) return OptimizationAlgorithm::Fail;
+        if (!q) {
+          (void)_dev->devPop();                            // (a device error half-way: no level may stay on the estimate stack)
+          return OptimizationAlgorithm::Fail;
+        }
       }
       if (!(fetched ? _dev->devFetchEnd() : _dev->devGetEstimates())) return OptimizationAlgorithm::Fail;
       if (ahead) {
