@@ -114,6 +114,14 @@ def test_device_producers_match_oracle(fused):
     cams_o, pts_o = O.ba_oplus(pr["cams"], pr["pts"], pr["cam_hidx"], np.arange(pr["L"], dtype=np.int32), o.x(), 6 * pr["nP"])
     assert relerr(cams, cams_o) < 1e-10 and relerr(pts, pts_o) < 1e-10
     assert np.array_equal(cams[:2], pr["cams"][:2])            # fixed poses untouched
+    # selected vertices only (g2ohip_ba_get_estimates_of: what a caller with a few host-side edges reads of a trial)
+    ci, pi = [3, 0, pr["P"] - 1], [7, pr["L"] - 1, 7, 0]
+    cs, ps = s.baGetEstimatesOf(ci, pi)
+    assert np.array_equal(cs, cams[ci]) and np.array_equal(ps, pts[pi])
+    cs, ps = s.baGetEstimatesOf([], [5])
+    assert cs.shape == (0, 12) and np.array_equal(ps, pts[[5]])
+    with pytest.raises(Exception):
+        s.baGetEstimatesOf([pr["P"]], [])                    # out of range
     g.pop()
     cams2, pts2 = s.baGetEstimates()
     assert np.array_equal(cams2, pr["cams"]) and np.array_equal(pts2, pr["pts"])   # pop restores bit-exactly
