@@ -75,7 +75,6 @@ typedef struct g2ohip_stats {
   size_t bandChains;                 /* leaf chains of the elimination tree factorised by the sliding-window band kernel */
   size_t bandCholeskyNNZ, bandPivots; /* ... their share of choleskyNNZ and of the pivot columns (scalars) */
   size_t shardedCollectives;         /* all-reduces of the last g2ohip_solve_sharded (2 with option sharded_merge where the partition allows, else 3) */
-  size_t treeFactorGroups;           /* groups of fronts (one workgroup each) that factorise the tree levels above the band chains (option tree_factor; 0: one workgroup per front) */
   size_t treeBackwardGroups;         /* groups of fronts (one workgroup each) that sweep the tree levels backward (option tree_backward; 0: task by task) */
 } g2ohip_stats;
 /* (G2OBatchStatistics::timeIteration / levenbergIterations / chi2 belong to the caller's optimisation loop:

@@ -504,7 +504,6 @@ static void fill_chol_stats(const CholStats* cs, g2ohip_stats* out) {
   out->bandCholeskyNNZ = cs->nnzL_band;
   out->bandPivots = cs->piv_band;
   out->treeBackwardGroups = cs->n_tree_groups;
-  out->treeFactorGroups = cs->n_factor_groups;
 }
 
 int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out) {
@@ -548,7 +547,6 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   else if (!std::strcmp(name, "wave_kernel")) s->impl->chol_opt.wave_kernel = (int)value;
   else if (!std::strcmp(name, "band_kernel")) s->impl->chol_opt.band_kernel = (int)value;
   else if (!std::strcmp(name, "tree_backward")) s->impl->chol_opt.tree_backward = (int)value;
-  else if (!std::strcmp(name, "tree_factor")) s->impl->chol_opt.tree_factor = (int)value;
   else if (!std::strcmp(name, "overlap_level_halves")) s->impl->chol_opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "lazy_level_joins")) s->impl->chol_opt.lazy_level_joins = (int)value;
   else if (!std::strcmp(name, "big_gather")) s->impl->chol_opt.big_gather = (int)value;
@@ -1074,7 +1072,6 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   else if (!std::strcmp(name, "wave_kernel")) ls->opt.wave_kernel = (int)value;
   else if (!std::strcmp(name, "band_kernel")) ls->opt.band_kernel = (int)value;
   else if (!std::strcmp(name, "tree_backward")) ls->opt.tree_backward = (int)value;
-  else if (!std::strcmp(name, "tree_factor")) ls->opt.tree_factor = (int)value;
   else if (!std::strcmp(name, "overlap_level_halves")) ls->opt.overlap_level_halves = (int)value;
   else if (!std::strcmp(name, "lazy_level_joins")) ls->opt.lazy_level_joins = (int)value;
   else if (!std::strcmp(name, "big_gather")) ls->opt.big_gather = (int)value;

@@ -74,10 +74,6 @@ struct CholOptions {
   int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
   size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
   int band_kernel = 1;                   // leaf chains of a band (+ one dense border) on the sliding-window kernel (band_chain.inc)
-  int tree_factor = 0;                   // tree levels of the factorisation above the band chains by GROUPS of fronts: a subtree of up to eight small
-                                         // fronts in one eight-wave workgroup, one wave per front, children -> parent through LDS (tree_factor.inc).
-                                         // Built, bit-identical, and measured SLOWER (0.316 against 0.207 ms at the metric configuration: what the
-                                         // hand-offs save, one wave per front loses on the assembly and the scatter; profiles/r5_tree_factor_stamps.txt): off
   int tree_backward = 1;                 // backward sweep of the tree levels of a dependency-driven group by GROUPS of fronts: one sixteen-wave workgroup
                                          // per subtree of up to sixteen small fronts, hand-offs inside a group through LDS (tree_backward_kernel); 2: also
                                          // the leaf chains below them by one wave per chain (chain_backward_kernel: measured slower, see there); 0: task by task
@@ -88,7 +84,6 @@ struct CholStats {
   size_t n_fronts = 0, n_levels = 0, n_tasks = 0, max_front_dim = 0;
   size_t n_band = 0;      // leaf chains on the band kernel
   size_t nnzL_band = 0, piv_band = 0;   // ... their share of nnz(L) and of the pivot columns (scalars)
-  size_t n_factor_groups = 0; // groups of fronts of the factorisation's tree levels (tree_factor_kernel)
   size_t n_tree_groups = 0;   // groups of fronts of the backward sweep (tree_backward_kernel)
   double flops = 0;       // factorisation flops (dense-front count)
   double t_symbolic = 0;  // seconds, host
@@ -153,8 +148,6 @@ struct BandChainRec {
 };
 // tree_backward_kernel: the fronts it takes (pivot columns, boundary rows: scalars) and the fronts (waves) of a group
 constexpr int kTreePiv = 24, kTreeBnd = 48, kTreeWaves = 16;
-// tree_factor_kernel: fronts (waves) of a group, assembly buffers (fronts per level of a group), levels of a full group
-constexpr int kTfWaves = 8, kTfSlots = 4, kTfLevels = 3;
 constexpr int kChainCap = 1536;   // chain_backward_kernel: pivot scalars of a leaf chain kept in LDS (12 KB)
 constexpr int kBandFrontInts = 17;   // first pivot block, pivot scalars, L offset (2), m, local row of band blocks +0..+7, of border blocks 0..3
 
@@ -341,12 +334,10 @@ class SparseCholesky {
   struct FactorGroup {
     LevelLaunch LL; int first_level, last_level; bool dep; int band_count = 0, band_rec0 = 0, band_ent_cap = 0, band_tab_cap = 0;
     int tb_grp0 = 0, tb_ngrp = 0, tb_low = 0;   // tree_backward: its groups (d_tb_grec), the launch slots (lowest levels) left to the per-task kernel
-    int tf_grp0 = 0, tf_ngrp = 0;               // tree_factor: its groups (d_tf_grec): the tasks above the band chains by groups of fronts in one workgroup
     int tb_chain_cap = 0;                       // > 0: those slots are leaf chains swept by chain_backward_kernel (one wave each); the most pivot scalars of a chain
   };
   std::vector<FactorGroup> groups_[2];     // factorisation launches: runs of levels (dep: one launch, in-kernel dependencies)
   DevBuf<int> d_ready;
-  DevBuf<int4> d_tf_grec, d_tf_front;   // tree_factor: per group (first entry, fronts, levels, -), per front (see tree_factor.inc)
   DevBuf<int4> d_tb_grec;    // tree_backward: per group (first entry of d_tb_front, fronts, levels, front to wait for)
   DevBuf<int2> d_tb_front;   // ... per group front (front, level inside the group | tasks to release << 8), level by level
   DevBuf<int> d_tb_rows;     // ... the boundary row lists (indexed like d_rows) with the rows a front of the same group owns replaced by -1 - (offset in LDS)
@@ -370,7 +361,6 @@ class SparseCholesky {
   void launch_factor(const LevelLaunch& LL, const double* dA, bool fwd, hipStream_t st, bool dep = false, int parts = 3);
   bool band_usable(const FactorGroup& G, const double* dA) const;
   void launch_band(const FactorGroup& G, const double* dA, bool fused, hipStream_t st, bool dep);
-  void launch_tree_factor(const FactorGroup& G, const double* dA, bool fused, hipStream_t st);   // the group's band chains (band_chain.inc)
   hipStream_t side_[2] = {nullptr, nullptr};   // factor_phase: the two halves of a level / the forward step of its large fronts
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   void launch_solve(const LevelLaunch& LL, bool fwd, hipStream_t st, bool glb_only = false, bool dep = false, bool skip_glb = false, int dep_tail = 0);

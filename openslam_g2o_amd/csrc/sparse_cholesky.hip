@@ -1590,118 +1590,6 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   }
   d_ready.alloc((size_t)std::max(nf, 1));
   d_ready.zero(st);
-  // --- tree levels of the factorisation by groups of fronts (tree_factor_kernel, tree_factor.inc): the tasks of a dependency-driven
-  // wave-kernel group above its band chains are cut into groups top down -- a front takes its children into its group when it
-  // has one or two and all of them are such tasks' fronts; whole levels while at most kTfSlots fronts per level and kTfWaves in all
-  // (the first group of a tree is made shallower so that the groups below it are full).  A front with other children starts the
-  // bottom of its group: its children's fronts are roots of their own groups.  Groups are listed children first (launch order).
-  {
-    std::vector<int4> grec;
-    std::vector<int4> gent;
-    for (int ph = 0; ph < 2; ++ph)
-      for (FactorGroup& G : groups_[ph]) {
-        G.tf_grp0 = (int)grec.size();
-        G.tf_ngrp = 0;
-        if (!opt.tree_factor || !G.dep || !G.LL.wv || G.LL.glb_count > 0 || G.band_count >= G.LL.lds_count) continue;
-        std::vector<char> in_tree(nf, 0);
-        int n_tree = 0;
-        for (int q = G.LL.lds_begin + G.band_count; q < G.LL.lds_begin + G.LL.lds_count; ++q) {
-          const int t = factor_order[q];
-          for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
-            in_tree[S.task_fronts[k]] = 1;
-            ++n_tree;
-          }
-        }
-        std::vector<int> height(nf, 0), roots;
-        for (int f2 = 0; f2 < nf; ++f2) {   // (fronts are numbered children first)
-          if (!in_tree[f2]) continue;
-          height[f2] = std::max(height[f2], 1);
-          const int pf = S.f_parent[f2];
-          if (pf >= 0 && in_tree[pf]) height[pf] = std::max(height[pf], height[f2] + 1);
-          else roots.push_back(f2);
-        }
-        auto absorbs = [&](int f2) {   // all of its (one or two) children are tree fronts: they join its group
-          const int nc = S.child_off[f2 + 1] - S.child_off[f2];
-          if (nc < 1 || nc > 2) return false;
-          for (int ch = S.child_off[f2]; ch < S.child_off[f2 + 1]; ++ch)
-            if (!in_tree[S.children[ch]]) return false;
-          return true;
-        };
-        struct Grp { std::vector<std::vector<int>> lv; };
-        std::vector<Grp> grps;
-        std::vector<int> queue(roots);
-        for (size_t qi = 0; qi < queue.size(); ++qi) {
-          const int r = queue[qi];
-          const int depth_cap = (height[r] - 1) % kTfLevels + 1;
-          Grp gr;
-          gr.lv.push_back(std::vector<int>(1, r));
-          int cnt = 1;
-          for (;;) {
-            const std::vector<int>& cur = gr.lv.back();
-            std::vector<int> next;
-            for (int f2 : cur)
-              if (absorbs(f2))
-                for (int ch = S.child_off[f2]; ch < S.child_off[f2 + 1]; ++ch) next.push_back(S.children[ch]);
-            const bool grow = !next.empty() && (int)gr.lv.size() < depth_cap && (int)next.size() <= kTfSlots && cnt + (int)next.size() <= kTfWaves;
-            if (!grow) {   // the fronts of this level are the bottom of the group: their tree children start groups of their own
-              for (int f2 : cur)
-                for (int ch = S.child_off[f2]; ch < S.child_off[f2 + 1]; ++ch)
-                  if (in_tree[S.children[ch]]) queue.push_back(S.children[ch]);
-              break;
-            }
-            // (fronts of this level that do not absorb: bottom of the group at this depth)
-            for (int f2 : cur)
-              if (!absorbs(f2))
-                for (int ch = S.child_off[f2]; ch < S.child_off[f2 + 1]; ++ch)
-                  if (in_tree[S.children[ch]]) queue.push_back(S.children[ch]);
-            cnt += (int)next.size();
-            gr.lv.push_back(next);
-          }
-          grps.push_back(gr);
-        }
-        int covered = 0;
-        for (size_t gi = grps.size(); gi-- > 0;) {   // children first
-          const Grp& gr = grps[gi];
-          const int nlev = (int)gr.lv.size(), first = (int)gent.size();
-          std::vector<int> wave_of(nf, -1);
-          int wv = 0;
-          for (int d = nlev - 1; d >= 0; --d)       // waves: the deepest level first
-            for (int f2 : gr.lv[d]) wave_of[f2] = wv++;
-          for (int d = nlev - 1; d >= 0; --d) {
-            const bool bottom = d == nlev - 1;
-            for (size_t j = 0; j < gr.lv[d].size(); ++j) {
-              const int f2 = gr.lv[d][j];
-              const int pf = S.f_parent[f2];
-              const int pw = (d > 0 && pf >= 0) ? wave_of[pf] : -1;
-              int ordinal = 0, inkids = 0;
-              if (pw >= 0)
-                for (int ch = S.child_off[pf]; ch < S.child_off[pf + 1]; ++ch)
-                  if (S.children[ch] == f2) ordinal = ch - S.child_off[pf];
-              if (!bottom)
-                for (int ch = S.child_off[f2]; ch < S.child_off[f2 + 1]; ++ch)
-                  if (wave_of[S.children[ch]] >= 0) ++inkids;
-              // a chain task cut by the group boundary: its next front waits for this one through the counter, like for any child
-              int extra = 0;
-              if (pw < 0 && pf >= 0 && in_tree[pf] && task_of[pf] == task_of[f2]) extra |= 0x100;
-              if (inkids == 0)
-                for (int ch = S.child_off[f2]; ch < S.child_off[f2 + 1]; ++ch)
-                  if (in_tree[S.children[ch]] && task_of[S.children[ch]] == task_of[f2]) ++extra;
-              gent.push_back(make_int4(f2, (nlev - 1 - d) | ((int)j << 8) | (ordinal << 12) | (inkids << 16), pw, extra));
-              ++covered;
-            }
-          }
-          grec.push_back(make_int4(first, wv, nlev, 0));
-        }
-        if (covered != n_tree) throw StateFailure("tree_factor: the groups do not cover the tree tasks");
-        G.tf_ngrp = (int)grec.size() - G.tf_grp0;
-        if (getenv("G2OHIP_PLAN_DUMP")) fprintf(stderr, "phase %d tree factor: %d fronts in %d groups\n", ph, n_tree, G.tf_ngrp);
-      }
-    stats_.n_factor_groups = grec.size();
-    if (grec.empty()) grec.push_back(make_int4(0, 0, 0, 0));
-    if (gent.empty()) gent.push_back(make_int4(0, 0, -1, 0));
-    d_tf_grec.upload(grec, st);
-    d_tf_front.upload(gent, st);
-  }
   // --- backward sweep of the tree levels by groups of fronts (tree_backward_kernel).  In a dependency-driven group the levels
   // above the leaf level whose fronts are all small (kTreePiv pivot columns, kTreeBnd boundary rows) are cut into groups top
   // down: a root and whole levels of descendants while they fit sixteen waves (the first group of a tree is made shallower so
@@ -4480,7 +4368,6 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
 
 #include "wave_front.inc"
 #include "band_chain.inc"
-#include "tree_factor.inc"
 
 // Pivot block of a scratch-slab front (n <= 64 columns) on the matrix cores: the blocked right-looking Cholesky of
 // wave_front_kernel restricted to the pivot block -- the symmetric n x n block as ten upper 16 x 16 tiles in accumulator
@@ -4993,50 +4880,6 @@ void SparseCholesky::launch_band(const FactorGroup& G, const double* dA, bool fu
   if (band_hook) band_hook(1);
 }
 
-// the tasks of the group above its band chains by groups of fronts (tree_factor.inc)
-void SparseCholesky::launch_tree_factor(const FactorGroup& G, const double* dA, bool fused, hipStream_t st) {
-  const bool virt = dA == nullptr;
-  if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
-  const size_t sh = (size_t)kTfSlots * kTfSlotDoubles * sizeof(double) + (size_t)kTfWaves * 128 * sizeof(int4) + (size_t)(2 * kTfWaves * 64 + 2 * 16 * kWvT) * sizeof(int);
-  const double* bp = fused ? d_xp.p : (const double*)nullptr;
-  double* yo = fused ? d_y.p : (double*)nullptr;
-  WvPlan wp = wv_plan(plan_);
-#ifdef G2OHIP_TF_STAMPS
-  if (!d_dbg.p) d_dbg.alloc(16 * 16);
-  d_dbg.zero(st);
-  wp.dbg = d_dbg.p;
-#endif
-  const TreeFactorGroup* gr = reinterpret_cast<const TreeFactorGroup*>(d_tf_grec.p) + G.tf_grp0;
-#define G2OHIP_TREE_FACTOR(BS_)                                                                                                         \
-  if (virt) hipLaunchKernelGGL((tree_factor_kernel<BS_, true>), dim3(G.tf_ngrp), dim3(64 * kTfWaves), sh, st, wp, gr, d_tf_front.p, dA, bp, yo, 1); \
-  else hipLaunchKernelGGL((tree_factor_kernel<BS_, false>), dim3(G.tf_ngrp), dim3(64 * kTfWaves), sh, st, wp, gr, d_tf_front.p, dA, bp, yo, 1)
-  switch (bs_) {
-    case 3: G2OHIP_TREE_FACTOR(3); break;
-    case 6: G2OHIP_TREE_FACTOR(6); break;
-    case 7: G2OHIP_TREE_FACTOR(7); break;
-    default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
-  }
-#undef G2OHIP_TREE_FACTOR
-  G2OHIP_LAUNCH_CHECK("tree_factor_kernel");
-#ifdef G2OHIP_TF_STAMPS
-  if (getenv("G2OHIP_TF_STAMPS_PRINT")) {
-    std::vector<long long> hs(16 * 8);
-    d_dbg.download(hs.data(), hs.size(), st);
-    G2OHIP_HIP_CHECK(hipStreamSynchronize(st));
-    long long t0 = 0;
-    for (int w = 0; w < 8; ++w)
-      if ((hs[16 * w] & 0xff) > 0 && (t0 == 0 || hs[16 * w + 1] < t0)) t0 = hs[16 * w + 1];
-    for (int w = 0; w < 8; ++w) {
-      const int n = (int)(hs[16 * w] & 0xff);
-      if (!n) continue;
-      fprintf(stderr, "tree_factor group %d wave %d (front %lld, level %d):", (int)G2OHIP_TF_STAMPS, w, hs[16 * w] >> 16, (int)((hs[16 * w] >> 8) & 0xff));
-      for (int k = 0; k < n; ++k) fprintf(stderr, " %.2f", (hs[16 * w + 1 + k] - t0) * 0.01);
-      fprintf(stderr, "\n");
-    }
-  }
-#endif
-}
-
 bool SparseCholesky::has_band_chains(int phase) const {
   for (const FactorGroup& G : groups_[phase])
     if (G.band_count > 0 && opt.band_kernel && bs_ == 6) return true;
@@ -5049,12 +4892,6 @@ bool SparseCholesky::has_band_chains(int phase) const {
 void SparseCholesky::prepare_kernels() {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)tree_factor_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)tree_factor_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)tree_factor_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)tree_factor_kernel<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)tree_factor_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)tree_factor_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // allow > 64 KiB dynamic LDS for the LDS-resident front kernels
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)front_factor_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -5234,10 +5071,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
       LevelLaunch rest = LL;
       rest.lds_begin += G.band_count;
       rest.lds_count -= G.band_count;
-      if (rest.lds_count > 0 && G.tf_ngrp > 0 && G.dep && !dep_off_ && (fused || !fwd)) launch_tree_factor(G, dA, fused, st);
-      else if (rest.lds_count > 0) launch_factor(rest, dA, fused, st, G.dep);
-    } else if (G.band_count == 0 && G.tf_ngrp > 0 && G.dep && !dep_off_ && (fused || !fwd) && (parts & 2)) {
-      launch_tree_factor(G, dA, fused, st);
+      if (rest.lds_count > 0) launch_factor(rest, dA, fused, st, G.dep);
     } else {
       launch_factor(LL, dA, fused, st, G.dep);
     }

@@ -108,49 +108,3 @@ def test_tree_levels_swept_by_groups_of_fronts_equal_the_task_by_task_sweep_bit_
     o.set_lambda(lam, True)
     assert o.solve()
     assert relerr(x1, o.x()) < (dx_tolerance(o)[0] if P <= 300 else 1e-7)
-
-
-@pytest.mark.parametrize("P,L,huber,fold", [(257, 2600, 0.0, 1), (1500, 15000, 0.0, 1), (1500, 15000, 0.0, 0), (4000, 40000, 0.0, 1), (9000, 45000, 1.0, 1),
-                                            (20000, 100000, 0.0, 1)])
-def test_tree_levels_factorised_by_groups_of_fronts_equal_the_front_by_front_kernel_bit_for_bit(P, L, huber, fold):
-    """Tree levels of the factorisation above the band chains by groups of fronts in one workgroup (tree_factor_kernel, option
-    tree_factor: one wave per front, children -> parent through LDS in child order) against one four-wave workgroup per front with
-    the update matrices through HBM (wave_front_kernel): the same additions in the same order, the same matrix instructions on the
-    same operands -- the solution is identical bit for bit; against the oracle to the usual tolerance.  fold = 0: the matrix comes
-    from a materialised Hschur instead of Hpp and the Schur tiles' partial blocks."""
-    pr = ba_case(P, L, outlier_frac=0.05 if huber else 0.0)
-    lam = 25.0
-    ok1, x1, st1 = _solve(pr, lam, {"tree_factor": 1, "fuse_schur_reduce": fold}, huber=huber)
-    ok0, x0, st0 = _solve(pr, lam, {"tree_factor": 0, "fuse_schur_reduce": fold}, huber=huber)
-    assert ok0 and ok1
-    assert st1["numFronts"] == st0["numFronts"] and st0["treeFactorGroups"] == 0
-    if P >= 1500:
-        assert st1["treeFactorGroups"] > 0     # (the kernel under test really ran)
-    assert np.array_equal(x1, x0)
-    if P <= 9000:
-        o = oracle_ba(pr, huber=huber)
-        o.build_system()
-        o.set_lambda(lam, True)
-        assert o.solve()
-        assert relerr(x1, o.x()) < (dx_tolerance(o)[0] if P <= 300 else 1e-7)
-
-
-def test_tree_factor_groups_flag_a_non_positive_pivot_and_repeat_bit_for_bit():
-    pr = ba_case(4000, 40000)
-    s = hip_ba(pr, options={"tree_factor": 1})
-    s.buildSystem()
-    xs = []
-    for _ in range(3):
-        s.setLambda(3.0, True)
-        assert s.solve()
-        s.restoreDiagonal()
-        xs.append(s.x())
-    assert s.stats()["treeFactorGroups"] > 0
-    assert np.array_equal(xs[0], xs[1]) and np.array_equal(xs[0], xs[2])
-    s.setLambda(-1e9, True)
-    assert not s.solve()
-    s.restoreDiagonal()
-    s.setLambda(3.0, True)
-    assert s.solve()
-    s.restoreDiagonal()
-    assert np.array_equal(s.x(), xs[0])
