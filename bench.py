@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
+MFMA_F64_PEAK_TFLOPS = 78.6   # dense fp64 matrix rate: 256 CUs x 4 SIMDs x (v_mfma_f64_16x16x4_f64 = 2048 flops / 64 cycles) x 2.4 GHz
 
 
 def algorithmic_bytes(E, P, L, S, pp_nnzb, nnzL, p=6, l=3, d=2, folded=False):
@@ -241,6 +242,7 @@ def main():
     # falls back to the torch.distributed formulation of the same exchange if the library communicator cannot be
     # brought up (the reason goes to stderr and into the JSON line)
     lib_comm = "n/a"
+    world_checked = None     # what an all-reduce of ones through the library's communicator returned (= the ranks that took part)
     if emulate and solver.mode == "subtree" and solver._native_exchange():
         # the library's own sharded solve (g2ohip_solve_sharded: every phase queued by one call) with the all-reduces skipped
         solver.local.setOption("comm_emulate", 1)
@@ -257,6 +259,7 @@ def main():
                 torch.cuda.synchronize()
                 if not bool((one == float(world)).all().item()):
                     raise RuntimeError("library all-reduce self-check failed: %r" % one.tolist())
+                world_checked = int(one[0].item())
         except Exception as e:      # noqa: BLE001
             sys.stderr.write("bench: library communicator unavailable (%s); using torch.distributed\n" % e)
             solver._lib_comm = None
@@ -366,6 +369,7 @@ def main():
     # same command (profiles/r1_pmc_traffic.json, recipe in its _note); null when that file is absent
     # or the workload differs from the profiled one.
     traffic = None
+    pmc_all = {}
     pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % r) for r in (9, 8, 7, 6, 5, 4, 3, 2, 1))
                      if os.path.exists(q)), "")
     if pmc_path and world == 1 and not emulate and (P, L) == (100000, 1000000):   # (the counters were taken on the whole graph on one GPU)
@@ -381,11 +385,27 @@ def main():
                 per_launch = q["hbm_bytes_per_step"] / max(row["launches_per_step"], 1e-9)   # (per launch of the SLOT, like avg_ms)
                 row["pmc_traffic_GB"] = per_launch / 1e9
                 row["pmc_GBs"] = per_launch / 1e9 / (1e-3 * row["avg_ms"])
+                # matrix cores: v_mfma_f64_16x16x4_f64 wave instructions counted by SQ_INSTS_MFMA (2048 flops each) over this
+                # run's time for the slot, against the dense fp64 matrix peak; the busy-cycle counter beside it
+                n_mfma = q.get("SQ_INSTS_MFMA_per_step", 0)
+                if n_mfma:
+                    step_s = 1e-3 * row["avg_ms"] * row["launches_per_step"]
+                    row["mfma_TFLOPs"] = 2048.0 * n_mfma / step_s / 1e12
+                    row["mfma_util"] = row["mfma_TFLOPs"] / MFMA_F64_PEAK_TFLOPS
+                    if q.get("SQ_BUSY_CYCLES_per_step"):
+                        row["mfma_busy_cycles_over_sq_busy_cycles"] = q.get("SQ_VALU_MFMA_BUSY_CYCLES_per_step", 0) / q["SQ_BUSY_CYCLES_per_step"]
     roofline = dict(kernel=dname, bound="hbm", achieved=dk["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=dk["achieved_GBs"] / HBM_PEAK_GBS, traffic=traffic,
+                    # the same fraction on the bytes the counters saw move (traffic / this run's launch time / peak)
+                    frac_traffic=(traffic / (1e-3 * dk["avg_ms"]) / 1e9 / HBM_PEAK_GBS) if traffic and dk["avg_ms"] > 0 else None,
                     algorithmic_bytes_per_launch=kb.get(dname, 0), avg_launch_ms=dk["avg_ms"],
                     traffic_source="profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, 2x FETCH correction)" % os.path.basename(pmc_path)
-                    if traffic else None)
+                    if traffic else None,
+                    # the counters come from a separate rocprofv3 pass (gpurun refuses --pmc next to other tracing), taken at this commit
+                    traffic_commit=(pmc_all.get("_commit") if traffic else None))
+    mfma_kernels = {k: {"mfma_util": round(v["mfma_util"], 4), "mfma_TFLOPs": round(v["mfma_TFLOPs"], 2)} for k, v in per_kernel.items() if "mfma_util" in v}
+    if mfma_kernels:
+        roofline["mfma"] = dict(peak_TFLOPs=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s (dense fp64 matrix)", kernels=mfma_kernels)
 
     x_gpu = solver.local.x()
     if args.dump_xp:
@@ -417,6 +437,8 @@ def main():
         out["emulate"] = "rank %d of %d alone, exchange skipped: timing only" % emulate
     if world > 1 or emulate:
         out["collectives"] = lib_comm
+        if world_checked is not None:
+            out["rccl_world_checked" if lib_comm == "rccl" else "comm_world_checked"] = world_checked
         out["shard"] = dict(rank0_edges=E_loc, rank0_landmarks=L_loc, exchange_doubles_per_solve=solver.exchange_volume(),
                             comm=comm_asked if comm_asked == "peer" else args.comm)
         if comm_note:

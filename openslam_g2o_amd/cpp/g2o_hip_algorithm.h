@@ -300,8 +300,8 @@ class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNew
       } else {
         if (_fetched) _dev->devFetchCancel();
         if (!_dev->devPop()) return OptimizationAlgorithm::Fail;     // the increment of a factorisation that broke down is not applied
-        if (ok == 2) {                                     // (a dependency-driven launch gave up waiting: again, synchronously)
-          ok = _dev->devSolve();
+        if (ok == 2 || ok == 0) {                          // (a dependency-driven launch gave up waiting, or the undamped factorisation broke down:
+          ok = _dev->devSolve();                           //  again, synchronously -- devSolve repeats a singular undamped solve once with a tiny lambda)
           if (ok == 1 && !_dev->devUpdate()) return OptimizationAlgorithm::Fail;
         }
       }

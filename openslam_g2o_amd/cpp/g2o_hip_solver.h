@@ -211,7 +211,7 @@ class HipDeviceGraph {
 template <int p, int l>
 class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
  public:
-  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0), _devValid(false), _hybrid(false), _touchedPushed(false), _fetchBegun(false), _lookPending(false), _lookEnabled(true), _queueing(false) {
+  explicit BlockSolverHip(int device = 0) : _h(0), _doSchur(true), _writeDebug(false), _nP(0), _nL(0), _fastPath(true), _fastGroups(0), _devValid(false), _hybrid(false), _touchedPushed(false), _fetchBegun(false), _lookPending(false), _lookEnabled(true), _queueing(false), _lambdaInForce(false), _undampedRetries(0) {
     const char* la = std::getenv("G2OHIP_ADAPTER_LOOKAHEAD");   // 0: the LM driver never queues the next iteration's first trial early (A/B)
     if (la && la[0] == '0') _lookEnabled = false;
     const char* fp = std::getenv("G2OHIP_ADAPTER_FASTPATH");
@@ -776,11 +776,37 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
 
   // block_solver.hpp:353-486: x() <- solution of (H (+ lambda I)) x = b, full length; b() untouched; false iff not
   // positive definite
+  // Gauss-Newton drop-in on numerically singular systems (round 6).  The reference's up-looking Cholesky under block-AMD gets through
+  // an undamped long camera chain (kappa x eps >= 1) where the pivot test of csparse_helper.cpp:136 happens to pass, and
+  // OptimizationAlgorithmGaussNewton applies that step (optimization_algorithm_gauss_newton.cpp:73-85); the nested-dissection
+  // factorisation meets d <= 0 there and used to return Fail.  An UNDAMPED solve (no setLambda in force: Gauss-Newton, Dogleg's
+  // Gauss-Newton step) that breaks down is therefore repeated ONCE with lambda = 1e-14 x the largest diagonal entry -- from there on
+  // both solvers succeed and agree to kappa x eps (profiles/r5_gn_lambda0.txt) -- and says so on cerr.  Levenberg-Marquardt trials
+  // (setLambda in force) keep the reference's behaviour: solve() == false, the driver raises lambda.
+  int solveUndampedRetry() {
+    int rc = g2ohip_solve(_h);
+    if (rc == G2OHIP_NOT_PD && !_lambdaInForce) {
+      double md = 0.;
+      if (g2ohip_max_diagonal(_h, &md) == G2OHIP_OK && md > 0.) {
+        const double lam = 1e-14 * md;
+        std::cerr << "HipBlockSolver: the undamped system is numerically singular (non-positive pivot); solving once more with lambda = "
+                  << lam << " (1e-14 x the largest diagonal entry)" << std::endl;
+        if (g2ohip_set_lambda(_h, lam, 1) == G2OHIP_OK) {
+          rc = g2ohip_solve(_h);
+          g2ohip_restore_diagonal(_h);
+          ++_undampedRetries;
+        }
+      }
+    }
+    return rc;
+  }
+  int undampedRetries() const { return _undampedRetries; }
+
   virtual bool solve() {
     if (!_h) return false;
     devDropLookAhead();
     double t = get_monotonic_time();
-    const int rc = g2ohip_solve(_h);
+    const int rc = solveUndampedRetry();
     if (rc != G2OHIP_OK) {
       if (rc != G2OHIP_NOT_PD) fail("solve");
       else if (_writeDebug) {   // linear_solver_csparse.h:127-133: the matrix the Cholesky was given, loadable by Octave
@@ -814,10 +840,12 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   // block_solver.hpp:563-604: lambda on every scalar diagonal entry of Hpp and Hll; exact restore
   virtual bool setLambda(double lambda, bool backup = false) {
     devDropLookAhead();
+    _lambdaInForce = true;
     return _h && g2ohip_set_lambda(_h, lambda, backup ? 1 : 0) == G2OHIP_OK;
   }
   virtual void restoreDiagonal() {
     devDropLookAhead();
+    _lambdaInForce = false;
     if (_h) g2ohip_restore_diagonal(_h);
   }
 
@@ -1017,7 +1045,7 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   virtual bool devComputeScale(double lambda, double& scale) { return g2ohip_compute_scale(_h, lambda, &scale) == G2OHIP_OK || fail("compute_scale"); }
   virtual int devSolve() {
     double t = get_monotonic_time();
-    const int rc = g2ohip_solve(_h);
+    const int rc = solveUndampedRetry();
     _phase.deviceSolve += lap(t);
     ++_phase.solves;
     if (rc == G2OHIP_OK) return 1;
@@ -1672,6 +1700,8 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   bool _fastPath;
   int _fastGroups;                                     // groups bound to a device front end (Group::fast)
   bool _devValid;                                      // the front ends hold estimates for the current structure
+  bool _lambdaInForce;                                 // between setLambda and restoreDiagonal (a Levenberg-Marquardt trial): no undamped retry
+  int _undampedRetries;                                // undamped solves repeated with lambda = 1e-14 x max diag (solveUndampedRetry)
   bool _pin, _timing;
   int _threads;
   // hybrid loop (deviceResident with host-linearised groups): the free vertices those groups touch, as (vertex, camera / point, index)

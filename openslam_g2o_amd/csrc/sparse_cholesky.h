@@ -28,7 +28,7 @@
 namespace g2ohip {
 
 struct CholOptions {
-  int nd_leaf = 32;          // nested-dissection leaf size (blocks)
+  int nd_leaf = 0;           // nested-dissection leaf size (blocks); 0: 32 (and more, see analyze) for band-shaped graphs, 4 for the others
   int max_sn_scalars = 48;   // supernode (pivot panel) width cap, scalars
   int max_sn_scalars_lds = 24;  // ... for the fronts small enough for LDS
   double relax_zeros = 0.25; // relaxed amalgamation: tolerated share of explicit zero blocks in a panel

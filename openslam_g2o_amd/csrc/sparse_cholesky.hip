@@ -357,8 +357,30 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   std::vector<int> perm0;
   // leaf size: large systems get about as many leaves as the band kernel has chain slots (256 CUs x 8 one-wave chains, one
   // round instead of two and one tree level less: 0.53 -> 0.48 ms at the metric configuration), within what a chain may hold
+  // (round 6) nd_leaf = 0 (default): by the shape of the graph.  A camera trajectory's reduced system is a BAND -- the level structure
+  // from a pseudo-peripheral node has a handful of blocks per level --: its leaves are the band kernel's chains, long ones (32 blocks
+  // and more).  Anything wider (pose graphs, loop closures) gets leaves of 4 blocks: the separators then do the ordering and the tree
+  // is a third shallower (sphere 2 200: 57 -> 37 levels, 2.07 -> 1.44 ms per solve; manhattan: fill 2.45 -> 1.89 x the reference's
+  // block-AMD; profiles/r6_nd_leaf.txt).
   int nd_leaf = opt.nd_leaf;
-  if (opt.band_kernel && bs == 6) nd_leaf = std::min(std::max(nd_leaf, (nb / std::max(opt.world, 1) + 2047) / 2048), 128);   // (per rank: its share of the chains)
+  if (nd_leaf <= 0) {
+    bool band_like = false;
+    if (nb > 0) {
+      NdWork W(nb, xadj, adj);
+      int nlev = W.bfs(0, 0);
+      for (int sweep = 0; sweep < 2; ++sweep) {
+        const int far = W.queue.back();
+        W.clear_levels();
+        nlev = W.bfs(far, 0);
+      }
+      std::vector<int> lsize(nlev, 0);
+      for (int v : W.queue) lsize[W.level[v]]++;
+      const int widest = *std::max_element(lsize.begin(), lsize.end());
+      band_like = widest <= 12 && (long long)W.queue.size() <= 6LL * nlev;   // (the component of block 0 stands for the graph)
+    }
+    nd_leaf = band_like ? 32 : 4;
+  }
+  if (opt.band_kernel && bs == 6 && nd_leaf >= 32) nd_leaf = std::min(std::max(nd_leaf, (nb / std::max(opt.world, 1) + 2047) / 2048), 128);   // (per rank: its share of the chains)
   nested_dissection(nb, xadj, adj, nd_leaf, perm0);
   // --- etree + postorder, compose
   std::vector<int> iperm(nb), cp, ci, rp, ri, parent, post;

@@ -24,8 +24,8 @@ pytestmark = pytest.mark.gpu
 
 LNZ = json.load(open(os.path.join(GOLD, "lnz_amd.json")))
 # nested dissection with 24-scalar supernodes against AMD's pure band order: every column carries one separator
-# (24 rows) on top of the band: 2.19 measured; the bound leaves room for other leaf sizes
-FILL_BOUND = 2.5
+# (24 rows) on top of the band: 2.19 measured at the metric configuration (2.14-2.18 at the smaller sizes)
+FILL_BOUND = 2.25
 
 
 def _host_chi2(pr, huber=0.0):
