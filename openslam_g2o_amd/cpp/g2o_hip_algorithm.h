@@ -234,6 +234,8 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
         double chi = 0.;
         if (!lookAheadSolve(chi) || (!hybrid && !lookAheadErrors())) {
           (void)_dev->devPop();                          // (a device error half-way: the estimate stack must not keep the trial's level)
+          if (_fetched) _dev->devFetchCancel();          // ... nor the accepted trial's read-back stay in flight
+          _fetched = false;
           return false;
         }
         _lookChi = chi;
@@ -244,6 +246,7 @@ class OptimizationAlgorithmLevenbergHip : public OptimizationAlgorithmLevenberg 
       if (ahead) {
         if (hybrid && !lookAheadErrors()) {
           (void)_dev->devPop();
+          _fetched = false;
           return false;
         }
         _fetched = _dev->devFetchBegin();                // the queued trial's estimates, behind its update
@@ -291,6 +294,10 @@ class OptimizationAlgorithmGaussNewtonHip : public OptimizationAlgorithmGaussNew
     int ok = -1;
     bool fetched = false;
     if (consume) {
+      // (BatchStatistics on this path: the errors / buildSystem / solve of this iteration ran inside the previous solve()'s
+      // write-back; timeResiduals and timeQuadraticForm are reported as 0 -- not left over from an earlier iteration -- and
+      // timeLinearSolution is the wait for the queued solve's status.  G2OHIP_ADAPTER_LOOKAHEAD=0 restores the reference's split.)
+      if (globalStats) globalStats->timeResiduals = globalStats->timeQuadraticForm = 0.;
       _dev->devSetLookAheadPending(false);
       double chi = 0., scale = 0.;
       ok = _dev->devTrialStats(0., chi, scale);          // (the status of the queued solve; the sums ride along unused)

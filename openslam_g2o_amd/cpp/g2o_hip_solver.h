@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -29,6 +30,9 @@
 #include <typeinfo>
 #include <utility>
 #include <vector>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #include "g2o/core/batch_stats.h"
 #include "g2o/core/block_solver.h"
@@ -114,10 +118,21 @@ class HipWorkers {
   // A worker spins on the generation counter for a few milliseconds after its last job (an optimize() run hands out a job per
   // millisecond: waking 31 sleeping threads through a condition variable cost 0.3-0.5 ms per loop), then sleeps.
   void loop(size_t id, unsigned long long seen) {
+    // (the spin is bounded by TIME -- G2OHIP_ADAPTER_SPIN_US, default 1 500 us: one Levenberg-Marquardt iteration of the
+    // measured runs -- not by a yield count whose duration depends on the host's load: an embedding application gets its cores
+    // back a millisecond and a half after the solver's last parallel loop)
+    static const long spin_us = [] {
+      const char* e = std::getenv("G2OHIP_ADAPTER_SPIN_US");
+      return e ? std::atol(e) : 1500L;
+    }();
     for (;;) {
       unsigned spins = 0;
+      std::chrono::steady_clock::time_point t0;
       while (!_stop.load(std::memory_order_relaxed) && _gen.load(std::memory_order_acquire) == seen) {
-        if (++spins < 40000) {
+        if ((++spins & 63) == 1 && spins == 1) t0 = std::chrono::steady_clock::now();
+        const bool keep = spin_us > 0 && ((spins & 63) != 0 ||
+                          std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < spin_us);
+        if (keep) {
           std::this_thread::yield();
         } else {
           std::unique_lock<std::mutex> lk(_m);
@@ -219,7 +234,19 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     const char* pin = std::getenv("G2OHIP_ADAPTER_PINNED");
     _pin = !(pin && pin[0] == '0');
     const char* th = std::getenv("G2OHIP_ADAPTER_THREADS");   // host threads of the estimate gather / write-back loops (1 = serial)
-    const unsigned hc = std::thread::hardware_concurrency();
+    // (the CPUs this PROCESS may run on -- affinity mask / cpuset of a container --, not the machine's: hardware_concurrency counts
+    // cores a container was never given)
+    unsigned hc = std::thread::hardware_concurrency();
+#if defined(__linux__)
+    {
+      cpu_set_t cs;
+      CPU_ZERO(&cs);
+      if (sched_getaffinity(0, sizeof(cs), &cs) == 0) {
+        const int n = CPU_COUNT(&cs);
+        if (n > 0 && (hc == 0 || (unsigned)n < hc)) hc = (unsigned)n;
+      }
+    }
+#endif
     // (default: an eighth of the hardware threads, 8 to 32 -- the write-back of 1.1 M vertices is a cache miss per vertex and
     // scales with the threads up to there: 1.8 / 1.05 / 1.06 ms on 16 / 32 / 64 of the 256 threads of the measurement host)
     _threads = th ? std::atoi(th) : (int)std::min(32u, std::max(8u, hc / 8));
@@ -1035,9 +1062,10 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
     _lookPending = false;
     int ok = 0;
     double chi2 = 0., scale = 0.;
-    (void)g2ohip_trial_stats(_h, 0., &ok, &chi2, &scale);   // (drains the queued read-back)
+    const bool drained = g2ohip_trial_stats(_h, 0., &ok, &chi2, &scale) == G2OHIP_OK;   // (drains the queued read-back)
     if (_fetchBegun) devFetchCancel();
-    (void)devPop();                                     // the device holds what the vertices hold again
+    const bool popped = devPop();                       // the device holds what the vertices hold again
+    if (!drained || !popped) _devValid = false;         // ... unless one of the two failed: the next solve() uploads the estimates afresh
     ++_lookDropped;
   }
   int lookAheadsDropped() const { return _lookDropped; }
@@ -1700,8 +1728,6 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   bool _fastPath;
   int _fastGroups;                                     // groups bound to a device front end (Group::fast)
   bool _devValid;                                      // the front ends hold estimates for the current structure
-  bool _lambdaInForce;                                 // between setLambda and restoreDiagonal (a Levenberg-Marquardt trial): no undamped retry
-  int _undampedRetries;                                // undamped solves repeated with lambda = 1e-14 x max diag (solveUndampedRetry)
   bool _pin, _timing;
   int _threads;
   // hybrid loop (deviceResident with host-linearised groups): the free vertices those groups touch, as (vertex, camera / point, index)
@@ -1716,6 +1742,8 @@ class BlockSolverHip : public BlockSolverBase, public HipDeviceGraph {
   bool _touchedSpec = false;                           // the cache holds the touched vertices' estimates of a look-ahead trial the vertices have not seen
   int _lookDropped = 0, _lookQueued = 0;
   bool _lookPending, _lookEnabled, _queueing;          // look-ahead trial in flight | allowed (G2OHIP_ADAPTER_LOOKAHEAD) | being queued (no timing synchronisation)
+  bool _lambdaInForce;                                 // between setLambda and restoreDiagonal (a Levenberg-Marquardt trial): no undamped retry
+  int _undampedRetries;                                // undamped solves repeated with lambda = 1e-14 x max diag (solveUndampedRetry)
   enum { kFetchPieces = 4 };                           // point ranges of the pipelined write-back (devFetchBegin / devFetchEnd)
   mutable HipWorkers _workers;                         // persistent helper threads of parallelFor
   std::vector<void*> _pinned;                          // buffers registered with g2ohip_host_register

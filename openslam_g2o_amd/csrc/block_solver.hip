@@ -3053,7 +3053,10 @@ void BlockSolver::set_edge_data(int set, const double* J0, const double* J1, con
     es.omega = es.own_omega.p;
     es.err = es.own_err.p;
   }
-  if (had && !on_device && pJ0 == es.J0 && pJ1 == es.J1 && pO == es.omega && pE == es.err) chi2_valid_ = false;
+  // (a set bound to a device front end holds that front end's evaluations: host arrays uploaded into it replace them, the cached
+  // err_valid / jac_valid flags must go -- the full invalidation)
+  const bool front_end_set = set == ba_.set || set == pg_.set;
+  if (had && !on_device && !front_end_set && pJ0 == es.J0 && pJ1 == es.J1 && pO == es.omega && pE == es.err) chi2_valid_ = false;
   else invalidate_graphs();
   es.has_data = true;
   es.has_err = true;
@@ -5360,16 +5363,16 @@ void BlockSolver::ba_linearize(bool jacobians) {
     if (jacobians) es.has_data = true;
     return;
   }
-  ba_.err_valid = true;
-  if (need_jac) ba_.jac_valid = true;
-  chi2_valid_ = false;
   if (need_jac && (es.own_J0.n < (size_t)es.n * 6 || es.own_J1.n < (size_t)es.n * 12)) {   // (left out by ba_set_edges on the fused path)
     es.own_J0.alloc((size_t)es.n * 6);
     es.own_J1.alloc((size_t)es.n * 12);
     es.J0 = es.own_J0.p;
     es.J1 = es.own_J1.p;
-    invalidate_graphs();
+    invalidate_graphs();   // (clears err_valid / jac_valid: before they are set for the evaluation below)
   }
+  ba_.err_valid = true;
+  if (need_jac) ba_.jac_valid = true;
+  chi2_valid_ = false;
   if (profiling) tfe_.start(st_);
   // the chi2 of these errors rides along: 1 024 partial sums in this set's slot of the trial read-back buffer (chi2() and
   // trial_stats() take them from there while err_valid holds)

@@ -784,7 +784,8 @@ def test_gauss_newton_on_a_numerically_singular_chain_repeats_the_solve_with_a_t
     reduced system has kappa x eps >= 1; the reference's pivot test (csparse_helper.cpp:136) happens to pass under block-AMD and
     gn_fix6_3 takes the step, the nested-dissection factorisation meets d <= 0 (rounds 1-5: Fail at iteration 0).  The adapter
     now repeats an UNDAMPED solve that broke down once with lambda = 1e-14 x max diag, says so on cerr, and the iteration proceeds:
-    two iterations return OK and chi2 drops by more than an order of magnitude."""
+    both iterations return OK with finite chi2.  (What is NOT promised: a good step.  At kappa x eps >= 1 neither solver's increment
+    has a correct digit -- chi2 goes 2.6e8 -> 3.5e9 -> 1.1e8 here --; the point is that optimize() runs on like gn_fix6_3's does.)"""
     exe, plugin = host
     out = str(tmp_path / "gn.json")
     r = subprocess.run([exe, "none", plugin, solver, "2", out, "bench:20000:100000:5"], capture_output=True, text=True, timeout=900)
@@ -792,4 +793,4 @@ def test_gauss_newton_on_a_numerically_singular_chain_repeats_the_solve_with_a_t
     assert "numerically singular" in r.stderr and "1e-14" in r.stderr
     d = json.load(open(out))
     chis = [it["chi2"] for it in d["iterations"]]
-    assert len(chis) == 2 and chis[-1] < 0.1 * d["chi2_initial"], (d["chi2_initial"], chis)
+    assert len(chis) == 2 and np.isfinite(chis).all() and chis[-1] < d["chi2_initial"], (d["chi2_initial"], chis)
