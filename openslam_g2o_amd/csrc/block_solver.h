@@ -106,7 +106,6 @@ class BlockSolver {
   const double* x_device() const { return d_x.p; }
   const double* b_device() {
     ensure_bl();
-    ensure_pp();   // (ba_lazy_pose: the pose half of b is otherwise the previous iteration's until the next solve)
     return d_b.p;
   }
   void sync();
@@ -144,14 +143,14 @@ class BlockSolver {
   size_t schur_tile_bytes = 39 * 1024;     // LDS budget of one Schur tile
   int comm_emulate = 0;                    // TIMING ONLY: solve_sharded of one rank of an N-rank job run alone, the all-reduces skipped
                                            // (results are wrong; bench.py --emulate r/N: the per-rank time an N-GPU run is bounded by)
-  bool rhs_prefill = true;                 // solve(): schur_rhs_kernel also writes the permuted right-hand side and clears the factorisation's status word
+  static constexpr bool rhs_prefill = true;                 // solve(): schur_rhs_kernel also writes the permuted right-hand side and clears the factorisation's status word
   bool rhs_prefilled_ = false;             // ... and has done so for the next solve_reduced_device
   bool ba_fused = true;                    // evaluate BA errors/Jacobians inside the assembly kernels (no J arrays)
   // hipGraph replay of the launch-bound kernel sequences (one launch per tree level: factorisation with the
   // fused forward sweep, backward sweep): ~30 launches per iteration, which is what limits a rank once the
   // per-rank work shrinks (multi-GPU).  Needs a non-default stream.  Timing events sit between the graphs.
   bool use_graph = false;
-  int sharded_virtual = 1;                 // sharded solve: the factorisation reads Hpp + partial blocks itself (as on one GPU); only the
+  static constexpr int sharded_virtual = 1;                 // sharded solve: the factorisation reads Hpp + partial blocks itself (as on one GPU); only the
                                            // boundary blocks of the reduced system are reduced, exchanged and read back as blocks
   int sharded_merge = 1;                   // sharded solve: TWO all-reduces instead of three -- the boundary blocks and b_p travel with the
                                            // subtree roots (after the own subtrees) whenever only the shared top of the tree consumes them
@@ -169,15 +168,15 @@ class BlockSolver {
                                            // 2: the same PCG matrix-free (Schur complement never formed; Schur mode only)
   PcgOptions pcg_opt;
   int pcg_iterations = 0;
-  bool schur_sort_dests = true;            // order a tile's destinations by entry count (lockstep lane groups)
+  static constexpr bool schur_sort_dests = true;            // order a tile's destinations by entry count (lockstep lane groups)
   int num_cus_ = 256;
-  bool fuse_landmark_inverse = true;       // invert the landmark blocks inside the Schur tile kernel
-  bool overlap_assembly = false;           // fused BA assembly: pose-side kernel on a side stream next to the landmark-side one (measured: 0.2 ms SLOWER per iteration, kept as a switch)
+  static constexpr bool fuse_landmark_inverse = true;       // invert the landmark blocks inside the Schur tile kernel
+  static constexpr bool overlap_assembly = false;           // fused BA assembly: pose-side kernel on a side stream next to the landmark-side one (measured: 0.2 ms SLOWER per iteration, kept as a switch)
   bool fuse_schur_reduce = true;           // solve(): the factorisation assembles its fronts from Hpp and the tiles' partial
                                            // blocks directly; Hschur is only written out when somebody asks for it
   bool tiles_cover_all_ = false;
   bool mask_solution = true;               // solve_reduced_shared zeroes the x_p entries other ranks own (all-reduce of x_p)
-  int schur_group = 0;                     // lanes per destination in the Schur tile kernel (0 = auto)
+  static constexpr int schur_group = 0;                     // lanes per destination in the Schur tile kernel (0 = auto)
   const CholStats* chol_stats() const { return chol_ ? &chol_->stats() : nullptr; }
   int p() const { return p_; }
   int l() const { return l_; }
@@ -272,14 +271,11 @@ class BlockSolver {
   bool hschur_valid_ = true, virt_now_ = false;
  public:
   size_t dependency_fallbacks = 0;   // dependency-driven launches that gave up and were repeated level by level
-  bool ba_skip_hpl = true;            // fused BA path: Hpl is not written at all while nobody reads it (ensure_hpl)
-  bool ba_lazy_pose = false;          // fused BA path: the pose side of the assembly runs inside the solve, on a side stream next to the Schur tiles (ensure_pp).
-                                      // Measured round 4: the tiles take 0.402 instead of 0.347 ms with the pose kernel next to them, the iteration 1.231
-                                      // instead of 1.207 ms -- both kernels are bound by instruction issue on the same CUs; off, kept for A/B
+  static constexpr bool ba_skip_hpl = true;            // fused BA path: Hpl is not written at all while nobody reads it (ensure_hpl)
   bool ba_fuse_landmarks = true;      // ... and the landmark side (Hll, b_l, errors) is assembled by the Schur tiles of the solve
-  int ba_store_ll = 0;                // ... which then also write Hll and the errors to memory (0: only b_l and Dinv, what the solve reads)
-  bool ba_recompute_backsub = true;   // fused BA path: back-substitution from the Jacobians instead of reading Hpl
-  double fuse_reduce_max_partials = 6.0;   // solve() folds the Schur reduction into the factorisation only while a block of the reduced system has at most this many partial blocks on average
+  static constexpr int ba_store_ll = 0;                // ... which then also write Hll and the errors to memory (0: only b_l and Dinv, what the solve reads)
+  static constexpr bool ba_recompute_backsub = true;   // fused BA path: back-substitution from the Jacobians instead of reading Hpl
+  static constexpr double fuse_reduce_max_partials = 6.0;   // solve() folds the Schur reduction into the factorisation only while a block of the reduced system has at most this many partial blocks on average
   bool marginals_recursion = true;  // compute_marginals: all entries on the pattern of L in one top-down pass (sparse inverse) instead of one pair of sweeps per column
   bool marginals_reduced = false;   // compute_marginals: invert the reduced pose system instead of Hpp alone (the reference inverts Hpp)
  private:
@@ -338,14 +334,12 @@ class BlockSolver {
   bool ba_fuse_ll_ok() const;
   int ba_lm_group() const;
   void ensure_hpl();
-  void ensure_pp();
   void ensure_side();
   void launch_ba_poses(hipStream_t sp);
   void ensure_ll();
   void ensure_bl();
   void launch_ba_landmarks(bool write_hpl);
   bool hpl_valid_ = true;
-  bool pp_valid_ = true;   // Hpp's diagonal blocks and b_p of the fused BA path match the last build_system (false: left to the next solve)
   bool ll_valid_ = true;   // Hll, b_l and the errors of the fused BA path match the last build_system
   bool ll_hbm_partial_ = false;   // ... but the Schur tiles that assembled them wrote b_l only (Hll and the errors stayed on chip)
   void pg_validate();

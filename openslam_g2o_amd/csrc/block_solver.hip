@@ -2390,7 +2390,6 @@ void BlockSolver::require_structure() const {
 
 void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
   invalidate_graphs();
-  pp_valid_ = true;
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   nP_ = nP;
   nL_ = nL;
@@ -3311,18 +3310,6 @@ void BlockSolver::launch_ba_poses(hipStream_t sp) {
 #undef G2OHIP_BA_POSE_
 }
 
-// a reader of Hpp / b_p before the solve that was to run the pose side (build_system_impl, `lazy`)
-void BlockSolver::ensure_pp() {
-  if (pp_valid_) return;
-  if (!ba_recompute_ok())
-    throw StateFailure("the pose blocks were left to solve() by the last build_system and the estimates (or the robust kernel) have "
-                       "changed since: call build_system again, or set option ba_lazy_pose = 0");
-  G2OHIP_HIP_CHECK(hipSetDevice(device_));
-  launch_ba_poses(st_);
-  pp_valid_ = true;
-  G2OHIP_HIP_CHECK(hipGetLastError());
-}
-
 void BlockSolver::ensure_side() {
   if (side_) return;
   G2OHIP_HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
@@ -3333,7 +3320,7 @@ void BlockSolver::ensure_side() {
 void BlockSolver::build_system_impl() {
   if (profiling) tq_.start(st_);
   ba_.sys_version = -1;   // (set again by the fused BA branch)
-  hpl_valid_ = ll_valid_ = pp_valid_ = true;
+  hpl_valid_ = ll_valid_ = true;
   ll_hbm_partial_ = false;
   const size_t sizeP = (size_t)nP_ * p_;
   bool any_pose = false, any_lm = false;
@@ -3364,17 +3351,6 @@ void BlockSolver::build_system_impl() {
         launch_ba_landmarks(hpl_valid_);
         prof.end(KernelProf::kAsmLandmark, st_);
       }
-      // The pose side (Hpp diagonal blocks, b_p) is read by nothing the Schur tiles of the solve do: where the solve will run
-      // them (the tiles assemble the landmark side themselves), the pose kernel is left to that solve, which runs it on a side
-      // stream NEXT TO the tiles (ensure_pp() for any reader that comes first: maxDiagonal, b(), multiplyHessian, ...).
-      const bool lazy = ba_lazy_pose && !ll_valid_ && es.touches_pose && es.first_pose && chol_opt.world == 1 && linear_solver == 0 &&
-                        !prof.timing(KernelProf::kAsmPose) && [&] {
-                          for (size_t i = 0; i < sets_.size(); ++i)
-                            if ((int)i != ba_.set && sets_[i]->n > 0 && sets_[i]->touches_pose) return false;
-                          return true;
-                        }();
-      pp_valid_ = !lazy;
-      if (lazy) continue;
       prof.begin(KernelProf::kAsmPose, st_);
       launch_ba_poses(overlap ? side_ : st_);
       if (overlap) {
@@ -3523,7 +3499,6 @@ void BlockSolver::restore_diagonal() {
 }
 
 double BlockSolver::max_diagonal() {
-  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ensure_ll();
@@ -3557,7 +3532,6 @@ __global__ void gather_diag_kernel(int nv, int dim, const double* __restrict__ H
 }
 
 void BlockSolver::copy_diagonal(double* host) {
-  ensure_pp();
   require_structure();
   if (!host) throw ArgFailure("copy_diagonal: null pointer");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
@@ -3574,7 +3548,6 @@ void BlockSolver::copy_diagonal(double* host) {
 }
 
 double BlockSolver::compute_scale(double lambda) {
-  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ensure_bl();
@@ -3626,17 +3599,6 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
   if (!ba_tiles) {   // the generic tiles read Hpl, Hll and b_l from memory: both must be there (a fused solve with
     ensure_hpl();    // ba_store_ll = 0 leaves Hll partial, and with ba_skip_hpl = 0 ensure_hpl alone returns at once)
     ensure_ll();
-    ensure_pp();
-  }
-  bool pose_forked = false;
-  if (ba_tiles && !pp_valid_) {   // the pose side of the assembly next to the tiles (it reads what they read, writes Hpp / b_p)
-    ensure_side();
-    G2OHIP_HIP_CHECK(hipEventRecord(side_fork_, st_));
-    G2OHIP_HIP_CHECK(hipStreamWaitEvent(side_, side_fork_, 0));
-    launch_ba_poses(side_);
-    G2OHIP_HIP_CHECK(hipEventRecord(side_join_, side_));
-    pp_valid_ = true;
-    pose_forked = true;
   }
   if (ba_tiles) {
     EdgeSet& es = *sets_[ba_.set];
@@ -3721,7 +3683,6 @@ void BlockSolver::solve_schur_impl(bool want_matrix) {
   G2OHIP_SCHUR(3, 3) { throw ArgFailure("unsupported (pose_dim, landmark_dim) for Schur"); }
 #undef G2OHIP_SCHUR
 #undef G2OHIP_TILE_ARGS
-  if (pose_forked) G2OHIP_HIP_CHECK(hipStreamWaitEvent(st_, side_join_, 0));   // Hpp / b_p are read from here on
   prof.begin(KernelProf::kSchurRhs, st_);
   launch_schur_reduce(want_matrix);
   prof.end(KernelProf::kSchurRhs, st_);
@@ -3781,7 +3742,6 @@ void BlockSolver::launch_schur_reduce(bool matrix) {
 
 // somebody reads Hschur (copy_values, PCG, marginals, multi-GPU exchange) after a solve() that skipped it
 void BlockSolver::ensure_hschur() {
-  ensure_pp();
   if (!schur_ || hschur_valid_) return;
   launch_schur_reduce(true);
   G2OHIP_HIP_CHECK(hipGetLastError());
@@ -4252,9 +4212,6 @@ int BlockSolver::solve_sharded_once() {
                             (int)use_graph, (int)prof.enabled, (int)profiling, (int)comm.kind(), segs_[kSegShardedAll].state);
   }
   if (one_graph) {
-    // (ba_lazy_pose: whether the pose side of the assembly runs inside solve_schur is a HOST decision (pp_valid_) that a captured
-    // body would freeze at capture time -- inside the one graph the pose side is never conditional: it runs in front of it)
-    ensure_pp();
     run_seg(kSegShardedAll, whole_solve);
   } else {
     whole_solve();
@@ -4329,7 +4286,6 @@ double BlockSolver::chi2_sharded() {
 }
 
 double BlockSolver::compute_scale_sharded(double lambda) {
-  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ensure_bl();
@@ -4342,7 +4298,6 @@ double BlockSolver::compute_scale_sharded(double lambda) {
 }
 
 double BlockSolver::max_diagonal_sharded() {
-  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   ensure_ll();
@@ -4519,7 +4474,6 @@ void BlockSolver::mf_prepare_lists() {
 
 // Dinv = (Hll + lam_l I)^-1, bschur = b_p - Hpl Dinv b_l, diagonal blocks of the reduced system (device array 107)
 void BlockSolver::schur_operator_prepare() {
-  ensure_pp();
   require_structure();
   if (!system_built_) throw StateFailure("schur_operator_prepare before build_system");
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
@@ -4624,7 +4578,6 @@ void BlockSolver::solve_async() {
 // trial) calls this, does that work, and calls trial_stats() -- which then only waits for the event and sums.
 void BlockSolver::trial_stats_begin(double lambda) {
   if (trial_.begun) throw StateFailure("trial_stats_begin: the previous one has not been read (trial_stats)");
-  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   constexpr int kMaxBlocks = 1024;
@@ -4734,7 +4687,6 @@ void BlockSolver::trial_stats(double lambda, int* ok, double* chi2_out, double* 
 }
 
 void BlockSolver::multiply_hessian(double* dest_host, const double* src_host) {
-  ensure_pp();
   require_structure();
   G2OHIP_HIP_CHECK(hipSetDevice(device_));
   const size_t n = vector_size();
@@ -4796,7 +4748,6 @@ void BlockSolver::copy_x(double* h) {
   d_x.download(h, vector_size(), st_);
 }
 void BlockSolver::copy_b(double* h) {
-  ensure_pp();
   require_structure();
   ensure_bl();
   d_b.download(h, vector_size(), st_);
@@ -4825,7 +4776,6 @@ void BlockSolver::get_pattern(int which, int* colptr, int* rowidx) const {
   std::copy(ri->begin(), ri->end(), rowidx);
 }
 void BlockSolver::copy_values(int which, double* h) {
-  ensure_pp();
   require_structure();
   switch (which) {
     case 0:
@@ -5584,7 +5534,6 @@ __global__ void gather_inverse_blocks_kernel(int n, int p, const long long* __re
 }
 
 int BlockSolver::compute_marginals(int n, const int* rows, const int* cols, double* out) {
-  ensure_pp();
   require_structure();
   if (!system_built_) throw StateFailure("compute_marginals before build_system");
   if (n < 0 || (n > 0 && (!rows || !cols || !out))) throw ArgFailure("compute_marginals: bad arguments");
@@ -5699,7 +5648,6 @@ void BlockSolver::copy_edge_data(int set, double* J0, double* J1, double* err) {
 }
 
 void BlockSolver::device_array(int which, double** ptr, size_t* count) {
-  ensure_pp();
   require_structure();
   switch (which) {
     case 0: *ptr = d_Hpp.p; *count = pp_row.size() * p_ * p_; break;

@@ -536,73 +536,33 @@ int g2ohip_set_option(g2ohip_solver* s, const char* name, double value) {
   if (!std::strcmp(name, "nd_leaf")) s->impl->chol_opt.nd_leaf = (int)value;
   else if (!std::strcmp(name, "max_sn_scalars")) s->impl->chol_opt.max_sn_scalars = (int)value;
   else if (!std::strcmp(name, "max_sn_scalars_lds")) s->impl->chol_opt.max_sn_scalars_lds = (int)value;
-  else if (!std::strcmp(name, "lds_front_bytes")) s->impl->chol_opt.lds_front_bytes = (size_t)value;
-  else if (!std::strcmp(name, "lds_budget_bytes")) s->impl->chol_opt.lds_budget_bytes = (size_t)value;
-  else if (!std::strcmp(name, "relax_zeros")) s->impl->chol_opt.relax_zeros = value;
-  else if (!std::strcmp(name, "relax_front_bytes")) s->impl->chol_opt.relax_front_bytes = (size_t)value;
-  else if (!std::strcmp(name, "fuse_chains")) s->impl->chol_opt.fuse_chains = value != 0;
-  else if (!std::strcmp(name, "max_chain_fronts")) s->impl->chol_opt.max_chain_fronts = (int)value;
-  else if (!std::strcmp(name, "wave_front_tasks")) s->impl->chol_opt.wave_front_tasks = (int)value;
   else if (!std::strcmp(name, "dep_levels")) s->impl->chol_opt.dep_levels = (int)value;
-  else if (!std::strcmp(name, "wave_kernel")) s->impl->chol_opt.wave_kernel = (int)value;
   else if (!std::strcmp(name, "band_kernel")) s->impl->chol_opt.band_kernel = (int)value;
   else if (!std::strcmp(name, "tree_backward")) s->impl->chol_opt.tree_backward = (int)value;
-  else if (!std::strcmp(name, "overlap_level_halves")) s->impl->chol_opt.overlap_level_halves = (int)value;
-  else if (!std::strcmp(name, "lazy_level_joins")) s->impl->chol_opt.lazy_level_joins = (int)value;
-  else if (!std::strcmp(name, "big_gather")) s->impl->chol_opt.big_gather = (int)value;
-  else if (!std::strcmp(name, "split_sweeps")) s->impl->chol_opt.split_sweeps = (int)value;
-  else if (!std::strcmp(name, "merge_diag_panel")) s->impl->chol_opt.merge_diag_panel = (int)value;
-  else if (!std::strcmp(name, "big_merge_tiles")) s->impl->chol_opt.big_merge_tiles = (int)value;
   else if (!std::strcmp(name, "big_group")) s->impl->chol_opt.big_group = (int)value;
-  else if (!std::strcmp(name, "group_forward_side")) s->impl->chol_opt.group_forward_side = (int)value;
   else if (!std::strcmp(name, "big_group_min_rows")) s->impl->chol_opt.big_group_min_rows = (int)value;
-  else if (!std::strcmp(name, "merge_backward_levels")) s->impl->chol_opt.merge_backward_levels = (int)value;
-  else if (!std::strcmp(name, "fuse_big_forward")) s->impl->chol_opt.fuse_big_forward = (int)value;
-  else if (!std::strcmp(name, "hoist_big_assembly")) s->impl->chol_opt.hoist_big_assembly = (int)value;
-  else if (!std::strcmp(name, "split_sweeps_min_dim")) s->impl->chol_opt.split_sweeps_min_dim = (int)value;
-  else if (!std::strcmp(name, "inplace_chains")) s->impl->chol_opt.inplace_chains = (int)value;
-  else if (!std::strcmp(name, "fuse_panel")) s->impl->chol_opt.fuse_panel = (int)value;
-  else if (!std::strcmp(name, "mfma_diag")) s->impl->chol_opt.mfma_diag = (int)value;
-  else if (!std::strcmp(name, "dep_delay")) s->impl->chol_opt.dep_delay = (int)value;
   else if (!std::strcmp(name, "dep_backward")) s->impl->chol_opt.dep_backward = (int)value;
   else if (!std::strcmp(name, "big_front_passes")) s->impl->chol_opt.big_front_passes = (int)value;
-  else if (!std::strcmp(name, "wide_front_doubles")) s->impl->chol_opt.wide_front_doubles = (int)value;
-  else if (!std::strcmp(name, "big_front_min_dim")) s->impl->chol_opt.big_front_min_dim = (int)value;
   else if (!std::strcmp(name, "dep_spin_limit")) s->impl->chol_opt.dep_spin_limit = (int)value;
-  else if (!std::strcmp(name, "dep_acq_rel")) s->impl->chol_opt.dep_acq_rel = (int)value;
-  else if (!std::strcmp(name, "lds_mfma")) s->impl->chol_opt.lds_mfma = (int)value;
-  else if (!std::strcmp(name, "fuse_fwd_any")) s->impl->chol_opt.fuse_fwd_any = (int)value;
-  else if (!std::strcmp(name, "wave_front_bytes")) s->impl->chol_opt.wave_front_bytes = (size_t)value;
   else if (!std::strcmp(name, "schur_tile_bytes")) s->impl->schur_tile_bytes = (size_t)value;
   else if (!std::strcmp(name, "comm_emulate")) s->impl->comm_emulate = (int)value;
-  else if (!std::strcmp(name, "schur_group")) s->impl->schur_group = (int)value;
   else if (!std::strcmp(name, "mask_solution")) s->impl->mask_solution = value != 0;
-  else if (!std::strcmp(name, "schur_sort_dests")) s->impl->schur_sort_dests = value != 0;
   else if (!std::strcmp(name, "linear_solver")) s->impl->linear_solver = (int)value;       // 0 Cholesky, 1 PCG
   else if (!std::strcmp(name, "pcg_tolerance")) s->impl->pcg_opt.tolerance = value;
   else if (!std::strcmp(name, "pcg_max_iterations")) s->impl->pcg_opt.max_iter = (int)value;
   else if (!std::strcmp(name, "pcg_absolute_tolerance")) s->impl->pcg_opt.absolute_tolerance = value != 0;
   else if (!std::strcmp(name, "pcg_check_every")) s->impl->pcg_opt.check_every = std::max(1, (int)value);
-  else if (!std::strcmp(name, "fuse_landmark_inverse")) s->impl->fuse_landmark_inverse = value != 0;
   else if (!std::strcmp(name, "fuse_schur_reduce")) s->impl->fuse_schur_reduce = value != 0;
   else if (!std::strcmp(name, "marginals_reduced")) s->impl->marginals_reduced = value != 0;
   else if (!std::strcmp(name, "marginals_recursion")) s->impl->marginals_recursion = value != 0;
-  else if (!std::strcmp(name, "fuse_reduce_max_partials")) s->impl->fuse_reduce_max_partials = value;
-  else if (!std::strcmp(name, "ba_recompute_backsub")) s->impl->ba_recompute_backsub = value != 0;
-  else if (!std::strcmp(name, "ba_skip_hpl")) s->impl->ba_skip_hpl = value != 0;
-  else if (!std::strcmp(name, "ba_lazy_pose")) s->impl->ba_lazy_pose = value != 0;
-  else if (!std::strcmp(name, "ba_fuse_landmarks")) s->impl->ba_fuse_landmarks = value != 0;
-  else if (!std::strcmp(name, "ba_store_ll")) s->impl->ba_store_ll = (int)value;
-  else if (!std::strcmp(name, "overlap_assembly")) s->impl->overlap_assembly = value != 0;
   else if (!std::strcmp(name, "use_graph")) s->impl->use_graph = value != 0;
   else if (!std::strcmp(name, "sharded_graph")) s->impl->sharded_graph = (int)value;
   else if (!std::strcmp(name, "sharded_merge")) s->impl->sharded_merge = (int)value;
   else if (!std::strcmp(name, "sharded_selftest")) s->impl->sharded_selftest = (int)value;
   else if (!std::strcmp(name, "setup_overlap")) s->impl->setup_overlap = value != 0.0;
   else if (!std::strcmp(name, "sharded_selftest_break")) s->impl->selftest_break = (int)value;   // (tests: corrupt the first variant solve)
-  else if (!std::strcmp(name, "rhs_prefill")) s->impl->rhs_prefill = value != 0.0;
-  else if (!std::strcmp(name, "sharded_virtual")) s->impl->sharded_virtual = (int)value;
   else if (!std::strcmp(name, "ba_fused")) s->impl->ba_fused = value != 0;
+  else if (!std::strcmp(name, "ba_fuse_landmarks")) s->impl->ba_fuse_landmarks = value != 0;
   else {
     set_error(std::string("unknown option ") + name);
     return G2OHIP_ERR_ARG;
@@ -1061,43 +1021,14 @@ int g2ohip_ls_set_option(g2ohip_linear_solver* ls, const char* name, double valu
   if (!std::strcmp(name, "nd_leaf")) ls->opt.nd_leaf = (int)value;
   else if (!std::strcmp(name, "max_sn_scalars")) ls->opt.max_sn_scalars = (int)value;
   else if (!std::strcmp(name, "max_sn_scalars_lds")) ls->opt.max_sn_scalars_lds = (int)value;
-  else if (!std::strcmp(name, "lds_front_bytes")) ls->opt.lds_front_bytes = (size_t)value;
-  else if (!std::strcmp(name, "lds_budget_bytes")) ls->opt.lds_budget_bytes = (size_t)value;
-  else if (!std::strcmp(name, "relax_zeros")) ls->opt.relax_zeros = value;
-  else if (!std::strcmp(name, "relax_front_bytes")) ls->opt.relax_front_bytes = (size_t)value;
-  else if (!std::strcmp(name, "fuse_chains")) ls->opt.fuse_chains = value != 0;
-  else if (!std::strcmp(name, "max_chain_fronts")) ls->opt.max_chain_fronts = (int)value;
-  else if (!std::strcmp(name, "wave_front_tasks")) ls->opt.wave_front_tasks = (int)value;
   else if (!std::strcmp(name, "dep_levels")) ls->opt.dep_levels = (int)value;
-  else if (!std::strcmp(name, "wave_kernel")) ls->opt.wave_kernel = (int)value;
   else if (!std::strcmp(name, "band_kernel")) ls->opt.band_kernel = (int)value;
   else if (!std::strcmp(name, "tree_backward")) ls->opt.tree_backward = (int)value;
-  else if (!std::strcmp(name, "overlap_level_halves")) ls->opt.overlap_level_halves = (int)value;
-  else if (!std::strcmp(name, "lazy_level_joins")) ls->opt.lazy_level_joins = (int)value;
-  else if (!std::strcmp(name, "big_gather")) ls->opt.big_gather = (int)value;
-  else if (!std::strcmp(name, "split_sweeps")) ls->opt.split_sweeps = (int)value;
-  else if (!std::strcmp(name, "merge_diag_panel")) ls->opt.merge_diag_panel = (int)value;
-  else if (!std::strcmp(name, "big_merge_tiles")) ls->opt.big_merge_tiles = (int)value;
   else if (!std::strcmp(name, "big_group")) ls->opt.big_group = (int)value;
-  else if (!std::strcmp(name, "group_forward_side")) ls->opt.group_forward_side = (int)value;
   else if (!std::strcmp(name, "big_group_min_rows")) ls->opt.big_group_min_rows = (int)value;
-  else if (!std::strcmp(name, "merge_backward_levels")) ls->opt.merge_backward_levels = (int)value;
-  else if (!std::strcmp(name, "fuse_big_forward")) ls->opt.fuse_big_forward = (int)value;
-  else if (!std::strcmp(name, "hoist_big_assembly")) ls->opt.hoist_big_assembly = (int)value;
-  else if (!std::strcmp(name, "split_sweeps_min_dim")) ls->opt.split_sweeps_min_dim = (int)value;
-  else if (!std::strcmp(name, "inplace_chains")) ls->opt.inplace_chains = (int)value;
-  else if (!std::strcmp(name, "fuse_panel")) ls->opt.fuse_panel = (int)value;
-  else if (!std::strcmp(name, "mfma_diag")) ls->opt.mfma_diag = (int)value;
-  else if (!std::strcmp(name, "dep_delay")) ls->opt.dep_delay = (int)value;
   else if (!std::strcmp(name, "dep_backward")) ls->opt.dep_backward = (int)value;
   else if (!std::strcmp(name, "big_front_passes")) ls->opt.big_front_passes = (int)value;
-  else if (!std::strcmp(name, "wide_front_doubles")) ls->opt.wide_front_doubles = (int)value;
-  else if (!std::strcmp(name, "big_front_min_dim")) ls->opt.big_front_min_dim = (int)value;
   else if (!std::strcmp(name, "dep_spin_limit")) ls->opt.dep_spin_limit = (int)value;
-  else if (!std::strcmp(name, "dep_acq_rel")) ls->opt.dep_acq_rel = (int)value;
-  else if (!std::strcmp(name, "lds_mfma")) ls->opt.lds_mfma = (int)value;
-  else if (!std::strcmp(name, "fuse_fwd_any")) ls->opt.fuse_fwd_any = (int)value;
-  else if (!std::strcmp(name, "wave_front_bytes")) ls->opt.wave_front_bytes = (size_t)value;
   else return G2OHIP_ERR_ARG;
   return G2OHIP_OK;
 }

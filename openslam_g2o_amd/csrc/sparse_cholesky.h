@@ -31,52 +31,50 @@ struct CholOptions {
   int nd_leaf = 0;           // nested-dissection leaf size (blocks); 0: 32 (and more, see analyze) for band-shaped graphs, 4 for the others
   int max_sn_scalars = 48;   // supernode (pivot panel) width cap, scalars
   int max_sn_scalars_lds = 24;  // ... for the fronts small enough for LDS
-  double relax_zeros = 0.25; // relaxed amalgamation: tolerated share of explicit zero blocks in a panel
-  size_t lds_front_bytes = 256 * 1024;  // fronts up to this DENSE size (m*m*8) are candidates for LDS (stored packed: half) ...
-  size_t lds_budget_bytes = 150 * 1024; // ... if blocks + vectors + index tables fit this per-workgroup LDS budget
-  bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task
-  int max_chain_fronts = 0;  // > 0: chains longer than this are cut into equal segments
+  static constexpr double relax_zeros = 0.25; // relaxed amalgamation: tolerated share of explicit zero blocks in a panel
+  static constexpr size_t lds_front_bytes = 256 * 1024;  // fronts up to this DENSE size (m*m*8) are candidates for LDS (stored packed: half) ...
+  static constexpr size_t lds_budget_bytes = 150 * 1024; // ... if blocks + vectors + index tables fit this per-workgroup LDS budget
+  static constexpr bool fuse_chains = true;   // fuse parent/only-child chains into one workgroup task
+  static constexpr int max_chain_fronts = 0;  // > 0: chains longer than this are cut into equal segments
   int rank = 0, world = 1;   // multi-GPU: this rank factorises its own subtrees + (redundantly) the shared top of the tree
   int dep_levels = 64;                   // > 1: up to this many consecutive task levels share ONE launch; a parent task waits for its
                                          // children through device-scope counters instead of the launch boundary
-  int fuse_fwd_any = 1;                  // forward sweep fused into the factor kernel whatever the number / size of a front's children
-  int lds_mfma = (4 << 16) | 96;                     // LDS fronts with at least (low 16 bits) boundary rows and (high bits) pivot blocks: pivot steps update the panel only, ONE MFMA rank-npiv
+  static constexpr int fuse_fwd_any = 1;                  // forward sweep fused into the factor kernel whatever the number / size of a front's children
+  static constexpr int lds_mfma = (4 << 16) | 96;                     // LDS fronts with at least (low 16 bits) boundary rows and (high bits) pivot blocks: pivot steps update the panel only, ONE MFMA rank-npiv
                                          // update of the trailing matrix afterwards (0: off -- every pivot block updates the whole trailing matrix)
-  int dep_acq_rel = 0;                   // A/B validation of the hand-offs: release increment / acquire poll on the factor launches' counters
   int dep_spin_limit = 1 << 21;          // polls (~0.2 us each) before a waiting workgroup gives up and flags status 2
-  int big_front_min_dim = 180;           // ... for the launches whose largest front has at least this many rows
-  int wide_front_doubles = 5000;         // launches whose largest LDS front has this many packed doubles (100 rows) use 512 threads per front
+  static constexpr int big_front_min_dim = 180;           // ... for the launches whose largest front has at least this many rows
+  static constexpr int wide_front_doubles = 5000;         // launches whose largest LDS front has this many packed doubles (100 rows) use 512 threads per front
   int big_front_passes = 1;              // scratch-slab (large) fronts: whole-GPU passes instead of one workgroup per front
   int dep_backward = 1;                  // the backward sweep uses the same dependency-driven groups (parents first)
-  int dep_delay = 0;                     // launch-order distance between a task and its parent inside a wide dependency-driven launch
-  int wave_front_tasks = 1024;           // launches at least this wide use two waves (128 threads) per front
-  size_t wave_front_bytes = 0;           // (unused)
-  int mfma_diag = 1;                     // scratch-slab fronts: pivot block on the matrix cores (four waves) instead of one wave with v_readlane broadcasts
-  int fuse_panel = 1;                    // scratch-slab fronts: panel solve and trailing update of a level in one launch
-  int inplace_chains = 1;                // chains of scratch-slab fronts with identical rows (panels of one large supernode) are factorised in place
-  int hoist_big_assembly = 1;            // zero fill + original blocks of ALL scratch-slab fronts of a phase in two launches up front (their slab regions are never reused)
-  int fuse_big_forward = 1;              // forward step of scratch-slab fronts inside the pivot-block and panel kernels (levels on the fused panel path)
+  static constexpr int dep_delay = 0;                     // launch-order distance between a task and its parent inside a wide dependency-driven launch
+  static constexpr int wave_front_tasks = 1024;           // launches at least this wide use two waves (128 threads) per front
+  static constexpr size_t wave_front_bytes = 0;           // (unused)
+  static constexpr int mfma_diag = 1;                     // scratch-slab fronts: pivot block on the matrix cores (four waves) instead of one wave with v_readlane broadcasts
+  static constexpr int fuse_panel = 1;                    // scratch-slab fronts: panel solve and trailing update of a level in one launch
+  static constexpr int inplace_chains = 1;                // chains of scratch-slab fronts with identical rows (panels of one large supernode) are factorised in place
+  static constexpr int hoist_big_assembly = 1;            // zero fill + original blocks of ALL scratch-slab fronts of a phase in two launches up front (their slab regions are never reused)
+  static constexpr int fuse_big_forward = 1;              // forward step of scratch-slab fronts inside the pivot-block and panel kernels (levels on the fused panel path)
   int big_group = 8;                     // panels of a long in-place chain (one large supernode) are grouped: inside a group a panel's rank-npiv update
                                          // touches only the columns of the group's remaining panels, the rest of the trailing matrix gets ONE rank-(group)
                                          // update behind the group's last panel -- a quarter of the passes over a frontal matrix that lives in HBM (1: off)
-  int group_forward_side = 1;            // ... and the forward steps of such panels run on a side stream next to the next panel's factorisation
+  static constexpr int group_forward_side = 1;            // ... and the forward steps of such panels run on a side stream next to the next panel's factorisation
   int big_group_min_rows = 1536;         // ... for chains whose first front has at least this many rows (smaller ones are latency chains, not traffic)
-  int big_merge_tiles = 256;             // scratch-slab levels of at most this many 64 x 64 tiles run the fused panel kernel (panel solve + update
+  static constexpr int big_merge_tiles = 256;             // scratch-slab levels of at most this many 64 x 64 tiles run the fused panel kernel (panel solve + update
                                          // [+ pivot blocks, merge_diag_panel] in one launch); wider levels the separate whole-GPU passes
-  int merge_diag_panel = 1;              // pivot blocks and panel tiles of a level of scratch-slab fronts in ONE launch (tiles wait for their front's flag)
-  int merge_backward_levels = 1;         // backward step of consecutive levels of scratch-slab fronts in ONE launch (workgroups wait for their parent front's flag)
-  int split_sweeps = 1;                  // forward / backward step of scratch-slab fronts by several workgroups per front (256 boundary rows each)
-  int split_sweeps_min_dim = 512;        // ... on levels whose largest such front has at least this many rows
-  int big_gather = 1;                    // scratch-slab levels in the merged pivot-block / panel launch: the children's update matrices are added where the
+  static constexpr int merge_diag_panel = 1;              // pivot blocks and panel tiles of a level of scratch-slab fronts in ONE launch (tiles wait for their front's flag)
+  static constexpr int merge_backward_levels = 1;         // backward step of consecutive levels of scratch-slab fronts in ONE launch (workgroups wait for their parent front's flag)
+  static constexpr int split_sweeps = 1;                  // forward / backward step of scratch-slab fronts by several workgroups per front (256 boundary rows each)
+  static constexpr int split_sweeps_min_dim = 512;        // ... on levels whose largest such front has at least this many rows
+  static constexpr int big_gather = 1;                    // scratch-slab levels in the merged pivot-block / panel launch: the children's update matrices are added where the
                                          // frontal matrix is loaded (inverse block maps) instead of by one extend-add pass per child ordinal in front of it
-  int lazy_level_joins = 1;              // ... the two streams wait for each other only where a front has a child on the other one (0: at every such level)
-  int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
-  int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
-  size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
+  static constexpr int lazy_level_joins = 1;              // ... the two streams wait for each other only where a front has a child on the other one (0: at every such level)
+  static constexpr int overlap_level_halves = 1;          // levels with LDS fronts AND scratch-slab fronts: the two halves on two streams, the forward step of the large fronts next to the following level
+  static constexpr int wave_kernel = 1;                   // small fronts (<= 24 pivot columns, <= 48 boundary rows): one wavefront per task, the front in registers
+  static constexpr size_t relax_front_bytes = 42 * 1024;  // relaxed merges only while the front stays this small (3 workgroups per CU)
   int band_kernel = 1;                   // leaf chains of a band (+ one dense border) on the sliding-window kernel (band_chain.inc)
   int tree_backward = 1;                 // backward sweep of the tree levels of a dependency-driven group by GROUPS of fronts: one sixteen-wave workgroup
-                                         // per subtree of up to sixteen small fronts, hand-offs inside a group through LDS (tree_backward_kernel); 2: also
-                                         // the leaf chains below them by one wave per chain (chain_backward_kernel: measured slower, see there); 0: task by task
+                                         // per subtree of up to sixteen small fronts, hand-offs inside a group through LDS (tree_backward_kernel); 0: task by task
 };
 
 struct CholStats {
@@ -148,7 +146,6 @@ struct BandChainRec {
 };
 // tree_backward_kernel: the fronts it takes (pivot columns, boundary rows: scalars) and the fronts (waves) of a group
 constexpr int kTreePiv = 24, kTreeBnd = 48, kTreeWaves = 16;
-constexpr int kChainCap = 1536;   // chain_backward_kernel: pivot scalars of a leaf chain kept in LDS (12 KB)
 constexpr int kBandFrontInts = 17;   // first pivot block, pivot scalars, L offset (2), m, local row of band blocks +0..+7, of border blocks 0..3
 
 struct CholPlanDev {
@@ -175,7 +172,6 @@ struct CholPlanDev {
   int* status;
   int* ready;        // dependency-driven launches: children finished so far, per front
   int dep_spin_limit;
-  int dep_acq_rel;
   int lds_mfma;
   long long* dbg;   // G2OHIP_CHOL_STAMPS builds only: per-launch wall-clock stamps of workgroup 0
   long long* tl;    // ... and (start, end) wall-clock of every workgroup of the wave-kernel launch
@@ -334,7 +330,6 @@ class SparseCholesky {
   struct FactorGroup {
     LevelLaunch LL; int first_level, last_level; bool dep; int band_count = 0, band_rec0 = 0, band_ent_cap = 0, band_tab_cap = 0;
     int tb_grp0 = 0, tb_ngrp = 0, tb_low = 0;   // tree_backward: its groups (d_tb_grec), the launch slots (lowest levels) left to the per-task kernel
-    int tb_chain_cap = 0;                       // > 0: those slots are leaf chains swept by chain_backward_kernel (one wave each); the most pivot scalars of a chain
   };
   std::vector<FactorGroup> groups_[2];     // factorisation launches: runs of levels (dep: one launch, in-kernel dependencies)
   DevBuf<int> d_ready;

@@ -1694,42 +1694,6 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         }
         G.tb_ngrp = (int)grec.size() - G.tb_grp0;
         for (int l = G.first_level; l < lc; ++l) G.tb_low += launches_[ph][l].lds_count;
-        // the leaf level below the tree levels on chain_backward_kernel: ONE level (every front above a chain is in the tree
-        // launch or in an earlier one), small fronts only, the chain's pivots within the LDS budget
-        G.tb_chain_cap = 0;
-        if (opt.tree_backward == 2 && lc == G.first_level + 1) {
-          const LevelLaunch& N = launches_[ph][G.first_level];
-          int cap = 0;
-          bool ok = N.lds_count > 0;
-          for (int q = N.lds_begin; q < N.lds_begin + N.lds_count && ok; ++q) {
-            const int t = S.level_fronts[q];
-            int sum = 0;
-            for (int k = S.task_ptr[t]; k < S.task_ptr[t + 1]; ++k) {
-              ok = ok && small(S.task_fronts[k]);
-              sum += S.f_ns[S.task_fronts[k]] * bs;
-            }
-            cap = std::max(cap, sum);
-          }
-          if (ok && cap <= kChainCap) G.tb_chain_cap = cap;
-        }
-        if (G.tb_chain_cap > 0) {   // where the boundary values of a chain's fronts come from: the chain's own pivots (LDS, top front first) or memory
-          const LevelLaunch& N = launches_[ph][G.first_level];
-          for (int q = N.lds_begin; q < N.lds_begin + N.lds_count; ++q) {
-            const int t = S.level_fronts[q];
-            std::vector<std::pair<int, int>> own;   // (front, offset of its pivots)
-            int xoff = 0;
-            for (int k = S.task_ptr[t + 1] - 1; k >= S.task_ptr[t]; --k) {
-              const int f2 = S.task_fronts[k];
-              for (int j = 0; j < S.f_nb[f2]; ++j) {
-                const int r = S.rows[S.rows_off[f2] + j], o = sn_of[r];
-                for (const auto& pr : own)
-                  if (pr.first == o) grows[S.rows_off[f2] + j] = -1 - (pr.second + (r - S.sn_start[o]) * bs);
-              }
-              own.emplace_back(f2, xoff);
-              xoff += S.f_ns[f2] * bs;
-            }
-          }
-        }
         // what a front releases: the groups rooted below it and the tasks of the per-task launch that wait for it; where the
         // boundary values of a front come from
         std::vector<int> rel(nf, 0);
@@ -1741,8 +1705,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           } else {
             const int t = task_of[f2];
             const bool top = S.task_fronts[S.task_ptr[t + 1] - 1] == f2;
-            // (the chains of chain_backward_kernel start behind the tree launch: they wait for nothing)
-            if (G.tb_chain_cap == 0 && top && task_level[t] >= G.first_level && task_level[t] < lc && (recs[f2].pad[0] & 2)) ++rel[pf];
+            if (top && task_level[t] >= G.first_level && task_level[t] < lc && (recs[f2].pad[0] & 2)) ++rel[pf];
           }
         }
         for (int e = grec[G.tb_grp0].x; e < (int)gfr.size(); ++e) {
@@ -1914,7 +1877,6 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.status = d_status.p;
   plan_.ready = d_ready.p;
   plan_.dep_spin_limit = opt.dep_spin_limit;
-  plan_.dep_acq_rel = opt.dep_acq_rel;
   plan_.lds_mfma = opt.lds_mfma;
   plan_.dbg = nullptr;
   plan_.tl = nullptr;
@@ -1965,18 +1927,12 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double d, double& s, double& r) {
 // This relies on gfx9's in-order issue and completion accounting of a wave's vector memory operations (vmcnt) and on sc1
 // accesses being coherent at agent scope; it does not rely on workgroup dispatch order beyond "a child of a task is
 // running or finished when the task starts" (deadlock freedom).
-// Dependency counters of the grouped factor launches.  The product path uses relaxed agent-scope atomics: the data a counter
-// guards is written with sc1 stores that have been acknowledged (s_waitcnt vmcnt(0)) before the increment and read with sc1
-// loads after the poll, so no cache has to be written back or invalidated.  acq_rel (option dep_acq_rel, for A/B
-// validation of that reasoning): the textbook release increment / acquire poll instead, i.e. an L2 write-back and an
-// invalidate per task.
-__device__ __forceinline__ void dep_add(int* c, int v, int acq_rel) {
-  if (acq_rel) (void)__hip_atomic_fetch_add(c, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  else (void)__hip_atomic_fetch_add(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int dep_poll(const int* c, int acq_rel) {
-  return acq_rel ? __hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// Dependency counters of the grouped factor launches: relaxed agent-scope atomics.  The data a counter guards is written with sc1
+// stores that have been acknowledged (s_waitcnt vmcnt(0)) before the increment and read with sc1 loads after the poll, so no cache
+// has to be written back or invalidated.  (The textbook release increment / acquire poll -- an L2 write-back and an invalidate per
+// task -- was kept as an A/B option through round 5: the same bits, slower; removed with its option in round 6.)
+__device__ __forceinline__ void dep_add(int* c, int v) { (void)__hip_atomic_fetch_add(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int dep_poll(const int* c) { return __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -2158,7 +2114,7 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
     const int dep_wait = dep ? ((rec.pad[1] >> 24) & 0x7f) : 0;
     if (dep_wait > 0 && tid == 0) {
       int spins = 0;
-      while (dep_poll(P.ready + f, P.dep_acq_rel) < dep_wait) {
+      while (dep_poll(P.ready + f) < dep_wait) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > P.dep_spin_limit || ((spins & 255) == 0 && __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
           __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2767,7 +2723,7 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
     if (dep_signal) {
       __builtin_amdgcn_s_waitcnt(0);   // every wave: its own (coherent) U / w stores have been acknowledged
       __syncthreads();
-      if (tid == 0) dep_add(P.ready + (rec.pad[1] & 0x00ffffff), 1, P.dep_acq_rel);
+      if (tid == 0) dep_add(P.ready + (rec.pad[1] & 0x00ffffff), 1);
       write_panel();
     }
     __syncthreads();   // F and the LDS tables are reused by the next front of the chain
@@ -3993,132 +3949,6 @@ __global__ void __launch_bounds__(kTreeWaves * 64) tree_backward_kernel(CholPlan
   }
 }
 
-// The LEAF chains below the tree levels (option tree_backward = 2; launched behind tree_backward_kernel: every front above a
-// chain is done): ONE wave per chain walks its fronts top down with the same register panel and the same sums; the pivot
-// solutions of the chain stay in LDS for the fronts below, the values from the fronts above the chain are plain loads.
-// The panel of a front is contiguous in memory (m x npiv column-major + the reciprocal diagonal): it is requested as a LINEAR
-// copy (64 consecutive doubles per instruction) one front AHEAD, written to LDS with the column stride padded to an odd
-// number, and the lanes take their column / parity layout from there -- read straight from memory in that layout (a stride of
-// m doubles between lanes) every 64-byte line came through the 32 KB L1 eight times with eight waves per CU streaming 14 KB
-// panels through it: 160 us for the 2 048 chains of the metric configuration against 97 us for the per-task kernel.  The
-// index table and the boundary values of a front are requested one / two fronts ahead as well (a dependent pair of loads).
-struct ChainMini {   // what the sweep needs of a FrontRec (scalar loads: 6 registers instead of 32 per record in flight)
-  int ns, nb, c0, rows_off;
-  long long L_off;
-};
-__device__ __forceinline__ ChainMini load_chain_mini(const FrontRec* p) {
-  const __attribute__((address_space(4))) int* rp = (const __attribute__((address_space(4))) int*)reinterpret_cast<uintptr_t>(p);
-  ChainMini r;
-  r.ns = rp[offsetof(FrontRec, ns) / 4];
-  r.nb = rp[offsetof(FrontRec, nb) / 4];
-  r.c0 = rp[offsetof(FrontRec, c0) / 4];
-  r.rows_off = rp[offsetof(FrontRec, rows_off) / 4];
-  const unsigned int lo = (unsigned int)rp[offsetof(FrontRec, L_off) / 4], hi = (unsigned int)rp[offsetof(FrontRec, L_off) / 4 + 1];
-  r.L_off = (long long)(((unsigned long long)hi << 32) | lo);
-  return r;
-}
-template <int BS>
-__global__ void __launch_bounds__(64) chain_backward_kernel(CholPlanDev P, const int2* __restrict__ chains, const int* __restrict__ grows,
-                                                           const double* __restrict__ y, double* __restrict__ xp, int nt_ref) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int MP = kTreePiv + kTreeBnd + 1;                                   // padded column stride of the staged panel
-  constexpr int NPRE = ((kTreePiv + kTreeBnd) * kTreePiv + kTreePiv + 63) / 64;   // doubles per lane of a linear panel copy
-  constexpr int JH = TreePanel<BS>::JH;
-  double* tw = smem;                              // boundary values of the current front
-  double* pan = smem + kTreeBnd;                  // the current front's panel, column c at c * MP (column npiv: the reciprocal diagonal)
-  double* xs = pan + (kTreePiv + 1) * MP;         // pivot solutions of the chain so far, top front first
-  const int2 ch = chains[blockIdx.x];
-  const int f_first = __builtin_amdgcn_readfirstlane(ch.x), nfr = __builtin_amdgcn_readfirstlane(ch.y);
-  const int lane = threadIdx.x;
-  const int k = lane >> 1, h = lane & 1, off = lane % BS, blk = lane / BS;
-  double pre[NPRE];
-  auto request_panel = [&](const ChainMini& r) {
-    const int m = (r.ns + r.nb) * BS, tot = m * r.ns * BS + r.ns * BS;
-    const double* Lg = P.L + r.L_off;
-#pragma unroll
-    for (int u = 0; u < NPRE; ++u) pre[u] = Lg[min(lane + 64 * u, tot - 1)];
-  };
-  int ti = nfr - 1;
-  ChainMini r0 = load_chain_mini(P.rec + f_first + ti);
-  ChainMini r1 = load_chain_mini(P.rec + f_first + max(ti - 1, 0));
-  request_panel(r0);
-  double yk0 = k < r0.ns * BS ? y[(size_t)r0.c0 * BS + k] : 0.0;
-  int src0 = lane < r0.nb * BS ? grows[r0.rows_off + blk] : 0;                   // >= 0: block row in memory, < 0: -1 - (offset in xs)
-  int src1 = lane < r1.nb * BS ? grows[r1.rows_off + blk] : 0;
-  double xb0 = (lane < r0.nb * BS && src0 >= 0) ? xp[(size_t)src0 * BS + off] : 0.0;
-  int xoff = 0;
-  for (; ti >= 0; --ti) {
-    TreePanel<BS> T;
-    T.ns = r0.ns;
-    T.npiv = r0.ns * BS;
-    T.nbs = r0.nb * BS;
-    T.m = T.npiv + T.nbs;
-    T.c0 = r0.c0;
-    const int m = T.m, npiv = T.npiv, tot = m * npiv + npiv;
-    {   // the linear copy into the padded layout: element e = column e / m, row e % m
-      int col = lane / m, row = lane - col * m;
-#pragma unroll
-      for (int u = 0; u < NPRE; ++u) {
-        if (lane + 64 * u < tot) pan[col * MP + row] = pre[u];
-        row += 64;
-        while (row >= m) {
-          row -= m;
-          ++col;
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // the next front's panel, right-hand side and boundary values; the index table of the one after it
-    ChainMini r2 = r1;
-    double yk1 = 0.0, xb1 = 0.0;
-    int src2 = 0;
-    if (ti > 0) {
-      request_panel(r1);
-      yk1 = k < r1.ns * BS ? y[(size_t)r1.c0 * BS + k] : 0.0;
-      xb1 = (lane < r1.nb * BS && src1 >= 0) ? xp[(size_t)src1 * BS + off] : 0.0;
-      r2 = load_chain_mini(P.rec + f_first + max(ti - 2, 0));
-      src2 = lane < r2.nb * BS ? grows[r2.rows_off + blk] : 0;
-    }
-    const bool colk = k < npiv;
-    const double* pk = pan + (colk ? k : 0) * MP;
-#pragma unroll
-    for (int j = 0; j < JH; ++j) {
-      const int i = npiv + h + 2 * j;
-      const double v = pk[min(i, m - 1)];
-      T.L21[j] = (colk && i < m) ? v : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < kTreePiv; ++q) {
-      const double v = pk[min(q, m - 1)];
-      T.L11[q] = (colk && q < npiv) ? v : 0.0;
-    }
-    T.linv = colk ? pan[npiv * MP + k] : 0.0;
-    T.yk = yk0;
-    if (lane < kTreeBnd) tw[lane] = lane < T.nbs ? (src0 < 0 ? xs[-1 - src0 + off] : xb0) : 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#ifdef G2OHIP_CHAIN_ABL   // (timing experiment, wrong results: the memory side of the sweep alone)
-    const double xout = T.L21[0] + T.L11[0] + T.linv + T.yk + tw[lane & 31];
-#else
-    const double xout = tree_front_solve<BS>(T, tw, lane, bw_parts(nt_ref, max(npiv, 1), m));
-#endif
-    if (colk && h == 0) {
-      xs[xoff + k] = xout;
-      xp[(size_t)T.c0 * BS + k] = xout;
-    }
-    xoff += npiv;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    r0 = r1;
-    r1 = r2;
-    yk0 = yk1;
-    xb0 = xb1;
-    src0 = src1;
-    src1 = src2;
-  }
-}
-
 // Forward / backward step of the scratch-slab fronts of a level by SEVERAL workgroups per front.  One workgroup per front
 // (front_forward_kernel / front_backward_kernel) pulls the whole m x npiv panel through one CU: ~55 GB/s, 14-16 us for
 // the 2 000-row fronts at the top of a pose graph's tree, on the critical path of every level.  Here a workgroup owns 256
@@ -5065,7 +4895,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
       side_dirty = false;
     }
     if (LL.split_ok) side_unsure = true;   // (a level the plan put on the side stream ran here: its fork / join flags no longer describe the streams)
-    if (opt.group_forward_side && st != nullptr && big_passes && (LL.grouped || LL.group_in || opt.group_forward_side >= 2) && LL.lds_count == 0 && LL.glb_count > 0 && !G.dep && fwd &&
+    if (opt.group_forward_side && st != nullptr && big_passes && (LL.grouped || LL.group_in) && LL.lds_count == 0 && LL.glb_count > 0 && !G.dep && fwd &&
         !big_forward_carried(LL)) {
       // Panels of a grouped in-place chain: the forward step of a panel (20 us of a 65 us level) needs the panel's solved rows and the
       // previous panel's update vector, nothing of the next panel's factorisation -- it runs on the side stream next to it (inside a
@@ -5448,20 +5278,7 @@ void SparseCholesky::solve_backward_phase(int phase, hipStream_t st) {
         }
 #undef G2OHIP_TREE_BACKWARD
         G2OHIP_LAUNCH_CHECK("tree_backward_kernel");
-        if (G.tb_low > 0 && G.tb_chain_cap > 0) {
-          const int2* chains = d_bslots.p + (n_slots_ - (G.LL.lds_begin + G.LL.lds_count)) + (G.LL.lds_count - G.tb_low);   // (the last slots of the reversed list)
-          const size_t sh = (size_t)(kTreeBnd + (kTreePiv + 1) * (kTreePiv + kTreeBnd + 1) + G.tb_chain_cap) * sizeof(double);
-#define G2OHIP_CHAIN_BACKWARD(BS_) \
-  hipLaunchKernelGGL((chain_backward_kernel<BS_>), dim3(G.tb_low), dim3(64), sh, st, plan_, chains, d_tb_rows.p, d_y.p, d_xp.p, nt_ref)
-          switch (bs_) {
-            case 3: G2OHIP_CHAIN_BACKWARD(3); break;
-            case 6: G2OHIP_CHAIN_BACKWARD(6); break;
-            case 7: G2OHIP_CHAIN_BACKWARD(7); break;
-            default: throw ArgFailure("SparseCholesky: unsupported block size (3, 6, 7)");
-          }
-#undef G2OHIP_CHAIN_BACKWARD
-          G2OHIP_LAUNCH_CHECK("chain_backward_kernel");
-        } else if (G.tb_low > 0) {
+        if (G.tb_low > 0) {
           launch_solve(G.LL, false, st, false, true, false, G.tb_low);
         }
       } else {

@@ -103,25 +103,6 @@ def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused, x_exch
     assert (seen == 1).all() and edges == pr["E"]
 
 
-def test_virtual_source_on_a_rank_equals_the_materialised_reduction(tmp_path):
-    """sharded_virtual (default): a rank's factorisation assembles its fronts from Hpp and the Schur tiles' partial blocks as
-    on one GPU; only the boundary blocks of the reduced system are reduced, summed over the ranks and read back as blocks
-    (from the region behind Hpp).  Against option 0 -- every block this rank forms goes through Hschur -- on three ranks:
-    the same x to rounding (the reduction order of a block is the same, its place in the front assembly is not)."""
-    import torch.multiprocessing as mp
-    P, L, lam, world = 700, 6000, 30.0, 3
-    outs = []
-    for k, opt in enumerate(("sharded_virtual=1", "sharded_virtual=0")):
-        d = tmp_path / ("v%d" % k)
-        d.mkdir()
-        mp.spawn(_worker, args=(world, _free_port(), P, L, lam, True, "halo", str(d), opt), nprocs=world, join=True)
-        outs.append([np.load(os.path.join(str(d), "r%d.npz" % r)) for r in range(world)])
-    for r in range(world):
-        a, b = outs[0][r], outs[1][r]
-        assert bool(a["ok"]) and bool(b["ok"])
-        assert relerr(a["xp"], b["xp"]) < 1e-11 and relerr(a["xl"], b["xl"]) < 1e-11
-
-
 @pytest.mark.parametrize("world", [2, 3])
 def test_subtree_distributed_solve_on_a_graph_with_loop_closures(tmp_path, world):
     """The same sharded solve on a graph that is not a band: the elimination tree has a dense top (most of it shared), the

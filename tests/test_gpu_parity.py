@@ -424,11 +424,9 @@ def test_update_structure_grows_a_pose_graph_online():
 
 @pytest.mark.parametrize("graph", ["manhattan", "sphere"])
 def test_front_kernel_variants_agree_on_the_pose_graphs(graph):
-    """Round-3 variants of the LDS-front kernel against the earlier ones on the two golden pose graphs: the forward sweep
-    fused into the factor kernel whatever the number / size of a front's children (fuse_fwd_any: the fifth and later children
-    and those with more boundary rows than threads are added by a loop), all LDS levels in dependency-driven launches
-    (dep_levels 64 against 16 and against one launch per level), the trailing matrix updated ONCE per front on the matrix
-    cores (lds_mfma) against once per pivot block on the VALU.  Same solution to rounding, and the reference's."""
+    """The LDS-front kernel on the two golden pose graphs with all LDS levels in dependency-driven launches (dep_levels 64
+    against 16 and against one launch per level: the schedule the stall fallback drops to).  Same solution to rounding, and the
+    reference's.  (Round 6: the A/B options of the kernel's earlier forms -- fuse_fwd_any, lds_mfma -- left the library.)"""
     capi = _capi()
     from tests.helpers import sphere_golden
     if graph == "manhattan":
@@ -438,7 +436,7 @@ def test_front_kernel_variants_agree_on_the_pose_graphs(graph):
         g = sphere_golden(); p, l, d = 6, 3, 6
         J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
     xs, stats = [], []
-    variants = ({}, {"fuse_fwd_any": 0, "dep_levels": 16, "lds_mfma": 0}, {"dep_levels": 0}, {"lds_mfma": (1 << 16) | 24}, {"lds_mfma": 0})
+    variants = ({}, {"dep_levels": 16}, {"dep_levels": 0})
     for opts in variants:
         s = capi.HipBlockSolver(p, l, 0)
         for k_, v_ in opts.items():
@@ -591,7 +589,7 @@ def test_dependency_driven_launches_and_stall_fallback():
     pr = ba_case(600, 6000)
     xs = []
     cases = ({"dep_levels": 0}, {"dep_levels": 16, "dep_backward": 0}, {"dep_levels": 16, "dep_spin_limit": 0},
-             {"dep_levels": 16}, {"dep_levels": 3, "use_graph": 1}, {"dep_levels": 16, "dep_backward": 0, "dep_acq_rel": 1})
+             {"dep_levels": 16}, {"dep_levels": 3, "use_graph": 1})
     for opts in cases:
         s = hip_ba(pr, options=opts)
         assert s.stats()["numLevels"] >= 4
@@ -608,7 +606,6 @@ def test_dependency_driven_launches_and_stall_fallback():
     # group's workgroup size, which changes the partition (not the terms) of its dot products
     assert np.array_equal(xs[1], xs[0]) and np.array_equal(xs[2], xs[0])
     assert relerr(xs[3], xs[0]) < 1e-13 and relerr(xs[4], xs[0]) < 1e-13
-    assert np.array_equal(xs[5], xs[0])   # release / acquire on the counters instead of relaxed atomics around sc1 data: the same bits
     o = oracle_ba(pr)
     o.build_system()
     o.set_lambda(10.0, True)
@@ -687,22 +684,18 @@ def _random_block_spd(bs, nb, dens, seed):
 
 @pytest.mark.parametrize("bs", [3, 6, 7])
 def test_scratch_slab_sweep_variants(bs):
-    """The forward / backward steps of the scratch-slab fronts exist in several forms (one workgroup per front; several
-    workgroups per front with ticketed partial sums; forward step inside the panel kernel; zero fill + original blocks
-    per level or per phase): every combination against a dense LAPACK solve, and the forms that promise the operation
-    order of the one-workgroup kernel bit for bit against it."""
+    """The scratch-slab fronts (several workgroups per front with ticketed partial sums, forward step inside the panel kernel,
+    zero fill + original blocks per phase) against a dense LAPACK solve, in the default schedule, with one launch per level (what
+    the stall fallback uses) and with one workgroup per front (big_front_passes = 0).  (Round 6: the options that selected the
+    earlier forms of these kernels one by one left the library with the forms.)"""
     capi = _capi()
     A, cp, row, vals, rng = _random_block_spd(bs, 200 if bs > 3 else 380, 0.2, 70 + bs)
     b = rng.normal(size=A.shape[0])
     xr = np.linalg.solve(A, b)
     variants = {
         "default": {},
-        "split everywhere, own forward launch": {"split_sweeps_min_dim": 0, "fuse_big_forward": 0},
-        "forward in the panel kernel, one workgroup backward": {"split_sweeps": 0, "hoist_big_assembly": 0},
-        "one workgroup per front": {"split_sweeps": 0, "fuse_big_forward": 0, "hoist_big_assembly": 0},
-        "two-launch panel": {"fuse_panel": 0},
-        "a backward launch per level": {"merge_backward_levels": 0},
-        "pivot blocks and panel tiles as two launches": {"merge_diag_panel": 0},
+        "one launch per level": {"dep_levels": 0},
+        "one workgroup per scratch-slab front": {"big_front_passes": 0},
     }
     xs = {}
     for name, opts in variants.items():
@@ -717,8 +710,7 @@ def test_scratch_slab_sweep_variants(bs):
             ok, x2 = ls.solve(cp, row, vals, b)
             assert ok and np.array_equal(x, x2), name + ": not repeatable"
         xs[name] = x
-    assert np.array_equal(xs["forward in the panel kernel, one workgroup backward"], xs["one workgroup per front"])
-    assert np.array_equal(xs["pivot blocks and panel tiles as two launches"], xs["default"])   # same arithmetic, one launch less
+    assert relerr(xs["one launch per level"], xs["default"]) < 1e-12
 
 
 def test_merged_backward_launch_stall_fallback():
@@ -734,7 +726,7 @@ def test_merged_backward_launch_stall_fallback():
         ok, x = ls.solve(cp, row, vals, b)
         assert ok and relerr(x, xr) < 1e-10
     ls2 = capi.HipLinearSolver(6, 0)
-    ls2.setOption("merge_backward_levels", 0)
+    ls2.setOption("dep_levels", 0)
     ok, x2 = ls2.solve(cp, row, vals, b)
     assert ok and relerr(x, x2) < 1e-13      # (the fallback also ungroups the sweeps of the LDS fronts: same terms, other partitions)
 
@@ -838,7 +830,7 @@ def test_env_options_are_applied_by_the_library(monkeypatch):
     ref = hip_ba(pr)
     ref.buildSystem()
     assert ref.solve()
-    monkeypatch.setenv("G2OHIP_OPTIONS", " band_kernel=0, wave_kernel = 0 ")
+    monkeypatch.setenv("G2OHIP_OPTIONS", " band_kernel=0, dep_levels = 0 ")
     s = hip_ba(pr)
     s.buildSystem()
     assert s.solve()

@@ -232,37 +232,6 @@ def test_robust_kernels_on_the_loop_closures_only_stay_one_device_set():
     assert s.chi2() > robust * (1 + 1e-6)
 
 
-def test_lazy_stream_joins_and_gathered_children_equal_the_plain_level_schedule():
-    """Two schedule options of the scratch-slab levels (sparse_cholesky.hip), both with the same kernels' arithmetic in the same order:
-    * levels with LDS fronts AND scratch-slab fronts run on two streams (LevelLaunch::fork / join): with `lazy_level_joins` the streams
-      wait for each other only where a front has a child on the other one;
-    * `big_gather`: the merged pivot-block / panel launch of a level adds the children's update matrices where it loads the frontal
-      matrix (inverse block maps, own value first, then child by child) instead of one extend-add pass per child ordinal in front of it.
-    The solutions are bit-identical to the ones with a fork and a join at every such level and with the passes, with and without graph
-    replay, and repeatable (a missing dependency would show as a race)."""
-    capi = _capi()
-    g = sphere_golden()
-    J0, J1, err = O.se3_edges(g["poses"], g["vi"], g["vj"], g["Z"])
-    xs = []
-    for lazy, gather, graph in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 0, 1)):
-        s = capi.HipBlockSolver(6, 3, 0)
-        s.setOption("lazy_level_joins", lazy)
-        s.setOption("big_gather", gather)
-        k = s.addEdgeSet(6, g["hidx"][g["vi"]], g["hidx"][g["vj"]])
-        s.buildStructure(g["nP"], 0, False)
-        s.setEdgeData(k, J0, J1, g["omega"], err)
-        s.setOption("use_graph", graph)
-        s.buildSystem()
-        lam = 1e-5 * s.maxDiagonal()
-        for _ in range(6):
-            s.setLambda(lam, True)
-            assert s.solve()
-            s.restoreDiagonal()
-            xs.append(s.x().copy())
-    for x in xs[1:]:
-        assert np.array_equal(x, xs[0])
-
-
 def test_fill_of_the_pose_graph_fixtures_against_the_reference_block_amd():
     """nnz(L) of the device factorisation (nested dissection, leaves of 4 blocks for graphs that are not a band) against the
     reference's own cs_amd block ordering (lnz_block_amd in the golden fixtures, from oracle/_ref): manhattan 1.89 x (2.45 x with the
