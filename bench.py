@@ -135,6 +135,11 @@ def main():
     ap.add_argument("--poses", type=int, default=100000)
     ap.add_argument("--landmarks", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["chain", "grid"], default="chain",
+                    help="chain: BASELINE.json's metric configuration (a camera trajectory: the reduced system is a band); grid: cameras on a "
+                         "square lattice, every point seen by all cameras within a radius (synthetic.make_ba_grid: a two-dimensional mesh "
+                         "with real fill -- a parity / sizing workload next to the headline, --poses 10000 / 50000; --landmarks = 10 per "
+                         "camera unless given)")
     ap.add_argument("--nd-leaf", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="solver option name=value (tuning experiments)")
     ap.add_argument("--edge-data", choices=["fused", "arrays"], default="fused",
@@ -204,7 +209,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     P, L = args.poses, args.landmarks
-    prob = S.make_ba_problem(P, L)                      # identical on every rank (counter-based RNG)
+    if args.workload == "grid":
+        ppc = max(L // P, 1) if L != 1000000 or P == 100000 else 10
+        prob = S.make_ba_grid(P, pts_per_cam=ppc)
+        P, L = prob["P"], prob["L"]
+    else:
+        prob = S.make_ba_problem(P, L)                  # identical on every rank (counter-based RNG)
     fused = args.edge_data == "fused"
     prob["omega"] = S.ba_omega(prob)
     if args.information == "edge":
@@ -403,6 +413,19 @@ def main():
                     if traffic else None,
                     # the counters come from a separate rocprofv3 pass (gpurun refuses --pmc next to other tracing), taken at this commit
                     traffic_commit=(pmc_all.get("_commit") if traffic else None))
+    # the factorisation on its FLOPS (dense-front count of the symbolic analysis, g2ohip_stats.choleskyFlops) over the time of its slots:
+    # where it is the dominant kernel (graphs with real fill: --workload grid) the matrix cores bound the path, not HBM
+    fl = float(st.get("choleskyFlops", 0.0))
+    t_factor = sum(1e-3 * v["avg_ms"] * v["launches_per_step"] for k, v in per_kernel.items() if k.startswith("chol_factor"))
+    if fl > 0 and t_factor > 0:
+        for k, v in per_kernel.items():
+            if k.startswith("chol_factor"):
+                v["factor_TFLOPs(all factor slots)"] = fl / t_factor / 1e12
+        if dname.startswith("chol_factor"):
+            roofline = dict(kernel=dname, bound="mfma", achieved=fl / t_factor / 1e12, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=fl / t_factor / 1e12 / MFMA_F64_PEAK_TFLOPS, traffic=None, flops_per_launch=fl, avg_launch_ms=1e3 * t_factor,
+                            note="dense fp64 matrix peak; flops = dense-front count of this factorisation's symbolic analysis (nnz(L) %d)" % st["choleskyNNZ"],
+                            hbm_view=roofline)
     mfma_kernels = {k: {"mfma_util": round(v["mfma_util"], 4), "mfma_TFLOPs": round(v["mfma_TFLOPs"], 2)} for k, v in per_kernel.items() if "mfma_util" in v}
     if mfma_kernels:
         roofline["mfma"] = dict(peak_TFLOPs=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s (dense fp64 matrix)", kernels=mfma_kernels)
@@ -412,12 +435,16 @@ def main():
         os.makedirs(os.path.dirname(os.path.abspath(args.dump_xp)), exist_ok=True)
         np.save(args.dump_xp, x_gpu[:6 * prob["nP"]])
     out = {
-        "metric": "linear-solve ms/iter (buildSystem + setLambda + solve + restoreDiagonal), 100k-pose BA",
+        "metric": "linear-solve ms/iter (buildSystem + setLambda + solve + restoreDiagonal), 100k-pose BA" if args.workload == "chain"
+        else "linear-solve ms/iter (buildSystem + setLambda + solve + restoreDiagonal), grid BA (visibility by distance)",
         "value": ms, "unit": "ms/iter", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "iters_per_s": 1e3 / ms, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "synthetic BA (BASELINE.json configs[3]): %d poses / %d landmarks / %d observations, "
-                               "BlockSolver_6_3 semantics, Schur + multifrontal block Cholesky, lambda=%g" % (P, L, prob["E"], lam),
+        "config": {"workload": ("synthetic BA (BASELINE.json configs[3]): %d poses / %d landmarks / %d observations, "
+                                "BlockSolver_6_3 semantics, Schur + multifrontal block Cholesky, lambda=%g" % (P, L, prob["E"], lam))
+                   if args.workload == "chain" else
+                   ("synthetic BA, visibility by distance (NOT the metric configuration): %d cameras on a square lattice / %d points / %d "
+                    "observations, BlockSolver_6_3 semantics, Schur + multifrontal block Cholesky, lambda=%g" % (P, L, prob["E"], lam)),
                    "poses": P, "landmarks": L, "edges": prob["E"], "parallelism": solver.parallelism(),
                    "edge_data": "estimates+measurements in HBM, errors/Jacobians evaluated inside buildSystem" if fused
                    else "precomputed Jacobian arrays in HBM",
@@ -431,7 +458,7 @@ def main():
         "kernels": per_kernel,
         "stage_algorithmic_GB": {k: v / 1e9 for k, v in stage_b.items()},
         "solver_stats": {k: st[k] for k in ("choleskyNNZ", "numFronts", "numLevels", "maxFrontDim", "timeSymbolicDecomposition", "bandChains",
-                                            "bandCholeskyNNZ", "bandPivots")},
+                                            "bandCholeskyNNZ", "bandPivots", "choleskyFlops")},
     }
     if emulate:
         out["emulate"] = "rank %d of %d alone, exchange skipped: timing only" % emulate
@@ -457,23 +484,27 @@ def main():
     solver.restoreDiagonal()
 
     if world == 1 and not emulate and not args.no_cpu_baseline:
-        cb, x_cpu = cpu_baseline(prob, lam, include_linearize=fused)
+        grid = args.workload == "grid"   # (a CPU iteration of the grid graph is minutes, not seconds: one timed repetition, no thread sweep)
+        cb, x_cpu = cpu_baseline(prob, lam, include_linearize=fused, reps=1 if grid else 3)
         cpu_ms = 1e3 * (cb["t_assembly"] + cb["t_solve"])
         # "best CPU": the reference's optional OpenMP regions.  Its Schur loop takes a mutex per pose row
         # (block_solver.hpp:411) and neighbouring landmarks hit the same rows, so more threads are not always faster:
         # a few thread counts are tried (one iteration each), the best one is then measured like the 1-thread case
         from oracle import oracle as O_
         ncores = os.cpu_count() or 1
-        cands = sorted({t for t in (4, 8, 16, 32, 64, ncores // 2, ncores) if 1 < t <= ncores})
+        cands = [] if grid else sorted({t for t in (4, 8, 16, 32, 64, ncores // 2, ncores) if 1 < t <= ncores})
         tried = {}
         for t in cands:
             O_.lib(True).orc_set_num_threads(t)
             c1, _ = cpu_baseline(prob, lam, want_x=False, include_linearize=fused, omp=True, reps=1)
             tried[t] = 1e3 * (c1["t_assembly"] + c1["t_solve"])
         best_t = min(tried, key=tried.get) if tried else 1
-        O_.lib(True).orc_set_num_threads(best_t)
-        cbo, _ = cpu_baseline(prob, lam, want_x=False, include_linearize=fused, omp=True)
-        omp_ms = 1e3 * (cbo["t_assembly"] + cbo["t_solve"])
+        if grid:
+            cbo, omp_ms = cb, cpu_ms
+        else:
+            O_.lib(True).orc_set_num_threads(best_t)
+            cbo, _ = cpu_baseline(prob, lam, want_x=False, include_linearize=fused, omp=True)
+            omp_ms = 1e3 * (cbo["t_assembly"] + cbo["t_solve"])
         out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms/iter", "cores": 1, "kind": "port",
                                "sample": "median of %d full iterations of the same %d-pose workload, one thread = the reference's "
                                          "default build (assembly %.0f ms + solve %.0f ms, spread %.1f %%; one-time structure %.1f s "

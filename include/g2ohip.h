@@ -76,6 +76,7 @@ typedef struct g2ohip_stats {
   size_t bandCholeskyNNZ, bandPivots; /* ... their share of choleskyNNZ and of the pivot columns (scalars) */
   size_t shardedCollectives;         /* all-reduces of the last g2ohip_solve_sharded (2 with option sharded_merge where the partition allows, else 3) */
   size_t treeBackwardGroups;         /* groups of fronts (one workgroup each) that sweep the tree levels backward (option tree_backward; 0: task by task) */
+  double choleskyFlops;              /* floating-point operations of one numeric factorisation (dense-front count of the symbolic analysis: sum over the fronts of npiv m^2 - npiv^2 m + npiv^3 / 3) */
 } g2ohip_stats;
 /* (G2OBatchStatistics::timeIteration / levenbergIterations / chi2 belong to the caller's optimisation loop:
  *  openslam_g2o_amd/lm.py fills them and prints the `g2o -stats` line, batch_stats.cpp:49-82.) */

@@ -36,7 +36,7 @@ class Stats(C.Structure):
         "timeLinearSolution", "timeLinearSolver", "timeBackSubstitution")] + [(n, C.c_size_t) for n in (
             "hessianDimension", "hessianPoseDimension", "hessianLandmarkDimension", "choleskyNNZ", "numFronts",
             "numLevels", "maxFrontDim", "iterationsLinearSolver")] + [(n, C.c_double) for n in (
-                "timeResiduals", "timeLinearize", "timeUpdate")] + [("dependencyFallbacks", C.c_size_t), ("bandChains", C.c_size_t), ("bandCholeskyNNZ", C.c_size_t), ("bandPivots", C.c_size_t), ("shardedCollectives", C.c_size_t), ("treeBackwardGroups", C.c_size_t)]
+                "timeResiduals", "timeLinearize", "timeUpdate")] + [("dependencyFallbacks", C.c_size_t), ("bandChains", C.c_size_t), ("bandCholeskyNNZ", C.c_size_t), ("bandPivots", C.c_size_t), ("shardedCollectives", C.c_size_t), ("treeBackwardGroups", C.c_size_t), ("choleskyFlops", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

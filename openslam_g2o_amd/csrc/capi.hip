@@ -504,6 +504,7 @@ static void fill_chol_stats(const CholStats* cs, g2ohip_stats* out) {
   out->bandCholeskyNNZ = cs->nnzL_band;
   out->bandPivots = cs->piv_band;
   out->treeBackwardGroups = cs->n_tree_groups;
+  out->choleskyFlops = cs->flops;
 }
 
 int g2ohip_get_stats(g2ohip_solver* s, g2ohip_stats* out) {

@@ -173,6 +173,63 @@ def make_ba_loops(P, L, laps=4, hubs=3, drop=0.2, seed=7, spacing=0.5, f=1000.0,
                 v0=(nP + pt_idx).astype(np.int32), v1=cam_hidx[cam_idx].astype(np.int32))
 
 
+def make_ba_grid(P, pts_per_cam=10, radius=0.9, seed=11, spacing=0.5, f=1000.0, cx=320.0, cy=240.0):
+    """A bundle-adjustment graph with VISIBILITY BY DISTANCE (round 6; the shape of an aerial survey / a street grid seen from above,
+    after g2o's ba_demo geometry, g2o/examples/ba/ba_demo.cpp:151-256, and the visibility lists of a BAL file,
+    g2o/examples/bal/bal_example.cpp:294-406): G x G cameras stand on a square lattice (pitch `spacing`) in the plane z = 0 and
+    look along +z, `pts_per_cam` points per camera are spread uniformly over the area at depth 3 .. 4, and a point is observed by
+    EVERY camera within the horizontal distance `radius` of it (6 .. 13 observations per point at the defaults: ragged lists).  Two
+    cameras share points when they are closer than 2 x radius: every camera is coupled to ~40 others, the reduced pose system is
+    a two-dimensional mesh with a wide stencil -- real fill, separators of hundreds of columns, frontal matrices far beyond the
+    24-column register fronts of the camera-trajectory graphs.  P is rounded down to a square.  Same dictionary as
+    make_ba_problem (edges point-major, cameras row-major on the lattice, the first two cameras fixed)."""
+    rng = CounterRng(seed)
+    G = int(np.floor(np.sqrt(P)))
+    P = G * G
+    L = P * pts_per_cam
+    side = (G - 1) * spacing
+    px = rng.uniform(1, L) * side
+    py = rng.uniform(2, L) * side
+    true_pts = np.stack([px, py, 3.0 + rng.uniform(3, L)], axis=1)
+    reach = int(np.ceil(radius / spacing))
+    off = np.arange(-reach, reach + 1)
+    oi, oj = np.meshgrid(off, off, indexing="ij")
+    oi, oj = oi.reshape(-1), oj.reshape(-1)
+    ci = np.rint(px / spacing).astype(np.int64)[:, None] + oi[None, :]
+    cj = np.rint(py / spacing).astype(np.int64)[:, None] + oj[None, :]
+    d2 = (ci * spacing - px[:, None]) ** 2 + (cj * spacing - py[:, None]) ** 2
+    vis = (ci >= 0) & (ci < G) & (cj >= 0) & (cj < G) & (d2 <= radius * radius)
+    cam_all = (ci * G + cj)
+    # point-major edge list, cameras ascending inside a list
+    order = np.argsort(np.where(vis, cam_all, np.iinfo(np.int64).max), axis=1, kind="stable")
+    cam_sorted = np.take_along_axis(cam_all, order, axis=1)
+    vis_sorted = np.take_along_axis(vis, order, axis=1)
+    cam_idx = cam_sorted[vis_sorted].astype(np.int32)
+    pt_idx = np.repeat(np.arange(L, dtype=np.int32), vis_sorted.sum(axis=1))
+    assert vis_sorted.sum(axis=1).min() >= 2, "a point with fewer than two observations"
+    E = len(cam_idx)
+    cams_true = np.zeros((P, 12))
+    cams_true[:, 0] = cams_true[:, 4] = cams_true[:, 8] = 1.0
+    cams_true[:, 9] = -(np.arange(P) // G) * spacing
+    cams_true[:, 10] = -(np.arange(P) % G) * spacing
+    Xc = true_pts[pt_idx] + cams_true[cam_idx, 9:12]
+    meas = np.stack([Xc[:, 0] / Xc[:, 2] * f + cx, Xc[:, 1] / Xc[:, 2] * f + cy], axis=1)
+    meas[:, 0] += rng.normal(4, E)
+    meas[:, 1] += rng.normal(5, E)
+    pts = true_pts + 0.05 * np.stack([rng.normal(6, L), rng.normal(7, L), rng.normal(8, L)], axis=1)
+    upd = np.zeros((P, 6))
+    upd[:, 0:3] = 0.005 * np.stack([rng.normal(9, P), rng.normal(10, P), rng.normal(11, P)], axis=1)
+    upd[:, 3:6] = 0.01 * np.stack([rng.normal(12, P), rng.normal(13, P), rng.normal(14, P)], axis=1)
+    upd[:2] = 0.0
+    cams = _apply_cam_update(cams_true, upd)
+    cam_hidx = np.arange(P, dtype=np.int32) - 2
+    cam_hidx[:2] = -1
+    nP = P - 2
+    return dict(P=P, L=L, E=E, nP=nP, nL=L, f=f, cx=cx, cy=cy, cams=cams, pts=pts, meas=meas,
+                cam_idx=cam_idx, pt_idx=pt_idx, cam_hidx=cam_hidx,
+                v0=(nP + pt_idx).astype(np.int32), v1=cam_hidx[cam_idx].astype(np.int32))
+
+
 def _apply_cam_update(cams, upd):
     """estimate <- exp(update) * estimate, update = (omega, upsilon)."""
     R, V = _exp_so3(upd[:, 0:3])

@@ -167,3 +167,63 @@ def test_dense_reduced_system_with_a_front_beyond_the_lds_limit():
     s.restoreDiagonal()
     g.compute_active_errors()
     assert g.chi2() < chi0
+
+
+def test_grid_graph_with_visibility_by_distance_against_the_oracle_and_at_size():
+    """The bundle-adjustment graph that is NOT a camera trajectory (synthetic.make_ba_grid: cameras on a square lattice, every point
+    observed by all cameras within a radius -- 4 .. 12 observations per point, every camera coupled to ~40 others; the workload of
+    `bench.py --workload grid`).  At 400 cameras against the CPU oracle (b, Hschur, Dinv to 1e-12, the step to the condition-aware
+    tolerance); at 10 000 cameras (60 000 x 60 000 reduced system, frontal matrices of 3 500 rows, nnz(L) 60 M) through the
+    size-independent properties: residual of the damped system, bit-repeatability, fill against the oracle's block-AMD count at the
+    small size, and an accepted Levenberg-Marquardt trial."""
+    from tests.helpers import dx_tolerance
+    pr = S.make_ba_grid(400)
+    K = np.bincount(pr["pt_idx"])
+    assert K.min() >= 2 and K.max() > 8 and K.min() < K.max()          # ragged observation lists
+    s, g = lm.setup_device_ba(pr)
+    g.linearize()
+    chi0 = g.chi2()
+    assert abs(chi0 - _host_chi2(pr)) <= 1e-9 * chi0
+    s.buildSystem()
+    lam = 1e-5 * s.maxDiagonal()
+    s.setLambda(lam, True)
+    assert s.solve()
+    x, b = s.x(), s.b()
+    Jp, Jc, err = O.ba_edges(pr["cams"], pr["pts"], pr["cam_idx"], pr["pt_idx"], pr["meas"], pr["f"], pr["cx"], pr["cy"])
+    o = O.OracleSolver(6, 3, pr["nP"], pr["nL"], True)
+    k = o.add_edge_set(2, pr["v0"], pr["v1"])
+    o.set_dims(k, 3, 6)
+    o.build_structure()
+    o.set_edge_data(k, Jp, Jc, S.ba_omega(pr), err)
+    o.build_system()
+    assert abs(o.chi2() - chi0) <= 1e-9 * chi0
+    assert relerr(b, o.b()) < 1e-12
+    o.set_lambda(lam, True)
+    assert o.solve()
+    cp, ri = s.pattern(capi.HSCHUR)
+    ocp, ori = o.pattern("hs")
+    assert np.array_equal(cp, ocp) and np.array_equal(ri, ori)
+    assert relerr(s.values(capi.HSCHUR), o.values("Hschur")) < 1e-12 and relerr(s.values(capi.DINV), o.values("Dinv")) < 1e-12
+    assert relerr(x, o.x()) < dx_tolerance(o)[0]
+    assert s.stats()["choleskyNNZ"] <= 1.25 * o.lnz()                   # nested dissection against the oracle's block-AMD on a mesh (measured 0.84 at 10 000)
+    assert s.stats()["bandChains"] == 0                                 # (nothing here is a band)
+    # ---- at size
+    pr = S.make_ba_grid(10000)
+    s, g = lm.setup_device_ba(pr, huber_delta=1.0)
+    g.linearize()
+    chi0 = g.chi2()
+    s.buildSystem()
+    lam = 1e-5 * s.maxDiagonal()
+    s.setLambda(lam, True)
+    assert s.solve()
+    x, b = s.x(), s.b()
+    r = s.multiplyHessian(x) - b
+    assert np.abs(r).max() <= 1e-10 * np.abs(b).max()
+    st = s.stats()
+    assert st["maxFrontDim"] > 2000 and st["hessianPoseDimension"] == 6 * pr["nP"]
+    assert s.solve() and np.array_equal(s.x(), x)
+    g.push()
+    g.update()
+    s.restoreDiagonal()
+    g.compute_active_errors()
+    assert g.chi2() < chi0

@@ -38,4 +38,6 @@ bash tools/gpu_schur_abl.sh > $OUT/${P}_schur_tile_ablation.txt 2>&1
 bash tools/gpu_band_abl.sh > $OUT/${P}_band_ablation.txt 2>&1
 # the k-block issue-rate probe the band kernel's design rests on
 (cd tools/probe && hipcc --offload-arch=gfx950 -O3 -o /tmp/kblock_probe kblock_probe.hip 2>/dev/null && /tmp/kblock_probe) > $OUT/${P}_kblock_probe.txt 2>&1
+# in-kernel stamps of the tree levels (stamps variant: make -C openslam_g2o_amd/csrc VARIANT=stamps EXTRA="-DG2OHIP_CHOL_STAMPS -DWSTAMP_BLOCK=2044")
+if [ -f variants/stamps/libg2ohip.so ]; then bash tools/gpu_tree_timeline.sh "" > $OUT/${P}_tree_stamps.txt 2>&1; fi
 ls -la $OUT
