@@ -63,6 +63,37 @@ def test_generator_is_deterministic_and_shaped():
             assert np.allclose((ep - em) / (2 * h), Jc[k].reshape(6, 2)[c], rtol=1e-4, atol=1e-3)
 
 
+def test_grid_generator_is_deterministic_ragged_and_consistent_with_the_oracle():
+    """synthetic.make_ba_grid (visibility by distance, round 6): deterministic, point-major edges with cameras ascending inside a
+    list, ragged observation lists, every camera coupled to many others; the oracle solves the 100-camera instance and the Schur
+    path agrees with the dense full-system solve (the identity of SURVEY.md 8c, golden vector 2)."""
+    from oracle import oracle as O
+    a, b = S.make_ba_grid(100), S.make_ba_grid(100)
+    for k in ("cams", "pts", "meas", "cam_idx", "pt_idx", "v0", "v1"):
+        assert np.array_equal(a[k], b[k])
+    assert a["P"] == 100 and a["L"] == 1000 and a["nP"] == 98
+    K = np.bincount(a["pt_idx"], minlength=a["L"])
+    assert K.min() >= 2 and K.max() >= 10 and len(np.unique(K)) > 3          # ragged
+    assert (np.diff(a["pt_idx"]) >= 0).all()                                   # point-major
+    same = np.diff(a["pt_idx"]) == 0
+    assert (np.diff(a["cam_idx"])[same] > 0).all()                             # cameras ascending inside a list
+    Jp, Jc, err = S.ba_linearize(a)
+    o = O.OracleSolver(6, 3, a["nP"], a["nL"], True)
+    k = o.add_edge_set(2, a["v0"], a["v1"])
+    o.set_dims(k, 3, 6)
+    o.build_structure()
+    o.set_edge_data(k, Jp, Jc, S.ba_omega(a), err)
+    o.build_system()
+    o.set_lambda(10.0, True)
+    assert o.solve()
+    cp, ri = o.pattern("hs")
+    deg = np.diff(cp)
+    assert deg.max() >= 15
+    H = o.dense_full()
+    x = np.linalg.solve(H, o.b())
+    assert np.abs(o.x() - x).max() <= 1e-9 * np.abs(x).max()
+
+
 def test_g2o_reader(tmp_path):
     p = tmp_path / "t.g2o"
     p.write_text("VERTEX_SE2 3 1 2 0.5\nVERTEX_SE2 1 0 0 0\nEDGE_SE2 1 3 1 2 0.5 10 1 2 20 3 30\nFIX 1\n")
