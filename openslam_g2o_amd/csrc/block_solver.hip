@@ -2860,6 +2860,9 @@ void BlockSolver::build_structure(int nP, int nL, bool do_schur) {
       n_td_ = (long)td_dest.size();
       n_sc_ = (long)te_pack.size();
       schur_lds_bytes_ = max_lds;
+      if (getenv("G2OHIP_PLAN_DUMP"))
+        fprintf(stderr, "schur tiles: %d tiles (LDS %zu B of %zu), %ld partial blocks for %d destinations = %.3f per destination\n", n_tiles_, (size_t)max_lds,
+                (size_t)schur_tile_bytes, n_td_, hs_nnzb, hs_nnzb > 0 ? (double)n_td_ / hs_nnzb : 0.0);
       // per destination: its partial slots in tile order
       std::vector<int> rd_ptr(hs_nnzb + 1, 0), rd_slot(td_dest.size());
       for (int d = 0; d < hs_nnzb; ++d) rd_ptr[d + 1] = rd_ptr[d] + rd_cnt[d];
