@@ -421,7 +421,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
     }
   }
   // --- supernodes (maximal chains with nested structure), capped in width
-  const int max_sn_blocks = std::max(1, opt.max_sn_scalars / bs);
+  // (a pivot panel wider than 64 scalars has no whole-GPU pass: its level would fall back to one workgroup per front -- 430 ms instead of
+  // 18 on the 10 000-camera grid graph, profiles/r6_grid_sweep.txt -- so the cap is itself capped)
+  const int max_sn_blocks = std::max(1, std::min(opt.max_sn_scalars, 64) / bs);
   S.sn_start.clear();
   {
     // Exact merges (identical structure) always; relaxed merges along a parent chain while the
