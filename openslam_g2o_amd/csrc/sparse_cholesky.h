@@ -30,7 +30,7 @@ namespace g2ohip {
 struct CholOptions {
   int nd_leaf = 0;           // nested-dissection leaf size (blocks); 0: 32 (and more, see analyze) for band-shaped graphs, 4 for the others
   int max_sn_scalars = 48;   // supernode (pivot panel) width cap, scalars
-  int max_sn_scalars_lds = 24;  // ... for the fronts small enough for LDS
+  int max_sn_scalars_lds = 0;   // ... for the fronts small enough for LDS; 0: 24 for band-shaped graphs (the register fronts), 48 otherwise
   static constexpr double relax_zeros = 0.25; // relaxed amalgamation: tolerated share of explicit zero blocks in a panel
   static constexpr size_t lds_front_bytes = 256 * 1024;  // fronts up to this DENSE size (m*m*8) are candidates for LDS (stored packed: half) ...
   static constexpr size_t lds_budget_bytes = 150 * 1024; // ... if blocks + vectors + index tables fit this per-workgroup LDS budget

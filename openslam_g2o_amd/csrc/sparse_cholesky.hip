@@ -363,8 +363,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   // is a third shallower (sphere 2 200: 57 -> 37 levels, 2.07 -> 1.44 ms per solve; manhattan: fill 2.45 -> 1.89 x the reference's
   // block-AMD; profiles/r6_nd_leaf.txt).
   int nd_leaf = opt.nd_leaf;
+  bool band_like = true;   // (an explicit leaf size keeps the band kernel's supernode width)
   if (nd_leaf <= 0) {
-    bool band_like = false;
+    band_like = false;
     if (nb > 0) {
       NdWork W(nb, xadj, adj);
       int nlev = W.bfs(0, 0);
@@ -424,6 +425,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   // (a pivot panel wider than 64 scalars has no whole-GPU pass: its level would fall back to one workgroup per front -- 430 ms instead of
   // 18 on the 10 000-camera grid graph, profiles/r6_grid_sweep.txt -- so the cap is itself capped)
   const int max_sn_blocks = std::max(1, std::min(opt.max_sn_scalars, 64) / bs);
+  // supernodes of the LDS-resident fronts: 24 scalars = the register fronts of the band graphs (wave_front_kernel); graphs that are not a
+  // band have few such fronts and gain from twice the width (manhattan 0.845 -> 0.831, sphere 1.442 -> 1.414 ms: fewer levels)
+  const int sn_lds = (opt.max_sn_scalars_lds <= 0) ? (band_like ? 24 : 48) : opt.max_sn_scalars_lds;
   S.sn_start.clear();
   {
     // Exact merges (identical structure) always; relaxed merges along a parent chain while the
@@ -442,7 +446,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         // narrower panels for the fronts that live in LDS (shorter pivot loops per front, smaller solve panels), wide
         // ones for the scratch-slab fronts (each panel is a whole-GPU pass there)
         const bool lds_class = m * m * 8 <= opt.lds_front_bytes;
-        const long cap = lds_class ? std::max(1, std::min(opt.max_sn_scalars, opt.max_sn_scalars_lds) / bs) : max_sn_blocks;
+        const long cap = lds_class ? std::max(1, std::min(opt.max_sn_scalars, sn_lds) / bs) : max_sn_blocks;
         if (w <= cap && (exact || (fits && (double)(total - tb) <= opt.relax_zeros * (double)total))) merge = true;
       }
       if (!merge) {
