@@ -778,6 +778,16 @@ def test_linear_solver_large_fronts_all_block_sizes(bs, passes):
     ok, _ = ls.solve(cp, row, -vals, b)
     assert not ok
     assert ls.solvePattern(cp, row, -vals, rr[:2], cc[:2]) is None
+    if passes == 1:
+        # a supernode cap beyond 64 scalars is capped by the analysis (wider pivot panels have no whole-GPU pass and used to fall back
+        # to one workgroup per front): the same fronts as with 60, the same solution
+        a, c = capi.HipLinearSolver(bs, 0), capi.HipLinearSolver(bs, 0)
+        a.setOption("max_sn_scalars", 144)
+        c.setOption("max_sn_scalars", 64)
+        oka, xa = a.solve(cp, row, vals, b)
+        okc, xc = c.solve(cp, row, vals, b)
+        assert oka and okc and a.stats()["numFronts"] == c.stats()["numFronts"] and np.array_equal(xa, xc)
+        assert relerr(xa, xr) < 1e-10
 
 
 def test_dependency_driven_launches_soak():
