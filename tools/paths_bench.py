@@ -29,6 +29,65 @@ def med(v):
     return float(np.median(v))
 
 
+CPU_ONLY = "--cpu-only" in sys.argv     # the CPU leg alone (build container: oracle/_ref = the reference's compiled CSparse is present there)
+if CPU_ONLY:
+    sys.argv.remove("--cpu-only")
+
+
+def run_cpu_only(name, g, p, l, d, lin, v0, v1, reps_cpu=5):
+    """errors / Jacobians / buildSystem by the oracle (port), the linear solver by the reference's own compiled CSparse path (oracle/_ref:
+    block-AMD ordering + cs_schol once, then cs_cholsolsymb per iteration) -- no GPU involved."""
+    import ctypes as C
+    R = O.ref()
+    assert R is not None, "oracle/_ref not built"
+    o = O.OracleSolver(p, l, g["nP"], 0, schur=False)
+    ko = o.add_edge_set(d, v0, v1)
+    o.set_dims(ko, p, p)
+    o.build_structure()
+    J0, J1, err = lin()
+    o.set_edge_data(ko, J0, J1, g["omega"], err)
+    o.build_system()
+    lam = 1e-5 * o.max_diagonal()
+    ip = lambda a: a.ctypes.data_as(O.c_int_p)
+    dp = lambda a: a.ctypes.data_as(O.c_dbl_p)
+    t_lin, t_asm, t_ref, t_port = [], [], [], []
+    h = None
+    for rep in range(reps_cpu + 1):
+        t0 = time.perf_counter(); J0, J1, err = lin(); tl = time.perf_counter() - t0
+        o.set_edge_data(ko, J0, J1, g["omega"], err)
+        t0 = time.perf_counter(); o.build_system(); ta = time.perf_counter() - t0
+        o.set_lambda(lam, True)
+        t0 = time.perf_counter(); assert o.solve(); tp = time.perf_counter() - t0
+        xo = o.x()
+        cp, ri = o.pattern("pp")
+        cp, ri = np.ascontiguousarray(cp, np.int32), np.ascontiguousarray(ri, np.int32)
+        nb, n = g["nP"], g["nP"] * p
+        if h is None:
+            P = np.zeros(nb, np.int32)
+            t0 = time.perf_counter()
+            Ap, Ai, Ax = O.scalar_ccs(nb, p, cp, ri, o.values("Hpp"))
+            assert R.ref_block_amd(nb, ip(cp), ip(ri), ip(P))
+            sperm = (P[:, None] * p + np.arange(p, dtype=np.int32)[None, :]).reshape(-1).astype(np.int32)
+            h = C.c_void_p(R.ref_symbolic(n, ip(Ap), ip(Ai), ip(sperm)))
+            t_sym = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Ap, Ai, Ax = O.scalar_ccs(nb, p, cp, ri, o.values("Hpp"))
+        xr = o.b().copy()
+        ok = R.ref_cholsolve(h, ip(Ap), ip(Ai), dp(Ax), dp(xr))
+        tr = time.perf_counter() - t0
+        assert ok
+        o.restore_diagonal()
+        if rep > 0:
+            t_lin.append(tl); t_asm.append(ta); t_port.append(tp); t_ref.append(tr)
+    print(json.dumps({"path": "CPU leg of config %s (%s), build container" % ("1" if name == "manhattan" else "2", name), "graph": name,
+                      "poses": int(g["nP"]), "edges": int(len(g["vi"])), "kind": "port (assembly) + reference (linear solver)", "cores": 1,
+                      "host": host_model(), "host_cores": os.cpu_count(), "linearize_ms": 1e3 * med(t_lin), "build_system_ms": 1e3 * med(t_asm),
+                      "reference_solve_ms": 1e3 * med(t_ref), "reference_ordering_symbolic_ms": 1e3 * t_sym, "reference_lnz": R.ref_lnz(h),
+                      "port_solve_ms": 1e3 * med(t_port), "value_ms_per_iteration": 1e3 * (med(t_lin) + med(t_asm) + med(t_ref)),
+                      "dx_rel_err_reference_vs_port": float(np.abs(xr - xo).max() / np.abs(xo).max())}), flush=True)
+    R.ref_free(h)
+
+
 def run(name, reps_gpu=50, reps_cpu=5):
     if name == "manhattan":
         g = manhattan_golden(); p, l, d, typ = 3, 2, 3, 1
@@ -39,6 +98,8 @@ def run(name, reps_gpu=50, reps_cpu=5):
         est, meas = g["poses"], g["Z"]
         lin = lambda: O.se3_edges(est, g["vi"], g["vj"], meas)
     v0, v1 = g["hidx"][g["vi"]], g["hidx"][g["vj"]]
+    if CPU_ONLY:
+        return run_cpu_only(name, g, p, l, d, lin, v0, v1)
     # ---- MI355X: the device front end (errors + Jacobians evaluated inside the iteration, like the reference's buildSystem)
     s = capi.HipBlockSolver(p, l, 0)
     k = s.addEdgeSet(d, v0, v1)
