@@ -794,3 +794,23 @@ def test_gauss_newton_on_a_numerically_singular_chain_repeats_the_solve_with_a_t
     d = json.load(open(out))
     chis = [it["chi2"] for it in d["iterations"]]
     assert len(chis) == 2 and np.isfinite(chis).all() and chis[-1] < d["chi2_initial"], (d["chi2_initial"], chis)
+
+
+@pytest.mark.parametrize("solver", ["lm_fix6_3_hip", "lm_fix6_3_hipdev"])
+def test_levenberg_through_the_plugin_on_the_grid_graph_with_visibility_by_distance(host, tmp_path, solver):
+    """The graph that is not a camera trajectory (synthetic.make_ba_grid: 144 cameras on a lattice, ragged observation lists of 4-12,
+    every camera coupled to ~40 others) through the g2o vtables, host loop and device-resident driver: chi2, lambda, the number of
+    trials per iteration and the final estimates of five Levenberg-Marquardt iterations equal the oracle-driven loop."""
+    from openslam_g2o_amd import synthetic as S
+    pr = S.make_ba_grid(144)
+    Jp, Jc, err = S.ba_linearize(pr)
+    pr.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(pr))
+    prob = str(tmp_path / "p.txt")
+    _write_problem(prob, pr, 1.0)
+    chi0, n_o, chis_o, lams_o, trials_o, cams_o, pts_o = _oracle_lm(pr, 5, 1.0)
+    out, err_ = _run(host, prob, solver, 5, str(tmp_path / "o.json"))
+    assert abs(out["chi2_initial"] - chi0) <= 1e-9 * chi0
+    assert out["iterations"] == n_o and out["trials"] == trials_o, (out["trials"], trials_o)
+    assert np.allclose(out["chi2"], chis_o, rtol=1e-7, atol=0), (out["chi2"], chis_o)
+    assert np.allclose(out["lambda"], lams_o, rtol=1e-7, atol=0)
+    assert relerr(np.array(out["cams"]).reshape(-1, 12), cams_o) < 1e-7 and relerr(np.array(out["points"]).reshape(-1, 3), pts_o) < 1e-7

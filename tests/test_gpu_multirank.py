@@ -52,11 +52,12 @@ def _worker(rank, world, port, P, L, lam, fused, x_exchange, out_dir, options=""
 
 
 def _case(P, L):
-    """L < 0: the graph with loop closures, ragged lists and a hub point (synthetic.make_ba_loops) instead of the band."""
+    """L < 0: the graph with loop closures, ragged lists and a hub point (synthetic.make_ba_loops) instead of the band; L == 0: the
+    grid graph with visibility by distance (synthetic.make_ba_grid, P cameras)."""
     if L > 0:
         return ba_case(P, L)
     from openslam_g2o_amd import synthetic as S
-    pr = S.make_ba_loops(P, -L, laps=4, hubs=1)
+    pr = S.make_ba_grid(P) if L == 0 else S.make_ba_loops(P, -L, laps=4, hubs=1)
     Jp, Jc, err = S.ba_linearize(pr)
     pr.update(Jp=Jp, Jc=Jc, err=err, omega=S.ba_omega(pr))
     return pr
@@ -103,12 +104,13 @@ def test_subtree_distributed_solve_matches_oracle(tmp_path, world, fused, x_exch
     assert (seen == 1).all() and edges == pr["E"]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_subtree_distributed_solve_on_a_graph_with_loop_closures(tmp_path, world):
-    """The same sharded solve on a graph that is not a band: the elimination tree has a dense top (most of it shared), the
-    subtrees are uneven, a hub point couples a third of the poses.  Only correctness is asserted."""
+@pytest.mark.parametrize("world,P,L", [(2, 420, -1600), (3, 420, -1600), (2, 400, 0), (4, 400, 0)])
+def test_subtree_distributed_solve_on_a_graph_with_loop_closures(tmp_path, world, P, L):
+    """The same sharded solve on graphs that are not a band: the loop-closure graph (the elimination tree has a dense top, most of it
+    shared, the subtrees are uneven, a hub point couples a third of the poses) and the grid graph with visibility by distance (a
+    two-dimensional mesh: every separator is shared by several ranks' subtrees).  Only correctness is asserted."""
     import torch.multiprocessing as mp
-    P, L, lam = 420, -1600, 30.0
+    lam = 30.0
     mp.spawn(_worker, args=(world, _free_port(), P, L, lam, True, "halo", str(tmp_path)), nprocs=world, join=True)
     pr = _case(P, L)
     o = oracle_ba(pr)
