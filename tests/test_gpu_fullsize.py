@@ -227,3 +227,27 @@ def test_grid_graph_with_visibility_by_distance_against_the_oracle_and_at_size()
     s.restoreDiagonal()
     g.compute_active_errors()
     assert g.chi2() < chi0
+
+
+def test_bench_line_contract_on_both_workloads(tmp_path):
+    """bench.py prints ONE JSON line with the contract's keys; `roofline` carries frac_traffic / traffic_commit / the matrix-core block
+    on the chain workload at the metric configuration only (the PMC file is for that size) and switches to the MFMA bound with the
+    factorisation's flop count where the factorisation dominates (--workload grid); `cpu_baseline` (the oracle, one repetition on the
+    grid) sits beside it with dx / chi2 against it."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for args, bound in ((["--workload", "grid", "--poses", "900"], "mfma"), (["--poses", "3000", "--landmarks", "30000"], "hbm")):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2"] + args, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-1500:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                  "roofline", "cpu_baseline"):
+            assert k in d, k
+        assert d["steps"] == 3 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["higher_is_better"] is False
+        assert d["roofline"]["bound"] == bound and 0 < d["roofline"]["frac"] < 1
+        assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+        assert d["dx_rel_err"] < 1e-8 and d["chi2_rel_err"] < 1e-9 and d["residual_rel"] < 1e-11
+        if bound == "mfma":
+            assert d["roofline"]["unit"] == "TFLOP/s" and d["solver_stats"]["choleskyFlops"] > 0 and "visibility by distance" in d["config"]["workload"]
