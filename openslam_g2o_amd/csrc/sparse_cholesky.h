@@ -59,8 +59,12 @@ struct CholOptions {
                                          // touches only the columns of the group's remaining panels, the rest of the trailing matrix gets ONE rank-(group)
                                          // update behind the group's last panel -- a quarter of the passes over a frontal matrix that lives in HBM (1: off)
   static constexpr int group_forward_side = 1;            // ... and the forward steps of such panels run on a side stream next to the next panel's factorisation
-  int big_group_min_rows = 1536;         // ... for chains whose first front has at least this many rows (smaller ones are latency chains, not traffic)
-  static constexpr int big_merge_tiles = 256;             // scratch-slab levels of at most this many 64 x 64 tiles run the fused panel kernel (panel solve + update
+  int big_group_min_rows = 1024;         // ... for chains whose first front has at least this many rows (smaller ones are latency chains, not traffic:
+                                         // 512 takes sphere from 1.41 to 2.0 ms)
+#ifndef G2OHIP_BIG_MERGE_TILES
+#define G2OHIP_BIG_MERGE_TILES 256
+#endif
+  static constexpr int big_merge_tiles = G2OHIP_BIG_MERGE_TILES;             // scratch-slab levels of at most this many 64 x 64 tiles run the fused panel kernel (panel solve + update
                                          // [+ pivot blocks, merge_diag_panel] in one launch); wider levels the separate whole-GPU passes
   static constexpr int merge_diag_panel = 1;              // pivot blocks and panel tiles of a level of scratch-slab fronts in ONE launch (tiles wait for their front's flag)
   static constexpr int merge_backward_levels = 1;         // backward step of consecutive levels of scratch-slab fronts in ONE launch (workgroups wait for their parent front's flag)
@@ -158,6 +162,8 @@ struct CholPlanDev {
   const int* cinv;         // scratch-slab fronts whose children are gathered at load time: per front a header (children, offsets of their update
                            // matrices) and per child ordinal the map front block -> the child's boundary block (-1: none)
   const int2* cinv_slot;   // ... per launch slot: (offset into cinv or -1, ints)
+  const int *gtab, *gtab_off;   // grouped in-place chains: per group's last panel (gtab_off[front], -1: none) the earlier panels of the group --
+                                // count, then (L offset low, high, rows of the front, pivot columns, row offset) each
   const int* tri;    // row-major enumeration of a lower triangle: idx -> (i | j << 16)
   const int *f_ns, *f_nb, *f_c0, *rows_off, *rows, *rel_off, *rel;
   const long long *L_off, *U_off, *w_off;
@@ -283,7 +289,7 @@ class SparseCholesky {
   int spinv_npiv_max_ = 0;
   DevBuf<FrontRec> d_rec;
   DevBuf<ChildDesc> d_cdesc;
-  DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts, d_cinv;
+  DevBuf<int> d_crel, d_cmap, d_tri, d_task_ptr, d_task_fronts, d_cinv, d_gtab, d_gtab_off;
   DevBuf<int2> d_cinv_slot;
   DevBuf<double> d_L, d_U, d_w, d_y, d_xp, d_scratch;
   int hz_begin_[2] = {0, 0}, hz_count_[2] = {0, 0}, ha_begin_[2] = {0, 0}, ha_count_[2] = {0, 0};   // phase-wide fill / assembly chunks (d_big_tiles)
@@ -320,6 +326,7 @@ class SparseCholesky {
     std::vector<std::pair<int, int>> be_pass;
     long long glb_scratch = 0;                           // doubles of the scratch slab this launch uses
     bool big_ok = false;
+    bool tr_all = false;                                 // every scratch-slab front of the level has boundary rows (big_panel_solve_kernel)
     // levels whose LDS fronts run on a side stream next to the scratch-slab passes (overlap_level_halves): split_ok = the level
     // qualifies by its structure; fork = an LDS front of it has a child that ran on the main stream since the side stream last
     // waited for it; join = a front of the main part has a child that ran on the side stream since the main stream last did

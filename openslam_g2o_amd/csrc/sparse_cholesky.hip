@@ -21,6 +21,7 @@ constexpr int kGatherLdsOff = 3 * 64 * 65 + 64 + 128;   // ... behind the level 
 constexpr int kFactorThreadsGlobal = 512;
 constexpr int kChainU = 6;  // doubles per thread that carry an update matrix from one chain front to the next
 // register-resident wave kernel (wave_front.inc): limits of a front
+constexpr int kPanelSolveWgs = 512;      // big_panel_solve_kernel (pivot blocks + panel rows of a level in one launch) on launches of at most this many workgroups
 constexpr int kFillChunk = 4096;         // doubles zeroed by one workgroup of big_fill_kernel
 constexpr int kWvNPV = 24;             // pivot columns (scalars)
 constexpr int kWvNTL = 3;              // 16-row tiles of boundary rows (48 rows)
@@ -428,6 +429,11 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   // supernodes of the LDS-resident fronts: 24 scalars = the register fronts of the band graphs (wave_front_kernel); graphs that are not a
   // band have few such fronts and gain from twice the width (manhattan 0.845 -> 0.831, sphere 1.442 -> 1.414 ms: fewer levels)
   const int sn_lds = (opt.max_sn_scalars_lds <= 0) ? (band_like ? 24 : 48) : opt.max_sn_scalars_lds;
+  // scratch-slab fronts of a thousand rows and more: panels of the full 64 scalars (every panel is a level of whole-GPU passes: fewer of them)
+  // (10 000-camera grid graph: 169 -> 143 levels, 21.6 -> 20.6 ms; 49 729 cameras 100.7 -> 97.6; narrower thresholds cost the pose graphs
+  // levels of their own: profiles/r6_grid_sweep.txt)
+  constexpr int wide_rows = 1024;
+  const int wide_blocks = opt.max_sn_scalars >= 48 ? std::max(max_sn_blocks, 64 / bs) : max_sn_blocks;
   S.sn_start.clear();
   {
     // Exact merges (identical structure) always; relaxed merges along a parent chain while the
@@ -446,7 +452,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         // narrower panels for the fronts that live in LDS (shorter pivot loops per front, smaller solve panels), wide
         // ones for the scratch-slab fronts (each panel is a whole-GPU pass there)
         const bool lds_class = m * m * 8 <= opt.lds_front_bytes;
-        const long cap = lds_class ? std::max(1, std::min(opt.max_sn_scalars, sn_lds) / bs) : max_sn_blocks;
+        const long cap = lds_class ? std::max(1, std::min(opt.max_sn_scalars, sn_lds) / bs) : (m >= (size_t)wide_rows ? wide_blocks : max_sn_blocks);
         if (w <= cap && (exact || (fits && (double)(total - tb) <= opt.relax_zeros * (double)total))) merge = true;
       }
       if (!merge) {
@@ -1001,7 +1007,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   // what its 250 ms were.  Panels are grouped by big_group: a panel inside a group updates only the columns of the group's
   // remaining panels (what their pivot blocks and panel rows need), the group's LAST panel updates everything behind the group
   // with all the group's pivot columns at once (they are adjacent columns of the same frontal matrix).
-  std::vector<int> grp_prev(nf, 0), grp_rem(nf, 0);
+  std::vector<int> grp_prev(nf, 0), grp_rem(nf, 0), gtab, gtab_off(nf, -1);
   if (opt.big_group > 1)
     for (int f0 = 0; f0 < nf; ++f0) {
       if (inpl_prev[f0] >= 0 || inpl_next[f0] < 0) continue;   // (chain heads only)
@@ -1019,6 +1025,24 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           if (i + 1 == g1) grp_prev[f] = before;                 // the group's last panel: all of the group's columns
           else grp_rem[f] = total - before - np_;                // inside the group: up to the group's end
           before += np_;
+        }
+        // the group's last panel reads the earlier panels' solved rows from THEIR L panels (not from the frontal matrix: the fused
+        // solve + update kernel leaves the raw rows there): per earlier panel (L offset low / high, rows of its front, pivot columns,
+        // row of its trailing part that is row 0 of the last panel's trailing part)
+        if (g1 - g0 > 1) {
+          const int fl = chain[g1 - 1];
+          gtab_off[fl] = (int)gtab.size();
+          gtab.push_back((int)(g1 - g0 - 1));
+          for (size_t i = g0; i + 1 < g1; ++i) {
+            const int f = chain[i];
+            int rowoff = 0;
+            for (size_t k = i + 1; k < g1; ++k) rowoff += S.f_ns[chain[k]] * bs;
+            gtab.push_back((int)(unsigned int)(S.L_off[f] & 0xffffffffLL));
+            gtab.push_back((int)(S.L_off[f] >> 32));
+            gtab.push_back((int)front_dim(f));
+            gtab.push_back(S.f_ns[f] * bs);
+            gtab.push_back(rowoff);
+          }
         }
       }
     }
@@ -1108,6 +1132,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           for (int r = 0; r < rows; r += 256) bt.push_back(make_int4(q, r, 0, 0));
         }
         LL.tr_count = (int)bt.size() - LL.tr_begin;
+        LL.tr_all = LL.glb_count > 0;   // every front has panel rows (big_panel_solve_kernel: a front without would have no workgroup)
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q)
+          if (S.f_nb[S.task_fronts[S.task_ptr[S.level_fronts[q]]]] == 0) LL.tr_all = false;
         // row chunks for the multi-workgroup sweeps (big_forward_kernel / big_backward_kernel): the chunks of a front are
         // contiguous, w = ordinal | count << 16
         LL.sw_begin = (int)bt.size();
@@ -1756,6 +1783,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   d_crel.upload(crel, st);
   if (cinv.empty()) cinv.push_back(-1);
   if (cinv_slot.empty()) cinv_slot.push_back(make_int2(-1, 0));
+  if (gtab.empty()) gtab.push_back(0);
+  d_gtab.upload(gtab, st);
+  d_gtab_off.upload(gtab_off, st);
   d_cinv.upload(cinv, st);
   d_cinv_slot.upload(cinv_slot, st);
   d_cmap.upload(cmap, st);
@@ -1858,6 +1888,8 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
   plan_.rec = d_rec.p;
   plan_.cdesc = d_cdesc.p;
   plan_.crel = d_crel.p;
+  plan_.gtab = d_gtab.p;
+  plan_.gtab_off = d_gtab_off.p;
   plan_.cinv = d_cinv.p;
   plan_.cinv_slot = d_cinv_slot.p;
   plan_.cmap = d_cmap.p;
@@ -3022,37 +3054,44 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-  const double* Lr[2];
-  const double* Lc[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    Lr[q] = F + npiv + min(r0 + 16 * q + lr, mt - 1);
-    Lc[q] = F + npiv + min(c0 + 16 * q + lr, mt - 1);
-  }
-  // KS k-steps of operands are requested together (a step per round trip would make the kernel a chain of L2 latencies)
+  // Operands straight from the L panels (L2-resident, 128-byte coalesced: 16 consecutive rows per k), KS k-steps requested together (a
+  // step per round trip would make the kernel a chain of L2 latencies).  kprev > 0 (the last panel of a grouped in-place chain): the
+  // group's earlier panels first -- their solved rows for these rows sit in THEIR L panels (CholPlanDev::gtab) --, then this front's:
+  // one rank-(kprev + npiv) update.
   constexpr int KS = 6;
-  // (kprev > 0: the pivot columns of the group's earlier panels sit right in front of this front's in the same frontal matrix --
-  // columns -kprev .. -1 relative to it -- and their rows are these rows: one rank-(kprev + npiv) update)
-  for (int k00 = -kprev; k00 < npiv; k00 += 4 * KS) {
-    double rv[KS][2], cv[KS][2];
+  const int rr[2] = {min(r0 + lr, mt - 1), min(r0 + 16 + lr, mt - 1)}, cc[2] = {min(c0 + lr, mt - 1), min(c0 + 16 + lr, mt - 1)};
+  auto rank_update = [&](const double* __restrict__ Lp, long long mm, int nn) {   // Lp: row 0 of the trailing part, column 0 of the panel
+    for (int k00 = 0; k00 < nn; k00 += 4 * KS) {
+      double rv[KS][2], cv[KS][2];
 #pragma unroll
-    for (int s_ = 0; s_ < KS; ++s_) {
-      const int k0 = k00 + 4 * s_;
-      const int k = min(k0 + lk, npiv - 1);
-      const double keep = (k0 + lk < npiv) ? 1.0 : 0.0;
+      for (int s_ = 0; s_ < KS; ++s_) {
+        const int k0 = k00 + 4 * s_;
+        const int k = min(k0 + lk, nn - 1);
+        const double keep = (k0 + lk < nn) ? 1.0 : 0.0;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        rv[s_][q] = Lr[q][(long long)m * k] * keep;
-        cv[s_][q] = Lc[q][(long long)m * k];
+        for (int q = 0; q < 2; ++q) {
+          rv[s_][q] = Lp[rr[q] + mm * k] * keep;
+          cv[s_][q] = Lp[cc[q] + mm * k];
+        }
       }
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[s_][b], rv[s_][a], acc[a][b], 0, 0, 0);
     }
-#pragma unroll
-    for (int s_ = 0; s_ < KS; ++s_)
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[s_][b], rv[s_][a], acc[a][b], 0, 0, 0);
+  };
+  if (kprev > 0) {
+    const int* gt = P.gtab + P.gtab_off[f];
+    const int np_ = gt[0];
+    for (int j = 0; j < np_; ++j) {
+      const int* e = gt + 1 + 5 * j;
+      const long long lo = ((long long)e[1] << 32) | (long long)(unsigned int)e[0];
+      rank_update(P.L + lo + e[3] + e[4], (long long)e[2], e[3]);
+    }
   }
+  rank_update(P.L + rec.L_off + npiv, (long long)(npiv + mt), npiv);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -4238,10 +4277,13 @@ __global__ void mask_kernel(size_t n, const double* __restrict__ mask, double* _
 // LDS copy of the finished pivot block with the operation order of front_forward_kernel.
 // COH (big_level_kernel): L11 and the reciprocal diagonal go to memory with device-coherent stores -- the panel tiles of the
 // same launch read them.  lds: 512 doubles (FWD: 4 800).
-template <int BS, bool FWD, bool COH, bool GATH = false>
+// WINV (big_panel_solve_kernel: every workgroup of the panel solve factorises the pivot block itself): L11 stays in LDS (L11s, lis), the
+// inverses of its diagonal 16 x 16 tiles follow (Ws), and only the workgroup with `writer` stores L11 and the reciprocal diagonal to L --
+// the frontal matrix keeps the RAW pivot block, the other workgroups of the launch are still reading it.
+template <int BS, bool FWD, bool COH, bool GATH = false, bool WINV = false>
 __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const int slot, double* __restrict__ scratch,
                                                    const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld,
-                                                   const double* __restrict__ bperm, double* __restrict__ yout, double* lds) {
+                                                   const double* __restrict__ bperm, double* __restrict__ yout, double* lds, bool writer = true) {
   double* Rb = lds;
   double* Lb = lds + 256;
   double* L11s = lds + 512;   // (FWD only)
@@ -4366,7 +4408,8 @@ __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const i
         const int col = k0 + lk;
         if (lr == 0 && col < n) {
           if (COH) st_coh(Lg + (size_t)m * n + col, rssel);
-          else Lg[(size_t)m * n + col] = rssel;
+          else if (!WINV || writer) Lg[(size_t)m * n + col] = rssel;
+          if (WINV) lis[col] = rssel;
         }
         double Lp[T];   // scaled panel rows of the tile columns: operand layout of the update
 #pragma unroll
@@ -4383,8 +4426,9 @@ __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const i
             }
             if (col < n && row < n) {
               if (COH) st_coh(Lg + (size_t)row + (size_t)m * col, v);
-              else Lg[(size_t)row + (size_t)m * col] = v;
-              F[(size_t)row + (size_t)ld * col] = v;
+              else if (!WINV || writer) Lg[(size_t)row + (size_t)m * col] = v;
+              if (!WINV) F[(size_t)row + (size_t)ld * col] = v;
+              if (WINV) L11s[row + 65 * col] = v;
             }
           }
         }
@@ -4400,6 +4444,41 @@ __device__ __forceinline__ void big_diag_mfma_body(const CholPlanDev& P, const i
   (void)Rb;
   (void)Lb;
   if (bad && lane == 0) atomicMax(P.status, 1);
+  if (WINV) {
+    // The panel solve runs on the matrix cores, 16 columns at a time: it needs the INVERSES of the diagonal 16 x 16 tiles of L11
+    // (triangular; the conditioning of a 16 x 16 tile only).  Wave t inverts tile t from the LDS copy -- lane j the column j, rows in
+    // sequence, the multipliers broadcast -- into Ws[t][row][column] (zeros above the diagonal and beyond n).
+    double* Ws = tJ + 64;
+    __syncthreads();
+    const int base = 16 * w;
+    if (lane < 16) {
+      const int j = lane;
+      // (branch-free: every load unconditional -- rows beyond n read what the LDS holds and are dropped by the selects)
+      double wv[16], ri[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const double r_ = lis[base + i];
+        ri[i] = base + i < n ? r_ : 0.0;
+        wv[i] = i == j ? ri[i] : 0.0;
+      }
+#pragma unroll
+      for (int i = 1; i < 16; ++i) {
+        double lrow[15];
+#pragma unroll
+        for (int k = 0; k < i; ++k) lrow[k] = L11s[(base + i) + 65 * (base + k)];
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+          if (k & 1) s1 = fma(lrow[k], wv[k], s1);
+          else s0 = fma(lrow[k], wv[k], s0);
+        }
+        const double nv = -ri[i] * (s0 + s1);
+        wv[i] = (i > j && base + i < n) ? nv : wv[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Ws[w * 256 + i * 16 + j] = wv[i];
+    }
+  }
   if (fwd_here) {
     if (tid < 64) tJ[tid] = bJ;
     __syncthreads();   // (also: the pivot block written above is visible to the whole workgroup)
@@ -4444,6 +4523,81 @@ __global__ void __launch_bounds__(256) big_diag_mfma_kernel(CholPlanDev P, int s
   big_diag_mfma_body<BS, FWD, false>(P, slot0 + blockIdx.x, scratch, scratch_off, scratch_ld, bperm, yout, lds);
 }
 
+// Pivot block AND panel rows of the scratch-slab fronts of a level in one launch, the rows on the matrix cores (big_diag_mfma_kernel
+// + big_trsm_kernel: two launches of 16 and 23 us on every level of a large separator's chain -- one wave's factorisation, then one
+// thread per row with n^2 / 2 dependent multiply-adds; both mostly start-up and latency).  A workgroup owns 64 panel rows (a quarter
+// of a chunk of big_trsm_kernel's list) and factorises the pivot block ITSELF (a few dozen workgroups repeat one wave's 8 us next to
+// each other instead of queueing behind it); the first workgroup of a front writes L11 to L.  Then x L11' = row for 16 rows per wave:
+// the rows are loaded TRANSPOSED into the accumulator layout D[k][row] (lane = row: coalesced) and block forward substitution over the
+// 16-column tiles t of the panel runs as MFMAs whose B operand is the accumulator of an earlier tile -- the layouts chain (D[4 v + q][j]
+// in register v of lane j + 16 q is B[j][k = q] of k-step v):
+//     -Q_t = -R_t + sum_{u < t} L11(t, u) X_u        X_t = (-W_t) (-Q_t),   W_t = L11(t, t)^-1.
+// The solved rows go to L only (big_front_update_kernel reads them there); the frontal matrix keeps the raw panel.
+// Needs every front of the launch to have boundary rows (LevelLaunch::tr_all): a front without has no workgroup here.
+template <int BS>
+__global__ void __launch_bounds__(256) big_panel_solve_kernel(CholPlanDev P, const int4* __restrict__ chunks, double* __restrict__ scratch,
+                                                             const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
+  __shared__ double lds[4800 + 4 * 256];
+  const int4 ck = chunks[blockIdx.x >> 2];   // x: launch slot, y: first row (relative to the pivot block's end)
+  const int sub = blockIdx.x & 3;
+  const int f = P.slots[ck.x].x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int n = rec.ns * BS, mt = rec.nb * BS, m = n + mt;
+  if (ck.y + 64 * sub >= mt) return;   // (whole workgroup)
+  const int ld = scratch_ld[ck.x];
+  const double* F = scratch + scratch_off[ck.x];
+  double* Lg = P.L + rec.L_off;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+  const int row = ck.y + 64 * sub + 16 * wave + lr;
+  // this wave's 16 rows, requested before the pivot block
+  mfma_d4 X[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = 16 * t + 4 * v + lk;
+      const double x = F[(size_t)(n + min(row, mt - 1)) + (size_t)ld * min(k, n - 1)];
+      X[t][v] = (row < mt && k < n) ? -x : 0.0;
+    }
+  big_diag_mfma_body<BS, false, false, false, true>(P, ck.x, scratch, scratch_off, scratch_ld, nullptr, nullptr, lds, ck.y == 0 && sub == 0);
+  __syncthreads();
+  const double* L11s = lds + 512;
+  const double* Ws = lds + 4800;
+  const int ntl = (n + 15) >> 4;   // 16-column tiles of the panel (1..4)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < ntl) {   // (uniform)
+      const int i = 16 * t + lr;
+      double Lop[3][4], Wop[4];
+#pragma unroll
+      for (int u = 0; u < t; ++u)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          const int k = 16 * u + 4 * s_ + lk;
+          const double x = L11s[i + 65 * k];
+          Lop[u][s_] = i < n ? x : 0.0;   // (k < 16 t <= n - 1)
+        }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) Wop[s_] = -Ws[t * 256 + lr * 16 + 4 * s_ + lk];
+#pragma unroll
+      for (int u = 0; u < t; ++u)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) X[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lop[u][s_], X[u][s_], X[t], 0, 0, 0);
+      mfma_d4 y0 = mfma_d4{0.0, 0.0, 0.0, 0.0}, y1 = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wop[0], X[t][0], y0, 0, 0, 0);
+      y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wop[1], X[t][1], y1, 0, 0, 0);
+      y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wop[2], X[t][2], y0, 0, 0, 0);
+      y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wop[3], X[t][3], y1, 0, 0, 0);
+      X[t] = y0 + y1;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int k = 16 * t + 4 * v + lk;
+        if (row < mt && k < n) Lg[(size_t)(n + row) + (size_t)m * k] = X[t][v];
+      }
+    }
+  }
+}
+
 // Pivot blocks and panel tiles of the scratch-slab fronts of a level in ONE launch: workgroups [0, ndiag) factorise the pivot
 // blocks and raise their front's flag, the others are the tiles of big_panel_kernel and wait for it -- their start-up (tile
 // and front records, panel rows, children's vectors: three to four dependent round trips) runs next to the pivot block
@@ -4479,6 +4633,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   bool mfma_diag;    // big_diag_mfma_kernel instead of big_diag_kernel
   int merge_tiles = 256;   // the fused panel kernel on levels of at most this many tiles (CholOptions::big_merge_tiles)
   bool gather = false;     // the merged level launch gathers the children's update matrices itself: no extend-add passes (LevelLaunch::gather)
+  bool panel_solve = false;   // pivot blocks + panel rows of the level in one launch (big_panel_solve_kernel): LevelLaunch::tr_all and not a merged / fused level
 };
 
 __global__ void __launch_bounds__(256) fill_zero_kernel(double* __restrict__ p, size_t n) {
@@ -4569,31 +4724,41 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
       G2OHIP_LAUNCH_CHECK("big_level_kernel");
       return;
     }
-    if (big.mfma_diag && big.fwd)
-      hipLaunchKernelGGL((big_diag_mfma_kernel<BS, true>), dim3(glb_count), dim3(256), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld, bperm, yout);
-    else if (big.mfma_diag)
-      hipLaunchKernelGGL((big_diag_mfma_kernel<BS, false>), dim3(glb_count), dim3(256), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld,
-                         (const double*)nullptr, (double*)nullptr);
-    else
-      hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
-    G2OHIP_LAUNCH_CHECK("big_diag_kernel");
-    if (big.fuse_panel && bt_count <= big.merge_tiles) {   // panel solve + update in one launch -- while the level is a latency chain (at most one
-                                               // workgroup per CU); a level that fills the GPU pays for the rows solved more than once
-      if (bt_count > 0) {
-        const size_t shp = (size_t)(3 * 64 * 65 + 64 + 128) * sizeof(double);
-        if (big.fwd)
-          hipLaunchKernelGGL((big_panel_kernel<BS, true>), dim3(bt_count), dim3(256), shp, st, P, big_tiles, d_scratch, d_scratch_off, big.ld, bperm, yout);
-        else
-          hipLaunchKernelGGL((big_panel_kernel<BS, false>), dim3(bt_count), dim3(256), shp, st, P, big_tiles, d_scratch, d_scratch_off, big.ld,
-                             (const double*)nullptr, (double*)nullptr);
-        G2OHIP_LAUNCH_CHECK("big_panel_kernel");
-      }
-      return;
-    }
-    if (big.tr_count > 0)
-      hipLaunchKernelGGL((big_trsm_kernel<BS>), dim3(big.tr_count), dim3(256), 0, st, P, big.chunks + big.tr_begin, d_scratch,
+    // (at most kPanelSolveWgs workgroups: each repeats the pivot block on one wave and holds a CU's registers meanwhile -- a level of many
+    // fronts is faster with the two separate launches; profiles/r6_grid_sweep.txt)
+    constexpr int ps_max = kPanelSolveWgs;
+    if (big.mfma_diag && !big.fwd && big.panel_solve && big.tr_count > 0 && 4 * big.tr_count <= ps_max && !(big.fuse_panel && bt_count <= big.merge_tiles)) {
+      // pivot blocks + panel rows in one launch (every front of the level has boundary rows: BigLaunch::panel_solve)
+      hipLaunchKernelGGL((big_panel_solve_kernel<BS>), dim3(4 * big.tr_count), dim3(256), 0, st, P, big.chunks + big.tr_begin, d_scratch,
                          d_scratch_off, big.ld);
-    G2OHIP_LAUNCH_CHECK("big_trsm_kernel");
+      G2OHIP_LAUNCH_CHECK("big_panel_solve_kernel");
+    } else {
+      if (big.mfma_diag && big.fwd)
+        hipLaunchKernelGGL((big_diag_mfma_kernel<BS, true>), dim3(glb_count), dim3(256), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld, bperm, yout);
+      else if (big.mfma_diag)
+        hipLaunchKernelGGL((big_diag_mfma_kernel<BS, false>), dim3(glb_count), dim3(256), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld,
+                           (const double*)nullptr, (double*)nullptr);
+      else
+        hipLaunchKernelGGL((big_diag_kernel<BS>), dim3(glb_count), dim3(64), 0, st, P, glb_begin, d_scratch, d_scratch_off, big.ld);
+      G2OHIP_LAUNCH_CHECK("big_diag_kernel");
+      if (big.fuse_panel && bt_count <= big.merge_tiles) {   // panel solve + update in one launch -- while the level is a latency chain (at most one
+                                                 // workgroup per CU); a level that fills the GPU pays for the rows solved more than once
+        if (bt_count > 0) {
+          const size_t shp = (size_t)(3 * 64 * 65 + 64 + 128) * sizeof(double);
+          if (big.fwd)
+            hipLaunchKernelGGL((big_panel_kernel<BS, true>), dim3(bt_count), dim3(256), shp, st, P, big_tiles, d_scratch, d_scratch_off, big.ld, bperm, yout);
+          else
+            hipLaunchKernelGGL((big_panel_kernel<BS, false>), dim3(bt_count), dim3(256), shp, st, P, big_tiles, d_scratch, d_scratch_off, big.ld,
+                               (const double*)nullptr, (double*)nullptr);
+          G2OHIP_LAUNCH_CHECK("big_panel_kernel");
+        }
+        return;
+      }
+      if (big.tr_count > 0)
+        hipLaunchKernelGGL((big_trsm_kernel<BS>), dim3(big.tr_count), dim3(256), 0, st, P, big.chunks + big.tr_begin, d_scratch,
+                           d_scratch_off, big.ld);
+      G2OHIP_LAUNCH_CHECK("big_trsm_kernel");
+    }
     if (bt_count > 0)
       hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off, big.ld);
     G2OHIP_LAUNCH_CHECK("big_front_update_kernel");
@@ -4691,7 +4856,8 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   fplan.slots = d_fslots.p;
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
                       LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL),
-                      (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, merge_tiles_of(LL), LL.gather && opt.big_gather != 0};
+                      (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, merge_tiles_of(LL), LL.gather && opt.big_gather != 0,
+                      LL.tr_all};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
