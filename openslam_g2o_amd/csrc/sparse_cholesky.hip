@@ -1074,8 +1074,15 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
           if (inpl_prev[f] >= 0) continue;
-          const long long mm = (long long)front_dim(f) * (long long)front_dim(f);
-          for (long long c0 = 0; c0 < mm; c0 += kFillChunk) bt.push_back(make_int4(q, (int)(c0 / kFillChunk), (int)std::min<long long>(kFillChunk, mm - c0), 0));
+          // (the lower block triangle only -- nothing uses what lies above a diagonal block: a chunk = a few columns from the first row of
+          // their diagonal block down, ~kFillChunk doubles; the full squares were 5.4 GB = 1 ms per iteration of the 10 000-camera grid graph)
+          const int m = (int)front_dim(f);
+          for (int c0 = 0; c0 < m;) {
+            const int row0 = (c0 / bs) * bs, h = m - row0;
+            const int nc = std::max(1, std::min(m - c0, kFillChunk / h));
+            bt.push_back(make_int4(q, c0, nc, row0));
+            c0 += nc;
+          }
         }
         LL.fz_count = (int)bt.size() - LL.fz_begin;
         // assembly chunks (32 original blocks each)
@@ -2852,13 +2859,19 @@ __global__ void __launch_bounds__(256) big_assemble_kernel(CholPlanDev P, const 
   }
 }
 
-// zero the regions of the fronts that start one at this level (x: launch slot, y: chunk of kFillChunk doubles, z: doubles)
+// zero the lower block triangle of the fronts that start a region at this level (x: launch slot, y: first column, z: columns, w: first row --
+// the first row of the diagonal block of column y; a region's leading dimension is its front's size)
 __global__ void __launch_bounds__(256) big_fill_kernel(const int4* __restrict__ chunks, double* __restrict__ scratch,
-                                                      const long long* __restrict__ scratch_off) {
+                                                      const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
   const int4 ck = chunks[blockIdx.x];
-  double* p = scratch + scratch_off[ck.x] + (size_t)ck.y * kFillChunk;
+  const int m = scratch_ld[ck.x], h = m - ck.w;
+  double* p = scratch + scratch_off[ck.x] + (size_t)ck.y * m + ck.w;
+  const int rx = threadIdx.x & 63;   // a wave per column, its lanes down the rows
+  for (int c = threadIdx.x >> 6; c < ck.z; c += 4) {
+    double* pc = p + (size_t)c * m;
 #pragma unroll 4
-  for (int i = threadIdx.x; i < ck.z; i += 256) p[i] = 0.0;
+    for (int r = rx; r < h; r += 64) pc[r] = 0.0;
+  }
 }
 
 template <int BS>
@@ -4694,7 +4707,7 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
   if (!(parts & 2)) return;
   if (glb_count > 0 && big.ok) {   // large fronts as whole-GPU passes
     if (big.fz_count > 0 && !big.hoisted) {   // zero the regions that start at this level (a kernel: hipMemsetAsync reaches ~1 TB/s only)
-      hipLaunchKernelGGL(big_fill_kernel, dim3(big.fz_count), dim3(256), 0, st, big.chunks + big.fz_begin, d_scratch, d_scratch_off);
+      hipLaunchKernelGGL(big_fill_kernel, dim3(big.fz_count), dim3(256), 0, st, big.chunks + big.fz_begin, d_scratch, d_scratch_off, big.ld);
       G2OHIP_LAUNCH_CHECK("big_fill_kernel");
     }
     if (big.ba_count > 0 && !big.hoisted)
@@ -4978,7 +4991,7 @@ void SparseCholesky::factor_phase(const double* dA, int phase, hipStream_t st, b
     const bool virt = dA == nullptr;
     if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
     if (hz_count_[phase] > 0)
-      hipLaunchKernelGGL(big_fill_kernel, dim3(hz_count_[phase]), dim3(256), 0, st, d_big_tiles.p + hz_begin_[phase], d_scratch.p, d_scratch_off.p);
+      hipLaunchKernelGGL(big_fill_kernel, dim3(hz_count_[phase]), dim3(256), 0, st, d_big_tiles.p + hz_begin_[phase], d_scratch.p, d_scratch_off.p, d_scratch_ld.p);
     G2OHIP_LAUNCH_CHECK("big_fill_kernel");
     if (ha_count_[phase] > 0) {
       const int4* ch = d_big_tiles.p + ha_begin_[phase];
