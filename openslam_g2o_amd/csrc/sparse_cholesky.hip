@@ -1100,11 +1100,17 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         if (max_children > 16) LL.big_ok = false;   // (one launch per child ordinal)
         // inverse block maps for the gather at load time (big_level_kernel): front block -> child's boundary block
         LL.gather = LL.big_ok && max_children <= kGatherChildren;
-        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count && LL.gather; ++q) {
+        // ... and for the extend-add of a level in ONE launch (big_extend_gather_kernel: a workgroup owns blocks of the parent and adds
+        // its children's entries in child order -- one read-modify-write of the frontal matrix instead of one per child ordinal); the
+        // header has room for seven children
+        LL.eg_ok = LL.big_ok && max_children >= 2 && max_children <= 7;
+        LL.eg_begin = (int)bt.size();
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count && (LL.gather || LL.eg_ok); ++q) {
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
           const int nch = S.child_off[f + 1] - S.child_off[f], mb = S.f_ns[f] + S.f_nb[f];
           if (nch == 0 || inpl_prev[f] >= 0) continue;
-          if (kGatherHeader + nch * mb > kGatherInts) LL.gather = false;   // (the table of a front is staged in LDS)
+          if (kGatherHeader + nch * mb > kGatherInts) LL.gather = false;   // (the merged level launch stages the table of a front in LDS)
+          if (!LL.gather && !LL.eg_ok) break;
           // table: [0] children, [1 + 2 c], [2 + 2 c] offset of child c's update matrix (low, high word), [kGatherHeader + c mb + b] the maps
           const size_t t0 = cinv.size();
           cinv.resize(t0 + kGatherHeader + (size_t)nch * mb, -1);
@@ -1117,7 +1123,12 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
             for (int k = 0; k < S.f_nb[c]; ++k) cinv[t0 + kGatherHeader + (size_t)k0 * mb + rl[k]] = k;
           }
           cinv_slot[q] = make_int2((int)t0, kGatherHeader + nch * mb);
+          if (LL.eg_ok) {   // chunks of 64 lower blocks of the parent (row-major enumeration of its block triangle)
+            const long long nblk = (long long)mb * (mb + 1) / 2;
+            for (long long b = 0; b < nblk; b += 64) bt.push_back(make_int4(q, (int)b, (int)std::min<long long>(64, nblk - b), 0));
+          }
         }
+        LL.eg_count = LL.eg_ok ? (int)bt.size() - LL.eg_begin : 0;
         // extend-add passes: pass c handles child c of every front (the children of one front may hit the same blocks)
         LL.be_pass.clear();
         for (int c = 0; c < max_children && LL.big_ok; ++c) {
@@ -2906,6 +2917,74 @@ __global__ void __launch_bounds__(256) big_extend_add_kernel(CholPlanDev P, cons
   }
 }
 
+// The extend-add of a level in ONE launch: a workgroup owns 64 lower blocks of a parent front and adds the entries its children have
+// there, child by child in child order (the sums of the passes above, bit for bit) -- the frontal matrix is read and written once
+// instead of once per child ordinal, and a level with two or three children per front is one launch instead of two or three.
+// chunks: x launch slot, y first block (row-major enumeration of the block triangle), z blocks.  Maps: CholPlanDev::cinv.
+template <int BS>
+__global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, const int4* __restrict__ chunks, double* __restrict__ scratch,
+                                                               const long long* __restrict__ scratch_off) {
+  constexpr int BB = BS * BS, MAXC = 7;
+  __shared__ long long soff[MAXC][64];   // per child and block of the chunk: offset of the child's block in P.U, or -1
+  __shared__ int sdst[64];               // (ib | jb << 16) of the block
+  const int4 ck = chunks[blockIdx.x];
+  const int f = P.slots[ck.x].x;
+  const int2 cs = P.cinv_slot[ck.x];
+  const int* tab = P.cinv + cs.x;
+  const FrontRec rec = load_front_rec(P.rec + f);
+  const int mb = rec.ns + rec.nb, m = mb * BS;
+  double* F = scratch + scratch_off[ck.x];
+  const int nch = min(tab[0], MAXC);
+  if (threadIdx.x < 64) {
+    const int blk = ck.y + min((int)threadIdx.x, ck.z - 1);
+    // block (ib, jb), ib >= jb, of index ib (ib + 1) / 2 + jb
+    int ib = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
+    while ((long long)(ib + 1) * (ib + 2) / 2 <= blk) ++ib;
+    while ((long long)ib * (ib + 1) / 2 > blk) --ib;
+    const int jb = blk - (int)((long long)ib * (ib + 1) / 2);
+    sdst[threadIdx.x] = ib | (jb << 16);
+    for (int ch = 0; ch < nch; ++ch) {
+      const int ci = tab[kGatherHeader + ch * mb + ib], cj = tab[kGatherHeader + ch * mb + jb];
+      const long long base = ((long long)tab[2 + 2 * ch] << 32) | (long long)(unsigned int)tab[1 + 2 * ch];
+      soff[ch][threadIdx.x] = (ci | cj) >= 0 ? base + (long long)(ci * (ci + 1) / 2 + cj) * BB : -1LL;
+    }
+  }
+  __syncthreads();
+  const int n = ck.z * BB;
+  for (int base = threadIdx.x; base < n; base += 3 * 256) {   // three elements per thread in flight
+    double v[3], u[3][MAXC];
+    size_t dst[3];
+    bool any[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int t = min(base + q * 256, n - 1);
+      const int blk = t / BB, e = t % BB;
+      const int d = sdst[blk];
+      dst[q] = (size_t)((d & 0xffff) * BS + e % BS) + (size_t)m * ((d >> 16) * BS + e / BS);
+      any[q] = false;
+#pragma unroll
+      for (int ch = 0; ch < MAXC; ++ch) {
+        const long long o = ch < nch ? soff[ch][blk] : -1LL;
+        u[q][ch] = o >= 0 ? P.U[o + e] : 0.0;
+        any[q] = any[q] || o >= 0;
+      }
+      v[q] = F[dst[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (base + q * 256 < n && any[q]) {
+        double x = v[q];
+#pragma unroll
+        for (int ch = 0; ch < MAXC; ++ch) {
+          const long long o = ch < nch ? soff[ch][min(base + q * 256, n - 1) / BB] : -1LL;
+          if (o >= 0) x += u[q][ch];   // (child order; a child without an entry here adds nothing -- not even + 0.0)
+        }
+        F[dst[q]] = x;
+      }
+    }
+  }
+}
+
 // pivot block (npiv <= 64): right-looking Cholesky, one wave per front, lane i owns row i IN REGISTERS; column j of L
 // reaches the other lanes through v_readlane (the loops are fully unrolled: lane and register indices are
 // compile-time constants) -- no LDS, no barriers, ~n^2/2 FMAs with scalar operands
@@ -4646,6 +4725,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   bool mfma_diag;    // big_diag_mfma_kernel instead of big_diag_kernel
   int merge_tiles = 256;   // the fused panel kernel on levels of at most this many tiles (CholOptions::big_merge_tiles)
   bool gather = false;     // the merged level launch gathers the children's update matrices itself: no extend-add passes (LevelLaunch::gather)
+  int eg_begin = 0, eg_count = 0;   // the level's extend-add in one launch (big_extend_gather_kernel); 0: the passes per child ordinal
   bool panel_solve = false;   // pivot blocks + panel rows of the level in one launch (big_panel_solve_kernel): LevelLaunch::tr_all and not a merged / fused level
 };
 
@@ -4718,7 +4798,10 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     bool any_pass = false;
     for (const auto& pass : *big.be_pass) any_pass = any_pass || pass.second > 0;
     const bool gather = level_launch && big.gather && any_pass;   // (the level's launch adds the children's update matrices where it loads the fronts)
-    if (!gather)
+    if (!gather && big.eg_count > 0) {   // every child ordinal in one launch
+      hipLaunchKernelGGL((big_extend_gather_kernel<BS>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+      G2OHIP_LAUNCH_CHECK("big_extend_gather_kernel");
+    } else if (!gather)
       for (const auto& pass : *big.be_pass)
         if (pass.second > 0)
           hipLaunchKernelGGL((big_extend_add_kernel<BS>), dim3(pass.second), dim3(256), 0, st, P, big.chunks + pass.first, d_scratch,
@@ -4870,7 +4953,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
                       LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL),
                       (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, merge_tiles_of(LL), LL.gather && opt.big_gather != 0,
-                      LL.tr_all};
+                      LL.eg_begin, LL.eg_count, LL.tr_all};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
