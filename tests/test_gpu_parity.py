@@ -710,6 +710,15 @@ def test_scratch_slab_sweep_variants(bs):
             ok, x2 = ls.solve(cp, row, vals, b)
             assert ok and np.array_equal(x, x2), name + ": not repeatable"
         xs[name] = x
+        if name == "default":
+            # (fronts of 1 000 rows and more: panels of 64 scalars, pivot block + panel rows in one launch with the rows on the matrix cores --
+            # big_panel_solve_kernel --, the level's extend-add in one launch) a matrix that is not positive definite is reported from
+            # there too, and the handle solves the good one again afterwards, to the same bits
+            assert ls.stats()["maxFrontDim"] >= 1024
+            bad, _ = ls.solve(cp, row, -vals, b)
+            assert not bad
+            ok, x3 = ls.solve(cp, row, vals, b)
+            assert ok and np.array_equal(x, x3)
     assert relerr(xs["one launch per level"], xs["default"]) < 1e-12
 
 
