@@ -3150,7 +3150,7 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
   // step per round trip would make the kernel a chain of L2 latencies).  kprev > 0 (the last panel of a grouped in-place chain): the
   // group's earlier panels first -- their solved rows for these rows sit in THEIR L panels (CholPlanDev::gtab) --, then this front's:
   // one rank-(kprev + npiv) update.
-  constexpr int KS = 6;
+  constexpr int KS = 15;   // (a panel of 60 columns in ONE round trip: 93.1 -> 90.9 ms on the 49 729-camera grid graph against 6; 16 loses it again)
   const int rr[2] = {min(r0 + lr, mt - 1), min(r0 + 16 + lr, mt - 1)}, cc[2] = {min(c0 + lr, mt - 1), min(c0 + 16 + lr, mt - 1)};
   auto rank_update = [&](const double* __restrict__ Lp, long long mm, int nn) {   // Lp: row 0 of the trailing part, column 0 of the panel
     for (int k00 = 0; k00 < nn; k00 += 4 * KS) {
