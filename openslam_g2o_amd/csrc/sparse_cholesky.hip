@@ -1069,11 +1069,39 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
             for (int tj = 0; tj <= std::min(ti, ntc - 1); ++tj) bt.push_back(make_int4(q, ti, tj, w));
         }
         LL.bt_count = (int)bt.size() - LL.bt_begin;
+      }
+    // --- fronts whose region is WRITTEN by the extend-add (big_extend_gather_kernel<.., true>: the children's entries or zero for every
+    // lower block) instead of zero-filled, read and written: the heads of levels that run the one-launch extend-add as a whole-GPU
+    // pass of its own.  Their original blocks -- and those of the fronts that continue in place behind them -- are added behind that
+    // launch (LevelLaunch::la_*) instead of with everybody else's at the start of the phase.
+    std::vector<char> write_head(nf, 0), late(nf, 0);
+    std::vector<int> slot_of_f(nf, -1);
+    for (int ph = 0; ph < 2; ++ph)
+      for (LevelLaunch& LL : launches_[ph]) {
+        int max_children = 0;
+        bool ok = LL.glb_count > 0 && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim && opt.world == 1;
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          slot_of_f[f] = q;
+          if (S.f_ns[f] * bs > 64) ok = false;
+          max_children = std::max(max_children, S.child_off[f + 1] - S.child_off[f]);
+        }
+        LL.eg_write = ok && max_children >= 2 && max_children <= 7 && LL.bt_count > merge_tiles_of(LL);
+        if (!LL.eg_write) continue;
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          if (S.child_off[f + 1] == S.child_off[f] || inpl_prev[f] >= 0) continue;
+          write_head[f] = 1;
+          for (int g = f; g >= 0; g = inpl_next[g]) late[g] = 1;
+        }
+      }
+    for (int ph = 0; ph < 2; ++ph)
+      for (LevelLaunch& LL : launches_[ph]) {
         // zero-fill chunks of the fronts that start a region at this level
         LL.fz_begin = (int)bt.size();
         for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
-          if (inpl_prev[f] >= 0) continue;
+          if (inpl_prev[f] >= 0 || write_head[f]) continue;
           // (the lower block triangle only -- nothing uses what lies above a diagonal block: a chunk = a few columns from the first row of
           // their diagonal block down, ~kFillChunk doubles; the full squares were 5.4 GB = 1 ms per iteration of the 10 000-camera grid graph)
           const int m = (int)front_dim(f);
@@ -1093,7 +1121,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
           if (S.f_ns[f] * bs > 64) LL.big_ok = false;
           const int na = S.asm_off[f + 1] - S.asm_off[f];
-          for (int e = 0; e < na; e += 32) bt.push_back(make_int4(q, e, std::min(32, na - e), inpl_prev[f] >= 0 ? 1 : 0));   // w: add to what is there
+          for (int e = 0; e < na && !late[f]; e += 32) bt.push_back(make_int4(q, e, std::min(32, na - e), inpl_prev[f] >= 0 ? 1 : 0));   // w: add to what is there
           max_children = std::max(max_children, S.child_off[f + 1] - S.child_off[f]);
         }
         LL.ba_count = (int)bt.size() - LL.ba_begin;
@@ -1129,6 +1157,18 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           }
         }
         LL.eg_count = LL.eg_ok ? (int)bt.size() - LL.eg_begin : 0;
+        // original blocks added behind the writing extend-add: the heads of this level and the fronts continued in place behind them
+        LL.la_begin = (int)bt.size();
+        for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count && LL.eg_write; ++q) {
+          const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
+          if (!write_head[f]) continue;
+          for (int g = f; g >= 0; g = inpl_next[g]) {
+            const int na = S.asm_off[g + 1] - S.asm_off[g];
+            for (int e = 0; e < na; e += 32) bt.push_back(make_int4(slot_of_f[g], e, std::min(32, na - e), 1));
+          }
+        }
+        LL.la_count = (int)bt.size() - LL.la_begin;
+        if (LL.eg_write && (!LL.eg_ok || LL.eg_count == 0)) throw StateFailure("symbolic: a level marked for the writing extend-add has no gather tables");
         // extend-add passes: pass c handles child c of every front (the children of one front may hit the same blocks)
         LL.be_pass.clear();
         for (int c = 0; c < max_children && LL.big_ok; ++c) {
@@ -2921,7 +2961,9 @@ __global__ void __launch_bounds__(256) big_extend_add_kernel(CholPlanDev P, cons
 // there, child by child in child order (the sums of the passes above, bit for bit) -- the frontal matrix is read and written once
 // instead of once per child ordinal, and a level with two or three children per front is one launch instead of two or three.
 // chunks: x launch slot, y first block (row-major enumeration of the block triangle), z blocks.  Maps: CholPlanDev::cinv.
-template <int BS>
+// WRITE: the region has NOT been zero-filled -- every lower block of the parent is written, the sum of the children's entries or zero
+// (fronts without a map table, i.e. without children, are not in the chunk list: their regions were filled); the original blocks follow.
+template <int BS, bool WRITE>
 __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, const int4* __restrict__ chunks, double* __restrict__ scratch,
                                                                const long long* __restrict__ scratch_off) {
   constexpr int BB = BS * BS, MAXC = 7;
@@ -2968,11 +3010,11 @@ __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, c
         u[q][ch] = o >= 0 ? P.U[o + e] : 0.0;
         any[q] = any[q] || o >= 0;
       }
-      v[q] = F[dst[q]];
+      v[q] = WRITE ? 0.0 : F[dst[q]];
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      if (base + q * 256 < n && any[q]) {
+      if (base + q * 256 < n && (WRITE || any[q])) {
         double x = v[q];
 #pragma unroll
         for (int ch = 0; ch < MAXC; ++ch) {
@@ -4738,6 +4780,8 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   int merge_tiles = 256;   // the fused panel kernel on levels of at most this many tiles (CholOptions::big_merge_tiles)
   bool gather = false;     // the merged level launch gathers the children's update matrices itself: no extend-add passes (LevelLaunch::gather)
   int eg_begin = 0, eg_count = 0;   // the level's extend-add in one launch (big_extend_gather_kernel); 0: the passes per child ordinal
+  bool eg_write = false;            // ... into regions that were not zero-filled (LevelLaunch::eg_write), the original blocks la_* behind it
+  int la_begin = 0, la_count = 0;
   bool panel_solve = false;   // pivot blocks + panel rows of the level in one launch (big_panel_solve_kernel): LevelLaunch::tr_all and not a merged / fused level
 };
 
@@ -4810,8 +4854,15 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     bool any_pass = false;
     for (const auto& pass : *big.be_pass) any_pass = any_pass || pass.second > 0;
     const bool gather = level_launch && big.gather && any_pass;   // (the level's launch adds the children's update matrices where it loads the fronts)
-    if (!gather && big.eg_count > 0) {   // every child ordinal in one launch
-      hipLaunchKernelGGL((big_extend_gather_kernel<BS>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+    if (big.eg_write) {   // every child ordinal in one launch, into regions that were not zero-filled; then the original blocks
+      hipLaunchKernelGGL((big_extend_gather_kernel<BS, true>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+      G2OHIP_LAUNCH_CHECK("big_extend_gather_kernel");
+      if (big.la_count > 0)
+        hipLaunchKernelGGL((big_assemble_kernel<BS, VIRT>), dim3(big.la_count), dim3(256), 0, st, P, big.chunks + big.la_begin, dA, d_scratch,
+                           d_scratch_off, big.ld);
+      G2OHIP_LAUNCH_CHECK("big_assemble_kernel");
+    } else if (!gather && big.eg_count > 0) {   // every child ordinal in one launch
+      hipLaunchKernelGGL((big_extend_gather_kernel<BS, false>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
       G2OHIP_LAUNCH_CHECK("big_extend_gather_kernel");
     } else if (!gather)
       for (const auto& pass : *big.be_pass)
@@ -4965,7 +5016,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
                       LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL),
                       (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, merge_tiles_of(LL), LL.gather && opt.big_gather != 0,
-                      LL.eg_begin, LL.eg_count, LL.tr_all};
+                      LL.eg_begin, LL.eg_count, LL.eg_write, LL.la_begin, LL.la_count, LL.tr_all};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
