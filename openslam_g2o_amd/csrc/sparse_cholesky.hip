@@ -1086,14 +1086,17 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           if (S.f_ns[f] * bs > 64) ok = false;
           max_children = std::max(max_children, S.child_off[f + 1] - S.child_off[f]);
         }
-        LL.eg_write = ok && max_children >= 2 && max_children <= 7 && LL.bt_count > merge_tiles_of(LL);
+        LL.eg_write = ok && max_children >= 1 && max_children <= 7 && LL.bt_count > merge_tiles_of(LL);
         if (!LL.eg_write) continue;
+        int heads = 0;
         for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count; ++q) {
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
           if (S.child_off[f + 1] == S.child_off[f] || inpl_prev[f] >= 0) continue;
           write_head[f] = 1;
+          ++heads;
           for (int g = f; g >= 0; g = inpl_next[g]) late[g] = 1;
         }
+        if (heads == 0) LL.eg_write = false;   // (a level of fronts continued in place: nothing to extend-add)
       }
     for (int ph = 0; ph < 2; ++ph)
       for (LevelLaunch& LL : launches_[ph]) {
@@ -1131,7 +1134,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
         // ... and for the extend-add of a level in ONE launch (big_extend_gather_kernel: a workgroup owns blocks of the parent and adds
         // its children's entries in child order -- one read-modify-write of the frontal matrix instead of one per child ordinal); the
         // header has room for seven children
-        LL.eg_ok = LL.big_ok && max_children >= 2 && max_children <= 7;
+        LL.eg_ok = LL.big_ok && (max_children >= 2 || LL.eg_write) && max_children <= 7;   // (one child per front: a pass per ordinal is one launch too -- unless it writes)
         LL.eg_begin = (int)bt.size();
         for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count && (LL.gather || LL.eg_ok); ++q) {
           const int f = S.task_fronts[S.task_ptr[S.level_fronts[q]]];
