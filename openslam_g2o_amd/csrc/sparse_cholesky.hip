@@ -1154,10 +1154,9 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
             for (int k = 0; k < S.f_nb[c]; ++k) cinv[t0 + kGatherHeader + (size_t)k0 * mb + rl[k]] = k;
           }
           cinv_slot[q] = make_int2((int)t0, kGatherHeader + nch * mb);
-          if (LL.eg_ok) {   // chunks of 64 lower blocks of the parent (row-major enumeration of its block triangle)
-            const long long nblk = (long long)mb * (mb + 1) / 2;
-            for (long long b = 0; b < nblk; b += 64) bt.push_back(make_int4(q, (int)b, (int)std::min<long long>(64, nblk - b), 0));
-          }
+          if (LL.eg_ok)   // chunks of up to 64 lower blocks of ONE block column of the parent (consecutive rows: the stores of a chunk are contiguous per column)
+            for (int jb = 0; jb < mb; ++jb)
+              for (int ib = jb; ib < mb; ib += 64) bt.push_back(make_int4(q, jb, ib, std::min(64, mb - ib)));
         }
         LL.eg_count = LL.eg_ok ? (int)bt.size() - LL.eg_begin : 0;
         // original blocks added behind the writing extend-add: the heads of this level and the fronts continued in place behind them
@@ -2963,7 +2962,7 @@ __global__ void __launch_bounds__(256) big_extend_add_kernel(CholPlanDev P, cons
 // The extend-add of a level in ONE launch: a workgroup owns 64 lower blocks of a parent front and adds the entries its children have
 // there, child by child in child order (the sums of the passes above, bit for bit) -- the frontal matrix is read and written once
 // instead of once per child ordinal, and a level with two or three children per front is one launch instead of two or three.
-// chunks: x launch slot, y first block (row-major enumeration of the block triangle), z blocks.  Maps: CholPlanDev::cinv.
+// chunks: up to 64 consecutive block rows of one block column (the stores of a chunk are contiguous column by column).  Maps: CholPlanDev::cinv.
 // WRITE: the region has NOT been zero-filled -- every lower block of the parent is written, the sum of the children's entries or zero
 // (fronts without a map table, i.e. without children, are not in the chunk list: their regions were filled); the original blocks follow.
 template <int BS, bool WRITE>
@@ -2971,8 +2970,7 @@ __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, c
                                                                const long long* __restrict__ scratch_off) {
   constexpr int BB = BS * BS, MAXC = 7;
   __shared__ long long soff[MAXC][64];   // per child and block of the chunk: offset of the child's block in P.U, or -1
-  __shared__ int sdst[64];               // (ib | jb << 16) of the block
-  const int4 ck = chunks[blockIdx.x];
+  const int4 ck = chunks[blockIdx.x];   // x: launch slot, y: block column, z: first block row, w: block rows (<= 64)
   const int f = P.slots[ck.x].x;
   const int2 cs = P.cinv_slot[ck.x];
   const int* tab = P.cinv + cs.x;
@@ -2980,14 +2978,9 @@ __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, c
   const int mb = rec.ns + rec.nb, m = mb * BS;
   double* F = scratch + scratch_off[ck.x];
   const int nch = min(tab[0], MAXC);
+  const int jb = ck.y, cnt = ck.w;
   if (threadIdx.x < 64) {
-    const int blk = ck.y + min((int)threadIdx.x, ck.z - 1);
-    // block (ib, jb), ib >= jb, of index ib (ib + 1) / 2 + jb
-    int ib = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
-    while ((long long)(ib + 1) * (ib + 2) / 2 <= blk) ++ib;
-    while ((long long)ib * (ib + 1) / 2 > blk) --ib;
-    const int jb = blk - (int)((long long)ib * (ib + 1) / 2);
-    sdst[threadIdx.x] = ib | (jb << 16);
+    const int ib = ck.z + min((int)threadIdx.x, cnt - 1);
     for (int ch = 0; ch < nch; ++ch) {
       const int ci = tab[kGatherHeader + ch * mb + ib], cj = tab[kGatherHeader + ch * mb + jb];
       const long long base = ((long long)tab[2 + 2 * ch] << 32) | (long long)(unsigned int)tab[1 + 2 * ch];
@@ -2995,17 +2988,21 @@ __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, c
     }
   }
   __syncthreads();
-  const int n = ck.z * BB;
+  // element t: column c of the block column, then block row, then row inside the block -- consecutive threads, consecutive addresses of F
+  const int rows = cnt * BS, n = rows * BS;
+  double* Fc = F + (size_t)ck.z * BS + (size_t)m * (jb * BS);
   for (int base = threadIdx.x; base < n; base += 3 * 256) {   // three elements per thread in flight
     double v[3], u[3][MAXC];
     size_t dst[3];
+    int bl[3];
     bool any[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int t = min(base + q * 256, n - 1);
-      const int blk = t / BB, e = t % BB;
-      const int d = sdst[blk];
-      dst[q] = (size_t)((d & 0xffff) * BS + e % BS) + (size_t)m * ((d >> 16) * BS + e / BS);
+      const int c = t / rows, rr = t - c * rows;
+      const int blk = rr / BS, e = (rr - blk * BS) + BS * c;
+      bl[q] = blk;
+      dst[q] = (size_t)rr + (size_t)m * c;
       any[q] = false;
 #pragma unroll
       for (int ch = 0; ch < MAXC; ++ch) {
@@ -3013,7 +3010,7 @@ __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, c
         u[q][ch] = o >= 0 ? P.U[o + e] : 0.0;
         any[q] = any[q] || o >= 0;
       }
-      v[q] = WRITE ? 0.0 : F[dst[q]];
+      v[q] = WRITE ? 0.0 : Fc[dst[q]];
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -3021,10 +3018,10 @@ __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, c
         double x = v[q];
 #pragma unroll
         for (int ch = 0; ch < MAXC; ++ch) {
-          const long long o = ch < nch ? soff[ch][min(base + q * 256, n - 1) / BB] : -1LL;
+          const long long o = ch < nch ? soff[ch][bl[q]] : -1LL;
           if (o >= 0) x += u[q][ch];   // (child order; a child without an entry here adds nothing -- not even + 0.0)
         }
-        F[dst[q]] = x;
+        Fc[dst[q]] = x;
       }
     }
   }
