@@ -3164,7 +3164,7 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(CholPlanDev P, const int4
 // (L2-resident, 128-byte coalesced: 16 consecutive rows per k).  Layout of the instruction (probed on gfx950,
 // tools/probe/mfma_f64_layout.hip): A[i][k] from lane i + 16k, B[j][k] from lane j + 16k, D[lane/16 + 4v][lane%16]
 // in register v.  The ROW of the trailing matrix rides on j (lanes 0..15: consecutive addresses), the column on i.
-template <int BS>
+template <int BS, int KS = 15>
 __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, const int4* __restrict__ tiles,
                                                               double* __restrict__ scratch,
                                                               const long long* __restrict__ scratch_off, const int* __restrict__ scratch_ld) {
@@ -3205,7 +3205,7 @@ __global__ void __launch_bounds__(256) big_front_update_kernel(CholPlanDev P, co
   // step per round trip would make the kernel a chain of L2 latencies).  kprev > 0 (the last panel of a grouped in-place chain): the
   // group's earlier panels first -- their solved rows for these rows sit in THEIR L panels (CholPlanDev::gtab) --, then this front's:
   // one rank-(kprev + npiv) update.
-  constexpr int KS = 15;   // (a panel of 60 columns in ONE round trip: 93.1 -> 90.9 ms on the 49 729-camera grid graph against 6; 16 loses it again)
+  // KS: k-steps requested together (15: a panel of 60 columns in ONE round trip: 93.1 -> 90.9 ms on the 49 729-camera grid graph against 6; 16 loses it again)
   const int rr[2] = {min(r0 + lr, mt - 1), min(r0 + 16 + lr, mt - 1)}, cc[2] = {min(c0 + lr, mt - 1), min(c0 + 16 + lr, mt - 1)};
   auto rank_update = [&](const double* __restrict__ Lp, long long mm, int nn) {   // Lp: row 0 of the trailing part, column 0 of the panel
     for (int k00 = 0; k00 < nn; k00 += 4 * KS) {
@@ -4920,7 +4920,13 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
       G2OHIP_LAUNCH_CHECK("big_trsm_kernel");
     }
     if (bt_count > 0)
-      hipLaunchKernelGGL((big_front_update_kernel<BS>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off, big.ld);
+    {
+      // (a launch that fills the GPU several times over is served better by four waves per SIMD than by one round trip per panel:
+      // 116 against 180 registers; 16.5 -> 16.3 / 80.8 -> 79.4 ms on the grid graphs, profiles/r6_grid_sweep.txt)
+      constexpr int ks_split = 4096;
+      if (bt_count > ks_split) hipLaunchKernelGGL((big_front_update_kernel<BS, 6>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off, big.ld);
+      else hipLaunchKernelGGL((big_front_update_kernel<BS, 15>), dim3(bt_count), dim3(256), 0, st, P, big_tiles, d_scratch, d_scratch_off, big.ld);
+    }
     G2OHIP_LAUNCH_CHECK("big_front_update_kernel");
   } else if (glb_count > 0) {
     const int idx_off = 2 * (BS * BS + BS);
