@@ -2839,10 +2839,16 @@ __global__ void __launch_bounds__(NTC, (USE_LDS && NTC <= 256) ? (NTC == 128 ? G
 
 // ---- Scratch-slab (large) fronts as whole-GPU passes.  One workgroup per front cannot feed a front of several
 // hundred rows (zeroing, extend-add and the trailing update are megabytes each); per level the work is cut into
-//   memset -> big_assemble (original entries) -> big_extend_add (one pass per child ordinal) -> big_diag (the
-//   npiv x npiv pivot block, one wave per front) -> big_trsm (panel rows, one thread per row) -> big_front_update
-// (MFMA rank-npiv update straight into the packed update matrix).  The dense front F (m x m, column-major, lower
-// triangle) lives in the level's scratch slab.
+//   [extend-add] -> pivot block (npiv <= 64 columns, one wave) -> panel rows -> rank-npiv update of the trailing matrix (MFMA)
+// in one of three forms: ONE launch for pivot blocks + panel tiles that solve their rows themselves and gather the children's
+// entries where they load (big_level_kernel; levels of at most 256 tiles: the latency chains of the pose graphs); pivot block + panel
+// rows in one launch (big_panel_solve_kernel, the rows as chained MFMAs) + big_front_update_kernel (levels of one or a few large
+// fronts); big_diag_mfma + big_trsm + big_front_update (levels of many fronts).  The extend-add of the last two: one launch
+// (big_extend_gather_kernel) that WRITES the parent's region -- its children's entries in child order, or zero -- followed by the
+// original blocks of the chain (big_assemble_kernel); regions nobody writes that way are zero-filled (big_fill_kernel) and get
+// their original blocks at the start of the phase.  The dense front F (m x m, column-major, lower block triangle) lives in the
+// scratch slab; a supernode of more than 64 columns is a chain of fronts factorised IN PLACE in the first one's region, its
+// trailing updates grouped (big_group).  profiles/r6_grid_timeline.txt shows the launches of one iteration.
 template <int BS, bool VIRT>
 __global__ void __launch_bounds__(256) big_assemble_kernel(CholPlanDev P, const int4* __restrict__ chunks, const double* __restrict__ A,
                                                           double* __restrict__ scratch, const long long* __restrict__ scratch_off,
