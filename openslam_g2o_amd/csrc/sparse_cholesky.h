@@ -328,6 +328,7 @@ class SparseCholesky {
     bool big_ok = false;
     bool eg_ok = false;                                  // the level's extend-add as one launch (big_extend_gather_kernel: every front has a map table, 2..7 children)
     int eg_begin = 0, eg_count = 0;                      // ... its chunks (d_big_tiles)
+    int eg_maxc = 7;                                     // ... children per front at most
     bool eg_write = false;                               // ... and it WRITES the regions of its fronts (no zero fill for them; their original blocks, and those of the
                                                          // fronts continued in place behind them, are added behind it: la_*)
     int la_begin = 0, la_count = 0;

@@ -1159,6 +1159,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
               for (int ib = jb; ib < mb; ib += 64) bt.push_back(make_int4(q, jb, ib, std::min(64, mb - ib)));
         }
         LL.eg_count = LL.eg_ok ? (int)bt.size() - LL.eg_begin : 0;
+        LL.eg_maxc = max_children;
         // original blocks added behind the writing extend-add: the heads of this level and the fronts continued in place behind them
         LL.la_begin = (int)bt.size();
         for (int q = LL.glb_begin; q < LL.glb_begin + LL.glb_count && LL.eg_write; ++q) {
@@ -2971,10 +2972,11 @@ __global__ void __launch_bounds__(256) big_extend_add_kernel(CholPlanDev P, cons
 // chunks: up to 64 consecutive block rows of one block column (the stores of a chunk are contiguous column by column).  Maps: CholPlanDev::cinv.
 // WRITE: the region has NOT been zero-filled -- every lower block of the parent is written, the sum of the children's entries or zero
 // (fronts without a map table, i.e. without children, are not in the chunk list: their regions were filled); the original blocks follow.
-template <int BS, bool WRITE>
+template <int BS, bool WRITE, int MAXC>
 __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, const int4* __restrict__ chunks, double* __restrict__ scratch,
                                                                const long long* __restrict__ scratch_off) {
-  constexpr int BB = BS * BS, MAXC = 7;
+  // MAXC: children per front of the level at most (2: the binary tree of a nested dissection -- the loops over the children are unrolled)
+  constexpr int BB = BS * BS;
   __shared__ long long soff[MAXC][64];   // per child and block of the chunk: offset of the child's block in P.U, or -1
   const int4 ck = chunks[blockIdx.x];   // x: launch slot, y: block column, z: first block row, w: block rows (<= 64)
   const int f = P.slots[ck.x].x;
@@ -2987,47 +2989,50 @@ __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, c
   const int jb = ck.y, cnt = ck.w;
   if (threadIdx.x < 64) {
     const int ib = ck.z + min((int)threadIdx.x, cnt - 1);
-    for (int ch = 0; ch < nch; ++ch) {
-      const int ci = tab[kGatherHeader + ch * mb + ib], cj = tab[kGatherHeader + ch * mb + jb];
-      const long long base = ((long long)tab[2 + 2 * ch] << 32) | (long long)(unsigned int)tab[1 + 2 * ch];
-      soff[ch][threadIdx.x] = (ci | cj) >= 0 ? base + (long long)(ci * (ci + 1) / 2 + cj) * BB : -1LL;
+#pragma unroll
+    for (int ch = 0; ch < MAXC; ++ch) {
+      long long o = -1LL;
+      if (ch < nch) {
+        const int ci = tab[kGatherHeader + ch * mb + ib], cj = tab[kGatherHeader + ch * mb + jb];
+        const long long base = ((long long)tab[2 + 2 * ch] << 32) | (long long)(unsigned int)tab[1 + 2 * ch];
+        o = (ci | cj) >= 0 ? base + (long long)(ci * (ci + 1) / 2 + cj) * BB : -1LL;
+      }
+      soff[ch][threadIdx.x] = o;
     }
   }
   __syncthreads();
-  // element t: column c of the block column, then block row, then row inside the block -- consecutive threads, consecutive addresses of F
-  const int rows = cnt * BS, n = rows * BS;
+  // scalar column c of the block column, rows down the chunk: consecutive threads, consecutive addresses of F; the elements of one
+  // thread (rows tid, tid + 256 of every column) are requested three at a time
+  const int rows = cnt * BS;
   double* Fc = F + (size_t)ck.z * BS + (size_t)m * (jb * BS);
-  for (int base = threadIdx.x; base < n; base += 3 * 256) {   // three elements per thread in flight
-    double v[3], u[3][MAXC];
-    size_t dst[3];
-    int bl[3];
-    bool any[3];
+  for (int r0 = threadIdx.x; r0 < rows; r0 += 256) {
+    const int blk = r0 / BS, eb = r0 - blk * BS;
+    long long o[MAXC];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int t = min(base + q * 256, n - 1);
-      const int c = t / rows, rr = t - c * rows;
-      const int blk = rr / BS, e = (rr - blk * BS) + BS * c;
-      bl[q] = blk;
-      dst[q] = (size_t)rr + (size_t)m * c;
-      any[q] = false;
+    for (int ch = 0; ch < MAXC; ++ch) o[ch] = soff[ch][blk];
+    constexpr int CU = 3;   // columns in flight
 #pragma unroll
-      for (int ch = 0; ch < MAXC; ++ch) {
-        const long long o = ch < nch ? soff[ch][blk] : -1LL;
-        u[q][ch] = o >= 0 ? P.U[o + e] : 0.0;
-        any[q] = any[q] || o >= 0;
+    for (int c0 = 0; c0 < BS; c0 += CU) {
+      double v[CU], u[CU][MAXC];
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < CU; ++q) {
+        const int c = c0 + q < BS ? c0 + q : BS - 1;
+#pragma unroll
+        for (int ch = 0; ch < MAXC; ++ch) u[q][ch] = o[ch] >= 0 ? P.U[o[ch] + eb + BS * c] : 0.0;
+        v[q] = WRITE ? 0.0 : Fc[(size_t)r0 + (size_t)m * c];
       }
-      v[q] = WRITE ? 0.0 : Fc[dst[q]];
-    }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      if (base + q * 256 < n && (WRITE || any[q])) {
-        double x = v[q];
+      for (int ch = 0; ch < MAXC; ++ch) any = any || o[ch] >= 0;
 #pragma unroll
-        for (int ch = 0; ch < MAXC; ++ch) {
-          const long long o = ch < nch ? soff[ch][bl[q]] : -1LL;
-          if (o >= 0) x += u[q][ch];   // (child order; a child without an entry here adds nothing -- not even + 0.0)
+      for (int q = 0; q < CU; ++q) {
+        if (c0 + q < BS && (WRITE || any)) {
+          double x = v[q];
+#pragma unroll
+          for (int ch = 0; ch < MAXC; ++ch)
+            if (o[ch] >= 0) x += u[q][ch];   // (child order; a child without an entry here adds nothing -- not even + 0.0)
+          Fc[(size_t)r0 + (size_t)m * (c0 + q)] = x;
         }
-        Fc[dst[q]] = x;
       }
     }
   }
@@ -4788,6 +4793,7 @@ struct BigLaunch {   // whole-GPU passes over the scratch-slab fronts of one lev
   bool gather = false;     // the merged level launch gathers the children's update matrices itself: no extend-add passes (LevelLaunch::gather)
   int eg_begin = 0, eg_count = 0;   // the level's extend-add in one launch (big_extend_gather_kernel); 0: the passes per child ordinal
   bool eg_write = false;            // ... into regions that were not zero-filled (LevelLaunch::eg_write), the original blocks la_* behind it
+  int eg_maxc = 7;                  // ... children per front of the level at most
   int la_begin = 0, la_count = 0;
   bool panel_solve = false;   // pivot blocks + panel rows of the level in one launch (big_panel_solve_kernel): LevelLaunch::tr_all and not a merged / fused level
 };
@@ -4862,14 +4868,20 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     for (const auto& pass : *big.be_pass) any_pass = any_pass || pass.second > 0;
     const bool gather = level_launch && big.gather && any_pass;   // (the level's launch adds the children's update matrices where it loads the fronts)
     if (big.eg_write) {   // every child ordinal in one launch, into regions that were not zero-filled; then the original blocks
-      hipLaunchKernelGGL((big_extend_gather_kernel<BS, true>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+      if (big.eg_maxc <= 2)
+        hipLaunchKernelGGL((big_extend_gather_kernel<BS, true, 2>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+      else
+        hipLaunchKernelGGL((big_extend_gather_kernel<BS, true, 7>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
       G2OHIP_LAUNCH_CHECK("big_extend_gather_kernel");
       if (big.la_count > 0)
         hipLaunchKernelGGL((big_assemble_kernel<BS, VIRT>), dim3(big.la_count), dim3(256), 0, st, P, big.chunks + big.la_begin, dA, d_scratch,
                            d_scratch_off, big.ld);
       G2OHIP_LAUNCH_CHECK("big_assemble_kernel");
     } else if (!gather && big.eg_count > 0) {   // every child ordinal in one launch
-      hipLaunchKernelGGL((big_extend_gather_kernel<BS, false>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+      if (big.eg_maxc <= 2)
+        hipLaunchKernelGGL((big_extend_gather_kernel<BS, false, 2>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+      else
+        hipLaunchKernelGGL((big_extend_gather_kernel<BS, false, 7>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
       G2OHIP_LAUNCH_CHECK("big_extend_gather_kernel");
     } else if (!gather)
       for (const auto& pass : *big.be_pass)
@@ -5029,7 +5041,7 @@ void SparseCholesky::launch_factor(const LevelLaunch& LL, const double* dA, bool
   const BigLaunch big{LL.big_ok && opt.big_front_passes && LL.glb_max_m >= opt.big_front_min_dim, d_big_tiles.p, LL.ba_begin, LL.ba_count, LL.tr_begin, LL.tr_count, &LL.be_pass,
                       LL.fz_begin, LL.fz_count, LL.hoisted && opt.hoist_big_assembly != 0, fwd && big_forward_carried(LL),
                       (opt.merge_diag_panel && !dep_off_) ? d_sw_flag.p : (int*)nullptr, d_scratch_ld.p, opt.fuse_panel != 0, opt.mfma_diag != 0, merge_tiles_of(LL), LL.gather && opt.big_gather != 0,
-                      LL.eg_begin, LL.eg_count, LL.eg_write, LL.la_begin, LL.la_count, LL.tr_all};
+                      LL.eg_begin, LL.eg_count, LL.eg_write, LL.eg_maxc, LL.la_begin, LL.la_count, LL.tr_all};
   const bool virt = dA == nullptr;   // assemble from the virtual source (set_virtual_blocks)
   if (virt && !has_virtual_blocks()) throw StateFailure("SparseCholesky::factor: no matrix and no virtual source");
 #define G2OHIP_FACTOR_LEVEL(BS_, V_)                                                                                          \
