@@ -3010,7 +3010,7 @@ __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, c
     long long o[MAXC];
 #pragma unroll
     for (int ch = 0; ch < MAXC; ++ch) o[ch] = soff[ch][blk];
-    constexpr int CU = 3;   // columns in flight
+    constexpr int CU = (MAXC <= 2 && BS <= 6) ? BS : 3;   // columns in flight
 #pragma unroll
     for (int c0 = 0; c0 < BS; c0 += CU) {
       double v[CU], u[CU][MAXC];
