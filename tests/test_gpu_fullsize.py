@@ -229,6 +229,28 @@ def test_grid_graph_with_visibility_by_distance_against_the_oracle_and_at_size()
     assert g.chi2() < chi0
 
 
+def test_grid_graph_whole_gpu_passes_against_one_workgroup_per_front():
+    """2 500 cameras on the lattice (frontal matrices of 1 700 rows, levels of more than 256 tiles, grouped in-place chains): the
+    scratch-slab path as it runs by default -- pivot block + panel rows in one launch with the rows on the matrix cores
+    (big_panel_solve_kernel), the extend-add of a level as ONE launch that writes its fronts' regions (big_extend_gather_kernel), the
+    grouped rank-480 updates reading solved rows from the L panels -- against the independent form of the same factorisation, one
+    workgroup per front with everything in one kernel (big_front_passes = 0): the same step to rounding, both with a clean residual."""
+    pr = S.make_ba_grid(2500)
+    xs = {}
+    for name, opts in (("whole-GPU passes", {}), ("one workgroup per front", {"big_front_passes": 0})):
+        s, g = lm.setup_device_ba(pr, huber_delta=1.0, options=opts)
+        g.linearize()
+        s.buildSystem()
+        s.setLambda(1e-5 * s.maxDiagonal(), True)
+        assert s.solve(), name
+        x, b = s.x(), s.b()
+        r = s.multiplyHessian(x) - b
+        assert np.abs(r).max() <= 1e-10 * np.abs(b).max(), name
+        assert s.stats()["maxFrontDim"] >= 1024
+        xs[name] = x
+    assert relerr(xs["whole-GPU passes"], xs["one workgroup per front"]) < 1e-9
+
+
 def test_bench_line_contract_on_both_workloads(tmp_path):
     """bench.py prints ONE JSON line with the contract's keys; `roofline` carries frac_traffic / traffic_commit / the matrix-core block
     on the chain workload at the metric configuration only (the PMC file is for that size) and switches to the MFMA bound with the
