@@ -1154,9 +1154,12 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
             for (int k = 0; k < S.f_nb[c]; ++k) cinv[t0 + kGatherHeader + (size_t)k0 * mb + rl[k]] = k;
           }
           cinv_slot[q] = make_int2((int)t0, kGatherHeader + nch * mb);
-          if (LL.eg_ok)   // chunks of up to 64 lower blocks of ONE block column of the parent (consecutive rows: the stores of a chunk are contiguous per column)
+          if (LL.eg_ok) {   // chunks of lower blocks of ONE block column of the parent (consecutive rows: the stores of a chunk are contiguous per column),
+                            // 256 scalar rows each: one row per thread (more per workgroup was measured slower: what the kernel lives on is requests in flight)
+            const int cb = std::max(1, std::min(64, 256 / bs));
             for (int jb = 0; jb < mb; ++jb)
-              for (int ib = jb; ib < mb; ib += 64) bt.push_back(make_int4(q, jb, ib, std::min(64, mb - ib)));
+              for (int ib = jb; ib < mb; ib += cb) bt.push_back(make_int4(q, jb, ib, std::min(cb, mb - ib)));
+          }
         }
         LL.eg_count = LL.eg_ok ? (int)bt.size() - LL.eg_begin : 0;
         LL.eg_maxc = max_children;
