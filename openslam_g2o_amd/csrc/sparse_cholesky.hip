@@ -22,6 +22,7 @@ constexpr int kFactorThreadsGlobal = 512;
 constexpr int kChainU = 6;  // doubles per thread that carry an update matrix from one chain front to the next
 // register-resident wave kernel (wave_front.inc): limits of a front
 constexpr int kPanelSolveWgs = 512;      // big_panel_solve_kernel (pivot blocks + panel rows of a level in one launch) on launches of at most this many workgroups
+constexpr int kEgThreads = 256;           // big_extend_gather_kernel: threads per workgroup = scalar rows per chunk (128 / 64: no different)
 constexpr int kFillChunk = 4096;         // doubles zeroed by one workgroup of big_fill_kernel
 constexpr int kWvNPV = 24;             // pivot columns (scalars)
 constexpr int kWvNTL = 3;              // 16-row tiles of boundary rows (48 rows)
@@ -1156,7 +1157,7 @@ void SparseCholesky::analyze(int nb, const int* colptr, const int* rowidx, hipSt
           cinv_slot[q] = make_int2((int)t0, kGatherHeader + nch * mb);
           if (LL.eg_ok) {   // chunks of lower blocks of ONE block column of the parent (consecutive rows: the stores of a chunk are contiguous per column),
                             // 256 scalar rows each: one row per thread (more per workgroup was measured slower: what the kernel lives on is requests in flight)
-            const int cb = std::max(1, std::min(64, 256 / bs));
+            const int cb = std::max(1, std::min(64, kEgThreads / bs));
             for (int jb = 0; jb < mb; ++jb)
               for (int ib = jb; ib < mb; ib += cb) bt.push_back(make_int4(q, jb, ib, std::min(cb, mb - ib)));
           }
@@ -3008,7 +3009,7 @@ __global__ void __launch_bounds__(256) big_extend_gather_kernel(CholPlanDev P, c
   // thread (rows tid, tid + 256 of every column) are requested three at a time
   const int rows = cnt * BS;
   double* Fc = F + (size_t)ck.z * BS + (size_t)m * (jb * BS);
-  for (int r0 = threadIdx.x; r0 < rows; r0 += 256) {
+  for (int r0 = threadIdx.x; r0 < rows; r0 += (int)blockDim.x) {
     const int blk = r0 / BS, eb = r0 - blk * BS;
     long long o[MAXC];
 #pragma unroll
@@ -4872,9 +4873,9 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
     const bool gather = level_launch && big.gather && any_pass;   // (the level's launch adds the children's update matrices where it loads the fronts)
     if (big.eg_write) {   // every child ordinal in one launch, into regions that were not zero-filled; then the original blocks
       if (big.eg_maxc <= 2)
-        hipLaunchKernelGGL((big_extend_gather_kernel<BS, true, 2>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+        hipLaunchKernelGGL((big_extend_gather_kernel<BS, true, 2>), dim3(big.eg_count), dim3(kEgThreads), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
       else
-        hipLaunchKernelGGL((big_extend_gather_kernel<BS, true, 7>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+        hipLaunchKernelGGL((big_extend_gather_kernel<BS, true, 7>), dim3(big.eg_count), dim3(kEgThreads), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
       G2OHIP_LAUNCH_CHECK("big_extend_gather_kernel");
       if (big.la_count > 0)
         hipLaunchKernelGGL((big_assemble_kernel<BS, VIRT>), dim3(big.la_count), dim3(256), 0, st, P, big.chunks + big.la_begin, dA, d_scratch,
@@ -4882,9 +4883,9 @@ void launch_factor_level(const CholPlanDev& P, const int* d_tasks, const long lo
       G2OHIP_LAUNCH_CHECK("big_assemble_kernel");
     } else if (!gather && big.eg_count > 0) {   // every child ordinal in one launch
       if (big.eg_maxc <= 2)
-        hipLaunchKernelGGL((big_extend_gather_kernel<BS, false, 2>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+        hipLaunchKernelGGL((big_extend_gather_kernel<BS, false, 2>), dim3(big.eg_count), dim3(kEgThreads), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
       else
-        hipLaunchKernelGGL((big_extend_gather_kernel<BS, false, 7>), dim3(big.eg_count), dim3(256), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
+        hipLaunchKernelGGL((big_extend_gather_kernel<BS, false, 7>), dim3(big.eg_count), dim3(kEgThreads), 0, st, P, big.chunks + big.eg_begin, d_scratch, d_scratch_off);
       G2OHIP_LAUNCH_CHECK("big_extend_gather_kernel");
     } else if (!gather)
       for (const auto& pass : *big.be_pass)
